@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Headline benchmark: log-likelihoods/sec of a Gaussian RAT-SPN (D=784, depth 2, 8 repetitions) on
+synthetic batches of 65536 samples per GPU, evaluated by the fused HIP kernel.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A step = one pass of the hot path over one resident batch: parameter-table kernels + the fused
+forward kernel (per-sample LLs written to HBM, fp64 sum fused in) + for N > 1 the RCCL all-reduce of
+{sum LL, count} that yields the mean LL on every rank (asynchronous, overlapped with the next step).
+Inputs live in HBM before the timed region; a ring of distinct batches larger than the 256 MiB
+Infinity Cache is cycled so the x stream really comes from HBM.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (ratspn_leaf_kernel, fused
+whole-model forward): algorithmic bytes per launch = B * 4*(784 + C) (SURVEY 8d fully-fused bound)
+over its mean duration measured with HIP events on the launch stream inside the timed loop.
+`cpu_baseline` times the oracle (op-for-op PyTorch-CPU restatement of the reference) on the host
+cores over a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, 'deeprob-kit_amd'), ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--batch', type=int, default=65536, help='samples per GPU per step')
+    ap.add_argument('--rg-batch', type=int, default=2)
+    ap.add_argument('--rg-sum', type=int, default=2)
+    ap.add_argument('--ring', type=int, default=0, help='distinct resident batches (0: > 256 MiB worth)')
+    ap.add_argument('--cpu-samples', type=int, default=32768, help='cpu_baseline sample size (0 = skip)')
+    ap.add_argument('--no-kernel-events', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline(model_state, D, n_samples):
+    """Oracle timed on the host cores: chunks of 4096 (the reference materialises [B,R,I,d]
+    temporaries), 1 warm-up chunk, all cores."""
+    from oracle import ratspn_oracle as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    chunk = 4096
+    x = torch.randn(n_samples, D, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        orc.ratspn_forward(model_state, x[:chunk])
+        t0 = time.perf_counter()
+        for i in range(0, n_samples, chunk):
+            orc.ratspn_forward(model_state, x[i:i + chunk])
+        dt = time.perf_counter() - t0
+    return {'value': n_samples / dt, 'unit': 'log-likelihoods/sec', 'cores': cores, 'kind': 'port',
+            'sample': '{} samples of the same workload in chunks of {} ({:.1f} s), oracle/ratspn_oracle.py '
+                      '(op-for-op PyTorch-CPU restatement of the reference)'.format(n_samples, chunk, dt)}
+
+
+def read_traffic():
+    """HBM bytes per launch of the fused kernel from the last committed rocprofv3 --pmc pass."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        with open(path) as f:
+            return json.load(f).get('bytes_per_launch')
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world == 1:
+        sys.exit('for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...')
+    assert world == max(args.gpus, 1), 'WORLD_SIZE {} != --gpus {}'.format(world, args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from deeprob.spn.models import GaussianRatSpn
+    from deeprob.parallel import ShardedLogLikelihood
+
+    D, B = 784, args.batch
+    torch.manual_seed(0)  # identical replica on every rank
+    model = GaussianRatSpn(D, rg_depth=2, rg_repetitions=8, rg_batch=args.rg_batch, rg_sum=args.rg_sum,
+                           random_state=42).eval()
+    cpu_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(dev)
+
+    ring = args.ring or max(2, -(-(320 << 20) // (B * D * 4)))
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)  # every rank its own shard of the batch
+    xs = [torch.randn(B, D, device=dev, generator=gen) for _ in range(ring)]
+
+    evaluator = ShardedLogLikelihood(model, group=dist.group.WORLD if world > 1 else None)
+    time_kernel = not args.no_kernel_events
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps if time_kernel else 0)]
+
+    def step(i, timed_idx=None):
+        marks = ev[timed_idx] if (timed_idx is not None and time_kernel) else None
+        return evaluator.step(xs[i % ring], kernel_events=marks)
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            step(i)
+        evaluator.drain()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, i)
+        results = evaluator.drain()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    mean_ll = results[-1]
+
+    if rank == 0:
+        total = B * world * args.steps
+        out = {
+            'metric': 'log-likelihoods/sec, RAT-SPN D=784 batch=64k at 1/2/4/8 MI355X',
+            'value': total / dt, 'unit': 'log-likelihoods/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'GaussianRatSpn(784, rg_depth=2, rg_repetitions=8, rg_batch={}, rg_sum={}) '
+                                   'forward log-likelihood, {} samples per GPU per step, mean LL reduced on '
+                                   'device{}'.format(args.rg_batch, args.rg_sum, B,
+                                                     ' + RCCL all-reduce' if world > 1 else ''),
+                       'global_batch': B * world, 'resident_batches': ring, 'mean_ll': mean_ll},
+        }
+        if time_kernel:
+            torch.cuda.synchronize()
+            k_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+            alg_bytes = B * 4 * (D + model.out_classes)
+            achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+            out['roofline'] = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                               'frac': achieved / HBM_PEAK_GBS, 'traffic': read_traffic(),
+                               'kernel': 'ratspn_leaf_kernel (fused RatSpn.forward)',
+                               'kernel_ms': k_ms, 'algorithmic_bytes_per_launch': alg_bytes}
+        if args.cpu_samples > 0 and world == 1:
+            out['cpu_baseline'] = cpu_baseline(cpu_state, D, args.cpu_samples)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,126 @@
+// Shared host/device helpers for libdeeprob_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <float.h>
+#include "../../include/deeprob_hip.h"
+
+namespace dpk {
+
+void set_error(const char *fmt, ...);
+void profile_take(hipEvent_t *start, hipEvent_t *stop);  // one-shot measurement hook
+
+#define DPK_REQUIRE(cond, code, ...)       \
+    do {                                   \
+        if (!(cond)) {                     \
+            dpk::set_error(__VA_ARGS__);   \
+            return (code);                 \
+        }                                  \
+    } while (0)
+
+#define DPK_CHECK_LAUNCH(what)                                                      \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            dpk::set_error("%s: %s", (what), hipGetErrorString(e__));               \
+            return DPK_ELAUNCH;                                                     \
+        }                                                                           \
+    } while (0)
+
+constexpr int kWave = 64;           // CDNA wavefront
+constexpr int kChunk = 128;         // features staged in LDS per chunk (FC)
+constexpr int kLeafWaves = 8;       // waves per work-group of the leaf / fused kernels
+constexpr float kLogSqrt2Pi = 0.918938533204672741780329736406f;
+
+static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Workspace carve-up shared by every RAT-SPN entry point.
+//
+// Every region's variable ids are sorted and cut into per-chunk segments (chunk c = features
+// [c*kChunk, (c+1)*kChunk)); each segment is padded to a multiple of kBlock entries with
+// neutral entries (fl = kChunk, the all-zero LDS row; parameters 0), so the kernels walk whole
+// blocks and never mask.  dP = padded entries per region.
+constexpr int kBlock = 4;
+struct RatWs {
+    // structure tables (depend on mask / pad_mask only)
+    int *fl;      // [R*dP+slack] (feature id) % kChunk, kChunk for a neutral entry
+    int *src;     // [R*dP]   original position j of the entry, -1 for dummy / neutral entries
+    int *feat;    // [R*dP]   feature id, -1 for neutral entries
+    int *cb;      // [R*(NC+1)] first (padded) position of every chunk segment
+    // parameter tables (rebuilt on every call)
+    float *par;   // [(R*dP+slack)*2I] {p0[I], p1[I]} per entry
+    float *cel;   // [(R*dP+slack)*I]  additive constant per entry
+    float *biasc; // [R*NC*I] per-chunk sum of cel
+    float *w[3];  // linear softmax weights: sum layer 0, sum layer 1, root
+    float *lw[3]; // log-softmax weights
+    int64_t bytes;
+    int NC, dP;
+};
+constexpr int kTableSlack = 16;  // entries the software-pipelined readers may run past the end
+
+inline RatWs carve_ratspn_ws(void *base, int D, int R, int d, int I, int depth, int reps, int S,
+                             int C) {
+    RatWs w{};
+    char *p = (char *)base;
+    int64_t o = 0;
+    auto take = [&](int64_t n_bytes) {
+        char *q = p ? p + o : nullptr;
+        o = align_up(o + n_bytes, 256);
+        return q;
+    };
+    const int NC = cdiv(D, kChunk);
+    w.NC = NC;
+    w.dP = (int)align_up(d + (kBlock - 1) * NC, kBlock);
+    const int64_t Rd = (int64_t)R * w.dP + kTableSlack;
+    w.fl = (int *)take(Rd * 4);
+    w.src = (int *)take(Rd * 4);
+    w.feat = (int *)take(Rd * 4);
+    w.cb = (int *)take((int64_t)R * (NC + 1) * 4);
+    w.par = (float *)take(Rd * 2 * I * 4);
+    w.cel = (float *)take(Rd * I * 4);
+    w.biasc = (float *)take((int64_t)R * NC * I * 4);
+    // sum layers (only meaningful for the fused model entry point)
+    int64_t n0 = 0, n1 = 0, nr = 0;
+    if (depth >= 1 && reps >= 1) {
+        const int Q = 1 << depth;
+        if (depth >= 2) n0 = (int64_t)reps * (Q / 2) * S * I * I;
+        if (depth >= 3) n1 = (int64_t)reps * (Q / 4) * S * S * S;
+        const int nlast = depth >= 2 ? S : I;
+        nr = (int64_t)C * reps * nlast * nlast;
+    }
+    const int64_t n[3] = {n0, n1, nr};
+    for (int i = 0; i < 3; ++i) {
+        w.w[i] = (float *)take(n[i] * 4);
+        w.lw[i] = (float *)take(n[i] * 4);
+    }
+    w.bytes = o;
+    return w;
+}
+
+// ---- device helpers -------------------------------------------------------
+
+__device__ __forceinline__ float nan_to_num_f(float t) {
+    // torch.nan_to_num_ defaults: nan -> 0, +inf -> FLT_MAX, -inf -> -FLT_MAX
+    if (t != t) return 0.0f;
+    return fminf(fmaxf(t, -FLT_MAX), FLT_MAX);
+}
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_reduce_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace dpk

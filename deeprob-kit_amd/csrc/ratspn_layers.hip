@@ -1,0 +1,484 @@
+// Per-layer RAT-SPN operators for gfx950: ProductLayer, SumLayer / RootLayer (forward and
+// backward) and the backward of the leaf layers.  These are the general-shape operators behind
+// the individual reference modules; the inference fast path is the fused kernel in
+// ratspn_fwd.hip.
+#include "common.h"
+#include <math.h>
+
+namespace dpk {
+
+#define DPK_CONST __attribute__((address_space(4)))
+typedef const DPK_CONST float *cfloat_p;
+template <typename T> __host__ __device__ __forceinline__ const DPK_CONST T *as_const(const T *p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return (const DPK_CONST T *)p;
+#pragma clang diagnostic pop
+}
+
+__global__ void softmax_rows_kernel2(const float *__restrict__ w, int rows, int n, float *__restrict__ W,
+                                     float *__restrict__ LW) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float *src = w + (int64_t)row * n;
+    float m = -INFINITY;
+    for (int i = lane; i < n; i += 64) m = fmaxf(m, src[i]);
+    m = wave_reduce_max(m);
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) s += expf(src[i] - m);
+    s = wave_reduce_sum(s);
+    const float ls = logf(s);
+    for (int i = lane; i < n; i += 64) {
+        const float l = src[i] - m - ls;
+        LW[(int64_t)row * n + i] = l;
+        W[(int64_t)row * n + i] = expf(l);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// ProductLayer (reference: deeprob/spn/layers/ratspn.py:272-286)
+// ------------------------------------------------------------------------------------
+__global__ void product_fwd_kernel(const float *__restrict__ in, int64_t total, int R, int N,
+                                   float *__restrict__ out) {
+    const int NN = N * N, Ph = R / 2;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int ij = (int)(e % NN);
+        const int64_t bp = e / NN;
+        const int p = (int)(bp % Ph);
+        const int64_t b = bp / Ph;
+        const int i = ij / N, j = ij - i * N;
+        const float *row = in + (b * R + 2 * p) * N;
+        out[e] = row[i] + row[N + j];
+    }
+}
+
+// gx[b,2p,i] = sum_j g[b,p,i,j];  gx[b,2p+1,j] = sum_i g[b,p,i,j]
+__global__ void product_bwd_kernel(const float *__restrict__ g, int64_t total, int R, int N,
+                                   float *__restrict__ gx) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(e % N);
+        const int64_t br = e / N;
+        const int r = (int)(br % R);
+        const int64_t b = br / R;
+        const float *gp = g + (b * (R / 2) + (r >> 1)) * N * N;
+        float s = 0.f;
+        if ((r & 1) == 0)
+            for (int j = 0; j < N; ++j) s += gp[n * N + j];
+        else
+            for (int i = 0; i < N; ++i) s += gp[i * N + n];
+        gx[e] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// SumLayer / RootLayer forward (reference: ratspn.py:363-378, :446-458)
+//   out[b,p,o] = logsumexp_n(x[b,p,n] + lw[p,o,n])
+// One wave per (64 samples, partition).  x is staged through LDS in chunks of kNC columns
+// (coalesced rows in, conflict-free column reads out); per sample the row maximum m is taken
+// once and v_o = sum_n softmax(W)[o,n] * exp(x_n - m) accumulated for OB outputs at a time with
+// the weights on the scalar path.  v_o < 1e-30 falls back to the exact two-pass form with the
+// true maximum of x_n + lw_on (what torch.logsumexp computes).
+// ------------------------------------------------------------------------------------
+constexpr int kNC = 128;
+constexpr int kOB = 4;
+
+__device__ __forceinline__ void stage_rows(const float *__restrict__ in, int64_t row_stride, int64_t b0,
+                                           int64_t B, int n0, int N, float *tile, int lane) {
+    // tile[r][c], row stride kNC+1
+#pragma unroll 4
+    for (int r = 0; r < 64; ++r) {
+        const int64_t b = min(b0 + r, B - 1);
+        const float *src = in + b * row_stride + n0;
+        for (int c = lane; c < kNC; c += 64) tile[r * (kNC + 1) + c] = (n0 + c < N) ? src[c] : -INFINITY;
+    }
+}
+
+__global__ __launch_bounds__(64) void sum_fwd_kernel(const float *__restrict__ in, cfloat_p W, cfloat_p LW,
+                                                    int64_t B, int P, int N, int S,
+                                                    float *__restrict__ out) {
+    __shared__ float tile[64 * (kNC + 1)];
+    const int lane = threadIdx.x;
+    const int p = blockIdx.y;
+    const int64_t b0 = (int64_t)blockIdx.x * 64;
+    const int64_t b = b0 + lane;
+    const int64_t row_stride = (int64_t)P * N;
+    const float *xin = in + (int64_t)p * N;
+
+    // pass A: row maximum
+    float m = -INFINITY;
+    for (int n0 = 0; n0 < N; n0 += kNC) {
+        __syncthreads();
+        stage_rows(xin, row_stride, b0, B, n0, N, tile, lane);
+        __syncthreads();
+        const int nn = min(kNC, N - n0);
+        for (int c = 0; c < nn; ++c) m = fmaxf(m, tile[lane * (kNC + 1) + c]);
+    }
+    const float m0 = (m == -INFINITY) ? 0.f : m;
+
+    for (int ob = 0; ob < S; ob += kOB) {
+        float v[kOB];
+#pragma unroll
+        for (int q = 0; q < kOB; ++q) v[q] = 0.f;
+        for (int n0 = 0; n0 < N; n0 += kNC) {
+            __syncthreads();
+            stage_rows(xin, row_stride, b0, B, n0, N, tile, lane);
+            __syncthreads();
+            const int nn = min(kNC, N - n0);
+            for (int c = 0; c < nn; ++c) {
+                const float e = __expf(tile[lane * (kNC + 1) + c] - m0);
+#pragma unroll
+                for (int q = 0; q < kOB; ++q) {
+                    const int o = min(ob + q, S - 1);
+                    v[q] = fmaf(W[((int64_t)p * S + o) * N + n0 + c], e, v[q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kOB; ++q) {
+            const int o = ob + q;
+            if (o < S && b < B) {
+                float r;
+                if (v[q] < 1e-30f) {
+                    const float *xr = xin + b * row_stride;
+                    cfloat_p lw = LW + ((int64_t)p * S + o) * N;
+                    float mm = -INFINITY;
+                    for (int n = 0; n < N; ++n) mm = fmaxf(mm, xr[n] + lw[n]);
+                    if (mm > -INFINITY) {
+                        float s = 0.f;
+                        for (int n = 0; n < N; ++n) s += expf(xr[n] + lw[n] - mm);
+                        r = mm + logf(s);
+                    } else {
+                        r = -INFINITY;
+                    }
+                } else {
+                    r = m0 + __logf(v[q]);
+                }
+                out[(b * P + p) * S + o] = r;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// SumLayer / RootLayer backward.
+//   pi[b,p,o,n] = exp(x[b,p,n] + lw[p,o,n] - out[b,p,o])
+//   gx[b,p,n]   = sum_o g[b,p,o] pi ;  glw[p,o,n] = sum_b g[b,p,o] pi
+//   gW          = glw - softmax(W) * sum_n glw            (log_softmax Jacobian)
+// Lanes run over the (p,n) columns, so neither sum needs a cross-lane reduction: gx is a sum over
+// o inside the thread and glw a sum over the samples of the tile, flushed with one atomic per
+// (tile, column, o).
+// ------------------------------------------------------------------------------------
+constexpr int kBwdTile = 128;  // samples per block in the sum backward
+
+__global__ __launch_bounds__(256) void sum_bwd_kernel(const float *__restrict__ x,
+                                                     const float *__restrict__ LW,
+                                                     const float *__restrict__ out,
+                                                     const float *__restrict__ g, int64_t B, int P, int N,
+                                                     int S, float *__restrict__ gx,
+                                                     float *__restrict__ glw) {
+    const int col = blockIdx.y * blockDim.x + threadIdx.x;  // (p, n) flattened
+    if (col >= P * N) return;
+    const int p = col / N, n = col - p * N;
+    const int64_t b0 = (int64_t)blockIdx.x * kBwdTile;
+    const int64_t b1 = min(b0 + kBwdTile, B);
+    for (int o = 0; o < S; ++o) {
+        const float lw = LW[((int64_t)p * S + o) * N + n];
+        float acc = 0.f;
+        for (int64_t b = b0; b < b1; ++b) {
+            const float xo = out[(b * P + p) * S + o];
+            const float go = g[(b * P + p) * S + o];
+            const float xv = x[b * P * N + col];
+            // an all -inf row has out = -inf: its gradient is defined as zero (reference: the
+            // masked_fill guard inside torch.logsumexp's backward gives the same)
+            float t = 0.f;
+            if (xo > -INFINITY) t = go * expf(xv + lw - xo);
+            acc += t;
+            if (gx != nullptr) {
+                float *dst = gx + b * P * N + col;
+                *dst = (o == 0) ? t : (*dst + t);
+            }
+        }
+        if (glw != nullptr) atomicAdd(glw + ((int64_t)p * S + o) * N + n, acc);
+    }
+}
+
+__global__ void logsoftmax_jacobian_kernel(const float *__restrict__ glw, const float *__restrict__ W,
+                                           int rows, int n, float *__restrict__ gW) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) s += glw[(int64_t)row * n + i];
+    s = wave_reduce_sum(s);
+    for (int i = lane; i < n; i += 64)
+        gW[(int64_t)row * n + i] = glw[(int64_t)row * n + i] - W[(int64_t)row * n + i] * s;
+}
+
+// ------------------------------------------------------------------------------------
+// Leaf backward.  Parameter-stationary: a thread owns one table entry (region r,
+// variable j) for CBK channels and walks the samples of its tile, so the parameter gradients are
+// plain register sums; upstream g[b,r,k] is wave-uniform (scalar path); x is gathered from the
+// row.  Tiles meet through one atomic per (tile, entry, channel).
+//   Gaussian: dmu = sum_b g m (x-mu)/s^2 ; dsigma = sum_b g m ((x-mu)^2/s^3 - 1/s)
+//   Bernoulli: dlogit = sum_b g m (x - sigmoid(l))
+// A second kernel, one thread per (sample, variable), forms d/dx = sum over the repetitions.
+// ------------------------------------------------------------------------------------
+constexpr int kLeafBwdTile = 256;
+
+template <int DIST>
+__global__ __launch_bounds__(256) void leaf_bwd_param_kernel(
+    const float *__restrict__ x, const float *__restrict__ g, int64_t B, int D, int R, int I, int d, int dP,
+    const int *__restrict__ feat, const int *__restrict__ src, const float *__restrict__ p0,
+    const float *__restrict__ p1, float *__restrict__ gp0, float *__restrict__ gp1) {
+    const int r = blockIdx.y;
+    const int64_t b0 = (int64_t)blockIdx.x * kLeafBwdTile;
+    const int64_t b1 = min(b0 + kLeafBwdTile, B);
+    for (int e = threadIdx.x; e < dP; e += blockDim.x) {
+        const int j = src[(int64_t)r * dP + e];
+        if (j < 0) continue;
+        const int f = feat[(int64_t)r * dP + e];
+        for (int k = 0; k < I; ++k) {
+            const int64_t po = ((int64_t)r * I + k) * d + j;
+            float a0 = 0.f, a1 = 0.f;
+            if (DIST == 0) {
+                const float mu = p0[po], sg = p1[po];
+                const float iv = 1.f / (sg * sg), is = 1.f / sg;
+                for (int64_t b = b0; b < b1; ++b) {
+                    const float xv = x[b * D + f];
+                    const float gv = g[(b * R + r) * I + k];
+                    if (xv == xv) {
+                        const float dl = xv - mu;
+                        a0 = fmaf(gv, dl * iv, a0);
+                        a1 = fmaf(gv, dl * dl * iv * is - is, a1);
+                    }
+                }
+                if (gp0) atomicAdd(gp0 + po, a0);
+                if (gp1) atomicAdd(gp1 + po, a1);
+            } else {
+                const float l = p0[po];
+                const float sgm = 1.f / (1.f + expf(-l));
+                for (int64_t b = b0; b < b1; ++b) {
+                    const float xv = x[b * D + f];
+                    const float gv = g[(b * R + r) * I + k];
+                    if (xv == xv) a0 = fmaf(gv, xv - sgm, a0);
+                }
+                if (gp0) atomicAdd(gp0 + po, a0);
+            }
+        }
+    }
+}
+
+// inverse structure: for repetition rho and variable f, the (region, position) holding it
+__global__ void leaf_inverse_kernel(const int *__restrict__ feat, const int *__restrict__ src, int R, int d,
+                                    int dP, int D, int regions_per_rep, int *__restrict__ inv) {
+    const int r = blockIdx.x;
+    const int rho = r / regions_per_rep;
+    for (int e = threadIdx.x; e < dP; e += blockDim.x) {
+        const int j = src[(int64_t)r * dP + e];
+        if (j >= 0) inv[(int64_t)rho * D + feat[(int64_t)r * dP + e]] = r * d + j;
+    }
+}
+
+__global__ __launch_bounds__(256) void gaussian_leaf_bwd_x_kernel(
+    const float *__restrict__ x, const float *__restrict__ g, int64_t B, int D, int R, int I, int d, int reps,
+    const int *__restrict__ inv, const float *__restrict__ loc, const float *__restrict__ scale,
+    float *__restrict__ gx) {
+    const int64_t total = B * D;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(e % D);
+        const int64_t b = e / D;
+        const float xv = x[e];
+        float acc = 0.f;
+        if (xv == xv) {
+            for (int rho = 0; rho < reps; ++rho) {
+                const int rj = inv[(int64_t)rho * D + f];
+                if (rj < 0) continue;
+                const int r = rj / d, j = rj - r * d;
+                for (int k = 0; k < I; ++k) {
+                    const int64_t po = ((int64_t)r * I + k) * d + j;
+                    const float sg = scale[po];
+                    acc = fmaf(g[(b * R + r) * I + k], -(xv - loc[po]) / (sg * sg), acc);
+                }
+            }
+        }
+        gx[e] = acc;
+    }
+}
+
+// structure kernels live in ratspn_fwd.hip
+int prepare_leaf_structure(const RatWs &w, const int64_t *mask, const uint8_t *pad, int R, int d, uint32_t flags,
+                           hipStream_t st);
+
+}  // namespace dpk
+
+using namespace dpk;
+
+static int grid_for(int64_t total, int block, int cap = 8192) {
+    int64_t g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+extern "C" int dpk_product_forward(const float *in, int64_t B, int32_t R, int32_t N, float *out, void *stream) {
+    DPK_REQUIRE(in && out, DPK_EINVAL, "product_forward: null pointer");
+    DPK_REQUIRE(B >= 0 && R > 0 && (R % 2) == 0 && N > 0, DPK_EINVAL, "product_forward: bad sizes");
+    const int64_t total = B * (R / 2) * N * N;
+    if (total == 0) return DPK_OK;
+    hipLaunchKernelGGL(product_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                       total, R, N, out);
+    DPK_CHECK_LAUNCH("product_fwd_kernel");
+    return DPK_OK;
+}
+
+extern "C" int dpk_product_backward(const float *g, int64_t B, int32_t R, int32_t N, float *grad_in,
+                                    void *stream) {
+    DPK_REQUIRE(g && grad_in, DPK_EINVAL, "product_backward: null pointer");
+    DPK_REQUIRE(B >= 0 && R > 0 && (R % 2) == 0 && N > 0, DPK_EINVAL, "product_backward: bad sizes");
+    const int64_t total = B * R * N;
+    if (total == 0) return DPK_OK;
+    hipLaunchKernelGGL(product_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, g,
+                       total, R, N, grad_in);
+    DPK_CHECK_LAUNCH("product_bwd_kernel");
+    return DPK_OK;
+}
+
+// workspace of the sum / root operators: W, LW, glw  (each P*S*N floats)
+extern "C" int64_t dpk_sum_workspace_bytes(int64_t B, int32_t P, int32_t N, int32_t S) {
+    if (P <= 0 || N <= 0 || S <= 0) return DPK_EINVAL;
+    (void)B;
+    return 3 * align_up((int64_t)P * S * N * 4, 256);
+}
+
+static int sum_forward_impl(const float *in, const float *weight, int64_t B, int P, int N, int S, float *out,
+                            void *ws, int64_t ws_bytes, void *stream, const char *who) {
+    DPK_REQUIRE(in && weight && out && ws, DPK_EINVAL, "%s: null pointer", who);
+    DPK_REQUIRE(B >= 0 && P > 0 && N > 0 && S > 0, DPK_EINVAL, "%s: bad sizes", who);
+    DPK_REQUIRE(P <= 65535, DPK_EUNSUPPORTED, "%s: partitions=%d > 65535", who, P);
+    const int64_t seg = align_up((int64_t)P * S * N * 4, 256);
+    DPK_REQUIRE(ws_bytes >= 3 * seg, DPK_EWORKSPACE, "%s: workspace too small", who);
+    if (B == 0) return DPK_OK;
+    float *W = (float *)ws, *LW = (float *)((char *)ws + seg);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(softmax_rows_kernel2, dim3(cdiv(P * S, 4)), dim3(256), 0, st, weight, P * S, N, W, LW);
+    hipLaunchKernelGGL(sum_fwd_kernel, dim3(cdiv(B, 64), P), dim3(64), 0, st, in, as_const(W), as_const(LW), B,
+                       P, N, S, out);
+    DPK_CHECK_LAUNCH("sum_fwd_kernel");
+    return DPK_OK;
+}
+
+static int sum_backward_impl(const float *in, const float *weight, const float *out, const float *g, int64_t B,
+                             int P, int N, int S, float *grad_in, float *grad_weight, void *ws,
+                             int64_t ws_bytes, void *stream, const char *who) {
+    DPK_REQUIRE(in && weight && out && g && ws, DPK_EINVAL, "%s: null pointer", who);
+    DPK_REQUIRE(B >= 0 && P > 0 && N > 0 && S > 0, DPK_EINVAL, "%s: bad sizes", who);
+    const int64_t seg = align_up((int64_t)P * S * N * 4, 256);
+    DPK_REQUIRE(ws_bytes >= 3 * seg, DPK_EWORKSPACE, "%s: workspace too small", who);
+    float *W = (float *)ws, *LW = (float *)((char *)ws + seg), *glw = (float *)((char *)ws + 2 * seg);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(softmax_rows_kernel2, dim3(cdiv(P * S, 4)), dim3(256), 0, st, weight, P * S, N, W, LW);
+    if (grad_weight) {
+        hipError_t e = hipMemsetAsync(glw, 0, (size_t)P * S * N * 4, st);
+        DPK_REQUIRE(e == hipSuccess, DPK_ELAUNCH, "%s: memset: %s", who, hipGetErrorString(e));
+    }
+    if (B > 0) {
+        const int cols = P * N;
+        hipLaunchKernelGGL(sum_bwd_kernel, dim3(cdiv(B, kBwdTile), cdiv(cols, 256)), dim3(256), 0, st, in, LW,
+                           out, g, B, P, N, S, grad_in, grad_weight ? glw : nullptr);
+    } else if (grad_in) {
+        // nothing to write
+    }
+    if (grad_weight)
+        hipLaunchKernelGGL(logsoftmax_jacobian_kernel, dim3(cdiv(P * S, 4)), dim3(256), 0, st, glw, W, P * S, N,
+                           grad_weight);
+    DPK_CHECK_LAUNCH("sum_bwd_kernel");
+    return DPK_OK;
+}
+
+extern "C" int dpk_sum_forward(const float *in, const float *weight, int64_t B, int32_t P, int32_t N, int32_t S,
+                               float *out, void *ws, int64_t ws_bytes, void *stream) {
+    return sum_forward_impl(in, weight, B, P, N, S, out, ws, ws_bytes, stream, "sum_forward");
+}
+extern "C" int dpk_sum_backward(const float *in, const float *weight, const float *out, const float *g,
+                                int64_t B, int32_t P, int32_t N, int32_t S, float *grad_in,
+                                float *grad_weight, void *ws, int64_t ws_bytes, void *stream) {
+    return sum_backward_impl(in, weight, out, g, B, P, N, S, grad_in, grad_weight, ws, ws_bytes, stream,
+                             "sum_backward");
+}
+extern "C" int dpk_root_forward(const float *in, const float *weight, int64_t B, int32_t M, int32_t C,
+                                float *out, void *ws, int64_t ws_bytes, void *stream) {
+    return sum_forward_impl(in, weight, B, 1, M, C, out, ws, ws_bytes, stream, "root_forward");
+}
+extern "C" int dpk_root_backward(const float *in, const float *weight, const float *out, const float *g,
+                                 int64_t B, int32_t M, int32_t C, float *grad_in, float *grad_weight, void *ws,
+                                 int64_t ws_bytes, void *stream) {
+    return sum_backward_impl(in, weight, out, g, B, 1, M, C, grad_in, grad_weight, ws, ws_bytes, stream,
+                             "root_backward");
+}
+
+static int leaf_backward_common(int dist, const float *x, const float *g, int64_t B, int32_t D,
+                                const int64_t *mask, const uint8_t *pad_mask, const float *p0, const float *p1,
+                                int32_t R, int32_t I, int32_t d, float *gp0, float *gp1, float *gx, void *ws,
+                                int64_t ws_bytes, uint32_t flags, void *stream) {
+    DPK_REQUIRE(x && g && mask && p0 && ws, DPK_EINVAL, "leaf_backward: null pointer");
+    DPK_REQUIRE(dist == 1 || p1, DPK_EINVAL, "leaf_backward: null scale");
+    DPK_REQUIRE(B >= 0 && D > 0 && R > 0 && I > 0 && d > 0, DPK_EINVAL, "leaf_backward: bad sizes");
+    DPK_REQUIRE(R <= 65535, DPK_EUNSUPPORTED, "leaf_backward: regions=%d > 65535", R);
+    RatWs w = carve_ratspn_ws(ws, D, R, d, I, 0, 0, 0, 0);
+    DPK_REQUIRE(ws_bytes >= w.bytes, DPK_EWORKSPACE, "leaf_backward: workspace %lld < %lld", (long long)ws_bytes,
+                (long long)w.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = prepare_leaf_structure(w, mask, pad_mask, R, d, flags, st);
+    if (rc) return rc;
+    const size_t pbytes = (size_t)R * I * d * 4;
+    if (gp0) DPK_REQUIRE(hipMemsetAsync(gp0, 0, pbytes, st) == hipSuccess, DPK_ELAUNCH, "leaf_backward: memset");
+    if (gp1) DPK_REQUIRE(hipMemsetAsync(gp1, 0, pbytes, st) == hipSuccess, DPK_ELAUNCH, "leaf_backward: memset");
+    if (B > 0 && (gp0 || gp1)) {
+        if (dist == 0)
+            hipLaunchKernelGGL(leaf_bwd_param_kernel<0>, dim3(cdiv(B, kLeafBwdTile), R), dim3(256), 0, st, x, g,
+                               B, D, R, I, d, w.dP, w.feat, w.src, p0, p1, gp0, gp1);
+        else
+            hipLaunchKernelGGL(leaf_bwd_param_kernel<1>, dim3(cdiv(B, kLeafBwdTile), R), dim3(256), 0, st, x, g,
+                               B, D, R, I, d, w.dP, w.feat, w.src, p0, p1, gp0, gp1);
+        DPK_CHECK_LAUNCH("leaf_bwd_param_kernel");
+    }
+    if (gx && B > 0) {
+        DPK_REQUIRE(dist == 0, DPK_EUNSUPPORTED, "leaf_backward: d/dx only for Gaussian leaves");
+        // regions per repetition: every repetition covers each variable exactly once, so
+        // regions_per_rep = (D + pad) / d
+        const int per_rep = (D + d - 1) / d;
+        const int reps = R / per_rep;
+        DPK_REQUIRE(reps * per_rep == R, DPK_EINVAL, "leaf_backward: R=%d is not reps*%d", R, per_rep);
+        // the inverse table reuses the `par` segment (parameter tables are not needed here)
+        int *inv = (int *)w.par;
+        DPK_REQUIRE((int64_t)reps * D * 4 <= ((int64_t)R * w.dP + kTableSlack) * 2 * I * 4, DPK_EWORKSPACE,
+                    "leaf_backward: inverse table does not fit");
+        DPK_REQUIRE(hipMemsetAsync(inv, 0xff, (size_t)reps * D * 4, st) == hipSuccess, DPK_ELAUNCH,
+                    "leaf_backward: memset");
+        hipLaunchKernelGGL(leaf_inverse_kernel, dim3(R), dim3(256), 0, st, w.feat, w.src, R, d, w.dP, D, per_rep,
+                           inv);
+        hipLaunchKernelGGL(gaussian_leaf_bwd_x_kernel, dim3(grid_for(B * D, 256)), dim3(256), 0, st, x, g, B, D,
+                           R, I, d, reps, inv, p0, p1, gx);
+        DPK_CHECK_LAUNCH("gaussian_leaf_bwd_x_kernel");
+    }
+    return DPK_OK;
+}
+
+extern "C" int dpk_gaussian_leaf_backward(const float *x, const float *g, int64_t B, int32_t D,
+                                          const int64_t *mask, const uint8_t *pad_mask, const float *loc,
+                                          const float *scale, int32_t R, int32_t I, int32_t d, float *grad_loc,
+                                          float *grad_scale, float *grad_x, void *ws, int64_t ws_bytes,
+                                          uint32_t flags, void *stream) {
+    return leaf_backward_common(0, x, g, B, D, mask, pad_mask, loc, scale, R, I, d, grad_loc, grad_scale, grad_x,
+                                ws, ws_bytes, flags, stream);
+}
+
+extern "C" int dpk_bernoulli_leaf_backward(const float *x, const float *g, int64_t B, int32_t D,
+                                           const int64_t *mask, const uint8_t *pad_mask, const float *logits,
+                                           int32_t R, int32_t I, int32_t d, float *grad_logits, void *ws,
+                                           int64_t ws_bytes, uint32_t flags, void *stream) {
+    return leaf_backward_common(1, x, g, B, D, mask, pad_mask, logits, nullptr, R, I, d, grad_logits, nullptr,
+                                nullptr, ws, ws_bytes, flags, stream);
+}

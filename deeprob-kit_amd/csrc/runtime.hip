@@ -1,0 +1,57 @@
+// Error reporting, ABI version and the fp64 log-likelihood accumulator.
+#include "common.h"
+#include <stdarg.h>
+#include <string.h>
+
+namespace dpk {
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+void profile_take(hipEvent_t *a, hipEvent_t *b) {
+    *a = g_ev_start;
+    *b = g_ev_stop;
+    g_ev_start = g_ev_stop = nullptr;
+}
+
+// acc[0] += sum(ll), acc[1] += n  -- the per-rank partial of the mean-LL all-reduce
+// (the reference averages on the host: deeprob/torch/routines.py:419-425).
+__global__ void ll_accumulate_kernel(const float *__restrict__ ll, int64_t n, double *acc) {
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        s += (double)ll[i];
+    s = wave_reduce_sum(s);
+    __shared__ double part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) part[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+        if (blockIdx.x == 0) atomicAdd(acc + 1, (double)n);
+    }
+}
+}  // namespace dpk
+
+extern "C" const char *dpk_last_error(void) { return dpk::g_err; }
+extern "C" int dpk_abi_version(void) { return 1; }
+extern "C" int dpk_profile_next_kernel(void *ev_start, void *ev_stop) {
+    dpk::g_ev_start = (hipEvent_t)ev_start;
+    dpk::g_ev_stop = (hipEvent_t)ev_stop;
+    return DPK_OK;
+}
+
+extern "C" int dpk_ll_accumulate(const float *ll, int64_t n, double *acc, void *stream) {
+    DPK_REQUIRE(ll && acc && n >= 0, DPK_EINVAL, "ll_accumulate: bad argument");
+    if (n == 0) return DPK_OK;
+    int grid = dpk::cdiv(n, 256 * 8);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(dpk::ll_accumulate_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ll, n, acc);
+    DPK_CHECK_LAUNCH("ll_accumulate_kernel");
+    return DPK_OK;
+}

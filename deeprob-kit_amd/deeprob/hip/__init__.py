@@ -1,0 +1,126 @@
+"""ctypes binding of ``libdeeprob_hip.so`` (the C ABI declared in ``include/deeprob_hip.h``).
+
+This module is the ONLY place the Python mirror of the DeeProb-kit interface touches native
+code.  There is no CPU / PyTorch fallback: if the shared library is missing, or a tensor is not
+a contiguous fp32 tensor on a HIP device, the call raises.  PyTorch is used for device memory,
+streams and ``torch.distributed`` only.
+"""
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libdeeprob_hip.so'))
+
+DPK_FLAG_STRUCT_CACHED = 1
+
+_c_void = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_i32 = ctypes.c_int32
+_u32 = ctypes.c_uint32
+
+# name -> (restype, argtypes); mirrors include/deeprob_hip.h one to one
+SIGNATURES = {
+    'dpk_last_error': (ctypes.c_char_p, []),
+    'dpk_abi_version': (ctypes.c_int, []),
+    'dpk_ratspn_workspace_bytes': (_i64, [_i32] * 8),
+    'dpk_gaussian_leaf_forward': (ctypes.c_int, [_c_void, _i64, _i32, _c_void, _c_void, _c_void, _c_void,
+                                                 _i32, _i32, _i32, _c_void, _c_void, _i64, _u32, _c_void]),
+    'dpk_bernoulli_leaf_forward': (ctypes.c_int, [_c_void, _i64, _i32, _c_void, _c_void, _c_void,
+                                                  _i32, _i32, _i32, _c_void, _c_void, _i64, _u32, _c_void]),
+    'dpk_gaussian_leaf_backward': (ctypes.c_int, [_c_void, _c_void, _i64, _i32, _c_void, _c_void, _c_void,
+                                                  _c_void, _i32, _i32, _i32, _c_void, _c_void, _c_void,
+                                                  _c_void, _i64, _u32, _c_void]),
+    'dpk_bernoulli_leaf_backward': (ctypes.c_int, [_c_void, _c_void, _i64, _i32, _c_void, _c_void, _c_void,
+                                                   _i32, _i32, _i32, _c_void, _c_void, _i64, _u32, _c_void]),
+    'dpk_product_forward': (ctypes.c_int, [_c_void, _i64, _i32, _i32, _c_void, _c_void]),
+    'dpk_product_backward': (ctypes.c_int, [_c_void, _i64, _i32, _i32, _c_void, _c_void]),
+    'dpk_sum_forward': (ctypes.c_int, [_c_void, _c_void, _i64, _i32, _i32, _i32, _c_void, _c_void, _i64,
+                                       _c_void]),
+    'dpk_sum_backward': (ctypes.c_int, [_c_void, _c_void, _c_void, _c_void, _i64, _i32, _i32, _i32,
+                                        _c_void, _c_void, _c_void, _i64, _c_void]),
+    'dpk_sum_workspace_bytes': (_i64, [_i64, _i32, _i32, _i32]),
+    'dpk_root_forward': (ctypes.c_int, [_c_void, _c_void, _i64, _i32, _i32, _c_void, _c_void, _i64,
+                                        _c_void]),
+    'dpk_root_backward': (ctypes.c_int, [_c_void, _c_void, _c_void, _c_void, _i64, _i32, _i32, _c_void,
+                                         _c_void, _c_void, _i64, _c_void]),
+    'dpk_ratspn_forward': (ctypes.c_int, [_c_void, _i64, _i32, _c_void, _c_void, _c_void, _c_void, _c_void,
+                                          _c_void, _c_void, _i32, _i32, _i32, _i32, _i32, _c_void, _c_void,
+                                          _c_void, _c_void, _i64, _u32, _c_void]),
+    'dpk_profile_next_kernel': (ctypes.c_int, [_c_void, _c_void]),
+    'dpk_ll_accumulate': (ctypes.c_int, [_c_void, _i64, _c_void, _c_void]),
+}
+
+_lib = None
+
+
+class HipError(RuntimeError):
+    """Raised when the native library is missing or a C-ABI call reports a failure."""
+
+
+def load_library() -> ctypes.CDLL:
+    """Load ``libdeeprob_hip.so`` (built in-tree by ``__graft_entry__.build()``) and bind every symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise HipError(
+            "libdeeprob_hip.so not found at {} -- build it with `make -C deeprob-kit_amd/csrc` "
+            "(or __graft_entry__.build()); there is no CPU fallback".format(LIB_PATH)
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so and the header disagree
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load_library().dpk_last_error()
+        raise HipError("{} failed ({}): {}".format(what, rc, msg.decode() if msg else ''))
+
+
+def is_unsupported(rc: int) -> bool:
+    return rc == -4
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_device_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    """The kernels take contiguous fp32 HIP tensors.  Anything that is not on a HIP device is an error
+    (no CPU path); other floating dtypes / layouts are converted on the device."""
+    if not t.is_cuda:
+        raise HipError(
+            "{} lives on '{}': the deeprob HIP path only evaluates tensors on a HIP device "
+            "(there is no CPU fallback)".format(name, t.device)
+        )
+    if t.dtype != torch.float32:
+        if not t.is_floating_point():
+            raise HipError("{} must be a floating point tensor, got {}".format(name, t.dtype))
+        t = t.float()
+    return t.contiguous()
+
+
+class Workspace:
+    """A growable device scratch buffer owned by a module (never shared between streams)."""
+
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+        self.struct_key = None  # what the cached structure tables were built from
+
+    def get(self, n_bytes: int, device: torch.device) -> torch.Tensor:
+        if self.buf is None or self.buf.numel() < n_bytes or self.buf.device != device:
+            self.buf = torch.empty(max(int(n_bytes), 256), dtype=torch.uint8, device=device)
+            self.struct_key = None
+        return self.buf

@@ -1,0 +1,250 @@
+"""Operator layer: one ``torch.autograd.Function`` per C-ABI forward/backward pair.
+
+Each ``forward`` enqueues hand-written gfx950 kernels on the caller's current stream through
+``ctypes``; each ``backward`` does the same with the matching ``*_backward`` entry point.  Nothing
+in here computes with PyTorch ops.
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from deeprob.hip import (
+    load_library, check, ptr, stream_ptr, require_device_f32, Workspace, DPK_FLAG_STRUCT_CACHED,
+)
+
+
+def _buffers_key(*tensors) -> tuple:
+    return tuple((t.data_ptr(), t._version, tuple(t.shape)) if t is not None else None for t in tensors)
+
+
+class LeafContext:
+    """Static description of a region-graph leaf layer handed to the kernels."""
+
+    def __init__(self, in_features: int, regions: int, channels: int, dimension: int, depth: int = 0,
+                 reps: int = 0, sums: int = 0, classes: int = 0):
+        self.D, self.R, self.I, self.d = in_features, regions, channels, dimension
+        self.depth, self.reps, self.S, self.C = depth, reps, sums, classes
+        self.ws = Workspace()
+
+    def workspace(self, device, mask, pad_mask) -> Tuple[torch.Tensor, int]:
+        lib = load_library()
+        n = lib.dpk_ratspn_workspace_bytes(self.D, self.R, self.d, self.I, self.depth, self.reps,
+                                           max(self.S, 1), max(self.C, 1))
+        if n < 0:
+            check(int(n), 'dpk_ratspn_workspace_bytes')
+        buf = self.ws.get(n, device)
+        key = _buffers_key(mask, pad_mask)
+        flags = DPK_FLAG_STRUCT_CACHED if self.ws.struct_key == key else 0
+        self.ws.struct_key = key
+        return buf, flags
+
+
+def _pad_u8(pad_mask: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    # torch.bool is one byte per element: reinterpret, no copy
+    return None if pad_mask is None else pad_mask.contiguous().view(torch.uint8)
+
+
+class GaussianLeafFn(torch.autograd.Function):
+    """RegionGraphLayer.forward with Normal leaves (reference: deeprob/spn/layers/ratspn.py:87-108)."""
+
+    @staticmethod
+    def forward(ctx, x, loc, scale, mask, pad_mask, lctx: LeafContext):
+        lib = load_library()
+        x = require_device_f32(x, 'x')
+        loc_c, scale_c = require_device_f32(loc, 'loc'), require_device_f32(scale, 'scale')
+        B = x.shape[0]
+        out = torch.empty((B, lctx.R, lctx.I), dtype=torch.float32, device=x.device)
+        pad = _pad_u8(pad_mask)
+        ws, flags = lctx.workspace(x.device, mask, pad_mask)
+        check(lib.dpk_gaussian_leaf_forward(ptr(x), B, lctx.D, ptr(mask), ptr(pad), ptr(loc_c), ptr(scale_c),
+                                            lctx.R, lctx.I, lctx.d, ptr(out), ptr(ws), ws.numel(), flags,
+                                            stream_ptr(x.device)), 'dpk_gaussian_leaf_forward')
+        ctx.save_for_backward(x, loc_c, scale_c, mask, pad_mask)
+        ctx.lctx = lctx
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load_library()
+        x, loc, scale, mask, pad_mask = ctx.saved_tensors
+        lctx = ctx.lctx
+        g = require_device_f32(g, 'grad')
+        need_x, need_loc, need_scale = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        gx = torch.empty_like(x) if need_x else None
+        gloc = torch.empty_like(loc) if need_loc else None
+        gscale = torch.empty_like(scale) if need_scale else None
+        ws, flags = lctx.workspace(x.device, mask, pad_mask)
+        check(lib.dpk_gaussian_leaf_backward(ptr(x), ptr(g), x.shape[0], lctx.D, ptr(mask),
+                                             ptr(_pad_u8(pad_mask)), ptr(loc), ptr(scale), lctx.R, lctx.I,
+                                             lctx.d, ptr(gloc), ptr(gscale), ptr(gx), ptr(ws), ws.numel(),
+                                             flags, stream_ptr(x.device)), 'dpk_gaussian_leaf_backward')
+        return gx, gloc, gscale, None, None, None
+
+
+class BernoulliLeafFn(torch.autograd.Function):
+    """RegionGraphLayer.forward with Bernoulli leaves (reference: ratspn.py:87-108, :216-247)."""
+
+    @staticmethod
+    def forward(ctx, x, logits, mask, pad_mask, lctx: LeafContext):
+        lib = load_library()
+        x = require_device_f32(x, 'x')
+        logits_c = require_device_f32(logits, 'logits')
+        B = x.shape[0]
+        out = torch.empty((B, lctx.R, lctx.I), dtype=torch.float32, device=x.device)
+        ws, flags = lctx.workspace(x.device, mask, pad_mask)
+        check(lib.dpk_bernoulli_leaf_forward(ptr(x), B, lctx.D, ptr(mask), ptr(_pad_u8(pad_mask)),
+                                             ptr(logits_c), lctx.R, lctx.I, lctx.d, ptr(out), ptr(ws),
+                                             ws.numel(), flags, stream_ptr(x.device)),
+              'dpk_bernoulli_leaf_forward')
+        ctx.save_for_backward(x, logits_c, mask, pad_mask)
+        ctx.lctx = lctx
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load_library()
+        x, logits, mask, pad_mask = ctx.saved_tensors
+        lctx = ctx.lctx
+        g = require_device_f32(g, 'grad')
+        glog = torch.empty_like(logits) if ctx.needs_input_grad[1] else None
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("d/dx through Bernoulli leaves is not defined by the reference use")
+        ws, flags = lctx.workspace(x.device, mask, pad_mask)
+        check(lib.dpk_bernoulli_leaf_backward(ptr(x), ptr(g), x.shape[0], lctx.D, ptr(mask),
+                                              ptr(_pad_u8(pad_mask)), ptr(logits), lctx.R, lctx.I, lctx.d,
+                                              ptr(glog), ptr(ws), ws.numel(), flags, stream_ptr(x.device)),
+              'dpk_bernoulli_leaf_backward')
+        return None, glog, None, None, None
+
+
+class ProductFn(torch.autograd.Function):
+    """ProductLayer.forward (reference: ratspn.py:272-286)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = load_library()
+        x = require_device_f32(x, 'x')
+        B, R, N = x.shape
+        out = torch.empty((B, R // 2, N * N), dtype=torch.float32, device=x.device)
+        check(lib.dpk_product_forward(ptr(x), B, R, N, ptr(out), stream_ptr(x.device)), 'dpk_product_forward')
+        ctx.shape = (B, R, N)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load_library()
+        B, R, N = ctx.shape
+        g = require_device_f32(g, 'grad')
+        gx = torch.empty((B, R, N), dtype=torch.float32, device=g.device)
+        check(lib.dpk_product_backward(ptr(g), B, R, N, ptr(gx), stream_ptr(g.device)), 'dpk_product_backward')
+        return gx
+
+
+def _sum_ws(ws: Workspace, B, P, N, S, device):
+    lib = load_library()
+    n = lib.dpk_sum_workspace_bytes(B, P, N, S)
+    if n < 0:
+        check(int(n), 'dpk_sum_workspace_bytes')
+    return ws.get(n, device)
+
+
+class SumFn(torch.autograd.Function):
+    """SumLayer.forward in eval mode (reference: ratspn.py:363-378)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, ws: Workspace):
+        lib = load_library()
+        x = require_device_f32(x, 'x')
+        w = require_device_f32(weight, 'weight')
+        B, P, N = x.shape
+        S = w.shape[1]
+        out = torch.empty((B, P, S), dtype=torch.float32, device=x.device)
+        buf = _sum_ws(ws, B, P, N, S, x.device)
+        check(lib.dpk_sum_forward(ptr(x), ptr(w), B, P, N, S, ptr(out), ptr(buf), buf.numel(),
+                                  stream_ptr(x.device)), 'dpk_sum_forward')
+        ctx.save_for_backward(x, w, out)
+        ctx.ws = ws
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load_library()
+        x, w, out = ctx.saved_tensors
+        g = require_device_f32(g, 'grad')
+        B, P, N = x.shape
+        S = w.shape[1]
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        buf = _sum_ws(ctx.ws, B, P, N, S, x.device)
+        check(lib.dpk_sum_backward(ptr(x), ptr(w), ptr(out), ptr(g), B, P, N, S, ptr(gx), ptr(gw), ptr(buf),
+                                   buf.numel(), stream_ptr(x.device)), 'dpk_sum_backward')
+        return gx, gw, None
+
+
+class RootFn(torch.autograd.Function):
+    """RootLayer.forward (reference: ratspn.py:446-458)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, ws: Workspace):
+        lib = load_library()
+        x = require_device_f32(x, 'x')
+        w = require_device_f32(weight, 'weight')
+        B = x.shape[0]
+        x2 = x.reshape(B, -1)
+        M, C = x2.shape[1], w.shape[0]
+        out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        buf = _sum_ws(ws, B, 1, M, C, x.device)
+        check(lib.dpk_root_forward(ptr(x2), ptr(w), B, M, C, ptr(out), ptr(buf), buf.numel(),
+                                   stream_ptr(x.device)), 'dpk_root_forward')
+        ctx.save_for_backward(x2, w, out)
+        ctx.ws = ws
+        ctx.in_shape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load_library()
+        x2, w, out = ctx.saved_tensors
+        g = require_device_f32(g, 'grad')
+        B, M = x2.shape
+        C = w.shape[0]
+        gx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        buf = _sum_ws(ctx.ws, B, 1, M, C, x2.device)
+        check(lib.dpk_root_backward(ptr(x2), ptr(w), ptr(out), ptr(g), B, M, C, ptr(gx), ptr(gw), ptr(buf),
+                                    buf.numel(), stream_ptr(x2.device)), 'dpk_root_backward')
+        return (gx.reshape(ctx.in_shape) if gx is not None else None), gw, None
+
+
+def ratspn_forward_fused(x, mask, pad_mask, loc, scale, sum_weights, root_weight, lctx: LeafContext,
+                         ll_acc: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """RatSpn.forward in one launch (reference: deeprob/spn/models/ratspn.py:105-122).
+
+    Returns None when the shape is outside what the fused kernel is built for (the caller then
+    chains the per-layer operators); raises on any other failure.
+    """
+    lib = load_library()
+    x = require_device_f32(x, 'x')
+    loc_c, scale_c = require_device_f32(loc, 'loc'), require_device_f32(scale, 'scale')
+    sw = [require_device_f32(w, 'sum weight') for w in sum_weights]
+    rw = require_device_f32(root_weight, 'root weight')
+    B = x.shape[0]
+    out = torch.empty((B, lctx.C), dtype=torch.float32, device=x.device)
+    ws, flags = lctx.workspace(x.device, mask, pad_mask)
+    rc = lib.dpk_ratspn_forward(ptr(x), B, lctx.D, ptr(mask), ptr(_pad_u8(pad_mask)), ptr(loc_c), ptr(scale_c),
+                                ptr(sw[0]) if len(sw) > 0 else None, ptr(sw[1]) if len(sw) > 1 else None,
+                                ptr(rw), lctx.depth, lctx.reps, lctx.I, lctx.S, lctx.C, ptr(out), None,
+                                ptr(ll_acc), ptr(ws), ws.numel(), flags, stream_ptr(x.device))
+    if rc == -4:  # DPK_EUNSUPPORTED
+        lctx.ws.struct_key = None
+        return None
+    check(rc, 'dpk_ratspn_forward')
+    return out
+
+
+def ll_accumulate(ll: torch.Tensor, acc: torch.Tensor):
+    """acc[0] += sum(ll) (fp64), acc[1] += ll.numel()."""
+    lib = load_library()
+    ll = require_device_f32(ll, 'll')
+    assert acc.dtype == torch.float64 and acc.numel() == 2 and acc.is_cuda
+    check(lib.dpk_ll_accumulate(ptr(ll), ll.numel(), ptr(acc), stream_ptr(ll.device)), 'dpk_ll_accumulate')

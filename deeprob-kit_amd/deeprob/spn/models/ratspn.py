@@ -1,0 +1,222 @@
+"""RAT-SPN models behind the reference interface (deeprob/spn/models/ratspn.py), evaluated on MI355X.
+
+``RatSpn.forward`` has two routes, both made of hand-written HIP kernels only:
+  * inference (no autograd graph needed, Gaussian leaves, shape inside the built set): ONE fused
+    launch for the whole model (``dpk_ratspn_forward``);
+  * otherwise: the per-layer operators chained exactly like the reference's python loop, each with
+    its own backward kernel.
+"""
+from typing import Optional, Tuple, Type
+
+import torch
+
+from deeprob.utils.random import RandomState
+from deeprob.utils.region import RegionGraph
+from deeprob.torch.base import ProbabilisticModel
+from deeprob.torch.constraints import ScaleClipper
+from deeprob.spn.layers.ratspn import RegionGraphLayer, GaussianLayer, BernoulliLayer
+from deeprob.spn.layers.ratspn import SumLayer, ProductLayer, RootLayer
+from deeprob.hip import ops, HipError
+
+
+class RatSpn(ProbabilisticModel):
+    def __init__(
+        self,
+        in_features: int,
+        base_cls: Type[RegionGraphLayer],
+        base_kwargs: Optional[dict] = None,
+        out_classes: int = 1,
+        rg_depth: int = 2,
+        rg_repetitions: int = 1,
+        rg_batch: int = 2,
+        rg_sum: int = 2,
+        in_dropout: Optional[float] = None,
+        sum_dropout: Optional[float] = None,
+        random_state: Optional[RandomState] = None
+    ):
+        """
+        Randomized-and-tensorized SPN (constructor contract of the reference, ratspn.py:17-103).
+
+        :param in_features: number of input features.
+        :param base_cls: leaf layer class, a sub-class of RegionGraphLayer.
+        :param base_kwargs: extra keyword arguments of the leaf layer.
+        :param out_classes: number of root nodes (1 = plain density estimation).
+        :param rg_depth: region graph depth.
+        :param rg_repetitions: number of random repetitions of the region graph.
+        :param rg_batch: leaf distributions per region.
+        :param rg_sum: sum nodes per inner region.
+        :param in_dropout: leaf dropout rate or None.
+        :param sum_dropout: sum layer dropout rate or None.
+        :param random_state: None, a seed or a NumPy RandomState.
+        :raises ValueError: if a parameter is out of domain.
+        """
+        if not issubclass(base_cls, RegionGraphLayer):
+            raise ValueError("The base distribution's class must be a sub-class of RegionGraphLayer")
+        if in_features <= 0:
+            raise ValueError("The number of input features must be positve")
+        if out_classes <= 0:
+            raise ValueError("The number of output classes must be positive")
+        if rg_batch <= 0:
+            raise ValueError("The number of base distribution batches must be positive")
+        if rg_sum <= 0:
+            raise ValueError("The number of sum nodes per region must be positive")
+        if in_dropout is not None and not 0.0 < in_dropout < 1.0:
+            raise ValueError("The dropout rate at base distribution must be in (0, 1)")
+        if sum_dropout is not None and not 0.0 < sum_dropout < 1.0:
+            raise ValueError("The dropout rate at sum layers must be in (0, 1)")
+
+        super().__init__()
+        self.in_features = in_features
+        self.out_classes = out_classes
+        self.rg_depth = rg_depth
+        self.rg_batch = rg_batch
+        self.rg_sum = rg_sum
+        self.in_dropout = in_dropout
+        self.sum_dropout = sum_dropout
+        self.layers = torch.nn.ModuleList()
+
+        # leaves first: [leaf regions], [partitions], [regions], ..., [root]
+        graph = RegionGraph(self.in_features, self.rg_depth, random_state)
+        self.rg_layers = list(reversed(graph.make_layers(rg_repetitions)))
+        self.rg_repetitions = rg_repetitions
+
+        self.base_layer = base_cls(
+            self.in_features, self.rg_batch,
+            regions=self.rg_layers[0], rg_depth=self.rg_depth, dropout=self.in_dropout,
+            **(base_kwargs or {})
+        )
+
+        # odd levels are partitions (Product), even levels are regions (Sum)
+        groups, nodes = self.base_layer.in_regions, self.base_layer.out_channels
+        for level in range(1, len(self.rg_layers) - 1):
+            if level % 2 == 1:
+                layer = ProductLayer(groups, nodes)
+                groups, nodes = layer.out_partitions, layer.out_nodes
+            else:
+                layer = SumLayer(groups, nodes, self.rg_sum, self.sum_dropout)
+                groups, nodes = layer.out_regions, layer.out_nodes
+            self.layers.append(layer)
+        self.root_layer = RootLayer(groups, nodes, self.out_classes)
+
+        self._fused_ctx = ops.LeafContext(
+            self.in_features, self.base_layer.in_regions, self.rg_batch, self.base_layer.dimension,
+            depth=self.rg_depth, reps=rg_repetitions, sums=self.rg_sum, classes=self.out_classes
+        )
+
+    def _needs_graph(self, x: torch.Tensor) -> bool:
+        if not torch.is_grad_enabled():
+            return False
+        return x.requires_grad or any(p.requires_grad for p in self.parameters())
+
+    def _forward_fused(self, x: torch.Tensor, ll_acc: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        if not isinstance(self.base_layer, GaussianLayer):
+            return None
+        if self.training and (self.in_dropout is not None or self.sum_dropout is not None):
+            return None
+        base = self.base_layer
+        sum_weights = [layer.weight for layer in self.layers if isinstance(layer, SumLayer)]
+        return ops.ratspn_forward_fused(
+            x, base.mask, base._pad_mask_or_none(), base.loc, base.scale, sum_weights,
+            self.root_layer.weight, self._fused_ctx, ll_acc
+        )
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """
+        Log-likelihood ``[B, out_classes]`` of the evidence ``x [B, D]``; NaN entries are marginalised
+        (reference: ratspn.py:105-122).
+        """
+        if not self._needs_graph(x):
+            out = self._forward_fused(x)
+            if out is not None:
+                return out
+        x = self.base_layer(x)
+        for layer in self.layers:
+            x = layer(x)
+        return self.root_layer(x)
+
+    @torch.no_grad()
+    def mpe(self, x: torch.Tensor, y: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Most probable completion of the NaN entries of ``x`` (reference: ratspn.py:124-162)."""
+        evidence = x
+        n_samples = x.shape[0]
+        x = self.base_layer(x)
+        lls = []
+        for layer in self.layers:
+            lls.append(x)
+            x = layer(x)
+        if self.out_classes == 1:
+            y = torch.zeros(n_samples, dtype=torch.long, device=x.device)
+        elif y is None:
+            y = torch.argmax(self.root_layer(x), dim=1)
+        idx_group, idx_offset = self.root_layer.mpe(x, y)
+        for i in reversed(range(len(self.layers))):
+            idx_group, idx_offset = self.layers[i].mpe(lls[i], idx_group, idx_offset)
+        return self.base_layer.mpe(evidence, idx_group, idx_offset)
+
+    @torch.no_grad()
+    def sample(self, n_samples: int, y: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Ancestral sampling, top-down (reference: ratspn.py:164-182)."""
+        device = self.root_layer.weight.device
+        if self.out_classes == 1:
+            y = torch.zeros(n_samples, dtype=torch.long, device=device)
+        elif y is None:
+            y = torch.randint(self.out_classes, [n_samples], device=device)
+        idx_group, idx_offset = self.root_layer.sample(y)
+        for i in reversed(range(len(self.layers))):
+            idx_group, idx_offset = self.layers[i].sample(idx_group, idx_offset)
+        return self.base_layer.sample(idx_group, idx_offset)
+
+    def loss(self, x: torch.Tensor, y: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """-mean LL (generative) or cross entropy over classes (reference: ratspn.py:184-191)."""
+        if self.out_classes == 1:
+            return -torch.mean(x)
+        return torch.nn.functional.nll_loss(torch.log_softmax(x, dim=1), y)
+
+
+class GaussianRatSpn(RatSpn):
+    def __init__(
+        self,
+        in_features: int,
+        out_classes: int = 1,
+        rg_depth: int = 2,
+        rg_repetitions: int = 1,
+        rg_batch: int = 2,
+        rg_sum: int = 2,
+        in_dropout: Optional[float] = None,
+        sum_dropout: Optional[float] = None,
+        random_state: Optional[RandomState] = None,
+        uniform_loc: Optional[Tuple[float, float]] = None,
+        optimize_scale: bool = False
+    ):
+        """RAT-SPN with Gaussian leaves (reference: ratspn.py:194-239)."""
+        super().__init__(
+            in_features, GaussianLayer, {'uniform_loc': uniform_loc, 'optimize_scale': optimize_scale},
+            out_classes, rg_depth, rg_repetitions, rg_batch, rg_sum, in_dropout, sum_dropout, random_state
+        )
+        self.optimize_scale = optimize_scale
+        if self.optimize_scale:
+            self.scale_clipper = ScaleClipper()
+
+    def apply_constraints(self):
+        if self.optimize_scale:
+            self.scale_clipper(self.base_layer)
+
+
+class BernoulliRatSpn(RatSpn):
+    def __init__(
+        self,
+        in_features: int,
+        out_classes: int = 1,
+        rg_depth: int = 2,
+        rg_repetitions: int = 1,
+        rg_batch: int = 2,
+        rg_sum: int = 2,
+        in_dropout: Optional[float] = None,
+        sum_dropout: Optional[float] = None,
+        random_state: Optional[RandomState] = None
+    ):
+        """RAT-SPN with Bernoulli leaves (reference: ratspn.py:242-273)."""
+        super().__init__(
+            in_features, BernoulliLayer, None,
+            out_classes, rg_depth, rg_repetitions, rg_batch, rg_sum, in_dropout, sum_dropout, random_state
+        )

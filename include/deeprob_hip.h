@@ -1,0 +1,149 @@
+/*
+ * deeprob_hip.h -- C ABI of libdeeprob_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the tensorized density-evaluation path of DeeProb-kit
+ * (RAT-SPN / DGC-SPN layers, RealNVP-1D coupling).  The reference is pure
+ * Python on PyTorch and has no FFI of its own; every entry point below takes
+ * the place of one `forward` / `apply_backward` body (or its autograd
+ * backward) of a reference nn.Module and is what a ctypes binding placed in
+ * that method would call.  The reference location replaced by each entry is
+ * cited as `file:line` relative to the reference tree.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch CUDA storage),
+ *     fp32 tensors are contiguous row-major, last index fastest;
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued
+ *     asynchronously on it, nothing here synchronises or allocates;
+ *   - scratch memory is handed in by the caller (`ws`, `ws_bytes`); the
+ *     matching *_workspace_bytes() query gives the required size;
+ *   - the return value is 0 on success and a negative DPK_E* code otherwise;
+ *     dpk_last_error() returns a thread-local message for the last failure.
+ *     No C++ exception crosses the boundary.
+ */
+#ifndef DEEPROB_HIP_H
+#define DEEPROB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPK_OK 0
+#define DPK_EINVAL (-1)   /* bad argument (null pointer, size out of domain)   */
+#define DPK_EWORKSPACE (-2) /* workspace too small                               */
+#define DPK_ELAUNCH (-3)  /* hipLaunch / runtime error                          */
+#define DPK_EUNSUPPORTED (-4) /* shape outside what the kernels are built for    */
+
+/* flags shared by the RAT-SPN entry points */
+#define DPK_FLAG_STRUCT_CACHED 1u /* structure tables in `ws` (built from mask /
+                                     pad_mask by an earlier call with the same
+                                     shapes) are still valid: skip rebuilding   */
+
+const char *dpk_last_error(void);
+int dpk_abi_version(void);
+
+/* ------------------------------------------------------------------------ *
+ * RAT-SPN                                                                   *
+ * ------------------------------------------------------------------------ */
+
+/* Scratch size for every dpk_*leaf* / dpk_ratspn_* call of a model with R leaf
+ * regions of `dimension` features, `channels` distributions per region, sum
+ * layers of `sums` nodes, `classes` root outputs. */
+int64_t dpk_ratspn_workspace_bytes(int32_t in_features, int32_t regions, int32_t dimension,
+                                   int32_t channels, int32_t depth, int32_t reps, int32_t sums,
+                                   int32_t classes);
+
+/* RegionGraphLayer.forward with GaussianLayer, eval mode
+ * (deeprob/spn/layers/ratspn.py:87-108, distribution :160-213).
+ *   x        [B, D]        inputs, NaN = marginalised
+ *   mask     [R, d] int64  region variable ids (buffer `mask`)
+ *   pad_mask [R, d] uint8  1 = dummy variable (buffer `pad_mask`, may be NULL)
+ *   loc,scale[R, I, d]
+ *   out      [B, R, I]     sum_j nan_to_num(Normal(loc,scale).log_prob(x[:,mask]))   */
+int dpk_gaussian_leaf_forward(const float *x, int64_t B, int32_t D, const int64_t *mask,
+                              const uint8_t *pad_mask, const float *loc, const float *scale,
+                              int32_t R, int32_t I, int32_t d, float *out, void *ws,
+                              int64_t ws_bytes, uint32_t flags, void *stream);
+
+/* Same with BernoulliLayer (ratspn.py:216-247): log p = -BCEWithLogits(logits, x). */
+int dpk_bernoulli_leaf_forward(const float *x, int64_t B, int32_t D, const int64_t *mask,
+                               const uint8_t *pad_mask, const float *logits, int32_t R,
+                               int32_t I, int32_t d, float *out, void *ws, int64_t ws_bytes,
+                               uint32_t flags, void *stream);
+
+/* Autograd backward of the Gaussian leaf.  g [B,R,I] upstream.
+ * grad_loc / grad_scale [R,I,d] are OVERWRITTEN (may be NULL to skip),
+ * grad_x [B,D] is OVERWRITTEN (may be NULL).  Marginalised (NaN) inputs get a
+ * zero gradient.                                                            */
+int dpk_gaussian_leaf_backward(const float *x, const float *g, int64_t B, int32_t D,
+                               const int64_t *mask, const uint8_t *pad_mask, const float *loc,
+                               const float *scale, int32_t R, int32_t I, int32_t d,
+                               float *grad_loc, float *grad_scale, float *grad_x, void *ws,
+                               int64_t ws_bytes, uint32_t flags, void *stream);
+
+int dpk_bernoulli_leaf_backward(const float *x, const float *g, int64_t B, int32_t D,
+                                const int64_t *mask, const uint8_t *pad_mask,
+                                const float *logits, int32_t R, int32_t I, int32_t d,
+                                float *grad_logits, void *ws, int64_t ws_bytes, uint32_t flags,
+                                void *stream);
+
+/* ProductLayer.forward (ratspn.py:272-286): in [B,R,N] -> out [B,R/2,N*N],
+ * out[b,p,i*N+j] = in[b,2p,i] + in[b,2p+1,j].                                */
+int dpk_product_forward(const float *in, int64_t B, int32_t R, int32_t N, float *out,
+                        void *stream);
+/* backward: g [B,R/2,N*N] -> grad_in [B,R,N] (overwritten). */
+int dpk_product_backward(const float *g, int64_t B, int32_t R, int32_t N, float *grad_in,
+                         void *stream);
+
+/* SumLayer.forward, eval mode (ratspn.py:363-378): in [B,P,N], weight [P,S,N],
+ * out[b,p,o] = logsumexp_n(in[b,p,n] + log_softmax(weight,2)[p,o,n]).        */
+int dpk_sum_forward(const float *in, const float *weight, int64_t B, int32_t P, int32_t N,
+                    int32_t S, float *out, void *ws, int64_t ws_bytes, void *stream);
+/* backward: grad_in [B,P,N] and grad_weight [P,S,N] overwritten (either may be
+ * NULL).  `out` is the forward result.                                       */
+int dpk_sum_backward(const float *in, const float *weight, const float *out, const float *g,
+                     int64_t B, int32_t P, int32_t N, int32_t S, float *grad_in,
+                     float *grad_weight, void *ws, int64_t ws_bytes, void *stream);
+int64_t dpk_sum_workspace_bytes(int64_t B, int32_t P, int32_t N, int32_t S);
+
+/* RootLayer.forward (ratspn.py:446-458): in [B,M] (flattened), weight [C,M],
+ * out[b,c] = logsumexp_n(in[b,n] + log_softmax(weight,1)[c,n]).  It is the sum
+ * layer with P = 1.                                                          */
+int dpk_root_forward(const float *in, const float *weight, int64_t B, int32_t M, int32_t C,
+                     float *out, void *ws, int64_t ws_bytes, void *stream);
+int dpk_root_backward(const float *in, const float *weight, const float *out, const float *g,
+                      int64_t B, int32_t M, int32_t C, float *grad_in, float *grad_weight,
+                      void *ws, int64_t ws_bytes, void *stream);
+
+/* RatSpn.forward, eval mode, Gaussian leaves, whole model in ONE launch
+ * (deeprob/spn/models/ratspn.py:105-122).  Built for depth in {1,2,3} and
+ * channels, sums in {2,4,8}; anything else returns DPK_EUNSUPPORTED and the
+ * caller chains the per-layer entry points instead.
+ *   sum_weight0    [reps*2^(depth-1), S, I*I]   first sum layer (depth >= 2)
+ *   sum_weight1    [reps*2^(depth-2), S, S*S]   second sum layer (depth == 3)
+ *   root_weight    [C, reps*N_last]
+ *   out            [B, C]
+ *   leaf_out       [B, R, I] or NULL -- leaf log-likelihoods kept for backward
+ *   ll_sum         double[2] or NULL -- += {sum of out, number of entries}    */
+int dpk_ratspn_forward(const float *x, int64_t B, int32_t D, const int64_t *mask,
+                       const uint8_t *pad_mask, const float *loc, const float *scale,
+                       const float *sum_weight0, const float *sum_weight1,
+                       const float *root_weight,
+                       int32_t depth, int32_t reps, int32_t I, int32_t S, int32_t C,
+                       float *out, float *leaf_out, double *ll_sum, void *ws, int64_t ws_bytes,
+                       uint32_t flags, void *stream);
+
+/* Measurement hook: the NEXT dominant-kernel launch made from this thread (the fused / leaf
+ * forward kernel) is bracketed by hipEventRecord(ev_start) / hipEventRecord(ev_stop) on its stream,
+ * so a harness can time that kernel alone inside a longer step.  One-shot; pass NULLs to cancel. */
+int dpk_profile_next_kernel(void *ev_start, void *ev_stop);
+
+/* sum and count of a vector of log-likelihoods in fp64 (the per-rank partial of
+ * the mean-LL all-reduce): acc[0] += sum(ll), acc[1] += n.                   */
+int dpk_ll_accumulate(const float *ll, int64_t n, double *acc, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPROB_HIP_H */

@@ -1,0 +1,211 @@
+"""Parity of the HIP RAT-SPN path (through the C ABI) with the oracle and the golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ratspn_oracle as orc
+from tests.util import rel_err, grad_err, state_to_model
+
+pytestmark = pytest.mark.gpu
+
+LL_TOL = 1e-5     # north-star: 1e-5 relative on fp32 log-likelihoods
+GRAD_TOL = 1e-4   # relative to the largest magnitude of the tensor
+
+# name -> constructor kwargs of GaussianRatSpn
+MODELS = {
+    'ratspn_g784_d2_r8_i2_s2': dict(in_features=784, rg_depth=2, rg_repetitions=8, rg_batch=2, rg_sum=2),
+    'ratspn_g784_d2_r8_i8_s8': dict(in_features=784, rg_depth=2, rg_repetitions=8, rg_batch=8, rg_sum=8),
+    'ratspn_g784_d2_r8_i4_s2': dict(in_features=784, rg_depth=2, rg_repetitions=8, rg_batch=4, rg_sum=2),
+    'ratspn_g784_d2_r8_i16_s16': dict(in_features=784, rg_depth=2, rg_repetitions=8, rg_batch=16, rg_sum=16),
+    'ratspn_g784_d1_r4_i8_scale': dict(in_features=784, rg_depth=1, rg_repetitions=4, rg_batch=8, rg_sum=8,
+                                       optimize_scale=True),
+    'ratspn_g784_d3_r5_i4_s4_c10': dict(in_features=784, out_classes=10, rg_depth=3, rg_repetitions=5,
+                                        rg_batch=4, rg_sum=4, optimize_scale=True),
+    'ratspn_g100_d2_r11_i2_s4_c3': dict(in_features=100, out_classes=3, rg_depth=2, rg_repetitions=11,
+                                        rg_batch=2, rg_sum=4),
+    'ratspn_g15_d2_r3_i3_s5_pad': dict(in_features=15, rg_depth=2, rg_repetitions=3, rg_batch=3, rg_sum=5,
+                                       optimize_scale=True),
+    'ratspn_g15_d3_r2_i2_s2_pad': dict(in_features=15, rg_depth=3, rg_repetitions=2, rg_batch=2, rg_sum=2),
+}
+SEEDS = {'ratspn_g784_d3_r5_i4_s4_c10': 7, 'ratspn_g100_d2_r11_i2_s4_c3': 3, 'ratspn_g15_d3_r2_i2_s2_pad': 1}
+
+
+def build(name, golden, device='cuda'):
+    from deeprob.spn.models import GaussianRatSpn
+    g = golden(name)
+    model = GaussianRatSpn(random_state=SEEDS.get(name, 42), **MODELS[name])
+    # the region graph must come out identical to the reference's for the same seed
+    assert np.array_equal(model.base_layer.mask.numpy(), g['sd.base_layer.mask'])
+    state_to_model(model, g, device).eval()
+    return model, g
+
+
+@pytest.mark.parametrize('name', sorted(MODELS))
+def test_forward_golden(golden, name):
+    model, g = build(name, golden)
+    with torch.no_grad():
+        ll = model(torch.from_numpy(g['x']).cuda())
+        ll_nan = model(torch.from_numpy(g['x_nan']).cuda())
+    assert ll.shape == g['ll'].shape and ll.dtype == torch.float32 and ll.is_contiguous()
+    assert rel_err(ll.cpu().numpy(), g['ll']) <= LL_TOL
+    assert rel_err(ll_nan.cpu().numpy(), g['ll_nan']) <= LL_TOL
+    assert np.all(np.abs(ll_nan.cpu().numpy()[1]) < 1e-5)
+
+
+@pytest.mark.parametrize('name', sorted(MODELS))
+def test_layers_golden(golden, name):
+    """Per-layer operators chained like the reference's python loop (the non-fused route)."""
+    model, g = build(name, golden)
+    x = torch.from_numpy(g['x']).cuda()
+    with torch.no_grad():
+        h = model.base_layer(x)
+        if 'act.leaf' in g.files:
+            assert rel_err(h.cpu().numpy(), g['act.leaf']) <= LL_TOL
+        for i, layer in enumerate(model.layers):
+            h = layer(h)
+            key = 'act.layer{}'.format(i)
+            if key in g.files:
+                assert rel_err(h.cpu().numpy(), g[key]) <= LL_TOL, key
+        out = model.root_layer(h)
+    assert rel_err(out.cpu().numpy(), g['ll']) <= LL_TOL
+
+
+@pytest.mark.parametrize('name', [n for n in sorted(MODELS) if 'i16' not in n])
+def test_backward_golden(golden, name):
+    model, g = build(name, golden)
+    x = torch.from_numpy(g['x']).cuda().requires_grad_(True)
+    y = torch.from_numpy(g['y']).cuda() if 'y' in g.files else None
+    with torch.enable_grad():
+        loss = model.loss(model(x), y)
+        loss.backward()
+    assert abs(loss.item() - float(g['loss'])) <= LL_TOL * max(1.0, abs(float(g['loss'])))
+    assert grad_err(x.grad.cpu().numpy(), g['grad.x']) <= GRAD_TOL
+    for k, p in model.named_parameters():
+        if 'grad.' + k in g.files:
+            assert p.grad is not None, k
+            assert grad_err(p.grad.cpu().numpy(), g['grad.' + k]) <= GRAD_TOL, k
+
+
+@pytest.mark.parametrize('B', [1, 63, 64, 129, 1000])
+@pytest.mark.parametrize('name', ['ratspn_g784_d2_r8_i2_s2', 'ratspn_g784_d2_r8_i8_s8',
+                                  'ratspn_g15_d2_r3_i3_s5_pad'])
+def test_forward_vs_oracle_ragged_batches(golden, name, B):
+    """Seeded inputs at batch sizes around the tile size, with NaN / inf evidence, vs the oracle."""
+    model, g = build(name, golden)
+    D = MODELS[name]['in_features']
+    gen = torch.Generator().manual_seed(B)
+    x = torch.randn(B, D, generator=gen) * 1.5
+    x[torch.rand(B, D, generator=gen) < 0.1] = float('nan')
+    if B > 2:
+        x[B // 2] = float('nan')
+        x[0, 0] = float('-inf')
+    sd = orc.state_from_npz(g)
+    want = orc.ratspn_forward(sd, x).numpy()
+    with torch.no_grad():
+        got = model(x.cuda()).cpu().numpy()
+    assert rel_err(got, want) <= LL_TOL
+
+
+def test_empty_batch(golden):
+    model, g = build('ratspn_g784_d2_r8_i2_s2', golden)
+    with torch.no_grad():
+        out = model(torch.empty(0, 784, device='cuda'))
+    assert out.shape == (0, 1)
+
+
+def test_float64_and_noncontiguous_inputs(golden):
+    model, g = build('ratspn_g784_d2_r8_i2_s2', golden)
+    x = torch.from_numpy(g['x'])
+    with torch.no_grad():
+        a = model(x.double().cuda())
+        b = model(x.cuda().t().contiguous().t())
+    assert rel_err(a.float().cpu().numpy(), g['ll']) <= LL_TOL
+    assert rel_err(b.cpu().numpy(), g['ll']) <= LL_TOL
+
+
+def test_cpu_tensor_fails_loudly(golden):
+    from deeprob.hip import HipError
+    model, g = build('ratspn_g784_d2_r8_i2_s2', golden)
+    with pytest.raises(HipError):
+        model(torch.from_numpy(g['x']))
+
+
+def test_bernoulli_known_answer(golden):
+    """Reference KAT (tests/test_ratspn.py:46-48) on the HIP path: sum over 2^15 assignments = 1."""
+    from deeprob.spn.models import BernoulliRatSpn
+    g = golden('ratspn_bernoulli_15_d3_r4_i4_s2')
+    model = BernoulliRatSpn(15, rg_depth=3, rg_repetitions=4, rg_batch=4, rg_sum=2, random_state=42)
+    state_to_model(model, g, 'cuda').eval()
+    bits = ((np.arange(2 ** 15)[:, None] >> np.arange(14, -1, -1)[None, :]) & 1).astype(np.float32)
+    with torch.no_grad():
+        ll = model(torch.from_numpy(bits).cuda())
+        ll_nan = model(torch.from_numpy(g['x_sub']).cuda())
+    assert rel_err(ll.cpu().numpy(), g['ll']) <= LL_TOL
+    assert np.isclose(torch.sum(torch.exp(ll)).item(), 1.0)
+    assert rel_err(ll_nan.cpu().numpy(), g['ll_sub_nan']) <= LL_TOL
+    x = torch.from_numpy(g['x_grad_in']).cuda()
+    with torch.enable_grad():
+        loss = model.loss(model(x))
+        loss.backward()
+    assert abs(loss.item() - float(g['loss'])) <= LL_TOL * abs(float(g['loss']))
+    for k, p in model.named_parameters():
+        assert grad_err(p.grad.cpu().numpy(), g['grad.' + k]) <= GRAD_TOL, k
+
+
+def test_layer_edge_cases(golden):
+    """-inf inputs through Product / Sum / Root: -inf out, never NaN; vanishing-weight exact path."""
+    from deeprob.spn.layers.ratspn import ProductLayer, SumLayer, RootLayer
+    g = golden('ratspn_layers_edge')
+    prod, sm, root = ProductLayer(8, 3).cuda(), SumLayer(4, 9, 5).cuda(), RootLayer(4, 5, 2).cuda()
+    with torch.no_grad():
+        sm.weight.copy_(torch.from_numpy(g['sum_weight']))
+        root.weight.copy_(torch.from_numpy(g['root_weight']))
+        p = prod(torch.from_numpy(g['h']).cuda())
+        s = sm(p)
+        r = root(s)
+    assert rel_err(p.cpu().numpy(), g['prod_out']) == 0.0
+    assert rel_err(s.cpu().numpy(), g['sum_out']) <= LL_TOL
+    assert rel_err(r.cpu().numpy(), g['root_out']) <= LL_TOL
+
+
+def test_fused_exact_path_with_vanishing_weights(golden):
+    """Trained-looking sum weights (one dominant, the rest ~e^-200) and widely spread leaf values force
+    the fused kernel off the exp-domain fast path; it must still match the oracle."""
+    model, g = build('ratspn_g784_d2_r8_i4_s2', golden)
+    with torch.no_grad():
+        for layer in model.layers:
+            if hasattr(layer, 'weight'):
+                layer.weight[:, :, :] = -200.0
+                layer.weight[:, :, 5] = 0.0
+        model.root_layer.weight[:, :] = -150.0
+        model.root_layer.weight[:, 3] = 0.0
+        model.base_layer.loc.mul_(3.0)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    x = torch.from_numpy(g['x']) * 2.0
+    want = orc.ratspn_forward(sd, x).numpy()
+    with torch.no_grad():
+        got = model(x.cuda()).cpu().numpy()
+    assert np.isfinite(want).all()
+    assert rel_err(got, want) <= LL_TOL
+
+
+def test_full_size_properties():
+    """BASELINE config at full batch (65536): size-independent properties instead of an oracle run --
+    tile independence (any slice of the batch gives the same LLs), all-NaN rows give LL = 0, and the
+    fused fp64 sum equals the sum of the returned LLs."""
+    from deeprob.spn.models import GaussianRatSpn
+    from deeprob.hip import ops
+    torch.manual_seed(0)
+    model = GaussianRatSpn(784, rg_depth=2, rg_repetitions=8, random_state=42).cuda().eval()
+    x = torch.randn(65536, 784, device='cuda', generator=torch.Generator('cuda').manual_seed(0))
+    x[12345] = float('nan')
+    with torch.no_grad():
+        ll = model(x)
+        part = model(x[1000:1000 + 4097])
+        acc = torch.zeros(2, dtype=torch.float64, device='cuda')
+        ll2 = model._forward_fused(x, acc)
+    assert torch.equal(ll[1000:1000 + 4097], part)
+    assert abs(ll[12345].item()) < 1e-5
+    assert torch.equal(ll, ll2)
+    assert acc[1].item() == 65536
+    assert abs(acc[0].item() - ll.double().sum().item()) <= 1e-9 * abs(acc[0].item())
