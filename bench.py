@@ -50,19 +50,31 @@ def cpu_baseline(model_state, D, n_samples):
     """Oracle timed on the host cores: chunks of 4096 (the reference materialises [B,R,I,d]
     temporaries), 1 warm-up chunk, all cores."""
     from oracle import ratspn_oracle as orc
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     chunk = 4096
     x = torch.randn(n_samples, D, generator=torch.Generator().manual_seed(0))
+    best = None
+    # PyTorch's intra-op pool does not scale to every core of a big host on these element-wise
+    # sweeps: probe a few pool sizes on one chunk and keep the fastest for the timed sample
     with torch.no_grad():
-        orc.ratspn_forward(model_state, x[:chunk])
+        for threads in sorted({ncpu, min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}):
+            torch.set_num_threads(threads)
+            orc.ratspn_forward(model_state, x[:chunk])
+            t0 = time.perf_counter()
+            orc.ratspn_forward(model_state, x[:chunk])
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[1]:
+                best = (threads, dt)
+        threads = best[0]
+        torch.set_num_threads(threads)
         t0 = time.perf_counter()
         for i in range(0, n_samples, chunk):
             orc.ratspn_forward(model_state, x[i:i + chunk])
         dt = time.perf_counter() - t0
-    return {'value': n_samples / dt, 'unit': 'log-likelihoods/sec', 'cores': cores, 'kind': 'port',
-            'sample': '{} samples of the same workload in chunks of {} ({:.1f} s), oracle/ratspn_oracle.py '
-                      '(op-for-op PyTorch-CPU restatement of the reference)'.format(n_samples, chunk, dt)}
+    return {'value': n_samples / dt, 'unit': 'log-likelihoods/sec', 'cores': threads, 'kind': 'port',
+            'sample': '{} samples of the same workload in chunks of {} ({:.1f} s) on {} of {} host threads '
+                      '(fastest of the probed pool sizes), oracle/ratspn_oracle.py = op-for-op PyTorch-CPU '
+                      'restatement of the reference'.format(n_samples, chunk, dt, threads, ncpu)}
 
 
 def read_traffic():
@@ -109,6 +121,9 @@ def main():
     time_kernel = not args.no_kernel_events
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps if time_kernel else 0)]
+    for a, b in ev:  # torch creates the hipEvent lazily at the first record: force the handles to exist
+        a.record()
+        b.record()
 
     def step(i, timed_idx=None):
         marks = ev[timed_idx] if (timed_idx is not None and time_kernel) else None

@@ -29,7 +29,7 @@ void profile_take(hipEvent_t *start, hipEvent_t *stop);  // one-shot measurement
     } while (0)
 
 constexpr int kWave = 64;           // CDNA wavefront
-constexpr int kChunk = 128;         // features staged in LDS per chunk (FC)
+constexpr int kChunk = 64;          // features staged in LDS per chunk (FC)
 constexpr int kLeafWaves = 8;       // waves per work-group of the leaf / fused kernels
 constexpr float kLogSqrt2Pi = 0.918938533204672741780329736406f;
 
@@ -38,29 +38,36 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Workspace carve-up shared by every RAT-SPN entry point.
 //
-// Every region's variable ids are sorted and cut into per-chunk segments (chunk c = features
-// [c*kChunk, (c+1)*kChunk)); each segment is padded to a multiple of kBlock entries with
-// neutral entries (fl = kChunk, the all-zero LDS row; parameters 0), so the kernels walk whole
-// blocks and never mask.  dP = padded entries per region.
+// Regions are handled in groups of QB consecutive regions (fused model: QB = 2^depth = one
+// repetition).  A group's table entries form ONE stream in the order its wave consumes them: for
+// chunk c (features [c*kChunk, (c+1)*kChunk)), for region slot q, the sorted variables of region
+// g*QB+q inside the chunk; every (c,q) segment is padded to a multiple of kBlock entries with neutral
+// entries (LDS row kChunk = all zeros, parameters 0).  SP = stream capacity per group.
 constexpr int kBlock = 4;
+constexpr int kTableSlack = 16;  // neutral entries the software-pipelined readers may run into
 struct RatWs {
     // structure tables (depend on mask / pad_mask only)
-    int *fl;      // [R*dP+slack] (feature id) % kChunk, kChunk for a neutral entry
-    int *src;     // [R*dP]   original position j of the entry, -1 for dummy / neutral entries
-    int *feat;    // [R*dP]   feature id, -1 for neutral entries
-    int *cb;      // [R*(NC+1)] first (padded) position of every chunk segment
+    int *fl1;     // [G*SP] LDS byte offset of the entry's row for 1 sample per lane
+    int *fl2;     //        ... for 2 samples per lane
+    int *srcr;    // [G*SP] r*d + j of the entry (position in loc/scale), -1 for dummy / neutral
+    int *feat;    // [G*SP] variable id, -1 for neutral entries
+    int *nblk;    // [G*NC*QB] blocks of every segment
+    int *segoff;  // [G*NC*QB] first stream position of every segment
     // parameter tables (rebuilt on every call)
-    float *par;   // [(R*dP+slack)*2I] {p0[I], p1[I]} per entry
-    float *cel;   // [(R*dP+slack)*I]  additive constant per entry
-    float *biasc; // [R*NC*I] per-chunk sum of cel
+    float *par;   // [G*ncb*SP*2CB] {p0[CB], p1[CB]} per entry, channel-block major
+    float *cel;   // [G*ncb*SP*CB]  additive constant per entry
+    float *biasc; // [R*NC*I] per-(region, chunk) sum of cel
+    int *unit;    // [R] 1 if every scale of the region equals 1 (Gaussian leaves)
     float *w[3];  // linear softmax weights: sum layer 0, sum layer 1, root
     float *lw[3]; // log-softmax weights
     int64_t bytes;
-    int NC, dP;
+    int NC, SP, G, QB;
 };
-constexpr int kTableSlack = 16;  // entries the software-pipelined readers may run past the end
 
-inline RatWs carve_ratspn_ws(void *base, int D, int R, int d, int I, int depth, int reps, int S,
+// region-group size used by the per-layer leaf operators (the fused model uses 2^depth)
+static inline int leaf_group(int R) { return (R % 4 == 0) ? 4 : 2; }
+
+inline RatWs carve_ratspn_ws(void *base, int D, int R, int d, int I, int QB, int depth, int reps, int S,
                              int C) {
     RatWs w{};
     char *p = (char *)base;
@@ -72,15 +79,20 @@ inline RatWs carve_ratspn_ws(void *base, int D, int R, int d, int I, int depth, 
     };
     const int NC = cdiv(D, kChunk);
     w.NC = NC;
-    w.dP = (int)align_up(d + (kBlock - 1) * NC, kBlock);
-    const int64_t Rd = (int64_t)R * w.dP + kTableSlack;
-    w.fl = (int *)take(Rd * 4);
-    w.src = (int *)take(Rd * 4);
-    w.feat = (int *)take(Rd * 4);
-    w.cb = (int *)take((int64_t)R * (NC + 1) * 4);
-    w.par = (float *)take(Rd * 2 * I * 4);
-    w.cel = (float *)take(Rd * I * 4);
+    w.QB = QB;
+    w.G = R / QB;
+    w.SP = (int)align_up((int64_t)QB * d + (kBlock - 1) * QB * NC, kBlock) + kTableSlack;
+    const int64_t GS = (int64_t)w.G * w.SP;
+    w.fl1 = (int *)take(GS * 4);
+    w.fl2 = (int *)take(GS * 4);
+    w.srcr = (int *)take(GS * 4);
+    w.feat = (int *)take(GS * 4);
+    w.nblk = (int *)take((int64_t)w.G * NC * QB * 4);
+    w.segoff = (int *)take((int64_t)w.G * NC * QB * 4);
+    w.par = (float *)take(GS * 2 * I * 4);
+    w.cel = (float *)take(GS * I * 4);
     w.biasc = (float *)take((int64_t)R * NC * I * 4);
+    w.unit = (int *)take((int64_t)R * 4);
     // sum layers (only meaningful for the fused model entry point)
     int64_t n0 = 0, n1 = 0, nr = 0;
     if (depth >= 1 && reps >= 1) {

@@ -37,72 +37,83 @@ template <typename T> __host__ __device__ __forceinline__ const DPK_CONST T *as_
 // reference: RegionGraphLayer.__init__ mask / pad_mask, deeprob/spn/layers/ratspn.py:42-56
 // --------------------------------------------------------------------------------------
 __global__ void ratspn_struct_kernel(const int64_t *__restrict__ mask,
-                                     const uint8_t *__restrict__ pad, int R, int d, int NC, int dP,
-                                     int *__restrict__ fl, int *__restrict__ src,
-                                     int *__restrict__ feat, int *__restrict__ cb) {
+                                     const uint8_t *__restrict__ pad, int R, int d, int NC, int QB, int SP,
+                                     int *__restrict__ fl1, int *__restrict__ fl2,
+                                     int *__restrict__ srcr, int *__restrict__ feat,
+                                     int *__restrict__ nblk, int *__restrict__ segoff_out) {
+    // One block per group g of QB consecutive regions (for the fused model: one repetition).
+    // The group's entries are laid out in CONSUMPTION order of the wave that owns it:
+    //   for chunk c: for region slot q: the variables of region g*QB+q that fall in chunk c,
+    // every (c,q) segment padded to a multiple of kBlock with neutral entries.  One contiguous
+    // stream per group lets the software pipeline run across segment and chunk boundaries.
     extern __shared__ int sm_i[];
-    int *ids = sm_i;            // [d]
-    int *sid = ids + d;         // [d] sorted ids
-    int *ssrc = sid + d;        // [d] original position (or -1) of the sorted entry
-    int *lo = ssrc + d;         // [NC+1] first sorted position of every chunk
-    int *ps = lo + NC + 1;      // [NC+1] first padded position of every chunk
-    const int r = blockIdx.x;
-    for (int j = threadIdx.x; j < d; j += blockDim.x) ids[j] = (int)mask[(int64_t)r * d + j];
-    __syncthreads();
-    for (int j = threadIdx.x; j < d; j += blockDim.x) {
-        const int key = ids[j];
+    int *sid = sm_i;                    // [QB*d] sorted ids per region
+    int *ssrc = sid + QB * d;           // [QB*d] r*d + j of the sorted entry, -1 for a dummy variable
+    int *lo = ssrc + QB * d;            // [QB*(NC+1)] first sorted position of every chunk
+    int *segoff = lo + QB * (NC + 1);   // [NC*QB+1] first stream position of every segment
+    const int g = blockIdx.x;
+    for (int e = threadIdx.x; e < QB * d; e += blockDim.x) {
+        const int q = e / d, j = e - q * d;
+        const int r = g * QB + q;
+        const int64_t *row = mask + (int64_t)r * d;
+        const int key = (int)row[j];
         int rank = 0;
         for (int jj = 0; jj < d; ++jj) {
-            const int kk = ids[jj];
+            const int kk = (int)row[jj];
             rank += (kk < key) || (kk == key && jj < j);
         }
-        sid[rank] = key;
-        ssrc[rank] = (pad != nullptr && pad[(int64_t)r * d + j]) ? -1 : j;
+        sid[q * d + rank] = key;
+        ssrc[q * d + rank] = (pad != nullptr && pad[(int64_t)r * d + j]) ? -1 : r * d + j;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c <= NC; c += blockDim.x) {
+    for (int e = threadIdx.x; e < QB * (NC + 1); e += blockDim.x) {
+        const int q = e / (NC + 1), c = e - q * (NC + 1);
         const int lim = c * kChunk;
-        int l = 0, h = d;  // first position with sid[pos] >= lim
+        int l = 0, h = d;  // first position with sid[q][pos] >= lim
         while (l < h) {
             const int mid = (l + h) >> 1;
-            if (sid[mid] < lim) l = mid + 1; else h = mid;
+            if (sid[q * d + mid] < lim) l = mid + 1; else h = mid;
         }
-        lo[c] = l;
+        lo[e] = l;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int c = 0; c <= NC; ++c) {
-            ps[c] = acc;
-            cb[r * (NC + 1) + c] = acc;
-            if (c < NC) acc += (lo[c + 1] - lo[c] + kBlock - 1) / kBlock * kBlock;
-        }
+        int run = 0;
+        for (int c = 0; c < NC; ++c)
+            for (int q = 0; q < QB; ++q) {
+                const int n = lo[q * (NC + 1) + c + 1] - lo[q * (NC + 1) + c];
+                const int nb = (n + kBlock - 1) / kBlock;
+                segoff[c * QB + q] = run;
+                nblk[((int64_t)g * NC + c) * QB + q] = nb;
+                segoff_out[((int64_t)g * NC + c) * QB + q] = run;
+                run += nb * kBlock;
+            }
+        segoff[NC * QB] = run;
     }
     __syncthreads();
-    for (int q = threadIdx.x; q < dP; q += blockDim.x) {
-        int c = 0;
-        while (c + 1 <= NC && ps[c + 1] <= q) ++c;  // segment holding padded position q
+    const int total = segoff[NC * QB];
+    for (int p = threadIdx.x; p < SP; p += blockDim.x) {
         int f = -1, sj = -1, l = kChunk;
-        if (c < NC) {
-            const int p = lo[c] + (q - ps[c]);
-            if (p < lo[c + 1]) {
-                f = sid[p];
-                sj = ssrc[p];
+        if (p < total) {
+            int s0 = 0, s1 = NC * QB;  // last segment with segoff[s] <= p
+            while (s1 - s0 > 1) {
+                const int mid = (s0 + s1) >> 1;
+                if (segoff[mid] <= p) s0 = mid; else s1 = mid;
+            }
+            const int c = s0 / QB, q = s0 - c * QB;
+            const int idx = lo[q * (NC + 1) + c] + (p - segoff[s0]);
+            if (idx < lo[q * (NC + 1) + c + 1]) {
+                f = sid[q * d + idx];
+                sj = ssrc[q * d + idx];
                 l = f % kChunk;
             }
         }
-        const int64_t o = (int64_t)r * dP + q;
+        const int64_t o = (int64_t)g * SP + p;
         feat[o] = f;
-        src[o] = sj;
-        fl[o] = l;
+        srcr[o] = sj;
+        fl1[o] = l * 65 * 4;   // TileGeom<1>::ROWB
+        fl2[o] = l * 130 * 4;  // TileGeom<2>::ROWB
     }
-    if (r == 0)  // slack behind the last region: neutral entries
-        for (int q = threadIdx.x; q < kTableSlack; q += blockDim.x) {
-            const int64_t o = (int64_t)R * dP + q;
-            feat[o] = -1;
-            src[o] = -1;
-            fl[o] = kChunk;
-        }
 }
 
 // --------------------------------------------------------------------------------------
@@ -113,20 +124,27 @@ __global__ void ratspn_struct_kernel(const int64_t *__restrict__ mask,
 // --------------------------------------------------------------------------------------
 template <int DIST>
 __global__ void leaf_param_kernel(const float *__restrict__ p0, const float *__restrict__ p1,
-                                  const int *__restrict__ src, const int *__restrict__ cb, int R,
-                                  int I, int d, int dP, int NC, float *__restrict__ par,
-                                  float *__restrict__ cel, float *__restrict__ biasc) {
-    const int r = blockIdx.x;
-    const int n_ent = dP + (r == R - 1 ? kTableSlack : 0);
-    const int n = n_ent * I;
-    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+                                  const int *__restrict__ srcr, const int *__restrict__ nblk,
+                                  const int *__restrict__ segoff, int R, int I, int CB, int d, int NC, int QB,
+                                  int SP, float *__restrict__ par, float *__restrict__ cel,
+                                  float *__restrict__ biasc, int *__restrict__ unit) {
+    // table layout: [group][channel block][stream position]{p0[CB], p1[CB]}: the kBlock entries of a
+    // block are one contiguous run for the wave that owns (group, channel block)
+    __shared__ int not_unit[8];
+    const int g = blockIdx.x;
+    const int ncb = I / CB;
+    if (threadIdx.x < 8) not_unit[threadIdx.x] = (DIST != 0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < SP * I; e += blockDim.x) {
         const int pidx = e / I, k = e - pidx * I;
-        const int j = src[(int64_t)r * dP + pidx];
+        const int rj = srcr[(int64_t)g * SP + pidx];
         float A = 0.f, Bv = 0.f, Cc = 0.f;
-        if (j >= 0) {
+        if (rj >= 0) {
+            const int r = rj / d, j = rj - r * d;
             const int64_t o = ((int64_t)r * I + k) * d + j;
             if (DIST == 0) {
                 const float mu = p0[o], sg = p1[o];
+                if (sg != 1.0f) not_unit[r - g * QB] = 1;
                 A = mu;
                 Bv = -0.5f / (sg * sg);
                 Cc = -logf(sg) - kLogSqrt2Pi;
@@ -136,18 +154,23 @@ __global__ void leaf_param_kernel(const float *__restrict__ p0, const float *__r
                 Cc = -(fmaxf(l, 0.f) + log1pf(expf(-fabsf(l))));
             }
         }
-        const int64_t po = ((int64_t)r * dP + pidx) * 2 * I;
-        par[po + k] = A;
-        par[po + I + k] = Bv;
-        cel[((int64_t)r * dP + pidx) * I + k] = Cc;
+        const int kbi = k / CB, kk = k - kbi * CB;
+        const int64_t ent = ((int64_t)g * ncb + kbi) * SP + pidx;
+        par[ent * 2 * CB + kk] = A;
+        par[ent * 2 * CB + CB + kk] = Bv;
+        cel[ent * CB + kk] = Cc;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < NC * I; e += blockDim.x) {
-        const int c = e / I, k = e - c * I;
-        const int j0 = cb[r * (NC + 1) + c], j1 = cb[r * (NC + 1) + c + 1];
+    if (threadIdx.x < QB) unit[g * QB + threadIdx.x] = !not_unit[threadIdx.x];
+    for (int e = threadIdx.x; e < NC * QB * I; e += blockDim.x) {
+        const int k = e % I, cq = e / I;
+        const int c = cq / QB, q = cq - c * QB;
+        const int kbi = k / CB, kk = k - kbi * CB;
+        const int64_t so = ((int64_t)g * NC + c) * QB + q;
+        const int j0 = segoff[so], j1 = j0 + nblk[so] * kBlock;
         float s = 0.f;
-        for (int p = j0; p < j1; ++p) s += cel[((int64_t)r * dP + p) * I + k];
-        biasc[((int64_t)r * NC + c) * I + k] = s;
+        for (int p = j0; p < j1; ++p) s += cel[(((int64_t)g * ncb + kbi) * SP + p) * CB + kk];
+        biasc[((int64_t)(g * QB + q) * NC + c) * I + k] = s;
     }
 }
 
@@ -277,12 +300,13 @@ __device__ __forceinline__ void root_partial(const float (&a)[NI], const float (
 struct LeafArgs {
     const float *x;
     int64_t B;
-    int D, R, I, d, NC, dP;
-    cint_p fl;
-    cint_p cb;
+    int D, R, I, d, NC, SP;
+    cint_p fl1, fl2;  // LDS byte offsets of the rows for SPL = 1 / 2
+    cint_p nblk;      // [G][NC][QB] blocks per segment
     cfloat_p par;
     cfloat_p cel;
     cfloat_p biasc;
+    cint_p unit;      // [R] 1 if every scale of the region is exactly 1
     float *leaf_out;  // [B,R,I] or nullptr
     // fused model
     int reps, C;
@@ -306,118 +330,269 @@ template <int SPL> struct XVec;
 template <> struct XVec<1> { using type = float; };
 template <> struct XVec<2> { using type = float2; };
 
+// Work-group barrier that orders LDS traffic only: lgkmcnt(0) + s_barrier.  __syncthreads()
+// carries a release fence that also waits vmcnt(0), which would stall every wave on the HBM
+// prefetch of the NEXT chunk that is deliberately in flight across the barrier.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // lgkmcnt(0) with vmcnt / expcnt left alone (gfx9 encoding: vmcnt 0x3f, expcnt 7, lgkmcnt 0)
 #define DPK_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
 
-// One block of kBlock table entries: parameters (SGPRs) and the x values (VGPRs).
-template <int CB, int SPL, bool SLOW> struct LeafBlock {
-    float p0[kBlock][CB], p1[kBlock][CB], pc[SLOW ? kBlock : 1][CB];
-    float x[kBlock][SPL];
-};
+// DPK_ABLATE (measurement builds only, never shipped): 1 = constant parameters, 2 = constant
+// parameters and row offsets (no SMEM in the inner loop), 3 = no LDS reads, 4 = no HBM staging
+#ifndef DPK_ABLATE
+#define DPK_ABLATE 0
+#endif
 
-__device__ __forceinline__ void leaf_load_off(int (&off)[kBlock], cint_p flp, int j, int rowb) {
-#pragma unroll
-    for (int u = 0; u < kBlock; ++u) off[u] = flp[j + u] * rowb;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Scalar-memory loads issued as inline asm.  The compiler schedules a C++ load "as late as
+// legal" and, with SMEM (out-of-order return) in flight, turns every wait into lgkmcnt(0) right
+// behind the issue; hand-issued loads plus ONE explicit lgkmcnt(0) at the end of each pipeline
+// step keep a full step of VALU work between issue and use.  hipcc does not count these loads
+// (cdna_hip_programming.md 5.7): every destination is consumed only behind DPK_WAIT_LGKM0().
+template <int OFF> __device__ __forceinline__ i32x4 sload_i4(cint_p p) {
+    i32x4 r;
+    if (DPK_ABLATE == 2) return (i32x4){0, 520, 1040, 1560};
+    asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(r) : "s"(p), "i"(OFF) : "memory");
+    return r;
 }
-template <int CB, int SPL, bool SLOW>
-__device__ __forceinline__ void leaf_load_par(LeafBlock<CB, SPL, SLOW> &blk, cfloat_p pp, cfloat_p cp,
-                                              int I, int j) {
-#pragma unroll
-    for (int u = 0; u < kBlock; ++u) {
-        cfloat_p pr = pp + (int64_t)(j + u) * 2 * I;
-#pragma unroll
-        for (int k = 0; k < CB; ++k) {
-            blk.p0[u][k] = pr[k];
-            blk.p1[u][k] = pr[I + k];
-            if (SLOW) blk.pc[u][k] = cp[(int64_t)(j + u) * I + k];
-        }
+template <int NDW> struct SVec;
+template <> struct SVec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct SVec<4> { typedef f32x4 type; };
+template <> struct SVec<8> { typedef f32x8 type; };
+template <> struct SVec<16> { typedef f32x16 type; };
+template <int NDW, int OFF> __device__ __forceinline__ typename SVec<NDW>::type sload_f(cfloat_p p) {
+    typename SVec<NDW>::type r;
+    if constexpr (NDW == 2) asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(r) : "s"(p), "i"(OFF) : "memory");
+    if constexpr (NDW == 4) asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(r) : "s"(p), "i"(OFF) : "memory");
+    if constexpr (NDW == 8) asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(r) : "s"(p), "i"(OFF) : "memory");
+    if constexpr (NDW == 16) asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(r) : "s"(p), "i"(OFF) : "memory");
+    return r;
+}
+
+// One block of kBlock table entries.  Parameters of the block are one contiguous run of
+// kBlock*2*CB dwords ({p0[CB], p1[CB]} per entry) fetched in pieces of at most 16 dwords.
+template <int CB> struct ParBlock {
+    static constexpr int NDW = kBlock * 2 * CB;           // 8, 16, 32, 64
+    static constexpr int PIECE = NDW < 16 ? NDW : 16;
+    static constexpr int NP = NDW / PIECE;
+    typename SVec<PIECE>::type v[NP];
+    __device__ __forceinline__ float get(int i) const { return v[i / PIECE][i % PIECE]; }
+    __device__ __forceinline__ float p0(int u, int k) const { return get(u * 2 * CB + k); }
+    __device__ __forceinline__ float p1(int u, int k) const { return get(u * 2 * CB + CB + k); }
+};
+template <int CB, int PIDX = 0>
+__device__ __forceinline__ void par_load(ParBlock<CB> &b, cfloat_p pp) {
+    if (DPK_ABLATE == 1 || DPK_ABLATE == 2) return;
+    if constexpr (PIDX < ParBlock<CB>::NP) {
+        b.v[PIDX] = sload_f<ParBlock<CB>::PIECE, PIDX * ParBlock<CB>::PIECE * 4>(pp);
+        par_load<CB, PIDX + 1>(b, pp);
     }
 }
-template <int CB, int SPL, bool SLOW>
-__device__ __forceinline__ void leaf_read_x(LeafBlock<CB, SPL, SLOW> &blk, const char *lane_base,
-                                            const int (&off)[kBlock]) {
+// additive constants of the block (exact path only): kBlock*CB dwords
+template <int CB> struct CelBlock {
+    static constexpr int NDW = kBlock * CB;               // 4, 8, 16, 32
+    static constexpr int PIECE = NDW < 16 ? NDW : 16;
+    static constexpr int NP = NDW / PIECE;
+    typename SVec<PIECE>::type v[NP];
+    __device__ __forceinline__ float pc(int u, int k) const { return v[(u * CB + k) / PIECE][(u * CB + k) % PIECE]; }
+};
+template <int CB, int PIDX = 0>
+__device__ __forceinline__ void cel_load(CelBlock<CB> &b, cfloat_p cp) {
+    if constexpr (PIDX < CelBlock<CB>::NP) {
+        b.v[PIDX] = sload_f<CelBlock<CB>::PIECE, PIDX * CelBlock<CB>::PIECE * 4>(cp);
+        cel_load<CB, PIDX + 1>(b, cp);
+    }
+}
+
+// Make the accumulators opaque at this point: the FMAs that produce them cannot be sunk below
+// (IR-level code motion would otherwise carry a whole block of compute across the wait that
+// follows and expose the load latency again).
+template <int CB, int SPL> __device__ __forceinline__ void pin_acc(float (&acc)[CB][SPL]) {
+#pragma unroll
+    for (int k = 0; k < CB; ++k)
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) asm volatile("" : "+v"(acc[k][s]));
+}
+
+template <int SPL>
+__device__ __forceinline__ void leaf_read_x(float (&x)[kBlock][SPL], const char *lane_base, const i32x4 off) {
 #pragma unroll
     for (int u = 0; u < kBlock; ++u) {
+        if (DPK_ABLATE == 3) {
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) x[u][s] = __int_as_float(off[u] + s);
+            continue;
+        }
         if (SPL == 2) {
             const float2 v = *reinterpret_cast<const float2 *>(lane_base + off[u]);
-            blk.x[u][0] = v.x;
-            blk.x[u][SPL - 1] = v.y;
+            x[u][0] = v.x;
+            x[u][SPL - 1] = v.y;
         } else {
-            blk.x[u][0] = *reinterpret_cast<const float *>(lane_base + off[u]);
+            x[u][0] = *reinterpret_cast<const float *>(lane_base + off[u]);
         }
     }
 }
-template <int DIST, int CB, int SPL, bool SLOW>
-__device__ __forceinline__ void leaf_block_compute(float (&acc)[CB][SPL],
-                                                   const LeafBlock<CB, SPL, SLOW> &blk) {
+
+// MODE 0: finite inputs, acc += a (x-mu)^2            (3 VALU / element)
+// MODE 1: exact per-element form with nan_to_num (NaN / inf evidence in the chunk)
+// MODE 2: finite inputs and sigma == 1 for the whole region, acc += (x-mu)^2 (2 VALU / element;
+//         the caller scales by -1/2 once per chunk)
+template <int DIST, int CB, int SPL, int MODE>
+__device__ __forceinline__ void leaf_block_compute(float (&acc)[CB][SPL], const float (&x)[kBlock][SPL],
+                                                   const ParBlock<CB> &par, const CelBlock<CB> &cel) {
+    constexpr bool SLOW = (MODE == 1);
 #pragma unroll
     for (int u = 0; u < kBlock; ++u)
 #pragma unroll
-        for (int k = 0; k < CB; ++k)
+        for (int k = 0; k < CB; ++k) {
+            const float p0 = (DPK_ABLATE == 1 || DPK_ABLATE == 2) ? 0.25f * (float)(k + 1) : par.p0(u, k);
+            const float p1 = (DPK_ABLATE == 1 || DPK_ABLATE == 2) ? -0.5f : par.p1(u, k);
 #pragma unroll
             for (int s = 0; s < SPL; ++s) {
                 if (DIST == 0) {
-                    const float dlt = blk.x[u][s] - blk.p0[u][k];
-                    if (!SLOW) acc[k][s] = fmaf(dlt * dlt, blk.p1[u][k], acc[k][s]);
-                    else acc[k][s] += nan_to_num_f(fmaf(dlt * dlt, blk.p1[u][k], blk.pc[u][k]));
+                    const float dlt = x[u][s] - p0;
+                    if (MODE == 2) acc[k][s] = fmaf(dlt, dlt, acc[k][s]);
+                    else if (!SLOW) acc[k][s] = fmaf(dlt * dlt, p1, acc[k][s]);
+                    else acc[k][s] += nan_to_num_f(fmaf(dlt * dlt, p1, cel.pc(u, k)));
                 } else {
-                    if (!SLOW) acc[k][s] = fmaf(blk.x[u][s], blk.p0[u][k], acc[k][s]);
-                    else acc[k][s] += nan_to_num_f(fmaf(blk.x[u][s], blk.p0[u][k], blk.pc[u][k]));
+                    if (!SLOW) acc[k][s] = fmaf(x[u][s], p0, acc[k][s]);
+                    else acc[k][s] += nan_to_num_f(fmaf(x[u][s], p0, cel.pc(u, k)));
                 }
             }
+        }
 }
 
-// Accumulate the table entries [j0, j1) (a multiple of kBlock) of one region over the chunk
-// held in LDS.  Software-pipelined by hand over two register sets: while block b is consumed,
-// the x reads and parameters of block b+1 and the row offsets of block b+2 are in flight.  The
-// single lgkmcnt(0) sits at the END of each step: SMEM returns out of order, so a wait placed
-// at first use (what the compiler would do) drains the loads it has just issued.
-template <int DIST, int CB, int SPL, bool SLOW>
-__device__ __forceinline__ void leaf_accum(float (&acc)[CB][SPL], const char *lane_base, cint_p flp,
-                                           cfloat_p pp, cfloat_p cp, int I, int j0, int j1) {
-    constexpr int ROWB = TileGeom<SPL>::ROWB;
-    if (j0 >= j1) return;
-    LeafBlock<CB, SPL, SLOW> A, Bk;
-    int off[kBlock];
-    leaf_load_off(off, flp, j0, ROWB);
-    leaf_load_par<CB, SPL, SLOW>(A, pp, cp, I, j0);
-    DPK_WAIT_LGKM0();
-    leaf_read_x<CB, SPL, SLOW>(A, lane_base, off);
-    __builtin_amdgcn_sched_barrier(0);
-    leaf_load_off(off, flp, j0 + kBlock, ROWB);
-    DPK_WAIT_LGKM0();
-    __builtin_amdgcn_sched_barrier(0);
-    for (int j = j0;; j += 2 * kBlock) {
-        leaf_read_x<CB, SPL, SLOW>(Bk, lane_base, off);
-        __builtin_amdgcn_sched_barrier(0);
-        leaf_load_off(off, flp, j + 2 * kBlock, ROWB);
-        leaf_load_par<CB, SPL, SLOW>(Bk, pp, cp, I, j + kBlock);
-        __builtin_amdgcn_sched_barrier(0);
-        leaf_block_compute<DIST, CB, SPL, SLOW>(acc, A);
-        DPK_WAIT_LGKM0();
-        __builtin_amdgcn_sched_barrier(0);
-        if (j + kBlock >= j1) break;
-        leaf_read_x<CB, SPL, SLOW>(A, lane_base, off);
-        __builtin_amdgcn_sched_barrier(0);
-        leaf_load_off(off, flp, j + 3 * kBlock, ROWB);
-        leaf_load_par<CB, SPL, SLOW>(A, pp, cp, I, j + 2 * kBlock);
-        __builtin_amdgcn_sched_barrier(0);
-        leaf_block_compute<DIST, CB, SPL, SLOW>(acc, Bk);
-        DPK_WAIT_LGKM0();
-        __builtin_amdgcn_sched_barrier(0);
-        if (j + 2 * kBlock >= j1) break;
+// Accumulate `nblk` blocks of table entries of one region over the chunk held in LDS.
+// flp: byte offsets of the LDS rows (premultiplied), pp / cp: parameters / constants, all
+// advancing by one block per step.  Software-pipelined over two register sets: while block b is
+// consumed, the x reads + parameters of block b+1 and the row offsets of block b+2 are in flight;
+// the only wait is the explicit lgkmcnt(0) that ends each step.
+// Plain version: compiler-issued scalar loads, one block at a time.  Used for the exact (NaN / inf)
+// path and for wide channel blocks, whose parameter sets do not fit twice in the SGPR file (the
+// hand-pipelined version below would make the register allocator spill SGPRs that an asm load is
+// still writing).
+template <int DIST, int CB, int SPL, int MODE>
+__device__ __forceinline__ void leaf_accum_plain(float (&acc)[CB][SPL], const char *lane_base, cint_p flp,
+                                                 cfloat_p pp, cfloat_p cp, int nblk) {
+    constexpr bool SLOW = (MODE == 1);
+    for (int b = 0; b < nblk; ++b) {
+        float x[kBlock][SPL];
+        i32x4 off;
+#pragma unroll
+        for (int u = 0; u < kBlock; ++u) off[u] = flp[u];
+        leaf_read_x<SPL>(x, lane_base, off);
+#pragma unroll
+        for (int u = 0; u < kBlock; ++u)
+#pragma unroll
+            for (int k = 0; k < CB; ++k) {
+                const float p0 = pp[u * 2 * CB + k];
+                const float p1 = pp[u * 2 * CB + CB + k];
+                const float pc = SLOW ? cp[u * CB + k] : 0.f;
+#pragma unroll
+                for (int s = 0; s < SPL; ++s) {
+                    if (DIST == 0) {
+                        const float dlt = x[u][s] - p0;
+                        if (MODE == 2) acc[k][s] = fmaf(dlt, dlt, acc[k][s]);
+                        else if (!SLOW) acc[k][s] = fmaf(dlt * dlt, p1, acc[k][s]);
+                        else acc[k][s] += nan_to_num_f(fmaf(dlt * dlt, p1, pc));
+                    } else {
+                        if (!SLOW) acc[k][s] = fmaf(x[u][s], p0, acc[k][s]);
+                        else acc[k][s] += nan_to_num_f(fmaf(x[u][s], p0, pc));
+                    }
+                }
+            }
+        flp += kBlock;
+        pp += kBlock * 2 * CB;
+        cp += kBlock * CB;
     }
 }
 
+// Software pipeline over one group's entry stream (CB <= 2).  It lives across segments and chunks:
+//   cur set (x, parameters) = block B, complete;  offn = row offsets of block B+1, complete;
+//   flp -> offsets of block B+2;  pp -> parameters of block B+1;  offc = row offsets of block B.
+// A step issues the x reads and parameters of B+1 and the offsets of B+2, consumes B, then drains
+// with ONE lgkmcnt(0).  Two register sets alternate (`sel`), so nothing is copied.
+template <int CB, int SPL> struct LeafPipe {
+    ParBlock<CB> par[2];
+    float x[2][kBlock][SPL];
+    i32x4 offc, offn;
+    cint_p flp;
+    cfloat_p pp;
+
+    __device__ __forceinline__ void prime(cint_p fl, cfloat_p par_base, int pos) {
+        offc = sload_i4<0>(fl + pos);
+        offn = sload_i4<kBlock * 4>(fl + pos);
+        par_load<CB>(par[0], par_base + (int64_t)pos * 2 * CB);
+        DPK_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        flp = fl + pos + 2 * kBlock;
+        pp = par_base + (int64_t)(pos + kBlock) * 2 * CB;
+    }
+    // the chunk in LDS changed: (re)read the x values of the current block (always set 0 between
+    // segments)
+    __device__ __forceinline__ void reread(const char *lane_base) {
+        leaf_read_x<SPL>(x[0], lane_base, offc);
+        DPK_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <int DIST, int MODE, int CUR>
+    __device__ __forceinline__ void step(float (&acc)[CB][SPL], const char *lane_base) {
+        constexpr int OTH = 1 - CUR;
+        const CelBlock<CB> nocel{};
+        leaf_read_x<SPL>(x[OTH], lane_base, offn);
+        offc = offn;
+        offn = sload_i4<0>(flp);
+        par_load<CB>(par[OTH], pp);
+        __builtin_amdgcn_sched_barrier(0);
+        leaf_block_compute<DIST, CB, SPL, MODE>(acc, x[CUR], par[CUR], nocel);
+        pin_acc<CB, SPL>(acc);
+        DPK_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        flp += kBlock;
+        pp += kBlock * 2 * CB;
+    }
+    // nb blocks into acc.  Sets alternate statically inside the loop; an odd count ends with the
+    // live block in set 1, which is then moved to set 0 (24 register moves per odd segment) so that
+    // every segment starts from the same state and no set index is ever a run-time value.
+    template <int DIST, int MODE>
+    __device__ __forceinline__ void run(float (&acc)[CB][SPL], const char *lane_base, int nb) {
+        for (int i = nb >> 1; i > 0; --i) {
+            step<DIST, MODE, 0>(acc, lane_base);
+            step<DIST, MODE, 1>(acc, lane_base);
+        }
+        if (nb & 1) {
+            step<DIST, MODE, 0>(acc, lane_base);
+            par[0] = par[1];
+#pragma unroll
+            for (int u = 0; u < kBlock; ++u)
+#pragma unroll
+                for (int s = 0; s < SPL; ++s) x[0][u][s] = x[1][u][s];
+        }
+    }
+};
+
 // DEPTH == 0: leaf only (QB regions x CB channels per wave item, written to leaf_out)
 // DEPTH >= 1: fused model, QB == 2^DEPTH, CB == I, S sum nodes
+#ifdef DPK_FORCE_SPL1
+#define DPK_MINW(SPL) 8
+#else
+#define DPK_MINW(SPL) 4
+#endif
 template <int DIST, int QB, int CB, int SPL, int DEPTH, int S>
-__global__ __launch_bounds__(kLeafWaves * 64, 4) void ratspn_leaf_kernel(const LeafArgs a) {
+__global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_kernel(const LeafArgs a) {
     using G = TileGeom<SPL>;
     constexpr int T = G::T, ROW = G::ROW, NLD = G::NLD;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *xs_lds = reinterpret_cast<float *>(smem);
-    float *run_m = reinterpret_cast<float *>(smem + G::BUF_BYTES);  // [C][T] fused only
+    int *flags_lds = reinterpret_cast<int *>(smem + G::BUF_BYTES);  // [waves]
+    float *run_m = reinterpret_cast<float *>(smem + G::BUF_BYTES + 64);  // [C][T] fused only
     float *run_s = run_m + (DEPTH > 0 ? a.C * T : 0);
 
     const int tid = threadIdx.x;
@@ -425,10 +600,10 @@ __global__ __launch_bounds__(kLeafWaves * 64, 4) void ratspn_leaf_kernel(const L
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t b0 = (int64_t)blockIdx.x * T;
     const int I = (DEPTH > 0) ? CB : a.I;  // static in the fused kernels
-    const int R = a.R, dP = a.dP, NC = a.NC, D = a.D;
+    const int R = a.R, NC = a.NC, D = a.D;
 
     const int n_cblk = (DEPTH > 0) ? 1 : I / CB;
-    const int n_items = (DEPTH > 0) ? a.reps : ((R + QB - 1) / QB) * n_cblk;
+    const int n_items = (DEPTH > 0) ? a.reps : (R / QB) * n_cblk;
     const int n_pass = (n_items + kLeafWaves - 1) / kLeafWaves;
 
     const char *lane_base = smem + lane * (4 * SPL);
@@ -460,8 +635,9 @@ __global__ __launch_bounds__(kLeafWaves * 64, 4) void ratspn_leaf_kernel(const L
         // s_i = 4*i + sq, so a wave reads 64 consecutive floats of one row (coalesced) and the
         // LDS image [feature][sample] is written at a compile-time stride.
         float pre[NLD];
+        constexpr int SQN = kLeafWaves * 64 / kChunk;  // samples staged per pass of the work-group
         const int flc = tid & (kChunk - 1);
-        const int sq = tid >> 7;
+        const int sq = tid / kChunk;
         const bool full_tile = (b0 + T <= a.B);
         const float *xt = a.x + b0 * D;
         auto load_chunk = [&](int c) {
@@ -469,55 +645,116 @@ __global__ __launch_bounds__(kLeafWaves * 64, 4) void ratspn_leaf_kernel(const L
             // NLD loop-invariant 64-bit addresses out of the chunk loop (and spilling them)
             int vo = sq * D + flc;
             asm volatile("" : "+v"(vo));
-            if (full_tile && (c + 1) * kChunk <= D) {
+            if (DPK_ABLATE == 4) {
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) pre[i] = (float)(vo + i);
+            } else if (full_tile && (c + 1) * kChunk <= D) {
                 const float *xc = xt + c * kChunk;
 #pragma unroll
-                for (int i = 0; i < NLD; ++i) pre[i] = (xc + (int64_t)i * 4 * D)[vo];
+                for (int i = 0; i < NLD; ++i) pre[i] = (xc + (int64_t)i * SQN * D)[vo];
             } else {  // ragged tile / last chunk: clamp (clamped slots are never consumed)
                 const int f = min(c * kChunk + flc, D - 1);
                 int sqv = sq;
                 asm volatile("" : "+v"(sqv));
                 const int nv1 = (int)min((int64_t)T, a.B - b0) - 1;
 #pragma unroll
-                for (int i = 0; i < NLD; ++i) pre[i] = xt[min(4 * i + sqv, nv1) * D + f];
+                for (int i = 0; i < NLD; ++i) pre[i] = xt[min(SQN * i + sqv, nv1) * D + f];
             }
         };
         load_chunk(0);
 
+        // this wave's entry stream (consumption order, see ratspn_struct_kernel)
+        constexpr bool kPipelined = (CB <= 2);
+        cint_p fl_g = (SPL == 2 ? a.fl2 : a.fl1) + (int64_t)g * a.SP;
+        cfloat_p par_g = a.par + ((int64_t)g * n_cblk + kb / CB) * a.SP * 2 * CB;
+        cfloat_p cel_g = a.cel + ((int64_t)g * n_cblk + kb / CB) * a.SP * CB;
+        LeafPipe<(kPipelined ? CB : 1), SPL> pipe;
+        bool primed = false;
+        int pos = 0;
+
         for (int c = 0; c < NC; ++c) {
-            __syncthreads();  // every wave is done with the previous chunk
+            lds_barrier();  // every wave is done with the previous chunk
             float chk = 0.f;
             float *wr = xs_lds + flc * ROW + (SPL == 2 ? 2 * sq : sq);
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const float v = pre[i];
                 chk = fmaf(v, 0.f, chk);  // NaN iff v is NaN or +-inf
-                const int pos = (SPL == 2) ? ((i < 16) ? 8 * i : 8 * (i - 16) + 1) : 4 * i;
+                constexpr int H = 64 / SQN;  // passes covering the first 64 samples of the tile
+                const int pos = (SPL == 2) ? ((i < H) ? 2 * SQN * i : 2 * SQN * (i - H) + 1) : SQN * i;
                 wr[pos] = v;
             }
             if (c + 1 < NC) load_chunk(c + 1);
-            const int slow = __syncthreads_or(chk != chk);
+            // work-group OR of "non-finite value staged" through 8 LDS words (no __syncthreads_or:
+            // its release fence is a vmcnt(0) that would drain the prefetch just issued)
+            const bool wave_bad = __any(chk != chk);
+            if (lane == 0) flags_lds[wave] = wave_bad ? 1 : 0;
+            lds_barrier();
+            int slow = 0;
+#pragma unroll
+            for (int w = 0; w < kLeafWaves; ++w) slow |= flags_lds[w];
+            slow = __builtin_amdgcn_readfirstlane(slow);
 
             if (active) {
+                cint_p nbp = a.nblk + ((int64_t)g * NC + c) * QB;
+                if (slow || !kPipelined) {
+                    // exact per-element path (NaN / inf evidence) or wide channel blocks
 #pragma unroll
-                for (int q = 0; q < QB; ++q) {
-                    const int r = g * QB + q;
-                    if (r < R) {
-                        const int j0 = a.cb[r * (NC + 1) + c], j1 = a.cb[r * (NC + 1) + c + 1];
-                        cint_p flp = a.fl + (int64_t)r * dP;
-                        cfloat_p pp = a.par + (int64_t)r * dP * 2 * I + kb;
-                        cfloat_p cp = a.cel + (int64_t)r * dP * I + kb;
-                        if (!slow) {
-                            leaf_accum<DIST, CB, SPL, false>(acc[q], lane_base, flp, pp, cp, I, j0, j1);
-                            cfloat_p bp = a.biasc + ((int64_t)r * NC + c) * I + kb;
+                    for (int q = 0; q < QB; ++q) {
+                        const int r = g * QB + q;
+                        const int nb = nbp[q];
+                        cfloat_p bp = a.biasc + ((int64_t)r * NC + c) * I + kb;
+                        if (slow) {
+                            leaf_accum_plain<DIST, CB, SPL, 1>(acc[q], lane_base, fl_g + pos,
+                                                               par_g + (int64_t)pos * 2 * CB,
+                                                               cel_g + (int64_t)pos * CB, nb);
+                        } else {
+                            leaf_accum_plain<DIST, CB, SPL, 0>(acc[q], lane_base, fl_g + pos,
+                                                               par_g + (int64_t)pos * 2 * CB,
+                                                               cel_g + (int64_t)pos * CB, nb);
 #pragma unroll
                             for (int k = 0; k < CB; ++k) {
                                 const float bk = bp[k];
 #pragma unroll
                                 for (int s = 0; s < SPL; ++s) acc[q][k][s] += bk;
                             }
-                        } else {
-                            leaf_accum<DIST, CB, SPL, true>(acc[q], lane_base, flp, pp, cp, I, j0, j1);
+                        }
+                        pos += nb * kBlock;
+                    }
+                    primed = false;
+                } else {
+                    if constexpr (kPipelined) {
+                        if (!primed) pipe.prime(fl_g, par_g, pos);
+                        primed = true;
+                        pipe.reread(lane_base);
+#pragma unroll
+                        for (int q = 0; q < QB; ++q) {
+                            const int r = g * QB + q;
+                            const int nb = nbp[q];
+                            cfloat_p bp = a.biasc + ((int64_t)r * NC + c) * I + kb;
+                            if (DIST == 0 && a.unit[r]) {
+                                float sq[CB][SPL];
+#pragma unroll
+                                for (int k = 0; k < CB; ++k)
+#pragma unroll
+                                    for (int s = 0; s < SPL; ++s) sq[k][s] = 0.f;
+                                pipe.template run<DIST, 2>(sq, lane_base, nb);
+#pragma unroll
+                                for (int k = 0; k < CB; ++k) {
+                                    const float bk = bp[k];
+#pragma unroll
+                                    for (int s = 0; s < SPL; ++s) acc[q][k][s] += fmaf(-0.5f, sq[k][s], bk);
+                                }
+                            } else {
+                                pipe.template run<DIST, 0>(acc[q], lane_base, nb);
+#pragma unroll
+                                for (int k = 0; k < CB; ++k) {
+                                    const float bk = bp[k];
+#pragma unroll
+                                    for (int s = 0; s < SPL; ++s) acc[q][k][s] += bk;
+                                }
+                            }
+                            pos += nb * kBlock;
                         }
                     }
                 }
@@ -661,34 +898,43 @@ __global__ __launch_bounds__(kLeafWaves * 64, 4) void ratspn_leaf_kernel(const L
 int prepare_leaf_structure(const RatWs &w, const int64_t *mask, const uint8_t *pad, int R, int d,
                            uint32_t flags, hipStream_t st) {
     if (flags & DPK_FLAG_STRUCT_CACHED) return DPK_OK;
-    const size_t lds = (size_t)(3 * d + 2 * (w.NC + 1)) * sizeof(int);
+    const size_t lds = (size_t)(2 * w.QB * d + w.QB * (w.NC + 1) + w.NC * w.QB + 1) * sizeof(int);
     DPK_REQUIRE(lds <= 64 * 1024, DPK_EUNSUPPORTED, "region dimension %d too large for the structure kernel", d);
-    hipLaunchKernelGGL(ratspn_struct_kernel, dim3(R), dim3(256), lds, st, mask, pad, R, d, w.NC, w.dP, w.fl,
-                       w.src, w.feat, w.cb);
+    hipLaunchKernelGGL(ratspn_struct_kernel, dim3(w.G), dim3(256), lds, st, mask, pad, R, d, w.NC, w.QB, w.SP,
+                       w.fl1, w.fl2, w.srcr, w.feat, w.nblk, w.segoff);
     DPK_CHECK_LAUNCH("ratspn_struct_kernel");
     return DPK_OK;
 }
 
+// channel block the kernels use for `I` channels: the largest of {8,4,2,1} dividing I
+static int channel_block(int I) { return (I % 8 == 0) ? 8 : (I % 4 == 0) ? 4 : (I % 2 == 0) ? 2 : 1; }
+
 static int prepare_leaf_tables(int dist, const RatWs &w, const int64_t *mask, const uint8_t *pad,
-                               const float *p0, const float *p1, int R, int I, int d, uint32_t flags,
+                               const float *p0, const float *p1, int R, int I, int CB, int d, uint32_t flags,
                                hipStream_t st) {
     int rc = prepare_leaf_structure(w, mask, pad, R, d, flags, st);
     if (rc) return rc;
     if (dist == 0)
-        hipLaunchKernelGGL(leaf_param_kernel<0>, dim3(R), dim3(256), 0, st, p0, p1, w.src, w.cb, R, I, d,
-                           w.dP, w.NC, w.par, w.cel, w.biasc);
+        hipLaunchKernelGGL(leaf_param_kernel<0>, dim3(w.G), dim3(256), 0, st, p0, p1, w.srcr, w.nblk, w.segoff, R,
+                           I, CB, d, w.NC, w.QB, w.SP, w.par, w.cel, w.biasc, w.unit);
     else
-        hipLaunchKernelGGL(leaf_param_kernel<1>, dim3(R), dim3(256), 0, st, p0, p1, w.src, w.cb, R, I, d,
-                           w.dP, w.NC, w.par, w.cel, w.biasc);
+        hipLaunchKernelGGL(leaf_param_kernel<1>, dim3(w.G), dim3(256), 0, st, p0, p1, w.srcr, w.nblk, w.segoff, R,
+                           I, CB, d, w.NC, w.QB, w.SP, w.par, w.cel, w.biasc, w.unit);
     DPK_CHECK_LAUNCH("leaf_param_kernel");
     return DPK_OK;
+}
+
+static void fill_leaf_args(LeafArgs &a, const RatWs &w) {
+    a.NC = w.NC; a.SP = w.SP;
+    a.fl1 = as_const(w.fl1); a.fl2 = as_const(w.fl2); a.nblk = as_const(w.nblk);
+    a.par = as_const(w.par); a.cel = as_const(w.cel); a.biasc = as_const(w.biasc); a.unit = as_const(w.unit);
 }
 
 template <int DIST, int QB, int CB, int SPL, int DEPTH, int S>
 static int launch_leaf(const LeafArgs &a, hipStream_t st) {
     using G = TileGeom<SPL>;
     const int grid = cdiv(a.B, G::T);
-    size_t lds = G::BUF_BYTES;
+    size_t lds = G::BUF_BYTES + 64;
     if (DEPTH > 0) lds += (size_t)2 * a.C * G::T * sizeof(float);
     auto kern = ratspn_leaf_kernel<DIST, QB, CB, SPL, DEPTH, S>;
     if (lds > 64 * 1024) {
@@ -710,9 +956,12 @@ static int launch_leaf(const LeafArgs &a, hipStream_t st) {
 
 template <int DIST>
 static int leaf_forward_dispatch(const LeafArgs &a, hipStream_t st) {
-    // largest channel block in {8,4,2,1} dividing I; two samples per lane while registers allow
+    // channel block = largest of {8,4,2,1} dividing I; two samples per lane while registers allow
     const int I = a.I;
-    const bool q4 = (a.R % 4) == 0;
+    const bool q4 = leaf_group(a.R) == 4;
+#ifdef DPK_HEADLINE_ONLY
+    return launch_leaf<DIST, 4, 2, 2, 0, 1>(a, st);
+#endif
     if (I % 8 == 0) return q4 ? launch_leaf<DIST, 4, 8, 1, 0, 1>(a, st) : launch_leaf<DIST, 2, 8, 1, 0, 1>(a, st);
     if (I % 4 == 0) return q4 ? launch_leaf<DIST, 4, 4, 2, 0, 1>(a, st) : launch_leaf<DIST, 2, 4, 2, 0, 1>(a, st);
     if (I % 2 == 0) return q4 ? launch_leaf<DIST, 4, 2, 2, 0, 1>(a, st) : launch_leaf<DIST, 2, 2, 2, 0, 1>(a, st);
@@ -723,27 +972,30 @@ static int leaf_forward_common(int dist, const float *x, int64_t B, int32_t D, c
                                const uint8_t *pad_mask, const float *p0, const float *p1, int32_t R,
                                int32_t I, int32_t d, float *out, void *ws, int64_t ws_bytes,
                                uint32_t flags, void *stream) {
+    DPK_REQUIRE(B >= 0 && D > 0 && R > 0 && (R % 2) == 0 && I > 0 && d > 0, DPK_EINVAL, "leaf_forward: bad sizes");
+    if (B == 0) return DPK_OK;
     DPK_REQUIRE(x && mask && p0 && out && ws, DPK_EINVAL, "leaf_forward: null pointer");
     DPK_REQUIRE(dist == 1 || p1, DPK_EINVAL, "leaf_forward: null scale");
-    DPK_REQUIRE(B >= 0 && D > 0 && R > 0 && I > 0 && d > 0, DPK_EINVAL, "leaf_forward: bad sizes");
-    RatWs w = carve_ratspn_ws(ws, D, R, d, I, 0, 0, 0, 0);
+    RatWs w = carve_ratspn_ws(ws, D, R, d, I, leaf_group(R), 0, 0, 0, 0);
     DPK_REQUIRE(ws_bytes >= w.bytes, DPK_EWORKSPACE, "leaf_forward: workspace %lld < %lld",
                 (long long)ws_bytes, (long long)w.bytes);
-    if (B == 0) return DPK_OK;
     hipStream_t st = (hipStream_t)stream;
-    int rc = prepare_leaf_tables(dist, w, mask, pad_mask, p0, p1, R, I, d, flags, st);
+    int rc = prepare_leaf_tables(dist, w, mask, pad_mask, p0, p1, R, I, channel_block(I), d, flags, st);
     if (rc) return rc;
     LeafArgs a{};
-    a.x = x; a.B = B; a.D = D; a.R = R; a.I = I; a.d = d; a.NC = w.NC; a.dP = w.dP;
-    a.fl = as_const(w.fl); a.cb = as_const(w.cb); a.par = as_const(w.par); a.cel = as_const(w.cel);
-    a.biasc = as_const(w.biasc);
+    a.x = x; a.B = B; a.D = D; a.R = R; a.I = I; a.d = d;
+    fill_leaf_args(a, w);
     a.leaf_out = out;
     return dist == 0 ? leaf_forward_dispatch<0>(a, st) : leaf_forward_dispatch<1>(a, st);
 }
 
 template <int DEPTH, int I, int S>
 static int fused_launch(const LeafArgs &a, hipStream_t st) {
+#ifdef DPK_FORCE_SPL1
+    constexpr int SPL = 1;
+#else
     constexpr int SPL = (I <= 4) ? 2 : 1;
+#endif
     return launch_leaf<0, (1 << DEPTH), I, SPL, DEPTH, S>(a, st);
 }
 
@@ -777,9 +1029,16 @@ using namespace dpk;
 extern "C" int64_t dpk_ratspn_workspace_bytes(int32_t in_features, int32_t regions, int32_t dimension,
                                               int32_t channels, int32_t depth, int32_t reps,
                                               int32_t sums, int32_t classes) {
-    if (in_features <= 0 || regions <= 0 || dimension <= 0 || channels <= 0) return DPK_EINVAL;
-    return carve_ratspn_ws(nullptr, in_features, regions, dimension, channels, depth, reps, sums, classes)
-        .bytes;
+    if (in_features <= 0 || regions <= 0 || (regions % 2) != 0 || dimension <= 0 || channels <= 0)
+        return DPK_EINVAL;
+    // the per-layer operators group regions by leaf_group(R), the fused model by repetition: size for both
+    const int64_t a = carve_ratspn_ws(nullptr, in_features, regions, dimension, channels, leaf_group(regions), 0,
+                                      0, 0, 0).bytes;
+    int64_t b = 0;
+    if (depth >= 1 && depth <= 3 && reps >= 1 && regions == reps * (1 << depth))
+        b = carve_ratspn_ws(nullptr, in_features, regions, dimension, channels, 1 << depth, depth, reps,
+                            sums > 0 ? sums : 1, classes > 0 ? classes : 1).bytes;
+    return a > b ? a : b;
 }
 
 extern "C" int dpk_gaussian_leaf_forward(const float *x, int64_t B, int32_t D, const int64_t *mask,
@@ -804,10 +1063,10 @@ extern "C" int dpk_ratspn_forward(const float *x, int64_t B, int32_t D, const in
                                   const float *root_weight, int32_t depth, int32_t reps, int32_t I,
                                   int32_t S, int32_t C, float *out, float *leaf_out, double *ll_sum,
                                   void *ws, int64_t ws_bytes, uint32_t flags, void *stream) {
-    DPK_REQUIRE(x && mask && loc && scale && root_weight && out && ws, DPK_EINVAL,
-                "ratspn_forward: null pointer");
     DPK_REQUIRE(B >= 0 && D > 0 && reps > 0 && I > 0 && S > 0 && C > 0, DPK_EINVAL,
                 "ratspn_forward: bad sizes");
+    DPK_REQUIRE(B == 0 || (x && out), DPK_EINVAL, "ratspn_forward: null pointer");
+    DPK_REQUIRE(mask && loc && scale && root_weight && ws, DPK_EINVAL, "ratspn_forward: null pointer");
     DPK_REQUIRE(depth >= 1 && depth <= 3, DPK_EUNSUPPORTED, "ratspn_forward: depth=%d not built (1..3)",
                 depth);
     DPK_REQUIRE(C <= 64, DPK_EUNSUPPORTED, "ratspn_forward: classes=%d > 64", C);
@@ -818,7 +1077,7 @@ extern "C" int dpk_ratspn_forward(const float *x, int64_t B, int32_t D, const in
     const int pad = (Q - D % Q) % Q;
     const int d = (D + pad) / Q;
     DPK_REQUIRE(pad == 0 || pad_mask, DPK_EINVAL, "ratspn_forward: padded model needs pad_mask");
-    RatWs w = carve_ratspn_ws(ws, D, R, d, I, depth, reps, S, C);
+    RatWs w = carve_ratspn_ws(ws, D, R, d, I, Q, depth, reps, S, C);
     DPK_REQUIRE(ws_bytes >= w.bytes, DPK_EWORKSPACE, "ratspn_forward: workspace %lld < %lld",
                 (long long)ws_bytes, (long long)w.bytes);
     if (!(I == 2 || I == 4 || I == 8) || (depth >= 2 && !(S == 2 || S == 4 || S == 8))) {
@@ -827,7 +1086,7 @@ extern "C" int dpk_ratspn_forward(const float *x, int64_t B, int32_t D, const in
     }
     if (B == 0) return DPK_OK;
     hipStream_t st = (hipStream_t)stream;
-    int rc = prepare_leaf_tables(0, w, mask, pad_mask, loc, scale, R, I, d, flags, st);
+    int rc = prepare_leaf_tables(0, w, mask, pad_mask, loc, scale, R, I, I, d, flags, st);
     if (rc) return rc;
     const int nlast = depth >= 2 ? S : I;
     if (depth >= 2) {
@@ -845,17 +1104,22 @@ extern "C" int dpk_ratspn_forward(const float *x, int64_t B, int32_t D, const in
     DPK_CHECK_LAUNCH("softmax_rows_kernel");
 
     LeafArgs a{};
-    a.x = x; a.B = B; a.D = D; a.R = R; a.I = I; a.d = d; a.NC = w.NC; a.dP = w.dP;
-    a.fl = as_const(w.fl); a.cb = as_const(w.cb); a.par = as_const(w.par); a.cel = as_const(w.cel);
-    a.biasc = as_const(w.biasc);
+    a.x = x; a.B = B; a.D = D; a.R = R; a.I = I; a.d = d;
+    fill_leaf_args(a, w);
     a.leaf_out = leaf_out;
     a.reps = reps; a.C = C;
     a.W0 = as_const(w.w[0]); a.LW0 = as_const(w.lw[0]); a.W1 = as_const(w.w[1]);
     a.LW1 = as_const(w.lw[1]); a.Wr = as_const(w.w[2]); a.LWr = as_const(w.lw[2]);
     a.out = out; a.ll_sum = ll_sum;
+#ifdef DPK_HEADLINE_ONLY  // measurement builds: only the headline instantiation
+    if (depth == 2 && I == 2 && S == 2) return fused_launch<2, 2, 2>(a, st);
+    set_error("measurement build: only depth=2, channels=2, sums=2");
+    return DPK_EUNSUPPORTED;
+#else
     switch (depth) {
         case 1: return fused_dispatch_i<1>(a, S, st);
         case 2: return fused_dispatch_i<2>(a, S, st);
         default: return fused_dispatch_i<3>(a, S, st);
     }
+#endif
 }

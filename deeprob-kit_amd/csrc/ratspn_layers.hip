@@ -230,16 +230,17 @@ constexpr int kLeafBwdTile = 256;
 
 template <int DIST>
 __global__ __launch_bounds__(256) void leaf_bwd_param_kernel(
-    const float *__restrict__ x, const float *__restrict__ g, int64_t B, int D, int R, int I, int d, int dP,
-    const int *__restrict__ feat, const int *__restrict__ src, const float *__restrict__ p0,
+    const float *__restrict__ x, const float *__restrict__ g, int64_t B, int D, int R, int I, int d, int SP,
+    const int *__restrict__ feat, const int *__restrict__ srcr, const float *__restrict__ p0,
     const float *__restrict__ p1, float *__restrict__ gp0, float *__restrict__ gp1) {
-    const int r = blockIdx.y;
+    const int grp = blockIdx.y;  // region group: its entry stream holds (variable, r*d+j) pairs
     const int64_t b0 = (int64_t)blockIdx.x * kLeafBwdTile;
     const int64_t b1 = min(b0 + kLeafBwdTile, B);
-    for (int e = threadIdx.x; e < dP; e += blockDim.x) {
-        const int j = src[(int64_t)r * dP + e];
-        if (j < 0) continue;
-        const int f = feat[(int64_t)r * dP + e];
+    for (int e = threadIdx.x; e < SP; e += blockDim.x) {
+        const int rj = srcr[(int64_t)grp * SP + e];
+        if (rj < 0) continue;
+        const int r = rj / d, j = rj - r * d;
+        const int f = feat[(int64_t)grp * SP + e];
         for (int k = 0; k < I; ++k) {
             const int64_t po = ((int64_t)r * I + k) * d + j;
             float a0 = 0.f, a1 = 0.f;
@@ -271,14 +272,16 @@ __global__ __launch_bounds__(256) void leaf_bwd_param_kernel(
     }
 }
 
-// inverse structure: for repetition rho and variable f, the (region, position) holding it
-__global__ void leaf_inverse_kernel(const int *__restrict__ feat, const int *__restrict__ src, int R, int d,
-                                    int dP, int D, int regions_per_rep, int *__restrict__ inv) {
-    const int r = blockIdx.x;
-    const int rho = r / regions_per_rep;
-    for (int e = threadIdx.x; e < dP; e += blockDim.x) {
-        const int j = src[(int64_t)r * dP + e];
-        if (j >= 0) inv[(int64_t)rho * D + feat[(int64_t)r * dP + e]] = r * d + j;
+// inverse structure: for repetition rho and variable f, the (region, position) r*d+j holding it
+__global__ void leaf_inverse_kernel(const int *__restrict__ feat, const int *__restrict__ srcr, int d, int SP,
+                                    int D, int regions_per_rep, int *__restrict__ inv) {
+    const int grp = blockIdx.x;
+    for (int e = threadIdx.x; e < SP; e += blockDim.x) {
+        const int rj = srcr[(int64_t)grp * SP + e];
+        if (rj >= 0) {
+            const int rho = (rj / d) / regions_per_rep;
+            inv[(int64_t)rho * D + feat[(int64_t)grp * SP + e]] = rj;
+        }
     }
 }
 
@@ -426,7 +429,8 @@ static int leaf_backward_common(int dist, const float *x, const float *g, int64_
     DPK_REQUIRE(dist == 1 || p1, DPK_EINVAL, "leaf_backward: null scale");
     DPK_REQUIRE(B >= 0 && D > 0 && R > 0 && I > 0 && d > 0, DPK_EINVAL, "leaf_backward: bad sizes");
     DPK_REQUIRE(R <= 65535, DPK_EUNSUPPORTED, "leaf_backward: regions=%d > 65535", R);
-    RatWs w = carve_ratspn_ws(ws, D, R, d, I, 0, 0, 0, 0);
+    DPK_REQUIRE((R % 2) == 0, DPK_EINVAL, "leaf_backward: odd number of regions");
+    RatWs w = carve_ratspn_ws(ws, D, R, d, I, leaf_group(R), 0, 0, 0, 0);
     DPK_REQUIRE(ws_bytes >= w.bytes, DPK_EWORKSPACE, "leaf_backward: workspace %lld < %lld", (long long)ws_bytes,
                 (long long)w.bytes);
     hipStream_t st = (hipStream_t)stream;
@@ -437,11 +441,11 @@ static int leaf_backward_common(int dist, const float *x, const float *g, int64_
     if (gp1) DPK_REQUIRE(hipMemsetAsync(gp1, 0, pbytes, st) == hipSuccess, DPK_ELAUNCH, "leaf_backward: memset");
     if (B > 0 && (gp0 || gp1)) {
         if (dist == 0)
-            hipLaunchKernelGGL(leaf_bwd_param_kernel<0>, dim3(cdiv(B, kLeafBwdTile), R), dim3(256), 0, st, x, g,
-                               B, D, R, I, d, w.dP, w.feat, w.src, p0, p1, gp0, gp1);
+            hipLaunchKernelGGL(leaf_bwd_param_kernel<0>, dim3(cdiv(B, kLeafBwdTile), w.G), dim3(256), 0, st, x, g,
+                               B, D, R, I, d, w.SP, w.feat, w.srcr, p0, p1, gp0, gp1);
         else
-            hipLaunchKernelGGL(leaf_bwd_param_kernel<1>, dim3(cdiv(B, kLeafBwdTile), R), dim3(256), 0, st, x, g,
-                               B, D, R, I, d, w.dP, w.feat, w.src, p0, p1, gp0, gp1);
+            hipLaunchKernelGGL(leaf_bwd_param_kernel<1>, dim3(cdiv(B, kLeafBwdTile), w.G), dim3(256), 0, st, x, g,
+                               B, D, R, I, d, w.SP, w.feat, w.srcr, p0, p1, gp0, gp1);
         DPK_CHECK_LAUNCH("leaf_bwd_param_kernel");
     }
     if (gx && B > 0) {
@@ -453,11 +457,11 @@ static int leaf_backward_common(int dist, const float *x, const float *g, int64_
         DPK_REQUIRE(reps * per_rep == R, DPK_EINVAL, "leaf_backward: R=%d is not reps*%d", R, per_rep);
         // the inverse table reuses the `par` segment (parameter tables are not needed here)
         int *inv = (int *)w.par;
-        DPK_REQUIRE((int64_t)reps * D * 4 <= ((int64_t)R * w.dP + kTableSlack) * 2 * I * 4, DPK_EWORKSPACE,
+        DPK_REQUIRE((int64_t)reps * D * 4 <= (int64_t)w.G * w.SP * 2 * I * 4, DPK_EWORKSPACE,
                     "leaf_backward: inverse table does not fit");
         DPK_REQUIRE(hipMemsetAsync(inv, 0xff, (size_t)reps * D * 4, st) == hipSuccess, DPK_ELAUNCH,
                     "leaf_backward: memset");
-        hipLaunchKernelGGL(leaf_inverse_kernel, dim3(R), dim3(256), 0, st, w.feat, w.src, R, d, w.dP, D, per_rep,
+        hipLaunchKernelGGL(leaf_inverse_kernel, dim3(w.G), dim3(256), 0, st, w.feat, w.srcr, d, w.SP, D, per_rep,
                            inv);
         hipLaunchKernelGGL(gaussian_leaf_bwd_x_kernel, dim3(grid_for(B * D, 256)), dim3(256), 0, st, x, g, B, D,
                            R, I, d, reps, inv, p0, p1, gx);

@@ -12,7 +12,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libdeeprob_hip.so'))
+LIB_PATH = os.environ.get(  # DEEPROB_HIP_LIB: measurement builds of the same ABI (profiles/README)
+    'DEEPROB_HIP_LIB', os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libdeeprob_hip.so')))
 
 DPK_FLAG_STRUCT_CACHED = 1
 

@@ -70,6 +70,20 @@ def test_layers_golden(golden, name):
     assert rel_err(out.cpu().numpy(), g['ll']) <= LL_TOL
 
 
+def _oracle_grads_fp64(g):
+    sd = orc.state_from_npz(g, dtype=torch.float64)
+    names = [k[5:] for k in g.files if k.startswith('grad.') and k != 'grad.x']
+    for k in names:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    x = torch.from_numpy(g['x']).double().requires_grad_(True)
+    y = torch.from_numpy(g['y']) if 'y' in g.files else None
+    with torch.enable_grad():
+        orc.ratspn_loss(orc.ratspn_forward(sd, x), y).backward()
+    out = {k: sd[k].grad.numpy() for k in names}
+    out['x'] = x.grad.numpy()
+    return out
+
+
 @pytest.mark.parametrize('name', [n for n in sorted(MODELS) if 'i16' not in n])
 def test_backward_golden(golden, name):
     model, g = build(name, golden)
@@ -79,11 +93,19 @@ def test_backward_golden(golden, name):
         loss = model.loss(model(x), y)
         loss.backward()
     assert abs(loss.item() - float(g['loss'])) <= LL_TOL * max(1.0, abs(float(g['loss'])))
-    assert grad_err(x.grad.cpu().numpy(), g['grad.x']) <= GRAD_TOL
+    # Tolerance: GRAD_TOL, widened to the reference's OWN fp32 noise where that is larger.  The
+    # discriminative loss differentiates softmax(out) - onehot, which cancels catastrophically for
+    # confident samples, so the golden (fp32) gradient itself sits up to ~1e-3 away from the fp64 one.
+    ref64 = _oracle_grads_fp64(g)
+
+    def tol(key):
+        return max(GRAD_TOL, 4.0 * grad_err(g['grad.' + key], ref64[key]))
+
+    assert grad_err(x.grad.cpu().numpy(), g['grad.x']) <= tol('x')
     for k, p in model.named_parameters():
         if 'grad.' + k in g.files:
             assert p.grad is not None, k
-            assert grad_err(p.grad.cpu().numpy(), g['grad.' + k]) <= GRAD_TOL, k
+            assert grad_err(p.grad.cpu().numpy(), g['grad.' + k]) <= tol(k), k
 
 
 @pytest.mark.parametrize('B', [1, 63, 64, 129, 1000])
