@@ -58,6 +58,8 @@ struct RatWs {
     float *cel;   // [G*ncb*SP*CB]  additive constant per entry
     float *biasc; // [R*NC*I] per-(region, chunk) sum of cel
     int *unit;    // [R] 1 if every scale of the region equals 1 (Gaussian leaves)
+    float *rec;   // [G*(SP/4)*(4+8I)] block records staged into LDS by the kernels (I <= 2 only)
+    int tabcap;   // LDS bytes per wave for the records of one chunk, 0 = records not used
     float *w[3];  // linear softmax weights: sum layer 0, sum layer 1, root
     float *lw[3]; // log-softmax weights
     int64_t bytes;
@@ -93,6 +95,20 @@ inline RatWs carve_ratspn_ws(void *base, int D, int R, int d, int I, int QB, int
     w.cel = (float *)take(GS * I * 4);
     w.biasc = (float *)take((int64_t)R * NC * I * 4);
     w.unit = (int *)take((int64_t)R * 4);
+    w.rec = nullptr;
+    w.tabcap = 0;
+    if (I <= 2) {
+        const int recb = 4 + 8 * I;
+        w.rec = (float *)take((int64_t)w.G * (w.SP / kBlock) * recb * 4);
+        // blocks of one (group, chunk): the regions of one repetition are disjoint, so a group spanning
+        // `rpg` repetitions holds at most rpg*(kChunk + padding) entries of a chunk, plus < 1 block of
+        // padding per region and two blocks of pipeline run-ahead
+        const int per_rep = cdiv(D, d);
+        const int rpg = cdiv(QB, per_rep);
+        const int blocks = rpg * (kChunk / kBlock + 1) + QB + 2;
+        const int cap = (int)align_up((int64_t)blocks * recb * 4, 16);
+        if (cap <= 3 * 1024) w.tabcap = cap;  // three 16-byte loads per lane (NTL in the kernel)
+    }
     // sum layers (only meaningful for the fused model entry point)
     int64_t n0 = 0, n1 = 0, nr = 0;
     if (depth >= 1 && reps >= 1) {

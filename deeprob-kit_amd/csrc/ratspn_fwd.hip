@@ -15,6 +15,7 @@
 //     LDS log-sum-exp for the root.
 #include "common.h"
 #include <math.h>
+#include <type_traits>
 
 namespace dpk {
 
@@ -105,7 +106,9 @@ __global__ void ratspn_struct_kernel(const int64_t *__restrict__ mask,
             if (idx < lo[q * (NC + 1) + c + 1]) {
                 f = sid[q * d + idx];
                 sj = ssrc[q * d + idx];
-                l = f % kChunk;
+                // a dummy (padding) variable reads the all-zero row like a neutral entry: the
+                // unit-scale path applies no per-entry multiplier that could mask it
+                if (sj >= 0) l = f % kChunk;
             }
         }
         const int64_t o = (int64_t)g * SP + p;
@@ -122,77 +125,138 @@ __global__ void ratspn_struct_kernel(const int64_t *__restrict__ mask,
 //              (torch.distributions.Normal.log_prob as used at ratspn.py:96)
 //   Bernoulli: term = x*l - softplus(l) = -BCEWithLogits(l, x)   (ratspn.py:243)
 // --------------------------------------------------------------------------------------
-template <int DIST>
-__global__ void leaf_param_kernel(const float *__restrict__ p0, const float *__restrict__ p1,
-                                  const int *__restrict__ srcr, const int *__restrict__ nblk,
-                                  const int *__restrict__ segoff, int R, int I, int CB, int d, int NC, int QB,
-                                  int SP, float *__restrict__ par, float *__restrict__ cel,
-                                  float *__restrict__ biasc, int *__restrict__ unit) {
-    // table layout: [group][channel block][stream position]{p0[CB], p1[CB]}: the kBlock entries of a
-    // block are one contiguous run for the wave that owns (group, channel block)
-    __shared__ int not_unit[8];
-    const int g = blockIdx.x;
-    const int ncb = I / CB;
-    if (threadIdx.x < 8) not_unit[threadIdx.x] = (DIST != 0);
-    __syncthreads();
-    for (int e = threadIdx.x; e < SP * I; e += blockDim.x) {
-        const int pidx = e / I, k = e - pidx * I;
-        const int rj = srcr[(int64_t)g * SP + pidx];
-        float A = 0.f, Bv = 0.f, Cc = 0.f;
-        if (rj >= 0) {
-            const int r = rj / d, j = rj - r * d;
-            const int64_t o = ((int64_t)r * I + k) * d + j;
-            if (DIST == 0) {
-                const float mu = p0[o], sg = p1[o];
-                if (sg != 1.0f) not_unit[r - g * QB] = 1;
-                A = mu;
-                Bv = -0.5f / (sg * sg);
-                Cc = -logf(sg) - kLogSqrt2Pi;
-            } else {
-                const float l = p0[o];
-                A = l;
-                Cc = -(fmaxf(l, 0.f) + log1pf(expf(-fabsf(l))));
-            }
-        }
-        const int kbi = k / CB, kk = k - kbi * CB;
-        const int64_t ent = ((int64_t)g * ncb + kbi) * SP + pidx;
-        par[ent * 2 * CB + kk] = A;
-        par[ent * 2 * CB + CB + kk] = Bv;
-        cel[ent * CB + kk] = Cc;
-    }
-    __syncthreads();
-    if (threadIdx.x < QB) unit[g * QB + threadIdx.x] = !not_unit[threadIdx.x];
-    for (int e = threadIdx.x; e < NC * QB * I; e += blockDim.x) {
-        const int k = e % I, cq = e / I;
-        const int c = cq / QB, q = cq - c * QB;
-        const int kbi = k / CB, kk = k - kbi * CB;
-        const int64_t so = ((int64_t)g * NC + c) * QB + q;
-        const int j0 = segoff[so], j1 = j0 + nblk[so] * kBlock;
-        float s = 0.f;
-        for (int p = j0; p < j1; ++p) s += cel[(((int64_t)g * ncb + kbi) * SP + p) * CB + kk];
-        biasc[((int64_t)(g * QB + q) * NC + c) * I + k] = s;
+// One launch prepares everything that depends on the live parameters: blocks [0, G*kPrepSlices) build
+// the leaf tables (kPrepSlices blocks per region group, each a slice of the group's entry stream),
+// the blocks behind them take the rows of the sum / root weight matrices (softmax + log_softmax).
+constexpr int kPrepSlices = 32;
+
+struct PrepArgs {
+    // leaf tables
+    const float *p0, *p1;
+    const int *srcr, *nblk, *segoff, *fl2;
+    int R, I, CB, d, NC, QB, SP, G;
+    float *par, *cel, *biasc, *rec;
+    int *unit;
+    // up to three weight matrices [rows, n] -> W (softmax), LW (log_softmax)
+    const float *w[3];
+    float *W[3], *LW[3];
+    int rows[3], n[3];
+};
+
+__device__ __forceinline__ void leaf_entry_params(int dist, const float *p0, const float *p1, int64_t o, float &A,
+                                                  float &Bv, float &Cc) {
+    if (dist == 0) {
+        const float mu = p0[o], sg = p1[o];
+        A = mu;
+        Bv = -0.5f / (sg * sg);
+        Cc = -logf(sg) - kLogSqrt2Pi;
+    } else {
+        const float l = p0[o];
+        A = l;
+        Bv = 0.f;
+        Cc = -(fmaxf(l, 0.f) + log1pf(expf(-fabsf(l))));
     }
 }
 
-// softmax / log_softmax of every row of a [rows, n] weight matrix (one wave per row).
-// reference: torch.log_softmax at ratspn.py:375 and :455
-__global__ void softmax_rows_kernel(const float *__restrict__ w, int rows, int n,
-                                    float *__restrict__ W, float *__restrict__ LW) {
-    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    const float *src = w + (int64_t)row * n;
-    float m = -INFINITY;
-    for (int i = lane; i < n; i += 64) m = fmaxf(m, src[i]);
-    m = wave_reduce_max(m);
-    float s = 0.f;
-    for (int i = lane; i < n; i += 64) s += expf(src[i] - m);
-    s = wave_reduce_sum(s);
-    const float ls = logf(s);
-    for (int i = lane; i < n; i += 64) {
-        const float l = src[i] - m - ls;
-        LW[(int64_t)row * n + i] = l;
-        W[(int64_t)row * n + i] = expf(l);
+template <int DIST>
+__global__ __launch_bounds__(256) void ratspn_prep_kernel(const PrepArgs a) {
+    const int n_leaf_blocks = a.G * kPrepSlices;
+    if ((int)blockIdx.x >= n_leaf_blocks) {
+        // ---- softmax rows: one wave per row (reference: torch.log_softmax at ratspn.py:375 and :455)
+        int row = (blockIdx.x - n_leaf_blocks) * 4 + (threadIdx.x >> 6);
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            if (row < a.rows[m]) {
+                const int n = a.n[m];
+                const float *src = a.w[m] + (int64_t)row * n;
+                float mx = -INFINITY;
+                for (int i = lane; i < n; i += 64) mx = fmaxf(mx, src[i]);
+                mx = wave_reduce_max(mx);
+                float sum = 0.f;
+                for (int i = lane; i < n; i += 64) sum += expf(src[i] - mx);
+                sum = wave_reduce_sum(sum);
+                const float ls = logf(sum);
+                for (int i = lane; i < n; i += 64) {
+                    const float l = src[i] - mx - ls;
+                    a.LW[m][(int64_t)row * n + i] = l;
+                    a.W[m][(int64_t)row * n + i] = expf(l);
+                }
+                return;
+            }
+            row -= a.rows[m];
+        }
+        return;
+    }
+    // ---- leaf tables: [group][channel block][stream position]{p0[CB], p1[CB]}; the kBlock entries of
+    // a block are one contiguous run for the wave that owns (group, channel block)
+    const int g = blockIdx.x / kPrepSlices, sl = blockIdx.x - g * kPrepSlices;
+    const int I = a.I, CB = a.CB, d = a.d, SP = a.SP, QB = a.QB, NC = a.NC;
+    const int ncb = I / CB;
+    const int per = ((SP / kBlock + kPrepSlices - 1) / kPrepSlices) * kBlock;  // positions per slice
+    const int p_lo = sl * per, p_hi = min(SP, p_lo + per);
+    for (int e = threadIdx.x; e < (p_hi - p_lo) * I; e += blockDim.x) {
+        const int pidx = p_lo + e / I, k = e % I;
+        const int rj = a.srcr[(int64_t)g * SP + pidx];
+        float A = 0.f, Bv = 0.f, Cc = 0.f;
+        if (rj >= 0) {
+            const int r = rj / d, j = rj - r * d;
+            leaf_entry_params(DIST, a.p0, a.p1, ((int64_t)r * I + k) * d + j, A, Bv, Cc);
+        }
+        const int kbi = k / CB, kk = k - kbi * CB;
+        const int64_t ent = ((int64_t)g * ncb + kbi) * SP + pidx;
+        a.par[ent * 2 * CB + kk] = A;
+        a.par[ent * 2 * CB + CB + kk] = Bv;
+        a.cel[ent * CB + kk] = Cc;
+        if (a.rec != nullptr) {
+            // block records for the LDS-resident tables (I == CB <= 2): {row offsets[4], p0[4][CB],
+            // p1[4][CB]} -- see LdsPipe
+            const int RECB = 4 + 8 * CB;
+            const int blk = pidx / kBlock, u = pidx - blk * kBlock;
+            float *rp = a.rec + ((int64_t)g * (SP / kBlock) + blk) * RECB;
+            rp[4 + u * CB + k] = A;
+            rp[4 + 4 * CB + u * CB + k] = Bv;
+            if (k == 0) rp[u] = __int_as_float(a.fl2[(int64_t)g * SP + pidx]);
+        }
+    }
+    // per-(region, chunk) constants: segments are dealt round-robin to the slices, one wave per
+    // (segment, channel), lanes over the entries, summed from the parameters directly (no dependence
+    // on what the other slices write)
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        for (int e = wv; e < NC * QB * I; e += 4) {
+            const int k = e % I, cq = e / I;
+            if (cq % kPrepSlices != sl) continue;
+            const int c = cq / QB, q = cq - c * QB;
+            const int64_t so = ((int64_t)g * NC + c) * QB + q;
+            const int j0 = a.segoff[so], j1 = j0 + a.nblk[so] * kBlock;
+            float s = 0.f;
+            for (int p = j0 + lane; p < j1; p += 64) {
+                const int rj = a.srcr[(int64_t)g * SP + p];
+                if (rj >= 0) {
+                    const int r = rj / d, j = rj - r * d;
+                    float A, Bv, Cc;
+                    leaf_entry_params(DIST, a.p0, a.p1, ((int64_t)r * I + k) * d + j, A, Bv, Cc);
+                    s += Cc;
+                }
+            }
+            s = wave_reduce_sum(s);
+            if (lane == 0) a.biasc[((int64_t)(g * QB + q) * NC + c) * I + k] = s;
+        }
+    }
+    // unit-scale flag per region (slice 0 scans the group's scales)
+    if (sl == 0) {
+        __shared__ int not_unit[8];
+        if (threadIdx.x < 8) not_unit[threadIdx.x] = (DIST != 0);
+        __syncthreads();
+        if (DIST == 0) {
+            for (int e = threadIdx.x; e < QB * I * d; e += blockDim.x) {
+                const int q = e / (I * d);
+                if (a.p1[(int64_t)g * QB * I * d + e] != 1.0f) not_unit[q] = 1;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < QB) a.unit[g * QB + threadIdx.x] = !not_unit[threadIdx.x];
     }
 }
 
@@ -303,6 +367,10 @@ struct LeafArgs {
     int D, R, I, d, NC, SP;
     cint_p fl1, fl2;  // LDS byte offsets of the rows for SPL = 1 / 2
     cint_p nblk;      // [G][NC][QB] blocks per segment
+    cint_p segoff;    // [G][NC][QB] first stream position of every segment
+    const float *rec; // [G][SP/4] block records for the LDS-resident tables (CB <= 2)
+    int tabcap;       // bytes of LDS per wave for the records of one chunk
+    int unit_hint;    // host hint: every scale is 1 (DPK_FLAG_UNIT_SCALE)
     cfloat_p par;
     cfloat_p cel;
     cfloat_p biasc;
@@ -514,53 +582,69 @@ __device__ __forceinline__ void leaf_accum_plain(float (&acc)[CB][SPL], const ch
     }
 }
 
-// Software pipeline over one group's entry stream (CB <= 2).  It lives across segments and chunks:
-//   cur set (x, parameters) = block B, complete;  offn = row offsets of block B+1, complete;
-//   flp -> offsets of block B+2;  pp -> parameters of block B+1;  offc = row offsets of block B.
-// A step issues the x reads and parameters of B+1 and the offsets of B+2, consumes B, then drains
-// with ONE lgkmcnt(0).  Two register sets alternate (`sel`), so nothing is copied.
-template <int CB, int SPL> struct LeafPipe {
-    ParBlock<CB> par[2];
-    float x[2][kBlock][SPL];
-    i32x4 offc, offn;
-    cint_p flp;
-    cfloat_p pp;
+// Software pipeline over the table blocks of one (wave, chunk), tables resident in LDS (CB <= 2).
+//
+// Why LDS and not the scalar cache for the hot loop: an s_load that misses costs ~750-900 cycles
+// here (PMC SmemLatency), returns out of order (so every wait is a full lgkmcnt(0)) and one step of
+// four entries is only ~140 cycles of VALU work per wave -- with four waves per SIMD the scalar
+// latency cannot be covered.  An LDS broadcast read (all lanes, same address) returns in ~130
+// cycles, in order, so the compiler's counted waits pipeline it, and the operands arrive in VGPRs
+// (plain VOP2 encodings).  The block record (see leaf_param_kernel):
+//     dwords 0..3            LDS byte offsets of the 4 entries' x rows
+//     dwords 4..4+4CB-1      p0 (mean)        [entry][channel]
+//     dwords 4+4CB..4+8CB-1  p1 (-1/2sigma^2) [entry][channel]
+template <int CB> struct RecGeom {
+    static constexpr int RECB = 4 + 8 * CB;   // dwords per block record
+    static constexpr int RECBB = RECB * 4;    // bytes
+};
 
-    __device__ __forceinline__ void prime(cint_p fl, cfloat_p par_base, int pos) {
-        offc = sload_i4<0>(fl + pos);
-        offn = sload_i4<kBlock * 4>(fl + pos);
-        par_load<CB>(par[0], par_base + (int64_t)pos * 2 * CB);
-        DPK_WAIT_LGKM0();
-        __builtin_amdgcn_sched_barrier(0);
-        flp = fl + pos + 2 * kBlock;
-        pp = par_base + (int64_t)(pos + kBlock) * 2 * CB;
+template <int CB, int SPL, bool GENERAL> struct LdsPipe {
+    typedef float pvec __attribute__((ext_vector_type(4 * CB)));  // p0 or p1 of one block
+    static constexpr int RECBB = RecGeom<CB>::RECBB;
+    float x[2][kBlock][SPL];
+    pvec mu[2], av[2];
+    i32x4 offc, offn;
+    const char *tbn;  // record of block b+1
+
+    template <int SET> __device__ __forceinline__ void load_par(const char *rec) {
+        mu[SET] = *reinterpret_cast<const pvec *>(rec + 16);
+        if (GENERAL) av[SET] = *reinterpret_cast<const pvec *>(rec + 16 + 16 * CB);
     }
-    // the chunk in LDS changed: (re)read the x values of the current block (always set 0 between
-    // segments)
-    __device__ __forceinline__ void reread(const char *lane_base) {
+    __device__ __forceinline__ void prime(const char *tb0, const char *lane_base) {
+        offc = *reinterpret_cast<const i32x4 *>(tb0);
+        load_par<0>(tb0);
+        offn = *reinterpret_cast<const i32x4 *>(tb0 + RECBB);
         leaf_read_x<SPL>(x[0], lane_base, offc);
-        DPK_WAIT_LGKM0();
-        __builtin_amdgcn_sched_barrier(0);
+        tbn = tb0 + RECBB;
     }
     template <int DIST, int MODE, int CUR>
     __device__ __forceinline__ void step(float (&acc)[CB][SPL], const char *lane_base) {
         constexpr int OTH = 1 - CUR;
-        const CelBlock<CB> nocel{};
         leaf_read_x<SPL>(x[OTH], lane_base, offn);
         offc = offn;
-        offn = sload_i4<0>(flp);
-        par_load<CB>(par[OTH], pp);
+        offn = *reinterpret_cast<const i32x4 *>(tbn + RECBB);
+        load_par<OTH>(tbn);
+        tbn += RECBB;
         __builtin_amdgcn_sched_barrier(0);
-        leaf_block_compute<DIST, CB, SPL, MODE>(acc, x[CUR], par[CUR], nocel);
-        pin_acc<CB, SPL>(acc);
-        DPK_WAIT_LGKM0();
+#pragma unroll
+        for (int u = 0; u < kBlock; ++u)
+#pragma unroll
+            for (int k = 0; k < CB; ++k) {
+                const float p0 = mu[CUR][u * CB + k];
+#pragma unroll
+                for (int s = 0; s < SPL; ++s) {
+                    if (DIST == 0) {
+                        const float dlt = x[CUR][u][s] - p0;
+                        if (MODE == 2) acc[k][s] = fmaf(dlt, dlt, acc[k][s]);
+                        else acc[k][s] = fmaf(dlt * dlt, av[CUR][u * CB + k], acc[k][s]);
+                    } else {
+                        acc[k][s] = fmaf(x[CUR][u][s], p0, acc[k][s]);
+                    }
+                }
+            }
         __builtin_amdgcn_sched_barrier(0);
-        flp += kBlock;
-        pp += kBlock * 2 * CB;
     }
-    // nb blocks into acc.  Sets alternate statically inside the loop; an odd count ends with the
-    // live block in set 1, which is then moved to set 0 (24 register moves per odd segment) so that
-    // every segment starts from the same state and no set index is ever a run-time value.
+    // nb blocks into acc; register sets alternate statically, an odd count ends with one set move
     template <int DIST, int MODE>
     __device__ __forceinline__ void run(float (&acc)[CB][SPL], const char *lane_base, int nb) {
         for (int i = nb >> 1; i > 0; --i) {
@@ -569,7 +653,8 @@ template <int CB, int SPL> struct LeafPipe {
         }
         if (nb & 1) {
             step<DIST, MODE, 0>(acc, lane_base);
-            par[0] = par[1];
+            mu[0] = mu[1];
+            if (GENERAL) av[0] = av[1];
 #pragma unroll
             for (int u = 0; u < kBlock; ++u)
 #pragma unroll
@@ -585,14 +670,18 @@ template <int CB, int SPL> struct LeafPipe {
 #else
 #define DPK_MINW(SPL) 4
 #endif
-template <int DIST, int QB, int CB, int SPL, int DEPTH, int S>
+// GEN: the LDS-table pipeline carries the per-entry scale factors (general sigma).  With GEN = false
+// (host hint "scale is frozen at 1", checked on the device per region) only the means travel, which
+// keeps the kernel under 128 VGPRs without scratch; a group whose scales are not all 1 then takes
+// the scalar-cache path, so the hint can only cost speed, never correctness.
+template <int DIST, int QB, int CB, int SPL, int DEPTH, int S, bool GEN>
 __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_kernel(const LeafArgs a) {
     using G = TileGeom<SPL>;
     constexpr int T = G::T, ROW = G::ROW, NLD = G::NLD;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *xs_lds = reinterpret_cast<float *>(smem);
     int *flags_lds = reinterpret_cast<int *>(smem + G::BUF_BYTES);  // [waves]
-    float *run_m = reinterpret_cast<float *>(smem + G::BUF_BYTES + 64);  // [C][T] fused only
+    float *run_m = reinterpret_cast<float *>(smem + G::BUF_BYTES + 64 + kLeafWaves * 2 * a.tabcap);  // [C][T] fused only
     float *run_s = run_m + (DEPTH > 0 ? a.C * T : 0);
 
     const int tid = threadIdx.x;
@@ -661,16 +750,54 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
                 for (int i = 0; i < NLD; ++i) pre[i] = xt[min(SQN * i + sqv, nv1) * D + f];
             }
         };
-        load_chunk(0);
-
         // this wave's entry stream (consumption order, see ratspn_struct_kernel)
-        constexpr bool kPipelined = (CB <= 2);
+        constexpr bool kLdsTables = (CB <= 2) && (SPL == 2);
+        bool use_lds = kLdsTables && a.tabcap > 0;
         cint_p fl_g = (SPL == 2 ? a.fl2 : a.fl1) + (int64_t)g * a.SP;
         cfloat_p par_g = a.par + ((int64_t)g * n_cblk + kb / CB) * a.SP * 2 * CB;
         cfloat_p cel_g = a.cel + ((int64_t)g * n_cblk + kb / CB) * a.SP * CB;
-        LeafPipe<(kPipelined ? CB : 1), SPL> pipe;
-        bool primed = false;
         int pos = 0;
+
+        // LDS-resident block records of this wave for the current chunk (kLdsTables): every wave
+        // copies its own records, so no other wave ever reads them and only lgkmcnt orders them
+        constexpr int RECBB = RecGeom<(kLdsTables ? CB : 1)>::RECBB;
+        constexpr int NTL = (QB <= 4) ? 2 : 3;  // float4 per lane: 2 / 3 KiB of records per (wave, chunk)
+        // two buffers per wave; the records of chunk c+1 are copied by LDS-DMA (no VGPRs) while chunk
+        // c is consumed.  Ordering: the DMA is issued BEFORE the x prefetch of the same chunk, vmcnt
+        // retires in order, and the x prefetch is waited for before the chunk is staged.
+        char *tab_lds = smem + G::BUF_BYTES + 64 + wave * (2 * a.tabcap);
+        const char *rec_g = reinterpret_cast<const char *>(a.rec) + (int64_t)g * (a.SP / kBlock) * RECBB;
+        bool grp_unit = (DIST == 0);
+        if (kLdsTables && active) {
+#pragma unroll
+            for (int q = 0; q < QB; ++q) grp_unit = grp_unit && (a.unit[g * QB + q] != 0);
+        }
+        if (DIST == 0 && !GEN && !grp_unit) use_lds = false;  // hint was wrong for this group
+        // GEN = false on the LDS route: acc holds sum (x-mu)^2 - 2*(constants) until the end of the pass
+        bool acc_is_squares = (DIST == 0) && !GEN && use_lds;
+        auto load_tab = [&](int c) {
+            if (!use_lds || !active) return;
+            // records of chunk c plus two blocks of run-ahead for the pipeline (the stream is
+            // contiguous, so these are the first blocks of the next chunk or neutral slack)
+            const int64_t so = ((int64_t)g * NC + c) * QB;
+            const int blk0 = a.segoff[so] / kBlock;
+            int nbc = 2;
+#pragma unroll
+            for (int q = 0; q < QB; ++q) nbc += a.nblk[so + q];
+            const int bytes = min(nbc * RECBB, a.tabcap);
+            const char *src = rec_g + (int64_t)blk0 * RECBB;
+            char *dst = tab_lds + (c & 1) * a.tabcap;
+#pragma unroll
+            for (int i = 0; i < NTL; ++i) {
+                const int o = (lane + 64 * i) * 16;
+                if (o < bytes)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(src + o),
+                        (__attribute__((address_space(3))) void *)(dst + i * 1024), 16, 0, 0);
+            }
+        };
+        load_tab(0);
+        load_chunk(0);
 
         for (int c = 0; c < NC; ++c) {
             lds_barrier();  // every wave is done with the previous chunk
@@ -679,15 +806,19 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const float v = pre[i];
-                chk = fmaf(v, 0.f, chk);  // NaN iff v is NaN or +-inf
+                chk = fmaf(v, 1e20f, chk);  // non-finite iff some v is NaN, +-inf or so large that
+                                            // (v - mu)^2 could overflow (those chunks take the exact path)
                 constexpr int H = 64 / SQN;  // passes covering the first 64 samples of the tile
-                const int pos = (SPL == 2) ? ((i < H) ? 2 * SQN * i : 2 * SQN * (i - H) + 1) : SQN * i;
-                wr[pos] = v;
+                const int pos_i = (SPL == 2) ? ((i < H) ? 2 * SQN * i : 2 * SQN * (i - H) + 1) : SQN * i;
+                wr[pos_i] = v;
             }
-            if (c + 1 < NC) load_chunk(c + 1);
+            if (c + 1 < NC) {
+                load_tab(c + 1);
+                load_chunk(c + 1);
+            }
             // work-group OR of "non-finite value staged" through 8 LDS words (no __syncthreads_or:
             // its release fence is a vmcnt(0) that would drain the prefetch just issued)
-            const bool wave_bad = __any(chk != chk);
+            const bool wave_bad = __any(!(fabsf(chk) <= FLT_MAX));
             if (lane == 0) flags_lds[wave] = wave_bad ? 1 : 0;
             lds_barrier();
             int slow = 0;
@@ -697,8 +828,22 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
 
             if (active) {
                 cint_p nbp = a.nblk + ((int64_t)g * NC + c) * QB;
-                if (slow || !kPipelined) {
-                    // exact per-element path (NaN / inf evidence) or wide channel blocks
+                if (slow && acc_is_squares) {
+                    // first non-finite chunk of a unit-scale tile: bring acc to final units (the exact
+                    // terms can be as large as -FLT_MAX and must not be rescaled) and finish this tile on
+                    // the scalar-cache paths
+#pragma unroll
+                    for (int q = 0; q < QB; ++q)
+#pragma unroll
+                        for (int k = 0; k < CB; ++k)
+#pragma unroll
+                            for (int s = 0; s < SPL; ++s) acc[q][k][s] *= -0.5f;
+                    acc_is_squares = false;
+                    use_lds = false;
+                }
+                if (slow || !use_lds) {
+                    // exact per-element path (NaN / inf evidence) or wide channel blocks: tables
+                    // through the scalar cache
 #pragma unroll
                     for (int q = 0; q < QB; ++q) {
                         const int r = g * QB + q;
@@ -721,44 +866,43 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
                         }
                         pos += nb * kBlock;
                     }
-                    primed = false;
                 } else {
-                    if constexpr (kPipelined) {
-                        if (!primed) pipe.prime(fl_g, par_g, pos);
-                        primed = true;
-                        pipe.reread(lane_base);
+                    if constexpr (kLdsTables) {
+                        auto chunk_lds = [&](auto &pipe, auto mode_tag) {
+                            constexpr int MODE = decltype(mode_tag)::value;
+                            pipe.prime(tab_lds + (c & 1) * a.tabcap, lane_base);
 #pragma unroll
-                        for (int q = 0; q < QB; ++q) {
-                            const int r = g * QB + q;
-                            const int nb = nbp[q];
-                            cfloat_p bp = a.biasc + ((int64_t)r * NC + c) * I + kb;
-                            if (DIST == 0 && a.unit[r]) {
-                                float sq[CB][SPL];
-#pragma unroll
-                                for (int k = 0; k < CB; ++k)
-#pragma unroll
-                                    for (int s = 0; s < SPL; ++s) sq[k][s] = 0.f;
-                                pipe.template run<DIST, 2>(sq, lane_base, nb);
+                            for (int q = 0; q < QB; ++q) {
+                                const int r = g * QB + q;
+                                const int nb = nbp[q];
+                                cfloat_p bp = a.biasc + ((int64_t)r * NC + c) * I + kb;
+                                // unit-scale groups keep acc = sum (x-mu)^2 - 2*(constants), finished with
+                                // one multiply by -1/2 after the last chunk (kAccIsSquares)
+                                pipe.template run<DIST, MODE>(acc[q], lane_base, nb);
 #pragma unroll
                                 for (int k = 0; k < CB; ++k) {
-                                    const float bk = bp[k];
-#pragma unroll
-                                    for (int s = 0; s < SPL; ++s) acc[q][k][s] += fmaf(-0.5f, sq[k][s], bk);
-                                }
-                            } else {
-                                pipe.template run<DIST, 0>(acc[q], lane_base, nb);
-#pragma unroll
-                                for (int k = 0; k < CB; ++k) {
-                                    const float bk = bp[k];
+                                    const float bk = (MODE == 2) ? -2.0f * bp[k] : bp[k];
 #pragma unroll
                                     for (int s = 0; s < SPL; ++s) acc[q][k][s] += bk;
                                 }
+                                pos += nb * kBlock;
                             }
-                            pos += nb * kBlock;
-                        }
+                        };
+                        LdsPipe<CB, SPL, GEN> pipe;
+                        if (GEN || DIST != 0) chunk_lds(pipe, std::integral_constant<int, 0>{});
+                        else chunk_lds(pipe, std::integral_constant<int, 2>{});
                     }
                 }
             }
+        }
+
+        if (acc_is_squares) {
+#pragma unroll
+            for (int q = 0; q < QB; ++q)
+#pragma unroll
+                for (int k = 0; k < CB; ++k)
+#pragma unroll
+                    for (int s = 0; s < SPL; ++s) acc[q][k][s] *= -0.5f;
         }
 
         // ---- leaf outputs ---------------------------------------------------------
@@ -909,34 +1053,51 @@ int prepare_leaf_structure(const RatWs &w, const int64_t *mask, const uint8_t *p
 // channel block the kernels use for `I` channels: the largest of {8,4,2,1} dividing I
 static int channel_block(int I) { return (I % 8 == 0) ? 8 : (I % 4 == 0) ? 4 : (I % 2 == 0) ? 2 : 1; }
 
+struct SoftmaxJob {
+    const float *w;
+    float *W, *LW;
+    int rows, n;
+};
+
 static int prepare_leaf_tables(int dist, const RatWs &w, const int64_t *mask, const uint8_t *pad,
                                const float *p0, const float *p1, int R, int I, int CB, int d, uint32_t flags,
-                               hipStream_t st) {
+                               hipStream_t st, const SoftmaxJob *jobs = nullptr, int n_jobs = 0) {
     int rc = prepare_leaf_structure(w, mask, pad, R, d, flags, st);
     if (rc) return rc;
-    if (dist == 0)
-        hipLaunchKernelGGL(leaf_param_kernel<0>, dim3(w.G), dim3(256), 0, st, p0, p1, w.srcr, w.nblk, w.segoff, R,
-                           I, CB, d, w.NC, w.QB, w.SP, w.par, w.cel, w.biasc, w.unit);
-    else
-        hipLaunchKernelGGL(leaf_param_kernel<1>, dim3(w.G), dim3(256), 0, st, p0, p1, w.srcr, w.nblk, w.segoff, R,
-                           I, CB, d, w.NC, w.QB, w.SP, w.par, w.cel, w.biasc, w.unit);
-    DPK_CHECK_LAUNCH("leaf_param_kernel");
+    PrepArgs a{};
+    a.p0 = p0; a.p1 = p1; a.srcr = w.srcr; a.nblk = w.nblk; a.segoff = w.segoff; a.fl2 = w.fl2;
+    a.R = R; a.I = I; a.CB = CB; a.d = d; a.NC = w.NC; a.QB = w.QB; a.SP = w.SP; a.G = w.G;
+    a.par = w.par; a.cel = w.cel; a.biasc = w.biasc; a.unit = w.unit;
+    a.rec = (CB == I && CB <= 2) ? w.rec : nullptr;
+    int rows = 0;
+    for (int m = 0; m < 3; ++m) {
+        if (m < n_jobs) {
+            a.w[m] = jobs[m].w; a.W[m] = jobs[m].W; a.LW[m] = jobs[m].LW;
+            a.rows[m] = jobs[m].rows; a.n[m] = jobs[m].n;
+            rows += jobs[m].rows;
+        }
+    }
+    const int grid = w.G * kPrepSlices + cdiv(rows, 4);
+    if (dist == 0) hipLaunchKernelGGL(ratspn_prep_kernel<0>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(ratspn_prep_kernel<1>, dim3(grid), dim3(256), 0, st, a);
+    DPK_CHECK_LAUNCH("ratspn_prep_kernel");
     return DPK_OK;
 }
 
 static void fill_leaf_args(LeafArgs &a, const RatWs &w) {
     a.NC = w.NC; a.SP = w.SP;
     a.fl1 = as_const(w.fl1); a.fl2 = as_const(w.fl2); a.nblk = as_const(w.nblk);
+    a.segoff = as_const(w.segoff); a.rec = w.rec; a.tabcap = w.tabcap;
     a.par = as_const(w.par); a.cel = as_const(w.cel); a.biasc = as_const(w.biasc); a.unit = as_const(w.unit);
 }
 
-template <int DIST, int QB, int CB, int SPL, int DEPTH, int S>
-static int launch_leaf(const LeafArgs &a, hipStream_t st) {
+template <int DIST, int QB, int CB, int SPL, int DEPTH, int S, bool GEN>
+static int launch_leaf_gen(const LeafArgs &a, hipStream_t st) {
     using G = TileGeom<SPL>;
     const int grid = cdiv(a.B, G::T);
-    size_t lds = G::BUF_BYTES + 64;
+    size_t lds = G::BUF_BYTES + 64 + (size_t)kLeafWaves * 2 * a.tabcap;
     if (DEPTH > 0) lds += (size_t)2 * a.C * G::T * sizeof(float);
-    auto kern = ratspn_leaf_kernel<DIST, QB, CB, SPL, DEPTH, S>;
+    auto kern = ratspn_leaf_kernel<DIST, QB, CB, SPL, DEPTH, S, GEN>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -952,6 +1113,15 @@ static int launch_leaf(const LeafArgs &a, hipStream_t st) {
     if (ev1) (void)hipEventRecord(ev1, st);
     DPK_CHECK_LAUNCH("ratspn_leaf_kernel");
     return DPK_OK;
+}
+
+template <int DIST, int QB, int CB, int SPL, int DEPTH, int S>
+static int launch_leaf(const LeafArgs &a, hipStream_t st) {
+    // the means-only variant exists where the LDS-table pipeline does (Gaussian, CB <= 2, SPL == 2)
+    if constexpr (DIST == 0 && CB <= 2 && SPL == 2) {
+        if (a.unit_hint) return launch_leaf_gen<DIST, QB, CB, SPL, DEPTH, S, false>(a, st);
+    }
+    return launch_leaf_gen<DIST, QB, CB, SPL, DEPTH, S, true>(a, st);
 }
 
 template <int DIST>
@@ -985,6 +1155,7 @@ static int leaf_forward_common(int dist, const float *x, int64_t B, int32_t D, c
     LeafArgs a{};
     a.x = x; a.B = B; a.D = D; a.R = R; a.I = I; a.d = d;
     fill_leaf_args(a, w);
+    a.unit_hint = (flags & DPK_FLAG_UNIT_SCALE) != 0;
     a.leaf_out = out;
     return dist == 0 ? leaf_forward_dispatch<0>(a, st) : leaf_forward_dispatch<1>(a, st);
 }
@@ -1086,26 +1257,19 @@ extern "C" int dpk_ratspn_forward(const float *x, int64_t B, int32_t D, const in
     }
     if (B == 0) return DPK_OK;
     hipStream_t st = (hipStream_t)stream;
-    int rc = prepare_leaf_tables(0, w, mask, pad_mask, loc, scale, R, I, I, d, flags, st);
-    if (rc) return rc;
     const int nlast = depth >= 2 ? S : I;
-    if (depth >= 2) {
-        const int rows = reps * (Q / 2) * S;
-        hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, sum_weight0, rows,
-                           I * I, w.w[0], w.lw[0]);
-    }
-    if (depth >= 3) {
-        const int rows = reps * (Q / 4) * S;
-        hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, sum_weight1, rows,
-                           S * S, w.w[1], w.lw[1]);
-    }
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, root_weight, C,
-                       reps * nlast * nlast, w.w[2], w.lw[2]);
-    DPK_CHECK_LAUNCH("softmax_rows_kernel");
+    SoftmaxJob jobs[3];
+    int n_jobs = 0;
+    if (depth >= 2) jobs[n_jobs++] = SoftmaxJob{sum_weight0, w.w[0], w.lw[0], reps * (Q / 2) * S, I * I};
+    if (depth >= 3) jobs[n_jobs++] = SoftmaxJob{sum_weight1, w.w[1], w.lw[1], reps * (Q / 4) * S, S * S};
+    jobs[n_jobs++] = SoftmaxJob{root_weight, w.w[2], w.lw[2], C, reps * nlast * nlast};
+    int rc = prepare_leaf_tables(0, w, mask, pad_mask, loc, scale, R, I, I, d, flags, st, jobs, n_jobs);
+    if (rc) return rc;
 
     LeafArgs a{};
     a.x = x; a.B = B; a.D = D; a.R = R; a.I = I; a.d = d;
     fill_leaf_args(a, w);
+    a.unit_hint = (flags & DPK_FLAG_UNIT_SCALE) != 0;
     a.leaf_out = leaf_out;
     a.reps = reps; a.C = C;
     a.W0 = as_const(w.w[0]); a.LW0 = as_const(w.lw[0]); a.W1 = as_const(w.w[1]);

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get(  # DEEPROB_HIP_LIB: measurement builds of the same AB
     'DEEPROB_HIP_LIB', os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libdeeprob_hip.so')))
 
 DPK_FLAG_STRUCT_CACHED = 1
+DPK_FLAG_UNIT_SCALE = 2
 
 _c_void = ctypes.c_void_p
 _i64 = ctypes.c_int64

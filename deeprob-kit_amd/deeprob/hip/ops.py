@@ -10,6 +10,7 @@ import torch
 
 from deeprob.hip import (
     load_library, check, ptr, stream_ptr, require_device_f32, Workspace, DPK_FLAG_STRUCT_CACHED,
+    DPK_FLAG_UNIT_SCALE,
 )
 
 
@@ -26,7 +27,7 @@ class LeafContext:
         self.depth, self.reps, self.S, self.C = depth, reps, sums, classes
         self.ws = Workspace()
 
-    def workspace(self, device, mask, pad_mask) -> Tuple[torch.Tensor, int]:
+    def workspace(self, device, mask, pad_mask, scale=None) -> Tuple[torch.Tensor, int]:
         lib = load_library()
         n = lib.dpk_ratspn_workspace_bytes(self.D, self.R, self.d, self.I, self.depth, self.reps,
                                            max(self.S, 1), max(self.C, 1))
@@ -36,6 +37,10 @@ class LeafContext:
         key = _buffers_key(mask, pad_mask)
         flags = DPK_FLAG_STRUCT_CACHED if self.ws.struct_key == key else 0
         self.ws.struct_key = key
+        # a frozen scale parameter is the reference's "scale == 1" configuration (optimize_scale=False);
+        # only a hint: the kernels verify it on the device
+        if scale is not None and not scale.requires_grad:
+            flags |= DPK_FLAG_UNIT_SCALE
         return buf, flags
 
 
@@ -55,7 +60,7 @@ class GaussianLeafFn(torch.autograd.Function):
         B = x.shape[0]
         out = torch.empty((B, lctx.R, lctx.I), dtype=torch.float32, device=x.device)
         pad = _pad_u8(pad_mask)
-        ws, flags = lctx.workspace(x.device, mask, pad_mask)
+        ws, flags = lctx.workspace(x.device, mask, pad_mask, scale)
         check(lib.dpk_gaussian_leaf_forward(ptr(x), B, lctx.D, ptr(mask), ptr(pad), ptr(loc_c), ptr(scale_c),
                                             lctx.R, lctx.I, lctx.d, ptr(out), ptr(ws), ws.numel(), flags,
                                             stream_ptr(x.device)), 'dpk_gaussian_leaf_forward')
@@ -230,7 +235,7 @@ def ratspn_forward_fused(x, mask, pad_mask, loc, scale, sum_weights, root_weight
     rw = require_device_f32(root_weight, 'root weight')
     B = x.shape[0]
     out = torch.empty((B, lctx.C), dtype=torch.float32, device=x.device)
-    ws, flags = lctx.workspace(x.device, mask, pad_mask)
+    ws, flags = lctx.workspace(x.device, mask, pad_mask, scale)
     rc = lib.dpk_ratspn_forward(ptr(x), B, lctx.D, ptr(mask), ptr(_pad_u8(pad_mask)), ptr(loc_c), ptr(scale_c),
                                 ptr(sw[0]) if len(sw) > 0 else None, ptr(sw[1]) if len(sw) > 1 else None,
                                 ptr(rw), lctx.depth, lctx.reps, lctx.I, lctx.S, lctx.C, ptr(out), None,

@@ -49,11 +49,21 @@ class ShardedLogLikelihood:
         self.local_sum_fn = local_sum_fn
         self._pending: List[Tuple[torch.Tensor, Optional[object]]] = []
         self.last_ll: Optional[torch.Tensor] = None
+        self._pool: Optional[torch.Tensor] = None  # zeroed {sum, count} slots, one fill per 256 steps
+        self._pool_next = 0
+
+    def _acc_slot(self, device) -> torch.Tensor:
+        if self._pool is None or self._pool_next >= self._pool.shape[0] or self._pool.device != device:
+            self._pool = torch.zeros(256, 2, dtype=torch.float64, device=device)
+            self._pool_next = 0
+        slot = self._pool[self._pool_next]
+        self._pool_next += 1
+        return slot
 
     def _local(self, x: torch.Tensor, kernel_events=None) -> torch.Tensor:
         if self.local_sum_fn is not None:
             return self.local_sum_fn(x)
-        acc = torch.zeros(2, dtype=torch.float64, device=x.device)
+        acc = self._acc_slot(x.device)
         if kernel_events is not None:
             from deeprob.hip import load_library, check
             check(load_library().dpk_profile_next_kernel(kernel_events[0].cuda_event,

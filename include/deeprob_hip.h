@@ -40,6 +40,11 @@ extern "C" {
                                      pad_mask by an earlier call with the same
                                      shapes) are still valid: skip rebuilding   */
 
+#define DPK_FLAG_UNIT_SCALE 2u    /* hint: every Gaussian scale equals 1 (optimize_scale=False, the
+                                     reference default).  Selects kernels that move only the means;
+                                     the device re-checks and takes the general path where the hint
+                                     is wrong, so it never changes results                         */
+
 const char *dpk_last_error(void);
 int dpk_abi_version(void);
 
