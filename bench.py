@@ -41,7 +41,7 @@ def parse():
     ap.add_argument('--rg-batch', type=int, default=2)
     ap.add_argument('--rg-sum', type=int, default=2)
     ap.add_argument('--ring', type=int, default=0, help='distinct resident batches (0: > 256 MiB worth)')
-    ap.add_argument('--cpu-samples', type=int, default=32768, help='cpu_baseline sample size (0 = skip)')
+    ap.add_argument('--cpu-samples', type=int, default=262144, help='cpu_baseline sample size (0 = skip)')
     ap.add_argument('--no-kernel-events', action='store_true')
     return ap.parse_args()
 

@@ -371,6 +371,9 @@ struct LeafArgs {
     const float *rec; // [G][SP/4] block records for the LDS-resident tables (CB <= 2)
     int tabcap;       // bytes of LDS per wave for the records of one chunk
     int unit_hint;    // host hint: every scale is 1 (DPK_FLAG_UNIT_SCALE)
+#ifdef DPK_TIMELINE
+    unsigned long long *dbg;  // [blocks][waves][NC+2][6] s_memtime stamps (measurement builds)
+#endif
     cfloat_p par;
     cfloat_p cel;
     cfloat_p biasc;
@@ -799,8 +802,15 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
         load_tab(0);
         load_chunk(0);
 
+#ifdef DPK_TIMELINE
+#define DPK_STAMP(slot) do { if (a.dbg && lane == 0) a.dbg[(((int64_t)blockIdx.x * kLeafWaves + wave) * (NC + 2) + c) * 6 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DPK_STAMP(slot) do { } while (0)
+#endif
         for (int c = 0; c < NC; ++c) {
+            DPK_STAMP(0);
             lds_barrier();  // every wave is done with the previous chunk
+            DPK_STAMP(1);
             float chk = 0.f;
             float *wr = xs_lds + flc * ROW + (SPL == 2 ? 2 * sq : sq);
 #pragma unroll
@@ -812,19 +822,23 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
                 const int pos_i = (SPL == 2) ? ((i < H) ? 2 * SQN * i : 2 * SQN * (i - H) + 1) : SQN * i;
                 wr[pos_i] = v;
             }
-            if (c + 1 < NC) {
-                load_tab(c + 1);
-                load_chunk(c + 1);
-            }
             // work-group OR of "non-finite value staged" through 8 LDS words (no __syncthreads_or:
             // its release fence is a vmcnt(0) that would drain the prefetch just issued)
             const bool wave_bad = __any(!(fabsf(chk) <= FLT_MAX));
             if (lane == 0) flags_lds[wave] = wave_bad ? 1 : 0;
+            DPK_STAMP(2);
             lds_barrier();
+            DPK_STAMP(3);
             int slow = 0;
 #pragma unroll
             for (int w = 0; w < kLeafWaves; ++w) slow |= flags_lds[w];
             slow = __builtin_amdgcn_readfirstlane(slow);
+            // prefetch of the next chunk: issued AFTER the barrier so that no wave holds the others
+            // up with the address arithmetic and the scalar loads behind the record copy
+            if (c + 1 < NC) {
+                load_tab(c + 1);
+                load_chunk(c + 1);
+            }
 
             if (active) {
                 cint_p nbp = a.nblk + ((int64_t)g * NC + c) * QB;
@@ -891,6 +905,7 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
                         LdsPipe<CB, SPL, GEN> pipe;
                         if (GEN || DIST != 0) chunk_lds(pipe, std::integral_constant<int, 0>{});
                         else chunk_lds(pipe, std::integral_constant<int, 2>{});
+                        DPK_STAMP(4);
                     }
                 }
             }
@@ -1106,6 +1121,15 @@ static int launch_leaf_gen(const LeafArgs &a, hipStream_t st) {
             return DPK_ELAUNCH;
         }
     }
+#ifdef DPK_TIMELINE
+    {
+        static unsigned long long *dbg = nullptr;
+        if (!dbg) (void)hipMalloc(&dbg, (size_t)4096 * kLeafWaves * 64 * 6 * 8);
+        const_cast<LeafArgs &>(a).dbg = dbg;
+        FILE *f = fopen("/tmp/dpk_timeline_ptr.txt", "w");
+        if (f) { fprintf(f, "%p %d %d\n", (void *)dbg, grid, a.NC); fclose(f); }
+    }
+#endif
     hipEvent_t ev0, ev1;
     profile_take(&ev0, &ev1);
     if (ev0) (void)hipEventRecord(ev0, st);
