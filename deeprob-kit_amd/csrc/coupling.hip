@@ -1,0 +1,463 @@
+// RealNVP-1D affine / NICE coupling for gfx950: conditioner MLP (Linear -> ReLU -> Linear) on the
+// fp32 matrix cores, fused with the tanh / exp / affine / log-det epilogue.
+//
+// reference: CouplingLayer1d.apply_backward / apply_forward, deeprob/flows/layers/coupling.py:72-104
+//            (conditioner :45-56, ScaledTanh deeprob/torch/utils.py:52-70)
+//
+//   z = W2 relu(W1 (mask*x) + b1) + b2 ;  t, s = chunk(z) ; s = a tanh(s) ; t, s *= inv_mask
+//   backward (density) direction:  u = (x - t) exp(-s),  ildj = -sum_d s
+//   forward (sampling) direction:  x = u exp(s) + t,     ldj  = +sum_d s
+//
+// Mapping: a work-group of 4 waves owns 64 samples.  Only the columns where mask != 0 enter the first
+// GEMM (K1 = nnz(mask)) and only the rows where inv_mask != 0 leave the second one (N2 = nnz(inv_mask)):
+// the weights are re-packed per call into MFMA B-fragment order (coupling_pack_kernel), so a wave
+// fetches one float4 per four v_mfma_f32_32x32x2_f32 straight from L2 and no weight ever sits in LDS.
+// The x tile (A operand of GEMM 1) is staged through LDS in chunks of 64 masked columns, the hidden
+// activations H (A operand of GEMM 2) stay in LDS; t and s tiles of the same 32 variables accumulate
+// in the same wave, so the epilogue is register-local.  fp32 MFMA = exact fp32 FMA chains (1e-5 parity
+// rules out bf16).  An optional per-variable affine (in_scale, in_shift) is applied to x on load: this
+// is how an eval-mode BatchNormLayer1d in front of the coupling is folded in (flows/utils.py:118-139).
+#include "common.h"
+#include <math.h>
+
+namespace dpk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kCM = 64;        // samples per work-group
+constexpr int kCKC = 64;       // masked columns staged per chunk
+constexpr int kCWaves = 4;
+
+struct CouplingWs {
+    int *kidx;      // [K1p] variable id of the k-th masked column (-1 = padding)
+    int *nidx;      // [N2p] variable id of the n-th transformed variable (-1 = padding)
+    float *w1p;     // [U/32][K1p/8][64][4]   B fragments of GEMM 1
+    float *w2tp;    // [N2p/32][U/8][64][4]   B fragments of GEMM 2, translation rows
+    float *w2sp;    // same, log-scale rows (affine only)
+    float *b2tp;    // [N2p]
+    float *b2sp;    // [N2p]
+    int64_t bytes;
+    int K1p, N2p;
+};
+
+static inline CouplingWs carve_coupling_ws(void *base, int D, int U, int K1, int N2) {
+    CouplingWs w{};
+    char *p = (char *)base;
+    int64_t o = 0;
+    auto take = [&](int64_t n) {
+        char *q = p ? p + o : nullptr;
+        o = align_up(o + n, 256);
+        return q;
+    };
+    w.K1p = (int)align_up(K1 > 0 ? K1 : 1, kCKC);
+    w.N2p = (int)align_up(N2 > 0 ? N2 : 1, 32);
+    w.kidx = (int *)take((int64_t)w.K1p * 4);
+    w.nidx = (int *)take((int64_t)w.N2p * 4);
+    w.w1p = (float *)take((int64_t)U * w.K1p * 4);
+    w.w2tp = (float *)take((int64_t)w.N2p * U * 4);
+    w.w2sp = (float *)take((int64_t)w.N2p * U * 4);
+    w.b2tp = (float *)take((int64_t)w.N2p * 4);
+    w.b2sp = (float *)take((int64_t)w.N2p * 4);
+    w.bytes = o;
+    (void)D;
+    return w;
+}
+
+// index lists of the non-zero entries of mask / inv_mask (single block, D is small)
+__global__ void coupling_index_kernel(const float *__restrict__ mask, const float *__restrict__ inv_mask, int D,
+                                      int K1p, int N2p, int *__restrict__ kidx, int *__restrict__ nidx,
+                                      int *__restrict__ bad) {
+    if (threadIdx.x == 0) {
+        int k = 0, n = 0, nonbinary = 0;
+        for (int d = 0; d < D; ++d) {
+            const float m = mask[d], im = inv_mask[d];
+            nonbinary |= !((m == 0.f || m == 1.f) && (im == 0.f || im == 1.f));
+            if (m != 0.f && k < K1p) kidx[k++] = d;
+            if (im != 0.f && n < N2p) nidx[n++] = d;
+        }
+        for (; k < K1p; ++k) kidx[k] = -1;
+        for (; n < N2p; ++n) nidx[n] = -1;
+        *bad = nonbinary;
+    }
+}
+
+// B-fragment order of v_mfma_f32_32x32x2_f32: lane l holds B[k = l>>5][j = l&31]; four consecutive
+// k-steps are packed into one float4 per lane.
+__global__ void coupling_pack_kernel(const float *__restrict__ W1, const float *__restrict__ W2,
+                                     const float *__restrict__ b2, const int *__restrict__ kidx,
+                                     const int *__restrict__ nidx, int D, int U, int K1p, int N2p, int affine,
+                                     float *__restrict__ w1p, float *__restrict__ w2tp,
+                                     float *__restrict__ w2sp, float *__restrict__ b2tp,
+                                     float *__restrict__ b2sp) {
+    const int64_t n1 = (int64_t)U * K1p, n2 = (int64_t)N2p * U;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n1 + n2 + N2p;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        if (e < n1) {
+            // e = ((nt * (K1p/8) + ks4) * 64 + lane) * 4 + q
+            const int q = (int)(e & 3), lane = (int)((e >> 2) & 63);
+            const int64_t r = e >> 8;
+            const int ks4 = (int)(r % (K1p / 8)), nt = (int)(r / (K1p / 8));
+            const int k = 2 * (4 * ks4 + q) + (lane >> 5), j = nt * 32 + (lane & 31);
+            const int col = kidx[k];
+            w1p[e] = (col >= 0) ? W1[(int64_t)j * D + col] : 0.f;
+        } else if (e < n1 + n2) {
+            const int64_t f = e - n1;
+            const int q = (int)(f & 3), lane = (int)((f >> 2) & 63);
+            const int64_t r = f >> 8;
+            const int ks4 = (int)(r % (U / 8)), pt = (int)(r / (U / 8));
+            const int k = 2 * (4 * ks4 + q) + (lane >> 5);
+            const int var = nidx[pt * 32 + (lane & 31)];
+            w2tp[f] = (var >= 0) ? W2[(int64_t)var * U + k] : 0.f;
+            if (affine) w2sp[f] = (var >= 0) ? W2[(int64_t)(D + var) * U + k] : 0.f;
+        } else {
+            const int n = (int)(e - n1 - n2);
+            const int var = nidx[n];
+            b2tp[n] = (var >= 0) ? b2[var] : 0.f;
+            if (affine) b2sp[n] = (var >= 0) ? b2[D + var] : 0.f;
+        }
+    }
+}
+
+struct CouplingArgs {
+    const float *x;
+    float *out;
+    float *ldj;          // [B]
+    int64_t B;
+    int D, U, K1p, N2p;
+    const int *kidx, *nidx;
+    const float *w1p, *b1, *w2tp, *w2sp, *b2tp, *b2sp;
+    const float *in_scale, *in_shift;  // nullable: x <- x*in_scale + in_shift on load
+    const float *act_weight;           // ScaledTanh weight (1 float), affine only
+    int inverse;                       // 0: density direction (u, ildj); 1: sampling direction (x, ldj)
+    int accumulate;                    // ldj[b] += ... instead of =
+};
+
+// row of accumulator register `reg` for this lane (32x32 MFMA C/D layout)
+__device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+template <bool AFFINE>
+__global__ __launch_bounds__(kCWaves * 64) void coupling1d_kernel(const CouplingArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int U = a.U, D = a.D;
+    const int HS = U + 1;                      // row stride of H
+    float *hs = lds;                           // [kCM][U+1]
+    float *xs = hs + kCM * HS;                 // [kCM][kCKC+1]
+    float *ldj_lds = xs + kCM * (kCKC + 1);    // [kCWaves][kCM] per-wave partial sums (fixed order)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t b0 = (int64_t)blockIdx.x * kCM;
+    const int rows = (int)min((int64_t)kCM, a.B - b0);
+    const bool has_aff = a.in_scale != nullptr;
+
+    // ---- phase 0: pass-through copy of the tile (every variable), log-det scratch
+    for (int e = tid; e < rows * D; e += kCWaves * 64) {
+        const int r = e / D, d = e - r * D;
+        float v = a.x[(b0 + r) * D + d];
+        if (has_aff) v = fmaf(v, a.in_scale[d], a.in_shift[d]);
+        a.out[(b0 + r) * D + d] = v;
+    }
+    ldj_lds[tid] = 0.f;  // kCWaves * kCM == blockDim.x
+
+    // ---- phase 1: H = relu(Xm W1^T + b1); wave w owns hidden units [32w', 32w'+32) for w' = w, w+4, ..
+    const int n_ntiles = U / 32;
+    for (int nt0 = 0; nt0 < n_ntiles; nt0 += kCWaves) {
+        const int nt = nt0 + wave;
+        const bool nt_ok = nt < n_ntiles;
+        f32x16 acc0 = {0}, acc1 = {0};
+        for (int kc = 0; kc < a.K1p; kc += kCKC) {
+            __syncthreads();
+            for (int e = tid; e < kCM * kCKC; e += kCWaves * 64) {
+                const int r = e / kCKC, c = e - r * kCKC;
+                const int col = a.kidx[kc + c];
+                float v = 0.f;
+                if (col >= 0 && r < rows) {
+                    v = a.x[(b0 + r) * D + col];
+                    if (has_aff) v = fmaf(v, a.in_scale[col], a.in_shift[col]);
+                }
+                xs[r * (kCKC + 1) + c] = v;
+            }
+            __syncthreads();
+            if (nt_ok) {
+                const f32x4 *bp = reinterpret_cast<const f32x4 *>(a.w1p) +
+                                  ((int64_t)nt * (a.K1p / 8) + kc / 8) * 64 + lane;
+                const float *ap = xs + (lane & 31) * (kCKC + 1) + (lane >> 5);
+#pragma unroll 2
+                for (int ks4 = 0; ks4 < kCKC / 8; ++ks4) {
+                    const f32x4 b = bp[ks4 * 64];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int k = 2 * (4 * ks4 + q);
+                        const float a0 = ap[k], a1 = ap[32 * (kCKC + 1) + k];
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[q], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[q], acc1, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (nt_ok) {
+            const int col = nt * 32 + (lane & 31);
+            const float bias = a.b1[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma_row(r, lane);
+                hs[row * HS + col] = fmaxf(acc0[r] + bias, 0.f);
+                hs[(32 + row) * HS + col] = fmaxf(acc1[r] + bias, 0.f);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: z = H W2^T + b2 on the transformed variables, fused epilogue
+    const float act = AFFINE ? a.act_weight[0] : 0.f;
+    float ssum0[16], ssum1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ssum0[r] = ssum1[r] = 0.f;
+    const int n_pairs = a.N2p / 32;
+    for (int pt = wave; pt < n_pairs; pt += kCWaves) {
+        f32x16 t0 = {0}, t1 = {0}, s0 = {0}, s1 = {0};
+        const f32x4 *btp = reinterpret_cast<const f32x4 *>(a.w2tp) + (int64_t)pt * (U / 8) * 64 + lane;
+        const f32x4 *bsp = reinterpret_cast<const f32x4 *>(a.w2sp) + (int64_t)pt * (U / 8) * 64 + lane;
+        const float *ap = hs + (lane & 31) * HS + (lane >> 5);
+#pragma unroll 2
+        for (int ks4 = 0; ks4 < U / 8; ++ks4) {
+            const f32x4 bt = btp[ks4 * 64];
+            f32x4 bs = {0};
+            if (AFFINE) bs = bsp[ks4 * 64];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 2 * (4 * ks4 + q);
+                const float a0 = ap[k], a1 = ap[32 * HS + k];
+                t0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bt[q], t0, 0, 0, 0);
+                t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bt[q], t1, 0, 0, 0);
+                if (AFFINE) {
+                    s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bs[q], s0, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bs[q], s1, 0, 0, 0);
+                }
+            }
+        }
+        const int n = pt * 32 + (lane & 31);
+        const int var = a.nidx[n];
+        if (var >= 0) {
+            const float bt = a.b2tp[n], bs = AFFINE ? a.b2sp[n] : 0.f;
+            float sc = 1.f, sh = 0.f;
+            if (has_aff) {
+                sc = a.in_scale[var];
+                sh = a.in_shift[var];
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = half * 32 + mfma_row(r, lane);
+                    if (row < rows) {
+                        const float tv = (half ? t1[r] : t0[r]) + bt;
+                        const float xv = fmaf(a.x[(b0 + row) * D + var], sc, sh);
+                        float o;
+                        if (AFFINE) {
+                            const float sv = act * tanhf((half ? s1[r] : s0[r]) + bs);
+                            o = a.inverse ? fmaf(xv, expf(sv), tv) : (xv - tv) * expf(-sv);
+                            if (half) ssum1[r] += sv; else ssum0[r] += sv;
+                        } else {
+                            o = a.inverse ? xv + tv : xv - tv;
+                        }
+                        a.out[(b0 + row) * D + var] = o;
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- phase 3: log-det = -/+ sum over the transformed variables of s, per sample
+    if (AFFINE) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v0 = ssum0[r], v1 = ssum1[r];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {  // over the 32 columns held by this half-wave
+                v0 += __shfl_xor(v0, o, 64);
+                v1 += __shfl_xor(v1, o, 64);
+            }
+            if ((lane & 31) == 0) {  // one writer per (wave, row): no atomics, deterministic
+                ldj_lds[wave * kCM + mfma_row(r, lane)] = v0;
+                ldj_lds[wave * kCM + 32 + mfma_row(r, lane)] = v1;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < rows) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < kCWaves; ++w) tot += ldj_lds[w * kCM + tid];
+        const float v = AFFINE ? (a.inverse ? tot : -tot) : 0.f;
+        if (a.accumulate) a.ldj[b0 + tid] += v; else a.ldj[b0 + tid] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Eval-mode BatchNormLayer1d as a per-variable affine (flows/utils.py:118-153):
+//   backward: u = (x - mean)/sqrt(var+eps) * exp(weight) + bias,  ildj = sum(weight - log(var+eps)/2)
+//   forward : x = (u - bias) exp(-weight) sqrt(var+eps) + mean,   ldj  = -ildj
+// The kernel composes it with an incoming affine (sc_in, sh_in):  y = (x*sc_in + sh_in)*g + h.
+// ------------------------------------------------------------------------------------------------
+__global__ void bn1d_fold_kernel(const float *__restrict__ weight, const float *__restrict__ bias,
+                                 const float *__restrict__ var, const float *__restrict__ mean, float eps, int D,
+                                 int inverse, const float *__restrict__ sc_in, const float *__restrict__ sh_in,
+                                 float *__restrict__ sc_out, float *__restrict__ sh_out,
+                                 float *__restrict__ ldj_const, int accumulate) {
+    float part = 0.f;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        const float v = var[d] + eps;
+        float g, h;
+        if (!inverse) {
+            g = expf(weight[d]) / sqrtf(v);
+            h = bias[d] - mean[d] * g;
+            part += weight[d] - 0.5f * logf(v);
+        } else {
+            g = expf(-weight[d]) * sqrtf(v);
+            h = mean[d] - bias[d] * g;
+            part += -weight[d] + 0.5f * logf(v);
+        }
+        const float s0 = sc_in ? sc_in[d] : 1.f, h0 = sh_in ? sh_in[d] : 0.f;
+        sc_out[d] = s0 * g;
+        sh_out[d] = fmaf(h0, g, h);
+    }
+    part = wave_reduce_sum(part);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = red[0] + red[1] + red[2] + red[3];
+        if (accumulate) *ldj_const += tot; else *ldj_const = tot;
+    }
+}
+
+// y = x*scale + shift (per variable), grid-stride, coalesced
+__global__ void affine1d_kernel(const float *__restrict__ x, const float *__restrict__ sc,
+                                const float *__restrict__ sh, int64_t total, int D, float *__restrict__ out) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(e % D);
+        out[e] = fmaf(x[e], sc[d], sh[d]);
+    }
+}
+
+// out[b] = sum_d log N(u[b,d]*sc[d]+sh[d]; loc[d], scale[d]) + ildj[b] + ildj_const
+// (NormalizingFlow.forward, flows/models/base.py:139-143 with the default Normal base)
+__global__ __launch_bounds__(256) void normal_base_logprob_kernel(
+    const float *__restrict__ u, const float *__restrict__ sc, const float *__restrict__ sh,
+    const float *__restrict__ loc, const float *__restrict__ scale, const float *__restrict__ ildj,
+    const float *__restrict__ ildj_const, int64_t B, int D, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per sample
+    if (b >= B) return;
+    float acc = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        float v = u[b * D + d];
+        if (sc) v = fmaf(v, sc[d], sh[d]);
+        const float s = scale[d], dl = v - loc[d];
+        acc += -(dl * dl) / (2.f * s * s) - logf(s) - kLogSqrt2Pi;
+    }
+    acc = wave_reduce_sum(acc);
+    if (lane == 0) out[b] = acc + (ildj ? ildj[b] : 0.f) + (ildj_const ? *ildj_const : 0.f);
+}
+
+}  // namespace dpk
+
+using namespace dpk;
+
+extern "C" int64_t dpk_coupling1d_workspace_bytes(int32_t D, int32_t units, int32_t n_masked,
+                                                  int32_t n_transformed) {
+    if (D <= 0 || units <= 0 || n_masked < 0 || n_transformed < 0) return DPK_EINVAL;
+    return carve_coupling_ws(nullptr, D, units, n_masked, n_transformed).bytes + 256;
+}
+
+extern "C" int dpk_coupling1d_forward(const float *x, int64_t B, int32_t D, const float *mask,
+                                      const float *inv_mask, int32_t n_masked, int32_t n_transformed,
+                                      const float *W1, const float *b1, const float *W2, const float *b2,
+                                      int32_t units, const float *act_weight, const float *in_scale,
+                                      const float *in_shift, int32_t affine, int32_t inverse, float *out,
+                                      float *ldj, int32_t accumulate_ldj, void *ws, int64_t ws_bytes,
+                                      void *stream) {
+    DPK_REQUIRE(B >= 0 && D > 0 && units > 0, DPK_EINVAL, "coupling1d: bad sizes");
+    DPK_REQUIRE(mask && inv_mask && W1 && b1 && W2 && b2 && ws, DPK_EINVAL, "coupling1d: null pointer");
+    DPK_REQUIRE(!affine || act_weight, DPK_EINVAL, "coupling1d: affine coupling needs the ScaledTanh weight");
+    DPK_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), DPK_EINVAL, "coupling1d: scale/shift mismatch");
+    DPK_REQUIRE(units % 32 == 0 && units <= 512, DPK_EUNSUPPORTED,
+                "coupling1d: hidden units=%d not built (multiple of 32, <= 512)", units);
+    if (B == 0) return DPK_OK;
+    DPK_REQUIRE(x && out && ldj, DPK_EINVAL, "coupling1d: null pointer");
+    CouplingWs w = carve_coupling_ws(ws, D, units, n_masked, n_transformed);
+    DPK_REQUIRE(ws_bytes >= w.bytes + 256, DPK_EWORKSPACE, "coupling1d: workspace %lld < %lld",
+                (long long)ws_bytes, (long long)w.bytes + 256);
+    int *bad = (int *)((char *)ws + w.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(coupling_index_kernel, dim3(1), dim3(64), 0, st, mask, inv_mask, D, w.K1p, w.N2p, w.kidx,
+                       w.nidx, bad);
+    const int64_t n_pack = (int64_t)units * w.K1p + (int64_t)w.N2p * units + w.N2p;
+    hipLaunchKernelGGL(coupling_pack_kernel, dim3(cdiv(n_pack, 256) > 2048 ? 2048 : cdiv(n_pack, 256)), dim3(256),
+                       0, st, W1, W2, b2, w.kidx, w.nidx, D, units, w.K1p, w.N2p, affine, w.w1p, w.w2tp, w.w2sp,
+                       w.b2tp, w.b2sp);
+    DPK_CHECK_LAUNCH("coupling_pack_kernel");
+    CouplingArgs a{};
+    a.x = x; a.out = out; a.ldj = ldj; a.B = B; a.D = D; a.U = units; a.K1p = w.K1p; a.N2p = w.N2p;
+    a.kidx = w.kidx; a.nidx = w.nidx; a.w1p = w.w1p; a.b1 = b1; a.w2tp = w.w2tp; a.w2sp = w.w2sp;
+    a.b2tp = w.b2tp; a.b2sp = w.b2sp; a.in_scale = in_scale; a.in_shift = in_shift; a.act_weight = act_weight;
+    a.inverse = inverse; a.accumulate = accumulate_ldj;
+    const size_t lds = ((size_t)kCM * (units + 1) + (size_t)kCM * (kCKC + 1) + kCWaves * kCM) * sizeof(float);
+    const int grid = cdiv(B, kCM);
+    if (affine) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(coupling1d_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(coupling1d_kernel<true>, dim3(grid), dim3(kCWaves * 64), lds, st, a);
+    } else {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(coupling1d_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(coupling1d_kernel<false>, dim3(grid), dim3(kCWaves * 64), lds, st, a);
+    }
+    DPK_CHECK_LAUNCH("coupling1d_kernel");
+    return DPK_OK;
+}
+
+extern "C" int dpk_bn1d_fold(const float *weight, const float *bias, const float *running_var,
+                             const float *running_mean, float eps, int32_t D, int32_t inverse,
+                             const float *scale_in, const float *shift_in, float *scale_out, float *shift_out,
+                             float *ldj_const, int32_t accumulate, void *stream) {
+    DPK_REQUIRE(weight && bias && running_var && running_mean && scale_out && shift_out && ldj_const, DPK_EINVAL,
+                "bn1d_fold: null pointer");
+    DPK_REQUIRE(D > 0 && (scale_in == nullptr) == (shift_in == nullptr), DPK_EINVAL, "bn1d_fold: bad arguments");
+    hipLaunchKernelGGL(bn1d_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, weight, bias, running_var,
+                       running_mean, eps, D, inverse, scale_in, shift_in, scale_out, shift_out, ldj_const,
+                       accumulate);
+    DPK_CHECK_LAUNCH("bn1d_fold_kernel");
+    return DPK_OK;
+}
+
+extern "C" int dpk_affine1d_forward(const float *x, const float *scale, const float *shift, int64_t B, int32_t D,
+                                    float *out, void *stream) {
+    DPK_REQUIRE(B >= 0 && D > 0, DPK_EINVAL, "affine1d: bad sizes");
+    if (B == 0) return DPK_OK;
+    DPK_REQUIRE(x && scale && shift && out, DPK_EINVAL, "affine1d: null pointer");
+    const int64_t total = B * D;
+    int grid = cdiv(total, 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(affine1d_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, scale, shift, total, D,
+                       out);
+    DPK_CHECK_LAUNCH("affine1d_kernel");
+    return DPK_OK;
+}
+
+extern "C" int dpk_normal_base_logprob(const float *u, const float *scale_in, const float *shift_in,
+                                       const float *loc, const float *scale, const float *ildj,
+                                       const float *ildj_const, int64_t B, int32_t D, float *out, void *stream) {
+    DPK_REQUIRE(B >= 0 && D > 0, DPK_EINVAL, "normal_base_logprob: bad sizes");
+    if (B == 0) return DPK_OK;
+    DPK_REQUIRE(u && loc && scale && out, DPK_EINVAL, "normal_base_logprob: null pointer");
+    DPK_REQUIRE((scale_in == nullptr) == (shift_in == nullptr), DPK_EINVAL, "normal_base_logprob: scale/shift");
+    hipLaunchKernelGGL(normal_base_logprob_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, u,
+                       scale_in, shift_in, loc, scale, ildj, ildj_const, B, D, out);
+    DPK_CHECK_LAUNCH("normal_base_logprob_kernel");
+    return DPK_OK;
+}

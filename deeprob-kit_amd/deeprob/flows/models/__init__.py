@@ -1,0 +1,2 @@
+from .base import NormalizingFlow
+from .realnvp import RealNVP1d

@@ -1,0 +1,129 @@
+"""Bijector pieces of the 1-D flows behind the reference interface (deeprob/flows/utils.py).
+
+`Bijector`, `BatchNormLayer1d`, `DequantizeLayer`, `LogitLayer` keep the reference's constructor
+signatures, attributes and `state_dict` names.  Eval-mode batch norm runs on the HIP kernels (a
+per-variable affine, foldable into the next coupling); Dequantize / Logit are cheap element-wise
+device ops left to PyTorch, as SURVEY 2#7 allows (Dequantize is stochastic in the reference too).
+The 2-D pieces (squeeze, BatchNormLayer2d) are out of scope (RealNVP2d only).
+"""
+import abc
+from typing import Union, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from deeprob.hip import HipError
+
+
+class Bijector(abc.ABC, nn.Module):
+    """Invertible transformation with a tractable log-det-Jacobian (reference :41-88)."""
+
+    def __init__(self, in_features: Union[int, Tuple[int, int, int]]):
+        if isinstance(in_features, torch.Size):
+            in_features = tuple(in_features)
+        if not isinstance(in_features, int):
+            if not isinstance(in_features, tuple) or len(in_features) != 3:
+                raise ValueError("The number of input features must be either an int or a (C, H, W) tuple")
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = in_features
+
+    def forward(self, x: torch.Tensor, backward: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+        return self.apply_backward(x) if backward else self.apply_forward(x)
+
+    @abc.abstractmethod
+    def apply_backward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """data -> latent; returns (u, inverse log-det-Jacobian)."""
+
+    @abc.abstractmethod
+    def apply_forward(self, u: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """latent -> data; returns (x, log-det-Jacobian)."""
+
+
+class BatchNormLayer1d(Bijector):
+    def __init__(self, in_features: int, momentum: float = 0.9, eps: float = 1e-5):
+        """Batch normalisation as a bijector (reference :91-116): parameters `weight` (log-gain), `bias`,
+        buffers `running_var`, `running_mean`, all of shape [1, D].
+
+        :raises ValueError: if momentum is not in (0, 1) or eps is not positive."""
+        if momentum <= 0.0 or momentum >= 1.0:
+            raise ValueError("The momentum value must be in (0, 1)")
+        if eps <= 0.0:
+            raise ValueError("The epsilon value must be positive")
+        super().__init__(in_features)
+        self.momentum = momentum
+        self.eps = eps
+        self.weight = nn.Parameter(torch.zeros(1, self.in_features), requires_grad=True)
+        self.bias = nn.Parameter(torch.zeros(1, self.in_features), requires_grad=True)
+        self.register_buffer('running_var', torch.ones(1, self.in_features))
+        self.register_buffer('running_mean', torch.zeros(1, self.in_features))
+
+    def _eval_only(self):
+        if self.training:
+            raise HipError("training-mode BatchNormLayer1d (batch statistics) is not on the HIP path yet; "
+                           "call .eval()")
+
+    def apply_backward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """u = (x - mean)/sqrt(var + eps) * exp(weight) + bias (reference :118-139, eval branch)."""
+        from deeprob.hip import ops_flows
+        self._eval_only()
+        ops_flows._no_graph(x, self.weight)
+        affine, ldj = ops_flows.bn1d_fold(self, inverse=False)
+        return ops_flows.affine1d(x, affine), ldj.expand(x.shape[0])
+
+    def apply_forward(self, u: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Inverse of apply_backward with the running statistics (reference :141-153)."""
+        from deeprob.hip import ops_flows
+        ops_flows._no_graph(u, self.weight)
+        affine, ldj = ops_flows.bn1d_fold(self, inverse=True)
+        return ops_flows.affine1d(u, affine), ldj.expand(u.shape[0])
+
+
+class DequantizeLayer(Bijector):
+    def __init__(self, in_features: Union[int, Tuple[int, int, int]], n_bits: int = 8):
+        """Uniform dequantisation of `n_bits` data scaled to [0, 1] (reference :224-255).
+
+        :raises ValueError: if n_bits is not positive."""
+        if n_bits <= 0:
+            raise ValueError("The number of bits must be positive")
+        super().__init__(in_features)
+        self.n_bits = n_bits
+        self.bins = 2 ** self.n_bits
+        dims = np.prod(self.in_features)
+        self.register_buffer('ldj', torch.tensor(dims * np.log(self.bins), dtype=torch.float32))
+
+    def apply_backward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        u = (x * (self.bins - 1) + torch.rand_like(x)) / self.bins
+        return u, -self.ldj.expand(x.shape[0])
+
+    def apply_forward(self, u: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        x = torch.clamp(torch.floor(u * self.bins), min=0, max=self.bins - 1) / (self.bins - 1)
+        return x, self.ldj.expand(u.shape[0])
+
+
+class LogitLayer(Bijector):
+    def __init__(self, in_features: Union[int, Tuple[int, int, int]], alpha: float = 0.05):
+        """u = logit(alpha + (1 - 2 alpha) x) (reference :257-294).
+
+        :raises ValueError: if alpha is not in (0, 1)."""
+        if alpha <= 0.0 or alpha >= 1.0:
+            raise ValueError("The alpha logit parameter must be in (0, 1)")
+        super().__init__(in_features)
+        self.alpha = alpha
+        dims = np.prod(self.in_features)
+        self.register_buffer('ldj', torch.tensor(-dims * np.log(1.0 - 2.0 * self.alpha), dtype=torch.float32))
+
+    def apply_backward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        n = x.shape[0]
+        p = self.alpha + (1.0 - 2.0 * self.alpha) * x
+        log_p, log_q = torch.log(p), torch.log(1.0 - p)
+        ldj = torch.sum((log_p + log_q).view(n, -1), dim=1) + self.ldj
+        return log_p - log_q, -ldj
+
+    def apply_forward(self, u: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        n = u.shape[0]
+        p = torch.sigmoid(u)
+        x = (p - self.alpha) / (1.0 - 2.0 * self.alpha)
+        ldj = torch.sum((torch.log(p) + torch.log(1.0 - p)).view(n, -1), dim=1) + self.ldj
+        return x, ldj

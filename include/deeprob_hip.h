@@ -139,6 +139,47 @@ int dpk_ratspn_forward(const float *x, int64_t B, int32_t D, const int64_t *mask
                        float *out, float *leaf_out, double *ll_sum, void *ws, int64_t ws_bytes,
                        uint32_t flags, void *stream);
 
+/* ------------------------------------------------------------------------ *
+ * RealNVP-1D                                                                *
+ * ------------------------------------------------------------------------ */
+
+/* CouplingLayer1d.apply_backward (inverse = 0) / apply_forward (inverse = 1),
+ * conditioner depth 1 (deeprob/flows/layers/coupling.py:72-104, network :45-56,
+ * ScaledTanh deeprob/torch/utils.py:52-70).  One fused launch on the fp32
+ * matrix cores: Linear(D,units) -> ReLU -> Linear(units, 2D or D) -> epilogue.
+ *   x [B,D];  mask, inv_mask [D] binary floats with n_masked / n_transformed
+ *   non-zeros;  W1 [units,D], b1 [units], W2 [2D or D, units], b2 [2D or D];
+ *   act_weight [1] (ScaledTanh, affine only);  affine = 1 RealNVP, 0 NICE.
+ *   in_scale / in_shift [D] or NULL: per-variable affine applied to x on load
+ *   (an eval-mode BatchNormLayer1d in front of the layer, see dpk_bn1d_fold).
+ *   out [B,D] (must not alias x);  ldj [B] = (-/+) sum_d s, overwritten or
+ *   accumulated (accumulate_ldj).                                              */
+int64_t dpk_coupling1d_workspace_bytes(int32_t D, int32_t units, int32_t n_masked, int32_t n_transformed);
+int dpk_coupling1d_forward(const float *x, int64_t B, int32_t D, const float *mask, const float *inv_mask,
+                           int32_t n_masked, int32_t n_transformed, const float *W1, const float *b1,
+                           const float *W2, const float *b2, int32_t units, const float *act_weight,
+                           const float *in_scale, const float *in_shift, int32_t affine, int32_t inverse,
+                           float *out, float *ldj, int32_t accumulate_ldj, void *ws, int64_t ws_bytes,
+                           void *stream);
+
+/* Eval-mode BatchNormLayer1d.apply_backward (inverse = 0) / apply_forward (1)
+ * (deeprob/flows/utils.py:118-153) as a per-variable affine y = x*scale_out + shift_out
+ * composed with an optional incoming affine; ldj_const [1] = its (constant) log-det,
+ * overwritten or accumulated.  All vectors have D entries (the reference's [1,D]).   */
+int dpk_bn1d_fold(const float *weight, const float *bias, const float *running_var,
+                  const float *running_mean, float eps, int32_t D, int32_t inverse, const float *scale_in,
+                  const float *shift_in, float *scale_out, float *shift_out, float *ldj_const,
+                  int32_t accumulate, void *stream);
+/* out[b,d] = x[b,d]*scale[d] + shift[d]  (materialises a folded BatchNormLayer1d). */
+int dpk_affine1d_forward(const float *x, const float *scale, const float *shift, int64_t B, int32_t D,
+                         float *out, void *stream);
+/* NormalizingFlow.forward tail with the default Normal base (flows/models/base.py:139-143):
+ * out[b] = sum_d log N(u[b,d]*scale_in[d]+shift_in[d]; loc[d], scale[d]) + ildj[b] + ildj_const.
+ * scale_in/shift_in, ildj, ildj_const may be NULL.                                     */
+int dpk_normal_base_logprob(const float *u, const float *scale_in, const float *shift_in, const float *loc,
+                            const float *scale, const float *ildj, const float *ildj_const, int64_t B,
+                            int32_t D, float *out, void *stream);
+
 /* Measurement hook: the NEXT dominant-kernel launch made from this thread (the fused / leaf
  * forward kernel) is bracketed by hipEventRecord(ev_start) / hipEventRecord(ev_stop) on its stream,
  * so a harness can time that kernel alone inside a longer step.  One-shot; pass NULLs to cancel. */

@@ -1,0 +1,138 @@
+"""ORACLE (test infrastructure, NOT product code) -- CPU restatement of the reference's RealNVP-1D path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+Op-for-op restatement (same ATen op sequence) of
+  deeprob/flows/layers/coupling.py:72-104   CouplingLayer1d.apply_backward / apply_forward
+  deeprob/flows/utils.py:118-153            BatchNormLayer1d (eval mode)
+  deeprob/flows/utils.py:276-294            LogitLayer
+  deeprob/flows/models/base.py:123-143      NormalizingFlow.forward
+as plain functions over a state_dict.  Pinned by tests/test_oracle_flows.py against golden vectors that
+tools/gen_golden_flows.py produced from the imported reference (per-layer outputs, log-dets, LLs, inverse
+round trip) and against the reference's invertibility test (tests/test_flows.py:22-26, atol 5e-7).
+"""
+import math
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def coupling_params(sd: Dict[str, torch.Tensor], i: int):
+    p = 'layers.{}.'.format(i)
+    lins = []
+    j = 0
+    while p + 'network.{}.weight'.format(j) in sd:
+        lins.append((sd[p + 'network.{}.weight'.format(j)], sd[p + 'network.{}.bias'.format(j)]))
+        j += 2
+    return sd[p + 'mask'], sd[p + 'inv_mask'], lins, sd.get(p + 'scale_act.weight')
+
+
+def _network(h, lins):
+    """nn.Sequential(Linear, ReLU, ..., Linear) (coupling.py:45-56)."""
+    for w, b in lins[:-1]:
+        h = torch.relu(F.linear(h, w, b))
+    return F.linear(h, *lins[-1])
+
+
+def coupling_backward(x, mask, inv_mask, lins, act_w):
+    """coupling.py:72-87."""
+    z = _network(mask * x, lins)
+    if act_w is not None:
+        t, s = torch.chunk(z, chunks=2, dim=1)
+        s = act_w * torch.tanh(s)
+        t = inv_mask * t
+        s = inv_mask * s
+        return (x - t) * torch.exp(-s), -torch.sum(s, dim=1)
+    return x - inv_mask * z, torch.zeros(x.shape[0], dtype=x.dtype)
+
+
+def coupling_forward(u, mask, inv_mask, lins, act_w):
+    """coupling.py:89-104."""
+    z = _network(mask * u, lins)
+    if act_w is not None:
+        t, s = torch.chunk(z, chunks=2, dim=1)
+        s = act_w * torch.tanh(s)
+        t = inv_mask * t
+        s = inv_mask * s
+        return u * torch.exp(s) + t, torch.sum(s, dim=1)
+    return u + inv_mask * z, torch.zeros(u.shape[0], dtype=u.dtype)
+
+
+def bn_backward(x, weight, bias, var, mean, eps=1e-5):
+    """flows/utils.py:118-139, eval branch."""
+    var = var + eps
+    u = (x - mean) / torch.sqrt(var)
+    u = u * torch.exp(weight) + bias
+    return u, torch.sum(weight - 0.5 * torch.log(var)).expand(x.shape[0])
+
+
+def bn_forward(u, weight, bias, var, mean, eps=1e-5):
+    """flows/utils.py:141-153."""
+    var = var + eps
+    u = (u - bias) * torch.exp(-weight)
+    return u * torch.sqrt(var) + mean, torch.sum(-weight + 0.5 * torch.log(var)).expand(u.shape[0])
+
+
+def logit_backward(x, alpha, ldj_const):
+    """flows/utils.py:276-284."""
+    n = x.shape[0]
+    x = alpha + (1.0 - 2.0 * alpha) * x
+    lx, rx = torch.log(x), torch.log(1.0 - x)
+    return lx - rx, -(torch.sum((lx + rx).view(n, -1), dim=1) + ldj_const)
+
+
+def flow_layers(sd) -> List[Tuple[str, int]]:
+    out, i = [], 0
+    while True:
+        p = 'layers.{}.'.format(i)
+        if p + 'mask' in sd:
+            out.append(('coupling', i))
+        elif p + 'running_var' in sd:
+            out.append(('bn', i))
+        else:
+            return out
+        i += 1
+
+
+def flow_apply_backward(sd, x, collect=None):
+    """NormalizingFlow.apply_backward (base.py:182-193)."""
+    ildj = torch.zeros(x.shape[0], dtype=x.dtype)
+    for kind, i in flow_layers(sd):
+        p = 'layers.{}.'.format(i)
+        if kind == 'coupling':
+            x, d = coupling_backward(x, *coupling_params(sd, i))
+        else:
+            x, d = bn_backward(x, sd[p + 'weight'], sd[p + 'bias'], sd[p + 'running_var'], sd[p + 'running_mean'])
+        ildj = ildj + d
+        if collect is not None:
+            collect.append((x, d))
+    return x, ildj
+
+
+def flow_apply_forward(sd, u):
+    """NormalizingFlow.apply_forward (base.py:195-206)."""
+    ldj = torch.zeros(u.shape[0], dtype=u.dtype)
+    for kind, i in reversed(flow_layers(sd)):
+        p = 'layers.{}.'.format(i)
+        if kind == 'coupling':
+            u, d = coupling_forward(u, *coupling_params(sd, i))
+        else:
+            u, d = bn_forward(u, sd[p + 'weight'], sd[p + 'bias'], sd[p + 'running_var'], sd[p + 'running_mean'])
+        ldj = ldj + d
+    return u, ldj
+
+
+def flow_log_prob(sd, x, logit_alpha=None):
+    """NormalizingFlow.forward with the default Normal base (base.py:123-143)."""
+    n = x.shape[0]
+    ildj = torch.zeros(n, dtype=x.dtype)
+    if logit_alpha is not None:
+        x, d = logit_backward(x, logit_alpha, sd['logit.ldj'])
+        ildj = ildj + d
+    u, d = flow_apply_backward(sd, x)
+    ildj = ildj + d
+    loc, scale = sd['in_base_loc'], sd['in_base_scale']
+    lp = -((u - loc) ** 2) / (2 * scale ** 2) - scale.log() - math.log(math.sqrt(2 * math.pi))
+    return torch.sum(lp.view(n, -1), dim=1) + ildj

@@ -1,0 +1,91 @@
+"""Parity of the HIP RealNVP-1D path (fused MFMA coupling, folded batch norm) with reference vectors."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import flows_oracle as forc
+from tests.flow_cases import CASES, build_flow
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_log_prob_golden(golden, name):
+    g = golden(name)
+    model = build_flow(name, g).cuda()
+    with torch.no_grad():
+        ll = model(torch.from_numpy(g['x']).cuda())
+    assert ll.shape == g['ll'].shape
+    assert rel_err(ll.cpu().numpy(), g['ll']) <= TOL
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_layers_and_inverse_golden(golden, name):
+    g = golden(name)
+    model = build_flow(name, g).cuda()
+    x = torch.from_numpy(g['x']).cuda()
+    with torch.no_grad():
+        h = x
+        for i, layer in enumerate(model.layers):
+            h, d = layer.apply_backward(h)
+            if 'layer{}.u'.format(i) in g.files:
+                assert rel_err(h.cpu().numpy(), g['layer{}.u'.format(i)]) <= TOL, i
+                assert rel_err(d.cpu().numpy(), g['layer{}.ildj'.format(i)]) <= TOL, i
+        u, ildj = model.apply_backward(x)
+        xr, ldj = model.apply_forward(u)
+    assert rel_err(u.cpu().numpy(), g['u']) <= TOL
+    assert rel_err(ildj.cpu().numpy(), g['ildj']) <= TOL
+    assert rel_err(xr.cpu().numpy(), g['x_rec']) <= 2e-5   # two passes
+    assert rel_err(ldj.cpu().numpy(), g['ldj']) <= TOL
+
+
+def test_invertibility_like_reference():
+    """Reference tests/test_flows.py:22-26,65-75 on the HIP path."""
+    from deeprob.flows.models import RealNVP1d
+    torch.manual_seed(42)
+    x = torch.rand(32, 192, device='cuda')
+    for kw in [dict(batch_norm=True, affine=True), dict(batch_norm=False, affine=True),
+               dict(batch_norm=True, affine=False)]:
+        flow = RealNVP1d(192, **kw).cuda().eval()
+        with torch.no_grad():
+            u, ildj = flow.apply_backward(x)
+            xr, ldj = flow.apply_forward(u)
+        assert torch.allclose(ildj, -ldj, atol=5e-7) and torch.allclose(xr, x, atol=5e-7)
+    for bad in (dict(n_flows=0), dict(depth=0), dict(units=0)):
+        with pytest.raises(ValueError):
+            RealNVP1d(10, **bad)
+
+
+@pytest.mark.parametrize('B', [1, 63, 65, 1000])
+def test_ragged_batches_vs_oracle(golden, B):
+    g = golden('realnvp1d_15')
+    model = build_flow('realnvp1d_15', g)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    x = torch.randn(B, 15, generator=torch.Generator().manual_seed(B))
+    want = forc.flow_log_prob(sd, x).numpy()
+    with torch.no_grad():
+        got = model.cuda()(x.cuda()).cpu().numpy()
+    assert rel_err(got, want) <= TOL
+
+
+def test_full_size_round_trip():
+    """BASELINE config 5 at full batch: 65536 x 784 through 5 couplings + BN; size-independent properties:
+    apply_forward(apply_backward(x)) == x and ldj == -ildj, and slice independence."""
+    from deeprob.flows.models import RealNVP1d
+    from tests.util import randomise_flow
+    torch.manual_seed(10)
+    flow = RealNVP1d(784)
+    randomise_flow(flow, 11)
+    flow = flow.cuda().eval()
+    x = torch.randn(65536, 784, device='cuda', generator=torch.Generator('cuda').manual_seed(0))
+    with torch.no_grad():
+        ll = flow(x)
+        u, ildj = flow.apply_backward(x)
+        xr, ldj = flow.apply_forward(u)
+        part = flow(x[777:777 + 4097])
+    assert torch.isfinite(ll).all()
+    assert torch.allclose(xr, x, atol=2e-4, rtol=1e-4)
+    assert torch.allclose(ldj, -ildj, atol=1e-3, rtol=1e-5)
+    assert torch.equal(ll[777:777 + 4097], part)

@@ -31,3 +31,22 @@ def state_to_model(model, npz, device=None):
     if device is not None:
         model.to(device)
     return model
+
+
+def randomise_flow(model, seed):
+    """Same perturbation as tools/gen_golden_flows.py::_randomise_flow (the 784-variable flow fixtures ship
+    seeds instead of 6 MB of weights; the parameters are rebuilt from the same torch RNG stream)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith('scale_act.weight'):
+                p.fill_(0.3 + 0.4 * torch.rand(1, generator=g).item())
+            elif '.network.' in name:
+                p.add_(0.02 * torch.randn(p.shape, generator=g))
+            elif name.endswith('.weight') or name.endswith('.bias'):
+                p.copy_(0.3 * torch.randn(p.shape, generator=g))
+        for name, b in model.named_buffers():
+            if name.endswith('running_var'):
+                b.copy_(0.5 + torch.rand(b.shape, generator=g))
+            elif name.endswith('running_mean'):
+                b.copy_(0.5 * torch.randn(b.shape, generator=g))

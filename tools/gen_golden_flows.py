@@ -1,0 +1,73 @@
+"""Golden vectors for the RealNVP-1D path and the DGC-SPN path (imported by tools/gen_golden.py; needs the
+reference on PYTHONPATH)."""
+import numpy as np
+import torch
+
+from gen_golden import _np, _sd, _save
+
+
+def _randomise_flow(model, seed):
+    """Default init makes s == 0 and BN the identity; perturb every parameter / running statistic so that
+    all code paths carry signal."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith('scale_act.weight'):
+                p.fill_(0.3 + 0.4 * torch.rand(1, generator=g).item())
+            elif '.network.' in name:
+                p.add_(0.02 * torch.randn(p.shape, generator=g))
+            elif name.endswith('.weight') or name.endswith('.bias'):      # batch norm log-gain / bias
+                p.copy_(0.3 * torch.randn(p.shape, generator=g))
+        for name, b in model.named_buffers():
+            if name.endswith('running_var'):
+                b.copy_(0.5 + torch.rand(b.shape, generator=g))
+            elif name.endswith('running_mean'):
+                b.copy_(0.5 * torch.randn(b.shape, generator=g))
+
+
+def _flow_fixture(name, model, x, store_state=True, layers=None):
+    """store_state=False: the test rebuilds the parameters from the seeds (same torch RNG stream and the
+    same _randomise_flow, which tests/util.py restates) instead of shipping ~6 MB of weights."""
+    model.eval()
+    arrays = _sd(model) if store_state else {}
+    arrays['x'] = _np(x)
+    with torch.no_grad():
+        arrays['ll'] = _np(model(x))
+        u, ildj = model.apply_backward(x)
+        arrays['u'] = _np(u)
+        arrays['ildj'] = _np(ildj if torch.is_tensor(ildj) else torch.zeros(x.shape[0]))
+        xr, ldj = model.apply_forward(u)
+        arrays['x_rec'] = _np(xr)
+        arrays['ldj'] = _np(ldj if torch.is_tensor(ldj) else torch.zeros(x.shape[0]))
+        h = x
+        for i, layer in enumerate(model.layers):
+            h, d = layer.apply_backward(h)
+            if layers is None or i in layers:
+                arrays['layer{}.u'.format(i)] = _np(h)
+                arrays['layer{}.ildj'.format(i)] = _np(d if torch.is_tensor(d) else torch.zeros(x.shape[0]))
+    _save(name, **arrays)
+
+
+def gen_flows():
+    from deeprob.flows.models.realnvp import RealNVP1d
+    x = torch.randn(70, 784, generator=torch.Generator().manual_seed(0))
+    for tag, kw in [('bn_affine', dict()), ('nobn_affine', dict(batch_norm=False)),
+                    ('bn_nice', dict(affine=False)), ('u64', dict(units=64, n_flows=3))]:
+        torch.manual_seed(10)
+        m = RealNVP1d(784, **kw)
+        _randomise_flow(m, 11)
+        _flow_fixture('realnvp1d_784_' + tag, m, x, store_state=False, layers=(0, 1))
+    # logit preprocessing (deterministic; dequantize is stochastic and left out), data in [0, 1]
+    torch.manual_seed(12)
+    m = RealNVP1d(100, logit=0.05, n_flows=4, units=96)
+    _randomise_flow(m, 13)
+    _flow_fixture('realnvp1d_100_logit', m, torch.rand(37, 100, generator=torch.Generator().manual_seed(1)))
+    # odd number of variables: mask and inv_mask have different sizes
+    torch.manual_seed(14)
+    m = RealNVP1d(15, n_flows=2, units=32)
+    _randomise_flow(m, 15)
+    _flow_fixture('realnvp1d_15', m, torch.randn(9, 15, generator=torch.Generator().manual_seed(2)))
+
+
+def gen_dgcspn():
+    pass
