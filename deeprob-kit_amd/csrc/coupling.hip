@@ -64,22 +64,34 @@ static inline CouplingWs carve_coupling_ws(void *base, int D, int U, int K1, int
     return w;
 }
 
-// index lists of the non-zero entries of mask / inv_mask (single block, D is small)
-__global__ void coupling_index_kernel(const float *__restrict__ mask, const float *__restrict__ inv_mask, int D,
-                                      int K1p, int N2p, int *__restrict__ kidx, int *__restrict__ nidx,
-                                      int *__restrict__ bad) {
-    if (threadIdx.x == 0) {
-        int k = 0, n = 0, nonbinary = 0;
-        for (int d = 0; d < D; ++d) {
-            const float m = mask[d], im = inv_mask[d];
-            nonbinary |= !((m == 0.f || m == 1.f) && (im == 0.f || im == 1.f));
-            if (m != 0.f && k < K1p) kidx[k++] = d;
-            if (im != 0.f && n < N2p) nidx[n++] = d;
+// index lists of the non-zero entries of mask / inv_mask: one wave, ballot compaction (order preserved)
+__global__ __launch_bounds__(64) void coupling_index_kernel(const float *__restrict__ mask,
+                                                           const float *__restrict__ inv_mask, int D, int K1p,
+                                                           int N2p, int *__restrict__ kidx,
+                                                           int *__restrict__ nidx, int *__restrict__ bad) {
+    const int lane = threadIdx.x;
+    int kbase = 0, nbase = 0, nonbinary = 0;
+    for (int d0 = 0; d0 < D; d0 += 64) {
+        const int d = d0 + lane;
+        const float m = d < D ? mask[d] : 0.f, im = d < D ? inv_mask[d] : 0.f;
+        nonbinary |= !((m == 0.f || m == 1.f) && (im == 0.f || im == 1.f));
+        const unsigned long long bm = __ballot(m != 0.f), bi = __ballot(im != 0.f);
+        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        if (m != 0.f) {
+            const int pos = kbase + __popcll(bm & below);
+            if (pos < K1p) kidx[pos] = d;
         }
-        for (; k < K1p; ++k) kidx[k] = -1;
-        for (; n < N2p; ++n) nidx[n] = -1;
-        *bad = nonbinary;
+        if (im != 0.f) {
+            const int pos = nbase + __popcll(bi & below);
+            if (pos < N2p) nidx[pos] = d;
+        }
+        kbase += __popcll(bm);
+        nbase += __popcll(bi);
     }
+    for (int k = kbase + lane; k < K1p; k += 64) kidx[k] = -1;
+    for (int n = nbase + lane; n < N2p; n += 64) nidx[n] = -1;
+    if (__any(nonbinary) && lane == 0) *bad = 1;
+    else if (lane == 0) *bad = 0;
 }
 
 // B-fragment order of v_mfma_f32_32x32x2_f32: lane l holds B[k = l>>5][j = l&31]; four consecutive

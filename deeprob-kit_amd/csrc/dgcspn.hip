@@ -1,0 +1,443 @@
+// DGC-SPN spatial layers for gfx950 (reference: deeprob/spn/layers/dgcspn.py).
+//
+// All tensors are NCHW fp32 like the reference.  Lanes run over pixels (w fastest), so activations
+// and the position-dependent sum weights [Cout, Cin, H, W] are read coalesced; the batch is the outer
+// (grid-stride) dimension.  These are streaming kernels: the roofline is HBM bandwidth on the
+// activation tensors (588 KB/sample for config 4).
+//   spatial_gaussian : SpatialGaussianLayer.forward  dgcspn.py:101-120
+//   spatial_product  : SpatialProductLayer.forward   dgcspn.py:224-236 (F.pad + F.conv2d with ones /
+//                      one-hot kernels == a sum of kh*kw dilated taps)
+//   spatial_sum      : SpatialSumLayer.forward       dgcspn.py:289-304
+// SpatialRootLayer.forward (:343-355) is dpk_root_forward on the flattened map.
+#include "common.h"
+#include <math.h>
+
+namespace dpk {
+
+static inline int grid_cap(int64_t total, int block, int cap = 16384) {
+    int64_t g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gaussian leaves: y[b,k,p] = sum_c nan_to_num(log N(x[b,c,p]; loc[k,c,p], scale[k,c,p]))
+// ------------------------------------------------------------------------------------------------
+__global__ void spatial_gaussian_fwd_kernel(const float *__restrict__ x, const float *__restrict__ loc,
+                                            const float *__restrict__ scale, int64_t B, int K, int C, int HW,
+                                            float *__restrict__ out) {
+    const int64_t total = B * K * HW;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(e % HW);
+        const int64_t bk = e / HW;
+        const int k = (int)(bk % K);
+        const int64_t b = bk / K;
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float xv = x[(b * C + c) * HW + p];
+            const float mu = loc[((int64_t)k * C + c) * HW + p], sg = scale[((int64_t)k * C + c) * HW + p];
+            const float d = xv - mu;
+            acc += nan_to_num_f(-(d * d) / (2.f * sg * sg) - logf(sg) - kLogSqrt2Pi);
+        }
+        out[e] = acc;
+    }
+}
+
+// d/dx: gx[b,c,p] = sum_k g[b,k,p] * (-(x-mu)/s^2) (0 where x is NaN)
+__global__ void spatial_gaussian_bwd_x_kernel(const float *__restrict__ x, const float *__restrict__ g,
+                                              const float *__restrict__ loc, const float *__restrict__ scale,
+                                              int64_t B, int K, int C, int HW, float *__restrict__ gx) {
+    const int64_t total = B * C * HW;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(e % HW);
+        const int64_t bc = e / HW;
+        const int c = (int)(bc % C);
+        const int64_t b = bc / C;
+        const float xv = x[e];
+        float acc = 0.f;
+        if (xv == xv) {
+            for (int k = 0; k < K; ++k) {
+                const float sg = scale[((int64_t)k * C + c) * HW + p];
+                acc = fmaf(g[(b * K + k) * HW + p], -(xv - loc[((int64_t)k * C + c) * HW + p]) / (sg * sg), acc);
+            }
+        }
+        gx[e] = acc;
+    }
+}
+
+// parameter gradients: one thread per (k,c,p), a slice of the batch per blockIdx.y, one atomic per slice
+__global__ void spatial_gaussian_bwd_p_kernel(const float *__restrict__ x, const float *__restrict__ g,
+                                              const float *__restrict__ loc, const float *__restrict__ scale,
+                                              int64_t B, int K, int C, int HW, int bslice,
+                                              float *__restrict__ gloc, float *__restrict__ gscale) {
+    const int64_t n = (int64_t)K * C * HW;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int p = (int)(e % HW);
+    const int64_t kc = e / HW;
+    const int c = (int)(kc % C), k = (int)(kc / C);
+    const float mu = loc[e], sg = scale[e];
+    const float iv = 1.f / (sg * sg), is = 1.f / sg;
+    const int64_t b0 = (int64_t)blockIdx.y * bslice, b1 = min(b0 + bslice, B);
+    float a0 = 0.f, a1 = 0.f;
+    for (int64_t b = b0; b < b1; ++b) {
+        const float xv = x[(b * C + c) * HW + p];
+        if (xv == xv) {
+            const float gv = g[(b * K + k) * HW + p], d = xv - mu;
+            a0 = fmaf(gv, d * iv, a0);
+            a1 = fmaf(gv, d * d * iv * is - is, a1);
+        }
+    }
+    if (gloc) atomicAdd(gloc + e, a0);
+    if (gscale) atomicAdd(gscale + e, a1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Product layer geometry (kh x kw taps, dilation, stride, zero padding on the left / top)
+// ------------------------------------------------------------------------------------------------
+struct ProdGeom {
+    int C, H, W;        // input
+    int OC, OH, OW;     // output
+    int kh, kw, sh, sw, dh, dw, pt, pl;
+    int depthwise;
+};
+
+__device__ __forceinline__ int ipow(int base, int e) {
+    int r = 1;
+    for (int i = 0; i < e; ++i) r *= base;
+    return r;
+}
+
+__global__ void spatial_product_fwd_kernel(const float *__restrict__ in, int64_t B, ProdGeom q,
+                                           float *__restrict__ out) {
+    const int OHW = q.OH * q.OW, T = q.kh * q.kw;
+    const int64_t total = B * q.OC * OHW;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int op = (int)(e % OHW);
+        const int64_t bo = e / OHW;
+        const int oc = (int)(bo % q.OC);
+        const int64_t b = bo / q.OC;
+        const int oh = op / q.OW, ow = op - oh * q.OW;
+        float acc = 0.f;
+        int div = q.depthwise ? 1 : ipow(q.C, T - 1);
+        for (int t = 0; t < T; ++t) {
+            const int th = t / q.kw, tw = t - th * q.kw;
+            const int ih = oh * q.sh - q.pt + th * q.dh, iw = ow * q.sw - q.pl + tw * q.dw;
+            // non-depthwise: output channel = combination (c_0..c_{T-1}) in itertools.product order
+            const int c = q.depthwise ? oc : (oc / div) % q.C;
+            if (!q.depthwise) div /= q.C;
+            if (ih >= 0 && ih < q.H && iw >= 0 && iw < q.W) acc += in[((b * q.C + c) * q.H + ih) * q.W + iw];
+        }
+        out[e] = acc;
+    }
+}
+
+// gin[b,c,ih,iw] = sum of g over every (output channel, tap, output pixel) that read it
+__global__ void spatial_product_bwd_kernel(const float *__restrict__ g, int64_t B, ProdGeom q,
+                                           float *__restrict__ gin) {
+    const int HW = q.H * q.W, T = q.kh * q.kw;
+    const int64_t total = B * q.C * HW;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int ip = (int)(e % HW);
+        const int64_t bc = e / HW;
+        const int c = (int)(bc % q.C);
+        const int64_t b = bc / q.C;
+        const int ih = ip / q.W, iw = ip - ih * q.W;
+        float acc = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const int th = t / q.kw, tw = t - th * q.kw;
+            const int nh = ih + q.pt - th * q.dh, nw = iw + q.pl - tw * q.dw;
+            if (nh < 0 || nw < 0 || nh % q.sh || nw % q.sw) continue;
+            const int oh = nh / q.sh, ow = nw / q.sw;
+            if (oh >= q.OH || ow >= q.OW) continue;
+            if (q.depthwise) {
+                acc += g[((b * q.OC + c) * q.OH + oh) * q.OW + ow];
+            } else {
+                // all combinations whose digit t equals c: hi * C^(T-t) + c * C^(T-1-t) + lo
+                const int lo_n = ipow(q.C, T - 1 - t), hi_n = ipow(q.C, t);
+                for (int hi = 0; hi < hi_n; ++hi)
+                    for (int lo = 0; lo < lo_n; ++lo) {
+                        const int oc = (hi * q.C + c) * lo_n + lo;
+                        acc += g[((b * q.OC + oc) * q.OH + oh) * q.OW + ow];
+                    }
+            }
+        }
+        gin[e] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sum layer: out[b,o,p] = logsumexp_c(x[b,c,p] + log_softmax(weight, 1)[o,c,p])
+// ------------------------------------------------------------------------------------------------
+// softmax over the input channels for every (o, p): W, LW [Cout, Cin, HW]
+__global__ void spatial_softmax_kernel(const float *__restrict__ w, int Cout, int Cin, int HW,
+                                       float *__restrict__ Wl, float *__restrict__ LW) {
+    const int64_t n = (int64_t)Cout * HW;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(e % HW), o = (int)(e / HW);
+        const float *src = w + (int64_t)o * Cin * HW + p;
+        float m = -INFINITY;
+        for (int c = 0; c < Cin; ++c) m = fmaxf(m, src[(int64_t)c * HW]);
+        float s = 0.f;
+        for (int c = 0; c < Cin; ++c) s += expf(src[(int64_t)c * HW] - m);
+        // W by (correctly rounded) division: rows sum to 1 without the common-mode error that
+        // exp(w - m - log s) inherits from the rounding of log s
+        const float ls = logf(s);
+        for (int c = 0; c < Cin; ++c) {
+            const float d = src[(int64_t)c * HW] - m;
+            LW[((int64_t)o * Cin + c) * HW + p] = d - ls;
+            Wl[((int64_t)o * Cin + c) * HW + p] = expf(d) / s;
+        }
+    }
+}
+
+// thread per (b, p); exp-domain with the row maximum, exact two-pass fallback when the scaled sum
+// vanishes (same policy as the RAT-SPN sum layer).  CMAX > 0: the Cin <= CMAX exponentials live in
+// registers and are computed once; CMAX == 0: any Cin, exponentials recomputed per output channel.
+// expf / logf are the correctly-rounded-to-1-ulp OCML versions on purpose: the fast intrinsics are
+// biased near 1, and the bias is amplified 4x by every product level above.
+template <int CMAX>
+__global__ void spatial_sum_fwd_kernel(const float *__restrict__ x, const float *__restrict__ Wl,
+                                       const float *__restrict__ LW, int64_t B, int Cin, int Cout, int HW,
+                                       float *__restrict__ out) {
+    const int64_t total = B * HW;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(e % HW);
+        const int64_t b = e / HW;
+        const float *xp = x + b * Cin * HW + p;
+        float ev[CMAX > 0 ? CMAX : 1];
+        float m = -INFINITY;
+        if (CMAX > 0) {
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) {
+                ev[c] = c < Cin ? xp[(int64_t)c * HW] : -INFINITY;
+                m = fmaxf(m, ev[c]);
+            }
+        } else {
+            for (int c = 0; c < Cin; ++c) m = fmaxf(m, xp[(int64_t)c * HW]);
+        }
+        const float m0 = (m == -INFINITY) ? 0.f : m;
+        if (CMAX > 0) {
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) ev[c] = expf(ev[c] - m0);
+        }
+        for (int o = 0; o < Cout; ++o) {
+            const float *wp = Wl + (int64_t)o * Cin * HW + p;
+            float v = 0.f;
+            if (CMAX > 0) {
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c)
+                    if (c < Cin) v = fmaf(wp[(int64_t)c * HW], ev[c], v);
+            } else {
+                for (int c = 0; c < Cin; ++c) v = fmaf(wp[(int64_t)c * HW], expf(xp[(int64_t)c * HW] - m0), v);
+            }
+            float r;
+            if (v < 1e-30f) {
+                const float *lp = LW + (int64_t)o * Cin * HW + p;
+                float mm = -INFINITY;
+                for (int c = 0; c < Cin; ++c) mm = fmaxf(mm, xp[(int64_t)c * HW] + lp[(int64_t)c * HW]);
+                if (mm > -INFINITY) {
+                    float s = 0.f;
+                    for (int c = 0; c < Cin; ++c) s += expf(xp[(int64_t)c * HW] + lp[(int64_t)c * HW] - mm);
+                    r = mm + logf(s);
+                } else {
+                    r = -INFINITY;
+                }
+            } else {
+                r = m0 + logf(v);
+            }
+            out[(b * Cout + o) * HW + p] = r;
+        }
+    }
+}
+
+// backward: pi = exp(x_c + lw[o,c,p] - out[o]);  gx[b,c,p] = sum_o g pi;  glw[o,c,p] = sum_b g pi
+__global__ void spatial_sum_bwd_kernel(const float *__restrict__ x, const float *__restrict__ LW,
+                                       const float *__restrict__ out, const float *__restrict__ g, int64_t B,
+                                       int Cin, int Cout, int HW, int bslice, float *__restrict__ gx,
+                                       float *__restrict__ glw) {
+    const int64_t n = (int64_t)Cin * HW;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (c, p)
+    if (e >= n) return;
+    const int p = (int)(e % HW), c = (int)(e / HW);
+    const int64_t b0 = (int64_t)blockIdx.y * bslice, b1 = min(b0 + bslice, B);
+    for (int o = 0; o < Cout; ++o) {
+        const float lw = LW[((int64_t)o * Cin + c) * HW + p];
+        float acc = 0.f;
+        for (int64_t b = b0; b < b1; ++b) {
+            const float xo = out[(b * Cout + o) * HW + p];
+            float t = 0.f;
+            if (xo > -INFINITY) t = g[(b * Cout + o) * HW + p] * expf(x[(b * Cin + c) * HW + p] + lw - xo);
+            acc += t;
+            if (gx) {
+                float *dst = gx + (b * Cin + c) * HW + p;
+                *dst = (o == 0) ? t : (*dst + t);
+            }
+        }
+        if (glw) atomicAdd(glw + ((int64_t)o * Cin + c) * HW + p, acc);
+    }
+}
+
+// gW[o,c,p] = glw[o,c,p] - W[o,c,p] * sum_c glw[o,c,p]
+__global__ void spatial_softmax_jacobian_kernel(const float *__restrict__ glw, const float *__restrict__ Wl,
+                                                int Cout, int Cin, int HW, float *__restrict__ gW) {
+    const int64_t n = (int64_t)Cout * HW;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(e % HW), o = (int)(e / HW);
+        float s = 0.f;
+        for (int c = 0; c < Cin; ++c) s += glw[((int64_t)o * Cin + c) * HW + p];
+        for (int c = 0; c < Cin; ++c) {
+            const int64_t i = ((int64_t)o * Cin + c) * HW + p;
+            gW[i] = glw[i] - Wl[i] * s;
+        }
+    }
+}
+
+}  // namespace dpk
+
+using namespace dpk;
+
+extern "C" int dpk_spatial_gaussian_forward(const float *x, const float *loc, const float *scale, int64_t B,
+                                            int32_t K, int32_t C, int32_t H, int32_t W, float *out, void *stream) {
+    DPK_REQUIRE(B >= 0 && K > 0 && C > 0 && H > 0 && W > 0, DPK_EINVAL, "spatial_gaussian: bad sizes");
+    if (B == 0) return DPK_OK;
+    DPK_REQUIRE(x && loc && scale && out, DPK_EINVAL, "spatial_gaussian: null pointer");
+    const int64_t total = B * K * H * W;
+    hipLaunchKernelGGL(spatial_gaussian_fwd_kernel, dim3(grid_cap(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, loc, scale, B, K, C, H * W, out);
+    DPK_CHECK_LAUNCH("spatial_gaussian_fwd_kernel");
+    return DPK_OK;
+}
+
+extern "C" int dpk_spatial_gaussian_backward(const float *x, const float *g, const float *loc, const float *scale,
+                                             int64_t B, int32_t K, int32_t C, int32_t H, int32_t W, float *grad_loc,
+                                             float *grad_scale, float *grad_x, void *stream) {
+    DPK_REQUIRE(B >= 0 && K > 0 && C > 0 && H > 0 && W > 0, DPK_EINVAL, "spatial_gaussian_backward: bad sizes");
+    DPK_REQUIRE(loc && scale, DPK_EINVAL, "spatial_gaussian_backward: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int HW = H * W;
+    const size_t pbytes = (size_t)K * C * HW * 4;
+    if (grad_loc) DPK_REQUIRE(hipMemsetAsync(grad_loc, 0, pbytes, st) == hipSuccess, DPK_ELAUNCH, "memset");
+    if (grad_scale) DPK_REQUIRE(hipMemsetAsync(grad_scale, 0, pbytes, st) == hipSuccess, DPK_ELAUNCH, "memset");
+    if (B == 0) return DPK_OK;
+    DPK_REQUIRE(x && g, DPK_EINVAL, "spatial_gaussian_backward: null pointer");
+    if (grad_x)
+        hipLaunchKernelGGL(spatial_gaussian_bwd_x_kernel, dim3(grid_cap(B * C * HW, 256)), dim3(256), 0, st, x, g,
+                           loc, scale, B, K, C, HW, grad_x);
+    if (grad_loc || grad_scale) {
+        const int bslice = 64;
+        hipLaunchKernelGGL(spatial_gaussian_bwd_p_kernel, dim3(cdiv((int64_t)K * C * HW, 256), cdiv(B, bslice)),
+                           dim3(256), 0, st, x, g, loc, scale, B, K, C, HW, bslice, grad_loc, grad_scale);
+    }
+    DPK_CHECK_LAUNCH("spatial_gaussian_bwd");
+    return DPK_OK;
+}
+
+static int make_geom(ProdGeom &q, int C, int H, int W, int OC, int OH, int OW, int kh, int kw, int sh, int sw,
+                     int dh, int dw, int pt, int pl, int depthwise) {
+    DPK_REQUIRE(C > 0 && H > 0 && W > 0 && OC > 0 && OH > 0 && OW > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 &&
+                    dh > 0 && dw > 0 && pt >= 0 && pl >= 0,
+                DPK_EINVAL, "spatial_product: bad geometry");
+    if (depthwise) {
+        DPK_REQUIRE(OC == C, DPK_EINVAL, "spatial_product: depthwise needs OC == C");
+    } else {
+        int64_t want = 1;
+        for (int t = 0; t < kh * kw; ++t) want *= C;
+        DPK_REQUIRE(want == OC, DPK_EINVAL, "spatial_product: OC must be C^(kh*kw)");
+    }
+    q = ProdGeom{C, H, W, OC, OH, OW, kh, kw, sh, sw, dh, dw, pt, pl, depthwise};
+    return DPK_OK;
+}
+
+extern "C" int dpk_spatial_product_forward(const float *in, int64_t B, int32_t C, int32_t H, int32_t W, int32_t OC,
+                                           int32_t OH, int32_t OW, int32_t kh, int32_t kw, int32_t sh, int32_t sw,
+                                           int32_t dh, int32_t dw, int32_t pad_top, int32_t pad_left,
+                                           int32_t depthwise, float *out, void *stream) {
+    ProdGeom q;
+    int rc = make_geom(q, C, H, W, OC, OH, OW, kh, kw, sh, sw, dh, dw, pad_top, pad_left, depthwise);
+    if (rc) return rc;
+    if (B <= 0) return B == 0 ? DPK_OK : DPK_EINVAL;
+    DPK_REQUIRE(in && out, DPK_EINVAL, "spatial_product: null pointer");
+    hipLaunchKernelGGL(spatial_product_fwd_kernel, dim3(grid_cap(B * OC * OH * OW, 256)), dim3(256), 0,
+                       (hipStream_t)stream, in, B, q, out);
+    DPK_CHECK_LAUNCH("spatial_product_fwd_kernel");
+    return DPK_OK;
+}
+
+extern "C" int dpk_spatial_product_backward(const float *g, int64_t B, int32_t C, int32_t H, int32_t W, int32_t OC,
+                                            int32_t OH, int32_t OW, int32_t kh, int32_t kw, int32_t sh, int32_t sw,
+                                            int32_t dh, int32_t dw, int32_t pad_top, int32_t pad_left,
+                                            int32_t depthwise, float *grad_in, void *stream) {
+    ProdGeom q;
+    int rc = make_geom(q, C, H, W, OC, OH, OW, kh, kw, sh, sw, dh, dw, pad_top, pad_left, depthwise);
+    if (rc) return rc;
+    if (B <= 0) return B == 0 ? DPK_OK : DPK_EINVAL;
+    DPK_REQUIRE(g && grad_in, DPK_EINVAL, "spatial_product_backward: null pointer");
+    hipLaunchKernelGGL(spatial_product_bwd_kernel, dim3(grid_cap(B * C * H * W, 256)), dim3(256), 0,
+                       (hipStream_t)stream, g, B, q, grad_in);
+    DPK_CHECK_LAUNCH("spatial_product_bwd_kernel");
+    return DPK_OK;
+}
+
+// workspace: W, LW, glw of [Cout, Cin, H, W]
+extern "C" int64_t dpk_spatial_sum_workspace_bytes(int32_t Cin, int32_t Cout, int32_t H, int32_t W) {
+    if (Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return DPK_EINVAL;
+    return 3 * align_up((int64_t)Cout * Cin * H * W * 4, 256);
+}
+
+extern "C" int dpk_spatial_sum_forward(const float *x, const float *weight, int64_t B, int32_t Cin, int32_t Cout,
+                                       int32_t H, int32_t W, float *out, void *ws, int64_t ws_bytes, void *stream) {
+    DPK_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, DPK_EINVAL, "spatial_sum: bad sizes");
+    DPK_REQUIRE(weight && ws, DPK_EINVAL, "spatial_sum: null pointer");
+    const int HW = H * W;
+    const int64_t seg = align_up((int64_t)Cout * Cin * HW * 4, 256);
+    DPK_REQUIRE(ws_bytes >= 3 * seg, DPK_EWORKSPACE, "spatial_sum: workspace too small");
+    if (B == 0) return DPK_OK;
+    DPK_REQUIRE(x && out, DPK_EINVAL, "spatial_sum: null pointer");
+    float *Wl = (float *)ws, *LW = (float *)((char *)ws + seg);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * HW, 256)), dim3(256), 0, st, weight,
+                       Cout, Cin, HW, Wl, LW);
+    const dim3 grid(grid_cap(B * HW, 256)), block(256);
+    if (Cin <= 8)
+        hipLaunchKernelGGL(spatial_sum_fwd_kernel<8>, grid, block, 0, st, x, Wl, LW, B, Cin, Cout, HW, out);
+    else if (Cin <= 16)
+        hipLaunchKernelGGL(spatial_sum_fwd_kernel<16>, grid, block, 0, st, x, Wl, LW, B, Cin, Cout, HW, out);
+    else if (Cin <= 32)
+        hipLaunchKernelGGL(spatial_sum_fwd_kernel<32>, grid, block, 0, st, x, Wl, LW, B, Cin, Cout, HW, out);
+    else
+        hipLaunchKernelGGL(spatial_sum_fwd_kernel<0>, grid, block, 0, st, x, Wl, LW, B, Cin, Cout, HW, out);
+    DPK_CHECK_LAUNCH("spatial_sum_fwd_kernel");
+    return DPK_OK;
+}
+
+extern "C" int dpk_spatial_sum_backward(const float *x, const float *weight, const float *out, const float *g,
+                                        int64_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W, float *grad_x,
+                                        float *grad_weight, void *ws, int64_t ws_bytes, void *stream) {
+    DPK_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, DPK_EINVAL, "spatial_sum_backward: bad sizes");
+    DPK_REQUIRE(weight && ws, DPK_EINVAL, "spatial_sum_backward: null pointer");
+    const int HW = H * W;
+    const int64_t seg = align_up((int64_t)Cout * Cin * HW * 4, 256);
+    DPK_REQUIRE(ws_bytes >= 3 * seg, DPK_EWORKSPACE, "spatial_sum_backward: workspace too small");
+    float *Wl = (float *)ws, *LW = (float *)((char *)ws + seg), *glw = (float *)((char *)ws + 2 * seg);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * HW, 256)), dim3(256), 0, st, weight,
+                       Cout, Cin, HW, Wl, LW);
+    if (grad_weight)
+        DPK_REQUIRE(hipMemsetAsync(glw, 0, (size_t)Cout * Cin * HW * 4, st) == hipSuccess, DPK_ELAUNCH, "memset");
+    if (B > 0) {
+        DPK_REQUIRE(x && out && g, DPK_EINVAL, "spatial_sum_backward: null pointer");
+        const int bslice = 64;
+        hipLaunchKernelGGL(spatial_sum_bwd_kernel, dim3(cdiv((int64_t)Cin * HW, 256), cdiv(B, bslice)), dim3(256), 0,
+                           st, x, LW, out, g, B, Cin, Cout, HW, bslice, grad_x, grad_weight ? glw : nullptr);
+    }
+    if (grad_weight)
+        hipLaunchKernelGGL(spatial_softmax_jacobian_kernel, dim3(grid_cap((int64_t)Cout * HW, 256)), dim3(256), 0, st,
+                           glw, Wl, Cout, Cin, HW, grad_weight);
+    DPK_CHECK_LAUNCH("spatial_sum_bwd_kernel");
+    return DPK_OK;
+}

@@ -357,8 +357,8 @@ extern "C" int64_t dpk_sum_workspace_bytes(int64_t B, int32_t P, int32_t N, int3
 
 static int sum_forward_impl(const float *in, const float *weight, int64_t B, int P, int N, int S, float *out,
                             void *ws, int64_t ws_bytes, void *stream, const char *who) {
-    DPK_REQUIRE(in && weight && out && ws, DPK_EINVAL, "%s: null pointer", who);
     DPK_REQUIRE(B >= 0 && P > 0 && N > 0 && S > 0, DPK_EINVAL, "%s: bad sizes", who);
+    DPK_REQUIRE(weight && ws && (B == 0 || (in && out)), DPK_EINVAL, "%s: null pointer", who);
     DPK_REQUIRE(P <= 65535, DPK_EUNSUPPORTED, "%s: partitions=%d > 65535", who, P);
     const int64_t seg = align_up((int64_t)P * S * N * 4, 256);
     DPK_REQUIRE(ws_bytes >= 3 * seg, DPK_EWORKSPACE, "%s: workspace too small", who);
@@ -375,8 +375,8 @@ static int sum_forward_impl(const float *in, const float *weight, int64_t B, int
 static int sum_backward_impl(const float *in, const float *weight, const float *out, const float *g, int64_t B,
                              int P, int N, int S, float *grad_in, float *grad_weight, void *ws,
                              int64_t ws_bytes, void *stream, const char *who) {
-    DPK_REQUIRE(in && weight && out && g && ws, DPK_EINVAL, "%s: null pointer", who);
     DPK_REQUIRE(B >= 0 && P > 0 && N > 0 && S > 0, DPK_EINVAL, "%s: bad sizes", who);
+    DPK_REQUIRE(weight && ws && (B == 0 || (in && out && g)), DPK_EINVAL, "%s: null pointer", who);
     const int64_t seg = align_up((int64_t)P * S * N * 4, 256);
     DPK_REQUIRE(ws_bytes >= 3 * seg, DPK_EWORKSPACE, "%s: workspace too small", who);
     float *W = (float *)ws, *LW = (float *)((char *)ws + seg), *glw = (float *)((char *)ws + 2 * seg);

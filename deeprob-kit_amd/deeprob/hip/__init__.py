@@ -60,6 +60,17 @@ SIGNATURES = {
     'dpk_affine1d_forward': (ctypes.c_int, [_c_void, _c_void, _c_void, _i64, _i32, _c_void, _c_void]),
     'dpk_normal_base_logprob': (ctypes.c_int, [_c_void, _c_void, _c_void, _c_void, _c_void, _c_void, _c_void,
                                                _i64, _i32, _c_void, _c_void]),
+    'dpk_spatial_gaussian_forward': (ctypes.c_int, [_c_void, _c_void, _c_void, _i64, _i32, _i32, _i32, _i32,
+                                                    _c_void, _c_void]),
+    'dpk_spatial_gaussian_backward': (ctypes.c_int, [_c_void, _c_void, _c_void, _c_void, _i64, _i32, _i32, _i32,
+                                                     _i32, _c_void, _c_void, _c_void, _c_void]),
+    'dpk_spatial_product_forward': (ctypes.c_int, [_c_void, _i64] + [_i32] * 15 + [_c_void, _c_void]),
+    'dpk_spatial_product_backward': (ctypes.c_int, [_c_void, _i64] + [_i32] * 15 + [_c_void, _c_void]),
+    'dpk_spatial_sum_workspace_bytes': (_i64, [_i32, _i32, _i32, _i32]),
+    'dpk_spatial_sum_forward': (ctypes.c_int, [_c_void, _c_void, _i64, _i32, _i32, _i32, _i32, _c_void, _c_void,
+                                               _i64, _c_void]),
+    'dpk_spatial_sum_backward': (ctypes.c_int, [_c_void, _c_void, _c_void, _c_void, _i64, _i32, _i32, _i32, _i32,
+                                                _c_void, _c_void, _c_void, _i64, _c_void]),
     'dpk_profile_next_kernel': (ctypes.c_int, [_c_void, _c_void]),
     'dpk_ll_accumulate': (ctypes.c_int, [_c_void, _i64, _c_void, _c_void]),
 }

@@ -195,8 +195,8 @@ class RootFn(torch.autograd.Function):
         x = require_device_f32(x, 'x')
         w = require_device_f32(weight, 'weight')
         B = x.shape[0]
-        x2 = x.reshape(B, -1)
-        M, C = x2.shape[1], w.shape[0]
+        M, C = w.shape[1], w.shape[0]
+        x2 = x.reshape(B, M)
         out = torch.empty((B, C), dtype=torch.float32, device=x.device)
         buf = _sum_ws(ws, B, 1, M, C, x.device)
         check(lib.dpk_root_forward(ptr(x2), ptr(w), B, M, C, ptr(out), ptr(buf), buf.numel(),

@@ -1,0 +1,123 @@
+"""Autograd operators over the DGC-SPN spatial kernels (csrc/dgcspn.hip).
+
+Every operator calls the C ABI directly and raises when the library or a device tensor is missing;
+there is no CPU path.
+"""
+import torch
+
+from deeprob.hip import load_library, check, ptr, stream_ptr, require_device_f32, Workspace
+
+
+class SpatialGaussianFn(torch.autograd.Function):
+    """SpatialGaussianLayer.forward (reference: deeprob/spn/layers/dgcspn.py:101-120)."""
+
+    @staticmethod
+    def forward(ctx, x, loc, scale):
+        lib = load_library()
+        x = require_device_f32(x, 'x')
+        loc_c, scale_c = require_device_f32(loc, 'loc'), require_device_f32(scale, 'scale')
+        if x.dim() != 4 or tuple(x.shape[1:]) != tuple(loc_c.shape[1:]):
+            raise ValueError(f"expected input [B, {', '.join(map(str, loc_c.shape[1:]))}], got {tuple(x.shape)}")
+        B, C, H, W = x.shape
+        K = loc_c.shape[0]
+        out = torch.empty((B, K, H, W), dtype=torch.float32, device=x.device)
+        check(lib.dpk_spatial_gaussian_forward(ptr(x), ptr(loc_c), ptr(scale_c), B, K, C, H, W, ptr(out),
+                                               stream_ptr(x.device)), 'dpk_spatial_gaussian_forward')
+        ctx.save_for_backward(x, loc_c, scale_c)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load_library()
+        x, loc, scale = ctx.saved_tensors
+        g = require_device_f32(g, 'grad')
+        B, C, H, W = x.shape
+        K = loc.shape[0]
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gl = torch.empty_like(loc) if ctx.needs_input_grad[1] else None
+        gs = torch.empty_like(scale) if ctx.needs_input_grad[2] else None
+        check(lib.dpk_spatial_gaussian_backward(ptr(x), ptr(g), ptr(loc), ptr(scale), B, K, C, H, W, ptr(gl),
+                                                ptr(gs), ptr(gx), stream_ptr(x.device)),
+              'dpk_spatial_gaussian_backward')
+        return gx, gl, gs
+
+
+def _geom(layer):
+    """Geometry of a SpatialProductLayer as the C ABI takes it."""
+    C, H, W = layer.in_features
+    OC, OH, OW = layer.out_features
+    kh, kw = layer.kernel_size
+    return (C, H, W, OC, OH, OW, kh, kw, layer.stride[0], layer.stride[1], layer.dilation[0], layer.dilation[1],
+            layer.pad[2], layer.pad[0], 1 if layer.depthwise else 0)
+
+
+class SpatialProductFn(torch.autograd.Function):
+    """SpatialProductLayer.forward (reference: dgcspn.py:224-236)."""
+
+    @staticmethod
+    def forward(ctx, x, layer):
+        lib = load_library()
+        x = require_device_f32(x, 'x')
+        geom = _geom(layer)
+        if x.dim() != 4 or tuple(x.shape[1:]) != tuple(layer.in_features):
+            raise ValueError(f"expected input [B, {layer.in_features}], got {tuple(x.shape)}")
+        B = x.shape[0]
+        out = torch.empty((B,) + tuple(layer.out_features), dtype=torch.float32, device=x.device)
+        check(lib.dpk_spatial_product_forward(ptr(x), B, *geom, ptr(out), stream_ptr(x.device)),
+              'dpk_spatial_product_forward')
+        ctx.geom = geom
+        ctx.in_shape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load_library()
+        g = require_device_f32(g, 'grad')
+        gin = torch.empty(ctx.in_shape, dtype=torch.float32, device=g.device)
+        check(lib.dpk_spatial_product_backward(ptr(g), ctx.in_shape[0], *ctx.geom, ptr(gin), stream_ptr(g.device)),
+              'dpk_spatial_product_backward')
+        return gin, None
+
+
+def _spatial_sum_ws(ws: Workspace, Cin, Cout, H, W, device):
+    lib = load_library()
+    n = lib.dpk_spatial_sum_workspace_bytes(Cin, Cout, H, W)
+    if n < 0:
+        check(int(n), 'dpk_spatial_sum_workspace_bytes')
+    return ws.get(n, device)
+
+
+class SpatialSumFn(torch.autograd.Function):
+    """SpatialSumLayer.forward in eval mode (reference: dgcspn.py:289-304)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, ws: Workspace):
+        lib = load_library()
+        x = require_device_f32(x, 'x')
+        w = require_device_f32(weight, 'weight')
+        if x.dim() != 4 or tuple(x.shape[1:]) != tuple(w.shape[1:]):
+            raise ValueError(f"expected input [B, {', '.join(map(str, w.shape[1:]))}], got {tuple(x.shape)}")
+        B, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+        buf = _spatial_sum_ws(ws, Cin, Cout, H, W, x.device)
+        check(lib.dpk_spatial_sum_forward(ptr(x), ptr(w), B, Cin, Cout, H, W, ptr(out), ptr(buf), buf.numel(),
+                                          stream_ptr(x.device)), 'dpk_spatial_sum_forward')
+        ctx.save_for_backward(x, w, out)
+        ctx.ws = ws
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load_library()
+        x, w, out = ctx.saved_tensors
+        g = require_device_f32(g, 'grad')
+        B, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        buf = _spatial_sum_ws(ctx.ws, Cin, Cout, H, W, x.device)
+        check(lib.dpk_spatial_sum_backward(ptr(x), ptr(w), ptr(out), ptr(g), B, Cin, Cout, H, W, ptr(gx), ptr(gw),
+                                           ptr(buf), buf.numel(), stream_ptr(x.device)),
+              'dpk_spatial_sum_backward')
+        return gx, gw, None

@@ -180,6 +180,36 @@ int dpk_normal_base_logprob(const float *u, const float *scale_in, const float *
                             const float *scale, const float *ildj, const float *ildj_const, int64_t B,
                             int32_t D, float *out, void *stream);
 
+/* ---- DGC-SPN spatial layers (NCHW fp32; deeprob/spn/layers/dgcspn.py) ------------------ */
+/* SpatialGaussianLayer.forward (dgcspn.py:101-120):
+ * out[b,k,h,w] = sum_c nan_to_num(log N(x[b,c,h,w]; loc[k,c,h,w], scale[k,c,h,w])); NaN x = marginalised. */
+int dpk_spatial_gaussian_forward(const float *x, const float *loc, const float *scale, int64_t B, int32_t K,
+                                 int32_t C, int32_t H, int32_t W, float *out, void *stream);
+/* its autograd: grad_loc / grad_scale [K,C,H,W], grad_x [B,C,H,W]; any may be NULL. */
+int dpk_spatial_gaussian_backward(const float *x, const float *g, const float *loc, const float *scale,
+                                  int64_t B, int32_t K, int32_t C, int32_t H, int32_t W, float *grad_loc,
+                                  float *grad_scale, float *grad_x, void *stream);
+/* SpatialProductLayer.forward (dgcspn.py:224-236): F.pad(zero; pad_left/pad_top, the right/bottom
+ * padding is implied by OH/OW) then F.conv2d with the all-ones depthwise kernel (depthwise=1,
+ * OC == C) or the one-hot kernels enumerating every channel combination in itertools.product
+ * order (depthwise=0, OC == C^(kh*kw); dgcspn.py:187-193).                                    */
+int dpk_spatial_product_forward(const float *in, int64_t B, int32_t C, int32_t H, int32_t W, int32_t OC,
+                                int32_t OH, int32_t OW, int32_t kh, int32_t kw, int32_t sh, int32_t sw,
+                                int32_t dh, int32_t dw, int32_t pad_top, int32_t pad_left, int32_t depthwise,
+                                float *out, void *stream);
+int dpk_spatial_product_backward(const float *g, int64_t B, int32_t C, int32_t H, int32_t W, int32_t OC,
+                                 int32_t OH, int32_t OW, int32_t kh, int32_t kw, int32_t sh, int32_t sw,
+                                 int32_t dh, int32_t dw, int32_t pad_top, int32_t pad_left, int32_t depthwise,
+                                 float *grad_in, void *stream);
+/* SpatialSumLayer.forward (dgcspn.py:289-304):
+ * out[b,o,h,w] = logsumexp_c(x[b,c,h,w] + log_softmax(weight,1)[o,c,h,w]), weight [Cout,Cin,H,W]. */
+int64_t dpk_spatial_sum_workspace_bytes(int32_t Cin, int32_t Cout, int32_t H, int32_t W);
+int dpk_spatial_sum_forward(const float *x, const float *weight, int64_t B, int32_t Cin, int32_t Cout, int32_t H,
+                            int32_t W, float *out, void *ws, int64_t ws_bytes, void *stream);
+int dpk_spatial_sum_backward(const float *x, const float *weight, const float *out, const float *g, int64_t B,
+                             int32_t Cin, int32_t Cout, int32_t H, int32_t W, float *grad_x, float *grad_weight,
+                             void *ws, int64_t ws_bytes, void *stream);
+
 /* Measurement hook: the NEXT dominant-kernel launch made from this thread (the fused / leaf
  * forward kernel) is bracketed by hipEventRecord(ev_start) / hipEventRecord(ev_stop) on its stream,
  * so a harness can time that kernel alone inside a longer step.  One-shot; pass NULLs to cancel. */

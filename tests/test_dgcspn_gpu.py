@@ -1,0 +1,165 @@
+"""Parity of the HIP DGC-SPN path (through the C ABI) with the oracle and the golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dgcspn_oracle as dorc
+from tests.dgc_cases import CASES, SMALL, build_dgc, plan_of
+from tests.util import rel_err, grad_err
+
+pytestmark = pytest.mark.gpu
+
+LL_TOL = 1e-5     # north-star: 1e-5 relative on fp32 log-likelihoods
+GRAD_TOL = 1e-4   # relative to the largest magnitude of the tensor
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_forward_golden(golden, name):
+    g = golden(name)
+    model = build_dgc(name, g).cuda()
+    with torch.no_grad():
+        ll = model(torch.from_numpy(g['x']).cuda())
+        ll_nan = model(torch.from_numpy(g['x_nan']).cuda())
+    assert ll.shape == g['ll'].shape and ll.dtype == torch.float32
+    assert rel_err(ll.cpu().numpy(), g['ll']) <= LL_TOL
+    assert rel_err(ll_nan.cpu().numpy(), g['ll_nan']) <= LL_TOL
+
+
+@pytest.mark.parametrize('name', sorted(SMALL))
+def test_layers_golden(golden, name):
+    g = golden(name)
+    model = build_dgc(name, g).cuda()
+    with torch.no_grad():
+        h = model.base_layer(torch.from_numpy(g['x']).cuda())
+        assert rel_err(h.cpu().numpy(), g['act.leaf']) <= LL_TOL
+        for i, layer in enumerate(model.layers):
+            h = layer(h)
+            assert tuple(h.shape[1:]) == tuple(layer.out_features)
+            assert rel_err(h.cpu().numpy(), g['act.layer{}'.format(i)]) <= LL_TOL, i
+
+
+def _fp64_oracle(name, g, model):
+    """fp64 restatement on the CPU: measures the reference's own fp32 rounding noise in the golden gradients /
+    MPE completions (they involve cancellations the forward pass does not), which sets the tolerance."""
+    sd64 = {k: (v.detach().cpu().double() if v.is_floating_point() else v.cpu()) for k, v in
+            model.state_dict().items()}
+    return sd64, plan_of(name)
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_mpe_golden(golden, name):
+    g = golden(name)
+    model = build_dgc(name, g).cuda()
+    xn = torch.from_numpy(g['x_nan'])
+    with torch.enable_grad():
+        mpe = model.mpe(xn.cuda()).cpu().numpy()
+    sd64, plan = _fp64_oracle(name, g, model)
+    mpe64 = dorc.dgcspn_mpe(sd64, xn.double(), plan).numpy()
+    noise = float(np.max(np.abs(g['mpe'] - mpe64)))
+    assert np.array_equal(np.isnan(g['x_nan']) | (mpe == g['x_nan']), np.ones_like(mpe, dtype=bool))
+    assert float(np.max(np.abs(mpe - mpe64))) <= max(1e-5, 4 * noise)
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_gradients_golden(golden, name):
+    g = golden(name)
+    model = build_dgc(name, g).cuda()
+    x = torch.from_numpy(g['x']).cuda().requires_grad_(True)
+    y = torch.from_numpy(g['y']) if 'y' in g.files else None
+    loss = model.loss(model(x), y.cuda() if y is not None else None)
+    loss.backward()
+    assert rel_err(loss.detach().cpu().numpy(), g['loss']) <= LL_TOL
+    # fp64 gradients: tolerance = max(GRAD_TOL, 4 x the reference's own fp32 error)
+    sd64, plan = _fp64_oracle(name, g, model)
+    leaves = {k: v.requires_grad_(True) for k, v in sd64.items() if v.is_floating_point()}
+    x64 = torch.from_numpy(g['x']).double().requires_grad_(True)
+    dorc.dgcspn_loss(dorc.dgcspn_forward(leaves, x64, plan), y).backward()
+
+    def check(got, key, exact):
+        noise = grad_err(g[key], exact)
+        assert grad_err(got, exact) <= max(GRAD_TOL, 4 * noise), (key, noise)
+
+    check(x.grad.cpu().numpy(), 'grad.x', x64.grad.numpy())
+    checked = 0
+    for k, p in model.named_parameters():
+        if 'grad.' + k in g.files:
+            check(p.grad.cpu().numpy(), 'grad.' + k, leaves[k].grad.numpy())
+            checked += 1
+    assert checked >= 2
+
+
+def test_product_invariants_like_reference():
+    """Reference tests/test_dgcspn.py:46-75 on the HIP layers."""
+    from deeprob.spn.layers.dgcspn import SpatialProductLayer
+    ones = torch.ones(8, 3, 32, 32, device='cuda')
+    p = SpatialProductLayer((3, 32, 32), kernel_size=2, padding='full', stride=1, dilation=4, depthwise=True)
+    assert p.pad == [4, 4, 4, 4] and p.out_features == (3, 36, 36)
+    assert torch.allclose(p(ones)[:, :, 4:-4, 4:-4], torch.tensor(4.0, device='cuda'))
+    p = SpatialProductLayer((3, 32, 32), kernel_size=2, padding='valid', stride=2, dilation=1, depthwise=True)
+    assert p.out_features == (3, 16, 16) and torch.allclose(p(ones), torch.tensor(4.0, device='cuda'))
+    p = SpatialProductLayer((3, 32, 32), kernel_size=2, padding='full', stride=1, dilation=8, depthwise=False)
+    assert tuple(p.weight.shape) == (81, 3, 2, 2) and p.out_features == (81, 40, 40)
+    out = p(ones)
+    assert tuple(out.shape) == (8, 81, 40, 40)
+    assert torch.allclose(out[:, :, 8:-8, 8:-8], torch.tensor(4.0, device='cuda'))
+
+
+@pytest.mark.parametrize('n_pooling,depthwise', [(0, False), (2, False), (0, True), (2, True)])
+def test_mpe_log_prob_like_reference(n_pooling, depthwise):
+    """Reference tests/test_dgcspn.py:89-96."""
+    from deeprob.spn.models import DgcSpn
+    data = torch.randn(8, 3, 32, 32)
+    mar = data.clone()
+    mar[torch.rand_like(mar) < 0.5] = np.nan
+    model = DgcSpn((3, 32, 32), n_batch=4, sum_channels=4, n_pooling=n_pooling, depthwise=depthwise).cuda()
+    lls = model.log_prob(data.cuda())
+    with torch.enable_grad():
+        mpe_data = model.mpe(mar.cuda())
+    mpe_lls = model.log_prob(mpe_data)
+    assert torch.all(mpe_lls.squeeze() > lls.squeeze())
+
+
+def test_random_shapes_against_oracle():
+    """Layer-level sweep over geometries the models do not reach (3x3 windows are out of the ABI's scope:
+    the reference model only builds 2x2), odd sizes, stride 2, -inf inputs to the sum layer."""
+    from deeprob.spn.layers.dgcspn import SpatialGaussianLayer, SpatialProductLayer, SpatialSumLayer
+    gen = torch.Generator().manual_seed(5)
+    for (c, h, w), padding, stride, dil, dw in [((5, 7, 9), 'full', 1, 3, True), ((2, 9, 9), 'valid', 2, 1, False),
+                                                ((3, 6, 6), 'final', 1, 4, True), ((3, 11, 5), 'full', 1, 2, False)]:
+        if padding == 'final' and h != w:
+            continue
+        x = torch.randn(5, c, h, w, generator=gen)
+        layer = SpatialProductLayer((c, h, w), 2, padding, stride, dil, depthwise=dw).cuda()
+        want = dorc.spatial_product(x, layer.pad, stride, dil, dw)
+        got = layer(x.cuda())
+        assert rel_err(got.cpu().numpy(), want.numpy()) <= 1e-6
+    x = torch.randn(9, 6, 5, 5, generator=gen) * 20
+    x[0] = float('-inf')
+    x[1, :3] = float('-inf')
+    s = SpatialSumLayer((6, 5, 5), 4).cuda()
+    with torch.no_grad():
+        s.weight[0, 1] = -200.0
+        s.weight[0, 1, 2, 2] = 50.0
+        got = s(x.cuda())
+    want = dorc.spatial_sum(x, s.weight.detach().cpu())
+    assert rel_err(got.cpu().numpy(), want.numpy()) <= LL_TOL
+    xg = torch.randn(4, 2, 5, 5, generator=gen)
+    xg[0, 0, 1, 1] = float('nan')
+    xg[1, 1, 2, 2] = float('inf')
+    leaf = SpatialGaussianLayer((2, 5, 5), 3, optimize_scale=True).cuda()
+    with torch.no_grad():
+        got = leaf(xg.cuda())
+    want = dorc.spatial_gaussian(xg, leaf.loc.detach().cpu(), leaf.scale.detach().cpu())
+    assert rel_err(got.cpu().numpy(), want.numpy()) <= LL_TOL
+
+
+def test_empty_batch_and_errors():
+    from deeprob.hip import HipError
+    from deeprob.spn.models import DgcSpn
+    model = DgcSpn((1, 8, 8), n_batch=2, sum_channels=2, depthwise=True).cuda()
+    with torch.no_grad():
+        assert tuple(model(torch.empty(0, 1, 8, 8, device='cuda')).shape) == (0, 1)
+        with pytest.raises((ValueError, HipError)):
+            model(torch.zeros(2, 1, 9, 8, device='cuda'))
+        with pytest.raises((HipError, TypeError, ValueError)):
+            model(torch.zeros(2, 1, 8, 8))       # CPU tensor: no silent fallback

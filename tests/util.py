@@ -50,3 +50,17 @@ def randomise_flow(model, seed):
                 b.copy_(0.5 + torch.rand(b.shape, generator=g))
             elif name.endswith('running_mean'):
                 b.copy_(0.5 * torch.randn(b.shape, generator=g))
+
+
+def randomise_dgc(model, seed):
+    """Same as tools/gen_golden_dgcspn.py::_randomise_dgc: the (3,32,32) DGC-SPN fixtures ship seeds, not the
+    tens of MB of position-dependent sum weights."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if not p.requires_grad:
+                continue
+            if name.endswith('scale'):
+                p.copy_(0.5 + 0.5 * torch.rand(p.shape, generator=g))
+            else:
+                p.copy_(torch.randn(p.shape, generator=g))

@@ -190,7 +190,8 @@ def main():
     todo = set(args.only.split(','))
     gens = {'region': gen_region, 'ratspn': gen_ratspn}
     try:
-        from gen_golden_flows import gen_flows, gen_dgcspn  # added with those paths
+        from gen_golden_flows import gen_flows
+        from gen_golden_dgcspn import gen_dgcspn
         gens.update({'flows': gen_flows, 'dgcspn': gen_dgcspn})
     except ImportError:
         pass

@@ -1,4 +1,4 @@
-"""Golden vectors for the RealNVP-1D path and the DGC-SPN path (imported by tools/gen_golden.py; needs the
+"""Golden vectors for the RealNVP-1D path (imported by tools/gen_golden.py; needs the
 reference on PYTHONPATH)."""
 import numpy as np
 import torch
@@ -68,6 +68,3 @@ def gen_flows():
     _randomise_flow(m, 15)
     _flow_fixture('realnvp1d_15', m, torch.randn(9, 15, generator=torch.Generator().manual_seed(2)))
 
-
-def gen_dgcspn():
-    pass
