@@ -297,6 +297,97 @@ __global__ void spatial_softmax_jacobian_kernel(const float *__restrict__ glw, c
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused depthwise product + sum level (the eval route of DgcSpn.forward): the [B,C,OH,OW] product map is
+// never written.  Thread = one output pixel for NB consecutive samples, so each softmaxed weight
+// W[o,c,p] is loaded once per NB samples; lanes run over pixels (coalesced taps, weights and stores).
+//   out[b,o,p] = logsumexp_c( sum_taps in[b,c,tap(p)] + lw[o,c,p] )
+// HBM traffic per level and sample: C*H*W read (the 4 taps of a pixel hit L2) + Cout*OH*OW written.
+// ------------------------------------------------------------------------------------------------
+template <int CMAX, int NB>
+__global__ __launch_bounds__(256) void spatial_prodsum_fwd_kernel(const float *__restrict__ in,
+                                                                   const float *__restrict__ Wl,
+                                                                   const float *__restrict__ LW, int B, ProdGeom q,
+                                                                   int Cout, float *__restrict__ out) {
+    const int OHW = q.OH * q.OW, HW = q.H * q.W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= OHW) return;
+    const int b0 = blockIdx.y * NB;
+    const int oh = p / q.OW, ow = p - oh * q.OW;
+    // tap offsets inside one channel plane, -1 = padding (contributes log 1 = 0)
+    int toff[4];
+    {
+        const int T = q.kh * q.kw;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int th = t / q.kw, tw = t - th * q.kw;
+            const int ih = oh * q.sh - q.pt + th * q.dh, iw = ow * q.sw - q.pl + tw * q.dw;
+            toff[t] = (t < T && ih >= 0 && ih < q.H && iw >= 0 && iw < q.W) ? ih * q.W + iw : -1;
+        }
+    }
+    float ev[NB][CMAX], m0[NB];
+#pragma unroll
+    for (int s = 0; s < NB; ++s) {
+        const float *src = in + (size_t)min(b0 + s, B - 1) * q.C * HW;
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            float a = -INFINITY;
+            if (c < q.C) {
+                a = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (toff[t] >= 0) a += src[c * HW + toff[t]];
+            }
+            ev[s][c] = a;
+            m = fmaxf(m, a);
+        }
+        m0[s] = (m == -INFINITY) ? 0.f : m;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) ev[s][c] = expf(ev[s][c] - m0[s]);
+    }
+    for (int o = 0; o < Cout; ++o) {
+        float w[CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) w[c] = c < q.C ? Wl[((size_t)o * q.C + c) * OHW + p] : 0.f;
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+            if (b0 + s >= B) break;
+            float v = 0.f;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) v = fmaf(w[c], ev[s][c], v);
+            float r;
+            if (v < 1e-30f) {
+                // exact log-domain pass (rare): rebuild the products from the taps
+                const float *src = in + (size_t)(b0 + s) * q.C * HW;
+                const float *lp = LW + (size_t)o * q.C * OHW + p;
+                float mm = -INFINITY;
+                for (int c = 0; c < q.C; ++c) {
+                    float a = 0.f;
+                    for (int t = 0; t < 4; ++t)
+                        if (toff[t] >= 0) a += src[c * HW + toff[t]];
+                    mm = fmaxf(mm, a + lp[(size_t)c * OHW]);
+                }
+                if (mm > -INFINITY) {
+                    float acc = 0.f;
+                    for (int c = 0; c < q.C; ++c) {
+                        float a = 0.f;
+                        for (int t = 0; t < 4; ++t)
+                            if (toff[t] >= 0) a += src[c * HW + toff[t]];
+                        acc += expf(a + lp[(size_t)c * OHW] - mm);
+                    }
+                    r = mm + logf(acc);
+                } else {
+                    r = -INFINITY;
+                }
+            } else {
+                r = m0[s] + logf(v);
+            }
+            out[((size_t)(b0 + s) * Cout + o) * OHW + p] = r;
+        }
+    }
+}
+
 }  // namespace dpk
 
 using namespace dpk;
@@ -439,5 +530,48 @@ extern "C" int dpk_spatial_sum_backward(const float *x, const float *weight, con
         hipLaunchKernelGGL(spatial_softmax_jacobian_kernel, dim3(grid_cap((int64_t)Cout * HW, 256)), dim3(256), 0, st,
                            glw, Wl, Cout, Cin, HW, grad_weight);
     DPK_CHECK_LAUNCH("spatial_sum_bwd_kernel");
+    return DPK_OK;
+}
+
+// SpatialProductLayer (depthwise, <= 4 taps) followed by SpatialSumLayer, product map kept in registers.
+// DPK_EUNSUPPORTED for non-depthwise products, more than 4 taps or more than 32 channels: the caller chains
+// dpk_spatial_product_forward + dpk_spatial_sum_forward instead.
+extern "C" int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C, int32_t H, int32_t W, int32_t OH,
+                                           int32_t OW, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t dh,
+                                           int32_t dw, int32_t pad_top, int32_t pad_left, const float *weight,
+                                           int32_t Cout, float *out, void *ws, int64_t ws_bytes, void *stream) {
+    ProdGeom q;
+    int rc = make_geom(q, C, H, W, C, OH, OW, kh, kw, sh, sw, dh, dw, pad_top, pad_left, 1);
+    if (rc) return rc;
+    DPK_REQUIRE(B >= 0 && Cout > 0, DPK_EINVAL, "spatial_prodsum: bad sizes");
+    DPK_REQUIRE(kh * kw <= 4 && C <= 32, DPK_EUNSUPPORTED, "spatial_prodsum: taps=%d channels=%d not fused",
+                kh * kw, C);
+    DPK_REQUIRE(B <= INT32_MAX / 2 && (int64_t)B * (C > Cout ? C : Cout) * (int64_t)(H * W > OH * OW ? H * W : OH * OW) <
+                                          ((int64_t)1 << 46),
+                DPK_EUNSUPPORTED, "spatial_prodsum: tensor too large");
+    DPK_REQUIRE(weight && ws, DPK_EINVAL, "spatial_prodsum: null pointer");
+    const int OHW = OH * OW;
+    const int64_t seg = align_up((int64_t)Cout * C * OHW * 4, 256);
+    DPK_REQUIRE(ws_bytes >= 3 * seg, DPK_EWORKSPACE, "spatial_prodsum: workspace too small");
+    if (B == 0) return DPK_OK;
+    DPK_REQUIRE(in && out, DPK_EINVAL, "spatial_prodsum: null pointer");
+    float *Wl = (float *)ws, *LW = (float *)((char *)ws + seg);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW, 256)), dim3(256), 0, st, weight,
+                       Cout, C, OHW, Wl, LW);
+    const int Bi = (int)B;
+#define DPK_PRODSUM(CMAX, NB)                                                                                      \
+    hipLaunchKernelGGL((spatial_prodsum_fwd_kernel<CMAX, NB>), dim3(cdiv(OHW, 256), cdiv(Bi, NB)), dim3(256), 0, st, \
+                       in, Wl, LW, Bi, q, Cout, out)
+    if (C <= 4)
+        DPK_PRODSUM(4, 4);
+    else if (C <= 8)
+        DPK_PRODSUM(8, 4);
+    else if (C <= 16)
+        DPK_PRODSUM(16, 2);
+    else
+        DPK_PRODSUM(32, 1);
+#undef DPK_PRODSUM
+    DPK_CHECK_LAUNCH("spatial_prodsum_fwd_kernel");
     return DPK_OK;
 }

@@ -162,6 +162,44 @@ __global__ __launch_bounds__(64) void sum_fwd_kernel(const float *__restrict__ i
     }
 }
 
+// Wide single-partition rows (SpatialRootLayer: N = Cin*H*W in the thousands, few classes): one wave
+// per sample, lanes stride the row (coalesced), per-lane online log-sum-exp in the log domain, then a
+// wave combine.  The row is re-read once per class (it stays in L2).
+__global__ __launch_bounds__(256) void root_wide_kernel(const float *__restrict__ in, const float *__restrict__ LW,
+                                                        int64_t B, int N, int S, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float *xr = in + b * N;
+    for (int o = 0; o < S; ++o) {
+        const float *lw = LW + (int64_t)o * N;
+        float m = -INFINITY, s = 0.f;
+        int n = lane;
+        for (; n + 192 < N; n += 256) {
+            const float t0 = xr[n] + lw[n], t1 = xr[n + 64] + lw[n + 64];
+            const float t2 = xr[n + 128] + lw[n + 128], t3 = xr[n + 192] + lw[n + 192];
+            const float cm = fmaxf(fmaxf(t0, t1), fmaxf(t2, t3));
+            if (cm > m) {
+                s *= expf(m - cm);   // m == -inf: s == 0 stays 0 (exp(-inf) == 0)
+                m = cm;
+            }
+            if (m > -INFINITY) s += (expf(t0 - m) + expf(t1 - m)) + (expf(t2 - m) + expf(t3 - m));
+        }
+        for (; n < N; n += 64) {
+            const float t = xr[n] + lw[n];
+            if (t > m) {
+                s *= expf(m - t);
+                m = t;
+            }
+            if (m > -INFINITY) s += expf(t - m);
+        }
+        const float M = wave_reduce_max(m);
+        const float part = (m > -INFINITY) ? s * expf(m - M) : 0.f;
+        const float tot = wave_reduce_sum(part);
+        if (lane == 0) out[b * S + o] = (M > -INFINITY) ? M + logf(tot) : -INFINITY;
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // SumLayer / RootLayer backward.
 //   pi[b,p,o,n] = exp(x[b,p,n] + lw[p,o,n] - out[b,p,o])
@@ -366,8 +404,11 @@ static int sum_forward_impl(const float *in, const float *weight, int64_t B, int
     float *W = (float *)ws, *LW = (float *)((char *)ws + seg);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(softmax_rows_kernel2, dim3(cdiv(P * S, 4)), dim3(256), 0, st, weight, P * S, N, W, LW);
-    hipLaunchKernelGGL(sum_fwd_kernel, dim3(cdiv(B, 64), P), dim3(64), 0, st, in, as_const(W), as_const(LW), B,
-                       P, N, S, out);
+    if (P == 1 && N >= 1024)
+        hipLaunchKernelGGL(root_wide_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, in, LW, B, N, S, out);
+    else
+        hipLaunchKernelGGL(sum_fwd_kernel, dim3(cdiv(B, 64), P), dim3(64), 0, st, in, as_const(W), as_const(LW), B,
+                           P, N, S, out);
     DPK_CHECK_LAUNCH("sum_fwd_kernel");
     return DPK_OK;
 }

@@ -71,6 +71,8 @@ SIGNATURES = {
                                                _i64, _c_void]),
     'dpk_spatial_sum_backward': (ctypes.c_int, [_c_void, _c_void, _c_void, _c_void, _i64, _i32, _i32, _i32, _i32,
                                                 _c_void, _c_void, _c_void, _i64, _c_void]),
+    'dpk_spatial_prodsum_forward': (ctypes.c_int, [_c_void, _i64] + [_i32] * 13 + [_c_void, _i32, _c_void, _c_void,
+                                                                                  _i64, _c_void]),
     'dpk_profile_next_kernel': (ctypes.c_int, [_c_void, _c_void]),
     'dpk_ll_accumulate': (ctypes.c_int, [_c_void, _i64, _c_void, _c_void]),
 }

@@ -121,3 +121,26 @@ class SpatialSumFn(torch.autograd.Function):
                                            ptr(buf), buf.numel(), stream_ptr(x.device)),
               'dpk_spatial_sum_backward')
         return gx, gw, None
+
+
+def spatial_prodsum(x, prod_layer, weight, ws: Workspace):
+    """One eval-mode DGC-SPN level, depthwise SpatialProductLayer + SpatialSumLayer in a single launch
+    (reference: deeprob/spn/models/dgcspn.py:146-147).  No autograd graph is recorded.  Returns None when
+    the level is outside what the fused kernel covers (the caller chains the two layer operators)."""
+    lib = load_library()
+    x = require_device_f32(x, 'x')
+    w = require_device_f32(weight, 'weight')
+    if not prod_layer.depthwise:
+        return None
+    if x.dim() != 4 or tuple(x.shape[1:]) != tuple(prod_layer.in_features):
+        raise ValueError(f"expected input [B, {prod_layer.in_features}], got {tuple(x.shape)}")
+    C, H, W, _, OH, OW, kh, kw, sh, sw, dh, dw, pt, pl, _ = _geom(prod_layer)
+    B, Cout = x.shape[0], w.shape[0]
+    out = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
+    buf = _spatial_sum_ws(ws, C, Cout, OH, OW, x.device)
+    rc = lib.dpk_spatial_prodsum_forward(ptr(x), B, C, H, W, OH, OW, kh, kw, sh, sw, dh, dw, pt, pl, ptr(w), Cout,
+                                         ptr(out), ptr(buf), buf.numel(), stream_ptr(x.device))
+    if rc == -4:  # DPK_EUNSUPPORTED
+        return None
+    check(rc, 'dpk_spatial_prodsum_forward')
+    return out

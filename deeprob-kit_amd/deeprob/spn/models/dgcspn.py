@@ -101,10 +101,32 @@ class DgcSpn(ProbabilisticModel):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """Log-likelihood ``[B, out_classes]`` of images ``x [B,C,H,W]``, NaN = marginalised
         (reference: dgcspn.py:134-151)."""
+        if self._needs_graph(x):
+            x = self.base_layer(x)
+            for layer in self.layers:
+                x = layer(x)
+            return self.root_layer(x)
+        # evaluation: every depthwise product is folded into the sum layer above it
+        from deeprob.hip import ops_spatial
         x = self.base_layer(x)
-        for layer in self.layers:
+        i, n = 0, len(self.layers)
+        while i < n:
+            layer = self.layers[i]
+            if i + 1 < n and isinstance(layer, SpatialProductLayer) and isinstance(self.layers[i + 1], SpatialSumLayer):
+                nxt = self.layers[i + 1]
+                dropout = self.training and nxt.dropout is not None   # the sum layer raises: not on this path
+                y = None if dropout else ops_spatial.spatial_prodsum(x, layer, nxt.weight, nxt._ws)
+                if y is not None:
+                    x, i = y, i + 2
+                    continue
             x = layer(x)
+            i += 1
         return self.root_layer(x)
+
+    def _needs_graph(self, x: torch.Tensor) -> bool:
+        if not torch.is_grad_enabled():
+            return False
+        return x.requires_grad or any(p.requires_grad for p in self.parameters())
 
     def mpe(self, x: torch.Tensor) -> torch.Tensor:
         """Gradient-based MPE completion of NaN pixels (reference: dgcspn.py:153-184)."""

@@ -210,6 +210,15 @@ int dpk_spatial_sum_backward(const float *x, const float *weight, const float *o
                              int32_t Cin, int32_t Cout, int32_t H, int32_t W, float *grad_x, float *grad_weight,
                              void *ws, int64_t ws_bytes, void *stream);
 
+/* Eval route of one DGC-SPN level: depthwise SpatialProductLayer (<= 4 taps, C <= 32) fused with the
+ * SpatialSumLayer that follows it (models/dgcspn.py:146-147), the product map never reaches HBM.
+ * Geometry as dpk_spatial_product_forward, weight [Cout,C,OH,OW], workspace of
+ * dpk_spatial_sum_workspace_bytes(C,Cout,OH,OW).  DPK_EUNSUPPORTED outside that envelope.      */
+int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C, int32_t H, int32_t W, int32_t OH,
+                                int32_t OW, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t dh,
+                                int32_t dw, int32_t pad_top, int32_t pad_left, const float *weight, int32_t Cout,
+                                float *out, void *ws, int64_t ws_bytes, void *stream);
+
 /* Measurement hook: the NEXT dominant-kernel launch made from this thread (the fused / leaf
  * forward kernel) is bracketed by hipEventRecord(ev_start) / hipEventRecord(ev_stop) on its stream,
  * so a harness can time that kernel alone inside a longer step.  One-shot; pass NULLs to cancel. */

@@ -88,6 +88,22 @@ def test_gradients_golden(golden, name):
     assert checked >= 2
 
 
+@pytest.mark.parametrize('name', ['dgcspn_1x28x28_dw', 'dgcspn_1x12x12_mixed_pool2', 'dgcspn_3x32x32_pool2_dw'])
+def test_fused_levels_match_layer_chain(golden, name):
+    """DgcSpn.forward without a graph folds depthwise products into the sums; with a graph it chains the
+    layer operators.  Same numbers either way (the fused kernel does the same arithmetic per pixel)."""
+    g = golden(name)
+    model = build_dgc(name, g).cuda()
+    x = torch.from_numpy(g['x_nan']).cuda()
+    with torch.no_grad():
+        fused = model(x)
+    chained = model(x).detach()          # parameters require grad -> layer chain
+    assert rel_err(fused.cpu().numpy(), chained.cpu().numpy()) <= 1e-6
+    # B not a multiple of the samples-per-thread blocking
+    with torch.no_grad():
+        assert torch.equal(model(x[:3]), fused[:3])
+
+
 def test_product_invariants_like_reference():
     """Reference tests/test_dgcspn.py:46-75 on the HIP layers."""
     from deeprob.spn.layers.dgcspn import SpatialProductLayer
