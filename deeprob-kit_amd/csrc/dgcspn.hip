@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void spatial_prodsum_fwd_kernel(const float *_
         }
         m0[s] = (m == -INFINITY) ? 0.f : m;
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) ev[s][c] = expf(ev[s][c] - m0[s]);
+        for (int c = 0; c < CMAX; ++c) ev[s][c] = __expf(ev[s][c] - m0[s]);
     }
     for (int o = 0; o < Cout; ++o) {
         float w[CMAX];
