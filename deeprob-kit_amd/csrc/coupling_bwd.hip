@@ -1,0 +1,429 @@
+// Training route of the RealNVP-1D path on gfx950: backward of CouplingLayer1d.apply_backward (depth-1
+// conditioner), train-mode BatchNormLayer1d (batch statistics) forward / backward, Normal base backward.
+// Formulas: SURVEY 8a "Backward formulas" (checked there against the reference's autograd in float64).
+//
+// The conditioner's five backward GEMMs (recomputed forward H, Z; dW2 = dZ^T H; dH = dZ W2; dW1 = dH^T xm;
+// dx += mask * dH W1) all go through ONE generic fp32-MFMA kernel (v_mfma_f32_32x32x2_f32, 64x64 tile per
+// 4-wave work-group, operands addressed through strides so the transposed products need no copies).  Training
+// batches are hundreds of samples, so this route is correctness-first; the 64k-sample density path is the
+// fused forward kernel in coupling.hip.
+#include "common.h"
+#include <math.h>
+
+namespace dpk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+    const float *A, *Bm;
+    float *C;
+    int M, N, K;
+    int64_t sam, sak, sbk, sbn, ldc;
+    const float *kscale;   // A(m,k) *= kscale[k]
+    const float *nscale;   // result(m,n) *= nscale[n]
+    const float *bias;     // + bias[n] (before relu)
+    const float *gate;     // result zeroed where gate[m*ldg + n] <= 0
+    int64_t ldg;
+    int relu, accumulate;
+};
+
+constexpr int kGT = 64, kGK = 16;
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
+    __shared__ float As[kGT][kGK + 1];
+    __shared__ float Bs[kGK][kGT + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * kGT, n0 = blockIdx.x * kGT;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bool a_kfast = g.sak == 1, b_nfast = g.sbn == 1;
+    for (int k0 = 0; k0 < g.K; k0 += kGK) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + i * 256;
+            // A tile 64 x 16, B tile 16 x 64; thread order follows the contiguous axis of the operand
+            const int am = a_kfast ? e / kGK : e % kGT, ak = a_kfast ? e % kGK : e / kGT;
+            float av = 0.f;
+            if (m0 + am < g.M && k0 + ak < g.K) {
+                av = g.A[(int64_t)(m0 + am) * g.sam + (int64_t)(k0 + ak) * g.sak];
+                if (g.kscale) av *= g.kscale[k0 + ak];
+            }
+            As[am][ak] = av;
+            const int bk = b_nfast ? e / kGT : e % kGK, bn = b_nfast ? e % kGT : e / kGK;
+            float bv = 0.f;
+            if (k0 + bk < g.K && n0 + bn < g.N) bv = g.Bm[(int64_t)(k0 + bk) * g.sbk + (int64_t)(n0 + bn) * g.sbn];
+            Bs[bk][bn] = bv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < kGK; kk += 2) {
+            const float a = As[wm + (lane & 31)][kk + (lane >> 5)];
+            const float b = Bs[kk + (lane >> 5)][wn + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+    const int n = n0 + wn + (lane & 31);
+    if (n >= g.N) return;
+    const float ns = g.nscale ? g.nscale[n] : 1.f, bs = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= g.M) continue;
+        float v = acc[r] + bs;
+        if (g.relu) v = fmaxf(v, 0.f);
+        v *= ns;
+        if (g.gate && !(g.gate[(int64_t)m * g.ldg + n] > 0.f)) v = 0.f;
+        float *dst = g.C + (int64_t)m * g.ldc + n;
+        *dst = g.accumulate ? *dst + v : v;
+    }
+}
+
+static void launch_gemm(const GemmArgs &g, hipStream_t st) {
+    if (g.M <= 0 || g.N <= 0) return;
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(g.N, kGT), cdiv(g.M, kGT)), dim3(256), 0, st, g);
+}
+
+// column sums over the batch: out[n] = sum_m src[m*ld + n]   (64 columns x 4 row groups per block)
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ src, int64_t M, int N, int64_t ld,
+                                                     float *__restrict__ out) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < N)
+        for (int64_t m = rg; m < M; m += 4) s += src[m * ld + c];
+    red[rg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rg == 0 && c < N) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// element-wise core of the coupling backward.  Z holds [t_hat | s_hat] (affine) or z (NICE); it is
+// overwritten with dZ.  gx receives the direct term g_u * exp(-s).
+//   ds = -g_u u - g_ildj ; dt = -g_u e^{-s} ; ds_hat = inv_mask ds a (1 - tanh^2) ; da = sum inv_mask ds tanh
+__global__ __launch_bounds__(256) void coupling_bwd_elem_kernel(const float *__restrict__ x, float *__restrict__ Z,
+                                                                const float *__restrict__ inv_mask,
+                                                                const float *__restrict__ act_weight,
+                                                                const float *__restrict__ gu,
+                                                                const float *__restrict__ gildj, int64_t B, int D,
+                                                                int affine, float *__restrict__ gx,
+                                                                float *__restrict__ gact) {
+    const int64_t total = B * D;
+    const float a = affine ? act_weight[0] : 0.f;
+    float da = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(e % D);
+        const int64_t b = e / D;
+        const float g = gu ? gu[e] : 0.f;
+        const bool live = inv_mask[d] != 0.f;
+        if (affine) {
+            float *zt = Z + b * 2 * D + d, *zs = zt + D;
+            if (live) {
+                const float th = tanhf(*zs);
+                const float s = a * th, t = *zt;
+                const float es = expf(-s);
+                const float u = (x[e] - t) * es;
+                const float ds = -g * u - (gildj ? gildj[b] : 0.f);
+                *zt = -g * es;
+                *zs = ds * a * (1.f - th * th);
+                da += ds * th;
+                gx[e] = g * es;
+            } else {
+                *zt = 0.f;
+                *zs = 0.f;
+                gx[e] = g;
+            }
+        } else {
+            Z[b * D + d] = live ? -g : 0.f;
+            gx[e] = g;
+        }
+    }
+    if (affine && gact) {
+        da = wave_reduce_sum(da);
+        if ((threadIdx.x & 63) == 0 && da != 0.f) atomicAdd(gact, da);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BatchNormLayer1d, training mode (deeprob/flows/utils.py:118-139)
+// ---------------------------------------------------------------------------------------------------------
+// per-column mean and unbiased variance over the batch (two passes), running statistics updated in place,
+// and the affine (scale, shift) + constant log-det of the transformation with these statistics.
+__global__ __launch_bounds__(256) void bn1d_stats_kernel(const float *__restrict__ x, int64_t B, int D,
+                                                         const float *__restrict__ weight,
+                                                         const float *__restrict__ bias, float momentum, float eps,
+                                                         float *__restrict__ running_var,
+                                                         float *__restrict__ running_mean, float *__restrict__ mean_out,
+                                                         float *__restrict__ var_out, float *__restrict__ scale_out,
+                                                         float *__restrict__ shift_out, float *__restrict__ ldj_const) {
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + col;
+    float s = 0.f;
+    if (c < D)
+        for (int64_t b = rg; b < B; b += 4) s += x[b * D + c];
+    red[rg][col] = s;
+    __syncthreads();
+    const float mean = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) / (float)B;
+    __syncthreads();
+    float q = 0.f;
+    if (c < D)
+        for (int64_t b = rg; b < B; b += 4) {
+            const float dlt = x[b * D + c] - mean;
+            q = fmaf(dlt, dlt, q);
+        }
+    red[rg][col] = q;
+    __syncthreads();
+    float term = 0.f;
+    if (rg == 0 && c < D) {
+        const float var = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) / (float)(B - 1);
+        running_var[c] = running_var[c] * momentum + var * (1.f - momentum);
+        running_mean[c] = running_mean[c] * momentum + mean * (1.f - momentum);
+        mean_out[c] = mean;
+        var_out[c] = var;
+        const float ve = var + eps;
+        const float sc = expf(weight[c]) / sqrtf(ve);
+        scale_out[c] = sc;
+        shift_out[c] = bias[c] - mean * sc;
+        term = weight[c] - 0.5f * logf(ve);
+    }
+    if (rg == 0) {
+        term = wave_reduce_sum(term);
+        if (col == 0) atomicAdd(ldj_const, term);
+    }
+}
+
+// column reductions of the backward: s1[d] = sum_b g_u, s2[d] = sum_b g_u * xhat
+__global__ __launch_bounds__(256) void bn1d_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ gu,
+                                                              int64_t B, int D, const float *__restrict__ mean,
+                                                              const float *__restrict__ var, float eps,
+                                                              float *__restrict__ s1, float *__restrict__ s2) {
+    __shared__ float r1[4][64], r2[4][64];
+    const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + col;
+    float a1 = 0.f, a2 = 0.f;
+    if (c < D) {
+        const float mu = mean[c], is = 1.f / sqrtf(var[c] + eps);
+        for (int64_t b = rg; b < B; b += 4) {
+            const float g = gu[b * D + c];
+            a1 += g;
+            a2 = fmaf(g, (x[b * D + c] - mu) * is, a2);
+        }
+    }
+    r1[rg][col] = a1;
+    r2[rg][col] = a2;
+    __syncthreads();
+    if (rg == 0 && c < D) {
+        s1[c] = (r1[0][col] + r1[1][col]) + (r1[2][col] + r1[3][col]);
+        s2[c] = (r2[0][col] + r2[1][col]) + (r2[2][col] + r2[3][col]);
+    }
+}
+
+// gx and the parameter gradients.  train != 0: the statistics depend on x (unbiased variance).
+//   u = xhat e^w + bias, ildj = sum_d (w_d - 0.5 log(var_d + eps))
+__global__ void bn1d_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ gu,
+                                      const float *__restrict__ sg, int64_t B, int D, const float *__restrict__ weight,
+                                      const float *__restrict__ mean, const float *__restrict__ var, float eps,
+                                      const float *__restrict__ s1, const float *__restrict__ s2, int train,
+                                      float *__restrict__ gx, float *__restrict__ gw, float *__restrict__ gb) {
+    const int64_t total = B * D;
+    const float gsum = sg ? sg[0] : 0.f;   // sum_b g_ildj[b]
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(e % D);
+        const float ve = var[d] + eps, is = 1.f / sqrtf(ve), ew = expf(weight[d]);
+        float v = gu[e] * ew * is;
+        if (train) {
+            const float xhat = (x[e] - mean[d]) * is;
+            // d/dvar: through u (-0.5 e^w s2 / ve) and through ildj (-0.5 gsum / ve); var = sum (x-mean)^2/(B-1)
+            const float dvar = -0.5f * (ew * s2[d] + gsum) / ve;
+            const float dmean = -ew * is * s1[d];
+            v += dvar * 2.f * (xhat / is) / (float)(B - 1) + dmean / (float)B;
+        }
+        gx[e] = v;
+        if (e < D) {   // first row's threads also finish the parameter gradients
+            if (gw) gw[d] = ew * s2[d] + gsum;
+            if (gb) gb[d] = s1[d];
+        }
+    }
+}
+
+__global__ void vecsum_kernel(const float *__restrict__ v, int64_t n, float *__restrict__ out) {
+    // one block; fp32 pairwise-ish: per-thread strided partials, LDS tree
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += v[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// d/du of sum_d log N(u; loc, scale) weighted by g[b]
+__global__ void normal_base_bwd_kernel(const float *__restrict__ u, const float *__restrict__ loc,
+                                       const float *__restrict__ scale, const float *__restrict__ g, int64_t B, int D,
+                                       float *__restrict__ gu) {
+    const int64_t total = B * D;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(e % D);
+        const float sg = scale[d];
+        gu[e] = -g[e / D] * (u[e] - loc[d]) / (sg * sg);
+    }
+}
+
+static inline int grid1d(int64_t total, int block = 256, int cap = 8192) {
+    int64_t n = (total + block - 1) / block;
+    return (int)(n < 1 ? 1 : (n > cap ? cap : n));
+}
+
+}  // namespace dpk
+
+using namespace dpk;
+
+// workspace: H [B,units], Z [B,zc], dH [B,units]   (zc = 2D affine, D NICE)
+extern "C" int64_t dpk_coupling1d_backward_workspace_bytes(int64_t B, int32_t D, int32_t units, int32_t affine) {
+    if (B < 0 || D <= 0 || units <= 0) return DPK_EINVAL;
+    const int64_t zc = affine ? 2 * (int64_t)D : D;
+    return 2 * align_up(B * units * 4, 256) + align_up(B * zc * 4, 256) + 256;
+}
+
+extern "C" int dpk_coupling1d_backward(const float *x, int64_t B, int32_t D, const float *mask, const float *inv_mask,
+                                       const float *W1, const float *b1, const float *W2, const float *b2,
+                                       int32_t units, const float *act_weight, int32_t affine, const float *grad_u,
+                                       const float *grad_ildj, float *grad_x, float *grad_W1, float *grad_b1,
+                                       float *grad_W2, float *grad_b2, float *grad_act, void *ws, int64_t ws_bytes,
+                                       void *stream) {
+    DPK_REQUIRE(B >= 0 && D > 0 && units > 0, DPK_EINVAL, "coupling1d_backward: bad sizes");
+    DPK_REQUIRE(mask && inv_mask && W1 && b1 && W2 && b2 && ws, DPK_EINVAL, "coupling1d_backward: null pointer");
+    DPK_REQUIRE(!affine || act_weight, DPK_EINVAL, "coupling1d_backward: affine coupling needs the ScaledTanh weight");
+    const int64_t need = dpk_coupling1d_backward_workspace_bytes(B, D, units, affine);
+    DPK_REQUIRE(ws_bytes >= need, DPK_EWORKSPACE, "coupling1d_backward: workspace %lld < %lld", (long long)ws_bytes,
+                (long long)need);
+    hipStream_t st = (hipStream_t)stream;
+    const int zc = affine ? 2 * D : D;
+    if (grad_act) DPK_REQUIRE(hipMemsetAsync(grad_act, 0, 4, st) == hipSuccess, DPK_ELAUNCH, "memset");
+    if (B == 0) {
+        if (grad_W1) (void)hipMemsetAsync(grad_W1, 0, (size_t)units * D * 4, st);
+        if (grad_b1) (void)hipMemsetAsync(grad_b1, 0, (size_t)units * 4, st);
+        if (grad_W2) (void)hipMemsetAsync(grad_W2, 0, (size_t)zc * units * 4, st);
+        if (grad_b2) (void)hipMemsetAsync(grad_b2, 0, (size_t)zc * 4, st);
+        return DPK_OK;
+    }
+    DPK_REQUIRE(x && grad_x && (grad_u || grad_ildj), DPK_EINVAL, "coupling1d_backward: null pointer");
+    char *p = (char *)ws;
+    float *H = (float *)p;
+    p += align_up(B * units * 4, 256);
+    float *dH = (float *)p;
+    p += align_up(B * units * 4, 256);
+    float *Z = (float *)p;
+
+    GemmArgs g{};
+    // H = relu((mask * x) W1^T + b1)
+    g = GemmArgs{};
+    g.A = x; g.sam = D; g.sak = 1; g.kscale = mask;
+    g.Bm = W1; g.sbk = 1; g.sbn = D;
+    g.C = H; g.ldc = units; g.M = (int)B; g.N = units; g.K = D; g.bias = b1; g.relu = 1;
+    launch_gemm(g, st);
+    // Z = H W2^T + b2
+    g = GemmArgs{};
+    g.A = H; g.sam = units; g.sak = 1;
+    g.Bm = W2; g.sbk = 1; g.sbn = units;
+    g.C = Z; g.ldc = zc; g.M = (int)B; g.N = zc; g.K = units; g.bias = b2;
+    launch_gemm(g, st);
+    // element-wise core: Z <- dZ, grad_x <- direct term
+    hipLaunchKernelGGL(coupling_bwd_elem_kernel, dim3(grid1d(B * D)), dim3(256), 0, st, x, Z, inv_mask, act_weight,
+                       grad_u, grad_ildj, B, D, affine, grad_x, grad_act);
+    // dW2 = dZ^T H, db2 = colsum(dZ)
+    if (grad_W2) {
+        g = GemmArgs{};
+        g.A = Z; g.sam = 1; g.sak = zc;
+        g.Bm = H; g.sbk = units; g.sbn = 1;
+        g.C = grad_W2; g.ldc = units; g.M = zc; g.N = units; g.K = (int)B;
+        launch_gemm(g, st);
+    }
+    if (grad_b2) hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(zc, 64)), dim3(256), 0, st, Z, B, zc, (int64_t)zc, grad_b2);
+    // dH = (dZ W2) * [H > 0]
+    g = GemmArgs{};
+    g.A = Z; g.sam = zc; g.sak = 1;
+    g.Bm = W2; g.sbk = units; g.sbn = 1;
+    g.C = dH; g.ldc = units; g.M = (int)B; g.N = units; g.K = zc; g.gate = H; g.ldg = units;
+    launch_gemm(g, st);
+    // dW1 = dH^T (mask * x), db1 = colsum(dH)
+    if (grad_W1) {
+        g = GemmArgs{};
+        g.A = dH; g.sam = 1; g.sak = units;
+        g.Bm = x; g.sbk = D; g.sbn = 1; g.nscale = mask;
+        g.C = grad_W1; g.ldc = D; g.M = units; g.N = D; g.K = (int)B;
+        launch_gemm(g, st);
+    }
+    if (grad_b1)
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(units, 64)), dim3(256), 0, st, dH, B, units, (int64_t)units, grad_b1);
+    // grad_x += mask * (dH W1)
+    g = GemmArgs{};
+    g.A = dH; g.sam = units; g.sak = 1;
+    g.Bm = W1; g.sbk = D; g.sbn = 1; g.nscale = mask;
+    g.C = grad_x; g.ldc = D; g.M = (int)B; g.N = D; g.K = units; g.accumulate = 1;
+    launch_gemm(g, st);
+    DPK_CHECK_LAUNCH("coupling1d_backward");
+    return DPK_OK;
+}
+
+// Training-mode BatchNormLayer1d.apply_backward (deeprob/flows/utils.py:118-139): batch var_mean (unbiased),
+// running statistics updated in place with `momentum`, u = (x - mean)/sqrt(var + eps) * exp(weight) + bias,
+// ildj_const[0] = sum_d (weight_d - 0.5 log(var_d + eps)).  save_mean / save_var [D] feed the backward.
+extern "C" int dpk_bn1d_train_forward(const float *x, int64_t B, int32_t D, const float *weight, const float *bias,
+                                      float *running_var, float *running_mean, float momentum, float eps, float *out,
+                                      float *ildj_const, float *save_mean, float *save_var, void *ws, int64_t ws_bytes,
+                                      void *stream) {
+    DPK_REQUIRE(B >= 2 && D > 0, DPK_EINVAL, "bn1d_train_forward: needs at least 2 samples (unbiased variance)");
+    DPK_REQUIRE(x && weight && bias && running_var && running_mean && out && ildj_const && save_mean && save_var && ws,
+                DPK_EINVAL, "bn1d_train_forward: null pointer");
+    DPK_REQUIRE(ws_bytes >= (int64_t)2 * D * 4, DPK_EWORKSPACE, "bn1d_train_forward: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float *sc = (float *)ws, *sh = sc + D;
+    DPK_REQUIRE(hipMemsetAsync(ildj_const, 0, 4, st) == hipSuccess, DPK_ELAUNCH, "memset");
+    hipLaunchKernelGGL(bn1d_stats_kernel, dim3(cdiv(D, 64)), dim3(256), 0, st, x, B, D, weight, bias, momentum, eps,
+                       running_var, running_mean, save_mean, save_var, sc, sh, ildj_const);
+    DPK_CHECK_LAUNCH("bn1d_stats_kernel");
+    return dpk_affine1d_forward(x, sc, sh, B, D, out, stream);
+}
+
+// Backward of BatchNormLayer1d.apply_backward.  train=1: mean/var are the saved batch statistics and the
+// gradient flows through them; train=0: mean/var are the running statistics (constants).
+// grad_ildj [B] may be NULL.  Workspace: 3*D + 1 floats.
+extern "C" int dpk_bn1d_backward(const float *x, const float *grad_u, const float *grad_ildj, int64_t B, int32_t D,
+                                 const float *weight, const float *mean, const float *var, float eps, int32_t train,
+                                 float *grad_x, float *grad_weight, float *grad_bias, void *ws, int64_t ws_bytes,
+                                 void *stream) {
+    DPK_REQUIRE(B >= 1 && D > 0 && (!train || B >= 2), DPK_EINVAL, "bn1d_backward: bad sizes");
+    DPK_REQUIRE(x && grad_u && weight && mean && var && grad_x && ws, DPK_EINVAL, "bn1d_backward: null pointer");
+    DPK_REQUIRE(ws_bytes >= (int64_t)(2 * D + 64) * 4, DPK_EWORKSPACE, "bn1d_backward: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float *s1 = (float *)ws, *s2 = s1 + D, *sg = s2 + D;
+    if (grad_ildj) hipLaunchKernelGGL(vecsum_kernel, dim3(1), dim3(256), 0, st, grad_ildj, B, sg);
+    hipLaunchKernelGGL(bn1d_bwd_reduce_kernel, dim3(cdiv(D, 64)), dim3(256), 0, st, x, grad_u, B, D, mean, var, eps, s1,
+                       s2);
+    hipLaunchKernelGGL(bn1d_bwd_apply_kernel, dim3(grid1d(B * D)), dim3(256), 0, st, x, grad_u,
+                       grad_ildj ? sg : nullptr, B, D, weight, mean, var, eps, s1, s2, train, grad_x, grad_weight,
+                       grad_bias);
+    DPK_CHECK_LAUNCH("bn1d_backward");
+    return DPK_OK;
+}
+
+// d/du of dpk_normal_base_logprob (no incoming affine): grad_u[b,d] = -g[b] (u - loc)/scale^2
+extern "C" int dpk_normal_base_backward(const float *u, const float *loc, const float *scale, const float *g, int64_t B,
+                                        int32_t D, float *grad_u, void *stream) {
+    DPK_REQUIRE(B >= 0 && D > 0, DPK_EINVAL, "normal_base_backward: bad sizes");
+    if (B == 0) return DPK_OK;
+    DPK_REQUIRE(u && loc && scale && g && grad_u, DPK_EINVAL, "normal_base_backward: null pointer");
+    hipLaunchKernelGGL(normal_base_bwd_kernel, dim3(grid1d(B * D)), dim3(256), 0, (hipStream_t)stream, u, loc, scale, g,
+                       B, D, grad_u);
+    DPK_CHECK_LAUNCH("normal_base_bwd_kernel");
+    return DPK_OK;
+}

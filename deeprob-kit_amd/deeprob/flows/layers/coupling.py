@@ -40,6 +40,7 @@ class CouplingLayer1d(Bijector):
         if affine:
             self.scale_act = ScaledTanh()
         self._ws = Workspace()
+        self._ws_bwd = Workspace()
         self._counts = None
 
     def build_alternating_masks(self) -> Tuple[np.ndarray, np.ndarray]:
@@ -60,7 +61,7 @@ class CouplingLayer1d(Bijector):
     def apply_backward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """u = (x - t) exp(-s), ildj = -sum(s) with (t, s) = conditioner(mask * x) (reference :72-87)."""
         from deeprob.hip import ops_flows
-        return ops_flows.coupling1d(x, self, inverse=False)
+        return ops_flows.coupling1d_autograd(x, self)
 
     def apply_forward(self, u: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """x = u exp(s) + t, ldj = sum(s) (reference :89-104)."""

@@ -84,7 +84,7 @@ class NormalizingFlow(ProbabilisticModel):
         Normal: the whole density evaluation chains HIP kernels with the batch norms folded away."""
         if not isinstance(self.in_base, distributions.Normal) or not hasattr(self, 'in_base_loc'):
             return False
-        if self.training:
+        if self.training or torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return False
         return all(isinstance(l, (CouplingLayer1d, BatchNormLayer1d)) for l in self.layers)
 
@@ -92,10 +92,13 @@ class NormalizingFlow(ProbabilisticModel):
         """Log-likelihood of complete evidence, shape [B] (reference :123-143)."""
         batch_size = x.shape[0]
         x, ildj = self.preprocess(x)
-        if self._fusable() and x.dim() == 2:
+        if self._fusable() and x.dim() == 2 and not (torch.is_grad_enabled() and x.requires_grad):
             return self._forward_fused(x, ildj)
         x, d = self.apply_backward(x)
         ildj = ildj + d
+        if isinstance(self.in_base, distributions.Normal) and hasattr(self, 'in_base_loc') and x.dim() == 2:
+            from deeprob.hip import ops_flows
+            return ops_flows.NormalBaseFn.apply(x, self.in_base_loc, self.in_base_scale) + ildj
         base_lls = self.in_base.log_prob(x)
         return torch.sum(base_lls.view(batch_size, -1), dim=1) + ildj
 

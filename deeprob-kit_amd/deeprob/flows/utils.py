@@ -13,7 +13,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from deeprob.hip import HipError
+from deeprob.hip import HipError, Workspace
 
 
 class Bijector(abc.ABC, nn.Module):
@@ -58,17 +58,14 @@ class BatchNormLayer1d(Bijector):
         self.bias = nn.Parameter(torch.zeros(1, self.in_features), requires_grad=True)
         self.register_buffer('running_var', torch.ones(1, self.in_features))
         self.register_buffer('running_mean', torch.zeros(1, self.in_features))
-
-    def _eval_only(self):
-        if self.training:
-            raise HipError("training-mode BatchNormLayer1d (batch statistics) is not on the HIP path yet; "
-                           "call .eval()")
+        self._ws = Workspace()
 
     def apply_backward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        """u = (x - mean)/sqrt(var + eps) * exp(weight) + bias (reference :118-139, eval branch)."""
+        """u = (x - mean)/sqrt(var + eps) * exp(weight) + bias with the batch statistics (training: running
+        statistics updated in place) or the running statistics (eval); reference :118-139."""
         from deeprob.hip import ops_flows
-        self._eval_only()
-        ops_flows._no_graph(x, self.weight)
+        if self.training or ops_flows._wants_graph(x, self.weight, self.bias):
+            return ops_flows.BatchNormFn.apply(x, self.weight, self.bias, self)
         affine, ldj = ops_flows.bn1d_fold(self, inverse=False)
         return ops_flows.affine1d(x, affine), ldj.expand(x.shape[0])
 

@@ -1,7 +1,9 @@
-"""Flow operators on top of the C ABI: RealNVP-1D coupling, folded eval-mode batch norm, Normal base.
+"""Flow operators on top of the C ABI: RealNVP-1D coupling, batch norm (folded in eval mode, batch statistics in
+training mode), Normal base.
 
-Forward (density / sampling) only in this round: the kernels have no backward yet, so calling them
-while autograd would need a graph raises instead of silently returning a detached result.
+Density direction (`apply_backward`, what `log_prob` / training uses): forward and autograd.  Sampling direction
+(`apply_forward`): forward only -- asking autograd for a graph through it raises instead of silently returning a
+detached result.
 """
 from typing import Optional, Tuple
 
@@ -13,8 +15,8 @@ from deeprob.hip import load_library, check, ptr, stream_ptr, require_device_f32
 def _no_graph(*tensors):
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
         raise HipError(
-            "the HIP flow kernels are forward-only in this round (no backward): wrap the call in "
-            "torch.no_grad() / model.eval(), or freeze the parameters"
+            "the sampling direction (apply_forward) of the HIP flow kernels has no backward: wrap the call in "
+            "torch.no_grad(), or freeze the parameters"
         )
 
 
@@ -24,7 +26,8 @@ def coupling1d(x: torch.Tensor, layer, inverse: bool, in_affine: Optional[Tuple[
     lib = load_library()
     x = require_device_f32(x, 'x')
     lin1, lin2 = layer.network[0], layer.network[-1]
-    _no_graph(x, lin1.weight, lin2.weight)
+    if inverse:
+        _no_graph(x, lin1.weight, lin2.weight)
     if len(layer.network) != 3:
         raise HipError("CouplingLayer1d on the HIP path supports conditioner depth 1 (got {} hidden layers)"
                        .format((len(layer.network) - 1) // 2))
@@ -91,3 +94,130 @@ def normal_base_logprob(u: torch.Tensor, affine, loc, scale, ildj, ildj_const) -
                                       ptr(require_device_f32(scale, 'scale')), ptr(ildj), ptr(ildj_const), B, D,
                                       ptr(out), stream_ptr(u.device)), 'dpk_normal_base_logprob')
     return out
+
+
+def _wants_graph(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+class CouplingFn(torch.autograd.Function):
+    """CouplingLayer1d.apply_backward with autograd (reference: flows/layers/coupling.py:72-87; backward
+    formulas SURVEY 8a).  The conditioner activations are recomputed in the backward."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, act, layer):
+        with torch.no_grad():
+            u, ildj = coupling1d(x, layer, inverse=False)
+        ctx.save_for_backward(x, W1, b1, W2, b2, act)
+        ctx.layer = layer
+        return u, ildj
+
+    @staticmethod
+    def backward(ctx, gu, gildj):
+        lib = load_library()
+        x, W1, b1, W2, b2, act = ctx.saved_tensors
+        layer = ctx.layer
+        B, D = x.shape
+        units = W1.shape[0]
+        gu = require_device_f32(gu, 'grad_u')
+        gildj = require_device_f32(gildj, 'grad_ildj')
+        need = ctx.needs_input_grad
+        gx = torch.empty_like(x)
+        gW1 = torch.empty_like(W1) if need[1] else None
+        gb1 = torch.empty_like(b1) if need[2] else None
+        gW2 = torch.empty_like(W2) if need[3] else None
+        gb2 = torch.empty_like(b2) if need[4] else None
+        gact = torch.empty_like(act) if (act is not None and need[5]) else None
+        n = lib.dpk_coupling1d_backward_workspace_bytes(B, D, units, int(layer.affine))
+        if n < 0:
+            check(int(n), 'dpk_coupling1d_backward_workspace_bytes')
+        ws = layer._ws_bwd.get(n, x.device)
+        check(lib.dpk_coupling1d_backward(
+            ptr(x), B, D, ptr(layer.mask), ptr(layer.inv_mask), ptr(W1), ptr(b1), ptr(W2), ptr(b2), units, ptr(act),
+            int(layer.affine), ptr(gu), ptr(gildj), ptr(gx), ptr(gW1), ptr(gb1), ptr(gW2), ptr(gb2), ptr(gact),
+            ptr(ws), ws.numel(), stream_ptr(x.device)), 'dpk_coupling1d_backward')
+        return gx, gW1, gb1, gW2, gb2, gact, None
+
+
+def coupling1d_autograd(x: torch.Tensor, layer) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Density direction of a coupling layer, recording an autograd node when a graph is needed."""
+    lin1, lin2 = layer.network[0], layer.network[-1]
+    act = layer.scale_act.weight if layer.affine else None
+    if not _wants_graph(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias, act):
+        return coupling1d(x, layer, inverse=False)
+    layer._mask_counts()   # binary-mask check
+    return CouplingFn.apply(require_device_f32(x, 'x'), require_device_f32(lin1.weight, 'W1'),
+                            require_device_f32(lin1.bias, 'b1'), require_device_f32(lin2.weight, 'W2'),
+                            require_device_f32(lin2.bias, 'b2'), act, layer)
+
+
+class BatchNormFn(torch.autograd.Function):
+    """BatchNormLayer1d.apply_backward (reference: flows/utils.py:118-139): batch statistics + running-statistics
+    update when the layer is training, running statistics otherwise; autograd through either."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn):
+        lib = load_library()
+        x = require_device_f32(x, 'x')
+        B, D = x.shape
+        dev = x.device
+        train = bool(bn.training)
+        if train:
+            u = torch.empty_like(x)
+            ldj = torch.empty(1, dtype=torch.float32, device=dev)
+            mean = torch.empty(D, dtype=torch.float32, device=dev)
+            var = torch.empty(D, dtype=torch.float32, device=dev)
+            ws = bn._ws.get(8 * D + 256, dev)
+            check(lib.dpk_bn1d_train_forward(ptr(x), B, D, ptr(require_device_f32(weight, 'weight')),
+                                             ptr(require_device_f32(bias, 'bias')), ptr(bn.running_var),
+                                             ptr(bn.running_mean), float(bn.momentum), float(bn.eps), ptr(u), ptr(ldj),
+                                             ptr(mean), ptr(var), ptr(ws), ws.numel(), stream_ptr(dev)),
+                  'dpk_bn1d_train_forward')
+        else:
+            affine, ldj = bn1d_fold(bn, inverse=False)
+            u = affine1d(x, affine)
+            mean, var = bn.running_mean.detach().reshape(-1).clone(), bn.running_var.detach().reshape(-1).clone()
+        ctx.save_for_backward(x, weight, mean, var)
+        ctx.bn, ctx.train = bn, train
+        return u, ldj.repeat(B)
+
+    @staticmethod
+    def backward(ctx, gu, gildj):
+        lib = load_library()
+        x, weight, mean, var = ctx.saved_tensors
+        bn = ctx.bn
+        B, D = x.shape
+        gu = require_device_f32(gu, 'grad_u')
+        gildj = require_device_f32(gildj, 'grad_ildj')
+        gx = torch.empty_like(x)
+        gw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
+        gb = torch.empty_like(weight) if ctx.needs_input_grad[2] else None
+        ws = bn._ws.get(4 * (2 * D + 64) + 256, x.device)
+        check(lib.dpk_bn1d_backward(ptr(x), ptr(gu), ptr(gildj), B, D, ptr(weight), ptr(mean), ptr(var),
+                                    float(bn.eps), int(ctx.train), ptr(gx), ptr(gw), ptr(gb), ptr(ws), ws.numel(),
+                                    stream_ptr(x.device)), 'dpk_bn1d_backward')
+        return gx, gw, gb, None
+
+
+class NormalBaseFn(torch.autograd.Function):
+    """sum_d log N(u_d; loc_d, scale_d) for the default (frozen) Normal base (reference: flows/models/base.py:139-140)."""
+
+    @staticmethod
+    def forward(ctx, u, loc, scale):
+        out = normal_base_logprob(u, None, loc, scale, None, None)
+        ctx.save_for_backward(u, loc, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load_library()
+        u, loc, scale = ctx.saved_tensors
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise HipError("the Normal base of the HIP flow path is frozen (in_base_loc / in_base_scale do not "
+                           "require grad in the reference either)")
+        g = require_device_f32(g, 'grad')
+        B, D = u.shape
+        gu = torch.empty_like(u)
+        check(lib.dpk_normal_base_backward(ptr(u), ptr(loc), ptr(scale), ptr(g), B, D, ptr(gu), stream_ptr(u.device)),
+              'dpk_normal_base_backward')
+        return gu, None, None

@@ -219,6 +219,36 @@ int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C, int32_t H
                                 int32_t dw, int32_t pad_top, int32_t pad_left, const float *weight, int32_t Cout,
                                 float *out, void *ws, int64_t ws_bytes, void *stream);
 
+/* ---- RealNVP-1D training route (autograd of the flow) ------------------- */
+/* Backward of CouplingLayer1d.apply_backward (flows/layers/coupling.py:72-87), depth-1 conditioner:
+ * given grad_u [B,D] and grad_ildj [B] (either may be NULL = zeros) writes grad_x [B,D] and, where
+ * non-NULL, grad_W1 [units,D], grad_b1 [units], grad_W2 [2D|D,units], grad_b2 [2D|D], grad_act [1].
+ * The forward activations are recomputed.  Binary masks.                                       */
+int64_t dpk_coupling1d_backward_workspace_bytes(int64_t B, int32_t D, int32_t units, int32_t affine);
+int dpk_coupling1d_backward(const float *x, int64_t B, int32_t D, const float *mask, const float *inv_mask,
+                            const float *W1, const float *b1, const float *W2, const float *b2, int32_t units,
+                            const float *act_weight, int32_t affine, const float *grad_u, const float *grad_ildj,
+                            float *grad_x, float *grad_W1, float *grad_b1, float *grad_W2, float *grad_b2,
+                            float *grad_act, void *ws, int64_t ws_bytes, void *stream);
+/* Training-mode BatchNormLayer1d.apply_backward (flows/utils.py:118-139): torch.var_mean over the batch
+ * (unbiased), running_var / running_mean updated IN PLACE with `momentum`, out = (x-mean)/sqrt(var+eps)
+ * * exp(weight) + bias, ildj_const[0] = sum_d(weight_d - 0.5 log(var_d+eps)); save_mean/save_var [D]
+ * are the batch statistics for dpk_bn1d_backward.  Workspace >= 2*D floats.  B >= 2.            */
+int dpk_bn1d_train_forward(const float *x, int64_t B, int32_t D, const float *weight, const float *bias,
+                           float *running_var, float *running_mean, float momentum, float eps, float *out,
+                           float *ildj_const, float *save_mean, float *save_var, void *ws, int64_t ws_bytes,
+                           void *stream);
+/* Backward of BatchNormLayer1d.apply_backward: train=1 with the saved batch statistics (gradient flows
+ * through them), train=0 with the running statistics as constants.  grad_ildj [B] may be NULL;
+ * grad_weight / grad_bias [D] may be NULL.  Workspace >= (2*D + 64) floats.                     */
+int dpk_bn1d_backward(const float *x, const float *grad_u, const float *grad_ildj, int64_t B, int32_t D,
+                      const float *weight, const float *mean, const float *var, float eps, int32_t train,
+                      float *grad_x, float *grad_weight, float *grad_bias, void *ws, int64_t ws_bytes,
+                      void *stream);
+/* d/du of dpk_normal_base_logprob without incoming affine: grad_u[b,d] = -g[b](u-loc)/scale^2.  */
+int dpk_normal_base_backward(const float *u, const float *loc, const float *scale, const float *g, int64_t B,
+                             int32_t D, float *grad_u, void *stream);
+
 /* Measurement hook: the NEXT dominant-kernel launch made from this thread (the fused / leaf
  * forward kernel) is bracketed by hipEventRecord(ev_start) / hipEventRecord(ev_stop) on its stream,
  * so a harness can time that kernel alone inside a longer step.  One-shot; pass NULLs to cancel. */

@@ -68,6 +68,18 @@ def bn_backward(x, weight, bias, var, mean, eps=1e-5):
     return u, torch.sum(weight - 0.5 * torch.log(var)).expand(x.shape[0])
 
 
+def bn_backward_train(x, weight, bias, running_var, running_mean, momentum=0.9, eps=1e-5):
+    """flows/utils.py:118-139, training branch: batch var_mean (unbiased), running statistics updated with
+    `momentum`.  Returns (u, ildj, new_running_var, new_running_mean)."""
+    var, mean = torch.var_mean(x, dim=0, keepdim=True)
+    new_var = running_var * momentum + var.detach() * (1.0 - momentum)
+    new_mean = running_mean * momentum + mean.detach() * (1.0 - momentum)
+    var = var + eps
+    u = (x - mean) / torch.sqrt(var)
+    u = u * torch.exp(weight) + bias
+    return u, torch.sum(weight - 0.5 * torch.log(var)).expand(x.shape[0]), new_var, new_mean
+
+
 def bn_forward(u, weight, bias, var, mean, eps=1e-5):
     """flows/utils.py:141-153."""
     var = var + eps
@@ -96,13 +108,19 @@ def flow_layers(sd) -> List[Tuple[str, int]]:
         i += 1
 
 
-def flow_apply_backward(sd, x, collect=None):
-    """NormalizingFlow.apply_backward (base.py:182-193)."""
+def flow_apply_backward(sd, x, collect=None, train=False, running=None):
+    """NormalizingFlow.apply_backward (base.py:182-193).  train=True: batch-norm layers use batch statistics;
+    the updated running statistics are written into the dict `running`."""
     ildj = torch.zeros(x.shape[0], dtype=x.dtype)
     for kind, i in flow_layers(sd):
         p = 'layers.{}.'.format(i)
         if kind == 'coupling':
             x, d = coupling_backward(x, *coupling_params(sd, i))
+        elif train:
+            x, d, nv, nm = bn_backward_train(x, sd[p + 'weight'], sd[p + 'bias'], sd[p + 'running_var'],
+                                             sd[p + 'running_mean'])
+            if running is not None:
+                running[p + 'running_var'], running[p + 'running_mean'] = nv, nm
         else:
             x, d = bn_backward(x, sd[p + 'weight'], sd[p + 'bias'], sd[p + 'running_var'], sd[p + 'running_mean'])
         ildj = ildj + d
@@ -124,15 +142,18 @@ def flow_apply_forward(sd, u):
     return u, ldj
 
 
-def flow_log_prob(sd, x, logit_alpha=None):
-    """NormalizingFlow.forward with the default Normal base (base.py:123-143)."""
+def flow_log_prob(sd, x, logit_alpha=None, train=False, running=None, base=None):
+    """NormalizingFlow.forward (base.py:123-143) with the default Normal base, or `base(u) -> [B, 1]` (a module
+    base density such as a RAT-SPN)."""
     n = x.shape[0]
     ildj = torch.zeros(n, dtype=x.dtype)
     if logit_alpha is not None:
         x, d = logit_backward(x, logit_alpha, sd['logit.ldj'])
         ildj = ildj + d
-    u, d = flow_apply_backward(sd, x)
+    u, d = flow_apply_backward(sd, x, train=train, running=running)
     ildj = ildj + d
+    if base is not None:
+        return torch.sum(base(u).view(n, -1), dim=1) + ildj
     loc, scale = sd['in_base_loc'], sd['in_base_scale']
     lp = -((u - loc) ** 2) / (2 * scale ** 2) - scale.log() - math.log(math.sqrt(2 * math.pi))
     return torch.sum(lp.view(n, -1), dim=1) + ildj

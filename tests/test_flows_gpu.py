@@ -89,3 +89,67 @@ def test_full_size_round_trip():
     assert torch.allclose(xr, x, atol=2e-4, rtol=1e-4)
     assert torch.allclose(ldj, -ildj, atol=1e-3, rtol=1e-5)
     assert torch.equal(ll[777:777 + 4097], part)
+
+
+@pytest.mark.parametrize('name', sorted(__import__('tests.flow_cases', fromlist=['TRAIN_CASES']).TRAIN_CASES))
+def test_training_route_golden(golden, name):
+    """Autograd through the HIP flow (coupling backward, train-mode batch norm, Normal / RAT-SPN base): LL, loss,
+    d/dx, every parameter gradient and the running statistics after the step, against the reference's."""
+    from tests.flow_cases import TRAIN_CASES, build_train_flow
+    from tests.util import grad_err
+    g = golden(name)
+    train = TRAIN_CASES[name][1]
+    model = build_train_flow(name, g).cuda()
+    model.train(train)
+    x = torch.from_numpy(g['x']).cuda().requires_grad_(True)
+    ll = model(x)
+    loss = model.loss(ll)
+    loss.backward()
+    assert rel_err(ll.detach().cpu().numpy(), g['ll']) <= 1e-5
+    assert rel_err(loss.detach().cpu().numpy(), g['loss']) <= 1e-5
+    assert grad_err(x.grad.cpu().numpy(), g['grad.x']) <= 1e-4
+    checked = 0
+    for k, p in model.named_parameters():
+        if 'grad.' + k in g.files:
+            assert p.grad is not None, k
+            ref = g['grad.' + k]
+            if np.max(np.abs(ref)) < 1e-6:
+                # mathematically zero (a NICE shift in front of a train-mode batch norm): the reference holds
+                # rounding noise only
+                assert np.max(np.abs(p.grad.cpu().numpy())) < 1e-6, k
+            else:
+                assert grad_err(p.grad.cpu().numpy(), ref) <= 1e-4, k
+            checked += 1
+    assert checked >= 4
+    sd = model.state_dict()
+    for k in g.files:
+        if k.startswith('after.'):
+            assert rel_err(sd[k[6:]].cpu().numpy(), g[k]) <= 1e-5, k
+
+
+def test_training_step_reduces_loss():
+    """A few Adam steps on the HIP training route (the loop of deeprob/torch/routines.py:117-170 in miniature)."""
+    from deeprob.flows.models import RealNVP1d
+    torch.manual_seed(0)
+    flow = RealNVP1d(32, n_flows=2, units=32).cuda().train()
+    data = (torch.randn(256, 32) * 0.5 + 1.0).cuda()
+    opt = torch.optim.Adam(flow.parameters(), lr=1e-2)
+    losses = []
+    for _ in range(15):
+        opt.zero_grad()
+        loss = flow.loss(flow(data))
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0] - 1.0 and all(np.isfinite(losses))
+
+
+def test_sampling_direction_has_no_silent_graph():
+    from deeprob.hip import HipError
+    from deeprob.flows.models import RealNVP1d
+    flow = RealNVP1d(16, n_flows=1, units=32).cuda().eval()
+    u = torch.randn(4, 16, device='cuda')
+    with pytest.raises(HipError):
+        flow.apply_forward(u)          # parameters require grad and grad mode is on
+    with torch.no_grad():
+        flow.apply_forward(u)

@@ -40,3 +40,34 @@ def test_invertibility_like_reference():
         u, ildj = forc.flow_apply_backward(sd, x)
         xr, ldj = forc.flow_apply_forward(sd, u)
         assert torch.allclose(ildj, -ldj, atol=5e-7) and torch.allclose(xr, x, atol=5e-7)
+
+
+@pytest.mark.parametrize('name', sorted(__import__('tests.flow_cases', fromlist=['TRAIN_CASES']).TRAIN_CASES))
+def test_training_route_matches_reference(golden, name):
+    """Autograd through the oracle == the reference's autograd (LL, loss, d/dx, every parameter gradient) and the
+    running statistics after a train-mode forward."""
+    from tests.flow_cases import TRAIN_CASES
+    from tests.util import grad_err
+    from oracle import ratspn_oracle as orc
+    g = golden(name)
+    kw, train, base_kw = TRAIN_CASES[name]
+    sd = {k[3:]: torch.from_numpy(np.asarray(g[k])).clone() for k in g.files if k.startswith('sd.')}
+    leaves = {k: v.requires_grad_(True) for k, v in sd.items() if 'grad.' + k in g.files}
+    x = torch.from_numpy(g['x']).requires_grad_(True)
+    base = None
+    if base_kw is not None:
+        bsd = {k[len('in_base.'):]: v for k, v in sd.items() if k.startswith('in_base.')}
+        base = lambda u: orc.ratspn_forward(bsd, u)   # noqa: E731
+    running = {}
+    ll = forc.flow_log_prob(sd, x, logit_alpha=kw.get('logit'), train=train and kw.get('batch_norm', True),
+                            running=running, base=base)
+    loss = -torch.mean(ll)
+    loss.backward()
+    assert rel_err(ll.detach().numpy(), g['ll']) <= 2e-6 and rel_err(loss.detach().numpy(), g['loss']) <= 2e-6
+    assert grad_err(x.grad.numpy(), g['grad.x']) <= 1e-5
+    assert leaves
+    for k, v in leaves.items():
+        assert grad_err(v.grad.numpy(), g['grad.' + k]) <= 1e-5, k
+    for k in g.files:
+        if k.startswith('after.') and train:
+            assert rel_err(running[k[6:]].numpy(), g[k]) <= 2e-6, k

@@ -19,7 +19,7 @@ OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'g
 
 
 def _np(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()
 
 
 def _sd(model):
@@ -180,7 +180,7 @@ def gen_ratspn():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='region,ratspn,flows,dgcspn')
+    ap.add_argument('--only', default='region,ratspn,flows,flows_train,dgcspn')
     args = ap.parse_args()
     import deeprob
     ref = os.path.realpath(os.path.dirname(deeprob.__file__))
@@ -190,9 +190,9 @@ def main():
     todo = set(args.only.split(','))
     gens = {'region': gen_region, 'ratspn': gen_ratspn}
     try:
-        from gen_golden_flows import gen_flows
+        from gen_golden_flows import gen_flows, gen_flows_train
         from gen_golden_dgcspn import gen_dgcspn
-        gens.update({'flows': gen_flows, 'dgcspn': gen_dgcspn})
+        gens.update({'flows': gen_flows, 'flows_train': gen_flows_train, 'dgcspn': gen_dgcspn})
     except ImportError:
         pass
     for key, fn in gens.items():

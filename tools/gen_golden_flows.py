@@ -68,3 +68,51 @@ def gen_flows():
     _randomise_flow(m, 15)
     _flow_fixture('realnvp1d_15', m, torch.randn(9, 15, generator=torch.Generator().manual_seed(2)))
 
+
+
+def _flow_train_fixture(name, model, x, train):
+    """One optimisation step's worth of autograd through the flow: LL, loss, d/dx, every parameter gradient
+    and (train mode) the running statistics after the batch-statistics forward."""
+    arrays = _sd(model)
+    arrays['x'] = _np(x)
+    model.train(train)
+    xg = x.clone().requires_grad_(True)
+    with torch.enable_grad():
+        ll = model(xg)
+        loss = model.loss(ll)
+        loss.backward()
+    arrays['ll'] = _np(ll)
+    arrays['loss'] = _np(loss)
+    arrays['grad.x'] = _np(xg.grad)
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            arrays['grad.' + k] = _np(p.grad)
+    for k, v in model.state_dict().items():
+        if 'running_' in k:
+            arrays['after.' + k] = _np(v)
+    _save(name, **arrays)
+
+
+def gen_flows_train():
+    from deeprob.flows.models.realnvp import RealNVP1d
+    from deeprob.spn.models.ratspn import GaussianRatSpn
+    g = torch.Generator().manual_seed(20)
+    for tag, train in [('realnvp1d_train_20', True), ('realnvp1d_evalgrad_20', False)]:
+        torch.manual_seed(21)
+        m = RealNVP1d(20, n_flows=3, units=32)
+        _randomise_flow(m, 22)
+        _flow_train_fixture(tag, m, torch.randn(24, 20, generator=torch.Generator().manual_seed(23)), train)
+    torch.manual_seed(24)
+    m = RealNVP1d(15, n_flows=2, units=64, affine=False)
+    _randomise_flow(m, 25)
+    _flow_train_fixture('realnvp1d_train_nice_15', m, torch.randn(10, 15, generator=g), True)
+    torch.manual_seed(26)
+    m = RealNVP1d(12, n_flows=2, units=32, batch_norm=False, logit=0.1)
+    _randomise_flow(m, 27)
+    _flow_train_fixture('realnvp1d_train_nobn_logit_12', m, torch.rand(70, 12, generator=g), True)
+    # RAT-SPN as the base density (examples/ratspn_nvp1d_mnist.py:35-54): needs d/dx of the SPN
+    torch.manual_seed(28)
+    base = GaussianRatSpn(16, rg_depth=1, rg_repetitions=2, rg_batch=2, rg_sum=2, random_state=42)
+    m = RealNVP1d(16, n_flows=2, units=32, in_base=base)
+    _randomise_flow(m, 29)
+    _flow_train_fixture('realnvp1d_train_ratspn_base_16', m, torch.randn(12, 16, generator=g), True)
