@@ -29,6 +29,7 @@ void profile_take(hipEvent_t *start, hipEvent_t *stop);  // one-shot measurement
     } while (0)
 
 constexpr int kWave = 64;           // CDNA wavefront
+constexpr float kExpandBound = 6.0f; // |x|, |mu| bound under which the unit-scale leaf uses the expanded square
 constexpr int kChunk = 64;          // features staged in LDS per chunk (FC)
 constexpr int kLeafWaves = 8;       // waves per work-group of the leaf / fused kernels
 constexpr float kLogSqrt2Pi = 0.918938533204672741780329736406f;
@@ -57,7 +58,9 @@ struct RatWs {
     float *par;   // [G*ncb*SP*2CB] {p0[CB], p1[CB]} per entry, channel-block major
     float *cel;   // [G*ncb*SP*CB]  additive constant per entry
     float *biasc; // [R*NC*I] per-(region, chunk) sum of cel
-    int *unit;    // [R] 1 if every scale of the region equals 1 (Gaussian leaves)
+    float *biasx; // [R*NC*I] the same minus half the sum of squared means (expanded unit-scale form)
+    int *unit;    // [R] Gaussian leaves: 1 if every scale of the region equals 1, 2 if additionally every
+                  // |mean| <= kExpandBound (the expanded form x^2 - 2 x mu + mu^2 is then safe)
     float *rec;   // [G*(SP/4)*(4+8I)] block records staged into LDS by the kernels (I <= 2 only)
     int tabcap;   // LDS bytes per wave for the records of one chunk, 0 = records not used
     float *w[3];  // linear softmax weights: sum layer 0, sum layer 1, root
@@ -94,6 +97,7 @@ inline RatWs carve_ratspn_ws(void *base, int D, int R, int d, int I, int QB, int
     w.par = (float *)take(GS * 2 * I * 4);
     w.cel = (float *)take(GS * I * 4);
     w.biasc = (float *)take((int64_t)R * NC * I * 4);
+    w.biasx = (float *)take((int64_t)R * NC * I * 4);
     w.unit = (int *)take((int64_t)R * 4);
     w.rec = nullptr;
     w.tabcap = 0;

@@ -135,7 +135,7 @@ struct PrepArgs {
     const float *p0, *p1;
     const int *srcr, *nblk, *segoff, *fl2;
     int R, I, CB, d, NC, QB, SP, G;
-    float *par, *cel, *biasc, *rec;
+    float *par, *cel, *biasc, *biasx, *rec;
     int *unit;
     // up to three weight matrices [rows, n] -> W (softmax), LW (log_softmax)
     const float *w[3];
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void ratspn_prep_kernel(const PrepArgs a) {
             const int c = cq / QB, q = cq - c * QB;
             const int64_t so = ((int64_t)g * NC + c) * QB + q;
             const int j0 = a.segoff[so], j1 = j0 + a.nblk[so] * kBlock;
-            float s = 0.f;
+            float s = 0.f, s2 = 0.f;
             for (int p = j0 + lane; p < j1; p += 64) {
                 const int rj = a.srcr[(int64_t)g * SP + p];
                 if (rj >= 0) {
@@ -238,25 +238,35 @@ __global__ __launch_bounds__(256) void ratspn_prep_kernel(const PrepArgs a) {
                     float A, Bv, Cc;
                     leaf_entry_params(DIST, a.p0, a.p1, ((int64_t)r * I + k) * d + j, A, Bv, Cc);
                     s += Cc;
+                    s2 = fmaf(A, A, s2);
                 }
             }
             s = wave_reduce_sum(s);
-            if (lane == 0) a.biasc[((int64_t)(g * QB + q) * NC + c) * I + k] = s;
+            s2 = wave_reduce_sum(s2);
+            if (lane == 0) {
+                a.biasc[((int64_t)(g * QB + q) * NC + c) * I + k] = s;
+                a.biasx[((int64_t)(g * QB + q) * NC + c) * I + k] = s - 0.5f * s2;
+            }
         }
     }
     // unit-scale flag per region (slice 0 scans the group's scales)
     if (sl == 0) {
-        __shared__ int not_unit[8];
-        if (threadIdx.x < 8) not_unit[threadIdx.x] = (DIST != 0);
+        __shared__ int not_unit[8], big_mean[8];
+        if (threadIdx.x < 8) {
+            not_unit[threadIdx.x] = (DIST != 0);
+            big_mean[threadIdx.x] = 0;
+        }
         __syncthreads();
         if (DIST == 0) {
             for (int e = threadIdx.x; e < QB * I * d; e += blockDim.x) {
                 const int q = e / (I * d);
                 if (a.p1[(int64_t)g * QB * I * d + e] != 1.0f) not_unit[q] = 1;
+                if (!(fabsf(a.p0[(int64_t)g * QB * I * d + e]) <= kExpandBound)) big_mean[q] = 1;
             }
         }
         __syncthreads();
-        if (threadIdx.x < QB) a.unit[g * QB + threadIdx.x] = !not_unit[threadIdx.x];
+        if (threadIdx.x < QB)
+            a.unit[g * QB + threadIdx.x] = not_unit[threadIdx.x] ? 0 : (big_mean[threadIdx.x] ? 1 : 2);
     }
 }
 
@@ -377,7 +387,8 @@ struct LeafArgs {
     cfloat_p par;
     cfloat_p cel;
     cfloat_p biasc;
-    cint_p unit;      // [R] 1 if every scale of the region is exactly 1
+    cfloat_p biasx;   // biasc - 0.5 * sum mu^2 (expanded unit-scale form)
+    cint_p unit;      // [R] 1: every scale of the region is exactly 1; 2: and every |mean| <= kExpandBound
     float *leaf_out;  // [B,R,I] or nullptr
     // fused model
     int reps, C;
@@ -596,6 +607,8 @@ __device__ __forceinline__ void leaf_accum_plain(float (&acc)[CB][SPL], const ch
 //     dwords 0..3            LDS byte offsets of the 4 entries' x rows
 //     dwords 4..4+4CB-1      p0 (mean)        [entry][channel]
 //     dwords 4+4CB..4+8CB-1  p1 (-1/2sigma^2) [entry][channel]
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int CB> struct RecGeom {
     static constexpr int RECB = 4 + 8 * CB;   // dwords per block record
     static constexpr int RECBB = RECB * 4;    // bytes
@@ -647,6 +660,44 @@ template <int CB, int SPL, bool GENERAL> struct LdsPipe {
             }
         __builtin_amdgcn_sched_barrier(0);
     }
+    // Expanded unit-scale form (MODE 3, SPL == 2): sum (x-mu)^2 = Q - 2 P + sum mu^2 with Q = sum x^2 (one
+    // packed FMA per entry, shared by the channels) and P[k] = sum x mu_k (one packed FMA per entry and
+    // channel, the mean broadcast to both samples by op_sel): 4 + 4*CB v_pk_fma_f32 per block instead of
+    // 16*CB VOP2.  Only taken when |x| and |mu| are bounded by kExpandBound (cancellation).
+    template <int CUR> __device__ __forceinline__ void step3(f32x2 (&P)[CB], f32x2 &Q, const char *lane_base) {
+        constexpr int OTH = 1 - CUR;
+        leaf_read_x<SPL>(x[OTH], lane_base, offn);
+        offc = offn;
+        offn = *reinterpret_cast<const i32x4 *>(tbn + RECBB);
+        load_par<OTH>(tbn);
+        tbn += RECBB;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kBlock; ++u) {
+            const f32x2 xv = {x[CUR][u][0], x[CUR][u][SPL - 1]};
+            Q = __builtin_elementwise_fma(xv, xv, Q);
+#pragma unroll
+            for (int k = 0; k < CB; ++k) {
+                const float m = mu[CUR][u * CB + k];
+                P[k] = __builtin_elementwise_fma(xv, (f32x2){m, m}, P[k]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void run3(f32x2 (&P)[CB], f32x2 &Q, const char *lane_base, int nb) {
+        for (int i = nb >> 1; i > 0; --i) {
+            step3<0>(P, Q, lane_base);
+            step3<1>(P, Q, lane_base);
+        }
+        if (nb & 1) {
+            step3<0>(P, Q, lane_base);
+            mu[0] = mu[1];
+#pragma unroll
+            for (int u = 0; u < kBlock; ++u)
+#pragma unroll
+                for (int s = 0; s < SPL; ++s) x[0][u][s] = x[1][u][s];
+        }
+    }
     // nb blocks into acc; register sets alternate statically, an odd count ends with one set move
     template <int DIST, int MODE>
     __device__ __forceinline__ void run(float (&acc)[CB][SPL], const char *lane_base, int nb) {
@@ -668,6 +719,9 @@ template <int CB, int SPL, bool GENERAL> struct LdsPipe {
 
 // DEPTH == 0: leaf only (QB regions x CB channels per wave item, written to leaf_out)
 // DEPTH >= 1: fused model, QB == 2^DEPTH, CB == I, S sum nodes
+#ifndef DPK_NO_EXPAND
+#define DPK_NO_EXPAND 0
+#endif
 #ifdef DPK_FORCE_SPL1
 #define DPK_MINW(SPL) 8
 #else
@@ -706,6 +760,16 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
             run_s[e] = 0.f;
         }
     }
+
+    // Expanded unit-scale form (LdsPipe::step3): only when every region's means are bounded, and then every
+    // staged |x| above the bound sends its tile to the exact path like a non-finite value does.
+    bool expand_all = (DIST == 0) && !GEN && (CB <= 2) && (SPL == 2) && a.tabcap > 0 && (DPK_NO_EXPAND == 0);
+    if (expand_all) {
+        for (int r = 0; r < R; ++r) expand_all = expand_all && (a.unit[r] == 2);
+    }
+    // a staged value v is "bad" iff bits(v*v) > thr_bits: NaN, +-inf, |v| > bound (or so large that
+    // (v - mu)^2 could overflow when the direct form is used)
+    const unsigned thr_bits = __float_as_uint(expand_all ? kExpandBound * kExpandBound : 1.0e37f);
 
     for (int pass = 0; pass < n_pass; ++pass) {
         const int item = pass * kLeafWaves + wave;
@@ -777,7 +841,10 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
         }
         if (DIST == 0 && !GEN && !grp_unit) use_lds = false;  // hint was wrong for this group
         // GEN = false on the LDS route: acc holds sum (x-mu)^2 - 2*(constants) until the end of the pass
-        bool acc_is_squares = (DIST == 0) && !GEN && use_lds;
+        bool expand = expand_all && use_lds;
+        // the unit-scale kernel only carries the expanded pipeline: unbounded means take the scalar-cache path
+        if (DIST == 0 && !GEN && SPL == 2 && !DPK_NO_EXPAND && !expand) use_lds = false;
+        bool acc_is_squares = (DIST == 0) && !GEN && use_lds && !expand;
         auto load_tab = [&](int c) {
             if (!use_lds || !active) return;
             // records of chunk c plus two blocks of run-ahead for the pipeline (the stream is
@@ -811,20 +878,19 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
             DPK_STAMP(0);
             lds_barrier();  // every wave is done with the previous chunk
             DPK_STAMP(1);
-            float chk = 0.f;
+            unsigned chk = 0u;
             float *wr = xs_lds + flc * ROW + (SPL == 2 ? 2 * sq : sq);
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const float v = pre[i];
-                chk = fmaf(v, 1e20f, chk);  // non-finite iff some v is NaN, +-inf or so large that
-                                            // (v - mu)^2 could overflow (those chunks take the exact path)
+                chk = max(chk, __float_as_uint(v * v));  // v*v >= 0: its bit pattern is monotone, NaN on top
                 constexpr int H = 64 / SQN;  // passes covering the first 64 samples of the tile
                 const int pos_i = (SPL == 2) ? ((i < H) ? 2 * SQN * i : 2 * SQN * (i - H) + 1) : SQN * i;
                 wr[pos_i] = v;
             }
             // work-group OR of "non-finite value staged" through 8 LDS words (no __syncthreads_or:
             // its release fence is a vmcnt(0) that would drain the prefetch just issued)
-            const bool wave_bad = __any(!(fabsf(chk) <= FLT_MAX));
+            const bool wave_bad = __any(chk > thr_bits);
             if (lane == 0) flags_lds[wave] = wave_bad ? 1 : 0;
             DPK_STAMP(2);
             lds_barrier();
@@ -853,6 +919,10 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
 #pragma unroll
                             for (int s = 0; s < SPL; ++s) acc[q][k][s] *= -0.5f;
                     acc_is_squares = false;
+                    use_lds = false;
+                }
+                if (slow && expand) {  // acc is already in final units: just leave the LDS pipeline
+                    expand = false;
                     use_lds = false;
                 }
                 if (slow || !use_lds) {
@@ -903,8 +973,35 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
                             }
                         };
                         LdsPipe<CB, SPL, GEN> pipe;
-                        if (GEN || DIST != 0) chunk_lds(pipe, std::integral_constant<int, 0>{});
-                        else chunk_lds(pipe, std::integral_constant<int, 2>{});
+                        if constexpr (DIST == 0 && !GEN && SPL == 2) {
+                            if (expand) {
+                                pipe.prime(tab_lds + (c & 1) * a.tabcap, lane_base);
+#pragma unroll
+                                for (int q = 0; q < QB; ++q) {
+                                    const int r = g * QB + q;
+                                    const int nb = nbp[q];
+                                    cfloat_p bp = a.biasx + ((int64_t)r * NC + c) * I + kb;
+                                    f32x2 P[CB], Q = {0.f, 0.f};
+#pragma unroll
+                                    for (int k = 0; k < CB; ++k) P[k] = (f32x2){acc[q][k][0], acc[q][k][1]};
+                                    pipe.run3(P, Q, lane_base, nb);
+                                    // log-density sum = P - Q/2 + (constants - sum mu^2 / 2)
+#pragma unroll
+                                    for (int k = 0; k < CB; ++k) {
+                                        const float bk = bp[k];
+                                        acc[q][k][0] = fmaf(-0.5f, Q[0], P[k][0]) + bk;
+                                        acc[q][k][1] = fmaf(-0.5f, Q[1], P[k][1]) + bk;
+                                    }
+                                    pos += nb * kBlock;
+                                }
+                            } else if (DPK_NO_EXPAND) {
+                                chunk_lds(pipe, std::integral_constant<int, 2>{});
+                            }
+                        } else if (GEN || DIST != 0) {
+                            chunk_lds(pipe, std::integral_constant<int, 0>{});
+                        } else {
+                            chunk_lds(pipe, std::integral_constant<int, 2>{});
+                        }
                         DPK_STAMP(4);
                     }
                 }
@@ -1082,7 +1179,7 @@ static int prepare_leaf_tables(int dist, const RatWs &w, const int64_t *mask, co
     PrepArgs a{};
     a.p0 = p0; a.p1 = p1; a.srcr = w.srcr; a.nblk = w.nblk; a.segoff = w.segoff; a.fl2 = w.fl2;
     a.R = R; a.I = I; a.CB = CB; a.d = d; a.NC = w.NC; a.QB = w.QB; a.SP = w.SP; a.G = w.G;
-    a.par = w.par; a.cel = w.cel; a.biasc = w.biasc; a.unit = w.unit;
+    a.par = w.par; a.cel = w.cel; a.biasc = w.biasc; a.biasx = w.biasx; a.unit = w.unit;
     a.rec = (CB == I && CB <= 2) ? w.rec : nullptr;
     int rows = 0;
     for (int m = 0; m < 3; ++m) {
@@ -1103,7 +1200,8 @@ static void fill_leaf_args(LeafArgs &a, const RatWs &w) {
     a.NC = w.NC; a.SP = w.SP;
     a.fl1 = as_const(w.fl1); a.fl2 = as_const(w.fl2); a.nblk = as_const(w.nblk);
     a.segoff = as_const(w.segoff); a.rec = w.rec; a.tabcap = w.tabcap;
-    a.par = as_const(w.par); a.cel = as_const(w.cel); a.biasc = as_const(w.biasc); a.unit = as_const(w.unit);
+    a.par = as_const(w.par); a.cel = as_const(w.cel); a.biasc = as_const(w.biasc); a.biasx = as_const(w.biasx);
+    a.unit = as_const(w.unit);
 }
 
 template <int DIST, int QB, int CB, int SPL, int DEPTH, int S, bool GEN>
