@@ -754,6 +754,13 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
 
     const char *lane_base = smem + lane * (4 * SPL);
 
+#ifdef DPK_TIMELINE
+    if (a.dbg && lane == 0) {
+        unsigned long long *row = a.dbg + (((int64_t)blockIdx.x * kLeafWaves + wave) * (NC + 2) + NC) * 6;
+        row[0] = __builtin_amdgcn_s_memtime();
+        row[2] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     if constexpr (DEPTH > 0) {
         for (int e = tid; e < a.C * T; e += kLeafWaves * 64) {
             run_m[e] = -INFINITY;
@@ -765,7 +772,10 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
     // staged |x| above the bound sends its tile to the exact path like a non-finite value does.
     bool expand_all = (DIST == 0) && !GEN && (CB <= 2) && (SPL == 2) && a.tabcap > 0 && (DPK_NO_EXPAND == 0);
     if (expand_all) {
-        for (int r = 0; r < R; ++r) expand_all = expand_all && (a.unit[r] == 2);
+        // lanes read the flags in parallel (a serial scalar loop costs ~150 ns per region)
+        bool ok = true;
+        for (int r = lane; r < R; r += 64) ok = ok && (a.unit[r] == 2);
+        expand_all = __all(ok);
     }
     // a staged value v is "bad" iff bits(v*v) > thr_bits: NaN, +-inf, |v| > bound (or so large that
     // (v - mu)^2 could overflow when the direct form is used)
@@ -1003,6 +1013,9 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
                             chunk_lds(pipe, std::integral_constant<int, 2>{});
                         }
                         DPK_STAMP(4);
+#ifdef DPK_TIMELINE
+                        if (a.dbg && lane == 0) a.dbg[(((int64_t)blockIdx.x * kLeafWaves + wave) * (NC + 2) + c) * 6 + 5] = __builtin_amdgcn_s_memrealtime();
+#endif
                     }
                 }
             }
@@ -1146,6 +1159,13 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
             }
         }
     }
+#ifdef DPK_TIMELINE
+    if (a.dbg && lane == 0) {
+        unsigned long long *row = a.dbg + (((int64_t)blockIdx.x * kLeafWaves + wave) * (NC + 2) + NC) * 6;
+        row[1] = __builtin_amdgcn_s_memtime();
+        row[3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // --------------------------------------------------------------------------------------

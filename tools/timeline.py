@@ -21,7 +21,11 @@ lib.dpk_debug_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
 n = grid * 8 * (NC + 2) * 6
 buf = np.zeros(n, dtype=np.uint64)
 assert lib.dpk_debug_read(int(ptr, 16), buf.ctypes.data, n * 8) == 0
-t = buf.reshape(grid, 8, NC + 2, 6)[:, :, :NC, :5].astype(np.int64)
+full = buf.reshape(grid, 8, NC + 2, 6)[:, :, :NC, :].astype(np.int64)
+t = full[..., :5]
+rt = full[..., 5]
+print('shader clock during the kernel: s_memtime ticks per s_memrealtime tick (100 MHz):',
+      float((t[0, 0, -1, 4] - t[0, 0, 0, 4]) / max(1, rt[0, 0, -1] - rt[0, 0, 0])), '-> x100 MHz')
 t0 = t[:, :, 0, 0].min()
 print('s_memtime ticks (100 MHz => 10 ns each?) relative to the first stamp')
 for b in (0, 1, 255, 256, 511):
@@ -37,3 +41,11 @@ print('  wait B2     ', (d[..., 3] - d[..., 2]).mean())
 print('  compute     ', (d[..., 4] - d[..., 3]).mean())
 print('  chunk total ', (d[:, :, 1:, 0] - d[:, :, :-1, 0]).mean())
 print('  kernel span ', d[..., 4].max() - d[..., 0].min())
+
+ext = buf.reshape(grid, 8, NC + 2, 6)[:, :, NC, :4].astype(np.int64)   # [entry, exit, rt_entry, rt_exit]
+print('per-wave (ticks): entry -> first chunk stamp', (t[:, :, 0, 0] - ext[:, :, 0]).mean(),
+      ' last compute stamp -> exit', (ext[:, :, 1] - t[:, :, -1, 4]).mean(),
+      ' entry -> exit', (ext[:, :, 1] - ext[:, :, 0]).mean(), 'max', (ext[:, :, 1] - ext[:, :, 0]).max())
+rt0, rt1 = ext[:, :, 2], ext[:, :, 3]
+print('realtime (10 ns ticks): first entry -> last exit over the grid', rt1.max() - rt0.min(),
+      ' entry spread', rt0.max() - rt0.min(), ' per-block span mean', (rt1.max(axis=1) - rt0.min(axis=1)).mean())
