@@ -277,6 +277,39 @@ __global__ void normal_base_bwd_kernel(const float *__restrict__ u, const float 
     }
 }
 
+
+// element-wise tail of the generic (any-depth) coupling route: Z = conditioner output [t_hat | s_hat] (affine)
+// or z (NICE).  One wave per sample: writes out[b,:] and the row's log-det.
+__global__ __launch_bounds__(256) void coupling_fwd_elem_kernel(const float *__restrict__ x, const float *__restrict__ Z,
+                                                                const float *__restrict__ inv_mask,
+                                                                const float *__restrict__ act_weight, int64_t B, int D,
+                                                                int affine, int inverse, float *__restrict__ out,
+                                                                float *__restrict__ ldj) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float a = affine ? act_weight[0] : 0.f;
+    float acc = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float xv = x[b * D + d];
+        const bool live = inv_mask[d] != 0.f;
+        float r = xv;
+        if (affine) {
+            if (live) {
+                const float t = Z[b * 2 * D + d], s = a * tanhf(Z[b * 2 * D + D + d]);
+                r = inverse ? fmaf(xv, expf(s), t) : (xv - t) * expf(-s);
+                acc += s;
+            }
+        } else if (live) {
+            const float z = Z[b * D + d];
+            r = inverse ? xv + z : xv - z;
+        }
+        out[b * D + d] = r;
+    }
+    acc = wave_reduce_sum(acc);
+    if (lane == 0) ldj[b] = inverse ? acc : -acc;
+}
+
 static inline int grid1d(int64_t total, int block = 256, int cap = 8192) {
     int64_t n = (total + block - 1) / block;
     return (int)(n < 1 ? 1 : (n > cap ? cap : n));
@@ -425,5 +458,159 @@ extern "C" int dpk_normal_base_backward(const float *u, const float *loc, const 
     hipLaunchKernelGGL(normal_base_bwd_kernel, dim3(grid1d(B * D)), dim3(256), 0, (hipStream_t)stream, u, loc, scale, g,
                        B, D, grad_u);
     DPK_CHECK_LAUNCH("normal_base_bwd_kernel");
+    return DPK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Generic conditioner depth (CouplingLayer1d(depth = n_hidden), flows/layers/coupling.py:45-56): the MLP is
+// chained through the generic GEMM kernel, layer by layer.  W[i] [widths[i], in_i], b[i] [widths[i]] for
+// i = 0..n_hidden (host arrays of device pointers); widths[n_hidden] = 2D (affine) or D.
+// ---------------------------------------------------------------------------------------------------------
+struct MlpWs {
+    float *H[9];   // hidden activations, H[i] [B, widths[i]]
+    float *Z;      // [B, zc]
+    float *dA, *dB;
+    int64_t bytes;
+};
+static MlpWs carve_mlp_ws(void *base, int64_t B, int n_hidden, const int32_t *widths, bool backward) {
+    MlpWs w{};
+    int64_t o = 0;
+    auto take = [&](int64_t n_bytes) {
+        char *p = base ? (char *)base + o : nullptr;
+        o = align_up(o + n_bytes, 256);
+        return (float *)p;
+    };
+    int maxw = 0;
+    for (int i = 0; i < n_hidden; ++i) {
+        w.H[i] = take(B * widths[i] * 4);
+        maxw = widths[i] > maxw ? widths[i] : maxw;
+    }
+    w.Z = take(B * widths[n_hidden] * 4);
+    if (backward) {
+        w.dA = take(B * maxw * 4);
+        w.dB = take(B * maxw * 4);
+    }
+    w.bytes = o + 256;
+    return w;
+}
+
+static int mlp_check(int64_t B, int D, int n_hidden, const float *const *W, const float *const *b,
+                     const int32_t *widths, int affine, const char *who) {
+    DPK_REQUIRE(B >= 0 && D > 0 && n_hidden >= 1 && n_hidden <= 8, DPK_EINVAL, "%s: bad sizes (1..8 hidden layers)", who);
+    DPK_REQUIRE(W && b && widths, DPK_EINVAL, "%s: null pointer", who);
+    for (int i = 0; i <= n_hidden; ++i) {
+        DPK_REQUIRE(W[i] && b[i] && widths[i] > 0, DPK_EINVAL, "%s: layer %d missing", who, i);
+    }
+    DPK_REQUIRE(widths[n_hidden] == (affine ? 2 * D : D), DPK_EINVAL, "%s: last layer must have %d outputs", who,
+                affine ? 2 * D : D);
+    return DPK_OK;
+}
+
+// forward of the MLP into ws (H[i], Z)
+static void mlp_forward(const MlpWs &w, const float *x, int64_t B, int D, const float *mask, int n_hidden,
+                        const float *const *W, const float *const *b, const int32_t *widths, hipStream_t st) {
+    const float *in = x;
+    int in_w = D;
+    for (int i = 0; i <= n_hidden; ++i) {
+        GemmArgs g{};
+        g.A = in; g.sam = in_w; g.sak = 1; g.kscale = (i == 0) ? mask : nullptr;
+        g.Bm = W[i]; g.sbk = 1; g.sbn = in_w;
+        g.C = (i < n_hidden) ? w.H[i] : w.Z; g.ldc = widths[i];
+        g.M = (int)B; g.N = widths[i]; g.K = in_w; g.bias = b[i]; g.relu = (i < n_hidden);
+        launch_gemm(g, st);
+        in = g.C;
+        in_w = widths[i];
+    }
+}
+
+extern "C" int64_t dpk_coupling1d_mlp_workspace_bytes(int64_t B, int32_t n_hidden, const int32_t *widths,
+                                                      int32_t backward) {
+    if (B < 0 || n_hidden < 1 || n_hidden > 8 || !widths) return DPK_EINVAL;
+    return carve_mlp_ws(nullptr, B, n_hidden, widths, backward != 0).bytes;
+}
+
+extern "C" int dpk_coupling1d_mlp_forward(const float *x, int64_t B, int32_t D, const float *mask, const float *inv_mask,
+                                          int32_t n_hidden, const float *const *W, const float *const *b,
+                                          const int32_t *widths, const float *act_weight, int32_t affine,
+                                          int32_t inverse, float *out, float *ldj, void *ws, int64_t ws_bytes,
+                                          void *stream) {
+    int rc = mlp_check(B, D, n_hidden, W, b, widths, affine, "coupling1d_mlp_forward");
+    if (rc) return rc;
+    DPK_REQUIRE(mask && inv_mask && ws, DPK_EINVAL, "coupling1d_mlp_forward: null pointer");
+    DPK_REQUIRE(!affine || act_weight, DPK_EINVAL, "coupling1d_mlp_forward: affine coupling needs the ScaledTanh weight");
+    MlpWs w = carve_mlp_ws(ws, B, n_hidden, widths, false);
+    DPK_REQUIRE(ws_bytes >= w.bytes, DPK_EWORKSPACE, "coupling1d_mlp_forward: workspace %lld < %lld",
+                (long long)ws_bytes, (long long)w.bytes);
+    if (B == 0) return DPK_OK;
+    DPK_REQUIRE(x && out && ldj, DPK_EINVAL, "coupling1d_mlp_forward: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    mlp_forward(w, x, B, D, mask, n_hidden, W, b, widths, st);
+    hipLaunchKernelGGL(coupling_fwd_elem_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, x, w.Z, inv_mask, act_weight, B, D,
+                       affine, inverse, out, ldj);
+    DPK_CHECK_LAUNCH("coupling1d_mlp_forward");
+    return DPK_OK;
+}
+
+// grad_W[i] / grad_b[i] may be NULL pointers inside the arrays (or the arrays themselves NULL).
+extern "C" int dpk_coupling1d_mlp_backward(const float *x, int64_t B, int32_t D, const float *mask,
+                                           const float *inv_mask, int32_t n_hidden, const float *const *W,
+                                           const float *const *b, const int32_t *widths, const float *act_weight,
+                                           int32_t affine, const float *grad_u, const float *grad_ildj, float *grad_x,
+                                           float *const *grad_W, float *const *grad_b, float *grad_act, void *ws,
+                                           int64_t ws_bytes, void *stream) {
+    int rc = mlp_check(B, D, n_hidden, W, b, widths, affine, "coupling1d_mlp_backward");
+    if (rc) return rc;
+    DPK_REQUIRE(mask && inv_mask && ws, DPK_EINVAL, "coupling1d_mlp_backward: null pointer");
+    DPK_REQUIRE(!affine || act_weight, DPK_EINVAL, "coupling1d_mlp_backward: affine coupling needs the ScaledTanh weight");
+    MlpWs w = carve_mlp_ws(ws, B, n_hidden, widths, true);
+    DPK_REQUIRE(ws_bytes >= w.bytes, DPK_EWORKSPACE, "coupling1d_mlp_backward: workspace %lld < %lld",
+                (long long)ws_bytes, (long long)w.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    if (grad_act) DPK_REQUIRE(hipMemsetAsync(grad_act, 0, 4, st) == hipSuccess, DPK_ELAUNCH, "memset");
+    if (B == 0) {
+        int in_w = D;
+        for (int i = 0; i <= n_hidden; ++i) {
+            if (grad_W && grad_W[i]) (void)hipMemsetAsync(grad_W[i], 0, (size_t)widths[i] * in_w * 4, st);
+            if (grad_b && grad_b[i]) (void)hipMemsetAsync(grad_b[i], 0, (size_t)widths[i] * 4, st);
+            in_w = widths[i];
+        }
+        return DPK_OK;
+    }
+    DPK_REQUIRE(x && grad_x && (grad_u || grad_ildj), DPK_EINVAL, "coupling1d_mlp_backward: null pointer");
+    mlp_forward(w, x, B, D, mask, n_hidden, W, b, widths, st);
+    hipLaunchKernelGGL(coupling_bwd_elem_kernel, dim3(grid1d(B * D)), dim3(256), 0, st, x, w.Z, inv_mask, act_weight,
+                       grad_u, grad_ildj, B, D, affine, grad_x, grad_act);
+    // back through the layers: dOut starts as dZ (in w.Z)
+    float *dout = w.Z;
+    float *spare[2] = {w.dA, w.dB};
+    for (int i = n_hidden; i >= 0; --i) {
+        const int ow = widths[i];
+        const int in_w = (i == 0) ? D : widths[i - 1];
+        const float *in = (i == 0) ? x : w.H[i - 1];
+        GemmArgs g{};
+        if (grad_W && grad_W[i]) {   // dW = dOut^T In  (In = mask * x for the first layer)
+            g = GemmArgs{};
+            g.A = dout; g.sam = 1; g.sak = ow;
+            g.Bm = in; g.sbk = in_w; g.sbn = 1; g.nscale = (i == 0) ? mask : nullptr;
+            g.C = grad_W[i]; g.ldc = in_w; g.M = ow; g.N = in_w; g.K = (int)B;
+            launch_gemm(g, st);
+        }
+        if (grad_b && grad_b[i])
+            hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(ow, 64)), dim3(256), 0, st, dout, B, ow, (int64_t)ow, grad_b[i]);
+        g = GemmArgs{};
+        g.A = dout; g.sam = ow; g.sak = 1;
+        g.Bm = W[i]; g.sbk = in_w; g.sbn = 1;
+        g.M = (int)B; g.N = in_w; g.K = ow;
+        if (i == 0) {   // grad_x += mask * (dOut W0)
+            g.C = grad_x; g.ldc = D; g.nscale = mask; g.accumulate = 1;
+            launch_gemm(g, st);
+        } else {        // dIn = (dOut W_i) * [H_{i-1} > 0]
+            float *dst = spare[i & 1];
+            g.C = dst; g.ldc = in_w; g.gate = w.H[i - 1]; g.ldg = in_w;
+            launch_gemm(g, st);
+            dout = dst;
+        }
+    }
+    DPK_CHECK_LAUNCH("coupling1d_mlp_backward");
     return DPK_OK;
 }

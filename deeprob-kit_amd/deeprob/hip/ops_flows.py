@@ -28,9 +28,15 @@ def coupling1d(x: torch.Tensor, layer, inverse: bool, in_affine: Optional[Tuple[
     lin1, lin2 = layer.network[0], layer.network[-1]
     if inverse:
         _no_graph(x, lin1.weight, lin2.weight)
-    if len(layer.network) != 3:
-        raise HipError("CouplingLayer1d on the HIP path supports conditioner depth 1 (got {} hidden layers)"
-                       .format((len(layer.network) - 1) // 2))
+    if len(layer.network) != 3 or lin1.weight.shape[0] % 32 != 0 or lin1.weight.shape[0] > 512:
+        # deeper conditioners / odd widths: layer-by-layer route on the generic GEMM kernel
+        if in_affine is not None:
+            x = affine1d(x, in_affine)
+        out, d = _coupling1d_mlp(x, layer, inverse)
+        if ldj is not None:
+            ldj += d
+            d = ldj
+        return out, d
     B, D = x.shape
     units = lin1.weight.shape[0]
     n_masked, n_trans = layer._mask_counts()
@@ -50,6 +56,39 @@ def coupling1d(x: torch.Tensor, layer, inverse: bool, in_affine: Optional[Tuple[
         ptr(require_device_f32(lin2.weight, 'W2')), ptr(require_device_f32(lin2.bias, 'b2')), units,
         ptr(act), ptr(sc), ptr(sh), int(layer.affine), int(inverse), ptr(out), ptr(ldj), int(accumulate),
         ptr(ws), ws.numel(), stream_ptr(x.device)), 'dpk_coupling1d_forward')
+    return out, ldj
+
+
+def _mlp_args(layer):
+    """(n_hidden, W pointer array, b pointer array, widths array, tensors kept alive) of the conditioner."""
+    import ctypes
+    lins = [m for m in layer.network if isinstance(m, torch.nn.Linear)]
+    ws = [require_device_f32(m.weight, 'weight') for m in lins]
+    bs = [require_device_f32(m.bias, 'bias') for m in lins]
+    n = len(lins)
+    Wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
+    bp = (ctypes.c_void_p * n)(*[b.data_ptr() for b in bs])
+    widths = (ctypes.c_int32 * n)(*[w.shape[0] for w in ws])
+    return n - 1, Wp, bp, widths, (ws, bs)
+
+
+def _coupling1d_mlp(x: torch.Tensor, layer, inverse: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    """CouplingLayer1d with any conditioner depth (reference: coupling.py:45-56, :72-104)."""
+    lib = load_library()
+    layer._mask_counts()
+    B, D = x.shape
+    n_hidden, Wp, bp, widths, keep = _mlp_args(layer)
+    n = lib.dpk_coupling1d_mlp_workspace_bytes(B, n_hidden, widths, 0)
+    if n < 0:
+        check(int(n), 'dpk_coupling1d_mlp_workspace_bytes')
+    ws = layer._ws.get(n, x.device)
+    out = torch.empty_like(x)
+    ldj = torch.empty(B, dtype=torch.float32, device=x.device)
+    act = layer.scale_act.weight if layer.affine else None
+    check(lib.dpk_coupling1d_mlp_forward(ptr(x), B, D, ptr(layer.mask), ptr(layer.inv_mask), n_hidden, Wp, bp, widths,
+                                         ptr(act), int(layer.affine), int(inverse), ptr(out), ptr(ldj), ptr(ws),
+                                         ws.numel(), stream_ptr(x.device)), 'dpk_coupling1d_mlp_forward')
+    del keep
     return out, ldj
 
 
@@ -139,13 +178,63 @@ class CouplingFn(torch.autograd.Function):
         return gx, gW1, gb1, gW2, gb2, gact, None
 
 
+class CouplingMlpFn(torch.autograd.Function):
+    """CouplingLayer1d.apply_backward with autograd for any conditioner depth: inputs are x, the ScaledTanh weight
+    (or None) and then weight, bias of every Linear in order."""
+
+    @staticmethod
+    def forward(ctx, layer, x, act, *params):
+        u, ildj = _coupling1d_mlp(x, layer, inverse=False)
+        ctx.save_for_backward(x, act, *params)
+        ctx.layer = layer
+        return u, ildj
+
+    @staticmethod
+    def backward(ctx, gu, gildj):
+        import ctypes
+        lib = load_library()
+        x, act, *params = ctx.saved_tensors
+        layer = ctx.layer
+        B, D = x.shape
+        gu = require_device_f32(gu, 'grad_u')
+        gildj = require_device_f32(gildj, 'grad_ildj')
+        ws_t, bs_t = params[0::2], params[1::2]
+        n = len(ws_t)
+        need = ctx.needs_input_grad
+        gws = [torch.empty_like(w) if need[3 + 2 * i] else None for i, w in enumerate(ws_t)]
+        gbs = [torch.empty_like(b) if need[4 + 2 * i] else None for i, b in enumerate(bs_t)]
+        Wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws_t])
+        bp = (ctypes.c_void_p * n)(*[b.data_ptr() for b in bs_t])
+        gWp = (ctypes.c_void_p * n)(*[g.data_ptr() if g is not None else None for g in gws])
+        gbp = (ctypes.c_void_p * n)(*[g.data_ptr() if g is not None else None for g in gbs])
+        widths = (ctypes.c_int32 * n)(*[w.shape[0] for w in ws_t])
+        gx = torch.empty_like(x)
+        gact = torch.empty_like(act) if (act is not None and need[2]) else None
+        nb = lib.dpk_coupling1d_mlp_workspace_bytes(B, n - 1, widths, 1)
+        if nb < 0:
+            check(int(nb), 'dpk_coupling1d_mlp_workspace_bytes')
+        ws = layer._ws_bwd.get(nb, x.device)
+        check(lib.dpk_coupling1d_mlp_backward(ptr(x), B, D, ptr(layer.mask), ptr(layer.inv_mask), n - 1, Wp, bp, widths,
+                                              ptr(act), int(layer.affine), ptr(gu), ptr(gildj), ptr(gx), gWp, gbp,
+                                              ptr(gact), ptr(ws), ws.numel(), stream_ptr(x.device)),
+              'dpk_coupling1d_mlp_backward')
+        grads = []
+        for gw, gb in zip(gws, gbs):
+            grads += [gw, gb]
+        return (None, gx, gact, *grads)
+
+
 def coupling1d_autograd(x: torch.Tensor, layer) -> Tuple[torch.Tensor, torch.Tensor]:
     """Density direction of a coupling layer, recording an autograd node when a graph is needed."""
     lin1, lin2 = layer.network[0], layer.network[-1]
     act = layer.scale_act.weight if layer.affine else None
-    if not _wants_graph(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias, act):
+    lins = [m for m in layer.network if isinstance(m, torch.nn.Linear)]
+    if not _wants_graph(x, act, *[t for m in lins for t in (m.weight, m.bias)]):
         return coupling1d(x, layer, inverse=False)
     layer._mask_counts()   # binary-mask check
+    if len(lins) != 2:
+        flat = [require_device_f32(t, 'parameter') for m in lins for t in (m.weight, m.bias)]
+        return CouplingMlpFn.apply(layer, require_device_f32(x, 'x'), act, *flat)
     return CouplingFn.apply(require_device_f32(x, 'x'), require_device_f32(lin1.weight, 'W1'),
                             require_device_f32(lin1.bias, 'b1'), require_device_f32(lin2.weight, 'W2'),
                             require_device_f32(lin2.bias, 'b2'), act, layer)

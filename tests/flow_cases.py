@@ -12,6 +12,7 @@ CASES = {
     'realnvp1d_784_u64': (dict(in_features=784, units=64, n_flows=3), 10, 11, False),
     'realnvp1d_100_logit': (dict(in_features=100, logit=0.05, n_flows=4, units=96), 12, 13, True),
     'realnvp1d_15': (dict(in_features=15, n_flows=2, units=32), 14, 15, True),
+    'realnvp1d_20_depth2_u48': (dict(in_features=20, n_flows=3, depth=2, units=48), 16, 17, True),
 }
 
 
@@ -37,6 +38,7 @@ TRAIN_CASES = {
     'realnvp1d_train_nice_15': (dict(in_features=15, n_flows=2, units=64, affine=False), True, None),
     'realnvp1d_train_nobn_logit_12': (dict(in_features=12, n_flows=2, units=32, batch_norm=False, logit=0.1), True,
                                       None),
+    'realnvp1d_train_depth3_14': (dict(in_features=14, n_flows=2, depth=3, units=40), True, None),
     'realnvp1d_train_ratspn_base_16': (dict(in_features=16, n_flows=2, units=32), True,
                                        dict(in_features=16, rg_depth=1, rg_repetitions=2, rg_batch=2, rg_sum=2,
                                             random_state=42)),

@@ -67,6 +67,11 @@ def gen_flows():
     m = RealNVP1d(15, n_flows=2, units=32)
     _randomise_flow(m, 15)
     _flow_fixture('realnvp1d_15', m, torch.randn(9, 15, generator=torch.Generator().manual_seed(2)))
+    # deeper conditioner and a hidden width that is not a multiple of the MFMA tile
+    torch.manual_seed(16)
+    m = RealNVP1d(20, n_flows=3, depth=2, units=48)
+    _randomise_flow(m, 17)
+    _flow_fixture('realnvp1d_20_depth2_u48', m, torch.randn(33, 20, generator=torch.Generator().manual_seed(3)))
 
 
 
@@ -110,6 +115,10 @@ def gen_flows_train():
     m = RealNVP1d(12, n_flows=2, units=32, batch_norm=False, logit=0.1)
     _randomise_flow(m, 27)
     _flow_train_fixture('realnvp1d_train_nobn_logit_12', m, torch.rand(70, 12, generator=g), True)
+    torch.manual_seed(30)
+    m = RealNVP1d(14, n_flows=2, depth=3, units=40)
+    _randomise_flow(m, 31)
+    _flow_train_fixture('realnvp1d_train_depth3_14', m, torch.randn(18, 14, generator=g), True)
     # RAT-SPN as the base density (examples/ratspn_nvp1d_mnist.py:35-54): needs d/dx of the SPN
     torch.manual_seed(28)
     base = GaussianRatSpn(16, rg_depth=1, rg_repetitions=2, rg_batch=2, rg_sum=2, random_state=42)
