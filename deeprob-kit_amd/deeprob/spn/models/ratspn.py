@@ -120,6 +120,19 @@ class RatSpn(ProbabilisticModel):
             self.root_layer.weight, self._fused_ctx, ll_acc
         )
 
+    def fused_plan(self, x: torch.Tensor) -> Optional['ops.FusedForwardPlan']:
+        """A pre-bound fused forward for a resident input buffer (see ``ops.FusedForwardPlan``); None when the
+        model is outside the fused kernel's envelope."""
+        if not isinstance(self.base_layer, GaussianLayer):
+            return None
+        if self.training and (self.in_dropout is not None or self.sum_dropout is not None):
+            return None
+        base = self.base_layer
+        sum_weights = [layer.weight for layer in self.layers if isinstance(layer, SumLayer)]
+        plan = ops.FusedForwardPlan(x, base.mask, base._pad_mask_or_none(), base.loc, base.scale, sum_weights,
+                                    self.root_layer.weight, self._fused_ctx)
+        return plan if plan.supported else None
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """
         Log-likelihood ``[B, out_classes]`` of the evidence ``x [B, D]``; NaN entries are marginalised

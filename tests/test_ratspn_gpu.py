@@ -231,3 +231,24 @@ def test_full_size_properties():
     assert torch.equal(ll, ll2)
     assert acc[1].item() == 65536
     assert abs(acc[0].item() - ll.double().sum().item()) <= 1e-9 * abs(acc[0].item())
+
+
+def test_fused_plan_is_the_same_call(golden):
+    """ops.FusedForwardPlan (pre-bound call for a resident buffer) == model(x) bit for bit; it reads live
+    parameters and notices when a pinned address moved."""
+    name = 'ratspn_g784_d2_r8_i2_s2'
+    model, g = build(name, golden)
+    x = torch.from_numpy(g['x_nan']).cuda()
+    with torch.no_grad():
+        want = model(x)
+        plan = model.fused_plan(x)
+        assert plan is not None and plan.valid()
+        acc = torch.zeros(2, dtype=torch.float64, device='cuda')
+        got = plan.run(acc)
+        assert torch.equal(got, want)
+        assert abs(acc[0].item() - want.double().sum().item()) < 1e-6 * abs(want.double().sum().item())
+        assert acc[1].item() == want.numel()
+        model.base_layer.loc.add_(0.25)            # in place: same storage, the plan must see it
+        assert torch.equal(plan.run(), model(x))
+        model.base_layer.loc.data = model.base_layer.loc.data.clone()   # storage moved
+        assert not plan.valid()
