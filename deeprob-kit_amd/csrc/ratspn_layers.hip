@@ -82,64 +82,70 @@ __global__ void product_bwd_kernel(const float *__restrict__ g, int64_t total, i
 // the weights on the scalar path.  v_o < 1e-30 falls back to the exact two-pass form with the
 // true maximum of x_n + lw_on (what torch.logsumexp computes).
 // ------------------------------------------------------------------------------------
-constexpr int kNC = 128;
-constexpr int kOB = 4;
+constexpr int kNC = 128;   // columns of x staged per pass
+constexpr int kOG = 4;     // output groups per work-group (one wave each)
+constexpr int kOB = 4;     // outputs accumulated at a time per thread
 
-__device__ __forceinline__ void stage_rows(const float *__restrict__ in, int64_t row_stride, int64_t b0,
-                                           int64_t B, int n0, int N, float *tile, int lane) {
-    // tile[r][c], row stride kNC+1
-#pragma unroll 4
-    for (int r = 0; r < 64; ++r) {
-        const int64_t b = min(b0 + r, B - 1);
-        const float *src = in + b * row_stride + n0;
-        for (int c = lane; c < kNC; c += 64) tile[r * (kNC + 1) + c] = (n0 + c < N) ? src[c] : -INFINITY;
-    }
-}
-
-__global__ __launch_bounds__(64) void sum_fwd_kernel(const float *__restrict__ in, cfloat_p W, cfloat_p LW,
-                                                    int64_t B, int P, int N, int S,
-                                                    float *__restrict__ out) {
+// Work-group = 4 waves = 64 samples of one partition.  Per 128-column chunk: the four waves stage the
+// [64 x 128] slice of x into LDS (coalesced rows), then lane = sample, wave = output group: every wave reads
+// the exponentials of its lane's row from LDS (row stride kNC+1: conflict-free) and accumulates its share of
+// the S outputs, the softmaxed weights arriving on the scalar path (uniform per wave).  The row maxima come
+// from a first pass over the same chunks (the second read of x hits L2).
+__global__ __launch_bounds__(256) void sum_fwd_kernel(const float *__restrict__ in, cfloat_p W, cfloat_p LW,
+                                                     int64_t B, int P, int N, int S,
+                                                     float *__restrict__ out) {
     __shared__ float tile[64 * (kNC + 1)];
-    const int lane = threadIdx.x;
+    __shared__ float rowmax[64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: keeps the weight loads scalar
     const int p = blockIdx.y;
     const int64_t b0 = (int64_t)blockIdx.x * 64;
     const int64_t b = b0 + lane;
     const int64_t row_stride = (int64_t)P * N;
     const float *xin = in + (int64_t)p * N;
 
-    // pass A: row maximum
-    float m = -INFINITY;
-    for (int n0 = 0; n0 < N; n0 += kNC) {
-        __syncthreads();
-        stage_rows(xin, row_stride, b0, B, n0, N, tile, lane);
-        __syncthreads();
-        const int nn = min(kNC, N - n0);
-        for (int c = 0; c < nn; ++c) m = fmaxf(m, tile[lane * (kNC + 1) + c]);
+    // pass A: row maxima (wave w owns rows w, w+4, ...; lanes over the columns)
+    for (int r = wave; r < 64; r += 4) {
+        const float *src = xin + min(b0 + r, B - 1) * row_stride;
+        float m = -INFINITY;
+        for (int n = lane; n < N; n += 64) m = fmaxf(m, src[n]);
+        m = wave_reduce_max(m);
+        if (lane == 0) rowmax[r] = (m == -INFINITY) ? 0.f : m;
     }
-    const float m0 = (m == -INFINITY) ? 0.f : m;
+    __syncthreads();
+    const float m0 = rowmax[lane];
 
-    for (int ob = 0; ob < S; ob += kOB) {
+    // outputs of this wave: o = wave, wave + 4, ... (kOB at a time)
+    const int n_own = (S > wave) ? (S - wave + kOG - 1) / kOG : 0;
+    for (int ob = 0; ob < (S + kOG - 1) / kOG; ob += kOB) {   // uniform trip count: the barriers are inside
         float v[kOB];
 #pragma unroll
         for (int q = 0; q < kOB; ++q) v[q] = 0.f;
         for (int n0 = 0; n0 < N; n0 += kNC) {
             __syncthreads();
-            stage_rows(xin, row_stride, b0, B, n0, N, tile, lane);
+            for (int r = wave; r < 64; r += 4) {
+                const float *src = xin + min(b0 + r, B - 1) * row_stride + n0;
+                const float mr = rowmax[r];
+                for (int c = lane; c < kNC; c += 64)
+                    tile[r * (kNC + 1) + c] = (n0 + c < N) ? __expf(src[c] - mr) : 0.f;
+            }
             __syncthreads();
             const int nn = min(kNC, N - n0);
-            for (int c = 0; c < nn; ++c) {
-                const float e = __expf(tile[lane * (kNC + 1) + c] - m0);
+            if (ob < n_own) {
+                int oq[kOB];
 #pragma unroll
-                for (int q = 0; q < kOB; ++q) {
-                    const int o = min(ob + q, S - 1);
-                    v[q] = fmaf(W[((int64_t)p * S + o) * N + n0 + c], e, v[q]);
+                for (int q = 0; q < kOB; ++q) oq[q] = min(wave + (ob + q) * kOG, S - 1);
+                for (int c = 0; c < nn; ++c) {
+                    const float e = tile[lane * (kNC + 1) + c];
+#pragma unroll
+                    for (int q = 0; q < kOB; ++q) v[q] = fmaf(W[((int64_t)p * S + oq[q]) * N + n0 + c], e, v[q]);
                 }
             }
         }
 #pragma unroll
         for (int q = 0; q < kOB; ++q) {
-            const int o = ob + q;
-            if (o < S && b < B) {
+            const int o = wave + (ob + q) * kOG;
+            if (ob + q < n_own && b < B) {
                 float r;
                 if (v[q] < 1e-30f) {
                     const float *xr = xin + b * row_stride;
@@ -407,7 +413,7 @@ static int sum_forward_impl(const float *in, const float *weight, int64_t B, int
     if (P == 1 && N >= 1024)
         hipLaunchKernelGGL(root_wide_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, in, LW, B, N, S, out);
     else
-        hipLaunchKernelGGL(sum_fwd_kernel, dim3(cdiv(B, 64), P), dim3(64), 0, st, in, as_const(W), as_const(LW), B,
+        hipLaunchKernelGGL(sum_fwd_kernel, dim3(cdiv(B, 64), P), dim3(256), 0, st, in, as_const(W), as_const(LW), B,
                            P, N, S, out);
     DPK_CHECK_LAUNCH("sum_fwd_kernel");
     return DPK_OK;
