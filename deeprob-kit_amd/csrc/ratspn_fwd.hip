@@ -781,7 +781,11 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
     // (v - mu)^2 could overflow when the direct form is used)
     const unsigned thr_bits = __float_as_uint(expand_all ? kExpandBound * kExpandBound : 1.0e37f);
 
-    for (int pass = 0; pass < n_pass; ++pass) {
+    // leaf-only launches spread the passes over blockIdx.y (small training batches would otherwise occupy
+    // B/T compute units); the fused model keeps them in the work-group (the root exchange spans them)
+    const int pass_lo = (DEPTH == 0) ? (int)blockIdx.y : 0;
+    const int pass_hi = (DEPTH == 0) ? min(pass_lo + 1, n_pass) : n_pass;
+    for (int pass = pass_lo; pass < pass_hi; ++pass) {
         const int item = pass * kLeafWaves + wave;
         const bool active = item < n_items;
         const int g = item / n_cblk;
@@ -1251,7 +1255,12 @@ static int launch_leaf_gen(const LeafArgs &a, hipStream_t st) {
     hipEvent_t ev0, ev1;
     profile_take(&ev0, &ev1);
     if (ev0) (void)hipEventRecord(ev0, st);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kLeafWaves * 64), lds, st, a);
+    int gy = 1;
+    if (DEPTH == 0) {
+        const int n_items = (a.R / QB) * (a.I / CB);
+        gy = cdiv(n_items, kLeafWaves);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid, gy), dim3(kLeafWaves * 64), lds, st, a);
     if (ev1) (void)hipEventRecord(ev1, st);
     DPK_CHECK_LAUNCH("ratspn_leaf_kernel");
     return DPK_OK;

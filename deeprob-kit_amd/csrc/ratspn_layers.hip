@@ -215,7 +215,8 @@ __global__ __launch_bounds__(256) void root_wide_kernel(const float *__restrict_
 // o inside the thread and glw a sum over the samples of the tile, flushed with one atomic per
 // (tile, column, o).
 // ------------------------------------------------------------------------------------
-constexpr int kBwdTile = 128;  // samples per block in the sum backward
+constexpr int kBwdTile = 32;   // samples per block in the sum backward
+constexpr int kBwdOB = 16;     // outputs held in registers at a time
 
 __global__ __launch_bounds__(256) void sum_bwd_kernel(const float *__restrict__ x,
                                                      const float *__restrict__ LW,
@@ -228,24 +229,40 @@ __global__ __launch_bounds__(256) void sum_bwd_kernel(const float *__restrict__ 
     const int p = col / N, n = col - p * N;
     const int64_t b0 = (int64_t)blockIdx.x * kBwdTile;
     const int64_t b1 = min(b0 + kBwdTile, B);
-    for (int o = 0; o < S; ++o) {
-        const float lw = LW[((int64_t)p * S + o) * N + n];
-        float acc = 0.f;
+    // samples outer, outputs inner: x and gx are touched once per sample, the per-output weights and the
+    // batch sums of glw stay in registers (kBwdOB outputs at a time)
+    for (int ob = 0; ob < S; ob += kBwdOB) {
+        float lw[kBwdOB], acc[kBwdOB];
+#pragma unroll
+        for (int q = 0; q < kBwdOB; ++q) {
+            lw[q] = (ob + q < S) ? LW[((int64_t)p * S + ob + q) * N + n] : 0.f;
+            acc[q] = 0.f;
+        }
         for (int64_t b = b0; b < b1; ++b) {
-            const float xo = out[(b * P + p) * S + o];
-            const float go = g[(b * P + p) * S + o];
             const float xv = x[b * P * N + col];
-            // an all -inf row has out = -inf: its gradient is defined as zero (reference: the
-            // masked_fill guard inside torch.logsumexp's backward gives the same)
-            float t = 0.f;
-            if (xo > -INFINITY) t = go * expf(xv + lw - xo);
-            acc += t;
+            const float *op = out + (b * P + p) * S + ob, *gp = g + (b * P + p) * S + ob;
+            float tot = 0.f;
+#pragma unroll
+            for (int q = 0; q < kBwdOB; ++q) {
+                if (ob + q < S) {
+                    const float xo = op[q];
+                    // an all -inf row has out = -inf: its gradient is defined as zero (reference: the
+                    // masked_fill guard inside torch.logsumexp's backward gives the same)
+                    const float t = (xo > -INFINITY) ? gp[q] * expf(xv + lw[q] - xo) : 0.f;
+                    acc[q] += t;
+                    tot += t;
+                }
+            }
             if (gx != nullptr) {
                 float *dst = gx + b * P * N + col;
-                *dst = (o == 0) ? t : (*dst + t);
+                *dst = (ob == 0) ? tot : (*dst + tot);
             }
         }
-        if (glw != nullptr) atomicAdd(glw + ((int64_t)p * S + o) * N + n, acc);
+        if (glw != nullptr) {
+#pragma unroll
+            for (int q = 0; q < kBwdOB; ++q)
+                if (ob + q < S) atomicAdd(glw + ((int64_t)p * S + ob + q) * N + n, acc[q]);
+        }
     }
 }
 
@@ -270,14 +287,17 @@ __global__ void logsoftmax_jacobian_kernel(const float *__restrict__ glw, const 
 //   Bernoulli: dlogit = sum_b g m (x - sigmoid(l))
 // A second kernel, one thread per (sample, variable), forms d/dx = sum over the repetitions.
 // ------------------------------------------------------------------------------------
-constexpr int kLeafBwdTile = 256;
+constexpr int kLeafBwdTile = 64;
 
-template <int DIST>
+// block = (sample tile, region group, channel block of CBK): thread = one table entry, CBK channels in registers,
+// samples outer so that x[b, f] is gathered once for the CBK channels
+template <int DIST, int CBK>
 __global__ __launch_bounds__(256) void leaf_bwd_param_kernel(
     const float *__restrict__ x, const float *__restrict__ g, int64_t B, int D, int R, int I, int d, int SP,
     const int *__restrict__ feat, const int *__restrict__ srcr, const float *__restrict__ p0,
     const float *__restrict__ p1, float *__restrict__ gp0, float *__restrict__ gp1) {
     const int grp = blockIdx.y;  // region group: its entry stream holds (variable, r*d+j) pairs
+    const int kb = blockIdx.z * CBK;
     const int64_t b0 = (int64_t)blockIdx.x * kLeafBwdTile;
     const int64_t b1 = min(b0 + kLeafBwdTile, B);
     for (int e = threadIdx.x; e < SP; e += blockDim.x) {
@@ -285,33 +305,42 @@ __global__ __launch_bounds__(256) void leaf_bwd_param_kernel(
         if (rj < 0) continue;
         const int r = rj / d, j = rj - r * d;
         const int f = feat[(int64_t)grp * SP + e];
-        for (int k = 0; k < I; ++k) {
-            const int64_t po = ((int64_t)r * I + k) * d + j;
-            float a0 = 0.f, a1 = 0.f;
+        float c0[CBK], c1[CBK], c2[CBK], a0[CBK], a1[CBK];
+#pragma unroll
+        for (int k = 0; k < CBK; ++k) {
+            const int64_t po = ((int64_t)r * I + kb + k) * d + j;
+            a0[k] = a1[k] = 0.f;
             if (DIST == 0) {
-                const float mu = p0[po], sg = p1[po];
-                const float iv = 1.f / (sg * sg), is = 1.f / sg;
-                for (int64_t b = b0; b < b1; ++b) {
-                    const float xv = x[b * D + f];
-                    const float gv = g[(b * R + r) * I + k];
-                    if (xv == xv) {
-                        const float dl = xv - mu;
-                        a0 = fmaf(gv, dl * iv, a0);
-                        a1 = fmaf(gv, dl * dl * iv * is - is, a1);
-                    }
-                }
-                if (gp0) atomicAdd(gp0 + po, a0);
-                if (gp1) atomicAdd(gp1 + po, a1);
+                const float sg = p1[po];
+                c0[k] = p0[po];           // mu
+                c1[k] = 1.f / (sg * sg);  // 1/s^2
+                c2[k] = 1.f / sg;
             } else {
-                const float l = p0[po];
-                const float sgm = 1.f / (1.f + expf(-l));
-                for (int64_t b = b0; b < b1; ++b) {
-                    const float xv = x[b * D + f];
-                    const float gv = g[(b * R + r) * I + k];
-                    if (xv == xv) a0 = fmaf(gv, xv - sgm, a0);
-                }
-                if (gp0) atomicAdd(gp0 + po, a0);
+                c0[k] = 1.f / (1.f + expf(-p0[po]));  // sigmoid(logit)
+                c1[k] = c2[k] = 0.f;
             }
+        }
+        for (int64_t b = b0; b < b1; ++b) {
+            const float xv = x[b * D + f];
+            if (!(xv == xv)) continue;   // marginalised: no contribution
+            const float *gp = g + (b * R + r) * I + kb;
+#pragma unroll
+            for (int k = 0; k < CBK; ++k) {
+                const float gv = gp[k];
+                if (DIST == 0) {
+                    const float dl = xv - c0[k];
+                    a0[k] = fmaf(gv, dl * c1[k], a0[k]);
+                    a1[k] = fmaf(gv, dl * dl * c1[k] * c2[k] - c2[k], a1[k]);
+                } else {
+                    a0[k] = fmaf(gv, xv - c0[k], a0[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CBK; ++k) {
+            const int64_t po = ((int64_t)r * I + kb + k) * d + j;
+            if (gp0) atomicAdd(gp0 + po, a0[k]);
+            if (DIST == 0 && gp1) atomicAdd(gp1 + po, a1[k]);
         }
     }
 }
@@ -487,12 +516,21 @@ static int leaf_backward_common(int dist, const float *x, const float *g, int64_
     if (gp0) DPK_REQUIRE(hipMemsetAsync(gp0, 0, pbytes, st) == hipSuccess, DPK_ELAUNCH, "leaf_backward: memset");
     if (gp1) DPK_REQUIRE(hipMemsetAsync(gp1, 0, pbytes, st) == hipSuccess, DPK_ELAUNCH, "leaf_backward: memset");
     if (B > 0 && (gp0 || gp1)) {
-        if (dist == 0)
-            hipLaunchKernelGGL(leaf_bwd_param_kernel<0>, dim3(cdiv(B, kLeafBwdTile), w.G), dim3(256), 0, st, x, g,
-                               B, D, R, I, d, w.SP, w.feat, w.srcr, p0, p1, gp0, gp1);
-        else
-            hipLaunchKernelGGL(leaf_bwd_param_kernel<1>, dim3(cdiv(B, kLeafBwdTile), w.G), dim3(256), 0, st, x, g,
-                               B, D, R, I, d, w.SP, w.feat, w.srcr, p0, p1, gp0, gp1);
+        const int cbk = (I % 4 == 0) ? 4 : ((I % 2 == 0) ? 2 : 1);
+        const dim3 grid(cdiv(B, kLeafBwdTile), w.G, I / cbk), block(256);
+#define DPK_LEAF_BWD(DIST, CBK)                                                                                  \
+    hipLaunchKernelGGL((leaf_bwd_param_kernel<DIST, CBK>), grid, block, 0, st, x, g, B, D, R, I, d, w.SP, w.feat, \
+                       w.srcr, p0, p1, gp0, gp1)
+        if (dist == 0) {
+            if (cbk == 4) DPK_LEAF_BWD(0, 4);
+            else if (cbk == 2) DPK_LEAF_BWD(0, 2);
+            else DPK_LEAF_BWD(0, 1);
+        } else {
+            if (cbk == 4) DPK_LEAF_BWD(1, 4);
+            else if (cbk == 2) DPK_LEAF_BWD(1, 2);
+            else DPK_LEAF_BWD(1, 1);
+        }
+#undef DPK_LEAF_BWD
         DPK_CHECK_LAUNCH("leaf_bwd_param_kernel");
     }
     if (gx && B > 0) {
