@@ -256,6 +256,9 @@ __global__ void spatial_sum_fwd_kernel(const float *__restrict__ x, const float 
 }
 
 // backward: pi = exp(x_c + lw[o,c,p] - out[o]);  gx[b,c,p] = sum_o g pi;  glw[o,c,p] = sum_b g pi
+// thread = (c, p) for a slice of the batch: samples outer, output channels inner with the per-output weights and
+// the batch sums of glw in registers (kSpOB outputs at a time), so x and gx are touched once per sample
+constexpr int kSpOB = 16;
 __global__ void spatial_sum_bwd_kernel(const float *__restrict__ x, const float *__restrict__ LW,
                                        const float *__restrict__ out, const float *__restrict__ g, int64_t B,
                                        int Cin, int Cout, int HW, int bslice, float *__restrict__ gx,
@@ -265,20 +268,35 @@ __global__ void spatial_sum_bwd_kernel(const float *__restrict__ x, const float 
     if (e >= n) return;
     const int p = (int)(e % HW), c = (int)(e / HW);
     const int64_t b0 = (int64_t)blockIdx.y * bslice, b1 = min(b0 + bslice, B);
-    for (int o = 0; o < Cout; ++o) {
-        const float lw = LW[((int64_t)o * Cin + c) * HW + p];
-        float acc = 0.f;
+    for (int ob = 0; ob < Cout; ob += kSpOB) {
+        float lw[kSpOB], acc[kSpOB];
+#pragma unroll
+        for (int q = 0; q < kSpOB; ++q) {
+            lw[q] = (ob + q < Cout) ? LW[((int64_t)(ob + q) * Cin + c) * HW + p] : 0.f;
+            acc[q] = 0.f;
+        }
         for (int64_t b = b0; b < b1; ++b) {
-            const float xo = out[(b * Cout + o) * HW + p];
-            float t = 0.f;
-            if (xo > -INFINITY) t = g[(b * Cout + o) * HW + p] * expf(x[(b * Cin + c) * HW + p] + lw - xo);
-            acc += t;
+            const float xv = x[(b * Cin + c) * HW + p];
+            float tot = 0.f;
+#pragma unroll
+            for (int q = 0; q < kSpOB; ++q) {
+                if (ob + q < Cout) {
+                    const float xo = out[(b * Cout + ob + q) * HW + p];
+                    const float t = (xo > -INFINITY) ? g[(b * Cout + ob + q) * HW + p] * expf(xv + lw[q] - xo) : 0.f;
+                    acc[q] += t;
+                    tot += t;
+                }
+            }
             if (gx) {
                 float *dst = gx + (b * Cin + c) * HW + p;
-                *dst = (o == 0) ? t : (*dst + t);
+                *dst = (ob == 0) ? tot : (*dst + tot);
             }
         }
-        if (glw) atomicAdd(glw + ((int64_t)o * Cin + c) * HW + p, acc);
+        if (glw) {
+#pragma unroll
+            for (int q = 0; q < kSpOB; ++q)
+                if (ob + q < Cout) atomicAdd(glw + ((int64_t)(ob + q) * Cin + c) * HW + p, acc[q]);
+        }
     }
 }
 
@@ -522,7 +540,7 @@ extern "C" int dpk_spatial_sum_backward(const float *x, const float *weight, con
         DPK_REQUIRE(hipMemsetAsync(glw, 0, (size_t)Cout * Cin * HW * 4, st) == hipSuccess, DPK_ELAUNCH, "memset");
     if (B > 0) {
         DPK_REQUIRE(x && out && g, DPK_EINVAL, "spatial_sum_backward: null pointer");
-        const int bslice = 64;
+        const int bslice = 16;
         hipLaunchKernelGGL(spatial_sum_bwd_kernel, dim3(cdiv((int64_t)Cin * HW, 256), cdiv(B, bslice)), dim3(256), 0,
                            st, x, LW, out, g, B, Cin, Cout, HW, bslice, grad_x, grad_weight ? glw : nullptr);
     }
