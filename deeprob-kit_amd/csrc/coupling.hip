@@ -20,6 +20,12 @@
 #include "common.h"
 #include <math.h>
 
+// DPK_CPL_ABLATE (measurement builds only): 1 = no phase-0 copy, 2 = no staging of x (GEMM 1 on stale LDS),
+// 3 = no GEMM-1 MFMAs, 4 = no GEMM-2 MFMAs, 5 = no epilogue (math + x gather + stores)
+#ifndef DPK_CPL_ABLATE
+#define DPK_CPL_ABLATE 0
+#endif
+
 namespace dpk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -28,6 +34,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kCM = 64;        // samples per work-group
 constexpr int kCKC = 64;       // masked columns staged per chunk
 constexpr int kCWaves = 4;
+#ifndef DPK_CPL_PF
+#define DPK_CPL_PF 2
+#endif
+#ifndef DPK_CPL_XPRE
+#define DPK_CPL_XPRE 1
+#endif
+constexpr int kPF = DPK_CPL_PF;  // B-fragment prefetch distance (float4 per lane)
 
 struct CouplingWs {
     int *kidx;      // [K1p] variable id of the k-th masked column (-1 = padding)
@@ -145,6 +158,14 @@ struct CouplingArgs {
     int accumulate;                    // ldj[b] += ... instead of =
 };
 
+// tanh(v) = (e^{2v} - 1) / (e^{2v} + 1) on the hardware exp2 / rcp: absolute error ~1e-7 (the scale s = a tanh(.)
+// enters exp(-s) and the log-det sum, where 1e-7 absolute is 1e-7 relative); |v| clamped so e^{2v} stays finite
+__device__ __forceinline__ float fast_tanh(float v) {
+    const float c = fminf(fmaxf(v, -15.f), 15.f);
+    const float t = __expf(2.f * c);
+    return __fdividef(t - 1.f, t + 1.f);
+}
+
 // row of accumulator register `reg` for this lane (32x32 MFMA C/D layout)
 __device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
@@ -162,12 +183,36 @@ __global__ __launch_bounds__(kCWaves * 64) void coupling1d_kernel(const Coupling
     const int rows = (int)min((int64_t)kCM, a.B - b0);
     const bool has_aff = a.in_scale != nullptr;
 
-    // ---- phase 0: pass-through copy of the tile (every variable), log-det scratch
-    for (int e = tid; e < rows * D; e += kCWaves * 64) {
-        const int r = e / D, d = e - r * D;
-        float v = a.x[(b0 + r) * D + d];
-        if (has_aff) v = fmaf(v, a.in_scale[d], a.in_shift[d]);
-        a.out[(b0 + r) * D + d] = v;
+    // ---- phase 0: pass-through copy of the tile (every variable; the transformed ones are overwritten by
+    // the epilogue), log-det scratch.  Rows over the waves, columns over the lanes: no index division, and
+    // 16-byte accesses when the rows are 16-byte aligned.
+    if (DPK_CPL_ABLATE != 1) {
+        const float *xb = a.x + b0 * D;
+        float *ob = a.out + b0 * D;
+        if ((D & 3) == 0) {
+            const int D4 = D >> 2;
+            for (int r = wave; r < rows; r += kCWaves) {
+                const f32x4 *src = reinterpret_cast<const f32x4 *>(xb + (int64_t)r * D);
+                f32x4 *dst = reinterpret_cast<f32x4 *>(ob + (int64_t)r * D);
+                for (int c = lane; c < D4; c += 64) {
+                    f32x4 v = src[c];
+                    if (has_aff) {
+                        const f32x4 sc = reinterpret_cast<const f32x4 *>(a.in_scale)[c];
+                        const f32x4 sh = reinterpret_cast<const f32x4 *>(a.in_shift)[c];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = fmaf(v[q], sc[q], sh[q]);
+                    }
+                    dst[c] = v;
+                }
+            }
+        } else {
+            for (int r = wave; r < rows; r += kCWaves)
+                for (int c = lane; c < D; c += 64) {
+                    float v = xb[(int64_t)r * D + c];
+                    if (has_aff) v = fmaf(v, a.in_scale[c], a.in_shift[c]);
+                    ob[(int64_t)r * D + c] = v;
+                }
+        }
     }
     ldj_lds[tid] = 0.f;  // kCWaves * kCM == blockDim.x
 
@@ -179,7 +224,7 @@ __global__ __launch_bounds__(kCWaves * 64) void coupling1d_kernel(const Coupling
         f32x16 acc0 = {0}, acc1 = {0};
         for (int kc = 0; kc < a.K1p; kc += kCKC) {
             __syncthreads();
-            for (int e = tid; e < kCM * kCKC; e += kCWaves * 64) {
+            for (int e = tid; e < (DPK_CPL_ABLATE == 2 ? 0 : kCM * kCKC); e += kCWaves * 64) {
                 const int r = e / kCKC, c = e - r * kCKC;
                 const int col = a.kidx[kc + c];
                 float v = 0.f;
@@ -190,13 +235,19 @@ __global__ __launch_bounds__(kCWaves * 64) void coupling1d_kernel(const Coupling
                 xs[r * (kCKC + 1) + c] = v;
             }
             __syncthreads();
-            if (nt_ok) {
+            if (nt_ok && DPK_CPL_ABLATE != 3) {
                 const f32x4 *bp = reinterpret_cast<const f32x4 *>(a.w1p) +
                                   ((int64_t)nt * (a.K1p / 8) + kc / 8) * 64 + lane;
                 const float *ap = xs + (lane & 31) * (kCKC + 1) + (lane >> 5);
-#pragma unroll 2
+                // B fragments run kPF float4 ahead of the MFMAs that consume them (an L2 round trip is ~4x the
+                // 8 MFMAs one fragment feeds)
+                f32x4 bq[kPF];
+#pragma unroll
+                for (int j = 0; j < kPF; ++j) bq[j] = bp[j * 64];
+#pragma unroll
                 for (int ks4 = 0; ks4 < kCKC / 8; ++ks4) {
-                    const f32x4 b = bp[ks4 * 64];
+                    const f32x4 b = bq[ks4 % kPF];
+                    if (ks4 + kPF < kCKC / 8) bq[ks4 % kPF] = bp[(ks4 + kPF) * 64];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int k = 2 * (4 * ks4 + q);
@@ -228,52 +279,84 @@ __global__ __launch_bounds__(kCWaves * 64) void coupling1d_kernel(const Coupling
     const int n_pairs = a.N2p / 32;
     for (int pt = wave; pt < n_pairs; pt += kCWaves) {
         f32x16 t0 = {0}, t1 = {0}, s0 = {0}, s1 = {0};
+        // the x values this lane transforms are requested BEFORE the MFMA loop: one exposed memory latency per
+        // 32-variable tile instead of one per accumulator register in the epilogue
+        const int var_p = a.nidx[pt * 32 + (lane & 31)];
+        float xpre[2][16];
+        {
+            const float *xb = a.x + b0 * D;
+            const int lane_off = 4 * (lane >> 5) * D + max(var_p, 0);
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row0 = half * 32 + (r & 3) + 8 * (r >> 2);
+                    const int rowc = min(row0 + 4 * (lane >> 5), rows - 1) - 4 * (lane >> 5);  // clamp ragged tiles
+                    xpre[half][r] = (DPK_CPL_ABLATE == 5 || !DPK_CPL_XPRE) ? 0.f : xb[lane_off + rowc * D];
+                }
+        }
         const f32x4 *btp = reinterpret_cast<const f32x4 *>(a.w2tp) + (int64_t)pt * (U / 8) * 64 + lane;
         const f32x4 *bsp = reinterpret_cast<const f32x4 *>(a.w2sp) + (int64_t)pt * (U / 8) * 64 + lane;
         const float *ap = hs + (lane & 31) * HS + (lane >> 5);
-#pragma unroll 2
-        for (int ks4 = 0; ks4 < U / 8; ++ks4) {
-            const f32x4 bt = btp[ks4 * 64];
-            f32x4 bs = {0};
-            if (AFFINE) bs = bsp[ks4 * 64];
+        const int nk4 = (DPK_CPL_ABLATE == 4) ? 0 : U / 8;   // a multiple of 4 (U % 32 == 0)
+        f32x4 btq[kPF], bsq[kPF];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int k = 2 * (4 * ks4 + q);
-                const float a0 = ap[k], a1 = ap[32 * HS + k];
-                t0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bt[q], t0, 0, 0, 0);
-                t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bt[q], t1, 0, 0, 0);
-                if (AFFINE) {
-                    s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bs[q], s0, 0, 0, 0);
-                    s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bs[q], s1, 0, 0, 0);
+        for (int j = 0; j < kPF; ++j) {
+            btq[j] = btp[j * 64];
+            bsq[j] = AFFINE ? bsp[j * 64] : f32x4{0, 0, 0, 0};
+        }
+        for (int ks0 = 0; ks0 < nk4; ks0 += kPF) {
+#pragma unroll
+            for (int j = 0; j < kPF; ++j) {
+                const int ks4 = ks0 + j;
+                const f32x4 bt = btq[j], bs = bsq[j];
+                if (ks4 + kPF < nk4) {
+                    btq[j] = btp[(ks4 + kPF) * 64];
+                    if (AFFINE) bsq[j] = bsp[(ks4 + kPF) * 64];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = 2 * (4 * ks4 + q);
+                    const float a0 = ap[k], a1 = ap[32 * HS + k];
+                    t0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bt[q], t0, 0, 0, 0);
+                    t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bt[q], t1, 0, 0, 0);
+                    if (AFFINE) {
+                        s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bs[q], s0, 0, 0, 0);
+                        s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bs[q], s1, 0, 0, 0);
+                    }
                 }
             }
         }
         const int n = pt * 32 + (lane & 31);
-        const int var = a.nidx[n];
-        if (var >= 0) {
+        const int var = var_p;
+        if (var >= 0 && DPK_CPL_ABLATE != 5) {
             const float bt = a.b2tp[n], bs = AFFINE ? a.b2sp[n] : 0.f;
             float sc = 1.f, sh = 0.f;
             if (has_aff) {
                 sc = a.in_scale[var];
                 sh = a.in_shift[var];
             }
+            // 32-bit offsets inside the tile: lane part (column, +4 rows for the upper half-wave) + a uniform row part
+            float *ob = a.out + b0 * D;
+            const int lane_off = 4 * (lane >> 5) * D + var;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = half * 32 + mfma_row(r, lane);
-                    if (row < rows) {
+                    const int row0 = half * 32 + (r & 3) + 8 * (r >> 2);   // + 4 * (lane >> 5) = mfma_row
+                    const int off = lane_off + row0 * D;
+                    if (row0 + 4 * (lane >> 5) < rows) {
                         const float tv = (half ? t1[r] : t0[r]) + bt;
-                        const float xv = fmaf(a.x[(b0 + row) * D + var], sc, sh);
+                        const float xv = fmaf(DPK_CPL_XPRE ? xpre[half][r] : a.x[b0 * D + off], sc, sh);
                         float o;
                         if (AFFINE) {
-                            const float sv = act * tanhf((half ? s1[r] : s0[r]) + bs);
-                            o = a.inverse ? fmaf(xv, expf(sv), tv) : (xv - tv) * expf(-sv);
+                            const float sv = act * fast_tanh((half ? s1[r] : s0[r]) + bs);
+                            o = a.inverse ? fmaf(xv, __expf(sv), tv) : (xv - tv) * __expf(-sv);
                             if (half) ssum1[r] += sv; else ssum0[r] += sv;
                         } else {
                             o = a.inverse ? xv + tv : xv - tv;
                         }
-                        a.out[(b0 + row) * D + var] = o;
+                        ob[off] = o;
                     }
                 }
             }
