@@ -179,3 +179,27 @@ def test_empty_batch_and_errors():
             model(torch.zeros(2, 1, 9, 8, device='cuda'))
         with pytest.raises((HipError, TypeError, ValueError)):
             model(torch.zeros(2, 1, 8, 8))       # CPU tensor: no silent fallback
+
+
+def test_full_size_properties():
+    """BASELINE config 4 at full batch (8192 images 28x28): size-independent properties -- any slice of the batch
+    gives the same LLs (bit for bit), fully marginalised images give LL = 0, marginalising pixels changes nothing
+    for the other samples."""
+    from deeprob.spn.models import DgcSpn
+    torch.manual_seed(5)
+    model = DgcSpn((1, 28, 28), n_batch=8, sum_channels=8, depthwise=True, n_pooling=0).cuda().eval()
+    x = torch.randn(8192, 1, 28, 28, device='cuda', generator=torch.Generator('cuda').manual_seed(0))
+    x[777] = float('nan')
+    with torch.no_grad():
+        ll = model(x)
+        part = model(x[1001:1001 + 515])
+        x2 = x.clone()
+        x2[::2, :, :, 14:] = float('nan')
+        ll2 = model(x2)
+    assert tuple(ll.shape) == (8192, 1) and torch.isfinite(ll).all()
+    assert torch.equal(ll[1001:1001 + 515], part)
+    assert abs(ll[777].item()) < 1e-5
+    assert torch.equal(ll2[1::2], ll[1::2])
+    # marginalising half of an image removes non-positive-on-average terms: not an identity, but the result must
+    # stay finite and differ
+    assert torch.isfinite(ll2).all() and not torch.equal(ll2[0], ll[0])
