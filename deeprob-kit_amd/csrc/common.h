@@ -132,6 +132,17 @@ inline RatWs carve_ratspn_ws(void *base, int D, int R, int d, int I, int QB, int
 }
 
 // ---- device helpers -------------------------------------------------------
+// Counter-based dropout decision shared by the training forward and backward kernels: element `idx` of a call
+// with seed `seed` is dropped iff the top 24 bits of splitmix64(seed + idx * golden) fall below p * 2^24.
+// The same (seed, idx) gives the same answer in every kernel, so no mask tensor is stored.
+__host__ __device__ __forceinline__ bool dropout_hit(uint64_t seed, uint64_t idx, float p) {
+    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(uint32_t)(z >> 40) < p * 16777216.0f;
+}
+
 
 __device__ __forceinline__ float nan_to_num_f(float t) {
     // torch.nan_to_num_ defaults: nan -> 0, +inf -> FLT_MAX, -inf -> -FLT_MAX

@@ -24,7 +24,7 @@ static inline int grid_cap(int64_t total, int block, int cap = 16384) {
 // ------------------------------------------------------------------------------------------------
 __global__ void spatial_gaussian_fwd_kernel(const float *__restrict__ x, const float *__restrict__ loc,
                                             const float *__restrict__ scale, int64_t B, int K, int C, int HW,
-                                            float *__restrict__ out) {
+                                            float *__restrict__ out, float drop_p, uint64_t seed) {
     const int64_t total = B * K * HW;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
@@ -34,6 +34,8 @@ __global__ void spatial_gaussian_fwd_kernel(const float *__restrict__ x, const f
         const int64_t b = bk / K;
         float acc = 0.f;
         for (int c = 0; c < C; ++c) {
+            // training-mode input dropout (dgcspn.py:113-114) on the [B,K,C,H,W] element
+            if (drop_p > 0.f && dropout_hit(seed, ((uint64_t)bk * C + c) * HW + p, drop_p)) continue;
             const float xv = x[(b * C + c) * HW + p];
             const float mu = loc[((int64_t)k * C + c) * HW + p], sg = scale[((int64_t)k * C + c) * HW + p];
             const float d = xv - mu;
@@ -46,7 +48,8 @@ __global__ void spatial_gaussian_fwd_kernel(const float *__restrict__ x, const f
 // d/dx: gx[b,c,p] = sum_k g[b,k,p] * (-(x-mu)/s^2) (0 where x is NaN)
 __global__ void spatial_gaussian_bwd_x_kernel(const float *__restrict__ x, const float *__restrict__ g,
                                               const float *__restrict__ loc, const float *__restrict__ scale,
-                                              int64_t B, int K, int C, int HW, float *__restrict__ gx) {
+                                              int64_t B, int K, int C, int HW, float *__restrict__ gx, float drop_p,
+                                              uint64_t seed) {
     const int64_t total = B * C * HW;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
@@ -58,6 +61,7 @@ __global__ void spatial_gaussian_bwd_x_kernel(const float *__restrict__ x, const
         float acc = 0.f;
         if (xv == xv) {
             for (int k = 0; k < K; ++k) {
+                if (drop_p > 0.f && dropout_hit(seed, (((uint64_t)b * K + k) * C + c) * HW + p, drop_p)) continue;
                 const float sg = scale[((int64_t)k * C + c) * HW + p];
                 acc = fmaf(g[(b * K + k) * HW + p], -(xv - loc[((int64_t)k * C + c) * HW + p]) / (sg * sg), acc);
             }
@@ -70,7 +74,8 @@ __global__ void spatial_gaussian_bwd_x_kernel(const float *__restrict__ x, const
 __global__ void spatial_gaussian_bwd_p_kernel(const float *__restrict__ x, const float *__restrict__ g,
                                               const float *__restrict__ loc, const float *__restrict__ scale,
                                               int64_t B, int K, int C, int HW, int bslice,
-                                              float *__restrict__ gloc, float *__restrict__ gscale) {
+                                              float *__restrict__ gloc, float *__restrict__ gscale, float drop_p,
+                                              uint64_t seed) {
     const int64_t n = (int64_t)K * C * HW;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
@@ -83,7 +88,7 @@ __global__ void spatial_gaussian_bwd_p_kernel(const float *__restrict__ x, const
     float a0 = 0.f, a1 = 0.f;
     for (int64_t b = b0; b < b1; ++b) {
         const float xv = x[(b * C + c) * HW + p];
-        if (xv == xv) {
+        if (xv == xv && !(drop_p > 0.f && dropout_hit(seed, (((uint64_t)b * K + k) * C + c) * HW + p, drop_p))) {
             const float gv = g[(b * K + k) * HW + p], d = xv - mu;
             a0 = fmaf(gv, d * iv, a0);
             a1 = fmaf(gv, d * d * iv * is - is, a1);
@@ -410,22 +415,34 @@ __global__ __launch_bounds__(256) void spatial_prodsum_fwd_kernel(const float *_
 
 using namespace dpk;
 
-extern "C" int dpk_spatial_gaussian_forward(const float *x, const float *loc, const float *scale, int64_t B,
-                                            int32_t K, int32_t C, int32_t H, int32_t W, float *out, void *stream) {
+static int spatial_gaussian_forward_impl(const float *x, const float *loc, const float *scale, int64_t B, int32_t K,
+                                         int32_t C, int32_t H, int32_t W, float *out, void *stream, float drop_p,
+                                         uint64_t seed) {
     DPK_REQUIRE(B >= 0 && K > 0 && C > 0 && H > 0 && W > 0, DPK_EINVAL, "spatial_gaussian: bad sizes");
+    DPK_REQUIRE(drop_p >= 0.f && drop_p < 1.f, DPK_EINVAL, "spatial_gaussian: dropout rate must be in [0, 1)");
     if (B == 0) return DPK_OK;
     DPK_REQUIRE(x && loc && scale && out, DPK_EINVAL, "spatial_gaussian: null pointer");
     const int64_t total = B * K * H * W;
     hipLaunchKernelGGL(spatial_gaussian_fwd_kernel, dim3(grid_cap(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       x, loc, scale, B, K, C, H * W, out);
+                       x, loc, scale, B, K, C, H * W, out, drop_p, seed);
     DPK_CHECK_LAUNCH("spatial_gaussian_fwd_kernel");
     return DPK_OK;
 }
+extern "C" int dpk_spatial_gaussian_forward(const float *x, const float *loc, const float *scale, int64_t B,
+                                            int32_t K, int32_t C, int32_t H, int32_t W, float *out, void *stream) {
+    return spatial_gaussian_forward_impl(x, loc, scale, B, K, C, H, W, out, stream, 0.f, 0);
+}
+extern "C" int dpk_spatial_gaussian_forward_dropout(const float *x, const float *loc, const float *scale, int64_t B,
+                                                    int32_t K, int32_t C, int32_t H, int32_t W, float drop_p,
+                                                    uint64_t seed, float *out, void *stream) {
+    return spatial_gaussian_forward_impl(x, loc, scale, B, K, C, H, W, out, stream, drop_p, seed);
+}
 
-extern "C" int dpk_spatial_gaussian_backward(const float *x, const float *g, const float *loc, const float *scale,
-                                             int64_t B, int32_t K, int32_t C, int32_t H, int32_t W, float *grad_loc,
-                                             float *grad_scale, float *grad_x, void *stream) {
+static int spatial_gaussian_backward_impl(const float *x, const float *g, const float *loc, const float *scale,
+                                          int64_t B, int32_t K, int32_t C, int32_t H, int32_t W, float *grad_loc,
+                                          float *grad_scale, float *grad_x, void *stream, float drop_p, uint64_t seed) {
     DPK_REQUIRE(B >= 0 && K > 0 && C > 0 && H > 0 && W > 0, DPK_EINVAL, "spatial_gaussian_backward: bad sizes");
+    DPK_REQUIRE(drop_p >= 0.f && drop_p < 1.f, DPK_EINVAL, "spatial_gaussian_backward: dropout rate must be in [0, 1)");
     DPK_REQUIRE(loc && scale, DPK_EINVAL, "spatial_gaussian_backward: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const int HW = H * W;
@@ -436,14 +453,26 @@ extern "C" int dpk_spatial_gaussian_backward(const float *x, const float *g, con
     DPK_REQUIRE(x && g, DPK_EINVAL, "spatial_gaussian_backward: null pointer");
     if (grad_x)
         hipLaunchKernelGGL(spatial_gaussian_bwd_x_kernel, dim3(grid_cap(B * C * HW, 256)), dim3(256), 0, st, x, g,
-                           loc, scale, B, K, C, HW, grad_x);
+                           loc, scale, B, K, C, HW, grad_x, drop_p, seed);
     if (grad_loc || grad_scale) {
         const int bslice = 64;
         hipLaunchKernelGGL(spatial_gaussian_bwd_p_kernel, dim3(cdiv((int64_t)K * C * HW, 256), cdiv(B, bslice)),
-                           dim3(256), 0, st, x, g, loc, scale, B, K, C, HW, bslice, grad_loc, grad_scale);
+                           dim3(256), 0, st, x, g, loc, scale, B, K, C, HW, bslice, grad_loc, grad_scale, drop_p, seed);
     }
     DPK_CHECK_LAUNCH("spatial_gaussian_bwd");
     return DPK_OK;
+}
+extern "C" int dpk_spatial_gaussian_backward(const float *x, const float *g, const float *loc, const float *scale,
+                                             int64_t B, int32_t K, int32_t C, int32_t H, int32_t W, float *grad_loc,
+                                             float *grad_scale, float *grad_x, void *stream) {
+    return spatial_gaussian_backward_impl(x, g, loc, scale, B, K, C, H, W, grad_loc, grad_scale, grad_x, stream, 0.f, 0);
+}
+extern "C" int dpk_spatial_gaussian_backward_dropout(const float *x, const float *g, const float *loc,
+                                                     const float *scale, int64_t B, int32_t K, int32_t C, int32_t H,
+                                                     int32_t W, float drop_p, uint64_t seed, float *grad_loc,
+                                                     float *grad_scale, float *grad_x, void *stream) {
+    return spatial_gaussian_backward_impl(x, g, loc, scale, B, K, C, H, W, grad_loc, grad_scale, grad_x, stream, drop_p,
+                                          seed);
 }
 
 static int make_geom(ProdGeom &q, int C, int H, int W, int OC, int OH, int OW, int kh, int kw, int sh, int sw,

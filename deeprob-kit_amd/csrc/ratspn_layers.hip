@@ -295,7 +295,8 @@ template <int DIST, int CBK>
 __global__ __launch_bounds__(256) void leaf_bwd_param_kernel(
     const float *__restrict__ x, const float *__restrict__ g, int64_t B, int D, int R, int I, int d, int SP,
     const int *__restrict__ feat, const int *__restrict__ srcr, const float *__restrict__ p0,
-    const float *__restrict__ p1, float *__restrict__ gp0, float *__restrict__ gp1) {
+    const float *__restrict__ p1, float *__restrict__ gp0, float *__restrict__ gp1, float drop_p,
+    uint64_t seed) {
     const int grp = blockIdx.y;  // region group: its entry stream holds (variable, r*d+j) pairs
     const int kb = blockIdx.z * CBK;
     const int64_t b0 = (int64_t)blockIdx.x * kLeafBwdTile;
@@ -326,6 +327,8 @@ __global__ __launch_bounds__(256) void leaf_bwd_param_kernel(
             const float *gp = g + (b * R + r) * I + kb;
 #pragma unroll
             for (int k = 0; k < CBK; ++k) {
+                // training-mode input dropout: the same (seed, element) decision as the forward kernel
+                if (drop_p > 0.f && dropout_hit(seed, (((uint64_t)b * R + r) * I + kb + k) * d + j, drop_p)) continue;
                 const float gv = gp[k];
                 if (DIST == 0) {
                     const float dl = xv - c0[k];
@@ -361,7 +364,7 @@ __global__ void leaf_inverse_kernel(const int *__restrict__ feat, const int *__r
 __global__ __launch_bounds__(256) void gaussian_leaf_bwd_x_kernel(
     const float *__restrict__ x, const float *__restrict__ g, int64_t B, int D, int R, int I, int d, int reps,
     const int *__restrict__ inv, const float *__restrict__ loc, const float *__restrict__ scale,
-    float *__restrict__ gx) {
+    float *__restrict__ gx, float drop_p, uint64_t seed) {
     const int64_t total = B * D;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
@@ -375,6 +378,7 @@ __global__ __launch_bounds__(256) void gaussian_leaf_bwd_x_kernel(
                 if (rj < 0) continue;
                 const int r = rj / d, j = rj - r * d;
                 for (int k = 0; k < I; ++k) {
+                    if (drop_p > 0.f && dropout_hit(seed, (((uint64_t)b * R + r) * I + k) * d + j, drop_p)) continue;
                     const int64_t po = ((int64_t)r * I + k) * d + j;
                     const float sg = scale[po];
                     acc = fmaf(g[(b * R + r) * I + k], -(xv - loc[po]) / (sg * sg), acc);
@@ -500,7 +504,9 @@ extern "C" int dpk_root_backward(const float *in, const float *weight, const flo
 static int leaf_backward_common(int dist, const float *x, const float *g, int64_t B, int32_t D,
                                 const int64_t *mask, const uint8_t *pad_mask, const float *p0, const float *p1,
                                 int32_t R, int32_t I, int32_t d, float *gp0, float *gp1, float *gx, void *ws,
-                                int64_t ws_bytes, uint32_t flags, void *stream) {
+                                int64_t ws_bytes, uint32_t flags, void *stream, float drop_p = 0.f,
+                                uint64_t seed = 0) {
+    DPK_REQUIRE(drop_p >= 0.f && drop_p < 1.f, DPK_EINVAL, "leaf_backward: dropout rate must be in [0, 1)");
     DPK_REQUIRE(x && g && mask && p0 && ws, DPK_EINVAL, "leaf_backward: null pointer");
     DPK_REQUIRE(dist == 1 || p1, DPK_EINVAL, "leaf_backward: null scale");
     DPK_REQUIRE(B >= 0 && D > 0 && R > 0 && I > 0 && d > 0, DPK_EINVAL, "leaf_backward: bad sizes");
@@ -520,7 +526,7 @@ static int leaf_backward_common(int dist, const float *x, const float *g, int64_
         const dim3 grid(cdiv(B, kLeafBwdTile), w.G, I / cbk), block(256);
 #define DPK_LEAF_BWD(DIST, CBK)                                                                                  \
     hipLaunchKernelGGL((leaf_bwd_param_kernel<DIST, CBK>), grid, block, 0, st, x, g, B, D, R, I, d, w.SP, w.feat, \
-                       w.srcr, p0, p1, gp0, gp1)
+                       w.srcr, p0, p1, gp0, gp1, drop_p, seed)
         if (dist == 0) {
             if (cbk == 4) DPK_LEAF_BWD(0, 4);
             else if (cbk == 2) DPK_LEAF_BWD(0, 2);
@@ -549,7 +555,7 @@ static int leaf_backward_common(int dist, const float *x, const float *g, int64_
         hipLaunchKernelGGL(leaf_inverse_kernel, dim3(w.G), dim3(256), 0, st, w.feat, w.srcr, d, w.SP, D, per_rep,
                            inv);
         hipLaunchKernelGGL(gaussian_leaf_bwd_x_kernel, dim3(grid_for(B * D, 256)), dim3(256), 0, st, x, g, B, D,
-                           R, I, d, reps, inv, p0, p1, gx);
+                           R, I, d, reps, inv, p0, p1, gx, drop_p, seed);
         DPK_CHECK_LAUNCH("gaussian_leaf_bwd_x_kernel");
     }
     return DPK_OK;
@@ -570,4 +576,89 @@ extern "C" int dpk_bernoulli_leaf_backward(const float *x, const float *g, int64
                                            int64_t ws_bytes, uint32_t flags, void *stream) {
     return leaf_backward_common(1, x, g, B, D, mask, pad_mask, logits, nullptr, R, I, d, grad_logits, nullptr,
                                 nullptr, ws, ws_bytes, flags, stream);
+}
+
+// ------------------------------------------------------------------------------------
+// Training-mode input dropout of the leaf layer (reference: ratspn.py:98-100): every element of the
+// [B,R,I,d] log-density tensor is dropped (-> NaN -> 0) with probability p before the sum over d.
+// Plain kernel for training batches: thread per (b, r, k).
+// ------------------------------------------------------------------------------------
+template <int DIST>
+__global__ void leaf_fwd_dropout_kernel(const float *__restrict__ x, int64_t B, int D, const int64_t *__restrict__ mask,
+                                        const uint8_t *__restrict__ pad_mask, const float *__restrict__ p0,
+                                        const float *__restrict__ p1, int R, int I, int d, float drop_p, uint64_t seed,
+                                        float *__restrict__ out) {
+    const int64_t total = B * R * I;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(e % I);
+        const int64_t br = e / I;
+        const int r = (int)(br % R);
+        const int64_t b = br / R;
+        float acc = 0.f;
+        for (int j = 0; j < d; ++j) {
+            if (pad_mask && pad_mask[(int64_t)r * d + j]) continue;
+            if (dropout_hit(seed, (uint64_t)e * d + j, drop_p)) continue;
+            const float xv = x[b * D + mask[(int64_t)r * d + j]];
+            const int64_t po = ((int64_t)r * I + k) * d + j;
+            float t;
+            if (DIST == 0) {
+                const float sg = p1[po], dl = xv - p0[po];
+                t = -(dl * dl) / (2.f * sg * sg) - logf(sg) - kLogSqrt2Pi;
+            } else {
+                const float l = p0[po];
+                t = -(fmaxf(l, 0.f) - l * xv + log1pf(expf(-fabsf(l))));   // -BCEWithLogits(l, x)
+            }
+            acc += nan_to_num_f(t);
+        }
+        out[e] = acc;
+    }
+}
+
+extern "C" int dpk_leaf_forward_dropout(int32_t dist, const float *x, int64_t B, int32_t D, const int64_t *mask,
+                                        const uint8_t *pad_mask, const float *p0, const float *p1, int32_t R,
+                                        int32_t I, int32_t d, float drop_p, uint64_t seed, float *out, void *stream) {
+    DPK_REQUIRE(B >= 0 && D > 0 && R > 0 && I > 0 && d > 0, DPK_EINVAL, "leaf_forward_dropout: bad sizes");
+    DPK_REQUIRE(dist == 0 || dist == 1, DPK_EINVAL, "leaf_forward_dropout: dist must be 0 (Normal) or 1 (Bernoulli)");
+    DPK_REQUIRE(drop_p > 0.f && drop_p < 1.f, DPK_EINVAL, "leaf_forward_dropout: dropout rate must be in (0, 1)");
+    if (B == 0) return DPK_OK;
+    DPK_REQUIRE(x && mask && p0 && out && (dist == 1 || p1), DPK_EINVAL, "leaf_forward_dropout: null pointer");
+    const int64_t total = B * R * I;
+    if (dist == 0)
+        hipLaunchKernelGGL(leaf_fwd_dropout_kernel<0>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                           x, B, D, mask, pad_mask, p0, p1, R, I, d, drop_p, seed, out);
+    else
+        hipLaunchKernelGGL(leaf_fwd_dropout_kernel<1>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                           x, B, D, mask, pad_mask, p0, p1, R, I, d, drop_p, seed, out);
+    DPK_CHECK_LAUNCH("leaf_fwd_dropout_kernel");
+    return DPK_OK;
+}
+
+extern "C" int dpk_leaf_backward_dropout(int32_t dist, const float *x, const float *g, int64_t B, int32_t D,
+                                         const int64_t *mask, const uint8_t *pad_mask, const float *p0,
+                                         const float *p1, int32_t R, int32_t I, int32_t d, float drop_p,
+                                         uint64_t seed, float *grad_p0, float *grad_p1, float *grad_x, void *ws,
+                                         int64_t ws_bytes, uint32_t flags, void *stream) {
+    DPK_REQUIRE(dist == 0 || dist == 1, DPK_EINVAL, "leaf_backward_dropout: dist must be 0 (Normal) or 1 (Bernoulli)");
+    return leaf_backward_common(dist, x, g, B, D, mask, pad_mask, p0, p1, R, I, d, grad_p0, dist == 0 ? grad_p1 : nullptr,
+                                grad_x, ws, ws_bytes, flags, stream, drop_p, seed);
+}
+
+// Sum-layer dropout (reference: ratspn.py:371-372, dgcspn.py:297-298): out = (dropped ? fill : x) on the flat
+// element index; backward: grad_in = (dropped ? 0 : g).
+__global__ void dropout_fill_kernel(const float *__restrict__ x, int64_t n, float drop_p, uint64_t seed, float fill,
+                                    float *__restrict__ out) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+        out[e] = dropout_hit(seed, (uint64_t)e, drop_p) ? fill : x[e];
+}
+
+extern "C" int dpk_dropout_fill(const float *x, int64_t n, float drop_p, uint64_t seed, float fill, float *out,
+                                void *stream) {
+    DPK_REQUIRE(n >= 0 && drop_p >= 0.f && drop_p < 1.f, DPK_EINVAL, "dropout_fill: bad arguments");
+    if (n == 0) return DPK_OK;
+    DPK_REQUIRE(x && out, DPK_EINVAL, "dropout_fill: null pointer");
+    hipLaunchKernelGGL(dropout_fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, n, drop_p,
+                       seed, fill, out);
+    DPK_CHECK_LAUNCH("dropout_fill_kernel");
+    return DPK_OK;
 }

@@ -88,6 +88,18 @@ SIGNATURES = {
     'dpk_bn1d_backward': (ctypes.c_int, [_c_void, _c_void, _c_void, _i64, _i32, _c_void, _c_void, _c_void,
                                          ctypes.c_float, _i32, _c_void, _c_void, _c_void, _c_void, _i64, _c_void]),
     'dpk_normal_base_backward': (ctypes.c_int, [_c_void, _c_void, _c_void, _c_void, _i64, _i32, _c_void, _c_void]),
+    'dpk_leaf_forward_dropout': (ctypes.c_int, [_i32, _c_void, _i64, _i32, _c_void, _c_void, _c_void, _c_void, _i32, _i32,
+                                                _i32, ctypes.c_float, ctypes.c_uint64, _c_void, _c_void]),
+    'dpk_leaf_backward_dropout': (ctypes.c_int, [_i32, _c_void, _c_void, _i64, _i32, _c_void, _c_void, _c_void, _c_void,
+                                                 _i32, _i32, _i32, ctypes.c_float, ctypes.c_uint64, _c_void, _c_void,
+                                                 _c_void, _c_void, _i64, ctypes.c_uint32, _c_void]),
+    'dpk_spatial_gaussian_forward_dropout': (ctypes.c_int, [_c_void, _c_void, _c_void, _i64, _i32, _i32, _i32, _i32,
+                                                            ctypes.c_float, ctypes.c_uint64, _c_void, _c_void]),
+    'dpk_spatial_gaussian_backward_dropout': (ctypes.c_int, [_c_void, _c_void, _c_void, _c_void, _i64, _i32, _i32, _i32,
+                                                             _i32, ctypes.c_float, ctypes.c_uint64, _c_void, _c_void,
+                                                             _c_void, _c_void]),
+    'dpk_dropout_fill': (ctypes.c_int, [_c_void, _i64, ctypes.c_float, ctypes.c_uint64, ctypes.c_float, _c_void,
+                                        _c_void]),
     'dpk_profile_next_kernel': (ctypes.c_int, [_c_void, _c_void]),
     'dpk_ll_accumulate': (ctypes.c_int, [_c_void, _i64, _c_void, _c_void]),
 }

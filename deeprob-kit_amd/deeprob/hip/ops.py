@@ -122,6 +122,74 @@ class BernoulliLeafFn(torch.autograd.Function):
         return None, glog, None, None, None
 
 
+def draw_seed() -> int:
+    """A fresh 62-bit dropout seed from torch's CPU generator (so torch.manual_seed makes training reproducible)."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+class LeafDropoutFn(torch.autograd.Function):
+    """Training-mode RegionGraphLayer.forward with input dropout (reference: ratspn.py:94-108): the element-wise
+    Bernoulli(p) decisions are a counter-based hash of (seed, element), replayed by the backward kernels."""
+
+    @staticmethod
+    def forward(ctx, x, p0, p1, mask, pad_mask, lctx: LeafContext, dist: int, rate: float, seed: int):
+        lib = load_library()
+        x = require_device_f32(x, 'x')
+        p0_c = require_device_f32(p0, 'loc' if dist == 0 else 'logits')
+        p1_c = require_device_f32(p1, 'scale') if p1 is not None else None
+        B = x.shape[0]
+        out = torch.empty((B, lctx.R, lctx.I), dtype=torch.float32, device=x.device)
+        check(lib.dpk_leaf_forward_dropout(dist, ptr(x), B, lctx.D, ptr(mask), ptr(_pad_u8(pad_mask)), ptr(p0_c),
+                                           ptr(p1_c), lctx.R, lctx.I, lctx.d, float(rate), seed, ptr(out),
+                                           stream_ptr(x.device)), 'dpk_leaf_forward_dropout')
+        ctx.save_for_backward(x, p0_c, p1_c, mask, pad_mask)
+        ctx.meta = (lctx, dist, float(rate), seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load_library()
+        x, p0, p1, mask, pad_mask = ctx.saved_tensors
+        lctx, dist, rate, seed = ctx.meta
+        g = require_device_f32(g, 'grad')
+        if dist == 1 and ctx.needs_input_grad[0]:
+            raise NotImplementedError("d/dx through Bernoulli leaves is not defined by the reference use")
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        g0 = torch.empty_like(p0) if ctx.needs_input_grad[1] else None
+        g1 = torch.empty_like(p1) if (p1 is not None and ctx.needs_input_grad[2]) else None
+        ws, flags = lctx.workspace(x.device, mask, pad_mask)
+        check(lib.dpk_leaf_backward_dropout(dist, ptr(x), ptr(g), x.shape[0], lctx.D, ptr(mask), ptr(_pad_u8(pad_mask)),
+                                            ptr(p0), ptr(p1), lctx.R, lctx.I, lctx.d, rate, seed, ptr(g0), ptr(g1),
+                                            ptr(gx), ptr(ws), ws.numel(), flags, stream_ptr(x.device)),
+              'dpk_leaf_backward_dropout')
+        return gx, g0, g1, None, None, None, None, None, None
+
+
+class DropoutFillFn(torch.autograd.Function):
+    """Sum-layer input dropout (reference: ratspn.py:371-372, dgcspn.py:297-298): dropped inputs become -inf;
+    their gradient is zero."""
+
+    @staticmethod
+    def forward(ctx, x, rate: float, seed: int):
+        lib = load_library()
+        x = require_device_f32(x, 'x')
+        out = torch.empty_like(x)
+        check(lib.dpk_dropout_fill(ptr(x), x.numel(), float(rate), seed, float('-inf'), ptr(out), stream_ptr(x.device)),
+              'dpk_dropout_fill')
+        ctx.meta = (float(rate), seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load_library()
+        g = require_device_f32(g, 'grad')
+        rate, seed = ctx.meta
+        gx = torch.empty_like(g)
+        check(lib.dpk_dropout_fill(ptr(g), g.numel(), rate, seed, 0.0, ptr(gx), stream_ptr(g.device)),
+              'dpk_dropout_fill')
+        return gx, None, None
+
+
 class ProductFn(torch.autograd.Function):
     """ProductLayer.forward (reference: ratspn.py:272-286)."""
 

@@ -12,7 +12,8 @@ class SpatialGaussianFn(torch.autograd.Function):
     """SpatialGaussianLayer.forward (reference: deeprob/spn/layers/dgcspn.py:101-120)."""
 
     @staticmethod
-    def forward(ctx, x, loc, scale):
+    def forward(ctx, x, loc, scale, rate=0.0, seed=0):
+        """rate > 0: training-mode input dropout (reference :113-114), decisions hashed from (seed, element)."""
         lib = load_library()
         x = require_device_f32(x, 'x')
         loc_c, scale_c = require_device_f32(loc, 'loc'), require_device_f32(scale, 'scale')
@@ -21,9 +22,15 @@ class SpatialGaussianFn(torch.autograd.Function):
         B, C, H, W = x.shape
         K = loc_c.shape[0]
         out = torch.empty((B, K, H, W), dtype=torch.float32, device=x.device)
-        check(lib.dpk_spatial_gaussian_forward(ptr(x), ptr(loc_c), ptr(scale_c), B, K, C, H, W, ptr(out),
-                                               stream_ptr(x.device)), 'dpk_spatial_gaussian_forward')
+        if rate > 0.0:
+            check(lib.dpk_spatial_gaussian_forward_dropout(ptr(x), ptr(loc_c), ptr(scale_c), B, K, C, H, W, float(rate),
+                                                           seed, ptr(out), stream_ptr(x.device)),
+                  'dpk_spatial_gaussian_forward_dropout')
+        else:
+            check(lib.dpk_spatial_gaussian_forward(ptr(x), ptr(loc_c), ptr(scale_c), B, K, C, H, W, ptr(out),
+                                                   stream_ptr(x.device)), 'dpk_spatial_gaussian_forward')
         ctx.save_for_backward(x, loc_c, scale_c)
+        ctx.drop = (float(rate), seed)
         return out
 
     @staticmethod
@@ -36,10 +43,11 @@ class SpatialGaussianFn(torch.autograd.Function):
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gl = torch.empty_like(loc) if ctx.needs_input_grad[1] else None
         gs = torch.empty_like(scale) if ctx.needs_input_grad[2] else None
-        check(lib.dpk_spatial_gaussian_backward(ptr(x), ptr(g), ptr(loc), ptr(scale), B, K, C, H, W, ptr(gl),
-                                                ptr(gs), ptr(gx), stream_ptr(x.device)),
-              'dpk_spatial_gaussian_backward')
-        return gx, gl, gs
+        rate, seed = ctx.drop
+        check(lib.dpk_spatial_gaussian_backward_dropout(ptr(x), ptr(g), ptr(loc), ptr(scale), B, K, C, H, W, rate, seed,
+                                                        ptr(gl), ptr(gs), ptr(gx), stream_ptr(x.device)),
+              'dpk_spatial_gaussian_backward_dropout')
+        return gx, gl, gs, None, None
 
 
 def _geom(layer):

@@ -89,8 +89,9 @@ class SpatialGaussianLayer(_SpatialShape, nn.Module):
         (reference :101-120)."""
         from deeprob.hip import ops_spatial
         if self.training and self.dropout is not None:
-            raise HipError("training-mode dropout is not part of the HIP density-evaluation path")
-        return ops_spatial.SpatialGaussianFn.apply(x, self.loc, self.scale)
+            from deeprob.hip import ops
+            return ops_spatial.SpatialGaussianFn.apply(x, self.loc, self.scale, self.dropout, ops.draw_seed())
+        return ops_spatial.SpatialGaussianFn.apply(x, self.loc, self.scale, 0.0, 0)
 
 
 class SpatialProductLayer(_SpatialShape, nn.Module):
@@ -168,7 +169,8 @@ class SpatialSumLayer(_SpatialShape, nn.Module):
         """out[b,o,h,w] = logsumexp_c(x[b,c,h,w] + log_softmax(weight, 1)[o,c,h,w]) (reference :289-304)."""
         from deeprob.hip import ops_spatial
         if self.training and self.dropout is not None:
-            raise HipError("training-mode dropout is not part of the HIP density-evaluation path")
+            from deeprob.hip import ops
+            x = ops.DropoutFillFn.apply(x, self.dropout, ops.draw_seed())
         return ops_spatial.SpatialSumFn.apply(x, self.weight, self._ws)
 
 

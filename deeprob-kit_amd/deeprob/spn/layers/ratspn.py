@@ -18,14 +18,6 @@ from deeprob.hip import Workspace, HipError
 from deeprob.hip import ops
 
 
-def _reject_training_dropout(module: nn.Module, rate: Optional[float]):
-    if module.training and rate is not None:
-        raise HipError(
-            "training-mode probabilistic dropout (rate={}) is not part of the HIP density-evaluation "
-            "path; call .eval() or build the model with dropout=None".format(rate)
-        )
-
-
 class RegionGraphLayer(abc.ABC, nn.Module):
     def __init__(
         self,
@@ -105,8 +97,13 @@ class RegionGraphLayer(abc.ABC, nn.Module):
         :param x: inputs ``[B, D]`` on a HIP device.
         :return: ``[B, R, I]``.
         """
-        _reject_training_dropout(self, self.dropout)
+        if self.training and self.dropout is not None:
+            return self._leaf_forward_dropout(x, self.dropout, ops.draw_seed())
         return self._leaf_forward(x)
+
+    @abc.abstractmethod
+    def _leaf_forward_dropout(self, x: torch.Tensor, rate: float, seed: int) -> torch.Tensor:
+        """Training-mode forward with input dropout (reference :98-100)."""
 
     @abc.abstractmethod
     def distribution_mode(self) -> torch.Tensor:
@@ -163,6 +160,10 @@ class GaussianLayer(RegionGraphLayer):
         return ops.GaussianLeafFn.apply(x, self.loc, self.scale, self.mask, self._pad_mask_or_none(),
                                         self._leaf_ctx)
 
+    def _leaf_forward_dropout(self, x: torch.Tensor, rate: float, seed: int) -> torch.Tensor:
+        return ops.LeafDropoutFn.apply(x, self.loc, self.scale, self.mask, self._pad_mask_or_none(), self._leaf_ctx, 0,
+                                       rate, seed)
+
     def distribution_mode(self) -> torch.Tensor:
         return self.distribution.mean
 
@@ -185,6 +186,10 @@ class BernoulliLayer(RegionGraphLayer):
 
     def _leaf_forward(self, x: torch.Tensor) -> torch.Tensor:
         return ops.BernoulliLeafFn.apply(x, self.logits, self.mask, self._pad_mask_or_none(), self._leaf_ctx)
+
+    def _leaf_forward_dropout(self, x: torch.Tensor, rate: float, seed: int) -> torch.Tensor:
+        return ops.LeafDropoutFn.apply(x, self.logits, None, self.mask, self._pad_mask_or_none(), self._leaf_ctx, 1,
+                                       rate, seed)
 
     def distribution_mode(self) -> torch.Tensor:
         return (self.distribution.mean >= 0.5).float()
@@ -242,7 +247,8 @@ class SumLayer(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """out[b,r,o] = logsumexp_n(x[b,r,n] + log_softmax(weight, 2)[r,o,n]) (reference :363-378)."""
-        _reject_training_dropout(self, self.dropout)
+        if self.training and self.dropout is not None:
+            x = ops.DropoutFillFn.apply(x, self.dropout, ops.draw_seed())
         return ops.SumFn.apply(x, self.weight, self._ws)
 
     @torch.no_grad()

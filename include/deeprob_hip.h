@@ -264,6 +264,29 @@ int dpk_bn1d_backward(const float *x, const float *grad_u, const float *grad_ild
 int dpk_normal_base_backward(const float *u, const float *loc, const float *scale, const float *g, int64_t B,
                              int32_t D, float *grad_u, void *stream);
 
+/* ---- training-mode probabilistic dropout (RAT-SPN ratspn.py:98-100, :371-372; DGC-SPN dgcspn.py:113-114,
+ * :297-298).  The reference draws torch.rand_like masks; here element `idx` of a call is dropped iff
+ * splitmix64(seed + idx * 0x9E3779B97F4A7C15) >> 40 < p * 2^24, evaluated identically by the forward and the
+ * backward kernels (no mask tensor).  idx = flat index of the reference's masked tensor: [B,R,I,d] for the
+ * RAT-SPN leaf layer, [B,K,C,H,W] for the spatial Gaussian layer, the sum layer's input for dpk_dropout_fill. */
+int dpk_leaf_forward_dropout(int32_t dist /* 0 Normal, 1 Bernoulli */, const float *x, int64_t B, int32_t D,
+                             const int64_t *mask, const uint8_t *pad_mask, const float *p0, const float *p1,
+                             int32_t R, int32_t I, int32_t d, float drop_p, uint64_t seed, float *out, void *stream);
+int dpk_leaf_backward_dropout(int32_t dist, const float *x, const float *g, int64_t B, int32_t D, const int64_t *mask,
+                              const uint8_t *pad_mask, const float *p0, const float *p1, int32_t R, int32_t I,
+                              int32_t d, float drop_p, uint64_t seed, float *grad_p0, float *grad_p1, float *grad_x,
+                              void *ws, int64_t ws_bytes, uint32_t flags, void *stream);
+int dpk_spatial_gaussian_forward_dropout(const float *x, const float *loc, const float *scale, int64_t B, int32_t K,
+                                         int32_t C, int32_t H, int32_t W, float drop_p, uint64_t seed, float *out,
+                                         void *stream);
+int dpk_spatial_gaussian_backward_dropout(const float *x, const float *g, const float *loc, const float *scale,
+                                          int64_t B, int32_t K, int32_t C, int32_t H, int32_t W, float drop_p,
+                                          uint64_t seed, float *grad_loc, float *grad_scale, float *grad_x,
+                                          void *stream);
+/* out[i] = dropped(i) ? fill : x[i]  (sum-layer input dropout, fill = -inf); its backward is the same call on the
+ * upstream gradient with fill = 0.                                                                           */
+int dpk_dropout_fill(const float *x, int64_t n, float drop_p, uint64_t seed, float fill, float *out, void *stream);
+
 /* Measurement hook: the NEXT dominant-kernel launch made from this thread (the fused / leaf
  * forward kernel) is bracketed by hipEventRecord(ev_start) / hipEventRecord(ev_stop) on its stream,
  * so a harness can time that kernel alone inside a longer step.  One-shot; pass NULLs to cancel. */

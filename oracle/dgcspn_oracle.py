@@ -22,10 +22,13 @@ import torch
 import torch.nn.functional as F
 
 
-def spatial_gaussian(x, loc, scale):
-    """SpatialGaussianLayer.forward (layers/dgcspn.py:101-120), eval mode."""
+def spatial_gaussian(x, loc, scale, drop=None):
+    """SpatialGaussianLayer.forward (layers/dgcspn.py:101-120); ``drop`` (bool [B,K,C,H,W]) = the training-mode
+    dropout mask of :113-114."""
     v = torch.unsqueeze(x, dim=1)                                             # [B,1,C,H,W]
     lp = -((v - loc) ** 2) / (2 * scale ** 2) - torch.log(scale) - math.log(math.sqrt(2 * math.pi))
+    if drop is not None:
+        lp = torch.where(drop, torch.full_like(lp, float('nan')), lp)
     lp = torch.nan_to_num(lp)
     return torch.sum(lp, dim=2)
 
@@ -77,8 +80,10 @@ def spatial_product(x, pad: Sequence[int], stride: int, dilation: int, depthwise
     return out
 
 
-def spatial_sum(x, weight):
-    """SpatialSumLayer.forward (layers/dgcspn.py:289-304), eval mode."""
+def spatial_sum(x, weight, drop=None):
+    """SpatialSumLayer.forward (layers/dgcspn.py:289-304); ``drop`` (bool, shape of x) = dropout mask of :297-298."""
+    if drop is not None:
+        x = x.masked_fill(drop, float('-inf'))
     w = torch.log_softmax(weight, dim=1)
     return torch.logsumexp(torch.unsqueeze(x, dim=1) + w, dim=2)
 
@@ -114,17 +119,19 @@ def schedule(in_features: Tuple[int, int, int], n_batch: int, sum_channels: int,
 
 
 def dgcspn_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, plan, return_activations: bool = False,
-                   z: Optional[torch.Tensor] = None):
-    """DgcSpn.forward (models/dgcspn.py:134-151).  ``z``: start from given leaf outputs (for mpe)."""
+                   z: Optional[torch.Tensor] = None, drops: Optional[Dict[str, torch.Tensor]] = None):
+    """DgcSpn.forward (models/dgcspn.py:134-151).  ``z``: start from given leaf outputs (for mpe); ``drops``:
+    training-mode dropout masks {'leaf': [B,K,C,H,W], 'layers.<i>': shape of that sum layer's input}."""
+    drops = drops or {}
     acts = []
-    h = spatial_gaussian(x, sd['base_layer.loc'], sd['base_layer.scale']) if z is None else z
+    h = spatial_gaussian(x, sd['base_layer.loc'], sd['base_layer.scale'], drops.get('leaf')) if z is None else z
     acts.append(h)
     for i, step in enumerate(plan):
         if step[0] == 'prod':
             _, pad, stride, dilation, dw = step
             h = spatial_product(h, pad, stride, dilation, dw)
         else:
-            h = spatial_sum(h, sd['layers.{}.weight'.format(i)])
+            h = spatial_sum(h, sd['layers.{}.weight'.format(i)], drops.get('layers.{}'.format(i)))
         acts.append(h)
     out = spatial_root(h, sd['root_layer.weight'])
     return (out, acts) if return_activations else out

@@ -72,24 +72,29 @@ def _normal_log_prob(value, loc, scale):
     return -((value - loc) ** 2) / (2 * var) - log_scale - math.log(math.sqrt(2 * math.pi))
 
 
-def gaussian_leaf(x, mask, pad_mask, loc, scale):
-    """RegionGraphLayer.forward with GaussianLayer, eval mode (ratspn.py:87-108)."""
+def gaussian_leaf(x, mask, pad_mask, loc, scale, drop=None):
+    """RegionGraphLayer.forward with GaussianLayer (ratspn.py:87-108).  ``drop`` (bool [B,R,I,d]) plays the
+    training-mode dropout mask ``torch.lt(torch.rand_like(x), p)`` of :98-100."""
     g = torch.unsqueeze(x[:, mask], dim=2)                 # :95  [B,R,1,d]
     g = _normal_log_prob(g, loc, scale)                    # :96  [B,R,I,d]
-    torch.nan_to_num_(g)                                   # :103
+    if drop is not None:
+        g = torch.where(drop, torch.full_like(g, float('nan')), g)   # :100 (out of place: keeps autograd usable)
+    g = torch.nan_to_num(g)                                # :103
     if pad_mask is not None:
-        g.masked_fill_(pad_mask, 0.0)                      # :106-107
+        g = g.masked_fill(pad_mask, 0.0)                   # :106-107
     return torch.sum(g, dim=-1)                            # :108
 
 
-def bernoulli_leaf(x, mask, pad_mask, logits):
+def bernoulli_leaf(x, mask, pad_mask, logits, drop=None):
     """Same with BernoulliLayer: Bernoulli(logits).log_prob = -BCEWithLogits (ratspn.py:243)."""
     g = torch.unsqueeze(x[:, mask], dim=2)
     lg, v = torch.broadcast_tensors(logits, g)
     g = -torch.nn.functional.binary_cross_entropy_with_logits(lg, v, reduction='none')
-    torch.nan_to_num_(g)
+    if drop is not None:
+        g = torch.where(drop, torch.full_like(g, float('nan')), g)
+    g = torch.nan_to_num(g)
     if pad_mask is not None:
-        g.masked_fill_(pad_mask, 0.0)
+        g = g.masked_fill(pad_mask, 0.0)
     return torch.sum(g, dim=-1)
 
 
@@ -102,8 +107,11 @@ def product_layer(x):
     return (x1 + x2).view(-1, n_part, n_nodes * n_nodes)
 
 
-def sum_layer(x, weight):
-    """SumLayer.forward, eval mode (ratspn.py:363-378)."""
+def sum_layer(x, weight, drop=None):
+    """SumLayer.forward (ratspn.py:363-378); ``drop`` (bool, shape of x) = the training-mode dropout mask of
+    :371-372 (dropped inputs become -inf)."""
+    if drop is not None:
+        x = x.masked_fill(drop, float('-inf'))
     w = torch.log_softmax(weight, dim=2)
     return torch.logsumexp(torch.unsqueeze(x, dim=2) + w, dim=3)
 
@@ -118,22 +126,25 @@ def root_layer(x, weight):
 # --------------------------------------------------------------------------------------------
 # model
 # --------------------------------------------------------------------------------------------
-def ratspn_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, return_activations: bool = False):
+def ratspn_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, return_activations: bool = False,
+                   drops: Optional[Dict[str, torch.Tensor]] = None):
     """RatSpn.forward (deeprob/spn/models/ratspn.py:105-122) from a state_dict.
 
     Layer kinds are read off the state_dict keys exactly as the reference builds them (:91-100):
     ``layers.{even}.mask`` -> Product, ``layers.{odd}.weight`` -> Sum.
     """
+    drops = drops or {}   # training mode: {'leaf': mask [B,R,I,d], 'layers.<i>': mask of that sum layer's input}
     pad_mask = sd.get('base_layer.pad_mask')
     if 'base_layer.logits' in sd:
-        h = bernoulli_leaf(x, sd['base_layer.mask'], pad_mask, sd['base_layer.logits'])
+        h = bernoulli_leaf(x, sd['base_layer.mask'], pad_mask, sd['base_layer.logits'], drops.get('leaf'))
     else:
-        h = gaussian_leaf(x, sd['base_layer.mask'], pad_mask, sd['base_layer.loc'], sd['base_layer.scale'])
+        h = gaussian_leaf(x, sd['base_layer.mask'], pad_mask, sd['base_layer.loc'], sd['base_layer.scale'],
+                          drops.get('leaf'))
     acts = {'leaf': h}
     i = 0
     while 'layers.{}.mask'.format(i) in sd or 'layers.{}.weight'.format(i) in sd:
         if 'layers.{}.weight'.format(i) in sd:
-            h = sum_layer(h, sd['layers.{}.weight'.format(i)])
+            h = sum_layer(h, sd['layers.{}.weight'.format(i)], drops.get('layers.{}'.format(i)))
         else:
             h = product_layer(h)
         acts['layer{}'.format(i)] = h

@@ -159,3 +159,18 @@ def test_cpu_tensor_is_rejected():
     model = GaussianRatSpn(16, rg_depth=1).eval()
     with pytest.raises(HipError):
         model(torch.randn(4, 16))
+
+
+def test_dropout_hash_restatement():
+    """tests/util.py::dropout_mask (numpy) == the documented formula of include/deeprob_hip.h, element by element."""
+    from tests.util import dropout_mask
+    seed, p, n = 0x1234_5678_9ABC, 0.37, 500
+    got = dropout_mask(seed, (n,), p).numpy()
+    M = (1 << 64) - 1
+    for idx in range(n):
+        z = (seed + idx * 0x9E3779B97F4A7C15) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        z ^= z >> 31
+        assert bool(got[idx]) == ((z >> 40) < np.float32(p) * np.float32(16777216.0)), idx
+    assert abs(dropout_mask(7, (200000,), 0.2).float().mean().item() - 0.2) < 0.005

@@ -64,3 +64,16 @@ def randomise_dgc(model, seed):
                 p.copy_(0.5 + 0.5 * torch.rand(p.shape, generator=g))
             else:
                 p.copy_(torch.randn(p.shape, generator=g))
+
+
+def dropout_mask(seed: int, shape, p: float):
+    """The counter-based dropout decision of the HIP kernels (csrc/common.h::dropout_hit) restated in numpy:
+    element idx is dropped iff splitmix64(seed + idx * golden) >> 40 < p * 2^24.  Returns a bool tensor."""
+    n = int(np.prod(shape))
+    with np.errstate(over='ignore'):
+        z = np.uint64(seed) + np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    top = (z >> np.uint64(40)).astype(np.float32)
+    return torch.from_numpy((top < np.float32(p) * np.float32(16777216.0)).reshape(shape))
