@@ -1,0 +1,47 @@
+"""The reference's train / test entry points (deeprob/torch/routines.py) driving the HIP models."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ratspn_oracle as orc
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_and_test_model_ratspn(tmp_path):
+    from deeprob.spn.models import GaussianRatSpn
+    from deeprob.torch.routines import train_model, test_model
+    torch.manual_seed(0)
+    gen = torch.Generator().manual_seed(1)
+    centre = torch.randn(20, generator=gen)
+    train = (centre + 0.5 * torch.randn(600, 20, generator=gen)).numpy()
+    valid = (centre + 0.5 * torch.randn(150, 20, generator=gen)).numpy()
+    model = GaussianRatSpn(20, rg_depth=2, rg_repetitions=4, rg_batch=4, rg_sum=4, optimize_scale=True, in_dropout=0.1,
+                           random_state=42)
+    hist = train_model(model, train, valid, setting='generative', lr=2e-2, batch_size=100, epochs=8, patience=3,
+                       checkpoint=str(tmp_path / 'ck.pt'), verbose=False)
+    assert set(hist) == {'train', 'valid'} and len(hist['train']) == len(hist['valid']) <= 8
+    assert hist['valid'][-1] < hist['valid'][0] - 1.0 and np.isfinite(hist['train']).all()
+    mean_ll, two_se = test_model(model, valid, setting='generative', batch_size=64, verbose=False)
+    # same numbers as the reference's recipe (np.mean / 2 np.std / sqrt(n)) on the oracle's log-likelihoods
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    lls = orc.ratspn_forward(sd, torch.from_numpy(valid)).double().numpy().reshape(-1)
+    assert abs(mean_ll - lls.mean()) <= 1e-5 * abs(lls.mean())
+    assert abs(two_se - 2.0 * lls.std() / np.sqrt(lls.size)) <= 1e-3 * two_se
+    assert float(model.base_layer.scale.min()) >= 1e-5          # ScaleClipper ran (apply_constraints)
+    with pytest.raises(ValueError):
+        train_model(model, train, valid, setting='unsupervised')
+
+
+def test_train_flow_with_batch_norm(tmp_path):
+    from deeprob.flows.models import RealNVP1d
+    from deeprob.torch.routines import train_model, test_model
+    torch.manual_seed(2)
+    data = (torch.randn(512, 16) * torch.linspace(0.3, 2.0, 16) + 1.0).numpy()
+    flow = RealNVP1d(16, n_flows=2, units=32)
+    before = test_model(flow, data[:128], verbose=False)[0]
+    hist = train_model(flow, data[:384], data[384:], lr=1e-2, batch_size=128, epochs=10, patience=10,
+                       checkpoint=str(tmp_path / 'ck.pt'), verbose=False)
+    after = test_model(flow, data[:128], verbose=False)[0]
+    assert after > before + 1.0 and hist['train'][-1] < hist['train'][0]
