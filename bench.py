@@ -44,6 +44,9 @@ def parse():
     ap.add_argument('--ring', type=int, default=0, help='distinct resident batches (0: > 256 MiB worth)')
     ap.add_argument('--cpu-samples', type=int, default=262144, help='cpu_baseline sample size (0 = skip)')
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only to "
+                    "rehearse the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument('--share-device', action='store_true', help='rehearsal: every rank uses cuda:0')
     ap.add_argument('--kernel-event-every', type=int, default=1,
                     help='bracket the fused kernel with HIP events on every Nth timed step (some hosts pay '
                          '~0.15 ms of runtime bookkeeping per timing event; the stride is widened there)')
@@ -99,13 +102,18 @@ def main():
     if args.gpus > 1 and world == 1:
         sys.exit('for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...')
     assert world == max(args.gpus, 1), 'WORLD_SIZE {} != --gpus {}'.format(world, args.gpus)
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from deeprob.spn.models import GaussianRatSpn
     from deeprob.parallel import ShardedLogLikelihood
