@@ -7,7 +7,7 @@ OUT=$PWD/gpurun_out/pmc
 mkdir -p $OUT
 run() {
   name=$1; shift
-  (cd /tmp && rocprofv3 --pmc "$@" -d $OUT/$name -o $name --output-format csv -- python $OLDPWD/bench.py --steps 20 --warmup 3 --cpu-samples 0 --no-kernel-events > /dev/null 2>$OUT/$name.err)
+  (cd /tmp && timeout -k 10 300 rocprofv3 --pmc "$@" -d $OUT/$name -o $name --output-format csv -- python $OLDPWD/bench.py --steps 20 --warmup 3 --cpu-samples 0 --no-kernel-events > /dev/null 2>$OUT/$name.err)
   f=$(find $OUT/$name -name "*counter_collection.csv" | head -1)
   python - "$f" <<'PY'
 import csv, sys, collections

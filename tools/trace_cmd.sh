@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/trace_$tag
 rm -rf $OUT; mkdir -p $OUT
-(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT -o t --output-format csv -- "$@" > $OUT/stdout.txt 2>$OUT/stderr.txt)
+(cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT -o t --output-format csv -- "$@" > $OUT/stdout.txt 2>$OUT/stderr.txt)
 f=$(find $OUT -name "*kernel_stats.csv" | head -1)
 python - "$f" "$*" <<'PY' | tee $OUT/kernel_stats_summary.txt
 import csv, sys
