@@ -348,6 +348,15 @@ __global__ __launch_bounds__(256) void spatial_prodsum_fwd_kernel(const float *_
             toff[t] = (t < T && ih >= 0 && ih < q.H && iw >= 0 && iw < q.W) ? ih * q.W + iw : -1;
         }
     }
+    // unconditional loads at clamped offsets + a select: no per-load exec-mask juggling at the map borders
+    int tclamp[4];
+    bool tval[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        tval[t] = toff[t] >= 0;
+        tclamp[t] = max(toff[t], 0);
+    }
+    const bool full_c = (q.C == CMAX);
     float ev[NB][CMAX], m0[NB];
 #pragma unroll
     for (int s = 0; s < NB; ++s) {
@@ -355,13 +364,14 @@ __global__ __launch_bounds__(256) void spatial_prodsum_fwd_kernel(const float *_
         float m = -INFINITY;
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) {
-            float a = -INFINITY;
-            if (c < q.C) {
-                a = 0.f;
+            const int cc = full_c ? c : min(c, q.C - 1);
+            float a = 0.f;
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    if (toff[t] >= 0) a += src[c * HW + toff[t]];
+            for (int t = 0; t < 4; ++t) {
+                const float v = src[cc * HW + tclamp[t]];
+                a += tval[t] ? v : 0.f;
             }
+            if (!full_c && c >= q.C) a = -INFINITY;
             ev[s][c] = a;
             m = fmaxf(m, a);
         }
