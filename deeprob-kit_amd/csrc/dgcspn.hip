@@ -421,6 +421,87 @@ __global__ __launch_bounds__(256) void spatial_prodsum_fwd_kernel(const float *_
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Last level of the eval route: depthwise product ('final' padding) folded into the root sum nodes.
+//   out[b,k] = logsumexp_m( prod[b,m] + log_softmax(weight,1)[k,m] ),  m = (c, oh, ow) flattened,
+//   prod[b,m] = sum of the window taps of in[b,c] -- never written.  One wave per sample, lanes stride m,
+//   per-lane online log-sum-exp in the log domain for up to kRootK classes at a time, then a wave combine.
+// ------------------------------------------------------------------------------------------------
+// one 256-thread block per row (rows are thousands of entries long, there are only a few of them)
+__global__ __launch_bounds__(256) void rowwise_logsoftmax_kernel(const float *__restrict__ w, int rows, int n,
+                                                                  float *__restrict__ LW) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *src = w + (int64_t)row * n;
+    float mx = -INFINITY;
+    for (int i = tid; i < n; i += 256) mx = fmaxf(mx, src[i]);
+    mx = wave_reduce_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = tid; i < n; i += 256) sum += expf(src[i] - mx);
+    sum = wave_reduce_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    const float ls = logf((red[0] + red[1]) + (red[2] + red[3]));
+    for (int i = tid; i < n; i += 256) LW[(int64_t)row * n + i] = src[i] - mx - ls;
+}
+
+constexpr int kRootK = 4;
+__global__ __launch_bounds__(256) void spatial_prodroot_fwd_kernel(const float *__restrict__ in,
+                                                                    const float *__restrict__ LW, int64_t B,
+                                                                    ProdGeom q, int K, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int OHW = q.OH * q.OW, HW = q.H * q.W, M = q.C * OHW, T = q.kh * q.kw;
+    const float *src = in + b * q.C * HW;
+    for (int k0 = 0; k0 < K; k0 += kRootK) {
+        float mx[kRootK], sm[kRootK];
+#pragma unroll
+        for (int j = 0; j < kRootK; ++j) {
+            mx[j] = -INFINITY;
+            sm[j] = 0.f;
+        }
+        for (int m = lane; m < M; m += 64) {
+            const int c = m / OHW, p = m - c * OHW;
+            const int oh = p / q.OW, ow = p - oh * q.OW;
+            float a = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int th = t / q.kw, tw = t - th * q.kw;
+                const int ih = oh * q.sh - q.pt + th * q.dh, iw = ow * q.sw - q.pl + tw * q.dw;
+                const bool ok = t < T && ih >= 0 && ih < q.H && iw >= 0 && iw < q.W;
+                const float v = src[c * HW + (ok ? ih * q.W + iw : 0)];
+                a += ok ? v : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < kRootK; ++j) {
+                if (k0 + j < K) {
+                    const float t = a + LW[(int64_t)(k0 + j) * M + m];
+                    if (t > mx[j]) {
+                        sm[j] *= expf(mx[j] - t);
+                        mx[j] = t;
+                    }
+                    if (mx[j] > -INFINITY) sm[j] += expf(t - mx[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kRootK; ++j) {
+            if (k0 + j < K) {
+                const float Mx = wave_reduce_max(mx[j]);
+                const float part = (mx[j] > -INFINITY) ? sm[j] * expf(mx[j] - Mx) : 0.f;
+                const float tot = wave_reduce_sum(part);
+                if (lane == 0) out[b * K + k0 + j] = (Mx > -INFINITY) ? Mx + logf(tot) : -INFINITY;
+            }
+        }
+    }
+}
+
 }  // namespace dpk
 
 using namespace dpk;
@@ -630,5 +711,37 @@ extern "C" int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C
         DPK_PRODSUM(32, 1);
 #undef DPK_PRODSUM
     DPK_CHECK_LAUNCH("spatial_prodsum_fwd_kernel");
+    return DPK_OK;
+}
+
+// Depthwise SpatialProductLayer (<= 4 taps) followed by SpatialRootLayer (models/dgcspn.py:146-150 in eval mode):
+// weight [K, C*OH*OW]; workspace = K*C*OH*OW floats (+256 B).
+extern "C" int64_t dpk_spatial_prodroot_workspace_bytes(int32_t C, int32_t OH, int32_t OW, int32_t K) {
+    if (C <= 0 || OH <= 0 || OW <= 0 || K <= 0) return DPK_EINVAL;
+    return align_up((int64_t)K * C * OH * OW * 4, 256) + 256;
+}
+
+extern "C" int dpk_spatial_prodroot_forward(const float *in, int64_t B, int32_t C, int32_t H, int32_t W, int32_t OH,
+                                            int32_t OW, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t dh,
+                                            int32_t dw, int32_t pad_top, int32_t pad_left, const float *weight,
+                                            int32_t K, float *out, void *ws, int64_t ws_bytes, void *stream) {
+    ProdGeom q;
+    int rc = make_geom(q, C, H, W, C, OH, OW, kh, kw, sh, sw, dh, dw, pad_top, pad_left, 1);
+    if (rc) return rc;
+    DPK_REQUIRE(B >= 0 && K > 0, DPK_EINVAL, "spatial_prodroot: bad sizes");
+    DPK_REQUIRE(kh * kw <= 4, DPK_EUNSUPPORTED, "spatial_prodroot: taps=%d not fused", kh * kw);
+    DPK_REQUIRE((int64_t)C * H * W < ((int64_t)1 << 30) && (int64_t)C * OH * OW < ((int64_t)1 << 30), DPK_EUNSUPPORTED,
+                "spatial_prodroot: map too large");
+    DPK_REQUIRE(weight && ws, DPK_EINVAL, "spatial_prodroot: null pointer");
+    const int M = C * OH * OW;
+    DPK_REQUIRE(ws_bytes >= dpk_spatial_prodroot_workspace_bytes(C, OH, OW, K), DPK_EWORKSPACE,
+                "spatial_prodroot: workspace too small");
+    if (B == 0) return DPK_OK;
+    DPK_REQUIRE(in && out, DPK_EINVAL, "spatial_prodroot: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    float *LW = (float *)ws;
+    hipLaunchKernelGGL(rowwise_logsoftmax_kernel, dim3(K), dim3(256), 0, st, weight, K, M, LW);
+    hipLaunchKernelGGL(spatial_prodroot_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, in, LW, B, q, K, out);
+    DPK_CHECK_LAUNCH("spatial_prodroot_fwd_kernel");
     return DPK_OK;
 }

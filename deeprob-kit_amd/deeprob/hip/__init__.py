@@ -100,6 +100,9 @@ SIGNATURES = {
                                                              _c_void, _c_void]),
     'dpk_dropout_fill': (ctypes.c_int, [_c_void, _i64, ctypes.c_float, ctypes.c_uint64, ctypes.c_float, _c_void,
                                         _c_void]),
+    'dpk_spatial_prodroot_workspace_bytes': (_i64, [_i32, _i32, _i32, _i32]),
+    'dpk_spatial_prodroot_forward': (ctypes.c_int, [_c_void, _i64] + [_i32] * 13 + [_c_void, _i32, _c_void, _c_void,
+                                                                                   _i64, _c_void]),
     'dpk_profile_next_kernel': (ctypes.c_int, [_c_void, _c_void]),
     'dpk_ll_accumulate': (ctypes.c_int, [_c_void, _i64, _c_void, _c_void]),
 }

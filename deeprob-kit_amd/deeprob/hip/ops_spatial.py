@@ -152,3 +152,30 @@ def spatial_prodsum(x, prod_layer, weight, ws: Workspace):
         return None
     check(rc, 'dpk_spatial_prodsum_forward')
     return out
+
+
+def spatial_prodroot(x, prod_layer, weight, ws: Workspace):
+    """Last level of the eval route: depthwise SpatialProductLayer + SpatialRootLayer in one launch (reference:
+    deeprob/spn/models/dgcspn.py:146-150).  No autograd graph; None when outside the fused kernel's envelope."""
+    lib = load_library()
+    x = require_device_f32(x, 'x')
+    w = require_device_f32(weight, 'weight')
+    if not prod_layer.depthwise:
+        return None
+    if x.dim() != 4 or tuple(x.shape[1:]) != tuple(prod_layer.in_features):
+        raise ValueError(f"expected input [B, {prod_layer.in_features}], got {tuple(x.shape)}")
+    C, H, W, _, OH, OW, kh, kw, sh, sw, dh, dw, pt, pl, _ = _geom(prod_layer)
+    B, K = x.shape[0], w.shape[0]
+    if w.shape[1] != C * OH * OW:
+        raise ValueError("root weight does not match the product layer's output")
+    n = lib.dpk_spatial_prodroot_workspace_bytes(C, OH, OW, K)
+    if n < 0:
+        check(int(n), 'dpk_spatial_prodroot_workspace_bytes')
+    buf = ws.get(n, x.device)
+    out = torch.empty((B, K), dtype=torch.float32, device=x.device)
+    rc = lib.dpk_spatial_prodroot_forward(ptr(x), B, C, H, W, OH, OW, kh, kw, sh, sw, dh, dw, pt, pl, ptr(w), K,
+                                          ptr(out), ptr(buf), buf.numel(), stream_ptr(x.device))
+    if rc == -4:  # DPK_EUNSUPPORTED
+        return None
+    check(rc, 'dpk_spatial_prodroot_forward')
+    return out

@@ -184,6 +184,7 @@ class SpatialRootLayer(nn.Module):
         self.weight = nn.Parameter(torch.empty(self.out_channels, flat), requires_grad=True)
         dirichlet_(self.weight, alpha=1.0)
         self._ws = Workspace()
+        self._ws2 = Workspace()   # fused product+root route (deeprob.hip.ops_spatial.spatial_prodroot)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """Flatten + log-sum-exp with ``log_softmax(weight, 1)`` (reference :343-355)."""

@@ -119,6 +119,11 @@ class DgcSpn(ProbabilisticModel):
                 if y is not None:
                     x, i = y, i + 2
                     continue
+            if i == n - 1 and isinstance(layer, SpatialProductLayer):
+                # the last product feeds the root sum nodes directly
+                y = ops_spatial.spatial_prodroot(x, layer, self.root_layer.weight, self.root_layer._ws2)
+                if y is not None:
+                    return y
             x = layer(x)
             i += 1
         return self.root_layer(x)

@@ -287,6 +287,15 @@ int dpk_spatial_gaussian_backward_dropout(const float *x, const float *g, const 
  * upstream gradient with fill = 0.                                                                           */
 int dpk_dropout_fill(const float *x, int64_t n, float drop_p, uint64_t seed, float fill, float *out, void *stream);
 
+/* Eval route of the last DGC-SPN level: depthwise product (<= 4 taps) folded into SpatialRootLayer
+ * (models/dgcspn.py:146-150, layers/dgcspn.py:343-355): out[b,k] = logsumexp_m(prod[b,m] + log_softmax(weight,1)[k,m]),
+ * weight [K, C*OH*OW], the product map never reaches HBM.  DPK_EUNSUPPORTED outside that envelope.        */
+int64_t dpk_spatial_prodroot_workspace_bytes(int32_t C, int32_t OH, int32_t OW, int32_t K);
+int dpk_spatial_prodroot_forward(const float *in, int64_t B, int32_t C, int32_t H, int32_t W, int32_t OH,
+                                 int32_t OW, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t dh,
+                                 int32_t dw, int32_t pad_top, int32_t pad_left, const float *weight, int32_t K,
+                                 float *out, void *ws, int64_t ws_bytes, void *stream);
+
 /* Measurement hook: the NEXT dominant-kernel launch made from this thread (the fused / leaf
  * forward kernel) is bracketed by hipEventRecord(ev_start) / hipEventRecord(ev_stop) on its stream,
  * so a harness can time that kernel alone inside a longer step.  One-shot; pass NULLs to cancel. */
