@@ -662,3 +662,164 @@ extern "C" int dpk_dropout_fill(const float *x, int64_t n, float drop_p, uint64_
     DPK_CHECK_LAUNCH("dropout_fill_kernel");
     return DPK_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// Eval route for shapes the single-launch model kernel does not cover (e.g. I = S = 16, the reference's MNIST
+// example): ProductLayer folded into the SumLayer / RootLayer above it, so the [B, P, N^2] product tensor
+// (1 GB at B = 65536, N = 16) is never written.
+//   prodsum : out[b,p,o] = logsumexp_{i,j}( x[b,2p,i] + x[b,2p+1,j] + lw[p,o,i,j] )
+//   prodroot: out[b,k]   = logsumexp_{p,i,j}( x[b,2p,i] + x[b,2p+1,j] + lw[k,p,i,j] )
+// Exp domain: ea_i = exp(a_i - max a), ec_j likewise, v = sum_i ea_i sum_j W[i,j] ec_j with the linear softmax
+// weights on the scalar path (uniform per wave); v < 1e-30 falls back to the exact log-domain double loop.
+// lane = sample, wave = partition (prodsum) / class block (prodroot).
+// ------------------------------------------------------------------------------------
+template <int NMAX>
+__device__ __forceinline__ void load_children(const float *__restrict__ xa, const float *__restrict__ xc, int N,
+                                              float (&a)[NMAX], float (&c)[NMAX], float (&ea)[NMAX],
+                                              float (&ec)[NMAX], float &ma, float &mc) {
+    float m1 = -INFINITY, m2 = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) {
+        a[i] = i < N ? xa[i] : -INFINITY;
+        c[i] = i < N ? xc[i] : -INFINITY;
+        m1 = fmaxf(m1, a[i]);
+        m2 = fmaxf(m2, c[i]);
+    }
+    ma = (m1 == -INFINITY) ? 0.f : m1;
+    mc = (m2 == -INFINITY) ? 0.f : m2;
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) {
+        ea[i] = __expf(a[i] - ma);
+        ec[i] = __expf(c[i] - mc);
+    }
+}
+
+template <int NMAX>
+__device__ __forceinline__ float bilinear(cfloat_p W, int N, const float (&ea)[NMAX], const float (&ec)[NMAX]) {
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) {   // fully unrolled: ea / ec stay in registers
+        if (i < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < NMAX; ++j)
+                if (j < N) t = fmaf(W[i * N + j], ec[j], t);
+            v = fmaf(ea[i], t, v);
+        }
+    }
+    return v;
+}
+
+// exact log-domain (m, s) of logsumexp_{i,j}(a_i + c_j + lw[i,j]); rare and lane-divergent
+__device__ __forceinline__ void exact_pair_lse(const float *__restrict__ xa, const float *__restrict__ xc,
+                                               cfloat_p lw, int N, float &m, float &sum) {
+    m = -INFINITY;
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) m = fmaxf(m, xa[i] + xc[j] + lw[i * N + j]);
+    sum = 0.f;
+    if (m > -INFINITY)
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) sum += expf(xa[i] + xc[j] + lw[i * N + j] - m);
+}
+
+template <int NMAX>
+__global__ __launch_bounds__(256) void prodsum_fwd_kernel(const float *__restrict__ in, cfloat_p W, cfloat_p LW,
+                                                         int64_t B, int R, int N, int S, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int P = R / 2;
+    const int p = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
+    const int64_t b = min((int64_t)blockIdx.x * 64 + lane, B - 1);
+    if (p >= P) return;
+    const float *xa = in + (b * R + 2 * p) * N, *xc = xa + N;
+    float a[NMAX], c[NMAX], ea[NMAX], ec[NMAX], ma, mc;
+    load_children<NMAX>(xa, xc, N, a, c, ea, ec, ma, mc);
+    const int NN = N * N;
+    for (int o = 0; o < S; ++o) {
+        const float v = bilinear<NMAX>(W + ((int64_t)p * S + o) * NN, N, ea, ec);
+        float r;
+        if (v < 1e-30f) {
+            float m, sum;
+            exact_pair_lse(xa, xc, LW + ((int64_t)p * S + o) * NN, N, m, sum);
+            r = (m > -INFINITY) ? m + logf(sum) : -INFINITY;
+        } else {
+            r = ma + mc + __logf(v);
+        }
+        if ((int64_t)blockIdx.x * 64 + lane < B) out[(b * P + p) * S + o] = r;
+    }
+}
+
+// classes over the waves of the block (k = wave, wave + 4, ...), partitions inside the thread
+template <int NMAX>
+__global__ __launch_bounds__(256) void prodroot_fwd_kernel(const float *__restrict__ in, cfloat_p W, cfloat_p LW,
+                                                          int64_t B, int R, int N, int C, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int P = R / 2, NN = N * N;
+    const int64_t b = min((int64_t)blockIdx.x * 64 + lane, B - 1);
+    for (int k = wave; k < C; k += 4) {
+        float rm = -INFINITY, rs = 0.f;   // running (max, scaled sum) over the partitions
+        for (int p = 0; p < P; ++p) {
+            const float *xa = in + (b * R + 2 * p) * N, *xc = xa + N;
+            float a[NMAX], c[NMAX], ea[NMAX], ec[NMAX], ma, mc;
+            load_children<NMAX>(xa, xc, N, a, c, ea, ec, ma, mc);
+            float m = ma + mc, v = bilinear<NMAX>(W + ((int64_t)k * P + p) * NN, N, ea, ec);
+            if (v < 1e-30f) exact_pair_lse(xa, xc, LW + ((int64_t)k * P + p) * NN, N, m, v);
+            if (v > 0.f && m > -INFINITY) {
+                if (m > rm) {
+                    rs = rs * __expf(rm - m) + v;
+                    rm = m;
+                } else {
+                    rs += v * __expf(m - rm);
+                }
+            }
+        }
+        if ((int64_t)blockIdx.x * 64 + lane < B) out[b * C + k] = (rm > -INFINITY) ? rm + logf(rs) : -INFINITY;
+    }
+}
+
+static int prod_fused_common(bool root, const float *in, const float *weight, int64_t B, int R, int N, int S,
+                             float *out, void *ws, int64_t ws_bytes, void *stream, const char *who) {
+    DPK_REQUIRE(B >= 0 && R > 0 && (R % 2) == 0 && N > 0 && S > 0, DPK_EINVAL, "%s: bad sizes", who);
+    DPK_REQUIRE(N <= 32, DPK_EUNSUPPORTED, "%s: %d nodes per region > 32", who, N);
+    DPK_REQUIRE(weight && ws, DPK_EINVAL, "%s: null pointer", who);
+    const int P = R / 2;
+    const int rows = root ? S : P * S;                 // S = classes for the root
+    const int n = root ? P * N * N : N * N;
+    const int64_t seg = align_up((int64_t)rows * n * 4, 256);
+    DPK_REQUIRE(ws_bytes >= 2 * seg, DPK_EWORKSPACE, "%s: workspace too small", who);
+    if (B == 0) return DPK_OK;
+    DPK_REQUIRE(in && out, DPK_EINVAL, "%s: null pointer", who);
+    float *W = (float *)ws, *LW = (float *)((char *)ws + seg);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(softmax_rows_kernel2, dim3(cdiv(rows, 4)), dim3(256), 0, st, weight, rows, n, W, LW);
+    const dim3 block(256);
+#define DPK_LAUNCH_PS(NMAX)                                                                                         \
+    do {                                                                                                            \
+        if (root)                                                                                                   \
+            hipLaunchKernelGGL(prodroot_fwd_kernel<NMAX>, dim3(cdiv(B, 64)), block, 0, st, in, as_const(W),         \
+                               as_const(LW), B, R, N, S, out);                                                      \
+        else                                                                                                        \
+            hipLaunchKernelGGL(prodsum_fwd_kernel<NMAX>, dim3(cdiv(B, 64), cdiv(P, 4)), block, 0, st, in,           \
+                               as_const(W), as_const(LW), B, R, N, S, out);                                         \
+    } while (0)
+    if (N <= 4) DPK_LAUNCH_PS(4);
+    else if (N <= 8) DPK_LAUNCH_PS(8);
+    else if (N <= 16) DPK_LAUNCH_PS(16);
+    else DPK_LAUNCH_PS(32);
+#undef DPK_LAUNCH_PS
+    DPK_CHECK_LAUNCH(who);
+    return DPK_OK;
+}
+
+extern "C" int64_t dpk_prodsum_workspace_bytes(int32_t R, int32_t N, int32_t S) {
+    if (R <= 0 || N <= 0 || S <= 0) return DPK_EINVAL;
+    return 2 * align_up((int64_t)(R / 2) * S * N * N * 4, 256) + 256;
+}
+extern "C" int dpk_prodsum_forward(const float *in, const float *weight, int64_t B, int32_t R, int32_t N, int32_t S,
+                                   float *out, void *ws, int64_t ws_bytes, void *stream) {
+    return prod_fused_common(false, in, weight, B, R, N, S, out, ws, ws_bytes, stream, "prodsum_forward");
+}
+extern "C" int dpk_prodroot_forward(const float *in, const float *weight, int64_t B, int32_t R, int32_t N, int32_t C,
+                                    float *out, void *ws, int64_t ws_bytes, void *stream) {
+    return prod_fused_common(true, in, weight, B, R, N, C, out, ws, ws_bytes, stream, "prodroot_forward");
+}

@@ -374,3 +374,45 @@ def ll_accumulate(ll: torch.Tensor, acc: torch.Tensor):
     ll = require_device_f32(ll, 'll')
     assert acc.dtype == torch.float64 and acc.numel() == 2 and acc.is_cuda
     check(lib.dpk_ll_accumulate(ptr(ll), ll.numel(), ptr(acc), stream_ptr(ll.device)), 'dpk_ll_accumulate')
+
+
+def _prodsum_ws(ws: Workspace, R, N, S, device):
+    lib = load_library()
+    n = lib.dpk_prodsum_workspace_bytes(R, N, S)
+    if n < 0:
+        check(int(n), 'dpk_prodsum_workspace_bytes')
+    return ws.get(n, device)
+
+
+def prodsum_forward(x: torch.Tensor, weight: torch.Tensor, ws: Workspace) -> Optional[torch.Tensor]:
+    """ProductLayer + SumLayer in one launch, eval mode, no autograd graph (reference: ratspn.py:272-286, :363-378).
+    x [B,R,N], weight [R/2,S,N*N] -> [B,R/2,S]; None when N is beyond what the kernel is built for."""
+    lib = load_library()
+    x = require_device_f32(x, 'x')
+    w = require_device_f32(weight, 'weight')
+    B, R, N = x.shape
+    S = w.shape[1]
+    out = torch.empty((B, R // 2, S), dtype=torch.float32, device=x.device)
+    buf = _prodsum_ws(ws, R, N, S, x.device)
+    rc = lib.dpk_prodsum_forward(ptr(x), ptr(w), B, R, N, S, ptr(out), ptr(buf), buf.numel(), stream_ptr(x.device))
+    if rc == -4:
+        return None
+    check(rc, 'dpk_prodsum_forward')
+    return out
+
+
+def prodroot_forward(x: torch.Tensor, weight: torch.Tensor, ws: Workspace) -> Optional[torch.Tensor]:
+    """Last ProductLayer + RootLayer in one launch (reference: ratspn.py:272-286, :446-458). x [B,R,N],
+    weight [C,(R/2)*N*N] -> [B,C]."""
+    lib = load_library()
+    x = require_device_f32(x, 'x')
+    w = require_device_f32(weight, 'weight')
+    B, R, N = x.shape
+    C = w.shape[0]
+    out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    buf = _prodsum_ws(ws, R, N, C, x.device)
+    rc = lib.dpk_prodroot_forward(ptr(x), ptr(w), B, R, N, C, ptr(out), ptr(buf), buf.numel(), stream_ptr(x.device))
+    if rc == -4:
+        return None
+    check(rc, 'dpk_prodroot_forward')
+    return out

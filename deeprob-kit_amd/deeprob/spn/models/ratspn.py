@@ -120,6 +120,34 @@ class RatSpn(ProbabilisticModel):
             self.root_layer.weight, self._fused_ctx, ll_acc
         )
 
+    def _forward_folded(self, x: torch.Tensor) -> Optional[torch.Tensor]:
+        """Evaluation outside the single-launch kernel's envelope (e.g. rg_batch = rg_sum = 16): leaf kernel, then
+        every ProductLayer folded into the Sum / Root layer above it (the product tensors are never written)."""
+        if self.training and (self.in_dropout is not None or self.sum_dropout is not None):
+            return None
+        with torch.no_grad():
+            h = self.base_layer(x)
+            layers = list(self.layers)
+            i = 0
+            while i < len(layers):
+                if not isinstance(layers[i], ProductLayer):
+                    return None
+                if i + 1 < len(layers):
+                    nxt = layers[i + 1]
+                    if not isinstance(nxt, SumLayer):
+                        return None
+                    h = ops.prodsum_forward(h, nxt.weight, nxt._ws)
+                    i += 2
+                else:
+                    h = ops.prodroot_forward(h, self.root_layer.weight, self.root_layer._ws)
+                    i += 1
+                    if h is None:
+                        return None
+                    return h
+                if h is None:
+                    return None
+            return None
+
     def fused_plan(self, x: torch.Tensor) -> Optional['ops.FusedForwardPlan']:
         """A pre-bound fused forward for a resident input buffer (see ``ops.FusedForwardPlan``); None when the
         model is outside the fused kernel's envelope."""
@@ -140,6 +168,9 @@ class RatSpn(ProbabilisticModel):
         """
         if not self._needs_graph(x):
             out = self._forward_fused(x)
+            if out is not None:
+                return out
+            out = self._forward_folded(x)
             if out is not None:
                 return out
         x = self.base_layer(x)

@@ -180,6 +180,16 @@ int dpk_normal_base_logprob(const float *u, const float *scale_in, const float *
                             const float *scale, const float *ildj, const float *ildj_const, int64_t B,
                             int32_t D, float *out, void *stream);
 
+/* Eval route for RAT-SPN shapes outside dpk_ratspn_forward's envelope (e.g. I = S = 16): a ProductLayer folded
+ * into the SumLayer / RootLayer above it (ratspn.py:272-286 + :363-378 / :446-458), the [B,P,N^2] product tensor
+ * never reaches HBM.  in [B,R,N]; prodsum: weight [R/2,S,N^2] -> out [B,R/2,S]; prodroot: weight [C,(R/2)*N^2] ->
+ * out [B,C].  N <= 32.  Workspace: dpk_prodsum_workspace_bytes(R,N,S) (S = C for the root).                 */
+int64_t dpk_prodsum_workspace_bytes(int32_t R, int32_t N, int32_t S);
+int dpk_prodsum_forward(const float *in, const float *weight, int64_t B, int32_t R, int32_t N, int32_t S, float *out,
+                        void *ws, int64_t ws_bytes, void *stream);
+int dpk_prodroot_forward(const float *in, const float *weight, int64_t B, int32_t R, int32_t N, int32_t C, float *out,
+                         void *ws, int64_t ws_bytes, void *stream);
+
 /* ---- DGC-SPN spatial layers (NCHW fp32; deeprob/spn/layers/dgcspn.py) ------------------ */
 /* SpatialGaussianLayer.forward (dgcspn.py:101-120):
  * out[b,k,h,w] = sum_c nan_to_num(log N(x[b,c,h,w]; loc[k,c,h,w], scale[k,c,h,w])); NaN x = marginalised. */

@@ -282,3 +282,30 @@ def test_expanded_square_guard(golden, case):
         got = model(x.cuda()).cpu().numpy()
     assert rel_err(got, want) <= LL_TOL
     assert rel_err(got, want64) <= LL_TOL
+
+
+@pytest.mark.parametrize('kw', [dict(rg_depth=2, rg_batch=16, rg_sum=16), dict(rg_depth=1, rg_batch=16, rg_sum=16),
+                                dict(rg_depth=3, rg_batch=16, rg_sum=12, out_classes=7, rg_repetitions=5)])
+def test_folded_route_for_wide_models(kw):
+    """Shapes outside the single-launch kernel (16 channels) evaluate as leaf kernel + products folded into the sum /
+    root layers; same numbers as the per-layer chain and as the oracle, including NaN / -inf evidence."""
+    from deeprob.spn.models import GaussianRatSpn
+    torch.manual_seed(1)
+    base = dict(in_features=100, rg_repetitions=8, random_state=3, optimize_scale=True)
+    base.update(kw)
+    model = GaussianRatSpn(**base).eval()
+    with torch.no_grad():
+        model.root_layer.weight[:, ::5] = -300.0        # vanishing root weights: exercises the exact fallback
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    x = torch.randn(130, 100, generator=torch.Generator().manual_seed(2)) * 2.0
+    x[3] = float('nan')
+    x[5, :40] = float('nan')
+    x[7, 11] = float('inf')
+    want = orc.ratspn_forward(sd, x).numpy()
+    model = model.cuda()
+    with torch.no_grad():
+        assert model._forward_fused(x.cuda()) is None      # really outside the fused envelope
+        folded = model(x.cuda())
+    chained = model(x.cuda()).detach()                     # graph needed -> per-layer operators
+    assert rel_err(folded.cpu().numpy(), want) <= LL_TOL
+    assert rel_err(folded.cpu().numpy(), chained.cpu().numpy()) <= LL_TOL
