@@ -309,3 +309,39 @@ def test_folded_route_for_wide_models(kw):
     chained = model(x.cuda()).detach()                     # graph needed -> per-layer operators
     assert rel_err(folded.cpu().numpy(), want) <= LL_TOL
     assert rel_err(folded.cpu().numpy(), chained.cpu().numpy()) <= LL_TOL
+
+
+def test_gradients_with_marginalised_inputs(golden):
+    """with NaN evidence and autograd on, the reference's Normal.log_prob backward computes 0 * NaN
+    and returns NaN in loc.grad / scale.grad / x.grad wherever a NaN input was touched (the oracle, which replays
+    the same ATen ops, shows it).  The HIP path returns the mathematically masked gradient: marginalised entries
+    contribute nothing.  This test documents the divergence and pins the masked gradient."""
+    name = 'ratspn_g15_d2_r3_i3_s5_pad'
+    model, g = build(name, golden)
+    model.train()
+    x = torch.from_numpy(g['x']).clone()
+    nan_mask = torch.rand(x.shape, generator=torch.Generator().manual_seed(9)) < 0.3
+    x[nan_mask] = float('nan')
+    xg = x.cuda().requires_grad_(True)
+    model.loss(model(xg)).backward()
+    assert torch.isfinite(model.base_layer.loc.grad).all() and torch.isfinite(xg.grad).all()
+    assert torch.equal(xg.grad.cpu()[nan_mask], torch.zeros(int(nan_mask.sum())))
+
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    # (1) the reference's behaviour, via the oracle: NaN gradients
+    leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
+    xo = x.clone().requires_grad_(True)
+    orc.ratspn_loss(orc.ratspn_forward({**sd, **leaves}, xo)).backward()
+    assert torch.isnan(leaves['base_layer.loc'].grad).any() and torch.isnan(xo.grad[nan_mask]).all()
+    # (2) the masked gradient: same forward value, marginalised terms cut out of the graph
+    for v in leaves.values():
+        v.grad = None
+    mask, d = sd['base_layer.mask'], sd['base_layer.mask'].shape[1]
+    drop = nan_mask[:, mask].unsqueeze(2).expand(-1, -1, sd['base_layer.loc'].shape[1], -1)     # [B,R,I,d]
+    xf = torch.where(nan_mask, torch.zeros_like(x), x).requires_grad_(True)
+    out = orc.ratspn_forward({**sd, **leaves}, xf, drops={'leaf': drop})
+    orc.ratspn_loss(out).backward()
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            assert grad_err(p.grad.cpu().numpy(), leaves[k].grad.numpy()) <= GRAD_TOL, k
+    assert grad_err(xg.grad.cpu().numpy(), xf.grad.numpy()) <= GRAD_TOL
