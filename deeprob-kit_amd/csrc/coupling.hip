@@ -175,8 +175,12 @@ __global__ __launch_bounds__(kCWaves * 64) void coupling1d_kernel(const Coupling
     const int U = a.U, D = a.D;
     const int HS = U + 1;                      // row stride of H
     float *hs = lds;                           // [kCM][U+1]
-    float *xs = hs + kCM * HS;                 // [kCM][kCKC+1]
-    float *ldj_lds = xs + kCM * (kCKC + 1);    // [kCWaves][kCM] per-wave partial sums (fixed order)
+    // x chunk [kCM][kCKC+1], phase 1 only.  With a single pass over the hidden tiles (64 <= U <= 32 * waves) H is
+    // only written after the last chunk has been consumed, so the chunk buffer aliases H (34 KB of LDS per
+    // work-group at U = 128: four work-groups per CU); otherwise it lives behind H.
+    const bool alias_xs = (U >= 64 && U <= 32 * kCWaves);
+    float *ldj_lds = hs + kCM * HS;            // [kCWaves][kCM] per-wave partial sums (fixed order)
+    float *xs = alias_xs ? lds : ldj_lds + kCWaves * kCM;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t b0 = (int64_t)blockIdx.x * kCM;
@@ -258,6 +262,7 @@ __global__ __launch_bounds__(kCWaves * 64) void coupling1d_kernel(const Coupling
                 }
             }
         }
+        __syncthreads();   // every wave is done reading the last x chunk: H may overwrite it
         if (nt_ok) {
             const int col = nt * 32 + (lane & 31);
             const float bias = a.b1[col];
@@ -271,33 +276,34 @@ __global__ __launch_bounds__(kCWaves * 64) void coupling1d_kernel(const Coupling
     }
     __syncthreads();
 
-    // ---- phase 2: z = H W2^T + b2 on the transformed variables, fused epilogue
+    // ---- phase 2: z = H W2^T + b2 on the transformed variables, fused epilogue.  Work item = (32-variable tile,
+    // 32-row half): two 32x32 accumulators (t, s) per wave keep the kernel near 100 VGPRs (4 work-groups per CU),
+    // and 2 * n_pairs items spread evenly over the 4 waves.
     const float act = AFFINE ? a.act_weight[0] : 0.f;
     float ssum0[16], ssum1[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) ssum0[r] = ssum1[r] = 0.f;
-    const int n_pairs = a.N2p / 32;
-    for (int pt = wave; pt < n_pairs; pt += kCWaves) {
-        f32x16 t0 = {0}, t1 = {0}, s0 = {0}, s1 = {0};
+    const int n_items = 2 * (a.N2p / 32);
+    for (int it = wave; it < n_items; it += kCWaves) {
+        const int pt = it >> 1, half = it & 1;   // wave-uniform
+        f32x16 t0 = {0}, s0 = {0};
         // the x values this lane transforms are requested BEFORE the MFMA loop: one exposed memory latency per
-        // 32-variable tile instead of one per accumulator register in the epilogue
+        // item instead of one per accumulator register in the epilogue
         const int var_p = a.nidx[pt * 32 + (lane & 31)];
-        float xpre[2][16];
+        float xpre[16];
         {
             const float *xb = a.x + b0 * D;
             const int lane_off = 4 * (lane >> 5) * D + max(var_p, 0);
 #pragma unroll
-            for (int half = 0; half < 2; ++half)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row0 = half * 32 + (r & 3) + 8 * (r >> 2);
-                    const int rowc = min(row0 + 4 * (lane >> 5), rows - 1) - 4 * (lane >> 5);  // clamp ragged tiles
-                    xpre[half][r] = (DPK_CPL_ABLATE == 5 || !DPK_CPL_XPRE) ? 0.f : xb[lane_off + rowc * D];
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int row0 = half * 32 + (r & 3) + 8 * (r >> 2);
+                const int rowc = min(row0 + 4 * (lane >> 5), rows - 1) - 4 * (lane >> 5);  // clamp ragged tiles
+                xpre[r] = (DPK_CPL_ABLATE == 5 || !DPK_CPL_XPRE) ? 0.f : xb[lane_off + rowc * D];
+            }
         }
         const f32x4 *btp = reinterpret_cast<const f32x4 *>(a.w2tp) + (int64_t)pt * (U / 8) * 64 + lane;
         const f32x4 *bsp = reinterpret_cast<const f32x4 *>(a.w2sp) + (int64_t)pt * (U / 8) * 64 + lane;
-        const float *ap = hs + (lane & 31) * HS + (lane >> 5);
+        const float *ap = hs + (half * 32 + (lane & 31)) * HS + (lane >> 5);
         const int nk4 = (DPK_CPL_ABLATE == 4) ? 0 : U / 8;   // a multiple of 4 (U % 32 == 0)
         f32x4 btq[kPF], bsq[kPF];
 #pragma unroll
@@ -316,14 +322,9 @@ __global__ __launch_bounds__(kCWaves * 64) void coupling1d_kernel(const Coupling
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int k = 2 * (4 * ks4 + q);
-                    const float a0 = ap[k], a1 = ap[32 * HS + k];
+                    const float a0 = ap[2 * (4 * ks4 + q)];
                     t0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bt[q], t0, 0, 0, 0);
-                    t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bt[q], t1, 0, 0, 0);
-                    if (AFFINE) {
-                        s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bs[q], s0, 0, 0, 0);
-                        s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bs[q], s1, 0, 0, 0);
-                    }
+                    if (AFFINE) s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bs[q], s0, 0, 0, 0);
                 }
             }
         }
@@ -340,24 +341,21 @@ __global__ __launch_bounds__(kCWaves * 64) void coupling1d_kernel(const Coupling
             float *ob = a.out + b0 * D;
             const int lane_off = 4 * (lane >> 5) * D + var;
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row0 = half * 32 + (r & 3) + 8 * (r >> 2);   // + 4 * (lane >> 5) = mfma_row
-                    const int off = lane_off + row0 * D;
-                    if (row0 + 4 * (lane >> 5) < rows) {
-                        const float tv = (half ? t1[r] : t0[r]) + bt;
-                        const float xv = fmaf(DPK_CPL_XPRE ? xpre[half][r] : a.x[b0 * D + off], sc, sh);
-                        float o;
-                        if (AFFINE) {
-                            const float sv = act * fast_tanh((half ? s1[r] : s0[r]) + bs);
-                            o = a.inverse ? fmaf(xv, __expf(sv), tv) : (xv - tv) * __expf(-sv);
-                            if (half) ssum1[r] += sv; else ssum0[r] += sv;
-                        } else {
-                            o = a.inverse ? xv + tv : xv - tv;
-                        }
-                        ob[off] = o;
+            for (int r = 0; r < 16; ++r) {
+                const int row0 = half * 32 + (r & 3) + 8 * (r >> 2);   // + 4 * (lane >> 5) = mfma_row
+                const int off = lane_off + row0 * D;
+                if (row0 + 4 * (lane >> 5) < rows) {
+                    const float tv = t0[r] + bt;
+                    const float xv = fmaf(DPK_CPL_XPRE ? xpre[r] : a.x[b0 * D + off], sc, sh);
+                    float o;
+                    if (AFFINE) {
+                        const float sv = act * fast_tanh(s0[r] + bs);
+                        o = a.inverse ? fmaf(xv, __expf(sv), tv) : (xv - tv) * __expf(-sv);
+                        if (half) ssum1[r] += sv; else ssum0[r] += sv;
+                    } else {
+                        o = a.inverse ? xv + tv : xv - tv;
                     }
+                    ob[off] = o;
                 }
             }
         }
@@ -499,7 +497,9 @@ extern "C" int dpk_coupling1d_forward(const float *x, int64_t B, int32_t D, cons
     a.kidx = w.kidx; a.nidx = w.nidx; a.w1p = w.w1p; a.b1 = b1; a.w2tp = w.w2tp; a.w2sp = w.w2sp;
     a.b2tp = w.b2tp; a.b2sp = w.b2sp; a.in_scale = in_scale; a.in_shift = in_shift; a.act_weight = act_weight;
     a.inverse = inverse; a.accumulate = accumulate_ldj;
-    const size_t lds = ((size_t)kCM * (units + 1) + (size_t)kCM * (kCKC + 1) + kCWaves * kCM) * sizeof(float);
+    const size_t hs_floats = (size_t)kCM * (units + 1), xs_floats = (size_t)kCM * (kCKC + 1);
+    const bool alias_xs = units >= 64 && units <= 32 * kCWaves;   // as in the kernel
+    const size_t lds = (hs_floats + kCWaves * kCM + (alias_xs ? 0 : xs_floats)) * sizeof(float);
     const int grid = cdiv(B, kCM);
     if (affine) {
         if (lds > 64 * 1024)
