@@ -1,4 +1,5 @@
-"""Train / test loops behind the reference interface (deeprob/torch/routines.py:21-210, :349-426), generative setting.
+"""Train / test loops behind the reference interface (deeprob/torch/routines.py:21-478), generative and
+discriminative settings.
 
 Differences that matter on an MI355X node:
 * the running loss stays on the device: no ``loss.item()`` host synchronisation per batch (reference :166);
@@ -59,9 +60,8 @@ def train_model(
 ) -> Dict[str, list]:
     """Reference signature (:21-37).  ``batch_size`` is the GLOBAL batch: with N ranks each one sees batch_size/N
     samples per step.  :raises ValueError: for an unknown setting or non-positive epochs."""
-    if setting != 'generative':
-        raise ValueError("Unknown train setting called {}".format(setting) if setting != 'discriminative' else
-                         "The discriminative routines are outside the HIP density-evaluation path")
+    if setting not in ('generative', 'discriminative'):
+        raise ValueError("Unknown train setting called {}".format(setting))
     if device is None:
         device = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else None
     if device is None or device.type != 'cuda':
@@ -72,7 +72,8 @@ def train_model(
     opt = get_optimizer_class(optimizer)(filter(lambda p: p.requires_grad, model.parameters()), lr=lr,
                                          **(optimizer_kwargs or {}))
     early_stopping = EarlyStopping(model, patience=patience, filepath=checkpoint)
-    return train_generative(model, train_loader, valid_loader, opt, device, early_stopping, epochs, train_base, verbose)
+    fit = train_generative if setting == 'generative' else train_discriminative
+    return fit(model, train_loader, valid_loader, opt, device, early_stopping, epochs, train_base, verbose)
 
 
 def train_generative(
@@ -87,22 +88,55 @@ def train_generative(
     verbose: bool = True
 ) -> Dict[str, list]:
     """Reference :98-210.  Returns ``{'train': [...], 'valid': [...]}`` (average loss per epoch)."""
+    hist = _fit(model, train_loader, valid_loader, optimizer, device, early_stopping, epochs, train_base, verbose,
+                supervised=False)
+    return {'train': hist['train']['loss'], 'valid': hist['valid']['loss']}
+
+
+def train_discriminative(
+    model: ProbabilisticModel,
+    train_loader: data.DataLoader,
+    valid_loader: data.DataLoader,
+    optimizer: optim.Optimizer,
+    device: torch.device,
+    early_stopping: EarlyStopping,
+    epochs: int = 1000,
+    train_base: bool = True,
+    verbose: bool = True
+) -> Dict[str, Dict[str, list]]:
+    """Reference :213-346: loaders yield ``(inputs, targets)``; returns ``{'train': {'loss', 'accuracy'}, 'valid':
+    {...}}`` per epoch."""
+    return _fit(model, train_loader, valid_loader, optimizer, device, early_stopping, epochs, train_base, verbose,
+                supervised=True)
+
+
+def _batch(item, device, rank, world, supervised):
+    """This rank's shard of a loader item, moved to the device."""
+    if supervised:
+        inputs, targets = item
+        return (shard_batch(inputs.to(device, non_blocking=True), rank, world),
+                shard_batch(targets.to(device, non_blocking=True), rank, world))
+    return shard_batch(item.to(device, non_blocking=True), rank, world), None
+
+
+def _fit(model, train_loader, valid_loader, optimizer, device, early_stopping, epochs, train_base, verbose, supervised):
     if epochs <= 0:
         raise ValueError("The number of epochs must be positve")
     rank, world = _world()
-    history = {'train': [], 'valid': []}
-    run_train, run_valid = RunningAverageMetric(), RunningAverageMetric()
+    history = {'train': {'loss': [], 'accuracy': []}, 'valid': {'loss': [], 'accuracy': []}}
+    meters = {k: RunningAverageMetric() for k in ('train_loss', 'train_hits', 'valid_loss', 'valid_hits')}
     for epoch in range(1, epochs + 1):
-        run_train.reset()
-        run_valid.reset()
+        for m in meters.values():
+            m.reset()
         t0 = time.perf_counter()
         _train_mode(model, train_base)
-        for inputs in train_loader:
-            inputs = shard_batch(inputs.to(device, non_blocking=True), rank, world)
+        for item in train_loader:
+            inputs, targets = _batch(item, device, rank, world, supervised)
             n_local = inputs.shape[0]
             optimizer.zero_grad()
             if n_local > 0:
-                loss = model.loss(model(inputs))
+                outputs = model(inputs)
+                loss = model.loss(outputs, y=targets) if supervised else model.loss(outputs)
                 loss.backward()
             if world > 1:
                 # every rank joins the collective, also one whose shard of a short last batch is empty
@@ -110,22 +144,39 @@ def train_generative(
             optimizer.step()
             model.apply_constraints()
             if n_local > 0:
-                run_train(loss, num_samples=n_local)              # stays on the device
+                meters['train_loss'](loss, num_samples=n_local)           # stays on the device
+                if supervised:
+                    with torch.no_grad():
+                        hits = torch.eq(torch.argmax(outputs, dim=1), targets).float().mean()
+                    meters['train_hits'](hits, num_samples=n_local)
         model.eval()
         with torch.no_grad():
-            for inputs in valid_loader:
-                inputs = shard_batch(inputs.to(device, non_blocking=True), rank, world)
+            for item in valid_loader:
+                inputs, targets = _batch(item, device, rank, world, supervised)
                 if inputs.shape[0] == 0:
                     continue
-                run_valid(model.loss(model(inputs)), num_samples=inputs.shape[0])
-        train_loss, valid_loss = _epoch_averages((run_train, run_valid), device, world)
+                outputs = model(inputs)
+                meters['valid_loss'](model.loss(outputs, y=targets) if supervised else model.loss(outputs),
+                                     num_samples=inputs.shape[0])
+                if supervised:
+                    hits = torch.eq(torch.argmax(outputs, dim=1), targets).float().mean()
+                    meters['valid_hits'](hits, num_samples=inputs.shape[0])
+        names = ('train_loss', 'valid_loss') + (('train_hits', 'valid_hits') if supervised else ())
+        avg = dict(zip(names, _epoch_averages([meters[k] for k in names], device, world)))
         elapsed = int(time.perf_counter() - t0)
         if verbose and rank == 0:
-            print("Epoch {}/{} - train_loss: {:.4f}, valid_loss: {:.4f} [{}s]".format(
-                epoch, epochs, train_loss, valid_loss, elapsed if elapsed > 0 else '<1'))
-        history['train'].append(train_loss)
-        history['valid'].append(valid_loss)
-        early_stopping(valid_loss, epoch, save=(rank == 0))
+            line = "Epoch {}/{} - train_loss: {:.4f}, valid_loss: {:.4f}".format(epoch, epochs, avg['train_loss'],
+                                                                                avg['valid_loss'])
+            if supervised:
+                line += ", train_acc: {:.1f}%, valid_acc: {:.1f}%".format(avg['train_hits'] * 100,
+                                                                         avg['valid_hits'] * 100)
+            print(line + " [{}s]".format(elapsed if elapsed > 0 else '<1'))
+        history['train']['loss'].append(avg['train_loss'])
+        history['valid']['loss'].append(avg['valid_loss'])
+        if supervised:
+            history['train']['accuracy'].append(avg['train_hits'])
+            history['valid']['accuracy'].append(avg['valid_hits'])
+        early_stopping(avg['valid_loss'], epoch, save=(rank == 0))
         if early_stopping.should_stop:
             if verbose and rank == 0:
                 print("Early Stopping... {}".format(early_stopping))
@@ -159,7 +210,7 @@ def test_model(
     verbose: bool = True
 ) -> Tuple[float, float]:
     """Reference :349-388 (generative): mean log-likelihood and two standard errors."""
-    if setting != 'generative':
+    if setting not in ('generative', 'discriminative'):
         raise ValueError("Unknown test setting called {}".format(setting))
     if device is None:
         device = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else None
@@ -167,6 +218,8 @@ def test_model(
         raise ValueError("deeprob on MI355X evaluates on a HIP device (there is no CPU path)")
     loader = data.DataLoader(data_test, batch_size, shuffle=False, drop_last=False, num_workers=num_workers)
     model.to(device)
+    if setting == 'discriminative':
+        return test_discriminative(model, loader, device, verbose)
     return test_generative(model, loader, device, verbose)
 
 
@@ -191,3 +244,34 @@ def test_generative(model: ProbabilisticModel, test_loader: data.DataLoader, dev
     mean = s / n
     var = max(q / n - mean * mean, 0.0)
     return mean, 2.0 * float(np.sqrt(var)) / float(np.sqrt(n))
+
+
+def test_discriminative(model: ProbabilisticModel, test_loader: data.DataLoader, device: torch.device,
+                        verbose: bool = True) -> Tuple[float, dict]:
+    """Reference :429-478: ``(negative log-likelihood, sklearn classification report dict)``.  Predictions and
+    targets are gathered on the host once, after the loop (and across the ranks when sharded)."""
+    from sklearn import metrics as skm
+    rank, world = _world()
+    model.eval()
+    run = RunningAverageMetric()
+    preds, trues = [], []
+    with torch.no_grad():
+        for item in test_loader:
+            inputs, targets = _batch(item, device, rank, world, True)
+            if inputs.shape[0] == 0:
+                continue
+            outputs = model(inputs)
+            run(model.loss(outputs, y=targets), num_samples=inputs.shape[0])
+            preds.append(torch.argmax(outputs, dim=1))
+            trues.append(targets)
+    nll, = _epoch_averages([run], device, world)
+    y_pred = torch.cat(preds).cpu() if preds else torch.empty(0, dtype=torch.long)
+    y_true = torch.cat(trues).cpu() if trues else torch.empty(0, dtype=torch.long)
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (y_true.tolist(), y_pred.tolist()))
+        y_true = [v for t, _ in gathered for v in t]
+        y_pred = [v for _, q in gathered for v in q]
+    else:
+        y_true, y_pred = y_true.tolist(), y_pred.tolist()
+    return nll, skm.classification_report(y_true, y_pred, output_dict=True, zero_division=0)

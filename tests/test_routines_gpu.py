@@ -45,3 +45,23 @@ def test_train_flow_with_batch_norm(tmp_path):
                        checkpoint=str(tmp_path / 'ck.pt'), verbose=False)
     after = test_model(flow, data[:128], verbose=False)[0]
     assert after > before + 1.0 and hist['train'][-1] < hist['train'][0]
+
+
+def test_discriminative_setting(tmp_path):
+    """train_model / test_model with setting='discriminative' (reference :213-346, :429-478) on a 3-class RAT-SPN."""
+    from deeprob.spn.models import GaussianRatSpn
+    from deeprob.torch.routines import train_model, test_model
+    torch.manual_seed(0)
+    gen = torch.Generator().manual_seed(3)
+    centres = 2.0 * torch.randn(3, 12, generator=gen)
+    y = torch.randint(0, 3, (900,), generator=gen)
+    x = centres[y] + 0.7 * torch.randn(900, 12, generator=gen)
+    ds = torch.utils.data.TensorDataset(x, y)
+    tr, va = torch.utils.data.random_split(ds, [700, 200], generator=gen)
+    model = GaussianRatSpn(12, out_classes=3, rg_depth=1, rg_repetitions=4, rg_batch=4, rg_sum=4, random_state=1)
+    hist = train_model(model, tr, va, setting='discriminative', lr=5e-2, batch_size=100, epochs=6, patience=6,
+                       checkpoint=str(tmp_path / 'ck.pt'), verbose=False)
+    assert set(hist['train']) == {'loss', 'accuracy'} and len(hist['valid']['accuracy']) == len(hist['train']['loss'])
+    assert hist['valid']['accuracy'][-1] > 0.8 and hist['train']['loss'][-1] < hist['train']['loss'][0]
+    nll, report = test_model(model, va, setting='discriminative', verbose=False)
+    assert nll < 0.8 and report['accuracy'] > 0.8 and set(report) >= {'0', '1', '2', 'accuracy', 'macro avg'}
