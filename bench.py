@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--ring', type=int, default=0, help='distinct resident batches (0: > 256 MiB worth)')
     ap.add_argument('--cpu-samples', type=int, default=262144, help='cpu_baseline sample size (0 = skip)')
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--prewarm', type=int, default=384, help='untimed steps before the warm-up (runtime pool growth)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only to "
                     "rehearse the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument('--share-device', action='store_true', help='rehearsal: every rank uses cuda:0')
@@ -135,7 +136,8 @@ def main():
     # records around the fused kernel on the stream it is launched on
     hiprt = ctypes.CDLL('libamdhip64.so')
     handles = []
-    for _ in range(args.steps + 4 if time_kernel else 0):
+    n_spare = 64   # event pairs for the untimed steps
+    for _ in range(args.steps + n_spare if time_kernel else 0):
         pair = []
         for _k in range(2):
             h = ctypes.c_void_p()
@@ -161,6 +163,16 @@ def main():
         return evaluator.step(xs[i % ring], kernel_events=marks)
 
     with torch.no_grad():
+        # Runtime pre-warm, before the W warm-up steps of the contract: the HIP runtime grows its per-queue pools
+        # (kernel arguments / signals) after a few hundred launches and that one-off growth stalls the host for
+        # ~40 ms (measured: one step of ~38 ms around the 180th step of a process, tools/host_overhead3.py); it
+        # must not land in the timed window, whatever W is.
+        for j in range(args.prewarm):
+            marks = handles[args.steps + j % n_spare] if time_kernel else None
+            evaluator.step(xs[j % ring], kernel_events=marks)
+            if (j + 1) % 64 == 0:
+                evaluator.drain()
+        evaluator.drain()
         for i in range(args.warmup):
             step(i)
         if time_kernel:

@@ -676,10 +676,18 @@ template <int CB, int SPL, bool GENERAL> struct LdsPipe {
         for (int u = 0; u < kBlock; ++u) {
             const f32x2 xv = {x[CUR][u][0], x[CUR][u][SPL - 1]};
             Q = __builtin_elementwise_fma(xv, xv, Q);
+            if constexpr (CB == 2) {
+                // the two channel means of an entry sit in one aligned register pair: broadcast its low / high
+                // half to both samples with op_sel (the compiler otherwise copies the high half into a fresh pair)
+                const f32x2 mp = {mu[CUR][2 * u], mu[CUR][2 * u + 1]};
+                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(P[0]) : "v"(xv), "v"(mp));
+                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(P[1]) : "v"(xv), "v"(mp));
+            } else {
 #pragma unroll
-            for (int k = 0; k < CB; ++k) {
-                const float m = mu[CUR][u * CB + k];
-                P[k] = __builtin_elementwise_fma(xv, (f32x2){m, m}, P[k]);
+                for (int k = 0; k < CB; ++k) {
+                    const float m = mu[CUR][u * CB + k];
+                    P[k] = __builtin_elementwise_fma(xv, (f32x2){m, m}, P[k]);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
