@@ -160,7 +160,13 @@ __device__ __forceinline__ void leaf_entry_params(int dist, const float *p0, con
 
 template <int DIST>
 __global__ __launch_bounds__(256) void ratspn_prep_kernel(const PrepArgs a) {
-    const int n_leaf_blocks = a.G * kPrepSlices;
+    // block roles (all independent, so their dependent-load chains overlap instead of adding up):
+    //   [0, nT)            leaf tables, slice sl of group g
+    //   [nT, 2 nT)         per-(region, chunk) constants, slice sl of group g
+    //   [2 nT, 2 nT + G)   unit-scale / bounded-mean flags of group g
+    //   rest               softmax rows
+    const int nT = a.G * kPrepSlices;
+    const int n_leaf_blocks = 2 * nT + a.G;
     if ((int)blockIdx.x >= n_leaf_blocks) {
         // ---- softmax rows: one wave per row (reference: torch.log_softmax at ratspn.py:375 and :455)
         int row = (blockIdx.x - n_leaf_blocks) * 4 + (threadIdx.x >> 6);
@@ -190,12 +196,14 @@ __global__ __launch_bounds__(256) void ratspn_prep_kernel(const PrepArgs a) {
     }
     // ---- leaf tables: [group][channel block][stream position]{p0[CB], p1[CB]}; the kBlock entries of
     // a block are one contiguous run for the wave that owns (group, channel block)
-    const int g = blockIdx.x / kPrepSlices, sl = blockIdx.x - g * kPrepSlices;
+    const int role = (int)blockIdx.x < nT ? 0 : ((int)blockIdx.x < 2 * nT ? 1 : 2);
+    const int bid = (int)blockIdx.x - role * nT;
+    const int g = role == 2 ? bid : bid / kPrepSlices, sl = role == 2 ? 0 : bid - g * kPrepSlices;
     const int I = a.I, CB = a.CB, d = a.d, SP = a.SP, QB = a.QB, NC = a.NC;
     const int ncb = I / CB;
     const int per = ((SP / kBlock + kPrepSlices - 1) / kPrepSlices) * kBlock;  // positions per slice
     const int p_lo = sl * per, p_hi = min(SP, p_lo + per);
-    for (int e = threadIdx.x; e < (p_hi - p_lo) * I; e += blockDim.x) {
+    for (int e = threadIdx.x; role == 0 && e < (p_hi - p_lo) * I; e += blockDim.x) {
         const int pidx = p_lo + e / I, k = e % I;
         const int rj = a.srcr[(int64_t)g * SP + pidx];
         float A = 0.f, Bv = 0.f, Cc = 0.f;
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(256) void ratspn_prep_kernel(const PrepArgs a) {
     // per-(region, chunk) constants: segments are dealt round-robin to the slices, one wave per
     // (segment, channel), lanes over the entries, summed from the parameters directly (no dependence
     // on what the other slices write)
-    {
+    if (role == 1) {
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         for (int e = wv; e < NC * QB * I; e += 4) {
             const int k = e % I, cq = e / I;
@@ -249,8 +257,8 @@ __global__ __launch_bounds__(256) void ratspn_prep_kernel(const PrepArgs a) {
             }
         }
     }
-    // unit-scale flag per region (slice 0 scans the group's scales)
-    if (sl == 0) {
+    // unit-scale flag per region (one block scans the group's scales and means)
+    if (role == 2) {
         __shared__ int not_unit[8], big_mean[8];
         if (threadIdx.x < 8) {
             not_unit[threadIdx.x] = (DIST != 0);
@@ -1221,7 +1229,7 @@ static int prepare_leaf_tables(int dist, const RatWs &w, const int64_t *mask, co
             rows += jobs[m].rows;
         }
     }
-    const int grid = w.G * kPrepSlices + cdiv(rows, 4);
+    const int grid = 2 * w.G * kPrepSlices + w.G + cdiv(rows, 4);   // block roles: see ratspn_prep_kernel
     if (dist == 0) hipLaunchKernelGGL(ratspn_prep_kernel<0>, dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(ratspn_prep_kernel<1>, dim3(grid), dim3(256), 0, st, a);
     DPK_CHECK_LAUNCH("ratspn_prep_kernel");
