@@ -16,6 +16,11 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a MI355X (HIP device); run with -m gpu on the GPU box')
+    # the C-ABI library is a build artefact (git-ignored): build it once if this checkout has none yet
+    lib = os.path.join(PKG, 'lib', 'libdeeprob_hip.so')
+    if not os.path.isfile(lib):
+        import subprocess
+        subprocess.run(['make', '-C', os.path.join(PKG, 'csrc'), '-j', str(min(8, os.cpu_count() or 1))], check=True)
 
 
 def pytest_collection_modifyitems(config, items):
