@@ -672,7 +672,8 @@ template <int CB, int SPL, bool GENERAL> struct LdsPipe {
     // packed FMA per entry, shared by the channels) and P[k] = sum x mu_k (one packed FMA per entry and
     // channel, the mean broadcast to both samples by op_sel): 4 + 4*CB v_pk_fma_f32 per block instead of
     // 16*CB VOP2.  Only taken when |x| and |mu| are bounded by kExpandBound (cancellation).
-    template <int CUR> __device__ __forceinline__ void step3(f32x2 (&P)[CB], f32x2 &Q, const char *lane_base) {
+    template <int CUR, bool WITHQ>
+    __device__ __forceinline__ void step3(f32x2 (&P)[CB], f32x2 &Q, const char *lane_base) {
         constexpr int OTH = 1 - CUR;
         leaf_read_x<SPL>(x[OTH], lane_base, offn);
         offc = offn;
@@ -683,7 +684,7 @@ template <int CB, int SPL, bool GENERAL> struct LdsPipe {
 #pragma unroll
         for (int u = 0; u < kBlock; ++u) {
             const f32x2 xv = {x[CUR][u][0], x[CUR][u][SPL - 1]};
-            Q = __builtin_elementwise_fma(xv, xv, Q);
+            if (WITHQ) Q = __builtin_elementwise_fma(xv, xv, Q);
             if constexpr (CB == 2) {
                 // the two channel means of an entry sit in one aligned register pair: broadcast its low / high
                 // half to both samples with op_sel (the compiler otherwise copies the high half into a fresh pair)
@@ -700,13 +701,14 @@ template <int CB, int SPL, bool GENERAL> struct LdsPipe {
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    template <bool WITHQ>
     __device__ __forceinline__ void run3(f32x2 (&P)[CB], f32x2 &Q, const char *lane_base, int nb) {
         for (int i = nb >> 1; i > 0; --i) {
-            step3<0>(P, Q, lane_base);
-            step3<1>(P, Q, lane_base);
+            step3<0, WITHQ>(P, Q, lane_base);
+            step3<1, WITHQ>(P, Q, lane_base);
         }
         if (nb & 1) {
-            step3<0>(P, Q, lane_base);
+            step3<0, WITHQ>(P, Q, lane_base);
             mu[0] = mu[1];
 #pragma unroll
             for (int u = 0; u < kBlock; ++u)
@@ -756,6 +758,7 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
     int *flags_lds = reinterpret_cast<int *>(smem + G::BUF_BYTES);  // [waves]
     float *run_m = reinterpret_cast<float *>(smem + G::BUF_BYTES + 64 + kLeafWaves * 2 * a.tabcap);  // [C][T] fused only
     float *run_s = run_m + (DEPTH > 0 ? a.C * T : 0);
+    float *qlds = run_s + (DEPTH > 0 ? a.C * T : 0);   // [waves][T] partial sums of x^2 (fused model, see qfree)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -786,7 +789,8 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
 
     // Expanded unit-scale form (LdsPipe::step3): only when every region's means are bounded, and then every
     // staged |x| above the bound sends its tile to the exact path like a non-finite value does.
-    bool expand_all = (DIST == 0) && !GEN && (CB <= 2) && (SPL == 2) && a.tabcap > 0 && (DPK_NO_EXPAND == 0);
+    bool expand_all = (DIST == 0) && !GEN && (CB <= 2) && (SPL == 2) && a.tabcap > 0 && (DPK_NO_EXPAND == 0) &&
+                      (DEPTH == 0 || a.leaf_out == nullptr);
     if (expand_all) {
         // lanes read the flags in parallel (a serial scalar loop costs ~150 ns per region)
         bool ok = true;
@@ -796,6 +800,15 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
     // a staged value v is "bad" iff bits(v*v) > thr_bits: NaN, +-inf, |v| > bound (or so large that
     // (v - mu)^2 could overflow when the direct form is used)
     const unsigned thr_bits = __float_as_uint(expand_all ? kExpandBound * kExpandBound : 1.0e37f);
+    // Fused model, expanded form: the -1/2 sum_f x_f^2 of a region is common to all its channels, so it factors
+    // out of every sum node above it; every repetition covers each variable once, so what reaches the root is
+    // -1/2 sum over ALL variables of x^2 -- one scalar per sample, the same for every repetition.  The waves
+    // therefore accumulate only P = sum x mu (8 instead of 12 packed FMAs per block) and share out the x^2 sums
+    // (8 rows of each chunk per wave); the scalar is added to the root output.  Chunks that take the exact path
+    // carry their complete terms and are left out of the scalar.  A fused call that also wants the leaf outputs
+    // does not take the expanded form at all.
+    const bool qfree = expand_all && (DEPTH > 0);   // expand_all excludes leaf_out for the fused model (below)
+    f32x2 qpart = {0.f, 0.f};
 
     // leaf-only launches spread the passes over blockIdx.y (small training batches would otherwise occupy
     // B/T compute units); the fused model keeps them in the work-group (the root exchange spans them)
@@ -896,6 +909,7 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
                         (__attribute__((address_space(3))) void *)(dst + i * 1024), 16, 0, 0);
             }
         };
+        bool qgo = qfree && pass == 0 && SPL == 2;
         load_tab(0);
         load_chunk(0);
 
@@ -934,6 +948,21 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
             if (c + 1 < NC) {
                 load_tab(c + 1);
                 load_chunk(c + 1);
+            }
+
+            if (slow) qgo = false;
+            if (qgo) {
+                // this wave's share of sum_f x_f^2 for the chunk: rows 8*wave .. 8*wave+7 (see qfree)
+                const char *qb = lane_base + wave * (kChunk / kLeafWaves) * G::ROWB;
+                const int nvalid = min(kChunk, D - c * kChunk) - wave * (kChunk / kLeafWaves);
+#pragma unroll
+                for (int j = 0; j < kChunk / kLeafWaves; ++j) {
+                    if (j < nvalid) {
+                        const float2 v = *reinterpret_cast<const float2 *>(qb + j * G::ROWB);
+                        const f32x2 xv = {v.x, v.y};
+                        qpart = __builtin_elementwise_fma(xv, xv, qpart);
+                    }
+                }
             }
 
             if (active) {
@@ -1014,8 +1043,8 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
                                     f32x2 P[CB], Q = {0.f, 0.f};
 #pragma unroll
                                     for (int k = 0; k < CB; ++k) P[k] = (f32x2){acc[q][k][0], acc[q][k][1]};
-                                    pipe.run3(P, Q, lane_base, nb);
-                                    // log-density sum = P - Q/2 + (constants - sum mu^2 / 2)
+                                    pipe.template run3<(DEPTH == 0)>(P, Q, lane_base, nb);   // fused model: qfree
+                                    // log-density sum = P - Q/2 + (constants - sum mu^2 / 2); Q == 0 when factored out
 #pragma unroll
                                     for (int k = 0; k < CB; ++k) {
                                         const float bk = bp[k];
@@ -1157,13 +1186,25 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
     }
 
     if constexpr (DEPTH > 0) {
+        float qterm = 0.f;
+        if (qfree) {
+            qlds[wave * T + lane] = qpart[0];
+            qlds[wave * T + lane + 64 * (SPL - 1)] = qpart[1];
+            __syncthreads();
+            if (tid < T) {
+                float qs = 0.f;
+#pragma unroll
+                for (int w = 0; w < kLeafWaves; ++w) qs += qlds[w * T + tid];
+                qterm = -0.5f * qs;
+            }
+        }
         double part = 0.0;
         if (tid < T) {
             const int64_t b = b0 + tid;
             if (b < a.B) {
                 for (int cl = 0; cl < a.C; ++cl) {
                     const float mm = run_m[cl * T + tid];
-                    const float ll = (mm > -INFINITY) ? mm + __logf(run_s[cl * T + tid]) : -INFINITY;
+                    const float ll = (mm > -INFINITY) ? mm + __logf(run_s[cl * T + tid]) + qterm : -INFINITY;
                     a.out[b * a.C + cl] = ll;
                     part += (double)ll;
                 }
@@ -1249,7 +1290,7 @@ static int launch_leaf_gen(const LeafArgs &a, hipStream_t st) {
     using G = TileGeom<SPL>;
     const int grid = cdiv(a.B, G::T);
     size_t lds = G::BUF_BYTES + 64 + (size_t)kLeafWaves * 2 * a.tabcap;
-    if (DEPTH > 0) lds += (size_t)2 * a.C * G::T * sizeof(float);
+    if (DEPTH > 0) lds += (size_t)(2 * a.C + kLeafWaves) * G::T * sizeof(float);
     auto kern = ratspn_leaf_kernel<DIST, QB, CB, SPL, DEPTH, S, GEN>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
