@@ -29,6 +29,7 @@ void profile_take(hipEvent_t *start, hipEvent_t *stop);  // one-shot measurement
     } while (0)
 
 constexpr int kWave = 64;           // CDNA wavefront
+constexpr int kCompactRec = 48;      // bytes of a compact block record: 8 means + 4 u16 row offsets + pad
 constexpr float kExpandBound = 6.0f; // |x|, |mu| bound under which the unit-scale leaf uses the expanded square
 constexpr int kChunk = 64;          // features staged in LDS per chunk (FC)
 constexpr int kLeafWaves = 8;       // waves per work-group of the leaf / fused kernels
@@ -63,6 +64,7 @@ struct RatWs {
                   // |mean| <= kExpandBound (the expanded form x^2 - 2 x mu + mu^2 is then safe)
     float *rec;   // [G*(SP/4)*(4+8I)] block records staged into LDS by the kernels (I <= 2 only)
     int tabcap;   // LDS bytes per wave for the records of one chunk, 0 = records not used
+    int tabcap_c; // the same for the compact 48-byte records of the unit-scale two-channel kernel
     float *w[3];  // linear softmax weights: sum layer 0, sum layer 1, root
     float *lw[3]; // log-softmax weights
     int64_t bytes;
@@ -101,6 +103,7 @@ inline RatWs carve_ratspn_ws(void *base, int D, int R, int d, int I, int QB, int
     w.unit = (int *)take((int64_t)R * 4);
     w.rec = nullptr;
     w.tabcap = 0;
+    w.tabcap_c = 0;
     if (I <= 2) {
         const int recb = 4 + 8 * I;
         w.rec = (float *)take((int64_t)w.G * (w.SP / kBlock) * recb * 4);
@@ -112,6 +115,7 @@ inline RatWs carve_ratspn_ws(void *base, int D, int R, int d, int I, int QB, int
         const int blocks = rpg * (kChunk / kBlock + 1) + QB + 2;
         const int cap = (int)align_up((int64_t)blocks * recb * 4, 16);
         if (cap <= 3 * 1024) w.tabcap = cap;  // three 16-byte loads per lane (NTL in the kernel)
+        w.tabcap_c = (int)align_up((int64_t)blocks * kCompactRec, 16);
     }
     // sum layers (only meaningful for the fused model entry point)
     int64_t n0 = 0, n1 = 0, nr = 0;

@@ -136,6 +136,7 @@ struct PrepArgs {
     const int *srcr, *nblk, *segoff, *fl2;
     int R, I, CB, d, NC, QB, SP, G;
     float *par, *cel, *biasc, *biasx, *rec;
+    int rec_compact;   // 1: 48-byte records {mean[4][2], u16 row offset[4], pad} (unit-scale hint, I == 2)
     int *unit;
     // up to three weight matrices [rows, n] -> W (softmax), LW (log_softmax)
     const float *w[3];
@@ -216,7 +217,16 @@ __global__ __launch_bounds__(256) void ratspn_prep_kernel(const PrepArgs a) {
         a.par[ent * 2 * CB + kk] = A;
         a.par[ent * 2 * CB + CB + kk] = Bv;
         a.cel[ent * CB + kk] = Cc;
-        if (a.rec != nullptr) {
+        if (a.rec != nullptr && a.rec_compact) {
+            // compact records (CompactPipe): {mean[4][2], row offsets as 4 x u16, 8 bytes of padding}
+            const int blk = pidx / kBlock, u = pidx - blk * kBlock;
+            float *rp = a.rec + ((int64_t)g * (SP / kBlock) + blk) * (kCompactRec / 4);
+            rp[u * 2 + k] = A;
+            if (k == 0 && (u & 1) == 0) {
+                const int o0 = a.fl2[(int64_t)g * SP + pidx], o1 = a.fl2[(int64_t)g * SP + pidx + 1];
+                rp[8 + (u >> 1)] = __int_as_float((o0 & 0xffff) | (o1 << 16));
+            }
+        } else if (a.rec != nullptr) {
             // block records for the LDS-resident tables (I == CB <= 2): {row offsets[4], p0[4][CB],
             // p1[4][CB]} -- see LdsPipe
             const int RECB = 4 + 8 * CB;
@@ -388,6 +398,7 @@ struct LeafArgs {
     cint_p segoff;    // [G][NC][QB] first stream position of every segment
     const float *rec; // [G][SP/4] block records for the LDS-resident tables (CB <= 2)
     int tabcap;       // bytes of LDS per wave for the records of one chunk
+    int tabcap_c;     // the same for compact records (host side only: launch_leaf moves it into tabcap)
     int unit_hint;    // host hint: every scale is 1 (DPK_FLAG_UNIT_SCALE)
 #ifdef DPK_TIMELINE
     unsigned long long *dbg;  // [blocks][waves][NC+2][6] s_memtime stamps (measurement builds)
@@ -431,7 +442,8 @@ __device__ __forceinline__ void lds_barrier() {
 #define DPK_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
 
 // DPK_ABLATE (measurement builds only, never shipped): 1 = constant parameters, 2 = constant
-// parameters and row offsets (no SMEM in the inner loop), 3 = no LDS reads, 4 = no HBM staging
+// parameters and row offsets (no SMEM in the inner loop), 3 = no LDS reads of x, 4 = no HBM staging,
+// 5 = no LDS reads of the block records in the expanded pipeline
 #ifndef DPK_ABLATE
 #define DPK_ABLATE 0
 #endif
@@ -631,6 +643,11 @@ template <int CB, int SPL, bool GENERAL> struct LdsPipe {
     const char *tbn;  // record of block b+1
 
     template <int SET> __device__ __forceinline__ void load_par(const char *rec) {
+        if (DPK_ABLATE == 5) {   // measurement: no record reads
+#pragma unroll
+            for (int i = 0; i < 4 * CB; ++i) mu[SET][i] = 0.25f * (float)(i + 1);
+            return;
+        }
         mu[SET] = *reinterpret_cast<const pvec *>(rec + 16);
         if (GENERAL) av[SET] = *reinterpret_cast<const pvec *>(rec + 16 + 16 * CB);
     }
@@ -677,7 +694,8 @@ template <int CB, int SPL, bool GENERAL> struct LdsPipe {
         constexpr int OTH = 1 - CUR;
         leaf_read_x<SPL>(x[OTH], lane_base, offn);
         offc = offn;
-        offn = *reinterpret_cast<const i32x4 *>(tbn + RECBB);
+        if (DPK_ABLATE == 5) offn = (i32x4){0, 520, 1040, 1560};
+        else offn = *reinterpret_cast<const i32x4 *>(tbn + RECBB);
         load_par<OTH>(tbn);
         tbn += RECBB;
         __builtin_amdgcn_sched_barrier(0);
@@ -731,6 +749,77 @@ template <int CB, int SPL, bool GENERAL> struct LdsPipe {
             for (int u = 0; u < kBlock; ++u)
 #pragma unroll
                 for (int s = 0; s < SPL; ++s) x[0][u][s] = x[1][u][s];
+        }
+    }
+};
+
+// The unit-scale two-channel pipeline on compact records.  The accumulate loop is LDS-return-bandwidth bound
+// (tools/ubench/leaf_loop.hip: 256 B/clk per CU whether or not the lanes share an address; a broadcast
+// ds_read_b128 costs ~4.6 LDS cycles, a ds_read_b64 ~1.9), so the record is cut from 3 x b128 to 2 x b128 (the 8
+// means) + 1 x b64 (the 4 row offsets as u16), the unpack folded into the address add by SDWA: 18.7 instead of
+// 21.4 LDS cycles per block, 173 instead of 205 ns per block and wave in the microbenchmark.
+__device__ __forceinline__ int sdwa_add_w0(int base, int pk) {
+    int r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+        : "=v"(r) : "v"(base), "v"(pk));
+    return r;
+}
+__device__ __forceinline__ int sdwa_add_w1(int base, int pk) {
+    int r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+        : "=v"(r) : "v"(base), "v"(pk));
+    return r;
+}
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+struct CompactPipe {
+    f32x2 x[2][kBlock];
+    f32x8 mu[2];
+    i32x2 offn;        // packed row offsets of block b+1
+    const char *tbn;   // record of block b+1
+
+    __device__ __forceinline__ void read_x(f32x2 (&dst)[kBlock], const char *smem0, int lane_off, i32x2 o) {
+        dst[0] = *reinterpret_cast<const f32x2 *>(smem0 + sdwa_add_w0(lane_off, o[0]));
+        dst[1] = *reinterpret_cast<const f32x2 *>(smem0 + sdwa_add_w1(lane_off, o[0]));
+        dst[2] = *reinterpret_cast<const f32x2 *>(smem0 + sdwa_add_w0(lane_off, o[1]));
+        dst[3] = *reinterpret_cast<const f32x2 *>(smem0 + sdwa_add_w1(lane_off, o[1]));
+    }
+    __device__ __forceinline__ void prime(const char *tb0, const char *smem0, int lane_off) {
+        mu[0] = *reinterpret_cast<const f32x8 *>(tb0);
+        read_x(x[0], smem0, lane_off, *reinterpret_cast<const i32x2 *>(tb0 + 32));
+        offn = *reinterpret_cast<const i32x2 *>(tb0 + kCompactRec + 32);
+        tbn = tb0 + kCompactRec;
+    }
+    template <int CUR, bool WITHQ>
+    __device__ __forceinline__ void step(f32x2 (&P)[2], f32x2 &Q, const char *smem0, int lane_off) {
+        constexpr int OTH = 1 - CUR;
+        read_x(x[OTH], smem0, lane_off, offn);
+        offn = *reinterpret_cast<const i32x2 *>(tbn + kCompactRec + 32);
+        mu[OTH] = *reinterpret_cast<const f32x8 *>(tbn);
+        tbn += kCompactRec;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kBlock; ++u) {
+            const f32x2 xv = x[CUR][u];
+            if (WITHQ) Q = __builtin_elementwise_fma(xv, xv, Q);
+            const f32x2 mp = {mu[CUR][2 * u], mu[CUR][2 * u + 1]};
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(P[0]) : "v"(xv), "v"(mp));
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(P[1]) : "v"(xv), "v"(mp));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <bool WITHQ>
+    __device__ __forceinline__ void run(f32x2 (&P)[2], f32x2 &Q, const char *smem0, int lane_off, int nb) {
+        for (int i = nb >> 1; i > 0; --i) {
+            step<0, WITHQ>(P, Q, smem0, lane_off);
+            step<1, WITHQ>(P, Q, smem0, lane_off);
+        }
+        if (nb & 1) {
+            step<0, WITHQ>(P, Q, smem0, lane_off);
+            mu[0] = mu[1];
+#pragma unroll
+            for (int u = 0; u < kBlock; ++u) x[0][u] = x[1][u];
         }
     }
 };
@@ -870,7 +959,9 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
 
         // LDS-resident block records of this wave for the current chunk (kLdsTables): every wave
         // copies its own records, so no other wave ever reads them and only lgkmcnt orders them
-        constexpr int RECBB = RecGeom<(kLdsTables ? CB : 1)>::RECBB;
+        // the unit-scale two-channel kernel reads compact records (CompactPipe), everything else the full ones
+        constexpr bool kCompact = (DIST == 0) && !GEN && (CB == 2) && (SPL == 2) && (DPK_NO_EXPAND == 0);
+        constexpr int RECBB = kCompact ? kCompactRec : RecGeom<(kLdsTables ? CB : 1)>::RECBB;
         constexpr int NTL = (QB <= 4) ? 2 : 3;  // float4 per lane: 2 / 3 KiB of records per (wave, chunk)
         // two buffers per wave; the records of chunk c+1 are copied by LDS-DMA (no VGPRs) while chunk
         // c is consumed.  Ordering: the DMA is issued BEFORE the x prefetch of the same chunk, vmcnt
@@ -1034,7 +1125,10 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
                         LdsPipe<CB, SPL, GEN> pipe;
                         if constexpr (DIST == 0 && !GEN && SPL == 2) {
                             if (expand) {
-                                pipe.prime(tab_lds + (c & 1) * a.tabcap, lane_base);
+                                CompactPipe cp;
+                                const int lane_off = lane * (4 * SPL);
+                                if constexpr (kCompact) cp.prime(tab_lds + (c & 1) * a.tabcap, smem, lane_off);
+                                else pipe.prime(tab_lds + (c & 1) * a.tabcap, lane_base);
 #pragma unroll
                                 for (int q = 0; q < QB; ++q) {
                                     const int r = g * QB + q;
@@ -1043,7 +1137,13 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
                                     f32x2 P[CB], Q = {0.f, 0.f};
 #pragma unroll
                                     for (int k = 0; k < CB; ++k) P[k] = (f32x2){acc[q][k][0], acc[q][k][1]};
-                                    pipe.template run3<(DEPTH == 0)>(P, Q, lane_base, nb);   // fused model: qfree
+                                    // fused model: the x^2 sums are factored out (qfree)
+                                    if constexpr (kCompact) {
+                                        f32x2 (&P2)[2] = reinterpret_cast<f32x2 (&)[2]>(P);
+                                        cp.template run<(DEPTH == 0)>(P2, Q, smem, lane_off, nb);
+                                    } else {
+                                        pipe.template run3<(DEPTH == 0)>(P, Q, lane_base, nb);
+                                    }
                                     // log-density sum = P - Q/2 + (constants - sum mu^2 / 2); Q == 0 when factored out
 #pragma unroll
                                     for (int k = 0; k < CB; ++k) {
@@ -1262,6 +1362,8 @@ static int prepare_leaf_tables(int dist, const RatWs &w, const int64_t *mask, co
     a.R = R; a.I = I; a.CB = CB; a.d = d; a.NC = w.NC; a.QB = w.QB; a.SP = w.SP; a.G = w.G;
     a.par = w.par; a.cel = w.cel; a.biasc = w.biasc; a.biasx = w.biasx; a.unit = w.unit;
     a.rec = (CB == I && CB <= 2) ? w.rec : nullptr;
+    // the unit-scale two-channel kernel (launch_leaf: hint && Gaussian && CB == 2) reads compact records
+    a.rec_compact = (dist == 0 && I == 2 && CB == 2 && (flags & DPK_FLAG_UNIT_SCALE) != 0 && DPK_NO_EXPAND == 0) ? 1 : 0;
     int rows = 0;
     for (int m = 0; m < 3; ++m) {
         if (m < n_jobs) {
@@ -1280,7 +1382,7 @@ static int prepare_leaf_tables(int dist, const RatWs &w, const int64_t *mask, co
 static void fill_leaf_args(LeafArgs &a, const RatWs &w) {
     a.NC = w.NC; a.SP = w.SP;
     a.fl1 = as_const(w.fl1); a.fl2 = as_const(w.fl2); a.nblk = as_const(w.nblk);
-    a.segoff = as_const(w.segoff); a.rec = w.rec; a.tabcap = w.tabcap;
+    a.segoff = as_const(w.segoff); a.rec = w.rec; a.tabcap = w.tabcap; a.tabcap_c = w.tabcap_c;
     a.par = as_const(w.par); a.cel = as_const(w.cel); a.biasc = as_const(w.biasc); a.biasx = as_const(w.biasx);
     a.unit = as_const(w.unit);
 }
@@ -1327,7 +1429,14 @@ template <int DIST, int QB, int CB, int SPL, int DEPTH, int S>
 static int launch_leaf(const LeafArgs &a, hipStream_t st) {
     // the means-only variant exists where the LDS-table pipeline does (Gaussian, CB <= 2, SPL == 2)
     if constexpr (DIST == 0 && CB <= 2 && SPL == 2) {
-        if (a.unit_hint) return launch_leaf_gen<DIST, QB, CB, SPL, DEPTH, S, false>(a, st);
+        if (a.unit_hint) {
+            if (CB == 2 && DPK_NO_EXPAND == 0) {   // compact records (prepare_leaf_tables wrote them for this case)
+                LeafArgs c = a;
+                c.tabcap = a.tabcap_c;
+                return launch_leaf_gen<DIST, QB, CB, SPL, DEPTH, S, false>(c, st);
+            }
+            return launch_leaf_gen<DIST, QB, CB, SPL, DEPTH, S, false>(a, st);
+        }
     }
     return launch_leaf_gen<DIST, QB, CB, SPL, DEPTH, S, true>(a, st);
 }

@@ -3,7 +3,7 @@
 # usage: tools/ablate.sh [bench args]
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-for v in "" _ab1 _ab2 _ab3 _ab4 _spl1; do
+for v in "" _ab3 _ab4 _ab5; do
   lib=deeprob-kit_amd/lib/libdeeprob_hip$v.so
   [ -f "$lib" ] || continue
   echo -n "variant '${v:-full}': "
