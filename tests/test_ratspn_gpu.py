@@ -345,3 +345,30 @@ def test_gradients_with_marginalised_inputs(golden):
         if p.grad is not None:
             assert grad_err(p.grad.cpu().numpy(), leaves[k].grad.numpy()) <= GRAD_TOL, k
     assert grad_err(xg.grad.cpu().numpy(), xf.grad.numpy()) <= GRAD_TOL
+
+
+@pytest.mark.parametrize('kw', [dict(rg_depth=1, rg_repetitions=8), dict(rg_depth=1, rg_repetitions=3, out_classes=4),
+                                dict(rg_depth=2, rg_repetitions=19), dict(rg_depth=3, rg_repetitions=8, out_classes=2),
+                                dict(rg_depth=2, rg_repetitions=8, rg_batch=1, rg_sum=2),
+                                dict(rg_depth=2, rg_repetitions=5, rg_batch=2, rg_sum=8, in_features=77)])
+def test_unit_scale_fused_shapes_vs_oracle(kw):
+    """The expanded / x^2-factored unit-scale kernel over depths, repetition counts (more than one pass of 8 waves),
+    class counts and a padded (77-variable) region graph, with clean rows, rows that turn exact mid-way (one large
+    value in a late chunk), NaN rows and ragged batch sizes."""
+    from deeprob.spn.models import GaussianRatSpn
+    torch.manual_seed(4)
+    base = dict(in_features=784, rg_batch=2, rg_sum=2, random_state=11)
+    base.update(kw)
+    model = GaussianRatSpn(**base).eval()
+    D = base['in_features']
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    x = torch.randn(333, D, generator=torch.Generator().manual_seed(5))
+    x[5, D - 3] = 9.0                 # beyond the bound in the last chunk only
+    x[140, D // 2] = float('nan')
+    x[141] = float('nan')
+    x[300, 0] = -7.0                  # beyond the bound in the first chunk
+    want = orc.ratspn_forward(sd, x).numpy()
+    model = model.cuda()
+    with torch.no_grad():
+        got = model(x.cuda()).cpu().numpy()
+    assert rel_err(got, want) <= LL_TOL
