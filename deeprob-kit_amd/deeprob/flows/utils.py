@@ -13,7 +13,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from deeprob.hip import HipError, Workspace
+from deeprob.hip import Workspace
 
 
 class Bijector(abc.ABC, nn.Module):

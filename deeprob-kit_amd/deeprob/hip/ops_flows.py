@@ -9,7 +9,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from deeprob.hip import load_library, check, ptr, stream_ptr, require_device_f32, Workspace, HipError
+from deeprob.hip import load_library, check, ptr, stream_ptr, require_device_f32, HipError
 
 
 def _no_graph(*tensors):

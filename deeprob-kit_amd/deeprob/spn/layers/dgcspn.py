@@ -11,7 +11,7 @@ import torch
 from torch import nn
 
 from deeprob.torch.initializers import dirichlet_
-from deeprob.hip import HipError, Workspace
+from deeprob.hip import Workspace
 
 
 def _pair(v: Union[int, Tuple[int, int]]) -> Tuple[int, int]:

@@ -14,7 +14,7 @@ from torch import nn
 from torch import distributions
 
 from deeprob.torch.initializers import dirichlet_
-from deeprob.hip import Workspace, HipError
+from deeprob.hip import Workspace
 from deeprob.hip import ops
 
 

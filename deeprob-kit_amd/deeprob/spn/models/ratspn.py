@@ -16,7 +16,7 @@ from deeprob.torch.base import ProbabilisticModel
 from deeprob.torch.constraints import ScaleClipper
 from deeprob.spn.layers.ratspn import RegionGraphLayer, GaussianLayer, BernoulliLayer
 from deeprob.spn.layers.ratspn import SumLayer, ProductLayer, RootLayer
-from deeprob.hip import ops, HipError
+from deeprob.hip import ops
 
 
 class RatSpn(ProbabilisticModel):

@@ -15,7 +15,7 @@ against the reference's own invariants (tests/test_dgcspn.py:46-75: all-ones inp
 """
 import math
 from itertools import product as iproduct
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
 import torch

@@ -14,7 +14,6 @@ round trip) and against the reference's invertibility test (tests/test_flows.py:
 import math
 from typing import Dict, List, Tuple
 
-import numpy as np
 import torch
 import torch.nn.functional as F
 

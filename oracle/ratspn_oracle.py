@@ -15,7 +15,7 @@ build container (outputs, per-layer activations, loss and gradients), and agains
 own known-answer test (Bernoulli RAT-SPN normalisation, reference tests/test_ratspn.py:46-48).
 """
 import math
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch

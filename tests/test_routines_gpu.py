@@ -4,7 +4,6 @@ import pytest
 import torch
 
 from oracle import ratspn_oracle as orc
-from tests.util import rel_err
 
 pytestmark = pytest.mark.gpu
 

@@ -1,5 +1,5 @@
 """Measurement: fused RAT-SPN forward for model variants (general scale, more channels, classes, depth 3)."""
-import os, sys, time, json
+import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, 'deeprob-kit_amd'), ROOT]
 import torch
