@@ -1,0 +1,89 @@
+"""Error behaviour of the C ABI called directly (include/deeprob_hip.h): negative DPK_E* codes and a message in
+dpk_last_error(), never a crash, never a silent success."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DPK_EINVAL, DPK_EWORKSPACE, DPK_EUNSUPPORTED = -1, -2, -4
+
+
+def _model(**kw):
+    from deeprob.spn.models import GaussianRatSpn
+    base = dict(in_features=64, rg_depth=2, rg_repetitions=4, rg_batch=2, rg_sum=2, random_state=1)
+    base.update(kw)
+    return GaussianRatSpn(**base).cuda().eval()
+
+
+def _fused_args(m, x, out, ws, ws_bytes=None):
+    from deeprob.hip import ptr
+    base = m.base_layer
+    sums = [l.weight for l in m.layers if hasattr(l, 'weight')]
+    R, I, d = base.mask.shape[0], base.out_channels, base.mask.shape[1]
+    return [ptr(x), x.shape[0], x.shape[1], ptr(base.mask), None, ptr(base.loc), ptr(base.scale),
+            ptr(sums[0]) if sums else None, ptr(sums[1]) if len(sums) > 1 else None, ptr(m.root_layer.weight),
+            m.rg_depth, R // 2 ** m.rg_depth, I, m.rg_sum, m.out_classes, ptr(out), None, None, ptr(ws),
+            ws.numel() if ws_bytes is None else ws_bytes, 0, torch.cuda.current_stream().cuda_stream]
+
+
+def test_fused_forward_error_codes():
+    from deeprob.hip import load_library
+    lib = load_library()
+    m = _model()
+    x = torch.randn(10, 64, device='cuda')
+    out = torch.empty(10, 1, device='cuda')
+    R, I, d = m.base_layer.mask.shape[0], 2, m.base_layer.mask.shape[1]
+    n = lib.dpk_ratspn_workspace_bytes(64, R, d, I, 2, 4, 2, 1)
+    assert n > 0
+    ws = torch.empty(n, dtype=torch.uint8, device='cuda')
+    assert lib.dpk_ratspn_forward(*_fused_args(m, x, out, ws)) == 0
+    # workspace too small
+    assert lib.dpk_ratspn_forward(*_fused_args(m, x, out, ws, ws_bytes=1024)) == DPK_EWORKSPACE
+    assert b'workspace' in lib.dpk_last_error()
+    # null input
+    args = _fused_args(m, x, out, ws)
+    args[0] = None
+    assert lib.dpk_ratspn_forward(*args) == DPK_EINVAL and lib.dpk_last_error()
+    # negative batch
+    args = _fused_args(m, x, out, ws)
+    args[1] = -3
+    assert lib.dpk_ratspn_forward(*args) == DPK_EINVAL
+    # a shape outside the fused envelope is reported, not mis-evaluated
+    m16 = _model(rg_batch=16, rg_sum=16)
+    R16, d16 = m16.base_layer.mask.shape[0], m16.base_layer.mask.shape[1]
+    n16 = lib.dpk_ratspn_workspace_bytes(64, R16, d16, 16, 2, 4, 16, 1)
+    ws16 = torch.empty(max(n16, 256), dtype=torch.uint8, device='cuda')
+    assert lib.dpk_ratspn_forward(*_fused_args(m16, x, out, ws16)) == DPK_EUNSUPPORTED
+    assert lib.dpk_ratspn_workspace_bytes(0, R, d, I, 2, 4, 2, 1) < 0
+
+
+def test_layer_entry_error_codes():
+    from deeprob.hip import load_library, ptr
+    lib = load_library()
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.randn(8, 4, 6, device='cuda')           # [B, R, N]
+    out = torch.empty(8, 2, 36, device='cuda')
+    assert lib.dpk_product_forward(ptr(x), 8, 4, 6, ptr(out), st) == 0
+    assert lib.dpk_product_forward(None, 8, 4, 6, ptr(out), st) == DPK_EINVAL
+    assert lib.dpk_product_forward(ptr(x), 8, 3, 6, ptr(out), st) == DPK_EINVAL      # odd number of regions
+    w = torch.randn(2, 5, 36, device='cuda')
+    o2 = torch.empty(8, 2, 5, device='cuda')
+    n = lib.dpk_sum_workspace_bytes(8, 2, 36, 5)
+    ws = torch.empty(n, dtype=torch.uint8, device='cuda')
+    assert lib.dpk_sum_forward(ptr(out), ptr(w), 8, 2, 36, 5, ptr(o2), ptr(ws), n, st) == 0
+    assert lib.dpk_sum_forward(ptr(out), ptr(w), 8, 2, 36, 5, ptr(o2), ptr(ws), 16, st) == DPK_EWORKSPACE
+    assert lib.dpk_sum_forward(ptr(out), None, 8, 2, 36, 5, ptr(o2), ptr(ws), n, st) == DPK_EINVAL
+    # coupling: hidden width the fused kernel is not built for -> DPK_EUNSUPPORTED (the host then takes the MLP route)
+    D, U = 10, 20
+    xx = torch.randn(4, D, device='cuda')
+    mask = (torch.arange(D) % 2).float().cuda()
+    W1, b1 = torch.randn(U, D, device='cuda'), torch.randn(U, device='cuda')
+    W2, b2 = torch.randn(2 * D, U, device='cuda'), torch.randn(2 * D, device='cuda')
+    act = torch.ones(1, device='cuda')
+    o3, ldj = torch.empty_like(xx), torch.empty(4, device='cuda')
+    nws = max(lib.dpk_coupling1d_workspace_bytes(D, 32, 5, 5), 1 << 16)
+    wsc = torch.empty(nws, dtype=torch.uint8, device='cuda')
+    rc = lib.dpk_coupling1d_forward(ptr(xx), 4, D, ptr(mask), ptr(1 - mask), 5, 5, ptr(W1), ptr(b1), ptr(W2), ptr(b2), U,
+                                    ptr(act), None, None, 1, 0, ptr(o3), ptr(ldj), 0, ptr(wsc), nws, st)
+    assert rc == DPK_EUNSUPPORTED and b'units' in lib.dpk_last_error()
+    torch.cuda.synchronize()
