@@ -2,9 +2,10 @@
 
 New functionality with no reference counterpart (the reference is single device): samples are
 independent and the model is a few MB, so every rank holds a replica and evaluates a contiguous slice
-of the batch; the only exchange is ONE all-reduce (sum) of ``{sum LL, count}`` in fp64 -- 16 bytes
-over RCCL/xGMI -- after which every rank knows the mean log-likelihood.  The all-reduce is issued
-asynchronously so it overlaps the next step's kernel; per-sample LLs stay sharded.
+of the batch; the only exchange is an all-reduce (sum) of ``{sum LL, count}`` in fp64 -- 16 bytes per
+step over RCCL/xGMI, the pairs of up to 32 consecutive steps sharing one asynchronous collective --
+after which every rank knows the mean log-likelihood of every step.  Per-sample LLs stay sharded.
+Training shards the same way; the gradients meet in one flat all-reduce per step (``allreduce_gradients``).
 """
 from typing import Callable, List, Optional, Tuple
 
@@ -44,10 +45,17 @@ class ShardedLogLikelihood:
     """
 
     def __init__(self, model=None, group=None, local_sum_fn: Optional[Callable] = None,
-                 static_inputs: bool = False):
+                 static_inputs: bool = False, reduce_every: int = 32):
         self.model = model
         self.group = group
         self.local_sum_fn = local_sum_fn
+        # The {sum LL, count} pairs of up to ``reduce_every`` consecutive steps travel in ONE all-reduce (they sit
+        # next to each other in the slot pool).  Fewer, larger collectives is what the xGMI mesh wants, and a
+        # per-step collective kernel would also take a compute unit away from the model kernel, whose 512
+        # work-groups need every one of the 2 x 256 slots to run in a single round.
+        self.reduce_every = max(1, int(reduce_every))
+        self._open = []        # steps whose slots are not in a collective yet: (slot tensor, pool, index)
+        self._works = []
         # static_inputs: the caller steps over a fixed set of resident buffers (an evaluation ring): the fused
         # call is bound once per buffer (model.fused_plan) and each step is one C call
         self.static_inputs = static_inputs
@@ -62,6 +70,7 @@ class ShardedLogLikelihood:
             self._pool = torch.zeros(256, 2, dtype=torch.float64, device=device)
             self._pool_next = 0
         slot = self._pool[self._pool_next]
+        self._slot_ref = (self._pool, self._pool_next)
         self._pool_next += 1
         return slot
 
@@ -93,18 +102,39 @@ class ShardedLogLikelihood:
         return acc
 
     def step(self, x_local: torch.Tensor, kernel_events=None):
+        self._slot_ref = None
         acc = self._local(x_local, kernel_events)
-        work = None
+        self._pending.append((acc, None))
         if self.group is not None and dist.get_world_size(self.group) > 1:
-            work = dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._pending.append((acc, work))
+            self._open.append((acc, self._slot_ref))
+            if len(self._open) >= self.reduce_every:
+                self._reduce_open()
+
+    def _reduce_open(self):
+        """One asynchronous all-reduce over the slots of the open steps (contiguous runs of the slot pool are
+        reduced in place; anything else -- a custom local_sum_fn -- is stacked first)."""
+        if not self._open:
+            return
+        runs, cur = [], None
+        for acc, ref in self._open:
+            if ref is not None and cur is not None and cur[0] is ref[0] and cur[2] == ref[1]:
+                cur[2] += 1
+            else:
+                cur = [ref[0], ref[1], ref[1] + 1] if ref is not None else None
+                runs.append(cur if cur is not None else acc)
+        for r in runs:
+            t = r[0][r[1]:r[2]] if isinstance(r, list) else r
+            self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._open = []
 
     def drain(self) -> List[float]:
         if not self._pending:
             return []
-        for _, work in self._pending:
-            if work is not None:
-                work.wait()
+        if self.group is not None and dist.get_world_size(self.group) > 1:
+            self._reduce_open()
+        for work in self._works:
+            work.wait()
+        self._works = []
         accs = torch.stack([a for a, _ in self._pending])
         self._pending = []
         means = (accs[:, 0] / accs[:, 1]).cpu().tolist()  # one device->host copy for the whole window

@@ -43,6 +43,24 @@ def _worker(rank, world, port, out_dir):
     ok = all(abs(a - b) <= 1e-9 * abs(b) for a, b in zip(means, want))
     lo, hi = shard_bounds(33, rank, world)
     ok = ok and (hi - lo) in (16, 17) and ev.drain() == []
+
+    # the product's slot-pool path: several steps per collective, contiguous pool runs reduced in place, a run that
+    # wraps from one pool to the next
+    class PoolEval(ShardedLogLikelihood):
+        def _local(self, x, kernel_events=None):
+            acc = self._acc_slot(x.device)
+            acc.copy_(local_sum(x))
+            return acc
+
+    ev2 = PoolEval(model=None, group=dist.group.WORLD, reduce_every=3)
+    ev2._acc_slot(torch.device('cpu'))
+    ev2._pool_next = 254                                   # two slots left: the first window straddles two pools
+    more = [torch.randn(n, 15, generator=gen) for n in (5, 9, 21, 40, 3, 12, 8)]
+    for x in more:
+        ev2.step(shard_batch(x, rank, world))
+    means2 = ev2.drain()
+    want2 = [float(orc.ratspn_forward(sd, x).double().mean()) for x in more]
+    ok = ok and len(means2) == 7 and all(abs(a - b) <= 1e-9 * abs(b) for a, b in zip(means2, want2))
     np.save(os.path.join(out_dir, 'r{}.npy'.format(rank)), np.asarray([float(ok)] + means))
     dist.destroy_process_group()
 
