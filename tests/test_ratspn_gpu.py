@@ -372,3 +372,46 @@ def test_unit_scale_fused_shapes_vs_oracle(kw):
     with torch.no_grad():
         got = model(x.cuda()).cpu().numpy()
     assert rel_err(got, want) <= LL_TOL
+
+
+@pytest.mark.parametrize('name', ['ratspn_g784_d2_r8_i4_s2', 'ratspn_g100_d2_r11_i2_s4_c3'])
+def test_mpe_golden(golden, name):
+    """RatSpn.mpe (reference: models/ratspn.py:124-162) on the HIP forward activations: same completions as the
+    reference, observed entries untouched, also with given class labels."""
+    model, _ = build(name, golden)
+    g = golden(name + '_mpe')
+    x = torch.from_numpy(g['x']).cuda()
+    got = model.mpe(x).cpu().numpy()
+    assert got.shape == g["mpe"].shape and not np.isnan(got).any()
+    rows = np.ones(got.shape[0], dtype=bool)
+    if model.out_classes > 1:
+        # without labels the class is the arg-max of the root outputs: rows whose two best classes tie to within
+        # fp32 noise (the fully marginalised row: every class scores ~0) may legitimately pick another class
+        with torch.no_grad():
+            top = torch.topk(model(x), 2, dim=1).values
+        rows = ((top[:, 0] - top[:, 1]) > 1e-4).cpu().numpy()
+        assert rows.sum() >= got.shape[0] - 2
+    assert np.allclose(got[rows], g['mpe'][rows], rtol=1e-5, atol=1e-6)
+    obs = ~np.isnan(g['x'])
+    assert np.array_equal(got[obs], g['x'][obs])
+    if 'y' in g.files:
+        got_y = model.mpe(x, y=torch.from_numpy(g['y']).cuda()).cpu().numpy()
+        assert np.allclose(got_y, g['mpe_y'], rtol=1e-5, atol=1e-6)
+
+
+def test_sample_shapes_and_statistics():
+    """RatSpn.sample (reference :164-182): ancestral sampling is random, so the check is statistical -- the samples
+    of a model whose leaves are tight around known means must reproduce the mixture's overall mean."""
+    from deeprob.spn.models import GaussianRatSpn
+    torch.manual_seed(0)
+    model = GaussianRatSpn(16, rg_depth=2, rg_repetitions=4, rg_batch=2, rg_sum=2, optimize_scale=True,
+                           random_state=5).cuda().eval()
+    with torch.no_grad():
+        model.base_layer.scale.fill_(0.05)
+        model.base_layer.loc.copy_(3.0 + 0.1 * torch.randn_like(model.base_layer.loc))
+    s = model.sample(4000)
+    assert tuple(s.shape) == (4000, 16) and torch.isfinite(s).all() and s.is_cuda
+    assert abs(s.mean().item() - 3.0) < 0.1 and 0.02 < s.std(dim=0).mean().item() < 0.3
+    # sampled points are likely under the model: far above the density of points drawn elsewhere
+    with torch.no_grad():
+        assert model(s).mean().item() > model(s + 2.0).mean().item() + 100.0
