@@ -153,3 +153,24 @@ def test_sampling_direction_has_no_silent_graph():
         flow.apply_forward(u)          # parameters require grad and grad mode is on
     with torch.no_grad():
         flow.apply_forward(u)
+
+
+def test_sampling_entry_points():
+    """NormalizingFlow.sample / rsample (reference: flows/models/base.py:145-180): base draw pushed through
+    apply_forward and the inverse preprocessing; samples must be likely under the flow itself."""
+    from deeprob.flows.models import RealNVP1d
+    from tests.util import randomise_flow
+    torch.manual_seed(3)
+    flow = RealNVP1d(24, n_flows=3, units=32, logit=0.05)
+    randomise_flow(flow, 4)
+    flow = flow.cuda().eval()
+    s = flow.sample(500)
+    assert tuple(s.shape) == (500, 24) and s.is_cuda and torch.isfinite(s).all()
+    lo, hi = -0.05 / 0.9, 0.95 / 0.9                             # inverse logit range: (sigmoid(u) - a) / (1 - 2a)
+    assert (s > lo).all() and (s < hi).all()
+    with torch.no_grad():
+        ll = flow(s)
+        far = flow(torch.rand_like(s))
+        r = flow.rsample(64)
+    assert torch.isfinite(ll).all() and ll.mean().item() > far.mean().item()
+    assert tuple(r.shape) == (64, 24)
