@@ -616,6 +616,35 @@ __device__ __forceinline__ void leaf_accum_plain(float (&acc)[CB][SPL], const ch
     }
 }
 
+// Expanded unit-scale form on the scalar-cache tables (wide channel blocks): acc[k] += x mu_k, one FMA per
+// (entry, channel, sample) with the mean as a scalar operand, instead of sub / mul / fma.  WITHQ: also q += x^2
+// (leaf-only launches; the fused model factors the x^2 sums out, see qfree in the kernel).
+template <int CB, int SPL, bool WITHQ>
+__device__ __forceinline__ void leaf_accum_linear(float (&acc)[CB][SPL], float (&q)[SPL], const char *lane_base,
+                                                  cint_p flp, cfloat_p pp, int nblk) {
+    for (int b = 0; b < nblk; ++b) {
+        float x[kBlock][SPL];
+        i32x4 off;
+#pragma unroll
+        for (int u = 0; u < kBlock; ++u) off[u] = flp[u];
+        leaf_read_x<SPL>(x, lane_base, off);
+#pragma unroll
+        for (int u = 0; u < kBlock; ++u) {
+#pragma unroll
+            for (int s = 0; s < SPL; ++s)
+                if (WITHQ) q[s] = fmaf(x[u][s], x[u][s], q[s]);
+#pragma unroll
+            for (int k = 0; k < CB; ++k) {
+                const float mu = pp[u * 2 * CB + k];
+#pragma unroll
+                for (int s = 0; s < SPL; ++s) acc[k][s] = fmaf(x[u][s], mu, acc[k][s]);
+            }
+        }
+        flp += kBlock;
+        pp += kBlock * 2 * CB;
+    }
+}
+
 // Software pipeline over the table blocks of one (wave, chunk), tables resident in LDS (CB <= 2).
 //
 // Why LDS and not the scalar cache for the hot loop: an s_load that misses costs ~750-900 cycles
@@ -878,8 +907,10 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
 
     // Expanded unit-scale form (LdsPipe::step3): only when every region's means are bounded, and then every
     // staged |x| above the bound sends its tile to the exact path like a non-finite value does.
-    bool expand_all = (DIST == 0) && !GEN && (CB <= 2) && (SPL == 2) && a.tabcap > 0 && (DPK_NO_EXPAND == 0) &&
-                      (DEPTH == 0 || a.leaf_out == nullptr);
+    // kernels with the LDS-table pipeline (unit hint, CB <= 2) or with wide channel blocks on the scalar-cache tables
+    constexpr bool kWide = (CB > 2);
+    bool expand_all = (DIST == 0) && (DPK_NO_EXPAND == 0) && (DEPTH == 0 || a.leaf_out == nullptr) &&
+                      (kWide || (!GEN && (SPL == 2) && a.tabcap > 0));
     if (expand_all) {
         // lanes read the flags in parallel (a serial scalar loop costs ~150 ns per region)
         bool ok = true;
@@ -975,7 +1006,7 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
         }
         if (DIST == 0 && !GEN && !grp_unit) use_lds = false;  // hint was wrong for this group
         // GEN = false on the LDS route: acc holds sum (x-mu)^2 - 2*(constants) until the end of the pass
-        bool expand = expand_all && use_lds;
+        bool expand = expand_all && (use_lds || kWide);
         // the unit-scale kernel only carries the expanded pipeline: unbounded means take the scalar-cache path
         if (DIST == 0 && !GEN && SPL == 2 && !DPK_NO_EXPAND && !expand) use_lds = false;
         bool acc_is_squares = (DIST == 0) && !GEN && use_lds && !expand;
@@ -1000,7 +1031,7 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
                         (__attribute__((address_space(3))) void *)(dst + i * 1024), 16, 0, 0);
             }
         };
-        bool qgo = qfree && pass == 0 && SPL == 2;
+        bool qgo = qfree && pass == 0;
         load_tab(0);
         load_chunk(0);
 
@@ -1049,9 +1080,14 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
 #pragma unroll
                 for (int j = 0; j < kChunk / kLeafWaves; ++j) {
                     if (j < nvalid) {
-                        const float2 v = *reinterpret_cast<const float2 *>(qb + j * G::ROWB);
-                        const f32x2 xv = {v.x, v.y};
-                        qpart = __builtin_elementwise_fma(xv, xv, qpart);
+                        if constexpr (SPL == 2) {
+                            const float2 v = *reinterpret_cast<const float2 *>(qb + j * G::ROWB);
+                            const f32x2 xv = {v.x, v.y};
+                            qpart = __builtin_elementwise_fma(xv, xv, qpart);
+                        } else {
+                            const float v = *reinterpret_cast<const float *>(qb + j * G::ROWB);
+                            qpart[0] = fmaf(v, v, qpart[0]);
+                        }
                     }
                 }
             }
@@ -1087,6 +1123,19 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
                             leaf_accum_plain<DIST, CB, SPL, 1>(acc[q], lane_base, fl_g + pos,
                                                                par_g + (int64_t)pos * 2 * CB,
                                                                cel_g + (int64_t)pos * CB, nb);
+                        } else if (kWide && expand) {
+                            float qr[SPL];
+#pragma unroll
+                            for (int s = 0; s < SPL; ++s) qr[s] = 0.f;
+                            leaf_accum_linear<CB, SPL, (DEPTH == 0)>(acc[q], qr, lane_base, fl_g + pos,
+                                                                     par_g + (int64_t)pos * 2 * CB, nb);
+                            cfloat_p bx = a.biasx + ((int64_t)r * NC + c) * I + kb;
+#pragma unroll
+                            for (int k = 0; k < CB; ++k) {
+                                const float bk = bx[k];
+#pragma unroll
+                                for (int s = 0; s < SPL; ++s) acc[q][k][s] += fmaf(-0.5f, qr[s], bk);
+                            }
                         } else {
                             leaf_accum_plain<DIST, CB, SPL, 0>(acc[q], lane_base, fl_g + pos,
                                                                par_g + (int64_t)pos * 2 * CB,
@@ -1289,7 +1338,7 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
         float qterm = 0.f;
         if (qfree) {
             qlds[wave * T + lane] = qpart[0];
-            qlds[wave * T + lane + 64 * (SPL - 1)] = qpart[1];
+            if (SPL == 2) qlds[wave * T + lane + 64] = qpart[1];
             __syncthreads();
             if (tid < T) {
                 float qs = 0.f;

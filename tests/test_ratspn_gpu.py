@@ -254,20 +254,22 @@ def test_fused_plan_is_the_same_call(golden):
         assert not plan.valid()
 
 
+@pytest.mark.parametrize('name', ['ratspn_g784_d2_r8_i2_s2', 'ratspn_g784_d2_r8_i4_s2', 'ratspn_g784_d2_r8_i8_s8',
+                                  'ratspn_g784_d2_r8_i16_s16'])
 @pytest.mark.parametrize('case', ['means_beyond_bound', 'outlier_evidence', 'offset_data', 'at_the_bound'])
-def test_expanded_square_guard(golden, case):
+def test_expanded_square_guard(golden, case, name):
     """The unit-scale fused kernel evaluates sum (x-mu)^2 as sum x^2 - 2 sum x mu + sum mu^2 only while |x| and
     |mu| stay <= 6; outside it must take the direct / exact forms.  Every regime is held to the same
     1e-5 relative bar against the oracle, including the adversarial one (x ~ mu, both at the bound)."""
-    model, g = build('ratspn_g784_d2_r8_i2_s2', golden)
+    model, g = build(name, golden)
     x = torch.from_numpy(g['x']).clone()
     with torch.no_grad():
         if case == 'means_beyond_bound':
             model.base_layer.loc.mul_(4.0)           # N(0,1) * 4: many |mu| > 6 -> direct form for the model
         elif case == 'outlier_evidence':
             x[3, 100] = 50.0                         # one value beyond the bound: its tile leaves the fast path
-            x[40] = 7.5
-            x[41, ::3] = -6.5
+            x[20] = 7.5
+            x[21, ::3] = -6.5
         elif case == 'offset_data':
             x += 5.0                                 # |x| ~ 5 +- 1 with zero-centred means: large cancellation-free LL
         else:
