@@ -909,8 +909,12 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
     // staged |x| above the bound sends its tile to the exact path like a non-finite value does.
     // kernels with the LDS-table pipeline (unit hint, CB <= 2) or with wide channel blocks on the scalar-cache tables
     constexpr bool kWide = (CB > 2);
-    bool expand_all = (DIST == 0) && (DPK_NO_EXPAND == 0) && (DEPTH == 0 || a.leaf_out == nullptr) &&
-                      (kWide || (!GEN && (SPL == 2) && a.tabcap > 0));
+    bool expand_all;
+    if constexpr (kWide)
+        expand_all = (DIST == 0) && (DPK_NO_EXPAND == 0) && (DEPTH == 0 || a.leaf_out == nullptr);
+    else
+        expand_all = (DIST == 0) && !GEN && (SPL == 2) && a.tabcap > 0 && (DPK_NO_EXPAND == 0) &&
+                     (DEPTH == 0 || a.leaf_out == nullptr);
     if (expand_all) {
         // lanes read the flags in parallel (a serial scalar loop costs ~150 ns per region)
         bool ok = true;
