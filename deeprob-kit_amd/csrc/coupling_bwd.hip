@@ -25,6 +25,7 @@ struct GemmArgs {
     const float *gate;     // result zeroed where gate[m*ldg + n] <= 0
     int64_t ldg;
     int relu, accumulate;
+    int ksplit, kchunk;    // > 1: blockIdx.z owns K range [z*kchunk, (z+1)*kchunk), partial sums meet by atomicAdd
 };
 
 constexpr int kGT = 64, kGK = 16;
@@ -39,7 +40,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const bool a_kfast = g.sak == 1, b_nfast = g.sbn == 1;
-    for (int k0 = 0; k0 < g.K; k0 += kGK) {
+    const int kbeg = (g.ksplit > 1) ? (int)blockIdx.z * g.kchunk : 0;
+    const int kend = (g.ksplit > 1) ? min(g.K, kbeg + g.kchunk) : g.K;
+    for (int k0 = kbeg; k0 < kend; k0 += kGK) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -47,14 +50,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
             // A tile 64 x 16, B tile 16 x 64; thread order follows the contiguous axis of the operand
             const int am = a_kfast ? e / kGK : e % kGT, ak = a_kfast ? e % kGK : e / kGT;
             float av = 0.f;
-            if (m0 + am < g.M && k0 + ak < g.K) {
+            if (m0 + am < g.M && k0 + ak < kend) {
                 av = g.A[(int64_t)(m0 + am) * g.sam + (int64_t)(k0 + ak) * g.sak];
                 if (g.kscale) av *= g.kscale[k0 + ak];
             }
             As[am][ak] = av;
             const int bk = b_nfast ? e / kGT : e % kGK, bn = b_nfast ? e % kGT : e / kGK;
             float bv = 0.f;
-            if (k0 + bk < g.K && n0 + bn < g.N) bv = g.Bm[(int64_t)(k0 + bk) * g.sbk + (int64_t)(n0 + bn) * g.sbn];
+            if (k0 + bk < kend && n0 + bn < g.N) bv = g.Bm[(int64_t)(k0 + bk) * g.sbk + (int64_t)(n0 + bn) * g.sbn];
             Bs[bk][bn] = bv;
         }
         __syncthreads();
@@ -68,6 +71,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     const int n = n0 + wn + (lane & 31);
     if (n >= g.N) return;
     const float ns = g.nscale ? g.nscale[n] : 1.f, bs = g.bias ? g.bias[n] : 0.f;
+    if (g.ksplit > 1) {
+        // split-K: raw partial sums (times the per-column scale, which is linear) are added into C; bias / ReLU /
+        // gate are applied by gemm_epilogue_kernel once every slice has landed
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < g.M) atomicAdd(g.C + (int64_t)m * g.ldc + n, acc[r] * ns);
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -81,8 +94,49 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     }
 }
 
-static void launch_gemm(const GemmArgs &g, hipStream_t st) {
-    if (g.M <= 0 || g.N <= 0) return;
+// bias / ReLU / gate of a split-K product (the per-column scale was applied to the partial sums; with a bias the
+// scale is 1 in every call site, so the order bias -> relu -> scale of the unsplit epilogue is preserved)
+__global__ void gemm_epilogue_kernel(const GemmArgs g) {
+    const int64_t total = (int64_t)g.M * g.N;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(e % g.N);
+        const int64_t m = e / g.N;
+        float v = g.C[m * g.ldc + n] + (g.bias ? g.bias[n] : 0.f);
+        if (g.relu) v = fmaxf(v, 0.f);
+        if (g.gate && !(g.gate[m * g.ldg + n] > 0.f)) v = 0.f;
+        g.C[m * g.ldc + n] = v;
+    }
+}
+
+// Few output tiles and a long K (the training-batch products dH = dZ W2, H = x W1^T, dW = dOut^T In): split K over
+// blockIdx.z so that the grid fills the chip; partial sums meet by atomicAdd.
+static void launch_gemm(const GemmArgs &g_in, hipStream_t st) {
+    if (g_in.M <= 0 || g_in.N <= 0) return;
+    GemmArgs g = g_in;
+    const int tiles = cdiv(g.N, kGT) * cdiv(g.M, kGT);
+    int ksplit = 1;
+    if (tiles < 128 && g.K >= 256 && !(g.bias && g.nscale)) {
+        ksplit = 256 / tiles;
+        const int max_split = g.K / 64;                       // at least 64 of K per slice
+        if (ksplit > max_split) ksplit = max_split;
+        if (ksplit > 32) ksplit = 32;
+    }
+    if (ksplit > 1) {
+        g.kchunk = (int)align_up(cdiv(g.K, ksplit), kGK);
+        g.ksplit = cdiv(g.K, g.kchunk);
+        if (!g.accumulate) {
+            if (g.ldc == g.N) (void)hipMemsetAsync(g.C, 0, (size_t)g.M * g.N * 4, st);
+            else (void)hipMemset2DAsync(g.C, (size_t)g.ldc * 4, 0, (size_t)g.N * 4, (size_t)g.M, st);
+        }
+        hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(g.N, kGT), cdiv(g.M, kGT), g.ksplit), dim3(256), 0, st, g);
+        if (g.bias || g.relu || g.gate) {
+            const int64_t total = (int64_t)g.M * g.N;
+            const int64_t nb = (total + 255) / 256;
+            hipLaunchKernelGGL(gemm_epilogue_kernel, dim3((int)(nb > 4096 ? 4096 : nb)), dim3(256), 0, st, g);
+        }
+        return;
+    }
+    g.ksplit = 1;
     hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(g.N, kGT), cdiv(g.M, kGT)), dim3(256), 0, st, g);
 }
 
