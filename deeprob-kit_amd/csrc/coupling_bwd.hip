@@ -28,8 +28,11 @@ struct GemmArgs {
     int ksplit, kchunk;    // > 1: blockIdx.z owns K range [z*kchunk, (z+1)*kchunk), partial sums meet by atomicAdd
 };
 
-constexpr int kGT = 64, kGK = 16;
+constexpr int kGT = 64, kGK = 64;
 
+// 64 x 64 output tile per work-group, K walked in slabs of 64: the next slab's operands are fetched into registers
+// (16 + 16 loads in flight per thread) before the MFMAs of the current one, so a slab costs max(load latency, MFMA
+// time) instead of their sum; products too small to fill the chip are split over K by launch_gemm.
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     __shared__ float As[kGT][kGK + 1];
     __shared__ float Bs[kGK][kGT + 1];
@@ -42,26 +45,38 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     const bool a_kfast = g.sak == 1, b_nfast = g.sbn == 1;
     const int kbeg = (g.ksplit > 1) ? (int)blockIdx.z * g.kchunk : 0;
     const int kend = (g.ksplit > 1) ? min(g.K, kbeg + g.kchunk) : g.K;
-    for (int k0 = kbeg; k0 < kend; k0 += kGK) {
-        __syncthreads();
+    constexpr int kPer = kGT * kGK / 256;
+    float ar[kPer], br[kPer];
+    // thread order follows the contiguous axis of the operand
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < kPer; ++i) {
             const int e = tid + i * 256;
-            // A tile 64 x 16, B tile 16 x 64; thread order follows the contiguous axis of the operand
             const int am = a_kfast ? e / kGK : e % kGT, ak = a_kfast ? e % kGK : e / kGT;
             float av = 0.f;
             if (m0 + am < g.M && k0 + ak < kend) {
                 av = g.A[(int64_t)(m0 + am) * g.sam + (int64_t)(k0 + ak) * g.sak];
                 if (g.kscale) av *= g.kscale[k0 + ak];
             }
-            As[am][ak] = av;
+            ar[i] = av;
             const int bk = b_nfast ? e / kGT : e % kGK, bn = b_nfast ? e % kGT : e / kGK;
             float bv = 0.f;
             if (k0 + bk < kend && n0 + bn < g.N) bv = g.Bm[(int64_t)(k0 + bk) * g.sbk + (int64_t)(n0 + bn) * g.sbn];
-            Bs[bk][bn] = bv;
+            br[i] = bv;
         }
+    };
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += kGK) {
         __syncthreads();
 #pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const int e = tid + i * 256;
+            As[a_kfast ? e / kGK : e % kGT][a_kfast ? e % kGK : e / kGT] = ar[i];
+            Bs[b_nfast ? e / kGT : e % kGK][b_nfast ? e % kGT : e / kGK] = br[i];
+        }
+        __syncthreads();
+        if (k0 + kGK < kend) fetch(k0 + kGK);
+#pragma unroll 8
         for (int kk = 0; kk < kGK; kk += 2) {
             const float a = As[wm + (lane & 31)][kk + (lane >> 5)];
             const float b = Bs[kk + (lane >> 5)][wn + (lane & 31)];
@@ -115,11 +130,11 @@ static void launch_gemm(const GemmArgs &g_in, hipStream_t st) {
     GemmArgs g = g_in;
     const int tiles = cdiv(g.N, kGT) * cdiv(g.M, kGT);
     int ksplit = 1;
-    if (tiles < 128 && g.K >= 256 && !(g.bias && g.nscale)) {
-        ksplit = 256 / tiles;
-        const int max_split = g.K / 64;                       // at least 64 of K per slice
+    constexpr int target = 1024;                              // about four work-groups per compute unit
+    if (tiles < target / 2 && g.K >= 2 * kGK && !(g.bias && g.nscale)) {
+        ksplit = cdiv(target, tiles);
+        const int max_split = cdiv(g.K, kGK);
         if (ksplit > max_split) ksplit = max_split;
-        if (ksplit > 32) ksplit = 32;
     }
     if (ksplit > 1) {
         g.kchunk = (int)align_up(cdiv(g.K, ksplit), kGK);
@@ -140,17 +155,34 @@ static void launch_gemm(const GemmArgs &g_in, hipStream_t st) {
     hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(g.N, kGT), cdiv(g.M, kGT)), dim3(256), 0, st, g);
 }
 
-// column sums over the batch: out[n] = sum_m src[m*ld + n]   (64 columns x 4 row groups per block)
-__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ src, int64_t M, int N, int64_t ld,
-                                                     float *__restrict__ out) {
-    __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+// Column reducers over the batch: a work-group of 1024 threads owns kRC = 16 adjacent columns, its 64 row groups
+// stride the batch (a training batch of 512 rows leaves 8 loads per thread; 64-column blocks left the chip to
+// a dozen work-groups).  colblock_sum returns the column total to every thread of that column.
+constexpr int kRC = 16;
+constexpr int kRThreads = 1024;
+__device__ inline float colblock_sum(float v, float (*red)[kRC]) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane < kRC) red[wave][lane] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < kRThreads / 64; ++w) s += red[w][threadIdx.x & (kRC - 1)];
+    return s;
+}
+
+// out[n] = sum_m src[m*ld + n]
+__global__ __launch_bounds__(kRThreads) void colsum_kernel(const float *__restrict__ src, int64_t M, int N, int64_t ld,
+                                                           float *__restrict__ out) {
+    __shared__ float red[kRThreads / 64][kRC];
+    const int c = blockIdx.x * kRC + (threadIdx.x & (kRC - 1)), rg = threadIdx.x >> 4;
     float s = 0.f;
     if (c < N)
-        for (int64_t m = rg; m < M; m += 4) s += src[m * ld + c];
-    red[rg][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (rg == 0 && c < N) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        for (int64_t m = rg; m < M; m += kRThreads / kRC) s += src[m * ld + c];
+    s = colblock_sum(s, red);
+    if (rg == 0 && c < N) out[c] = s;
 }
 
 // element-wise core of the coupling backward.  Z holds [t_hat | s_hat] (affine) or z (NICE); it is
@@ -194,9 +226,15 @@ __global__ __launch_bounds__(256) void coupling_bwd_elem_kernel(const float *__r
             gx[e] = g;
         }
     }
-    if (affine && gact) {
+    if (affine && gact) {   // one atomic per work-group (every wave adding on its own serialised on the one address)
+        __shared__ float wsum[4];
         da = wave_reduce_sum(da);
-        if ((threadIdx.x & 63) == 0 && da != 0.f) atomicAdd(gact, da);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = da;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float t = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+            if (t != 0.f) atomicAdd(gact, t);
+        }
     }
 }
 
@@ -205,34 +243,32 @@ __global__ __launch_bounds__(256) void coupling_bwd_elem_kernel(const float *__r
 // ---------------------------------------------------------------------------------------------------------
 // per-column mean and unbiased variance over the batch (two passes), running statistics updated in place,
 // and the affine (scale, shift) + constant log-det of the transformation with these statistics.
-__global__ __launch_bounds__(256) void bn1d_stats_kernel(const float *__restrict__ x, int64_t B, int D,
-                                                         const float *__restrict__ weight,
-                                                         const float *__restrict__ bias, float momentum, float eps,
-                                                         float *__restrict__ running_var,
-                                                         float *__restrict__ running_mean, float *__restrict__ mean_out,
-                                                         float *__restrict__ var_out, float *__restrict__ scale_out,
-                                                         float *__restrict__ shift_out, float *__restrict__ ldj_const) {
-    __shared__ float red[4][64];
-    const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + col;
+__global__ __launch_bounds__(kRThreads) void bn1d_stats_kernel(const float *__restrict__ x, int64_t B, int D,
+                                                               const float *__restrict__ weight,
+                                                               const float *__restrict__ bias, float momentum, float eps,
+                                                               float *__restrict__ running_var,
+                                                               float *__restrict__ running_mean,
+                                                               float *__restrict__ mean_out, float *__restrict__ var_out,
+                                                               float *__restrict__ scale_out,
+                                                               float *__restrict__ shift_out,
+                                                               float *__restrict__ ldj_const) {
+    __shared__ float red[kRThreads / 64][kRC];
+    const int c = blockIdx.x * kRC + (threadIdx.x & (kRC - 1)), rg = threadIdx.x >> 4;
+    constexpr int kStep = kRThreads / kRC;
     float s = 0.f;
     if (c < D)
-        for (int64_t b = rg; b < B; b += 4) s += x[b * D + c];
-    red[rg][col] = s;
-    __syncthreads();
-    const float mean = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) / (float)B;
-    __syncthreads();
+        for (int64_t b = rg; b < B; b += kStep) s += x[b * D + c];
+    const float mean = colblock_sum(s, red) / (float)B;
     float q = 0.f;
     if (c < D)
-        for (int64_t b = rg; b < B; b += 4) {
+        for (int64_t b = rg; b < B; b += kStep) {
             const float dlt = x[b * D + c] - mean;
             q = fmaf(dlt, dlt, q);
         }
-    red[rg][col] = q;
-    __syncthreads();
+    q = colblock_sum(q, red);
     float term = 0.f;
     if (rg == 0 && c < D) {
-        const float var = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) / (float)(B - 1);
+        const float var = q / (float)(B - 1);
         running_var[c] = running_var[c] * momentum + var * (1.f - momentum);
         running_mean[c] = running_mean[c] * momentum + mean * (1.f - momentum);
         mean_out[c] = mean;
@@ -243,35 +279,34 @@ __global__ __launch_bounds__(256) void bn1d_stats_kernel(const float *__restrict
         shift_out[c] = bias[c] - mean * sc;
         term = weight[c] - 0.5f * logf(ve);
     }
-    if (rg == 0) {
+    if (threadIdx.x < 64) {   // rg == 0 lives in lanes 0..15 of wave 0
         term = wave_reduce_sum(term);
-        if (col == 0) atomicAdd(ldj_const, term);
+        if (threadIdx.x == 0) atomicAdd(ldj_const, term);
     }
 }
 
 // column reductions of the backward: s1[d] = sum_b g_u, s2[d] = sum_b g_u * xhat
-__global__ __launch_bounds__(256) void bn1d_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ gu,
-                                                              int64_t B, int D, const float *__restrict__ mean,
-                                                              const float *__restrict__ var, float eps,
-                                                              float *__restrict__ s1, float *__restrict__ s2) {
-    __shared__ float r1[4][64], r2[4][64];
-    const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + col;
+__global__ __launch_bounds__(kRThreads) void bn1d_bwd_reduce_kernel(const float *__restrict__ x,
+                                                                    const float *__restrict__ gu, int64_t B, int D,
+                                                                    const float *__restrict__ mean,
+                                                                    const float *__restrict__ var, float eps,
+                                                                    float *__restrict__ s1, float *__restrict__ s2) {
+    __shared__ float red[kRThreads / 64][kRC];
+    const int c = blockIdx.x * kRC + (threadIdx.x & (kRC - 1)), rg = threadIdx.x >> 4;
     float a1 = 0.f, a2 = 0.f;
     if (c < D) {
         const float mu = mean[c], is = 1.f / sqrtf(var[c] + eps);
-        for (int64_t b = rg; b < B; b += 4) {
+        for (int64_t b = rg; b < B; b += kRThreads / kRC) {
             const float g = gu[b * D + c];
             a1 += g;
             a2 = fmaf(g, (x[b * D + c] - mu) * is, a2);
         }
     }
-    r1[rg][col] = a1;
-    r2[rg][col] = a2;
-    __syncthreads();
+    a1 = colblock_sum(a1, red);
+    a2 = colblock_sum(a2, red);
     if (rg == 0 && c < D) {
-        s1[c] = (r1[0][col] + r1[1][col]) + (r1[2][col] + r1[3][col]);
-        s2[c] = (r2[0][col] + r2[1][col]) + (r2[2][col] + r2[3][col]);
+        s1[c] = a1;
+        s2[c] = a2;
     }
 }
 
@@ -424,7 +459,7 @@ extern "C" int dpk_coupling1d_backward(const float *x, int64_t B, int32_t D, con
     g.C = Z; g.ldc = zc; g.M = (int)B; g.N = zc; g.K = units; g.bias = b2;
     launch_gemm(g, st);
     // element-wise core: Z <- dZ, grad_x <- direct term
-    hipLaunchKernelGGL(coupling_bwd_elem_kernel, dim3(grid1d(B * D)), dim3(256), 0, st, x, Z, inv_mask, act_weight,
+    hipLaunchKernelGGL(coupling_bwd_elem_kernel, dim3(grid1d(B * D, 256, 1024)), dim3(256), 0, st, x, Z, inv_mask, act_weight,
                        grad_u, grad_ildj, B, D, affine, grad_x, grad_act);
     // dW2 = dZ^T H, db2 = colsum(dZ)
     if (grad_W2) {
@@ -434,7 +469,7 @@ extern "C" int dpk_coupling1d_backward(const float *x, int64_t B, int32_t D, con
         g.C = grad_W2; g.ldc = units; g.M = zc; g.N = units; g.K = (int)B;
         launch_gemm(g, st);
     }
-    if (grad_b2) hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(zc, 64)), dim3(256), 0, st, Z, B, zc, (int64_t)zc, grad_b2);
+    if (grad_b2) hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(zc, kRC)), dim3(kRThreads), 0, st, Z, B, zc, (int64_t)zc, grad_b2);
     // dH = (dZ W2) * [H > 0]
     g = GemmArgs{};
     g.A = Z; g.sam = zc; g.sak = 1;
@@ -450,7 +485,7 @@ extern "C" int dpk_coupling1d_backward(const float *x, int64_t B, int32_t D, con
         launch_gemm(g, st);
     }
     if (grad_b1)
-        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(units, 64)), dim3(256), 0, st, dH, B, units, (int64_t)units, grad_b1);
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(units, kRC)), dim3(kRThreads), 0, st, dH, B, units, (int64_t)units, grad_b1);
     // grad_x += mask * (dH W1)
     g = GemmArgs{};
     g.A = dH; g.sam = units; g.sak = 1;
@@ -475,7 +510,7 @@ extern "C" int dpk_bn1d_train_forward(const float *x, int64_t B, int32_t D, cons
     hipStream_t st = (hipStream_t)stream;
     float *sc = (float *)ws, *sh = sc + D;
     DPK_REQUIRE(hipMemsetAsync(ildj_const, 0, 4, st) == hipSuccess, DPK_ELAUNCH, "memset");
-    hipLaunchKernelGGL(bn1d_stats_kernel, dim3(cdiv(D, 64)), dim3(256), 0, st, x, B, D, weight, bias, momentum, eps,
+    hipLaunchKernelGGL(bn1d_stats_kernel, dim3(cdiv(D, kRC)), dim3(kRThreads), 0, st, x, B, D, weight, bias, momentum, eps,
                        running_var, running_mean, save_mean, save_var, sc, sh, ildj_const);
     DPK_CHECK_LAUNCH("bn1d_stats_kernel");
     return dpk_affine1d_forward(x, sc, sh, B, D, out, stream);
@@ -494,7 +529,7 @@ extern "C" int dpk_bn1d_backward(const float *x, const float *grad_u, const floa
     hipStream_t st = (hipStream_t)stream;
     float *s1 = (float *)ws, *s2 = s1 + D, *sg = s2 + D;
     if (grad_ildj) hipLaunchKernelGGL(vecsum_kernel, dim3(1), dim3(256), 0, st, grad_ildj, B, sg);
-    hipLaunchKernelGGL(bn1d_bwd_reduce_kernel, dim3(cdiv(D, 64)), dim3(256), 0, st, x, grad_u, B, D, mean, var, eps, s1,
+    hipLaunchKernelGGL(bn1d_bwd_reduce_kernel, dim3(cdiv(D, kRC)), dim3(kRThreads), 0, st, x, grad_u, B, D, mean, var, eps, s1,
                        s2);
     hipLaunchKernelGGL(bn1d_bwd_apply_kernel, dim3(grid1d(B * D)), dim3(256), 0, st, x, grad_u,
                        grad_ildj ? sg : nullptr, B, D, weight, mean, var, eps, s1, s2, train, grad_x, grad_weight,
@@ -610,8 +645,8 @@ extern "C" int dpk_coupling1d_mlp_backward(const float *x, int64_t B, int32_t D,
                                            const float *inv_mask, int32_t n_hidden, const float *const *W,
                                            const float *const *b, const int32_t *widths, const float *act_weight,
                                            int32_t affine, const float *grad_u, const float *grad_ildj, float *grad_x,
-                                           float *const *grad_W, float *const *grad_b, float *grad_act, void *ws,
-                                           int64_t ws_bytes, void *stream) {
+                                           float *const *grad_W, float *const *grad_b, float *grad_act,
+                                           int32_t ws_holds_forward, void *ws, int64_t ws_bytes, void *stream) {
     int rc = mlp_check(B, D, n_hidden, W, b, widths, affine, "coupling1d_mlp_backward");
     if (rc) return rc;
     DPK_REQUIRE(mask && inv_mask && ws, DPK_EINVAL, "coupling1d_mlp_backward: null pointer");
@@ -631,8 +666,8 @@ extern "C" int dpk_coupling1d_mlp_backward(const float *x, int64_t B, int32_t D,
         return DPK_OK;
     }
     DPK_REQUIRE(x && grad_x && (grad_u || grad_ildj), DPK_EINVAL, "coupling1d_mlp_backward: null pointer");
-    mlp_forward(w, x, B, D, mask, n_hidden, W, b, widths, st);
-    hipLaunchKernelGGL(coupling_bwd_elem_kernel, dim3(grid1d(B * D)), dim3(256), 0, st, x, w.Z, inv_mask, act_weight,
+    if (!ws_holds_forward) mlp_forward(w, x, B, D, mask, n_hidden, W, b, widths, st);
+    hipLaunchKernelGGL(coupling_bwd_elem_kernel, dim3(grid1d(B * D, 256, 1024)), dim3(256), 0, st, x, w.Z, inv_mask, act_weight,
                        grad_u, grad_ildj, B, D, affine, grad_x, grad_act);
     // back through the layers: dOut starts as dZ (in w.Z)
     float *dout = w.Z;
@@ -650,7 +685,7 @@ extern "C" int dpk_coupling1d_mlp_backward(const float *x, int64_t B, int32_t D,
             launch_gemm(g, st);
         }
         if (grad_b && grad_b[i])
-            hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(ow, 64)), dim3(256), 0, st, dout, B, ow, (int64_t)ow, grad_b[i]);
+            hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(ow, kRC)), dim3(kRThreads), 0, st, dout, B, ow, (int64_t)ow, grad_b[i]);
         g = GemmArgs{};
         g.A = dout; g.sam = ow; g.sak = 1;
         g.Bm = W[i]; g.sbk = in_w; g.sbn = 1;

@@ -81,7 +81,7 @@ SIGNATURES = {
                                                   _c_void, _i32, _i32, _c_void, _c_void, _c_void, _i64, _c_void]),
     'dpk_coupling1d_mlp_backward': (ctypes.c_int, [_c_void, _i64, _i32, _c_void, _c_void, _i32, _c_void, _c_void,
                                                    _c_void, _c_void, _i32, _c_void, _c_void, _c_void, _c_void, _c_void,
-                                                   _c_void, _c_void, _i64, _c_void]),
+                                                   _c_void, _i32, _c_void, _i64, _c_void]),
     'dpk_bn1d_train_forward': (ctypes.c_int, [_c_void, _i64, _i32, _c_void, _c_void, _c_void, _c_void, ctypes.c_float,
                                               ctypes.c_float, _c_void, _c_void, _c_void, _c_void, _c_void, _i64,
                                               _c_void]),

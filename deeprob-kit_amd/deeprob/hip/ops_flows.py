@@ -72,24 +72,40 @@ def _mlp_args(layer):
     return n - 1, Wp, bp, widths, (ws, bs)
 
 
-def _coupling1d_mlp(x: torch.Tensor, layer, inverse: bool) -> Tuple[torch.Tensor, torch.Tensor]:
-    """CouplingLayer1d with any conditioner depth (reference: coupling.py:45-56, :72-104)."""
+# a training forward keeps the conditioner activations for its backward while they fit this many bytes per layer call
+# (beyond it the backward evaluates the conditioner again)
+KEEP_ACTIVATIONS_BYTES = 1 << 30
+
+
+def _mlp_backward_bytes(B: int, n_hidden: int, widths) -> int:
+    n = load_library().dpk_coupling1d_mlp_workspace_bytes(B, n_hidden, widths, 1)
+    if n < 0:
+        check(int(n), 'dpk_coupling1d_mlp_workspace_bytes')
+    return int(n)
+
+
+def _coupling1d_mlp(x: torch.Tensor, layer, inverse: bool, keep: bool = False):
+    """CouplingLayer1d with any conditioner depth (reference: coupling.py:45-56, :72-104).  keep: the workspace
+    is a fresh buffer laid out for the backward, returned as third value (it holds the conditioner activations)."""
     lib = load_library()
     layer._mask_counts()
     B, D = x.shape
-    n_hidden, Wp, bp, widths, keep = _mlp_args(layer)
-    n = lib.dpk_coupling1d_mlp_workspace_bytes(B, n_hidden, widths, 0)
-    if n < 0:
-        check(int(n), 'dpk_coupling1d_mlp_workspace_bytes')
-    ws = layer._ws.get(n, x.device)
+    n_hidden, Wp, bp, widths, alive = _mlp_args(layer)
+    if keep:
+        ws = torch.empty(_mlp_backward_bytes(B, n_hidden, widths), dtype=torch.uint8, device=x.device)
+    else:
+        n = lib.dpk_coupling1d_mlp_workspace_bytes(B, n_hidden, widths, 0)
+        if n < 0:
+            check(int(n), 'dpk_coupling1d_mlp_workspace_bytes')
+        ws = layer._ws.get(n, x.device)
     out = torch.empty_like(x)
     ldj = torch.empty(B, dtype=torch.float32, device=x.device)
     act = layer.scale_act.weight if layer.affine else None
     check(lib.dpk_coupling1d_mlp_forward(ptr(x), B, D, ptr(layer.mask), ptr(layer.inv_mask), n_hidden, Wp, bp, widths,
                                          ptr(act), int(layer.affine), int(inverse), ptr(out), ptr(ldj), ptr(ws),
                                          ws.numel(), stream_ptr(x.device)), 'dpk_coupling1d_mlp_forward')
-    del keep
-    return out, ldj
+    del alive
+    return (out, ldj, ws) if keep else (out, ldj)
 
 
 def bn1d_fold(bn, inverse: bool, in_affine=None, ldj_const: Optional[torch.Tensor] = None):
@@ -184,7 +200,13 @@ class CouplingMlpFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, layer, x, act, *params):
-        u, ildj = _coupling1d_mlp(x, layer, inverse=False)
+        widths = [w.shape[0] for w in params[0::2]]
+        import ctypes
+        need = _mlp_backward_bytes(x.shape[0], len(widths) - 1, (ctypes.c_int32 * len(widths))(*widths))
+        if need <= KEEP_ACTIVATIONS_BYTES:
+            u, ildj, ctx.kept = _coupling1d_mlp(x, layer, inverse=False, keep=True)
+        else:
+            (u, ildj), ctx.kept = _coupling1d_mlp(x, layer, inverse=False), None
         ctx.save_for_backward(x, act, *params)
         ctx.layer = layer
         return u, ildj
@@ -210,14 +232,13 @@ class CouplingMlpFn(torch.autograd.Function):
         widths = (ctypes.c_int32 * n)(*[w.shape[0] for w in ws_t])
         gx = torch.empty_like(x)
         gact = torch.empty_like(act) if (act is not None and need[2]) else None
-        nb = lib.dpk_coupling1d_mlp_workspace_bytes(B, n - 1, widths, 1)
-        if nb < 0:
-            check(int(nb), 'dpk_coupling1d_mlp_workspace_bytes')
-        ws = layer._ws_bwd.get(nb, x.device)
+        kept = ctx.kept
+        ctx.kept = None   # a second backward through the same node evaluates the conditioner again
+        ws = kept if kept is not None else layer._ws_bwd.get(_mlp_backward_bytes(B, n - 1, widths), x.device)
         check(lib.dpk_coupling1d_mlp_backward(ptr(x), B, D, ptr(layer.mask), ptr(layer.inv_mask), n - 1, Wp, bp, widths,
                                               ptr(act), int(layer.affine), ptr(gu), ptr(gildj), ptr(gx), gWp, gbp,
-                                              ptr(gact), ptr(ws), ws.numel(), stream_ptr(x.device)),
-              'dpk_coupling1d_mlp_backward')
+                                              ptr(gact), int(kept is not None), ptr(ws), ws.numel(),
+                                              stream_ptr(x.device)), 'dpk_coupling1d_mlp_backward')
         grads = []
         for gw, gb in zip(gws, gbs):
             grads += [gw, gb]
@@ -232,10 +253,15 @@ def coupling1d_autograd(x: torch.Tensor, layer) -> Tuple[torch.Tensor, torch.Ten
     if not _wants_graph(x, act, *[t for m in lins for t in (m.weight, m.bias)]):
         return coupling1d(x, layer, inverse=False)
     layer._mask_counts()   # binary-mask check
-    if len(lins) != 2:
+    x = require_device_f32(x, 'x')
+    import ctypes
+    widths = (ctypes.c_int32 * len(lins))(*[m.weight.shape[0] for m in lins])
+    if len(lins) != 2 or _mlp_backward_bytes(x.shape[0], len(lins) - 1, widths) <= KEEP_ACTIVATIONS_BYTES:
+        # GEMM-chained conditioner whose activations stay resident for the backward
         flat = [require_device_f32(t, 'parameter') for m in lins for t in (m.weight, m.bias)]
-        return CouplingMlpFn.apply(layer, require_device_f32(x, 'x'), act, *flat)
-    return CouplingFn.apply(require_device_f32(x, 'x'), require_device_f32(lin1.weight, 'W1'),
+        return CouplingMlpFn.apply(layer, x, act, *flat)
+    # too large to keep: fused forward, conditioner evaluated again in the backward
+    return CouplingFn.apply(x, require_device_f32(lin1.weight, 'W1'),
                             require_device_f32(lin1.bias, 'b1'), require_device_f32(lin2.weight, 'W2'),
                             require_device_f32(lin2.bias, 'b2'), act, layer)
 

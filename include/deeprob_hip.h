@@ -244,7 +244,11 @@ int dpk_coupling1d_backward(const float *x, int64_t B, int32_t D, const float *m
  * b[i] [widths[i]] for i = 0..n_hidden are HOST arrays of device pointers, widths[n_hidden] = 2D (affine) or D;
  * the MLP is chained through the generic fp32-MFMA GEMM kernel.  forward: inverse = 0 apply_backward, 1
  * apply_forward; ldj is overwritten.  backward: as dpk_coupling1d_backward, grad_W / grad_b host arrays of
- * device pointers (entries or the arrays may be NULL).  1 <= n_hidden <= 8.                              */
+ * device pointers (entries or the arrays may be NULL).  1 <= n_hidden <= 8.
+ * The forward's workspace layout (hidden activations, conditioner output) is a prefix of the backward's:
+ * ws_holds_forward != 0 tells the backward that `ws` (sized for backward = 1) still holds what
+ * dpk_coupling1d_mlp_forward(inverse = 0) left there for the same x and parameters, so the conditioner is
+ * not evaluated again; 0 recomputes it.                                                                   */
 int64_t dpk_coupling1d_mlp_workspace_bytes(int64_t B, int32_t n_hidden, const int32_t *widths, int32_t backward);
 int dpk_coupling1d_mlp_forward(const float *x, int64_t B, int32_t D, const float *mask, const float *inv_mask,
                                int32_t n_hidden, const float *const *W, const float *const *b, const int32_t *widths,
@@ -253,8 +257,8 @@ int dpk_coupling1d_mlp_forward(const float *x, int64_t B, int32_t D, const float
 int dpk_coupling1d_mlp_backward(const float *x, int64_t B, int32_t D, const float *mask, const float *inv_mask,
                                 int32_t n_hidden, const float *const *W, const float *const *b, const int32_t *widths,
                                 const float *act_weight, int32_t affine, const float *grad_u, const float *grad_ildj,
-                                float *grad_x, float *const *grad_W, float *const *grad_b, float *grad_act, void *ws,
-                                int64_t ws_bytes, void *stream);
+                                float *grad_x, float *const *grad_W, float *const *grad_b, float *grad_act,
+                                int32_t ws_holds_forward, void *ws, int64_t ws_bytes, void *stream);
 /* Training-mode BatchNormLayer1d.apply_backward (flows/utils.py:118-139): torch.var_mean over the batch
  * (unbiased), running_var / running_mean updated IN PLACE with `momentum`, out = (x-mean)/sqrt(var+eps)
  * * exp(weight) + bias, ildj_const[0] = sum_d(weight_d - 0.5 log(var_d+eps)); save_mean/save_var [D]

@@ -91,12 +91,18 @@ def test_full_size_round_trip():
     assert torch.equal(ll[777:777 + 4097], part)
 
 
+@pytest.mark.parametrize('keep', [True, False], ids=['kept-activations', 'recompute'])
 @pytest.mark.parametrize('name', sorted(__import__('tests.flow_cases', fromlist=['TRAIN_CASES']).TRAIN_CASES))
-def test_training_route_golden(golden, name):
+def test_training_route_golden(golden, name, keep, monkeypatch):
     """Autograd through the HIP flow (coupling backward, train-mode batch norm, Normal / RAT-SPN base): LL, loss,
-    d/dx, every parameter gradient and the running statistics after the step, against the reference's."""
+    d/dx, every parameter gradient and the running statistics after the step, against the reference's.  Both
+    coupling routes: conditioner activations kept from the forward, or evaluated again in the backward (fused
+    forward kernel for the two-Linear conditioner)."""
     from tests.flow_cases import TRAIN_CASES, build_train_flow
     from tests.util import grad_err
+    from deeprob.hip import ops_flows
+    if not keep:
+        monkeypatch.setattr(ops_flows, 'KEEP_ACTIVATIONS_BYTES', 0)
     g = golden(name)
     train = TRAIN_CASES[name][1]
     model = build_train_flow(name, g).cuda()
@@ -125,6 +131,23 @@ def test_training_route_golden(golden, name):
     for k in g.files:
         if k.startswith('after.'):
             assert rel_err(sd[k[6:]].cpu().numpy(), g[k]) <= 1e-5, k
+
+
+def test_second_backward_through_kept_activations():
+    """retain_graph: the first backward consumes the kept conditioner output, the second evaluates it again."""
+    from deeprob.flows.models import RealNVP1d
+    torch.manual_seed(0)
+    flow = RealNVP1d(16, n_flows=2, units=16, batch_norm=False).cuda().train()
+    x = torch.randn(64, 16).cuda()
+    loss = flow.loss(flow(x))
+    loss.backward(retain_graph=True)
+    first = [p.grad.clone() for p in flow.parameters() if p.grad is not None]
+    flow.zero_grad()
+    loss.backward()
+    second = [p.grad for p in flow.parameters() if p.grad is not None]
+    assert len(first) == len(second) > 0
+    for a, b in zip(first, second):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
 
 
 def test_training_step_reduces_loss():
