@@ -305,6 +305,121 @@ __global__ void spatial_sum_bwd_kernel(const float *__restrict__ x, const float 
     }
 }
 
+// Cin, Cout <= 8 (the DGC-SPN defaults): thread = pixel x half of the input channels x slice of samples, with the
+// pixel's 8 x 4 linear weights and the batch sums of glw in registers.  pi[o,c] = W[o,c] e^{x_c - m} e^{m - out_o}
+// with m = max_c x_c: 12 exponentials per thread and sample instead of 32, gx written once.  m - out_o is bounded
+// by -log(max_c W[o,c]); an output whose bound leaves the fp32 range takes the exact log-domain expression.
+constexpr int kSp8C = 4;
+__global__ __launch_bounds__(256) void spatial_sum_bwd8_kernel(const float *__restrict__ x, const float *__restrict__ Wl,
+                                                               const float *__restrict__ LW,
+                                                               const float *__restrict__ out,
+                                                               const float *__restrict__ g, int64_t B, int Cin,
+                                                               int Cout, int HW, int bslice, float *__restrict__ gx,
+                                                               float *__restrict__ glw) {
+    const int p = min((int)(blockIdx.x * 64 + threadIdx.x), HW - 1);   // tail lanes shadow the last pixel, stores masked
+    const bool own = (int)(blockIdx.x * 64 + threadIdx.x) < HW;
+    const int c0 = blockIdx.z * kSp8C;
+    float w[8][kSp8C], acc[8][kSp8C];
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int q = 0; q < kSp8C; ++q) {
+            w[o][q] = (o < Cout && c0 + q < Cin) ? Wl[((int64_t)o * Cin + c0 + q) * HW + p] : 0.f;
+            acc[o][q] = 0.f;
+        }
+    // the slice index is uniform over the wave (blockDim.x = 64): sample offsets stay on the scalar unit
+    const int slice = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * blockDim.y + threadIdx.y));
+    const int64_t b0 = (int64_t)slice * bslice, b1 = min(b0 + bslice, B);
+    float nx[8], nxo[8], ng[8];   // inputs of the next sample, in flight under the arithmetic of the current one
+    const int cin1 = Cin - 1, cout1 = Cout - 1;
+    // padding rows (c >= Cin, o >= Cout) read a valid row and are replaced when consumed: no branch per load
+    auto fetch = [&](int64_t b) {
+        const float *xb = x + b * Cin * HW + p, *ob = out + b * Cout * HW + p, *gb = g + b * Cout * HW + p;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) nx[c] = xb[(int64_t)min(c, cin1) * HW];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            nxo[o] = ob[(int64_t)min(o, cout1) * HW];
+            ng[o] = gb[(int64_t)min(o, cout1) * HW];
+        }
+    };
+    if (b0 < b1) fetch(b0);
+    for (int64_t b = b0; b < b1; ++b) {
+        float xa[8], xo8[8], g8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            xa[i] = (i < Cin) ? nx[i] : -INFINITY;
+            xo8[i] = (i < Cout) ? nxo[i] : -INFINITY;
+            g8[i] = ng[i];
+        }
+        if (b + 1 < b1) fetch(b + 1);
+        float xv[kSp8C], ex[kSp8C], tot[kSp8C];
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) m = fmaxf(m, xa[c]);
+#pragma unroll
+        for (int q = 0; q < kSp8C; ++q) xv[q] = (blockIdx.z == 0) ? xa[q] : xa[kSp8C + q];
+        const float mm = (m > -INFINITY) ? m : 0.f;
+#pragma unroll
+        for (int q = 0; q < kSp8C; ++q) {
+            ex[q] = __expf(xv[q] - mm);
+            tot[q] = 0.f;
+        }
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const float xo = xo8[o], gv = g8[o];
+            if (!(xo > -INFINITY)) continue;   // also the padding outputs o >= Cout
+            const float d = mm - xo;
+            if (d < 80.f) {
+                const float eo = gv * __expf(d);
+#pragma unroll
+                for (int q = 0; q < kSp8C; ++q) {
+                    const float t = w[o][q] * ex[q] * eo;
+                    acc[o][q] += t;
+                    tot[q] += t;
+                }
+            } else {
+                const float *lwp = LW;
+                asm volatile("" : "+s"(lwp));   // keeps the rare path's 32 addresses out of the loop's registers
+#pragma unroll
+                for (int q = 0; q < kSp8C; ++q) {
+                    if (c0 + q >= Cin) break;
+                    const float t = gv * expf(xv[q] + lwp[((int64_t)o * Cin + c0 + q) * HW + p] - xo);
+                    acc[o][q] += t;
+                    tot[q] += t;
+                }
+            }
+        }
+        if (gx) {
+            float *gxb = gx + b * Cin * HW;
+#pragma unroll
+            for (int q = 0; q < kSp8C; ++q)
+                if (own && c0 + q < Cin) gxb[(int64_t)(c0 + q) * HW + p] = tot[q];
+        }
+    }
+    if (glw) {
+        // the four sample slices of the work-group meet in LDS; one wave's worth of atomics per work-group
+        __shared__ float red[3][8 * kSp8C][64];
+        if (threadIdx.y > 0) {
+#pragma unroll
+            for (int o = 0; o < 8; ++o)
+#pragma unroll
+                for (int q = 0; q < kSp8C; ++q) red[threadIdx.y - 1][o * kSp8C + q][threadIdx.x] = acc[o][q];
+        }
+        __syncthreads();
+        if (threadIdx.y == 0) {
+#pragma unroll
+            for (int o = 0; o < 8; ++o)
+#pragma unroll
+                for (int q = 0; q < kSp8C; ++q) {
+                    const float v = acc[o][q] + red[0][o * kSp8C + q][threadIdx.x] +
+                                    red[1][o * kSp8C + q][threadIdx.x] + red[2][o * kSp8C + q][threadIdx.x];
+                    if (own && o < Cout && c0 + q < Cin) atomicAdd(glw + ((int64_t)o * Cin + c0 + q) * HW + p, v);
+                }
+        }
+    }
+}
+
 // gW[o,c,p] = glw[o,c,p] - W[o,c,p] * sum_c glw[o,c,p]
 __global__ void spatial_softmax_jacobian_kernel(const float *__restrict__ glw, const float *__restrict__ Wl,
                                                 int Cout, int Cin, int HW, float *__restrict__ gW) {
@@ -660,9 +775,21 @@ extern "C" int dpk_spatial_sum_backward(const float *x, const float *weight, con
         DPK_REQUIRE(hipMemsetAsync(glw, 0, (size_t)Cout * Cin * HW * 4, st) == hipSuccess, DPK_ELAUNCH, "memset");
     if (B > 0) {
         DPK_REQUIRE(x && out && g, DPK_EINVAL, "spatial_sum_backward: null pointer");
-        const int bslice = 16;
-        hipLaunchKernelGGL(spatial_sum_bwd_kernel, dim3(cdiv((int64_t)Cin * HW, 256), cdiv(B, bslice)), dim3(256), 0,
-                           st, x, LW, out, g, B, Cin, Cout, HW, bslice, grad_x, grad_weight ? glw : nullptr);
+        if (Cin <= 8 && Cout <= 8) {
+            // about 8192 waves: (pixels / 64) columns x channel halves x sample slices of at least 8
+            const int64_t cols = cdiv(HW, 64), halves = cdiv(Cin, kSp8C);
+            int64_t slices = cdiv(8192, cols * halves);
+            int64_t bslice = cdiv(B, slices);
+            if (bslice < 8) bslice = 8;
+            slices = cdiv(B, bslice);
+            hipLaunchKernelGGL(spatial_sum_bwd8_kernel, dim3((unsigned)cols, (unsigned)cdiv(slices, 4), (unsigned)halves), dim3(64, 4), 0,
+                               st, x, Wl, LW, out, g, B, Cin, Cout, HW, (int)bslice, grad_x,
+                               grad_weight ? glw : nullptr);
+        } else {
+            const int bslice = 16;
+            hipLaunchKernelGGL(spatial_sum_bwd_kernel, dim3(cdiv((int64_t)Cin * HW, 256), cdiv(B, bslice)), dim3(256),
+                               0, st, x, LW, out, g, B, Cin, Cout, HW, bslice, grad_x, grad_weight ? glw : nullptr);
+        }
     }
     if (grad_weight)
         hipLaunchKernelGGL(spatial_softmax_jacobian_kernel, dim3(grid_cap((int64_t)Cout * HW, 256)), dim3(256), 0, st,

@@ -169,6 +169,30 @@ def test_random_shapes_against_oracle():
     assert rel_err(got.cpu().numpy(), want.numpy()) <= LL_TOL
 
 
+@pytest.mark.parametrize('cin,cout', [(8, 8), (6, 4), (3, 7), (12, 5)])
+def test_sum_backward_extreme_weights_against_oracle(cin, cout):
+    """SpatialSumLayer backward (register kernel for <= 8 channels, generic kernel above) against fp64 autograd of
+    the oracle: ordinary inputs, a dominant input under a vanishing weight (the exact log-domain branch), batch
+    sizes that leave ragged sample slices."""
+    from deeprob.spn.layers.dgcspn import SpatialSumLayer
+    gen = torch.Generator().manual_seed(11)
+    for B in (1, 37):
+        x = torch.randn(B, cin, 6, 6, generator=gen) * 3
+        x[:, 1] += 100.0                                   # channel 1 dominates every pixel ...
+        s = SpatialSumLayer((cin, 6, 6), cout).cuda()
+        with torch.no_grad():
+            s.weight[0, 1] = -200.0                        # ... and output 0 all but ignores it
+            s.weight[1, 1, 2, :] = -95.0
+        go = torch.randn(B, cout, 6, 6, generator=gen)
+        xd = x.cuda().requires_grad_(True)
+        s(xd).backward(go.cuda())
+        x64 = x.double().requires_grad_(True)
+        w64 = s.weight.detach().cpu().double().requires_grad_(True)
+        dorc.spatial_sum(x64, w64).backward(go.double())
+        assert grad_err(xd.grad.cpu().numpy(), x64.grad.numpy()) <= GRAD_TOL
+        assert grad_err(s.weight.grad.cpu().numpy(), w64.grad.numpy()) <= GRAD_TOL
+
+
 def test_empty_batch_and_errors():
     from deeprob.hip import HipError
     from deeprob.spn.models import DgcSpn
