@@ -319,6 +319,27 @@ int dpk_profile_next_kernel(void *ev_start, void *ev_stop);
  * the mean-LL all-reduce): acc[0] += sum(ll), acc[1] += n.                   */
 int dpk_ll_accumulate(const float *ll, int64_t n, double *acc, void *stream);
 
+/* ---- vanilla (node-graph) SPN, flattened (BASELINE config 1) ---------------------------------------------
+ * Bottom-up log-likelihood of deeprob/spn/algorithms/inference.py:37-58 (eval_bottom_up, evaluation.py:37-96;
+ * node values clamped at -1e31 and kept in float32, inference.py:94-103) for a circuit given as arrays over
+ * node ids 0..n_nodes-1 (the ids of the reference's JSON export, deeprob/spn/structure/io.py:133-175):
+ *   order [n_nodes]   evaluation order, children before parents
+ *   kind  [n_nodes]   0 Sum (node.py:116-117), 1 Product (node.py:152-153), 2 Bernoulli (leaf.py:182-186),
+ *                     3 Categorical (:301-305), 4 Uniform (:475-479), 5 Gaussian (:553-557)
+ *   inner nodes: arg0 = first entry in child_index / child_weight, arg1 = number of children;
+ *                child_weight = the sum node's (linear) weight per child, unused for products
+ *   leaves:      arg0 = input column; par0 / par1 (double) = log p, log1p(-p) | start, width | mean, stddev;
+ *                Categorical: arg1 = first entry in cat_value / cat_logp, arg2 = number of categories
+ * x [B, D] with NaN = marginalised.  out [B] = value of `root`; node_values (optional, [n_nodes, B]) receives
+ * every node's value (return_results = True).  Circuits above 256 nodes without node_values need a workspace
+ * of dpk_flat_spn_workspace_bytes.                                                                          */
+int64_t dpk_flat_spn_workspace_bytes(int64_t B, int32_t n_nodes);
+int dpk_flat_spn_forward(const float *x, int64_t B, int32_t D, int32_t n_nodes, int32_t root, const int32_t *order,
+                         const int32_t *kind, const int32_t *arg0, const int32_t *arg1, const int32_t *arg2,
+                         const double *par0, const double *par1, const int32_t *child_index,
+                         const float *child_weight, const int32_t *cat_value, const float *cat_logp, float *out,
+                         float *node_values, void *ws, int64_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
