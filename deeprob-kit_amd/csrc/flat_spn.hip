@@ -7,8 +7,10 @@
 //   leaves   leaf.py:182-186 (Bernoulli), :301-305 (Categorical), :475-479 (Uniform), :553-557 (Gaussian);
 //            0 where the input is NaN (marginalised)
 // Layout: lane = sample, the node loop is uniform over the wave (node records come through scalar loads); the
-// table of node values is [node][sample] -- in LDS (one 64-sample wave per work-group) when the circuit fits,
-// else in a caller-provided [n_nodes, B] buffer -- so every access is one 256-byte row per wave.
+// table of node values is [row][sample], so every access is one 256-byte row per wave.  In LDS (one 64-sample wave
+// per work-group) a node's row is a slot that the host recycles after the node's last parent has been evaluated
+// (a tree-like circuit needs a handful of slots, so the wave count per CU is not bounded by LDS); a circuit whose
+// live set does not fit, or a caller that wants every node's value, uses a [n_nodes, B] buffer with row = node id.
 #include "common.h"
 
 namespace dpk {
@@ -22,7 +24,8 @@ struct FlatSpnArgs {
     int D, n_nodes, root;
     const int32_t *order, *kind, *arg0, *arg1, *arg2;
     const double *par0, *par1;
-    const int32_t *child_index;
+    const int32_t *child_index;   // node ids of the children (global table) or their slots (LDS table)
+    const int32_t *node_slot;     // LDS table: row of each node
     const float *child_weight;
     const int32_t *cat_value;
     const float *cat_logp;
@@ -32,7 +35,7 @@ struct FlatSpnArgs {
 };
 
 constexpr float kFlatFloor = -1e31f;            // inference.py:103
-constexpr int kFlatLdsNodes = 256;              // 256 nodes x 64 samples x 4 B = 64 KB of LDS
+constexpr int kFlatLdsSlots = 256;              // 256 rows x 64 samples x 4 B = 64 KB of LDS
 
 template <bool kLds>
 __global__ __launch_bounds__(64) void flat_spn_kernel(const FlatSpnArgs a) {
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(64) void flat_spn_kernel(const FlatSpnArgs a) {
     const bool own = b < a.B;
     const int64_t bb = own ? b : a.B - 1;       // tail lanes shadow the last sample, global stores masked
     const float *xrow = a.x + bb * a.D;
-    auto load = [&](int node) -> float { return kLds ? lds[node * 64 + lane] : a.table[node * a.tstride + bb]; };
+    auto load = [&](int row) -> float { return kLds ? lds[row * 64 + lane] : a.table[row * a.tstride + bb]; };
     for (int t = 0; t < a.n_nodes; ++t) {
         const int i = a.order[t];
         const int kind = a.kind[i];
@@ -86,29 +89,30 @@ __global__ __launch_bounds__(64) void flat_spn_kernel(const FlatSpnArgs a) {
         }
         v = fmaxf(v, kFlatFloor);
         if (kLds)
-            lds[i * 64 + lane] = v;
+            lds[a.node_slot[i] * 64 + lane] = v;
         else if (own)
             a.table[i * a.tstride + bb] = v;
         // a lane only ever reads its own column of the table: no barrier between nodes
     }
-    if (own) a.out[b] = load(a.root);
+    if (own) a.out[b] = load(kLds ? a.node_slot[a.root] : a.root);
 }
 
 }  // namespace dpk
 
 using namespace dpk;
 
-extern "C" int64_t dpk_flat_spn_workspace_bytes(int64_t B, int32_t n_nodes) {
-    if (B < 0 || n_nodes <= 0) return DPK_EINVAL;
-    return n_nodes <= kFlatLdsNodes ? 0 : (int64_t)n_nodes * B * 4 + 256;
+extern "C" int64_t dpk_flat_spn_workspace_bytes(int64_t B, int32_t n_nodes, int32_t n_slots) {
+    if (B < 0 || n_nodes <= 0 || n_slots < 0) return DPK_EINVAL;
+    return (n_slots > 0 && n_slots <= kFlatLdsSlots) ? 0 : (int64_t)n_nodes * B * 4 + 256;
 }
 
 extern "C" int dpk_flat_spn_forward(const float *x, int64_t B, int32_t D, int32_t n_nodes, int32_t root,
                                     const int32_t *order, const int32_t *kind, const int32_t *arg0,
                                     const int32_t *arg1, const int32_t *arg2, const double *par0, const double *par1,
                                     const int32_t *child_index, const float *child_weight, const int32_t *cat_value,
-                                    const float *cat_logp, float *out, float *node_values, void *ws, int64_t ws_bytes,
-                                    void *stream) {
+                                    const float *cat_logp, int32_t n_slots, const int32_t *node_slot,
+                                    const int32_t *child_slot, float *out, float *node_values, void *ws,
+                                    int64_t ws_bytes, void *stream) {
     DPK_REQUIRE(B >= 0 && D > 0 && n_nodes > 0 && root >= 0 && root < n_nodes, DPK_EINVAL,
                 "flat_spn_forward: bad sizes");
     DPK_REQUIRE(order && kind && arg0 && arg1 && arg2 && par0 && par1, DPK_EINVAL,
@@ -125,10 +129,13 @@ extern "C" int dpk_flat_spn_forward(const float *x, int64_t B, int32_t D, int32_
     if (node_values) {
         a.table = node_values;
         hipLaunchKernelGGL(flat_spn_kernel<false>, dim3(blocks), dim3(64), 0, st, a);
-    } else if (n_nodes <= kFlatLdsNodes) {
-        hipLaunchKernelGGL(flat_spn_kernel<true>, dim3(blocks), dim3(64), (size_t)n_nodes * 256, st, a);
+    } else if (n_slots > 0 && n_slots <= kFlatLdsSlots) {
+        DPK_REQUIRE(node_slot && child_slot, DPK_EINVAL, "flat_spn_forward: slot arrays missing");
+        a.node_slot = node_slot;
+        a.child_index = child_slot;
+        hipLaunchKernelGGL(flat_spn_kernel<true>, dim3(blocks), dim3(64), (size_t)n_slots * 256, st, a);
     } else {
-        const int64_t need = dpk_flat_spn_workspace_bytes(B, n_nodes);
+        const int64_t need = dpk_flat_spn_workspace_bytes(B, n_nodes, n_slots);
         DPK_REQUIRE(ws && ws_bytes >= need, DPK_EWORKSPACE, "flat_spn_forward: workspace %lld < %lld",
                     (long long)ws_bytes, (long long)need);
         a.table = (float *)ws;

@@ -43,7 +43,7 @@ def log_likelihood(root: FlatSpn, x: Union[np.ndarray, torch.Tensor], return_res
     table = torch.empty((root.n_nodes, B), dtype=torch.float32, device=dev) if return_results else None
     ws = None
     if table is None:
-        n = lib.dpk_flat_spn_workspace_bytes(B, root.n_nodes)
+        n = lib.dpk_flat_spn_workspace_bytes(B, root.n_nodes, root.n_slots)
         if n < 0:
             check(int(n), 'dpk_flat_spn_workspace_bytes')
         if n > 0:
@@ -51,7 +51,8 @@ def log_likelihood(root: FlatSpn, x: Union[np.ndarray, torch.Tensor], return_res
     check(lib.dpk_flat_spn_forward(ptr(xd), B, D, root.n_nodes, root.root, ptr(a['order']), ptr(a['kind']),
                                    ptr(a['arg0']), ptr(a['arg1']), ptr(a['arg2']), ptr(a['par0']), ptr(a['par1']),
                                    ptr(a['child_index']), ptr(a['child_weight']), ptr(a['cat_value']),
-                                   ptr(a['cat_logp']), ptr(out), ptr(table), ptr(ws),
+                                   ptr(a['cat_logp']), root.n_slots, ptr(a['node_slot']), ptr(a['child_slot']),
+                                   ptr(out), ptr(table), ptr(ws),
                                    0 if ws is None else ws.numel(), stream_ptr(dev)), 'dpk_flat_spn_forward')
     if as_numpy:
         out = out.cpu().numpy()

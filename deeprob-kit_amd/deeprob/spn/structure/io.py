@@ -82,6 +82,8 @@ class FlatSpn:
         self.child_weight = np.asarray(child_weight or [0.0], dtype=np.float32)
         self.cat_value = np.asarray(cat_value or [0], dtype=np.int32)
         self.cat_logp = np.asarray(cat_logp or [0.0], dtype=np.float32)
+        self.n_slots, self.node_slot = self._allocate_slots()
+        self.child_slot = self.node_slot[self.child_index].astype(np.int32) if child_index else self.child_index
         self.n_features = 1 + max(max(s) for s in self.scopes)
         self._checked = False
         self._device = {}
@@ -112,6 +114,33 @@ class FlatSpn:
                 self.n_nodes - len(order)))
         return order
 
+    def _allocate_slots(self):
+        """Rows of the evaluator's on-chip value table: a node keeps its row until its last parent (in evaluation
+        order) has been computed, then the row returns to the free list."""
+        position = {int(n): t for t, n in enumerate(self.order)}
+        last_use = [position[i] for i in range(self.n_nodes)]        # a node nobody reads dies where it is born
+        for parent in range(self.n_nodes):
+            for c in self.children[parent]:
+                last_use[c] = max(last_use[c], position[parent])
+        last_use[self.root] = self.n_nodes                           # the root's row is read at the end
+        expiring = {}
+        for i, t in enumerate(last_use):
+            expiring.setdefault(t, []).append(i)
+        slot = np.zeros(self.n_nodes, np.int32)
+        free, used = [], 0
+        for t, node in enumerate(self.order):
+            node = int(node)
+            if free:
+                slot[node] = free.pop()
+            else:
+                slot[node] = used
+                used += 1
+            # rows whose last reader is this node are free from the next node on (a node's own row is written
+            # after its children's rows have been read)
+            for dead in expiring.get(t, []):
+                free.append(int(slot[dead]))
+        return used, slot
+
     def check(self):
         """Smoothness and decomposability, as ``check_spn`` enforces before every evaluation (reference
         evaluation.py:67, utils/validity.py)."""
@@ -135,7 +164,7 @@ class FlatSpn:
         key = str(device)
         if key not in self._device:
             names = ('order', 'kind', 'arg0', 'arg1', 'arg2', 'par0', 'par1', 'child_index', 'child_weight',
-                     'cat_value', 'cat_logp')
+                     'cat_value', 'cat_logp', 'node_slot', 'child_slot')
             self._device[key] = {k: torch.from_numpy(getattr(self, k)).to(device) for k in names}
         return self._device[key]
 

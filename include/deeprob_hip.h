@@ -331,13 +331,16 @@ int dpk_ll_accumulate(const float *ll, int64_t n, double *acc, void *stream);
  *   leaves:      arg0 = input column; par0 / par1 (double) = log p, log1p(-p) | start, width | mean, stddev;
  *                Categorical: arg1 = first entry in cat_value / cat_logp, arg2 = number of categories
  * x [B, D] with NaN = marginalised.  out [B] = value of `root`; node_values (optional, [n_nodes, B]) receives
- * every node's value (return_results = True).  Circuits above 256 nodes without node_values need a workspace
- * of dpk_flat_spn_workspace_bytes.                                                                          */
-int64_t dpk_flat_spn_workspace_bytes(int64_t B, int32_t n_nodes);
+ * every node's value (return_results = True).  Without node_values the values live in an on-chip table of
+ * n_slots rows: node_slot [n_nodes] = row of each node, child_slot (parallel to child_index) = row of each
+ * child; a row may be reused once every parent of its node has been evaluated.  n_slots = 0 or > 256: the
+ * circuit is evaluated through a workspace of dpk_flat_spn_workspace_bytes instead.                        */
+int64_t dpk_flat_spn_workspace_bytes(int64_t B, int32_t n_nodes, int32_t n_slots);
 int dpk_flat_spn_forward(const float *x, int64_t B, int32_t D, int32_t n_nodes, int32_t root, const int32_t *order,
                          const int32_t *kind, const int32_t *arg0, const int32_t *arg1, const int32_t *arg2,
                          const double *par0, const double *par1, const int32_t *child_index,
-                         const float *child_weight, const int32_t *cat_value, const float *cat_logp, float *out,
+                         const float *child_weight, const int32_t *cat_value, const float *cat_logp,
+                         int32_t n_slots, const int32_t *node_slot, const int32_t *child_slot, float *out,
                          float *node_values, void *ws, int64_t ws_bytes, void *stream);
 
 #ifdef __cplusplus

@@ -74,7 +74,10 @@ def test_random_circuits_against_oracle(n_features, seed, B):
     _, table = log_likelihood(spn, x, return_results=True)
     assert rel_err(table, want_table) <= LL_TOL
     if n_features >= 12:
-        assert spn.n_nodes > 256
+        assert spn.n_nodes > 256 and spn.n_slots <= 64       # thousands of nodes, a few dozen live rows
+    spn.n_slots = 0                                          # no on-chip table: the workspace route
+    again = log_likelihood(spn, x)
+    assert np.array_equal(again, got)
 
 
 def test_empty_batch_and_errors():

@@ -52,6 +52,23 @@ def test_random_circuits_are_valid():
         assert spn.n_features == 9 and spn.n_nodes == len(d['nodes'])
 
 
+@pytest.mark.parametrize('n_features,seed', [(5, 0), (9, 2), (12, 3)])
+def test_value_table_rows_are_recycled_safely(n_features, seed):
+    """Replay of the evaluator's on-chip table: when a node is evaluated every child's row still holds that child,
+    and the root's row survives to the end; far fewer rows than nodes are needed."""
+    d, _ = random_circuit(n_features, seed)
+    spn = _flat(d)
+    owner = {}
+    for node in spn.order:
+        node = int(node)
+        c0, nc = (spn.arg0[node], spn.arg1[node]) if spn.kind[node] <= 1 else (0, 0)
+        for j in range(nc):
+            assert owner[int(spn.child_slot[c0 + j])] == int(spn.child_index[c0 + j])
+        owner[int(spn.node_slot[node])] = node
+    assert owner[int(spn.node_slot[spn.root])] == spn.root
+    assert spn.n_slots == 1 + max(spn.node_slot) and spn.n_slots <= min(spn.n_nodes, 64)
+
+
 def test_invalid_structures_raise_like_the_reference():
     d, _ = random_circuit(6, 1)
     bad = copy.deepcopy(d)                                # cycle: the root becomes a child of one of its products
