@@ -169,8 +169,15 @@ __device__ __forceinline__ float fast_tanh(float v) {
 // row of accumulator register `reg` for this lane (32x32 MFMA C/D layout)
 __device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
+// Four work-groups per CU (34 KB of LDS each at U = 128) need <= 128 VGPRs: the register budget is pinned to four
+// waves per SIMD (a few cold values spill); measured 452 -> 369 us per layer against the compiler's default of 168
+// registers / three waves.
+#ifndef DPK_CPL_WAVES
+#define DPK_CPL_WAVES 4
+#endif
 template <bool AFFINE>
-__global__ __launch_bounds__(kCWaves * 64) void coupling1d_kernel(const CouplingArgs a) {
+__global__ __launch_bounds__(kCWaves * 64) __attribute__((amdgpu_waves_per_eu(DPK_CPL_WAVES, DPK_CPL_WAVES)))
+void coupling1d_kernel(const CouplingArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int U = a.U, D = a.D;
     const int HS = U + 1;                      // row stride of H
@@ -280,9 +287,12 @@ __global__ __launch_bounds__(kCWaves * 64) void coupling1d_kernel(const Coupling
     // 32-row half): two 32x32 accumulators (t, s) per wave keep the kernel near 100 VGPRs (4 work-groups per CU),
     // and 2 * n_pairs items spread evenly over the 4 waves.
     const float act = AFFINE ? a.act_weight[0] : 0.f;
-    float ssum0[16], ssum1[16];
+    // items it = wave, wave + 4, ..: the row half (it & 1) is the same for every item of a wave, so one set of
+    // log-det partial sums per wave
+    float ssum[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ssum0[r] = ssum1[r] = 0.f;
+    for (int r = 0; r < 16; ++r) ssum[r] = 0.f;
+    static_assert((kCWaves & 1) == 0, "a wave's items must share their row half");
     const int n_items = 2 * (a.N2p / 32);
     for (int it = wave; it < n_items; it += kCWaves) {
         const int pt = it >> 1, half = it & 1;   // wave-uniform
@@ -351,7 +361,7 @@ __global__ __launch_bounds__(kCWaves * 64) void coupling1d_kernel(const Coupling
                     if (AFFINE) {
                         const float sv = act * fast_tanh(s0[r] + bs);
                         o = a.inverse ? fmaf(xv, __expf(sv), tv) : (xv - tv) * __expf(-sv);
-                        if (half) ssum1[r] += sv; else ssum0[r] += sv;
+                        ssum[r] += sv;
                     } else {
                         o = a.inverse ? xv + tv : xv - tv;
                     }
@@ -363,18 +373,14 @@ __global__ __launch_bounds__(kCWaves * 64) void coupling1d_kernel(const Coupling
 
     // ---- phase 3: log-det = -/+ sum over the transformed variables of s, per sample
     if (AFFINE) {
+        const int half_w = wave & 1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float v0 = ssum0[r], v1 = ssum1[r];
+            float v0 = ssum[r];
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) {  // over the 32 columns held by this half-wave
-                v0 += __shfl_xor(v0, o, 64);
-                v1 += __shfl_xor(v1, o, 64);
-            }
-            if ((lane & 31) == 0) {  // one writer per (wave, row): no atomics, deterministic
-                ldj_lds[wave * kCM + mfma_row(r, lane)] = v0;
-                ldj_lds[wave * kCM + 32 + mfma_row(r, lane)] = v1;
-            }
+            for (int o = 16; o > 0; o >>= 1) v0 += __shfl_xor(v0, o, 64);  // over the 32 columns of this half-wave
+            if ((lane & 31) == 0)  // one writer per (wave, row): no atomics, deterministic
+                ldj_lds[wave * kCM + half_w * 32 + mfma_row(r, lane)] = v0;
         }
     }
     __syncthreads();
