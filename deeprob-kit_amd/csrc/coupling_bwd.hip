@@ -33,46 +33,60 @@ constexpr int kGT = 64, kGK = 64;
 // 64 x 64 output tile per work-group, K walked in slabs of 64: the next slab's operands are fetched into registers
 // (16 + 16 loads in flight per thread) before the MFMAs of the current one, so a slab costs max(load latency, MFMA
 // time) instead of their sum; products too small to fill the chip are split over K by launch_gemm.
+// The operand orientations are template parameters (A contiguous along k or along m, B along n or along k): a thread's
+// 16 + 16 loads per slab are one base pointer plus constant steps, advanced by one add per slab.
+template <bool A_KFAST, bool B_NFAST>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     __shared__ float As[kGT][kGK + 1];
     __shared__ float Bs[kGK][kGT + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * kGT, n0 = blockIdx.x * kGT;
+    // Work-groups are dealt round-robin to the 8 XCDs (each with its own L2): renumber them so that every XCD walks
+    // a contiguous run of tiles (n fastest), i.e. the tiles sharing a row block of A meet in one L2.
+    const unsigned n_tx = gridDim.x, n_tiles = gridDim.x * gridDim.y, bid = blockIdx.x + n_tx * blockIdx.y;
+    const unsigned xcd = bid & 7u, per = n_tiles >> 3, rem = n_tiles & 7u;
+    const unsigned tile = xcd * per + min(xcd, rem) + (bid >> 3);
+    const int m0 = (int)(tile / n_tx) * kGT, n0 = (int)(tile % n_tx) * kGT;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const bool a_kfast = g.sak == 1, b_nfast = g.sbn == 1;
     const int kbeg = (g.ksplit > 1) ? (int)blockIdx.z * g.kchunk : 0;
     const int kend = (g.ksplit > 1) ? min(g.K, kbeg + g.kchunk) : g.K;
-    constexpr int kPer = kGT * kGK / 256;
+    constexpr int kPer = kGT * kGK / 256;       // 16 elements of each operand per thread and slab
+    // element i of this thread: fast index f (the operand's contiguous axis), slow index s0 + 4 i
+    const int f = lane, s0 = wave;
+    const float *pa = g.A + (int64_t)(m0 + (A_KFAST ? s0 : f)) * g.sam + (int64_t)(kbeg + (A_KFAST ? f : s0)) * g.sak;
+    const float *pb = g.Bm + (int64_t)(kbeg + (B_NFAST ? s0 : f)) * g.sbk + (int64_t)(n0 + (B_NFAST ? f : s0)) * g.sbn;
+    const int64_t a_step = 4 * (A_KFAST ? g.sam : g.sak), b_step = 4 * (B_NFAST ? g.sbk : g.sbn);
+    const int64_t a_slab = (int64_t)kGK * g.sak, b_slab = (int64_t)kGK * g.sbk;
     float ar[kPer], br[kPer];
-    // thread order follows the contiguous axis of the operand
     auto fetch = [&](int k0) {
+        const bool a_fast_ok = A_KFAST ? (k0 + f < kend) : (m0 + f < g.M);
+        const bool b_fast_ok = B_NFAST ? (n0 + f < g.N) : (k0 + f < kend);
+        const int a_slow0 = A_KFAST ? m0 + s0 : k0 + s0, a_lim = A_KFAST ? g.M : kend;
+        const int b_slow0 = B_NFAST ? k0 + s0 : n0 + s0, b_lim = B_NFAST ? kend : g.N;
+        const float ks_fast = (A_KFAST && g.kscale && a_fast_ok) ? g.kscale[k0 + f] : 1.f;
 #pragma unroll
         for (int i = 0; i < kPer; ++i) {
-            const int e = tid + i * 256;
-            const int am = a_kfast ? e / kGK : e % kGT, ak = a_kfast ? e % kGK : e / kGT;
             float av = 0.f;
-            if (m0 + am < g.M && k0 + ak < kend) {
-                av = g.A[(int64_t)(m0 + am) * g.sam + (int64_t)(k0 + ak) * g.sak];
-                if (g.kscale) av *= g.kscale[k0 + ak];
+            if (a_fast_ok && a_slow0 + 4 * i < a_lim) {
+                av = pa[i * a_step];
+                if (A_KFAST) av *= ks_fast;
+                else if (g.kscale) av *= g.kscale[a_slow0 + 4 * i];
             }
             ar[i] = av;
-            const int bk = b_nfast ? e / kGT : e % kGK, bn = b_nfast ? e % kGT : e / kGK;
-            float bv = 0.f;
-            if (k0 + bk < kend && n0 + bn < g.N) bv = g.Bm[(int64_t)(k0 + bk) * g.sbk + (int64_t)(n0 + bn) * g.sbn];
-            br[i] = bv;
+            br[i] = (b_fast_ok && b_slow0 + 4 * i < b_lim) ? pb[i * b_step] : 0.f;
         }
+        pa += a_slab;
+        pb += b_slab;
     };
     fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += kGK) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < kPer; ++i) {
-            const int e = tid + i * 256;
-            As[a_kfast ? e / kGK : e % kGT][a_kfast ? e % kGK : e / kGT] = ar[i];
-            Bs[b_nfast ? e / kGT : e % kGK][b_nfast ? e % kGT : e / kGK] = br[i];
+            if (A_KFAST) As[s0 + 4 * i][f] = ar[i]; else As[f][s0 + 4 * i] = ar[i];
+            if (B_NFAST) Bs[s0 + 4 * i][f] = br[i]; else Bs[f][s0 + 4 * i] = br[i];
         }
         __syncthreads();
         if (k0 + kGK < kend) fetch(k0 + kGK);
@@ -109,6 +123,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     }
 }
 
+static void launch_gemm_kernel(const GemmArgs &g, dim3 grid, hipStream_t st) {
+    const bool ak = g.sak == 1, bn = g.sbn == 1;   // any other stride pair runs as the "slow axis" orientation
+    if (ak && bn) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, g);
+    else if (ak) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, g);
+    else if (bn) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, g);
+}
+
 // bias / ReLU / gate of a split-K product (the per-column scale was applied to the partial sums; with a bias the
 // scale is 1 in every call site, so the order bias -> relu -> scale of the unsplit epilogue is preserved)
 __global__ void gemm_epilogue_kernel(const GemmArgs g) {
@@ -143,7 +165,7 @@ static void launch_gemm(const GemmArgs &g_in, hipStream_t st) {
             if (g.ldc == g.N) (void)hipMemsetAsync(g.C, 0, (size_t)g.M * g.N * 4, st);
             else (void)hipMemset2DAsync(g.C, (size_t)g.ldc * 4, 0, (size_t)g.N * 4, (size_t)g.M, st);
         }
-        hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(g.N, kGT), cdiv(g.M, kGT), g.ksplit), dim3(256), 0, st, g);
+        launch_gemm_kernel(g, dim3(cdiv(g.N, kGT), cdiv(g.M, kGT), g.ksplit), st);
         if (g.bias || g.relu || g.gate) {
             const int64_t total = (int64_t)g.M * g.N;
             const int64_t nb = (total + 255) / 256;
@@ -152,7 +174,7 @@ static void launch_gemm(const GemmArgs &g_in, hipStream_t st) {
         return;
     }
     g.ksplit = 1;
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(g.N, kGT), cdiv(g.M, kGT)), dim3(256), 0, st, g);
+    launch_gemm_kernel(g, dim3(cdiv(g.N, kGT), cdiv(g.M, kGT)), st);
 }
 
 // Column reducers over the batch: a work-group of 1024 threads owns kRC = 16 adjacent columns, its 64 row groups
