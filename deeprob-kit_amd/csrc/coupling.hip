@@ -443,22 +443,58 @@ __global__ void affine1d_kernel(const float *__restrict__ x, const float *__rest
 
 // out[b] = sum_d log N(u[b,d]*sc[d]+sh[d]; loc[d], scale[d]) + ildj[b] + ildj_const
 // (NormalizingFlow.forward, flows/models/base.py:139-143 with the default Normal base)
+// log N(v sc + sh; loc, s) = -t^2 + c_d with t = v sc' + sh', sc' = sc / (s sqrt 2), sh' = (sh - loc) / (s sqrt 2),
+// c_d = -log s - log sqrt(2 pi): a work-group turns the per-variable parameters into (sc', sh') pairs in LDS and
+// the constant sum_d c_d once, then its waves stream kBaseRows rows each at two FMAs per element.
+constexpr int kBaseRows = 8;
 __global__ __launch_bounds__(256) void normal_base_logprob_kernel(
     const float *__restrict__ u, const float *__restrict__ sc, const float *__restrict__ sh,
     const float *__restrict__ loc, const float *__restrict__ scale, const float *__restrict__ ildj,
     const float *__restrict__ ildj_const, int64_t B, int D, float *__restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per sample
-    if (b >= B) return;
-    float acc = 0.f;
-    for (int d = lane; d < D; d += 64) {
-        float v = u[b * D + d];
-        if (sc) v = fmaf(v, sc[d], sh[d]);
-        const float s = scale[d], dl = v - loc[d];
-        acc += -(dl * dl) / (2.f * s * s) - logf(s) - kLogSqrt2Pi;
+    extern __shared__ __attribute__((aligned(16))) float base_lds[];   // [2][D4*4] sc', sh' (zero padded), [4] sums
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Dp = (D + 3) & ~3;
+    float *scp = base_lds, *shp = base_lds + Dp, *part = base_lds + 2 * Dp;
+    float csum = 0.f;
+    for (int d = tid; d < Dp; d += 256) {
+        float a = 0.f, c = 0.f;
+        if (d < D) {
+            const float s = scale[d], r = 0.70710678118654752440f / s;
+            a = (sc ? sc[d] : 1.f) * r;
+            c = ((sc ? sh[d] : 0.f) - loc[d]) * r;
+            csum += -logf(s) - kLogSqrt2Pi;
+        }
+        scp[d] = a;
+        shp[d] = c;
     }
-    acc = wave_reduce_sum(acc);
-    if (lane == 0) out[b] = acc + (ildj ? ildj[b] : 0.f) + (ildj_const ? *ildj_const : 0.f);
+    csum = wave_reduce_sum(csum);
+    if (lane == 0) part[wave] = csum;
+    __syncthreads();
+    const float cst = (part[0] + part[1]) + (part[2] + part[3]) + (ildj_const ? *ildj_const : 0.f);
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * kBaseRows;
+    const bool vec = (D & 3) == 0;
+    for (int64_t b = r0; b < min(r0 + kBaseRows, B); ++b) {
+        const float *row = u + b * D;
+        float acc = 0.f;
+        if (vec) {
+            for (int q = lane; q < (D >> 2); q += 64) {
+                const f32x4 v = reinterpret_cast<const f32x4 *>(row)[q];
+                const f32x4 a = reinterpret_cast<const f32x4 *>(scp)[q], c = reinterpret_cast<const f32x4 *>(shp)[q];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float t = fmaf(v[j], a[j], c[j]);
+                    acc = fmaf(-t, t, acc);
+                }
+            }
+        } else {
+            for (int d = lane; d < D; d += 64) {
+                const float t = fmaf(row[d], scp[d], shp[d]);
+                acc = fmaf(-t, t, acc);
+            }
+        }
+        acc = wave_reduce_sum(acc);
+        if (lane == 0) out[b] = acc + cst + (ildj ? ildj[b] : 0.f);
+    }
 }
 
 }  // namespace dpk
@@ -557,8 +593,10 @@ extern "C" int dpk_normal_base_logprob(const float *u, const float *scale_in, co
     if (B == 0) return DPK_OK;
     DPK_REQUIRE(u && loc && scale && out, DPK_EINVAL, "normal_base_logprob: null pointer");
     DPK_REQUIRE((scale_in == nullptr) == (shift_in == nullptr), DPK_EINVAL, "normal_base_logprob: scale/shift");
-    hipLaunchKernelGGL(normal_base_logprob_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, u,
-                       scale_in, shift_in, loc, scale, ildj, ildj_const, B, D, out);
+    const size_t lds = (size_t)(2 * ((D + 3) & ~3) + 4) * sizeof(float);
+    DPK_REQUIRE(lds <= 64 * 1024, DPK_EUNSUPPORTED, "normal_base_logprob: D=%d above the on-chip parameter table", D);
+    hipLaunchKernelGGL(normal_base_logprob_kernel, dim3(cdiv(B, 4 * kBaseRows)), dim3(256), lds, (hipStream_t)stream,
+                       u, scale_in, shift_in, loc, scale, ildj, ildj_const, B, D, out);
     DPK_CHECK_LAUNCH("normal_base_logprob_kernel");
     return DPK_OK;
 }
