@@ -84,10 +84,15 @@ __global__ __launch_bounds__(64) void coupling_index_kernel(const float *__restr
                                                            int *__restrict__ nidx, int *__restrict__ bad) {
     const int lane = threadIdx.x;
     int kbase = 0, nbase = 0, nonbinary = 0;
+    int even_ok = 1, odd_ok = 1;   // transformed variables = exactly the even / the odd columns
     for (int d0 = 0; d0 < D; d0 += 64) {
         const int d = d0 + lane;
         const float m = d < D ? mask[d] : 0.f, im = d < D ? inv_mask[d] : 0.f;
         nonbinary |= !((m == 0.f || m == 1.f) && (im == 0.f || im == 1.f));
+        if (d < D) {
+            even_ok &= (im != 0.f) == ((d & 1) == 0);
+            odd_ok &= (im != 0.f) == ((d & 1) == 1);
+        }
         const unsigned long long bm = __ballot(m != 0.f), bi = __ballot(im != 0.f);
         const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
         if (m != 0.f) {
@@ -103,8 +108,14 @@ __global__ __launch_bounds__(64) void coupling_index_kernel(const float *__restr
     }
     for (int k = kbase + lane; k < K1p; k += 64) kidx[k] = -1;
     for (int n = nbase + lane; n < N2p; n += 64) nidx[n] = -1;
-    if (__any(nonbinary) && lane == 0) *bad = 1;
-    else if (lane == 0) *bad = 0;
+    const int any_bad = __any(nonbinary), all_even = __all(even_ok), all_odd = __all(odd_ok);
+    if (lane == 0) {
+        bad[0] = any_bad ? 1 : 0;
+        // bad[1]: 1 / 2 = the transformed variables are the even / odd columns of an even-width input (the
+        // reference's CouplingLayer1d masks, coupling.py:58-60): the epilogue then owns (pass-through, transformed)
+        // column pairs as 8-byte accesses and the tile is never copied separately; 0 = any other binary mask
+        bad[1] = ((D & 1) == 0 && !any_bad) ? (all_even ? 1 : (all_odd ? 2 : 0)) : 0;
+    }
 }
 
 // B-fragment order of v_mfma_f32_32x32x2_f32: lane l holds B[k = l>>5][j = l&31]; four consecutive
@@ -156,6 +167,7 @@ struct CouplingArgs {
     const float *act_weight;           // ScaledTanh weight (1 float), affine only
     int inverse;                       // 0: density direction (u, ildj); 1: sampling direction (x, ldj)
     int accumulate;                    // ldj[b] += ... instead of =
+    const int *flags;                  // [1]: column-pair mode (coupling_index_kernel)
 };
 
 // tanh(v) = (e^{2v} - 1) / (e^{2v} + 1) on the hardware exp2 / rcp: absolute error ~1e-7 (the scale s = a tanh(.)
@@ -193,11 +205,19 @@ void coupling1d_kernel(const CouplingArgs a) {
     const int64_t b0 = (int64_t)blockIdx.x * kCM;
     const int rows = (int)min((int64_t)kCM, a.B - b0);
     const bool has_aff = a.in_scale != nullptr;
+    // column-pair mode: 0 = generic mask; 1 / 2 = the transformed variables are the even / odd columns.  Then the
+    // epilogue reads and writes (pass-through, transformed) pairs and phase 0 is skipped.
+#ifdef DPK_CPL_NOPAIR
+    const int pair_mode = 0;
+#else
+    const int pair_mode = __builtin_amdgcn_readfirstlane(a.flags[1]);
+#endif
+    const bool paired = pair_mode != 0;
 
     // ---- phase 0: pass-through copy of the tile (every variable; the transformed ones are overwritten by
     // the epilogue), log-det scratch.  Rows over the waves, columns over the lanes: no index division, and
     // 16-byte accesses when the rows are 16-byte aligned.
-    if (DPK_CPL_ABLATE != 1) {
+    if (DPK_CPL_ABLATE != 1 && !paired) {
         const float *xb = a.x + b0 * D;
         float *ob = a.out + b0 * D;
         if ((D & 3) == 0) {
@@ -308,7 +328,7 @@ void coupling1d_kernel(const CouplingArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int row0 = half * 32 + (r & 3) + 8 * (r >> 2);
                 const int rowc = min(row0 + 4 * (lane >> 5), rows - 1) - 4 * (lane >> 5);  // clamp ragged tiles
-                xpre[r] = (DPK_CPL_ABLATE == 5 || !DPK_CPL_XPRE) ? 0.f : xb[lane_off + rowc * D];
+                xpre[r] = (DPK_CPL_ABLATE == 5 || !DPK_CPL_XPRE || paired) ? 0.f : xb[lane_off + rowc * D];
             }
         }
         const f32x4 *btp = reinterpret_cast<const f32x4 *>(a.w2tp) + (int64_t)pt * (U / 8) * 64 + lane;
@@ -342,10 +362,14 @@ void coupling1d_kernel(const CouplingArgs a) {
         const int var = var_p;
         if (var >= 0 && DPK_CPL_ABLATE != 5) {
             const float bt = a.b2tp[n], bs = AFFINE ? a.b2sp[n] : 0.f;
-            float sc = 1.f, sh = 0.f;
+            float sc = 1.f, sh = 0.f, scp = 1.f, shp = 0.f;
             if (has_aff) {
                 sc = a.in_scale[var];
                 sh = a.in_shift[var];
+                if (paired) {
+                    scp = a.in_scale[var ^ 1];
+                    shp = a.in_shift[var ^ 1];
+                }
             }
             // 32-bit offsets inside the tile: lane part (column, +4 rows for the upper half-wave) + a uniform row part
             float *ob = a.out + b0 * D;
@@ -356,7 +380,15 @@ void coupling1d_kernel(const CouplingArgs a) {
                 const int off = lane_off + row0 * D;
                 if (row0 + 4 * (lane >> 5) < rows) {
                     const float tv = t0[r] + bt;
-                    const float xv = fmaf(DPK_CPL_XPRE ? xpre[r] : a.x[b0 * D + off], sc, sh);
+                    float xraw, praw = 0.f;
+                    if (paired) {   // 8-byte access to the (even, odd) column pair of this lane's variable
+                        const float2 v2 = *reinterpret_cast<const float2 *>(a.x + b0 * D + (off & ~1));
+                        xraw = (pair_mode == 1) ? v2.x : v2.y;
+                        praw = (pair_mode == 1) ? v2.y : v2.x;
+                    } else {
+                        xraw = DPK_CPL_XPRE ? xpre[r] : a.x[b0 * D + off];
+                    }
+                    const float xv = fmaf(xraw, sc, sh);
                     float o;
                     if (AFFINE) {
                         const float sv = act * fast_tanh(s0[r] + bs);
@@ -365,7 +397,12 @@ void coupling1d_kernel(const CouplingArgs a) {
                     } else {
                         o = a.inverse ? xv + tv : xv - tv;
                     }
-                    ob[off] = o;
+                    if (paired) {
+                        const float pv = fmaf(praw, scp, shp);
+                        *reinterpret_cast<float2 *>(ob + (off & ~1)) = (pair_mode == 1) ? make_float2(o, pv) : make_float2(pv, o);
+                    } else {
+                        ob[off] = o;
+                    }
                 }
             }
         }
@@ -538,7 +575,7 @@ extern "C" int dpk_coupling1d_forward(const float *x, int64_t B, int32_t D, cons
     a.x = x; a.out = out; a.ldj = ldj; a.B = B; a.D = D; a.U = units; a.K1p = w.K1p; a.N2p = w.N2p;
     a.kidx = w.kidx; a.nidx = w.nidx; a.w1p = w.w1p; a.b1 = b1; a.w2tp = w.w2tp; a.w2sp = w.w2sp;
     a.b2tp = w.b2tp; a.b2sp = w.b2sp; a.in_scale = in_scale; a.in_shift = in_shift; a.act_weight = act_weight;
-    a.inverse = inverse; a.accumulate = accumulate_ldj;
+    a.inverse = inverse; a.accumulate = accumulate_ldj; a.flags = bad;
     const size_t hs_floats = (size_t)kCM * (units + 1), xs_floats = (size_t)kCM * (kCKC + 1);
     const bool alias_xs = units >= 64 && units <= 32 * kCWaves;   // as in the kernel
     const size_t lds = (hs_floats + kCWaves * kCM + (alias_xs ? 0 : xs_floats)) * sizeof(float);

@@ -58,6 +58,49 @@ def test_invertibility_like_reference():
             RealNVP1d(10, **bad)
 
 
+@pytest.mark.parametrize('D,pattern', [(40, 'blocks'), (40, 'random'), (40, 'alternating'), (40, 'reversed'),
+                                       (41, 'alternating'), (64, 'sparse')])
+def test_custom_masks_vs_oracle(D, pattern):
+    """The fused kernel on masks other than the layer's own: half blocks, a random binary split, a mask pair that
+    leaves some variables untouched by both (sparse), and the alternating pair at even / odd width (the column-pair
+    epilogue covers exactly the even-width alternating masks; everything else takes the generic route)."""
+    from deeprob.flows.layers.coupling import CouplingLayer1d
+    from oracle import flows_oracle as forc
+    gen = torch.Generator().manual_seed(D + len(pattern))
+    layer = CouplingLayer1d(D, depth=1, units=32, affine=True).cuda().eval()
+    idx = torch.arange(D)
+    if pattern == 'blocks':
+        mask = (idx < D // 2).float()
+        inv = 1 - mask
+    elif pattern == 'random':
+        mask = (torch.rand(D, generator=gen) < 0.4).float()
+        inv = 1 - mask
+    elif pattern == 'sparse':
+        mask = (idx % 3 == 0).float()
+        inv = (idx % 3 == 1).float()            # variables with idx % 3 == 2 are neither input nor transformed
+    else:
+        mask = (idx % 2).float()
+        inv = 1 - mask
+        if pattern == 'reversed':
+            mask, inv = inv, mask
+    with torch.no_grad():
+        layer.mask.copy_(mask)
+        layer.inv_mask.copy_(inv)
+        layer.scale_act.weight.fill_(0.7)
+        for p in layer.network.parameters():
+            p.copy_(torch.randn(p.shape, generator=gen) * 0.3)
+    lins = [(m.weight.detach().cpu(), m.bias.detach().cpu()) for m in layer.network if isinstance(m, torch.nn.Linear)]
+    for B in (3, 70):
+        x = torch.randn(B, D, generator=gen)
+        with torch.no_grad():
+            u, ildj = layer.apply_backward(x.cuda())
+            xr, ldj = layer.apply_forward(u)
+        wu, wildj = forc.coupling_backward(x, mask, inv, lins, torch.tensor([0.7]))
+        assert rel_err(u.cpu().numpy(), wu.numpy()) <= 1e-5
+        assert rel_err(ildj.cpu().numpy(), wildj.numpy()) <= 1e-5
+        assert torch.allclose(xr.cpu(), x, atol=5e-6) and torch.allclose(ldj, -ildj, atol=5e-6)
+
+
 @pytest.mark.parametrize('B', [1, 63, 65, 1000])
 def test_ragged_batches_vs_oracle(golden, B):
     g = golden('realnvp1d_15')
