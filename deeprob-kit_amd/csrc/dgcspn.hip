@@ -22,6 +22,42 @@ static inline int grid_cap(int64_t total, int block, int cap = 16384) {
 // ------------------------------------------------------------------------------------------------
 // Gaussian leaves: y[b,k,p] = sum_c nan_to_num(log N(x[b,c,p]; loc[k,c,p], scale[k,c,p]))
 // ------------------------------------------------------------------------------------------------
+// Evaluation form (no dropout) for up to kGaussC input channels: thread = (pixel, leaf channel k) over a slice of
+// samples; the pixel's parameters become (mu, 1 / (2 sigma^2), -log sigma - log sqrt(2 pi)) once, then every
+// sample costs one load per input channel, three flops and one store.
+constexpr int kGaussC = 4;
+__global__ __launch_bounds__(256) void spatial_gaussian_fwd_fast_kernel(const float *__restrict__ x,
+                                                                        const float *__restrict__ loc,
+                                                                        const float *__restrict__ scale, int64_t B,
+                                                                        int K, int C, int HW, int bslice,
+                                                                        float *__restrict__ out) {
+    const int p = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int k = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (p >= HW || k >= K) return;
+    float mu[kGaussC], iv[kGaussC], cs[kGaussC];
+#pragma unroll
+    for (int c = 0; c < kGaussC; ++c) {
+        const bool live = c < C;
+        const float sg = live ? scale[((int64_t)k * C + c) * HW + p] : 1.f;
+        mu[c] = live ? loc[((int64_t)k * C + c) * HW + p] : 0.f;
+        iv[c] = 0.5f / (sg * sg);
+        cs[c] = -logf(sg) - kLogSqrt2Pi;
+    }
+    const int64_t b0 = (int64_t)blockIdx.z * bslice, b1 = min(b0 + bslice, B);
+#pragma unroll 4
+    for (int64_t b = b0; b < b1; ++b) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < kGaussC; ++c) {
+            if (c < C) {
+                const float d = x[(b * C + c) * HW + p] - mu[c];
+                acc += nan_to_num_f(fmaf(-(d * d), iv[c], cs[c]));
+            }
+        }
+        out[(b * K + k) * HW + p] = acc;
+    }
+}
+
 __global__ void spatial_gaussian_fwd_kernel(const float *__restrict__ x, const float *__restrict__ loc,
                                             const float *__restrict__ scale, int64_t B, int K, int C, int HW,
                                             float *__restrict__ out, float drop_p, uint64_t seed) {
@@ -629,6 +665,18 @@ static int spatial_gaussian_forward_impl(const float *x, const float *loc, const
     if (B == 0) return DPK_OK;
     DPK_REQUIRE(x && loc && scale && out, DPK_EINVAL, "spatial_gaussian: null pointer");
     const int64_t total = B * K * H * W;
+    if (drop_p == 0.f && C <= kGaussC) {
+        const int HW = H * W;
+        const int64_t cols = cdiv(HW, 64), kb = cdiv(K, 4);
+        int64_t slices = cdiv(4096, cols * kb);                 // about 16 k waves
+        int64_t bslice = cdiv(B, slices);
+        if (bslice < 8) bslice = 8;
+        slices = cdiv(B, bslice);
+        hipLaunchKernelGGL(spatial_gaussian_fwd_fast_kernel, dim3((unsigned)cols, (unsigned)kb, (unsigned)slices),
+                           dim3(256), 0, (hipStream_t)stream, x, loc, scale, B, K, C, HW, (int)bslice, out);
+        DPK_CHECK_LAUNCH("spatial_gaussian_fwd_fast_kernel");
+        return DPK_OK;
+    }
     hipLaunchKernelGGL(spatial_gaussian_fwd_kernel, dim3(grid_cap(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        x, loc, scale, B, K, C, H * W, out, drop_p, seed);
     DPK_CHECK_LAUNCH("spatial_gaussian_fwd_kernel");
