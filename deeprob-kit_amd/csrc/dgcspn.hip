@@ -891,6 +891,197 @@ extern "C" int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C
 
 // Depthwise SpatialProductLayer (<= 4 taps) followed by SpatialRootLayer (models/dgcspn.py:146-150 in eval mode):
 // weight [K, C*OH*OW]; workspace = K*C*OH*OW floats (+256 B).
+// ------------------------------------------------------------------------------------------------
+// Last sum level + last product + root in one launch (models/dgcspn.py:146-150 at i = n-3 .. n-1).
+// The last product ('final' padding, dilation d) reads the last sum layer's map at four positions a distance d
+// apart and its d x d output only feeds the root: a thread owns one of those output pixels, evaluates the fused
+// product + sum level (as spatial_prodsum_fwd_kernel) at its (up to) four tap positions, adds them, and the
+// work-group (= NB samples) finishes the root's log-sum-exp in the log domain.  The largest map of the model
+// (8 x 59 x 59 per sample at 28 x 28 inputs: 0.9 GB written and read back at B = 8192) never reaches memory.
+// ------------------------------------------------------------------------------------------------
+template <int CMAX, int NB>
+__global__ __launch_bounds__(1024) void spatial_sumprodroot_fwd_kernel(const float *__restrict__ in,
+                                                                       const float *__restrict__ Wl,
+                                                                       const float *__restrict__ LW, int B,
+                                                                       ProdGeom q5, int Cout, ProdGeom q6,
+                                                                       const float *__restrict__ LWr, int K,
+                                                                       float *__restrict__ out) {
+    __shared__ float red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    const int OHW5 = q5.OH * q5.OW, HW = q5.H * q5.W, OHW6 = q6.OH * q6.OW;
+    const bool act = tid < OHW6;
+    const int b0 = blockIdx.x * NB;
+    const bool full_c = (q5.C == CMAX);
+    float P[NB][CMAX];
+#pragma unroll
+    for (int s = 0; s < NB; ++s)
+#pragma unroll
+        for (int o = 0; o < CMAX; ++o) P[s][o] = 0.f;
+    if (act) {
+        const int oh6 = tid / q6.OW, ow6 = tid - oh6 * q6.OW;
+        const int T6 = q6.kh * q6.kw;
+#pragma unroll 1
+        for (int t6 = 0; t6 < T6; ++t6) {
+            const int th6 = t6 / q6.kw, tw6 = t6 - th6 * q6.kw;
+            const int ph = oh6 * q6.sh - q6.pt + th6 * q6.dh, pw = ow6 * q6.sw - q6.pl + tw6 * q6.dw;
+            if (ph < 0 || ph >= q6.H || pw < 0 || pw >= q6.W) continue;   // zero padding of the last product
+            const int p = ph * q5.OW + pw;                                 // pixel of the last sum layer's map
+            int tclamp[4];
+            bool tval[4];
+            {
+                const int T = q5.kh * q5.kw;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int th = t / q5.kw, tw = t - th * q5.kw;
+                    const int ih = ph * q5.sh - q5.pt + th * q5.dh, iw = pw * q5.sw - q5.pl + tw * q5.dw;
+                    tval[t] = t < T && ih >= 0 && ih < q5.H && iw >= 0 && iw < q5.W;
+                    tclamp[t] = tval[t] ? ih * q5.W + iw : 0;
+                }
+            }
+            float ev[NB][CMAX], m0[NB];
+#pragma unroll
+            for (int s = 0; s < NB; ++s) {
+                const float *src = in + (size_t)min(b0 + s, B - 1) * q5.C * HW;
+                float m = -INFINITY;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) {
+                    const int cc = full_c ? c : min(c, q5.C - 1);
+                    float a = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float v = src[cc * HW + tclamp[t]];
+                        a += tval[t] ? v : 0.f;
+                    }
+                    if (!full_c && c >= q5.C) a = -INFINITY;
+                    ev[s][c] = a;
+                    m = fmaxf(m, a);
+                }
+                m0[s] = (m == -INFINITY) ? 0.f : m;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) ev[s][c] = __expf(ev[s][c] - m0[s]);
+            }
+#pragma unroll
+            for (int o = 0; o < CMAX; ++o) {
+                if (o >= Cout) break;
+                float w[CMAX];
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) w[c] = c < q5.C ? Wl[((size_t)o * q5.C + c) * OHW5 + p] : 0.f;
+#pragma unroll
+                for (int s = 0; s < NB; ++s) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) v = fmaf(w[c], ev[s][c], v);
+                    float r;
+                    if (v < 1e-30f) {
+                        // exact log-domain pass (rare): rebuild the products from the taps
+                        const float *src = in + (size_t)min(b0 + s, B - 1) * q5.C * HW;
+                        const float *lp = LW + (size_t)o * q5.C * OHW5 + p;
+                        float mm = -INFINITY;
+                        for (int c = 0; c < q5.C; ++c) {
+                            float a = 0.f;
+                            for (int t = 0; t < 4; ++t)
+                                if (tval[t]) a += src[c * HW + tclamp[t]];
+                            mm = fmaxf(mm, a + lp[(size_t)c * OHW5]);
+                        }
+                        if (mm > -INFINITY) {
+                            float acc = 0.f;
+                            for (int c = 0; c < q5.C; ++c) {
+                                float a = 0.f;
+                                for (int t = 0; t < 4; ++t)
+                                    if (tval[t]) a += src[c * HW + tclamp[t]];
+                                acc += expf(a + lp[(size_t)c * OHW5] - mm);
+                            }
+                            r = mm + logf(acc);
+                        } else {
+                            r = -INFINITY;
+                        }
+                    } else {
+                        r = m0[s] + logf(v);
+                    }
+                    P[s][o] += r;
+                }
+            }
+        }
+    }
+    // root (layers/dgcspn.py:343-355): log-sum-exp over (channel, pixel) of P + log_softmax(weight), per class
+    const int M = Cout * OHW6;
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+            float tv[CMAX], tmax = -INFINITY;
+#pragma unroll
+            for (int o = 0; o < CMAX; ++o) {
+                tv[o] = (act && o < Cout) ? P[s][o] + LWr[(size_t)k * M + o * OHW6 + tid] : -INFINITY;
+                tmax = fmaxf(tmax, tv[o]);
+            }
+            tmax = wave_reduce_max(tmax);
+            __syncthreads();
+            if (lane == 0) red[wave] = tmax;
+            __syncthreads();
+            float bmax = -INFINITY;
+            for (int w2 = 0; w2 < n_waves; ++w2) bmax = fmaxf(bmax, red[w2]);
+            float part = 0.f;
+            if (bmax > -INFINITY) {
+#pragma unroll
+                for (int o = 0; o < CMAX; ++o) part += expf(tv[o] - bmax);   // exp(-inf) = 0 for the padding
+            }
+            part = wave_reduce_sum(part);
+            __syncthreads();
+            if (lane == 0) red[wave] = part;
+            __syncthreads();
+            if (tid == 0 && b0 + s < B) {
+                float tot = 0.f;
+                for (int w2 = 0; w2 < n_waves; ++w2) tot += red[w2];
+                out[(size_t)(b0 + s) * K + k] = (bmax > -INFINITY) ? bmax + logf(tot) : -INFINITY;
+            }
+        }
+    }
+}
+
+extern "C" int64_t dpk_spatial_sumprodroot_workspace_bytes(int32_t C, int32_t Cout, int32_t OH5, int32_t OW5,
+                                                           int32_t OH6, int32_t OW6, int32_t K) {
+    if (C <= 0 || Cout <= 0 || OH5 <= 0 || OW5 <= 0 || OH6 <= 0 || OW6 <= 0 || K <= 0) return DPK_EINVAL;
+    return 2 * align_up((int64_t)Cout * C * OH5 * OW5 * 4, 256) + align_up((int64_t)K * Cout * OH6 * OW6 * 4, 256) + 256;
+}
+
+extern "C" int dpk_spatial_sumprodroot_forward(const float *in, int64_t B, int32_t C, int32_t H, int32_t W,
+                                               const int32_t *geom5, const float *sum_weight, int32_t Cout,
+                                               const int32_t *geom6, const float *root_weight, int32_t K, float *out,
+                                               void *ws, int64_t ws_bytes, void *stream) {
+    DPK_REQUIRE(geom5 && geom6, DPK_EINVAL, "spatial_sumprodroot: null geometry");
+    // geom = {OH, OW, kh, kw, sh, sw, dh, dw, pad_top, pad_left} of a depthwise product layer
+    ProdGeom q5, q6;
+    int rc = make_geom(q5, C, H, W, C, geom5[0], geom5[1], geom5[2], geom5[3], geom5[4], geom5[5], geom5[6], geom5[7],
+                       geom5[8], geom5[9], 1);
+    if (rc) return rc;
+    rc = make_geom(q6, Cout, geom5[0], geom5[1], Cout, geom6[0], geom6[1], geom6[2], geom6[3], geom6[4], geom6[5],
+                   geom6[6], geom6[7], geom6[8], geom6[9], 1);
+    if (rc) return rc;
+    DPK_REQUIRE(B >= 0 && Cout > 0 && K > 0, DPK_EINVAL, "spatial_sumprodroot: bad sizes");
+    DPK_REQUIRE(q5.kh * q5.kw <= 4 && q6.kh * q6.kw <= 4 && C <= 8 && Cout <= 8 && q6.OH * q6.OW <= 1024,
+                DPK_EUNSUPPORTED, "spatial_sumprodroot: shape outside the fused kernel (<= 8 channels, <= 1024 pixels)");
+    DPK_REQUIRE(B <= INT32_MAX / 2 && (int64_t)B * C * H * W < ((int64_t)1 << 46), DPK_EUNSUPPORTED,
+                "spatial_sumprodroot: tensor too large");
+    DPK_REQUIRE(sum_weight && root_weight && ws, DPK_EINVAL, "spatial_sumprodroot: null pointer");
+    DPK_REQUIRE(ws_bytes >= dpk_spatial_sumprodroot_workspace_bytes(C, Cout, q5.OH, q5.OW, q6.OH, q6.OW, K),
+                DPK_EWORKSPACE, "spatial_sumprodroot: workspace too small");
+    if (B == 0) return DPK_OK;
+    DPK_REQUIRE(in && out, DPK_EINVAL, "spatial_sumprodroot: null pointer");
+    const int OHW5 = q5.OH * q5.OW, OHW6 = q6.OH * q6.OW;
+    const int64_t seg = align_up((int64_t)Cout * C * OHW5 * 4, 256);
+    float *Wl = (float *)ws, *LW = (float *)((char *)ws + seg), *LWr = (float *)((char *)ws + 2 * seg);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW5, 256)), dim3(256), 0, st, sum_weight,
+                       Cout, C, OHW5, Wl, LW);
+    hipLaunchKernelGGL(rowwise_logsoftmax_kernel, dim3(K), dim3(256), 0, st, root_weight, K, Cout * OHW6, LWr);
+    constexpr int kNB = 2;
+    const int threads = (int)align_up(OHW6, 64);
+    hipLaunchKernelGGL((spatial_sumprodroot_fwd_kernel<8, kNB>), dim3(cdiv((int)B, kNB)), dim3(threads), 0, st, in, Wl,
+                       LW, (int)B, q5, Cout, q6, LWr, K, out);
+    DPK_CHECK_LAUNCH("spatial_sumprodroot_fwd_kernel");
+    return DPK_OK;
+}
+
 extern "C" int64_t dpk_spatial_prodroot_workspace_bytes(int32_t C, int32_t OH, int32_t OW, int32_t K) {
     if (C <= 0 || OH <= 0 || OW <= 0 || K <= 0) return DPK_EINVAL;
     return align_up((int64_t)K * C * OH * OW * 4, 256) + 256;

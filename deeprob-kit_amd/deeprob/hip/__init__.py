@@ -108,6 +108,9 @@ SIGNATURES = {
     'dpk_prodroot_forward': (ctypes.c_int, [_c_void, _c_void, _i64, _i32, _i32, _i32, _c_void, _c_void, _i64, _c_void]),
     'dpk_profile_next_kernel': (ctypes.c_int, [_c_void, _c_void]),
     'dpk_ll_accumulate': (ctypes.c_int, [_c_void, _i64, _c_void, _c_void]),
+    'dpk_spatial_sumprodroot_workspace_bytes': (_i64, [_i32] * 7),
+    'dpk_spatial_sumprodroot_forward': (ctypes.c_int, [_c_void, _i64, _i32, _i32, _i32, _c_void, _c_void, _i32, _c_void,
+                                                       _c_void, _i32, _c_void, _c_void, _i64, _c_void]),
     'dpk_flat_spn_workspace_bytes': (_i64, [_i64, _i32, _i32]),
     'dpk_flat_spn_forward': (ctypes.c_int, [_c_void, _i64, _i32, _i32, _i32] + [_c_void] * 11 +
                              [_i32, _c_void, _c_void, _c_void, _c_void, _c_void, _i64, _c_void]),

@@ -179,3 +179,38 @@ def spatial_prodroot(x, prod_layer, weight, ws: Workspace):
         return None
     check(rc, 'dpk_spatial_prodroot_forward')
     return out
+
+
+def spatial_sumprodroot(x, prod5, sum_weight, prod6, root_weight, ws: Workspace):
+    """Last three stages of the eval route in one launch: depthwise SpatialProductLayer + SpatialSumLayer, the final
+    depthwise SpatialProductLayer and the SpatialRootLayer (reference: deeprob/spn/models/dgcspn.py:146-150).  The
+    largest activation map of the model is never written.  No autograd graph; None when outside the fused kernel's
+    envelope (the caller falls back to spatial_prodsum + spatial_prodroot)."""
+    import ctypes
+    lib = load_library()
+    x = require_device_f32(x, 'x')
+    w5 = require_device_f32(sum_weight, 'weight')
+    wr = require_device_f32(root_weight, 'weight')
+    if not (prod5.depthwise and prod6.depthwise):
+        return None
+    if x.dim() != 4 or tuple(x.shape[1:]) != tuple(prod5.in_features):
+        raise ValueError(f"expected input [B, {prod5.in_features}], got {tuple(x.shape)}")
+    C, H, W, _, OH5, OW5, kh5, kw5, sh5, sw5, dh5, dw5, pt5, pl5, _ = _geom(prod5)
+    C6, H6, W6, _, OH6, OW6, kh6, kw6, sh6, sw6, dh6, dw6, pt6, pl6, _ = _geom(prod6)
+    Cout, K = w5.shape[0], wr.shape[0]
+    if tuple(w5.shape[1:]) != (C, OH5, OW5) or (C6, H6, W6) != (Cout, OH5, OW5) or wr.shape[1] != Cout * OH6 * OW6:
+        raise ValueError("layer shapes do not chain")
+    g5 = (ctypes.c_int32 * 10)(OH5, OW5, kh5, kw5, sh5, sw5, dh5, dw5, pt5, pl5)
+    g6 = (ctypes.c_int32 * 10)(OH6, OW6, kh6, kw6, sh6, sw6, dh6, dw6, pt6, pl6)
+    n = lib.dpk_spatial_sumprodroot_workspace_bytes(C, Cout, OH5, OW5, OH6, OW6, K)
+    if n < 0:
+        check(int(n), 'dpk_spatial_sumprodroot_workspace_bytes')
+    buf = ws.get(n, x.device)
+    B = x.shape[0]
+    out = torch.empty((B, K), dtype=torch.float32, device=x.device)
+    rc = lib.dpk_spatial_sumprodroot_forward(ptr(x), B, C, H, W, g5, ptr(w5), Cout, g6, ptr(wr), K, ptr(out), ptr(buf),
+                                             buf.numel(), stream_ptr(x.device))
+    if rc == -4:  # DPK_EUNSUPPORTED
+        return None
+    check(rc, 'dpk_spatial_sumprodroot_forward')
+    return out

@@ -185,6 +185,7 @@ class SpatialRootLayer(nn.Module):
         dirichlet_(self.weight, alpha=1.0)
         self._ws = Workspace()
         self._ws2 = Workspace()   # fused product+root route (deeprob.hip.ops_spatial.spatial_prodroot)
+        self._ws3 = Workspace()   # fused sum level + product + root route (ops_spatial.spatial_sumprodroot)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """Flatten + log-sum-exp with ``log_softmax(weight, 1)`` (reference :343-355)."""

@@ -112,6 +112,14 @@ class DgcSpn(ProbabilisticModel):
         i, n = 0, len(self.layers)
         while i < n:
             layer = self.layers[i]
+            if (i == n - 3 and isinstance(layer, SpatialProductLayer) and isinstance(self.layers[i + 1], SpatialSumLayer)
+                    and isinstance(self.layers[i + 2], SpatialProductLayer)
+                    and not (self.training and self.layers[i + 1].dropout is not None)):
+                # last sum level + last product + root: the largest map stays on chip
+                y = ops_spatial.spatial_sumprodroot(x, layer, self.layers[i + 1].weight, self.layers[i + 2],
+                                                    self.root_layer.weight, self.root_layer._ws3)
+                if y is not None:
+                    return y
             if i + 1 < n and isinstance(layer, SpatialProductLayer) and isinstance(self.layers[i + 1], SpatialSumLayer):
                 nxt = self.layers[i + 1]
                 dropout = self.training and nxt.dropout is not None   # the sum layer raises: not on this path

@@ -319,6 +319,18 @@ int dpk_profile_next_kernel(void *ev_start, void *ev_stop);
  * the mean-LL all-reduce): acc[0] += sum(ll), acc[1] += n.                   */
 int dpk_ll_accumulate(const float *ll, int64_t n, double *acc, void *stream);
 
+/* Last three stages of an eval-mode DGC-SPN in one launch (models/dgcspn.py:146-150): depthwise product + sum level
+ * (geom5, sum_weight [Cout, C, OH5, OW5]), the last depthwise product (geom6, on the [Cout, OH5, OW5] map) and the
+ * root (root_weight [K, Cout*OH6*OW6]); the largest activation map never reaches memory.
+ * geom = {OH, OW, kh, kw, sh, sw, dh, dw, pad_top, pad_left} (host array of 10 ints) of a SpatialProductLayer
+ * (layers/dgcspn.py:151-198).  DPK_EUNSUPPORTED outside <= 8 channels / <= 1024 final pixels / <= 4 taps.     */
+int64_t dpk_spatial_sumprodroot_workspace_bytes(int32_t C, int32_t Cout, int32_t OH5, int32_t OW5, int32_t OH6,
+                                                int32_t OW6, int32_t K);
+int dpk_spatial_sumprodroot_forward(const float *in, int64_t B, int32_t C, int32_t H, int32_t W, const int32_t *geom5,
+                                    const float *sum_weight, int32_t Cout, const int32_t *geom6,
+                                    const float *root_weight, int32_t K, float *out, void *ws, int64_t ws_bytes,
+                                    void *stream);
+
 /* ---- vanilla (node-graph) SPN, flattened (BASELINE config 1) ---------------------------------------------
  * Bottom-up log-likelihood of deeprob/spn/algorithms/inference.py:37-58 (eval_bottom_up, evaluation.py:37-96;
  * node values clamped at -1e31 and kept in float32, inference.py:94-103) for a circuit given as arrays over
