@@ -1533,11 +1533,18 @@ static int leaf_forward_common(int dist, const float *x, int64_t B, int32_t D, c
 template <int DEPTH, int I, int S>
 static int fused_launch(const LeafArgs &a, hipStream_t st) {
 #ifdef DPK_FORCE_SPL1
-    constexpr int SPL = 1;
+    return launch_leaf<0, (1 << DEPTH), I, 1, DEPTH, S>(a, st);
 #else
-    constexpr int SPL = (I <= 4) ? 2 : 1;
+    // Two samples per lane halve the per-sample cost of fetching the table entries (LDS records for <= 4 channels,
+    // scalar-cache loads for 8).  With 8 channels the 64 accumulators per wave fit the register budget up to depth 2,
+    // and the 128-sample tiles only pay off once there are more than two 64-sample tiles per CU to begin with.
+    if constexpr (I <= 4) {
+        return launch_leaf<0, (1 << DEPTH), I, 2, DEPTH, S>(a, st);
+    } else {
+        if (DEPTH <= 2 && a.B > 2 * 256 * 64) return launch_leaf<0, (1 << (DEPTH <= 2 ? DEPTH : 2)), I, 2, (DEPTH <= 2 ? DEPTH : 2), S>(a, st);
+        return launch_leaf<0, (1 << DEPTH), I, 1, DEPTH, S>(a, st);
+    }
 #endif
-    return launch_leaf<0, (1 << DEPTH), I, SPL, DEPTH, S>(a, st);
 }
 
 template <int DEPTH, int I>
