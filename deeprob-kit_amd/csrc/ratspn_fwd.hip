@@ -1502,7 +1502,11 @@ static int leaf_forward_dispatch(const LeafArgs &a, hipStream_t st) {
 #ifdef DPK_HEADLINE_ONLY
     return launch_leaf<DIST, 4, 2, 2, 0, 1>(a, st);
 #endif
-    if (I % 8 == 0) return q4 ? launch_leaf<DIST, 4, 8, 1, 0, 1>(a, st) : launch_leaf<DIST, 2, 8, 1, 0, 1>(a, st);
+    if (I % 8 == 0) {
+        // two samples per lane once there are more than two 64-sample tiles per CU (see fused_launch)
+        if (a.B > 2 * 256 * 64) return q4 ? launch_leaf<DIST, 4, 8, 2, 0, 1>(a, st) : launch_leaf<DIST, 2, 8, 2, 0, 1>(a, st);
+        return q4 ? launch_leaf<DIST, 4, 8, 1, 0, 1>(a, st) : launch_leaf<DIST, 2, 8, 1, 0, 1>(a, st);
+    }
     if (I % 4 == 0) return q4 ? launch_leaf<DIST, 4, 4, 2, 0, 1>(a, st) : launch_leaf<DIST, 2, 4, 2, 0, 1>(a, st);
     if (I % 2 == 0) return q4 ? launch_leaf<DIST, 4, 2, 2, 0, 1>(a, st) : launch_leaf<DIST, 2, 2, 2, 0, 1>(a, st);
     return q4 ? launch_leaf<DIST, 4, 1, 2, 0, 1>(a, st) : launch_leaf<DIST, 2, 1, 2, 0, 1>(a, st);
