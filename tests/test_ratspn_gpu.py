@@ -233,6 +233,39 @@ def test_full_size_properties():
     assert abs(acc[0].item() - ll.double().sum().item()) <= 1e-9 * abs(acc[0].item())
 
 
+@pytest.mark.parametrize('kw', [dict(rg_batch=8, rg_sum=8), dict(rg_batch=8, rg_sum=4, optimize_scale=True),
+                                dict(rg_batch=16, rg_sum=16), dict(rg_depth=1, rg_batch=8, rg_sum=8),
+                                dict(rg_depth=3, rg_batch=8, rg_sum=8, rg_repetitions=3)])
+def test_wide_channel_blocks_above_the_tile_switch(kw):
+    """Launches above 32768 samples run the 8-channel blocks with two samples per lane (fused kernel up to depth 2, leaf
+    kernel of the folded route): a 40000-sample batch (ragged last tile) against the oracle on a scattered subset
+    (NaN / inf / far-tail rows included), and against the same rows evaluated in a small launch (one sample per lane)."""
+    from deeprob.spn.models import GaussianRatSpn
+    torch.manual_seed(3)
+    base = dict(in_features=100, rg_depth=2, rg_repetitions=4, random_state=7)
+    base.update(kw)
+    model = GaussianRatSpn(**base).eval()
+    if base.get('optimize_scale'):
+        with torch.no_grad():
+            model.base_layer.scale.mul_(1.0 + 0.2 * torch.rand_like(model.base_layer.scale))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    B = 40000
+    x = torch.randn(B, 100, generator=torch.Generator().manual_seed(4))
+    x[5] = float('nan')
+    x[64, :30] = float('nan')
+    x[129, 3] = float('inf')
+    x[39999, 7] = 40.0                                   # beyond the expanded-square bound, in the ragged tile
+    rows = torch.cat([torch.tensor([5, 64, 129, 39999, 39936, 39937]), torch.randint(0, B, (250,),
+                                                                                     generator=torch.Generator().manual_seed(5))])
+    want = orc.ratspn_forward(sd, x[rows]).numpy()
+    model = model.cuda()
+    with torch.no_grad():
+        big = model(x.cuda())
+        small = model(x[rows].cuda())
+    assert rel_err(big[rows.cuda()].cpu().numpy(), want) <= LL_TOL
+    assert rel_err(small.cpu().numpy(), want) <= LL_TOL
+
+
 def test_fused_plan_is_the_same_call(golden):
     """ops.FusedForwardPlan (pre-bound call for a resident buffer) == model(x) bit for bit; it reads live
     parameters and notices when a pinned address moved."""
