@@ -181,9 +181,12 @@ class Workspace:
     def __init__(self):
         self.buf: Optional[torch.Tensor] = None
         self.struct_key = None  # what the cached structure tables were built from
+        self._retired = []      # outgrown buffers: a captured HIP graph may still address them
 
     def get(self, n_bytes: int, device: torch.device) -> torch.Tensor:
         if self.buf is None or self.buf.numel() < n_bytes or self.buf.device != device:
+            if self.buf is not None:
+                self._retired.append(self.buf)
             self.buf = torch.empty(max(int(n_bytes), 256), dtype=torch.uint8, device=device)
             self.struct_key = None
         return self.buf

@@ -56,10 +56,14 @@ def train_model(
     drop_last: bool = True,
     num_workers: int = 0,
     device: Optional[torch.device] = None,
-    verbose: bool = True
+    verbose: bool = True,
+    hip_graph: bool = False
 ) -> Dict[str, list]:
-    """Reference signature (:21-37).  ``batch_size`` is the GLOBAL batch: with N ranks each one sees batch_size/N
-    samples per step.  :raises ValueError: for an unknown setting or non-positive epochs."""
+    """Reference signature (:21-37) + ``hip_graph``.  ``batch_size`` is the GLOBAL batch: with N ranks each one sees
+    batch_size/N samples per step.  ``hip_graph`` (generative setting, single process, no dropout): the optimisation
+    step of full batches is captured once as a HIP graph and replayed (``deeprob.hip.graphs.GraphedTrainStep``);
+    Adam-family optimisers are built with ``capturable=True``.
+    :raises ValueError: for an unknown setting or non-positive epochs."""
     if setting not in ('generative', 'discriminative'):
         raise ValueError("Unknown train setting called {}".format(setting))
     if device is None:
@@ -69,9 +73,18 @@ def train_model(
     train_loader = data.DataLoader(data_train, batch_size, shuffle=True, drop_last=drop_last, num_workers=num_workers)
     valid_loader = data.DataLoader(data_valid, batch_size, shuffle=False, drop_last=False, num_workers=num_workers)
     model.to(device)
+    optimizer_kwargs = dict(optimizer_kwargs or {})
+    if hip_graph:
+        if setting != 'generative' or _world()[1] > 1:
+            raise ValueError("hip_graph covers the generative setting in a single process")
+        if optimizer in ('adam', 'adamw', 'nadam', 'radam', 'adamax', 'rmsprop', 'adagrad', 'adadelta'):
+            optimizer_kwargs.setdefault('capturable', True)
     opt = get_optimizer_class(optimizer)(filter(lambda p: p.requires_grad, model.parameters()), lr=lr,
-                                         **(optimizer_kwargs or {}))
+                                         **optimizer_kwargs)
     early_stopping = EarlyStopping(model, patience=patience, filepath=checkpoint)
+    if hip_graph:
+        return train_generative(model, train_loader, valid_loader, opt, device, early_stopping, epochs, train_base,
+                                verbose, hip_graph=True)
     fit = train_generative if setting == 'generative' else train_discriminative
     return fit(model, train_loader, valid_loader, opt, device, early_stopping, epochs, train_base, verbose)
 
@@ -85,11 +98,12 @@ def train_generative(
     early_stopping: EarlyStopping,
     epochs: int = 1000,
     train_base: bool = True,
-    verbose: bool = True
+    verbose: bool = True,
+    hip_graph: bool = False
 ) -> Dict[str, list]:
     """Reference :98-210.  Returns ``{'train': [...], 'valid': [...]}`` (average loss per epoch)."""
     hist = _fit(model, train_loader, valid_loader, optimizer, device, early_stopping, epochs, train_base, verbose,
-                supervised=False)
+                supervised=False, hip_graph=hip_graph)
     return {'train': hist['train']['loss'], 'valid': hist['valid']['loss']}
 
 
@@ -119,10 +133,17 @@ def _batch(item, device, rank, world, supervised):
     return shard_batch(item.to(device, non_blocking=True), rank, world), None
 
 
-def _fit(model, train_loader, valid_loader, optimizer, device, early_stopping, epochs, train_base, verbose, supervised):
+def _fit(model, train_loader, valid_loader, optimizer, device, early_stopping, epochs, train_base, verbose, supervised,
+         hip_graph=False):
     if epochs <= 0:
         raise ValueError("The number of epochs must be positve")
     rank, world = _world()
+    graphed = None
+    if hip_graph:
+        if supervised or world > 1:
+            raise ValueError("hip_graph covers the generative setting in a single process")
+        from deeprob.hip.graphs import GraphedTrainStep
+        graphed = GraphedTrainStep(model, optimizer)
     history = {'train': {'loss': [], 'accuracy': []}, 'valid': {'loss': [], 'accuracy': []}}
     meters = {k: RunningAverageMetric() for k in ('train_loss', 'train_hits', 'valid_loss', 'valid_hits')}
     for epoch in range(1, epochs + 1):
@@ -133,6 +154,9 @@ def _fit(model, train_loader, valid_loader, optimizer, device, early_stopping, e
         for item in train_loader:
             inputs, targets = _batch(item, device, rank, world, supervised)
             n_local = inputs.shape[0]
+            if graphed is not None and n_local > 0:
+                meters['train_loss'](graphed(inputs), num_samples=n_local)
+                continue
             optimizer.zero_grad()
             if n_local > 0:
                 outputs = model(inputs)

@@ -64,3 +64,37 @@ def test_discriminative_setting(tmp_path):
     assert hist['valid']['accuracy'][-1] > 0.8 and hist['train']['loss'][-1] < hist['train']['loss'][0]
     nll, report = test_model(model, va, setting='discriminative', verbose=False)
     assert nll < 0.8 and report['accuracy'] > 0.8 and set(report) >= {'0', '1', '2', 'accuracy', 'macro avg'}
+
+
+def test_train_model_with_hip_graph_matches_eager(tmp_path):
+    """The optimisation step captured as a HIP graph (deeprob.hip.graphs) trains like the eager loop: same history
+    shape, losses equal up to the split-K summation order, the ragged last batch handled eagerly; dropout refuses."""
+    from deeprob.flows.models import RealNVP1d
+    from deeprob.spn.models import GaussianRatSpn
+    from deeprob.torch.routines import train_model
+    gen = torch.Generator().manual_seed(0)
+    train = (torch.randn(5 * 64 + 17, 24, generator=gen) * 0.7 + 0.5).numpy()
+    valid = (torch.randn(96, 24, generator=gen) * 0.7 + 0.5).numpy()
+
+    def run(hip_graph):
+        torch.manual_seed(1)
+        flow = RealNVP1d(24, n_flows=2, units=32)
+        hist = train_model(flow, train, valid, setting='generative', lr=5e-3, batch_size=64, epochs=3, patience=5,
+                           checkpoint=str(tmp_path / ('g.pt' if hip_graph else 'e.pt')), drop_last=False, verbose=False,
+                           hip_graph=hip_graph)
+        return hist, flow
+
+    torch.manual_seed(7)            # same shuffling for both runs
+    eager, _ = run(False)
+    torch.manual_seed(7)
+    graphed, flow = run(True)
+    assert len(graphed['train']) == len(eager['train']) == 3
+    assert np.allclose(graphed['train'], eager['train'], rtol=2e-3)
+    assert np.allclose(graphed['valid'], eager['valid'], rtol=2e-3)
+    assert graphed['train'][-1] < graphed['train'][0]
+    spn = GaussianRatSpn(24, rg_depth=1, rg_repetitions=2, rg_batch=2, rg_sum=2, in_dropout=0.2, random_state=1)
+    with pytest.raises(NotImplementedError):
+        train_model(spn, train, valid, epochs=1, batch_size=64, checkpoint=str(tmp_path / 'd.pt'), verbose=False,
+                    hip_graph=True)
+    with pytest.raises(ValueError):
+        train_model(flow, train, valid, setting='discriminative', epochs=1, hip_graph=True)
