@@ -296,11 +296,11 @@ __global__ __launch_bounds__(256) void leaf_bwd_param_kernel(
     const float *__restrict__ x, const float *__restrict__ g, int64_t B, int D, int R, int I, int d, int SP,
     const int *__restrict__ feat, const int *__restrict__ srcr, const float *__restrict__ p0,
     const float *__restrict__ p1, float *__restrict__ gp0, float *__restrict__ gp1, float drop_p,
-    uint64_t seed) {
+    uint64_t seed, int tile) {
     const int grp = blockIdx.y;  // region group: its entry stream holds (variable, r*d+j) pairs
     const int kb = blockIdx.z * CBK;
-    const int64_t b0 = (int64_t)blockIdx.x * kLeafBwdTile;
-    const int64_t b1 = min(b0 + kLeafBwdTile, B);
+    const int64_t b0 = (int64_t)blockIdx.x * tile;
+    const int64_t b1 = min(b0 + tile, B);
     for (int e = threadIdx.x; e < SP; e += blockDim.x) {
         const int rj = srcr[(int64_t)grp * SP + e];
         if (rj < 0) continue;
@@ -321,15 +321,18 @@ __global__ __launch_bounds__(256) void leaf_bwd_param_kernel(
                 c1[k] = c2[k] = 0.f;
             }
         }
+        // the loads of four samples are issued together (the loop is a chain of dependent latencies otherwise)
+#pragma unroll 4
         for (int64_t b = b0; b < b1; ++b) {
-            const float xv = x[b * D + f];
-            if (!(xv == xv)) continue;   // marginalised: no contribution
+            const float xr = x[b * D + f];
+            const bool live = (xr == xr);   // marginalised: no contribution
+            const float xv = live ? xr : 0.f;
             const float *gp = g + (b * R + r) * I + kb;
 #pragma unroll
             for (int k = 0; k < CBK; ++k) {
                 // training-mode input dropout: the same (seed, element) decision as the forward kernel
                 if (drop_p > 0.f && dropout_hit(seed, (((uint64_t)b * R + r) * I + kb + k) * d + j, drop_p)) continue;
-                const float gv = gp[k];
+                const float gv = live ? gp[k] : 0.f;
                 if (DIST == 0) {
                     const float dl = xv - c0[k];
                     a0[k] = fmaf(gv, dl * c1[k], a0[k]);
@@ -523,10 +526,12 @@ static int leaf_backward_common(int dist, const float *x, const float *g, int64_
     if (gp1) DPK_REQUIRE(hipMemsetAsync(gp1, 0, pbytes, st) == hipSuccess, DPK_ELAUNCH, "leaf_backward: memset");
     if (B > 0 && (gp0 || gp1)) {
         const int cbk = (I % 4 == 0) ? 4 : ((I % 2 == 0) ? 2 : 1);
-        const dim3 grid(cdiv(B, kLeafBwdTile), w.G, I / cbk), block(256);
+        // small batches: shorter sample slices so that the grid still covers the chip (more atomics per parameter)
+        const int tile = (B > 1024) ? kLeafBwdTile : 16;
+        const dim3 grid(cdiv(B, tile), w.G, I / cbk), block(256);
 #define DPK_LEAF_BWD(DIST, CBK)                                                                                  \
     hipLaunchKernelGGL((leaf_bwd_param_kernel<DIST, CBK>), grid, block, 0, st, x, g, B, D, R, I, d, w.SP, w.feat, \
-                       w.srcr, p0, p1, gp0, gp1, drop_p, seed)
+                       w.srcr, p0, p1, gp0, gp1, drop_p, seed, tile)
         if (dist == 0) {
             if (cbk == 4) DPK_LEAF_BWD(0, 4);
             else if (cbk == 2) DPK_LEAF_BWD(0, 2);
