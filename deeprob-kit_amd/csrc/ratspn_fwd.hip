@@ -414,6 +414,9 @@ struct LeafArgs {
     cfloat_p W0, LW0, W1, LW1, Wr, LWr;
     float *out;      // [B,C]
     double *ll_sum;  // [2] or nullptr
+    // last, so that the offsets of everything above stay what the kernels were tuned with
+    int *slow_flag;   // host-mapped word: a work-group that meets a slow chunk stores launch_seq there
+    int launch_seq;
 };
 
 template <int SPL> struct TileGeom {
@@ -833,10 +836,49 @@ struct CompactPipe {
             const f32x2 xv = x[CUR][u];
             if (WITHQ) Q = __builtin_elementwise_fma(xv, xv, Q);
             const f32x2 mp = {mu[CUR][2 * u], mu[CUR][2 * u + 1]};
+
+
             asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(P[0]) : "v"(xv), "v"(mp));
             asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(P[1]) : "v"(xv), "v"(mp));
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
+    // Exact per-entry form on the same records, for chunks that hold NaN / inf / out-of-bound evidence:
+    // t = -(x-mu)^2/2 - log sqrt(2 pi) with nan_to_num semantics (NaN -> 0, -inf -> -FLT_MAX), complete terms (no
+    // bias afterwards).  The caller fills the neutral LDS row with NaN for the chunk, so padding entries add 0.
+    template <int CUR>
+    __device__ __forceinline__ void step_exact(f32x2 (&A)[2], const char *smem0, int lane_off) {
+        constexpr int OTH = 1 - CUR;
+        read_x(x[OTH], smem0, lane_off, offn);
+        offn = *reinterpret_cast<const i32x2 *>(tbn + kCompactRec + 32);
+        mu[OTH] = *reinterpret_cast<const f32x8 *>(tbn);
+        tbn += kCompactRec;
+#pragma unroll
+        for (int u = 0; u < kBlock; ++u) {
+            const f32x2 xv = x[CUR][u];
+            const bool n0 = xv[0] != xv[0], n1 = xv[1] != xv[1];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float mk = mu[CUR][2 * u + k];
+                const float d0 = xv[0] - mk, d1 = xv[1] - mk;
+                const float t0 = fmaxf(fmaf(d0 * d0, -0.5f, -kLogSqrt2Pi), -FLT_MAX);
+                const float t1 = fmaxf(fmaf(d1 * d1, -0.5f, -kLogSqrt2Pi), -FLT_MAX);
+                A[k][0] += n0 ? 0.f : t0;
+                A[k][1] += n1 ? 0.f : t1;
+            }
+        }
+    }
+    __device__ __forceinline__ void run_exact(f32x2 (&A)[2], const char *smem0, int lane_off, int nb) {
+        for (int i = nb >> 1; i > 0; --i) {
+            step_exact<0>(A, smem0, lane_off);
+            step_exact<1>(A, smem0, lane_off);
+        }
+        if (nb & 1) {
+            step_exact<0>(A, smem0, lane_off);
+            mu[0] = mu[1];
+#pragma unroll
+            for (int u = 0; u < kBlock; ++u) x[0][u] = x[1][u];
+        }
     }
     template <bool WITHQ>
     __device__ __forceinline__ void run(f32x2 (&P)[2], f32x2 &Q, const char *smem0, int lane_off, int nb) {
@@ -853,6 +895,7 @@ struct CompactPipe {
     }
 };
 
+
 // DEPTH == 0: leaf only (QB regions x CB channels per wave item, written to leaf_out)
 // DEPTH >= 1: fused model, QB == 2^DEPTH, CB == I, S sum nodes
 #ifndef DPK_NO_EXPAND
@@ -867,7 +910,7 @@ struct CompactPipe {
 // (host hint "scale is frozen at 1", checked on the device per region) only the means travel, which
 // keeps the kernel under 128 VGPRs without scratch; a group whose scales are not all 1 then takes
 // the scalar-cache path, so the hint can only cost speed, never correctness.
-template <int DIST, int QB, int CB, int SPL, int DEPTH, int S, bool GEN>
+template <int DIST, int QB, int CB, int SPL, int DEPTH, int S, bool GEN, bool XLDS = false>
 __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_kernel(const LeafArgs a) {
     using G = TileGeom<SPL>;
     constexpr int T = G::T, ROW = G::ROW, NLD = G::NLD;
@@ -936,6 +979,7 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
 
     // leaf-only launches spread the passes over blockIdx.y (small training batches would otherwise occupy
     // B/T compute units); the fused model keeps them in the work-group (the root exchange spans them)
+    bool saw_slow = false;
     const int pass_lo = (DEPTH == 0) ? (int)blockIdx.y : 0;
     const int pass_hi = (DEPTH == 0) ? min(pass_lo + 1, n_pass) : n_pass;
     for (int pass = pass_lo; pass < pass_hi; ++pass) {
@@ -1036,6 +1080,7 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
             }
         };
         bool qgo = qfree && pass == 0;
+        bool nan_row = false;
         load_tab(0);
         load_chunk(0);
 
@@ -1049,6 +1094,10 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
             lds_barrier();  // every wave is done with the previous chunk
             DPK_STAMP(1);
             unsigned chk = 0u;
+            if (XLDS && nan_row) {   // the previous chunk ran in the exact LDS form: the neutral row holds zeros again
+                if (tid < ROW) xs_lds[kChunk * ROW + tid] = 0.f;
+                nan_row = false;
+            }
             float *wr = xs_lds + flc * ROW + (SPL == 2 ? 2 * sq : sq);
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
@@ -1076,8 +1125,20 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
                 load_chunk(c + 1);
             }
 
-            if (slow) qgo = false;
-            if (qgo) {
+            // compact-record kernel: a slow chunk stays on the LDS pipeline in the exact per-entry form (complete
+            // terms, neutral row = NaN), and the chunks after it carry on in the expanded form
+            bool slow_lds = false;
+            if constexpr (kCompact && XLDS) {
+                slow_lds = slow && expand && use_lds;
+                if (slow_lds) {
+                    if (tid < ROW) xs_lds[kChunk * ROW + tid] = __int_as_float(0x7fc00000);
+                    if (tid == 0 && a.slow_flag != nullptr) *a.slow_flag = a.launch_seq;   // host hint (launch_leaf)
+                    nan_row = true;
+                    lds_barrier();
+                }
+            }
+            if (slow && !slow_lds) qgo = false;
+            if (qgo && !slow) {
                 // this wave's share of sum_f x_f^2 for the chunk: rows 8*wave .. 8*wave+7 (see qfree)
                 const char *qb = lane_base + wave * (kChunk / kLeafWaves) * G::ROWB;
                 const int nvalid = min(kChunk, D - c * kChunk) - wave * (kChunk / kLeafWaves);
@@ -1111,11 +1172,12 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
                     acc_is_squares = false;
                     use_lds = false;
                 }
-                if (slow && expand) {  // acc is already in final units: just leave the LDS pipeline
+                if (slow && expand && !slow_lds) {  // acc is already in final units: just leave the LDS pipeline
                     expand = false;
                     use_lds = false;
+                    saw_slow = true;
                 }
-                if (slow || !use_lds) {
+                if ((slow && !slow_lds) || !use_lds) {
                     // exact per-element path (NaN / inf evidence) or wide channel blocks: tables
                     // through the scalar cache
 #pragma unroll
@@ -1177,7 +1239,22 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
                         };
                         LdsPipe<CB, SPL, GEN> pipe;
                         if constexpr (DIST == 0 && !GEN && SPL == 2) {
-                            if (expand) {
+                            if (slow_lds) {
+                                if constexpr (kCompact && XLDS) {
+                                    CompactPipe cp;
+                                    const int lane_off = lane * (4 * SPL);
+                                    cp.prime(tab_lds + (c & 1) * a.tabcap, smem, lane_off);
+#pragma unroll
+                                    for (int q = 0; q < QB; ++q) {
+                                        const int nb = nbp[q];
+                                        f32x2 A[2] = {{acc[q][0][0], acc[q][0][1]}, {acc[q][1][0], acc[q][1][1]}};
+                                        cp.run_exact(A, smem, lane_off, nb);
+                                        acc[q][0][0] = A[0][0]; acc[q][0][1] = A[0][1];
+                                        acc[q][1][0] = A[1][0]; acc[q][1][1] = A[1][1];
+                                        pos += nb * kBlock;
+                                    }
+                                }
+                            } else if (expand) {
                                 CompactPipe cp;
                                 const int lane_off = lane * (4 * SPL);
                                 if constexpr (kCompact) cp.prime(tab_lds + (c & 1) * a.tabcap, smem, lane_off);
@@ -1373,6 +1450,9 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
             }
         }
     }
+    // host hint (launch_leaf): raised at the very end, where no register is under pressure -- a store inside the
+    // chunk loop's slow branch changes the SGPR allocation of the whole loop (+1.5 % on clean inputs)
+    if (saw_slow && lane == 0 && a.slow_flag != nullptr) *a.slow_flag = a.launch_seq;
 #ifdef DPK_TIMELINE
     if (a.dbg && lane == 0) {
         unsigned long long *row = a.dbg + (((int64_t)blockIdx.x * kLeafWaves + wave) * (NC + 2) + NC) * 6;
@@ -1440,13 +1520,36 @@ static void fill_leaf_args(LeafArgs &a, const RatWs &w) {
     a.unit = as_const(w.unit);
 }
 
-template <int DIST, int QB, int CB, int SPL, int DEPTH, int S, bool GEN>
+struct SlowHint {
+    int *host = nullptr, *dev = nullptr;   // one host-mapped word per process (one process per GPU)
+    unsigned seq = 0;
+};
+static SlowHint &slow_hint() {
+    static SlowHint h = [] {
+        SlowHint s;
+        int *p = nullptr;
+        if (hipHostMalloc((void **)&p, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && p) {
+            *p = -1000;
+            int *d = nullptr;
+            if (hipHostGetDevicePointer((void **)&d, p, 0) == hipSuccess && d) {
+                s.host = p;
+                s.dev = d;
+            }
+        } else {
+            (void)hipGetLastError();
+        }
+        return s;
+    }();
+    return h;
+}
+
+template <int DIST, int QB, int CB, int SPL, int DEPTH, int S, bool GEN, bool XLDS = false>
 static int launch_leaf_gen(const LeafArgs &a, hipStream_t st) {
     using G = TileGeom<SPL>;
     const int grid = cdiv(a.B, G::T);
     size_t lds = G::BUF_BYTES + 64 + (size_t)kLeafWaves * 2 * a.tabcap;
     if (DEPTH > 0) lds += (size_t)(2 * a.C + kLeafWaves) * G::T * sizeof(float);
-    auto kern = ratspn_leaf_kernel<DIST, QB, CB, SPL, DEPTH, S, GEN>;
+    auto kern = ratspn_leaf_kernel<DIST, QB, CB, SPL, DEPTH, S, GEN, XLDS>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1486,6 +1589,21 @@ static int launch_leaf(const LeafArgs &a, hipStream_t st) {
             if (CB == 2 && DPK_NO_EXPAND == 0) {   // compact records (prepare_leaf_tables wrote them for this case)
                 LeafArgs c = a;
                 c.tabcap = a.tabcap_c;
+                // Two builds of this kernel, both exact for any input: the default sends a tile that meets NaN / inf /
+                // out-of-bound evidence to the scalar-cache path; the other keeps such chunks on the LDS record
+                // pipeline in the exact per-entry form (1.2-1.6x faster on marginalised inputs, 2.6 % slower on clean
+                // ones because of the extra code in the chunk loop).  A work-group that meets a slow chunk stores the
+                // launch number in a host-mapped word; a launch takes the second build while one of the recent
+                // launches did so.  The word is read without synchronising: a stale value only costs speed.
+                SlowHint &h = slow_hint();
+                bool marginal = false;
+                if (h.dev != nullptr) {
+                    c.slow_flag = h.dev;
+                    c.launch_seq = (int)++h.seq;
+                    // the host runs ahead of the device by its launch queue: "recent" = within 256 launches
+                    marginal = (unsigned)(c.launch_seq - *(volatile int *)h.host) <= 256u;
+                }
+                if (marginal) return launch_leaf_gen<DIST, QB, CB, SPL, DEPTH, S, false, true>(c, st);
                 return launch_leaf_gen<DIST, QB, CB, SPL, DEPTH, S, false>(c, st);
             }
             return launch_leaf_gen<DIST, QB, CB, SPL, DEPTH, S, false>(a, st);

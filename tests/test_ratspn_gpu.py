@@ -266,6 +266,39 @@ def test_wide_channel_blocks_above_the_tile_switch(kw):
     assert rel_err(small.cpu().numpy(), want) <= LL_TOL
 
 
+def test_marginalised_inputs_on_both_kernel_builds():
+    """The two-channel unit-scale kernel exists in two builds (tiles with NaN / inf / out-of-bound evidence leave the
+    LDS record pipeline, or stay on it in the exact per-entry form); a launch takes the second one while a recent
+    launch met such a tile.  The same inputs evaluated before and after the switch: both match the oracle, an
+    all-NaN row is exactly 0 on both, and clean inputs are unaffected by which build ran."""
+    from deeprob.spn.models import GaussianRatSpn
+    torch.manual_seed(5)
+    model = GaussianRatSpn(784, rg_depth=2, rg_repetitions=8, random_state=42).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    gen = torch.Generator().manual_seed(6)
+    x = torch.randn(700, 784, generator=gen)
+    clean = x.clone()
+    x[torch.rand(700, 784, generator=gen) < 0.3] = float('nan')
+    x[3] = float('nan')
+    x[10, 5] = float('inf')
+    x[11, 700] = -float('inf')
+    x[12, 9] = 25.0                                   # beyond the expanded-square bound
+    x[200:264] = clean[200:264]                       # one clean tile in between
+    want = orc.ratspn_forward(sd, x).numpy()
+    want_clean = orc.ratspn_forward(sd, clean).numpy()
+    model = model.cuda()
+    outs = []
+    with torch.no_grad():
+        for _ in range(4):                            # the first launch raises the hint, the later ones see it
+            outs.append(model(x.cuda()).cpu().numpy())
+            torch.cuda.synchronize()
+        after = model(clean.cuda()).cpu().numpy()     # clean inputs right after: still the second build
+    for got in outs:
+        assert got[3, 0] == 0.0
+        assert rel_err(got, want) <= LL_TOL
+    assert rel_err(after, want_clean) <= LL_TOL
+
+
 def test_fused_plan_is_the_same_call(golden):
     """ops.FusedForwardPlan (pre-bound call for a resident buffer) == model(x) bit for bit; it reads live
     parameters and notices when a pinned address moved."""
