@@ -67,9 +67,24 @@ struct RatWs {
     int tabcap_c; // the same for the compact 48-byte records of the unit-scale two-channel kernel
     float *w[3];  // linear softmax weights: sum layer 0, sum layer 1, root
     float *lw[3]; // log-softmax weights
+    // MFMA leaf layer of the fused depth-2 model (ratspn_gemm.hip): the means as f16 (hi, lo) MFMA fragments
+    uint16_t *gm_tab;  // [NKSP][NT][2][64 lanes][8 halves]  mean table (x . mu GEMM)
+    uint16_t *gc_tab;  //  same layout: mu^2/2 + log sqrt(2 pi)  (marginalised-evidence correction GEMM)
+    float *gbias;      // [NCH][2][NT][16] per-(chunk, column) constants in the accumulator order of a lane
+    int *gelig;        // [NT*RPT] 1: repetition is unit-scale with bounded means
+    int g_nt, g_nksp;  // column tiles of 32, K-steps of 16 features (padded to whole chunks); 0 = not built
     int64_t bytes;
     int NC, SP, G, QB;
 };
+
+// geometry of the MFMA leaf layer (ratspn_gemm.hip)
+constexpr int kGemmKS = 4;                // K-steps of 16 features per staged chunk
+constexpr int kGemmKC = 16 * kGemmKS;     // features per chunk
+constexpr int kGemmMaxNT = 4;             // column tiles of 32 the fused kernel is built for
+static inline bool gemm_shape_ok(int D, int depth, int reps, int I, int S) {
+    if (depth != 2 || !(I == 2 || I == 4) || !(S == 2 || S == 4) || (D % 4) != 0 || reps < 1) return false;
+    return (reps * 4 * I + 31) / 32 <= kGemmMaxNT;
+}
 
 // region-group size used by the per-layer leaf operators (the fused model uses 2^depth)
 static inline int leaf_group(int R) { return (R % 4 == 0) ? 4 : 2; }
@@ -130,6 +145,17 @@ inline RatWs carve_ratspn_ws(void *base, int D, int R, int d, int I, int QB, int
     for (int i = 0; i < 3; ++i) {
         w.w[i] = (float *)take(n[i] * 4);
         w.lw[i] = (float *)take(n[i] * 4);
+    }
+    w.g_nt = 0;
+    w.g_nksp = 0;
+    if (gemm_shape_ok(D, depth, reps, I, S)) {
+        w.g_nt = (reps * 4 * I + 31) / 32;
+        w.g_nksp = ((D + kGemmKC - 1) / kGemmKC) * kGemmKS;
+        const int64_t tab = (int64_t)w.g_nksp * w.g_nt * 2 * 1024;
+        w.gm_tab = (uint16_t *)take(tab);
+        w.gc_tab = (uint16_t *)take(tab);
+        w.gbias = (float *)take((int64_t)((D + 31) / 32) * 2 * w.g_nt * 16 * 4);
+        w.gelig = (int *)take((int64_t)w.g_nt * 8 * 4);
     }
     w.bytes = o;
     return w;

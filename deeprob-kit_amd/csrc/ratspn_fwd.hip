@@ -14,23 +14,13 @@
 //     that repetition run in registers in the exp domain; the 8 repetitions meet in one
 //     LDS log-sum-exp for the root.
 #include "common.h"
+#include "ratspn_nodes.h"
 #include <math.h>
+#include <stdlib.h>
 #include <type_traits>
 
 namespace dpk {
 
-// Tables that only earlier kernels write are read through the constant address space: a
-// wave-uniform load from it is always selected as s_load (scalar cache), which is the whole
-// point of the lane <-> sample mapping.
-#define DPK_CONST __attribute__((address_space(4)))
-typedef const DPK_CONST float *cfloat_p;
-typedef const DPK_CONST int *cint_p;
-template <typename T> __host__ __device__ __forceinline__ const DPK_CONST T *as_const(const T *p) {
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wold-style-cast"
-    return (const DPK_CONST T *)p;
-#pragma clang diagnostic pop
-}
 
 // --------------------------------------------------------------------------------------
 // structure tables: sort every region's variable ids (the sum over a region is order
@@ -288,103 +278,6 @@ __global__ __launch_bounds__(256) void ratspn_prep_kernel(const PrepArgs a) {
     }
 }
 
-// --------------------------------------------------------------------------------------
-// in-register product+sum node:  out[o] = logsumexp_{i,j}(a[i] + c[j] + lw[o,i,j])
-// (ProductLayer.forward ratspn.py:280-285 followed by SumLayer.forward :375-377).
-// Fast path in the exp domain with linear softmax weights; when the scaled sum falls
-// below 1e-30 (dominant pair far from (argmax a, argmax c) AND a vanishing weight) the
-// exact two-pass form with the true maximum is used, which is what torch.logsumexp does.
-// --------------------------------------------------------------------------------------
-struct LseScratch {
-    float *slot;  // per-lane LDS slice, 2*NI floats
-};
-
-template <int NI>
-__device__ __forceinline__ void exact_lse(const float (&a)[NI], const float (&c)[NI],
-                                          cfloat_p lw, LseScratch sc, float &m_out, float &s_out) {
-    // rare, lane-divergent: keep it small (rolled loops over an LDS copy)
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        sc.slot[i] = a[i];
-        sc.slot[NI + i] = c[i];
-    }
-    float m = -INFINITY;
-#pragma unroll 1
-    for (int i = 0; i < NI; ++i)
-#pragma unroll 1
-        for (int j = 0; j < NI; ++j) m = fmaxf(m, sc.slot[i] + sc.slot[NI + j] + lw[i * NI + j]);
-    float s = 0.f;
-    if (m > -INFINITY) {
-#pragma unroll 1
-        for (int i = 0; i < NI; ++i)
-#pragma unroll 1
-            for (int j = 0; j < NI; ++j)
-                s += expf(sc.slot[i] + sc.slot[NI + j] + lw[i * NI + j] - m);
-    }
-    m_out = m;
-    s_out = s;
-}
-
-template <int NI>
-__device__ __forceinline__ void exp_children(const float (&a)[NI], float (&ea)[NI], float &ma) {
-    float m = a[0];
-#pragma unroll
-    for (int i = 1; i < NI; ++i) m = fmaxf(m, a[i]);
-    const float m0 = (m == -INFINITY) ? 0.f : m;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) ea[i] = __expf(a[i] - m0);
-    ma = m0;
-}
-
-template <int NI, int NO>
-__device__ __forceinline__ void prodsum_node(const float (&a)[NI], const float (&c)[NI],
-                                             cfloat_p W, cfloat_p LW, LseScratch sc,
-                                             float (&out)[NO]) {
-    float ea[NI], ec[NI], ma, mc;
-    exp_children<NI>(a, ea, ma);
-    exp_children<NI>(c, ec, mc);
-#pragma unroll
-    for (int o = 0; o < NO; ++o) {
-        float v = 0.f;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            float t = 0.f;
-#pragma unroll
-            for (int j = 0; j < NI; ++j) t = fmaf(W[(o * NI + i) * NI + j], ec[j], t);
-            v = fmaf(ea[i], t, v);
-        }
-        if (v < 1e-30f) {
-            float m, s;
-            exact_lse<NI>(a, c, LW + o * NI * NI, sc, m, s);
-            out[o] = (m > -INFINITY) ? m + logf(s) : -INFINITY;
-        } else {
-            out[o] = ma + mc + __logf(v);
-        }
-    }
-}
-
-// partial of the root log-sum-exp contributed by one repetition: (m, s) with
-// logsumexp = m + log s   (RootLayer.forward ratspn.py:454-457 restricted to one repetition)
-template <int NI>
-__device__ __forceinline__ void root_partial(const float (&a)[NI], const float (&c)[NI],
-                                             const float (&ea)[NI], const float (&ec)[NI], float ma,
-                                             float mc, cfloat_p W, cfloat_p LW, LseScratch sc,
-                                             float &m_out, float &s_out) {
-    float v = 0.f;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        float t = 0.f;
-#pragma unroll
-        for (int j = 0; j < NI; ++j) t = fmaf(W[i * NI + j], ec[j], t);
-        v = fmaf(ea[i], t, v);
-    }
-    if (v < 1e-30f) {
-        exact_lse<NI>(a, c, LW, sc, m_out, s_out);
-    } else {
-        m_out = ma + mc;
-        s_out = v;
-    }
-}
 
 // --------------------------------------------------------------------------------------
 // kernel arguments
@@ -1692,9 +1585,31 @@ static int fused_dispatch_i(const LeafArgs &a, int S, hipStream_t st) {
     return DPK_EUNSUPPORTED;
 }
 
+// ratspn_gemm.hip: fused forward with the leaf layer on the matrix cores
+int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const int64_t *mask, const uint8_t *pad,
+                        const float *loc, const float *scale, const float *sum_weight0, const float *root_weight,
+                        int reps, int I, int S, int C, float *out, double *ll_sum, uint32_t flags, hipStream_t st);
+
+// The MFMA route takes a fused evaluation when the model is in its envelope (depth 2, 2 or 4 channels / sums),
+// the caller hints unit scales (checked on the device), the rows of x are 16-byte aligned (LDS-DMA) and the leaf
+// outputs are not wanted.  DPK_RATSPN_GEMM=0 in the environment keeps the VALU kernels (A/B measurements).
+static bool gemm_route(const float *x, int D, int depth, int reps, int I, int S, int C, bool want_leaf, uint32_t flags) {
+    static const bool enabled = [] {
+        const char *e = getenv("DPK_RATSPN_GEMM");
+        return !(e && e[0] == '0');
+    }();
+    return enabled && !want_leaf && (flags & DPK_FLAG_UNIT_SCALE) != 0 && gemm_shape_ok(D, depth, reps, I, S) &&
+           C <= 64 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+}
+
 }  // namespace dpk
 
 using namespace dpk;
+
+extern "C" int dpk_ratspn_forward_on_mfma(const float *x, int32_t D, int32_t depth, int32_t reps, int32_t I,
+                                          int32_t S, int32_t C, int32_t want_leaf_out, uint32_t flags) {
+    return gemm_route(x, D, depth, reps, I, S, C, want_leaf_out != 0, flags) ? 1 : 0;
+}
 
 extern "C" int64_t dpk_ratspn_workspace_bytes(int32_t in_features, int32_t regions, int32_t dimension,
                                               int32_t channels, int32_t depth, int32_t reps,
@@ -1756,6 +1671,14 @@ extern "C" int dpk_ratspn_forward(const float *x, int64_t B, int32_t D, const in
     }
     if (B == 0) return DPK_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (gemm_route(x, D, depth, reps, I, S, C, leaf_out != nullptr, flags) && w.g_nt > 0) {
+        // keep the structure tables of the VALU route current too: a later call with the same (cached) structure
+        // may take that route (leaf outputs wanted, unaligned input)
+        int rc = prepare_leaf_structure(w, mask, pad_mask, R, d, flags, st);
+        if (rc) return rc;
+        return ratspn_gemm_forward(w, x, B, D, mask, pad_mask, loc, scale, sum_weight0, root_weight, reps, I, S, C,
+                                   out, ll_sum, flags, st);
+    }
     const int nlast = depth >= 2 ? S : I;
     SoftmaxJob jobs[3];
     int n_jobs = 0;

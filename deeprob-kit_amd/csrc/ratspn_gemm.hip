@@ -1,0 +1,723 @@
+// RAT-SPN fused forward with the leaf layer on the matrix cores (depth 2, unit-scale Gaussian leaves).
+//
+// reference: RegionGraphLayer.forward + GaussianLayer (deeprob/spn/layers/ratspn.py:87-108, :160-213),
+// ProductLayer :272-286, SumLayer :363-378, RootLayer :446-458, chained by RatSpn.forward
+// (deeprob/spn/models/ratspn.py:105-122).
+//
+// With sigma == 1 the leaf sum of region r, channel k is
+//     sum_f [f in r] ( x_f mu_rkf - mu_rkf^2/2 - log sqrt(2 pi) )  -  1/2 sum_f [f in r] x_f^2 .
+// The first part is a GEMM  P[b, n] = sum_f x[b, f] M[f, n]  over the n = (repetition, region, channel)
+// columns, with M[f, n] = mu where variable f belongs to the region of column n and 0 elsewhere (one
+// region per repetition holds f: M is 1/4 dense at depth 2).  The second part is common to the channels
+// of a region, hence factors out of every sum node above it; every repetition covers each variable once,
+// so what reaches the root is -1/2 sum_f x_f^2: one scalar per sample.
+//
+// The GEMM runs on v_mfma_f32_32x32x16_f16 with both operands split into two f16 halves (x = xh + xl,
+// mu = mh + ml, each half carrying 11 significant bits): x mu ~= mh xh + mh xl + ml xh, accumulated in
+// fp32; the dropped ml xl term is below 2^-22 |x mu|, i.e. the product keeps fp32 accuracy.  Three f16
+// MFMAs cost 3/16 of one fp32 MFMA, so even the dense form of the 1/4-dense matrix is ~5x cheaper than
+// the VALU form -- and, unlike it, leaves the kernel bound by the HBM stream of x.
+//
+// The constants: a chunk of 64 features without marginalised evidence adds its per-column sums of
+// -(mu^2/2 + log sqrt(2 pi)) ready-made (prepared table).  In a chunk that holds NaN evidence the NaN
+// entries become 0 and the constants of the OBSERVED variables only are accumulated by a second GEMM, a 0/1
+// validity indicator against the table of negated constants -- marginalisation is exact in the same form,
+// nothing is added and subtracted again, and an all-NaN row comes out as exactly 0 like the reference's.
+// Anything the expanded square cannot carry within the 1e-5 bar (+-inf or huge evidence, a sample whose
+// sum of squares is large, means beyond kExpandBound, non-unit scales) sends the 32 samples of the wave
+// through an exact per-element evaluation (gemm_exact_wave) -- correctness never depends on the hint.
+//
+// Mapping: a work-group of 4 waves owns 128 samples, a wave 32 of them.  The x tile streams through LDS
+// in chunks of 64 features by LDS-DMA (global_load_lds_dwordx4: full 256-byte row segments from HBM, the
+// 16-byte pieces XOR-swizzled on the SOURCE side so that the MFMA-shaped ds_read_b128 is conflict free),
+// three stages deep, counted vmcnt + raw s_barrier (no drain across the barrier).  The mean-table chunk
+// (16 KB of ready-made MFMA A-fragments, L2 resident) rides in the same stages.  The MFMA computes
+// P^T = M^T x^T, so a lane ends up holding, for ONE sample, the 16 columns of half a repetition set:
+// lane l (sample l & 31, half h = l >> 5) owns regions {2h, 2h+1} of every repetition, evaluates that
+// partition's product + sum nodes in registers, swaps the S outputs with lane l ^ 32 and finishes the
+// root.  Work-groups are persistent (grid = min(tiles, CUs)); the DMA ring runs across tile boundaries.
+#include "common.h"
+#include "ratspn_nodes.h"
+#include <math.h>
+
+namespace dpk {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2 __attribute__((ext_vector_type(2)));
+typedef float gf32x2 __attribute__((ext_vector_type(2)));
+typedef float gf32x4 __attribute__((ext_vector_type(4)));
+typedef float gf32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kGemmWaves = 4;
+constexpr int kGemmTile = 32 * kGemmWaves;           // samples per work-group tile
+constexpr int kGemmStages = 3;
+typedef __attribute__((address_space(3))) float lfloat;
+typedef __attribute__((address_space(3))) char lchar;
+typedef const __attribute__((address_space(1))) char *gcchar_p;
+typedef const __attribute__((address_space(1))) void *gvoid_p;
+// K-steps of 16 features per staged chunk: 64-feature chunks (256-byte row segments) while the mean table of a
+// chunk fits beside them, 32-feature chunks for wide column sets
+__host__ __device__ constexpr int gemm_ks(int NT) { return NT <= 2 ? 4 : 2; }
+constexpr float kGemmStepBound = 1.0e6f;             // a K-step whose 8 squares sum above this is examined
+constexpr float kGemmAbsBound = 1.0e3f;              // |x| above this: exact evaluation of the wave
+
+// ------------------------------------------------------------------------------------------------
+// tables, rebuilt from the live parameters: one block per repetition (+ the softmax rows behind them)
+// ------------------------------------------------------------------------------------------------
+struct GemmPrepArgs {
+    const int64_t *mask;
+    const uint8_t *pad;
+    const float *loc, *scale;
+    int D, d, reps, NT, NKSP, KS;
+    uint16_t *mtab, *ctab;
+    float *bias;
+    int *elig;
+    const float *w[3];
+    float *W[3], *LW[3];
+    int rows[3], n[3];
+};
+
+__device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
+template <int I>
+__global__ __launch_bounds__(256) void ratspn_gemm_prep_kernel(const GemmPrepArgs a) {
+    constexpr int RPT = 8 / I;       // repetitions per 32-column tile (4 regions x I channels each)
+    const int nrb = a.NT * RPT;
+    if ((int)blockIdx.x >= nrb) {
+        // softmax rows: one wave per row (torch.log_softmax at ratspn.py:375 and :455)
+        int row = (blockIdx.x - nrb) * 4 + (threadIdx.x >> 6);
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            if (row < a.rows[m]) {
+                const int n = a.n[m];
+                const float *src = a.w[m] + (int64_t)row * n;
+                float mx = -INFINITY;
+                for (int i = lane; i < n; i += 64) mx = fmaxf(mx, src[i]);
+                mx = wave_reduce_max(mx);
+                float sum = 0.f;
+                for (int i = lane; i < n; i += 64) sum += expf(src[i] - mx);
+                sum = wave_reduce_sum(sum);
+                const float ls = logf(sum);
+                for (int i = lane; i < n; i += 64) {
+                    const float l = src[i] - mx - ls;
+                    a.LW[m][(int64_t)row * n + i] = l;
+                    a.W[m][(int64_t)row * n + i] = expf(l);
+                }
+                return;
+            }
+            row -= a.rows[m];
+        }
+        return;
+    }
+    extern __shared__ int posrow[];  // [D] position q*d + j of variable f in this repetition, -1 if absent
+    __shared__ int bad_s;
+    const int rho = blockIdx.x;
+    const bool real = rho < a.reps;
+    const int D = a.D, d = a.d;
+    for (int f = threadIdx.x; f < D; f += blockDim.x) posrow[f] = -1;
+    if (threadIdx.x == 0) bad_s = 0;
+    __syncthreads();
+    if (real) {
+        for (int e = threadIdx.x; e < 4 * d; e += blockDim.x) {
+            const int64_t o = (int64_t)rho * 4 * d + e;
+            if (a.pad != nullptr && a.pad[o]) continue;
+            const int f = (int)a.mask[o];
+            if (f >= 0 && f < D) posrow[f] = e;
+        }
+    }
+    __syncthreads();
+    const int t = rho / RPT, ap = rho - t * RPT;
+    // fragment entries: (K-step, lane half, column of this repetition) -> 8 consecutive variables
+    for (int e = threadIdx.x; e < a.NKSP * 2 * 4 * I; e += blockDim.x) {
+        const int col = e % (4 * I);
+        const int hg = (e / (4 * I)) & 1;
+        const int ks = e / (8 * I);
+        const int q = col / I, k = col - q * I;
+        const int h = q >> 1, qq = q & 1;
+        const int u = (ap * 2 + qq) * I + k;               // accumulator register of the lane half
+        const int row = (u & 3) + 8 * (u >> 2) + 4 * h;    // MFMA output row = A-fragment row
+        const int r = rho * 4 + q;
+        half8 mh, ml, ch, cl;
+#pragma unroll
+        for (int el = 0; el < 8; ++el) {
+            const int f = ks * 16 + hg * 8 + el;
+            float mu = 0.f, cc = 0.f;
+            if (real && f < D) {
+                const int p = posrow[f];
+                if (p >= 0 && p / d == q) {
+                    mu = a.loc[((int64_t)r * I + k) * d + (p - q * d)];
+                    cc = -fmaf(0.5f * mu, mu, kLogSqrt2Pi);
+                }
+            }
+            _Float16 hi, lo;
+            split_f16(mu, hi, lo);
+            mh[el] = hi; ml[el] = lo;
+            split_f16(cc, hi, lo);
+            ch[el] = hi; cl[el] = lo;
+        }
+        const int64_t o = (((int64_t)ks * a.NT + t) * 2) * 512 + (hg * 32 + row) * 8;
+        *reinterpret_cast<half8 *>(a.mtab + o) = mh;
+        *reinterpret_cast<half8 *>(a.mtab + o + 512) = ml;
+        *reinterpret_cast<half8 *>(a.ctab + o) = ch;
+        *reinterpret_cast<half8 *>(a.ctab + o + 512) = cl;
+    }
+    // per-(chunk, column) constants - sum_f (mu^2/2 + log sqrt(2 pi)) over the variables of the chunk that belong to
+    // the column's region (a chunk without marginalised evidence adds them ready-made)
+    const int KC = 16 * a.KS;
+    const int NCH = (D + KC - 1) / KC;
+    for (int e = threadIdx.x; e < NCH * 4 * I; e += blockDim.x) {
+        const int col = e % (4 * I), c = e / (4 * I);
+        const int q = col / I, k = col - q * I;
+        const int r = rho * 4 + q;
+        float sum = 0.f;
+        if (real) {
+            const int f1 = min(D, (c + 1) * KC);
+            for (int f = c * KC; f < f1; ++f) {
+                const int p = posrow[f];
+                if (p >= 0 && p / d == q) {
+                    const float mu = a.loc[((int64_t)r * I + k) * d + (p - q * d)];
+                    sum -= fmaf(0.5f * mu, mu, kLogSqrt2Pi);
+                }
+            }
+        }
+        const int h = q >> 1, qq = q & 1;
+        const int u = (ap * 2 + qq) * I + k;
+        a.bias[((c * 2 + h) * a.NT + t) * 16 + u] = sum;
+    }
+    // eligibility of the repetition for the expanded form: scale == 1 everywhere, |mu| <= kExpandBound
+    bool bad = false;
+    if (real) {
+        for (int e = threadIdx.x; e < 4 * I * d; e += blockDim.x) {
+            const int64_t o = (int64_t)rho * 4 * I * d + e;
+            const int rr = e / (I * d), j = e % d;
+            if (a.pad != nullptr && a.pad[((int64_t)rho * 4 + rr) * d + j]) continue;
+            bad = bad || !(fabsf(a.loc[o]) <= kExpandBound) || (a.scale[o] != 1.0f);
+        }
+    }
+    if (bad) bad_s = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) a.elig[rho] = bad_s ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// main kernel
+// ------------------------------------------------------------------------------------------------
+struct GemmArgs {
+    const float *x;
+    int64_t B;
+    int D, d, reps, C, NCH, ntiles;
+    const uint16_t *mtab, *ctab;
+    const float *biasT;
+    const int *elig;
+    const float *W0;   // [reps*2][S][I*I] linear softmax weights (copied into LDS)
+    const float *LW0;  // log-softmax weights (exact fallback of a node, exact evaluation)
+    cfloat_p Wr, LWr;  // [C][reps*S*S]
+    float *out;
+    double *ll_sum;
+    // exact evaluation
+    const int64_t *mask;
+    const uint8_t *pad;
+    const float *loc, *scale;
+    int *slow_flag;   // host-mapped hint word (may be null): launch number of the last launch that met NaN evidence
+    int launch_seq;
+};
+
+__device__ __forceinline__ void lse_merge(float &m, float &s, float m2, float s2) {
+    const float mm = fmaxf(m, m2);
+    if (mm == -INFINITY) {
+        s = 0.f;
+        return;
+    }
+    s = s * __expf(m - mm) + s2 * __expf(m2 - mm);
+    m = mm;
+}
+
+__device__ __forceinline__ void gemm_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Exact per-element evaluation of the 32 samples of a wave (any scale, any evidence): lane (s, h) takes the
+// repetitions rho = 2m + h, the two lanes of a sample meet in one shuffle per class.  Slow by design.
+template <int I, int S, int NT>
+__device__ __noinline__ void gemm_exact_wave(const GemmArgs &a, int64_t bw0, int lane, LseScratch sc) {
+    constexpr int RPT = 8 / I;
+    constexpr int RH = (NT * RPT + 1) / 2;   // repetitions per lane half
+    const int s = lane & 31, h = lane >> 5;
+    const int64_t b = bw0 + s;
+    const bool valid = b < a.B;
+    const float *xr = a.x + (valid ? b : a.B - 1) * a.D;
+    const int d = a.d;
+    float n1[RH][2][S];
+#pragma unroll
+    for (int m = 0; m < RH; ++m) {
+        const int rho = 2 * m + h;
+        float leaf[4][I];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < I; ++k) leaf[q][k] = 0.f;
+        if (rho < a.reps) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = rho * 4 + q;
+                for (int j = 0; j < d; ++j) {
+                    const int64_t o = (int64_t)r * d + j;
+                    if (a.pad != nullptr && a.pad[o]) continue;
+                    const float xv = xr[a.mask[o]];
+#pragma unroll
+                    for (int k = 0; k < I; ++k) {
+                        const int64_t po = ((int64_t)r * I + k) * d + j;
+                        const float mu = a.loc[po], sg = a.scale[po];
+                        const float dlt = xv - mu;
+                        leaf[q][k] += nan_to_num_f(fmaf(dlt * dlt, -0.5f / (sg * sg), -logf(sg) - kLogSqrt2Pi));
+                    }
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int64_t wo = ((int64_t)rho * 2 + p) * S * I * I;
+                prodsum_node<I, S>(leaf[2 * p], leaf[2 * p + 1], a.W0 + wo, a.LW0 + wo, sc, n1[m][p]);
+            }
+        }
+    }
+    const int M = a.reps * S * S;
+    double part = 0.0;
+    for (int cl = 0; cl < a.C; ++cl) {
+        float mm = -INFINITY, ss = 0.f;
+#pragma unroll
+        for (int m = 0; m < RH; ++m) {
+            const int rho = 2 * m + h;
+            if (rho < a.reps) {
+                float ea[S], ec[S], ma, mc, pm, ps;
+                exp_children<S>(n1[m][0], ea, ma);
+                exp_children<S>(n1[m][1], ec, mc);
+                const float *wr = (const float *)a.Wr + (int64_t)cl * M + rho * S * S;
+                const float *lwr = (const float *)a.LWr + (int64_t)cl * M + rho * S * S;
+                root_partial<S>(n1[m][0], n1[m][1], ea, ec, ma, mc, wr, lwr, sc, pm, ps);
+                lse_merge(mm, ss, pm, ps);
+            }
+        }
+        const float om = __shfl_xor(mm, 32, 64), os = __shfl_xor(ss, 32, 64);
+        lse_merge(mm, ss, om, os);
+        const float ll = (mm > -INFINITY) ? mm + logf(ss) : -INFINITY;
+        if (h == 0 && valid) {
+            a.out[b * a.C + cl] = ll;
+            part += (double)ll;
+        }
+    }
+    if (a.ll_sum != nullptr) {
+        part = wave_reduce_sum(part);
+        if (lane == 0) {
+            int64_t nv = a.B - bw0;
+            nv = nv < 0 ? 0 : (nv > 32 ? 32 : nv);
+            atomicAdd(a.ll_sum, part);
+            atomicAdd(a.ll_sum + 1, (double)(nv * a.C));
+        }
+    }
+}
+
+template <int I, int S, int NT>
+__global__ __launch_bounds__(kGemmWaves * 64, 1) void ratspn_gemm_kernel(const GemmArgs a) {
+    constexpr int RPT = 8 / I;                           // repetitions per column tile
+    constexpr int KS = gemm_ks(NT);
+    constexpr int KC = 16 * KS;                          // features per chunk
+    constexpr int W = 4 * KS;                            // 16-byte pieces per staged row
+    constexpr int ROWB = KC * 4;
+    constexpr int RPI = 64 / W;                          // rows per x DMA instruction
+    constexpr int SWS = (W == 16) ? 0 : (W == 8 ? 1 : 2);  // swizzle: piece ^= (row >> SWS) & (W-1)
+    constexpr int XB = kGemmTile * ROWB;                 // x chunk bytes
+    constexpr int BB = KS * NT * 2 * 1024;               // mean-table bytes per chunk
+    constexpr int STAGE = XB + BB;
+    constexpr int NS = kGemmStages;
+    constexpr int PX = 32 / RPI;                         // x DMA instructions per wave and chunk
+    constexpr int PB = BB / (kGemmWaves * 1024);         // table DMA instructions per wave and chunk
+    constexpr int P = PX + PB;                           // DMA instructions per wave and chunk
+    static_assert(BB % (kGemmWaves * 1024) == 0, "table chunk must split over the waves");
+    static_assert((NS - 2) * P <= 63, "vmcnt field");
+    constexpr int NMAX = (I > S ? I : S);
+
+    extern __shared__ __attribute__((aligned(16))) char smem_generic[];
+    lchar *smem = (lchar *)smem_generic;
+    const int nbias = a.NCH * 2 * NT * 16;
+    lfloat *bias_l = (lfloat *)(smem + NS * STAGE);                  // [NCH][2][NT][16] constants per chunk
+    lfloat *w0_l = bias_l + nbias;                                   // [reps*2][S*I*I]
+    float *scr_l = reinterpret_cast<float *>(smem_generic + NS * STAGE) + nbias +
+                   a.reps * 2 * S * I * I;                           // [256][2*NMAX] exact_lse scratch
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = lane & 31, h = lane >> 5;
+    const int D = a.D, NCH = a.NCH;
+
+    // constants into LDS (ordinary loads: no DMA is in flight yet)
+    for (int e = tid; e < nbias; e += kGemmWaves * 64) bias_l[e] = a.biasT[e];
+    for (int e = tid; e < a.reps * 2 * S * I * I; e += kGemmWaves * 64) w0_l[e] = a.W0[e];
+    bool model_ok = true;
+    for (int e = lane; e < NT * RPT; e += 64) model_ok = model_ok && (a.elig[e] != 0);
+    model_ok = __all(model_ok);
+    __syncthreads();
+
+    LseScratch sc{scr_l + tid * (2 * NMAX)};
+
+    // this work-group's tiles: blockIdx.x, + gridDim.x, ... (persistent); every counter below is wave-uniform
+    static_assert(NS == 3, "the counted waits below leave exactly one chunk in flight");
+    const int grid = (int)gridDim.x;
+    const int ntiles = a.ntiles;
+    const gcchar_p mtab_b = (gcchar_p)a.mtab;
+
+    // per-lane source offsets of the x pieces this lane copies (full tile, full chunk), in bytes from the
+    // tile's first row + the chunk's first feature
+    int voff[PX];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        const int rl = wave * 32 + j * RPI + lane / W;
+        const int gp = (lane & (W - 1)) ^ ((rl >> SWS) & (W - 1));
+        voff[j] = (rl * D + gp * 4) * 4;
+    }
+    const int toff = wave * (PB * 1024) + lane * 16;
+
+    int ptile = (int)blockIdx.x, pc = 0, pstage = 0;   // next chunk to stage
+    auto issue_next = [&]() {
+        const int64_t b0 = (int64_t)ptile * kGemmTile;
+        lchar *st = smem + pstage * STAGE;
+        const gcchar_p xt = (gcchar_p)a.x + (b0 * D + pc * KC) * 4;
+        const bool full = (b0 + kGemmTile <= a.B) && ((pc + 1) * KC <= D);
+        if (full) {
+#pragma unroll
+            for (int j = 0; j < PX; ++j)
+                __builtin_amdgcn_global_load_lds((gvoid_p)(xt + voff[j]),
+                                                 (__attribute__((address_space(3))) void *)(st + (wave * 32 + j * RPI) * ROWB),
+                                                 16, 0, 0);
+        } else {   // ragged tile / last chunk: clamp to rows and pieces that exist (clamped slots are never consumed)
+            const int nvalid = (int)min((int64_t)kGemmTile, a.B - b0);
+            const int vp = min(W, (D - pc * KC) >> 2);
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                const int rl = wave * 32 + j * RPI + lane / W;
+                const int gp = min((lane & (W - 1)) ^ ((rl >> SWS) & (W - 1)), vp - 1);
+                const int off = (min(rl, nvalid - 1) * D + gp * 4) * 4;
+                __builtin_amdgcn_global_load_lds((gvoid_p)(xt + off),
+                                                 (__attribute__((address_space(3))) void *)(st + (wave * 32 + j * RPI) * ROWB),
+                                                 16, 0, 0);
+            }
+        }
+        const gcchar_p tsrc = mtab_b + (int64_t)pc * BB + toff;
+        lchar *tdst = st + XB + wave * (PB * 1024);
+#pragma unroll
+        for (int j = 0; j < PB; ++j)
+            __builtin_amdgcn_global_load_lds((gvoid_p)(tsrc + j * 1024),
+                                             (__attribute__((address_space(3))) void *)(tdst + j * 1024), 16, 0, 0);
+        pstage = (pstage + 1 == NS) ? 0 : pstage + 1;
+        if (++pc == NCH) {
+            pc = 0;
+            ptile += grid;
+        }
+    };
+
+#pragma unroll
+    for (int g = 0; g < NS - 1; ++g)
+        if (ptile < ntiles) issue_next();
+
+    bool saw_nan = false;
+    int cstage = 0;
+    for (int tile = (int)blockIdx.x; tile < ntiles; tile += grid) {
+        gf32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        float cacc[NT][16];   // per-column constants of the clean chunks
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cacc[t][i] = 0.f;
+        float qsum = 0.f;
+        bool need_exact = false;
+        for (int c = 0; c < NCH; ++c) {
+            // chunk (tile, c) has landed once at most one later chunk is still in flight (none exists at the very end)
+            if (c + 1 < NCH || tile + grid < ntiles) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            gemm_lds_barrier();   // everyone's share of this chunk is in LDS; everyone is done reading the previous one
+            if (ptile < ntiles) issue_next();
+
+            const lchar *st = smem + cstage * STAGE;
+            cstage = (cstage + 1 == NS) ? 0 : cstage + 1;
+            const int rl = wave * 32 + s;
+            const lchar *xr = st + rl * ROWB;
+            const int sw = (rl >> SWS) & (W - 1);
+            const int nks = min(KS, (D - c * KC + 15) >> 4);
+            typedef __attribute__((address_space(3))) const gf32x4 lf4;
+            typedef __attribute__((address_space(3))) const half8 lh8;
+            // the lane's 8*KS values of this chunk (K-steps beyond the row end re-read the first one: never used)
+            float v[KS][8];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int pcs = (ks < nks ? ks : 0) * 4 + h * 2;
+                const gf32x4 x0 = *(lf4 *)(xr + ((pcs ^ sw) << 4));
+                const gf32x4 x1 = *(lf4 *)(xr + (((pcs | 1) ^ sw) << 4));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[ks][i] = x0[i];
+                    v[ks][4 + i] = x1[i];
+                }
+            }
+            if ((c + 1) * KC > D) {   // last chunk: slots beyond D hold clamped copies (or nothing this chunk wrote)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int f0 = c * KC + ks * 16 + h * 8;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[ks][i] = (f0 + i < D) ? v[ks][i] : 0.f;
+                }
+            }
+            gf32x2 tq2 = {0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    const gf32x2 pv = {v[ks][i], v[ks][i + 1]};
+                    tq2 = __builtin_elementwise_fma(pv, pv, tq2);
+                }
+            float tq = tq2[0] + tq2[1];
+            // NaN / +-inf / huge evidence anywhere in the wave's share of the chunk?
+            const bool odd_chunk = __any(!(tq < kGemmStepBound));
+            half8 valid[KS];
+            if (odd_chunk) {
+                // NaN (marginalised) entries count as 0 and drop out of the constants (validity indicator below);
+                // +-inf / huge entries send the wave through the exact evaluation at the end of the tile
+                tq = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float vi = v[ks][i];
+                        const bool isn = vi != vi;
+                        const bool big = !isn && !(fabsf(vi) < kGemmAbsBound);
+                        need_exact = need_exact || big;
+                        saw_nan = saw_nan || isn;
+                        v[ks][i] = (isn || big) ? 0.f : vi;
+                        valid[ks][i] = isn ? (_Float16)0.0f : (_Float16)1.0f;
+                        tq = fmaf(v[ks][i], v[ks][i], tq);
+                    }
+            } else {
+                // clean chunk: its per-column constants come ready-made
+                lf4 *bc = (lf4 *)(bias_l + ((c * 2 + h) * NT) * 16);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const gf32x4 q4 = bc[t * 4 + i];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) cacc[t][4 * i + j] += q4[j];
+                    }
+            }
+            qsum += tq;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks < nks) {
+                    half8 xh, xl;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        xh[i] = (_Float16)v[ks][i];
+                        xl[i] = (_Float16)(v[ks][i] - (float)xh[i]);
+                    }
+                    const lchar *tb = st + XB + ks * (NT * 2048) + lane * 16;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const half8 mh = *(lh8 *)(tb + t * 2048);
+                        const half8 ml = *(lh8 *)(tb + t * 2048 + 1024);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh, xh, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh, xl, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml, xh, acc[t], 0, 0, 0);
+                    }
+                    if (odd_chunk) {
+                        // - (mu^2/2 + log sqrt(2 pi)) of the variables that ARE observed (table holds the negated constants)
+                        typedef const __attribute__((address_space(1))) half8 gh8;
+                        const gcchar_p cb = (gcchar_p)a.ctab + ((((int64_t)(c * KS + ks) * NT) * 2) * 512 + lane * 8) * 2;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const half8 ch = *(gh8 *)(cb + t * 2048);
+                            const half8 cl = *(gh8 *)(cb + t * 2048 + 1024);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, valid[ks], acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, valid[ks], acc[t], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        {
+            // ---- upper layers of the tile ------------------------------------------------------------
+            const int64_t b0 = (int64_t)tile * kGemmTile;
+            const int64_t bw0 = b0 + wave * 32;
+            const int64_t b = bw0 + s;
+            const float qtot = qsum + __shfl_xor(qsum, 32, 64);
+            // the expanded square is within the 1e-5 bar while sum x^2 <= 36 D (|mu| <= 6: DESIGN 3.3)
+            const bool lane_exact = need_exact || !(qtot <= kExpandBound * kExpandBound * (float)D);
+            if (!model_ok || __any(lane_exact)) {
+                // (a private copy: handing the kernel argument block itself to a call would move it, and with it
+                // every loop counter derived from it, out of the scalar registers)
+                const GemmArgs ac = a;
+                gemm_exact_wave<I, S, NT>(ac, bw0, lane, sc);
+            } else {
+                float ta[NT * RPT][S], tc[NT * RPT][S];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                    for (int ap = 0; ap < RPT; ++ap) {
+                        const int rho = t * RPT + ap;
+                        float n1[S];
+#pragma unroll
+                        for (int o = 0; o < S; ++o) n1[o] = -INFINITY;
+                        if (rho < a.reps) {
+                            float va[I], vc[I];
+#pragma unroll
+                            for (int k = 0; k < I; ++k) {
+                                va[k] = acc[t][(ap * 2) * I + k] + cacc[t][(ap * 2) * I + k];
+                                vc[k] = acc[t][(ap * 2 + 1) * I + k] + cacc[t][(ap * 2 + 1) * I + k];
+                            }
+                            const int wo = (rho * 2 + h) * S * I * I;
+                            prodsum_node<I, S>(va, vc, w0_l + wo, a.LW0 + wo, sc, n1);
+                        }
+                        // both lanes of a sample finish every repetition (the root weights stay wave-uniform)
+#pragma unroll
+                        for (int o = 0; o < S; ++o) {
+                            const float oth = __shfl_xor(n1[o], 32, 64);
+                            ta[rho][o] = h == 0 ? n1[o] : oth;
+                            tc[rho][o] = h == 0 ? oth : n1[o];
+                        }
+                    }
+                }
+                const int M = a.reps * S * S;
+                const float qterm = -0.5f * qtot;
+                double part = 0.0;
+                for (int cl = 0; cl < a.C; ++cl) {
+                    float mm = -INFINITY, ss = 0.f;
+#pragma unroll
+                    for (int rho = 0; rho < NT * RPT; ++rho) {
+                        if (rho < a.reps) {
+                            float ea[S], ec[S], ma, mc, pm, ps;
+                            exp_children<S>(ta[rho], ea, ma);
+                            exp_children<S>(tc[rho], ec, mc);
+                            const int wo = cl * M + rho * S * S;
+                            root_partial<S>(ta[rho], tc[rho], ea, ec, ma, mc, a.Wr + wo, a.LWr + wo, sc, pm, ps);
+                            lse_merge(mm, ss, pm, ps);
+                        }
+                    }
+                    const float ll = (mm > -INFINITY) ? mm + __logf(ss) + qterm : -INFINITY;
+                    if (h == 0 && b < a.B) {
+                        a.out[b * a.C + cl] = ll;
+                        part += (double)ll;
+                    }
+                }
+                if (a.ll_sum != nullptr) {
+                    part = wave_reduce_sum(part);
+                    if (lane == 0) {
+                        int64_t nv = a.B - bw0;
+                        nv = nv < 0 ? 0 : (nv > 32 ? 32 : nv);
+                        atomicAdd(a.ll_sum, part);
+                        atomicAdd(a.ll_sum + 1, (double)(nv * a.C));
+                    }
+                }
+            }
+        }
+    }
+    if (saw_nan && lane == 0 && a.slow_flag != nullptr) *a.slow_flag = a.launch_seq;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+template <int I, int S, int NT>
+static int gemm_launch(const GemmArgs &a, int reps, hipStream_t st) {
+    constexpr int KS = gemm_ks(NT);
+    constexpr int BB = KS * NT * 2 * 1024;
+    constexpr int NMAX = (I > S ? I : S);
+    const size_t lds = (size_t)kGemmStages * (kGemmTile * 64 * KS + BB) +
+                       (size_t)(a.NCH * 2 * NT * 16 + reps * 2 * S * I * I) * 4 + (size_t)kGemmWaves * 64 * 2 * NMAX * 4;
+    DPK_REQUIRE(lds <= 160 * 1024, DPK_EUNSUPPORTED, "ratspn_gemm: %zu bytes of LDS", lds);
+    auto kern = ratspn_gemm_kernel<I, S, NT>;
+    static bool attr_done = false;   // per instantiation
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
+            return DPK_ELAUNCH;
+        }
+        attr_done = true;
+    }
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else cus = 256;
+    }
+    const int grid = a.ntiles < cus ? a.ntiles : cus;
+    hipEvent_t ev0, ev1;
+    profile_take(&ev0, &ev1);
+    if (ev0) (void)hipEventRecord(ev0, st);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kGemmWaves * 64), lds, st, a);
+    if (ev1) (void)hipEventRecord(ev1, st);
+    DPK_CHECK_LAUNCH("ratspn_gemm_kernel");
+    return DPK_OK;
+}
+
+template <int I, int S>
+static int gemm_dispatch_nt(const GemmArgs &a, int reps, int NT, hipStream_t st) {
+    switch (NT) {
+        case 1: return gemm_launch<I, S, 1>(a, reps, st);
+        case 2: return gemm_launch<I, S, 2>(a, reps, st);
+        case 3: return gemm_launch<I, S, 3>(a, reps, st);
+        case 4: return gemm_launch<I, S, 4>(a, reps, st);
+    }
+    set_error("ratspn_gemm: %d column tiles not built", NT);
+    return DPK_EUNSUPPORTED;
+}
+
+// The caller (dpk_ratspn_forward) has validated the arguments and carved the workspace.
+int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const int64_t *mask, const uint8_t *pad,
+                        const float *loc, const float *scale, const float *sum_weight0, const float *root_weight,
+                        int reps, int I, int S, int C, float *out, double *ll_sum, uint32_t flags, hipStream_t st) {
+    const int d = (D + (4 - D % 4) % 4) / 4;
+    const int NT = w.g_nt;
+    if (!(flags & DPK_FLAG_PARAMS_CACHED)) {
+        GemmPrepArgs p{};
+        p.mask = mask; p.pad = pad; p.loc = loc; p.scale = scale;
+        p.D = D; p.d = d; p.reps = reps; p.NT = NT; p.NKSP = w.g_nksp; p.KS = gemm_ks(NT);
+        p.mtab = w.gm_tab; p.ctab = w.gc_tab; p.bias = w.gbias; p.elig = w.gelig;
+        p.w[0] = sum_weight0; p.W[0] = w.w[0]; p.LW[0] = w.lw[0]; p.rows[0] = reps * 2 * S; p.n[0] = I * I;
+        p.w[1] = root_weight; p.W[1] = w.w[2]; p.LW[1] = w.lw[2]; p.rows[1] = C; p.n[1] = reps * S * S;
+        const int nrb = NT * (8 / I);
+        const int grid = nrb + cdiv(p.rows[0] + p.rows[1], 4);
+        const size_t lds = (size_t)D * sizeof(int);
+        DPK_REQUIRE(lds <= 60 * 1024, DPK_EUNSUPPORTED, "ratspn_gemm: in_features=%d too large for the table kernel", D);
+        if (I == 2) hipLaunchKernelGGL(ratspn_gemm_prep_kernel<2>, dim3(grid), dim3(256), lds, st, p);
+        else hipLaunchKernelGGL(ratspn_gemm_prep_kernel<4>, dim3(grid), dim3(256), lds, st, p);
+        DPK_CHECK_LAUNCH("ratspn_gemm_prep_kernel");
+    }
+    GemmArgs a{};
+    a.x = x; a.B = B; a.D = D; a.d = d; a.reps = reps; a.C = C;
+    a.NCH = cdiv(D, 16 * gemm_ks(NT));
+    a.ntiles = cdiv(B, kGemmTile);
+    a.mtab = w.gm_tab; a.ctab = w.gc_tab; a.biasT = w.gbias; a.elig = w.gelig;
+    a.W0 = w.w[0]; a.LW0 = w.lw[0]; a.Wr = as_const(w.w[2]); a.LWr = as_const(w.lw[2]);
+    a.out = out; a.ll_sum = ll_sum;
+    a.mask = mask; a.pad = pad; a.loc = loc; a.scale = scale;
+    if (I == 2) {
+        if (S == 2) return gemm_dispatch_nt<2, 2>(a, reps, NT, st);
+        return gemm_dispatch_nt<2, 4>(a, reps, NT, st);
+    }
+    if (S == 2) return gemm_dispatch_nt<4, 2>(a, reps, NT, st);
+    return gemm_dispatch_nt<4, 4>(a, reps, NT, st);
+}
+
+}  // namespace dpk

@@ -45,6 +45,11 @@ extern "C" {
                                      the device re-checks and takes the general path where the hint
                                      is wrong, so it never changes results                         */
 
+#define DPK_FLAG_PARAMS_CACHED 4u  /* dpk_ratspn_forward on the MFMA route (dpk_ratspn_forward_on_mfma):
+                                     the parameter tables in `ws` were built by an earlier call from the
+                                     same, unchanged loc / scale / weights: skip rebuilding them.  Ignored
+                                     on every other route (tables are rebuilt per call there)              */
+
 const char *dpk_last_error(void);
 int dpk_abi_version(void);
 
@@ -131,6 +136,11 @@ int dpk_root_backward(const float *in, const float *weight, const float *out, co
  *   out            [B, C]
  *   leaf_out       [B, R, I] or NULL -- leaf log-likelihoods kept for backward
  *   ll_sum         double[2] or NULL -- += {sum of out, number of entries}    */
+/* 1 when dpk_ratspn_forward with these arguments evaluates the leaf layer on the matrix cores
+ * (depth 2, channels / sums in {2,4}, unit-scale hint, 16-byte aligned rows, no leaf_out): only then is
+ * DPK_FLAG_PARAMS_CACHED honoured.  Pure function of its arguments, no device work.                     */
+int dpk_ratspn_forward_on_mfma(const float *x, int32_t D, int32_t depth, int32_t reps, int32_t I, int32_t S,
+                               int32_t C, int32_t want_leaf_out, uint32_t flags);
 int dpk_ratspn_forward(const float *x, int64_t B, int32_t D, const int64_t *mask,
                        const uint8_t *pad_mask, const float *loc, const float *scale,
                        const float *sum_weight0, const float *sum_weight1,
