@@ -71,6 +71,7 @@ struct RatWs {
     uint16_t *gm_tab;  // [NKSP][NT][2][64 lanes][8 halves]  mean table (x . mu GEMM)
     uint16_t *gc_tab;  //  same layout: mu^2/2 + log sqrt(2 pi)  (marginalised-evidence correction GEMM)
     float *gbias;      // [NCH][2][NT][16] per-(chunk, column) constants in the accumulator order of a lane
+    float *gbias_row;  // [2][NT][16] the sums over all chunks
     int *gelig;        // [NT*RPT] 1: repetition is unit-scale with bounded means
     int g_nt, g_nksp;  // column tiles of 32, K-steps of 16 features (padded to whole chunks); 0 = not built
     int64_t bytes;
@@ -155,6 +156,7 @@ inline RatWs carve_ratspn_ws(void *base, int D, int R, int d, int I, int QB, int
         w.gm_tab = (uint16_t *)take(tab);
         w.gc_tab = (uint16_t *)take(tab);
         w.gbias = (float *)take((int64_t)((D + 31) / 32) * 2 * w.g_nt * 16 * 4);
+        w.gbias_row = (float *)take((int64_t)2 * w.g_nt * 16 * 4);
         w.gelig = (int *)take((int64_t)w.g_nt * 8 * 4);
     }
     w.bytes = o;

@@ -39,6 +39,7 @@
 #include "common.h"
 #include "ratspn_nodes.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace dpk {
 
@@ -71,7 +72,7 @@ struct GemmPrepArgs {
     const float *loc, *scale;
     int D, d, reps, NT, NKSP, KS;
     uint16_t *mtab, *ctab;
-    float *bias;
+    float *bias, *bias_row;
     int *elig;
     const float *w[3];
     float *W[3], *LW[3];
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(256) void ratspn_gemm_prep_kernel(const GemmPrepArg
         return;
     }
     extern __shared__ int posrow[];  // [D] position q*d + j of variable f in this repetition, -1 if absent
+    float *locs = reinterpret_cast<float *>(posrow + a.D);   // [4][I][d] the repetition's means
     __shared__ int bad_s;
     const int rho = blockIdx.x;
     const bool real = rho < a.reps;
@@ -122,6 +124,7 @@ __global__ __launch_bounds__(256) void ratspn_gemm_prep_kernel(const GemmPrepArg
     for (int f = threadIdx.x; f < D; f += blockDim.x) posrow[f] = -1;
     if (threadIdx.x == 0) bad_s = 0;
     __syncthreads();
+    bool bad = false;
     if (real) {
         for (int e = threadIdx.x; e < 4 * d; e += blockDim.x) {
             const int64_t o = (int64_t)rho * 4 * d + e;
@@ -129,7 +132,17 @@ __global__ __launch_bounds__(256) void ratspn_gemm_prep_kernel(const GemmPrepArg
             const int f = (int)a.mask[o];
             if (f >= 0 && f < D) posrow[f] = e;
         }
+        // eligibility of the repetition for the expanded form: scale == 1 everywhere, |mu| <= kExpandBound
+        for (int e = threadIdx.x; e < 4 * I * d; e += blockDim.x) {
+            const int64_t o = (int64_t)rho * 4 * I * d + e;
+            const float mu = a.loc[o];
+            locs[e] = mu;
+            const int rr = e / (I * d), j = e % d;
+            if (a.pad != nullptr && a.pad[((int64_t)rho * 4 + rr) * d + j]) continue;
+            bad = bad || !(fabsf(mu) <= kExpandBound) || (a.scale[o] != 1.0f);
+        }
     }
+    if (bad) bad_s = 1;
     __syncthreads();
     const int t = rho / RPT, ap = rho - t * RPT;
     // fragment entries: (K-step, lane half, column of this repetition) -> 8 consecutive variables
@@ -141,7 +154,6 @@ __global__ __launch_bounds__(256) void ratspn_gemm_prep_kernel(const GemmPrepArg
         const int h = q >> 1, qq = q & 1;
         const int u = (ap * 2 + qq) * I + k;               // accumulator register of the lane half
         const int row = (u & 3) + 8 * (u >> 2) + 4 * h;    // MFMA output row = A-fragment row
-        const int r = rho * 4 + q;
         half8 mh, ml, ch, cl;
 #pragma unroll
         for (int el = 0; el < 8; ++el) {
@@ -150,7 +162,7 @@ __global__ __launch_bounds__(256) void ratspn_gemm_prep_kernel(const GemmPrepArg
             if (real && f < D) {
                 const int p = posrow[f];
                 if (p >= 0 && p / d == q) {
-                    mu = a.loc[((int64_t)r * I + k) * d + (p - q * d)];
+                    mu = locs[(q * I + k) * d + (p - q * d)];
                     cc = -fmaf(0.5f * mu, mu, kLogSqrt2Pi);
                 }
             }
@@ -167,20 +179,20 @@ __global__ __launch_bounds__(256) void ratspn_gemm_prep_kernel(const GemmPrepArg
         *reinterpret_cast<half8 *>(a.ctab + o + 512) = cl;
     }
     // per-(chunk, column) constants - sum_f (mu^2/2 + log sqrt(2 pi)) over the variables of the chunk that belong to
-    // the column's region (a chunk without marginalised evidence adds them ready-made)
+    // the column's region, and their sum over the chunks; fixed summation order (launches must agree bit for bit)
     const int KC = 16 * a.KS;
     const int NCH = (D + KC - 1) / KC;
+    float *csum = locs + 4 * I * d;   // [NCH][4I]
     for (int e = threadIdx.x; e < NCH * 4 * I; e += blockDim.x) {
         const int col = e % (4 * I), c = e / (4 * I);
         const int q = col / I, k = col - q * I;
-        const int r = rho * 4 + q;
         float sum = 0.f;
         if (real) {
             const int f1 = min(D, (c + 1) * KC);
             for (int f = c * KC; f < f1; ++f) {
                 const int p = posrow[f];
                 if (p >= 0 && p / d == q) {
-                    const float mu = a.loc[((int64_t)r * I + k) * d + (p - q * d)];
+                    const float mu = locs[(q * I + k) * d + (p - q * d)];
                     sum -= fmaf(0.5f * mu, mu, kLogSqrt2Pi);
                 }
             }
@@ -188,19 +200,18 @@ __global__ __launch_bounds__(256) void ratspn_gemm_prep_kernel(const GemmPrepArg
         const int h = q >> 1, qq = q & 1;
         const int u = (ap * 2 + qq) * I + k;
         a.bias[((c * 2 + h) * a.NT + t) * 16 + u] = sum;
+        csum[e] = sum;
     }
-    // eligibility of the repetition for the expanded form: scale == 1 everywhere, |mu| <= kExpandBound
-    bool bad = false;
-    if (real) {
-        for (int e = threadIdx.x; e < 4 * I * d; e += blockDim.x) {
-            const int64_t o = (int64_t)rho * 4 * I * d + e;
-            const int rr = e / (I * d), j = e % d;
-            if (a.pad != nullptr && a.pad[((int64_t)rho * 4 + rr) * d + j]) continue;
-            bad = bad || !(fabsf(a.loc[o]) <= kExpandBound) || (a.scale[o] != 1.0f);
-        }
-    }
-    if (bad) bad_s = 1;
     __syncthreads();
+    if (threadIdx.x < 4 * I) {
+        const int col = threadIdx.x;
+        const int q = col / I, k = col - q * I;
+        float sum = 0.f;
+        for (int c = 0; c < NCH; ++c) sum += csum[c * 4 * I + col];
+        const int h = q >> 1, qq = q & 1;
+        const int u = (ap * 2 + qq) * I + k;
+        a.bias_row[(h * a.NT + t) * 16 + u] = sum;
+    }
     if (threadIdx.x == 0) a.elig[rho] = bad_s ? 0 : 1;
 }
 
@@ -212,7 +223,8 @@ struct GemmArgs {
     int64_t B;
     int D, d, reps, C, NCH, ntiles;
     const uint16_t *mtab, *ctab;
-    const float *biasT;
+    const float *biasT;   // [2][NT][16] whole-row constants in the accumulator order of a lane
+    const float *biasC;   // [NCH][2][NT][16] the same per chunk (tiles with marginalised evidence)
     const int *elig;
     const float *W0;   // [reps*2][S][I*I] linear softmax weights (copied into LDS)
     const float *LW0;  // log-softmax weights (exact fallback of a node, exact evaluation)
@@ -223,6 +235,10 @@ struct GemmArgs {
     const int64_t *mask;
     const uint8_t *pad;
     const float *loc, *scale;
+#ifdef DPK_TIMELINE
+    unsigned long long *dbg;   // [blocks][waves][64][8] s_memtime stamps (measurement builds)
+#endif
+    int ablate;       // measurement only (DPK_GEMM_ABLATE): 1 no compute, 2 no table DMA, 4 no x DMA
     int *slow_flag;   // host-mapped hint word (may be null): launch number of the last launch that met NaN evidence
     int launch_seq;
 };
@@ -239,6 +255,18 @@ __device__ __forceinline__ void lse_merge(float &m, float &s, float m2, float s2
 
 __device__ __forceinline__ void gemm_lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// ---- exp-domain helpers of the fast upper layers ---------------------------------------------------------------
+// e[i] = 2^((x[i] - max) log2 e); returns max (0 for an all -inf input, whose exponentials are then 0)
+template <int NI> __device__ __forceinline__ float exp2_children(const float (&x)[NI], float (&e)[NI]) {
+    float m = x[0];
+#pragma unroll
+    for (int i = 1; i < NI; ++i) m = fmaxf(m, x[i]);
+    const float m0 = (m == -INFINITY) ? 0.f : m;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) e[i] = __builtin_amdgcn_exp2f((x[i] - m0) * 1.4426950408889634f);
+    return m0;
 }
 
 // Exact per-element evaluation of the 32 samples of a wave (any scale, any evidence): lane (s, h) takes the
@@ -321,8 +349,51 @@ __device__ __noinline__ void gemm_exact_wave(const GemmArgs &a, int64_t bw0, int
     }
 }
 
+#ifdef DPK_TIMELINE
+#define GEMM_STAMP(row, slot) do { __builtin_amdgcn_sched_barrier(0); if (a.dbg && lane == 0 && !loader && (row) < 64) a.dbg[(((int64_t)blockIdx.x * kGemmWaves + wave) * 64 + (row)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define GEMM_STAMP(row, slot) do { } while (0)
+#endif
+
+// One LDS-DMA instruction: LDS[lds_dst + lane*16 .. +15] <- global[sbase + voff .. +15].  Issued as inline asm so that
+// hipcc neither counts it (the ring below is ordered by hand-counted vmcnt + s_barrier) nor drains it with a
+// vmcnt(0) in front of an unrelated load; M0 (the DMA's LDS base) is compiler-reserved, hence saved and restored.
+// The leading s_nop covers the SALU-write -> VMEM-read hazard of a freshly computed base (cdna_hip_programming 5.7).
+__device__ __forceinline__ void glds16(unsigned voff, gcchar_p sbase_in, unsigned lds_dst_in) {
+    // (readfirstlane: a no-op for values hipcc already holds in SGPRs, a guarantee where it has moved them to VGPRs)
+    const uint64_t sb = (uint64_t)(uintptr_t)sbase_in;
+    const uint64_t sbase = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sb >> 32)) << 32) |
+                           (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sb);
+    const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst_in);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
+// x (8 values of one sample) -> f16 halves xh + xl = x to 2^-22: xh = rn16(x), xl = rn16(x - xh)
+__device__ __forceinline__ void split8(const float (&v)[8], half8 &xh, half8 &xl) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 hp, lp;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        unsigned h2, l2;
+        float b0, b1;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h2) : "v"(v[2 * p]), "v"(v[2 * p + 1]));
+        asm("v_cvt_f32_f16_e32 %0, %1" : "=v"(b0) : "v"(h2));
+        asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(b1) : "v"(h2));
+        const float d0 = v[2 * p] - b0, d1 = v[2 * p + 1] - b1;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l2) : "v"(d0), "v"(d1));
+        hp[p] = h2;
+        lp[p] = l2;
+    }
+    xh = __builtin_bit_cast(half8, hp);
+    xl = __builtin_bit_cast(half8, lp);
+}
+
 template <int I, int S, int NT>
-__global__ __launch_bounds__(kGemmWaves * 64, 1) void ratspn_gemm_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(2 * kGemmWaves * 64) void ratspn_gemm_kernel(const GemmArgs a) {
     constexpr int RPT = 8 / I;                           // repetitions per column tile
     constexpr int KS = gemm_ks(NT);
     constexpr int KC = 16 * KS;                          // features per chunk
@@ -334,97 +405,129 @@ __global__ __launch_bounds__(kGemmWaves * 64, 1) void ratspn_gemm_kernel(const G
     constexpr int BB = KS * NT * 2 * 1024;               // mean-table bytes per chunk
     constexpr int STAGE = XB + BB;
     constexpr int NS = kGemmStages;
-    constexpr int PX = 32 / RPI;                         // x DMA instructions per wave and chunk
-    constexpr int PB = BB / (kGemmWaves * 1024);         // table DMA instructions per wave and chunk
-    constexpr int P = PX + PB;                           // DMA instructions per wave and chunk
+    constexpr int PX = 32 / RPI;                         // x DMA instructions per loader wave and chunk
+    constexpr int PB = BB / (kGemmWaves * 1024);         // table DMA instructions per loader wave and chunk
+    constexpr int P = PX + PB;                           // DMA instructions per loader wave and chunk
     static_assert(BB % (kGemmWaves * 1024) == 0, "table chunk must split over the waves");
-    static_assert((NS - 2) * P <= 63, "vmcnt field");
+    static_assert(NS == 3 && P <= 63, "the counted waits leave exactly one chunk in flight");
     constexpr int NMAX = (I > S ? I : S);
+    typedef __attribute__((address_space(3))) const gf32x4 lf4;
+    typedef __attribute__((address_space(3))) const half8 lh8;
 
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
     lchar *smem = (lchar *)smem_generic;
-    const int nbias = a.NCH * 2 * NT * 16;
-    lfloat *bias_l = (lfloat *)(smem + NS * STAGE);                  // [NCH][2][NT][16] constants per chunk
-    lfloat *w0_l = bias_l + nbias;                                   // [reps*2][S*I*I]
-    float *scr_l = reinterpret_cast<float *>(smem_generic + NS * STAGE) + nbias +
+    lfloat *bias_l = (lfloat *)(smem + NS * STAGE);                  // [2][NT][16] constants of a whole row
+    lfloat *w0_l = bias_l + 2 * NT * 16;                             // [reps*2][S*I*I]
+    float *scr_l = reinterpret_cast<float *>(smem_generic + NS * STAGE) + 2 * NT * 16 +
                    a.reps * 2 * S * I * I;                           // [256][2*NMAX] exact_lse scratch
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Waves 0-3 compute (one per SIMD), waves 4-7 only feed the LDS ring: wave 4+w copies the 32 rows of wave w and a
+    // quarter of the mean-table chunk.  A compute wave never issues a DMA (an LDS-DMA instruction costs its wave
+    // 60-150 issue cycles), a loader never touches a VALU; the two meet at one s_barrier per chunk.
+    const bool loader = wave8 >= kGemmWaves;
+    const int wave = wave8 & (kGemmWaves - 1);
     const int s = lane & 31, h = lane >> 5;
     const int D = a.D, NCH = a.NCH;
+    GEMM_STAMP(63, 0);
+#ifdef DPK_TIMELINE
+    if (a.dbg && lane == 0 && !loader) a.dbg[(((int64_t)blockIdx.x * kGemmWaves + wave) * 64 + 63) * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+#endif
 
-    // constants into LDS (ordinary loads: no DMA is in flight yet)
-    for (int e = tid; e < nbias; e += kGemmWaves * 64) bias_l[e] = a.biasT[e];
+    // this work-group's tiles: blockIdx.x, + gridDim.x, ... (persistent); every counter below is wave-uniform
+    const int grid = (int)gridDim.x;
+    const int ntiles = a.ntiles;
+
+    double red_ll = 0.0;
+    int red_n = 0;
+    bool saw_nan_any = false;
+    if (loader) {
+        const gcchar_p mtab_b = (gcchar_p)a.mtab;
+        const unsigned smem_base = (unsigned)(uintptr_t)smem;
+        // per-lane source offsets of the x pieces this lane copies (full tile, full chunk), in bytes from the
+        // tile's first row + the chunk's first feature
+        unsigned voff[PX];
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const int rl = wave * 32 + j * RPI + lane / W;
+            const int gp = (lane & (W - 1)) ^ ((rl >> SWS) & (W - 1));
+            voff[j] = (unsigned)(rl * D + gp * 4) * 4u;
+        }
+        const unsigned toff = (unsigned)(wave * (PB * 1024) + lane * 16);
+        int ptile = (int)blockIdx.x, pc = 0, pstage = 0;   // next chunk to stage
+        auto issue_next = [&]() {
+            const int64_t b0 = (int64_t)ptile * kGemmTile;
+            const gcchar_p xt = (gcchar_p)a.x + (b0 * D + pc * KC) * 4;
+            const gcchar_p tsrc = mtab_b + (int64_t)pc * BB;
+            const unsigned st = smem_base + pstage * STAGE;
+            const bool full = (b0 + kGemmTile <= a.B) && ((pc + 1) * KC <= D);
+            if (full) {
+#pragma unroll
+                for (int j = 0; j < PX; ++j) glds16(voff[j], xt, st + (wave * 32 + j * RPI) * ROWB);
+            } else {   // ragged tile / last chunk: clamp to rows and pieces that exist (clamped slots are never consumed)
+                const int nvalid = (int)min((int64_t)kGemmTile, a.B - b0);
+                const int vp = min(W, (D - pc * KC) >> 2);
+#pragma unroll
+                for (int j = 0; j < PX; ++j) {
+                    const int rl = wave * 32 + j * RPI + lane / W;
+                    const int gp = min((lane & (W - 1)) ^ ((rl >> SWS) & (W - 1)), vp - 1);
+                    glds16((unsigned)(min(rl, nvalid - 1) * D + gp * 4) * 4u, xt, st + (wave * 32 + j * RPI) * ROWB);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < PB; ++j) glds16(toff + j * 1024, tsrc, st + XB + wave * (PB * 1024) + j * 1024);
+            pstage = (pstage + 1 == NS) ? 0 : pstage + 1;
+            if (++pc == NCH) {
+                pc = 0;
+                ptile += grid;
+            }
+        };
+#pragma unroll
+        for (int g = 0; g < NS - 1; ++g)
+            if (ptile < ntiles) issue_next();
+        __syncthreads();   // (the compute waves fill the constants meanwhile; hipcc does not count the asm DMAs)
+        for (int tile = (int)blockIdx.x; tile < ntiles; tile += grid) {
+            for (int c = 0; c < NCH; ++c) {
+                // chunk (tile, c) has landed once at most one later chunk is still in flight (none exists at the very end)
+                if (c + 1 < NCH || tile + grid < ntiles) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                gemm_lds_barrier();   // this chunk is in LDS for everyone; everyone is done reading the previous one
+                if (ptile < ntiles) issue_next();
+            }
+        }
+    } else {
+    // ================================================ compute waves =========================================
+    // constants into LDS
+    for (int e = tid; e < 2 * NT * 16; e += kGemmWaves * 64) bias_l[e] = a.biasT[e];
     for (int e = tid; e < a.reps * 2 * S * I * I; e += kGemmWaves * 64) w0_l[e] = a.W0[e];
     bool model_ok = true;
     for (int e = lane; e < NT * RPT; e += 64) model_ok = model_ok && (a.elig[e] != 0);
     model_ok = __all(model_ok);
+    LseScratch sc{scr_l + tid * (2 * NMAX)};
     __syncthreads();
 
-    LseScratch sc{scr_l + tid * (2 * NMAX)};
-
-    // this work-group's tiles: blockIdx.x, + gridDim.x, ... (persistent); every counter below is wave-uniform
-    static_assert(NS == 3, "the counted waits below leave exactly one chunk in flight");
-    const int grid = (int)gridDim.x;
-    const int ntiles = a.ntiles;
-    const gcchar_p mtab_b = (gcchar_p)a.mtab;
-
-    // per-lane source offsets of the x pieces this lane copies (full tile, full chunk), in bytes from the
-    // tile's first row + the chunk's first feature
-    int voff[PX];
+    // LDS byte offsets (within a stage) of the lane's x pieces and of its table fragments
+    const int rl_own = wave * 32 + s;
+    const int sw = (rl_own >> SWS) & (W - 1);
+    unsigned xoff[2 * KS];
 #pragma unroll
-    for (int j = 0; j < PX; ++j) {
-        const int rl = wave * 32 + j * RPI + lane / W;
-        const int gp = (lane & (W - 1)) ^ ((rl >> SWS) & (W - 1));
-        voff[j] = (rl * D + gp * 4) * 4;
+    for (int ks = 0; ks < KS; ++ks) {
+        const int pcs = ks * 4 + h * 2;
+        xoff[2 * ks] = (unsigned)(rl_own * ROWB + ((pcs ^ sw) << 4));
+        xoff[2 * ks + 1] = (unsigned)(rl_own * ROWB + (((pcs | 1) ^ sw) << 4));
     }
-    const int toff = wave * (PB * 1024) + lane * 16;
+    const unsigned foff = (unsigned)(XB + lane * 16);
 
-    int ptile = (int)blockIdx.x, pc = 0, pstage = 0;   // next chunk to stage
-    auto issue_next = [&]() {
-        const int64_t b0 = (int64_t)ptile * kGemmTile;
-        lchar *st = smem + pstage * STAGE;
-        const gcchar_p xt = (gcchar_p)a.x + (b0 * D + pc * KC) * 4;
-        const bool full = (b0 + kGemmTile <= a.B) && ((pc + 1) * KC <= D);
-        if (full) {
-#pragma unroll
-            for (int j = 0; j < PX; ++j)
-                __builtin_amdgcn_global_load_lds((gvoid_p)(xt + voff[j]),
-                                                 (__attribute__((address_space(3))) void *)(st + (wave * 32 + j * RPI) * ROWB),
-                                                 16, 0, 0);
-        } else {   // ragged tile / last chunk: clamp to rows and pieces that exist (clamped slots are never consumed)
-            const int nvalid = (int)min((int64_t)kGemmTile, a.B - b0);
-            const int vp = min(W, (D - pc * KC) >> 2);
-#pragma unroll
-            for (int j = 0; j < PX; ++j) {
-                const int rl = wave * 32 + j * RPI + lane / W;
-                const int gp = min((lane & (W - 1)) ^ ((rl >> SWS) & (W - 1)), vp - 1);
-                const int off = (min(rl, nvalid - 1) * D + gp * 4) * 4;
-                __builtin_amdgcn_global_load_lds((gvoid_p)(xt + off),
-                                                 (__attribute__((address_space(3))) void *)(st + (wave * 32 + j * RPI) * ROWB),
-                                                 16, 0, 0);
-            }
-        }
-        const gcchar_p tsrc = mtab_b + (int64_t)pc * BB + toff;
-        lchar *tdst = st + XB + wave * (PB * 1024);
-#pragma unroll
-        for (int j = 0; j < PB; ++j)
-            __builtin_amdgcn_global_load_lds((gvoid_p)(tsrc + j * 1024),
-                                             (__attribute__((address_space(3))) void *)(tdst + j * 1024), 16, 0, 0);
-        pstage = (pstage + 1 == NS) ? 0 : pstage + 1;
-        if (++pc == NCH) {
-            pc = 0;
-            ptile += grid;
-        }
-    };
-
-#pragma unroll
-    for (int g = 0; g < NS - 1; ++g)
-        if (ptile < ntiles) issue_next();
-
+    GEMM_STAMP(63, 1);
+    [[maybe_unused]] int grow = 0;   // timeline row = chunk count of this work-group
     bool saw_nan = false;
+    int n_fast_w = 0;       // samples of this wave that went through the fast path
+    double ll_part = 0.0;   // this lane's share of the sum of the LLs written by the fast path (all tiles)
     int cstage = 0;
     for (int tile = (int)blockIdx.x; tile < ntiles; tile += grid) {
         gf32x16 acc[NT];
@@ -432,45 +535,41 @@ __global__ __launch_bounds__(kGemmWaves * 64, 1) void ratspn_gemm_kernel(const G
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-        float cacc[NT][16];   // per-column constants of the clean chunks
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) cacc[t][i] = 0.f;
         float qsum = 0.f;
         bool need_exact = false;
+        unsigned odd_mask = 0u;   // chunks that met NaN evidence: their constants were accumulated by the validity GEMM
         for (int c = 0; c < NCH; ++c) {
-            // chunk (tile, c) has landed once at most one later chunk is still in flight (none exists at the very end)
-            if (c + 1 < NCH || tile + grid < ntiles) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            gemm_lds_barrier();   // everyone's share of this chunk is in LDS; everyone is done reading the previous one
-            if (ptile < ntiles) issue_next();
-
+            GEMM_STAMP(grow, 0);
+            GEMM_STAMP(grow, 1);
+            gemm_lds_barrier();   // the loaders have seen this chunk land; everyone is done reading the previous one
+            GEMM_STAMP(grow, 2);
             const lchar *st = smem + cstage * STAGE;
             cstage = (cstage + 1 == NS) ? 0 : cstage + 1;
-            const int rl = wave * 32 + s;
-            const lchar *xr = st + rl * ROWB;
-            const int sw = (rl >> SWS) & (W - 1);
-            const int nks = min(KS, (D - c * KC + 15) >> 4);
-            typedef __attribute__((address_space(3))) const gf32x4 lf4;
-            typedef __attribute__((address_space(3))) const half8 lh8;
-            // the lane's 8*KS values of this chunk (K-steps beyond the row end re-read the first one: never used)
+            if (a.ablate & 1) continue;
+            const lchar *tb = st + foff;
+            // the chunk's table fragments and the lane's 8*KS values: every LDS read of the chunk is issued up front
+            half8 mh[KS][NT], ml[KS][NT];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    mh[ks][t] = *(lh8 *)(tb + (ks * NT + t) * 2048);
+                    ml[ks][t] = *(lh8 *)(tb + (ks * NT + t) * 2048 + 1024);
+                }
+            // the lane's 8*KS values of this chunk
             float v[KS][8];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const int pcs = (ks < nks ? ks : 0) * 4 + h * 2;
-                const gf32x4 x0 = *(lf4 *)(xr + ((pcs ^ sw) << 4));
-                const gf32x4 x1 = *(lf4 *)(xr + (((pcs | 1) ^ sw) << 4));
+                const gf32x4 x0 = *(lf4 *)(st + xoff[2 * ks]);
+                const gf32x4 x1 = *(lf4 *)(st + xoff[2 * ks + 1]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     v[ks][i] = x0[i];
                     v[ks][4 + i] = x1[i];
                 }
             }
-            if ((c + 1) * KC > D) {   // last chunk: slots beyond D hold clamped copies (or nothing this chunk wrote)
+            const bool partial = (c + 1) * KC > D;
+            if (partial) {   // last chunk: slots beyond D hold clamped copies (or nothing this chunk wrote)
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const int f0 = c * KC + ks * 16 + h * 8;
@@ -489,71 +588,76 @@ __global__ __launch_bounds__(kGemmWaves * 64, 1) void ratspn_gemm_kernel(const G
             float tq = tq2[0] + tq2[1];
             // NaN / +-inf / huge evidence anywhere in the wave's share of the chunk?
             const bool odd_chunk = __any(!(tq < kGemmStepBound));
-            half8 valid[KS];
-            if (odd_chunk) {
-                // NaN (marginalised) entries count as 0 and drop out of the constants (validity indicator below);
-                // +-inf / huge entries send the wave through the exact evaluation at the end of the tile
-                tq = 0.f;
+            if (!odd_chunk && !partial) {
+                // ---- hot path: clean, complete chunk -------------------------------------------------------
+                qsum += tq;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float vi = v[ks][i];
-                        const bool isn = vi != vi;
-                        const bool big = !isn && !(fabsf(vi) < kGemmAbsBound);
-                        need_exact = need_exact || big;
-                        saw_nan = saw_nan || isn;
-                        v[ks][i] = (isn || big) ? 0.f : vi;
-                        valid[ks][i] = isn ? (_Float16)0.0f : (_Float16)1.0f;
-                        tq = fmaf(v[ks][i], v[ks][i], tq);
-                    }
-            } else {
-                // clean chunk: its per-column constants come ready-made
-                lf4 *bc = (lf4 *)(bias_l + ((c * 2 + h) * NT) * 16);
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const gf32x4 q4 = bc[t * 4 + i];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) cacc[t][4 * i + j] += q4[j];
-                    }
-            }
-            qsum += tq;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                if (ks < nks) {
+                for (int ks = 0; ks < KS; ++ks) {
                     half8 xh, xl;
+                    split8(v[ks], xh, xl);
+                    // independent accumulators alternate (a dependent 32x32x16 chain would stall on its own latency)
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        xh[i] = (_Float16)v[ks][i];
-                        xl[i] = (_Float16)(v[ks][i] - (float)xh[i]);
-                    }
-                    const lchar *tb = st + XB + ks * (NT * 2048) + lane * 16;
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[ks][t], xh, acc[t], 0, 0, 0);
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const half8 mh = *(lh8 *)(tb + t * 2048);
-                        const half8 ml = *(lh8 *)(tb + t * 2048 + 1024);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh, xh, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh, xl, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml, xh, acc[t], 0, 0, 0);
-                    }
-                    if (odd_chunk) {
-                        // - (mu^2/2 + log sqrt(2 pi)) of the variables that ARE observed (table holds the negated constants)
-                        typedef const __attribute__((address_space(1))) half8 gh8;
-                        const gcchar_p cb = (gcchar_p)a.ctab + ((((int64_t)(c * KS + ks) * NT) * 2) * 512 + lane * 8) * 2;
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[ks][t], xl, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[ks][t], xh, acc[t], 0, 0, 0);
+                }
+            } else {
+                // ---- generic path: last (partial) chunk, or NaN / inf / huge evidence ----------------------------
+                const int nks = min(KS, (D - c * KC + 15) >> 4);
+                half8 valid[KS];
+                if (odd_chunk) {
+                    // NaN (marginalised) entries count as 0 and drop out of the constants (validity indicator below);
+                    // +-inf / huge entries send the wave through the exact evaluation at the end of the tile
+                    odd_mask |= 1u << c;
+                    tq = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const float vi = v[ks][i];
+                            const bool isn = vi != vi;
+                            const bool big = !isn && !(fabsf(vi) < kGemmAbsBound);
+                            need_exact = need_exact || big;
+                            saw_nan = saw_nan || isn;
+                            v[ks][i] = (isn || big) ? 0.f : vi;
+                            valid[ks][i] = isn ? (_Float16)0.0f : (_Float16)1.0f;
+                            tq = fmaf(v[ks][i], v[ks][i], tq);
+                        }
+                }
+                qsum += tq;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    if (ks < nks) {
+                        half8 xh, xl;
+                        split8(v[ks], xh, xl);
 #pragma unroll
                         for (int t = 0; t < NT; ++t) {
-                            const half8 ch = *(gh8 *)(cb + t * 2048);
-                            const half8 cl = *(gh8 *)(cb + t * 2048 + 1024);
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, valid[ks], acc[t], 0, 0, 0);
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, valid[ks], acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[ks][t], xh, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[ks][t], xl, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[ks][t], xh, acc[t], 0, 0, 0);
+                        }
+                        if (odd_chunk) {
+                            // - (mu^2/2 + log sqrt(2 pi)) of the variables that ARE observed (table of negated constants)
+                            typedef const __attribute__((address_space(1))) half8 gh8;
+                            const gcchar_p cb = (gcchar_p)a.ctab + ((((int64_t)(c * KS + ks) * NT) * 2) * 512 + lane * 8) * 2;
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) {
+                                const half8 ch = *(gh8 *)(cb + t * 2048);
+                                const half8 cl = *(gh8 *)(cb + t * 2048 + 1024);
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, valid[ks], acc[t], 0, 0, 0);
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, valid[ks], acc[t], 0, 0, 0);
+                            }
                         }
                     }
                 }
             }
+            GEMM_STAMP(grow, 4);
+            ++grow;
         }
-        {
+        GEMM_STAMP(grow - 1, 5);
+        if (!(a.ablate & 8)) {
             // ---- upper layers of the tile ------------------------------------------------------------
             const int64_t b0 = (int64_t)tile * kGemmTile;
             const int64_t bw0 = b0 + wave * 32;
@@ -567,69 +671,171 @@ __global__ __launch_bounds__(kGemmWaves * 64, 1) void ratspn_gemm_kernel(const G
                 const GemmArgs ac = a;
                 gemm_exact_wave<I, S, NT>(ac, bw0, lane, sc);
             } else {
-                float ta[NT * RPT][S], tc[NT * RPT][S];
+                // per-column constants: the whole-row sums, or -- after chunks with marginalised evidence, whose
+                // constants the validity GEMM accumulated -- the sums of the clean chunks only
+                float cst[NT][16];
+                if (odd_mask == 0u) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const gf32x4 q4 = *(lf4 *)(bias_l + (h * NT + t) * 16 + 4 * i);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) cst[t][4 * i + j] = q4[j];
+                        }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) cst[t][i] = 0.f;
+                    for (int c = 0; c < NCH; ++c) {
+                        if ((odd_mask >> c) & 1u) continue;
+                        const float *bc = a.biasC + ((c * 2 + h) * NT) * 16;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) cst[t][i] += bc[t * 16 + i];
+                    }
+                }
+                // Upper layers in the exp domain on the hardware's base-2 transcendentals; a node whose scaled sum
+                // vanishes (dominant pair under a vanishing weight) is redone exactly, out of line (gemm_node_exact).
+                constexpr float kL2E = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+                // phase A, branch free so that the independent nodes interleave (one wave per SIMD: a dependent chain of
+                // transcendentals would otherwise run at its latency): every product + sum node of the lane's partitions
+                GEMM_STAMP(grow - 1, 0);
+                float n1[NT * RPT][S];
+                bool vanished = false;   // some node's scaled sum fell below 1e-30 (dominant pair under a vanishing weight)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
 #pragma unroll
                     for (int ap = 0; ap < RPT; ++ap) {
                         const int rho = t * RPT + ap;
-                        float n1[S];
+                        float va[I], vc[I];
 #pragma unroll
-                        for (int o = 0; o < S; ++o) n1[o] = -INFINITY;
-                        if (rho < a.reps) {
-                            float va[I], vc[I];
-#pragma unroll
-                            for (int k = 0; k < I; ++k) {
-                                va[k] = acc[t][(ap * 2) * I + k] + cacc[t][(ap * 2) * I + k];
-                                vc[k] = acc[t][(ap * 2 + 1) * I + k] + cacc[t][(ap * 2 + 1) * I + k];
-                            }
-                            const int wo = (rho * 2 + h) * S * I * I;
-                            prodsum_node<I, S>(va, vc, w0_l + wo, a.LW0 + wo, sc, n1);
+                        for (int k = 0; k < I; ++k) {
+                            va[k] = acc[t][(ap * 2) * I + k] + cst[t][(ap * 2) * I + k];
+                            vc[k] = acc[t][(ap * 2 + 1) * I + k] + cst[t][(ap * 2 + 1) * I + k];
                         }
-                        // both lanes of a sample finish every repetition (the root weights stay wave-uniform)
+                        float ea[I], ec[I];
+                        const float ma = exp2_children<I>(va, ea), mc = exp2_children<I>(vc, ec);
+                        const int wo = (min(rho, a.reps - 1) * 2 + h) * S * I * I;
 #pragma unroll
                         for (int o = 0; o < S; ++o) {
-                            const float oth = __shfl_xor(n1[o], 32, 64);
-                            ta[rho][o] = h == 0 ? n1[o] : oth;
-                            tc[rho][o] = h == 0 ? oth : n1[o];
+                            float v = 0.f;
+#pragma unroll
+                            for (int i = 0; i < I; ++i) {
+                                float tt = 0.f;
+#pragma unroll
+                                for (int j = 0; j < I; ++j) tt = fmaf(w0_l[wo + (o * I + i) * I + j], ec[j], tt);
+                                v = fmaf(ea[i], tt, v);
+                            }
+                            n1[rho][o] = fmaf(__builtin_amdgcn_logf(v), kLn2, ma + mc);
+                            vanished = vanished || (v < 1e-30f && rho < a.reps);
                         }
                     }
                 }
+                // both lanes of a sample finish every repetition (the root weights stay wave-uniform):
+                // v_permlane32_swap leaves partition 0's outputs in one register and partition 1's in the other
+                float ta[NT * RPT][S], tc[NT * RPT][S];
+#pragma unroll
+                for (int rho = 0; rho < NT * RPT; ++rho)
+#pragma unroll
+                    for (int o = 0; o < S; ++o) {
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        const unsigned bits = __float_as_uint(n1[rho][o]);
+                        const u32x2 sw2 = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
+                        ta[rho][o] = __uint_as_float(sw2[0]);
+                        tc[rho][o] = __uint_as_float(sw2[1]);
+                    }
+                GEMM_STAMP(grow - 1, 1);
+                // root: per repetition (m, s) with logsumexp = m + ln s; the exponentials do not depend on the class
+                float ea[NT * RPT][S], ec[NT * RPT][S], mr[NT * RPT];
+                float mtop = -INFINITY;
+#pragma unroll
+                for (int rho = 0; rho < NT * RPT; ++rho) {   // (branch free: a column tile's spare repetitions get -inf)
+                    const float m2 = exp2_children<S>(ta[rho], ea[rho]) + exp2_children<S>(tc[rho], ec[rho]);
+                    mr[rho] = (rho < a.reps) ? m2 : -INFINITY;
+                    mtop = fmaxf(mtop, mr[rho]);
+                }
+                const float mtop0 = (mtop == -INFINITY) ? 0.f : mtop;
+                float scale[NT * RPT];
+#pragma unroll
+                for (int rho = 0; rho < NT * RPT; ++rho) scale[rho] = __builtin_amdgcn_exp2f((mr[rho] - mtop0) * kL2E);
                 const int M = a.reps * S * S;
                 const float qterm = -0.5f * qtot;
                 double part = 0.0;
+                GEMM_STAMP(grow - 1, 7);
+                // a vanished node anywhere in the wave: the wave's samples go through the exact evaluation instead
+                // (rare: a softmax weight below e^-69 on the dominant pair)
+                if (__any(vanished)) {
+                    const GemmArgs ac = a;
+                    gemm_exact_wave<I, S, NT>(ac, bw0, lane, sc);
+                    continue;
+                }
                 for (int cl = 0; cl < a.C; ++cl) {
-                    float mm = -INFINITY, ss = 0.f;
+                    float tot = 0.f;
 #pragma unroll
                     for (int rho = 0; rho < NT * RPT; ++rho) {
-                        if (rho < a.reps) {
-                            float ea[S], ec[S], ma, mc, pm, ps;
-                            exp_children<S>(ta[rho], ea, ma);
-                            exp_children<S>(tc[rho], ec, mc);
-                            const int wo = cl * M + rho * S * S;
-                            root_partial<S>(ta[rho], tc[rho], ea, ec, ma, mc, a.Wr + wo, a.LWr + wo, sc, pm, ps);
-                            lse_merge(mm, ss, pm, ps);
+                        const int wo = cl * M + min(rho, a.reps - 1) * S * S;   // (spare repetitions: scale == 0)
+                        float v = 0.f;
+#pragma unroll
+                        for (int i = 0; i < S; ++i) {
+                            float tt = 0.f;
+#pragma unroll
+                            for (int j = 0; j < S; ++j) tt = fmaf(a.Wr[wo + i * S + j], ec[rho][j], tt);
+                            v = fmaf(ea[rho][i], tt, v);
                         }
+                        vanished = vanished || (v < 1e-30f && mr[rho] > -INFINITY);
+                        tot = fmaf(v, scale[rho], tot);
                     }
-                    const float ll = (mm > -INFINITY) ? mm + __logf(ss) + qterm : -INFINITY;
+                    const float ll = ((mtop > -INFINITY) ? fmaf(__builtin_amdgcn_logf(tot), kLn2, mtop) : -INFINITY) + qterm;
                     if (h == 0 && b < a.B) {
                         a.out[b * a.C + cl] = ll;
                         part += (double)ll;
                     }
                 }
-                if (a.ll_sum != nullptr) {
-                    part = wave_reduce_sum(part);
-                    if (lane == 0) {
-                        int64_t nv = a.B - bw0;
-                        nv = nv < 0 ? 0 : (nv > 32 ? 32 : nv);
-                        atomicAdd(a.ll_sum, part);
-                        atomicAdd(a.ll_sum + 1, (double)(nv * a.C));
-                    }
+                if (__any(vanished)) {   // (the exact evaluation overwrites what this wave stored and adds its own sum)
+                    const GemmArgs ac = a;
+                    gemm_exact_wave<I, S, NT>(ac, bw0, lane, sc);
+                    continue;
                 }
+                GEMM_STAMP(grow - 1, 6);
+                ll_part += part;
+                n_fast_w += (int)max((int64_t)0, min((int64_t)32, a.B - bw0));
             }
         }
     }
-    if (saw_nan && lane == 0 && a.slow_flag != nullptr) *a.slow_flag = a.launch_seq;
+    GEMM_STAMP(63, 2);
+    red_ll = wave_reduce_sum(ll_part);
+    red_n = n_fast_w;
+    saw_nan_any = saw_nan;
+    }   // compute waves
+    // {sum LL, count}: one atomic per work-group, issued when no counted wait is left to trip over it (an atomic is a
+    // VMEM operation: inside the ring it would sit in every wave's vmcnt until the L2 has serialised thousands of them)
+    if (a.ll_sum != nullptr && !(a.ablate & 16)) {
+        double *red = reinterpret_cast<double *>(smem_generic);   // the stages are idle now
+        __syncthreads();
+        if (lane == 0 && !loader) {
+            red[wave] = red_ll;
+            red[kGemmWaves + wave] = (double)red_n;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0, n_fast = 0.0;
+#pragma unroll
+            for (int w = 0; w < kGemmWaves; ++w) {
+                tot += red[w];
+                n_fast += red[kGemmWaves + w];
+            }
+            atomicAdd(a.ll_sum, tot);
+            atomicAdd(a.ll_sum + 1, n_fast * (double)a.C);
+        }
+    }
+    if (saw_nan_any && lane == 0 && a.slow_flag != nullptr) *a.slow_flag = a.launch_seq;
+    GEMM_STAMP(63, 3);
+#ifdef DPK_TIMELINE
+    if (a.dbg && lane == 0 && !loader) a.dbg[(((int64_t)blockIdx.x * kGemmWaves + wave) * 64 + 63) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -641,7 +847,7 @@ static int gemm_launch(const GemmArgs &a, int reps, hipStream_t st) {
     constexpr int BB = KS * NT * 2 * 1024;
     constexpr int NMAX = (I > S ? I : S);
     const size_t lds = (size_t)kGemmStages * (kGemmTile * 64 * KS + BB) +
-                       (size_t)(a.NCH * 2 * NT * 16 + reps * 2 * S * I * I) * 4 + (size_t)kGemmWaves * 64 * 2 * NMAX * 4;
+                       (size_t)(2 * NT * 16 + reps * 2 * S * I * I) * 4 + (size_t)kGemmWaves * 64 * 2 * NMAX * 4;
     DPK_REQUIRE(lds <= 160 * 1024, DPK_EUNSUPPORTED, "ratspn_gemm: %zu bytes of LDS", lds);
     auto kern = ratspn_gemm_kernel<I, S, NT>;
     static bool attr_done = false;   // per instantiation
@@ -662,10 +868,19 @@ static int gemm_launch(const GemmArgs &a, int reps, hipStream_t st) {
         else cus = 256;
     }
     const int grid = a.ntiles < cus ? a.ntiles : cus;
+#ifdef DPK_TIMELINE
+    {
+        static unsigned long long *dbg = nullptr;
+        if (!dbg) (void)hipMalloc(&dbg, (size_t)1024 * kGemmWaves * 64 * 8 * 8);
+        const_cast<GemmArgs &>(a).dbg = dbg;
+        FILE *f = fopen("/tmp/dpk_timeline_ptr.txt", "w");
+        if (f) { fprintf(f, "%p %d %d\n", (void *)dbg, grid, a.NCH); fclose(f); }
+    }
+#endif
     hipEvent_t ev0, ev1;
     profile_take(&ev0, &ev1);
     if (ev0) (void)hipEventRecord(ev0, st);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kGemmWaves * 64), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * kGemmWaves * 64), lds, st, a);
     if (ev1) (void)hipEventRecord(ev1, st);
     DPK_CHECK_LAUNCH("ratspn_gemm_kernel");
     return DPK_OK;
@@ -693,12 +908,12 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
         GemmPrepArgs p{};
         p.mask = mask; p.pad = pad; p.loc = loc; p.scale = scale;
         p.D = D; p.d = d; p.reps = reps; p.NT = NT; p.NKSP = w.g_nksp; p.KS = gemm_ks(NT);
-        p.mtab = w.gm_tab; p.ctab = w.gc_tab; p.bias = w.gbias; p.elig = w.gelig;
+        p.mtab = w.gm_tab; p.ctab = w.gc_tab; p.bias = w.gbias; p.bias_row = w.gbias_row; p.elig = w.gelig;
         p.w[0] = sum_weight0; p.W[0] = w.w[0]; p.LW[0] = w.lw[0]; p.rows[0] = reps * 2 * S; p.n[0] = I * I;
         p.w[1] = root_weight; p.W[1] = w.w[2]; p.LW[1] = w.lw[2]; p.rows[1] = C; p.n[1] = reps * S * S;
         const int nrb = NT * (8 / I);
         const int grid = nrb + cdiv(p.rows[0] + p.rows[1], 4);
-        const size_t lds = (size_t)D * sizeof(int);
+        const size_t lds = ((size_t)D + (size_t)4 * I * d + (size_t)cdiv(D, 32) * 4 * I) * 4;
         DPK_REQUIRE(lds <= 60 * 1024, DPK_EUNSUPPORTED, "ratspn_gemm: in_features=%d too large for the table kernel", D);
         if (I == 2) hipLaunchKernelGGL(ratspn_gemm_prep_kernel<2>, dim3(grid), dim3(256), lds, st, p);
         else hipLaunchKernelGGL(ratspn_gemm_prep_kernel<4>, dim3(grid), dim3(256), lds, st, p);
@@ -708,10 +923,14 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
     a.x = x; a.B = B; a.D = D; a.d = d; a.reps = reps; a.C = C;
     a.NCH = cdiv(D, 16 * gemm_ks(NT));
     a.ntiles = cdiv(B, kGemmTile);
-    a.mtab = w.gm_tab; a.ctab = w.gc_tab; a.biasT = w.gbias; a.elig = w.gelig;
+    a.mtab = w.gm_tab; a.ctab = w.gc_tab; a.biasT = w.gbias_row; a.biasC = w.gbias; a.elig = w.gelig;
     a.W0 = w.w[0]; a.LW0 = w.lw[0]; a.Wr = as_const(w.w[2]); a.LWr = as_const(w.lw[2]);
     a.out = out; a.ll_sum = ll_sum;
     a.mask = mask; a.pad = pad; a.loc = loc; a.scale = scale;
+    {
+        static const int ab = [] { const char *e = getenv("DPK_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
+        a.ablate = ab;
+    }
     if (I == 2) {
         if (S == 2) return gemm_dispatch_nt<2, 2>(a, reps, NT, st);
         return gemm_dispatch_nt<2, 4>(a, reps, NT, st);
