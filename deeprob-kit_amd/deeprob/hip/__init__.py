@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get(  # DEEPROB_HIP_LIB: measurement builds of the same AB
 
 DPK_FLAG_STRUCT_CACHED = 1
 DPK_FLAG_UNIT_SCALE = 2
+DPK_FLAG_PARAMS_CACHED = 4
 
 _c_void = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -48,6 +49,7 @@ SIGNATURES = {
                                         _c_void]),
     'dpk_root_backward': (ctypes.c_int, [_c_void, _c_void, _c_void, _c_void, _i64, _i32, _i32, _c_void,
                                          _c_void, _c_void, _i64, _c_void]),
+    'dpk_ratspn_forward_on_mfma': (ctypes.c_int, [_c_void, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _u32]),
     'dpk_ratspn_forward': (ctypes.c_int, [_c_void, _i64, _i32, _c_void, _c_void, _c_void, _c_void, _c_void,
                                           _c_void, _c_void, _i32, _i32, _i32, _i32, _i32, _c_void, _c_void,
                                           _c_void, _c_void, _i64, _u32, _c_void]),
@@ -181,6 +183,7 @@ class Workspace:
     def __init__(self):
         self.buf: Optional[torch.Tensor] = None
         self.struct_key = None  # what the cached structure tables were built from
+        self.params_key = None  # parameters (addresses, versions) the MFMA route's tables were built from
         self._retired = []      # outgrown buffers: a captured HIP graph may still address them
 
     def get(self, n_bytes: int, device: torch.device) -> torch.Tensor:
@@ -189,4 +192,5 @@ class Workspace:
                 self._retired.append(self.buf)
             self.buf = torch.empty(max(int(n_bytes), 256), dtype=torch.uint8, device=device)
             self.struct_key = None
+            self.params_key = None
         return self.buf

@@ -10,7 +10,7 @@ import torch
 
 from deeprob.hip import (
     load_library, check, ptr, stream_ptr, require_device_f32, Workspace, DPK_FLAG_STRUCT_CACHED,
-    DPK_FLAG_UNIT_SCALE,
+    DPK_FLAG_UNIT_SCALE, DPK_FLAG_PARAMS_CACHED,
 )
 
 
@@ -42,6 +42,20 @@ class LeafContext:
         if scale is not None and not scale.requires_grad:
             flags |= DPK_FLAG_UNIT_SCALE
         return buf, flags
+
+
+def _params_flag(lib, lctx: 'LeafContext', x_ptr, flags: int, tensors) -> int:
+    """DPK_FLAG_PARAMS_CACHED when this fused call runs on the MFMA route and the tables in the workspace were built
+    by an earlier call on that route from the same, unchanged parameters (addresses and version counters; a
+    structure rebuild invalidates them too)."""
+    if not lib.dpk_ratspn_forward_on_mfma(x_ptr, lctx.D, lctx.depth, lctx.reps, lctx.I, lctx.S, lctx.C, 0, flags):
+        lctx.ws.params_key = None
+        return 0
+    key = (_buffers_key(*tensors), lctx.ws.struct_key)
+    if lctx.ws.params_key == key and (flags & DPK_FLAG_STRUCT_CACHED):
+        return DPK_FLAG_PARAMS_CACHED
+    lctx.ws.params_key = key
+    return 0
 
 
 def _pad_u8(pad_mask: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -304,13 +318,17 @@ def ratspn_forward_fused(x, mask, pad_mask, loc, scale, sum_weights, root_weight
     B = x.shape[0]
     out = torch.empty((B, lctx.C), dtype=torch.float32, device=x.device)
     ws, flags = lctx.workspace(x.device, mask, pad_mask, scale)
+    flags |= _params_flag(lib, lctx, ptr(x), flags, [loc_c, scale_c] + sw + [rw])
     rc = lib.dpk_ratspn_forward(ptr(x), B, lctx.D, ptr(mask), ptr(_pad_u8(pad_mask)), ptr(loc_c), ptr(scale_c),
                                 ptr(sw[0]) if len(sw) > 0 else None, ptr(sw[1]) if len(sw) > 1 else None,
                                 ptr(rw), lctx.depth, lctx.reps, lctx.I, lctx.S, lctx.C, ptr(out), None,
                                 ptr(ll_acc), ptr(ws), ws.numel(), flags, stream_ptr(x.device))
     if rc == -4:  # DPK_EUNSUPPORTED
         lctx.ws.struct_key = None
+        lctx.ws.params_key = None
         return None
+    if rc:
+        lctx.ws.params_key = None
     check(rc, 'dpk_ratspn_forward')
     return out
 
@@ -342,26 +360,36 @@ class FusedForwardPlan:
                      ptr(self.tensors[-1]), lctx.depth, lctx.reps, lctx.I, lctx.S, lctx.C, ptr(self.out), None,
                      None, ptr(ws), ws.numel(), flags, None]
         self.ptrs = self._addresses()
+        self.struct_key = lctx.ws.struct_key
+        self._struct_tensors = (mask, pad_mask)
+        self.params = self.tensors[3:]
         # the first call also builds (or re-validates) the structure tables and tells whether the shape is covered
         self.args[-1] = stream_ptr(self.device)
+        self.args[-2] = flags | _params_flag(self.lib, lctx, self.args[0], flags, self.params)
         rc = self.lib.dpk_ratspn_forward(*self.args)
         self.supported = rc != -4
         if self.supported:
             check(rc, 'dpk_ratspn_forward')
-            self.args[-2] = flags | DPK_FLAG_STRUCT_CACHED
+            self.base_flags = flags | DPK_FLAG_STRUCT_CACHED
         else:
             lctx.ws.struct_key = None
+            lctx.ws.params_key = None
 
     def _addresses(self):
         return tuple(t.data_ptr() for t in self.tensors if t is not None) + (self.ws.data_ptr(),)
 
     def valid(self) -> bool:
-        return self.lctx.ws.buf is self.ws and self._addresses() == self.ptrs
+        # addresses AND the structure buffers' version counters (an in-place load_state_dict of another region
+        # graph keeps the addresses): the module's cached structure key must still be the one this plan bound
+        return (self.lctx.ws.buf is self.ws and self._addresses() == self.ptrs
+                and self.lctx.ws.struct_key == self.struct_key
+                and _buffers_key(*self._struct_tensors) == self.struct_key)
 
     def run(self, ll_acc: Optional[torch.Tensor] = None) -> torch.Tensor:
         args = self.args
         args[17] = None if ll_acc is None else ll_acc.data_ptr()
         args[-1] = torch.cuda.current_stream(self.device).cuda_stream
+        args[-2] = self.base_flags | _params_flag(self.lib, self.lctx, args[0], self.base_flags, self.params)
         rc = self.lib.dpk_ratspn_forward(*args)
         if rc:
             check(rc, 'dpk_ratspn_forward')

@@ -483,3 +483,32 @@ def test_sample_shapes_and_statistics():
     # sampled points are likely under the model: far above the density of points drawn elsewhere
     with torch.no_grad():
         assert model(s).mean().item() > model(s + 2.0).mean().item() + 100.0
+
+
+def test_mfma_route_tables_follow_the_parameters(golden):
+    """The MFMA route keeps its parameter tables between calls (DPK_FLAG_PARAMS_CACHED) keyed on the parameters'
+    addresses and version counters: an in-place update (optimizer step, load_state_dict, copy_) must be seen by the
+    next call, and an unchanged model must give bit-identical results call after call."""
+    model, g = build('ratspn_g784_d2_r8_i2_s2', golden)
+    x = torch.randn(300, 784, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        a = model(x.cuda())
+        b = model(x.cuda())
+        assert torch.equal(a, b)
+        model.base_layer.loc.add_(0.05)
+        model.root_layer.weight.mul_(0.5)
+        model.layers[1].weight.add_(torch.randn_like(model.layers[1].weight))
+        c = model(x.cuda())
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    want = orc.ratspn_forward(sd, x).numpy()
+    assert rel_err(c.cpu().numpy(), want) <= LL_TOL
+    assert not torch.equal(a, c)
+    # a plan bound to a resident buffer sees updates too
+    plan = model.fused_plan(x.cuda())
+    with torch.no_grad():
+        p1 = plan.run().clone()
+        model.base_layer.loc.sub_(0.05)
+        p2 = plan.run().clone()
+    assert torch.equal(p1, c)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    assert rel_err(p2.cpu().numpy(), orc.ratspn_forward(sd, x).numpy()) <= LL_TOL
