@@ -361,6 +361,104 @@ __global__ void bn1d_bwd_apply_kernel(const float *__restrict__ x, const float *
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Batch-sharded (synchronised) training-mode BatchNormLayer1d: every rank holds a slice of the batch, the
+// statistics are those of the WHOLE batch (what the single-process reference computes, flows/utils.py:122-128).
+// Ranks exchange {count, mean, M2} per column (all-gather of 2D+1 floats) and combine them in rank order with the
+// pairwise update of Chan et al., so every rank derives bit-identical statistics.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kRThreads) void bn1d_local_moments_kernel(const float *__restrict__ x, int64_t B, int D,
+                                                                       float *__restrict__ mom) {
+    __shared__ float red[kRThreads / 64][kRC];
+    const int c = blockIdx.x * kRC + (threadIdx.x & (kRC - 1)), rg = threadIdx.x >> 4;
+    constexpr int kStep = kRThreads / kRC;
+    float s = 0.f;
+    if (c < D)
+        for (int64_t b = rg; b < B; b += kStep) s += x[b * D + c];
+    const float mean = B > 0 ? colblock_sum(s, red) / (float)B : 0.f;
+    float q = 0.f;
+    if (c < D)
+        for (int64_t b = rg; b < B; b += kStep) {
+            const float dlt = x[b * D + c] - mean;
+            q = fmaf(dlt, dlt, q);
+        }
+    q = colblock_sum(q, red);
+    if (rg == 0 && c < D) {
+        mom[1 + c] = mean;
+        mom[1 + D + c] = q;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) mom[0] = (float)B;
+}
+
+__global__ void bn1d_combine_kernel(const float *__restrict__ gathered, int W, int D, const float *__restrict__ weight,
+                                    const float *__restrict__ bias, float momentum, float eps,
+                                    float *__restrict__ running_var, float *__restrict__ running_mean,
+                                    float *__restrict__ mean_out, float *__restrict__ var_out,
+                                    float *__restrict__ scale_out, float *__restrict__ shift_out,
+                                    float *__restrict__ ldj_const) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    float term = 0.f;
+    if (c < D) {
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        for (int r = 0; r < W; ++r) {
+            const float *g = gathered + (int64_t)r * (2 * D + 1);
+            const float nr = g[0];
+            if (nr > 0.f) {
+                const float dlt = g[1 + c] - mean, nn = n + nr;
+                mean += dlt * (nr / nn);
+                m2 += g[1 + D + c] + dlt * dlt * (n * nr / nn);
+                n = nn;
+            }
+        }
+        const float var = m2 / (n - 1.f);
+        running_var[c] = running_var[c] * momentum + var * (1.f - momentum);
+        running_mean[c] = running_mean[c] * momentum + mean * (1.f - momentum);
+        mean_out[c] = mean;
+        var_out[c] = var;
+        const float ve = var + eps;
+        const float sc = expf(weight[c]) / sqrtf(ve);
+        scale_out[c] = sc;
+        shift_out[c] = bias[c] - mean * sc;
+        term = weight[c] - 0.5f * logf(ve);
+    }
+    // fixed-order sum of the D log-det terms: one block, LDS tree
+    __shared__ float red[1024];
+    red[threadIdx.x] = term;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(ldj_const, red[0]);
+}
+
+// gx with the whole-batch column sums (sx = {s1, s2, sum g_ildj}, already scaled to this rank's loss), parameter
+// gradients with this rank's own sums (sp); Bg = samples of the whole batch.
+__global__ void bn1d_sync_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ gu, int64_t B, int64_t Bg,
+                                           int D, const float *__restrict__ weight, const float *__restrict__ mean,
+                                           const float *__restrict__ var, float eps, const float *__restrict__ sx,
+                                           const float *__restrict__ sp, float *__restrict__ gx, float *__restrict__ gw,
+                                           float *__restrict__ gb) {
+    const int64_t total = B * D;
+    const float gsum = sx[2 * D];
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(e % D);
+        const float ve = var[d] + eps, is = 1.f / sqrtf(ve), ew = expf(weight[d]);
+        const float xhat = (x[e] - mean[d]) * is;
+        const float dvar = -0.5f * (ew * sx[D + d] + gsum) / ve;
+        const float dmean = -ew * is * sx[d];
+        gx[e] = gu[e] * ew * is + dvar * 2.f * (xhat / is) / (float)(Bg - 1) + dmean / (float)Bg;
+    }
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < D) {
+        const float ew = expf(weight[t]);
+        if (gw) gw[t] = ew * sp[D + t] + sp[2 * D];
+        if (gb) gb[t] = sp[t];
+    }
+}
+
 __global__ void vecsum_kernel(const float *__restrict__ v, int64_t n, float *__restrict__ out) {
     // one block; fp32 pairwise-ish: per-thread strided partials, LDS tree
     __shared__ float red[256];
@@ -557,6 +655,63 @@ extern "C" int dpk_bn1d_backward(const float *x, const float *grad_u, const floa
                        grad_ildj ? sg : nullptr, B, D, weight, mean, var, eps, s1, s2, train, grad_x, grad_weight,
                        grad_bias);
     DPK_CHECK_LAUNCH("bn1d_backward");
+    return DPK_OK;
+}
+
+
+// ---- batch-sharded BatchNormLayer1d (see the kernels above) ------------------------------------------------
+extern "C" int dpk_bn1d_local_moments(const float *x, int64_t B, int32_t D, float *moments, void *stream) {
+    DPK_REQUIRE(B >= 0 && D > 0 && moments && (B == 0 || x), DPK_EINVAL, "bn1d_local_moments: bad arguments");
+    hipLaunchKernelGGL(bn1d_local_moments_kernel, dim3(cdiv(D, kRC)), dim3(kRThreads), 0, (hipStream_t)stream, x, B, D,
+                       moments);
+    DPK_CHECK_LAUNCH("bn1d_local_moments_kernel");
+    return DPK_OK;
+}
+
+extern "C" int dpk_bn1d_sync_forward(const float *x, int64_t B, int32_t D, const float *weight, const float *bias,
+                                     const float *gathered, int32_t world, float *running_var, float *running_mean,
+                                     float momentum, float eps, float *out, float *ildj_const, float *save_mean,
+                                     float *save_var, void *ws, int64_t ws_bytes, void *stream) {
+    DPK_REQUIRE(B >= 0 && D > 0 && world >= 1, DPK_EINVAL, "bn1d_sync_forward: bad sizes");
+    DPK_REQUIRE(weight && bias && gathered && running_var && running_mean && ildj_const && save_mean && save_var && ws &&
+                    (B == 0 || (x && out)),
+                DPK_EINVAL, "bn1d_sync_forward: null pointer");
+    DPK_REQUIRE(ws_bytes >= (int64_t)2 * D * 4, DPK_EWORKSPACE, "bn1d_sync_forward: workspace too small");
+    DPK_REQUIRE(D <= 1024 * 1024, DPK_EUNSUPPORTED, "bn1d_sync_forward: D too large");
+    hipStream_t st = (hipStream_t)stream;
+    float *sc = (float *)ws, *sh = sc + D;
+    DPK_REQUIRE(hipMemsetAsync(ildj_const, 0, 4, st) == hipSuccess, DPK_ELAUNCH, "memset");
+    hipLaunchKernelGGL(bn1d_combine_kernel, dim3(cdiv(D, 1024)), dim3(1024), 0, st, gathered, world, D, weight, bias,
+                       momentum, eps, running_var, running_mean, save_mean, save_var, sc, sh, ildj_const);
+    DPK_CHECK_LAUNCH("bn1d_combine_kernel");
+    if (B == 0) return DPK_OK;
+    return dpk_affine1d_forward(x, sc, sh, B, D, out, stream);
+}
+
+extern "C" int dpk_bn1d_backward_sums(const float *x, const float *grad_u, const float *grad_ildj, int64_t B, int32_t D,
+                                      const float *mean, const float *var, float eps, float *sums, void *stream) {
+    DPK_REQUIRE(B >= 0 && D > 0 && mean && var && sums && (B == 0 || (x && grad_u)), DPK_EINVAL,
+                "bn1d_backward_sums: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0 || !grad_ildj) DPK_REQUIRE(hipMemsetAsync(sums + 2 * D, 0, 4, st) == hipSuccess, DPK_ELAUNCH, "memset");
+    if (B > 0 && grad_ildj) hipLaunchKernelGGL(vecsum_kernel, dim3(1), dim3(256), 0, st, grad_ildj, B, sums + 2 * D);
+    hipLaunchKernelGGL(bn1d_bwd_reduce_kernel, dim3(cdiv(D, kRC)), dim3(kRThreads), 0, st, x, grad_u, B, D, mean, var, eps,
+                       sums, sums + D);
+    DPK_CHECK_LAUNCH("bn1d_backward_sums");
+    return DPK_OK;
+}
+
+extern "C" int dpk_bn1d_sync_backward(const float *x, const float *grad_u, int64_t B, int64_t B_total, int32_t D,
+                                      const float *weight, const float *mean, const float *var, float eps,
+                                      const float *sums_x, const float *sums_p, float *grad_x, float *grad_weight,
+                                      float *grad_bias, void *stream) {
+    DPK_REQUIRE(B >= 0 && B_total >= 2 && D > 0 && weight && mean && var && sums_x && sums_p &&
+                    (B == 0 || (x && grad_u && grad_x)),
+                DPK_EINVAL, "bn1d_sync_backward: bad arguments");
+    const int64_t work = B * D > D ? B * D : D;
+    hipLaunchKernelGGL(bn1d_sync_bwd_apply_kernel, dim3(grid1d(work)), dim3(256), 0, (hipStream_t)stream, x, grad_u, B,
+                       B_total, D, weight, mean, var, eps, sums_x, sums_p, grad_x, grad_weight, grad_bias);
+    DPK_CHECK_LAUNCH("bn1d_sync_bwd_apply_kernel");
     return DPK_OK;
 }
 

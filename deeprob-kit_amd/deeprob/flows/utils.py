@@ -59,6 +59,9 @@ class BatchNormLayer1d(Bijector):
         self.register_buffer('running_var', torch.ones(1, self.in_features))
         self.register_buffer('running_mean', torch.zeros(1, self.in_features))
         self._ws = Workspace()
+        # process group over which train-mode statistics are taken when batches are sharded over ranks
+        # (deeprob.parallel.synchronize_batchnorm); None: the statistics of the rows this process sees
+        self.sync_group = None
 
     def apply_backward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """u = (x - mean)/sqrt(var + eps) * exp(weight) + bias with the batch statistics (training: running

@@ -89,6 +89,14 @@ SIGNATURES = {
                                               _c_void]),
     'dpk_bn1d_backward': (ctypes.c_int, [_c_void, _c_void, _c_void, _i64, _i32, _c_void, _c_void, _c_void,
                                          ctypes.c_float, _i32, _c_void, _c_void, _c_void, _c_void, _i64, _c_void]),
+    'dpk_bn1d_local_moments': (ctypes.c_int, [_c_void, _i64, _i32, _c_void, _c_void]),
+    'dpk_bn1d_sync_forward': (ctypes.c_int, [_c_void, _i64, _i32, _c_void, _c_void, _c_void, _i32, _c_void, _c_void,
+                                             ctypes.c_float, ctypes.c_float, _c_void, _c_void, _c_void, _c_void, _c_void,
+                                             _i64, _c_void]),
+    'dpk_bn1d_backward_sums': (ctypes.c_int, [_c_void, _c_void, _c_void, _i64, _i32, _c_void, _c_void, ctypes.c_float,
+                                              _c_void, _c_void]),
+    'dpk_bn1d_sync_backward': (ctypes.c_int, [_c_void, _c_void, _i64, _i64, _i32, _c_void, _c_void, _c_void,
+                                              ctypes.c_float, _c_void, _c_void, _c_void, _c_void, _c_void, _c_void]),
     'dpk_normal_base_backward': (ctypes.c_int, [_c_void, _c_void, _c_void, _c_void, _i64, _i32, _c_void, _c_void]),
     'dpk_leaf_forward_dropout': (ctypes.c_int, [_i32, _c_void, _i64, _i32, _c_void, _c_void, _c_void, _c_void, _i32, _i32,
                                                 _i32, ctypes.c_float, ctypes.c_uint64, _c_void, _c_void]),

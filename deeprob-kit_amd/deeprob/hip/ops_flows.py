@@ -277,6 +277,30 @@ class BatchNormFn(torch.autograd.Function):
         B, D = x.shape
         dev = x.device
         train = bool(bn.training)
+        group = getattr(bn, 'sync_group', None) if train else None
+        if group is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
+            # batch-sharded training: statistics of the whole batch (deeprob.parallel.synchronize_batchnorm)
+            from deeprob import parallel
+            world = torch.distributed.get_world_size(group)
+            mom = torch.empty(2 * D + 1, dtype=torch.float32, device=dev)
+            check(lib.dpk_bn1d_local_moments(ptr(x) if B else None, B, D, ptr(mom), stream_ptr(dev)),
+                  'dpk_bn1d_local_moments')
+            table = parallel.bn_gather_moments(mom, group)
+            n_total = int(round(float(table[:, 0].sum().item())))
+            u = torch.empty_like(x)
+            ldj = torch.empty(1, dtype=torch.float32, device=dev)
+            mean = torch.empty(D, dtype=torch.float32, device=dev)
+            var = torch.empty(D, dtype=torch.float32, device=dev)
+            ws = bn._ws.get(8 * D + 256, dev)
+            check(lib.dpk_bn1d_sync_forward(ptr(x) if B else None, B, D, ptr(require_device_f32(weight, 'weight')),
+                                            ptr(require_device_f32(bias, 'bias')), ptr(table), world,
+                                            ptr(bn.running_var), ptr(bn.running_mean), float(bn.momentum),
+                                            float(bn.eps), ptr(u) if B else None, ptr(ldj), ptr(mean), ptr(var), ptr(ws),
+                                            ws.numel(), stream_ptr(dev)), 'dpk_bn1d_sync_forward')
+            ctx.save_for_backward(x, weight, mean, var)
+            ctx.bn, ctx.train, ctx.sync = bn, True, (group, n_total)
+            return u, ldj.repeat(B)
+        ctx.sync = None
         if train:
             u = torch.empty_like(x)
             ldj = torch.empty(1, dtype=torch.float32, device=dev)
@@ -307,6 +331,19 @@ class BatchNormFn(torch.autograd.Function):
         gx = torch.empty_like(x)
         gw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
         gb = torch.empty_like(weight) if ctx.needs_input_grad[2] else None
+        if ctx.sync is not None:
+            from deeprob import parallel
+            group, n_total = ctx.sync
+            sums = torch.empty(2 * D + 1, dtype=torch.float32, device=x.device)
+            check(lib.dpk_bn1d_backward_sums(ptr(x) if B else None, ptr(gu) if B else None, ptr(gildj) if B else None,
+                                             B, D, ptr(mean), ptr(var), float(bn.eps), ptr(sums),
+                                             stream_ptr(x.device)), 'dpk_bn1d_backward_sums')
+            sums_x = parallel.bn_reduce_sums(sums, B, n_total, group)
+            check(lib.dpk_bn1d_sync_backward(ptr(x) if B else None, ptr(gu) if B else None, B, n_total, D, ptr(weight),
+                                             ptr(mean), ptr(var), float(bn.eps), ptr(sums_x), ptr(sums),
+                                             ptr(gx) if B else None, ptr(gw), ptr(gb), stream_ptr(x.device)),
+                  'dpk_bn1d_sync_backward')
+            return gx, gw, gb, None
         ws = bn._ws.get(4 * (2 * D + 64) + 256, x.device)
         check(lib.dpk_bn1d_backward(ptr(x), ptr(gu), ptr(gildj), B, D, ptr(weight), ptr(mean), ptr(var),
                                     float(bn.eps), int(ctx.train), ptr(gx), ptr(gw), ptr(gb), ptr(ws), ws.numel(),

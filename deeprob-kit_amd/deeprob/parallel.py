@@ -38,7 +38,8 @@ class ShardedLogLikelihood:
     ``drain()`` waits for everything outstanding and returns the mean LL of every step since the last
     drain (identical on all ranks).
 
-    :param model: a ``RatSpn`` on this rank's device (ignored if ``local_sum_fn`` is given).
+    :param model: a ``RatSpn``, ``DgcSpn`` or ``NormalizingFlow`` on this rank's device (ignored if
+                  ``local_sum_fn`` is given).
     :param group: process group (None = single process, no collective).
     :param local_sum_fn: ``x -> float64[2] {sum LL, count}`` on x's device; lets the sharding logic be
                          exercised with any evaluator (the gloo/CPU tests plug in a CPU checker).
@@ -74,6 +75,10 @@ class ShardedLogLikelihood:
         self._pool_next += 1
         return slot
 
+    def _is_ratspn(self) -> bool:
+        from deeprob.spn.models.ratspn import RatSpn
+        return isinstance(self.model, RatSpn)
+
     def _local(self, x: torch.Tensor, kernel_events=None) -> torch.Tensor:
         if self.local_sum_fn is not None:
             return self.local_sum_fn(x)
@@ -83,19 +88,24 @@ class ShardedLogLikelihood:
             # (start, stop): raw hipEvent_t handles, or torch.cuda.Event objects
             h0, h1 = (e if isinstance(e, int) else e.cuda_event for e in kernel_events)
             check(load_library().dpk_profile_next_kernel(h0, h1), 'dpk_profile_next_kernel')
+        from deeprob.hip import ops
+        fused = getattr(self.model, '_forward_fused', None)
         ll = None
-        if self.static_inputs and not torch.is_grad_enabled():
-            key = (x.data_ptr(), x.shape[0])
-            plan = self._plans.get(key)
-            if plan is None or (plan is not False and not plan.valid()):
-                plan = self.model.fused_plan(x) or False
-                self._plans[key] = plan
-            if plan is not False:
-                ll = plan.run(acc)
+        if self._is_ratspn():
+            # RAT-SPN: the fused kernel adds the tile's fp64 {sum, count} itself (no second pass over the LLs)
+            if self.static_inputs and not torch.is_grad_enabled():
+                key = (x.data_ptr(), x.shape[0])
+                plan = self._plans.get(key)
+                if plan is None or (plan is not False and not plan.valid()):
+                    plan = self.model.fused_plan(x) or False
+                    self._plans[key] = plan
+                if plan is not False:
+                    ll = plan.run(acc)
+            if ll is None:
+                ll = fused(x, acc)
         if ll is None:
-            ll = self.model._forward_fused(x, acc)
-        if ll is None:  # shape outside the fused kernel: per-layer operators + a reduction kernel
-            from deeprob.hip import ops
+            # DGC-SPN, normalizing flows, RAT-SPN shapes outside the fused kernel: the model's own forward
+            # (HIP kernels), then one reduction kernel over the B (x classes) log-likelihoods
             ll = self.model(x)
             ops.ll_accumulate(ll, acc)
         self.last_ll = ll
@@ -139,6 +149,71 @@ class ShardedLogLikelihood:
         self._pending = []
         means = (accs[:, 0] / accs[:, 1]).cpu().tolist()  # one device->host copy for the whole window
         return means
+
+
+def bn_gather_moments(moments: torch.Tensor, group=None) -> torch.Tensor:
+    """Sync-BN forward exchange: every rank contributes its ``{count, mean[D], M2[D]}`` vector, all ranks receive the
+    ``[world, 2D+1]`` table (an all-gather, done as an all-reduce of a table that is zero outside the own row: exact,
+    and available for device tensors on every backend)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    table = torch.zeros((world, moments.numel()), dtype=moments.dtype, device=moments.device)
+    table[rank].copy_(moments)
+    dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+    return table
+
+
+def bn_reduce_sums(sums: torch.Tensor, n_local: int, n_total: int, group=None) -> torch.Tensor:
+    """Sync-BN backward exchange.  ``sums`` = this rank's column sums of the gradient of ITS loss (the mean over its
+    ``n_local`` rows).  The single-process loss is the mean over all ``n_total`` rows, so the whole-batch sums are
+    ``sum_r (n_r / n_total) sums_r``; they are handed back rescaled by ``n_total / n_local`` -- in the units of this
+    rank's loss again, so that the later sample-weighted gradient average (``allreduce_gradients``) is the
+    single-process gradient.  One all-reduce of 2D+1 floats."""
+    t = sums * (float(n_local) / float(n_total))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    if n_local > 0:
+        t *= float(n_total) / float(n_local)
+    return t
+
+
+def synchronize_batchnorm(model: torch.nn.Module, group=None, enabled: bool = True):
+    """Make every train-mode ``BatchNormLayer1d`` of ``model`` use the statistics of the whole (sharded) batch:
+    sets ``layer.sync_group`` (None switches it off).  ``train_model`` does this when it shards batches."""
+    from deeprob.flows.utils import BatchNormLayer1d
+    for m in model.modules():
+        if isinstance(m, BatchNormLayer1d):
+            m.sync_group = (group if group is not None else dist.group.WORLD) if enabled else None
+
+
+def broadcast_model(model: torch.nn.Module, group=None, src: int = 0):
+    """Make every rank's replica the one of rank ``src``: parameters AND buffers (region-graph masks, BatchNorm running
+    statistics) are broadcast in ONE flat collective per dtype.  Data-parallel training assumes identical replicas;
+    without this, ranks that were initialised from different RNG states (``random_state=None`` region graphs,
+    ``randn`` / Dirichlet initialisers) would average the gradients of different models."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    by_dtype = {}
+    for t in list(model.parameters()) + list(model.buffers()):
+        by_dtype.setdefault(t.dtype, []).append(t)
+    with torch.no_grad():
+        for dtype, tensors in by_dtype.items():
+            wire = torch.uint8 if dtype == torch.bool else dtype   # (bool has no collective on every backend)
+            flat = torch.cat([t.detach().reshape(-1).to(wire) for t in tensors])
+            dist.broadcast(flat, src=src, group=group)
+            off = 0
+            for t in tensors:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view(t.shape).to(dtype))
+                off += n
+
+
+def broadcast_seed(device, group=None, src: int = 0) -> int:
+    """A random 63-bit seed drawn on rank ``src`` and agreed on by every rank (shuffles of sharded loaders)."""
+    seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        t = seed.to(device)
+        dist.broadcast(t, src=src, group=group)
+        seed = t.cpu()
+    return int(seed.item())
 
 
 def allreduce_gradients(model: torch.nn.Module, group=None, weight: Optional[float] = None):

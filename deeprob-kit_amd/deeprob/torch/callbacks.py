@@ -32,9 +32,11 @@ class EarlyStopping:
     def should_stop(self) -> bool:
         return self._stale >= self.patience
 
-    def get_best_state(self) -> OrderedDict:
+    def get_best_state(self, map_location=None) -> OrderedDict:
+        """The checkpointed state_dict; ``map_location`` as in ``torch.load`` (a rank of a sharded run passes its own
+        device: the file holds rank 0's tensors)."""
         with open(self.filepath, 'rb') as f:
-            return torch.load(f)
+            return torch.load(f, map_location=map_location)
 
     def __call__(self, loss: float, epoch: int, save: bool = True):
         """Record the epoch's validation loss; ``save=False`` on the ranks that do not own the checkpoint file."""

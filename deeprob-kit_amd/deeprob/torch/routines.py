@@ -23,7 +23,8 @@ from deeprob.torch.base import ProbabilisticModel
 from deeprob.torch.utils import get_optimizer_class
 from deeprob.torch.callbacks import EarlyStopping
 from deeprob.torch.metrics import RunningAverageMetric
-from deeprob.parallel import allreduce_gradients, shard_batch
+from deeprob.parallel import (allreduce_gradients, shard_batch, broadcast_model, broadcast_seed,
+                              synchronize_batchnorm)
 
 
 def _world() -> Tuple[int, int]:
@@ -70,15 +71,22 @@ def train_model(
         device = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else None
     if device is None or device.type != 'cuda':
         raise ValueError("deeprob on MI355X trains on a HIP device (there is no CPU path)")
-    train_loader = data.DataLoader(data_train, batch_size, shuffle=True, drop_last=drop_last, num_workers=num_workers)
+    # sharded training slices every batch over the ranks: all ranks must draw the SAME shuffle
+    shuffle_gen = torch.Generator().manual_seed(broadcast_seed(device)) if _world()[1] > 1 else None
+    train_loader = data.DataLoader(data_train, batch_size, shuffle=True, drop_last=drop_last, num_workers=num_workers,
+                                   generator=shuffle_gen)
     valid_loader = data.DataLoader(data_valid, batch_size, shuffle=False, drop_last=False, num_workers=num_workers)
     model.to(device)
     optimizer_kwargs = dict(optimizer_kwargs or {})
     if hip_graph:
         if setting != 'generative' or _world()[1] > 1:
             raise ValueError("hip_graph covers the generative setting in a single process")
-        if optimizer in ('adam', 'adamw', 'nadam', 'radam', 'adamax', 'rmsprop', 'adagrad', 'adadelta'):
+        import inspect
+        if 'capturable' in inspect.signature(get_optimizer_class(optimizer).__init__).parameters:
             optimizer_kwargs.setdefault('capturable', True)
+        elif optimizer != 'sgd':   # (plain SGD keeps no step counter on the host: it captures as it is)
+            raise ValueError("hip_graph needs an optimizer that can be captured (capturable=True); "
+                             "torch.optim's '{}' cannot".format(optimizer))
     opt = get_optimizer_class(optimizer)(filter(lambda p: p.requires_grad, model.parameters()), lr=lr,
                                          **optimizer_kwargs)
     early_stopping = EarlyStopping(model, patience=patience, filepath=checkpoint)
@@ -138,6 +146,11 @@ def _fit(model, train_loader, valid_loader, optimizer, device, early_stopping, e
     if epochs <= 0:
         raise ValueError("The number of epochs must be positve")
     rank, world = _world()
+    if world > 1:
+        # identical replicas on every rank (parameters and buffers of rank 0), whole-batch BatchNorm statistics.
+        # The caller's loaders must yield the same batches on every rank (train_model seeds its shuffle accordingly).
+        broadcast_model(model)
+        synchronize_batchnorm(model)
     graphed = None
     if hip_graph:
         if supervised or world > 1:
@@ -207,7 +220,7 @@ def _fit(model, train_loader, valid_loader, optimizer, device, early_stopping, e
             break
     if world > 1:
         dist.barrier()   # rank 0 finished writing the checkpoint
-    model.load_state_dict(early_stopping.get_best_state())
+    model.load_state_dict(early_stopping.get_best_state(map_location=device))
     return history
 
 

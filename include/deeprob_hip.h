@@ -277,6 +277,28 @@ int dpk_bn1d_train_forward(const float *x, int64_t B, int32_t D, const float *we
                            float *running_var, float *running_mean, float momentum, float eps, float *out,
                            float *ildj_const, float *save_mean, float *save_var, void *ws, int64_t ws_bytes,
                            void *stream);
+/* Batch-sharded (synchronised) training-mode BatchNormLayer1d: every rank holds B rows of a batch of B_total rows
+ * and all ranks derive the statistics of the WHOLE batch, i.e. what the single-process reference computes
+ * (flows/utils.py:122-128).  No reference counterpart for the exchange itself (the reference is single device).
+ *   1. dpk_bn1d_local_moments: moments[2D+1] = {B, mean_d of the local rows, sum_b (x - mean_d)^2}
+ *   2. the caller all-gathers them: gathered[world][2D+1]
+ *   3. dpk_bn1d_sync_forward: combines in rank order (Chan's pairwise update: bit-identical on every rank), updates
+ *      the running statistics, writes out / ildj_const / save_mean / save_var like dpk_bn1d_train_forward
+ *   backward: dpk_bn1d_backward_sums: sums[2D+1] = {sum_b g_u, sum_b g_u xhat, sum_b g_ildj} of the local rows; the
+ *   caller all-reduces them weighted by B/B_total and rescales by B_total/B (each rank's loss is the mean over ITS
+ *   rows) -> sums_x; dpk_bn1d_sync_backward: grad_x from sums_x (whole batch), grad_weight / grad_bias from the
+ *   local sums_p, so that the sample-weighted gradient average over the ranks equals the single-process gradient.  */
+int dpk_bn1d_local_moments(const float *x, int64_t B, int32_t D, float *moments, void *stream);
+int dpk_bn1d_sync_forward(const float *x, int64_t B, int32_t D, const float *weight, const float *bias,
+                          const float *gathered, int32_t world, float *running_var, float *running_mean,
+                          float momentum, float eps, float *out, float *ildj_const, float *save_mean,
+                          float *save_var, void *ws, int64_t ws_bytes, void *stream);
+int dpk_bn1d_backward_sums(const float *x, const float *grad_u, const float *grad_ildj, int64_t B, int32_t D,
+                           const float *mean, const float *var, float eps, float *sums, void *stream);
+int dpk_bn1d_sync_backward(const float *x, const float *grad_u, int64_t B, int64_t B_total, int32_t D,
+                           const float *weight, const float *mean, const float *var, float eps,
+                           const float *sums_x, const float *sums_p, float *grad_x, float *grad_weight,
+                           float *grad_bias, void *stream);
 /* Backward of BatchNormLayer1d.apply_backward: train=1 with the saved batch statistics (gradient flows
  * through them), train=0 with the running statistics as constants.  grad_ildj [B] may be NULL;
  * grad_weight / grad_bias [D] may be NULL.  Workspace >= (2*D + 64) floats.                     */

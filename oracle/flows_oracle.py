@@ -79,6 +79,62 @@ def bn_backward_train(x, weight, bias, running_var, running_mean, momentum=0.9, 
     return u, torch.sum(weight - 0.5 * torch.log(var)).expand(x.shape[0]), new_var, new_mean
 
 
+class _SyncBatchNormTrain(torch.autograd.Function):
+    """CPU checker of the batch-sharded training-mode BatchNormLayer1d (the product: dpk_bn1d_local_moments /
+    _sync_forward / _backward_sums / _sync_backward + deeprob.parallel.bn_gather_moments / bn_reduce_sums).  Same
+    protocol, torch arithmetic: every rank holds a slice of the batch, `gather` / `reduce` are the product's two
+    exchange functions, and the result must equal bn_backward_train on the unsharded batch."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, gather, reduce):
+        n, d = x.shape
+        mean_r = x.mean(dim=0) if n > 0 else torch.zeros(d, dtype=x.dtype)
+        m2_r = ((x - mean_r) ** 2).sum(dim=0) if n > 0 else torch.zeros(d, dtype=x.dtype)
+        table = gather(torch.cat([torch.tensor([float(n)], dtype=x.dtype), mean_r, m2_r]))
+        cnt, mean, m2 = 0.0, torch.zeros(d, dtype=x.dtype), torch.zeros(d, dtype=x.dtype)
+        for row in table:                       # rank order, Chan et al. pairwise update
+            nr = float(row[0])
+            if nr > 0:
+                dlt = row[1:1 + d] - mean
+                tot = cnt + nr
+                mean = mean + dlt * (nr / tot)
+                m2 = m2 + row[1 + d:] + dlt * dlt * (cnt * nr / tot)
+                cnt = tot
+        var = m2 / (cnt - 1.0)
+        inv = 1.0 / torch.sqrt(var + eps)
+        xhat = (x - mean) * inv
+        u = xhat * torch.exp(weight.reshape(-1)) + bias.reshape(-1)
+        ildj = torch.sum(weight.reshape(-1) - 0.5 * torch.log(var + eps)).expand(n)
+        ctx.save_for_backward(xhat, weight, inv)
+        ctx.reduce, ctx.n_total = reduce, int(round(cnt))
+        ctx.mark_non_differentiable(mean, var)
+        return u, ildj, mean, var
+
+    @staticmethod
+    def backward(ctx, gu, gildj, _gm, _gv):
+        xhat, weight, inv = ctx.saved_tensors
+        n, d = xhat.shape
+        ew = torch.exp(weight.reshape(-1))
+        sums = torch.cat([gu.sum(dim=0), (gu * xhat).sum(dim=0), gildj.sum().reshape(1)])
+        sx = ctx.reduce(sums.clone(), n, ctx.n_total)
+        s1, s2, sg = sx[:d], sx[d:2 * d], sx[2 * d]
+        nt = float(ctx.n_total)
+        dvar = -0.5 * (ew * s2 + sg) * inv * inv
+        dmean = -ew * inv * s1
+        gx = gu * ew * inv + dvar * 2.0 * (xhat / inv) / (nt - 1.0) + dmean / nt
+        gw = (ew * sums[d:2 * d] + sums[2 * d]).reshape(weight.shape)
+        gb = sums[:d].reshape(weight.shape)
+        return gx, gw, gb, None, None, None
+
+
+def bn_backward_train_sync(x, weight, bias, running_var, running_mean, gather, reduce, momentum=0.9, eps=1e-5):
+    """bn_backward_train for a batch sharded over ranks (statistics of the whole batch)."""
+    u, ildj, mean, var = _SyncBatchNormTrain.apply(x, weight, bias, eps, gather, reduce)
+    new_var = running_var * momentum + var.reshape(running_var.shape) * (1.0 - momentum)
+    new_mean = running_mean * momentum + mean.reshape(running_mean.shape) * (1.0 - momentum)
+    return u, ildj, new_var, new_mean
+
+
 def bn_forward(u, weight, bias, var, mean, eps=1e-5):
     """flows/utils.py:141-153."""
     var = var + eps
@@ -107,17 +163,22 @@ def flow_layers(sd) -> List[Tuple[str, int]]:
         i += 1
 
 
-def flow_apply_backward(sd, x, collect=None, train=False, running=None):
+def flow_apply_backward(sd, x, collect=None, train=False, running=None, sync=None):
     """NormalizingFlow.apply_backward (base.py:182-193).  train=True: batch-norm layers use batch statistics;
-    the updated running statistics are written into the dict `running`."""
+    the updated running statistics are written into the dict `running`.  sync=(gather, reduce): x is this rank's
+    slice of a sharded batch and the statistics are those of the whole batch (bn_backward_train_sync)."""
     ildj = torch.zeros(x.shape[0], dtype=x.dtype)
     for kind, i in flow_layers(sd):
         p = 'layers.{}.'.format(i)
         if kind == 'coupling':
             x, d = coupling_backward(x, *coupling_params(sd, i))
         elif train:
-            x, d, nv, nm = bn_backward_train(x, sd[p + 'weight'], sd[p + 'bias'], sd[p + 'running_var'],
-                                             sd[p + 'running_mean'])
+            if sync is not None:
+                x, d, nv, nm = bn_backward_train_sync(x, sd[p + 'weight'], sd[p + 'bias'], sd[p + 'running_var'],
+                                                      sd[p + 'running_mean'], *sync)
+            else:
+                x, d, nv, nm = bn_backward_train(x, sd[p + 'weight'], sd[p + 'bias'], sd[p + 'running_var'],
+                                                 sd[p + 'running_mean'])
             if running is not None:
                 running[p + 'running_var'], running[p + 'running_mean'] = nv, nm
         else:
@@ -141,7 +202,7 @@ def flow_apply_forward(sd, u):
     return u, ldj
 
 
-def flow_log_prob(sd, x, logit_alpha=None, train=False, running=None, base=None):
+def flow_log_prob(sd, x, logit_alpha=None, train=False, running=None, base=None, sync=None):
     """NormalizingFlow.forward (base.py:123-143) with the default Normal base, or `base(u) -> [B, 1]` (a module
     base density such as a RAT-SPN)."""
     n = x.shape[0]
@@ -149,7 +210,7 @@ def flow_log_prob(sd, x, logit_alpha=None, train=False, running=None, base=None)
     if logit_alpha is not None:
         x, d = logit_backward(x, logit_alpha, sd['logit.ldj'])
         ildj = ildj + d
-    u, d = flow_apply_backward(sd, x, train=train, running=running)
+    u, d = flow_apply_backward(sd, x, train=train, running=running, sync=sync)
     ildj = ildj + d
     if base is not None:
         return torch.sum(base(u).view(n, -1), dim=1) + ildj

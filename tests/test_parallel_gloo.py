@@ -142,3 +142,93 @@ def test_sharded_training_equals_single_process(tmp_path):
     assert np.allclose(r0, r1, rtol=0, atol=1e-12)               # replicas stay in lock step
     assert np.allclose(r0, ref, rtol=1e-5, atol=1e-6)
     assert ref[12] > ref[17]                                     # the training loss went down over the epochs
+
+
+def _flow_state(seed, d=12, units=16, n_flows=2, dtype=torch.float64):
+    """A small RealNVP-1D state_dict (coupling, batch norm, coupling, batch norm) with every parameter live."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {'in_base_loc': torch.zeros(d, dtype=dtype), 'in_base_scale': torch.ones(d, dtype=dtype)}
+    for k in range(n_flows):
+        p = 'layers.{}.'.format(2 * k)
+        mask = (torch.arange(d) % 2).to(dtype)
+        if k % 2:
+            mask = 1 - mask
+        sd[p + 'mask'], sd[p + 'inv_mask'] = mask, 1 - mask
+        sd[p + 'network.0.weight'] = 0.3 * torch.randn(units, d, generator=g, dtype=dtype)
+        sd[p + 'network.0.bias'] = 0.1 * torch.randn(units, generator=g, dtype=dtype)
+        sd[p + 'network.2.weight'] = 0.3 * torch.randn(2 * d, units, generator=g, dtype=dtype)
+        sd[p + 'network.2.bias'] = 0.1 * torch.randn(2 * d, generator=g, dtype=dtype)
+        sd[p + 'scale_act.weight'] = torch.tensor([0.5], dtype=dtype)
+        q = 'layers.{}.'.format(2 * k + 1)
+        sd[q + 'weight'] = 0.2 * torch.randn(1, d, generator=g, dtype=dtype)
+        sd[q + 'bias'] = 0.2 * torch.randn(1, d, generator=g, dtype=dtype)
+        sd[q + 'running_var'] = torch.ones(1, d, dtype=dtype)
+        sd[q + 'running_mean'] = torch.zeros(1, d, dtype=dtype)
+    return sd
+
+
+_TRAINABLE = ('network', 'scale_act', '.weight', '.bias')
+
+
+def _flow_step(sd, x, sync):
+    """One training-mode evaluation: loss = -mean LL of the rows in x, gradients of every trainable entry."""
+    from oracle import flows_oracle as forc
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+              if any(t in k for t in _TRAINABLE) and 'mask' not in k and 'running' not in k}
+    state = dict(sd)
+    state.update(params)
+    running = {}
+    if x.shape[0] > 0:
+        loss = -forc.flow_log_prob(state, x, train=True, running=running, sync=sync).mean()
+    else:   # an empty shard still joins the collectives of every batch-norm layer
+        loss = forc.flow_log_prob(state, x, train=True, running=running, sync=sync).sum()
+    loss.backward()
+    return params, running, float(loss.detach())
+
+
+def _syncbn_worker(rank, world, port, out_dir):
+    from tests import conftest  # noqa: F401  (sys.path)
+    from deeprob import parallel
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    sd = _flow_state(3)
+    x = torch.randn(37, 12, generator=torch.Generator().manual_seed(8), dtype=torch.float64) * 1.3 + 0.4
+    xs = parallel.shard_batch(x, rank, world)                       # 19 + 18 rows
+    sync = (lambda m: parallel.bn_gather_moments(m, dist.group.WORLD),
+            lambda t, n, nt: parallel.bn_reduce_sums(t, n, nt, dist.group.WORLD))
+    params, running, _ = _flow_step(sd, xs, sync)
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.ParameterList([torch.nn.Parameter(v.detach().clone()) for v in params.values()])
+
+    holder = Holder()
+    for hp, v in zip(holder.p, params.values()):
+        hp.grad = v.grad.clone()
+    parallel.allreduce_gradients(holder, weight=xs.shape[0])        # the product's sample-weighted gradient exchange
+    vec = torch.cat([hp.grad.reshape(-1).double() for hp in holder.p] +
+                    [running[k].reshape(-1).double() for k in sorted(running)])
+    np.save(os.path.join(out_dir, 'sbn_r{}.npy'.format(rank)), vec.numpy())
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_two_ranks_equal_single_process(tmp_path):
+    """Train-mode BatchNormLayer1d under batch sharding (SURVEY 8e caveat): with the product's moment / gradient-sum
+    exchange (deeprob.parallel.bn_gather_moments, bn_reduce_sums) and the sample-weighted gradient all-reduce, two
+    ranks on 19 + 18 rows reproduce the single-process gradients and running statistics of the 37-row batch."""
+    mp.start_processes(_syncbn_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, start_method='spawn')
+    sd = _flow_state(3)
+    x = torch.randn(37, 12, generator=torch.Generator().manual_seed(8), dtype=torch.float64) * 1.3 + 0.4
+    params, running, _ = _flow_step(sd, x, None)
+    ref = torch.cat([v.grad.reshape(-1) for v in params.values()] +
+                    [running[k].reshape(-1) for k in sorted(running)]).numpy()
+    r0, r1 = np.load(tmp_path / 'sbn_r0.npy'), np.load(tmp_path / 'sbn_r1.npy')
+    assert np.allclose(r0, r1, rtol=0, atol=1e-13)
+    # (the gradient bucket of allreduce_gradients is fp32; the running statistics, which do not pass through it, are exact)
+    assert np.max(np.abs(r0 - ref)) <= 5e-7 * max(1.0, np.max(np.abs(ref)))
+    n_run = 4 * 12
+    assert np.max(np.abs(r0[-n_run:] - ref[-n_run:])) <= 1e-12
+    assert np.max(np.abs(ref)) > 1e-3   # (the comparison is not of zeros)
