@@ -1,25 +1,33 @@
 #!/usr/bin/env python3
-"""Headline benchmark: log-likelihoods/sec of a Gaussian RAT-SPN (D=784, depth 2, 8 repetitions) on
-synthetic batches of 65536 samples per GPU, evaluated by the fused HIP kernel.
+"""Headline benchmark: log-likelihoods/sec of a Gaussian RAT-SPN (D=784, depth 2, 8 repetitions) on synthetic
+batches of 65536 samples per GPU, evaluated by the fused HIP kernel (leaf layer on the matrix cores).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
-A step = one pass of the hot path over one resident batch: parameter-table kernels + the fused
-forward kernel (per-sample LLs written to HBM, fp64 sum fused in) + for N > 1 the RCCL all-reduce of
-{sum LL, count} that yields the mean LL on every rank (asynchronous, overlapped with the next step).
-Inputs live in HBM before the timed region; a ring of distinct batches larger than the 256 MiB
-Infinity Cache is cycled so the x stream really comes from HBM.
+With N > 1 and no torch.distributed environment the script re-executes itself under torch.distributed.run (one
+process per GPU, RCCL); launched by torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE as usual.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (ratspn_leaf_kernel, fused
-whole-model forward): algorithmic bytes per launch = B * 4*(784 + C) (SURVEY 8d fully-fused bound)
-over its mean duration measured with HIP events on the launch stream inside the timed loop.
-`cpu_baseline` times the oracle (op-for-op PyTorch-CPU restatement of the reference) on the host
-cores over a bounded sample of the same workload.
+A step = one pass of the hot path over one resident batch: the fused forward kernel (per-sample LLs written to HBM,
+fp64 sum fused in; its parameter tables are rebuilt only when a parameter changed) + for N > 1 the RCCL all-reduce of
+{sum LL, count} that yields the mean LL on every rank (asynchronous, batched, overlapped with the next steps).
+Inputs live in HBM before the timed region; a ring of >= 4 distinct batches (>= 3x the 256 MiB Infinity Cache) is
+cycled so that the x stream really comes from HBM.  --scaling weak (default): 65536 samples per GPU; strong: 65536
+samples in total.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (ratspn_gemm_kernel, the fused whole-model
+forward): algorithmic bytes per launch = B * 4*(784 + C) (SURVEY 8d fully-fused bound) over its mean duration
+measured with HIP events on the launch stream inside the timed loop.  `cpu_baseline` times the oracle (op-for-op
+PyTorch-CPU restatement of the reference) on the host cores over a bounded sample of the same workload.  `secondary`
+(N = 1 only) carries the other BASELINE configurations, each measured the same way in this run: RAT-SPN at B = 4096
+for (rg_batch, rg_sum) = (2,2) / (8,8) / (16,16), DGC-SPN at B = 8192, RealNVP-1D at B = 65536, one optimisation step
+of each family, and the headline with a host-to-device copy of every batch inside the step.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,9 +36,9 @@ for _p in (os.path.join(ROOT, 'deeprob-kit_amd'), ROOT):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import torch  # noqa: E402
-
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+F32_PEAK_TFLOPS = 157.3    # fp32 vector = fp32 matrix peak
+KERNEL_FUSED, KERNEL_LEAF, KERNEL_COUPLING, KERNEL_PRODSUM, KERNEL_SUMPRODROOT = 1, 2, 3, 4, 5
 
 
 def parse():
@@ -38,11 +46,13 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--batch', type=int, default=65536, help='samples per GPU per step')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
+    ap.add_argument('--batch', type=int, default=65536, help='samples per GPU per step (weak) / in total (strong)')
     ap.add_argument('--rg-batch', type=int, default=2)
     ap.add_argument('--rg-sum', type=int, default=2)
-    ap.add_argument('--ring', type=int, default=0, help='distinct resident batches (0: > 256 MiB worth)')
+    ap.add_argument('--ring', type=int, default=0, help='distinct resident batches (0: >= 4 and >= 768 MiB worth)')
     ap.add_argument('--cpu-samples', type=int, default=262144, help='cpu_baseline sample size (0 = skip)')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary configurations')
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--prewarm', type=int, default=384, help='untimed steps before the warm-up (runtime pool growth)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only to "
@@ -54,16 +64,65 @@ def parse():
     return ap.parse_args()
 
 
+def respawn(args):
+    """--gpus N without a torch.distributed environment: run this script under torch.distributed.run."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# HIP events straight from the runtime (torch.cuda.Event sees only torch's current stream; these are recorded by the
+# library around one kernel on the stream it is launched on: dpk_profile_next_kernel[_of])
+# ------------------------------------------------------------------------------------------------------------------
+class KernelTimer:
+    def __init__(self):
+        self.rt = ctypes.CDLL('libamdhip64.so')
+
+    def pair(self):
+        out = []
+        for _ in range(2):
+            h = ctypes.c_void_p()
+            rc = self.rt.hipEventCreate(ctypes.byref(h))
+            assert rc == 0, 'hipEventCreate failed: {}'.format(rc)
+            out.append(h.value)
+        return tuple(out)
+
+    def ms(self, pair):
+        v = ctypes.c_float()
+        rc = self.rt.hipEventElapsedTime(ctypes.byref(v), ctypes.c_void_p(pair[0]), ctypes.c_void_p(pair[1]))
+        assert rc == 0, 'hipEventElapsedTime failed: {}'.format(rc)
+        return v.value
+
+
+def _oracle_rate(fn, n, chunk, threads):
+    import torch
+    torch.set_num_threads(threads)
+    with torch.no_grad():
+        fn(0, min(chunk, n))   # warm-up chunk
+        t0 = time.perf_counter()
+        for i in range(0, n, chunk):
+            fn(i, min(i + chunk, n))
+        dt = time.perf_counter() - t0
+    return n / dt, dt
+
+
 def cpu_baseline(model_state, D, n_samples):
-    """Oracle timed on the host cores: chunks of 4096 (the reference materialises [B,R,I,d]
-    temporaries), 1 warm-up chunk, all cores."""
+    """Oracle timed on the host cores: chunks of 4096 (the reference materialises [B,R,I,d] temporaries), 1 warm-up
+    chunk, the fastest of a few intra-op pool sizes (PyTorch's pool does not scale to every core of a big host on
+    these element-wise sweeps)."""
+    import torch
     from oracle import ratspn_oracle as orc
     ncpu = os.cpu_count() or 1
     chunk = 4096
     x = torch.randn(n_samples, D, generator=torch.Generator().manual_seed(0))
     best = None
-    # PyTorch's intra-op pool does not scale to every core of a big host on these element-wise
-    # sweeps: probe a few pool sizes on one chunk and keep the fastest for the timed sample
     with torch.no_grad():
         for threads in sorted({ncpu, min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}):
             torch.set_num_threads(threads)
@@ -73,42 +132,225 @@ def cpu_baseline(model_state, D, n_samples):
             dt = time.perf_counter() - t0
             if best is None or dt < best[1]:
                 best = (threads, dt)
-        threads = best[0]
-        torch.set_num_threads(threads)
-        t0 = time.perf_counter()
-        for i in range(0, n_samples, chunk):
-            orc.ratspn_forward(model_state, x[i:i + chunk])
-        dt = time.perf_counter() - t0
-    return {'value': n_samples / dt, 'unit': 'log-likelihoods/sec', 'cores': threads, 'kind': 'port',
+    threads = best[0]
+    rate, dt = _oracle_rate(lambda a, b: orc.ratspn_forward(model_state, x[a:b]), n_samples, chunk, threads)
+    return {'value': rate, 'unit': 'log-likelihoods/sec', 'cores': threads, 'kind': 'port',
             'sample': '{} samples of the same workload in chunks of {} ({:.1f} s) on {} of {} host threads '
                       '(fastest of the probed pool sizes), oracle/ratspn_oracle.py = op-for-op PyTorch-CPU '
-                      'restatement of the reference'.format(n_samples, chunk, dt, threads, ncpu)}
+                      'restatement of the reference'.format(n_samples, chunk, dt, threads, ncpu)}, threads
 
 
 def read_traffic():
-    """HBM bytes per launch of the fused kernel from the last committed rocprofv3 --pmc pass."""
+    """HBM bytes per launch of the fused kernel from this round's rocprofv3 --pmc pass (a separate run: PMC and
+    timing do not mix; tools/collect_profiles.sh writes the file, the summary sits beside it in profiles/)."""
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     try:
         with open(path) as f:
-            return json.load(f).get('bytes_per_launch')
+            d = json.load(f)
+        return d.get('bytes_per_launch'), d.get('source')
     except (OSError, ValueError):
-        return None
+        return None, None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# secondary configurations (N = 1): same protocol, smaller step counts
+# ------------------------------------------------------------------------------------------------------------------
+def _time_eval(model, xs, timer, kernel_id, steps=30, warm=5):
+    """(ms per model(x) call over `steps` calls on torch events, HIP-event ms of the dominant kernel)."""
+    import torch
+    from deeprob.hip import load_library
+    lib = load_library()
+    with torch.no_grad():
+        for i in range(warm):
+            model(xs[i % len(xs)])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(steps):
+            model(xs[i % len(xs)])
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        k_ms = []
+        for i in range(5):
+            pr = timer.pair()
+            lib.dpk_profile_next_kernel_of(pr[0], pr[1], kernel_id)
+            model(xs[i % len(xs)])
+            torch.cuda.synchronize()
+            lib.dpk_profile_next_kernel(None, None)
+            try:
+                k_ms.append(timer.ms(pr))
+            except AssertionError:
+                pass
+    return ms, (sum(k_ms) / len(k_ms) if k_ms else None)
+
+
+def _time_train(model, x, steps=15, warm=3):
+    import torch
+    model.train()
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+
+    def step():
+        opt.zero_grad()
+        loss = model.loss(model(x))
+        loss.backward()
+        opt.step()
+        model.apply_constraints()
+
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def secondary(dev, timer, threads, xs_headline, headline_model):
+    import torch
+    from deeprob.spn.models import GaussianRatSpn, DgcSpn
+    from deeprob.flows.models import RealNVP1d
+    from oracle import ratspn_oracle as orc, dgcspn_oracle as dorc, flows_oracle as forc
+    out = []
+    D = 784
+
+    def hbm(alg_bytes, ms):
+        a = alg_bytes / (ms * 1e-3) / 1e9
+        return {'bound': 'hbm', 'achieved': a, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': a / HBM_PEAK_GBS,
+                'traffic': None}
+
+    def flops(fl, ms, bound='mfma'):
+        a = fl / (ms * 1e-3) / 1e12
+        return {'bound': bound, 'achieved': a, 'peak': F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': a / F32_PEAK_TFLOPS,
+                'traffic': None}
+
+    # ---- BASELINE config 2: RAT-SPN, B = 4096 (SURVEY 8d: constructor defaults + the two wider settings) ----------
+    B = 4096
+    # bytes / flops per sample (SURVEY 8d): fully fused 4*(784+1); (16,16) runs as leaf | prod+sum | prod+root
+    rat = {(2, 2): (3140, 50.6e3), (8, 8): (3140, 219.6e3), (16, 16): (9284, 542.7e3)}
+    for (I, S), (alg, fl) in rat.items():
+        torch.manual_seed(0)
+        m = GaussianRatSpn(D, rg_depth=2, rg_repetitions=8, rg_batch=I, rg_sum=S, random_state=42).eval()
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        m.to(dev)
+        xs = [torch.randn(B, D, device=dev) for _ in range(4)]
+        kid = KERNEL_FUSED if I <= 8 else KERNEL_LEAF
+        ms, k_ms = _time_eval(m, xs, timer, kid, steps=50)
+        n_cpu = 4096 if I <= 8 else 1024
+        xc = torch.randn(n_cpu, D)
+        rate, dt = _oracle_rate(lambda a, b: orc.ratspn_forward(sd, xc[a:b]), n_cpu, 1024 if I > 8 else 4096, threads)
+        e = {'workload': 'GaussianRatSpn(784, rg_depth=2, rg_repetitions=8, rg_batch={}, rg_sum={}) forward, '
+                         'model(x) under no_grad'.format(I, S),
+             'config': 'BASELINE config 2', 'batch': B, 'ms_per_step': ms, 'value': B / ms * 1e3,
+             'unit': 'log-likelihoods/sec', 'kernel_ms': k_ms,
+             'kernel': 'fused forward' if I <= 8 else 'leaf kernel (then prod+sum, prod+root kernels)',
+             'roofline': hbm(B * alg, ms) if I <= 8 else flops(B * fl, ms, 'valu'),
+             'roofline_basis': 'whole step; {} algorithmic B/sample'.format(alg) if I <= 8
+                               else 'whole step; {:.0f} flop/sample on the fp32 VALU (SURVEY 8d: VALU-bound)'.format(fl),
+             'cpu_baseline': {'value': rate, 'unit': 'log-likelihoods/sec', 'cores': threads, 'kind': 'port',
+                              'sample': '{} samples ({:.1f} s), oracle/ratspn_oracle.py'.format(n_cpu, dt)}}
+        out.append(e)
+        del m, xs
+
+    # ---- BASELINE config 4: DGC-SPN, B = 8192 ----------------------------------------------------------------------
+    B = 8192
+    torch.manual_seed(5)
+    m = DgcSpn((1, 28, 28), n_batch=8, sum_channels=8, depthwise=True, n_pooling=0).eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m.to(dev)
+    xs = [torch.randn(B, 1, 28, 28, device=dev) for _ in range(2)]
+    ms, k_ms = _time_eval(m, xs, timer, KERNEL_SUMPRODROOT, steps=10, warm=3)
+    plan = dorc.schedule((1, 28, 28), 8, 8, True, 0)
+    xc = torch.randn(256, 1, 28, 28)
+    rate, dt = _oracle_rate(lambda a, b: dorc.dgcspn_forward(sd, xc[a:b], plan), 256, 128, threads)
+    out.append({'workload': 'DgcSpn((1,28,28), n_batch=8, sum_channels=8, depthwise=True, n_pooling=0) forward',
+                'config': 'BASELINE config 4', 'batch': B, 'ms_per_step': ms, 'value': B / ms * 1e3,
+                'unit': 'log-likelihoods/sec', 'kernel_ms': k_ms,
+                'kernel': 'spatial_sumprodroot_fwd_kernel (last sum level + product + root)',
+                'roofline': hbm(B * 588164, ms),
+                'roofline_basis': 'whole step; 588164 algorithmic B/sample (SURVEY 8d, products folded into sums)',
+                'cpu_baseline': {'value': rate, 'unit': 'log-likelihoods/sec', 'cores': threads, 'kind': 'port',
+                                 'sample': '256 samples ({:.1f} s), oracle/dgcspn_oracle.py'.format(dt)}})
+    m_dgc = m
+    del xs
+
+    # ---- BASELINE config 5: RealNVP-1D, B = 65536 ------------------------------------------------------------------
+    from tests.util import randomise_flow
+    B = 65536
+    torch.manual_seed(10)
+    m = RealNVP1d(D)
+    randomise_flow(m, 11)            # scale_act.weight / BN statistics live (the default init makes s == 0)
+    m.eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m.to(dev)
+    xs = [torch.randn(B, D, device=dev) for _ in range(2)]
+    ms, k_ms = _time_eval(m, xs, timer, KERNEL_COUPLING, steps=20, warm=3)
+    per_layer = B * 2 * (392 * 128 + 128 * 784)
+    xc = torch.randn(16384, D)
+    rate, dt = _oracle_rate(lambda a, b: forc.flow_log_prob(sd, xc[a:b]), 16384, 4096, threads)
+    e = {'workload': 'RealNVP1d(784, n_flows=5, depth=1, units=128, batch_norm, affine) forward log-likelihood',
+         'config': 'BASELINE config 5', 'batch': B, 'ms_per_step': ms, 'value': B / ms * 1e3,
+         'unit': 'log-likelihoods/sec', 'kernel_ms': k_ms, 'kernel': 'coupling1d_kernel (one of the 5 layers)',
+         'roofline': flops(per_layer, k_ms) if k_ms else flops(5 * per_layer, ms),
+         'roofline_basis': 'one coupling kernel; mask-aware 2*(392*128 + 128*784) flop per sample and layer on the '
+                           'fp32 MFMA' if k_ms else 'whole step, mask-aware flops',
+         'cpu_baseline': {'value': rate, 'unit': 'log-likelihoods/sec', 'cores': threads, 'kind': 'port',
+                          'sample': '16384 samples ({:.1f} s), oracle/flows_oracle.py'.format(dt)}}
+    out.append(e)
+    m_flow = m
+    del xs
+
+    # ---- forward + backward + Adam, B = 512 (SURVEY 8d "also report fwd+bwd step/s") ------------------------------
+    B = 512
+    torch.manual_seed(0)
+    trains = [('GaussianRatSpn(784, depth 2, reps 8, rg_batch=8, rg_sum=8)',
+               GaussianRatSpn(D, rg_depth=2, rg_repetitions=8, rg_batch=8, rg_sum=8, random_state=42).to(dev),
+               torch.randn(B, D, device=dev)),
+              ('DgcSpn((1,28,28), 8, 8, depthwise)', m_dgc, torch.randn(B, 1, 28, 28, device=dev)),
+              ('RealNVP1d(784)', m_flow, torch.randn(B, D, device=dev))]
+    for name, m, x in trains:
+        ms = _time_train(m, x)
+        out.append({'workload': name + ': forward + backward + Adam step', 'config': 'training step', 'batch': B,
+                    'ms_per_step': ms, 'value': B / ms * 1e3, 'unit': 'samples/sec'})
+
+    # ---- the headline with the host-to-device copy inside the step (SURVEY 8d: routines.py:159 copies per batch) ----
+    Bh = xs_headline[0].shape[0]
+    host = [torch.randn(Bh, D).pin_memory() for _ in range(2)]
+    stage = [torch.empty(Bh, D, device=dev) for _ in range(2)]
+    with torch.no_grad():
+        for i in range(3):
+            stage[i % 2].copy_(host[i % 2], non_blocking=True)
+            headline_model(stage[i % 2])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        K = 10
+        for i in range(K):
+            stage[i % 2].copy_(host[i % 2], non_blocking=True)
+            headline_model(stage[i % 2])
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / K * 1e3
+    out.append({'workload': 'headline model, batch copied from pinned host memory inside every step (PCIe-inclusive)',
+                'config': 'H2D-inclusive', 'batch': Bh, 'ms_per_step': ms, 'value': Bh / ms * 1e3,
+                'unit': 'log-likelihoods/sec', 'h2d_GBps': Bh * D * 4 / (ms * 1e-3) / 1e9})
+    return out
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(respawn(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus > 1 and world == 1:
-        sys.exit('for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...')
     assert world == max(args.gpus, 1), 'WORLD_SIZE {} != --gpus {}'.format(world, args.gpus)
+
+    import torch
+    import torch.distributed as dist
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-
-    import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if args.backend == 'nccl':
@@ -119,38 +361,23 @@ def main():
     from deeprob.spn.models import GaussianRatSpn
     from deeprob.parallel import ShardedLogLikelihood
 
-    D, B = 784, args.batch
+    D = 784
+    B = args.batch if args.scaling == 'weak' else max(1, args.batch // world)
     torch.manual_seed(0)  # identical replica on every rank
     model = GaussianRatSpn(D, rg_depth=2, rg_repetitions=8, rg_batch=args.rg_batch, rg_sum=args.rg_sum,
                            random_state=42).eval()
     cpu_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model.to(dev)
 
-    ring = args.ring or max(2, -(-(320 << 20) // (B * D * 4)))
+    ring = args.ring or max(4, -(-(768 << 20) // (B * D * 4)))
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)  # every rank its own shard of the batch
     xs = [torch.randn(B, D, device=dev, generator=gen) for _ in range(ring)]
 
     evaluator = ShardedLogLikelihood(model, group=dist.group.WORLD if world > 1 else None, static_inputs=True)
     time_kernel = not args.no_kernel_events
-    # HIP events straight from the runtime (hipEventCreate): (start, stop) pairs that dpk_profile_next_kernel
-    # records around the fused kernel on the stream it is launched on
-    hiprt = ctypes.CDLL('libamdhip64.so')
-    handles = []
+    timer = KernelTimer()
     n_spare = 64   # event pairs for the untimed steps
-    for _ in range(args.steps + n_spare if time_kernel else 0):
-        pair = []
-        for _k in range(2):
-            h = ctypes.c_void_p()
-            rc = hiprt.hipEventCreate(ctypes.byref(h))
-            assert rc == 0, 'hipEventCreate failed: {}'.format(rc)
-            pair.append(h.value)
-        handles.append(tuple(pair))
-
-    def elapsed_ms(pair):
-        ms = ctypes.c_float()
-        rc = hiprt.hipEventElapsedTime(ctypes.byref(ms), ctypes.c_void_p(pair[0]), ctypes.c_void_p(pair[1]))
-        assert rc == 0, 'hipEventElapsedTime failed: {}'.format(rc)
-        return ms.value
+    handles = [timer.pair() for _ in range(args.steps + n_spare)] if time_kernel else []
 
     stride = max(1, args.kernel_event_every)
     sampled = []
@@ -214,26 +441,37 @@ def main():
             'metric': 'log-likelihoods/sec, RAT-SPN D=784 batch=64k at 1/2/4/8 MI355X',
             'value': total / dt, 'unit': 'log-likelihoods/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'GaussianRatSpn(784, rg_depth=2, rg_repetitions=8, rg_batch={}, rg_sum={}) '
                                    'forward log-likelihood, {} samples per GPU per step, mean LL reduced on '
                                    'device{}'.format(args.rg_batch, args.rg_sum, B,
                                                      ' + RCCL all-reduce' if world > 1 else ''),
                        'global_batch': B * world, 'resident_batches': ring, 'mean_ll': mean_ll,
-                       'host_enqueue_ms_per_step': host_dt / args.steps * 1e3},
+                       'host_enqueue_ms_per_step': host_dt / args.steps * 1e3,
+                       'arithmetic': 'fp32 results; the leaf-layer GEMM runs as three f16 MFMAs on two-way f16 splits '
+                                     'of both operands with fp32 accumulation (>= 22 significant bits per product), '
+                                     'everything else fp32'},
         }
-        if time_kernel:
+        if time_kernel and sampled:
             torch.cuda.synchronize()
-            k_ms = sum(elapsed_ms(handles[i]) for i in sampled) / len(sampled)
+            k_ms = sum(timer.ms(handles[i]) for i in sampled) / len(sampled)
             alg_bytes = B * 4 * (D + model.out_classes)
             achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+            traffic, source = read_traffic()
             out['roofline'] = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                               'frac': achieved / HBM_PEAK_GBS, 'traffic': read_traffic(),
-                               'kernel': 'ratspn_leaf_kernel (fused RatSpn.forward)',
+                               'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic if B == 65536 else None,
+                               'traffic_source': source if B == 65536 else None,
+                               'kernel': 'ratspn_gemm_kernel (fused RatSpn.forward, leaf layer on MFMA)',
                                'kernel_ms': k_ms, 'kernel_event_samples': len(sampled),
                                'algorithmic_bytes_per_launch': alg_bytes}
+        threads = min(os.cpu_count() or 1, 32)
         if args.cpu_samples > 0 and world == 1:
-            out['cpu_baseline'] = cpu_baseline(cpu_state, D, args.cpu_samples)
+            out['cpu_baseline'], threads = cpu_baseline(cpu_state, D, args.cpu_samples)
+        if world == 1 and not args.no_secondary:
+            try:
+                out['secondary'] = secondary(dev, timer, threads, xs, model)
+            except Exception as ex:   # the headline line must survive a failure in a secondary configuration
+                out['secondary_error'] = '{}: {}'.format(type(ex).__name__, ex)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

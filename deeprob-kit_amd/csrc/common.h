@@ -9,7 +9,9 @@
 namespace dpk {
 
 void set_error(const char *fmt, ...);
-void profile_take(hipEvent_t *start, hipEvent_t *stop);  // one-shot measurement hook
+// one-shot measurement hook (dpk_profile_next_kernel[_of]): the events the caller wants recorded around the next launch
+// of the kernel with this id (DPK_KERNEL_* in deeprob_hip.h), or nulls
+void profile_take(hipEvent_t *start, hipEvent_t *stop, int kernel_id = 1);
 
 #define DPK_REQUIRE(cond, code, ...)       \
     do {                                   \

@@ -584,12 +584,20 @@ extern "C" int dpk_coupling1d_forward(const float *x, int64_t B, int32_t D, cons
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(coupling1d_kernel<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipEvent_t ev0, ev1;
+        profile_take(&ev0, &ev1, DPK_KERNEL_COUPLING1D);
+        if (ev0) (void)hipEventRecord(ev0, st);
         hipLaunchKernelGGL(coupling1d_kernel<true>, dim3(grid), dim3(kCWaves * 64), lds, st, a);
+        if (ev1) (void)hipEventRecord(ev1, st);
     } else {
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(coupling1d_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipEvent_t ev0, ev1;
+        profile_take(&ev0, &ev1, DPK_KERNEL_COUPLING1D);
+        if (ev0) (void)hipEventRecord(ev0, st);
         hipLaunchKernelGGL(coupling1d_kernel<false>, dim3(grid), dim3(kCWaves * 64), lds, st, a);
+        if (ev1) (void)hipEventRecord(ev1, st);
     }
     DPK_CHECK_LAUNCH("coupling1d_kernel");
     return DPK_OK;

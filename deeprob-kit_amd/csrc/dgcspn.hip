@@ -873,6 +873,9 @@ extern "C" int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C
     hipLaunchKernelGGL(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW, 256)), dim3(256), 0, st, weight,
                        Cout, C, OHW, Wl, LW);
     const int Bi = (int)B;
+    hipEvent_t pev0, pev1;
+    profile_take(&pev0, &pev1, DPK_KERNEL_SPATIAL_PRODSUM);
+    if (pev0) (void)hipEventRecord(pev0, st);
 #define DPK_PRODSUM(CMAX, NB)                                                                                      \
     hipLaunchKernelGGL((spatial_prodsum_fwd_kernel<CMAX, NB>), dim3(cdiv(OHW, 256), cdiv(Bi, NB)), dim3(256), 0, st, \
                        in, Wl, LW, Bi, q, Cout, out)
@@ -885,6 +888,7 @@ extern "C" int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C
     else
         DPK_PRODSUM(32, 1);
 #undef DPK_PRODSUM
+    if (pev1) (void)hipEventRecord(pev1, st);
     DPK_CHECK_LAUNCH("spatial_prodsum_fwd_kernel");
     return DPK_OK;
 }
@@ -1076,8 +1080,12 @@ extern "C" int dpk_spatial_sumprodroot_forward(const float *in, int64_t B, int32
     hipLaunchKernelGGL(rowwise_logsoftmax_kernel, dim3(K), dim3(256), 0, st, root_weight, K, Cout * OHW6, LWr);
     constexpr int kNB = 2;
     const int threads = (int)align_up(OHW6, 64);
+    hipEvent_t pev0, pev1;
+    profile_take(&pev0, &pev1, DPK_KERNEL_SPATIAL_SUMPRODROOT);
+    if (pev0) (void)hipEventRecord(pev0, st);
     hipLaunchKernelGGL((spatial_sumprodroot_fwd_kernel<8, kNB>), dim3(cdiv((int)B, kNB)), dim3(threads), 0, st, in, Wl,
                        LW, (int)B, q5, Cout, q6, LWr, K, out);
+    if (pev1) (void)hipEventRecord(pev1, st);
     DPK_CHECK_LAUNCH("spatial_sumprodroot_fwd_kernel");
     return DPK_OK;
 }

@@ -1461,7 +1461,7 @@ static int launch_leaf_gen(const LeafArgs &a, hipStream_t st) {
     }
 #endif
     hipEvent_t ev0, ev1;
-    profile_take(&ev0, &ev1);
+    profile_take(&ev0, &ev1, DEPTH > 0 ? DPK_KERNEL_RATSPN_FUSED : DPK_KERNEL_RATSPN_LEAF);
     if (ev0) (void)hipEventRecord(ev0, st);
     int gy = 1;
     if (DEPTH == 0) {

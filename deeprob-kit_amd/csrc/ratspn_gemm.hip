@@ -878,7 +878,7 @@ static int gemm_launch(const GemmArgs &a, int reps, hipStream_t st) {
     }
 #endif
     hipEvent_t ev0, ev1;
-    profile_take(&ev0, &ev1);
+    profile_take(&ev0, &ev1, DPK_KERNEL_RATSPN_FUSED);
     if (ev0) (void)hipEventRecord(ev0, st);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * kGemmWaves * 64), lds, st, a);
     if (ev1) (void)hipEventRecord(ev1, st);

@@ -13,7 +13,12 @@ void set_error(const char *fmt, ...) {
 }
 
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
-void profile_take(hipEvent_t *a, hipEvent_t *b) {
+static thread_local int g_ev_kernel = 0;
+void profile_take(hipEvent_t *a, hipEvent_t *b, int kernel_id) {
+    if (g_ev_kernel != 0 && g_ev_kernel != kernel_id) {
+        *a = *b = nullptr;
+        return;
+    }
     *a = g_ev_start;
     *b = g_ev_stop;
     g_ev_start = g_ev_stop = nullptr;
@@ -43,6 +48,13 @@ extern "C" int dpk_abi_version(void) { return 1; }
 extern "C" int dpk_profile_next_kernel(void *ev_start, void *ev_stop) {
     dpk::g_ev_start = (hipEvent_t)ev_start;
     dpk::g_ev_stop = (hipEvent_t)ev_stop;
+    dpk::g_ev_kernel = 0;
+    return DPK_OK;
+}
+extern "C" int dpk_profile_next_kernel_of(void *ev_start, void *ev_stop, int32_t kernel_id) {
+    dpk::g_ev_start = (hipEvent_t)ev_start;
+    dpk::g_ev_stop = (hipEvent_t)ev_stop;
+    dpk::g_ev_kernel = kernel_id;
     return DPK_OK;
 }
 

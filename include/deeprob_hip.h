@@ -346,6 +346,13 @@ int dpk_spatial_prodroot_forward(const float *in, int64_t B, int32_t C, int32_t 
  * forward kernel) is bracketed by hipEventRecord(ev_start) / hipEventRecord(ev_stop) on its stream,
  * so a harness can time that kernel alone inside a longer step.  One-shot; pass NULLs to cancel. */
 int dpk_profile_next_kernel(void *ev_start, void *ev_stop);
+/* The same for the next launch of ONE kernel family (a step of several kernels: time the dominant one). */
+#define DPK_KERNEL_RATSPN_FUSED 1        /* dpk_ratspn_forward (either route)                    */
+#define DPK_KERNEL_RATSPN_LEAF 2         /* dpk_gaussian_leaf_forward / dpk_bernoulli_leaf_forward */
+#define DPK_KERNEL_COUPLING1D 3          /* dpk_coupling1d_forward, fused kernel                 */
+#define DPK_KERNEL_SPATIAL_PRODSUM 4     /* dpk_spatial_prodsum_forward                          */
+#define DPK_KERNEL_SPATIAL_SUMPRODROOT 5 /* dpk_spatial_sumprodroot_forward                      */
+int dpk_profile_next_kernel_of(void *ev_start, void *ev_stop, int32_t kernel_id);
 
 /* sum and count of a vector of log-likelihoods in fp64 (the per-rank partial of
  * the mean-LL all-reduce): acc[0] += sum(ll), acc[1] += n.                   */
