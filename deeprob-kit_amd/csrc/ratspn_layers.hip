@@ -546,9 +546,11 @@ static int leaf_backward_common(int dist, const float *x, const float *g, int64_
     }
     if (gx && B > 0) {
         DPK_REQUIRE(dist == 0, DPK_EUNSUPPORTED, "leaf_backward: d/dx only for Gaussian leaves");
-        // regions per repetition: every repetition covers each variable exactly once, so
-        // regions_per_rep = (D + pad) / d
-        const int per_rep = (D + d - 1) / d;
+        // regions per repetition = 2^depth = (D + pad) / d with pad < 2^depth <= D (RegionGraph: depth <= log2 D), i.e.
+        // the smallest power of two p with p * d >= D -- NOT ceil(D / d), which is smaller whenever pad >= d
+        // (D = 9, depth 3: d = 2, 8 regions, ceil(9/2) = 5)
+        int per_rep = 1;
+        while ((int64_t)per_rep * d < D) per_rep *= 2;
         const int reps = R / per_rep;
         DPK_REQUIRE(reps * per_rep == R, DPK_EINVAL, "leaf_backward: R=%d is not reps*%d", R, per_rep);
         // the inverse table reuses the `par` segment (parameter tables are not needed here)

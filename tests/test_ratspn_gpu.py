@@ -512,3 +512,24 @@ def test_mfma_route_tables_follow_the_parameters(golden):
     assert torch.equal(p1, c)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     assert rel_err(p2.cpu().numpy(), orc.ratspn_forward(sd, x).numpy()) <= LL_TOL
+
+
+@pytest.mark.parametrize('D,depth,reps', [(9, 3, 5), (100, 6, 3), (15, 2, 3)])
+def test_input_gradient_with_heavily_padded_region_graphs(D, depth, reps):
+    """d/dx of the leaf layer when the padding is at least a region wide (pad >= d: 2^depth regions per repetition is
+    then more than ceil(D / d)) -- a RatSpn used as the base density of a flow, or gradients w.r.t. the evidence."""
+    from deeprob.spn.models import GaussianRatSpn
+    torch.manual_seed(3)
+    model = GaussianRatSpn(D, rg_depth=depth, rg_repetitions=reps, rg_batch=3, rg_sum=2, optimize_scale=True,
+                           random_state=7)
+    with torch.no_grad():
+        model.base_layer.scale.uniform_(0.6, 1.5)
+    x = torch.randn(37, D, generator=torch.Generator().manual_seed(1))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    xo = x.clone().double().requires_grad_(True)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    orc.ratspn_forward(sd64, xo).sum().backward()
+    model.cuda()
+    xg = x.cuda().requires_grad_(True)
+    model(xg).sum().backward()
+    assert grad_err(xg.grad.cpu().numpy(), xo.grad.numpy()) <= GRAD_TOL

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/profiles_$tag
 rm -rf $OUT; mkdir -p $OUT
 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err
-(cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- python $OLDPWD/bench.py --cpu-samples 0 > $OUT/trace_bench_line.json 2>/dev/null)
+(cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- python $OLDPWD/bench.py --cpu-samples 0 --no-secondary > $OUT/trace_bench_line.json 2>/dev/null)
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 python - "$f" > $OUT/kernel_stats_summary.txt <<'PY'
 import csv, sys

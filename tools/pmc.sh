@@ -7,14 +7,14 @@ OUT=$PWD/gpurun_out/pmc
 mkdir -p $OUT
 run() {
   name=$1; shift
-  (cd /tmp && timeout -k 10 300 rocprofv3 --pmc "$@" -d $OUT/$name -o $name --output-format csv -- python $OLDPWD/bench.py --steps 20 --warmup 3 --cpu-samples 0 --no-kernel-events > /dev/null 2>$OUT/$name.err)
+  (cd /tmp && timeout -k 10 300 rocprofv3 --pmc "$@" -d $OUT/$name -o $name --output-format csv -- python $OLDPWD/bench.py --steps 20 --warmup 3 --cpu-samples 0 --no-kernel-events --no-secondary > /dev/null 2>$OUT/$name.err)
   f=$(find $OUT/$name -name "*counter_collection.csv" | head -1)
   python - "$f" <<'PY'
-import csv, sys, collections
+import csv, sys, collections, os
 f = sys.argv[1]
 acc = collections.defaultdict(lambda: [0.0, 0])
 for row in csv.DictReader(open(f)):
-    if 'ratspn_leaf_kernel' not in row['Kernel_Name']:
+    if os.environ.get('KERN', 'ratspn_gemm_kernel') not in row['Kernel_Name']:
         continue
     acc[row['Counter_Name']][0] += float(row['Counter_Value']); acc[row['Counter_Name']][1] += 1
 for k, (v, n) in sorted(acc.items()):
