@@ -75,6 +75,7 @@ struct RatWs {
     float *gbias;      // [NCH][2][NT][16] per-(chunk, column) constants in the accumulator order of a lane
     float *gbias_row;  // [2][NT][16] the sums over all chunks
     int *gelig;        // [NT*RPT] 1: repetition is unit-scale with bounded means
+    void *lg;          // tables of the leaf-only MFMA kernel (leaf_gemm_ws_bytes), null when the shape is outside it
     int g_nt, g_nksp;  // column tiles of 32, K-steps of 16 features (padded to whole chunks); 0 = not built
     int64_t bytes;
     int NC, SP, G, QB;
@@ -87,6 +88,22 @@ constexpr int kGemmMaxNT = 4;             // column tiles of 32 the fused kernel
 static inline bool gemm_shape_ok(int D, int depth, int reps, int I, int S) {
     if (depth != 2 || !(I == 2 || I == 4) || !(S == 2 || S == 4) || (D % 4) != 0 || reps < 1) return false;
     return (reps * 4 * I + 31) / 32 <= kGemmMaxNT;
+}
+
+// geometry of the leaf-only MFMA kernel (ratspn_leaf_gemm.hip): column groups of NTG tiles, chunks of 32 features
+constexpr int kLeafGemmKS = 2;
+static inline int leaf_ntg(int I) { return I >= 4 ? 4 : I; }
+static inline bool leaf_gemm_shape_ok(int D, int R, int I, int d) {
+    if (!(I == 2 || I == 4 || I == 8 || I == 16) || (D % 4) != 0 || R < 1 || d < 1) return false;
+    return (D + 16 * kLeafGemmKS - 1) / (16 * kLeafGemmKS) <= 64;   // chunk bit masks of the kernel
+}
+static inline int64_t leaf_gemm_ws_bytes(int D, int R, int I) {
+    const int NTG = leaf_ntg(I), NG = (int)(((int64_t)R * I + 32 * NTG - 1) / (32 * NTG));
+    const int NCH = (D + 16 * kLeafGemmKS - 1) / (16 * kLeafGemmKS), NKSP = NCH * kLeafGemmKS;
+    const int64_t tab = align_up((int64_t)NG * NKSP * (2 * NTG + 2) * 1024, 256);
+    const int64_t bias = align_up((int64_t)NG * NCH * 2 * NTG * 16 * 4, 256);
+    const int64_t brow = align_up((int64_t)NG * 2 * NTG * 16 * 4, 256);
+    return 2 * tab + bias + brow + align_up((int64_t)R * 4, 256);
 }
 
 // region-group size used by the per-layer leaf operators (the fused model uses 2^depth)
@@ -161,6 +178,8 @@ inline RatWs carve_ratspn_ws(void *base, int D, int R, int d, int I, int QB, int
         w.gbias_row = (float *)take((int64_t)2 * w.g_nt * 16 * 4);
         w.gelig = (int *)take((int64_t)w.g_nt * 8 * 4);
     }
+    w.lg = nullptr;
+    if (leaf_gemm_shape_ok(D, R, I, d)) w.lg = take(leaf_gemm_ws_bytes(D, R, I));
     w.bytes = o;
     return w;
 }

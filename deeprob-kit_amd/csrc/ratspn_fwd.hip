@@ -1523,6 +1523,22 @@ static int leaf_forward_dispatch(const LeafArgs &a, hipStream_t st) {
     return q4 ? launch_leaf<DIST, 4, 1, 2, 0, 1>(a, st) : launch_leaf<DIST, 2, 1, 2, 0, 1>(a, st);
 }
 
+// ratspn_leaf_gemm.hip: the leaf layer alone on the matrix cores
+int ratspn_leaf_gemm_forward(void *ws, const float *x, int64_t B, int D, const int64_t *mask, const uint8_t *pad,
+                             const float *loc, const float *scale, int R, int I, int d, float *out, uint32_t flags,
+                             hipStream_t st);
+static bool mfma_enabled() {
+    static const bool enabled = [] {
+        const char *e = getenv("DPK_RATSPN_GEMM");
+        return !(e && e[0] == '0');
+    }();
+    return enabled;
+}
+static bool leaf_gemm_route(int dist, const float *x, const float *out, int D, int R, int I, int d, uint32_t flags) {
+    return mfma_enabled() && dist == 0 && (flags & DPK_FLAG_UNIT_SCALE) != 0 && leaf_gemm_shape_ok(D, R, I, d) &&
+           (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+}
+
 static int leaf_forward_common(int dist, const float *x, int64_t B, int32_t D, const int64_t *mask,
                                const uint8_t *pad_mask, const float *p0, const float *p1, int32_t R,
                                int32_t I, int32_t d, float *out, void *ws, int64_t ws_bytes,
@@ -1535,6 +1551,12 @@ static int leaf_forward_common(int dist, const float *x, int64_t B, int32_t D, c
     DPK_REQUIRE(ws_bytes >= w.bytes, DPK_EWORKSPACE, "leaf_forward: workspace %lld < %lld",
                 (long long)ws_bytes, (long long)w.bytes);
     hipStream_t st = (hipStream_t)stream;
+    if (leaf_gemm_route(dist, x, out, D, R, I, d, flags) && w.lg != nullptr) {
+        // (the structure tables of the VALU route stay current: a later call with the cached structure may take it)
+        int rc = prepare_leaf_structure(w, mask, pad_mask, R, d, flags, st);
+        if (rc) return rc;
+        return ratspn_leaf_gemm_forward(w.lg, x, B, D, mask, pad_mask, p0, p1, R, I, d, out, flags, st);
+    }
     int rc = prepare_leaf_tables(dist, w, mask, pad_mask, p0, p1, R, I, channel_block(I), d, flags, st);
     if (rc) return rc;
     LeafArgs a{};
@@ -1594,11 +1616,7 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
 // the caller hints unit scales (checked on the device), the rows of x are 16-byte aligned (LDS-DMA) and the leaf
 // outputs are not wanted.  DPK_RATSPN_GEMM=0 in the environment keeps the VALU kernels (A/B measurements).
 static bool gemm_route(const float *x, int D, int depth, int reps, int I, int S, int C, bool want_leaf, uint32_t flags) {
-    static const bool enabled = [] {
-        const char *e = getenv("DPK_RATSPN_GEMM");
-        return !(e && e[0] == '0');
-    }();
-    return enabled && !want_leaf && (flags & DPK_FLAG_UNIT_SCALE) != 0 && gemm_shape_ok(D, depth, reps, I, S) &&
+    return mfma_enabled() && !want_leaf && (flags & DPK_FLAG_UNIT_SCALE) != 0 && gemm_shape_ok(D, depth, reps, I, S) &&
            C <= 64 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
 }
 
@@ -1609,6 +1627,11 @@ using namespace dpk;
 extern "C" int dpk_ratspn_forward_on_mfma(const float *x, int32_t D, int32_t depth, int32_t reps, int32_t I,
                                           int32_t S, int32_t C, int32_t want_leaf_out, uint32_t flags) {
     return gemm_route(x, D, depth, reps, I, S, C, want_leaf_out != 0, flags) ? 1 : 0;
+}
+
+extern "C" int dpk_gaussian_leaf_forward_on_mfma(const float *x, const float *out, int32_t D, int32_t R, int32_t I,
+                                                 int32_t d, uint32_t flags) {
+    return leaf_gemm_route(0, x, out, D, R, I, d, flags) ? 1 : 0;
 }
 
 extern "C" int64_t dpk_ratspn_workspace_bytes(int32_t in_features, int32_t regions, int32_t dimension,

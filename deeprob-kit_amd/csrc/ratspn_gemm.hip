@@ -38,30 +38,11 @@
 // root.  Work-groups are persistent (grid = min(tiles, CUs)); the DMA ring runs across tile boundaries.
 #include "common.h"
 #include "ratspn_nodes.h"
+#include "ratspn_gemm_common.h"
 #include <math.h>
 #include <stdlib.h>
 
 namespace dpk {
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef _Float16 half2 __attribute__((ext_vector_type(2)));
-typedef float gf32x2 __attribute__((ext_vector_type(2)));
-typedef float gf32x4 __attribute__((ext_vector_type(4)));
-typedef float gf32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int kGemmWaves = 4;
-constexpr int kGemmTile = 32 * kGemmWaves;           // samples per work-group tile
-constexpr int kGemmStages = 3;
-typedef __attribute__((address_space(3))) float lfloat;
-typedef __attribute__((address_space(3))) char lchar;
-typedef const __attribute__((address_space(1))) char *gcchar_p;
-typedef const __attribute__((address_space(1))) void *gvoid_p;
-// K-steps of 16 features per staged chunk: 64-feature chunks (256-byte row segments) while the mean table of a
-// chunk fits beside them, 32-feature chunks for wide column sets
-__host__ __device__ constexpr int gemm_ks(int NT) { return NT <= 2 ? 4 : 2; }
-constexpr float kGemmStepBound = 1.0e6f;             // a K-step whose 8 squares sum above this is examined
-constexpr float kGemmAbsBound = 1.0e3f;              // |x| above this: exact evaluation of the wave
 
 // ------------------------------------------------------------------------------------------------
 // tables, rebuilt from the live parameters: one block per repetition (+ the softmax rows behind them)
@@ -79,10 +60,6 @@ struct GemmPrepArgs {
     int rows[3], n[3];
 };
 
-__device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
-    hi = (_Float16)v;
-    lo = (_Float16)(v - (float)hi);
-}
 
 template <int I>
 __global__ __launch_bounds__(256) void ratspn_gemm_prep_kernel(const GemmPrepArgs a) {
@@ -253,9 +230,6 @@ __device__ __forceinline__ void lse_merge(float &m, float &s, float m2, float s2
     m = mm;
 }
 
-__device__ __forceinline__ void gemm_lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 
 // ---- exp-domain helpers of the fast upper layers ---------------------------------------------------------------
 // e[i] = 2^((x[i] - max) log2 e); returns max (0 for an all -inf input, whose exponentials are then 0)
@@ -355,43 +329,6 @@ __device__ __noinline__ void gemm_exact_wave(const GemmArgs &a, int64_t bw0, int
 #define GEMM_STAMP(row, slot) do { } while (0)
 #endif
 
-// One LDS-DMA instruction: LDS[lds_dst + lane*16 .. +15] <- global[sbase + voff .. +15].  Issued as inline asm so that
-// hipcc neither counts it (the ring below is ordered by hand-counted vmcnt + s_barrier) nor drains it with a
-// vmcnt(0) in front of an unrelated load; M0 (the DMA's LDS base) is compiler-reserved, hence saved and restored.
-// The leading s_nop covers the SALU-write -> VMEM-read hazard of a freshly computed base (cdna_hip_programming 5.7).
-__device__ __forceinline__ void glds16(unsigned voff, gcchar_p sbase_in, unsigned lds_dst_in) {
-    // (readfirstlane: a no-op for values hipcc already holds in SGPRs, a guarantee where it has moved them to VGPRs)
-    const uint64_t sb = (uint64_t)(uintptr_t)sbase_in;
-    const uint64_t sbase = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sb >> 32)) << 32) |
-                           (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sb);
-    const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst_in);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_dst)
-                 : "memory");
-}
-
-// x (8 values of one sample) -> f16 halves xh + xl = x to 2^-22: xh = rn16(x), xl = rn16(x - xh)
-__device__ __forceinline__ void split8(const float (&v)[8], half8 &xh, half8 &xl) {
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 hp, lp;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        unsigned h2, l2;
-        float b0, b1;
-        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h2) : "v"(v[2 * p]), "v"(v[2 * p + 1]));
-        asm("v_cvt_f32_f16_e32 %0, %1" : "=v"(b0) : "v"(h2));
-        asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(b1) : "v"(h2));
-        const float d0 = v[2 * p] - b0, d1 = v[2 * p + 1] - b1;
-        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l2) : "v"(d0), "v"(d1));
-        hp[p] = h2;
-        lp[p] = l2;
-    }
-    xh = __builtin_bit_cast(half8, hp);
-    xl = __builtin_bit_cast(half8, lp);
-}
-
 template <int I, int S, int NT>
 __global__ __launch_bounds__(2 * kGemmWaves * 64) void ratspn_gemm_kernel(const GemmArgs a) {
     constexpr int RPT = 8 / I;                           // repetitions per column tile
@@ -444,62 +381,8 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void ratspn_gemm_kernel(const 
     int red_n = 0;
     bool saw_nan_any = false;
     if (loader) {
-        const gcchar_p mtab_b = (gcchar_p)a.mtab;
-        const unsigned smem_base = (unsigned)(uintptr_t)smem;
-        // per-lane source offsets of the x pieces this lane copies (full tile, full chunk), in bytes from the
-        // tile's first row + the chunk's first feature
-        unsigned voff[PX];
-#pragma unroll
-        for (int j = 0; j < PX; ++j) {
-            const int rl = wave * 32 + j * RPI + lane / W;
-            const int gp = (lane & (W - 1)) ^ ((rl >> SWS) & (W - 1));
-            voff[j] = (unsigned)(rl * D + gp * 4) * 4u;
-        }
-        const unsigned toff = (unsigned)(wave * (PB * 1024) + lane * 16);
-        int ptile = (int)blockIdx.x, pc = 0, pstage = 0;   // next chunk to stage
-        auto issue_next = [&]() {
-            const int64_t b0 = (int64_t)ptile * kGemmTile;
-            const gcchar_p xt = (gcchar_p)a.x + (b0 * D + pc * KC) * 4;
-            const gcchar_p tsrc = mtab_b + (int64_t)pc * BB;
-            const unsigned st = smem_base + pstage * STAGE;
-            const bool full = (b0 + kGemmTile <= a.B) && ((pc + 1) * KC <= D);
-            if (full) {
-#pragma unroll
-                for (int j = 0; j < PX; ++j) glds16(voff[j], xt, st + (wave * 32 + j * RPI) * ROWB);
-            } else {   // ragged tile / last chunk: clamp to rows and pieces that exist (clamped slots are never consumed)
-                const int nvalid = (int)min((int64_t)kGemmTile, a.B - b0);
-                const int vp = min(W, (D - pc * KC) >> 2);
-#pragma unroll
-                for (int j = 0; j < PX; ++j) {
-                    const int rl = wave * 32 + j * RPI + lane / W;
-                    const int gp = min((lane & (W - 1)) ^ ((rl >> SWS) & (W - 1)), vp - 1);
-                    glds16((unsigned)(min(rl, nvalid - 1) * D + gp * 4) * 4u, xt, st + (wave * 32 + j * RPI) * ROWB);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < PB; ++j) glds16(toff + j * 1024, tsrc, st + XB + wave * (PB * 1024) + j * 1024);
-            pstage = (pstage + 1 == NS) ? 0 : pstage + 1;
-            if (++pc == NCH) {
-                pc = 0;
-                ptile += grid;
-            }
-        };
-#pragma unroll
-        for (int g = 0; g < NS - 1; ++g)
-            if (ptile < ntiles) issue_next();
-        __syncthreads();   // (the compute waves fill the constants meanwhile; hipcc does not count the asm DMAs)
-        for (int tile = (int)blockIdx.x; tile < ntiles; tile += grid) {
-            for (int c = 0; c < NCH; ++c) {
-                // chunk (tile, c) has landed once at most one later chunk is still in flight (none exists at the very end)
-                if (c + 1 < NCH || tile + grid < ntiles) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                gemm_lds_barrier();   // this chunk is in LDS for everyone; everyone is done reading the previous one
-                if (ptile < ntiles) issue_next();
-            }
-        }
+        gemm_loader_run<KS, PB>(a.x, a.B, D, NCH, ntiles, (int)blockIdx.x, grid, (gcchar_p)a.mtab, BB, wave * PB,
+                                (unsigned)(uintptr_t)smem, STAGE, wave, lane);
     } else {
     // ================================================ compute waves =========================================
     // constants into LDS

@@ -29,6 +29,7 @@ SIGNATURES = {
     'dpk_last_error': (ctypes.c_char_p, []),
     'dpk_abi_version': (ctypes.c_int, []),
     'dpk_ratspn_workspace_bytes': (_i64, [_i32] * 8),
+    'dpk_gaussian_leaf_forward_on_mfma': (ctypes.c_int, [_c_void, _c_void, _i32, _i32, _i32, _i32, _u32]),
     'dpk_gaussian_leaf_forward': (ctypes.c_int, [_c_void, _i64, _i32, _c_void, _c_void, _c_void, _c_void,
                                                  _i32, _i32, _i32, _c_void, _c_void, _i64, _u32, _c_void]),
     'dpk_bernoulli_leaf_forward': (ctypes.c_int, [_c_void, _i64, _i32, _c_void, _c_void, _c_void,

@@ -75,6 +75,14 @@ class GaussianLeafFn(torch.autograd.Function):
         out = torch.empty((B, lctx.R, lctx.I), dtype=torch.float32, device=x.device)
         pad = _pad_u8(pad_mask)
         ws, flags = lctx.workspace(x.device, mask, pad_mask, scale)
+        if lib.dpk_gaussian_leaf_forward_on_mfma(ptr(x), ptr(out), lctx.D, lctx.R, lctx.I, lctx.d, flags):
+            # MFMA route: its parameter tables survive between calls while loc / scale are unchanged
+            key = (_buffers_key(loc_c, scale_c), lctx.ws.struct_key)
+            if lctx.ws.params_key == key and (flags & DPK_FLAG_STRUCT_CACHED):
+                flags |= DPK_FLAG_PARAMS_CACHED
+            lctx.ws.params_key = key
+        else:
+            lctx.ws.params_key = None
         check(lib.dpk_gaussian_leaf_forward(ptr(x), B, lctx.D, ptr(mask), ptr(pad), ptr(loc_c), ptr(scale_c),
                                             lctx.R, lctx.I, lctx.d, ptr(out), ptr(ws), ws.numel(), flags,
                                             stream_ptr(x.device)), 'dpk_gaussian_leaf_forward')

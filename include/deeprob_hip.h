@@ -71,6 +71,10 @@ int64_t dpk_ratspn_workspace_bytes(int32_t in_features, int32_t regions, int32_t
  *   pad_mask [R, d] uint8  1 = dummy variable (buffer `pad_mask`, may be NULL)
  *   loc,scale[R, I, d]
  *   out      [B, R, I]     sum_j nan_to_num(Normal(loc,scale).log_prob(x[:,mask]))   */
+/* 1 when dpk_gaussian_leaf_forward with these arguments runs on the matrix cores (unit-scale hint, channels in
+ * {2,4,8,16}, 16-byte aligned x rows and out): DPK_FLAG_PARAMS_CACHED is honoured there as in dpk_ratspn_forward. */
+int dpk_gaussian_leaf_forward_on_mfma(const float *x, const float *out, int32_t D, int32_t R, int32_t I, int32_t d,
+                                      uint32_t flags);
 int dpk_gaussian_leaf_forward(const float *x, int64_t B, int32_t D, const int64_t *mask,
                               const uint8_t *pad_mask, const float *loc, const float *scale,
                               int32_t R, int32_t I, int32_t d, float *out, void *ws,
