@@ -1,0 +1,532 @@
+// RealNVP-1D coupling with the reference's alternating masks (coupling.py:58-60: mask = arange(D) % 2, swapped
+// for every other layer), depth-1 conditioner, on the f16 matrix cores with fp32-grade products.
+//
+// reference: CouplingLayer1d.apply_backward / apply_forward, deeprob/flows/layers/coupling.py:72-104
+//
+//   z = W2 relu(W1 (mask*x) + b1) + b2 ;  t, s = chunk(z) ; s = a tanh(s) ; t, s *= inv_mask
+//   density direction:  u = (x - t) exp(-s),  ildj = -sum_d s ;   sampling direction:  x = u exp(s) + t
+//
+// Both GEMMs run on v_mfma_f32_32x32x16_f16 with every operand split in two f16 halves (v = vh + vl, 11 + 11
+// significant bits; a b ~= ah bh + ah bl + al bh, fp32 accumulation): the product keeps >= 22 bits -- the
+// accuracy class of the fp32 MFMA this replaces (coupling.hip, still used for other masks) -- at 3/16 of its cost,
+// which turns the layer from matrix-core-bound (0.40 of the fp32 MFMA peak, 311 us per 65536 x 784 layer) into a
+// stream of x, out and the L2-resident weight tables.
+//
+// Mapping (as ratspn_gemm.hip: 4 compute waves + 4 loader waves, 3-stage LDS ring, one s_barrier per chunk):
+//  * a work-group owns 128 samples, a compute wave 32 of them and ALL hidden units: GEMM 1 is computed transposed,
+//    H^T = W1m X^T, so lane (sample s = l & 31, half h = l >> 5) ends up holding 16 of every 32 hidden units of its
+//    own sample.  The K order of an MFMA is free as long as both operands agree, so those accumulator registers ARE
+//    the B fragments of GEMM 2 (Z^T = W2 H^T) once bias + ReLU + split are applied: the hidden activations never
+//    leave the registers, the W2 fragments are packed in that unit order.
+//  * phase 1 chunks: 64 raw columns of x (the 32 masked ones feed the MFMAs) + the matching W1 fragments (16 KB);
+//    phase 2 chunks: the W2 fragments of 32 transformed variables (t and s rows, hi and lo: 32 KB) + their biases
+//    and the folded input affine.  Lane (s, h) then holds t and s of 16 of those 32 variables for its sample,
+//    reads the (pass-through, transformed) column pairs as 32-byte runs, applies the epilogue and writes the pairs.
+//  * an eval-mode BatchNormLayer1d in front (in_scale / in_shift) is folded into W1 / b1 when the tables are packed
+//    and applied to the pairs in the epilogue.
+#include "common.h"
+#include "ratspn_gemm_common.h"
+#include <math.h>
+
+namespace dpk {
+
+constexpr int kX3Tile = kGemmTile;     // 128 samples per work-group
+constexpr int kX3XB = kX3Tile * 256;   // x chunk: 64 raw columns per row
+
+struct X3Geom {
+    int NU, NCH1, NPT, K1, N2, W1CH, W2CH;   // hidden tiles, phase-1 / phase-2 chunks, table chunk bytes
+};
+static inline X3Geom x3_geom(int D, int U) {
+    X3Geom g{};
+    g.NU = U / 32;
+    g.K1 = D / 2;
+    g.N2 = D / 2;
+    g.NCH1 = cdiv(D, 64);
+    g.NPT = cdiv(g.N2, 32);
+    g.W1CH = 2 * g.NU * 2 * 1024;                                 // 2 K-steps x NU tiles x (hi, lo) KiB
+    g.W2CH = (int)align_up((int64_t)(U / 16) * 4 * 1024 + 1024, 4096);  // K-steps x (t,s) x (hi,lo) KiB + extras
+    return g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tables
+// ------------------------------------------------------------------------------------------------
+struct X3PackArgs {
+    const float *W1, *b1, *W2, *b2, *in_scale, *in_shift;
+    int D, U, pm;        // pm: parity of the masked (conditioning) columns; the transformed ones are 1 - pm
+    int affine;
+    X3Geom g;
+    uint16_t *w1t;       // [NCH1][2][NU][2][512]
+    char *w2t;           // [NPT][W2CH bytes]
+    float *b1f;          // [U] b1 + W1 (mask * in_shift)
+};
+
+__global__ __launch_bounds__(256) void coupling_x3_pack_kernel(const X3PackArgs a) {
+    const int D = a.D, U = a.U, NU = a.g.NU, K1 = a.g.K1, N2 = a.g.N2;
+    const int64_t n1 = (int64_t)a.g.NCH1 * 2 * NU * 64;           // W1 fragment entries (hi + lo written together)
+    const int64_t n2 = (int64_t)a.g.NPT * (U / 16) * 2 * 64;      // W2 fragment entries
+    const int64_t n3 = (int64_t)a.g.NPT * 32;                     // per-variable extras
+    const int64_t total = n1 + n2 + n3 + U;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        if (e < n1) {
+            const int l = (int)(e & 63);
+            const int64_t r = e >> 6;
+            const int T = (int)(r % NU), ksg = (int)(r / NU);      // ksg = 2 * chunk + k-step in chunk
+            const int unit = 32 * T + (l & 31), hg = l >> 5;
+            half8 vh, vl;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = 16 * ksg + 8 * hg + i, col = 2 * m + a.pm;
+                float v = 0.f;
+                if (m < K1 && col < D) {
+                    v = a.W1[(int64_t)unit * D + col];
+                    if (a.in_scale) v *= a.in_scale[col];
+                }
+                _Float16 hi, lo;
+                split_f16(v, hi, lo);
+                vh[i] = hi; vl[i] = lo;
+            }
+            uint16_t *o = a.w1t + ((int64_t)ksg * NU + T) * 1024 + l * 8;
+            *reinterpret_cast<half8 *>(o) = vh;
+            *reinterpret_cast<half8 *>(o + 512) = vl;
+        } else if (e < n1 + n2) {
+            const int64_t f = e - n1;
+            const int l = (int)(f & 63);
+            const int64_t r = f >> 6;
+            const int ts = (int)(r & 1), kk = (int)((r >> 1) % (U / 16)), pt = (int)((r >> 1) / (U / 16));
+            const int n = 32 * pt + (l & 31), hg = l >> 5;
+            const int var = 2 * n + (1 - a.pm);
+            half8 vh, vl;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                // K slot (kk, hg, i) <-> the hidden unit a lane of GEMM 1 holds in accumulator register 8*(kk&1) + i
+                const int reg = 8 * (kk & 1) + i;
+                const int unit = 32 * (kk >> 1) + (reg & 3) + 8 * (reg >> 2) + 4 * hg;
+                float v = 0.f;
+                if (n < N2 && (ts == 0 || a.affine)) v = a.W2[((int64_t)ts * D + var) * U + unit];
+                _Float16 hi, lo;
+                split_f16(v, hi, lo);
+                vh[i] = hi; vl[i] = lo;
+            }
+            uint16_t *o = reinterpret_cast<uint16_t *>(a.w2t + (int64_t)pt * a.g.W2CH) + ((int64_t)kk * 2 + ts) * 1024 + l * 8;
+            *reinterpret_cast<half8 *>(o) = vh;
+            *reinterpret_cast<half8 *>(o + 512) = vl;
+        } else if (e < n1 + n2 + n3) {
+            const int64_t f = e - n1 - n2;
+            const int pt = (int)(f >> 5), j = (int)(f & 31);
+            const int n = 32 * pt + j, var = 2 * n + (1 - a.pm), par = var ^ 1;
+            float *x = reinterpret_cast<float *>(a.w2t + (int64_t)pt * a.g.W2CH + (int64_t)(U / 16) * 4096);
+            const bool ok = n < N2;
+            x[j] = ok ? a.b2[var] : 0.f;
+            x[32 + j] = (ok && a.affine) ? a.b2[D + var] : 0.f;
+            x[64 + j] = (ok && a.in_scale) ? a.in_scale[var] : 1.f;
+            x[96 + j] = (ok && a.in_shift) ? a.in_shift[var] : 0.f;
+            x[128 + j] = (ok && a.in_scale) ? a.in_scale[par] : 1.f;
+            x[160 + j] = (ok && a.in_shift) ? a.in_shift[par] : 0.f;
+        } else {
+            const int unit = (int)(e - n1 - n2 - n3);
+            float v = a.b1[unit];
+            if (a.in_shift)
+                for (int m = 0; m < K1; ++m) {
+                    const int col = 2 * m + a.pm;
+                    v = fmaf(a.W1[(int64_t)unit * D + col], a.in_shift[col], v);
+                }
+            a.b1f[unit] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// main kernel
+// ------------------------------------------------------------------------------------------------
+struct X3Args {
+    const float *x;
+    float *out, *ldj;
+    int64_t B;
+    int D, U, pm, inverse, accumulate, ntiles;
+    X3Geom g;
+    const uint16_t *w1t;
+    const char *w2t;
+    const float *b1f, *act_weight;
+};
+
+__device__ __forceinline__ float x3_tanh(float v) {
+    // tanh(v) = (e^{2v} - 1) / (e^{2v} + 1) on the hardware exp2 / rcp (absolute error ~1e-7, as coupling.hip)
+    const float c = fminf(fmaxf(v, -15.f), 15.f);
+    const float t = __builtin_amdgcn_exp2f(c * 2.8853900817779268f);
+    return (t - 1.f) * __builtin_amdgcn_rcpf(t + 1.f);
+}
+
+template <bool AFFINE, int NU>
+__global__ __launch_bounds__(2 * kGemmWaves * 64) void coupling_x3_kernel(const X3Args a) {
+    constexpr int W1CH = 2 * NU * 2 * 1024;
+    constexpr int KK = NU * 2;                                   // K-steps of GEMM 2 (16 hidden units each)
+    constexpr int W2CH = ((KK * 4 * 1024 + 1024 + 4095) / 4096) * 4096;
+    constexpr int STAGE = (kX3XB + W1CH) > W2CH ? (kX3XB + W1CH) : W2CH;
+    constexpr int P1 = 8 + W1CH / (4 * 1024);                    // DMA instructions per loader wave: phase-1 chunk
+    constexpr int P2 = W2CH / (4 * 1024);                        //                                   phase-2 chunk
+    static_assert(W1CH % 4096 == 0 && P1 <= 63 && P2 <= 63, "chunk split");
+    typedef __attribute__((address_space(3))) const gf32x4 lf4;
+    typedef __attribute__((address_space(3))) const half8 lh8;
+    typedef const __attribute__((address_space(1))) gf32x4 gf4;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_generic[];
+    lchar *smem = (lchar *)smem_generic;
+    lfloat *b1_l = (lfloat *)(smem + kGemmStages * STAGE);       // [U]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave8 >= kGemmWaves;
+    const int wave = wave8 & (kGemmWaves - 1);
+    const int s = lane & 31, h = lane >> 5;
+    const int D = a.D, NCH1 = a.g.NCH1, NPT = a.g.NPT;
+    const int grid = (int)gridDim.x, ntiles = a.ntiles;
+    const int nchunks = NCH1 + NPT;
+
+    if (loader) {
+        const unsigned smem_base = (unsigned)(uintptr_t)smem;
+        unsigned voff[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int rl = wave * 32 + j * 4 + (lane >> 4);
+            const int gp = (lane & 15) ^ (rl & 15);
+            voff[j] = (unsigned)(rl * D + gp * 4) * 4u;
+        }
+        int ptile = (int)blockIdx.x, pc = 0, pstage = 0;
+        auto issue_next = [&]() {
+            const unsigned st = smem_base + pstage * STAGE;
+            if (pc < NCH1) {
+                const int64_t b0 = (int64_t)ptile * kX3Tile;
+                const gcchar_p xt = (gcchar_p)a.x + (b0 * D + pc * 64) * 4;
+                const bool full = (b0 + kX3Tile <= a.B) && ((pc + 1) * 64 <= D);
+                if (full) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) glds16(voff[j], xt, st + (wave * 32 + j * 4) * 256);
+                } else {
+                    const int nvalid = (int)min((int64_t)kX3Tile, a.B - b0);
+                    const int vp = min(16, (D - pc * 64) >> 2);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int rl = wave * 32 + j * 4 + (lane >> 4);
+                        const int gp = min((lane & 15) ^ (rl & 15), vp - 1);
+                        glds16((unsigned)(min(rl, nvalid - 1) * D + gp * 4) * 4u, xt, st + (wave * 32 + j * 4) * 256);
+                    }
+                }
+                const gcchar_p tsrc = (gcchar_p)a.w1t + (int64_t)pc * W1CH;
+                const unsigned t0 = (unsigned)(wave * (W1CH / 4));
+#pragma unroll
+                for (int j = 0; j < W1CH / 4096; ++j)
+                    glds16(t0 + j * 1024 + lane * 16, tsrc, st + kX3XB + t0 + j * 1024);
+            } else {
+                const gcchar_p tsrc = (gcchar_p)a.w2t + (int64_t)(pc - NCH1) * W2CH;
+                const unsigned t0 = (unsigned)(wave * (W2CH / 4));
+#pragma unroll
+                for (int j = 0; j < P2; ++j) glds16(t0 + j * 1024 + lane * 16, tsrc, st + t0 + j * 1024);
+            }
+            pstage = (pstage + 1 == kGemmStages) ? 0 : pstage + 1;
+            if (++pc == nchunks) {
+                pc = 0;
+                ptile += grid;
+            }
+        };
+#pragma unroll
+        for (int g = 0; g < kGemmStages - 1; ++g)
+            if (ptile < ntiles) issue_next();
+        __syncthreads();
+        for (int tile = (int)blockIdx.x; tile < ntiles; tile += grid) {
+            for (int c = 0; c < nchunks; ++c) {
+                // chunk c has landed once only the chunk issued after it (if any) is still in flight
+                const bool last = (c + 1 == nchunks) && !(tile + grid < ntiles);
+                if (last) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else if ((c + 1) % nchunks < NCH1) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P1) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P2) : "memory");
+                }
+                gemm_lds_barrier();
+                if (ptile < ntiles) issue_next();
+            }
+        }
+        return;
+    }
+    // ================================================ compute waves =========================================
+    for (int e = tid; e < a.U; e += kGemmWaves * 64) b1_l[e] = a.b1f[e];
+    const float act = AFFINE ? a.act_weight[0] : 0.f;
+    __syncthreads();
+
+    const int rl_own = wave * 32 + s;
+    const int sw = rl_own & 15;
+    // LDS byte offsets of the lane's 16 raw columns of each of the chunk's two K-steps (4 pieces of 16 bytes each)
+    unsigned xoff[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xoff[j][q] = (unsigned)(rl_own * 256 + (((8 * j + 4 * h + q) ^ sw) << 4));
+    const unsigned foff = (unsigned)(lane * 16);
+    const int pm = a.pm;
+
+    int cstage = 0;
+    for (int tile = (int)blockIdx.x; tile < ntiles; tile += grid) {
+        gf32x16 acc[NU];
+#pragma unroll
+        for (int T = 0; T < NU; ++T)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[T][i] = 0.f;
+        // ---- phase 1: H^T = W1m X^T ----------------------------------------------------------------------
+        for (int c = 0; c < NCH1; ++c) {
+            gemm_lds_barrier();
+            const lchar *st = smem + cstage * STAGE;
+            cstage = (cstage + 1 == kGemmStages) ? 0 : cstage + 1;
+            const lchar *tb = st + kX3XB + foff;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (c * 64 + j * 32 < D) {
+                    float raw[16];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const gf32x4 p4 = *(lf4 *)(st + xoff[j][q]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) raw[4 * q + i] = p4[i];
+                    }
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float m = pm ? raw[2 * i + 1] : raw[2 * i];
+                        // (columns beyond D hold clamped copies; their W1 entries are zero, the values must be finite)
+                        v[i] = (c * 64 + j * 32 + 16 * h + 2 * i < D) ? m : 0.f;
+                    }
+                    half8 xh, xl;
+                    split8(v, xh, xl);
+#pragma unroll
+                    for (int T = 0; T < NU; ++T) {
+                        const half8 wh = *(lh8 *)(tb + (j * NU + T) * 2048);
+                        const half8 wl = *(lh8 *)(tb + (j * NU + T) * 2048 + 1024);
+                        acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc[T], 0, 0, 0);
+                        acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc[T], 0, 0, 0);
+                        acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc[T], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // ---- bias + ReLU + split: the accumulators become the B fragments of GEMM 2 ---------------------------
+        half8 hh[KK], hl[KK];
+#pragma unroll
+        for (int T = 0; T < NU; ++T)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int reg = 8 * j + i;
+                    const int unit = 32 * T + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    v[i] = fmaxf(acc[T][reg] + b1_l[unit], 0.f);
+                }
+                split8(v, hh[2 * T + j], hl[2 * T + j]);
+            }
+        // ---- phase 2: Z^T = W2 H^T per tile of 32 transformed variables, fused epilogue ------------------------
+        const int64_t b = (int64_t)tile * kX3Tile + rl_own;
+        const bool row_ok = b < a.B;
+        const float *xrow = a.x + (row_ok ? b : a.B - 1) * D;
+        float *orow = a.out + (row_ok ? b : a.B - 1) * D;
+        float ssum = 0.f;
+        for (int pt = 0; pt < NPT; ++pt) {
+            gemm_lds_barrier();
+            const lchar *st = smem + cstage * STAGE;
+            cstage = (cstage + 1 == kGemmStages) ? 0 : cstage + 1;
+            const lchar *tb = st + foff;
+            // the lane's pairs: accumulator register r <-> variable n = 32 pt + (r & 3) + 8 (r >> 2) + 4 h; the four
+            // registers of a group are four consecutive variables = 8 consecutive raw columns
+            gf32x4 xin[4][2];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int n0 = 32 * pt + 8 * g4 + 4 * h;
+                const int col = min(2 * n0, D - 8);   // (a group beyond the last variable re-reads the last run: unused)
+                xin[g4][0] = *(gf4 *)(xrow + col);
+                xin[g4][1] = *(gf4 *)(xrow + col + 4);
+            }
+            gf32x16 zt, zs;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                zt[i] = 0.f;
+                zs[i] = 0.f;
+            }
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const half8 th = *(lh8 *)(tb + (kk * 2 + 0) * 2048);
+                const half8 tl = *(lh8 *)(tb + (kk * 2 + 0) * 2048 + 1024);
+                zt = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, hh[kk], zt, 0, 0, 0);
+                if (AFFINE) {
+                    const half8 sh8 = *(lh8 *)(tb + (kk * 2 + 1) * 2048);
+                    zs = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh8, hh[kk], zs, 0, 0, 0);
+                }
+                zt = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, hl[kk], zt, 0, 0, 0);
+                if (AFFINE) {
+                    const half8 sh8 = *(lh8 *)(tb + (kk * 2 + 1) * 2048);
+                    zs = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh8, hl[kk], zs, 0, 0, 0);
+                }
+                zt = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl, hh[kk], zt, 0, 0, 0);
+                if (AFFINE) {
+                    const half8 sl8 = *(lh8 *)(tb + (kk * 2 + 1) * 2048 + 1024);
+                    zs = __builtin_amdgcn_mfma_f32_32x32x16_f16(sl8, hh[kk], zs, 0, 0, 0);
+                }
+            }
+            const lchar *ex = st + KK * 4096;   // extras: bt, bs, sc_t, sh_t, sc_p, sh_p (32 floats each)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int j0 = 8 * g4 + 4 * h;                  // first of the group's four variables in the tile
+                const int n0 = 32 * pt + j0;
+                const gf32x4 bt = *(lf4 *)(ex + (0 + j0) * 4), bs = *(lf4 *)(ex + (32 + j0) * 4);
+                const gf32x4 sct = *(lf4 *)(ex + (64 + j0) * 4), sht = *(lf4 *)(ex + (96 + j0) * 4);
+                const gf32x4 scp = *(lf4 *)(ex + (128 + j0) * 4), shp = *(lf4 *)(ex + (160 + j0) * 4);
+                gf32x4 o[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * g4 + i;
+                    // raw columns 2 (n0 + i) + {0, 1}: element 2 i + (1 - pm) is transformed, 2 i + pm passes through
+                    const float e0 = xin[g4][(2 * i) >> 2][(2 * i) & 3], e1 = xin[g4][(2 * i + 1) >> 2][(2 * i + 1) & 3];
+                    const float xt = pm ? e0 : e1, xp = pm ? e1 : e0;
+                    const float xv = fmaf(xt, sct[i], sht[i]);
+                    const float pv = fmaf(xp, scp[i], shp[i]);
+                    const float tv = zt[r] + bt[i];
+                    float ov;
+                    if (AFFINE) {
+                        const float sv = act * x3_tanh(zs[r] + bs[i]);
+                        const float es = __builtin_amdgcn_exp2f((a.inverse ? sv : -sv) * 1.4426950408889634f);
+                        ov = a.inverse ? fmaf(xv, es, tv) : (xv - tv) * es;
+                        if (n0 + i < a.g.N2) ssum += sv;
+                    } else {
+                        ov = a.inverse ? xv + tv : xv - tv;
+                    }
+                    const float lo = pm ? ov : pv, hi = pm ? pv : ov;
+                    o[(2 * i) >> 2][(2 * i) & 3] = lo;
+                    o[(2 * i + 1) >> 2][(2 * i + 1) & 3] = hi;
+                }
+                if (row_ok && 2 * n0 < D) {
+                    *reinterpret_cast<gf32x4 *>(orow + 2 * n0) = o[0];
+                    if (2 * n0 + 4 < D) *reinterpret_cast<gf32x4 *>(orow + 2 * n0 + 4) = o[1];
+                }
+            }
+        }
+        // ---- log-det: the two lanes of a sample hold disjoint halves of the transformed variables -----------------
+        const float tot = ssum + __shfl_xor(ssum, 32, 64);
+        if (h == 0 && row_ok) {
+            const float v = AFFINE ? (a.inverse ? tot : -tot) : 0.f;
+            if (a.accumulate) a.ldj[b] += v; else a.ldj[b] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct X3Ws {
+    uint16_t *w1t;
+    char *w2t;
+    float *b1f;
+    int64_t bytes;
+};
+static X3Ws x3_carve(void *base, const X3Geom &g, int U) {
+    X3Ws w{};
+    char *p = (char *)base;
+    int64_t o = 0;
+    auto take = [&](int64_t n) {
+        char *q = p ? p + o : nullptr;
+        o = align_up(o + n, 256);
+        return q;
+    };
+    w.w1t = (uint16_t *)take((int64_t)g.NCH1 * g.W1CH);
+    w.w2t = take((int64_t)g.NPT * g.W2CH);
+    w.b1f = (float *)take((int64_t)U * 4);
+    w.bytes = o;
+    return w;
+}
+
+// (D % 8: a lane's four consecutive transformed variables are one aligned run of 8 raw columns)
+static bool x3_shape_ok(int D, int U) { return D >= 8 && (D % 8) == 0 && (U == 32 || U == 64 || U == 96 || U == 128); }
+
+template <bool AFFINE, int NU>
+static int x3_launch(const X3Args &a, hipStream_t st) {
+    constexpr int W1CH = 2 * NU * 2 * 1024, KK = NU * 2;
+    constexpr int W2CH = ((KK * 4 * 1024 + 1024 + 4095) / 4096) * 4096;
+    constexpr int STAGE = (kX3XB + W1CH) > W2CH ? (kX3XB + W1CH) : W2CH;
+    const size_t lds = (size_t)kGemmStages * STAGE + (size_t)a.U * 4;
+    auto kern = coupling_x3_kernel<AFFINE, NU>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
+            return DPK_ELAUNCH;
+        }
+        attr_done = true;
+    }
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else cus = 256;
+    }
+    const int grid = a.ntiles < cus ? a.ntiles : cus;
+    hipEvent_t ev0, ev1;
+    profile_take(&ev0, &ev1, DPK_KERNEL_COUPLING1D);
+    if (ev0) (void)hipEventRecord(ev0, st);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * kGemmWaves * 64), lds, st, a);
+    if (ev1) (void)hipEventRecord(ev1, st);
+    DPK_CHECK_LAUNCH("coupling_x3_kernel");
+    return DPK_OK;
+}
+
+}  // namespace dpk
+
+using namespace dpk;
+
+extern "C" int64_t dpk_coupling1d_pairs_workspace_bytes(int32_t D, int32_t units) {
+    if (D <= 0 || units <= 0) return DPK_EINVAL;
+    if (!x3_shape_ok(D, units)) return DPK_EUNSUPPORTED;
+    return x3_carve(nullptr, x3_geom(D, units), units).bytes;
+}
+
+extern "C" int dpk_coupling1d_pairs_forward(const float *x, int64_t B, int32_t D, int32_t masked_parity,
+                                            const float *W1, const float *b1, const float *W2, const float *b2,
+                                            int32_t units, const float *act_weight, const float *in_scale,
+                                            const float *in_shift, int32_t affine, int32_t inverse, float *out,
+                                            float *ldj, int32_t accumulate_ldj, void *ws, int64_t ws_bytes,
+                                            uint32_t flags, void *stream) {
+    DPK_REQUIRE(B >= 0 && D > 0 && units > 0 && (masked_parity == 0 || masked_parity == 1), DPK_EINVAL,
+                "coupling1d_pairs: bad sizes");
+    DPK_REQUIRE(x3_shape_ok(D, units), DPK_EUNSUPPORTED, "coupling1d_pairs: D=%d units=%d not built", D, units);
+    DPK_REQUIRE(W1 && b1 && W2 && b2 && ws, DPK_EINVAL, "coupling1d_pairs: null pointer");
+    DPK_REQUIRE(!affine || act_weight, DPK_EINVAL, "coupling1d_pairs: affine coupling needs the ScaledTanh weight");
+    DPK_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), DPK_EINVAL, "coupling1d_pairs: scale/shift mismatch");
+    if (B == 0) return DPK_OK;
+    DPK_REQUIRE(x && out && ldj, DPK_EINVAL, "coupling1d_pairs: null pointer");
+    DPK_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+                DPK_EUNSUPPORTED, "coupling1d_pairs: x / out must be 16-byte aligned");
+    const X3Geom g = x3_geom(D, units);
+    const X3Ws w = x3_carve(ws, g, units);
+    DPK_REQUIRE(ws_bytes >= w.bytes, DPK_EWORKSPACE, "coupling1d_pairs: workspace %lld < %lld", (long long)ws_bytes,
+                (long long)w.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    if (!(flags & DPK_FLAG_PARAMS_CACHED)) {
+        X3PackArgs p{};
+        p.W1 = W1; p.b1 = b1; p.W2 = W2; p.b2 = b2; p.in_scale = in_scale; p.in_shift = in_shift;
+        p.D = D; p.U = units; p.pm = masked_parity; p.affine = affine; p.g = g;
+        p.w1t = w.w1t; p.w2t = w.w2t; p.b1f = w.b1f;
+        const int64_t total = (int64_t)g.NCH1 * 2 * g.NU * 64 + (int64_t)g.NPT * (units / 16) * 2 * 64 + (int64_t)g.NPT * 32 +
+                              units;
+        hipLaunchKernelGGL(coupling_x3_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p);
+        DPK_CHECK_LAUNCH("coupling_x3_pack_kernel");
+    }
+    X3Args a{};
+    a.x = x; a.out = out; a.ldj = ldj; a.B = B; a.D = D; a.U = units; a.pm = masked_parity; a.inverse = inverse;
+    a.accumulate = accumulate_ldj; a.ntiles = cdiv(B, kX3Tile); a.g = g;
+    a.w1t = w.w1t; a.w2t = w.w2t; a.b1f = w.b1f; a.act_weight = act_weight;
+    switch (units / 32) {
+        case 1: return affine ? x3_launch<true, 1>(a, st) : x3_launch<false, 1>(a, st);
+        case 2: return affine ? x3_launch<true, 2>(a, st) : x3_launch<false, 2>(a, st);
+        case 3: return affine ? x3_launch<true, 3>(a, st) : x3_launch<false, 3>(a, st);
+        default: return affine ? x3_launch<true, 4>(a, st) : x3_launch<false, 4>(a, st);
+    }
+}

@@ -1,7 +1,7 @@
 """RealNVP / NICE 1-D coupling layer behind the reference interface (deeprob/flows/layers/coupling.py:15-104),
 evaluated by one fused fp32-MFMA kernel per call (csrc/coupling.hip).  CouplingLayer2d / CouplingBlock2d are
 out of scope (RealNVP2d only)."""
-from typing import Tuple
+from typing import Optional, Tuple
 
 import numpy as np
 import torch
@@ -41,7 +41,9 @@ class CouplingLayer1d(Bijector):
             self.scale_act = ScaledTanh()
         self._ws = Workspace()
         self._ws_bwd = Workspace()
+        self._ws_pairs = Workspace()   # packed tables of the alternating-mask kernel (dpk_coupling1d_pairs_forward)
         self._counts = None
+        self._pairs = None
 
     def build_alternating_masks(self) -> Tuple[np.ndarray, np.ndarray]:
         """mask = 0,1,0,1,... and its complement (reference :62-70)."""
@@ -57,6 +59,22 @@ class CouplingLayer1d(Bijector):
                 raise HipError("CouplingLayer1d on the HIP path needs binary mask / inv_mask buffers")
             self._counts = (key, (int(m.sum().item()), int(im.sum().item())))
         return self._counts[1]
+
+    def _pair_parity(self) -> Optional[int]:
+        """Parity of the conditioning columns when the masks are the reference's alternating ones (mask =
+        arange(D) % 2 or its complement, inv_mask = 1 - mask), else None.  Host check, cached per buffer version."""
+        key = (self.mask._version, self.inv_mask._version, self.mask.data_ptr())
+        if self._pairs is None or self._pairs[0] != key:
+            m, im = self.mask.detach().cpu(), self.inv_mask.detach().cpu()
+            odd = (torch.arange(m.numel()) % 2).to(m.dtype)
+            par = None
+            if m.dim() == 1 and m.numel() % 2 == 0 and torch.equal(im, 1 - m):
+                if torch.equal(m, odd):
+                    par = 1
+                elif torch.equal(m, 1 - odd):
+                    par = 0
+            self._pairs = (key, par)
+        return self._pairs[1]
 
     def apply_backward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """u = (x - t) exp(-s), ildj = -sum(s) with (t, s) = conditioner(mask * x) (reference :72-87)."""

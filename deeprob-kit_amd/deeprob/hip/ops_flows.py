@@ -9,7 +9,12 @@ from typing import Optional, Tuple
 
 import torch
 
-from deeprob.hip import load_library, check, ptr, stream_ptr, require_device_f32, HipError
+from deeprob.hip import (load_library, check, ptr, stream_ptr, require_device_f32, HipError,
+                         DPK_FLAG_PARAMS_CACHED)
+
+
+def _versions(*tensors) -> tuple:
+    return tuple(None if t is None else (t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
 
 
 def _no_graph(*tensors):
@@ -40,6 +45,32 @@ def coupling1d(x: torch.Tensor, layer, inverse: bool, in_affine: Optional[Tuple[
     B, D = x.shape
     units = lin1.weight.shape[0]
     n_masked, n_trans = layer._mask_counts()
+    parity = layer._pair_parity()
+    if parity is not None and units in (32, 64, 96, 128) and D % 8 == 0:
+        # the reference's alternating masks: split-f16 MFMA kernel, packed tables kept while the weights (and the
+        # folded input affine) are unchanged
+        n = lib.dpk_coupling1d_pairs_workspace_bytes(D, units)
+        if n < 0:
+            check(int(n), 'dpk_coupling1d_pairs_workspace_bytes')
+        pw = layer._ws_pairs
+        ws = pw.get(n, x.device)
+        out = torch.empty_like(x)
+        accumulate = ldj is not None
+        if ldj is None:
+            ldj = torch.empty(B, dtype=torch.float32, device=x.device)
+        sc, sh = in_affine if in_affine is not None else (None, None)
+        act = layer.scale_act.weight if layer.affine else None
+        w1, b1 = require_device_f32(lin1.weight, 'W1'), require_device_f32(lin1.bias, 'b1')
+        w2, b2 = require_device_f32(lin2.weight, 'W2'), require_device_f32(lin2.bias, 'b2')
+        if x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0:
+            key = (_versions(w1, b1, w2, b2, sc, sh), parity, bool(layer.affine))
+            flags = DPK_FLAG_PARAMS_CACHED if pw.params_key == key else 0
+            pw.params_key = key
+            check(lib.dpk_coupling1d_pairs_forward(
+                ptr(x), B, D, parity, ptr(w1), ptr(b1), ptr(w2), ptr(b2), units, ptr(act), ptr(sc), ptr(sh),
+                int(layer.affine), int(inverse), ptr(out), ptr(ldj), int(accumulate), ptr(ws), ws.numel(), flags,
+                stream_ptr(x.device)), 'dpk_coupling1d_pairs_forward')
+            return out, ldj
     n = lib.dpk_coupling1d_workspace_bytes(D, units, n_masked, n_trans)
     if n < 0:
         check(int(n), 'dpk_coupling1d_workspace_bytes')
@@ -109,23 +140,34 @@ def _coupling1d_mlp(x: torch.Tensor, layer, inverse: bool, keep: bool = False):
 
 
 def bn1d_fold(bn, inverse: bool, in_affine=None, ldj_const: Optional[torch.Tensor] = None):
-    """Eval-mode BatchNormLayer1d as a per-variable affine (reference: deeprob/flows/utils.py:118-153).
-    Returns ((scale, shift), ldj_const[1])."""
+    """Eval-mode BatchNormLayer1d as a per-variable affine (reference: deeprob/flows/utils.py:118-153), composed with
+    an incoming affine.  Returns ((scale, shift), ldj_const[1]); a given ``ldj_const`` is accumulated into.
+
+    The fold depends only on the layer's parameters / running statistics and on the incoming affine: its result is
+    kept (the SAME tensors, so that the coupling behind it recognises its packed tables) while their addresses and
+    version counters are unchanged."""
     lib = load_library()
     D = bn.in_features
     dev = bn.weight.device
-    sc = torch.empty(D, dtype=torch.float32, device=dev)
-    sh = torch.empty(D, dtype=torch.float32, device=dev)
-    accumulate = ldj_const is not None
-    if ldj_const is None:
-        ldj_const = torch.empty(1, dtype=torch.float32, device=dev)
     s_in, h_in = in_affine if in_affine is not None else (None, None)
-    check(lib.dpk_bn1d_fold(ptr(require_device_f32(bn.weight, 'weight')), ptr(require_device_f32(bn.bias, 'bias')),
-                            ptr(require_device_f32(bn.running_var, 'running_var')),
-                            ptr(require_device_f32(bn.running_mean, 'running_mean')), float(bn.eps), D,
-                            int(inverse), ptr(s_in), ptr(h_in), ptr(sc), ptr(sh), ptr(ldj_const), int(accumulate),
-                            stream_ptr(dev)), 'dpk_bn1d_fold')
-    return (sc, sh), ldj_const
+    key = (_versions(bn.weight, bn.bias, bn.running_var, bn.running_mean, s_in, h_in), bool(inverse), float(bn.eps))
+    hit = getattr(bn, '_fold_cache', None)
+    if hit is None or hit[0] != key:
+        sc = torch.empty(D, dtype=torch.float32, device=dev)
+        sh = torch.empty(D, dtype=torch.float32, device=dev)
+        own = torch.empty(1, dtype=torch.float32, device=dev)     # this layer's constant log-det
+        check(lib.dpk_bn1d_fold(ptr(require_device_f32(bn.weight, 'weight')), ptr(require_device_f32(bn.bias, 'bias')),
+                                ptr(require_device_f32(bn.running_var, 'running_var')),
+                                ptr(require_device_f32(bn.running_mean, 'running_mean')), float(bn.eps), D,
+                                int(inverse), ptr(s_in), ptr(h_in), ptr(sc), ptr(sh), ptr(own), 0, stream_ptr(dev)),
+              'dpk_bn1d_fold')
+        # (s_in / h_in are kept alive with the entry: their addresses are part of the key)
+        hit = (key, (sc, sh), own, (s_in, h_in))
+        bn._fold_cache = hit
+    if ldj_const is None:
+        return hit[1], hit[2].clone()
+    ldj_const += hit[2]
+    return hit[1], ldj_const
 
 
 def affine1d(x: torch.Tensor, affine) -> torch.Tensor:

@@ -176,6 +176,19 @@ int dpk_coupling1d_forward(const float *x, int64_t B, int32_t D, const float *ma
                            float *out, float *ldj, int32_t accumulate_ldj, void *ws, int64_t ws_bytes,
                            void *stream);
 
+/* The same layer for the reference's own masks (coupling.py:58-60: mask = arange(D) % 2, or its complement for
+ * every other layer) with a depth-1 conditioner of 32 / 64 / 96 / 128 units and D % 8 == 0: both GEMMs on the f16
+ * matrix cores with two-way f16 splits of every operand and fp32 accumulation (>= 22 significant bits per product),
+ * hidden activations kept in registers.  masked_parity: parity of the columns where mask != 0.  flags:
+ * DPK_FLAG_PARAMS_CACHED = the packed tables in `ws` were built by an earlier call from the same, unchanged
+ * W1 / b1 / W2 / b2 / in_scale / in_shift.  x and out must be 16-byte aligned and must not alias.        */
+int64_t dpk_coupling1d_pairs_workspace_bytes(int32_t D, int32_t units);
+int dpk_coupling1d_pairs_forward(const float *x, int64_t B, int32_t D, int32_t masked_parity, const float *W1,
+                                 const float *b1, const float *W2, const float *b2, int32_t units,
+                                 const float *act_weight, const float *in_scale, const float *in_shift,
+                                 int32_t affine, int32_t inverse, float *out, float *ldj, int32_t accumulate_ldj,
+                                 void *ws, int64_t ws_bytes, uint32_t flags, void *stream);
+
 /* Eval-mode BatchNormLayer1d.apply_backward (inverse = 0) / apply_forward (1)
  * (deeprob/flows/utils.py:118-153) as a per-variable affine y = x*scale_out + shift_out
  * composed with an optional incoming affine; ldj_const [1] = its (constant) log-det,
