@@ -3,6 +3,7 @@
 // the individual reference modules; the inference fast path is the fused kernel in
 // ratspn_fwd.hip.
 #include "common.h"
+#include <stdlib.h>
 #include <math.h>
 
 namespace dpk {
@@ -784,6 +785,14 @@ __global__ __launch_bounds__(256) void prodroot_fwd_kernel(const float *__restri
     }
 }
 
+// ratspn_upper_gemm.hip: the same layers on the f16 matrix cores (8 / 16 nodes per region)
+namespace dpk {
+bool upper_mfma_shape_ok(bool root, int N, int S);
+int64_t upper_mfma_frag_bytes(int R, int N, int S);
+int upper_mfma_forward(bool root, const float *in, const float *W, const float *LW, int64_t B, int R, int N, int S,
+                       float *out, void *frag, hipStream_t st);
+}
+
 static int prod_fused_common(bool root, const float *in, const float *weight, int64_t B, int R, int N, int S,
                              float *out, void *ws, int64_t ws_bytes, void *stream, const char *who) {
     DPK_REQUIRE(B >= 0 && R > 0 && (R % 2) == 0 && N > 0 && S > 0, DPK_EINVAL, "%s: bad sizes", who);
@@ -799,6 +808,16 @@ static int prod_fused_common(bool root, const float *in, const float *weight, in
     float *W = (float *)ws, *LW = (float *)((char *)ws + seg);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(softmax_rows_kernel2, dim3(cdiv(rows, 4)), dim3(256), 0, st, weight, rows, n, W, LW);
+    {
+        static const bool mfma = [] {
+            const char *e = getenv("DPK_RATSPN_GEMM");
+            return !(e && e[0] == '0');
+        }();
+        const int64_t fb = upper_mfma_frag_bytes(R, N, S);
+        if (mfma && upper_mfma_shape_ok(root, N, S) && ws_bytes >= 2 * seg + fb &&
+            (reinterpret_cast<uintptr_t>(in) & 15) == 0)
+            return upper_mfma_forward(root, in, W, LW, B, R, N, S, out, (char *)ws + 2 * seg, st);
+    }
     const dim3 block(256);
 #define DPK_LAUNCH_PS(NMAX)                                                                                         \
     do {                                                                                                            \
@@ -820,7 +839,7 @@ static int prod_fused_common(bool root, const float *in, const float *weight, in
 
 extern "C" int64_t dpk_prodsum_workspace_bytes(int32_t R, int32_t N, int32_t S) {
     if (R <= 0 || N <= 0 || S <= 0) return DPK_EINVAL;
-    return 2 * align_up((int64_t)(R / 2) * S * N * N * 4, 256) + 256;
+    return 2 * align_up((int64_t)(R / 2) * S * N * N * 4, 256) + upper_mfma_frag_bytes(R, N, S) + 256;
 }
 extern "C" int dpk_prodsum_forward(const float *in, const float *weight, int64_t B, int32_t R, int32_t N, int32_t S,
                                    float *out, void *ws, int64_t ws_bytes, void *stream) {

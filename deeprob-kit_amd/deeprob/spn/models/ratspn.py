@@ -121,12 +121,12 @@ class RatSpn(ProbabilisticModel):
         )
 
     def _prefer_folded(self, x: torch.Tensor) -> bool:
-        """8-channel unit-scale models below ~32k samples: the leaf layer on the matrix cores + the folded product / sum
-        kernels beat the single-launch VALU kernel (measured 0.087 vs 0.194 ms at 4096 samples, a tie at 65536;
+        """8-channel unit-scale models: the leaf layer and the folded product / sum layers on the matrix cores beat the
+        single-launch VALU kernel (measured 0.065 vs 0.194 ms at 4096 samples, 0.209 vs 0.243 ms at 65536;
         tools/bench_wide.py)."""
         base = self.base_layer
-        return (isinstance(base, GaussianLayer) and self.rg_batch == 8 and not base.scale.requires_grad
-                and self.in_features % 4 == 0 and x.shape[0] <= 32768)
+        return (isinstance(base, GaussianLayer) and self.rg_batch == 8 and self.rg_sum in (8, 16)
+                and not base.scale.requires_grad and self.in_features % 4 == 0)
 
     def _forward_folded(self, x: torch.Tensor) -> Optional[torch.Tensor]:
         """Evaluation outside the single-launch kernel's envelope (e.g. rg_batch = rg_sum = 16): leaf kernel, then
