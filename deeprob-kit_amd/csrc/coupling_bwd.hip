@@ -210,12 +210,14 @@ __global__ __launch_bounds__(kRThreads) void colsum_kernel(const float *__restri
 // element-wise core of the coupling backward.  Z holds [t_hat | s_hat] (affine) or z (NICE); it is
 // overwritten with dZ.  gx receives the direct term g_u * exp(-s).
 //   ds = -g_u u - g_ildj ; dt = -g_u e^{-s} ; ds_hat = inv_mask ds a (1 - tanh^2) ; da = sum inv_mask ds tanh
+// inverse != 0: the sampling direction (coupling.py:89-104), x_out = x e^{s} + t, ldj = +sum s:
+//   ds = g x e^{s} + g_ldj ; dt = g ; direct term g e^{s}
 __global__ __launch_bounds__(256) void coupling_bwd_elem_kernel(const float *__restrict__ x, float *__restrict__ Z,
                                                                 const float *__restrict__ inv_mask,
                                                                 const float *__restrict__ act_weight,
                                                                 const float *__restrict__ gu,
                                                                 const float *__restrict__ gildj, int64_t B, int D,
-                                                                int affine, float *__restrict__ gx,
+                                                                int affine, int inverse, float *__restrict__ gx,
                                                                 float *__restrict__ gact) {
     const int64_t total = B * D;
     const float a = affine ? act_weight[0] : 0.f;
@@ -231,10 +233,17 @@ __global__ __launch_bounds__(256) void coupling_bwd_elem_kernel(const float *__r
             if (live) {
                 const float th = tanhf(*zs);
                 const float s = a * th, t = *zt;
-                const float es = expf(-s);
-                const float u = (x[e] - t) * es;
-                const float ds = -g * u - (gildj ? gildj[b] : 0.f);
-                *zt = -g * es;
+                float ds, es;
+                if (inverse) {
+                    es = expf(s);
+                    ds = g * x[e] * es + (gildj ? gildj[b] : 0.f);
+                    *zt = g;
+                } else {
+                    es = expf(-s);
+                    const float u = (x[e] - t) * es;
+                    ds = -g * u - (gildj ? gildj[b] : 0.f);
+                    *zt = -g * es;
+                }
                 *zs = ds * a * (1.f - th * th);
                 da += ds * th;
                 gx[e] = g * es;
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(256) void coupling_bwd_elem_kernel(const float *__r
                 gx[e] = g;
             }
         } else {
-            Z[b * D + d] = live ? -g : 0.f;
+            Z[b * D + d] = live ? (inverse ? g : -g) : 0.f;
             gx[e] = g;
         }
     }
@@ -459,6 +468,11 @@ __global__ void bn1d_sync_bwd_apply_kernel(const float *__restrict__ x, const fl
     }
 }
 
+__global__ void fill_kernel(float *__restrict__ p, float v, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 __global__ void vecsum_kernel(const float *__restrict__ v, int64_t n, float *__restrict__ out) {
     // one block; fp32 pairwise-ish: per-thread strided partials, LDS tree
     __shared__ float red[256];
@@ -580,7 +594,7 @@ extern "C" int dpk_coupling1d_backward(const float *x, int64_t B, int32_t D, con
     launch_gemm(g, st);
     // element-wise core: Z <- dZ, grad_x <- direct term
     hipLaunchKernelGGL(coupling_bwd_elem_kernel, dim3(grid1d(B * D, 256, 1024)), dim3(256), 0, st, x, Z, inv_mask, act_weight,
-                       grad_u, grad_ildj, B, D, affine, grad_x, grad_act);
+                       grad_u, grad_ildj, B, D, affine, 0, grad_x, grad_act);
     // dW2 = dZ^T H, db2 = colsum(dZ)
     if (grad_W2) {
         g = GemmArgs{};
@@ -715,6 +729,43 @@ extern "C" int dpk_bn1d_sync_backward(const float *x, const float *grad_u, int64
     return DPK_OK;
 }
 
+// Backward of the eval-statistics inverse BatchNormLayer1d.apply_forward (flows/utils.py:141-153):
+//   x = (u - bias) G + mean,  G = exp(-weight) sqrt(var + eps),  ldj = sum_d (-weight + 0.5 log(var + eps))
+//   grad_u = g G ;  grad_weight = -G sum_b g (u - bias) - sum_b g_ldj ;  grad_bias = -G sum_b g
+__global__ void bn1d_inverse_bwd_finish_kernel(const float *__restrict__ weight, const float *__restrict__ var, float eps,
+                                               int D, const float *__restrict__ s1, const float *__restrict__ s2,
+                                               const float *__restrict__ sg, float *__restrict__ G,
+                                               float *__restrict__ gw, float *__restrict__ gb) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    const float g = expf(-weight[d]) * sqrtf(var[d] + eps);
+    G[d] = g;
+    if (gw) gw[d] = -g * s2[d] - (sg ? sg[0] : 0.f);
+    if (gb) gb[d] = -g * s1[d];
+}
+
+extern "C" int dpk_bn1d_inverse_backward(const float *u, const float *grad_x, const float *grad_ldj, int64_t B, int32_t D,
+                                         const float *weight, const float *bias, const float *running_var, float eps,
+                                         float *grad_u, float *grad_weight, float *grad_bias, void *ws, int64_t ws_bytes,
+                                         void *stream) {
+    DPK_REQUIRE(B >= 1 && D > 0, DPK_EINVAL, "bn1d_inverse_backward: bad sizes");
+    DPK_REQUIRE(u && grad_x && weight && bias && running_var && grad_u && ws, DPK_EINVAL,
+                "bn1d_inverse_backward: null pointer");
+    DPK_REQUIRE(ws_bytes >= (int64_t)(5 * D + 64) * 4, DPK_EWORKSPACE, "bn1d_inverse_backward: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float *s1 = (float *)ws, *s2 = s1 + D, *G = s2 + D, *ones = G + D, *zero = ones + D, *sg = zero + D;
+    // column sums of g and g (u - bias): the reducer of the forward direction with mean := bias, 1 / sqrt(var + eps) := 1
+    DPK_REQUIRE(hipMemsetAsync(zero, 0, (size_t)D * 4, st) == hipSuccess, DPK_ELAUNCH, "memset");
+    hipLaunchKernelGGL(fill_kernel, dim3(cdiv(D, 256)), dim3(256), 0, st, ones, 1.0f, (int64_t)D);
+    if (grad_ldj) hipLaunchKernelGGL(vecsum_kernel, dim3(1), dim3(256), 0, st, grad_ldj, B, sg);
+    hipLaunchKernelGGL(bn1d_bwd_reduce_kernel, dim3(cdiv(D, kRC)), dim3(kRThreads), 0, st, u, grad_x, B, D, bias, ones, 0.f,
+                       s1, s2);
+    hipLaunchKernelGGL(bn1d_inverse_bwd_finish_kernel, dim3(cdiv(D, 256)), dim3(256), 0, st, weight, running_var, eps, D,
+                       s1, s2, grad_ldj ? sg : nullptr, G, grad_weight, grad_bias);
+    DPK_CHECK_LAUNCH("bn1d_inverse_backward");
+    return dpk_affine1d_forward(grad_x, G, zero, B, D, grad_u, stream);
+}
+
 // d/du of dpk_normal_base_logprob (no incoming affine): grad_u[b,d] = -g[b] (u - loc)/scale^2
 extern "C" int dpk_normal_base_backward(const float *u, const float *loc, const float *scale, const float *g, int64_t B,
                                         int32_t D, float *grad_u, void *stream) {
@@ -818,10 +869,10 @@ extern "C" int dpk_coupling1d_mlp_forward(const float *x, int64_t B, int32_t D, 
 }
 
 // grad_W[i] / grad_b[i] may be NULL pointers inside the arrays (or the arrays themselves NULL).
-extern "C" int dpk_coupling1d_mlp_backward(const float *x, int64_t B, int32_t D, const float *mask,
+static int mlp_backward_dir(const float *x, int64_t B, int32_t D, const float *mask,
                                            const float *inv_mask, int32_t n_hidden, const float *const *W,
                                            const float *const *b, const int32_t *widths, const float *act_weight,
-                                           int32_t affine, const float *grad_u, const float *grad_ildj, float *grad_x,
+                                           int32_t affine, int32_t inverse, const float *grad_u, const float *grad_ildj, float *grad_x,
                                            float *const *grad_W, float *const *grad_b, float *grad_act,
                                            int32_t ws_holds_forward, void *ws, int64_t ws_bytes, void *stream) {
     int rc = mlp_check(B, D, n_hidden, W, b, widths, affine, "coupling1d_mlp_backward");
@@ -845,7 +896,7 @@ extern "C" int dpk_coupling1d_mlp_backward(const float *x, int64_t B, int32_t D,
     DPK_REQUIRE(x && grad_x && (grad_u || grad_ildj), DPK_EINVAL, "coupling1d_mlp_backward: null pointer");
     if (!ws_holds_forward) mlp_forward(w, x, B, D, mask, n_hidden, W, b, widths, st);
     hipLaunchKernelGGL(coupling_bwd_elem_kernel, dim3(grid1d(B * D, 256, 1024)), dim3(256), 0, st, x, w.Z, inv_mask, act_weight,
-                       grad_u, grad_ildj, B, D, affine, grad_x, grad_act);
+                       grad_u, grad_ildj, B, D, affine, inverse, grad_x, grad_act);
     // back through the layers: dOut starts as dZ (in w.Z)
     float *dout = w.Z;
     float *spare[2] = {w.dA, w.dB};
@@ -879,4 +930,28 @@ extern "C" int dpk_coupling1d_mlp_backward(const float *x, int64_t B, int32_t D,
     }
     DPK_CHECK_LAUNCH("coupling1d_mlp_backward");
     return DPK_OK;
+}
+
+extern "C" int dpk_coupling1d_mlp_backward(const float *x, int64_t B, int32_t D, const float *mask,
+                                           const float *inv_mask, int32_t n_hidden, const float *const *W,
+                                           const float *const *b, const int32_t *widths, const float *act_weight,
+                                           int32_t affine, const float *grad_u, const float *grad_ildj, float *grad_x,
+                                           float *const *grad_W, float *const *grad_b, float *grad_act,
+                                           int32_t ws_holds_forward, void *ws, int64_t ws_bytes, void *stream) {
+    return mlp_backward_dir(x, B, D, mask, inv_mask, n_hidden, W, b, widths, act_weight, affine, 0, grad_u, grad_ildj,
+                            grad_x, grad_W, grad_b, grad_act, ws_holds_forward, ws, ws_bytes, stream);
+}
+
+// Backward of the SAMPLING direction (CouplingLayer1d.apply_forward, coupling.py:89-104; what NormalizingFlow.rsample
+// differentiates, flows/models/base.py:159-180): x = the input u of apply_forward, grad_u = gradient w.r.t. its
+// output, grad_ildj = gradient w.r.t. its log-det.  Everything else as dpk_coupling1d_mlp_backward.
+extern "C" int dpk_coupling1d_mlp_backward_inverse(const float *x, int64_t B, int32_t D, const float *mask,
+                                                   const float *inv_mask, int32_t n_hidden, const float *const *W,
+                                                   const float *const *b, const int32_t *widths,
+                                                   const float *act_weight, int32_t affine, const float *grad_out,
+                                                   const float *grad_ldj, float *grad_x, float *const *grad_W,
+                                                   float *const *grad_b, float *grad_act, int32_t ws_holds_forward,
+                                                   void *ws, int64_t ws_bytes, void *stream) {
+    return mlp_backward_dir(x, B, D, mask, inv_mask, n_hidden, W, b, widths, act_weight, affine, 1, grad_out, grad_ldj,
+                            grad_x, grad_W, grad_b, grad_act, ws_holds_forward, ws, ws_bytes, stream);
 }

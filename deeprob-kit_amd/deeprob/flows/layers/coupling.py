@@ -84,4 +84,4 @@ class CouplingLayer1d(Bijector):
     def apply_forward(self, u: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """x = u exp(s) + t, ldj = sum(s) (reference :89-104)."""
         from deeprob.hip import ops_flows
-        return ops_flows.coupling1d(u, self, inverse=True)
+        return ops_flows.coupling1d_autograd(u, self, inverse=True)

@@ -75,7 +75,8 @@ class BatchNormLayer1d(Bijector):
     def apply_forward(self, u: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """Inverse of apply_backward with the running statistics (reference :141-153)."""
         from deeprob.hip import ops_flows
-        ops_flows._no_graph(u, self.weight)
+        if ops_flows._wants_graph(u, self.weight, self.bias):
+            return ops_flows.BatchNormInverseFn.apply(u, self.weight, self.bias, self)
         affine, ldj = ops_flows.bn1d_fold(self, inverse=True)
         return ops_flows.affine1d(u, affine), ldj.expand(u.shape[0])
 

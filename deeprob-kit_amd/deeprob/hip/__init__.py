@@ -89,6 +89,11 @@ SIGNATURES = {
     'dpk_coupling1d_mlp_backward': (ctypes.c_int, [_c_void, _i64, _i32, _c_void, _c_void, _i32, _c_void, _c_void,
                                                    _c_void, _c_void, _i32, _c_void, _c_void, _c_void, _c_void, _c_void,
                                                    _c_void, _i32, _c_void, _i64, _c_void]),
+    'dpk_coupling1d_mlp_backward_inverse': (ctypes.c_int, [_c_void, _i64, _i32, _c_void, _c_void, _i32, _c_void, _c_void,
+                                                           _c_void, _c_void, _i32, _c_void, _c_void, _c_void, _c_void,
+                                                           _c_void, _c_void, _i32, _c_void, _i64, _c_void]),
+    'dpk_bn1d_inverse_backward': (ctypes.c_int, [_c_void, _c_void, _c_void, _i64, _i32, _c_void, _c_void, _c_void,
+                                                 ctypes.c_float, _c_void, _c_void, _c_void, _c_void, _i64, _c_void]),
     'dpk_bn1d_train_forward': (ctypes.c_int, [_c_void, _i64, _i32, _c_void, _c_void, _c_void, _c_void, ctypes.c_float,
                                               ctypes.c_float, _c_void, _c_void, _c_void, _c_void, _c_void, _i64,
                                               _c_void]),

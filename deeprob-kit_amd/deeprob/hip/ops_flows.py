@@ -241,16 +241,16 @@ class CouplingMlpFn(torch.autograd.Function):
     (or None) and then weight, bias of every Linear in order."""
 
     @staticmethod
-    def forward(ctx, layer, x, act, *params):
+    def forward(ctx, layer, inverse, x, act, *params):
         widths = [w.shape[0] for w in params[0::2]]
         import ctypes
         need = _mlp_backward_bytes(x.shape[0], len(widths) - 1, (ctypes.c_int32 * len(widths))(*widths))
         if need <= KEEP_ACTIVATIONS_BYTES:
-            u, ildj, ctx.kept = _coupling1d_mlp(x, layer, inverse=False, keep=True)
+            u, ildj, ctx.kept = _coupling1d_mlp(x, layer, inverse=inverse, keep=True)
         else:
-            (u, ildj), ctx.kept = _coupling1d_mlp(x, layer, inverse=False), None
+            (u, ildj), ctx.kept = _coupling1d_mlp(x, layer, inverse=inverse), None
         ctx.save_for_backward(x, act, *params)
-        ctx.layer = layer
+        ctx.layer, ctx.inverse = layer, bool(inverse)
         return u, ildj
 
     @staticmethod
@@ -265,43 +265,45 @@ class CouplingMlpFn(torch.autograd.Function):
         ws_t, bs_t = params[0::2], params[1::2]
         n = len(ws_t)
         need = ctx.needs_input_grad
-        gws = [torch.empty_like(w) if need[3 + 2 * i] else None for i, w in enumerate(ws_t)]
-        gbs = [torch.empty_like(b) if need[4 + 2 * i] else None for i, b in enumerate(bs_t)]
+        gws = [torch.empty_like(w) if need[4 + 2 * i] else None for i, w in enumerate(ws_t)]
+        gbs = [torch.empty_like(b) if need[5 + 2 * i] else None for i, b in enumerate(bs_t)]
         Wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws_t])
         bp = (ctypes.c_void_p * n)(*[b.data_ptr() for b in bs_t])
         gWp = (ctypes.c_void_p * n)(*[g.data_ptr() if g is not None else None for g in gws])
         gbp = (ctypes.c_void_p * n)(*[g.data_ptr() if g is not None else None for g in gbs])
         widths = (ctypes.c_int32 * n)(*[w.shape[0] for w in ws_t])
         gx = torch.empty_like(x)
-        gact = torch.empty_like(act) if (act is not None and need[2]) else None
+        gact = torch.empty_like(act) if (act is not None and need[3]) else None
         kept = ctx.kept
         ctx.kept = None   # a second backward through the same node evaluates the conditioner again
         ws = kept if kept is not None else layer._ws_bwd.get(_mlp_backward_bytes(B, n - 1, widths), x.device)
-        check(lib.dpk_coupling1d_mlp_backward(ptr(x), B, D, ptr(layer.mask), ptr(layer.inv_mask), n - 1, Wp, bp, widths,
-                                              ptr(act), int(layer.affine), ptr(gu), ptr(gildj), ptr(gx), gWp, gbp,
-                                              ptr(gact), int(kept is not None), ptr(ws), ws.numel(),
-                                              stream_ptr(x.device)), 'dpk_coupling1d_mlp_backward')
+        fn = lib.dpk_coupling1d_mlp_backward_inverse if ctx.inverse else lib.dpk_coupling1d_mlp_backward
+        check(fn(ptr(x), B, D, ptr(layer.mask), ptr(layer.inv_mask), n - 1, Wp, bp, widths, ptr(act),
+                 int(layer.affine), ptr(gu), ptr(gildj), ptr(gx), gWp, gbp, ptr(gact), int(kept is not None), ptr(ws),
+                 ws.numel(), stream_ptr(x.device)), 'dpk_coupling1d_mlp_backward')
         grads = []
         for gw, gb in zip(gws, gbs):
             grads += [gw, gb]
-        return (None, gx, gact, *grads)
+        return (None, None, gx, gact, *grads)
 
 
-def coupling1d_autograd(x: torch.Tensor, layer) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Density direction of a coupling layer, recording an autograd node when a graph is needed."""
+def coupling1d_autograd(x: torch.Tensor, layer, inverse: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """A coupling layer in either direction (density: apply_backward; sampling: apply_forward, what rsample
+    differentiates), recording an autograd node when a graph is needed."""
     lin1, lin2 = layer.network[0], layer.network[-1]
     act = layer.scale_act.weight if layer.affine else None
     lins = [m for m in layer.network if isinstance(m, torch.nn.Linear)]
     if not _wants_graph(x, act, *[t for m in lins for t in (m.weight, m.bias)]):
-        return coupling1d(x, layer, inverse=False)
+        return coupling1d(x, layer, inverse=inverse)
     layer._mask_counts()   # binary-mask check
     x = require_device_f32(x, 'x')
     import ctypes
     widths = (ctypes.c_int32 * len(lins))(*[m.weight.shape[0] for m in lins])
-    if len(lins) != 2 or _mlp_backward_bytes(x.shape[0], len(lins) - 1, widths) <= KEEP_ACTIVATIONS_BYTES:
-        # GEMM-chained conditioner whose activations stay resident for the backward
+    if inverse or len(lins) != 2 or \
+            _mlp_backward_bytes(x.shape[0], len(lins) - 1, widths) <= KEEP_ACTIVATIONS_BYTES:
+        # GEMM-chained conditioner whose activations stay resident for the backward (always for the sampling direction)
         flat = [require_device_f32(t, 'parameter') for m in lins for t in (m.weight, m.bias)]
-        return CouplingMlpFn.apply(layer, x, act, *flat)
+        return CouplingMlpFn.apply(layer, inverse, x, act, *flat)
     # too large to keep: fused forward, conditioner evaluated again in the backward
     return CouplingFn.apply(x, require_device_f32(lin1.weight, 'W1'),
                             require_device_f32(lin1.bias, 'b1'), require_device_f32(lin2.weight, 'W2'),
@@ -391,6 +393,38 @@ class BatchNormFn(torch.autograd.Function):
                                     float(bn.eps), int(ctx.train), ptr(gx), ptr(gw), ptr(gb), ptr(ws), ws.numel(),
                                     stream_ptr(x.device)), 'dpk_bn1d_backward')
         return gx, gw, gb, None
+
+
+class BatchNormInverseFn(torch.autograd.Function):
+    """BatchNormLayer1d.apply_forward with autograd (reference: flows/utils.py:141-153): the inverse transformation
+    with the running statistics, x = (u - bias) exp(-weight) sqrt(var + eps) + mean."""
+
+    @staticmethod
+    def forward(ctx, u, weight, bias, bn):
+        u = require_device_f32(u, 'u')
+        with torch.no_grad():
+            affine, ldj = bn1d_fold(bn, inverse=True)
+            x = affine1d(u, affine)
+        ctx.save_for_backward(u, weight, bias)
+        ctx.bn = bn
+        return x, ldj.expand(u.shape[0]).clone()
+
+    @staticmethod
+    def backward(ctx, gx, gldj):
+        lib = load_library()
+        u, weight, bias = ctx.saved_tensors
+        bn = ctx.bn
+        B, D = u.shape
+        gx = require_device_f32(gx, 'grad_x')
+        gldj = require_device_f32(gldj, 'grad_ldj')
+        gu = torch.empty_like(u)
+        gw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
+        gb = torch.empty_like(bias) if ctx.needs_input_grad[2] else None
+        ws = bn._ws.get(4 * (5 * D + 64) + 256, u.device)
+        check(lib.dpk_bn1d_inverse_backward(ptr(u), ptr(gx), ptr(gldj), B, D, ptr(weight), ptr(bias),
+                                            ptr(bn.running_var), float(bn.eps), ptr(gu), ptr(gw), ptr(gb), ptr(ws),
+                                            ws.numel(), stream_ptr(u.device)), 'dpk_bn1d_inverse_backward')
+        return gu, gw, gb, None
 
 
 class NormalBaseFn(torch.autograd.Function):

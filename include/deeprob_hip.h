@@ -286,6 +286,22 @@ int dpk_coupling1d_mlp_backward(const float *x, int64_t B, int32_t D, const floa
                                 const float *act_weight, int32_t affine, const float *grad_u, const float *grad_ildj,
                                 float *grad_x, float *const *grad_W, float *const *grad_b, float *grad_act,
                                 int32_t ws_holds_forward, void *ws, int64_t ws_bytes, void *stream);
+/* Backward of the SAMPLING direction, CouplingLayer1d.apply_forward (coupling.py:89-104): what
+ * NormalizingFlow.rsample differentiates (flows/models/base.py:159-180).  x = the input of apply_forward, grad_out /
+ * grad_ldj = gradients w.r.t. its two outputs; everything else as dpk_coupling1d_mlp_backward.               */
+int dpk_coupling1d_mlp_backward_inverse(const float *x, int64_t B, int32_t D, const float *mask, const float *inv_mask,
+                                        int32_t n_hidden, const float *const *W, const float *const *b,
+                                        const int32_t *widths, const float *act_weight, int32_t affine,
+                                        const float *grad_out, const float *grad_ldj, float *grad_x,
+                                        float *const *grad_W, float *const *grad_b, float *grad_act,
+                                        int32_t ws_holds_forward, void *ws, int64_t ws_bytes, void *stream);
+/* Backward of BatchNormLayer1d.apply_forward (flows/utils.py:141-153, running statistics):
+ * x = (u - bias) exp(-weight) sqrt(var + eps) + mean.  grad_ldj [B] may be NULL, grad_weight / grad_bias [D] may be
+ * NULL.  Workspace >= (5 D + 64) floats.                                                                     */
+int dpk_bn1d_inverse_backward(const float *u, const float *grad_x, const float *grad_ldj, int64_t B, int32_t D,
+                              const float *weight, const float *bias, const float *running_var, float eps,
+                              float *grad_u, float *grad_weight, float *grad_bias, void *ws, int64_t ws_bytes,
+                              void *stream);
 /* Training-mode BatchNormLayer1d.apply_backward (flows/utils.py:118-139): torch.var_mean over the batch
  * (unbiased), running_var / running_mean updated IN PLACE with `momentum`, out = (x-mean)/sqrt(var+eps)
  * * exp(weight) + bias, ildj_const[0] = sum_d(weight_d - 0.5 log(var_d+eps)); save_mean/save_var [D]

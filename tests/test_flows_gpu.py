@@ -5,7 +5,7 @@ import torch
 
 from oracle import flows_oracle as forc
 from tests.flow_cases import CASES, build_flow
-from tests.util import rel_err
+from tests.util import rel_err, grad_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -210,15 +210,46 @@ def test_training_step_reduces_loss():
     assert losses[-1] < losses[0] - 1.0 and all(np.isfinite(losses))
 
 
-def test_sampling_direction_has_no_silent_graph():
-    from deeprob.hip import HipError
+@pytest.mark.parametrize('kw', [dict(in_features=20, n_flows=3, units=32), dict(in_features=15, n_flows=2, units=64, affine=False),
+                                dict(in_features=14, n_flows=2, depth=3, units=40, batch_norm=False)])
+def test_sampling_direction_gradients_vs_oracle(kw):
+    """apply_forward (the direction NormalizingFlow.rsample differentiates, reference flows/models/base.py:159-180,
+    coupling.py:89-104, utils.py:141-153) is differentiable: gradients w.r.t. the latent input and every parameter
+    against the oracle's autograd in fp64."""
     from deeprob.flows.models import RealNVP1d
-    flow = RealNVP1d(16, n_flows=1, units=32).cuda().eval()
-    u = torch.randn(4, 16, device='cuda')
-    with pytest.raises(HipError):
-        flow.apply_forward(u)          # parameters require grad and grad mode is on
-    with torch.no_grad():
-        flow.apply_forward(u)
+    from tests.util import randomise_flow
+    torch.manual_seed(21)
+    flow = RealNVP1d(**kw)
+    randomise_flow(flow, 22)
+    flow.eval()
+    D = kw['in_features']
+    z = torch.randn(33, D, generator=torch.Generator().manual_seed(2))
+    wx = torch.randn(33, D, generator=torch.Generator().manual_seed(3))
+    wl = torch.randn(33, generator=torch.Generator().manual_seed(4))
+    # oracle, fp64
+    sd = {k: (v.detach().double() if v.is_floating_point() else v.detach().clone()) for k, v in flow.state_dict().items()}
+    names = [n for n, _ in flow.named_parameters()]
+    for n in names:
+        sd[n] = sd[n].clone().requires_grad_(True)
+    zo = z.double().requires_grad_(True)
+    xo, lo = forc.flow_apply_forward(sd, zo)
+    ((xo * wx.double()).sum() + (lo * wl.double()).sum()).backward()
+    # product
+    flow.cuda()
+    zg = z.cuda().requires_grad_(True)
+    xg, lg = flow.apply_forward(zg)
+    ((xg * wx.cuda()).sum() + (lg * wl.cuda()).sum()).backward()
+    assert rel_err(xg.detach().cpu().numpy(), xo.detach().numpy()) <= 2e-5
+    assert grad_err(zg.grad.cpu().numpy(), zo.grad.numpy()) <= 1e-4
+    for n, p in flow.named_parameters():
+        if sd[n].grad is None:
+            continue
+        assert p.grad is not None, n
+        assert grad_err(p.grad.cpu().numpy(), sd[n].grad.numpy()) <= 2e-4, n
+    # rsample: gradients reach the flow's parameters
+    flow.zero_grad()
+    flow.rsample(16).square().mean().backward()
+    assert any(p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0 for p in flow.parameters())
 
 
 def test_sampling_entry_points():
