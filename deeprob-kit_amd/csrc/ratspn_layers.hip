@@ -368,7 +368,7 @@ __global__ void leaf_inverse_kernel(const int *__restrict__ feat, const int *__r
 __global__ __launch_bounds__(256) void gaussian_leaf_bwd_x_kernel(
     const float *__restrict__ x, const float *__restrict__ g, int64_t B, int D, int R, int I, int d, int reps,
     const int *__restrict__ inv, const float *__restrict__ loc, const float *__restrict__ scale,
-    float *__restrict__ gx, float drop_p, uint64_t seed) {
+    float *__restrict__ gx, float drop_p, uint64_t seed, int dist) {
     const int64_t total = B * D;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
@@ -384,8 +384,12 @@ __global__ __launch_bounds__(256) void gaussian_leaf_bwd_x_kernel(
                 for (int k = 0; k < I; ++k) {
                     if (drop_p > 0.f && dropout_hit(seed, (((uint64_t)b * R + r) * I + k) * d + j, drop_p)) continue;
                     const int64_t po = ((int64_t)r * I + k) * d + j;
-                    const float sg = scale[po];
-                    acc = fmaf(g[(b * R + r) * I + k], -(xv - loc[po]) / (sg * sg), acc);
+                    if (dist == 0) {
+                        const float sg = scale[po];
+                        acc = fmaf(g[(b * R + r) * I + k], -(xv - loc[po]) / (sg * sg), acc);
+                    } else {   // Bernoulli: d/dx (x l - softplus(l)) = l   (ratspn.py:243, -BCEWithLogits)
+                        acc = fmaf(g[(b * R + r) * I + k], loc[po], acc);
+                    }
                 }
             }
         }
@@ -546,7 +550,6 @@ static int leaf_backward_common(int dist, const float *x, const float *g, int64_
         DPK_CHECK_LAUNCH("leaf_bwd_param_kernel");
     }
     if (gx && B > 0) {
-        DPK_REQUIRE(dist == 0, DPK_EUNSUPPORTED, "leaf_backward: d/dx only for Gaussian leaves");
         // regions per repetition = 2^depth = (D + pad) / d with pad < 2^depth <= D (RegionGraph: depth <= log2 D), i.e.
         // the smallest power of two p with p * d >= D -- NOT ceil(D / d), which is smaller whenever pad >= d
         // (D = 9, depth 3: d = 2, 8 regions, ceil(9/2) = 5)
@@ -563,7 +566,7 @@ static int leaf_backward_common(int dist, const float *x, const float *g, int64_
         hipLaunchKernelGGL(leaf_inverse_kernel, dim3(w.G), dim3(256), 0, st, w.feat, w.srcr, d, w.SP, D, per_rep,
                            inv);
         hipLaunchKernelGGL(gaussian_leaf_bwd_x_kernel, dim3(grid_for(B * D, 256)), dim3(256), 0, st, x, g, B, D,
-                           R, I, d, reps, inv, p0, p1, gx, drop_p, seed);
+                           R, I, d, reps, inv, p0, p1, gx, drop_p, seed, dist);
         DPK_CHECK_LAUNCH("gaussian_leaf_bwd_x_kernel");
     }
     return DPK_OK;
@@ -576,6 +579,17 @@ extern "C" int dpk_gaussian_leaf_backward(const float *x, const float *g, int64_
                                           uint32_t flags, void *stream) {
     return leaf_backward_common(0, x, g, B, D, mask, pad_mask, loc, scale, R, I, d, grad_loc, grad_scale, grad_x,
                                 ws, ws_bytes, flags, stream);
+}
+
+// d/dx of the Bernoulli leaf layer (the reference's autograd returns it, ratspn.py:243): grad_x[b,f] = sum over the
+// (region, position) pairs holding variable f and the channels k of g[b,r,k] * logits[r,k,j]; 0 where x is NaN.
+extern "C" int dpk_bernoulli_leaf_backward_input(const float *x, const float *g, int64_t B, int32_t D,
+                                                 const int64_t *mask, const uint8_t *pad_mask, const float *logits,
+                                                 int32_t R, int32_t I, int32_t d, float *grad_x, void *ws,
+                                                 int64_t ws_bytes, uint32_t flags, void *stream) {
+    DPK_REQUIRE(grad_x, DPK_EINVAL, "bernoulli_leaf_backward_input: null pointer");
+    return leaf_backward_common(1, x, g, B, D, mask, pad_mask, logits, nullptr, R, I, d, nullptr, nullptr, grad_x, ws,
+                                ws_bytes, flags, stream);
 }
 
 extern "C" int dpk_bernoulli_leaf_backward(const float *x, const float *g, int64_t B, int32_t D,

@@ -39,6 +39,8 @@ SIGNATURES = {
                                                   _c_void, _i64, _u32, _c_void]),
     'dpk_bernoulli_leaf_backward': (ctypes.c_int, [_c_void, _c_void, _i64, _i32, _c_void, _c_void, _c_void,
                                                    _i32, _i32, _i32, _c_void, _c_void, _i64, _u32, _c_void]),
+    'dpk_bernoulli_leaf_backward_input': (ctypes.c_int, [_c_void, _c_void, _i64, _i32, _c_void, _c_void, _c_void,
+                                                         _i32, _i32, _i32, _c_void, _c_void, _i64, _u32, _c_void]),
     'dpk_product_forward': (ctypes.c_int, [_c_void, _i64, _i32, _i32, _c_void, _c_void]),
     'dpk_product_backward': (ctypes.c_int, [_c_void, _i64, _i32, _i32, _c_void, _c_void]),
     'dpk_sum_forward': (ctypes.c_int, [_c_void, _c_void, _i64, _i32, _i32, _i32, _c_void, _c_void, _i64,

@@ -134,14 +134,19 @@ class BernoulliLeafFn(torch.autograd.Function):
         lctx = ctx.lctx
         g = require_device_f32(g, 'grad')
         glog = torch.empty_like(logits) if ctx.needs_input_grad[1] else None
-        if ctx.needs_input_grad[0]:
-            raise NotImplementedError("d/dx through Bernoulli leaves is not defined by the reference use")
         ws, flags = lctx.workspace(x.device, mask, pad_mask)
         check(lib.dpk_bernoulli_leaf_backward(ptr(x), ptr(g), x.shape[0], lctx.D, ptr(mask),
                                               ptr(_pad_u8(pad_mask)), ptr(logits), lctx.R, lctx.I, lctx.d,
                                               ptr(glog), ptr(ws), ws.numel(), flags, stream_ptr(x.device)),
               'dpk_bernoulli_leaf_backward')
-        return None, glog, None, None, None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            check(lib.dpk_bernoulli_leaf_backward_input(ptr(x), ptr(g), x.shape[0], lctx.D, ptr(mask),
+                                                        ptr(_pad_u8(pad_mask)), ptr(logits), lctx.R, lctx.I, lctx.d,
+                                                        ptr(gx), ptr(ws), ws.numel(), flags | DPK_FLAG_STRUCT_CACHED,
+                                                        stream_ptr(x.device)), 'dpk_bernoulli_leaf_backward_input')
+        return gx, glog, None, None, None
 
 
 def draw_seed() -> int:

@@ -13,7 +13,16 @@
  *   - every pointer is a DEVICE pointer (hipMalloc / torch CUDA storage),
  *     fp32 tensors are contiguous row-major, last index fastest;
  *   - `stream` is a hipStream_t passed as void*; kernels are enqueued
- *     asynchronously on it, nothing here synchronises or allocates;
+ *     asynchronously on it and no entry point synchronises the device or the
+ *     stream.  No device memory is allocated behind the caller's back.  Process
+ *     state beyond the thread-local error string, all of it created lazily and
+ *     once: (a) dpk_ratspn_forward's VALU route keeps ONE 64-byte host-mapped
+ *     word (hipHostMalloc) in which a kernel that met marginalised evidence
+ *     leaves the launch number -- a speed hint only, read without waiting: a
+ *     stale value never changes results; (b) the kernels that need more than
+ *     64 KB of LDS set hipFuncAttributeMaxDynamicSharedMemorySize on first use
+ *     and cache the device's compute-unit count; (c) dpk_profile_next_kernel
+ *     arms a thread-local, one-shot pair of events;
  *   - scratch memory is handed in by the caller (`ws`, `ws_bytes`); the
  *     matching *_workspace_bytes() query gives the required size;
  *   - the return value is 0 on success and a negative DPK_E* code otherwise;
@@ -101,6 +110,12 @@ int dpk_bernoulli_leaf_backward(const float *x, const float *g, int64_t B, int32
                                 const float *logits, int32_t R, int32_t I, int32_t d,
                                 float *grad_logits, void *ws, int64_t ws_bytes, uint32_t flags,
                                 void *stream);
+
+/* d/dx of the Bernoulli leaf layer (ratspn.py:243 through autograd): grad_x [B, D], 0 at marginalised inputs. */
+int dpk_bernoulli_leaf_backward_input(const float *x, const float *g, int64_t B, int32_t D,
+                                      const int64_t *mask, const uint8_t *pad_mask, const float *logits,
+                                      int32_t R, int32_t I, int32_t d, float *grad_x, void *ws,
+                                      int64_t ws_bytes, uint32_t flags, void *stream);
 
 /* ProductLayer.forward (ratspn.py:272-286): in [B,R,N] -> out [B,R/2,N*N],
  * out[b,p,i*N+j] = in[b,2p,i] + in[b,2p+1,j].                                */

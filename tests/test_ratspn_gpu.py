@@ -533,3 +533,55 @@ def test_input_gradient_with_heavily_padded_region_graphs(D, depth, reps):
     xg = x.cuda().requires_grad_(True)
     model(xg).sum().backward()
     assert grad_err(xg.grad.cpu().numpy(), xo.grad.numpy()) <= GRAD_TOL
+
+
+def test_bernoulli_input_gradient(golden):
+    """d/dx through Bernoulli leaves (the reference's autograd returns it: -BCEWithLogits is linear in x, ratspn.py:243),
+    against the oracle's autograd in fp64; marginalised (NaN) inputs get zero gradient."""
+    from deeprob.spn.models import BernoulliRatSpn
+    g = golden('ratspn_bernoulli_15_d3_r4_i4_s2')
+    model = BernoulliRatSpn(15, rg_depth=3, rg_repetitions=4, rg_batch=4, rg_sum=2, random_state=42)
+    state_to_model(model, g, 'cuda').eval()
+    x = torch.rand(41, 15, generator=torch.Generator().manual_seed(6))
+    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in orc.state_from_npz(g).items()}
+    xo = x.double().requires_grad_(True)
+    orc.ratspn_forward(sd, xo).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    model(xg).sum().backward()
+    assert grad_err(xg.grad.cpu().numpy(), xo.grad.numpy()) <= GRAD_TOL
+    xn = x.clone()
+    xn[3, 4] = float('nan')
+    xg = xn.cuda().requires_grad_(True)
+    model(xg).sum().backward()
+    assert xg.grad[3, 4].item() == 0.0 and torch.isfinite(xg.grad).all()
+
+
+def test_backward_wide_model_vs_oracle(golden):
+    """(16,16) backward: the reference-generated fixture of this model ships no gradients (171 k parameters), so the
+    check is against the oracle's fp64 autograd -- the oracle itself is pinned to reference gradients on the other
+    models (tests/test_oracle_ratspn.py).  Tolerance as in test_backward_golden: GRAD_TOL, widened to the fp32
+    restatement's own distance from fp64 (the log-softmax Jacobian of the 2048 root weights cancels)."""
+    model, g = build('ratspn_g784_d2_r8_i16_s16', golden)
+    x = torch.from_numpy(g['x'][:8])
+    names = [k for k, p in model.named_parameters() if p.requires_grad]
+
+    def oracle(dtype):
+        sd = orc.state_from_npz(g, dtype=dtype)
+        for k in names:
+            sd[k] = sd[k].clone().requires_grad_(True)
+        xo = x.to(dtype).clone().requires_grad_(True)
+        with torch.enable_grad():
+            orc.ratspn_loss(orc.ratspn_forward(sd, xo), None).backward()
+        out = {k: sd[k].grad.double().numpy() for k in names}
+        out['x'] = xo.grad.double().numpy()
+        return out
+
+    ref64, ref32 = oracle(torch.float64), oracle(torch.float32)
+    xg = x.cuda().requires_grad_(True)
+    with torch.enable_grad():
+        model.loss(model(xg)).backward()
+    got = {k: p.grad.cpu().numpy() for k, p in model.named_parameters() if p.requires_grad}
+    got['x'] = xg.grad.cpu().numpy()
+    for k in got:
+        tol = max(GRAD_TOL, 4.0 * grad_err(ref32[k], ref64[k]))
+        assert grad_err(got[k], ref64[k]) <= tol, k
