@@ -631,6 +631,48 @@ extern "C" int dpk_affine1d_forward(const float *x, const float *scale, const fl
     return DPK_OK;
 }
 
+// LogitLayer (deeprob/flows/utils.py:257-294), one pass: a wave per row.
+//   density direction (apply_backward): p = alpha + (1 - 2 alpha) x, u = log p - log(1 - p),
+//                                       ildj = -(sum_d (log p + log(1 - p)) + ldj_const)
+//   sampling direction (apply_forward): p = sigmoid(u), x = (p - alpha) / (1 - 2 alpha),
+//                                       ldj = sum_d (log p + log(1 - p)) + ldj_const
+__global__ __launch_bounds__(256) void logit1d_kernel(const float *__restrict__ x, int64_t B, int D, float alpha,
+                                                      float ldj_const, int inverse, float *__restrict__ out,
+                                                      float *__restrict__ ldj) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float *xr = x + b * D;
+    float *orow = out + b * D;
+    float acc = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float v = xr[d];
+        if (!inverse) {
+            const float p = alpha + (1.0f - 2.0f * alpha) * v;
+            const float lp = logf(p), lq = logf(1.0f - p);
+            orow[d] = lp - lq;
+            acc += lp + lq;
+        } else {
+            const float p = 1.0f / (1.0f + expf(-v));
+            orow[d] = (p - alpha) / (1.0f - 2.0f * alpha);
+            acc += logf(p) + logf(1.0f - p);
+        }
+    }
+    acc = wave_reduce_sum(acc);
+    if (lane == 0) ldj[b] = inverse ? (acc + ldj_const) : -(acc + ldj_const);
+}
+
+extern "C" int dpk_logit1d_forward(const float *x, int64_t B, int32_t D, float alpha, float ldj_const, int32_t inverse,
+                                   float *out, float *ldj, void *stream) {
+    DPK_REQUIRE(B >= 0 && D > 0 && alpha > 0.f && alpha < 1.f, DPK_EINVAL, "logit1d: bad arguments");
+    if (B == 0) return DPK_OK;
+    DPK_REQUIRE(x && out && ldj, DPK_EINVAL, "logit1d: null pointer");
+    hipLaunchKernelGGL(logit1d_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, x, B, D, alpha, ldj_const,
+                       inverse, out, ldj);
+    DPK_CHECK_LAUNCH("logit1d_kernel");
+    return DPK_OK;
+}
+
 extern "C" int dpk_normal_base_logprob(const float *u, const float *scale_in, const float *shift_in,
                                        const float *loc, const float *scale, const float *ildj,
                                        const float *ildj_const, int64_t B, int32_t D, float *out, void *stream) {

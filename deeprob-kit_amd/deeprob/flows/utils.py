@@ -114,8 +114,29 @@ class LogitLayer(Bijector):
         self.alpha = alpha
         dims = np.prod(self.in_features)
         self.register_buffer('ldj', torch.tensor(-dims * np.log(1.0 - 2.0 * self.alpha), dtype=torch.float32))
+        self._ldj_host = None
+
+    def _hip(self, x: torch.Tensor, inverse: bool):
+        """One HIP pass when no autograd graph through the layer is wanted (the input is data): the layer has no
+        parameters, so only an input that requires grad keeps the element-wise torch route."""
+        if not (x.is_cuda and x.dtype == torch.float32) or (torch.is_grad_enabled() and x.requires_grad):
+            return None
+        from deeprob.hip import load_library, check, ptr, stream_ptr
+        xc = x.contiguous()
+        n = xc.shape[0]
+        out = torch.empty_like(xc)
+        ldj = torch.empty(n, dtype=torch.float32, device=xc.device)
+        if self._ldj_host is None:
+            self._ldj_host = float(-np.prod(self.in_features) * np.log(1.0 - 2.0 * self.alpha))
+        check(load_library().dpk_logit1d_forward(ptr(xc), n, xc.numel() // max(n, 1) if n else 1, float(self.alpha),
+                                                 self._ldj_host, int(inverse), ptr(out), ptr(ldj),
+                                                 stream_ptr(xc.device)), 'dpk_logit1d_forward')
+        return out, ldj
 
     def apply_backward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        r = self._hip(x, False)
+        if r is not None:
+            return r
         n = x.shape[0]
         p = self.alpha + (1.0 - 2.0 * self.alpha) * x
         log_p, log_q = torch.log(p), torch.log(1.0 - p)
@@ -123,6 +144,9 @@ class LogitLayer(Bijector):
         return log_p - log_q, -ldj
 
     def apply_forward(self, u: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        r = self._hip(u, True)
+        if r is not None:
+            return r
         n = u.shape[0]
         p = torch.sigmoid(u)
         x = (p - self.alpha) / (1.0 - 2.0 * self.alpha)

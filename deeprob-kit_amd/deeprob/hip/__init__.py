@@ -67,6 +67,8 @@ SIGNATURES = {
     'dpk_bn1d_fold': (ctypes.c_int, [_c_void, _c_void, _c_void, _c_void, ctypes.c_float, _i32, _i32, _c_void,
                                      _c_void, _c_void, _c_void, _c_void, _i32, _c_void]),
     'dpk_affine1d_forward': (ctypes.c_int, [_c_void, _c_void, _c_void, _i64, _i32, _c_void, _c_void]),
+    'dpk_logit1d_forward': (ctypes.c_int, [_c_void, _i64, _i32, ctypes.c_float, ctypes.c_float, _i32, _c_void, _c_void,
+                                           _c_void]),
     'dpk_normal_base_logprob': (ctypes.c_int, [_c_void, _c_void, _c_void, _c_void, _c_void, _c_void, _c_void,
                                                _i64, _i32, _c_void, _c_void]),
     'dpk_spatial_gaussian_forward': (ctypes.c_int, [_c_void, _c_void, _c_void, _i64, _i32, _i32, _i32, _i32,

@@ -215,6 +215,11 @@ int dpk_bn1d_fold(const float *weight, const float *bias, const float *running_v
 /* out[b,d] = x[b,d]*scale[d] + shift[d]  (materialises a folded BatchNormLayer1d). */
 int dpk_affine1d_forward(const float *x, const float *scale, const float *shift, int64_t B, int32_t D,
                          float *out, void *stream);
+/* LogitLayer.apply_backward (inverse = 0) / apply_forward (1) in one pass (deeprob/flows/utils.py:276-294):
+ * x [B, D] (any trailing shape flattened to D), out [B, D], ldj [B] overwritten; ldj_const = the layer's `ldj`
+ * buffer, -D log(1 - 2 alpha).                                                                        */
+int dpk_logit1d_forward(const float *x, int64_t B, int32_t D, float alpha, float ldj_const, int32_t inverse,
+                        float *out, float *ldj, void *stream);
 /* NormalizingFlow.forward tail with the default Normal base (flows/models/base.py:139-143):
  * out[b] = sum_d log N(u[b,d]*scale_in[d]+shift_in[d]; loc[d], scale[d]) + ildj[b] + ildj_const.
  * scale_in/shift_in, ildj, ildj_const may be NULL.                                     */
