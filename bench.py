@@ -227,7 +227,7 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
 
     # ---- BASELINE config 2: RAT-SPN, B = 4096 (constructor defaults + the two wider settings) ----------
     B = 4096
-    # bytes / flops per sample: fully fused 4*(784+1); (16,16) runs as leaf | prod+sum | prod+root
+    # bytes / flops per sample: fully fused 4*(784+1); (8,8) and (16,16) run as leaf | prod+sum | prod+root
     rat = {(2, 2): (3140, 50.6e3), (8, 8): (3140, 219.6e3), (16, 16): (9284, 542.7e3)}
     for (I, S), (alg, fl) in rat.items():
         torch.manual_seed(0)
@@ -235,7 +235,7 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
         sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
         m.to(dev)
         xs = [torch.randn(B, D, device=dev) for _ in range(4)]
-        kid = KERNEL_FUSED if I <= 8 else KERNEL_LEAF
+        kid = KERNEL_FUSED if I < 8 else KERNEL_LEAF   # rg_batch 8 and 16 run leaf | prod+sum | prod+root on the MFMA
         ms, k_ms = _time_eval(m, xs, timer, kid, steps=50)
         n_cpu = 4096 if I <= 8 else 1024
         xc = torch.randn(n_cpu, D)
@@ -244,7 +244,7 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
                          'model(x) under no_grad'.format(I, S),
              'config': 'BASELINE config 2', 'batch': B, 'ms_per_step': ms, 'value': B / ms * 1e3,
              'unit': 'log-likelihoods/sec', 'kernel_ms': k_ms,
-             'kernel': 'fused forward' if I <= 8 else 'leaf kernel (then prod+sum, prod+root kernels)',
+             'kernel': 'fused forward' if I < 8 else 'leaf MFMA kernel (then the prod+sum and prod+root MFMA kernels)',
              'roofline': hbm(B * alg, ms) if I <= 8 else flops(B * fl, ms, 'valu'),
              'roofline_basis': 'whole step; {} algorithmic B/sample'.format(alg) if I <= 8
                                else 'whole step; {:.0f} flop/sample on the fp32 VALU (SURVEY 8d: VALU-bound)'.format(fl),
@@ -445,7 +445,9 @@ def main():
             'config': {'workload': 'GaussianRatSpn(784, rg_depth=2, rg_repetitions=8, rg_batch={}, rg_sum={}) '
                                    'forward log-likelihood, {} samples per GPU per step, mean LL reduced on '
                                    'device{}'.format(args.rg_batch, args.rg_sum, B,
-                                                     ' + RCCL all-reduce' if world > 1 else ''),
+                                                     ' + {} all-reduce of {{sum, count}} once per run'.format(
+                                                         'RCCL' if args.backend == 'nccl' else args.backend)
+                                                     if world > 1 else ''),
                        'global_batch': B * world, 'resident_batches': ring, 'mean_ll': mean_ll,
                        'host_enqueue_ms_per_step': host_dt / args.steps * 1e3,
                        'arithmetic': 'fp32 results; the leaf-layer GEMM runs as three f16 MFMAs on two-way f16 splits '

@@ -30,6 +30,15 @@ void profile_take(hipEvent_t *start, hipEvent_t *stop, int kernel_id = 1);
         }                                                                           \
     } while (0)
 
+// A launch reports its own status: whatever an earlier runtime call on this thread (the caller's own included, e.g. a
+// failed hipEventElapsedTime) left in the last-error slot is dropped first, so DPK_CHECK_LAUNCH never blames a kernel
+// for it.
+#define DPK_LAUNCH(...)                    \
+    do {                                   \
+        (void)hipGetLastError();           \
+        hipLaunchKernelGGL(__VA_ARGS__);   \
+    } while (0)
+
 constexpr int kWave = 64;           // CDNA wavefront
 constexpr int kCompactRec = 48;      // bytes of a compact block record: 8 means + 4 u16 row offsets + pad
 constexpr float kExpandBound = 6.0f; // |x|, |mu| bound under which the unit-scale leaf uses the expanded square

@@ -564,10 +564,10 @@ extern "C" int dpk_coupling1d_forward(const float *x, int64_t B, int32_t D, cons
                 (long long)ws_bytes, (long long)w.bytes + 256);
     int *bad = (int *)((char *)ws + w.bytes);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(coupling_index_kernel, dim3(1), dim3(64), 0, st, mask, inv_mask, D, w.K1p, w.N2p, w.kidx,
+    DPK_LAUNCH(coupling_index_kernel, dim3(1), dim3(64), 0, st, mask, inv_mask, D, w.K1p, w.N2p, w.kidx,
                        w.nidx, bad);
     const int64_t n_pack = (int64_t)units * w.K1p + (int64_t)w.N2p * units + w.N2p;
-    hipLaunchKernelGGL(coupling_pack_kernel, dim3(cdiv(n_pack, 256) > 2048 ? 2048 : cdiv(n_pack, 256)), dim3(256),
+    DPK_LAUNCH(coupling_pack_kernel, dim3(cdiv(n_pack, 256) > 2048 ? 2048 : cdiv(n_pack, 256)), dim3(256),
                        0, st, W1, W2, b2, w.kidx, w.nidx, D, units, w.K1p, w.N2p, affine, w.w1p, w.w2tp, w.w2sp,
                        w.b2tp, w.b2sp);
     DPK_CHECK_LAUNCH("coupling_pack_kernel");
@@ -587,7 +587,7 @@ extern "C" int dpk_coupling1d_forward(const float *x, int64_t B, int32_t D, cons
         hipEvent_t ev0, ev1;
         profile_take(&ev0, &ev1, DPK_KERNEL_COUPLING1D);
         if (ev0) (void)hipEventRecord(ev0, st);
-        hipLaunchKernelGGL(coupling1d_kernel<true>, dim3(grid), dim3(kCWaves * 64), lds, st, a);
+        DPK_LAUNCH(coupling1d_kernel<true>, dim3(grid), dim3(kCWaves * 64), lds, st, a);
         if (ev1) (void)hipEventRecord(ev1, st);
     } else {
         if (lds > 64 * 1024)
@@ -596,7 +596,7 @@ extern "C" int dpk_coupling1d_forward(const float *x, int64_t B, int32_t D, cons
         hipEvent_t ev0, ev1;
         profile_take(&ev0, &ev1, DPK_KERNEL_COUPLING1D);
         if (ev0) (void)hipEventRecord(ev0, st);
-        hipLaunchKernelGGL(coupling1d_kernel<false>, dim3(grid), dim3(kCWaves * 64), lds, st, a);
+        DPK_LAUNCH(coupling1d_kernel<false>, dim3(grid), dim3(kCWaves * 64), lds, st, a);
         if (ev1) (void)hipEventRecord(ev1, st);
     }
     DPK_CHECK_LAUNCH("coupling1d_kernel");
@@ -610,7 +610,7 @@ extern "C" int dpk_bn1d_fold(const float *weight, const float *bias, const float
     DPK_REQUIRE(weight && bias && running_var && running_mean && scale_out && shift_out && ldj_const, DPK_EINVAL,
                 "bn1d_fold: null pointer");
     DPK_REQUIRE(D > 0 && (scale_in == nullptr) == (shift_in == nullptr), DPK_EINVAL, "bn1d_fold: bad arguments");
-    hipLaunchKernelGGL(bn1d_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, weight, bias, running_var,
+    DPK_LAUNCH(bn1d_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, weight, bias, running_var,
                        running_mean, eps, D, inverse, scale_in, shift_in, scale_out, shift_out, ldj_const,
                        accumulate);
     DPK_CHECK_LAUNCH("bn1d_fold_kernel");
@@ -625,7 +625,7 @@ extern "C" int dpk_affine1d_forward(const float *x, const float *scale, const fl
     const int64_t total = B * D;
     int grid = cdiv(total, 256);
     if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(affine1d_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, scale, shift, total, D,
+    DPK_LAUNCH(affine1d_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, scale, shift, total, D,
                        out);
     DPK_CHECK_LAUNCH("affine1d_kernel");
     return DPK_OK;
@@ -667,7 +667,7 @@ extern "C" int dpk_logit1d_forward(const float *x, int64_t B, int32_t D, float a
     DPK_REQUIRE(B >= 0 && D > 0 && alpha > 0.f && alpha < 1.f, DPK_EINVAL, "logit1d: bad arguments");
     if (B == 0) return DPK_OK;
     DPK_REQUIRE(x && out && ldj, DPK_EINVAL, "logit1d: null pointer");
-    hipLaunchKernelGGL(logit1d_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, x, B, D, alpha, ldj_const,
+    DPK_LAUNCH(logit1d_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, x, B, D, alpha, ldj_const,
                        inverse, out, ldj);
     DPK_CHECK_LAUNCH("logit1d_kernel");
     return DPK_OK;
@@ -682,7 +682,7 @@ extern "C" int dpk_normal_base_logprob(const float *u, const float *scale_in, co
     DPK_REQUIRE((scale_in == nullptr) == (shift_in == nullptr), DPK_EINVAL, "normal_base_logprob: scale/shift");
     const size_t lds = (size_t)(2 * ((D + 3) & ~3) + 4) * sizeof(float);
     DPK_REQUIRE(lds <= 64 * 1024, DPK_EUNSUPPORTED, "normal_base_logprob: D=%d above the on-chip parameter table", D);
-    hipLaunchKernelGGL(normal_base_logprob_kernel, dim3(cdiv(B, 4 * kBaseRows)), dim3(256), lds, (hipStream_t)stream,
+    DPK_LAUNCH(normal_base_logprob_kernel, dim3(cdiv(B, 4 * kBaseRows)), dim3(256), lds, (hipStream_t)stream,
                        u, scale_in, shift_in, loc, scale, ildj, ildj_const, B, D, out);
     DPK_CHECK_LAUNCH("normal_base_logprob_kernel");
     return DPK_OK;

@@ -125,10 +125,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 
 static void launch_gemm_kernel(const GemmArgs &g, dim3 grid, hipStream_t st) {
     const bool ak = g.sak == 1, bn = g.sbn == 1;   // any other stride pair runs as the "slow axis" orientation
-    if (ak && bn) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, g);
-    else if (ak) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, g);
-    else if (bn) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, g);
+    if (ak && bn) DPK_LAUNCH((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, g);
+    else if (ak) DPK_LAUNCH((gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, g);
+    else if (bn) DPK_LAUNCH((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, g);
+    else DPK_LAUNCH((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, g);
 }
 
 // bias / ReLU / gate of a split-K product (the per-column scale was applied to the partial sums; with a bias the
@@ -169,7 +169,7 @@ static void launch_gemm(const GemmArgs &g_in, hipStream_t st) {
         if (g.bias || g.relu || g.gate) {
             const int64_t total = (int64_t)g.M * g.N;
             const int64_t nb = (total + 255) / 256;
-            hipLaunchKernelGGL(gemm_epilogue_kernel, dim3((int)(nb > 4096 ? 4096 : nb)), dim3(256), 0, st, g);
+            DPK_LAUNCH(gemm_epilogue_kernel, dim3((int)(nb > 4096 ? 4096 : nb)), dim3(256), 0, st, g);
         }
         return;
     }
@@ -593,7 +593,7 @@ extern "C" int dpk_coupling1d_backward(const float *x, int64_t B, int32_t D, con
     g.C = Z; g.ldc = zc; g.M = (int)B; g.N = zc; g.K = units; g.bias = b2;
     launch_gemm(g, st);
     // element-wise core: Z <- dZ, grad_x <- direct term
-    hipLaunchKernelGGL(coupling_bwd_elem_kernel, dim3(grid1d(B * D, 256, 1024)), dim3(256), 0, st, x, Z, inv_mask, act_weight,
+    DPK_LAUNCH(coupling_bwd_elem_kernel, dim3(grid1d(B * D, 256, 1024)), dim3(256), 0, st, x, Z, inv_mask, act_weight,
                        grad_u, grad_ildj, B, D, affine, 0, grad_x, grad_act);
     // dW2 = dZ^T H, db2 = colsum(dZ)
     if (grad_W2) {
@@ -603,7 +603,7 @@ extern "C" int dpk_coupling1d_backward(const float *x, int64_t B, int32_t D, con
         g.C = grad_W2; g.ldc = units; g.M = zc; g.N = units; g.K = (int)B;
         launch_gemm(g, st);
     }
-    if (grad_b2) hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(zc, kRC)), dim3(kRThreads), 0, st, Z, B, zc, (int64_t)zc, grad_b2);
+    if (grad_b2) DPK_LAUNCH(colsum_kernel, dim3(cdiv(zc, kRC)), dim3(kRThreads), 0, st, Z, B, zc, (int64_t)zc, grad_b2);
     // dH = (dZ W2) * [H > 0]
     g = GemmArgs{};
     g.A = Z; g.sam = zc; g.sak = 1;
@@ -619,7 +619,7 @@ extern "C" int dpk_coupling1d_backward(const float *x, int64_t B, int32_t D, con
         launch_gemm(g, st);
     }
     if (grad_b1)
-        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(units, kRC)), dim3(kRThreads), 0, st, dH, B, units, (int64_t)units, grad_b1);
+        DPK_LAUNCH(colsum_kernel, dim3(cdiv(units, kRC)), dim3(kRThreads), 0, st, dH, B, units, (int64_t)units, grad_b1);
     // grad_x += mask * (dH W1)
     g = GemmArgs{};
     g.A = dH; g.sam = units; g.sak = 1;
@@ -644,7 +644,7 @@ extern "C" int dpk_bn1d_train_forward(const float *x, int64_t B, int32_t D, cons
     hipStream_t st = (hipStream_t)stream;
     float *sc = (float *)ws, *sh = sc + D;
     DPK_REQUIRE(hipMemsetAsync(ildj_const, 0, 4, st) == hipSuccess, DPK_ELAUNCH, "memset");
-    hipLaunchKernelGGL(bn1d_stats_kernel, dim3(cdiv(D, kRC)), dim3(kRThreads), 0, st, x, B, D, weight, bias, momentum, eps,
+    DPK_LAUNCH(bn1d_stats_kernel, dim3(cdiv(D, kRC)), dim3(kRThreads), 0, st, x, B, D, weight, bias, momentum, eps,
                        running_var, running_mean, save_mean, save_var, sc, sh, ildj_const);
     DPK_CHECK_LAUNCH("bn1d_stats_kernel");
     return dpk_affine1d_forward(x, sc, sh, B, D, out, stream);
@@ -662,10 +662,10 @@ extern "C" int dpk_bn1d_backward(const float *x, const float *grad_u, const floa
     DPK_REQUIRE(ws_bytes >= (int64_t)(2 * D + 64) * 4, DPK_EWORKSPACE, "bn1d_backward: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float *s1 = (float *)ws, *s2 = s1 + D, *sg = s2 + D;
-    if (grad_ildj) hipLaunchKernelGGL(vecsum_kernel, dim3(1), dim3(256), 0, st, grad_ildj, B, sg);
-    hipLaunchKernelGGL(bn1d_bwd_reduce_kernel, dim3(cdiv(D, kRC)), dim3(kRThreads), 0, st, x, grad_u, B, D, mean, var, eps, s1,
+    if (grad_ildj) DPK_LAUNCH(vecsum_kernel, dim3(1), dim3(256), 0, st, grad_ildj, B, sg);
+    DPK_LAUNCH(bn1d_bwd_reduce_kernel, dim3(cdiv(D, kRC)), dim3(kRThreads), 0, st, x, grad_u, B, D, mean, var, eps, s1,
                        s2);
-    hipLaunchKernelGGL(bn1d_bwd_apply_kernel, dim3(grid1d(B * D)), dim3(256), 0, st, x, grad_u,
+    DPK_LAUNCH(bn1d_bwd_apply_kernel, dim3(grid1d(B * D)), dim3(256), 0, st, x, grad_u,
                        grad_ildj ? sg : nullptr, B, D, weight, mean, var, eps, s1, s2, train, grad_x, grad_weight,
                        grad_bias);
     DPK_CHECK_LAUNCH("bn1d_backward");
@@ -676,7 +676,7 @@ extern "C" int dpk_bn1d_backward(const float *x, const float *grad_u, const floa
 // ---- batch-sharded BatchNormLayer1d (see the kernels above) ------------------------------------------------
 extern "C" int dpk_bn1d_local_moments(const float *x, int64_t B, int32_t D, float *moments, void *stream) {
     DPK_REQUIRE(B >= 0 && D > 0 && moments && (B == 0 || x), DPK_EINVAL, "bn1d_local_moments: bad arguments");
-    hipLaunchKernelGGL(bn1d_local_moments_kernel, dim3(cdiv(D, kRC)), dim3(kRThreads), 0, (hipStream_t)stream, x, B, D,
+    DPK_LAUNCH(bn1d_local_moments_kernel, dim3(cdiv(D, kRC)), dim3(kRThreads), 0, (hipStream_t)stream, x, B, D,
                        moments);
     DPK_CHECK_LAUNCH("bn1d_local_moments_kernel");
     return DPK_OK;
@@ -695,7 +695,7 @@ extern "C" int dpk_bn1d_sync_forward(const float *x, int64_t B, int32_t D, const
     hipStream_t st = (hipStream_t)stream;
     float *sc = (float *)ws, *sh = sc + D;
     DPK_REQUIRE(hipMemsetAsync(ildj_const, 0, 4, st) == hipSuccess, DPK_ELAUNCH, "memset");
-    hipLaunchKernelGGL(bn1d_combine_kernel, dim3(cdiv(D, 1024)), dim3(1024), 0, st, gathered, world, D, weight, bias,
+    DPK_LAUNCH(bn1d_combine_kernel, dim3(cdiv(D, 1024)), dim3(1024), 0, st, gathered, world, D, weight, bias,
                        momentum, eps, running_var, running_mean, save_mean, save_var, sc, sh, ildj_const);
     DPK_CHECK_LAUNCH("bn1d_combine_kernel");
     if (B == 0) return DPK_OK;
@@ -708,8 +708,8 @@ extern "C" int dpk_bn1d_backward_sums(const float *x, const float *grad_u, const
                 "bn1d_backward_sums: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     if (B == 0 || !grad_ildj) DPK_REQUIRE(hipMemsetAsync(sums + 2 * D, 0, 4, st) == hipSuccess, DPK_ELAUNCH, "memset");
-    if (B > 0 && grad_ildj) hipLaunchKernelGGL(vecsum_kernel, dim3(1), dim3(256), 0, st, grad_ildj, B, sums + 2 * D);
-    hipLaunchKernelGGL(bn1d_bwd_reduce_kernel, dim3(cdiv(D, kRC)), dim3(kRThreads), 0, st, x, grad_u, B, D, mean, var, eps,
+    if (B > 0 && grad_ildj) DPK_LAUNCH(vecsum_kernel, dim3(1), dim3(256), 0, st, grad_ildj, B, sums + 2 * D);
+    DPK_LAUNCH(bn1d_bwd_reduce_kernel, dim3(cdiv(D, kRC)), dim3(kRThreads), 0, st, x, grad_u, B, D, mean, var, eps,
                        sums, sums + D);
     DPK_CHECK_LAUNCH("bn1d_backward_sums");
     return DPK_OK;
@@ -723,7 +723,7 @@ extern "C" int dpk_bn1d_sync_backward(const float *x, const float *grad_u, int64
                     (B == 0 || (x && grad_u && grad_x)),
                 DPK_EINVAL, "bn1d_sync_backward: bad arguments");
     const int64_t work = B * D > D ? B * D : D;
-    hipLaunchKernelGGL(bn1d_sync_bwd_apply_kernel, dim3(grid1d(work)), dim3(256), 0, (hipStream_t)stream, x, grad_u, B,
+    DPK_LAUNCH(bn1d_sync_bwd_apply_kernel, dim3(grid1d(work)), dim3(256), 0, (hipStream_t)stream, x, grad_u, B,
                        B_total, D, weight, mean, var, eps, sums_x, sums_p, grad_x, grad_weight, grad_bias);
     DPK_CHECK_LAUNCH("bn1d_sync_bwd_apply_kernel");
     return DPK_OK;
@@ -756,11 +756,11 @@ extern "C" int dpk_bn1d_inverse_backward(const float *u, const float *grad_x, co
     float *s1 = (float *)ws, *s2 = s1 + D, *G = s2 + D, *ones = G + D, *zero = ones + D, *sg = zero + D;
     // column sums of g and g (u - bias): the reducer of the forward direction with mean := bias, 1 / sqrt(var + eps) := 1
     DPK_REQUIRE(hipMemsetAsync(zero, 0, (size_t)D * 4, st) == hipSuccess, DPK_ELAUNCH, "memset");
-    hipLaunchKernelGGL(fill_kernel, dim3(cdiv(D, 256)), dim3(256), 0, st, ones, 1.0f, (int64_t)D);
-    if (grad_ldj) hipLaunchKernelGGL(vecsum_kernel, dim3(1), dim3(256), 0, st, grad_ldj, B, sg);
-    hipLaunchKernelGGL(bn1d_bwd_reduce_kernel, dim3(cdiv(D, kRC)), dim3(kRThreads), 0, st, u, grad_x, B, D, bias, ones, 0.f,
+    DPK_LAUNCH(fill_kernel, dim3(cdiv(D, 256)), dim3(256), 0, st, ones, 1.0f, (int64_t)D);
+    if (grad_ldj) DPK_LAUNCH(vecsum_kernel, dim3(1), dim3(256), 0, st, grad_ldj, B, sg);
+    DPK_LAUNCH(bn1d_bwd_reduce_kernel, dim3(cdiv(D, kRC)), dim3(kRThreads), 0, st, u, grad_x, B, D, bias, ones, 0.f,
                        s1, s2);
-    hipLaunchKernelGGL(bn1d_inverse_bwd_finish_kernel, dim3(cdiv(D, 256)), dim3(256), 0, st, weight, running_var, eps, D,
+    DPK_LAUNCH(bn1d_inverse_bwd_finish_kernel, dim3(cdiv(D, 256)), dim3(256), 0, st, weight, running_var, eps, D,
                        s1, s2, grad_ldj ? sg : nullptr, G, grad_weight, grad_bias);
     DPK_CHECK_LAUNCH("bn1d_inverse_backward");
     return dpk_affine1d_forward(grad_x, G, zero, B, D, grad_u, stream);
@@ -772,7 +772,7 @@ extern "C" int dpk_normal_base_backward(const float *u, const float *loc, const 
     DPK_REQUIRE(B >= 0 && D > 0, DPK_EINVAL, "normal_base_backward: bad sizes");
     if (B == 0) return DPK_OK;
     DPK_REQUIRE(u && loc && scale && g && grad_u, DPK_EINVAL, "normal_base_backward: null pointer");
-    hipLaunchKernelGGL(normal_base_bwd_kernel, dim3(grid1d(B * D)), dim3(256), 0, (hipStream_t)stream, u, loc, scale, g,
+    DPK_LAUNCH(normal_base_bwd_kernel, dim3(grid1d(B * D)), dim3(256), 0, (hipStream_t)stream, u, loc, scale, g,
                        B, D, grad_u);
     DPK_CHECK_LAUNCH("normal_base_bwd_kernel");
     return DPK_OK;
@@ -862,7 +862,7 @@ extern "C" int dpk_coupling1d_mlp_forward(const float *x, int64_t B, int32_t D, 
     DPK_REQUIRE(x && out && ldj, DPK_EINVAL, "coupling1d_mlp_forward: null pointer");
     hipStream_t st = (hipStream_t)stream;
     mlp_forward(w, x, B, D, mask, n_hidden, W, b, widths, st);
-    hipLaunchKernelGGL(coupling_fwd_elem_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, x, w.Z, inv_mask, act_weight, B, D,
+    DPK_LAUNCH(coupling_fwd_elem_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, x, w.Z, inv_mask, act_weight, B, D,
                        affine, inverse, out, ldj);
     DPK_CHECK_LAUNCH("coupling1d_mlp_forward");
     return DPK_OK;
@@ -895,7 +895,7 @@ static int mlp_backward_dir(const float *x, int64_t B, int32_t D, const float *m
     }
     DPK_REQUIRE(x && grad_x && (grad_u || grad_ildj), DPK_EINVAL, "coupling1d_mlp_backward: null pointer");
     if (!ws_holds_forward) mlp_forward(w, x, B, D, mask, n_hidden, W, b, widths, st);
-    hipLaunchKernelGGL(coupling_bwd_elem_kernel, dim3(grid1d(B * D, 256, 1024)), dim3(256), 0, st, x, w.Z, inv_mask, act_weight,
+    DPK_LAUNCH(coupling_bwd_elem_kernel, dim3(grid1d(B * D, 256, 1024)), dim3(256), 0, st, x, w.Z, inv_mask, act_weight,
                        grad_u, grad_ildj, B, D, affine, inverse, grad_x, grad_act);
     // back through the layers: dOut starts as dZ (in w.Z)
     float *dout = w.Z;
@@ -913,7 +913,7 @@ static int mlp_backward_dir(const float *x, int64_t B, int32_t D, const float *m
             launch_gemm(g, st);
         }
         if (grad_b && grad_b[i])
-            hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(ow, kRC)), dim3(kRThreads), 0, st, dout, B, ow, (int64_t)ow, grad_b[i]);
+            DPK_LAUNCH(colsum_kernel, dim3(cdiv(ow, kRC)), dim3(kRThreads), 0, st, dout, B, ow, (int64_t)ow, grad_b[i]);
         g = GemmArgs{};
         g.A = dout; g.sam = ow; g.sak = 1;
         g.Bm = W[i]; g.sbk = in_w; g.sbn = 1;

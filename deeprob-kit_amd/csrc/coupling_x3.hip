@@ -472,7 +472,7 @@ static int x3_launch(const X3Args &a, hipStream_t st) {
     hipEvent_t ev0, ev1;
     profile_take(&ev0, &ev1, DPK_KERNEL_COUPLING1D);
     if (ev0) (void)hipEventRecord(ev0, st);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * kGemmWaves * 64), lds, st, a);
+    DPK_LAUNCH(kern, dim3(grid), dim3(2 * kGemmWaves * 64), lds, st, a);
     if (ev1) (void)hipEventRecord(ev1, st);
     DPK_CHECK_LAUNCH("coupling_x3_kernel");
     return DPK_OK;
@@ -516,7 +516,7 @@ extern "C" int dpk_coupling1d_pairs_forward(const float *x, int64_t B, int32_t D
         p.w1t = w.w1t; p.w2t = w.w2t; p.b1f = w.b1f;
         const int64_t total = (int64_t)g.NCH1 * 2 * g.NU * 64 + (int64_t)g.NPT * (units / 16) * 2 * 64 + (int64_t)g.NPT * 32 +
                               units;
-        hipLaunchKernelGGL(coupling_x3_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p);
+        DPK_LAUNCH(coupling_x3_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p);
         DPK_CHECK_LAUNCH("coupling_x3_pack_kernel");
     }
     X3Args a{};

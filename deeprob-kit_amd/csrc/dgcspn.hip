@@ -672,12 +672,12 @@ static int spatial_gaussian_forward_impl(const float *x, const float *loc, const
         int64_t bslice = cdiv(B, slices);
         if (bslice < 8) bslice = 8;
         slices = cdiv(B, bslice);
-        hipLaunchKernelGGL(spatial_gaussian_fwd_fast_kernel, dim3((unsigned)cols, (unsigned)kb, (unsigned)slices),
+        DPK_LAUNCH(spatial_gaussian_fwd_fast_kernel, dim3((unsigned)cols, (unsigned)kb, (unsigned)slices),
                            dim3(256), 0, (hipStream_t)stream, x, loc, scale, B, K, C, HW, (int)bslice, out);
         DPK_CHECK_LAUNCH("spatial_gaussian_fwd_fast_kernel");
         return DPK_OK;
     }
-    hipLaunchKernelGGL(spatial_gaussian_fwd_kernel, dim3(grid_cap(total, 256)), dim3(256), 0, (hipStream_t)stream,
+    DPK_LAUNCH(spatial_gaussian_fwd_kernel, dim3(grid_cap(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        x, loc, scale, B, K, C, H * W, out, drop_p, seed);
     DPK_CHECK_LAUNCH("spatial_gaussian_fwd_kernel");
     return DPK_OK;
@@ -706,11 +706,11 @@ static int spatial_gaussian_backward_impl(const float *x, const float *g, const 
     if (B == 0) return DPK_OK;
     DPK_REQUIRE(x && g, DPK_EINVAL, "spatial_gaussian_backward: null pointer");
     if (grad_x)
-        hipLaunchKernelGGL(spatial_gaussian_bwd_x_kernel, dim3(grid_cap(B * C * HW, 256)), dim3(256), 0, st, x, g,
+        DPK_LAUNCH(spatial_gaussian_bwd_x_kernel, dim3(grid_cap(B * C * HW, 256)), dim3(256), 0, st, x, g,
                            loc, scale, B, K, C, HW, grad_x, drop_p, seed);
     if (grad_loc || grad_scale) {
         const int bslice = 64;
-        hipLaunchKernelGGL(spatial_gaussian_bwd_p_kernel, dim3(cdiv((int64_t)K * C * HW, 256), cdiv(B, bslice)),
+        DPK_LAUNCH(spatial_gaussian_bwd_p_kernel, dim3(cdiv((int64_t)K * C * HW, 256), cdiv(B, bslice)),
                            dim3(256), 0, st, x, g, loc, scale, B, K, C, HW, bslice, grad_loc, grad_scale, drop_p, seed);
     }
     DPK_CHECK_LAUNCH("spatial_gaussian_bwd");
@@ -754,7 +754,7 @@ extern "C" int dpk_spatial_product_forward(const float *in, int64_t B, int32_t C
     if (rc) return rc;
     if (B <= 0) return B == 0 ? DPK_OK : DPK_EINVAL;
     DPK_REQUIRE(in && out, DPK_EINVAL, "spatial_product: null pointer");
-    hipLaunchKernelGGL(spatial_product_fwd_kernel, dim3(grid_cap(B * OC * OH * OW, 256)), dim3(256), 0,
+    DPK_LAUNCH(spatial_product_fwd_kernel, dim3(grid_cap(B * OC * OH * OW, 256)), dim3(256), 0,
                        (hipStream_t)stream, in, B, q, out);
     DPK_CHECK_LAUNCH("spatial_product_fwd_kernel");
     return DPK_OK;
@@ -769,7 +769,7 @@ extern "C" int dpk_spatial_product_backward(const float *g, int64_t B, int32_t C
     if (rc) return rc;
     if (B <= 0) return B == 0 ? DPK_OK : DPK_EINVAL;
     DPK_REQUIRE(g && grad_in, DPK_EINVAL, "spatial_product_backward: null pointer");
-    hipLaunchKernelGGL(spatial_product_bwd_kernel, dim3(grid_cap(B * C * H * W, 256)), dim3(256), 0,
+    DPK_LAUNCH(spatial_product_bwd_kernel, dim3(grid_cap(B * C * H * W, 256)), dim3(256), 0,
                        (hipStream_t)stream, g, B, q, grad_in);
     DPK_CHECK_LAUNCH("spatial_product_bwd_kernel");
     return DPK_OK;
@@ -792,17 +792,17 @@ extern "C" int dpk_spatial_sum_forward(const float *x, const float *weight, int6
     DPK_REQUIRE(x && out, DPK_EINVAL, "spatial_sum: null pointer");
     float *Wl = (float *)ws, *LW = (float *)((char *)ws + seg);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * HW, 256)), dim3(256), 0, st, weight,
+    DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * HW, 256)), dim3(256), 0, st, weight,
                        Cout, Cin, HW, Wl, LW);
     const dim3 grid(grid_cap(B * HW, 256)), block(256);
     if (Cin <= 8)
-        hipLaunchKernelGGL(spatial_sum_fwd_kernel<8>, grid, block, 0, st, x, Wl, LW, B, Cin, Cout, HW, out);
+        DPK_LAUNCH(spatial_sum_fwd_kernel<8>, grid, block, 0, st, x, Wl, LW, B, Cin, Cout, HW, out);
     else if (Cin <= 16)
-        hipLaunchKernelGGL(spatial_sum_fwd_kernel<16>, grid, block, 0, st, x, Wl, LW, B, Cin, Cout, HW, out);
+        DPK_LAUNCH(spatial_sum_fwd_kernel<16>, grid, block, 0, st, x, Wl, LW, B, Cin, Cout, HW, out);
     else if (Cin <= 32)
-        hipLaunchKernelGGL(spatial_sum_fwd_kernel<32>, grid, block, 0, st, x, Wl, LW, B, Cin, Cout, HW, out);
+        DPK_LAUNCH(spatial_sum_fwd_kernel<32>, grid, block, 0, st, x, Wl, LW, B, Cin, Cout, HW, out);
     else
-        hipLaunchKernelGGL(spatial_sum_fwd_kernel<0>, grid, block, 0, st, x, Wl, LW, B, Cin, Cout, HW, out);
+        DPK_LAUNCH(spatial_sum_fwd_kernel<0>, grid, block, 0, st, x, Wl, LW, B, Cin, Cout, HW, out);
     DPK_CHECK_LAUNCH("spatial_sum_fwd_kernel");
     return DPK_OK;
 }
@@ -817,7 +817,7 @@ extern "C" int dpk_spatial_sum_backward(const float *x, const float *weight, con
     DPK_REQUIRE(ws_bytes >= 3 * seg, DPK_EWORKSPACE, "spatial_sum_backward: workspace too small");
     float *Wl = (float *)ws, *LW = (float *)((char *)ws + seg), *glw = (float *)((char *)ws + 2 * seg);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * HW, 256)), dim3(256), 0, st, weight,
+    DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * HW, 256)), dim3(256), 0, st, weight,
                        Cout, Cin, HW, Wl, LW);
     if (grad_weight)
         DPK_REQUIRE(hipMemsetAsync(glw, 0, (size_t)Cout * Cin * HW * 4, st) == hipSuccess, DPK_ELAUNCH, "memset");
@@ -830,17 +830,17 @@ extern "C" int dpk_spatial_sum_backward(const float *x, const float *weight, con
             int64_t bslice = cdiv(B, slices);
             if (bslice < 8) bslice = 8;
             slices = cdiv(B, bslice);
-            hipLaunchKernelGGL(spatial_sum_bwd8_kernel, dim3((unsigned)cols, (unsigned)cdiv(slices, 4), (unsigned)halves), dim3(64, 4), 0,
+            DPK_LAUNCH(spatial_sum_bwd8_kernel, dim3((unsigned)cols, (unsigned)cdiv(slices, 4), (unsigned)halves), dim3(64, 4), 0,
                                st, x, Wl, LW, out, g, B, Cin, Cout, HW, (int)bslice, grad_x,
                                grad_weight ? glw : nullptr);
         } else {
             const int bslice = 16;
-            hipLaunchKernelGGL(spatial_sum_bwd_kernel, dim3(cdiv((int64_t)Cin * HW, 256), cdiv(B, bslice)), dim3(256),
+            DPK_LAUNCH(spatial_sum_bwd_kernel, dim3(cdiv((int64_t)Cin * HW, 256), cdiv(B, bslice)), dim3(256),
                                0, st, x, LW, out, g, B, Cin, Cout, HW, bslice, grad_x, grad_weight ? glw : nullptr);
         }
     }
     if (grad_weight)
-        hipLaunchKernelGGL(spatial_softmax_jacobian_kernel, dim3(grid_cap((int64_t)Cout * HW, 256)), dim3(256), 0, st,
+        DPK_LAUNCH(spatial_softmax_jacobian_kernel, dim3(grid_cap((int64_t)Cout * HW, 256)), dim3(256), 0, st,
                            glw, Wl, Cout, Cin, HW, grad_weight);
     DPK_CHECK_LAUNCH("spatial_sum_bwd_kernel");
     return DPK_OK;
@@ -870,14 +870,14 @@ extern "C" int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C
     DPK_REQUIRE(in && out, DPK_EINVAL, "spatial_prodsum: null pointer");
     float *Wl = (float *)ws, *LW = (float *)((char *)ws + seg);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW, 256)), dim3(256), 0, st, weight,
+    DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW, 256)), dim3(256), 0, st, weight,
                        Cout, C, OHW, Wl, LW);
     const int Bi = (int)B;
     hipEvent_t pev0, pev1;
     profile_take(&pev0, &pev1, DPK_KERNEL_SPATIAL_PRODSUM);
     if (pev0) (void)hipEventRecord(pev0, st);
 #define DPK_PRODSUM(CMAX, NB)                                                                                      \
-    hipLaunchKernelGGL((spatial_prodsum_fwd_kernel<CMAX, NB>), dim3(cdiv(OHW, 256), cdiv(Bi, NB)), dim3(256), 0, st, \
+    DPK_LAUNCH((spatial_prodsum_fwd_kernel<CMAX, NB>), dim3(cdiv(OHW, 256), cdiv(Bi, NB)), dim3(256), 0, st, \
                        in, Wl, LW, Bi, q, Cout, out)
     if (C <= 4)
         DPK_PRODSUM(4, 4);
@@ -1075,15 +1075,15 @@ extern "C" int dpk_spatial_sumprodroot_forward(const float *in, int64_t B, int32
     const int64_t seg = align_up((int64_t)Cout * C * OHW5 * 4, 256);
     float *Wl = (float *)ws, *LW = (float *)((char *)ws + seg), *LWr = (float *)((char *)ws + 2 * seg);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW5, 256)), dim3(256), 0, st, sum_weight,
+    DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW5, 256)), dim3(256), 0, st, sum_weight,
                        Cout, C, OHW5, Wl, LW);
-    hipLaunchKernelGGL(rowwise_logsoftmax_kernel, dim3(K), dim3(256), 0, st, root_weight, K, Cout * OHW6, LWr);
+    DPK_LAUNCH(rowwise_logsoftmax_kernel, dim3(K), dim3(256), 0, st, root_weight, K, Cout * OHW6, LWr);
     constexpr int kNB = 2;
     const int threads = (int)align_up(OHW6, 64);
     hipEvent_t pev0, pev1;
     profile_take(&pev0, &pev1, DPK_KERNEL_SPATIAL_SUMPRODROOT);
     if (pev0) (void)hipEventRecord(pev0, st);
-    hipLaunchKernelGGL((spatial_sumprodroot_fwd_kernel<8, kNB>), dim3(cdiv((int)B, kNB)), dim3(threads), 0, st, in, Wl,
+    DPK_LAUNCH((spatial_sumprodroot_fwd_kernel<8, kNB>), dim3(cdiv((int)B, kNB)), dim3(threads), 0, st, in, Wl,
                        LW, (int)B, q5, Cout, q6, LWr, K, out);
     if (pev1) (void)hipEventRecord(pev1, st);
     DPK_CHECK_LAUNCH("spatial_sumprodroot_fwd_kernel");
@@ -1114,8 +1114,8 @@ extern "C" int dpk_spatial_prodroot_forward(const float *in, int64_t B, int32_t 
     DPK_REQUIRE(in && out, DPK_EINVAL, "spatial_prodroot: null pointer");
     hipStream_t st = (hipStream_t)stream;
     float *LW = (float *)ws;
-    hipLaunchKernelGGL(rowwise_logsoftmax_kernel, dim3(K), dim3(256), 0, st, weight, K, M, LW);
-    hipLaunchKernelGGL(spatial_prodroot_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, in, LW, B, q, K, out);
+    DPK_LAUNCH(rowwise_logsoftmax_kernel, dim3(K), dim3(256), 0, st, weight, K, M, LW);
+    DPK_LAUNCH(spatial_prodroot_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, in, LW, B, q, K, out);
     DPK_CHECK_LAUNCH("spatial_prodroot_fwd_kernel");
     return DPK_OK;
 }

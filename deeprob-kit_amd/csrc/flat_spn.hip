@@ -128,18 +128,18 @@ extern "C" int dpk_flat_spn_forward(const float *x, int64_t B, int32_t D, int32_
     const unsigned blocks = (unsigned)cdiv(B, 64);
     if (node_values) {
         a.table = node_values;
-        hipLaunchKernelGGL(flat_spn_kernel<false>, dim3(blocks), dim3(64), 0, st, a);
+        DPK_LAUNCH(flat_spn_kernel<false>, dim3(blocks), dim3(64), 0, st, a);
     } else if (n_slots > 0 && n_slots <= kFlatLdsSlots) {
         DPK_REQUIRE(node_slot && child_slot, DPK_EINVAL, "flat_spn_forward: slot arrays missing");
         a.node_slot = node_slot;
         a.child_index = child_slot;
-        hipLaunchKernelGGL(flat_spn_kernel<true>, dim3(blocks), dim3(64), (size_t)n_slots * 256, st, a);
+        DPK_LAUNCH(flat_spn_kernel<true>, dim3(blocks), dim3(64), (size_t)n_slots * 256, st, a);
     } else {
         const int64_t need = dpk_flat_spn_workspace_bytes(B, n_nodes, n_slots);
         DPK_REQUIRE(ws && ws_bytes >= need, DPK_EWORKSPACE, "flat_spn_forward: workspace %lld < %lld",
                     (long long)ws_bytes, (long long)need);
         a.table = (float *)ws;
-        hipLaunchKernelGGL(flat_spn_kernel<false>, dim3(blocks), dim3(64), 0, st, a);
+        DPK_LAUNCH(flat_spn_kernel<false>, dim3(blocks), dim3(64), 0, st, a);
     }
     DPK_CHECK_LAUNCH("flat_spn_forward");
     return DPK_OK;

@@ -1363,7 +1363,7 @@ int prepare_leaf_structure(const RatWs &w, const int64_t *mask, const uint8_t *p
     if (flags & DPK_FLAG_STRUCT_CACHED) return DPK_OK;
     const size_t lds = (size_t)(2 * w.QB * d + w.QB * (w.NC + 1) + w.NC * w.QB + 1) * sizeof(int);
     DPK_REQUIRE(lds <= 64 * 1024, DPK_EUNSUPPORTED, "region dimension %d too large for the structure kernel", d);
-    hipLaunchKernelGGL(ratspn_struct_kernel, dim3(w.G), dim3(256), lds, st, mask, pad, R, d, w.NC, w.QB, w.SP,
+    DPK_LAUNCH(ratspn_struct_kernel, dim3(w.G), dim3(256), lds, st, mask, pad, R, d, w.NC, w.QB, w.SP,
                        w.fl1, w.fl2, w.srcr, w.feat, w.nblk, w.segoff);
     DPK_CHECK_LAUNCH("ratspn_struct_kernel");
     return DPK_OK;
@@ -1399,8 +1399,8 @@ static int prepare_leaf_tables(int dist, const RatWs &w, const int64_t *mask, co
         }
     }
     const int grid = 2 * w.G * kPrepSlices + w.G + cdiv(rows, 4);   // block roles: see ratspn_prep_kernel
-    if (dist == 0) hipLaunchKernelGGL(ratspn_prep_kernel<0>, dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(ratspn_prep_kernel<1>, dim3(grid), dim3(256), 0, st, a);
+    if (dist == 0) DPK_LAUNCH(ratspn_prep_kernel<0>, dim3(grid), dim3(256), 0, st, a);
+    else DPK_LAUNCH(ratspn_prep_kernel<1>, dim3(grid), dim3(256), 0, st, a);
     DPK_CHECK_LAUNCH("ratspn_prep_kernel");
     return DPK_OK;
 }
@@ -1468,7 +1468,7 @@ static int launch_leaf_gen(const LeafArgs &a, hipStream_t st) {
         const int n_items = (a.R / QB) * (a.I / CB);
         gy = cdiv(n_items, kLeafWaves);
     }
-    hipLaunchKernelGGL(kern, dim3(grid, gy), dim3(kLeafWaves * 64), lds, st, a);
+    DPK_LAUNCH(kern, dim3(grid, gy), dim3(kLeafWaves * 64), lds, st, a);
     if (ev1) (void)hipEventRecord(ev1, st);
     DPK_CHECK_LAUNCH("ratspn_leaf_kernel");
     return DPK_OK;

@@ -763,7 +763,7 @@ static int gemm_launch(const GemmArgs &a, int reps, hipStream_t st) {
     hipEvent_t ev0, ev1;
     profile_take(&ev0, &ev1, DPK_KERNEL_RATSPN_FUSED);
     if (ev0) (void)hipEventRecord(ev0, st);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * kGemmWaves * 64), lds, st, a);
+    DPK_LAUNCH(kern, dim3(grid), dim3(2 * kGemmWaves * 64), lds, st, a);
     if (ev1) (void)hipEventRecord(ev1, st);
     DPK_CHECK_LAUNCH("ratspn_gemm_kernel");
     return DPK_OK;
@@ -798,8 +798,8 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
         const int grid = nrb + cdiv(p.rows[0] + p.rows[1], 4);
         const size_t lds = ((size_t)D + (size_t)4 * I * d + (size_t)cdiv(D, 32) * 4 * I) * 4;
         DPK_REQUIRE(lds <= 60 * 1024, DPK_EUNSUPPORTED, "ratspn_gemm: in_features=%d too large for the table kernel", D);
-        if (I == 2) hipLaunchKernelGGL(ratspn_gemm_prep_kernel<2>, dim3(grid), dim3(256), lds, st, p);
-        else hipLaunchKernelGGL(ratspn_gemm_prep_kernel<4>, dim3(grid), dim3(256), lds, st, p);
+        if (I == 2) DPK_LAUNCH(ratspn_gemm_prep_kernel<2>, dim3(grid), dim3(256), lds, st, p);
+        else DPK_LAUNCH(ratspn_gemm_prep_kernel<4>, dim3(grid), dim3(256), lds, st, p);
         DPK_CHECK_LAUNCH("ratspn_gemm_prep_kernel");
     }
     GemmArgs a{};

@@ -415,7 +415,7 @@ extern "C" int dpk_product_forward(const float *in, int64_t B, int32_t R, int32_
     DPK_REQUIRE(B >= 0 && R > 0 && (R % 2) == 0 && N > 0, DPK_EINVAL, "product_forward: bad sizes");
     const int64_t total = B * (R / 2) * N * N;
     if (total == 0) return DPK_OK;
-    hipLaunchKernelGGL(product_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in,
+    DPK_LAUNCH(product_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in,
                        total, R, N, out);
     DPK_CHECK_LAUNCH("product_fwd_kernel");
     return DPK_OK;
@@ -427,7 +427,7 @@ extern "C" int dpk_product_backward(const float *g, int64_t B, int32_t R, int32_
     DPK_REQUIRE(B >= 0 && R > 0 && (R % 2) == 0 && N > 0, DPK_EINVAL, "product_backward: bad sizes");
     const int64_t total = B * R * N;
     if (total == 0) return DPK_OK;
-    hipLaunchKernelGGL(product_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, g,
+    DPK_LAUNCH(product_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, g,
                        total, R, N, grad_in);
     DPK_CHECK_LAUNCH("product_bwd_kernel");
     return DPK_OK;
@@ -450,11 +450,11 @@ static int sum_forward_impl(const float *in, const float *weight, int64_t B, int
     if (B == 0) return DPK_OK;
     float *W = (float *)ws, *LW = (float *)((char *)ws + seg);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(softmax_rows_kernel2, dim3(cdiv(P * S, 4)), dim3(256), 0, st, weight, P * S, N, W, LW);
+    DPK_LAUNCH(softmax_rows_kernel2, dim3(cdiv(P * S, 4)), dim3(256), 0, st, weight, P * S, N, W, LW);
     if (P == 1 && N >= 1024)
-        hipLaunchKernelGGL(root_wide_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, in, LW, B, N, S, out);
+        DPK_LAUNCH(root_wide_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, in, LW, B, N, S, out);
     else
-        hipLaunchKernelGGL(sum_fwd_kernel, dim3(cdiv(B, 64), P), dim3(256), 0, st, in, as_const(W), as_const(LW), B,
+        DPK_LAUNCH(sum_fwd_kernel, dim3(cdiv(B, 64), P), dim3(256), 0, st, in, as_const(W), as_const(LW), B,
                            P, N, S, out);
     DPK_CHECK_LAUNCH("sum_fwd_kernel");
     return DPK_OK;
@@ -469,20 +469,20 @@ static int sum_backward_impl(const float *in, const float *weight, const float *
     DPK_REQUIRE(ws_bytes >= 3 * seg, DPK_EWORKSPACE, "%s: workspace too small", who);
     float *W = (float *)ws, *LW = (float *)((char *)ws + seg), *glw = (float *)((char *)ws + 2 * seg);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(softmax_rows_kernel2, dim3(cdiv(P * S, 4)), dim3(256), 0, st, weight, P * S, N, W, LW);
+    DPK_LAUNCH(softmax_rows_kernel2, dim3(cdiv(P * S, 4)), dim3(256), 0, st, weight, P * S, N, W, LW);
     if (grad_weight) {
         hipError_t e = hipMemsetAsync(glw, 0, (size_t)P * S * N * 4, st);
         DPK_REQUIRE(e == hipSuccess, DPK_ELAUNCH, "%s: memset: %s", who, hipGetErrorString(e));
     }
     if (B > 0) {
         const int cols = P * N;
-        hipLaunchKernelGGL(sum_bwd_kernel, dim3(cdiv(B, kBwdTile), cdiv(cols, 256)), dim3(256), 0, st, in, LW,
+        DPK_LAUNCH(sum_bwd_kernel, dim3(cdiv(B, kBwdTile), cdiv(cols, 256)), dim3(256), 0, st, in, LW,
                            out, g, B, P, N, S, grad_in, grad_weight ? glw : nullptr);
     } else if (grad_in) {
         // nothing to write
     }
     if (grad_weight)
-        hipLaunchKernelGGL(logsoftmax_jacobian_kernel, dim3(cdiv(P * S, 4)), dim3(256), 0, st, glw, W, P * S, N,
+        DPK_LAUNCH(logsoftmax_jacobian_kernel, dim3(cdiv(P * S, 4)), dim3(256), 0, st, glw, W, P * S, N,
                            grad_weight);
     DPK_CHECK_LAUNCH("sum_bwd_kernel");
     return DPK_OK;
@@ -535,7 +535,7 @@ static int leaf_backward_common(int dist, const float *x, const float *g, int64_
         const int tile = (B > 1024) ? kLeafBwdTile : 16;
         const dim3 grid(cdiv(B, tile), w.G, I / cbk), block(256);
 #define DPK_LEAF_BWD(DIST, CBK)                                                                                  \
-    hipLaunchKernelGGL((leaf_bwd_param_kernel<DIST, CBK>), grid, block, 0, st, x, g, B, D, R, I, d, w.SP, w.feat, \
+    DPK_LAUNCH((leaf_bwd_param_kernel<DIST, CBK>), grid, block, 0, st, x, g, B, D, R, I, d, w.SP, w.feat, \
                        w.srcr, p0, p1, gp0, gp1, drop_p, seed, tile)
         if (dist == 0) {
             if (cbk == 4) DPK_LEAF_BWD(0, 4);
@@ -563,9 +563,9 @@ static int leaf_backward_common(int dist, const float *x, const float *g, int64_
                     "leaf_backward: inverse table does not fit");
         DPK_REQUIRE(hipMemsetAsync(inv, 0xff, (size_t)reps * D * 4, st) == hipSuccess, DPK_ELAUNCH,
                     "leaf_backward: memset");
-        hipLaunchKernelGGL(leaf_inverse_kernel, dim3(w.G), dim3(256), 0, st, w.feat, w.srcr, d, w.SP, D, per_rep,
+        DPK_LAUNCH(leaf_inverse_kernel, dim3(w.G), dim3(256), 0, st, w.feat, w.srcr, d, w.SP, D, per_rep,
                            inv);
-        hipLaunchKernelGGL(gaussian_leaf_bwd_x_kernel, dim3(grid_for(B * D, 256)), dim3(256), 0, st, x, g, B, D,
+        DPK_LAUNCH(gaussian_leaf_bwd_x_kernel, dim3(grid_for(B * D, 256)), dim3(256), 0, st, x, g, B, D,
                            R, I, d, reps, inv, p0, p1, gx, drop_p, seed, dist);
         DPK_CHECK_LAUNCH("gaussian_leaf_bwd_x_kernel");
     }
@@ -647,10 +647,10 @@ extern "C" int dpk_leaf_forward_dropout(int32_t dist, const float *x, int64_t B,
     DPK_REQUIRE(x && mask && p0 && out && (dist == 1 || p1), DPK_EINVAL, "leaf_forward_dropout: null pointer");
     const int64_t total = B * R * I;
     if (dist == 0)
-        hipLaunchKernelGGL(leaf_fwd_dropout_kernel<0>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+        DPK_LAUNCH(leaf_fwd_dropout_kernel<0>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                            x, B, D, mask, pad_mask, p0, p1, R, I, d, drop_p, seed, out);
     else
-        hipLaunchKernelGGL(leaf_fwd_dropout_kernel<1>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+        DPK_LAUNCH(leaf_fwd_dropout_kernel<1>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                            x, B, D, mask, pad_mask, p0, p1, R, I, d, drop_p, seed, out);
     DPK_CHECK_LAUNCH("leaf_fwd_dropout_kernel");
     return DPK_OK;
@@ -679,7 +679,7 @@ extern "C" int dpk_dropout_fill(const float *x, int64_t n, float drop_p, uint64_
     DPK_REQUIRE(n >= 0 && drop_p >= 0.f && drop_p < 1.f, DPK_EINVAL, "dropout_fill: bad arguments");
     if (n == 0) return DPK_OK;
     DPK_REQUIRE(x && out, DPK_EINVAL, "dropout_fill: null pointer");
-    hipLaunchKernelGGL(dropout_fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, n, drop_p,
+    DPK_LAUNCH(dropout_fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, n, drop_p,
                        seed, fill, out);
     DPK_CHECK_LAUNCH("dropout_fill_kernel");
     return DPK_OK;
@@ -821,7 +821,7 @@ static int prod_fused_common(bool root, const float *in, const float *weight, in
     DPK_REQUIRE(in && out, DPK_EINVAL, "%s: null pointer", who);
     float *W = (float *)ws, *LW = (float *)((char *)ws + seg);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(softmax_rows_kernel2, dim3(cdiv(rows, 4)), dim3(256), 0, st, weight, rows, n, W, LW);
+    DPK_LAUNCH(softmax_rows_kernel2, dim3(cdiv(rows, 4)), dim3(256), 0, st, weight, rows, n, W, LW);
     {
         static const bool mfma = [] {
             const char *e = getenv("DPK_RATSPN_GEMM");
@@ -836,10 +836,10 @@ static int prod_fused_common(bool root, const float *in, const float *weight, in
 #define DPK_LAUNCH_PS(NMAX)                                                                                         \
     do {                                                                                                            \
         if (root)                                                                                                   \
-            hipLaunchKernelGGL(prodroot_fwd_kernel<NMAX>, dim3(cdiv(B, 64)), block, 0, st, in, as_const(W),         \
+            DPK_LAUNCH(prodroot_fwd_kernel<NMAX>, dim3(cdiv(B, 64)), block, 0, st, in, as_const(W),         \
                                as_const(LW), B, R, N, S, out);                                                      \
         else                                                                                                        \
-            hipLaunchKernelGGL(prodsum_fwd_kernel<NMAX>, dim3(cdiv(B, 64), cdiv(P, 4)), block, 0, st, in,           \
+            DPK_LAUNCH(prodsum_fwd_kernel<NMAX>, dim3(cdiv(B, 64), cdiv(P, 4)), block, 0, st, in,           \
                                as_const(W), as_const(LW), B, R, N, S, out);                                         \
     } while (0)
     if (N <= 4) DPK_LAUNCH_PS(4);

@@ -426,7 +426,7 @@ static int leaf_gemm_launch(const LeafGemmArgs &a, int NG, hipStream_t st) {
     hipEvent_t ev0, ev1;
     profile_take(&ev0, &ev1, DPK_KERNEL_RATSPN_LEAF);
     if (ev0) (void)hipEventRecord(ev0, st);
-    hipLaunchKernelGGL(kern, dim3(gx, NG), dim3(2 * kGemmWaves * 64), lds, st, a);
+    DPK_LAUNCH(kern, dim3(gx, NG), dim3(2 * kGemmWaves * 64), lds, st, a);
     if (ev1) (void)hipEventRecord(ev1, st);
     DPK_CHECK_LAUNCH("ratspn_leaf_gemm_kernel");
     return DPK_OK;
@@ -454,7 +454,7 @@ int ratspn_leaf_gemm_forward(void *ws, const float *x, int64_t B, int D, const i
         pa.mtab = mtab; pa.ctab = ctab; pa.bias = biasC; pa.bias_row = biasT; pa.elig = elig;
         const size_t lds = ((size_t)D + (size_t)I * d + (size_t)NCH * I) * 4;
         DPK_REQUIRE(lds <= 60 * 1024, DPK_EUNSUPPORTED, "leaf_gemm: in_features=%d too large for the table kernel", D);
-        hipLaunchKernelGGL(ratspn_leaf_gemm_prep_kernel, dim3(R), dim3(256), lds, st, pa);
+        DPK_LAUNCH(ratspn_leaf_gemm_prep_kernel, dim3(R), dim3(256), lds, st, pa);
         DPK_CHECK_LAUNCH("ratspn_leaf_gemm_prep_kernel");
     }
     LeafGemmArgs a{};

@@ -286,7 +286,7 @@ int64_t upper_mfma_frag_bytes(int R, int N, int S) {   // (covers the sum and th
 int upper_mfma_forward(bool root, const float *in, const float *W, const float *LW, int64_t B, int R, int N, int S,
                        float *out, void *frag, hipStream_t st) {
     const int P = R / 2, tiles = root ? root_ct(N, S) : cdiv((int64_t)S * N, 32);
-    hipLaunchKernelGGL(upper_pack_kernel, dim3(cdiv((int64_t)P * tiles * 64, 256)), dim3(256), 0, st, W, P, N, S,
+    DPK_LAUNCH(upper_pack_kernel, dim3(cdiv((int64_t)P * tiles * 64, 256)), dim3(256), 0, st, W, P, N, S,
                        root ? 1 : 0, tiles, (uint16_t *)frag);
     UpperArgs a{};
     a.in = in; a.frag = (const uint16_t *)frag; a.LW = LW; a.out = out; a.B = B; a.R = R; a.S = S; a.tiles = tiles;
@@ -297,10 +297,10 @@ int upper_mfma_forward(bool root, const float *in, const float *W, const float *
         while (ppb > 1 && (int64_t)gx * cdiv(P, ppb) < 1024) ppb = (ppb + 1) / 2;
         a.ppb = ppb;
         const dim3 grid(gx, cdiv(P, ppb));
-        if (N == 16) hipLaunchKernelGGL(prodsum_mfma_kernel<16>, grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(prodsum_mfma_kernel<8>, grid, dim3(256), 0, st, a);
+        if (N == 16) DPK_LAUNCH(prodsum_mfma_kernel<16>, grid, dim3(256), 0, st, a);
+        else DPK_LAUNCH(prodsum_mfma_kernel<8>, grid, dim3(256), 0, st, a);
     } else {
-#define DPK_ROOT(NN, CTT) hipLaunchKernelGGL((prodroot_mfma_kernel<NN, CTT>), dim3(gx), dim3(256), 0, st, a)
+#define DPK_ROOT(NN, CTT) DPK_LAUNCH((prodroot_mfma_kernel<NN, CTT>), dim3(gx), dim3(256), 0, st, a)
         if (N == 16) {
             if (tiles <= 1) DPK_ROOT(16, 1); else if (tiles <= 2) DPK_ROOT(16, 2); else if (tiles <= 4) DPK_ROOT(16, 4);
             else DPK_ROOT(16, 8);

@@ -63,7 +63,7 @@ extern "C" int dpk_ll_accumulate(const float *ll, int64_t n, double *acc, void *
     if (n == 0) return DPK_OK;
     int grid = dpk::cdiv(n, 256 * 8);
     if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(dpk::ll_accumulate_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ll, n, acc);
+    DPK_LAUNCH(dpk::ll_accumulate_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ll, n, acc);
     DPK_CHECK_LAUNCH("ll_accumulate_kernel");
     return DPK_OK;
 }
