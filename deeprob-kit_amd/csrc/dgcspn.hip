@@ -10,6 +10,7 @@
 //   spatial_sum      : SpatialSumLayer.forward       dgcspn.py:289-304
 // SpatialRootLayer.forward (:343-355) is dpk_root_forward on the flattened map.
 #include "common.h"
+#include "dgcspn_stream.h"
 #include <math.h>
 
 namespace dpk {
@@ -134,15 +135,7 @@ __global__ void spatial_gaussian_bwd_p_kernel(const float *__restrict__ x, const
     if (gscale) atomicAdd(gscale + e, a1);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Product layer geometry (kh x kw taps, dilation, stride, zero padding on the left / top)
-// ------------------------------------------------------------------------------------------------
-struct ProdGeom {
-    int C, H, W;        // input
-    int OC, OH, OW;     // output
-    int kh, kw, sh, sw, dh, dw, pt, pl;
-    int depthwise;
-};
+// (ProdGeom, the geometry of a product layer: dgcspn_stream.h)
 
 __device__ __forceinline__ int ipow(int base, int e) {
     int r = 1;
@@ -872,6 +865,8 @@ extern "C" int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C
     hipStream_t st = (hipStream_t)stream;
     DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW, 256)), dim3(256), 0, st, weight,
                        Cout, C, OHW, Wl, LW);
+    // large batches of the 8 -> 8 channel level: pixel-resident weights, taps staged through LDS (dgcspn_stream.hip)
+    if (stream_prodsum_ok(q, Cout, B, in)) return stream_prodsum_forward(in, B, q, Wl, LW, out, st);
     const int Bi = (int)B;
     hipEvent_t pev0, pev1;
     profile_take(&pev0, &pev1, DPK_KERNEL_SPATIAL_PRODSUM);
@@ -1048,6 +1043,25 @@ extern "C" int64_t dpk_spatial_sumprodroot_workspace_bytes(int32_t C, int32_t Co
     return 2 * align_up((int64_t)Cout * C * OH5 * OW5 * 4, 256) + align_up((int64_t)K * Cout * OH6 * OW6 * 4, 256) + 256;
 }
 
+// Workspace of dpk_spatial_sumprodroot_forward for a batch of B samples: the tables above plus, where the streaming
+// kernel applies, one (max, sum) pair per sample, class and compute wave for the root's log-sum-exp.  geom5 / geom6 as
+// in dpk_spatial_sumprodroot_forward.  With only dpk_spatial_sumprodroot_workspace_bytes() bytes the entry point
+// runs the batch-independent kernel.
+extern "C" int64_t dpk_spatial_sumprodroot_workspace_bytes_batch(int64_t B, int32_t C, int32_t H, int32_t W,
+                                                                 const int32_t *geom5, int32_t Cout,
+                                                                 const int32_t *geom6, int32_t K) {
+    if (!geom5 || !geom6 || B < 0) return DPK_EINVAL;
+    const int64_t base = dpk_spatial_sumprodroot_workspace_bytes(C, Cout, geom5[0], geom5[1], geom6[0], geom6[1], K);
+    if (base < 0) return base;
+    ProdGeom q5, q6;
+    if (make_geom(q5, C, H, W, C, geom5[0], geom5[1], geom5[2], geom5[3], geom5[4], geom5[5], geom5[6], geom5[7],
+                  geom5[8], geom5[9], 1) ||
+        make_geom(q6, Cout, geom5[0], geom5[1], Cout, geom6[0], geom6[1], geom6[2], geom6[3], geom6[4], geom6[5],
+                  geom6[6], geom6[7], geom6[8], geom6[9], 1))
+        return DPK_EINVAL;
+    return base + stream_sumprodroot_partial_bytes(q5, Cout, q6, K, B);
+}
+
 extern "C" int dpk_spatial_sumprodroot_forward(const float *in, int64_t B, int32_t C, int32_t H, int32_t W,
                                                const int32_t *geom5, const float *sum_weight, int32_t Cout,
                                                const int32_t *geom6, const float *root_weight, int32_t K, float *out,
@@ -1078,6 +1092,13 @@ extern "C" int dpk_spatial_sumprodroot_forward(const float *in, int64_t B, int32
     DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW5, 256)), dim3(256), 0, st, sum_weight,
                        Cout, C, OHW5, Wl, LW);
     DPK_LAUNCH(rowwise_logsoftmax_kernel, dim3(K), dim3(256), 0, st, root_weight, K, Cout * OHW6, LWr);
+    {
+        // streaming kernel when the workspace carries its per-wave partials (.._workspace_bytes_batch)
+        const int64_t base = dpk_spatial_sumprodroot_workspace_bytes(C, Cout, q5.OH, q5.OW, q6.OH, q6.OW, K);
+        const int64_t part = ((uintptr_t)in & 15) == 0 ? stream_sumprodroot_partial_bytes(q5, Cout, q6, K, B) : 0;
+        if (part > 0 && ws_bytes >= base + part)
+            return stream_sumprodroot_forward(in, B, q5, Wl, LW, q6, LWr, K, out, (char *)ws + base, st);
+    }
     constexpr int kNB = 2;
     const int threads = (int)align_up(OHW6, 64);
     hipEvent_t pev0, pev1;

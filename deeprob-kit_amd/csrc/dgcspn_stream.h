@@ -1,0 +1,29 @@
+// DGC-SPN: geometry of a product layer and the streaming (LDS-staged) product + sum level kernels.
+#pragma once
+#include "common.h"
+
+namespace dpk {
+
+// Product layer geometry (kh x kw taps, dilation, stride, zero padding on the left / top)
+struct ProdGeom {
+    int C, H, W;        // input
+    int OC, OH, OW;     // output
+    int kh, kw, sh, sw, dh, dw, pt, pl;
+    int depthwise;
+};
+
+// Streaming route of the fused depthwise product + sum level for 8 -> 8 channels (dgcspn_stream.hip).
+//   stream_prodsum_ok       : shape / batch inside the route's envelope
+//   stream_prodsum_forward  : out[b,o,p] = logsumexp_c(sum_taps in[b,c,tap(p)] + log W[o,c,p]);  Wl / LW are the
+//                             softmaxed weights and their logs, [Cout, C, OH*OW]
+//   stream_sumprodroot_*    : the same level followed by the last product and the root layer; `partials` holds
+//                             stream_sumprodroot_partial_bytes() bytes
+bool stream_prodsum_ok(const ProdGeom &q, int Cout, int64_t B, const float *in);
+int stream_prodsum_forward(const float *in, int64_t B, const ProdGeom &q, const float *Wl, const float *LW, float *out,
+                           hipStream_t st);
+int64_t stream_sumprodroot_partial_bytes(const ProdGeom &q5, int Cout, const ProdGeom &q6, int K, int64_t B);
+int stream_sumprodroot_forward(const float *in, int64_t B, const ProdGeom &q5, const float *Wl, const float *LW,
+                               const ProdGeom &q6, const float *LWr, int K, float *out, void *partials,
+                               hipStream_t st);
+
+}  // namespace dpk

@@ -1,0 +1,687 @@
+// DGC-SPN, evaluation route: streaming kernels of the fused depthwise product + sum level for 8 -> 8 channels
+// (reference: deeprob/spn/models/dgcspn.py:146-150 chaining layers/dgcspn.py:224-236 and :289-304).
+//
+//   out[b,o,p] = logsumexp_c( sum_taps in[b,c,tap(p)] + log W[o,c,p] )
+//
+// The sum layer's weights depend on the pixel, so a sample needs 64 weights per output pixel against 8 inputs and 8
+// outputs: the weights have to be amortised over the batch.  Here a thread owns one output pixel for the whole
+// launch and keeps its 8 x 8 softmaxed weights in registers; a work-group owns a tile of pixels and walks a slice of
+// the batch.  The rows of the input map that the tile's taps touch are copied into LDS by loader waves with LDS-DMA
+// (16 bytes per lane, nothing passes through registers) a few samples ahead of the compute waves, which read their
+// taps with ds_read_b32 -- no tap is fetched through the vector cache, no address is recomputed per sample, and the
+// zero padding of the product layer is a zeroed guard word that out-of-map taps point at.  One s_barrier per sample.
+//
+//   LDS, per stage (= one sample): 8 channel slots of CS floats; a slot holds the tile's row bands back to back
+//   (each band starts on a 16-byte piece of global memory; band starts are congruent mod 4 rows so that the
+//   sub-piece shift of a channel is the same in every band) and ends with 4 guard floats that stay zero.
+//   Address of tap t in channel c: offb[t] (per thread, set once) + Kb[c] (per channel, wave-uniform).
+//
+// MODE 0 writes the level's map.  MODE 1 is the model's last sum level: its map (8 x 59 x 59 per sample for 28 x 28
+// inputs, the largest of the model) is consumed in registers by the last product layer (the four taps of a root
+// pixel sit in four neighbouring lanes, one DPP quad reduction) and the root layer's log-sum-exp, which leaves one
+// (max, sum) pair per wave and sample for stream_root_combine_kernel.
+#include "dgcspn_stream.h"
+#include "ratspn_gemm_common.h"
+#include <algorithm>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+namespace dpk {
+
+constexpr int kStreamMaxTiles = 16;
+constexpr int kStreamMaxBands = 4;
+constexpr int kStreamLds = 160 * 1024;
+constexpr int kStreamMaxWaves = 16;     // 1024 threads; 128 VGPRs each
+constexpr int kStreamC = 8;
+// measured (s_memtime ticks): a wave's sample start to end when it has its SIMD to itself, the SIMD time of a sample
+// when several waves share it, one DMA instruction of a loader
+constexpr double kLatencyTicks = 2900, kComputeTicks = 900, kDmaTicks = 250;
+constexpr int kStreamMaxDma = 24;      // DMA instructions per loader wave and sample (24 KiB)
+
+struct StreamTile {
+    int first, count, nb;               // pixels (MODE 0) / root pixels (MODE 1) of the tile; row bands staged
+    int r0[kStreamMaxBands], nr[kStreamMaxBands], lb[kStreamMaxBands];   // first row, rows, float offset in the slot
+};
+
+struct StreamArgs {
+    const float *in, *Wl, *LW, *LWr;
+    float *out;
+    int B, per_wg, slices, T, cw, nl, nst, CS, stage_bytes, K;
+    long long *dbg;   // measurement only (DPK_DGC_STREAM_TIMELINE): s_memtime stamps of work-group 0
+    ProdGeom q5, q6;
+    StreamTile tile[kStreamMaxTiles];
+};
+
+__device__ __forceinline__ void stream_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// wait until at most k of this wave's DMA instructions are in flight (a smaller immediate only waits longer)
+__device__ __forceinline__ void stream_wait(int k) {
+    if (k >= 48)
+        asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+    else if (k >= 32)
+        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else if (k >= 24)
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (k >= 16)
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (k >= 12)
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (k >= 8)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (k >= 4)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ float dpp_quad_sum(float v) {
+    // lanes 4i .. 4i+3 all end with the sum of the four
+    float t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += t;
+    t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    return v + t;
+}
+
+#ifdef DPK_STREAM_TIMELINE
+#define DPK_STREAM_TL 1
+#else
+#define DPK_STREAM_TL 0
+#endif
+#define STREAM_STAMP(slot)                                                                          \
+    do {                                                                                           \
+        if (DPK_STREAM_TL && a.dbg && bid == 0 && lane == 0 && i < 16)                                              \
+            a.dbg[(wave * 16 + i) * 8 + (slot)] = (long long)__builtin_readcyclecounter();        \
+    } while (0)
+
+// wave-wide max / sum on the VALU's DPP path (no LDS round trips): quads, half rows, rows, then the row results walk
+// to lane 63, which is read back as a wave-uniform value
+#define DPK_DPP(x, old, ctrl, rmask) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, x), ctrl, rmask, 0xf, false))
+__device__ __forceinline__ float dpp_wave_max(float v) {
+    v = fmaxf(v, DPK_DPP(v, v, 0xB1, 0xf));    // quad_perm [1,0,3,2]
+    v = fmaxf(v, DPK_DPP(v, v, 0x4E, 0xf));    // quad_perm [2,3,0,1]
+    v = fmaxf(v, DPK_DPP(v, v, 0x141, 0xf));   // row_half_mirror
+    v = fmaxf(v, DPK_DPP(v, v, 0x140, 0xf));   // row_mirror
+    v = fmaxf(v, DPK_DPP(v, v, 0x142, 0xa));   // row_bcast:15 into rows 1 and 3
+    v = fmaxf(v, DPK_DPP(v, v, 0x143, 0xc));   // row_bcast:31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float dpp_wave_sum(float v) {
+    v += DPK_DPP(v, 0.f, 0xB1, 0xf);
+    v += DPK_DPP(v, 0.f, 0x4E, 0xf);
+    v += DPK_DPP(v, 0.f, 0x141, 0xf);
+    v += DPK_DPP(v, 0.f, 0x140, 0xf);
+    v += DPK_DPP(v, 0.f, 0x142, 0xa);
+    v += DPK_DPP(v, 0.f, 0x143, 0xc);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_generic[];
+    lchar *smem = (lchar *)smem_generic;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x;
+    if (DPK_STREAM_TL && a.dbg && threadIdx.x == 0) a.dbg[16 * 16 * 8 + 8 + bid * 4 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
+    // the T tiles of a batch slice sit 8 work-groups apart: same XCD (work-groups go round-robin over the 8 XCDs),
+    // about the same time, so the rows two tiles share are served by that XCD's L2
+    const int tile_i = (bid >> 3) % a.T, slice = ((bid >> 3) / a.T) * 8 + (bid & 7);
+    if (slice >= a.slices) return;
+    const int s0 = slice * a.per_wg, n = min(a.per_wg, a.B - s0);
+    const int nb = a.tile[tile_i].nb, first = a.tile[tile_i].first, count = a.tile[tile_i].count;
+    int r0[kStreamMaxBands], nr[kStreamMaxBands], lb[kStreamMaxBands];
+#pragma unroll
+    for (int k = 0; k < kStreamMaxBands; ++k) {
+        r0[k] = a.tile[tile_i].r0[k];
+        nr[k] = a.tile[tile_i].nr[k];
+        lb[k] = a.tile[tile_i].lb[k];
+    }
+    const int H = a.q5.H, W = a.q5.W, HW = H * W, CS = a.CS, nst = a.nst, stage_bytes = a.stage_bytes;
+    const int cw = a.cw, nl = a.nl;
+    const unsigned smem_base = (unsigned)(uintptr_t)smem;
+
+    // guard words (never written again: the DMA pieces of the last band end before them)
+    for (int i = tid; i < nst * kStreamC * 4; i += blockDim.x) {
+        const int stg = i / (kStreamC * 4), c = (i >> 2) % kStreamC;
+        *(lfloat *)(smem + stg * stage_bytes + 4 * (c * CS + CS - 4 + (i & 3))) = 0.f;
+    }
+
+    if (wave >= cw) {
+        // ---- loader waves ------------------------------------------------------------------------------------------
+        // A stage is 8 * CS / 4 pieces of 16 bytes; DMA instruction j fills pieces 64 j .. 64 j + 63 (one per lane,
+        // the LDS side of an LDS-DMA is contiguous) and belongs to loader (j mod nl).  Which global piece a lane
+        // fetches (or none: alignment slack, band gaps, the guard) never changes, so it is worked out here once and
+        // a sample costs the loader nothing but the DMA instructions themselves.
+        const int lw = wave - cw;
+        const int PPS = CS >> 2, NI = (kStreamC * PPS + 63) >> 6;
+        unsigned voff[kStreamMaxDma];
+        unsigned live = 0;   // instructions with at least one lane to fetch
+        int ninstr = 0;
+#pragma unroll
+        for (int jj = 0; jj < kStreamMaxDma; ++jj) {
+            const int j = lw + jj * nl;
+            const int piece = j * 64 + lane, c = piece / PPS, f = 4 * (piece - c * PPS);   // float offset in the slot
+            unsigned v = 0xffffffffu;
+            if (j < NI && c < kStreamC) {
+#pragma unroll
+                for (int k = 0; k < kStreamMaxBands; ++k) {
+                    const int gfl = c * HW + r0[k] * W, sh = gfl & 3, np = (sh + nr[k] * W + 3) >> 2;
+                    if (k < nb && f >= lb[k] && f < lb[k] + 4 * np) v = (unsigned)(gfl - sh + (f - lb[k])) * 4u;
+                }
+            }
+            voff[jj] = v;
+            if (__builtin_amdgcn_ballot_w64(v != 0xffffffffu) != 0) {
+                live |= 1u << jj;
+                ++ninstr;
+            }
+        }
+        const float *in = a.in;
+        auto issue = [&](int i, int stg) {
+            const gcchar_p sb = (gcchar_p)(in + (int64_t)(s0 + i) * kStreamC * HW);
+            const unsigned st = smem_base + stg * stage_bytes + lw * 1024;
+#pragma unroll
+            for (int jj = 0; jj < kStreamMaxDma; ++jj)
+                if (live & (1u << jj)) {
+                    if (voff[jj] != 0xffffffffu) glds16(voff[jj], sb, st + jj * nl * 1024);
+                }
+        };
+        int pst = 0;   // stage of the next sample to issue
+        for (int g = 0; g < nst - 1; ++g)
+            if (g < n) {
+                issue(g, pst);
+                pst = (pst + 1 == nst) ? 0 : pst + 1;
+            }
+        __syncthreads();
+        for (int i = 0; i < n; ++i) {
+            // sample i has landed once only the later ones (at most nst - 2 of them) are in flight
+            STREAM_STAMP(0);
+            stream_wait(min(n - 1 - i, nst - 2) * ninstr);
+            STREAM_STAMP(1);
+            stream_barrier();   // sample i is in LDS for everyone; everyone is done with sample i - 1
+            STREAM_STAMP(2);
+            if (i + nst - 1 < n) {
+                issue(i + nst - 1, pst);
+                pst = (pst + 1 == nst) ? 0 : pst + 1;
+            }
+            STREAM_STAMP(3);
+        }
+        return;
+    }
+
+    // ---- compute waves ---------------------------------------------------------------------------------------------
+    const int j = wave * 64 + lane;
+    const int OHW = a.q5.OH * a.q5.OW;
+    bool act;          // this thread's value is used
+    int p;             // its pixel in the level's output map
+    int q = 0;         // MODE 1: its root pixel
+    bool root_lane = false;
+    if (MODE == 0) {
+        act = j < count;
+        p = first + min(j, count - 1);
+    } else {
+        const int ql = j >> 2, t6 = j & 3;
+        const bool qv = ql < count;
+        q = first + min(ql, count - 1);
+        const int oh6 = q / a.q6.OW, ow6 = q - oh6 * a.q6.OW;
+        const int th6 = t6 / a.q6.kw, tw6 = t6 - th6 * a.q6.kw;
+        const int ph = oh6 * a.q6.sh - a.q6.pt + th6 * a.q6.dh, pw = ow6 * a.q6.sw - a.q6.pl + tw6 * a.q6.dw;
+        act = qv && t6 < a.q6.kh * a.q6.kw && ph >= 0 && ph < a.q6.H && pw >= 0 && pw < a.q6.W;
+        p = act ? ph * a.q5.OW + pw : 0;
+        root_lane = qv && t6 == 0;
+    }
+    unsigned offb[4];
+    {
+        const int oh = p / a.q5.OW, ow = p - oh * a.q5.OW, T5 = a.q5.kh * a.q5.kw;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int th = t / a.q5.kw, tw = t - th * a.q5.kw;
+            const int ih = oh * a.q5.sh - a.q5.pt + th * a.q5.dh, iw = ow * a.q5.sw - a.q5.pl + tw * a.q5.dw;
+            int off = CS - 4;   // guard: zero padding (log 1) and taps beyond kh*kw
+            if (act && t < T5 && ih >= 0 && ih < H && iw >= 0 && iw < W) {
+#pragma unroll
+                for (int k = 0; k < kStreamMaxBands; ++k)
+                    if (k < nb && ih >= r0[k] && ih < r0[k] + nr[k]) off = lb[k] + (ih - r0[k]) * W + iw;
+            }
+            offb[t] = 4u * (unsigned)off;
+        }
+    }
+    unsigned Kb[kStreamC];
+#pragma unroll
+    for (int c = 0; c < kStreamC; ++c) Kb[c] = 4u * (unsigned)(c * CS + ((c * HW + r0[0] * W) & 3));
+    gf32x2 w[kStreamC][kStreamC / 2];
+#pragma unroll
+    for (int o = 0; o < kStreamC; ++o)
+#pragma unroll
+        for (int c2 = 0; c2 < kStreamC / 2; ++c2) {
+            w[o][c2].x = a.Wl[((size_t)o * kStreamC + 2 * c2) * OHW + p];
+            w[o][c2].y = a.Wl[((size_t)o * kStreamC + 2 * c2 + 1) * OHW + p];
+        }
+    const int OHW6 = (MODE == 1) ? a.q6.OH * a.q6.OW : 0;
+    float lwr[kStreamC];
+    if (MODE == 1) {
+#pragma unroll
+        for (int o = 0; o < kStreamC; ++o) lwr[o] = root_lane ? a.LWr[o * OHW6 + q] : -INFINITY;
+    }
+    float *outp = (MODE == 0) ? a.out + (size_t)s0 * kStreamC * OHW + p : a.out;
+    // The weights are consumed here, once: hipcc otherwise puts the vmcnt waits of these loads at their first use
+    // INSIDE the sample loop, where they count down to vmcnt(0) in every iteration and drain the previous sample's
+    // stores (measured: 3x on the whole kernel).
+#pragma unroll
+    for (int o = 0; o < kStreamC; ++o)
+#pragma unroll
+        for (int c2 = 0; c2 < kStreamC / 2; ++c2) asm volatile("" : "+v"(w[o][c2].x), "+v"(w[o][c2].y));
+    if (MODE == 1) {
+#pragma unroll
+        for (int o = 0; o < kStreamC; ++o) asm volatile("" : "+v"(lwr[o]));
+    }
+    __syncthreads();
+
+    if (DPK_STREAM_TL && a.dbg && tid == 0) a.dbg[16 * 16 * 8 + 8 + bid * 4 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (DPK_STREAM_TL && a.dbg && bid == 0 && tid == 0) {
+        a.dbg[16 * 16 * 8 + 0] = (long long)__builtin_readcyclecounter();
+        a.dbg[16 * 16 * 8 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+    int stg = 0;
+    for (int i = 0; i < n; ++i) {
+        STREAM_STAMP(0);
+        stream_barrier();
+        STREAM_STAMP(1);
+        const unsigned sb = stg * stage_bytes;
+        stg = (stg + 1 == nst) ? 0 : stg + 1;
+        float acc[kStreamC], m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < kStreamC; ++c) {
+            const unsigned kc = sb + Kb[c];
+            const float t0 = *(lfloat *)(smem + (kc + offb[0])), t1 = *(lfloat *)(smem + (kc + offb[1]));
+            const float t2 = *(lfloat *)(smem + (kc + offb[2])), t3 = *(lfloat *)(smem + (kc + offb[3]));
+            acc[c] = (t0 + t1) + (t2 + t3);
+            m = fmaxf(m, acc[c]);
+        }
+        STREAM_STAMP(2);
+        const float m0 = (m == -INFINITY) ? 0.f : m;
+        const float m0l = -m0 * 1.44269504088896340736f;
+        gf32x2 e[kStreamC / 2];
+#pragma unroll
+        for (int c2 = 0; c2 < kStreamC / 2; ++c2) {
+            e[c2].x = __builtin_amdgcn_exp2f(fmaf(acc[2 * c2], 1.44269504088896340736f, m0l));
+            e[c2].y = __builtin_amdgcn_exp2f(fmaf(acc[2 * c2 + 1], 1.44269504088896340736f, m0l));
+        }
+        // the 8 output channels advance together: 8 independent FMA chains, 8 independent logs
+        gf32x2 v2[kStreamC];
+#pragma unroll
+        for (int o = 0; o < kStreamC; ++o) v2[o] = w[o][0] * e[0];
+#pragma unroll
+        for (int c2 = 1; c2 < kStreamC / 2; ++c2)
+#pragma unroll
+            for (int o = 0; o < kStreamC; ++o) v2[o] = w[o][c2] * e[c2] + v2[o];
+        float r[kStreamC], vmin = INFINITY;
+#pragma unroll
+        for (int o = 0; o < kStreamC; ++o) {
+            const float v = v2[o].x + v2[o].y;
+            vmin = fminf(vmin, v);
+            r[o] = fmaf(__builtin_amdgcn_logf(v), 0.69314718055994530942f, m0);
+        }
+        if (__builtin_expect(vmin < 1e-30f, 0)) {
+            // exact log-domain pass (rare: every term of some channel underflowed against the largest product)
+#pragma unroll
+            for (int o = 0; o < kStreamC; ++o)
+                if (v2[o].x + v2[o].y < 1e-30f) {
+                    const float *lp = a.LW + (size_t)o * kStreamC * OHW + p;
+                    float mm = -INFINITY;
+#pragma unroll 1
+                    for (int c = 0; c < kStreamC; ++c) mm = fmaxf(mm, acc[c] + lp[(size_t)c * OHW]);
+                    if (mm > -INFINITY) {
+                        float sx = 0.f;
+#pragma unroll 1
+                        for (int c = 0; c < kStreamC; ++c) sx += expf(acc[c] + lp[(size_t)c * OHW] - mm);
+                        r[o] = mm + logf(sx);
+                    } else {
+                        r[o] = -INFINITY;
+                    }
+                }
+        }
+        STREAM_STAMP(3);
+        if (MODE == 0) {
+            if (act) {
+#pragma unroll
+                for (int o = 0; o < kStreamC; ++o) outp[(size_t)o * OHW] = r[o];
+            }
+            outp += (size_t)kStreamC * OHW;
+        } else {
+            // last product layer: the four taps of a root pixel are the four lanes of a quad (padding taps add log 1)
+            float P[kStreamC];
+#pragma unroll
+            for (int o = 0; o < kStreamC; ++o) P[o] = dpp_quad_sum(act ? r[o] : 0.f);
+            for (int k = 0; k < a.K; ++k) {
+                float tv[kStreamC], tm = -INFINITY;
+#pragma unroll
+                for (int o = 0; o < kStreamC; ++o) {
+                    const float lw = (k == 0) ? lwr[o]
+                                              : (root_lane ? a.LWr[((size_t)k * kStreamC + o) * OHW6 + q] : -INFINITY);
+                    tv[o] = P[o] + lw;   // -inf outside the root lanes
+                    tm = fmaxf(tm, tv[o]);
+                }
+                const float wm = dpp_wave_max(tm);
+                const float wmf = (wm == -INFINITY) ? 0.f : wm;
+                float ts = 0.f;
+#pragma unroll
+                for (int o = 0; o < kStreamC; ++o)
+                    ts += __builtin_amdgcn_exp2f((tv[o] - wmf) * 1.44269504088896340736f);
+                ts = dpp_wave_sum(ts);
+                if (lane == 0) {
+                    float *pp = a.out + ((((size_t)(s0 + i) * a.T + tile_i) * cw + wave) * a.K + k) * 2;
+                    pp[0] = wm;
+                    pp[1] = ts;
+                }
+            }
+        }
+        STREAM_STAMP(4);
+    }
+    if (DPK_STREAM_TL && a.dbg && tid == 0) a.dbg[16 * 16 * 8 + 8 + bid * 4 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (DPK_STREAM_TL && a.dbg && bid == 0 && tid == 0) {
+        a.dbg[16 * 16 * 8 + 2] = (long long)__builtin_readcyclecounter();
+        a.dbg[16 * 16 * 8 + 3] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+}
+
+// out[b,k] = log-sum-exp of the (max, sum) pairs the waves of every tile left for sample b and class k
+__global__ __launch_bounds__(256) void stream_root_combine_kernel(const float *__restrict__ part, int64_t B, int np,
+                                                                   int K, float *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= B * K) return;
+    const int64_t b = e / K;
+    const int k = (int)(e - b * K);
+    const float *pp = part + ((size_t)b * np * K + k) * 2;
+    float m = -INFINITY;
+    for (int i = 0; i < np; ++i) m = fmaxf(m, pp[(size_t)i * K * 2]);
+    if (m == -INFINITY) {
+        out[e] = -INFINITY;
+        return;
+    }
+    float s = 0.f;
+    for (int i = 0; i < np; ++i) s += pp[(size_t)i * K * 2 + 1] * expf(pp[(size_t)i * K * 2] - m);
+    out[e] = m + logf(s);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// host: tiling plan
+// ----------------------------------------------------------------------------------------------------------------
+struct StreamPlan {
+    int T, cw, nl, nst, CS, stage_bytes, wg_per_cu;
+    StreamTile tile[kStreamMaxTiles];
+};
+
+// Batches below this run the batch-independent kernels (a work-group of the streaming kernels needs a few dozen samples
+// to amortise loading its weights).  DPK_DGC_STREAM_MIN_B overrides it, read at every call: 0 forces the streaming
+// route (parity tests on small batches), a huge value disables it.
+static int64_t stream_min_batch() {
+    const char *e = getenv("DPK_DGC_STREAM_MIN_B");
+    const long long v = e ? atoll(e) : 1024;
+    return v < 0 ? 0 : v;
+}
+
+// rows of the input map touched by the tile's taps -> at most kStreamMaxBands bands whose first rows are congruent mod 4
+static void tile_bands(int mode, const ProdGeom &q5, const ProdGeom *q6, StreamTile &t) {
+    std::vector<char> need(q5.H, 0);
+    auto mark5 = [&](int r) {
+        for (int th = 0; th < q5.kh; ++th) {
+            const int ih = r * q5.sh - q5.pt + th * q5.dh;
+            if (ih >= 0 && ih < q5.H) need[ih] = 1;
+        }
+    };
+    if (mode == 0) {
+        for (int r = t.first / q5.OW; r <= (t.first + t.count - 1) / q5.OW; ++r) mark5(r);
+    } else {
+        for (int qr = t.first / q6->OW; qr <= (t.first + t.count - 1) / q6->OW; ++qr)
+            for (int th6 = 0; th6 < q6->kh; ++th6) {
+                const int ph = qr * q6->sh - q6->pt + th6 * q6->dh;
+                if (ph >= 0 && ph < q6->H) mark5(ph);
+            }
+    }
+    std::vector<std::pair<int, int>> runs;   // [first, last]
+    for (int r = 0; r < q5.H; ++r)
+        if (need[r]) {
+            if (!runs.empty() && runs.back().second == r - 1)
+                runs.back().second = r;
+            else
+                runs.push_back({r, r});
+        }
+    if (runs.empty()) runs.push_back({0, 0});   // a tile of padding only: stage one row, every tap points at the guard
+    while ((int)runs.size() > kStreamMaxBands) {   // close the smallest gap
+        size_t best = 1;
+        for (size_t i = 2; i < runs.size(); ++i)
+            if (runs[i].first - runs[i - 1].second < runs[best].first - runs[best - 1].second) best = i;
+        runs[best - 1].second = runs[best].second;
+        runs.erase(runs.begin() + best);
+    }
+    std::vector<std::pair<int, int>> bands;
+    for (auto &r : runs) {
+        int s = r.first;
+        if (!bands.empty()) {
+            s -= (s - bands[0].first) & 3;
+            if (s <= bands.back().second + 1) {
+                bands.back().second = std::max(bands.back().second, r.second);
+                continue;
+            }
+        }
+        bands.push_back({s, r.second});
+    }
+    t.nb = (int)bands.size();
+    int lb = 0;
+    for (int k = 0; k < kStreamMaxBands; ++k) {
+        if (k < t.nb) {
+            t.r0[k] = bands[k].first;
+            t.nr[k] = bands[k].second - bands[k].first + 1;
+            t.lb[k] = lb;
+            lb += (int)align_up(3 + t.nr[k] * q5.W, 4);
+        } else {
+            t.r0[k] = t.nr[k] = t.lb[k] = 0;
+        }
+    }
+}
+
+static int tile_slot_floats(const StreamTile &t, int W) {
+    int lb = 0;
+    for (int k = 0; k < t.nb; ++k) lb += (int)align_up(3 + t.nr[k] * W, 4);
+    return lb + 4;
+}
+
+static bool stream_plan(int mode, const ProdGeom &q5, const ProdGeom *q6, StreamPlan &best) {
+    const int N = mode == 0 ? q5.OH * q5.OW : q6->OH * q6->OW;   // pixels / root pixels to distribute
+    const int per = mode == 0 ? 1 : 4;                           // thread slots per unit
+    double best_score = -1;
+    for (int T = 1; T <= kStreamMaxTiles; ++T) {
+        StreamPlan pl;
+        const int tile = cdiv(N, T);
+        if (cdiv(N, tile) != T) continue;   // same tiling as a smaller T
+        int cs = 0, dma = 0;
+        for (int i = 0; i < T; ++i) {
+            pl.tile[i].first = i * tile;
+            pl.tile[i].count = std::min(tile, N - i * tile);
+            tile_bands(mode, q5, q6, pl.tile[i]);
+            cs = std::max(cs, tile_slot_floats(pl.tile[i], q5.W));
+            int d = 0;
+            for (int k = 0; k < pl.tile[i].nb; ++k) d += cdiv(cdiv(3 + pl.tile[i].nr[k] * q5.W, 4), 64);
+            dma = std::max(dma, d * kStreamC);
+        }
+        pl.T = T;
+        pl.CS = cs;
+        pl.stage_bytes = kStreamC * cs * 4;
+        pl.cw = cdiv(tile * per, 64);
+        // loaders: an LDS-DMA instruction holds its wave for a few hundred cycles, a compute wave needs about
+        // kComputeTicks per sample -- enough loaders that the copy of a sample is not the longer of the two
+        const int NI = cdiv(kStreamC * cs / 4, 64);
+        pl.nl = std::min(4, std::max(cdiv(NI, kStreamMaxDma), cdiv(NI, 8)));
+        while (pl.nl > cdiv(NI, kStreamMaxDma) && pl.nl > 1 && pl.cw + pl.nl > kStreamMaxWaves) --pl.nl;
+        if (pl.cw + pl.nl > kStreamMaxWaves || cdiv(NI, pl.nl) > kStreamMaxDma) continue;
+        // the waves of a work-group go round-robin over the 4 SIMDs starting at the same one: a SIMD (4 waves of 128
+        // VGPRs) ends up with ceil(waves / 4) of every resident work-group
+        const int by_waves = 4 / cdiv(pl.cw + pl.nl, 4);
+        const int by_lds = kStreamLds / (2 * pl.stage_bytes);
+        if (by_waves < 1 || by_lds < 1) continue;
+        pl.wg_per_cu = std::min(by_waves, by_lds);
+        pl.nst = std::min(4, kStreamLds / (pl.wg_per_cu * pl.stage_bytes));
+        // samples of the whole map per tick and CU: wg work-groups each finish 1/T of a sample per period
+        const double t_compute = std::max(kLatencyTicks, kComputeTicks * cdiv(pl.wg_per_cu * pl.cw, 4));
+        const double t_dma = kDmaTicks * cdiv(NI, pl.nl);
+        const double score = pl.wg_per_cu / (T * std::max(t_compute, t_dma)) * (pl.nst >= 3 ? 1.0 : 0.8);
+        if (score > best_score * 1.02) {
+            best_score = score;
+            best = pl;
+        }
+    }
+    return best_score > 0;
+}
+
+static int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            cus = n;
+        else
+            cus = 256;
+    }
+    return cus;
+}
+
+static bool stream_shape_ok(const ProdGeom &q, int Cout, int64_t B, const float *in) {
+    return q.depthwise && q.C == kStreamC && Cout == kStreamC && q.kh * q.kw <= 4 && B >= stream_min_batch() &&
+           B >= 1 && ((uintptr_t)in & 15) == 0 && (int64_t)kStreamC * q.H * q.W * 4 < ((int64_t)1 << 30);
+}
+
+bool stream_prodsum_ok(const ProdGeom &q, int Cout, int64_t B, const float *in) {
+    if (!stream_shape_ok(q, Cout, B, in)) return false;
+    StreamPlan pl;
+    return stream_plan(0, q, nullptr, pl);
+}
+
+template <int MODE>
+static int stream_launch(StreamArgs &a, const StreamPlan &pl, int64_t B, hipStream_t st, int kernel_id) {
+    a.B = (int)B;
+    a.T = pl.T;
+    a.cw = pl.cw;
+    a.nl = pl.nl;
+    a.nst = pl.nst;
+    a.CS = pl.CS;
+    a.stage_bytes = pl.stage_bytes;
+    for (int i = 0; i < pl.T; ++i) a.tile[i] = pl.tile[i];
+    // one slice of the batch per resident work-group
+    // (all T tiles of a slice run on one XCD, see the kernel: 8 XCDs, each with an eighth of the work-group slots)
+    int64_t slices = 8 * std::max<int64_t>(1, (int64_t)(device_cus() / 8) * pl.wg_per_cu / pl.T);
+    if (slices > B) slices = B;
+    a.per_wg = (int)cdiv(B, slices);
+    a.slices = cdiv(B, a.per_wg);
+    auto kern = spatial_stream_kernel<MODE>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kStreamLds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
+            return DPK_ELAUNCH;
+        }
+        attr_done = true;
+    }
+    const unsigned grid = (unsigned)(pl.T * align_up(a.slices, 8));
+    static const bool debug = getenv("DPK_DGC_STREAM_DEBUG") != nullptr;
+    if (debug)
+        fprintf(stderr, "spatial_stream<%d>: in %dx%d out %dx%d  T=%d cw=%d nl=%d nst=%d CS=%d stage=%d B wg/cu=%d "
+                        "per_wg=%d slices=%d grid=%u bands(tile0)=%d rows=%d\n",
+                MODE, a.q5.H, a.q5.W, a.q5.OH, a.q5.OW, pl.T, pl.cw, pl.nl, pl.nst, pl.CS, pl.stage_bytes,
+                pl.wg_per_cu, a.per_wg, a.slices, grid, pl.tile[0].nb,
+                pl.tile[0].nr[0] + pl.tile[0].nr[1] + pl.tile[0].nr[2] + pl.tile[0].nr[3]);
+    hipEvent_t pev0, pev1;
+    profile_take(&pev0, &pev1, kernel_id);
+    if (pev0) (void)hipEventRecord(pev0, st);
+    static const bool timeline = DPK_STREAM_TL && getenv("DPK_DGC_STREAM_TIMELINE") != nullptr;
+    a.dbg = nullptr;
+    if (timeline) (void)hipMalloc(&a.dbg, 16 * 16 * 8 * 8 + 64 + 4096 * 32);
+    if (a.dbg) (void)hipMemset(a.dbg, 0, 16 * 16 * 8 * 8 + 64 + 4096 * 32);
+    DPK_LAUNCH(kern, dim3(grid), dim3((pl.cw + pl.nl) * 64), (size_t)pl.nst * pl.stage_bytes, st, a);
+    if (pev1) (void)hipEventRecord(pev1, st);
+    DPK_CHECK_LAUNCH("spatial_stream_kernel");
+    if (a.dbg) {   // measurement only: synchronous read-back of work-group 0's stamps
+        std::vector<long long> h(16 * 16 * 8 + 8 + 4096 * 4);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(a.dbg);
+        {
+            const long long *g = h.data() + 16 * 16 * 8 + 8;
+            long long first = -1;
+            for (unsigned b = 0; b < grid && b < 4096; ++b)
+                if (g[b * 4] && (first < 0 || g[b * 4] < first)) first = g[b * 4];
+            fprintf(stderr, "timeline<%d> work-group (start, loop start, end) in us after the first start:", MODE);
+            for (unsigned b = 0; b < grid && b < 4096; b += (grid > 64 ? grid / 32 : 1))
+                if (g[b * 4])
+                    fprintf(stderr, " %u:(%.1f %.1f %.1f)", b, (g[b * 4] - first) * 0.01, (g[b * 4 + 1] - first) * 0.01,
+                            (g[b * 4 + 2] - first) * 0.01);
+            fprintf(stderr, "\n");
+        }
+        const long long t0 = h[(0 * 16 + 0) * 8 + 0];
+        fprintf(stderr, "timeline<%d> loop of work-group 0: %lld s_memtime ticks, %lld s_memrealtime ticks (100 MHz), n=%d\n", MODE,
+                h[16 * 16 * 8 + 2] - h[16 * 16 * 8 + 0], h[16 * 16 * 8 + 3] - h[16 * 16 * 8 + 1], a.per_wg);
+        for (int w : {0, pl.cw - 1, pl.cw}) {
+            fprintf(stderr, "timeline<%d> %dx%d wave %d:", MODE, a.q5.H, a.q5.W, w);
+            for (int i = 0; i < 6; ++i) {
+                fprintf(stderr, "  [");
+                for (int sl = 0; sl < 5; ++sl) fprintf(stderr, " %lld", h[(w * 16 + i) * 8 + sl] ? h[(w * 16 + i) * 8 + sl] - t0 : -1);
+                fprintf(stderr, " ]");
+            }
+            fprintf(stderr, "\n");
+        }
+    }
+    return DPK_OK;
+}
+
+int stream_prodsum_forward(const float *in, int64_t B, const ProdGeom &q, const float *Wl, const float *LW, float *out,
+                           hipStream_t st) {
+    StreamPlan pl;
+    DPK_REQUIRE(stream_plan(0, q, nullptr, pl), DPK_EUNSUPPORTED, "spatial_prodsum: no streaming plan");
+    StreamArgs a{};
+    a.in = in;
+    a.Wl = Wl;
+    a.LW = LW;
+    a.LWr = nullptr;
+    a.out = out;
+    a.K = 0;
+    a.q5 = q;
+    a.q6 = q;
+    return stream_launch<0>(a, pl, B, st, DPK_KERNEL_SPATIAL_PRODSUM);
+}
+
+int64_t stream_sumprodroot_partial_bytes(const ProdGeom &q5, int Cout, const ProdGeom &q6, int K, int64_t B) {
+    if (!(q5.depthwise && q5.C == kStreamC && Cout == kStreamC && q5.kh * q5.kw <= 4 && q6.kh * q6.kw <= 4 &&
+          B >= stream_min_batch() && B >= 1 && K >= 1))
+        return 0;
+    StreamPlan pl;
+    if (!stream_plan(1, q5, &q6, pl)) return 0;
+    return align_up(B * pl.T * pl.cw * K * 2 * 4, 256);
+}
+
+int stream_sumprodroot_forward(const float *in, int64_t B, const ProdGeom &q5, const float *Wl, const float *LW,
+                               const ProdGeom &q6, const float *LWr, int K, float *out, void *partials,
+                               hipStream_t st) {
+    StreamPlan pl;
+    DPK_REQUIRE(stream_plan(1, q5, &q6, pl), DPK_EUNSUPPORTED, "spatial_sumprodroot: no streaming plan");
+    StreamArgs a{};
+    a.in = in;
+    a.Wl = Wl;
+    a.LW = LW;
+    a.LWr = LWr;
+    a.out = (float *)partials;
+    a.K = K;
+    a.q5 = q5;
+    a.q6 = q6;
+    int rc = stream_launch<1>(a, pl, B, st, DPK_KERNEL_SPATIAL_SUMPRODROOT);
+    if (rc) return rc;
+    DPK_LAUNCH(stream_root_combine_kernel, dim3(cdiv(B * K, 256)), dim3(256), 0, st, (const float *)partials, B,
+               pl.T * pl.cw, K, out);
+    DPK_CHECK_LAUNCH("stream_root_combine_kernel");
+    return DPK_OK;
+}
+
+}  // namespace dpk

@@ -202,11 +202,11 @@ def spatial_sumprodroot(x, prod5, sum_weight, prod6, root_weight, ws: Workspace)
         raise ValueError("layer shapes do not chain")
     g5 = (ctypes.c_int32 * 10)(OH5, OW5, kh5, kw5, sh5, sw5, dh5, dw5, pt5, pl5)
     g6 = (ctypes.c_int32 * 10)(OH6, OW6, kh6, kw6, sh6, sw6, dh6, dw6, pt6, pl6)
-    n = lib.dpk_spatial_sumprodroot_workspace_bytes(C, Cout, OH5, OW5, OH6, OW6, K)
-    if n < 0:
-        check(int(n), 'dpk_spatial_sumprodroot_workspace_bytes')
-    buf = ws.get(n, x.device)
     B = x.shape[0]
+    n = lib.dpk_spatial_sumprodroot_workspace_bytes_batch(B, C, H, W, g5, Cout, g6, K)
+    if n < 0:
+        check(int(n), 'dpk_spatial_sumprodroot_workspace_bytes_batch')
+    buf = ws.get(n, x.device)
     out = torch.empty((B, K), dtype=torch.float32, device=x.device)
     rc = lib.dpk_spatial_sumprodroot_forward(ptr(x), B, C, H, W, g5, ptr(w5), Cout, g6, ptr(wr), K, ptr(out), ptr(buf),
                                              buf.numel(), stream_ptr(x.device))

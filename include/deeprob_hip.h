@@ -418,6 +418,12 @@ int dpk_ll_accumulate(const float *ll, int64_t n, double *acc, void *stream);
  * (layers/dgcspn.py:151-198).  DPK_EUNSUPPORTED outside <= 8 channels / <= 1024 final pixels / <= 4 taps.     */
 int64_t dpk_spatial_sumprodroot_workspace_bytes(int32_t C, int32_t Cout, int32_t OH5, int32_t OW5, int32_t OH6,
                                                 int32_t OW6, int32_t K);
+/* Workspace for a batch of B samples: the tables of ..._workspace_bytes plus, where the streaming kernel applies
+ * (8 -> 8 channels, B >= 1024, `in` 16-byte aligned), one (max, sum) pair per sample, class and compute wave for the
+ * root's log-sum-exp.  With this much workspace the entry point streams the batch through LDS with the sum layer's
+ * weights resident in registers; with only ..._workspace_bytes it runs the batch-independent kernel.               */
+int64_t dpk_spatial_sumprodroot_workspace_bytes_batch(int64_t B, int32_t C, int32_t H, int32_t W, const int32_t *geom5,
+                                                      int32_t Cout, const int32_t *geom6, int32_t K);
 int dpk_spatial_sumprodroot_forward(const float *in, int64_t B, int32_t C, int32_t H, int32_t W, const int32_t *geom5,
                                     const float *sum_weight, int32_t Cout, const int32_t *geom6,
                                     const float *root_weight, int32_t K, float *out, void *ws, int64_t ws_bytes,

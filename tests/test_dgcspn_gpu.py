@@ -207,7 +207,7 @@ def test_empty_batch_and_errors():
 
 def test_full_size_properties():
     """BASELINE config 4 at full batch (8192 images 28x28): size-independent properties -- any slice of the batch
-    gives the same LLs (bit for bit), fully marginalised images give LL = 0, marginalising pixels changes nothing
+    served by the same kernels gives the same LLs (bit for bit), fully marginalised images give LL = 0, marginalising pixels changes nothing
     for the other samples."""
     from deeprob.spn.models import DgcSpn
     torch.manual_seed(5)
@@ -216,14 +216,61 @@ def test_full_size_properties():
     x[777] = float('nan')
     with torch.no_grad():
         ll = model(x)
-        part = model(x[1001:1001 + 515])
+        part = model(x[1001:1001 + 2048])
+        small = model(x[1001:1001 + 515])    # below the streaming kernels' batch threshold: the other route
         x2 = x.clone()
         x2[::2, :, :, 14:] = float('nan')
         ll2 = model(x2)
     assert tuple(ll.shape) == (8192, 1) and torch.isfinite(ll).all()
-    assert torch.equal(ll[1001:1001 + 515], part)
+    assert torch.equal(ll[1001:1001 + 2048], part)
+    # the two routes of the sum levels differ in summation order only (tolerance of the path: 1e-5 relative)
+    assert ((ll[1001:1001 + 515] - small).abs() / ll[1001:1001 + 515].abs().clamp_min(1.0)).max().item() < 2e-6
     assert abs(ll[777].item()) < 1e-5
     assert torch.equal(ll2[1::2], ll[1::2])
     # marginalising half of an image removes non-positive-on-average terms: not an identity, but the result must
     # stay finite and differ
     assert torch.isfinite(ll2).all() and not torch.equal(ll2[0], ll[0])
+
+
+def test_streaming_levels_golden(golden, monkeypatch):
+    """The streaming kernels of the 8 -> 8 channel levels (dgcspn_stream.hip; default route from B = 1024) forced onto
+    the golden batch of BASELINE config 4's model: same tolerance as the batch-independent route."""
+    monkeypatch.setenv('DPK_DGC_STREAM_MIN_B', '0')
+    g = golden('dgcspn_1x28x28_dw')
+    model = build_dgc('dgcspn_1x28x28_dw', g).cuda()
+    with torch.no_grad():
+        ll = model(torch.from_numpy(g['x']).cuda())
+        ll_nan = model(torch.from_numpy(g['x_nan']).cuda())
+    assert rel_err(ll.cpu().numpy(), g['ll']) <= LL_TOL
+    assert rel_err(ll_nan.cpu().numpy(), g['ll_nan']) <= LL_TOL
+
+
+@pytest.mark.parametrize('shape,classes,B', [((1, 20, 20), 3, 37), ((2, 16, 16), 1, 130), ((1, 28, 28), 10, 65)])
+def test_streaming_levels_against_oracle(monkeypatch, shape, classes, B):
+    """Streaming route against the oracle on maps and class counts the golden fixtures do not hold: ragged batch slices,
+    tiles that split rows, several root classes, far-tail inputs (exact log-domain pass), marginalised pixels."""
+    from deeprob.spn.models import DgcSpn
+    from tests.util import randomise_dgc
+    monkeypatch.setenv('DPK_DGC_STREAM_MIN_B', '0')
+    torch.manual_seed(11)
+    model = DgcSpn(shape, out_classes=classes, n_batch=8, sum_channels=8, depthwise=True, n_pooling=0)
+    randomise_dgc(model, 70)
+    model.eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    plan = dorc.schedule(shape, 8, 8, True, 0)
+    x = torch.randn(B, *shape, generator=torch.Generator().manual_seed(3))
+    x[1] = 35.0                                   # every Gaussian far in its tail
+    x[2, :, ::2] = float('nan')
+    x[3] = float('nan')
+    want = dorc.dgcspn_forward(sd, x, plan)
+    model.cuda()
+    with torch.no_grad():
+        got = model(x.cuda())
+        again = model(x.cuda()[5:])
+    assert tuple(got.shape) == (B, classes)
+    assert rel_err(got.cpu().numpy(), want.numpy()) <= LL_TOL
+    assert torch.equal(again, got[5:])
+    monkeypatch.setenv('DPK_DGC_STREAM_MIN_B', '1000000000')
+    with torch.no_grad():
+        other = model(x.cuda())
+    assert rel_err(got.cpu().numpy(), other.cpu().numpy()) <= 2e-6
