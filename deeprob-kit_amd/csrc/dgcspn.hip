@@ -845,7 +845,8 @@ extern "C" int dpk_spatial_sum_backward(const float *x, const float *weight, con
 extern "C" int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C, int32_t H, int32_t W, int32_t OH,
                                            int32_t OW, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t dh,
                                            int32_t dw, int32_t pad_top, int32_t pad_left, const float *weight,
-                                           int32_t Cout, float *out, void *ws, int64_t ws_bytes, void *stream) {
+                                           int32_t Cout, float *out, void *ws, int64_t ws_bytes, uint32_t flags,
+                                           void *stream) {
     ProdGeom q;
     int rc = make_geom(q, C, H, W, C, OH, OW, kh, kw, sh, sw, dh, dw, pad_top, pad_left, 1);
     if (rc) return rc;
@@ -863,8 +864,10 @@ extern "C" int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C
     DPK_REQUIRE(in && out, DPK_EINVAL, "spatial_prodsum: null pointer");
     float *Wl = (float *)ws, *LW = (float *)((char *)ws + seg);
     hipStream_t st = (hipStream_t)stream;
-    DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW, 256)), dim3(256), 0, st, weight,
-                       Cout, C, OHW, Wl, LW);
+    // (DPK_FLAG_PARAMS_CACHED: the workspace still holds the tables an earlier call built from this very weight)
+    if (!(flags & DPK_FLAG_PARAMS_CACHED))
+        DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW, 256)), dim3(256), 0, st, weight,
+                   Cout, C, OHW, Wl, LW);
     // large batches of the 8 -> 8 channel level: pixel-resident weights, taps staged through LDS (dgcspn_stream.hip)
     if (stream_prodsum_ok(q, Cout, B, in)) return stream_prodsum_forward(in, B, q, Wl, LW, out, st);
     const int Bi = (int)B;
@@ -1065,7 +1068,7 @@ extern "C" int64_t dpk_spatial_sumprodroot_workspace_bytes_batch(int64_t B, int3
 extern "C" int dpk_spatial_sumprodroot_forward(const float *in, int64_t B, int32_t C, int32_t H, int32_t W,
                                                const int32_t *geom5, const float *sum_weight, int32_t Cout,
                                                const int32_t *geom6, const float *root_weight, int32_t K, float *out,
-                                               void *ws, int64_t ws_bytes, void *stream) {
+                                               void *ws, int64_t ws_bytes, uint32_t flags, void *stream) {
     DPK_REQUIRE(geom5 && geom6, DPK_EINVAL, "spatial_sumprodroot: null geometry");
     // geom = {OH, OW, kh, kw, sh, sw, dh, dw, pad_top, pad_left} of a depthwise product layer
     ProdGeom q5, q6;
@@ -1089,9 +1092,11 @@ extern "C" int dpk_spatial_sumprodroot_forward(const float *in, int64_t B, int32
     const int64_t seg = align_up((int64_t)Cout * C * OHW5 * 4, 256);
     float *Wl = (float *)ws, *LW = (float *)((char *)ws + seg), *LWr = (float *)((char *)ws + 2 * seg);
     hipStream_t st = (hipStream_t)stream;
-    DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW5, 256)), dim3(256), 0, st, sum_weight,
-                       Cout, C, OHW5, Wl, LW);
-    DPK_LAUNCH(rowwise_logsoftmax_kernel, dim3(K), dim3(256), 0, st, root_weight, K, Cout * OHW6, LWr);
+    if (!(flags & DPK_FLAG_PARAMS_CACHED)) {   // else: tables of an earlier call from these very weights
+        DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW5, 256)), dim3(256), 0, st, sum_weight,
+                   Cout, C, OHW5, Wl, LW);
+        DPK_LAUNCH(rowwise_logsoftmax_kernel, dim3(K), dim3(256), 0, st, root_weight, K, Cout * OHW6, LWr);
+    }
     {
         // streaming kernel when the workspace carries its per-wave partials (.._workspace_bytes_batch)
         const int64_t base = dpk_spatial_sumprodroot_workspace_bytes(C, Cout, q5.OH, q5.OW, q6.OH, q6.OW, K);

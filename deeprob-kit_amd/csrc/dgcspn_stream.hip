@@ -216,7 +216,7 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
     bool act;          // this thread's value is used
     int p;             // its pixel in the level's output map
     int q = 0;         // MODE 1: its root pixel
-    bool root_lane = false;
+    bool root_q = false;   // MODE 1: the root pixel exists (all four lanes of its quad)
     if (MODE == 0) {
         act = j < count;
         p = first + min(j, count - 1);
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
         const int ph = oh6 * a.q6.sh - a.q6.pt + th6 * a.q6.dh, pw = ow6 * a.q6.sw - a.q6.pl + tw6 * a.q6.dw;
         act = qv && t6 < a.q6.kh * a.q6.kw && ph >= 0 && ph < a.q6.H && pw >= 0 && pw < a.q6.W;
         p = act ? ph * a.q5.OW + pw : 0;
-        root_lane = qv && t6 == 0;
+        root_q = qv;
     }
     unsigned offb[4];
     {
@@ -259,23 +259,20 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
             w[o][c2].y = a.Wl[((size_t)o * kStreamC + 2 * c2 + 1) * OHW + p];
         }
     const int OHW6 = (MODE == 1) ? a.q6.OH * a.q6.OW : 0;
-    float lwr[kStreamC];
+    // root layer: the four lanes of a quad hold the same product values; lane t6 takes output channels 2 t6, 2 t6 + 1
+    float lwr[2];
     if (MODE == 1) {
 #pragma unroll
-        for (int o = 0; o < kStreamC; ++o) lwr[o] = root_lane ? a.LWr[o * OHW6 + q] : -INFINITY;
+        for (int jj = 0; jj < 2; ++jj) lwr[jj] = root_q ? a.LWr[(2 * (j & 3) + jj) * OHW6 + q] : -INFINITY;
     }
-    float *outp = (MODE == 0) ? a.out + (size_t)s0 * kStreamC * OHW + p : a.out;
     // The weights are consumed here, once: hipcc otherwise puts the vmcnt waits of these loads at their first use
-    // INSIDE the sample loop, where they count down to vmcnt(0) in every iteration and drain the previous sample's
-    // stores (measured: 3x on the whole kernel).
+    // INSIDE the sample loop, where they count down to vmcnt(0) in every iteration and wait for the previous sample's
+    // stores.
 #pragma unroll
     for (int o = 0; o < kStreamC; ++o)
 #pragma unroll
         for (int c2 = 0; c2 < kStreamC / 2; ++c2) asm volatile("" : "+v"(w[o][c2].x), "+v"(w[o][c2].y));
-    if (MODE == 1) {
-#pragma unroll
-        for (int o = 0; o < kStreamC; ++o) asm volatile("" : "+v"(lwr[o]));
-    }
+    if (MODE == 1) asm volatile("" : "+v"(lwr[0]), "+v"(lwr[1]));
     __syncthreads();
 
     if (DPK_STREAM_TL && a.dbg && tid == 0) a.dbg[16 * 16 * 8 + 8 + bid * 4 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -328,14 +325,21 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
 #pragma unroll
             for (int o = 0; o < kStreamC; ++o)
                 if (v2[o].x + v2[o].y < 1e-30f) {
+                    // (the tap sums are read again from the stage: keeping them live across the hot path costs it
+                    // 8 registers)
                     const float *lp = a.LW + (size_t)o * kStreamC * OHW + p;
+                    auto taps = [&](int c) {
+                        const unsigned kc = sb + 4u * (unsigned)(c * CS + ((c * HW + r0[0] * W) & 3));
+                        return (*(lfloat *)(smem + (kc + offb[0])) + *(lfloat *)(smem + (kc + offb[1]))) +
+                               (*(lfloat *)(smem + (kc + offb[2])) + *(lfloat *)(smem + (kc + offb[3])));
+                    };
                     float mm = -INFINITY;
 #pragma unroll 1
-                    for (int c = 0; c < kStreamC; ++c) mm = fmaxf(mm, acc[c] + lp[(size_t)c * OHW]);
+                    for (int c = 0; c < kStreamC; ++c) mm = fmaxf(mm, taps(c) + lp[(size_t)c * OHW]);
                     if (mm > -INFINITY) {
                         float sx = 0.f;
 #pragma unroll 1
-                        for (int c = 0; c < kStreamC; ++c) sx += expf(acc[c] + lp[(size_t)c * OHW] - mm);
+                        for (int c = 0; c < kStreamC; ++c) sx += expf(taps(c) + lp[(size_t)c * OHW] - mm);
                         r[o] = mm + logf(sx);
                     } else {
                         r[o] = -INFINITY;
@@ -345,30 +349,29 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
         STREAM_STAMP(3);
         if (MODE == 0) {
             if (act) {
+                float *ob = a.out + (size_t)(s0 + i) * kStreamC * OHW;   // wave-uniform base + one lane offset
 #pragma unroll
-                for (int o = 0; o < kStreamC; ++o) outp[(size_t)o * OHW] = r[o];
+                for (int o = 0; o < kStreamC; ++o) ob[(size_t)o * OHW + p] = r[o];
             }
-            outp += (size_t)kStreamC * OHW;
         } else {
             // last product layer: the four taps of a root pixel are the four lanes of a quad (padding taps add log 1)
             float P[kStreamC];
 #pragma unroll
             for (int o = 0; o < kStreamC; ++o) P[o] = dpp_quad_sum(act ? r[o] : 0.f);
+            const int t6l = j & 3;
+            const float pa = t6l == 0 ? P[0] : t6l == 1 ? P[2] : t6l == 2 ? P[4] : P[6];
+            const float pb = t6l == 0 ? P[1] : t6l == 1 ? P[3] : t6l == 2 ? P[5] : P[7];
             for (int k = 0; k < a.K; ++k) {
-                float tv[kStreamC], tm = -INFINITY;
-#pragma unroll
-                for (int o = 0; o < kStreamC; ++o) {
-                    const float lw = (k == 0) ? lwr[o]
-                                              : (root_lane ? a.LWr[((size_t)k * kStreamC + o) * OHW6 + q] : -INFINITY);
-                    tv[o] = P[o] + lw;   // -inf outside the root lanes
-                    tm = fmaxf(tm, tv[o]);
+                float l0 = lwr[0], l1 = lwr[1];
+                if (k > 0) {
+                    l0 = root_q ? a.LWr[((size_t)k * kStreamC + 2 * t6l) * OHW6 + q] : -INFINITY;
+                    l1 = root_q ? a.LWr[((size_t)k * kStreamC + 2 * t6l + 1) * OHW6 + q] : -INFINITY;
                 }
-                const float wm = dpp_wave_max(tm);
-                const float wmf = (wm == -INFINITY) ? 0.f : wm;
-                float ts = 0.f;
-#pragma unroll
-                for (int o = 0; o < kStreamC; ++o)
-                    ts += __builtin_amdgcn_exp2f((tv[o] - wmf) * 1.44269504088896340736f);
+                const float tv0 = pa + l0, tv1 = pb + l1;   // -inf outside the map of root pixels
+                const float wm = dpp_wave_max(fmaxf(tv0, tv1));
+                const float wml = (wm == -INFINITY) ? 0.f : -wm * 1.44269504088896340736f;
+                float ts = __builtin_amdgcn_exp2f(fmaf(tv0, 1.44269504088896340736f, wml)) +
+                           __builtin_amdgcn_exp2f(fmaf(tv1, 1.44269504088896340736f, wml));
                 ts = dpp_wave_sum(ts);
                 if (lane == 0) {
                     float *pp = a.out + ((((size_t)(s0 + i) * a.T + tile_i) * cw + wave) * a.K + k) * 2;
@@ -386,23 +389,24 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
     }
 }
 
-// out[b,k] = log-sum-exp of the (max, sum) pairs the waves of every tile left for sample b and class k
+// out[b,k] = log-sum-exp of the (max, sum) pairs the waves of every tile left for sample b and class k: one wave per
+// (b, k), lanes over the pairs
 __global__ __launch_bounds__(256) void stream_root_combine_kernel(const float *__restrict__ part, int64_t B, int np,
                                                                    int K, float *__restrict__ out) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= B * K) return;
     const int64_t b = e / K;
     const int k = (int)(e - b * K);
     const float *pp = part + ((size_t)b * np * K + k) * 2;
     float m = -INFINITY;
-    for (int i = 0; i < np; ++i) m = fmaxf(m, pp[(size_t)i * K * 2]);
-    if (m == -INFINITY) {
-        out[e] = -INFINITY;
-        return;
-    }
+    for (int i = lane; i < np; i += 64) m = fmaxf(m, pp[(size_t)i * K * 2]);
+    m = wave_reduce_max(m);
     float s = 0.f;
-    for (int i = 0; i < np; ++i) s += pp[(size_t)i * K * 2 + 1] * expf(pp[(size_t)i * K * 2] - m);
-    out[e] = m + logf(s);
+    if (m > -INFINITY)
+        for (int i = lane; i < np; i += 64) s += pp[(size_t)i * K * 2 + 1] * expf(pp[(size_t)i * K * 2] - m);
+    s = wave_reduce_sum(s);
+    if (lane == 0) out[e] = (m > -INFINITY) ? m + logf(s) : -INFINITY;
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -678,7 +682,7 @@ int stream_sumprodroot_forward(const float *in, int64_t B, const ProdGeom &q5, c
     a.q6 = q6;
     int rc = stream_launch<1>(a, pl, B, st, DPK_KERNEL_SPATIAL_SUMPRODROOT);
     if (rc) return rc;
-    DPK_LAUNCH(stream_root_combine_kernel, dim3(cdiv(B * K, 256)), dim3(256), 0, st, (const float *)partials, B,
+    DPK_LAUNCH(stream_root_combine_kernel, dim3(cdiv(B * K, 4)), dim3(256), 0, st, (const float *)partials, B,
                pl.T * pl.cw, K, out);
     DPK_CHECK_LAUNCH("stream_root_combine_kernel");
     return DPK_OK;

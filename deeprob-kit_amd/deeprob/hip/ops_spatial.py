@@ -5,7 +5,7 @@ there is no CPU path.
 """
 import torch
 
-from deeprob.hip import load_library, check, ptr, stream_ptr, require_device_f32, Workspace
+from deeprob.hip import load_library, check, ptr, stream_ptr, require_device_f32, Workspace, DPK_FLAG_PARAMS_CACHED
 
 
 class SpatialGaussianFn(torch.autograd.Function):
@@ -131,6 +131,18 @@ class SpatialSumFn(torch.autograd.Function):
         return gx, gw, None
 
 
+def _tables_flag(ws: Workspace, route: str, *weights) -> int:
+    """DPK_FLAG_PARAMS_CACHED when the workspace's softmaxed-weight tables were built by an earlier call of the same
+    entry point from these very tensors (address, shape, version counter; Workspace.get() drops the key when the
+    buffer is replaced).  In-place writes that bypass the version counter (``weight.data.copy_``) are not seen --
+    the same caveat as the RAT-SPN tables."""
+    key = (route,) + tuple((w.data_ptr(), tuple(w.shape), w._version) for w in weights)
+    if ws.params_key == key:
+        return DPK_FLAG_PARAMS_CACHED
+    ws.params_key = key
+    return 0
+
+
 def spatial_prodsum(x, prod_layer, weight, ws: Workspace):
     """One eval-mode DGC-SPN level, depthwise SpatialProductLayer + SpatialSumLayer in a single launch
     (reference: deeprob/spn/models/dgcspn.py:146-147).  No autograd graph is recorded.  Returns None when
@@ -146,8 +158,11 @@ def spatial_prodsum(x, prod_layer, weight, ws: Workspace):
     B, Cout = x.shape[0], w.shape[0]
     out = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
     buf = _spatial_sum_ws(ws, C, Cout, OH, OW, x.device)
+    flags = _tables_flag(ws, 'prodsum', w)
     rc = lib.dpk_spatial_prodsum_forward(ptr(x), B, C, H, W, OH, OW, kh, kw, sh, sw, dh, dw, pt, pl, ptr(w), Cout,
-                                         ptr(out), ptr(buf), buf.numel(), stream_ptr(x.device))
+                                         ptr(out), ptr(buf), buf.numel(), flags, stream_ptr(x.device))
+    if rc:
+        ws.params_key = None
     if rc == -4:  # DPK_EUNSUPPORTED
         return None
     check(rc, 'dpk_spatial_prodsum_forward')
@@ -208,8 +223,11 @@ def spatial_sumprodroot(x, prod5, sum_weight, prod6, root_weight, ws: Workspace)
         check(int(n), 'dpk_spatial_sumprodroot_workspace_bytes_batch')
     buf = ws.get(n, x.device)
     out = torch.empty((B, K), dtype=torch.float32, device=x.device)
+    flags = _tables_flag(ws, 'sumprodroot', w5, wr)
     rc = lib.dpk_spatial_sumprodroot_forward(ptr(x), B, C, H, W, g5, ptr(w5), Cout, g6, ptr(wr), K, ptr(out), ptr(buf),
-                                             buf.numel(), stream_ptr(x.device))
+                                             buf.numel(), flags, stream_ptr(x.device))
+    if rc:
+        ws.params_key = None
     if rc == -4:  # DPK_EUNSUPPORTED
         return None
     check(rc, 'dpk_spatial_sumprodroot_forward')

@@ -270,11 +270,15 @@ int dpk_spatial_sum_backward(const float *x, const float *weight, const float *o
 /* Eval route of one DGC-SPN level: depthwise SpatialProductLayer (<= 4 taps, C <= 32) fused with the
  * SpatialSumLayer that follows it (models/dgcspn.py:146-147), the product map never reaches HBM.
  * Geometry as dpk_spatial_product_forward, weight [Cout,C,OH,OW], workspace of
- * dpk_spatial_sum_workspace_bytes(C,Cout,OH,OW).  DPK_EUNSUPPORTED outside that envelope.      */
+ * dpk_spatial_sum_workspace_bytes(C,Cout,OH,OW).  DPK_EUNSUPPORTED outside that envelope.
+ * flags: DPK_FLAG_PARAMS_CACHED = the workspace still holds the softmaxed weight tables a previous call built
+ * from this very weight tensor (unchanged since), they are not rebuilt.  8 -> 8 channel levels on batches of
+ * 1024 samples and more (input 16-byte aligned) take the streaming kernel: the 64 weights of an output pixel
+ * stay in registers while its work-group walks a slice of the batch staged through LDS.                     */
 int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C, int32_t H, int32_t W, int32_t OH,
                                 int32_t OW, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t dh,
                                 int32_t dw, int32_t pad_top, int32_t pad_left, const float *weight, int32_t Cout,
-                                float *out, void *ws, int64_t ws_bytes, void *stream);
+                                float *out, void *ws, int64_t ws_bytes, uint32_t flags, void *stream);
 
 /* ---- RealNVP-1D training route (autograd of the flow) ------------------- */
 /* Backward of CouplingLayer1d.apply_backward (flows/layers/coupling.py:72-87), depth-1 conditioner:
@@ -427,7 +431,7 @@ int64_t dpk_spatial_sumprodroot_workspace_bytes_batch(int64_t B, int32_t C, int3
 int dpk_spatial_sumprodroot_forward(const float *in, int64_t B, int32_t C, int32_t H, int32_t W, const int32_t *geom5,
                                     const float *sum_weight, int32_t Cout, const int32_t *geom6,
                                     const float *root_weight, int32_t K, float *out, void *ws, int64_t ws_bytes,
-                                    void *stream);
+                                    uint32_t flags, void *stream);   /* flags: DPK_FLAG_PARAMS_CACHED as above */
 
 /* ---- vanilla (node-graph) SPN, flattened (BASELINE config 1) ---------------------------------------------
  * Bottom-up log-likelihood of deeprob/spn/algorithms/inference.py:37-58 (eval_bottom_up, evaluation.py:37-96;
