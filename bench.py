@@ -291,10 +291,13 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
     rate, dt = _oracle_rate(lambda a, b: forc.flow_log_prob(sd, xc[a:b]), 16384, 4096, threads)
     e = {'workload': 'RealNVP1d(784, n_flows=5, depth=1, units=128, batch_norm, affine) forward log-likelihood',
          'config': 'BASELINE config 5', 'batch': B, 'ms_per_step': ms, 'value': B / ms * 1e3,
-         'unit': 'log-likelihoods/sec', 'kernel_ms': k_ms, 'kernel': 'coupling1d_kernel (one of the 5 layers)',
-         'roofline': flops(per_layer, k_ms) if k_ms else flops(5 * per_layer, ms),
-         'roofline_basis': 'one coupling kernel; mask-aware 2*(392*128 + 128*784) flop per sample and layer on the '
-                           'fp32 MFMA' if k_ms else 'whole step, mask-aware flops',
+         'unit': 'log-likelihoods/sec', 'kernel_ms': k_ms,
+         'kernel': 'coupling_x3_kernel (one of the 5 layers; split-f16 MFMA, fp32-grade products)',
+         'roofline': hbm(B * 2 * D * 4, k_ms) if k_ms else hbm(5 * B * 2 * D * 4, ms),
+         'roofline_basis': 'one coupling kernel; x read + out written once: 2*784*4 algorithmic B per sample and layer '
+                           '(the conditioner runs on the f16 matrix cores at 3 MFMAs per fp32-grade product, far '
+                           'from their peak)' if k_ms else 'whole step, 5 layers',
+         'fp32_equivalent_tflops': (per_layer / (k_ms * 1e-3) / 1e12) if k_ms else None,
          'cpu_baseline': {'value': rate, 'unit': 'log-likelihoods/sec', 'cores': threads, 'kind': 'port',
                           'sample': '16384 samples ({:.1f} s), oracle/flows_oracle.py'.format(dt)}}
     out.append(e)
