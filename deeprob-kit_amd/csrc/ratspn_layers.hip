@@ -804,11 +804,11 @@ namespace dpk {
 bool upper_mfma_shape_ok(bool root, int N, int S);
 int64_t upper_mfma_frag_bytes(int R, int N, int S);
 int upper_mfma_forward(bool root, const float *in, const float *W, const float *LW, int64_t B, int R, int N, int S,
-                       float *out, void *frag, hipStream_t st);
+                       float *out, void *frag, bool frag_cached, hipStream_t st);
 }
 
 static int prod_fused_common(bool root, const float *in, const float *weight, int64_t B, int R, int N, int S,
-                             float *out, void *ws, int64_t ws_bytes, void *stream, const char *who) {
+                             float *out, void *ws, int64_t ws_bytes, uint32_t flags, void *stream, const char *who) {
     DPK_REQUIRE(B >= 0 && R > 0 && (R % 2) == 0 && N > 0 && S > 0, DPK_EINVAL, "%s: bad sizes", who);
     DPK_REQUIRE(N <= 32, DPK_EUNSUPPORTED, "%s: %d nodes per region > 32", who, N);
     DPK_REQUIRE(weight && ws, DPK_EINVAL, "%s: null pointer", who);
@@ -821,7 +821,9 @@ static int prod_fused_common(bool root, const float *in, const float *weight, in
     DPK_REQUIRE(in && out, DPK_EINVAL, "%s: null pointer", who);
     float *W = (float *)ws, *LW = (float *)((char *)ws + seg);
     hipStream_t st = (hipStream_t)stream;
-    DPK_LAUNCH(softmax_rows_kernel2, dim3(cdiv(rows, 4)), dim3(256), 0, st, weight, rows, n, W, LW);
+    // DPK_FLAG_PARAMS_CACHED: softmax rows (and MFMA fragments) of an earlier call from this very weight are in ws
+    const bool cached = flags & DPK_FLAG_PARAMS_CACHED;
+    if (!cached) DPK_LAUNCH(softmax_rows_kernel2, dim3(cdiv(rows, 4)), dim3(256), 0, st, weight, rows, n, W, LW);
     {
         static const bool mfma = [] {
             const char *e = getenv("DPK_RATSPN_GEMM");
@@ -830,7 +832,7 @@ static int prod_fused_common(bool root, const float *in, const float *weight, in
         const int64_t fb = upper_mfma_frag_bytes(R, N, S);
         if (mfma && upper_mfma_shape_ok(root, N, S) && ws_bytes >= 2 * seg + fb &&
             (reinterpret_cast<uintptr_t>(in) & 15) == 0)
-            return upper_mfma_forward(root, in, W, LW, B, R, N, S, out, (char *)ws + 2 * seg, st);
+            return upper_mfma_forward(root, in, W, LW, B, R, N, S, out, (char *)ws + 2 * seg, cached, st);
     }
     const dim3 block(256);
 #define DPK_LAUNCH_PS(NMAX)                                                                                         \
@@ -856,10 +858,10 @@ extern "C" int64_t dpk_prodsum_workspace_bytes(int32_t R, int32_t N, int32_t S) 
     return 2 * align_up((int64_t)(R / 2) * S * N * N * 4, 256) + upper_mfma_frag_bytes(R, N, S) + 256;
 }
 extern "C" int dpk_prodsum_forward(const float *in, const float *weight, int64_t B, int32_t R, int32_t N, int32_t S,
-                                   float *out, void *ws, int64_t ws_bytes, void *stream) {
-    return prod_fused_common(false, in, weight, B, R, N, S, out, ws, ws_bytes, stream, "prodsum_forward");
+                                   float *out, void *ws, int64_t ws_bytes, uint32_t flags, void *stream) {
+    return prod_fused_common(false, in, weight, B, R, N, S, out, ws, ws_bytes, flags, stream, "prodsum_forward");
 }
 extern "C" int dpk_prodroot_forward(const float *in, const float *weight, int64_t B, int32_t R, int32_t N, int32_t C,
-                                    float *out, void *ws, int64_t ws_bytes, void *stream) {
-    return prod_fused_common(true, in, weight, B, R, N, C, out, ws, ws_bytes, stream, "prodroot_forward");
+                                    float *out, void *ws, int64_t ws_bytes, uint32_t flags, void *stream) {
+    return prod_fused_common(true, in, weight, B, R, N, C, out, ws, ws_bytes, flags, stream, "prodroot_forward");
 }

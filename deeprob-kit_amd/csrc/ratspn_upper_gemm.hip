@@ -284,9 +284,10 @@ int64_t upper_mfma_frag_bytes(int R, int N, int S) {   // (covers the sum and th
 
 // W / LW: linear and log softmax weights (already computed by the caller), frag: upper_mfma_frag_bytes() of scratch
 int upper_mfma_forward(bool root, const float *in, const float *W, const float *LW, int64_t B, int R, int N, int S,
-                       float *out, void *frag, hipStream_t st) {
+                       float *out, void *frag, bool frag_cached, hipStream_t st) {
     const int P = R / 2, tiles = root ? root_ct(N, S) : cdiv((int64_t)S * N, 32);
-    DPK_LAUNCH(upper_pack_kernel, dim3(cdiv((int64_t)P * tiles * 64, 256)), dim3(256), 0, st, W, P, N, S,
+    if (!frag_cached)
+        DPK_LAUNCH(upper_pack_kernel, dim3(cdiv((int64_t)P * tiles * 64, 256)), dim3(256), 0, st, W, P, N, S,
                        root ? 1 : 0, tiles, (uint16_t *)frag);
     UpperArgs a{};
     a.in = in; a.frag = (const uint16_t *)frag; a.LW = LW; a.out = out; a.B = B; a.R = R; a.S = S; a.tiles = tiles;

@@ -245,6 +245,7 @@ def _sum_ws(ws: Workspace, B, P, N, S, device):
     n = lib.dpk_sum_workspace_bytes(B, P, N, S)
     if n < 0:
         check(int(n), 'dpk_sum_workspace_bytes')
+    ws.params_key = None   # the per-layer route lays its own tables over the folded route's cached ones
     return ws.get(n, device)
 
 
@@ -425,6 +426,17 @@ def _prodsum_ws(ws: Workspace, R, N, S, device):
     return ws.get(n, device)
 
 
+def _upper_tables_flag(ws: Workspace, route: str, w: torch.Tensor) -> int:
+    """DPK_FLAG_PARAMS_CACHED when the layer's workspace still holds the softmax rows and MFMA fragments that the
+    same folded entry point built from this very weight tensor (address, shape, version counter).  The per-layer
+    operators sharing the workspace drop the key (_sum_ws), so does a replaced buffer (Workspace.get)."""
+    key = (route, w.data_ptr(), tuple(w.shape), w._version)
+    if ws.params_key == key:
+        return DPK_FLAG_PARAMS_CACHED
+    ws.params_key = key
+    return 0
+
+
 def prodsum_forward(x: torch.Tensor, weight: torch.Tensor, ws: Workspace) -> Optional[torch.Tensor]:
     """ProductLayer + SumLayer in one launch, eval mode, no autograd graph (reference: ratspn.py:272-286, :363-378).
     x [B,R,N], weight [R/2,S,N*N] -> [B,R/2,S]; None when N is beyond what the kernel is built for."""
@@ -435,7 +447,11 @@ def prodsum_forward(x: torch.Tensor, weight: torch.Tensor, ws: Workspace) -> Opt
     S = w.shape[1]
     out = torch.empty((B, R // 2, S), dtype=torch.float32, device=x.device)
     buf = _prodsum_ws(ws, R, N, S, x.device)
-    rc = lib.dpk_prodsum_forward(ptr(x), ptr(w), B, R, N, S, ptr(out), ptr(buf), buf.numel(), stream_ptr(x.device))
+    flags = _upper_tables_flag(ws, 'prodsum', w)
+    rc = lib.dpk_prodsum_forward(ptr(x), ptr(w), B, R, N, S, ptr(out), ptr(buf), buf.numel(), flags,
+                                 stream_ptr(x.device))
+    if rc:
+        ws.params_key = None
     if rc == -4:
         return None
     check(rc, 'dpk_prodsum_forward')
@@ -452,7 +468,11 @@ def prodroot_forward(x: torch.Tensor, weight: torch.Tensor, ws: Workspace) -> Op
     C = w.shape[0]
     out = torch.empty((B, C), dtype=torch.float32, device=x.device)
     buf = _prodsum_ws(ws, R, N, C, x.device)
-    rc = lib.dpk_prodroot_forward(ptr(x), ptr(w), B, R, N, C, ptr(out), ptr(buf), buf.numel(), stream_ptr(x.device))
+    flags = _upper_tables_flag(ws, 'prodroot', w)
+    rc = lib.dpk_prodroot_forward(ptr(x), ptr(w), B, R, N, C, ptr(out), ptr(buf), buf.numel(), flags,
+                                  stream_ptr(x.device))
+    if rc:
+        ws.params_key = None
     if rc == -4:
         return None
     check(rc, 'dpk_prodroot_forward')

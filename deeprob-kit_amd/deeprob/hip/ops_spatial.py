@@ -109,6 +109,7 @@ class SpatialSumFn(torch.autograd.Function):
         Cout = w.shape[0]
         out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
         buf = _spatial_sum_ws(ws, Cin, Cout, H, W, x.device)
+        ws.params_key = None   # (the folded eval route caches its tables in the same workspace)
         check(lib.dpk_spatial_sum_forward(ptr(x), ptr(w), B, Cin, Cout, H, W, ptr(out), ptr(buf), buf.numel(),
                                           stream_ptr(x.device)), 'dpk_spatial_sum_forward')
         ctx.save_for_backward(x, w, out)
@@ -125,6 +126,7 @@ class SpatialSumFn(torch.autograd.Function):
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
         buf = _spatial_sum_ws(ctx.ws, Cin, Cout, H, W, x.device)
+        ctx.ws.params_key = None
         check(lib.dpk_spatial_sum_backward(ptr(x), ptr(w), ptr(out), ptr(g), B, Cin, Cout, H, W, ptr(gx), ptr(gw),
                                            ptr(buf), buf.numel(), stream_ptr(x.device)),
               'dpk_spatial_sum_backward')

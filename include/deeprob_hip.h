@@ -232,10 +232,12 @@ int dpk_normal_base_logprob(const float *u, const float *scale_in, const float *
  * never reaches HBM.  in [B,R,N]; prodsum: weight [R/2,S,N^2] -> out [B,R/2,S]; prodroot: weight [C,(R/2)*N^2] ->
  * out [B,C].  N <= 32.  Workspace: dpk_prodsum_workspace_bytes(R,N,S) (S = C for the root).                 */
 int64_t dpk_prodsum_workspace_bytes(int32_t R, int32_t N, int32_t S);
+/* flags: DPK_FLAG_PARAMS_CACHED = the workspace still holds the softmax rows (and MFMA fragments) that an earlier
+ * call of the same entry point built from this very weight tensor, unchanged since: they are not rebuilt.     */
 int dpk_prodsum_forward(const float *in, const float *weight, int64_t B, int32_t R, int32_t N, int32_t S, float *out,
-                        void *ws, int64_t ws_bytes, void *stream);
+                        void *ws, int64_t ws_bytes, uint32_t flags, void *stream);
 int dpk_prodroot_forward(const float *in, const float *weight, int64_t B, int32_t R, int32_t N, int32_t C, float *out,
-                         void *ws, int64_t ws_bytes, void *stream);
+                         void *ws, int64_t ws_bytes, uint32_t flags, void *stream);
 
 /* ---- DGC-SPN spatial layers (NCHW fp32; deeprob/spn/layers/dgcspn.py) ------------------ */
 /* SpatialGaussianLayer.forward (dgcspn.py:101-120):

@@ -514,6 +514,39 @@ def test_mfma_route_tables_follow_the_parameters(golden):
     assert rel_err(p2.cpu().numpy(), orc.ratspn_forward(sd, x).numpy()) <= LL_TOL
 
 
+@pytest.mark.parametrize('I', [8, 16])
+def test_folded_route_tables_follow_the_parameters(I):
+    """Wide models (leaf | product+sum | product+root kernels): the softmax rows and MFMA fragments cached in each
+    layer's workspace follow in-place parameter updates, survive the per-layer (autograd) route writing its own
+    tables into the same workspaces, and an unchanged model repeats bit for bit."""
+    from deeprob.spn.models import GaussianRatSpn
+    torch.manual_seed(4)
+    model = GaussianRatSpn(64, rg_depth=2, rg_repetitions=4, rg_batch=I, rg_sum=I, random_state=3).cuda().eval()
+    x = torch.randn(200, 64, generator=torch.Generator().manual_seed(6))
+
+    def oracle():
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        return orc.ratspn_forward(sd, x).numpy()
+
+    with torch.no_grad():
+        a = model(x.cuda())
+        b = model(x.cuda())
+    assert torch.equal(a, b) and rel_err(a.cpu().numpy(), oracle()) <= LL_TOL
+    # the autograd route shares the layers' workspaces (same weights, other tables)
+    model.train()
+    model(x.cuda().requires_grad_(True)).sum().backward()
+    model.eval()
+    with torch.no_grad():
+        c = model(x.cuda())
+        assert torch.equal(a, c)
+        for layer in model.layers:
+            if hasattr(layer, 'weight') and layer.weight.requires_grad:
+                layer.weight.add_(torch.randn_like(layer.weight))
+        model.root_layer.weight.mul_(0.3)
+        d = model(x.cuda())
+    assert not torch.equal(a, d) and rel_err(d.cpu().numpy(), oracle()) <= LL_TOL
+
+
 @pytest.mark.parametrize('D,depth,reps', [(9, 3, 5), (100, 6, 3), (15, 2, 3)])
 def test_input_gradient_with_heavily_padded_region_graphs(D, depth, reps):
     """d/dx of the leaf layer when the padding is at least a region wide (pad >= d: 2^depth regions per repetition is
