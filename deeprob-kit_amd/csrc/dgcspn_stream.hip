@@ -496,7 +496,10 @@ static bool stream_plan(int mode, const ProdGeom &q5, const ProdGeom *q6, Stream
     const int N = mode == 0 ? q5.OH * q5.OW : q6->OH * q6->OW;   // pixels / root pixels to distribute
     const int per = mode == 0 ? 1 : 4;                           // thread slots per unit
     double best_score = -1;
+    const char *force = getenv("DPK_DGC_STREAM_T");   // measurement only: "<mode>:<T>" pins the tile count of a mode
+    const int forced_T = (force && force[0] - '0' == mode && force[1] == ':') ? atoi(force + 2) : 0;
     for (int T = 1; T <= kStreamMaxTiles; ++T) {
+        if (forced_T && T != forced_T) continue;
         StreamPlan pl;
         const int tile = cdiv(N, T);
         if (cdiv(N, tile) != T) continue;   // same tiling as a smaller T
