@@ -27,6 +27,9 @@
 #include "common.h"
 #include "ratspn_gemm_common.h"
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
 
 namespace dpk {
 
@@ -148,6 +151,7 @@ struct X3Args {
     const uint16_t *w1t;
     const char *w2t;
     const float *b1f, *act_weight;
+    long long *dbg;   // measurement only (-DDPK_X3_TIMELINE + DPK_X3_TIMELINE=1): s_memtime stamps of work-group 0
 };
 
 __device__ __forceinline__ float x3_tanh(float v) {
@@ -156,6 +160,19 @@ __device__ __forceinline__ float x3_tanh(float v) {
     const float t = __builtin_amdgcn_exp2f(c * 2.8853900817779268f);
     return (t - 1.f) * __builtin_amdgcn_rcpf(t + 1.f);
 }
+
+// s_memtime stamps of work-group 0 (row = chunk count of the wave; slots: 0 before the chunk's barrier, 1 after it,
+// 2 end of the chunk, 4 phase 2: MFMAs done; loaders: 0 before the counted wait, 1 after it, 2 after the barrier,
+// 3 after issuing the next chunk).  Compiled in with -DDPK_X3_TIMELINE only.
+#ifdef DPK_X3_TIMELINE
+#define X3_STAMP(row, slot)                                                                                  \
+    do {                                                                                                     \
+        if (a.dbg && blockIdx.x == 0 && lane == 0 && (row) < 64)                                             \
+            a.dbg[((wave8 * 64) + (row)) * 8 + (slot)] = (long long)__builtin_readcyclecounter();            \
+    } while (0)
+#else
+#define X3_STAMP(row, slot) do { } while (0)
+#endif
 
 template <bool AFFINE, int NU>
 __global__ __launch_bounds__(2 * kGemmWaves * 64) void coupling_x3_kernel(const X3Args a) {
@@ -232,8 +249,10 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void coupling_x3_kernel(const 
         for (int g = 0; g < kGemmStages - 1; ++g)
             if (ptile < ntiles) issue_next();
         __syncthreads();
+        [[maybe_unused]] int lrow = 0;
         for (int tile = (int)blockIdx.x; tile < ntiles; tile += grid) {
             for (int c = 0; c < nchunks; ++c) {
+                X3_STAMP(lrow, 0);
                 // chunk c has landed once only the chunk issued after it (if any) is still in flight
                 const bool last = (c + 1 == nchunks) && !(tile + grid < ntiles);
                 if (last) {
@@ -243,8 +262,12 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void coupling_x3_kernel(const 
                 } else {
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P2) : "memory");
                 }
+                X3_STAMP(lrow, 1);
                 gemm_lds_barrier();
+                X3_STAMP(lrow, 2);
                 if (ptile < ntiles) issue_next();
+                X3_STAMP(lrow, 3);
+                ++lrow;
             }
         }
         return;
@@ -266,6 +289,7 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void coupling_x3_kernel(const 
     const int pm = a.pm;
 
     int cstage = 0;
+    [[maybe_unused]] int crow = 0;   // timeline row (chunk count of this work-group)
     for (int tile = (int)blockIdx.x; tile < ntiles; tile += grid) {
         gf32x16 acc[NU];
 #pragma unroll
@@ -274,7 +298,9 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void coupling_x3_kernel(const 
             for (int i = 0; i < 16; ++i) acc[T][i] = 0.f;
         // ---- phase 1: H^T = W1m X^T ----------------------------------------------------------------------
         for (int c = 0; c < NCH1; ++c) {
+            X3_STAMP(crow, 0);
             gemm_lds_barrier();
+            X3_STAMP(crow, 1);
             const lchar *st = smem + cstage * STAGE;
             cstage = (cstage + 1 == kGemmStages) ? 0 : cstage + 1;
             const lchar *tb = st + kX3XB + foff;
@@ -307,6 +333,8 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void coupling_x3_kernel(const 
                     }
                 }
             }
+            X3_STAMP(crow, 2);
+            ++crow;
         }
         // ---- bias + ReLU + split: the accumulators become the B fragments of GEMM 2 ---------------------------
         half8 hh[KK], hl[KK];
@@ -330,7 +358,9 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void coupling_x3_kernel(const 
         float *orow = a.out + (row_ok ? b : a.B - 1) * D;
         float ssum = 0.f;
         for (int pt = 0; pt < NPT; ++pt) {
+            X3_STAMP(crow, 0);
             gemm_lds_barrier();
+            X3_STAMP(crow, 1);
             const lchar *st = smem + cstage * STAGE;
             cstage = (cstage + 1 == kGemmStages) ? 0 : cstage + 1;
             const lchar *tb = st + foff;
@@ -370,6 +400,7 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void coupling_x3_kernel(const 
                     zs = __builtin_amdgcn_mfma_f32_32x32x16_f16(sl8, hh[kk], zs, 0, 0, 0);
                 }
             }
+            X3_STAMP(crow, 4);
             const lchar *ex = st + KK * 4096;   // extras: bt, bs, sc_t, sh_t, sc_p, sh_p (32 floats each)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -406,6 +437,8 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void coupling_x3_kernel(const 
                     if (2 * n0 + 4 < D) *reinterpret_cast<gf32x4 *>(orow + 2 * n0 + 4) = o[1];
                 }
             }
+            X3_STAMP(crow, 2);
+            ++crow;
         }
         // ---- log-det: the two lanes of a sample hold disjoint halves of the transformed variables -----------------
         const float tot = ssum + __shfl_xor(ssum, 32, 64);
@@ -472,7 +505,34 @@ static int x3_launch(const X3Args &a, hipStream_t st) {
     hipEvent_t ev0, ev1;
     profile_take(&ev0, &ev1, DPK_KERNEL_COUPLING1D);
     if (ev0) (void)hipEventRecord(ev0, st);
+#ifdef DPK_X3_TIMELINE
+    X3Args at = a;
+    at.dbg = nullptr;
+    if (getenv("DPK_X3_TIMELINE")) {
+        (void)hipMalloc(&at.dbg, 8 * 64 * 8 * 8);
+        (void)hipMemset(at.dbg, 0, 8 * 64 * 8 * 8);
+    }
+    DPK_LAUNCH(kern, dim3(grid), dim3(2 * kGemmWaves * 64), lds, st, at);
+    if (at.dbg) {   // synchronous read-back: measurement builds only
+        std::vector<long long> hb(8 * 64 * 8);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(hb.data(), at.dbg, hb.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(at.dbg);
+        const long long t0 = hb[0];
+        for (int w : {0, 3, 4}) {
+            fprintf(stderr, "x3 timeline wave %d:", w);
+            for (int r = 0; r < 56; ++r) {
+                fprintf(stderr, " [");
+                for (int sl = 0; sl < 5; ++sl)
+                    fprintf(stderr, " %lld", hb[(w * 64 + r) * 8 + sl] ? hb[(w * 64 + r) * 8 + sl] - t0 : -1);
+                fprintf(stderr, " ]");
+            }
+            fprintf(stderr, "\n");
+        }
+    }
+#else
     DPK_LAUNCH(kern, dim3(grid), dim3(2 * kGemmWaves * 64), lds, st, a);
+#endif
     if (ev1) (void)hipEventRecord(ev1, st);
     DPK_CHECK_LAUNCH("coupling_x3_kernel");
     return DPK_OK;
