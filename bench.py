@@ -58,9 +58,11 @@ def parse():
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only to "
                     "rehearse the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument('--share-device', action='store_true', help='rehearsal: every rank uses cuda:0')
-    ap.add_argument('--kernel-event-every', type=int, default=1,
-                    help='bracket the fused kernel with HIP events on every Nth timed step (some hosts pay '
-                         '~0.15 ms of runtime bookkeeping per timing event; the stride is widened there)')
+    ap.add_argument('--kernel-event-every', type=int, default=8,
+                    help='bracket the fused kernel with HIP events on every Nth timed step: an event pair costs the '
+                         'stream 6-8 us of bubbles around a 48 us kernel (bracketing every step held ms_per_step at '
+                         '0.056-0.058 against 0.049 without events, tools/bench_graph_headline.py), and some hosts pay '
+                         '~0.15 ms of runtime bookkeeping per event; the stride is widened there')
     return ap.parse_args()
 
 
@@ -382,7 +384,7 @@ def main():
     n_spare = 64   # event pairs for the untimed steps
     handles = [timer.pair() for _ in range(args.steps + n_spare)] if time_kernel else []
 
-    stride = max(1, args.kernel_event_every)
+    stride = max(1, min(args.kernel_event_every, args.steps // 4))   # at least four bracketed steps
     sampled = []
 
     def step(i, timed_idx=None):
