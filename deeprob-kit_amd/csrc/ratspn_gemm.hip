@@ -314,12 +314,7 @@ __device__ __noinline__ void gemm_exact_wave(const GemmArgs &a, int64_t bw0, int
     }
     if (a.ll_sum != nullptr) {
         part = wave_reduce_sum(part);
-        if (lane == 0) {
-            int64_t nv = a.B - bw0;
-            nv = nv < 0 ? 0 : (nv > 32 ? 32 : nv);
-            atomicAdd(a.ll_sum, part);
-            atomicAdd(a.ll_sum + 1, (double)(nv * a.C));
-        }
+        if (lane == 0) atomicAdd(a.ll_sum, part);   // (the count: once per launch, at the end of the kernel)
     }
 }
 
@@ -378,7 +373,6 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void ratspn_gemm_kernel(const 
     const int ntiles = a.ntiles;
 
     double red_ll = 0.0;
-    int red_n = 0;
     bool saw_nan_any = false;
     if (loader) {
         gemm_loader_run<KS, PB>(a.x, a.B, D, NCH, ntiles, (int)blockIdx.x, grid, (gcchar_p)a.mtab, BB, wave * PB,
@@ -409,7 +403,6 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void ratspn_gemm_kernel(const 
     GEMM_STAMP(63, 1);
     [[maybe_unused]] int grow = 0;   // timeline row = chunk count of this work-group
     bool saw_nan = false;
-    int n_fast_w = 0;       // samples of this wave that went through the fast path
     double ll_part = 0.0;   // this lane's share of the sum of the LLs written by the fast path (all tiles)
     int cstage = 0;
     for (int tile = (int)blockIdx.x; tile < ntiles; tile += grid) {
@@ -684,13 +677,13 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void ratspn_gemm_kernel(const 
                 }
                 GEMM_STAMP(grow - 1, 6);
                 ll_part += part;
-                n_fast_w += (int)max((int64_t)0, min((int64_t)32, a.B - bw0));
             }
+            // (measured: sending the sums of all tiles but the last as one atomic per wave here, while the work-group
+            // is still streaming, costs 8 us per launch -- the compute waves' next LDS-DMA-fed chunk waits behind it)
         }
     }
     GEMM_STAMP(63, 2);
     red_ll = wave_reduce_sum(ll_part);
-    red_n = n_fast_w;
     saw_nan_any = saw_nan;
     }   // compute waves
     // {sum LL, count}: one atomic per work-group, issued when no counted wait is left to trip over it (an atomic is a
@@ -698,20 +691,16 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void ratspn_gemm_kernel(const 
     if (a.ll_sum != nullptr && !(a.ablate & 16)) {
         double *red = reinterpret_cast<double *>(smem_generic);   // the stages are idle now
         __syncthreads();
-        if (lane == 0 && !loader) {
-            red[wave] = red_ll;
-            red[kGemmWaves + wave] = (double)red_n;
-        }
+        if (lane == 0 && !loader) red[wave] = red_ll;
         __syncthreads();
         if (tid == 0) {
-            double tot = 0.0, n_fast = 0.0;
+            double tot = 0.0;
 #pragma unroll
-            for (int w = 0; w < kGemmWaves; ++w) {
-                tot += red[w];
-                n_fast += red[kGemmWaves + w];
-            }
+            for (int w = 0; w < kGemmWaves; ++w) tot += red[w];
             atomicAdd(a.ll_sum, tot);
-            atomicAdd(a.ll_sum + 1, n_fast * (double)a.C);
+            // every sample of the launch is evaluated by exactly one path: the count needs no per-work-group atomic
+            // (256 same-address fp64 atomics at the very end of the kernel cost it 1.5 us)
+            if (blockIdx.x == 0) atomicAdd(a.ll_sum + 1, (double)a.B * (double)a.C);
         }
     }
     if (saw_nan_any && lane == 0 && a.slow_flag != nullptr) *a.slow_flag = a.launch_seq;
