@@ -209,6 +209,28 @@ def _time_train(model, x, steps=15, warm=3):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+def _time_train_graph(model, x, steps=30):
+    """The same step replayed from a HIP graph (train_model(..., hip_graph=True)): None when it cannot be captured."""
+    import torch
+    from deeprob.hip.graphs import GraphedTrainStep
+    try:
+        model.train()
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, capturable=True)
+        gstep = GraphedTrainStep(model, opt)
+        for _ in range(6):
+            gstep(x)
+        torch.cuda.synchronize()
+        if gstep.graph is None:
+            return None
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            gstep(x)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+    except Exception:
+        return None
+
+
 def secondary(dev, timer, threads, xs_headline, headline_model):
     import torch
     from deeprob.spn.models import GaussianRatSpn, DgcSpn
@@ -316,8 +338,10 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
               ('RealNVP1d(784)', m_flow, torch.randn(B, D, device=dev))]
     for name, m, x in trains:
         ms = _time_train(m, x)
+        ms_g = _time_train_graph(m, x)
         out.append({'workload': name + ': forward + backward + Adam step', 'config': 'training step', 'batch': B,
-                    'ms_per_step': ms, 'value': B / ms * 1e3, 'unit': 'samples/sec'})
+                    'ms_per_step': ms, 'value': B / ms * 1e3, 'unit': 'samples/sec',
+                    'ms_per_step_hip_graph': ms_g, 'value_hip_graph': (B / ms_g * 1e3) if ms_g else None})
 
     # ---- the headline with the host-to-device copy inside the step (routines.py:159 copies per batch) ----
     Bh = xs_headline[0].shape[0]
