@@ -37,6 +37,54 @@ __global__ void softmax_rows_kernel2(const float *__restrict__ w, int rows, int 
     }
 }
 
+// Few, long rows (a DGC-SPN root: one row of C*H*W = 8192 weights per class): one 1024-thread block per row instead of
+// one wave -- the single-wave form takes 48 us for an 8192-entry row.
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float *red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    v = is_max ? wave_reduce_max(v) : wave_reduce_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float r = is_max ? -INFINITY : 0.f;
+    for (int w = 0; w < nw; ++w) r = is_max ? fmaxf(r, red[w]) : r + red[w];
+    return r;
+}
+__global__ __launch_bounds__(1024) void softmax_rows_wide_kernel(const float *__restrict__ w, int rows, int n,
+                                                                 float *__restrict__ W, float *__restrict__ LW) {
+    __shared__ float red[16];
+    const int row = blockIdx.x;
+    const float *src = w + (int64_t)row * n;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, src[i]);
+    m = block_reduce(m, true, red);
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += expf(src[i] - m);
+    s = block_reduce(s, false, red);
+    const float ls = logf(s);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float l = src[i] - m - ls;
+        LW[(int64_t)row * n + i] = l;
+        W[(int64_t)row * n + i] = expf(l);
+    }
+}
+__global__ __launch_bounds__(1024) void logsoftmax_jacobian_wide_kernel(const float *__restrict__ glw,
+                                                                        const float *__restrict__ W, int rows, int n,
+                                                                        float *__restrict__ gW) {
+    __shared__ float red[16];
+    const int row = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += glw[(int64_t)row * n + i];
+    s = block_reduce(s, false, red);
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        gW[(int64_t)row * n + i] = glw[(int64_t)row * n + i] - W[(int64_t)row * n + i] * s;
+}
+static void launch_softmax_rows(const float *weight, int rows, int n, float *W, float *LW, hipStream_t st) {
+    if (n >= 2048 && rows <= 1024)
+        DPK_LAUNCH(softmax_rows_wide_kernel, dim3(rows), dim3(1024), 0, st, weight, rows, n, W, LW);
+    else
+        DPK_LAUNCH(softmax_rows_kernel2, dim3(cdiv(rows, 4)), dim3(256), 0, st, weight, rows, n, W, LW);
+}
+
 // ------------------------------------------------------------------------------------
 // ProductLayer (reference: deeprob/spn/layers/ratspn.py:272-286)
 // ------------------------------------------------------------------------------------
@@ -450,7 +498,7 @@ static int sum_forward_impl(const float *in, const float *weight, int64_t B, int
     if (B == 0) return DPK_OK;
     float *W = (float *)ws, *LW = (float *)((char *)ws + seg);
     hipStream_t st = (hipStream_t)stream;
-    DPK_LAUNCH(softmax_rows_kernel2, dim3(cdiv(P * S, 4)), dim3(256), 0, st, weight, P * S, N, W, LW);
+    launch_softmax_rows(weight, P * S, N, W, LW, st);
     if (P == 1 && N >= 1024)
         DPK_LAUNCH(root_wide_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, in, LW, B, N, S, out);
     else
@@ -469,7 +517,7 @@ static int sum_backward_impl(const float *in, const float *weight, const float *
     DPK_REQUIRE(ws_bytes >= 3 * seg, DPK_EWORKSPACE, "%s: workspace too small", who);
     float *W = (float *)ws, *LW = (float *)((char *)ws + seg), *glw = (float *)((char *)ws + 2 * seg);
     hipStream_t st = (hipStream_t)stream;
-    DPK_LAUNCH(softmax_rows_kernel2, dim3(cdiv(P * S, 4)), dim3(256), 0, st, weight, P * S, N, W, LW);
+    launch_softmax_rows(weight, P * S, N, W, LW, st);
     if (grad_weight) {
         hipError_t e = hipMemsetAsync(glw, 0, (size_t)P * S * N * 4, st);
         DPK_REQUIRE(e == hipSuccess, DPK_ELAUNCH, "%s: memset: %s", who, hipGetErrorString(e));
@@ -482,8 +530,13 @@ static int sum_backward_impl(const float *in, const float *weight, const float *
         // nothing to write
     }
     if (grad_weight)
-        DPK_LAUNCH(logsoftmax_jacobian_kernel, dim3(cdiv(P * S, 4)), dim3(256), 0, st, glw, W, P * S, N,
-                           grad_weight);
+    {
+        if (N >= 2048 && P * S <= 1024)
+            DPK_LAUNCH(logsoftmax_jacobian_wide_kernel, dim3(P * S), dim3(1024), 0, st, glw, W, P * S, N, grad_weight);
+        else
+            DPK_LAUNCH(logsoftmax_jacobian_kernel, dim3(cdiv(P * S, 4)), dim3(256), 0, st, glw, W, P * S, N,
+                       grad_weight);
+    }
     DPK_CHECK_LAUNCH("sum_bwd_kernel");
     return DPK_OK;
 }
@@ -823,7 +876,7 @@ static int prod_fused_common(bool root, const float *in, const float *weight, in
     hipStream_t st = (hipStream_t)stream;
     // DPK_FLAG_PARAMS_CACHED: softmax rows (and MFMA fragments) of an earlier call from this very weight are in ws
     const bool cached = flags & DPK_FLAG_PARAMS_CACHED;
-    if (!cached) DPK_LAUNCH(softmax_rows_kernel2, dim3(cdiv(rows, 4)), dim3(256), 0, st, weight, rows, n, W, LW);
+    if (!cached) launch_softmax_rows(weight, rows, n, W, LW, st);
     {
         static const bool mfma = [] {
             const char *e = getenv("DPK_RATSPN_GEMM");
