@@ -58,11 +58,13 @@ def parse():
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only to "
                     "rehearse the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument('--share-device', action='store_true', help='rehearsal: every rank uses cuda:0')
-    ap.add_argument('--kernel-event-every', type=int, default=8,
-                    help='bracket the fused kernel with HIP events on every Nth timed step: an event pair costs the '
-                         'stream 6-8 us of bubbles around a 48 us kernel (bracketing every step held ms_per_step at '
-                         '0.056-0.058 against 0.049 without events, tools/bench_graph_headline.py), and some hosts pay '
-                         '~0.15 ms of runtime bookkeeping per event; the stride is widened there')
+    ap.add_argument('--kernel-event-every', type=int, default=16,
+                    help='a run of --kernel-event-run consecutive timed steps is bracketed by one HIP event pair every '
+                         'N timed steps (start before the first launch of the run, stop after its last).  An event pair '
+                         'around every single launch read 51.5 us where rocprofv3 reports 46.8 us for the same kernel '
+                         '(the pair brackets its own dispatch latency) and cost the stream 6-8 us of bubbles per step '
+                         '(ms_per_step 0.056-0.058 against 0.049 without events, tools/bench_graph_headline.py)')
+    ap.add_argument('--kernel-event-run', type=int, default=8)
     return ap.parse_args()
 
 
@@ -408,14 +410,21 @@ def main():
     n_spare = 64   # event pairs for the untimed steps
     handles = [timer.pair() for _ in range(args.steps + n_spare)] if time_kernel else []
 
-    stride = max(1, min(args.kernel_event_every, args.steps // 4))   # at least four bracketed steps
-    sampled = []
+    run = max(1, min(args.kernel_event_run, args.steps // 2))
+    stride = max(run, min(args.kernel_event_every, args.steps))
+    sampled = []   # index of the first step of every bracketed run (its handle pair carries the run's two events)
 
     def step(i, timed_idx=None):
         marks = None
-        if timed_idx is not None and time_kernel and timed_idx % stride == stride // 2:
-            marks = handles[timed_idx]
-            sampled.append(timed_idx)
+        if timed_idx is not None and time_kernel:
+            first = timed_idx - timed_idx % stride
+            if first + run <= args.steps and timed_idx < first + run:
+                if timed_idx == first:
+                    sampled.append(first)
+                marks = (handles[first][0] if timed_idx == first else None,
+                         handles[first][1] if timed_idx == first + run - 1 else None)
+                if marks == (None, None):
+                    marks = None
         return evaluator.step(xs[i % ring], kernel_events=marks)
 
     with torch.no_grad():
@@ -485,7 +494,7 @@ def main():
         }
         if time_kernel and sampled:
             torch.cuda.synchronize()
-            k_ms = sum(timer.ms(handles[i]) for i in sampled) / len(sampled)
+            k_ms = sum(timer.ms(handles[i]) for i in sampled) / (len(sampled) * run)
             alg_bytes = B * 4 * (D + model.out_classes)
             achieved = alg_bytes / (k_ms * 1e-3) / 1e9
             traffic, source = read_traffic()
@@ -493,7 +502,10 @@ def main():
                                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic if B == 65536 else None,
                                'traffic_source': source if B == 65536 else None,
                                'kernel': 'ratspn_gemm_kernel (fused RatSpn.forward, leaf layer on MFMA)',
-                               'kernel_ms': k_ms, 'kernel_event_samples': len(sampled),
+                               'kernel_ms': k_ms, 'kernel_event_samples': len(sampled) * run,
+                               'kernel_event_method': '{} runs of {} consecutive launches, one HIP event pair per run '
+                                                      '(includes the gaps between the launches of a run)'.format(
+                                                          len(sampled), run),
                                'algorithmic_bytes_per_launch': alg_bytes}
         threads = min(os.cpu_count() or 1, 32)
         if args.cpu_samples > 0 and world == 1:

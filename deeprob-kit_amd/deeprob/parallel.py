@@ -85,8 +85,9 @@ class ShardedLogLikelihood:
         acc = self._acc_slot(x.device)
         if kernel_events is not None:
             from deeprob.hip import load_library, check
-            # (start, stop): raw hipEvent_t handles, or torch.cuda.Event objects
-            h0, h1 = (e if isinstance(e, int) else e.cuda_event for e in kernel_events)
+            # (start, stop): raw hipEvent_t handles or torch.cuda.Event objects; either may be None (a run of
+            # launches bracketed by the start of its first and the stop of its last)
+            h0, h1 = (None if e is None else (e if isinstance(e, int) else e.cuda_event) for e in kernel_events)
             check(load_library().dpk_profile_next_kernel(h0, h1), 'dpk_profile_next_kernel')
         from deeprob.hip import ops
         fused = getattr(self.model, '_forward_fused', None)
