@@ -245,19 +245,22 @@ def test_streaming_levels_golden(golden, monkeypatch):
     assert rel_err(ll_nan.cpu().numpy(), g['ll_nan']) <= LL_TOL
 
 
-@pytest.mark.parametrize('shape,classes,B', [((1, 20, 20), 3, 37), ((2, 16, 16), 1, 130), ((1, 28, 28), 10, 65)])
-def test_streaming_levels_against_oracle(monkeypatch, shape, classes, B):
+@pytest.mark.parametrize('shape,classes,B,pooling', [((1, 20, 20), 3, 37, 0), ((2, 16, 16), 1, 130, 0),
+                                                     ((1, 28, 28), 10, 65, 0), ((1, 16, 16), 1, 33, 2),
+                                                     ((3, 32, 32), 2, 19, 1)])
+def test_streaming_levels_against_oracle(monkeypatch, shape, classes, B, pooling):
     """Streaming route against the oracle on maps and class counts the golden fixtures do not hold: ragged batch slices,
-    tiles that split rows, several root classes, far-tail inputs (exact log-domain pass), marginalised pixels."""
+    tiles that split rows, several root classes, stride-2 (pooling) levels, far-tail inputs (exact log-domain pass),
+    marginalised pixels."""
     from deeprob.spn.models import DgcSpn
     from tests.util import randomise_dgc
     monkeypatch.setenv('DPK_DGC_STREAM_MIN_B', '0')
     torch.manual_seed(11)
-    model = DgcSpn(shape, out_classes=classes, n_batch=8, sum_channels=8, depthwise=True, n_pooling=0)
+    model = DgcSpn(shape, out_classes=classes, n_batch=8, sum_channels=8, depthwise=True, n_pooling=pooling)
     randomise_dgc(model, 70)
     model.eval()
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    plan = dorc.schedule(shape, 8, 8, True, 0)
+    plan = dorc.schedule(shape, 8, 8, True, pooling)
     x = torch.randn(B, *shape, generator=torch.Generator().manual_seed(3))
     x[1] = 35.0                                   # every Gaussian far in its tail
     x[2, :, ::2] = float('nan')
