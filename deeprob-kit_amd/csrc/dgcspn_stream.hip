@@ -23,6 +23,8 @@
 #include "dgcspn_stream.h"
 #include "ratspn_gemm_common.h"
 #include <algorithm>
+#include <mutex>
+#include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -492,7 +494,7 @@ static int tile_slot_floats(const StreamTile &t, int W) {
     return lb + 4;
 }
 
-static bool stream_plan(int mode, const ProdGeom &q5, const ProdGeom *q6, StreamPlan &best) {
+static bool stream_plan_build(int mode, const ProdGeom &q5, const ProdGeom *q6, StreamPlan &best) {
     const int N = mode == 0 ? q5.OH * q5.OW : q6->OH * q6->OW;   // pixels / root pixels to distribute
     const int per = mode == 0 ? 1 : 4;                           // thread slots per unit
     double best_score = -1;
@@ -540,6 +542,35 @@ static bool stream_plan(int mode, const ProdGeom &q5, const ProdGeom *q6, Stream
         }
     }
     return best_score > 0;
+}
+
+// The plan depends on the geometry only: a model reuses a handful of them at every call (planning costs tens of
+// microseconds of host time: band search over up to 16 tilings), so the last few are kept.
+static bool stream_plan(int mode, const ProdGeom &q5, const ProdGeom *q6, StreamPlan &best) {
+    struct Entry {
+        int mode, ok;
+        ProdGeom q5, q6;
+        StreamPlan plan;
+    };
+    static std::mutex mu;
+    static std::vector<Entry> cache;
+    const char *force = getenv("DPK_DGC_STREAM_T");
+    const ProdGeom q6v = q6 ? *q6 : q5;
+    if (!force) {
+        std::lock_guard<std::mutex> lock(mu);
+        for (const Entry &e : cache)
+            if (e.mode == mode && memcmp(&e.q5, &q5, sizeof(ProdGeom)) == 0 && memcmp(&e.q6, &q6v, sizeof(ProdGeom)) == 0) {
+                best = e.plan;
+                return e.ok != 0;
+            }
+    }
+    const bool ok = stream_plan_build(mode, q5, q6, best);
+    if (!force) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (cache.size() >= 64) cache.erase(cache.begin());
+        cache.push_back(Entry{mode, ok ? 1 : 0, q5, q6v, best});
+    }
+    return ok;
 }
 
 static int device_cus() {
