@@ -275,7 +275,7 @@ int dpk_spatial_sum_backward(const float *x, const float *weight, const float *o
  * dpk_spatial_sum_workspace_bytes(C,Cout,OH,OW).  DPK_EUNSUPPORTED outside that envelope.
  * flags: DPK_FLAG_PARAMS_CACHED = the workspace still holds the softmaxed weight tables a previous call built
  * from this very weight tensor (unchanged since), they are not rebuilt.  8 -> 8 channel levels on batches of
- * 1024 samples and more (input 16-byte aligned) take the streaming kernel: the 64 weights of an output pixel
+ * 256 samples and more (input 16-byte aligned) take the streaming kernel: the 64 weights of an output pixel
  * stay in registers while its work-group walks a slice of the batch staged through LDS.                     */
 int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C, int32_t H, int32_t W, int32_t OH,
                                 int32_t OW, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t dh,
@@ -425,7 +425,7 @@ int dpk_ll_accumulate(const float *ll, int64_t n, double *acc, void *stream);
 int64_t dpk_spatial_sumprodroot_workspace_bytes(int32_t C, int32_t Cout, int32_t OH5, int32_t OW5, int32_t OH6,
                                                 int32_t OW6, int32_t K);
 /* Workspace for a batch of B samples: the tables of ..._workspace_bytes plus, where the streaming kernel applies
- * (8 -> 8 channels, B >= 1024, `in` 16-byte aligned), one (max, sum) pair per sample, class and compute wave for the
+ * (8 -> 8 channels, B >= 256, `in` 16-byte aligned), one (max, sum) pair per sample, class and compute wave for the
  * root's log-sum-exp.  With this much workspace the entry point streams the batch through LDS with the sum layer's
  * weights resident in registers; with only ..._workspace_bytes it runs the batch-independent kernel.               */
 int64_t dpk_spatial_sumprodroot_workspace_bytes_batch(int64_t B, int32_t C, int32_t H, int32_t W, const int32_t *geom5,
