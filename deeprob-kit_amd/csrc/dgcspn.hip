@@ -381,16 +381,34 @@ __global__ void spatial_sum_bwd_kernel(const float *__restrict__ x, const float 
 // pixel's 8 x 4 linear weights and the batch sums of glw in registers.  pi[o,c] = W[o,c] e^{x_c - m} e^{m - out_o}
 // with m = max_c x_c: 12 exponentials per thread and sample instead of 32, gx written once.  m - out_o is bounded
 // by -log(max_c W[o,c]); an output whose bound leaves the fp32 range takes the exact log-domain expression.
+// TAPS: the sum layer's input is the depthwise product of the map `x` [B,Cin,q.H,q.W] (dpk_spatial_prodsum_backward:
+// the product map of the training forward is never stored); x_c is then the sum of the pixel's taps, gx the gradient
+// of that product map.
 constexpr int kSp8C = 4;
+template <bool TAPS>
 __global__ __launch_bounds__(256) void spatial_sum_bwd8_kernel(const float *__restrict__ x, const float *__restrict__ Wl,
                                                                const float *__restrict__ LW,
                                                                const float *__restrict__ out,
                                                                const float *__restrict__ g, int64_t B, int Cin,
                                                                int Cout, int HW, int bslice, float *__restrict__ gx,
-                                                               float *__restrict__ glw) {
+                                                               float *__restrict__ glw, ProdGeom q) {
     const int p = min((int)(blockIdx.x * 64 + threadIdx.x), HW - 1);   // tail lanes shadow the last pixel, stores masked
     const bool own = (int)(blockIdx.x * 64 + threadIdx.x) < HW;
     const int c0 = blockIdx.z * kSp8C;
+    // TAPS: offsets of the pixel's taps inside an input plane (clamped; padding taps contribute log 1 = 0)
+    int tclamp[4] = {0, 0, 0, 0};
+    bool tval[4] = {false, false, false, false};
+    const int inHW = TAPS ? q.H * q.W : HW;
+    if (TAPS) {
+        const int oh = p / q.OW, ow = p - oh * q.OW, T = q.kh * q.kw;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int th = t / q.kw, tw = t - th * q.kw;
+            const int ih = oh * q.sh - q.pt + th * q.dh, iw = ow * q.sw - q.pl + tw * q.dw;
+            tval[t] = t < T && ih >= 0 && ih < q.H && iw >= 0 && iw < q.W;
+            tclamp[t] = tval[t] ? ih * q.W + iw : 0;
+        }
+    }
     float w[8][kSp8C], acc[8][kSp8C];
 #pragma unroll
     for (int o = 0; o < 8; ++o)
@@ -406,9 +424,25 @@ __global__ __launch_bounds__(256) void spatial_sum_bwd8_kernel(const float *__re
     const int cin1 = Cin - 1, cout1 = Cout - 1;
     // padding rows (c >= Cin, o >= Cout) read a valid row and are replaced when consumed: no branch per load
     auto fetch = [&](int64_t b) {
-        const float *xb = x + b * Cin * HW + p, *ob = out + b * Cout * HW + p, *gb = g + b * Cout * HW + p;
+        const float *ob = out + b * Cout * HW + p, *gb = g + b * Cout * HW + p;
+        if (TAPS) {
+            const float *xb = x + b * Cin * inHW;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) nx[c] = xb[(int64_t)min(c, cin1) * HW];
+            for (int c = 0; c < 8; ++c) {
+                const float *xc = xb + (int64_t)min(c, cin1) * inHW;
+                float a = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float v = xc[tclamp[t]];
+                    a += tval[t] ? v : 0.f;
+                }
+                nx[c] = a;
+            }
+        } else {
+            const float *xb = x + b * Cin * HW + p;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) nx[c] = xb[(int64_t)min(c, cin1) * HW];
+        }
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
             nxo[o] = ob[(int64_t)min(o, cout1) * HW];
@@ -877,9 +911,9 @@ extern "C" int dpk_spatial_sum_backward(const float *x, const float *weight, con
             int64_t bslice = cdiv(B, slices);
             if (bslice < 8) bslice = 8;
             slices = cdiv(B, bslice);
-            DPK_LAUNCH(spatial_sum_bwd8_kernel, dim3((unsigned)cols, (unsigned)cdiv(slices, 4), (unsigned)halves), dim3(64, 4), 0,
-                               st, x, Wl, LW, out, g, B, Cin, Cout, HW, (int)bslice, grad_x,
-                               grad_weight ? glw : nullptr);
+            DPK_LAUNCH(spatial_sum_bwd8_kernel<false>, dim3((unsigned)cols, (unsigned)cdiv(slices, 4), (unsigned)halves),
+                       dim3(64, 4), 0, st, x, Wl, LW, out, g, B, Cin, Cout, HW, (int)bslice, grad_x,
+                       grad_weight ? glw : nullptr, ProdGeom{});
         } else {
             const int bslice = 16;
             DPK_LAUNCH(spatial_sum_bwd_kernel, dim3(cdiv((int64_t)Cin * HW, 256), cdiv(B, bslice)), dim3(256),
@@ -890,6 +924,52 @@ extern "C" int dpk_spatial_sum_backward(const float *x, const float *weight, con
         DPK_LAUNCH(spatial_softmax_jacobian_kernel, dim3(grid_cap((int64_t)Cout * HW, 256)), dim3(256), 0, st,
                            glw, Wl, Cout, Cin, HW, grad_weight);
     DPK_CHECK_LAUNCH("spatial_sum_bwd_kernel");
+    return DPK_OK;
+}
+
+// Autograd of the fused depthwise product + sum level (training route of a DGC-SPN level whose forward ran as
+// dpk_spatial_prodsum_forward): the product map is recomputed from the taps, its gradient lands in grad_prod
+// [B,C,OH,OW] (caller scratch) and is scattered to grad_in by the product layer's backward kernel.
+extern "C" int dpk_spatial_prodsum_backward(const float *in, int64_t B, int32_t C, int32_t H, int32_t W, int32_t OH,
+                                            int32_t OW, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t dh,
+                                            int32_t dw, int32_t pad_top, int32_t pad_left, const float *weight,
+                                            int32_t Cout, const float *out, const float *g, float *grad_prod,
+                                            float *grad_in, float *grad_weight, void *ws, int64_t ws_bytes,
+                                            void *stream) {
+    ProdGeom q;
+    int rc = make_geom(q, C, H, W, C, OH, OW, kh, kw, sh, sw, dh, dw, pad_top, pad_left, 1);
+    if (rc) return rc;
+    DPK_REQUIRE(B >= 0 && Cout > 0, DPK_EINVAL, "spatial_prodsum_backward: bad sizes");
+    DPK_REQUIRE(kh * kw <= 4 && C <= 8 && Cout <= 8, DPK_EUNSUPPORTED,
+                "spatial_prodsum_backward: taps=%d channels=%d/%d outside the fused kernel", kh * kw, C, Cout);
+    DPK_REQUIRE(weight && ws, DPK_EINVAL, "spatial_prodsum_backward: null pointer");
+    const int HW = OH * OW;
+    const int64_t seg = align_up((int64_t)Cout * C * HW * 4, 256);
+    DPK_REQUIRE(ws_bytes >= 3 * seg, DPK_EWORKSPACE, "spatial_prodsum_backward: workspace too small");
+    float *Wl = (float *)ws, *LW = (float *)((char *)ws + seg), *glw = (float *)((char *)ws + 2 * seg);
+    hipStream_t st = (hipStream_t)stream;
+    DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * HW, 256)), dim3(256), 0, st, weight, Cout, C, HW,
+               Wl, LW);
+    if (grad_weight)
+        DPK_REQUIRE(hipMemsetAsync(glw, 0, (size_t)Cout * C * HW * 4, st) == hipSuccess, DPK_ELAUNCH, "memset");
+    if (B > 0) {
+        DPK_REQUIRE(in && out && g && (grad_prod || !grad_in), DPK_EINVAL, "spatial_prodsum_backward: null pointer");
+        const int64_t cols = cdiv(HW, 64), halves = cdiv(C, kSp8C);
+        int64_t slices = cdiv(8192, cols * halves);
+        int64_t bslice = cdiv(B, slices);
+        if (bslice < 8) bslice = 8;
+        slices = cdiv(B, bslice);
+        DPK_LAUNCH(spatial_sum_bwd8_kernel<true>, dim3((unsigned)cols, (unsigned)cdiv(slices, 4), (unsigned)halves),
+                   dim3(64, 4), 0, st, in, Wl, LW, out, g, B, C, Cout, HW, (int)bslice, grad_in ? grad_prod : nullptr,
+                   grad_weight ? glw : nullptr, q);
+        if (grad_in)
+            DPK_LAUNCH(spatial_product_bwd_kernel, dim3(grid_cap(B * C * H * W, 256)), dim3(256), 0, st, grad_prod, B, q,
+                       grad_in);
+    }
+    if (grad_weight)
+        DPK_LAUNCH(spatial_softmax_jacobian_kernel, dim3(grid_cap((int64_t)Cout * HW, 256)), dim3(256), 0, st, glw, Wl,
+                   Cout, C, HW, grad_weight);
+    DPK_CHECK_LAUNCH("spatial_prodsum_backward");
     return DPK_OK;
 }
 

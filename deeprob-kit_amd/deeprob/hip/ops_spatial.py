@@ -171,6 +171,59 @@ def spatial_prodsum(x, prod_layer, weight, ws: Workspace):
     return out
 
 
+class SpatialProdSumFn(torch.autograd.Function):
+    """Depthwise SpatialProductLayer + SpatialSumLayer as ONE autograd node (training route of a DGC-SPN level,
+    reference: deeprob/spn/models/dgcspn.py:146-147 chaining layers/dgcspn.py:224-236 and :289-304): the forward is the
+    fused evaluation kernel, the backward recomputes the product map from the taps -- the [B,C,OH,OW] product tensor is
+    neither written nor kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, geom, ws: Workspace):
+        lib = load_library()
+        x = require_device_f32(x, 'x')
+        w = require_device_f32(weight, 'weight')
+        C, H, W, _, OH, OW, kh, kw, sh, sw, dh, dw, pt, pl, _ = geom
+        B, Cout = x.shape[0], w.shape[0]
+        out = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
+        buf = _spatial_sum_ws(ws, C, Cout, OH, OW, x.device)
+        ws.params_key = None
+        check(lib.dpk_spatial_prodsum_forward(ptr(x), B, C, H, W, OH, OW, kh, kw, sh, sw, dh, dw, pt, pl, ptr(w), Cout,
+                                              ptr(out), ptr(buf), buf.numel(), 0, stream_ptr(x.device)),
+              'dpk_spatial_prodsum_forward')
+        ctx.save_for_backward(x, w, out)
+        ctx.geom, ctx.ws = geom, ws
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load_library()
+        x, w, out = ctx.saved_tensors
+        g = require_device_f32(g, 'grad')
+        C, H, W, _, OH, OW, kh, kw, sh, sw, dh, dw, pt, pl, _ = ctx.geom
+        B, Cout = x.shape[0], w.shape[0]
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        gprod = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device) if gx is not None else None
+        buf = _spatial_sum_ws(ctx.ws, C, Cout, OH, OW, x.device)
+        ctx.ws.params_key = None
+        check(lib.dpk_spatial_prodsum_backward(ptr(x), B, C, H, W, OH, OW, kh, kw, sh, sw, dh, dw, pt, pl, ptr(w), Cout,
+                                               ptr(out), ptr(g), ptr(gprod), ptr(gx), ptr(gw), ptr(buf), buf.numel(),
+                                               stream_ptr(x.device)), 'dpk_spatial_prodsum_backward')
+        return gx, gw, None, None
+
+
+def spatial_prodsum_autograd(x, prod_layer, weight, ws: Workspace):
+    """The fused level with an autograd graph; None when the level is outside the fused kernels' envelope (non-depthwise
+    product, more than 4 taps, more than 8 channels): the caller chains the two layers."""
+    if not prod_layer.depthwise:
+        return None
+    geom = _geom(prod_layer)
+    C, kh, kw = geom[0], geom[6], geom[7]
+    if kh * kw > 4 or C > 8 or weight.shape[0] > 8 or x.dim() != 4 or tuple(x.shape[1:]) != tuple(prod_layer.in_features):
+        return None
+    return SpatialProdSumFn.apply(x, weight, geom, ws)
+
+
 def spatial_prodroot(x, prod_layer, weight, ws: Workspace):
     """Last level of the eval route: depthwise SpatialProductLayer + SpatialRootLayer in one launch (reference:
     deeprob/spn/models/dgcspn.py:146-150).  No autograd graph; None when outside the fused kernel's envelope."""

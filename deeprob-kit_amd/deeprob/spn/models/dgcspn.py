@@ -102,9 +102,21 @@ class DgcSpn(ProbabilisticModel):
         """Log-likelihood ``[B, out_classes]`` of images ``x [B,C,H,W]``, NaN = marginalised
         (reference: dgcspn.py:134-151)."""
         if self._needs_graph(x):
+            # training / gradients: the layer chain, with every depthwise product + sum pair of at most 8 channels as
+            # one autograd node (no product map is written or kept; its backward recomputes it from the taps)
+            from deeprob.hip import ops_spatial
             x = self.base_layer(x)
-            for layer in self.layers:
+            i, n = 0, len(self.layers)
+            while i < n:
+                layer = self.layers[i]
+                if (i + 1 < n and isinstance(layer, SpatialProductLayer) and isinstance(self.layers[i + 1], SpatialSumLayer)
+                        and not (self.training and self.layers[i + 1].dropout is not None)):
+                    y = ops_spatial.spatial_prodsum_autograd(x, layer, self.layers[i + 1].weight, self.layers[i + 1]._ws)
+                    if y is not None:
+                        x, i = y, i + 2
+                        continue
                 x = layer(x)
+                i += 1
             return self.root_layer(x)
         # evaluation: every depthwise product is folded into the sum layer above it
         from deeprob.hip import ops_spatial
