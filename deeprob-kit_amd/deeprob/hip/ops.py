@@ -9,7 +9,7 @@ from typing import Optional, Tuple
 import torch
 
 from deeprob.hip import (
-    load_library, check, ptr, stream_ptr, require_device_f32, Workspace, DPK_FLAG_STRUCT_CACHED,
+    load_library, check, ptr, stream_ptr, require_device_f32, Workspace, HipError, DPK_FLAG_STRUCT_CACHED,
     DPK_FLAG_UNIT_SCALE, DPK_FLAG_PARAMS_CACHED,
 )
 
@@ -315,6 +315,57 @@ class RootFn(torch.autograd.Function):
         check(lib.dpk_root_backward(ptr(x2), ptr(w), ptr(out), ptr(g), B, M, C, ptr(gx), ptr(gw), ptr(buf),
                                     buf.numel(), stream_ptr(x2.device)), 'dpk_root_backward')
         return (gx.reshape(ctx.in_shape) if gx is not None else None), gw, None
+
+
+class ProdSumFn(torch.autograd.Function):
+    """ProductLayer + SumLayer (or + RootLayer) as ONE autograd node, the training route of a RAT-SPN level
+    (reference: ratspn.py:272-286 chained with :363-378 / :446-458): the forward is the folded evaluation kernel (on
+    the matrix cores for 8 / 16 nodes per region), the ``[B, P, N^2]`` product tensor is neither written nor kept; the
+    backward recomputes it and runs the two layers' own backward kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, ws: Workspace, root: bool):
+        out = prodroot_forward(x, weight, ws) if root else prodsum_forward(x, weight, ws)
+        if out is None:
+            raise HipError("ProdSumFn: shape outside the folded kernels (checked by prodsum_autograd)")
+        ctx.save_for_backward(x, weight, out)
+        ctx.ws, ctx.root = ws, root
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load_library()
+        x, w, out = ctx.saved_tensors
+        g = require_device_f32(g, 'grad')
+        B, R, N = x.shape
+        P, st = R // 2, stream_ptr(x.device)
+        prod = torch.empty((B, P, N * N), dtype=torch.float32, device=x.device)
+        check(lib.dpk_product_forward(ptr(x), B, R, N, ptr(prod), st), 'dpk_product_forward')
+        gprod = torch.empty_like(prod) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        if ctx.root:
+            M, C = P * N * N, w.shape[0]
+            buf = _sum_ws(ctx.ws, B, 1, M, C, x.device)
+            check(lib.dpk_root_backward(ptr(prod), ptr(w), ptr(out), ptr(g), B, M, C, ptr(gprod), ptr(gw), ptr(buf),
+                                        buf.numel(), st), 'dpk_root_backward')
+        else:
+            S = w.shape[1]
+            buf = _sum_ws(ctx.ws, B, P, N * N, S, x.device)
+            check(lib.dpk_sum_backward(ptr(prod), ptr(w), ptr(out), ptr(g), B, P, N * N, S, ptr(gprod), ptr(gw), ptr(buf),
+                                       buf.numel(), st), 'dpk_sum_backward')
+        gx = None
+        if gprod is not None:
+            gx = torch.empty_like(x)
+            check(lib.dpk_product_backward(ptr(gprod), B, R, N, ptr(gx), st), 'dpk_product_backward')
+        return gx, gw, None, None
+
+
+def prodsum_autograd(x: torch.Tensor, weight: torch.Tensor, ws: Workspace, root: bool = False) -> Optional[torch.Tensor]:
+    """The folded level with an autograd graph; None outside the folded kernels' envelope (more than 32 nodes per
+    region): the caller chains the two layers."""
+    if x.dim() != 3 or x.shape[2] > 32 or x.shape[1] % 2:
+        return None
+    return ProdSumFn.apply(x, weight, ws, root)
 
 
 def ratspn_forward_fused(x, mask, pad_mask, loc, scale, sum_weights, root_weight, lctx: LeafContext,

@@ -185,9 +185,24 @@ class RatSpn(ProbabilisticModel):
             out = self._forward_folded(x)
             if out is not None:
                 return out
+        # training / gradients: the layer chain, every ProductLayer folded with the Sum / Root layer above it into one
+        # autograd node (ops.ProdSumFn: no [B, P, N^2] product tensor in the forward)
         x = self.base_layer(x)
-        for layer in self.layers:
+        layers, i = list(self.layers), 0
+        while i < len(layers):
+            layer = layers[i]
+            if isinstance(layer, ProductLayer) and not (self.training and self.sum_dropout is not None):
+                if i + 1 < len(layers) and isinstance(layers[i + 1], SumLayer):
+                    y = ops.prodsum_autograd(x, layers[i + 1].weight, layers[i + 1]._ws)
+                    if y is not None:
+                        x, i = y, i + 2
+                        continue
+                elif i + 1 == len(layers):
+                    y = ops.prodsum_autograd(x, self.root_layer.weight, self.root_layer._ws, root=True)
+                    if y is not None:
+                        return y
             x = layer(x)
+            i += 1
         return self.root_layer(x)
 
     @torch.no_grad()
