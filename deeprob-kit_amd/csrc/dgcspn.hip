@@ -246,6 +246,53 @@ __global__ void spatial_product_bwd_kernel(const float *__restrict__ g, int64_t 
     }
 }
 
+// Depthwise, <= 4 taps (every product layer of the reference's DGC-SPN): thread = one input pixel, its (up to four)
+// source positions in the output-gradient plane worked out once, then a run of (sample, channel) planes with no
+// integer division and unconditional loads at clamped offsets.
+__global__ __launch_bounds__(256) void spatial_product_bwd_dw_kernel(const float *__restrict__ g, int64_t planes,
+                                                                     ProdGeom q, int pslice,
+                                                                     float *__restrict__ gin) {
+    const int HW = q.H * q.W, OHW = q.OH * q.OW, T = q.kh * q.kw;
+    const int ip = blockIdx.x * 256 + threadIdx.x;
+    if (ip >= HW) return;
+    const int ih = ip / q.W, iw = ip - ih * q.W;
+    int off[4];
+    bool ok[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int th = t / q.kw, tw = t - th * q.kw;
+        const int nh = ih + q.pt - th * q.dh, nw = iw + q.pl - tw * q.dw;
+        const int oh = nh / q.sh, ow = nw / q.sw;
+        ok[t] = t < T && nh >= 0 && nw >= 0 && nh % q.sh == 0 && nw % q.sw == 0 && oh < q.OH && ow < q.OW;
+        off[t] = ok[t] ? oh * q.OW + ow : 0;
+    }
+    const int64_t p0 = (int64_t)blockIdx.y * pslice, p1 = min(p0 + pslice, planes);
+#pragma unroll 4
+    for (int64_t pl = p0; pl < p1; ++pl) {
+        const float *gp = g + pl * OHW;
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float v = gp[off[t]];
+            acc += ok[t] ? v : 0.f;
+        }
+        gin[pl * HW + ip] = acc;
+    }
+}
+static void launch_product_bwd(const float *g, int64_t B, const ProdGeom &q, float *gin, hipStream_t st) {
+    if (q.depthwise && q.kh * q.kw <= 4) {
+        const int64_t planes = B * q.C, cols = cdiv(q.H * q.W, 256);
+        int64_t slices = cdiv(4096, cols);                      // about 16 k waves
+        int64_t pslice = cdiv(planes, slices);
+        if (pslice < 4) pslice = 4;
+        slices = cdiv(planes, pslice);
+        DPK_LAUNCH(spatial_product_bwd_dw_kernel, dim3((unsigned)cols, (unsigned)slices), dim3(256), 0, st, g, planes, q,
+                   (int)pslice, gin);
+    } else {
+        DPK_LAUNCH(spatial_product_bwd_kernel, dim3(grid_cap(B * q.C * q.H * q.W, 256)), dim3(256), 0, st, g, B, q, gin);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Sum layer: out[b,o,p] = logsumexp_c(x[b,c,p] + log_softmax(weight, 1)[o,c,p])
 // ------------------------------------------------------------------------------------------------
@@ -850,8 +897,7 @@ extern "C" int dpk_spatial_product_backward(const float *g, int64_t B, int32_t C
     if (rc) return rc;
     if (B <= 0) return B == 0 ? DPK_OK : DPK_EINVAL;
     DPK_REQUIRE(g && grad_in, DPK_EINVAL, "spatial_product_backward: null pointer");
-    DPK_LAUNCH(spatial_product_bwd_kernel, dim3(grid_cap(B * C * H * W, 256)), dim3(256), 0,
-                       (hipStream_t)stream, g, B, q, grad_in);
+    launch_product_bwd(g, B, q, grad_in, (hipStream_t)stream);
     DPK_CHECK_LAUNCH("spatial_product_bwd_kernel");
     return DPK_OK;
 }
@@ -935,7 +981,7 @@ extern "C" int dpk_spatial_prodsum_backward(const float *in, int64_t B, int32_t 
                                             int32_t dw, int32_t pad_top, int32_t pad_left, const float *weight,
                                             int32_t Cout, const float *out, const float *g, float *grad_prod,
                                             float *grad_in, float *grad_weight, void *ws, int64_t ws_bytes,
-                                            void *stream) {
+                                            uint32_t flags, void *stream) {
     ProdGeom q;
     int rc = make_geom(q, C, H, W, C, OH, OW, kh, kw, sh, sw, dh, dw, pad_top, pad_left, 1);
     if (rc) return rc;
@@ -948,8 +994,10 @@ extern "C" int dpk_spatial_prodsum_backward(const float *in, int64_t B, int32_t 
     DPK_REQUIRE(ws_bytes >= 3 * seg, DPK_EWORKSPACE, "spatial_prodsum_backward: workspace too small");
     float *Wl = (float *)ws, *LW = (float *)((char *)ws + seg), *glw = (float *)((char *)ws + 2 * seg);
     hipStream_t st = (hipStream_t)stream;
-    DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * HW, 256)), dim3(256), 0, st, weight, Cout, C, HW,
-               Wl, LW);
+    // (DPK_FLAG_PARAMS_CACHED: the forward of this very node left its tables in the workspace)
+    if (!(flags & DPK_FLAG_PARAMS_CACHED))
+        DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * HW, 256)), dim3(256), 0, st, weight, Cout, C, HW,
+                   Wl, LW);
     if (grad_weight)
         DPK_REQUIRE(hipMemsetAsync(glw, 0, (size_t)Cout * C * HW * 4, st) == hipSuccess, DPK_ELAUNCH, "memset");
     if (B > 0) {
@@ -962,9 +1010,7 @@ extern "C" int dpk_spatial_prodsum_backward(const float *in, int64_t B, int32_t 
         DPK_LAUNCH(spatial_sum_bwd8_kernel<true>, dim3((unsigned)cols, (unsigned)cdiv(slices, 4), (unsigned)halves),
                    dim3(64, 4), 0, st, in, Wl, LW, out, g, B, C, Cout, HW, (int)bslice, grad_in ? grad_prod : nullptr,
                    grad_weight ? glw : nullptr, q);
-        if (grad_in)
-            DPK_LAUNCH(spatial_product_bwd_kernel, dim3(grid_cap(B * C * H * W, 256)), dim3(256), 0, st, grad_prod, B, q,
-                       grad_in);
+        if (grad_in) launch_product_bwd(grad_prod, B, q, grad_in, st);
     }
     if (grad_weight)
         DPK_LAUNCH(spatial_softmax_jacobian_kernel, dim3(grid_cap((int64_t)Cout * HW, 256)), dim3(256), 0, st, glw, Wl,

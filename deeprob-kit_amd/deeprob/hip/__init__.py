@@ -135,7 +135,7 @@ SIGNATURES = {
     'dpk_ll_accumulate': (ctypes.c_int, [_c_void, _i64, _c_void, _c_void]),
     'dpk_spatial_prodsum_backward': (ctypes.c_int, [_c_void, _i64] + [_i32] * 13 + [_c_void, _i32, _c_void, _c_void,
                                                                                    _c_void, _c_void, _c_void, _c_void, _i64,
-                                                                                   _c_void]),
+                                                                                   _u32, _c_void]),
     'dpk_spatial_sumprodroot_workspace_bytes': (_i64, [_i32] * 7),
     'dpk_spatial_sumprodroot_workspace_bytes_batch': (_i64, [_i64, _i32, _i32, _i32, _c_void, _i32, _c_void, _i32]),
     'dpk_spatial_sumprodroot_forward': (ctypes.c_int, [_c_void, _i64, _i32, _i32, _i32, _c_void, _c_void, _i32, _c_void,

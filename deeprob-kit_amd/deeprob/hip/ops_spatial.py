@@ -186,9 +186,9 @@ class SpatialProdSumFn(torch.autograd.Function):
         B, Cout = x.shape[0], w.shape[0]
         out = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
         buf = _spatial_sum_ws(ws, C, Cout, OH, OW, x.device)
-        ws.params_key = None
+        flags = _tables_flag(ws, 'prodsum', w)   # (same tables as the evaluation route builds)
         check(lib.dpk_spatial_prodsum_forward(ptr(x), B, C, H, W, OH, OW, kh, kw, sh, sw, dh, dw, pt, pl, ptr(w), Cout,
-                                              ptr(out), ptr(buf), buf.numel(), 0, stream_ptr(x.device)),
+                                              ptr(out), ptr(buf), buf.numel(), flags, stream_ptr(x.device)),
               'dpk_spatial_prodsum_forward')
         ctx.save_for_backward(x, w, out)
         ctx.geom, ctx.ws = geom, ws
@@ -205,10 +205,11 @@ class SpatialProdSumFn(torch.autograd.Function):
         gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
         gprod = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device) if gx is not None else None
         buf = _spatial_sum_ws(ctx.ws, C, Cout, OH, OW, x.device)
-        ctx.ws.params_key = None
+        # the forward's tables (softmax(W), log softmax(W)) are still there unless the weight or the workspace changed
+        flags = _tables_flag(ctx.ws, 'prodsum', w)
         check(lib.dpk_spatial_prodsum_backward(ptr(x), B, C, H, W, OH, OW, kh, kw, sh, sw, dh, dw, pt, pl, ptr(w), Cout,
                                                ptr(out), ptr(g), ptr(gprod), ptr(gx), ptr(gw), ptr(buf), buf.numel(),
-                                               stream_ptr(x.device)), 'dpk_spatial_prodsum_backward')
+                                               flags, stream_ptr(x.device)), 'dpk_spatial_prodsum_backward')
         return gx, gw, None, None
 
 

@@ -428,12 +428,13 @@ int64_t dpk_spatial_sumprodroot_workspace_bytes(int32_t C, int32_t Cout, int32_t
  * product map (dgcspn.py:224-236) is recomputed from the taps instead of being kept from the forward; its gradient is
  * written to grad_prod [B,C,OH,OW] (caller scratch) and scattered to grad_in [B,C,H,W]; grad_weight [Cout,C,OH,OW].
  * out = the forward's output, g = its gradient.  Workspace of dpk_spatial_sum_workspace_bytes(C,Cout,OH,OW).
+ * flags: DPK_FLAG_PARAMS_CACHED = the softmaxed weight tables of the forward call are still in the workspace.
  * DPK_EUNSUPPORTED outside that envelope (the caller chains the two layers' own backward entries).            */
 int dpk_spatial_prodsum_backward(const float *in, int64_t B, int32_t C, int32_t H, int32_t W, int32_t OH, int32_t OW,
                                  int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t dh, int32_t dw,
                                  int32_t pad_top, int32_t pad_left, const float *weight, int32_t Cout,
                                  const float *out, const float *g, float *grad_prod, float *grad_in,
-                                 float *grad_weight, void *ws, int64_t ws_bytes, void *stream);
+                                 float *grad_weight, void *ws, int64_t ws_bytes, uint32_t flags, void *stream);
 
 /* Workspace for a batch of B samples: the tables of ..._workspace_bytes plus, where the streaming kernel applies
  * (8 -> 8 channels, B >= 256, `in` 16-byte aligned), one (max, sum) pair per sample, class and compute wave for the
