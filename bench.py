@@ -168,13 +168,16 @@ def _time_eval(model, xs, timer, kernel_id, steps=30, warm=5):
         for i in range(warm):
             model(xs[i % len(xs)])
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for i in range(steps):
-            model(xs[i % len(xs)])
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / steps
+        ms = float('inf')
+        for _ in range(2):   # two windows, the faster one: the runtime's one-off pool growth (a ~40 ms host stall after
+            # a few hundred launches of a process, tools/host_overhead3.py) must not pass for a property of the model
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(steps):
+                model(xs[i % len(xs)])
+            e1.record()
+            torch.cuda.synchronize()
+            ms = min(ms, e0.elapsed_time(e1) / steps)
         k_ms = []
         for i in range(5):
             pr = timer.pair()
@@ -203,12 +206,15 @@ def _time_train(model, x, steps=15, warm=3):
 
     for _ in range(warm):
         step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps * 1e3
+    best = float('inf')
+    for _ in range(2):   # (two windows, the faster one: see _time_eval)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / steps * 1e3)
+    return best
 
 
 def _time_train_graph(model, x, steps=30):
@@ -224,11 +230,14 @@ def _time_train_graph(model, x, steps=30):
         torch.cuda.synchronize()
         if gstep.graph is None:
             return None
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            gstep(x)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / steps * 1e3
+        best = float('inf')
+        for _ in range(2):
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                gstep(x)
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / steps * 1e3)
+        return best
     except Exception:
         return None
 
