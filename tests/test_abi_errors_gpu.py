@@ -87,3 +87,66 @@ def test_layer_entry_error_codes():
                                     ptr(act), None, None, 1, 0, ptr(o3), ptr(ldj), 0, ptr(wsc), nws, st)
     assert rc == DPK_EUNSUPPORTED and b'units' in lib.dpk_last_error()
     torch.cuda.synchronize()
+
+
+def test_round2_entry_error_codes():
+    """The entry points added in round 2, called directly: envelope, workspace and null-pointer errors."""
+    import ctypes
+    from deeprob.hip import load_library, ptr
+    lib = load_library()
+    st = torch.cuda.current_stream().cuda_stream
+    # --- alternating-mask coupling on the matrix cores ---------------------------------------------------------
+    D, U, B = 16, 32, 5
+    x = torch.randn(B, D, device='cuda')
+    W1, b1 = torch.randn(U, D, device='cuda'), torch.randn(U, device='cuda')
+    W2, b2 = torch.randn(2 * D, U, device='cuda'), torch.randn(2 * D, device='cuda')
+    act = torch.ones(1, device='cuda')
+    out, ldj = torch.empty_like(x), torch.empty(B, device='cuda')
+    n = lib.dpk_coupling1d_pairs_workspace_bytes(D, U)
+    assert n > 0
+    ws = torch.empty(n, dtype=torch.uint8, device='cuda')
+
+    def pairs(d=D, u=U, parity=0, w1=W1, nbytes=n):
+        return lib.dpk_coupling1d_pairs_forward(ptr(x), B, d, parity, ptr(w1), ptr(b1), ptr(W2), ptr(b2), u, ptr(act),
+                                                None, None, 1, 0, ptr(out), ptr(ldj), 0, ptr(ws), nbytes, 0, st)
+    assert pairs() == 0
+    assert pairs(u=20) == DPK_EUNSUPPORTED                       # hidden width not a multiple of 32
+    assert pairs(d=12) == DPK_EUNSUPPORTED                       # D % 8 != 0
+    assert lib.dpk_coupling1d_pairs_workspace_bytes(12, U) == DPK_EUNSUPPORTED
+    assert pairs(parity=2) == DPK_EINVAL
+    assert pairs(w1=None) == DPK_EINVAL
+    assert pairs(nbytes=64) == DPK_EWORKSPACE
+    # --- fused product + sum level of a DGC-SPN, forward and backward --------------------------------------------
+    C, H, W, OH, OW = 8, 6, 6, 7, 7                               # 2x2 taps, 'full' padding 1, dilation 1
+    xin = torch.randn(4, C, H, W, device='cuda')
+    wsum = torch.randn(8, C, OH, OW, device='cuda')
+    y = torch.empty(4, 8, OH, OW, device='cuda')
+    nws = lib.dpk_spatial_sum_workspace_bytes(C, 8, OH, OW)
+    wss = torch.empty(nws, dtype=torch.uint8, device='cuda')
+    geo = (C, H, W, OH, OW, 2, 2, 1, 1, 1, 1, 1, 1)
+
+    def fwd(g=geo, nbytes=nws, weight=wsum):
+        return lib.dpk_spatial_prodsum_forward(ptr(xin), 4, *g, ptr(weight), 8, ptr(y), ptr(wss), nbytes, 0, st)
+    assert fwd() == 0
+    assert fwd(nbytes=32) == DPK_EWORKSPACE
+    assert fwd(weight=None) == DPK_EINVAL
+    assert fwd(g=(C, H, W, OH, OW, 3, 3, 1, 1, 1, 1, 1, 1)) == DPK_EUNSUPPORTED      # 9 taps: not fused
+    g = torch.randn_like(y)
+    gprod, gx, gw = torch.empty(4, C, OH, OW, device='cuda'), torch.empty_like(xin), torch.empty_like(wsum)
+
+    def bwd(geom=geo, nbytes=nws, gp=gprod):
+        return lib.dpk_spatial_prodsum_backward(ptr(xin), 4, *geom, ptr(wsum), 8, ptr(y), ptr(g), ptr(gp), ptr(gx), ptr(gw),
+                                                ptr(wss), nbytes, 0, st)
+    assert bwd() == 0
+    assert bwd(nbytes=32) == DPK_EWORKSPACE
+    assert bwd(gp=None) == DPK_EINVAL                                                # grad_in wanted, no scratch
+    assert bwd(geom=(C, H, W, OH, OW, 3, 3, 1, 1, 1, 1, 1, 1)) == DPK_EUNSUPPORTED
+    # --- batch-sized workspace query of the last-level kernel ----------------------------------------------------
+    g5 = (ctypes.c_int32 * 10)(OH, OW, 2, 2, 1, 1, 1, 1, 1, 1)
+    g6 = (ctypes.c_int32 * 10)(5, 5, 2, 2, 1, 1, 2, 2, 0, 0)
+    base = lib.dpk_spatial_sumprodroot_workspace_bytes(C, 8, OH, OW, 5, 5, 1)
+    assert base > 0
+    assert lib.dpk_spatial_sumprodroot_workspace_bytes_batch(4096, C, H, W, g5, 8, g6, 1) >= base
+    assert lib.dpk_spatial_sumprodroot_workspace_bytes_batch(4096, C, H, W, None, 8, g6, 1) == DPK_EINVAL
+    assert lib.dpk_spatial_sumprodroot_workspace_bytes_batch(-1, C, H, W, g5, 8, g6, 1) == DPK_EINVAL
+    torch.cuda.synchronize()
