@@ -14,7 +14,8 @@
 // order (o, i) is chosen so that lane (sample l & 31, half h = l >> 5) receives all N rows i of the outputs o it
 // owns: the outer sum over i is a dot product with the lane's own ea, in registers.  A wave owns 32 samples; weight
 // fragments (256 KB at N = S = 16, L2 resident) are read straight from global memory, no LDS.  A node whose scaled
-// sum vanishes (v < 1e-30: dominant pair under a vanishing weight) is redone in the exact two-pass log domain.
+// sum falls below 1e-8 (dominant pair under a small weight: the split's absolute error would show) is redone in the
+// exact two-pass log domain.
 #include "common.h"
 #include "ratspn_gemm_common.h"
 #include <math.h>
@@ -23,6 +24,14 @@ namespace dpk {
 
 typedef const __attribute__((address_space(1))) half8 ug_h8;
 typedef const __attribute__((address_space(1))) gf32x4 ug_f4;
+
+// Both MFMA operands live in [0, 1] (softmax weights, exponentials scaled to their maximum).  An f16 split keeps 22
+// significant bits only while the LOW half is a normal f16 number: unscaled, a weight of 1/64 would be carried to 5e-6
+// relative, and the error is ABSOLUTE (3e-8, half a subnormal step) against a sum v that can itself be as small as the
+// dominant pair's weight.  Both operands are therefore scaled by 2^15 before the split (exact; <= 32768, inside the f16
+// range) and the accumulated sum by 2^-30 afterwards: absolute error 1e-12 per operand.  A node whose sum falls below
+// kUpExactBelow (where that absolute error would reach 1e-4 relative) is redone in the exact log domain.
+constexpr float kUpScale = 32768.f, kUpScaleLog2 = 15.f, kUpUnscale = 1.f / (32768.f * 32768.f), kUpExactBelow = 1e-8f;
 
 // A-fragment tables from the linear softmax weights
 //   sum layer : Wl [P][S][N*N]      -> frag [P][S*N/32 tiles][2][64][8]
@@ -57,7 +66,7 @@ __global__ __launch_bounds__(256) void upper_pack_kernel(const float *__restrict
             float v = 0.f;
             if (ok && j < N) {
                 const int64_t src = root ? (((int64_t)o * P + p) * N + i) * N + j : (((int64_t)p * S + o) * N + i) * N + j;
-                v = Wl[src];
+                v = Wl[src] * kUpScale;
             }
             _Float16 hi, lo;
             split_f16(v, hi, lo);
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(256) void prodsum_mfma_kernel(const UpperArgs a) {
         for (int el = 0; el < 8; ++el) {
             float cj;
             if (N == 16) cj = h ? cv[8 + el] : cv[el]; else cj = cv[el];
-            const float e = __builtin_amdgcn_exp2f((cj - mc) * kUpL2E);
+            const float e = __builtin_amdgcn_exp2f(fmaf(cj - mc, kUpL2E, kUpScaleLog2));   // e^{c - max c} * 2^15
             eb[el] = (N == 8 && h) ? 0.f : e;
         }
         half8 eh, el8;
@@ -157,8 +166,9 @@ __global__ __launch_bounds__(256) void prodsum_mfma_kernel(const UpperArgs a) {
                 float v = 0.f;
 #pragma unroll
                 for (int i = 0; i < N; ++i) v = fmaf(ea[i], acc[q * N + i], v);
+                v *= kUpUnscale;
                 const int o = (N == 16) ? 2 * t + h : 4 * t + 2 * h + q;
-                vanished = vanished || (v < 1e-30f);
+                vanished = vanished || (v < kUpExactBelow);
                 const float r = fmaf(__builtin_amdgcn_logf(v), kUpLn2, ma + mc);
                 if (row_ok && o < S) a.out[(b * P + p) * S + o] = r;
             }
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(256) void prodroot_mfma_kernel(const UpperArgs a) {
         for (int el = 0; el < 8; ++el) {
             float cj;
             if (N == 16) cj = h ? cv[8 + el] : cv[el]; else cj = cv[el];
-            const float e = __builtin_amdgcn_exp2f((cj - mc) * kUpL2E);
+            const float e = __builtin_amdgcn_exp2f(fmaf(cj - mc, kUpL2E, kUpScaleLog2));   // e^{c - max c} * 2^15
             eb[el] = (N == 8 && h) ? 0.f : e;
         }
         half8 eh, el8;
@@ -232,8 +242,9 @@ __global__ __launch_bounds__(256) void prodroot_mfma_kernel(const UpperArgs a) {
 #pragma unroll
                 for (int k = 0; k < HALF; ++k) v = fmaf(es[k], acc[q * HALF + k], v);
                 v += __shfl_xor(v, 32, 64);              // the other half of the i's
+                v *= kUpUnscale;
                 const int k = t * CPT + q;
-                vanished = vanished || (v < 1e-30f && k < C && m > -INFINITY);
+                vanished = vanished || (v < kUpExactBelow && k < C && m > -INFINITY);
                 // running (max, scaled sum) over the partitions
                 const float mm = fmaxf(rm[k], m);
                 const float mm0 = (mm == -INFINITY) ? 0.f : mm;

@@ -277,3 +277,33 @@ def test_streaming_levels_against_oracle(monkeypatch, shape, classes, B, pooling
     with torch.no_grad():
         other = model(x.cuda())
     assert rel_err(got.cpu().numpy(), other.cpu().numpy()) <= 2e-6
+
+
+@pytest.mark.parametrize('shape,padding,stride,dil,cout,B', [((8, 9, 9), 'full', 1, 2, 8, 21), ((5, 12, 12), 'valid', 2, 1, 7, 9),
+                                                           ((3, 7, 7), 'full', 1, 4, 4, 300), ((8, 16, 16), 'final', 1, 4, 8, 40)])
+def test_fused_level_autograd_matches_layer_chain(shape, padding, stride, dil, cout, B):
+    """The training route's single node for a depthwise product + sum pair (ops_spatial.SpatialProdSumFn: fused forward,
+    tap-reading backward) against the two layers chained: values, input gradient and weight gradient."""
+    from deeprob.spn.layers.dgcspn import SpatialProductLayer, SpatialSumLayer
+    from deeprob.hip import ops_spatial
+    gen = torch.Generator().manual_seed(9)
+    prod = SpatialProductLayer(shape, 2, padding, stride, dil, depthwise=True).cuda()
+    ssum = SpatialSumLayer(prod.out_features, cout).cuda()
+    with torch.no_grad():
+        ssum.weight.copy_(torch.randn(ssum.weight.shape, generator=gen) * 2)
+    x = (torch.randn(B, *shape, generator=gen) * 3).cuda()
+    x[0] = float('-inf')                                   # a sample whose every input is log 0
+    gout = torch.randn(B, cout, *prod.out_features[1:], generator=gen).cuda()
+
+    xa = x.clone().requires_grad_(True)
+    ya = ssum(prod(xa))
+    ga_x, ga_w = torch.autograd.grad(ya, [xa, ssum.weight], gout)
+    xb = x.clone().requires_grad_(True)
+    yb = ops_spatial.spatial_prodsum_autograd(xb, prod, ssum.weight, ssum._ws)
+    assert yb is not None
+    gb_x, gb_w = torch.autograd.grad(yb, [xb, ssum.weight], gout)
+    fin = torch.isfinite(ya)
+    assert torch.equal(fin, torch.isfinite(yb))
+    assert rel_err(yb[fin].detach().cpu().numpy(), ya[fin].detach().cpu().numpy()) <= 1e-6
+    assert grad_err(gb_x[1:].cpu().numpy(), ga_x[1:].cpu().numpy()) <= 1e-5
+    assert grad_err(gb_w.cpu().numpy(), ga_w.cpu().numpy()) <= 1e-5

@@ -618,3 +618,27 @@ def test_backward_wide_model_vs_oracle(golden):
     for k in got:
         tol = max(GRAD_TOL, 4.0 * grad_err(ref32[k], ref64[k]))
         assert grad_err(got[k], ref64[k]) <= tol, k
+
+
+@pytest.mark.parametrize('R,N,S,B,root', [(8, 8, 8, 33, False), (4, 16, 16, 70, False), (6, 5, 3, 17, False),
+                                           (8, 8, 10, 33, True), (2, 16, 1, 5, True)])
+def test_folded_level_autograd_matches_layer_chain(R, N, S, B, root):
+    """ops.ProdSumFn (product + sum / root as one autograd node: folded forward, product recomputed in the backward)
+    against the per-layer operators chained: values, input gradient and weight gradient."""
+    from deeprob.hip import ops, Workspace
+    gen = torch.Generator().manual_seed(12)
+    x = (torch.randn(B, R, N, generator=gen) * 4).cuda()
+    P = R // 2
+    w = (torch.randn((S, P * N * N) if root else (P, S, N * N), generator=gen) * 2).cuda().requires_grad_(True)
+    gout = torch.randn((B, S) if root else (B, P, S), generator=gen).cuda()
+    xa = x.clone().requires_grad_(True)
+    prod = ops.ProductFn.apply(xa)
+    ya = ops.RootFn.apply(prod, w, Workspace()) if root else ops.SumFn.apply(prod, w, Workspace())
+    ga_x, ga_w = torch.autograd.grad(ya, [xa, w], gout)
+    xb = x.clone().requires_grad_(True)
+    yb = ops.prodsum_autograd(xb, w, Workspace(), root=root)
+    assert yb is not None
+    gb_x, gb_w = torch.autograd.grad(yb, [xb, w], gout)
+    assert rel_err(yb.detach().cpu().numpy(), ya.detach().cpu().numpy()) <= 2e-6
+    assert grad_err(gb_x.cpu().numpy(), ga_x.cpu().numpy()) <= 1e-5
+    assert grad_err(gb_w.cpu().numpy(), ga_w.cpu().numpy()) <= 1e-5
