@@ -258,6 +258,13 @@ def test_streaming_levels_against_oracle(monkeypatch, shape, classes, B, pooling
     torch.manual_seed(11)
     model = DgcSpn(shape, out_classes=classes, n_batch=8, sum_channels=8, depthwise=True, n_pooling=pooling)
     randomise_dgc(model, 70)
+    with torch.no_grad():   # vanishing and dominating sum weights: the exact log-domain pass of the streaming kernels
+        from deeprob.spn.layers.dgcspn import SpatialSumLayer
+        sums = [l for l in model.layers if isinstance(l, SpatialSumLayer)]
+        sums[0].weight[0, 1] = -200.0
+        sums[0].weight[0, 1, 2, 2] = 50.0
+        sums[-1].weight[3, :, 1, :] = -150.0
+        sums[-1].weight[3, 5, 1, :] = 0.0
     model.eval()
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     plan = dorc.schedule(shape, 8, 8, True, pooling)
