@@ -64,7 +64,48 @@ struct X3PackArgs {
     uint16_t *w1t;       // [NCH1][2][NU][2][512]
     char *w2t;           // [NPT][W2CH bytes]
     float *b1f;          // [U] b1 + W1 (mask * in_shift)
+    float *scales;       // [2] power-of-two scales of the W1 / W2 tables (largest entry -> [2^12, 2^13))
 };
+
+// The f16 halves of a split are exact to 2^-22 relative only while the low half is a normal f16 number (|v| >= 0.25);
+// conditioner weights are a few hundredths, so unscaled they carry an ABSOLUTE error of 3e-8 each -- invisible on
+// standardised data, 1e-3 relative on a log-likelihood once BatchNorm scales of 100 and |x| of 30 multiply it (measured
+// against the fp64 oracle).  Each table is therefore multiplied by the power of two that puts its largest entry into
+// [2^12, 2^13); the kernel divides the accumulators by it again.  One block; the tables are rebuilt only when a
+// parameter changed.
+__global__ __launch_bounds__(1024) void coupling_x3_scale_kernel(const X3PackArgs a) {
+    __shared__ float red[2][16];
+    const int D = a.D, U = a.U, K1 = a.g.K1, N2 = a.g.N2;
+    float m1 = 0.f, m2 = 0.f;
+    for (int64_t e = threadIdx.x; e < (int64_t)U * K1; e += blockDim.x) {
+        const int unit = (int)(e / K1), col = 2 * (int)(e % K1) + a.pm;
+        float v = a.W1[(int64_t)unit * D + col];
+        if (a.in_scale) v *= a.in_scale[col];
+        m1 = fmaxf(m1, fabsf(v));
+    }
+    const int rows2 = a.affine ? 2 : 1;
+    for (int64_t e = threadIdx.x; e < (int64_t)rows2 * N2 * U; e += blockDim.x) {
+        const int unit = (int)(e % U);
+        const int64_t r = e / U;
+        const int ts = (int)(r / N2), var = 2 * (int)(r % N2) + (1 - a.pm);
+        m2 = fmaxf(m2, fabsf(a.W2[((int64_t)ts * D + var) * U + unit]));
+    }
+    m1 = wave_reduce_max(m1);
+    m2 = wave_reduce_max(m2);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = m1;
+        red[1][threadIdx.x >> 6] = m2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        float m = 0.f;
+        for (int w = 0; w < 16; ++w) m = fmaxf(m, red[threadIdx.x][w]);
+        // m * scale in [2^12, 2^13); degenerate tables (all zero, inf, NaN) keep scale 1
+        float sc = 1.f;
+        if (m > 0.f && m < 3.0e38f) sc = exp2f(fminf(fmaxf(12.f - floorf(log2f(m)), -60.f), 60.f));
+        a.scales[threadIdx.x] = sc;
+    }
+}
 
 __global__ __launch_bounds__(256) void coupling_x3_pack_kernel(const X3PackArgs a) {
     const int D = a.D, U = a.U, NU = a.g.NU, K1 = a.g.K1, N2 = a.g.N2;
@@ -86,6 +127,7 @@ __global__ __launch_bounds__(256) void coupling_x3_pack_kernel(const X3PackArgs 
                 if (m < K1 && col < D) {
                     v = a.W1[(int64_t)unit * D + col];
                     if (a.in_scale) v *= a.in_scale[col];
+                    v *= a.scales[0];
                 }
                 _Float16 hi, lo;
                 split_f16(v, hi, lo);
@@ -108,7 +150,7 @@ __global__ __launch_bounds__(256) void coupling_x3_pack_kernel(const X3PackArgs 
                 const int reg = 8 * (kk & 1) + i;
                 const int unit = 32 * (kk >> 1) + (reg & 3) + 8 * (reg >> 2) + 4 * hg;
                 float v = 0.f;
-                if (n < N2 && (ts == 0 || a.affine)) v = a.W2[((int64_t)ts * D + var) * U + unit];
+                if (n < N2 && (ts == 0 || a.affine)) v = a.W2[((int64_t)ts * D + var) * U + unit] * a.scales[1];
                 _Float16 hi, lo;
                 split_f16(v, hi, lo);
                 vh[i] = hi; vl[i] = lo;
@@ -152,7 +194,7 @@ struct X3Args {
     X3Geom g;
     const uint16_t *w1t;
     const char *w2t;
-    const float *b1f, *act_weight;
+    const float *b1f, *act_weight, *scales;
     long long *dbg;   // measurement only (-DDPK_X3_TIMELINE + DPK_X3_TIMELINE=1): s_memtime stamps of work-group 0
 };
 
@@ -277,6 +319,7 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void coupling_x3_kernel(const 
     // ================================================ compute waves =========================================
     for (int e = tid; e < a.U; e += kGemmWaves * 64) b1_l[e] = a.b1f[e];
     const float act = AFFINE ? a.act_weight[0] : 0.f;
+    const float w1sc = a.scales[0], w2sc = a.scales[1];
     __syncthreads();
 
     const int rl_own = wave * 32 + s;
@@ -298,6 +341,14 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void coupling_x3_kernel(const 
         for (int T = 0; T < NU; ++T)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[T][i] = 0.f;
+        // f16 range: the B operands (x, then the hidden activations) are carried per SAMPLE with a power-of-two scale
+        // that shrinks whenever a value would leave the f16 range (the split halves are f16: 65504 at most) -- exact,
+        // and free for ordinary data (one max + one compare per K-step); without it evidence beyond 6.5e4, or a badly
+        // conditioned flow, gave inf - inf = NaN where the reference's fp32 arithmetic stays finite.  A column of the
+        // transposed GEMM is one sample, so the scale is a per-lane scalar; the two lanes of a sample share the
+        // operand's K slots and therefore agree on it.
+        constexpr float kBig = 16384.f;
+        float xsc = 1.f;
         // ---- phase 1: H^T = W1m X^T ----------------------------------------------------------------------
         for (int c = 0; c < NCH1; ++c) {
             X3_STAMP(crow, 0);
@@ -323,6 +374,20 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void coupling_x3_kernel(const 
                         // (columns beyond D hold clamped copies; their W1 entries are zero, the values must be finite)
                         v[i] = (c * 64 + j * 32 + 16 * h + 2 * i < D) ? m : 0.f;
                     }
+                    float m8 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) m8 = fmaxf(m8, fabsf(v[i]));
+                    m8 = fmaxf(m8, __shfl_xor(m8, 32, 64));
+                    if (__builtin_expect(m8 * xsc > kBig && m8 < 3.0e38f, 0)) {
+                        const float f = exp2f(-ceilf(log2f(m8 * xsc * (1.f / kBig))));
+#pragma unroll
+                        for (int T = 0; T < NU; ++T)
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) acc[T][i] *= f;
+                        xsc *= f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] *= xsc;
                     half8 xh, xl;
                     split8(v, xh, xl);
 #pragma unroll
@@ -340,17 +405,27 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void coupling_x3_kernel(const 
         }
         // ---- bias + ReLU + split: the accumulators become the B fragments of GEMM 2 ---------------------------
         half8 hh[KK], hl[KK];
+        const float xinv = 1.f / (xsc * w1sc);     // (powers of two: the operand's scale and the W1 table's)
+        float hmax = 0.f;
+#pragma unroll
+        for (int T = 0; T < NU; ++T)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int unit = 32 * T + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                acc[T][reg] = fmaxf(fmaf(acc[T][reg], xinv, b1_l[unit]), 0.f);
+                hmax = fmaxf(hmax, acc[T][reg]);
+            }
+        hmax = fmaxf(hmax, __shfl_xor(hmax, 32, 64));
+        float hsc = 1.f;
+        if (__builtin_expect(hmax > kBig && hmax < 3.0e38f, 0)) hsc = exp2f(-ceilf(log2f(hmax * (1.f / kBig))));
+        const float hinv = 1.f / (hsc * w2sc);
 #pragma unroll
         for (int T = 0; T < NU; ++T)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float v[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int reg = 8 * j + i;
-                    const int unit = 32 * T + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                    v[i] = fmaxf(acc[T][reg] + b1_l[unit], 0.f);
-                }
+                for (int i = 0; i < 8; ++i) v[i] = acc[T][8 * j + i] * hsc;
                 split8(v, hh[2 * T + j], hl[2 * T + j]);
             }
         // ---- phase 2: Z^T = W2 H^T per tile of 32 transformed variables, fused epilogue ------------------------
@@ -420,10 +495,10 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void coupling_x3_kernel(const 
                     const float xt = pm ? e0 : e1, xp = pm ? e1 : e0;
                     const float xv = fmaf(xt, sct[i], sht[i]);
                     const float pv = fmaf(xp, scp[i], shp[i]);
-                    const float tv = zt[r] + bt[i];
+                    const float tv = fmaf(zt[r], hinv, bt[i]);
                     float ov;
                     if (AFFINE) {
-                        const float sv = act * x3_tanh(zs[r] + bs[i]);
+                        const float sv = act * x3_tanh(fmaf(zs[r], hinv, bs[i]));
                         const float es = __builtin_amdgcn_exp2f((a.inverse ? sv : -sv) * 1.4426950408889634f);
                         ov = a.inverse ? fmaf(xv, es, tv) : (xv - tv) * es;
                         if (n0 + i < a.g.N2) ssum += sv;
@@ -457,7 +532,7 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void coupling_x3_kernel(const 
 struct X3Ws {
     uint16_t *w1t;
     char *w2t;
-    float *b1f;
+    float *b1f, *scales;
     int64_t bytes;
 };
 static X3Ws x3_carve(void *base, const X3Geom &g, int U) {
@@ -472,6 +547,7 @@ static X3Ws x3_carve(void *base, const X3Geom &g, int U) {
     w.w1t = (uint16_t *)take((int64_t)g.NCH1 * g.W1CH);
     w.w2t = take((int64_t)g.NPT * g.W2CH);
     w.b1f = (float *)take((int64_t)U * 4);
+    w.scales = (float *)take(8);
     w.bytes = o;
     return w;
 }
@@ -575,7 +651,8 @@ extern "C" int dpk_coupling1d_pairs_forward(const float *x, int64_t B, int32_t D
         X3PackArgs p{};
         p.W1 = W1; p.b1 = b1; p.W2 = W2; p.b2 = b2; p.in_scale = in_scale; p.in_shift = in_shift;
         p.D = D; p.U = units; p.pm = masked_parity; p.affine = affine; p.g = g;
-        p.w1t = w.w1t; p.w2t = w.w2t; p.b1f = w.b1f;
+        p.w1t = w.w1t; p.w2t = w.w2t; p.b1f = w.b1f; p.scales = w.scales;
+        DPK_LAUNCH(coupling_x3_scale_kernel, dim3(1), dim3(1024), 0, st, p);
         const int64_t total = (int64_t)g.NCH1 * 2 * g.NU * 64 + (int64_t)g.NPT * (units / 16) * 2 * 64 + (int64_t)g.NPT * 32 +
                               units;
         DPK_LAUNCH(coupling_x3_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p);
@@ -584,7 +661,7 @@ extern "C" int dpk_coupling1d_pairs_forward(const float *x, int64_t B, int32_t D
     X3Args a{};
     a.x = x; a.out = out; a.ldj = ldj; a.B = B; a.D = D; a.U = units; a.pm = masked_parity; a.inverse = inverse;
     a.accumulate = accumulate_ldj; a.ntiles = cdiv(B, kX3Tile); a.g = g;
-    a.w1t = w.w1t; a.w2t = w.w2t; a.b1f = w.b1f; a.act_weight = act_weight;
+    a.w1t = w.w1t; a.w2t = w.w2t; a.b1f = w.b1f; a.act_weight = act_weight; a.scales = w.scales;
     switch (units / 32) {
         case 1: return affine ? x3_launch<true, 1>(a, st) : x3_launch<false, 1>(a, st);
         case 2: return affine ? x3_launch<true, 2>(a, st) : x3_launch<false, 2>(a, st);

@@ -37,8 +37,8 @@ def test_layers_and_inverse_golden(golden, name):
         xr, ldj = model.apply_forward(u)
     assert rel_err(u.cpu().numpy(), g['u']) <= TOL
     assert rel_err(ildj.cpu().numpy(), g['ildj']) <= TOL
-    assert rel_err(xr.cpu().numpy(), g['x_rec']) <= 2e-5   # two passes
-    assert rel_err(ldj.cpu().numpy(), g['ldj']) <= 2e-5     # (second pass too: it runs on the reconstructed inputs)
+    assert rel_err(xr.cpu().numpy(), g["x_rec"]) <= 1e-5   # two passes
+    assert rel_err(ldj.cpu().numpy(), g["ldj"]) <= 1e-5     # (second pass too: it runs on the reconstructed inputs)
 
 
 def test_invertibility_like_reference():
@@ -271,3 +271,38 @@ def test_sampling_entry_points():
         r = flow.rsample(64)
     assert torch.isfinite(ll).all() and ll.mean().item() > far.mean().item()
     assert tuple(r.shape) == (64, 24)
+
+
+@pytest.mark.parametrize('D,units', [(64, 128), (784, 128), (40, 32)])
+def test_pairs_kernel_stress_vs_fp64_oracle(D, units):
+    """The split-f16 coupling kernel away from the fixtures' comfortable ranges, against the oracle in fp64: conditioner
+    weights 10x the reference initialisation (saturating tanh), small weights (subnormal low halves of the split),
+    evidence up to |x| ~ 30, BatchNorm variances from 1e-4 to 1e2 folded into the first GEMM."""
+    from deeprob.flows.models import RealNVP1d
+    from tests.util import randomise_flow
+    torch.manual_seed(21)
+    model = RealNVP1d(D, n_flows=3, units=units)
+    randomise_flow(model, 31)
+    g = torch.Generator().manual_seed(32)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if '.network.' in name and name.endswith('weight'):
+                p.mul_(torch.where(torch.rand(p.shape, generator=g) < 0.5, 10.0, 1e-3))
+        for name, b in model.named_buffers():
+            if name.endswith('running_var'):
+                b.copy_(10 ** (torch.rand(b.shape, generator=g) * 6 - 4))
+    model.eval()
+    sd64 = {k: (v.detach().double() if v.is_floating_point() else v.detach().clone()) for k, v in model.state_dict().items()}
+    x = torch.randn(257, D, generator=g) * torch.where(torch.rand(257, 1, generator=g) < 0.2, 10.0, 1.0)
+    want = forc.flow_log_prob(sd64, x.double()).numpy()
+    sd32 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    want32 = forc.flow_log_prob(sd32, x).numpy()                   # the reference's own fp32 arithmetic on this input
+    noise = np.max(np.abs(want32 - want) / np.maximum(np.abs(want), 1.0))
+    with torch.no_grad():
+        got = model.cuda()(x.cuda()).cpu().numpy()
+    assert np.isfinite(want).all() and np.isfinite(got).all()
+    # per sample: the batch mixes log-likelihoods of very different magnitudes
+    per_sample = np.max(np.abs(got - want) / np.maximum(np.abs(want), 1.0))
+    # (two-way f16 splits carry 22 bits per product against fp32's 24: up to 4x the reference's own rounding error, which
+    # this ill-conditioned input amplifies for both alike)
+    assert per_sample <= max(TOL, 8 * noise), (per_sample, noise)
