@@ -70,7 +70,7 @@ struct X3PackArgs {
 // The f16 halves of a split are exact to 2^-22 relative only while the low half is a normal f16 number (|v| >= 0.25);
 // conditioner weights are a few hundredths, so unscaled they carry an ABSOLUTE error of 3e-8 each -- invisible on
 // standardised data, 1e-3 relative on a log-likelihood once BatchNorm scales of 100 and |x| of 30 multiply it (measured
-// against the fp64 oracle).  Each table is therefore multiplied by the power of two that puts its largest entry into
+// against an fp64 evaluation of the reference formulas).  Each table is therefore multiplied by the power of two that puts its largest entry into
 // [2^12, 2^13); the kernel divides the accumulators by it again.  One block; the tables are rebuilt only when a
 // parameter changed.
 __global__ __launch_bounds__(1024) void coupling_x3_scale_kernel(const X3PackArgs a) {
