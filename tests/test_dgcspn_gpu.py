@@ -270,6 +270,7 @@ def test_streaming_levels_against_oracle(monkeypatch, shape, classes, B, pooling
     plan = dorc.schedule(shape, 8, 8, True, pooling)
     x = torch.randn(B, *shape, generator=torch.Generator().manual_seed(3))
     x[1] = 35.0                                   # every Gaussian far in its tail
+    x[4, :, :3] = 3.0e3                           # part of an image absurdly far out: log-densities of -1e7
     x[2, :, ::2] = float('nan')
     x[3] = float('nan')
     want = dorc.dgcspn_forward(sd, x, plan)
@@ -278,7 +279,8 @@ def test_streaming_levels_against_oracle(monkeypatch, shape, classes, B, pooling
         got = model(x.cuda())
         again = model(x.cuda()[5:])
     assert tuple(got.shape) == (B, classes)
-    assert rel_err(got.cpu().numpy(), want.numpy()) <= LL_TOL
+    per_sample = ((got.cpu() - want).abs() / want.abs().clamp_min(1.0)).max().item()   # (magnitudes differ by 1e5)
+    assert per_sample <= LL_TOL
     assert torch.equal(again, got[5:])
     monkeypatch.setenv('DPK_DGC_STREAM_MIN_B', '1000000000')
     with torch.no_grad():
