@@ -649,3 +649,20 @@ def test_folded_level_autograd_matches_layer_chain(R, N, S, B, root):
     ok = torch.isfinite(ga_x)           # (where the chain itself yields nan for a -inf input, nothing is pinned)
     assert grad_err(gb_x[ok].cpu().numpy(), ga_x[ok].cpu().numpy()) <= 1e-5
     assert grad_err(gb_w.cpu().numpy(), ga_w.cpu().numpy()) <= 1e-5
+
+
+@pytest.mark.parametrize('name', ['ratspn_g784_d2_r8_i2_s2', 'ratspn_g784_d2_r8_i8_s8', 'ratspn_g784_d2_r8_i16_s16'])
+def test_mixed_magnitude_evidence_per_sample(golden, name):
+    """One batch whose rows span eight orders of magnitude (1e-3 ... 1e5, straddling the expansion bound 6 and the exact-path
+    bound 1e3 of the matrix-core kernels): every SAMPLE is held to the 1e-5 bar against fp64, not the batch's maximum."""
+    model, g = build(name, golden)
+    x = torch.randn(18 * 7, 784, generator=torch.Generator().manual_seed(77))
+    scales = torch.tensor([1e-3, 0.1, 1.0, 3.0, 5.5, 6.5, 30.0, 900.0, 1100.0, 3e3, 1e5, 1.0, 2.0, 4.0, 8.0, 16.0, 64.0, 256.0])
+    x = x * scales.repeat_interleave(7)[:, None]
+    x[5, ::5] = float('nan')
+    sd64 = {k: (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu()) for k, v in model.state_dict().items()}
+    want = orc.ratspn_forward(sd64, x.double())
+    with torch.no_grad():
+        got = model(x.cuda()).cpu().double()
+    per_sample = ((got - want).abs() / want.abs().clamp_min(1.0)).max().item()
+    assert torch.isfinite(got).all() and per_sample <= LL_TOL, per_sample
