@@ -515,7 +515,10 @@ def main():
                                'kernel_event_method': '{} runs of {} consecutive launches, one HIP event pair per run '
                                                       '(includes the gaps between the launches of a run)'.format(
                                                           len(sampled), run),
-                               'algorithmic_bytes_per_launch': alg_bytes}
+                               'algorithmic_bytes_per_launch': alg_bytes,
+                               'context': 'tools/ubench/read_bw.hip on the same GPU model: 6.4 TB/s for a linear 16-byte-load '
+                                          'stream, 5.7 TB/s for this kernel\'s access pattern (256-byte row segments at a '
+                                          '3136-byte stride); peak = the 8 TB/s specification'}
         threads = min(os.cpu_count() or 1, 32)
         if args.cpu_samples > 0 and world == 1:
             out['cpu_baseline'], threads = cpu_baseline(cpu_state, D, args.cpu_samples)
