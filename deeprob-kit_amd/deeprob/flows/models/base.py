@@ -104,7 +104,7 @@ class NormalizingFlow(ProbabilisticModel):
 
     def _forward_fused(self, x: torch.Tensor, pre_ildj) -> torch.Tensor:
         from deeprob.hip import ops_flows
-        affine, ldj_const, ildj = None, None, None
+        affine, ldj_const, ildj = None, [], None
         if torch.is_tensor(pre_ildj):
             ildj = pre_ildj.to(torch.float32).contiguous().clone()
         for layer in self.layers:
@@ -113,7 +113,8 @@ class NormalizingFlow(ProbabilisticModel):
             else:
                 x, ildj = ops_flows.coupling1d(x, layer, inverse=False, in_affine=affine, ldj=ildj)
                 affine = None
-        return ops_flows.normal_base_logprob(x, affine, self.in_base_loc, self.in_base_scale, ildj, ldj_const)
+        return ops_flows.normal_base_logprob(x, affine, self.in_base_loc, self.in_base_scale, ildj,
+                                             ops_flows.sum_constants(self, ldj_const))
 
     @torch.no_grad()
     def sample(self, n_samples: int, y: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -164,10 +164,27 @@ def bn1d_fold(bn, inverse: bool, in_affine=None, ldj_const: Optional[torch.Tenso
         # (s_in / h_in are kept alive with the entry: their addresses are part of the key)
         hit = (key, (sc, sh), own, (s_in, h_in))
         bn._fold_cache = hit
+    if isinstance(ldj_const, list):      # the caller sums the layers' constants itself (sum_constants below)
+        ldj_const.append(hit[2])
+        return hit[1], ldj_const
     if ldj_const is None:
         return hit[1], hit[2].clone()
     ldj_const += hit[2]
     return hit[1], ldj_const
+
+
+def sum_constants(owner, consts) -> Optional[torch.Tensor]:
+    """Total of the eval-mode BatchNorm layers' constant log-determinants (one-element tensors kept by bn1d_fold): summed
+    once and reused while every layer returns the very tensors it returned before -- four one-element additions per
+    call otherwise."""
+    if not consts:
+        return None
+    key = tuple(id(t) for t in consts)
+    hit = getattr(owner, '_const_sum_cache', None)
+    if hit is None or hit[0] != key:
+        hit = (key, torch.stack([t.reshape(()) for t in consts]).sum().reshape(1), list(consts))   # (keeps them alive)
+        owner._const_sum_cache = hit
+    return hit[1]
 
 
 def affine1d(x: torch.Tensor, affine) -> torch.Tensor:
