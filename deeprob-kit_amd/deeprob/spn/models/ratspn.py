@@ -98,6 +98,7 @@ class RatSpn(ProbabilisticModel):
             self.layers.append(layer)
         self.root_layer = RootLayer(groups, nodes, self.out_classes)
 
+        self._fused_declined = False
         self._fused_ctx = ops.LeafContext(
             self.in_features, self.base_layer.in_regions, self.rg_batch, self.base_layer.dimension,
             depth=self.rg_depth, reps=rg_repetitions, sums=self.rg_sum, classes=self.out_classes
@@ -179,9 +180,13 @@ class RatSpn(ProbabilisticModel):
                 out = self._forward_folded(x)
                 if out is not None:
                     return out
-            out = self._forward_fused(x)
-            if out is not None:
-                return out
+            # (the single-launch kernel declines on (depth, channels, sums, classes) alone -- constants of the model: once
+            # it has, later calls do not ask again; the attempt was a quarter of a wide model's host time per call)
+            if not self._fused_declined:
+                out = self._forward_fused(x)
+                if out is not None:
+                    return out
+                self._fused_declined = isinstance(self.base_layer, GaussianLayer) and not self.training
             out = self._forward_folded(x)
             if out is not None:
                 return out
