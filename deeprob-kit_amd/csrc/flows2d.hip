@@ -1,0 +1,345 @@
+// RealNVP-2D evaluation path: the convolutional conditioners (weight-normalised 3x3 / 1x1 convolutions
+// with eval-mode BatchNorm2d + ReLU folded into the operand load), the checkerboard / channel-wise coupling
+// transformation, the BatchNormLayer2d bijector and the squeeze / multi-scale permutations.
+//   reference: flows/layers/coupling.py:107-272 (CouplingLayer2d), :275-408 (CouplingBlock2d),
+//              flows/layers/resnet.py:9-90, flows/layers/densenet.py, torch/utils.py:86-121 (WeightNormConv2d),
+//              flows/utils.py:11-38 (squeeze), :165-222 (BatchNormLayer2d), flows/models/realnvp.py:75-220 (RealNVP2d)
+//
+// Convolution kernel: fp32 on the vector ALUs.  A thread owns 4 consecutive pixels of one output row and CO = 16 output
+// channels (64 accumulators); the weights of a (input channel, tap) are 16 consecutive floats of the packed table and
+// are wave-uniform, so they arrive through the scalar unit (s_load_dwordx16) and feed v_fma as SGPR operands: per input
+// channel a thread issues 18 loads for 576 FMAs.  The conditioners are compute-bound (14.4 MFLOP per 3x3 convolution
+// of 32 channels on 28x28 against 200 KB of activations), so no LDS staging is needed to stay off the HBM roof.
+#include "common.h"
+
+namespace dpk {
+
+constexpr int kConvCO = 16;   // output channels per thread
+constexpr int kConvPix = 4;   // pixels per thread (one row segment)
+
+// ---- weight normalisation + packing -------------------------------------------------------------------------------
+// w[co,ci,ky,kx] = g[co] * v[co,ci,ky,kx] / ||v[co]||  (torch.nn.utils.weight_norm, dim 0) -> wpack[ci][tap][CoutPad]
+// block co < Cout: one output channel; blocks Cout..CoutPad-1 write zeros; the last block folds the BatchNorm2d that
+// precedes the convolution into pre[0:Cin] = gamma / sqrt(var + eps), pre[Cin:2Cin] = beta - mean * pre[0:Cin].
+__global__ __launch_bounds__(256) void conv2d_prepare_kernel(const float *__restrict__ v, const float *__restrict__ g,
+                                                             int Cout, int CoutPad, int Cin, int taps,
+                                                             const float *__restrict__ bn_w,
+                                                             const float *__restrict__ bn_b,
+                                                             const float *__restrict__ bn_mean,
+                                                             const float *__restrict__ bn_var, float bn_eps,
+                                                             float *__restrict__ wpack, float *__restrict__ pre) {
+    const int co = blockIdx.x, n = Cin * taps;
+    if (co == CoutPad) {
+        for (int c = threadIdx.x; c < Cin; c += 256) {
+            const float a = bn_w[c] / sqrtf(bn_var[c] + bn_eps);
+            pre[c] = a;
+            pre[Cin + c] = bn_b[c] - bn_mean[c] * a;
+        }
+        return;
+    }
+    if (co >= Cout) {
+        for (int i = threadIdx.x; i < n; i += 256) wpack[(int64_t)i * CoutPad + co] = 0.f;
+        return;
+    }
+    const float *vc = v + (int64_t)co * n;
+    float scale = 1.f;
+    if (g) {
+        __shared__ float part[256];
+        float s = 0.f;
+        for (int i = threadIdx.x; i < n; i += 256) s = fmaf(vc[i], vc[i], s);
+        part[threadIdx.x] = s;
+        __syncthreads();
+        for (int k = 128; k > 0; k >>= 1) {
+            if ((int)threadIdx.x < k) part[threadIdx.x] += part[threadIdx.x + k];
+            __syncthreads();
+        }
+        scale = g[co] / sqrtf(part[0]);
+    }
+    for (int i = threadIdx.x; i < n; i += 256) wpack[(int64_t)i * CoutPad + co] = vc[i] * scale;
+}
+
+// ---- convolution ---------------------------------------------------------------------------------------------------
+struct Conv2dArgs {
+    const float *in;
+    int64_t in_bs;
+    int B, Cin, H, W;
+    const float *w;
+    int Cout, CoutPad;
+    const float *pre;   // [2*Cin] or null: relu(a*x + b) applied to the operand (zero padding stays zero)
+    const float *mask;  // [H*W] or null: multiplies the operand (checkerboard coupling mask)
+    const float *bias;  // [Cout] or null
+    const float *res;   // added to the result, or null
+    int64_t res_bs;
+    float *out;
+    int64_t out_bs;
+};
+
+template <int KS, bool PRE>
+__global__ __launch_bounds__(256) void conv2d_kernel(Conv2dArgs a) {
+    constexpr int P = KS / 2, NV = kConvPix + KS - 1, CO = kConvCO;
+    const int QW = (a.W + kConvPix - 1) / kConvPix;
+    const int per = a.H * QW;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = (int)(t / per);
+    if (b >= a.B) return;
+    const int rem = (int)(t - (int64_t)b * per);
+    const int y = rem / QW, x0 = (rem - y * QW) * kConvPix;
+    const int co0 = blockIdx.y * CO;
+    const int HW = a.H * a.W;
+
+    float acc[kConvPix][CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        const float bv = (a.bias && co0 + co < a.Cout) ? a.bias[co0 + co] : 0.f;
+#pragma unroll
+        for (int p = 0; p < kConvPix; ++p) acc[p][co] = bv;
+    }
+    const float *ip = a.in + (int64_t)b * a.in_bs;
+    const float *wp = a.w + co0;
+    for (int ci = 0; ci < a.Cin; ++ci, ip += HW, wp += (int64_t)KS * KS * a.CoutPad) {
+        float pa = 1.f, pb = 0.f;
+        if (PRE) {
+            pa = a.pre[ci];
+            pb = a.pre[a.Cin + ci];
+        }
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            const int yy = y + ky - P;
+            const bool rok = (unsigned)yy < (unsigned)a.H;
+            float v[NV];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int xx = x0 + j - P;
+                const bool ok = rok && (unsigned)xx < (unsigned)a.W;
+                float r = ok ? ip[yy * a.W + xx] : 0.f;
+                if (PRE) r = ok ? fmaxf(fmaf(r, pa, pb), 0.f) : 0.f;
+                if (a.mask) r *= ok ? a.mask[yy * a.W + xx] : 0.f;
+                v[j] = r;
+            }
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                const float *wt = wp + (int64_t)(ky * KS + kx) * a.CoutPad;
+#pragma unroll
+                for (int co = 0; co < CO; ++co) {
+                    const float wv = wt[co];
+#pragma unroll
+                    for (int p = 0; p < kConvPix; ++p) acc[p][co] = fmaf(v[p + kx], wv, acc[p][co]);
+                }
+            }
+        }
+    }
+    const int64_t pix = (int64_t)y * a.W + x0;
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        if (co0 + co >= a.Cout) break;
+        float *op = a.out + (int64_t)b * a.out_bs + (int64_t)(co0 + co) * HW + pix;
+        const float *rp = a.res ? a.res + (int64_t)b * a.res_bs + (int64_t)(co0 + co) * HW + pix : nullptr;
+#pragma unroll
+        for (int p = 0; p < kConvPix; ++p) {
+            if (x0 + p < a.W) op[p] = rp ? acc[p][co] + rp[p] : acc[p][co];
+        }
+    }
+}
+
+// ---- coupling transformation (one work-group per sample) ---------------------------------------------------------
+__device__ inline float block_sum_256(float v, float *sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// density direction: u = (x - t) exp(-s), ldj -= sum s;  inverse: x = u exp(s) + t, ldj += sum s.
+// checkerboard (inv_mask != null): z [B, 2C or C, H, W], t and s multiplied by inv_mask[H*W];
+// channel-wise: x = [my | mx] (reverse: [mx | my]) halves of Ch = C/2 channels, z [B, 2Ch or Ch, H, W] conditions on mx;
+// mx is copied through.
+__global__ __launch_bounds__(256) void coupling2d_kernel(const float *__restrict__ x, const float *__restrict__ z,
+                                                         const float *__restrict__ scale,
+                                                         const float *__restrict__ inv_mask, int C, int HW,
+                                                         int affine, int reverse, int inverse,
+                                                         const float *__restrict__ ldj_in, float *__restrict__ out,
+                                                         float *__restrict__ ldj_out) {
+    __shared__ float sh[4];
+    const int b = blockIdx.x;
+    const bool chw = inv_mask == nullptr;
+    const int Ch = chw ? C / 2 : C;
+    const int n = Ch * HW;
+    const int64_t zb = (int64_t)b * (affine ? 2 : 1) * n;
+    // offset of the transformed half inside x / out
+    const int off = chw ? (reverse ? n : 0) : 0;
+    const float *xb = x + (int64_t)b * C * HW;
+    float *ob = out + (int64_t)b * C * HW;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int c = i / HW, p = i - c * HW;
+        const float m = chw ? 1.f : inv_mask[p];
+        float t = z[zb + i] * m, s = 0.f;
+        if (affine) s = scale[c] * tanhf(z[zb + n + i]) * m;
+        const float xv = xb[off + i];
+        ob[off + i] = inverse ? fmaf(xv, expf(s), t) : (xv - t) * expf(-s);
+        acc += s;
+        if (chw) ob[(n - off) + i] = xb[(n - off) + i];
+    }
+    acc = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) ldj_out[b] = (ldj_in ? ldj_in[b] : 0.f) + (inverse ? acc : -acc);
+}
+
+// BatchNormLayer2d with running statistics (flows/utils.py:186-222).
+// density: u = (x - mean) / sqrt(var + eps) * exp(w) + bias, ldj += HW * sum_c (w - 0.5 log(var + eps));  inverse: the inverse.
+__global__ __launch_bounds__(256) void bn2d_bijector_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                            const float *__restrict__ bias,
+                                                            const float *__restrict__ mean,
+                                                            const float *__restrict__ var, float eps, int C, int HW,
+                                                            int inverse, const float *__restrict__ ldj_in,
+                                                            float *__restrict__ out, float *__restrict__ ldj_out) {
+    const int b = blockIdx.x;
+    const int n = C * HW;
+    const float *xb = x + (int64_t)b * n;
+    float *ob = out + (int64_t)b * n;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int c = i / HW;
+        const float sd = sqrtf(var[c] + eps);
+        ob[i] = inverse ? (xb[i] - bias[c]) * expf(-w[c]) * sd + mean[c] : (xb[i] - mean[c]) / sd * expf(w[c]) + bias[c];
+    }
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += w[c] - 0.5f * logf(var[c] + eps);
+        s *= (float)HW;
+        ldj_out[b] = (ldj_in ? ldj_in[b] : 0.f) + (inverse ? -s : s);
+    }
+}
+
+// ---- squeeze / multi-scale permutations -----------------------------------------------------------------------------
+// out channel o takes in[b, table[o] >> 2, 2h + ((table[o] >> 1) & 1), 2w + (table[o] & 1)];
+// channels [0, Ca) go to out_a, [Ca, 4C) to out_b.
+__global__ __launch_bounds__(256) void space_to_depth_kernel(float *__restrict__ in, int64_t total, int C, int H,
+                                                             int W, const int *__restrict__ table,
+                                                             float *__restrict__ out_a, int Ca,
+                                                             float *__restrict__ out_b, int inverse) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int h2 = H / 2, w2 = W / 2, hw2 = h2 * w2;
+    const int w = (int)(i % w2);
+    const int h = (int)((i / w2) % h2);
+    const int o = (int)((i / hw2) % (4 * C));
+    const int64_t b = i / ((int64_t)hw2 * 4 * C);
+    const int e = table[o];
+    const int64_t full = ((b * C + (e >> 2)) * H + 2 * h + ((e >> 1) & 1)) * W + 2 * w + (e & 1);
+    float *dst = o < Ca ? out_a + ((b * Ca + o) * hw2 + h * w2 + w) : out_b + ((b * (4 * C - Ca) + (o - Ca)) * hw2 + h * w2 + w);
+    if (inverse) in[full] = *dst;
+    else *dst = in[full];
+}
+
+}  // namespace dpk
+
+using namespace dpk;
+
+extern "C" {
+
+int64_t dpk_conv2d_pack_floats(int32_t Cout, int32_t Cin, int32_t ks) {
+    return (int64_t)Cin * ks * ks * align_up(Cout, kConvCO);
+}
+
+int dpk_conv2d_prepare(const float *weight_v, const float *weight_g, int32_t Cout, int32_t Cin, int32_t ks,
+                       const float *bn_weight, const float *bn_bias, const float *bn_mean, const float *bn_var,
+                       float bn_eps, float *wpack, float *pre, void *stream) {
+    DPK_REQUIRE(weight_v && wpack, DPK_EINVAL, "conv2d_prepare: null pointer");
+    DPK_REQUIRE(Cout > 0 && Cin > 0 && (ks == 1 || ks == 3), DPK_EINVAL, "conv2d_prepare: Cout=%d Cin=%d ks=%d", Cout,
+                Cin, ks);
+    const bool bn = bn_weight != nullptr;
+    DPK_REQUIRE(!bn || (bn_bias && bn_mean && bn_var && pre), DPK_EINVAL, "conv2d_prepare: incomplete BatchNorm2d");
+    const int CoutPad = (int)align_up(Cout, kConvCO);
+    DPK_LAUNCH(conv2d_prepare_kernel, dim3(CoutPad + (bn ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, weight_v, weight_g,
+               Cout, CoutPad, Cin, ks * ks, bn_weight, bn_bias, bn_mean, bn_var, bn_eps, wpack, pre);
+    DPK_CHECK_LAUNCH("conv2d_prepare_kernel");
+    return DPK_OK;
+}
+
+int dpk_conv2d_forward(const float *in, int64_t in_bstride, int64_t B, int32_t Cin, int32_t H, int32_t W,
+                       const float *wpack, int32_t Cout, int32_t ks, const float *pre, const float *in_mask,
+                       const float *bias, const float *res, int64_t res_bstride, float *out, int64_t out_bstride,
+                       void *stream) {
+    DPK_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, DPK_EINVAL, "conv2d_forward: bad sizes");
+    DPK_REQUIRE(ks == 1 || ks == 3, DPK_EUNSUPPORTED, "conv2d_forward: kernel size %d not built (1, 3)", ks);
+    if (B == 0) return DPK_OK;
+    DPK_REQUIRE(in && wpack && out, DPK_EINVAL, "conv2d_forward: null pointer");
+    DPK_REQUIRE(in_bstride >= (int64_t)Cin * H * W && out_bstride >= (int64_t)Cout * H * W &&
+                    (!res || res_bstride >= (int64_t)Cout * H * W),
+                DPK_EINVAL, "conv2d_forward: batch stride below the tensor size");
+    DPK_REQUIRE((int64_t)Cin * H * W < INT32_MAX && (int64_t)Cout * H * W < INT32_MAX, DPK_EUNSUPPORTED,
+                "conv2d_forward: image too large");
+    Conv2dArgs a{};
+    a.in = in; a.in_bs = in_bstride; a.B = (int)B; a.Cin = Cin; a.H = H; a.W = W;
+    a.w = wpack; a.Cout = Cout; a.CoutPad = (int)align_up(Cout, kConvCO);
+    a.pre = pre; a.mask = in_mask; a.bias = bias; a.res = res; a.res_bs = res_bstride;
+    a.out = out; a.out_bs = out_bstride;
+    DPK_REQUIRE(B <= INT32_MAX / 2, DPK_EUNSUPPORTED, "conv2d_forward: batch too large");
+    const int64_t threads = B * H * ((W + kConvPix - 1) / kConvPix);
+    const dim3 grid((unsigned)cdiv(threads, 256), (unsigned)(a.CoutPad / kConvCO));
+    hipStream_t st = (hipStream_t)stream;
+    if (ks == 3) {
+        if (pre) DPK_LAUNCH((conv2d_kernel<3, true>), grid, dim3(256), 0, st, a);
+        else DPK_LAUNCH((conv2d_kernel<3, false>), grid, dim3(256), 0, st, a);
+    } else {
+        if (pre) DPK_LAUNCH((conv2d_kernel<1, true>), grid, dim3(256), 0, st, a);
+        else DPK_LAUNCH((conv2d_kernel<1, false>), grid, dim3(256), 0, st, a);
+    }
+    DPK_CHECK_LAUNCH("conv2d_kernel");
+    return DPK_OK;
+}
+
+int dpk_coupling2d_transform(const float *x, const float *z, const float *scale, const float *inv_mask, int64_t B,
+                             int32_t C, int32_t H, int32_t W, int32_t affine, int32_t reverse, int32_t inverse,
+                             const float *ldj_in, float *out, float *ldj_out, void *stream) {
+    DPK_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0, DPK_EINVAL, "coupling2d_transform: bad sizes");
+    DPK_REQUIRE(inv_mask || C % 2 == 0, DPK_EINVAL, "coupling2d_transform: channel-wise coupling needs an even C=%d", C);
+    DPK_REQUIRE((int64_t)C * H * W < INT32_MAX && B < INT32_MAX, DPK_EUNSUPPORTED, "coupling2d_transform: too large");
+    if (B == 0) return DPK_OK;
+    DPK_REQUIRE(x && z && out && ldj_out && (!affine || scale), DPK_EINVAL, "coupling2d_transform: null pointer");
+    DPK_LAUNCH(coupling2d_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, z, scale, inv_mask, C, H * W,
+               affine, reverse, inverse, ldj_in, out, ldj_out);
+    DPK_CHECK_LAUNCH("coupling2d_kernel");
+    return DPK_OK;
+}
+
+int dpk_bn2d_bijector(const float *x, const float *weight, const float *bias, const float *mean, const float *var,
+                      float eps, int64_t B, int32_t C, int32_t H, int32_t W, int32_t inverse, const float *ldj_in,
+                      float *out, float *ldj_out, void *stream) {
+    DPK_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0, DPK_EINVAL, "bn2d_bijector: bad sizes");
+    DPK_REQUIRE((int64_t)C * H * W < INT32_MAX && B < INT32_MAX, DPK_EUNSUPPORTED, "bn2d_bijector: too large");
+    if (B == 0) return DPK_OK;
+    DPK_REQUIRE(x && weight && bias && mean && var && out && ldj_out, DPK_EINVAL, "bn2d_bijector: null pointer");
+    DPK_LAUNCH(bn2d_bijector_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, weight, bias, mean, var,
+               eps, C, H * W, inverse, ldj_in, out, ldj_out);
+    DPK_CHECK_LAUNCH("bn2d_bijector_kernel");
+    return DPK_OK;
+}
+
+static int depth_perm(const float *full, int64_t B, int32_t C, int32_t H, int32_t W, const int32_t *table,
+                      float *part_a, int32_t Ca, float *part_b, int inverse, void *stream, const char *who) {
+    DPK_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, DPK_EINVAL,
+                "%s: needs even H, W (C=%d H=%d W=%d)", who, C, H, W);
+    DPK_REQUIRE(Ca > 0 && Ca <= 4 * C, DPK_EINVAL, "%s: split %d outside (0, %d]", who, Ca, 4 * C);
+    if (B == 0) return DPK_OK;
+    DPK_REQUIRE(full && table && part_a && (Ca == 4 * C || part_b), DPK_EINVAL, "%s: null pointer", who);
+    const int64_t total = B * C * H * W;
+    DPK_REQUIRE(total / 256 < INT32_MAX, DPK_EUNSUPPORTED, "%s: too large", who);
+    DPK_LAUNCH(space_to_depth_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+               const_cast<float *>(full), total, C,
+               H, W, table, part_a, Ca, part_b, inverse);
+    DPK_CHECK_LAUNCH("space_to_depth_kernel");
+    return DPK_OK;
+}
+
+int dpk_space_to_depth(const float *in, int64_t B, int32_t C, int32_t H, int32_t W, const int32_t *table, float *out_a,
+                       int32_t Ca, float *out_b, void *stream) {
+    return depth_perm(in, B, C, H, W, table, out_a, Ca, out_b, 0, stream, "space_to_depth");
+}
+
+int dpk_depth_to_space(const float *in_a, int32_t Ca, const float *in_b, int64_t B, int32_t C, int32_t H, int32_t W,
+                       const int32_t *table, float *out, void *stream) {
+    return depth_perm(out, B, C, H, W, table, const_cast<float *>(in_a), Ca, const_cast<float *>(in_b), 1, stream,
+                      "depth_to_space");
+}
+
+}  // extern "C"

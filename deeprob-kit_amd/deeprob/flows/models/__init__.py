@@ -1,2 +1,2 @@
 from .base import NormalizingFlow
-from .realnvp import RealNVP1d
+from .realnvp import RealNVP1d, RealNVP2d

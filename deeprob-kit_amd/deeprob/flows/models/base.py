@@ -96,9 +96,16 @@ class NormalizingFlow(ProbabilisticModel):
             return self._forward_fused(x, ildj)
         x, d = self.apply_backward(x)
         ildj = ildj + d
-        if isinstance(self.in_base, distributions.Normal) and hasattr(self, 'in_base_loc') and x.dim() == 2:
+        if isinstance(self.in_base, distributions.Normal) and hasattr(self, 'in_base_loc'):
             from deeprob.hip import ops_flows
-            return ops_flows.NormalBaseFn.apply(x, self.in_base_loc, self.in_base_scale) + ildj
+            if x.dim() == 2:
+                return ops_flows.NormalBaseFn.apply(x, self.in_base_loc, self.in_base_scale) + ildj
+            if not ops_flows._wants_graph(x, ildj if torch.is_tensor(ildj) else None):
+                # image flows (RealNVP2d): the same kernel on the flattened latent, log-det-Jacobian added in the pass
+                acc = ildj.to(torch.float32).contiguous() if torch.is_tensor(ildj) else None
+                ll = ops_flows.normal_base_logprob(x.reshape(batch_size, -1), None, self.in_base_loc.reshape(-1),
+                                                   self.in_base_scale.reshape(-1), acc, None)
+                return ll if acc is not None else ll + ildj
         base_lls = self.in_base.log_prob(x)
         return torch.sum(base_lls.view(batch_size, -1), dim=1) + ildj
 

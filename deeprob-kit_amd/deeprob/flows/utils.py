@@ -4,7 +4,7 @@
 signatures, attributes and `state_dict` names.  Eval-mode batch norm runs on the HIP kernels (a
 per-variable affine, foldable into the next coupling); Dequantize / Logit are cheap element-wise
 device ops left to PyTorch, as SURVEY 2#7 allows (Dequantize is stochastic in the reference too).
-The 2-D pieces (squeeze, BatchNormLayer2d) are out of scope (RealNVP2d only).
+The 2-D pieces (squeeze / un-squeeze, BatchNormLayer2d) run on csrc/flows2d.hip, evaluation only.
 """
 import abc
 from typing import Union, Tuple
@@ -14,6 +14,20 @@ import torch
 from torch import nn
 
 from deeprob.hip import Workspace
+
+
+def squeeze_depth2d(x: torch.Tensor) -> torch.Tensor:
+    """[N, C, H, W] -> [N, 4C, H/2, W/2], output channel c*4 + dy*2 + dx (reference :11-23)."""
+    from deeprob.hip import ops_flows2d
+    ops_flows2d.require_eval(_EVAL, 'squeeze_depth2d', x)
+    return ops_flows2d.space_to_depth(x, ops_flows2d.squeeze_table(x.shape[1], x.device))
+
+
+def unsqueeze_depth2d(x: torch.Tensor) -> torch.Tensor:
+    """[N, 4C, H, W] -> [N, C, 2H, 2W], the inverse of :func:`squeeze_depth2d` (reference :26-38)."""
+    from deeprob.hip import ops_flows2d
+    ops_flows2d.require_eval(_EVAL, 'unsqueeze_depth2d', x)
+    return ops_flows2d.depth_to_space(x, ops_flows2d.squeeze_table(x.shape[1] // 4, x.device))
 
 
 class Bijector(abc.ABC, nn.Module):
@@ -39,6 +53,13 @@ class Bijector(abc.ABC, nn.Module):
     @abc.abstractmethod
     def apply_forward(self, u: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """latent -> data; returns (x, log-det-Jacobian)."""
+
+
+class _EvalOnly(nn.Module):
+    """Stand-in module (eval mode, no parameters) for the graph check of the free functions above."""
+
+
+_EVAL = _EvalOnly().eval()
 
 
 class BatchNormLayer1d(Bijector):
@@ -79,6 +100,39 @@ class BatchNormLayer1d(Bijector):
             return ops_flows.BatchNormInverseFn.apply(u, self.weight, self.bias, self)
         affine, ldj = ops_flows.bn1d_fold(self, inverse=True)
         return ops_flows.affine1d(u, affine), ldj.expand(u.shape[0])
+
+
+class BatchNormLayer2d(Bijector):
+    def __init__(self, in_features: int, momentum: float = 0.9, eps: float = 1e-5):
+        """Per-channel batch normalisation as a bijector (reference :165-184): parameters `weight` (log-gain), `bias`,
+        buffers `running_var`, `running_mean`, all of shape [1, C, 1, 1].  Evaluation (running statistics) only.
+
+        :raises ValueError: if momentum is not in (0, 1) or eps is not positive."""
+        if momentum <= 0.0 or momentum >= 1.0:
+            raise ValueError("The momentum value must be in (0, 1)")
+        if eps <= 0.0:
+            raise ValueError("The epsilon value must be positive")
+        super().__init__(in_features)
+        self.momentum = momentum
+        self.eps = eps
+        self.weight = nn.Parameter(torch.zeros(1, self.in_features, 1, 1), requires_grad=True)
+        self.bias = nn.Parameter(torch.zeros(1, self.in_features, 1, 1), requires_grad=True)
+        self.register_buffer('running_var', torch.ones(1, self.in_features, 1, 1))
+        self.register_buffer('running_mean', torch.zeros(1, self.in_features, 1, 1))
+
+    def transform(self, x: torch.Tensor, inverse: bool, ldj=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        from deeprob.hip import ops_flows2d
+        ops_flows2d.require_eval(self, 'BatchNormLayer2d', x)
+        return ops_flows2d.bn2d(x, self, inverse, ldj)
+
+    def apply_backward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """u = (x - mean)/sqrt(var + eps) * exp(weight) + bias, ildj = H W sum_c(weight - log(var + eps)/2)
+        (reference :186-208, eval branch)."""
+        return self.transform(x, False)
+
+    def apply_forward(self, u: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The inverse with the running statistics (reference :210-222)."""
+        return self.transform(u, True)
 
 
 class DequantizeLayer(Bijector):

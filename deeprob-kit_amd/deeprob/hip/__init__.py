@@ -69,6 +69,17 @@ SIGNATURES = {
     'dpk_affine1d_forward': (ctypes.c_int, [_c_void, _c_void, _c_void, _i64, _i32, _c_void, _c_void]),
     'dpk_logit1d_forward': (ctypes.c_int, [_c_void, _i64, _i32, ctypes.c_float, ctypes.c_float, _i32, _c_void, _c_void,
                                            _c_void]),
+    'dpk_conv2d_pack_floats': (_i64, [_i32] * 3),
+    'dpk_conv2d_prepare': (ctypes.c_int, [_c_void, _c_void, _i32, _i32, _i32, _c_void, _c_void, _c_void, _c_void,
+                                          ctypes.c_float, _c_void, _c_void, _c_void]),
+    'dpk_conv2d_forward': (ctypes.c_int, [_c_void, _i64, _i64, _i32, _i32, _i32, _c_void, _i32, _i32, _c_void, _c_void,
+                                          _c_void, _c_void, _i64, _c_void, _i64, _c_void]),
+    'dpk_coupling2d_transform': (ctypes.c_int, [_c_void, _c_void, _c_void, _c_void, _i64, _i32, _i32, _i32, _i32, _i32,
+                                                _i32, _c_void, _c_void, _c_void, _c_void]),
+    'dpk_bn2d_bijector': (ctypes.c_int, [_c_void, _c_void, _c_void, _c_void, _c_void, ctypes.c_float, _i64, _i32, _i32,
+                                         _i32, _i32, _c_void, _c_void, _c_void, _c_void]),
+    'dpk_space_to_depth': (ctypes.c_int, [_c_void, _i64, _i32, _i32, _i32, _c_void, _c_void, _i32, _c_void, _c_void]),
+    'dpk_depth_to_space': (ctypes.c_int, [_c_void, _i32, _c_void, _i64, _i32, _i32, _i32, _c_void, _c_void, _c_void]),
     'dpk_normal_base_logprob': (ctypes.c_int, [_c_void, _c_void, _c_void, _c_void, _c_void, _c_void, _c_void,
                                                _i64, _i32, _c_void, _c_void]),
     'dpk_spatial_gaussian_forward': (ctypes.c_int, [_c_void, _c_void, _c_void, _i64, _i32, _i32, _i32, _i32,

@@ -471,6 +471,44 @@ int dpk_flat_spn_forward(const float *x, int64_t B, int32_t D, int32_t n_nodes, 
                          int32_t n_slots, const int32_t *node_slot, const int32_t *child_slot, float *out,
                          float *node_values, void *ws, int64_t ws_bytes, void *stream);
 
+/* ---- RealNVP-2D evaluation path (density and sampling directions, running statistics) -----------
+ * Conditioner convolutions (torch/utils.py:86-121 WeightNormConv2d inside flows/layers/resnet.py:9-90 and
+ * flows/layers/densenet.py): NCHW fp32, kernel 1x1 or 3x3, stride 1, "same" zero padding.
+ * dpk_conv2d_prepare: w[co] = weight_g[co] * weight_v[co] / ||weight_v[co]|| (weight_g NULL: w = weight_v) packed as
+ *   wpack[ci][ky*ks+kx][CoutPad] (dpk_conv2d_pack_floats floats); bn_* non-NULL additionally folds the eval-mode
+ *   nn.BatchNorm2d that precedes the convolution into pre[0:Cin] = gamma/sqrt(var+eps), pre[Cin:2Cin] = beta - mean*pre[0:Cin].
+ * dpk_conv2d_forward: out[b,co] = bias[co] + sum_ci w[co,ci] * f(in[b,ci]) (+ res[b,co]);
+ *   f(v) = relu(pre_a v + pre_b) when pre != NULL (the BatchNorm2d + ReLU in front of the convolution), then * in_mask[H*W]
+ *   when in_mask != NULL (CouplingLayer2d's mask * x, coupling.py:209-210); padding pixels contribute 0.
+ *   in / res / out rows of a sample start in_bstride / res_bstride / out_bstride floats apart (channel slices of
+ *   larger tensors: torch.chunk inputs, DenseNet concatenations); res == out is allowed (z += skip(x)).      */
+int64_t dpk_conv2d_pack_floats(int32_t Cout, int32_t Cin, int32_t ks);
+int dpk_conv2d_prepare(const float *weight_v, const float *weight_g, int32_t Cout, int32_t Cin, int32_t ks,
+                       const float *bn_weight, const float *bn_bias, const float *bn_mean, const float *bn_var,
+                       float bn_eps, float *wpack, float *pre, void *stream);
+int dpk_conv2d_forward(const float *in, int64_t in_bstride, int64_t B, int32_t Cin, int32_t H, int32_t W,
+                       const float *wpack, int32_t Cout, int32_t ks, const float *pre, const float *in_mask,
+                       const float *bias, const float *res, int64_t res_bstride, float *out, int64_t out_bstride,
+                       void *stream);
+/* CouplingLayer2d.apply_backward (inverse = 0, coupling.py:181-226) / apply_forward (inverse = 1, :228-272) given the
+ * conditioner output z [B, 2*Ch or Ch, H, W] (t | s; NICE mode: t only).  inv_mask [H*W] != NULL: checkerboard
+ * coupling, Ch = C; NULL: channel-wise, Ch = C/2, x = [my | mx] (reverse: [mx | my]), mx copied through.
+ * scale [Ch] = ScaledTanh weight.  ldj_out[b] = (ldj_in ? ldj_in[b] : 0) -/+ sum s.                         */
+int dpk_coupling2d_transform(const float *x, const float *z, const float *scale, const float *inv_mask, int64_t B,
+                             int32_t C, int32_t H, int32_t W, int32_t affine, int32_t reverse, int32_t inverse,
+                             const float *ldj_in, float *out, float *ldj_out, void *stream);
+/* BatchNormLayer2d with running statistics (flows/utils.py:186-222): weight / bias / mean / var [C].          */
+int dpk_bn2d_bijector(const float *x, const float *weight, const float *bias, const float *mean, const float *var,
+                      float eps, int64_t B, int32_t C, int32_t H, int32_t W, int32_t inverse, const float *ldj_in,
+                      float *out, float *ldj_out, void *stream);
+/* squeeze_depth2d (flows/utils.py:11-23) and RealNVP2d's one-hot permutation convolution followed by torch.chunk
+ * (flows/models/realnvp.py:182-185), and their inverses (:26-38, :188-191): output channel o of the [B,4C,H/2,W/2]
+ * tensor = in[b, table[o]>>2, 2h + ((table[o]>>1)&1), 2w + (table[o]&1)]; channels [0,Ca) live in *_a, the rest in *_b. */
+int dpk_space_to_depth(const float *in, int64_t B, int32_t C, int32_t H, int32_t W, const int32_t *table, float *out_a,
+                       int32_t Ca, float *out_b, void *stream);
+int dpk_depth_to_space(const float *in_a, int32_t Ca, const float *in_b, int64_t B, int32_t C, int32_t H, int32_t W,
+                       const int32_t *table, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,3 +77,61 @@ def dropout_mask(seed: int, shape, p: float):
         z = z ^ (z >> np.uint64(31))
     top = (z >> np.uint64(40)).astype(np.float32)
     return torch.from_numpy((top < np.float32(p) * np.float32(16777216.0)).reshape(shape))
+
+
+def randomise_flow2d(model, seed):
+    """Same as tools/gen_golden_flows2d.py::randomise_flow2d: every parameter / running statistic of a RealNVP2d is a
+    pure function of (seed, tensor name), so the fixtures ship a checksum of the state instead of the weights."""
+    import zlib
+
+    def gen(name):
+        return torch.Generator().manual_seed((zlib.crc32(name.encode()) + seed) % (2 ** 31))
+
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            g = gen(name)
+            if name.endswith('scale_act.weight'):
+                p.copy_(0.2 + 0.3 * torch.rand(p.shape, generator=g))
+            elif name.endswith('conv.weight_v'):
+                p.copy_(0.3 * torch.randn(p.shape, generator=g))
+            elif name.endswith('conv.weight_g'):
+                p.copy_(0.15 + 0.2 * torch.rand(p.shape, generator=g))
+            elif name.endswith('conv.bias'):
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            elif '.network.' in name and name.endswith('.weight'):
+                p.copy_(0.8 + 0.4 * torch.rand(p.shape, generator=g))
+            elif '.network.' in name and name.endswith('.bias'):
+                p.copy_(0.2 * torch.randn(p.shape, generator=g))
+            elif 'couplings.' in name and (name.endswith('.weight') or name.endswith('.bias')):
+                p.copy_(0.2 * torch.randn(p.shape, generator=g))
+        for name, b in model.named_buffers():
+            g = gen(name)
+            if name.endswith('running_var'):
+                b.copy_(0.5 + torch.rand(b.shape, generator=g))
+            elif name.endswith('running_mean'):
+                b.copy_(0.3 * torch.randn(b.shape, generator=g))
+
+
+def state_checksum(model):
+    import numpy as np
+    sd = model.state_dict()
+    return np.array([float(sd[k].double().abs().sum()) for k in sorted(sd)], dtype=np.float64)
+
+
+FLOWS2D_CASES = [
+    # fixture, in_features, constructor arguments, seed (tools/gen_golden_flows2d.py::CASES)
+    ('realnvp2d_3x8x8_resnet', (3, 8, 8), dict(n_flows=2, n_blocks=2, channels=8, network='resnet', affine=True), 21),
+    ('realnvp2d_3x8x8_resnet_nice', (3, 8, 8), dict(n_flows=2, n_blocks=2, channels=8, network='resnet', affine=False), 22),
+    ('realnvp2d_3x8x8_densenet', (3, 8, 8), dict(n_flows=2, n_blocks=2, channels=8, network='densenet', affine=True), 23),
+    ('realnvp2d_3x8x8_densenet_nice', (3, 8, 8), dict(n_flows=2, n_blocks=2, channels=8, network='densenet', affine=False), 24),
+    ('realnvp2d_1x28x28_logit', (1, 28, 28), dict(n_flows=1, n_blocks=2, channels=32, network='resnet', affine=True, logit=0.05), 25),
+    ('realnvp2d_3x12x20_c20', (3, 12, 20), dict(n_flows=1, n_blocks=1, channels=20, network='resnet', affine=True), 26),
+]
+
+
+def flow2d_model(feats, kw, seed):
+    from deeprob.flows.models import RealNVP2d
+    torch.manual_seed(seed)
+    m = RealNVP2d(feats, **kw).eval()
+    randomise_flow2d(m, seed)
+    return m

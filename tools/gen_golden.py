@@ -180,7 +180,7 @@ def gen_ratspn():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='region,ratspn,flows,flows_train,dgcspn,mpe')
+    ap.add_argument('--only', default='region,ratspn,flows,flows_train,dgcspn,mpe,flows2d')
     args = ap.parse_args()
     import deeprob
     ref = os.path.realpath(os.path.dirname(deeprob.__file__))
@@ -195,6 +195,11 @@ def main():
         from gen_golden_mpe import gen_mpe
         gens['mpe'] = gen_mpe
         gens.update({'flows': gen_flows, 'flows_train': gen_flows_train, 'dgcspn': gen_dgcspn})
+    except ImportError:
+        pass
+    try:
+        from gen_golden_flows2d import gen_flows2d
+        gens['flows2d'] = gen_flows2d
     except ImportError:
         pass
     for key, fn in gens.items():
