@@ -16,6 +16,7 @@ namespace dpk {
 
 constexpr int kConvCO = 16;   // output channels per thread
 constexpr int kConvPix = 4;   // pixels per thread (one row segment)
+typedef float float2_t __attribute__((ext_vector_type(2)));
 
 // ---- weight normalisation + packing -------------------------------------------------------------------------------
 // w[co,ci,ky,kx] = g[co] * v[co,ci,ky,kx] / ||v[co]||  (torch.nn.utils.weight_norm, dim 0) -> wpack[ci][tap][CoutPad]
@@ -74,9 +75,9 @@ struct Conv2dArgs {
     int64_t out_bs;
 };
 
-template <int KS, bool PRE>
+template <int KS, bool PRE, bool MASK>
 __global__ __launch_bounds__(256) void conv2d_kernel(Conv2dArgs a) {
-    constexpr int P = KS / 2, NV = kConvPix + KS - 1, CO = kConvCO;
+    constexpr int P = KS / 2, NV = kConvPix + KS - 1, CO = kConvCO, NL = KS * NV;
     const int QW = (a.W + kConvPix - 1) / kConvPix;
     const int per = a.H * QW;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -87,45 +88,90 @@ __global__ __launch_bounds__(256) void conv2d_kernel(Conv2dArgs a) {
     const int co0 = blockIdx.y * CO;
     const int HW = a.H * a.W;
 
-    float acc[kConvPix][CO];
+    // the NL = KS * (4 + KS - 1) operand positions of this thread: clamped offsets (every load is in bounds and
+    // unconditional, so the loads of a channel go out back to back) and the padding / mask factor of each
+    int off[NL];
+    float fac[NL];   // MASK builds only
+    bool okb[NL];
 #pragma unroll
-    for (int co = 0; co < CO; ++co) {
-        const float bv = (a.bias && co0 + co < a.Cout) ? a.bias[co0 + co] : 0.f;
+    for (int ky = 0; ky < KS; ++ky) {
+        const int yy = y + ky - P;
+        const int yc = min(max(yy, 0), a.H - 1);
 #pragma unroll
-        for (int p = 0; p < kConvPix; ++p) acc[p][co] = bv;
+        for (int j = 0; j < NV; ++j) {
+            const int xx = x0 + j - P;
+            const int xc = min(max(xx, 0), a.W - 1);
+            const bool ok = (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+            off[ky * NV + j] = yc * a.W + xc;
+            okb[ky * NV + j] = ok;
+            fac[ky * NV + j] = ok ? (MASK ? a.mask[yc * a.W + xc] : 1.f) : 0.f;
+        }
+    }
+
+    // accumulators as pairs of neighbouring output channels: one v_pk_fma_f32 per pair (weights = an SGPR pair, the
+    // operand broadcast to both halves)
+    float2_t acc[kConvPix][CO / 2];
+#pragma unroll
+    for (int co = 0; co < CO; co += 2) {
+        float2_t bv;
+        bv.x = (a.bias && co0 + co < a.Cout) ? a.bias[co0 + co] : 0.f;
+        bv.y = (a.bias && co0 + co + 1 < a.Cout) ? a.bias[co0 + co + 1] : 0.f;
+#pragma unroll
+        for (int p = 0; p < kConvPix; ++p) acc[p][co / 2] = bv;
     }
     const float *ip = a.in + (int64_t)b * a.in_bs;
     const float *wp = a.w + co0;
-    for (int ci = 0; ci < a.Cin; ++ci, ip += HW, wp += (int64_t)KS * KS * a.CoutPad) {
+    float nxt[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) nxt[i] = ip[off[i]];
+    // weights: the 16 floats of a tap are wave-uniform (scalar loads); the next tap's are requested before this tap's
+    // FMAs so that the scalar-cache latency is covered by them
+    float2_t wc[CO / 2], wn[CO / 2];
+#pragma unroll
+    for (int co = 0; co < CO; co += 2) {
+        wc[co / 2].x = wp[co];
+        wc[co / 2].y = wp[co + 1];
+    }
+    for (int ci = 0; ci < a.Cin; ++ci) {
+        float v[NL];
         float pa = 1.f, pb = 0.f;
         if (PRE) {
             pa = a.pre[ci];
             pb = a.pre[a.Cin + ci];
         }
 #pragma unroll
-        for (int ky = 0; ky < KS; ++ky) {
-            const int yy = y + ky - P;
-            const bool rok = (unsigned)yy < (unsigned)a.H;
-            float v[NV];
+        for (int i = 0; i < NL; ++i) {
+            float r = nxt[i];
+            if (PRE) r = fmaxf(fmaf(r, pa, pb), 0.f);
+            v[i] = MASK ? r * fac[i] : (okb[i] ? r : 0.f);
+        }
+        // the next channel's operands are requested before this channel's FMAs (the last iteration re-reads channel
+        // Cin - 1: in bounds, unused)
+        const bool more = ci + 1 < a.Cin;
+        ip += more ? HW : 0;
 #pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int xx = x0 + j - P;
-                const bool ok = rok && (unsigned)xx < (unsigned)a.W;
-                float r = ok ? ip[yy * a.W + xx] : 0.f;
-                if (PRE) r = ok ? fmaxf(fmaf(r, pa, pb), 0.f) : 0.f;
-                if (a.mask) r *= ok ? a.mask[yy * a.W + xx] : 0.f;
-                v[j] = r;
+        for (int i = 0; i < NL; ++i) nxt[i] = ip[off[i]];
+#pragma unroll
+        for (int tap = 0; tap < KS * KS; ++tap) {
+            const int ky = tap / KS, kx = tap % KS;
+            // (after the last tap of the last channel: re-reads that tap, unused)
+            wp += (tap + 1 < KS * KS || more) ? a.CoutPad : 0;
+#pragma unroll
+            for (int co = 0; co < CO; co += 2) {
+                wn[co / 2].x = wp[co];
+                wn[co / 2].y = wp[co + 1];
             }
 #pragma unroll
-            for (int kx = 0; kx < KS; ++kx) {
-                const float *wt = wp + (int64_t)(ky * KS + kx) * a.CoutPad;
+            for (int co = 0; co < CO; co += 2) {
 #pragma unroll
-                for (int co = 0; co < CO; ++co) {
-                    const float wv = wt[co];
-#pragma unroll
-                    for (int p = 0; p < kConvPix; ++p) acc[p][co] = fmaf(v[p + kx], wv, acc[p][co]);
+                for (int p = 0; p < kConvPix; ++p) {
+                    float2_t vv;
+                    vv.x = vv.y = v[ky * NV + p + kx];
+                    acc[p][co / 2] = __builtin_elementwise_fma(vv, wc[co / 2], acc[p][co / 2]);
                 }
             }
+#pragma unroll
+            for (int co = 0; co < CO / 2; ++co) wc[co] = wn[co];
         }
     }
     const int64_t pix = (int64_t)y * a.W + x0;
@@ -136,7 +182,8 @@ __global__ __launch_bounds__(256) void conv2d_kernel(Conv2dArgs a) {
         const float *rp = a.res ? a.res + (int64_t)b * a.res_bs + (int64_t)(co0 + co) * HW + pix : nullptr;
 #pragma unroll
         for (int p = 0; p < kConvPix; ++p) {
-            if (x0 + p < a.W) op[p] = rp ? acc[p][co] + rp[p] : acc[p][co];
+            const float r = (co & 1) ? acc[p][co / 2].y : acc[p][co / 2].x;
+            if (x0 + p < a.W) op[p] = rp ? r + rp[p] : r;
         }
     }
 }
@@ -277,13 +324,20 @@ int dpk_conv2d_forward(const float *in, int64_t in_bstride, int64_t B, int32_t C
     const int64_t threads = B * H * ((W + kConvPix - 1) / kConvPix);
     const dim3 grid((unsigned)cdiv(threads, 256), (unsigned)(a.CoutPad / kConvCO));
     hipStream_t st = (hipStream_t)stream;
+    const dim3 blk(256);
+#define DPK_CONV_CASE(KS_, PRE_, MASK_) DPK_LAUNCH((conv2d_kernel<KS_, PRE_, MASK_>), grid, blk, 0, st, a)
     if (ks == 3) {
-        if (pre) DPK_LAUNCH((conv2d_kernel<3, true>), grid, dim3(256), 0, st, a);
-        else DPK_LAUNCH((conv2d_kernel<3, false>), grid, dim3(256), 0, st, a);
+        if (pre && in_mask) DPK_CONV_CASE(3, true, true);
+        else if (pre) DPK_CONV_CASE(3, true, false);
+        else if (in_mask) DPK_CONV_CASE(3, false, true);
+        else DPK_CONV_CASE(3, false, false);
     } else {
-        if (pre) DPK_LAUNCH((conv2d_kernel<1, true>), grid, dim3(256), 0, st, a);
-        else DPK_LAUNCH((conv2d_kernel<1, false>), grid, dim3(256), 0, st, a);
+        if (pre && in_mask) DPK_CONV_CASE(1, true, true);
+        else if (pre) DPK_CONV_CASE(1, true, false);
+        else if (in_mask) DPK_CONV_CASE(1, false, true);
+        else DPK_CONV_CASE(1, false, false);
     }
+#undef DPK_CONV_CASE
     DPK_CHECK_LAUNCH("conv2d_kernel");
     return DPK_OK;
 }
