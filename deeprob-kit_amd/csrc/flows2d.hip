@@ -11,6 +11,7 @@
 // channel a thread issues 18 loads for 576 FMAs.  The conditioners are compute-bound (14.4 MFLOP per 3x3 convolution
 // of 32 channels on 28x28 against 200 KB of activations), so no LDS staging is needed to stay off the HBM roof.
 #include "common.h"
+#include <stdlib.h>
 
 namespace dpk {
 
@@ -188,6 +189,167 @@ __global__ __launch_bounds__(256) void conv2d_kernel(Conv2dArgs a) {
     }
 }
 
+// ---- convolution on the matrix cores ------------------------------------------------------------------------------
+// D[cout][pixel] = sum_k W[cout][k] X[k][pixel] with v_mfma_f32_32x32x2_f32 (fp32 products and sums: the 1e-5 parity
+// rules out narrower operands); k runs over (input-channel pair, tap).  Lane l supplies W[cout = l & 31][k-half = l >> 5]
+// from the fragment-ordered table (one coalesced dword per k-step, straight from L2) and X[k-half][pixel = l & 31]: its own
+// pixel of channel 2*jp + (l >> 5), one tap per k-step, BatchNorm2d + ReLU + zero padding applied in registers.  A wave
+// owns 64 consecutive pixels of the flattened [B, H*W] axis (two 32-pixel tiles) times 32 output channels; the operands
+// of the next channel pair are requested before the 18 MFMAs of the current one.  Results leave as 128-byte runs (32
+// consecutive pixels of one channel per store).
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+constexpr int kMfmaTiles = 2;
+// DPK_C2D_ABLATE (measurement builds only): 1 = activations loaded for the first channel pair only, 2 = one MFMA per tile
+// and pair instead of nine, 4 = weight fragments loaded for the first pair only
+#ifndef DPK_C2D_ABLATE
+#define DPK_C2D_ABLATE 0
+#endif
+
+// fragment order: wfrag[((cog * nJ + jp) * taps + tap) * 64 + lane] = w[co = cog*32 + (lane & 31)][ci = 2*jp + (lane >> 5)][tap]
+__global__ __launch_bounds__(256) void conv2d_frag_kernel(const float *__restrict__ wpack, int Cout, int CoutPad, int Cin,
+                                                          int taps, float *__restrict__ wfrag, int64_t n) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int lane = (int)(e & 63);
+    const int64_t q = e >> 6;
+    const int tap = (int)(q % taps);
+    const int nJ = (Cin + 1) / 2;
+    const int jp = (int)((q / taps) % nJ);
+    const int cog = (int)(q / ((int64_t)taps * nJ));
+    const int ci = 2 * jp + (lane >> 5), co = cog * 32 + (lane & 31);
+    wfrag[e] = (ci < Cin && co < Cout) ? wpack[((int64_t)ci * taps + tap) * CoutPad + co] : 0.f;
+}
+
+template <int KS, bool PRE>
+__global__ __launch_bounds__(256) void conv2d_mfma_kernel(Conv2dArgs a, const float *__restrict__ wfrag) {
+    constexpr int TAPS = KS * KS, P = KS / 2, T = kMfmaTiles;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int HW = a.H * a.W;
+    const int64_t total = (int64_t)a.B * HW;
+    const int64_t slot0 = ((int64_t)blockIdx.x * 4 + wave) * (32 * T);
+    if (slot0 >= total) return;
+    const int cog = blockIdx.y;
+    const int nJ = (a.Cin + 1) / 2;
+
+    const float *ptr[T];
+    int offs[T][TAPS];
+    uint64_t vmask = 0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int sl = (int)min(slot0 + t * 32 + col, total - 1);   // (the entry point keeps B * H * W below 2^31)
+        const int b = sl / HW;
+        const int pix = sl - b * HW;
+        const int y = pix / a.W, x = pix - y * a.W;
+        ptr[t] = a.in + (int64_t)b * a.in_bs;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int yy = y + tap / KS - P, xx = x + tap % KS - P;
+            const bool ok = (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+            offs[t][tap] = min(max(yy, 0), a.H - 1) * a.W + min(max(xx, 0), a.W - 1);
+            vmask |= (uint64_t)(ok ? 1 : 0) << (t * TAPS + tap);
+        }
+    }
+    const float *wf = wfrag + (int64_t)cog * nJ * TAPS * 64 + lane;
+
+    f32x16_t acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // two operand sets used in turn (no register copies between iterations): while the MFMAs of one channel pair run,
+    // the other set receives the next pair's activations, weight fragments and BatchNorm factors
+    float xa[2][T][TAPS], wb[2][TAPS], pa[2] = {1.f, 1.f}, pb[2] = {0.f, 0.f};
+    auto request = [&](int set, int jp) {
+        const int ci = min(2 * jp + half, a.Cin - 1);
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+#if DPK_C2D_ABLATE == 1
+                if (jp == 0)
+#endif
+                xa[set][t][tap] = ptr[t][ci * HW + offs[t][tap]];
+            }
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+#if DPK_C2D_ABLATE == 4
+            if (jp == 0)
+#endif
+            wb[set][tap] = wf[((int64_t)jp * TAPS + tap) * 64];
+        }
+        if (PRE) {
+            pa[set] = a.pre[ci];
+            pb[set] = a.pre[a.Cin + ci];
+        }
+    };
+    auto step = [&](int set, int jp) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                float r = xa[set][t][tap];
+                if (PRE) r = fmaxf(fmaf(r, pa[set], pb[set]), 0.f);
+                xa[set][t][tap] = ((vmask >> (t * TAPS + tap)) & 1) ? r : 0.f;
+            }
+        // the requests stay above the MFMAs (left alone, the scheduler sinks every load to just before its use one
+        // iteration later -- shortest live ranges -- and each MFMA pair then waits a full memory latency: measured 3x);
+        // the last iteration re-reads its own operands: in bounds, unused
+        __builtin_amdgcn_sched_barrier(0);
+        request(set ^ 1, min(jp + 1, nJ - 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#if DPK_C2D_ABLATE == 2
+                if (tap > 0) continue;
+#endif
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[set][tap], xa[set][t][tap], acc[t], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    request(0, 0);
+    for (int jp = 0; jp < nJ; jp += 2) {
+        step(0, jp);
+        if (jp + 1 < nJ) step(1, jp + 1);
+    }
+    // epilogue: every residual / bias value is requested before the first addition (clamped addresses, no branches around
+    // the loads: one memory latency per tile instead of one per value), then 128-byte store runs under the lane predicate
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int sl = (int)min(slot0 + t * 32 + col, total - 1);
+        const bool live = slot0 + t * 32 + col < total;
+        const int b = sl / HW;
+        const int pix = sl - b * HW;
+        float add[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) add[r] = 0.f;
+        if (a.res) {
+            const float *rp = a.res + (int64_t)b * a.res_bs + pix;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = min(cog * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1);
+                add[r] = rp[(int64_t)co * HW];
+            }
+        }
+        if (a.bias) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = min(cog * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1);
+                add[r] += a.bias[co];
+            }
+        }
+        float *op = a.out + (int64_t)b * a.out_bs + pix;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cog * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (live && co < a.Cout) op[(int64_t)co * HW] = acc[t][r] + add[r];
+        }
+    }
+}
+
 // ---- coupling transformation (one work-group per sample) ---------------------------------------------------------
 __device__ inline float block_sum_256(float v, float *sh) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -283,8 +445,15 @@ using namespace dpk;
 
 extern "C" {
 
-int64_t dpk_conv2d_pack_floats(int32_t Cout, int32_t Cin, int32_t ks) {
+// packed table = the [ci][tap][CoutPad] table of the vector-ALU kernel, then the fragment-ordered table of the MFMA kernel
+static int64_t conv_valu_floats(int32_t Cout, int32_t Cin, int32_t ks) {
     return (int64_t)Cin * ks * ks * align_up(Cout, kConvCO);
+}
+static int64_t conv_frag_floats(int32_t Cout, int32_t Cin, int32_t ks) {
+    return (int64_t)cdiv(Cout, 32) * ((Cin + 1) / 2) * ks * ks * 64;
+}
+int64_t dpk_conv2d_pack_floats(int32_t Cout, int32_t Cin, int32_t ks) {
+    return conv_valu_floats(Cout, Cin, ks) + conv_frag_floats(Cout, Cin, ks);
 }
 
 int dpk_conv2d_prepare(const float *weight_v, const float *weight_g, int32_t Cout, int32_t Cin, int32_t ks,
@@ -299,6 +468,10 @@ int dpk_conv2d_prepare(const float *weight_v, const float *weight_g, int32_t Cou
     DPK_LAUNCH(conv2d_prepare_kernel, dim3(CoutPad + (bn ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, weight_v, weight_g,
                Cout, CoutPad, Cin, ks * ks, bn_weight, bn_bias, bn_mean, bn_var, bn_eps, wpack, pre);
     DPK_CHECK_LAUNCH("conv2d_prepare_kernel");
+    const int64_t nf = conv_frag_floats(Cout, Cin, ks);
+    DPK_LAUNCH(conv2d_frag_kernel, dim3((unsigned)cdiv(nf, 256)), dim3(256), 0, (hipStream_t)stream, wpack, Cout, CoutPad, Cin,
+               ks * ks, wpack + conv_valu_floats(Cout, Cin, ks), nf);
+    DPK_CHECK_LAUNCH("conv2d_frag_kernel");
     return DPK_OK;
 }
 
@@ -325,6 +498,26 @@ int dpk_conv2d_forward(const float *in, int64_t in_bstride, int64_t B, int32_t C
     const dim3 grid((unsigned)cdiv(threads, 256), (unsigned)(a.CoutPad / kConvCO));
     hipStream_t st = (hipStream_t)stream;
     const dim3 blk(256);
+    // matrix-core kernel: the unmasked 1x1 convolutions with enough input channels to fill the k-steps (skip / transition /
+    // layers of >= 16 output channels: one pass over the activations for all 32 output channels, 278 against 351 us at 4096 x 32 x 28 x 28).
+    // For 3x3 it is measured SLOWER than the vector-ALU kernel (1156 against 967 us): its nine per-tap operand
+    // loads per MFMA pair do not overlap with the MFMAs; DPK_CONV_MFMA3=1 selects it anyway, DPK_CONV_VALU=1 never uses it
+    static const bool force_valu = getenv("DPK_CONV_VALU") != nullptr && getenv("DPK_CONV_VALU")[0] == '1';
+    static const bool mfma3 = getenv("DPK_CONV_MFMA3") != nullptr && getenv("DPK_CONV_MFMA3")[0] == '1';
+    if (!in_mask && Cin >= 8 && Cout >= 16 && !force_valu && (ks == 1 || mfma3) && B * H * W < INT32_MAX) {
+        const float *wfrag = wpack + conv_valu_floats(Cout, Cin, ks);
+        const int64_t slots = B * H * W;
+        const dim3 mgrid((unsigned)cdiv(slots, 4 * 32 * kMfmaTiles), (unsigned)cdiv(Cout, 32));
+        if (ks == 3) {
+            if (pre) DPK_LAUNCH((conv2d_mfma_kernel<3, true>), mgrid, blk, 0, st, a, wfrag);
+            else DPK_LAUNCH((conv2d_mfma_kernel<3, false>), mgrid, blk, 0, st, a, wfrag);
+        } else {
+            if (pre) DPK_LAUNCH((conv2d_mfma_kernel<1, true>), mgrid, blk, 0, st, a, wfrag);
+            else DPK_LAUNCH((conv2d_mfma_kernel<1, false>), mgrid, blk, 0, st, a, wfrag);
+        }
+        DPK_CHECK_LAUNCH("conv2d_mfma_kernel");
+        return DPK_OK;
+    }
 #define DPK_CONV_CASE(KS_, PRE_, MASK_) DPK_LAUNCH((conv2d_kernel<KS_, PRE_, MASK_>), grid, blk, 0, st, a)
     if (ks == 3) {
         if (pre && in_mask) DPK_CONV_CASE(3, true, true);
