@@ -339,6 +339,49 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
     m_flow = m
     del xs
 
+    # ---- RealNVP-2D (constructor defaults on MNIST-shaped input), evaluation, B = 2048 ---------------
+    from tests.util import flow2d_model
+    from oracle import flows2d_oracle as f2orc
+    B = 2048
+    feats = (1, 28, 28)
+    m = flow2d_model(feats, dict(n_flows=1, n_blocks=2, channels=32, network='resnet', affine=True), 25)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    flops = 0          # 2 * Cout * Cin * k^2 * H * W per convolution at the resolution of its coupling
+    for mod in m.modules():
+        if type(mod).__name__ == 'CouplingLayer2d':
+            hw = mod.in_features[1] * mod.in_features[2]
+            for q in mod.network.modules():
+                if type(q).__name__ == '_WeightNormConvParameters':
+                    flops += 2 * q.out_channels * q.in_channels * q.kernel_size ** 2 * hw
+    m.to(dev)
+    xs = [torch.randn((B,) + feats, device=dev) for _ in range(2)]
+    with torch.no_grad():
+        for i in range(2):
+            m(xs[i % 2])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(8):
+            m(xs[i % 2])
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 8
+    xc = torch.randn((256,) + feats)
+    rate, dt = _oracle_rate(lambda a, b: f2orc.log_prob(sd, xc[a:b]), 256, 128, threads)
+    tf = B * flops / (ms * 1e-3) / 1e12
+    out.append({'workload': 'RealNVP2d((1,28,28), n_flows=1, n_blocks=2, channels=32, resnet, affine) forward '
+                            'log-likelihood (evaluation only)',
+                'config': 'SURVEY 8f-3', 'batch': B, 'ms_per_step': ms, 'value': B / ms * 1e3,
+                'unit': 'log-likelihoods/sec',
+                'kernel': 'conv2d_kernel<3> (3x3 conditioner convolutions, packed fp32 FMAs; > 75 % of the step)',
+                'roofline': {'bound': 'mfma', 'achieved': tf, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': tf / 157.3,
+                             'traffic': None},
+                'roofline_basis': 'whole step: {:.1f} MFLOP of convolutions per sample as written / step time, against the '
+                                  'fp32 matrix = packed fp32 vector peak'.format(flops / 1e6),
+                'cpu_baseline': {'value': rate, 'unit': 'log-likelihoods/sec', 'cores': threads, 'kind': 'port',
+                                 'sample': '256 samples ({:.1f} s), oracle/flows2d_oracle.py'.format(dt)}})
+    del xs, m
+
     # ---- forward + backward + Adam, B = 512 (SURVEY 8d "also report fwd+bwd step/s") ------------------------------
     B = 512
     torch.manual_seed(0)
