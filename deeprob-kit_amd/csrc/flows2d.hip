@@ -12,6 +12,8 @@
 // of 32 channels on 28x28 against 200 KB of activations), so no LDS staging is needed to stay off the HBM roof.
 #include "common.h"
 #include <stdlib.h>
+#include <algorithm>
+#include <type_traits>
 
 namespace dpk {
 
@@ -350,6 +352,188 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(Conv2dArgs a, const fl
     }
 }
 
+// ---- 3x3 convolution on the matrix cores, activations staged through LDS ------------------------------------------------
+// A work-group owns G consecutive samples (G * H * W <= 896 pixels) and 32 output channels.  The input is staged 4 channels
+// at a time into zero-bordered (H+2) x (W+2) planes in LDS -- each activation is fetched, normalised and rectified ONCE (the
+// per-tap global loads of conv2d_mfma_kernel<3> fetch it nine times and do not overlap with the MFMAs) and the zero padding
+// is the border, not a mask -- two buffers: the next 4 channels travel global -> registers while the MFMAs of the current 4
+// run, and are written to the other buffer afterwards.  MFMA operands: lane l reads its pixel of channel 2*jp + (l >> 5) at
+// the tap's constant offset (ds_read_b32, one per MFMA and tile, requested one tap ahead); weights as in conv2d_mfma_kernel.
+// A wave holds up to 7 tiles of 32 pixels (112 accumulator registers); tiles are dealt round-robin to the 4 waves.
+constexpr int kLdsCC = 4;        // channels per staged chunk
+constexpr int kLdsTW = 7;        // tiles per wave at most
+constexpr int kLdsPix = 896;     // pixels per work-group at most (28 tiles)
+
+struct ConvLdsGeom {
+    int G, plane, NP;            // samples per work-group, floats per padded plane, G * H * W
+};
+
+template <bool PRE>
+__global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(Conv2dArgs a, const float *__restrict__ wfrag, ConvLdsGeom q) {
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int HW = a.H * a.W, PW = a.W + 2;
+    const int b0 = blockIdx.x * q.G;
+    const int nb = min(q.G, a.B - b0);
+    const int npv = nb * HW;                      // live pixels of this work-group
+    const int cog = blockIdx.y;
+    const int nJ = (a.Cin + 1) / 2;
+    const int nchunk = (a.Cin + kLdsCC - 1) / kLdsCC;
+    const int chunk_floats = kLdsCC * q.G * q.plane;
+    const int ntile = (npv + 31) / 32;
+    const int TW = (ntile + 3) / 4;               // tiles of this wave: wave + 4 * t
+
+    // zero both buffers once: the borders stay zero for the whole kernel
+    for (int i = tid; i < 2 * chunk_floats; i += 256) lds[i] = 0.f;
+
+    // staging roles: pixel slots tid + 256 * k
+    int goff[4], loff[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p = tid + 256 * k;
+        const int pc = min(p, npv - 1);
+        const int g = pc / HW, pix = pc - g * HW;
+        const int y = pix / a.W, x = pix - y * a.W;
+        goff[k] = p < npv ? (int)(g * a.in_bs) + pix : -1;      // (the entry point keeps G * in_bstride below 2^31)
+        loff[k] = g * q.plane + (y + 1) * PW + (x + 1);
+    }
+    const float *inb = a.in + (int64_t)b0 * a.in_bs;
+    float stg[kLdsCC][4];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int ch = 0; ch < kLdsCC; ++ch) {
+            const int ci = min(c * kLdsCC + ch, a.Cin - 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) stg[ch][k] = inb[(int64_t)ci * HW + max(goff[k], 0)];
+        }
+    };
+    auto stash = [&](int c, float *buf) {
+#pragma unroll
+        for (int ch = 0; ch < kLdsCC; ++ch) {
+            const int ci = c * kLdsCC + ch;
+            const bool real = ci < a.Cin;
+            float pa = 1.f, pb = 0.f;
+            if (PRE && real) {
+                pa = a.pre[ci];
+                pb = a.pre[a.Cin + ci];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float r = stg[ch][k];
+                if (PRE) r = fmaxf(fmaf(r, pa, pb), 0.f);
+                if (goff[k] >= 0) buf[ch * q.G * q.plane + loff[k]] = real ? r : 0.f;
+            }
+        }
+    };
+
+    // MFMA roles
+    int lbase[kLdsTW];
+#pragma unroll
+    for (int t = 0; t < kLdsTW; ++t) {
+        const int p = min((wave + 4 * t) * 32 + col, npv - 1);
+        const int g = p / HW, pix = p - g * HW;
+        const int y = pix / a.W, x = pix - y * a.W;
+        lbase[t] = half * q.G * q.plane + g * q.plane + (y + 1) * PW + (x + 1);
+    }
+    const float *wf = wfrag + (int64_t)cog * nJ * 9 * 64 + lane;
+
+    f32x16_t acc[kLdsTW];
+#pragma unroll
+    for (int t = 0; t < kLdsTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    float wc[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) wc[tap] = wf[tap * 64];
+    fetch(0);
+    __syncthreads();                              // zero fill done
+    stash(0, lds);
+    __syncthreads();
+
+    for (int c = 0; c < nchunk; ++c) {
+        const float *cur = lds + (c & 1) * chunk_floats;
+        if (c + 1 < nchunk) fetch(c + 1);
+        const int njp = min(kLdsCC / 2, nJ - c * (kLdsCC / 2));
+        // k-steps of this chunk: (jp, tap).  The LDS operands of the next tap are requested before the MFMAs of this one;
+        // the nine weight fragments of the next channel pair (an L2 round trip: longer than one tap's MFMAs) before the
+        // nine taps of this pair
+        float xa[2][kLdsTW];
+        auto request = [&](int set, int jp, int tap) {
+            const int so = 2 * jp * q.G * q.plane + (tap / 3 - 1) * PW + (tap % 3 - 1);
+#pragma unroll
+            for (int t = 0; t < kLdsTW; ++t)
+                if (t < TW) xa[set][t] = cur[lbase[t] + so];
+        };
+        request(0, 0, 0);
+        // (nine taps per pair: the operand set of a tap is (tap + PAR) & 1 with PAR alternating between pairs)
+        auto pair = [&](auto par, int jp) {
+            constexpr int PAR = decltype(par)::value;
+            const int jg = c * (kLdsCC / 2) + jp;
+            const int jn = min(jg + 1, nJ - 1);
+            float wn[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) wn[tap] = wf[((int64_t)jn * 9 + tap) * 64];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (tap < 8) request((tap + 1 + PAR) & 1, jp, tap + 1);
+                else if (jp + 1 < njp) request((tap + 1 + PAR) & 1, jp + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < kLdsTW; ++t)
+                    if (t < TW)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[tap], xa[(tap + PAR) & 1][t], acc[t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) wc[tap] = wn[tap];
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int jp = 0; jp < njp; jp += 2) {
+            pair(std::integral_constant<int, 0>{}, jp);
+            if (jp + 1 < njp) pair(std::integral_constant<int, 1>{}, jp + 1);
+        }
+        if (c + 1 < nchunk) stash(c + 1, lds + ((c + 1) & 1) * chunk_floats);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int t = 0; t < kLdsTW; ++t) {
+        if (t >= TW) break;
+        const int p = (wave + 4 * t) * 32 + col;
+        const bool live = p < npv;
+        const int pc = min(p, npv - 1);
+        const int g = pc / HW, pix = pc - g * HW;
+        const int b = b0 + g;
+        float add[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) add[r] = 0.f;
+        if (a.res) {
+            const float *rp = a.res + (int64_t)b * a.res_bs + pix;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = min(cog * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1);
+                add[r] = rp[(int64_t)co * HW];
+            }
+        }
+        if (a.bias) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = min(cog * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1);
+                add[r] += a.bias[co];
+            }
+        }
+        float *op = a.out + (int64_t)b * a.out_bs + pix;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cog * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (live && co < a.Cout) op[(int64_t)co * HW] = acc[t][r] + add[r];
+        }
+    }
+}
+
 // ---- coupling transformation (one work-group per sample) ---------------------------------------------------------
 __device__ inline float block_sum_256(float v, float *sh) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -504,6 +688,33 @@ int dpk_conv2d_forward(const float *in, int64_t in_bstride, int64_t B, int32_t C
     // loads per MFMA pair do not overlap with the MFMAs; DPK_CONV_MFMA3=1 selects it anyway, DPK_CONV_VALU=1 never uses it
     static const bool force_valu = getenv("DPK_CONV_VALU") != nullptr && getenv("DPK_CONV_VALU")[0] == '1';
     static const bool mfma3 = getenv("DPK_CONV_MFMA3") != nullptr && getenv("DPK_CONV_MFMA3")[0] == '1';
+    // 3x3 with the activations staged through LDS (images of at most 1024 pixels; DPK_CONV_LDS=0 switches it off)
+    static const bool no_lds = getenv("DPK_CONV_LDS") != nullptr && getenv("DPK_CONV_LDS")[0] == '0';
+    if (!in_mask && ks == 3 && Cin >= 8 && Cout >= 16 && !force_valu && !mfma3 && !no_lds && H * W <= kLdsPix &&
+        B < INT32_MAX / 2) {
+        ConvLdsGeom q;
+        q.plane = (H + 2) * (W + 2);
+        q.G = (int)std::max<int64_t>(1, std::min<int64_t>(kLdsPix / (H * W), 1024 / q.plane));
+        q.G = (int)std::min<int64_t>(q.G, B);
+        q.NP = q.G * H * W;
+        if ((int64_t)q.G * in_bstride < INT32_MAX) {
+            const size_t lds_bytes = (size_t)2 * kLdsCC * q.G * q.plane * sizeof(float);
+            const float *wfrag = wpack + conv_valu_floats(Cout, Cin, ks);
+            const dim3 lgrid((unsigned)cdiv(B, q.G), (unsigned)cdiv(Cout, 32));
+            static bool attr_done = false;
+            if (!attr_done) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_lds_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_lds_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                attr_done = true;
+            }
+            if (pre) DPK_LAUNCH((conv3x3_lds_kernel<true>), lgrid, blk, lds_bytes, st, a, wfrag, q);
+            else DPK_LAUNCH((conv3x3_lds_kernel<false>), lgrid, blk, lds_bytes, st, a, wfrag, q);
+            DPK_CHECK_LAUNCH("conv3x3_lds_kernel");
+            return DPK_OK;
+        }
+    }
     if (!in_mask && Cin >= 8 && Cout >= 16 && !force_valu && (ks == 1 || mfma3) && B * H * W < INT32_MAX) {
         const float *wfrag = wpack + conv_valu_floats(Cout, Cin, ks);
         const int64_t slots = B * H * W;
