@@ -463,8 +463,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(Conv2dArgs a, const
         auto request = [&](int set, int jp, int tap) {
             const int so = 2 * jp * q.G * q.plane + (tap / 3 - 1) * PW + (tap % 3 - 1);
 #pragma unroll
-            for (int t = 0; t < kLdsTW; ++t)
-                if (t < TW) xa[set][t] = cur[lbase[t] + so];
+            for (int t = 0; t < kLdsTW; ++t) xa[set][t] = cur[lbase[t] + so];
         };
         request(0, 0, 0);
         // (nine taps per pair: the operand set of a tap is (tap + PAR) & 1 with PAR alternating between pairs)
@@ -482,9 +481,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(Conv2dArgs a, const
                 else if (jp + 1 < njp) request((tap + 1 + PAR) & 1, jp + 1, 0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < kLdsTW; ++t)
-                    if (t < TW)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[tap], xa[(tap + PAR) & 1][t], acc[t], 0, 0, 0);
+                for (int t = 0; t < kLdsTW; ++t)   // (every wave runs all 7 tiles: straight-line code, exact wait counts;
+                    // tiles past the work-group's pixels compute on a clamped pixel and are not stored)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[tap], xa[(tap + PAR) & 1][t], acc[t], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -694,7 +693,7 @@ int dpk_conv2d_forward(const float *in, int64_t in_bstride, int64_t B, int32_t C
         B < INT32_MAX / 2) {
         ConvLdsGeom q;
         q.plane = (H + 2) * (W + 2);
-        q.G = (int)std::max<int64_t>(1, std::min<int64_t>(kLdsPix / (H * W), 1024 / q.plane));
+        q.G = (int)std::max<int64_t>(1, std::min<int64_t>(kLdsPix / (H * W), 2048 / q.plane));
         q.G = (int)std::min<int64_t>(q.G, B);
         q.NP = q.G * H * W;
         if ((int64_t)q.G * in_bstride < INT32_MAX) {
