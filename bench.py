@@ -373,7 +373,7 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
                             'log-likelihood (evaluation only)',
                 'config': 'SURVEY 8f-3', 'batch': B, 'ms_per_step': ms, 'value': B / ms * 1e3,
                 'unit': 'log-likelihoods/sec',
-                'kernel': 'conv2d_kernel<3> (3x3 conditioner convolutions, packed fp32 FMAs; > 75 % of the step)',
+                'kernel': 'conv3x3_lds_kernel (3x3 conditioner convolutions on fp32 MFMA, activations staged through LDS; ~70 % of the step)',
                 'roofline': {'bound': 'mfma', 'achieved': tf, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': tf / 157.3,
                              'traffic': None},
                 'roofline_basis': 'whole step: {:.1f} MFLOP of convolutions per sample as written / step time, against the '

@@ -5,11 +5,11 @@
 //              flows/layers/resnet.py:9-90, flows/layers/densenet.py, torch/utils.py:86-121 (WeightNormConv2d),
 //              flows/utils.py:11-38 (squeeze), :165-222 (BatchNormLayer2d), flows/models/realnvp.py:75-220 (RealNVP2d)
 //
-// Convolution kernel: fp32 on the vector ALUs.  A thread owns 4 consecutive pixels of one output row and CO = 16 output
-// channels (64 accumulators); the weights of a (input channel, tap) are 16 consecutive floats of the packed table and
-// are wave-uniform, so they arrive through the scalar unit (s_load_dwordx16) and feed v_fma as SGPR operands: per input
-// channel a thread issues 18 loads for 576 FMAs.  The conditioners are compute-bound (14.4 MFLOP per 3x3 convolution
-// of 32 channels on 28x28 against 200 KB of activations), so no LDS staging is needed to stay off the HBM roof.
+// Convolutions, fp32 throughout (the 1e-5 parity bar): 3x3 layers on v_mfma_f32_32x32x2_f32 with the activations staged
+// through LDS (conv3x3_lds_kernel), 1x1 layers on the same MFMA with operands from global memory (conv2d_mfma_kernel),
+// masked / narrow layers on the vector ALUs (conv2d_kernel: a thread owns 4 pixels x 16 output channels, wave-uniform
+// weights arrive through the scalar unit and feed v_pk_fma_f32 as SGPR pairs).  The conditioners are compute-bound
+// (14.4 MFLOP per 3x3 convolution of 32 channels on 28x28 against 300 KB of activation traffic).
 #include "common.h"
 #include <stdlib.h>
 #include <algorithm>
