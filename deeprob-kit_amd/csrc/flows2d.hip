@@ -361,15 +361,15 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(Conv2dArgs a, const fl
 // the tap's constant offset (ds_read_b32, one per MFMA and tile, requested one tap ahead); weights as in conv2d_mfma_kernel.
 // A wave holds up to 7 tiles of 32 pixels (112 accumulator registers); tiles are dealt round-robin to the 4 waves.
 constexpr int kLdsCC = 4;        // channels per staged chunk
-constexpr int kLdsTW = 7;        // tiles per wave at most
 constexpr int kLdsPix = 896;     // pixels per work-group at most (28 tiles)
 
 struct ConvLdsGeom {
     int G, plane, NP;            // samples per work-group, floats per padded plane, G * H * W
 };
 
-template <bool PRE>
-__global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(Conv2dArgs a, const float *__restrict__ wfrag, ConvLdsGeom q) {
+// NW waves per work-group, TW tiles per wave (tile = wave + NW * t): (4, 7) covers 896 pixels, (4, 6) 24 tiles
+template <bool PRE, int NW, int TW>
+__global__ __launch_bounds__(NW * 64, NW > 4 ? 3 : 2) void conv3x3_lds_kernel(Conv2dArgs a, const float *__restrict__ wfrag, ConvLdsGeom q) {
     extern __shared__ float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col = lane & 31;
@@ -381,17 +381,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(Conv2dArgs a, const
     const int nJ = (a.Cin + 1) / 2;
     const int nchunk = (a.Cin + kLdsCC - 1) / kLdsCC;
     const int chunk_floats = kLdsCC * q.G * q.plane;
-    const int ntile = (npv + 31) / 32;
-    const int TW = (ntile + 3) / 4;               // tiles of this wave: wave + 4 * t
+    constexpr int NT = NW * 64, NS = (kLdsPix + NT - 1) / NT;   // threads, staged pixel slots per thread
 
     // zero both buffers once: the borders stay zero for the whole kernel
-    for (int i = tid; i < 2 * chunk_floats; i += 256) lds[i] = 0.f;
+    for (int i = tid; i < 2 * chunk_floats; i += NT) lds[i] = 0.f;
 
-    // staging roles: pixel slots tid + 256 * k
-    int goff[4], loff[4];
+    // staging roles: pixel slots tid + NT * k
+    int goff[NS], loff[NS];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int p = tid + 256 * k;
+    for (int k = 0; k < NS; ++k) {
+        const int p = tid + NT * k;
         const int pc = min(p, npv - 1);
         const int g = pc / HW, pix = pc - g * HW;
         const int y = pix / a.W, x = pix - y * a.W;
@@ -399,13 +398,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(Conv2dArgs a, const
         loff[k] = g * q.plane + (y + 1) * PW + (x + 1);
     }
     const float *inb = a.in + (int64_t)b0 * a.in_bs;
-    float stg[kLdsCC][4];
+    float stg[kLdsCC][NS];
     auto fetch = [&](int c) {
 #pragma unroll
         for (int ch = 0; ch < kLdsCC; ++ch) {
             const int ci = min(c * kLdsCC + ch, a.Cin - 1);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) stg[ch][k] = inb[(int64_t)ci * HW + max(goff[k], 0)];
+            for (int k = 0; k < NS; ++k) stg[ch][k] = inb[(int64_t)ci * HW + max(goff[k], 0)];
         }
     };
     auto stash = [&](int c, float *buf) {
@@ -419,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(Conv2dArgs a, const
                 pb = a.pre[a.Cin + ci];
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < NS; ++k) {
                 float r = stg[ch][k];
                 if (PRE) r = fmaxf(fmaf(r, pa, pb), 0.f);
                 if (goff[k] >= 0) buf[ch * q.G * q.plane + loff[k]] = real ? r : 0.f;
@@ -428,19 +427,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(Conv2dArgs a, const
     };
 
     // MFMA roles
-    int lbase[kLdsTW];
+    int lbase[TW];
 #pragma unroll
-    for (int t = 0; t < kLdsTW; ++t) {
-        const int p = min((wave + 4 * t) * 32 + col, npv - 1);
+    for (int t = 0; t < TW; ++t) {
+        const int p = min((wave + NW * t) * 32 + col, npv - 1);
         const int g = p / HW, pix = p - g * HW;
         const int y = pix / a.W, x = pix - y * a.W;
         lbase[t] = half * q.G * q.plane + g * q.plane + (y + 1) * PW + (x + 1);
     }
     const float *wf = wfrag + (int64_t)cog * nJ * 9 * 64 + lane;
 
-    f32x16_t acc[kLdsTW];
+    f32x16_t acc[TW];
 #pragma unroll
-    for (int t = 0; t < kLdsTW; ++t)
+    for (int t = 0; t < TW; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -459,11 +458,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(Conv2dArgs a, const
         // k-steps of this chunk: (jp, tap).  The LDS operands of the next tap are requested before the MFMAs of this one;
         // the nine weight fragments of the next channel pair (an L2 round trip: longer than one tap's MFMAs) before the
         // nine taps of this pair
-        float xa[2][kLdsTW];
+        float xa[2][TW];
         auto request = [&](int set, int jp, int tap) {
             const int so = 2 * jp * q.G * q.plane + (tap / 3 - 1) * PW + (tap % 3 - 1);
 #pragma unroll
-            for (int t = 0; t < kLdsTW; ++t) xa[set][t] = cur[lbase[t] + so];
+            for (int t = 0; t < TW; ++t) xa[set][t] = cur[lbase[t] + so];
         };
         request(0, 0, 0);
         // (nine taps per pair: the operand set of a tap is (tap + PAR) & 1 with PAR alternating between pairs)
@@ -481,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(Conv2dArgs a, const
                 else if (jp + 1 < njp) request((tap + 1 + PAR) & 1, jp + 1, 0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < kLdsTW; ++t)   // (every wave runs all 7 tiles: straight-line code, exact wait counts;
+                for (int t = 0; t < TW; ++t)   // (every wave runs all 7 tiles: straight-line code, exact wait counts;
                     // tiles past the work-group's pixels compute on a clamped pixel and are not stored)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[tap], xa[(tap + PAR) & 1][t], acc[t], 0, 0, 0);
             }
@@ -499,9 +498,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(Conv2dArgs a, const
     }
 
 #pragma unroll
-    for (int t = 0; t < kLdsTW; ++t) {
-        if (t >= TW) break;
-        const int p = (wave + 4 * t) * 32 + col;
+    for (int t = 0; t < TW; ++t) {
+        const int p = (wave + NW * t) * 32 + col;
         const bool live = p < npv;
         const int pc = min(p, npv - 1);
         const int g = pc / HW, pix = pc - g * HW;
@@ -700,16 +698,15 @@ int dpk_conv2d_forward(const float *in, int64_t in_bstride, int64_t B, int32_t C
             const size_t lds_bytes = (size_t)2 * kLdsCC * q.G * q.plane * sizeof(float);
             const float *wfrag = wpack + conv_valu_floats(Cout, Cin, ks);
             const dim3 lgrid((unsigned)cdiv(B, q.G), (unsigned)cdiv(Cout, 32));
-            static bool attr_done = false;
-            if (!attr_done) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_lds_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_lds_kernel<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                attr_done = true;
+            const int ntile = cdiv((int64_t)q.NP, 32);
+#define DPK_LDS_CASE(PRE_, NW_, TW_) \
+    DPK_LAUNCH((conv3x3_lds_kernel<PRE_, NW_, TW_>), lgrid, dim3(NW_ * 64), lds_bytes, st, a, wfrag, q)
+            if (ntile <= 24) {
+                if (pre) DPK_LDS_CASE(true, 4, 6); else DPK_LDS_CASE(false, 4, 6);
+            } else {   // (25 tiles on 5 waves x 5 tiles -- no padded tile -- measured 910 against 645 us: uneven SIMD load)
+                if (pre) DPK_LDS_CASE(true, 4, 7); else DPK_LDS_CASE(false, 4, 7);
             }
-            if (pre) DPK_LAUNCH((conv3x3_lds_kernel<true>), lgrid, blk, lds_bytes, st, a, wfrag, q);
-            else DPK_LAUNCH((conv3x3_lds_kernel<false>), lgrid, blk, lds_bytes, st, a, wfrag, q);
+#undef DPK_LDS_CASE
             DPK_CHECK_LAUNCH("conv3x3_lds_kernel");
             return DPK_OK;
         }
