@@ -16,7 +16,7 @@ from tests.conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
-FAMILIES = ('ratspn', 'ratspn_wide', 'dgcspn', 'realnvp1d')
+FAMILIES = ('ratspn', 'ratspn_wide', 'dgcspn', 'realnvp1d', 'realnvp2d')
 BATCHES = (257, 64, 1000, 33)
 
 
@@ -45,6 +45,12 @@ def _family(kind):
         sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
         plan = plan_of(name)
         return model, (3, 8, 8), lambda x: dorc.dgcspn_forward(sd, x, plan).detach()
+    if kind == 'realnvp2d':
+        from oracle import flows2d_oracle as f2orc
+        from tests.util import flow2d_model
+        model = flow2d_model((3, 8, 8), dict(n_flows=1, n_blocks=1, channels=16), 31)
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        return model, (3, 8, 8), lambda x: f2orc.log_prob(sd, x).detach()
     from tests.flow_cases import build_flow
     name = 'realnvp1d_15'
     model = build_flow(name, load_golden(name))
