@@ -353,21 +353,21 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(Conv2dArgs a, const fl
 }
 
 // ---- 3x3 convolution on the matrix cores, activations staged through LDS ------------------------------------------------
-// A work-group owns G consecutive samples (G * H * W <= 896 pixels) and 32 output channels.  The input is staged 4 channels
+// A work-group owns G consecutive samples (G * H * W <= 1024 pixels) and 32 output channels.  The input is staged 4 channels
 // at a time into zero-bordered (H+2) x (W+2) planes in LDS -- each activation is fetched, normalised and rectified ONCE (the
 // per-tap global loads of conv2d_mfma_kernel<3> fetch it nine times and do not overlap with the MFMAs) and the zero padding
 // is the border, not a mask -- two buffers: the next 4 channels travel global -> registers while the MFMAs of the current 4
 // run, and are written to the other buffer afterwards.  MFMA operands: lane l reads its pixel of channel 2*jp + (l >> 5) at
 // the tap's constant offset (ds_read_b32, one per MFMA and tile, requested one tap ahead); weights as in conv2d_mfma_kernel.
-// A wave holds up to 7 tiles of 32 pixels (112 accumulator registers); tiles are dealt round-robin to the 4 waves.
+// A wave holds up to 8 tiles of 32 pixels (128 accumulator registers); tiles are dealt round-robin to the 4 waves.
 constexpr int kLdsCC = 4;        // channels per staged chunk
-constexpr int kLdsPix = 896;     // pixels per work-group at most (28 tiles)
+constexpr int kLdsPix = 1024;    // pixels per work-group at most (32 tiles)
 
 struct ConvLdsGeom {
     int G, plane, NP;            // samples per work-group, floats per padded plane, G * H * W
 };
 
-// NW waves per work-group, TW tiles per wave (tile = wave + NW * t): (4, 7) covers 896 pixels, (4, 6) 24 tiles
+// NW waves per work-group, TW tiles per wave (tile = wave + NW * t): (4, 8) covers 1024 pixels (32x32; five 14x14 samples = 31 tiles), (4, 7) 28 tiles (28x28: 25), (4, 6) 24 tiles
 template <bool PRE, int NW, int TW>
 __global__ __launch_bounds__(NW * 64, NW > 4 ? 3 : 2) void conv3x3_lds_kernel(Conv2dArgs a, const float *__restrict__ wfrag, ConvLdsGeom q) {
     extern __shared__ float lds[];
@@ -703,8 +703,11 @@ int dpk_conv2d_forward(const float *in, int64_t in_bstride, int64_t B, int32_t C
     DPK_LAUNCH((conv3x3_lds_kernel<PRE_, NW_, TW_>), lgrid, dim3(NW_ * 64), lds_bytes, st, a, wfrag, q)
             if (ntile <= 24) {
                 if (pre) DPK_LDS_CASE(true, 4, 6); else DPK_LDS_CASE(false, 4, 6);
-            } else {   // (25 tiles on 5 waves x 5 tiles -- no padded tile -- measured 910 against 645 us: uneven SIMD load)
+            } else if (ntile <= 28) {   // (25 tiles on 5 waves x 5 tiles -- no padded tile -- measured 910 against 645 us:
+                // uneven SIMD load)
                 if (pre) DPK_LDS_CASE(true, 4, 7); else DPK_LDS_CASE(false, 4, 7);
+            } else {
+                if (pre) DPK_LDS_CASE(true, 4, 8); else DPK_LDS_CASE(false, 4, 8);
             }
 #undef DPK_LDS_CASE
             DPK_CHECK_LAUNCH("conv3x3_lds_kernel");

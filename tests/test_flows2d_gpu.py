@@ -41,6 +41,7 @@ def test_log_prob_and_latents_golden(golden, case):
     ((1, 28, 28), dict(n_flows=1, n_blocks=1, channels=24, network='densenet', affine=False), 11),
     ((4, 16, 16), dict(n_flows=3, n_blocks=1, channels=6, network='resnet'), 1),
     ((2, 10, 10), dict(n_flows=1, n_blocks=1, channels=19, network='resnet'), 23),   # odd channel counts on the LDS / MFMA kernels, ragged last work-group
+    ((3, 32, 32), dict(n_flows=1, n_blocks=1, channels=16, network='resnet'), 3),     # 1024 pixels: 8 tiles per wave; 16x16 after the squeeze
     ((1, 30, 28), dict(n_flows=1, n_blocks=1, channels=16, network='resnet'), 3),     # 840 pixels: one sample per work-group, 27 tiles
 ])
 def test_against_oracle(feats, kw, batch):
