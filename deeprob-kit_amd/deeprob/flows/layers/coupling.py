@@ -145,7 +145,9 @@ class CouplingLayer2d(Bijector):
     def transform(self, x: torch.Tensor, inverse: bool, ldj: Optional[torch.Tensor] = None):
         """Both directions; `ldj` [B] is an accumulator the layer's log-det-Jacobian is added to."""
         from deeprob.hip import ops_flows2d
-        ops_flows2d.require_eval(self, 'CouplingLayer2d', x)
+        graph = ops_flows2d.graph_route(x, self)
+        if graph and inverse:
+            ops_flows2d.require_eval(self, 'CouplingLayer2d', x)
         x = ops_flows2d._image(x, 'x')
         if tuple(x.shape[1:]) != tuple(self.in_features):
             raise HipError("CouplingLayer2d: input {} does not match in_features {}".format(tuple(x.shape[1:]),
@@ -156,6 +158,10 @@ class CouplingLayer2d(Bijector):
             z = self.network(mx)
         else:
             z = self.network(x, in_mask=self.mask)
+        if graph:
+            from deeprob.hip import ops_flows2d_train
+            u, d = ops_flows2d_train.coupling2d(x, z, self)
+            return u, (d if ldj is None else ldj + d)
         return ops_flows2d.coupling2d(x, z, self, inverse, ldj)
 
     def apply_backward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -204,7 +210,8 @@ class CouplingBlock2d(Bijector):
 
     def transform(self, x: torch.Tensor, inverse: bool, ldj: Optional[torch.Tensor] = None):
         from deeprob.hip import ops_flows2d
-        ops_flows2d.require_eval(self, 'CouplingBlock2d', x)
+        if inverse:
+            ops_flows2d.require_eval(self, 'CouplingBlock2d', x)
         table = None if self.last_block else ops_flows2d.squeeze_table(self.in_channels, x.device)
         if not inverse:
             for layer in self.in_couplings:

@@ -35,7 +35,6 @@ class DenseLayer(nn.Module):
         return ops_flows2d.conv2d(h, self.network[2], bn=self.network[0], out=out)
 
     def forward(self, inputs: List[torch.Tensor]) -> torch.Tensor:
-        ops_flows2d.require_eval(self, 'DenseLayer', *inputs)
         return self.evaluate(inputs[0] if len(inputs) == 1 else torch.cat(list(inputs), dim=1))
 
 
@@ -49,7 +48,12 @@ class DenseBlock(nn.Module):
             self.layers.append(DenseLayer(in_channels + i * out_channels, out_channels, use_checkpoint=use_checkpoint))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        ops_flows2d.require_eval(self, 'DenseBlock', x)
+        if ops_flows2d.graph_route(x, self):
+            # graph-building route: the concatenations are torch.cat nodes (deeprob/hip/ops_flows2d_train.py)
+            features = [x]
+            for layer in self.layers:
+                features.append(layer.evaluate(features[0] if len(features) == 1 else torch.cat(features, dim=1)))
+            return torch.cat(features, dim=1)
         B, C, H, W = x.shape
         total = C + len(self.layers) * self.out_channels
         buf = torch.empty((B, total, H, W), dtype=torch.float32, device=x.device)
@@ -71,7 +75,6 @@ class Transition(nn.Module):
         )
 
     def forward(self, x):
-        ops_flows2d.require_eval(self, 'Transition', x)
         return ops_flows2d.conv2d(x, self.network[2], bn=self.network[0])
 
 
@@ -90,7 +93,6 @@ class DenseNetwork(nn.Module):
                 self.blocks.append(Transition(5 * mid_channels, mid_channels, bias=False))
 
     def forward(self, x: torch.Tensor, in_mask=None) -> torch.Tensor:
-        ops_flows2d.require_eval(self, 'DenseNetwork', x)
         x = ops_flows2d.conv2d(x, self.in_conv, in_mask=in_mask)
         for block in self.blocks:
             x = block(x)

@@ -1,9 +1,10 @@
 """ResNet conditioner of the 2-D coupling layers behind the reference interface (deeprob/flows/layers/resnet.py:9-90).
 
 The modules keep the reference's structure (``nn.Sequential`` of BatchNorm2d / ReLU / WeightNormConv2d) so that
-``state_dict`` names match; evaluation does not call them one by one: every BatchNorm2d + ReLU is folded into the operand
+``state_dict`` names match; neither evaluation nor training calls them one by one: every BatchNorm2d + ReLU is folded into the operand
 load of the convolution that follows it and every residual / skip addition into the convolution that produces the
-addend (csrc/flows2d.hip), so a residual block is two launches and the network 3 + 3 * n_blocks.
+addend (csrc/flows2d.hip), so a residual block is two launches and the network 3 + 3 * n_blocks.  In training mode the
+same folded kernels run with the scale / shift vectors of the batch statistics (deeprob/hip/ops_flows2d_train.py).
 """
 import torch
 from torch import nn
@@ -26,7 +27,6 @@ class ResidualBlock(nn.Module):
         )
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        ops_flows2d.require_eval(self, 'ResidualBlock', x)
         h = ops_flows2d.conv2d(x, self.block[2], bn=self.block[0])
         return ops_flows2d.conv2d(h, self.block[5], bn=self.block[3], res=x)
 
@@ -55,7 +55,6 @@ class ResidualNetwork(nn.Module):
     def forward(self, x: torch.Tensor, in_mask=None) -> torch.Tensor:
         """`in_mask` [H, W]: evaluate the network on ``in_mask * x`` (the checkerboard coupling's masked input) without
         materialising the product."""
-        ops_flows2d.require_eval(self, 'ResidualNetwork', x)
         x = ops_flows2d.conv2d(x, self.in_conv, in_mask=in_mask)
         z = ops_flows2d.conv2d(x, self.in_skip)
         for block, skip in zip(self.blocks, self.skips):

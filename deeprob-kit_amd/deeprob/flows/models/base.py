@@ -106,6 +106,8 @@ class NormalizingFlow(ProbabilisticModel):
                 ll = ops_flows.normal_base_logprob(x.reshape(batch_size, -1), None, self.in_base_loc.reshape(-1),
                                                    self.in_base_scale.reshape(-1), acc, None)
                 return ll if acc is not None else ll + ildj
+            return ops_flows.NormalBaseFn.apply(x.reshape(batch_size, -1).contiguous(), self.in_base_loc.reshape(-1),
+                                                self.in_base_scale.reshape(-1)) + ildj
         base_lls = self.in_base.log_prob(x)
         return torch.sum(base_lls.view(batch_size, -1), dim=1) + ildj
 

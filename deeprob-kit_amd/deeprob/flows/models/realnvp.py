@@ -118,7 +118,6 @@ class RealNVP2d(NormalizingFlow):
         """data -> latent (reference :164-193): after every block but the last the tensor is down-scaled by the
         permutation and its second half of channels is set aside; the pieces are put back in reverse order."""
         from deeprob.hip import ops_flows2d
-        ops_flows2d.require_eval(self, 'RealNVP2d', x)
         ildj, slices = None, []
         last = len(self.layers) - 1
         for i, layer in enumerate(self.layers):

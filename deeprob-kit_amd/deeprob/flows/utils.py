@@ -19,14 +19,12 @@ from deeprob.hip import Workspace
 def squeeze_depth2d(x: torch.Tensor) -> torch.Tensor:
     """[N, C, H, W] -> [N, 4C, H/2, W/2], output channel c*4 + dy*2 + dx (reference :11-23)."""
     from deeprob.hip import ops_flows2d
-    ops_flows2d.require_eval(_EVAL, 'squeeze_depth2d', x)
     return ops_flows2d.space_to_depth(x, ops_flows2d.squeeze_table(x.shape[1], x.device))
 
 
 def unsqueeze_depth2d(x: torch.Tensor) -> torch.Tensor:
     """[N, 4C, H, W] -> [N, C, 2H, 2W], the inverse of :func:`squeeze_depth2d` (reference :26-38)."""
     from deeprob.hip import ops_flows2d
-    ops_flows2d.require_eval(_EVAL, 'unsqueeze_depth2d', x)
     return ops_flows2d.depth_to_space(x, ops_flows2d.squeeze_table(x.shape[1] // 4, x.device))
 
 
@@ -105,7 +103,7 @@ class BatchNormLayer1d(Bijector):
 class BatchNormLayer2d(Bijector):
     def __init__(self, in_features: int, momentum: float = 0.9, eps: float = 1e-5):
         """Per-channel batch normalisation as a bijector (reference :165-184): parameters `weight` (log-gain), `bias`,
-        buffers `running_var`, `running_mean`, all of shape [1, C, 1, 1].  Evaluation (running statistics) only.
+        buffers `running_var`, `running_mean`, all of shape [1, C, 1, 1].
 
         :raises ValueError: if momentum is not in (0, 1) or eps is not positive."""
         if momentum <= 0.0 or momentum >= 1.0:
@@ -122,12 +120,17 @@ class BatchNormLayer2d(Bijector):
 
     def transform(self, x: torch.Tensor, inverse: bool, ldj=None) -> Tuple[torch.Tensor, torch.Tensor]:
         from deeprob.hip import ops_flows2d
+        if not inverse and ops_flows2d.graph_route(x, self):
+            # batch statistics / gradients (reference :190-207): deeprob/hip/ops_flows2d_train.py
+            from deeprob.hip import ops_flows2d_train
+            u, d = ops_flows2d_train.bn2d(ops_flows2d._image(x, 'x'), self)
+            return u, (d if ldj is None else ldj + d)
         ops_flows2d.require_eval(self, 'BatchNormLayer2d', x)
         return ops_flows2d.bn2d(x, self, inverse, ldj)
 
     def apply_backward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """u = (x - mean)/sqrt(var + eps) * exp(weight) + bias, ildj = H W sum_c(weight - log(var + eps)/2)
-        (reference :186-208, eval branch)."""
+        (reference :186-208; batch statistics in training mode)."""
         return self.transform(x, False)
 
     def apply_forward(self, u: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -80,6 +80,17 @@ SIGNATURES = {
                                          _i32, _i32, _c_void, _c_void, _c_void, _c_void]),
     'dpk_space_to_depth': (ctypes.c_int, [_c_void, _i64, _i32, _i32, _i32, _c_void, _c_void, _i32, _c_void, _c_void]),
     'dpk_depth_to_space': (ctypes.c_int, [_c_void, _i32, _c_void, _i64, _i32, _i32, _i32, _c_void, _c_void, _c_void]),
+    'dpk_channel_stats': (ctypes.c_int, [_c_void, _i64, _i64, _i32, _i32, _i32, _i32, _c_void, _c_void]),
+    'dpk_channel_stats_backward': (ctypes.c_int, [_c_void, _i64, _i64, _i32, _i32, _i32, _c_void, _c_void, _c_void,
+                                                  _c_void, _c_void]),
+    'dpk_channel_affine_forward': (ctypes.c_int, [_c_void, _i64, _i32, _i32, _i32, _c_void, _c_void, _c_void]),
+    'dpk_channel_affine_backward': (ctypes.c_int, [_c_void, _i64, _c_void, _i64, _i32, _i32, _i32, _c_void, _i32,
+                                                   _c_void, _c_void, _c_void, _c_void]),
+    'dpk_conv2d_backward_weight': (ctypes.c_int, [_c_void, _i64, _c_void, _i64, _i32, _i32, _i32, _i32, _i32, _c_void,
+                                                  _c_void, _c_void, _c_void]),
+    'dpk_coupling2d_transform_backward': (ctypes.c_int, [_c_void, _c_void, _c_void, _c_void, _i64, _i32, _i32, _i32,
+                                                         _i32, _i32, _c_void, _c_void, _c_void, _c_void, _c_void,
+                                                         _c_void]),
     'dpk_normal_base_logprob': (ctypes.c_int, [_c_void, _c_void, _c_void, _c_void, _c_void, _c_void, _c_void,
                                                _i64, _i32, _c_void, _c_void]),
     'dpk_spatial_gaussian_forward': (ctypes.c_int, [_c_void, _c_void, _c_void, _i64, _i32, _i32, _i32, _i32,

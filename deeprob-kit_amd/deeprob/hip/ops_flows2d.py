@@ -2,9 +2,10 @@
 BatchNorm2d + ReLU folded into the operand load, coupling transformation, BatchNormLayer2d bijector and the
 squeeze / multi-scale permutations.
 
-Evaluation only (density and sampling directions with running statistics): asking autograd for a graph through these
-operators, or calling them on a module in training mode, raises -- there is no backward and no batch-statistics
-kernel for the 2-D flows, and nothing here falls back to torch operators.
+The functions here evaluate (density and sampling directions, running statistics, no autograd graph).  When a module is
+in training mode or a gradient through it is wanted they hand over to the autograd nodes of
+``deeprob.hip.ops_flows2d_train`` (density direction only; the sampling direction with gradients raises).  Nothing falls
+back to torch operators on image tensors.
 """
 from typing import Optional, Tuple
 
@@ -13,15 +14,26 @@ import torch
 from deeprob.hip import load_library, check, ptr, stream_ptr, require_device_f32, HipError
 
 
+def graph_route(x, *modules) -> bool:
+    """True when the call must build an autograd graph or use batch statistics: a module in training mode, or grad mode
+    with an input / parameter that requires grad."""
+    modules = [m for m in modules if m is not None]
+    if any(m.training for m in modules):
+        return True
+    if not torch.is_grad_enabled():
+        return False
+    return (torch.is_tensor(x) and x.requires_grad) or any(p.requires_grad for m in modules for p in m.parameters())
+
+
 def require_eval(module, what: str, *tensors):
-    """The 2-D flow kernels evaluate with running statistics and have no backward."""
+    """The sampling direction of the 2-D flows evaluates with running statistics and has no backward."""
     if module.training:
-        raise HipError("{}: the HIP RealNVP-2D path is evaluation only (call .eval(); training-mode batch statistics "
-                       "and gradients are not built)".format(what))
+        raise HipError("{}: the sampling direction of the HIP RealNVP-2D path is evaluation only (call .eval(); only "
+                       "the density direction is built for training)".format(what))
     if torch.is_grad_enabled() and (any(t is not None and t.requires_grad for t in tensors) or
                                     any(p.requires_grad for p in module.parameters())):
-        raise HipError("{}: the HIP RealNVP-2D path has no backward: wrap the call in torch.no_grad() or freeze the "
-                       "parameters".format(what))
+        raise HipError("{}: the sampling direction of the HIP RealNVP-2D path has no backward: wrap the call in "
+                       "torch.no_grad() or freeze the parameters".format(what))
 
 
 def _image(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -79,6 +91,11 @@ def conv2d(x: torch.Tensor, conv, bn=None, in_mask: Optional[torch.Tensor] = Non
            res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``conv(relu(bn(x)))`` (bn None: ``conv(x)``; in_mask: ``conv(in_mask * x)``) ``+ res``; `out` may be a channel
     slice of a larger tensor (reference: torch/utils.py:117-121 inside flows/layers/resnet.py, densenet.py)."""
+    if graph_route(x, conv, bn) or (res is not None and torch.is_grad_enabled() and res.requires_grad):
+        if out is not None and out is not res:
+            raise HipError("conv2d: an output slice cannot be written in place while an autograd graph is built")
+        from deeprob.hip import ops_flows2d_train
+        return ops_flows2d_train.conv2d(x, conv, bn, in_mask, res)
     lib = load_library()
     x = _image(x, 'x')
     B, cin, H, W = x.shape
@@ -162,6 +179,9 @@ def permutation_table(matrix: torch.Tensor) -> torch.Tensor:
 def space_to_depth(x: torch.Tensor, table: torch.Tensor, split: Optional[int] = None):
     """[B,C,H,W] -> [B,4C,H/2,W/2] in the channel order of `table`; with `split`, the two channel groups
     [0, split) and [split, 4C) as separate tensors (the torch.chunk of the multi-scale architecture)."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        from deeprob.hip import ops_flows2d_train
+        return ops_flows2d_train.space_to_depth(x, table, split)
     lib = load_library()
     x = require_device_f32(x, 'x')
     B, C, H, W = x.shape
@@ -177,6 +197,9 @@ def space_to_depth(x: torch.Tensor, table: torch.Tensor, split: Optional[int] = 
 
 def depth_to_space(a: torch.Tensor, table: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Inverse of :func:`space_to_depth` (of the concatenation [a | b] when b is given)."""
+    if torch.is_grad_enabled() and (a.requires_grad or (b is not None and b.requires_grad)):
+        from deeprob.hip import ops_flows2d_train
+        return ops_flows2d_train.depth_to_space(a, table, b)
     lib = load_library()
     a = require_device_f32(a, 'x')
     B, ca, h, w = a.shape

@@ -68,5 +68,4 @@ class WeightNormConv2d(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         from deeprob.hip import ops_flows2d
-        ops_flows2d.require_eval(self, 'WeightNormConv2d', x)
         return ops_flows2d.conv2d(x, self)

@@ -509,6 +509,40 @@ int dpk_space_to_depth(const float *in, int64_t B, int32_t C, int32_t H, int32_t
 int dpk_depth_to_space(const float *in_a, int32_t Ca, const float *in_b, int64_t B, int32_t C, int32_t H, int32_t W,
                        const int32_t *table, float *out, void *stream);
 
+/* ---- RealNVP-2D training direction (csrc/flows2d_train.hip) ---------------------------------------------------
+ * The reference trains RealNVP2d through ATen's autograd; these are the device passes our autograd nodes call.
+ * Reductions over the batch are accumulated with fp64 atomics into buffers the caller zeroed.
+ * dpk_channel_stats: sums[c] += sum_{b,h,w} x, sums[C+c] += sum x^2 (want_sq) -- the batch statistics of
+ *   nn.BatchNorm2d in training mode (flows/layers/resnet.py:19-33) and of BatchNormLayer2d (flows/utils.py:190-198);
+ *   also the bias gradient of a convolution (sum of the output gradient per channel).
+ * dpk_channel_stats_backward: with mean = sum/n and var = sumsq/n - mean^2: dx = (dmean + 2 dvar (x - mean)) / n.   */
+int dpk_channel_stats(const float *x, int64_t x_bstride, int64_t B, int32_t C, int32_t H, int32_t W, int32_t want_sq,
+                      double *sums, void *stream);
+int dpk_channel_stats_backward(const float *x, int64_t x_bstride, int64_t B, int32_t C, int32_t H, int32_t W,
+                               const float *mean, const float *dmean, const float *dvar, float *dx, void *stream);
+/* out = ab[c] x + ab[C+c] (BatchNormLayer2d.apply_backward with the batch statistics folded into ab,
+ * flows/utils.py:200-207).  Backward: g = dy * mask[h,w] (mask != NULL) * [ab[c] x + ab[C+c] > 0] (relu), dx = g ab[c],
+ * dab[c] += sum g x, dab[C+c] += sum g; ab == NULL: dx = dy * mask only.  With relu / mask this is the backward of the
+ * operand map dpk_conv2d_forward applies on load (BatchNorm2d + ReLU, CouplingLayer2d's mask * x).                  */
+int dpk_channel_affine_forward(const float *x, int64_t B, int32_t C, int32_t H, int32_t W, const float *ab, float *out,
+                               void *stream);
+int dpk_channel_affine_backward(const float *x, int64_t x_bstride, const float *dy, int64_t B, int32_t C, int32_t H,
+                                int32_t W, const float *ab, int32_t relu, const float *mask, float *dx, double *dab,
+                                void *stream);
+/* Weight gradient of dpk_conv2d_forward (F.conv2d's, torch/utils.py:117-121): dw[co][ci][ky][kx] += sum over samples
+ * and pixels of dout[b,co] * f(in[b,ci]) shifted by the tap, f as in dpk_conv2d_forward (pre / in_mask).  dw zeroed by
+ * the caller.  The input gradient is dpk_conv2d_forward itself on dout with the transposed, flipped weights.        */
+int dpk_conv2d_backward_weight(const float *in, int64_t in_bstride, const float *dout, int64_t B, int32_t Cin,
+                               int32_t Cout, int32_t H, int32_t W, int32_t ks, const float *pre, const float *in_mask,
+                               float *dw, void *stream);
+/* Backward of dpk_coupling2d_transform with inverse = 0 (flows/layers/coupling.py:181-226): gradients of (out, ldj)
+ * = (dout, dldj[B] or NULL) w.r.t. x (the direct path only: the path through the conditioner is dz), z and the
+ * ScaledTanh weight (dscale [Ch] fp64, zeroed by the caller).                                                        */
+int dpk_coupling2d_transform_backward(const float *x, const float *z, const float *scale, const float *inv_mask,
+                                      int64_t B, int32_t C, int32_t H, int32_t W, int32_t affine, int32_t reverse,
+                                      const float *dout, const float *dldj, float *dx, float *dz, double *dscale,
+                                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

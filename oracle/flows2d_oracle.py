@@ -15,12 +15,43 @@ Op-for-op restatement (same ATen op sequence, eval mode) of
 as plain functions over a state_dict (the model structure is read off the key names).  Pinned by
 tests/test_oracle_flows2d.py against golden vectors that tools/gen_golden_flows2d.py produced from the imported
 reference (latents, log-dets, LLs, inverse round trip; resnet / densenet, affine / NICE).
+
+Inside ``with training():`` the batch-normalisation layers use batch statistics as the reference's modules do in
+training mode (nn.BatchNorm2d training branch; flows/utils.py:190-198) -- without the running-statistics update, which
+the golden fixtures pin directly -- and torch's autograd over these ops (state tensors with requires_grad) gives the
+reference gradients; pinned against the reference's own training-mode LLs and gradients (``*_train.npz``).
 """
+import contextlib
 import math
 from typing import Dict
 
 import torch
 import torch.nn.functional as F
+
+
+_MODE = {'train': False, 'margins': None}
+
+
+@contextlib.contextmanager
+def training():
+    """Batch statistics instead of running statistics (the modules' training mode)."""
+    _MODE['train'] = True
+    try:
+        yield
+    finally:
+        _MODE['train'] = False
+
+
+@contextlib.contextmanager
+def relu_margins():
+    """Collects the smallest |ReLU argument| of every BatchNorm2d + ReLU evaluated inside the block.  The gradient of
+    the network is discontinuous where an argument crosses zero, and two fp32 evaluations of the same network disagree
+    on the sign of arguments within rounding of zero; tests use the margin to know which comparisons can be strict."""
+    _MODE['margins'] = []
+    try:
+        yield _MODE['margins']
+    finally:
+        _MODE['margins'] = None
 
 
 def _wn_conv(sd, p, x):
@@ -31,9 +62,15 @@ def _wn_conv(sd, p, x):
 
 
 def _bn_relu(sd, p, x):
-    """nn.BatchNorm2d (eval) + nn.ReLU."""
-    return torch.relu(F.batch_norm(x, sd[p + 'running_mean'], sd[p + 'running_var'], sd[p + 'weight'], sd[p + 'bias'],
-                                   False, 0.1, 1e-5))
+    """nn.BatchNorm2d + nn.ReLU."""
+    if _MODE['train']:
+        y = F.batch_norm(x, None, None, sd[p + 'weight'], sd[p + 'bias'], True, 0.1, 1e-5)
+    else:
+        y = F.batch_norm(x, sd[p + 'running_mean'], sd[p + 'running_var'], sd[p + 'weight'], sd[p + 'bias'],
+                         False, 0.1, 1e-5)
+    if _MODE['margins'] is not None:
+        _MODE['margins'].append(float(y.detach().abs().min()))
+    return torch.relu(y)
 
 
 def resnet(sd, p, x):
@@ -113,6 +150,9 @@ def bn2d(sd, p, x, inverse: bool, eps: float = 1e-5):
     """flows/utils.py:186-222 with the running statistics."""
     n, grid = x.shape[0], x.shape[2] * x.shape[3]
     w, b, var, mean = sd[p + 'weight'], sd[p + 'bias'], sd[p + 'running_var'] + eps, sd[p + 'running_mean']
+    if _MODE['train'] and not inverse:
+        mean = torch.mean(x, dim=[0, 2, 3], keepdim=True)
+        var = torch.mean((x - mean) ** 2.0, dim=[0, 2, 3], keepdim=True) + eps
     if inverse:
         u = (x - b) * torch.exp(-w)
         return u * torch.sqrt(var) + mean, (torch.sum(0.5 * torch.log(var) - w) * grid).expand(n)

@@ -77,3 +77,44 @@ def test_product_path_refuses_cpu_tensors_and_training_mode():
         m(x)                                  # graph wanted (parameters require grad)
     with torch.no_grad(), pytest.raises(HipError):
         m(x)                                  # CPU tensor
+
+
+def grad_probe(t):
+    """tools/gen_golden_flows2d.py::grad_probe: sum |g| and the inner product with a fixed cosine pattern."""
+    t = t.detach().double().reshape(-1).cpu()
+    return [float(t.abs().sum()), float((t * torch.cos(torch.arange(t.numel(), dtype=torch.float64) * 0.37)).sum())]
+
+
+def probe_err(got, want):
+    """Both probes of every gradient tensor relative to its magnitude sum |g| (the signed probe cancels)."""
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape and np.isfinite(got).all()
+    return float(np.max(np.abs(got - want) / np.maximum(1.0, want[:, :1])))
+
+
+TRAIN_CASES = [c for c in FLOWS2D_CASES if c[0] in ('realnvp2d_3x8x8_resnet', 'realnvp2d_3x8x8_resnet_nice',
+                                                    'realnvp2d_3x8x8_densenet', 'realnvp2d_3x12x20_c20')]
+
+
+@pytest.mark.parametrize('case', TRAIN_CASES, ids=[c[0] for c in TRAIN_CASES])
+def test_oracle_training_mode_matches_reference(golden, case):
+    """Batch statistics + autograd over the restatement against the reference's training-mode LLs and gradients of
+    loss = -mean(LL) (per-parameter probes and the full input gradient)."""
+    name, feats, kw, seed = case
+    g = golden(name + '_train')
+    model = flow2d_model(feats, kw, seed)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = [str(n) for n in g['grad_names']]
+    for n in names:
+        sd[n].requires_grad_(True)
+    x = torch.from_numpy(g['x']).requires_grad_(True)
+    with orc.training():
+        ll = orc.log_prob(sd, x)
+    loss = -torch.mean(ll)
+    loss.backward()
+    assert rel_err(ll.detach().numpy(), g['ll']) <= 5e-6 and abs(float(loss.detach()) - float(g['loss'])) <= 1e-5 * abs(float(g['loss']))
+    # (fp32 rounding through batch statistics of a few values per channel -- 12 at the 2x2 scale of the dense-net case,
+    # whose gradients differ by 2e-4 between ATen thread counts)
+    assert rel_err(x.grad.numpy(), g['x_grad']) <= (5e-4 if 'densenet' in name else 1e-4)
+    got = np.array([grad_probe(sd[n].grad if sd[n].grad is not None else torch.zeros_like(sd[n])) for n in names])
+    assert probe_err(got, g['grad_probe']) <= (5e-4 if 'densenet' in name else 5e-5)

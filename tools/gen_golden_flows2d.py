@@ -69,6 +69,59 @@ def _fixture(name, model, x):
     _save(name, **arrays)
 
 
+def grad_probe(t):
+    """Two checksums of a gradient tensor: sum |g| and the inner product with a fixed cosine pattern."""
+    t = t.detach().double().reshape(-1)
+    return [float(t.abs().sum()), float((t * torch.cos(torch.arange(t.numel(), dtype=torch.float64) * 0.37)).sum())]
+
+
+def relu_margin(model, x):
+    """Smallest |argument| of any nn.ReLU during one training-mode evaluation (statistics restored afterwards)."""
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    seen, hooks = [], []
+    for m in model.modules():
+        if isinstance(m, torch.nn.ReLU):
+            hooks.append(m.register_forward_pre_hook(lambda mod, inp: seen.append(float(inp[0].detach().abs().min()))))
+    model.train()
+    with torch.no_grad():
+        model(x)
+    for h in hooks:
+        h.remove()
+    model.load_state_dict(state)
+    return min(seen)
+
+
+def _train_fixture(name, model, feats, seed, batch):
+    """One training-mode evaluation of the reference (batch statistics, running-statistics update) and the gradients
+    of loss = -mean(LL): LLs, loss, per-parameter gradient probes, the input gradient, the state checksum afterwards.
+    The gradient is discontinuous where a ReLU argument crosses zero, and two fp32 evaluations of the same network
+    disagree on the sign of arguments within rounding of zero: the input is the first of 120 seeded draws whose smallest
+    |ReLU argument| is at least 3e-5, or the draw with the largest one (stored as `relu_margin`)."""
+    best = None
+    for k in range(120):
+        cand = torch.randn((batch,) + feats, generator=torch.Generator().manual_seed(seed + 200 + k))
+        m = relu_margin(model, cand)
+        if best is None or m > best[0]:
+            best = (m, cand)
+        if m >= 3e-5:
+            break
+    margin, x = best
+    model.train()
+    x = x.clone().requires_grad_(True)
+    ll = model(x)
+    loss = model.loss(ll)
+    loss.backward()
+    names = sorted(n for n, p in model.named_parameters() if p.requires_grad)
+    params = dict(model.named_parameters())
+    arrays = {'x': _np(x.detach()), 'll': _np(ll.detach()), 'loss': np.array(float(loss.detach())),
+              'grad_names': np.array(names), 'relu_margin': np.array(margin),
+              'grad_probe': np.array([grad_probe(params[n].grad if params[n].grad is not None
+                                                 else torch.zeros_like(params[n])) for n in names]),
+              'x_grad': _np(x.grad), 'sd_check_after': state_checksum(model)}
+    model.eval()
+    _save(name + '_train', **arrays)
+
+
 CASES = [
     # name, in_features, kwargs, batch, seed      (the first four: the reference's own test configuration, tests/test_flows.py:86-93)
     ('realnvp2d_3x8x8_resnet', (3, 8, 8), dict(n_flows=2, n_blocks=2, channels=8, network='resnet', affine=True), 6, 21),
@@ -80,6 +133,10 @@ CASES = [
 ]
 
 
+TRAIN_CASES = ('realnvp2d_3x8x8_resnet', 'realnvp2d_3x8x8_resnet_nice', 'realnvp2d_3x8x8_densenet',
+               'realnvp2d_3x12x20_c20')
+
+
 def gen_flows2d():
     from deeprob.flows.models.realnvp import RealNVP2d
     for name, feats, kw, batch, seed in CASES:
@@ -89,3 +146,5 @@ def gen_flows2d():
         g = torch.Generator().manual_seed(seed + 100)
         x = torch.rand((batch,) + feats, generator=g) if kw.get('logit') else torch.randn((batch,) + feats, generator=g)
         _fixture(name, m, x)
+        if name in TRAIN_CASES:
+            _train_fixture(name, m, feats, seed, 3 if 'densenet' in name else batch)
