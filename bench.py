@@ -397,6 +397,18 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
                     'ms_per_step': ms, 'value': B / ms * 1e3, 'unit': 'samples/sec',
                     'ms_per_step_hip_graph': ms_g, 'value_hip_graph': (B / ms_g * 1e3) if ms_g else None})
 
+    # RealNVP2d training direction: batch statistics, convolution / coupling backward kernels
+    from deeprob.flows.models import RealNVP2d
+    B2 = 256
+    torch.manual_seed(0)
+    m2d = RealNVP2d((1, 28, 28), n_flows=1, n_blocks=2, channels=32).to(dev)
+    ms = _time_train(m2d, torch.randn(B2, 1, 28, 28, device=dev), steps=4, warm=2)
+    out.append({'workload': 'RealNVP2d((1,28,28), n_flows=1, n_blocks=2, channels=32, resnet, affine): forward + backward '
+                            '+ Adam step (training mode, batch statistics)', 'config': 'training step', 'batch': B2,
+                'ms_per_step': ms, 'value': B2 / ms * 1e3, 'unit': 'samples/sec', 'ms_per_step_hip_graph': None,
+                'value_hip_graph': None})
+    del m2d
+
     # ---- the headline with the host-to-device copy inside the step (routines.py:159 copies per batch) ----
     Bh = xs_headline[0].shape[0]
     host = [torch.randn(Bh, D).pin_memory() for _ in range(2)]

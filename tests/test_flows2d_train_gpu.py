@@ -185,3 +185,73 @@ def test_training_kernels_error_codes():
     assert lib.dpk_conv2d_backward_weight(ptr(x), 48, ptr(x), 2, 3, 3, 4, 4, 5, None, None, ptr(x), None) == -4
     assert lib.dpk_coupling2d_transform_backward(ptr(x), ptr(x), None, None, 2, 3, 4, 4, 0, 0, ptr(x), None, ptr(x),
                                                  ptr(x), None, None) == -1                   # channel-wise with odd C
+
+
+def _err(a, b):
+    return float((a.double() - b.double()).abs().max() / max(1.0, float(b.double().abs().max())))
+
+
+@pytest.mark.parametrize('cin,cout,hw,ks,pre,mask,res,sliced', [
+    (3, 8, (8, 8), 3, False, True, False, False),      # masked first convolution of a checkerboard coupling
+    (8, 32, (8, 8), 1, True, False, False, False),     # BatchNorm2d + ReLU folded, matrix-core forward
+    (32, 8, (8, 8), 3, True, False, True, True),       # residual addend, channel-slice input
+    (24, 40, (4, 4), 1, False, False, False, True),
+    (128, 160, (2, 2), 1, True, False, False, False),  # dense-net bottleneck at the 2x2 scale
+    (32, 128, (2, 2), 3, False, False, False, False),
+    (19, 19, (10, 10), 3, True, False, True, False),   # odd channel counts
+    (64, 64, (14, 14), 3, True, False, True, False),   # the squeezed MNIST scale (LDS-staged forward kernel)
+])
+def test_convolution_node_against_fp64(cin, cout, hw, ks, pre, mask, res, sliced):
+    """Conv2dFn (forward, input / weight / bias / operand-map / residual gradients) against the same expression in fp64
+    torch operators on the device."""
+    import torch.nn.functional as F
+    from deeprob.hip import ops_flows2d_train as tr
+    B, (H, W) = 5, hw
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    big = torch.randn(B, cin + 3, H, W, generator=g).cuda()
+    x0 = (big[:, 1:1 + cin] if sliced else big[:, :cin].contiguous()).detach().requires_grad_(True)
+    w0 = (0.3 * torch.randn(cout, cin, ks, ks, generator=g)).cuda().requires_grad_(True)
+    b0 = torch.randn(cout, generator=g).cuda().requires_grad_(True)
+    p0 = (torch.cat([0.5 + torch.rand(cin, generator=g), 0.3 * torch.randn(cin, generator=g)]).cuda().requires_grad_(True)
+          if pre else None)
+    m0 = ((torch.arange(H)[:, None] + torch.arange(W)[None]) % 2).float().cuda() if mask else None
+    r0 = torch.randn(B, cout, H, W, generator=g).cuda().requires_grad_(True) if res else None
+    go = torch.randn(B, cout, H, W, generator=g).cuda()
+    out = tr.Conv2dFn.apply(x0, w0, b0, p0, None if m0 is None else m0.reshape(-1), r0)
+    ins = [t for t in (x0, w0, b0, p0, r0) if t is not None]
+    got = torch.autograd.grad(out, ins, go)
+    h = x0.double()
+    if pre:
+        h = torch.relu(p0[:cin].double().view(1, -1, 1, 1) * h + p0[cin:].double().view(1, -1, 1, 1))
+    if mask:
+        h = h * m0.double()
+    ref = F.conv2d(h, w0.double(), b0.double(), padding=ks // 2)
+    if res:
+        ref = ref + r0.double()
+    want = torch.autograd.grad(ref, ins, go.double())
+    assert _err(out, ref) <= TOL
+    for a, b in zip(got, want):
+        assert _err(a, b) <= 2e-5
+
+
+@pytest.mark.parametrize('C,B,H,W', [(3, 5, 8, 8), (40, 5, 4, 4), (17, 70, 6, 4), (32, 12, 28, 28)])
+def test_statistics_and_affine_nodes_against_fp64(C, B, H, W):
+    from deeprob.hip import ops_flows2d_train as tr
+    torch.manual_seed(C)
+    x = (torch.randn(B, C + 2, H, W).cuda() * 0.1 + 3.0)[:, 1:1 + C].detach().requires_grad_(True)   # |mean| >> std
+    mean, var = tr.ChannelStatsFn.apply(x)
+    gm, gv = torch.randn(C).cuda(), torch.randn(C).cuda()
+    got = torch.autograd.grad([mean, var], [x], [gm, gv])[0]
+    xd = x.double()
+    m2 = xd.mean(dim=[0, 2, 3])
+    v2 = ((xd - m2.view(1, -1, 1, 1)) ** 2).mean(dim=[0, 2, 3])
+    want = torch.autograd.grad([m2, v2], [x], [gm.double(), gv.double()])[0]
+    assert _err(mean, m2) <= 1e-6 and float(((var.double() - v2) / v2).abs().max()) <= 1e-5 and _err(got, want) <= 1e-5
+    ab = torch.randn(2 * C).cuda().requires_grad_(True)
+    xc = x.detach().contiguous().requires_grad_(True)
+    out = tr.ChannelAffineFn.apply(xc, ab)
+    go = torch.randn_like(out)
+    got = torch.autograd.grad(out, [xc, ab], go)
+    ref = ab[:C].view(1, -1, 1, 1).double() * xc.double() + ab[C:].view(1, -1, 1, 1).double()
+    want = torch.autograd.grad(ref, [xc, ab], go.double())
+    assert _err(out, ref) <= TOL and _err(got[0], want[0]) <= TOL and _err(got[1], want[1]) <= 2e-5
