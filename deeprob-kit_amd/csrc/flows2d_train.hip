@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void channel_stats_bwd_kernel(const float *__r
                                                                 const float *__restrict__ mean,
                                                                 const float *__restrict__ dmean,
                                                                 const float *__restrict__ dvar, float inv_n,
-                                                                float *__restrict__ dx) {
+                                                                int accumulate, float *__restrict__ dx) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int chw = C * HW;
@@ -69,7 +69,51 @@ __global__ __launch_bounds__(256) void channel_stats_bwd_kernel(const float *__r
     const int r = (int)(i - b * chw);
     const int c = r / HW;
     const float v = x[b * bstride + r];
-    dx[i] = (dmean[c] + 2.f * dvar[c] * (v - mean[c])) * inv_n;
+    const float t = (dmean[c] + 2.f * dvar[c] * (v - mean[c])) * inv_n;
+    dx[i] = accumulate ? dx[i] + t : t;
+}
+
+// nn.BatchNorm2d in training mode as the operand map of the convolution behind it: from the batch sums,
+// mean = S1/n, var = S2/n - mean^2 (biased), rstd = (var + eps)^-1/2, pre = [gamma rstd | beta - mean gamma rstd],
+// stat = [mean | rstd]; the running statistics move as torch's module moves them (unbiased variance).
+__global__ __launch_bounds__(256) void bn2d_fold_train_kernel(const double *__restrict__ sums, double n, int C,
+                                                              const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta, float eps, float momentum,
+                                                              float *__restrict__ running_mean,
+                                                              float *__restrict__ running_var, float *__restrict__ pre,
+                                                              float *__restrict__ stat) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double mean = sums[c] / n;
+    double var = sums[C + c] / n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float mf = (float)mean, vf = (float)var;
+    const float rstd = 1.f / sqrtf(vf + eps);
+    const float a = gamma[c] * rstd;
+    pre[c] = a;
+    pre[C + c] = beta[c] - mf * a;
+    stat[c] = mf;
+    stat[C + c] = rstd;
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * (n / (n > 1.0 ? n - 1.0 : 1.0)));
+    }
+}
+
+// gradients of (a, b) = (gamma rstd, beta - mean a) back to gamma, beta and the statistics:
+// da' = da - mean db,  dgamma = da' rstd,  dbeta = db,  dmean = -a db,  dvar = -da' gamma rstd^3 / 2
+__global__ __launch_bounds__(256) void bn2d_fold_bwd_kernel(const double *__restrict__ dab, int C,
+                                                            const float *__restrict__ gamma,
+                                                            const float *__restrict__ stat, float *__restrict__ dgamma,
+                                                            float *__restrict__ dbeta, float *__restrict__ dstat) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double mean = stat[c], rstd = stat[C + c], g = gamma[c];
+    const double da = dab[c] - mean * dab[C + c], db = dab[C + c];
+    dgamma[c] = (float)(da * rstd);
+    dbeta[c] = (float)db;
+    dstat[c] = (float)(-g * rstd * db);
+    dstat[C + c] = (float)(-0.5 * da * g * rstd * rstd * rstd);
 }
 
 // out = a[c] x + b[c]
@@ -268,7 +312,8 @@ int dpk_channel_stats(const float *x, int64_t x_bstride, int64_t B, int32_t C, i
 }
 
 int dpk_channel_stats_backward(const float *x, int64_t x_bstride, int64_t B, int32_t C, int32_t H, int32_t W,
-                               const float *mean, const float *dmean, const float *dvar, float *dx, void *stream) {
+                               const float *mean, const float *dmean, const float *dvar, int32_t accumulate, float *dx,
+                               void *stream) {
     DPK_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0, DPK_EINVAL, "channel_stats_backward: bad sizes");
     DPK_REQUIRE((int64_t)C * H * W < INT32_MAX, DPK_EUNSUPPORTED, "channel_stats_backward: too large");
     if (B == 0) return DPK_OK;
@@ -276,8 +321,29 @@ int dpk_channel_stats_backward(const float *x, int64_t x_bstride, int64_t B, int
     const int64_t total = B * C * H * W;
     DPK_REQUIRE(total / 256 < INT32_MAX, DPK_EUNSUPPORTED, "channel_stats_backward: too large");
     DPK_LAUNCH(channel_stats_bwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
-               x_bstride, total, C, H * W, mean, dmean, dvar, 1.f / (float)(B * H * W), dx);
+               x_bstride, total, C, H * W, mean, dmean, dvar, 1.f / (float)(B * H * W), accumulate, dx);
     DPK_CHECK_LAUNCH("channel_stats_bwd_kernel");
+    return DPK_OK;
+}
+
+int dpk_bn2d_fold_train(const double *sums, int64_t n, int32_t C, const float *gamma, const float *beta, float eps,
+                        float momentum, float *running_mean, float *running_var, float *pre, float *stat, void *stream) {
+    DPK_REQUIRE(C > 0 && n > 0, DPK_EINVAL, "bn2d_fold_train: bad sizes");
+    DPK_REQUIRE(sums && gamma && beta && pre && stat && (!running_mean == !running_var), DPK_EINVAL,
+                "bn2d_fold_train: null pointer");
+    DPK_LAUNCH(bn2d_fold_train_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, (double)n,
+               C, gamma, beta, eps, momentum, running_mean, running_var, pre, stat);
+    DPK_CHECK_LAUNCH("bn2d_fold_train_kernel");
+    return DPK_OK;
+}
+
+int dpk_bn2d_fold_backward(const double *dab, int32_t C, const float *gamma, const float *stat, float *dgamma,
+                           float *dbeta, float *dstat, void *stream) {
+    DPK_REQUIRE(C > 0, DPK_EINVAL, "bn2d_fold_backward: bad sizes");
+    DPK_REQUIRE(dab && gamma && stat && dgamma && dbeta && dstat, DPK_EINVAL, "bn2d_fold_backward: null pointer");
+    DPK_LAUNCH(bn2d_fold_bwd_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, dab, C, gamma, stat,
+               dgamma, dbeta, dstat);
+    DPK_CHECK_LAUNCH("bn2d_fold_bwd_kernel");
     return DPK_OK;
 }
 

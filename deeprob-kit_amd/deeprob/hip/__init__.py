@@ -82,7 +82,10 @@ SIGNATURES = {
     'dpk_depth_to_space': (ctypes.c_int, [_c_void, _i32, _c_void, _i64, _i32, _i32, _i32, _c_void, _c_void, _c_void]),
     'dpk_channel_stats': (ctypes.c_int, [_c_void, _i64, _i64, _i32, _i32, _i32, _i32, _c_void, _c_void]),
     'dpk_channel_stats_backward': (ctypes.c_int, [_c_void, _i64, _i64, _i32, _i32, _i32, _c_void, _c_void, _c_void,
-                                                  _c_void, _c_void]),
+                                                  _i32, _c_void, _c_void]),
+    'dpk_bn2d_fold_train': (ctypes.c_int, [_c_void, _i64, _i32, _c_void, _c_void, ctypes.c_float, ctypes.c_float,
+                                           _c_void, _c_void, _c_void, _c_void, _c_void]),
+    'dpk_bn2d_fold_backward': (ctypes.c_int, [_c_void, _i32, _c_void, _c_void, _c_void, _c_void, _c_void, _c_void]),
     'dpk_channel_affine_forward': (ctypes.c_int, [_c_void, _i64, _i32, _i32, _i32, _c_void, _c_void, _c_void]),
     'dpk_channel_affine_backward': (ctypes.c_int, [_c_void, _i64, _c_void, _i64, _i32, _i32, _i32, _c_void, _i32,
                                                    _c_void, _c_void, _c_void, _c_void]),

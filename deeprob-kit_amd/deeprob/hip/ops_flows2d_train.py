@@ -64,8 +64,8 @@ class ChannelStatsFn(torch.autograd.Function):
         dmean = torch.zeros_like(mean) if dmean is None else _grad_image(dmean)
         dvar = torch.zeros_like(mean) if dvar is None else _grad_image(dvar)
         dx = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
-        check(lib.dpk_channel_stats_backward(ptr(x), x.stride(0), B, C, H, W, ptr(mean), ptr(dmean), ptr(dvar), ptr(dx),
-                                             stream_ptr(x.device)), 'dpk_channel_stats_backward')
+        check(lib.dpk_channel_stats_backward(ptr(x), x.stride(0), B, C, H, W, ptr(mean), ptr(dmean), ptr(dvar), 0,
+                                             ptr(dx), stream_ptr(x.device)), 'dpk_channel_stats_backward')
         return dx
 
 
@@ -169,6 +169,78 @@ class Conv2dFn(torch.autograd.Function):
         return dx, dw, dbias, dpre, None, (g if ctx.has_res else None)
 
 
+class BnConv2dFn(torch.autograd.Function):
+    """Training-mode ``conv(mask * relu(bn(x)), w) + bias + res`` as ONE node: batch statistics, the fold of
+    (gamma, beta, mean, var) into the operand map, the convolution, and in the backward the whole BatchNorm2d gradient
+    (operand-map gradient -> gamma / beta / statistics -> input) without [C]-sized torch operators in between -- a
+    training step of the default MNIST flow is ~70 such nodes and the small launches between the kernels were what it
+    spent its time on.  The running statistics of `bn` are updated in the fold kernel."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, w, bias, mask, res, bn):
+        lib = load_library()
+        x = ev._image(x, 'x')
+        w = require_device_f32(w, 'weight')
+        gamma = require_device_f32(gamma, 'batch norm weight')
+        beta = require_device_f32(beta, 'batch norm bias')
+        B, cin, H, W = x.shape
+        cout, ks = w.shape[0], w.shape[2]
+        if w.shape[1] != cin:
+            raise HipError("conv2d: input has {} channels, the layer expects {}".format(cin, w.shape[1]))
+        if B * H * W == 0:
+            raise HipError("batch statistics of an empty batch")
+        dev = x.device
+        st = stream_ptr(dev)
+        sums = torch.zeros(2 * cin, dtype=torch.float64, device=dev)
+        check(lib.dpk_channel_stats(ptr(x), x.stride(0), B, cin, H, W, 1, ptr(sums), st), 'dpk_channel_stats')
+        pre = torch.empty(2 * cin, dtype=torch.float32, device=dev)
+        stat = torch.empty(2 * cin, dtype=torch.float32, device=dev)
+        bn.num_batches_tracked.add_(1)
+        momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked.item())
+        check(lib.dpk_bn2d_fold_train(ptr(sums), B * H * W, cin, ptr(gamma), ptr(beta), float(bn.eps), float(momentum),
+                                      ptr(bn.running_mean), ptr(bn.running_var), ptr(pre), ptr(stat), st),
+              'dpk_bn2d_fold_train')
+        bias = None if bias is None else require_device_f32(bias, 'bias')
+        mask = None if mask is None else require_device_f32(mask, 'mask')
+        res = None if res is None else ev._image(res, 'res')
+        out = _conv(x, _pack(w), cout, ks, pre, mask, bias, res)
+        ctx.save_for_backward(x, w, pre, stat, gamma, mask)
+        ctx.has_bias, ctx.has_res = bias is not None, res is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load_library()
+        x, w, pre, stat, gamma, mask = ctx.saved_tensors
+        B, cin, H, W = x.shape
+        cout, ks = w.shape[0], w.shape[2]
+        g = _grad_image(g)
+        dev = x.device
+        st = stream_ptr(dev)
+        wt = w.transpose(0, 1).flip(2, 3).contiguous()
+        dh = _conv(g, _pack(wt), cin, ks, None, None, None, None)
+        dx = torch.empty((B, cin, H, W), dtype=torch.float32, device=dev)
+        dab = torch.zeros(2 * cin, dtype=torch.float64, device=dev)
+        check(lib.dpk_channel_affine_backward(ptr(x), x.stride(0), ptr(dh), B, cin, H, W, ptr(pre), 1, ptr(mask), ptr(dx),
+                                              ptr(dab), st), 'dpk_channel_affine_backward')
+        small = torch.empty(4 * cin, dtype=torch.float32, device=dev)     # dgamma | dbeta | dmean | dvar
+        dgamma, dbeta, dstat = small[:cin], small[cin:2 * cin], small[2 * cin:]
+        check(lib.dpk_bn2d_fold_backward(ptr(dab), cin, ptr(gamma), ptr(stat), ptr(dgamma), ptr(dbeta), ptr(dstat), st),
+              'dpk_bn2d_fold_backward')
+        check(lib.dpk_channel_stats_backward(ptr(x), x.stride(0), B, cin, H, W, ptr(stat), ptr(dstat), ptr(dstat[cin:]),
+                                             1, ptr(dx), st), 'dpk_channel_stats_backward')
+        dw = dbias = None
+        if ctx.needs_input_grad[3]:
+            dw = torch.zeros_like(w)
+            check(lib.dpk_conv2d_backward_weight(ptr(x), x.stride(0), ptr(g), B, cin, cout, H, W, ks, ptr(pre), ptr(mask),
+                                                 ptr(dw), st), 'dpk_conv2d_backward_weight')
+        if ctx.has_bias and ctx.needs_input_grad[4]:
+            sums = torch.zeros(cout, dtype=torch.float64, device=dev)
+            check(lib.dpk_channel_stats(ptr(g), g.stride(0), B, cout, H, W, 0, ptr(sums), st), 'dpk_channel_stats')
+            dbias = sums.float()
+        return dx, dgamma, dbeta, dw, dbias, None, (g if ctx.has_res else None), None
+
+
 def effective_weight(p) -> torch.Tensor:
     """``g v / |v|`` per output channel (torch.nn.utils.weight_norm with dim 0, reference torch/utils.py:103-115)."""
     v, g = p.weight_v, p.weight_g
@@ -199,8 +271,12 @@ def conv2d(x: torch.Tensor, conv, bn=None, in_mask: Optional[torch.Tensor] = Non
            res: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The graph-building form of :func:`deeprob.hip.ops_flows2d.conv2d`."""
     p = conv.conv
-    pre = None if bn is None else batchnorm_operand_map(bn, x)
     mask = None if in_mask is None else in_mask.reshape(-1)
+    if bn is not None and bn.training:
+        if bn.weight is None or bn.running_mean is None:
+            raise HipError("conv2d: BatchNorm2d without affine parameters / running statistics is not built")
+        return BnConv2dFn.apply(x, bn.weight, bn.bias, effective_weight(p), p.bias, mask, res, bn)
+    pre = None if bn is None else batchnorm_operand_map(bn, x)
     return Conv2dFn.apply(x, effective_weight(p), p.bias, pre, mask, res)
 
 

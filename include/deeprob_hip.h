@@ -515,11 +515,21 @@ int dpk_depth_to_space(const float *in_a, int32_t Ca, const float *in_b, int64_t
  * dpk_channel_stats: sums[c] += sum_{b,h,w} x, sums[C+c] += sum x^2 (want_sq) -- the batch statistics of
  *   nn.BatchNorm2d in training mode (flows/layers/resnet.py:19-33) and of BatchNormLayer2d (flows/utils.py:190-198);
  *   also the bias gradient of a convolution (sum of the output gradient per channel).
- * dpk_channel_stats_backward: with mean = sum/n and var = sumsq/n - mean^2: dx = (dmean + 2 dvar (x - mean)) / n.   */
+ * dpk_channel_stats_backward: with mean = sum/n and var = sumsq/n - mean^2: dx (+)= (dmean + 2 dvar (x - mean)) / n.*/
 int dpk_channel_stats(const float *x, int64_t x_bstride, int64_t B, int32_t C, int32_t H, int32_t W, int32_t want_sq,
                       double *sums, void *stream);
 int dpk_channel_stats_backward(const float *x, int64_t x_bstride, int64_t B, int32_t C, int32_t H, int32_t W,
-                               const float *mean, const float *dmean, const float *dvar, float *dx, void *stream);
+                               const float *mean, const float *dmean, const float *dvar, int32_t accumulate, float *dx,
+                               void *stream);
+/* nn.BatchNorm2d in training mode (flows/layers/resnet.py:19-33) folded into the operand map of the convolution behind
+ * it: from the sums of dpk_channel_stats over n = B*H*W values per channel, pre = [gamma rstd | beta - mean gamma rstd],
+ * stat = [mean | rstd]; running_mean / running_var (NULL: left alone) move by `momentum` as torch's module moves them
+ * (unbiased variance).  dpk_bn2d_fold_backward: gradients dab [2C] of pre back to gamma, beta and to dstat =
+ * [dmean | dvar], which dpk_channel_stats_backward (accumulate = 1: added to dx) carries to the input.             */
+int dpk_bn2d_fold_train(const double *sums, int64_t n, int32_t C, const float *gamma, const float *beta, float eps,
+                        float momentum, float *running_mean, float *running_var, float *pre, float *stat, void *stream);
+int dpk_bn2d_fold_backward(const double *dab, int32_t C, const float *gamma, const float *stat, float *dgamma,
+                           float *dbeta, float *dstat, void *stream);
 /* out = ab[c] x + ab[C+c] (BatchNormLayer2d.apply_backward with the batch statistics folded into ab,
  * flows/utils.py:200-207).  Backward: g = dy * mask[h,w] (mask != NULL) * [ab[c] x + ab[C+c] > 0] (relu), dx = g ab[c],
  * dab[c] += sum g x, dab[C+c] += sum g; ab == NULL: dx = dy * mask only.  With relu / mask this is the backward of the

@@ -98,3 +98,18 @@ def test_train_model_with_hip_graph_matches_eager(tmp_path):
                     hip_graph=True)
     with pytest.raises(ValueError):
         train_model(flow, train, valid, setting='discriminative', epochs=1, hip_graph=True)
+
+
+def test_train_image_flow(tmp_path):
+    """train_model / test_model on a RealNVP2d (SURVEY 8f-1 x 8f-3): training-mode batch statistics and the 2-D backward
+    kernels under the reference's loop, evaluation kernels for validation and testing."""
+    from deeprob.flows.models import RealNVP2d
+    from deeprob.torch.routines import train_model, test_model
+    torch.manual_seed(4)
+    data = (0.5 * torch.randn(320, 1, 8, 8) + 0.7).numpy()
+    flow = RealNVP2d((1, 8, 8), n_flows=1, n_blocks=1, channels=8)
+    before = test_model(flow, data[:64], verbose=False)[0]
+    hist = train_model(flow, data[:256], data[256:], lr=2e-3, batch_size=64, epochs=6, patience=6,
+                       checkpoint=str(tmp_path / 'ck2d.pt'), verbose=False)
+    after = test_model(flow, data[:64], verbose=False)[0]
+    assert np.isfinite(hist['train']).all() and hist['train'][-1] < hist['train'][0] and after > before
