@@ -164,10 +164,9 @@ __global__ __launch_bounds__(256) void channel_affine_bwd_kernel(const float *__
 }
 
 // dw[co][ci][ky][kx] += sum_{b,p} dout[b,co,p] * h[b,ci,p + (ky-r, kx-r)],  h = mask * f(pre_a x + pre_b) (zero outside
-// the image).  Work-group: input channel ci, COT output channels, a slice of the batch; every thread walks pixels of the
-// slice with KS*KS*COT accumulators, then the group reduces and adds its partial to dw with fp32 atomics.
-constexpr int kCoT = 8;
-template <int KS>
+// the image).  Work-group: input channel ci, COT (8 or 16) output channels, a slice of the batch; every thread walks its
+// pixels over the samples of the slice with KS*KS*COT accumulators, then the group reduces and adds its partial to dw with fp32 atomics.
+template <int KS, int COT>
 __global__ __launch_bounds__(256) void conv2d_bwd_weight_kernel(const float *__restrict__ x, int64_t x_bstride,
                                                                 const float *__restrict__ dout, int64_t B, int Cin,
                                                                 int Cout, int H, int W,
@@ -175,56 +174,62 @@ __global__ __launch_bounds__(256) void conv2d_bwd_weight_kernel(const float *__r
                                                                 const float *__restrict__ mask, int b_per_group,
                                                                 float *__restrict__ dw) {
     constexpr int T = KS * KS, R = KS / 2;
-    __shared__ float sh[4][T * kCoT];
-    const int ci = blockIdx.x, co0 = blockIdx.y * kCoT;
+    __shared__ float sh[4][T * COT];
+    const int ci = blockIdx.x, co0 = blockIdx.y * COT;
     const int HW = H * W;
     const int64_t b0 = (int64_t)blockIdx.z * b_per_group;
     const int64_t b1 = b0 + b_per_group < B ? b0 + b_per_group : B;
     const float pa = pre ? pre[ci] : 1.f, pb = pre ? pre[Cin + ci] : 0.f;
-    float acc[T][kCoT];
+    float acc[T][COT];
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
-        for (int j = 0; j < kCoT; ++j) acc[t][j] = 0.f;
-    const int64_t n_el = (b1 - b0) * HW;
-    for (int64_t e = threadIdx.x; e < n_el; e += 256) {
-        const int64_t b = b0 + e / HW;
-        const int p = (int)(e % HW);
+        for (int j = 0; j < COT; ++j) acc[t][j] = 0.f;
+    // a thread keeps its pixels (p = tid, tid + 256, ...) over the samples of the slice: tap offsets / validity per pixel
+    // are computed once per pixel, not per sample
+    for (int p = threadIdx.x; p < HW; p += 256) {
         const int h = p / W, w = p - h * W;
-        const float *xc = x + b * x_bstride + (int64_t)ci * HW;
-        float hv[T];
+        int off[T];
+        float keep[T];
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx) {
                 const int hh = h + ky - R, ww = w + kx - R;
-                float v = 0.f;
-                if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
-                    v = xc[hh * W + ww];
-                    if (pre) v = fmaxf(fmaf(pa, v, pb), 0.f);
-                    if (mask) v *= mask[hh * W + ww];
-                }
-                hv[ky * KS + kx] = v;
+                const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+                const int o = ok ? hh * W + ww : p;
+                off[ky * KS + kx] = o;
+                keep[ky * KS + kx] = ok ? (mask ? mask[o] : 1.f) : 0.f;
             }
-        const float *dc = dout + (b * Cout + co0) * HW + p;
+        for (int64_t b = b0; b < b1; ++b) {
+            const float *xc = x + b * x_bstride + (int64_t)ci * HW;
+            float hv[T];
 #pragma unroll
-        for (int j = 0; j < kCoT; ++j) {
-            const float d = co0 + j < Cout ? dc[(int64_t)j * HW] : 0.f;
+            for (int t = 0; t < T; ++t) {
+                float v = xc[off[t]];
+                if (pre) v = fmaxf(fmaf(pa, v, pb), 0.f);
+                hv[t] = v * keep[t];
+            }
+            const float *dc = dout + (b * Cout + co0) * HW + p;
 #pragma unroll
-            for (int t = 0; t < T; ++t) acc[t][j] = fmaf(d, hv[t], acc[t][j]);
+            for (int j = 0; j < COT; ++j) {
+                const float d = co0 + j < Cout ? dc[(int64_t)j * HW] : 0.f;
+#pragma unroll
+                for (int t = 0; t < T; ++t) acc[t][j] = fmaf(d, hv[t], acc[t][j]);
+            }
         }
     }
     const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
-        for (int j = 0; j < kCoT; ++j) {
+        for (int j = 0; j < COT; ++j) {
             const float v = wave_sum_f(acc[t][j]);
-            if (ln == 0) sh[wv][t * kCoT + j] = v;
+            if (ln == 0) sh[wv][t * COT + j] = v;
         }
     __syncthreads();
-    if (threadIdx.x < T * kCoT) {
-        const int t = threadIdx.x / kCoT, j = threadIdx.x - t * kCoT;
+    if (threadIdx.x < T * COT) {
+        const int t = threadIdx.x / COT, j = threadIdx.x - t * COT;
         if (co0 + j < Cout) {
             const float v = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
             atomicAdd(&dw[((int64_t)(co0 + j) * Cin + ci) * T + t], v);
@@ -381,26 +386,31 @@ int dpk_conv2d_backward_weight(const float *in, int64_t in_bstride, const float 
                                float *dw, void *stream) {
     DPK_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, DPK_EINVAL, "conv2d_backward_weight: bad sizes");
     DPK_REQUIRE(ks == 1 || ks == 3, DPK_EUNSUPPORTED, "conv2d_backward_weight: kernel size %d (1 and 3 are built)", ks);
-    DPK_REQUIRE((int64_t)Cin * H * W < INT32_MAX && (int64_t)Cout * H * W < INT32_MAX && Cout / kCoT < 65535,
+    DPK_REQUIRE((int64_t)Cin * H * W < INT32_MAX && (int64_t)Cout * H * W < INT32_MAX && Cout / 8 < 65535,
                 DPK_EUNSUPPORTED, "conv2d_backward_weight: too large");
     if (B == 0) return DPK_OK;
     DPK_REQUIRE(in && dout && dw, DPK_EINVAL, "conv2d_backward_weight: null pointer");
     DPK_REQUIRE(in_bstride >= (int64_t)Cin * H * W, DPK_EINVAL, "conv2d_backward_weight: batch stride below Cin*H*W");
-    // enough work-groups to fill 256 CUs a few times over, at least 2048 pixel-samples each
-    const int groups = Cin * cdiv(Cout, kCoT);
+    // 16 output channels per work-group when the layer has them (half the operand loads per FMA), else 8; enough
+    // work-groups to fill 256 CUs a few times over, at least 2048 pixel-samples each
+    const int cot = Cout >= 16 ? 16 : 8;
+    const int groups = Cin * cdiv(Cout, cot);
     int64_t split = cdiv(2048, groups);
     const int64_t min_b = cdiv(2048, (int64_t)H * W);
     if (split > cdiv(B, min_b)) split = cdiv(B, min_b);
     if (split < 1) split = 1;
     if (split > 65535) split = 65535;
     const int b_per_group = cdiv(B, split);
-    const dim3 grid((unsigned)Cin, (unsigned)cdiv(Cout, kCoT), (unsigned)cdiv(B, b_per_group));
-    if (ks == 3)
-        DPK_LAUNCH(conv2d_bwd_weight_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, in, in_bstride, dout, B, Cin,
-                   Cout, H, W, pre, in_mask, b_per_group, dw);
-    else
-        DPK_LAUNCH(conv2d_bwd_weight_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, in, in_bstride, dout, B, Cin,
-                   Cout, H, W, pre, in_mask, b_per_group, dw);
+    const dim3 grid((unsigned)Cin, (unsigned)cdiv(Cout, cot), (unsigned)cdiv(B, b_per_group));
+#define DPK_BW_CASE(KS_, COT_)                                                                                      \
+    DPK_LAUNCH((conv2d_bwd_weight_kernel<KS_, COT_>), grid, dim3(256), 0, (hipStream_t)stream, in, in_bstride, dout, B, \
+               Cin, Cout, H, W, pre, in_mask, b_per_group, dw)
+    if (ks == 3) {
+        if (cot == 16) DPK_BW_CASE(3, 16); else DPK_BW_CASE(3, 8);
+    } else {
+        if (cot == 16) DPK_BW_CASE(1, 16); else DPK_BW_CASE(1, 8);
+    }
+#undef DPK_BW_CASE
     DPK_CHECK_LAUNCH("conv2d_bwd_weight_kernel");
     return DPK_OK;
 }
