@@ -5,7 +5,9 @@ flows/utils.py:186-208).  Here every pass over an image tensor is a HIP kernel b
 
 * batch statistics of nn.BatchNorm2d / BatchNormLayer2d (``ChannelStatsFn``), whose mean and variance stay in the graph;
   the BatchNorm2d + ReLU in front of a convolution stays folded into the convolution's operand load, now with the scale /
-  shift vectors computed from the batch statistics (small [C] tensor arithmetic, left to torch's autograd),
+  shift vectors computed from the batch statistics -- in training mode inside one node with the convolution
+  (``BnConv2dFn``: statistics, fold, convolution and the whole BatchNorm gradient as device passes), with running
+  statistics and gradients wanted as small [C] tensor arithmetic left to torch's autograd,
 * the convolution (``Conv2dFn``): input gradient = the forward kernel on the output gradient with transposed, flipped
   weights, then the backward of the folded operand map; weight gradient = ``dpk_conv2d_backward_weight``; the weight
   normalisation ``g v / |v|`` is [Cout, Cin, k, k] parameter arithmetic, left to torch's autograd,
