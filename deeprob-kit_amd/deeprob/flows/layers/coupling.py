@@ -1,6 +1,6 @@
 """RealNVP / NICE 1-D coupling layer behind the reference interface (deeprob/flows/layers/coupling.py:15-104),
 evaluated by one fused fp32-MFMA kernel per call (csrc/coupling.hip), and the 2-D coupling layers / blocks of RealNVP2d
-(:107-408; evaluation only, csrc/flows2d.hip)."""
+(:107-408; csrc/flows2d.hip, training direction csrc/flows2d_train.hip)."""
 from typing import Optional, Tuple
 
 import numpy as np

@@ -1,5 +1,6 @@
 """RealNVP-1D and RealNVP-2D behind the reference interface (deeprob/flows/models/realnvp.py:16-72, :75-220).
-RealNVP2d is evaluation only (density / sampling directions with running statistics, csrc/flows2d.hip)."""
+RealNVP2d: density / sampling directions with running statistics on csrc/flows2d.hip; training mode and gradients of
+the density direction on csrc/flows2d_train.hip (deeprob/hip/ops_flows2d_train.py)."""
 from typing import Optional, Tuple
 
 import numpy as np

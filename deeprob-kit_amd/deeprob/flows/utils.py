@@ -4,7 +4,8 @@
 signatures, attributes and `state_dict` names.  Eval-mode batch norm runs on the HIP kernels (a
 per-variable affine, foldable into the next coupling); Dequantize / Logit are cheap element-wise
 device ops left to PyTorch, as SURVEY 2#7 allows (Dequantize is stochastic in the reference too).
-The 2-D pieces (squeeze / un-squeeze, BatchNormLayer2d) run on csrc/flows2d.hip, evaluation only.
+The 2-D pieces (squeeze / un-squeeze, BatchNormLayer2d) run on csrc/flows2d.hip; their training direction
+(batch statistics, gradients) on csrc/flows2d_train.hip.
 """
 import abc
 from typing import Union, Tuple
