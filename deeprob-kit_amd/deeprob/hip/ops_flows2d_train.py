@@ -243,11 +243,32 @@ class BnConv2dFn(torch.autograd.Function):
         return dx, dgamma, dbeta, dw, dbias, None, (g if ctx.has_res else None), None
 
 
+class WeightNormFn(torch.autograd.Function):
+    """``w = g v / |v|`` per output channel (torch.nn.utils.weight_norm with dim 0, reference torch/utils.py:103-115) with
+    a hand-written backward: 9 small launches instead of the ~19 of autograd over reshape / norm / div / mul -- a
+    training step has 180 of these.  dg = <dw, v> / |v|,  dv = (g / |v|) dw - (g <dw, v> / |v|^3) v."""
+
+    @staticmethod
+    def forward(ctx, v, g):
+        cout = v.shape[0]
+        norm = v.reshape(cout, -1).norm(dim=1)
+        scale = g.reshape(-1) / norm
+        ctx.save_for_backward(v, scale, norm)
+        ctx.g_shape = g.shape
+        return v * scale.view(-1, 1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, dw):
+        v, scale, norm = ctx.saved_tensors
+        cout = v.shape[0]
+        s = (dw * v).reshape(cout, -1).sum(dim=1) / norm
+        dv = torch.addcmul(dw * scale.view(-1, 1, 1, 1), v, (-(scale * s / norm)).view(-1, 1, 1, 1))
+        return dv, s.reshape(ctx.g_shape)
+
+
 def effective_weight(p) -> torch.Tensor:
-    """``g v / |v|`` per output channel (torch.nn.utils.weight_norm with dim 0, reference torch/utils.py:103-115)."""
-    v, g = p.weight_v, p.weight_g
-    norm = v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, 1, 1, 1)
-    return v * (g / norm)
+    """The weight-normalised kernel of a WeightNormConv2d's parameters."""
+    return WeightNormFn.apply(p.weight_v, p.weight_g)
 
 
 def batchnorm_operand_map(bn, x: torch.Tensor) -> torch.Tensor:
