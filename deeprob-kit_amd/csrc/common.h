@@ -12,6 +12,11 @@ void set_error(const char *fmt, ...);
 // one-shot measurement hook (dpk_profile_next_kernel[_of]): the events the caller wants recorded around the next launch
 // of the kernel with this id (DPK_KERNEL_* in deeprob_hip.h), or nulls
 void profile_take(hipEvent_t *start, hipEvent_t *stop, int kernel_id = 1);
+// Per-DEVICE launch state (a process may drive several GPUs): the compute-unit count of the calling thread's current
+// device, and the raised dynamic-LDS limit of a kernel, set once per (kernel, device) -- hipFuncSetAttribute and the
+// CU count both belong to a device, not to the process.  ensure_dynamic_lds returns DPK_OK or DPK_ELAUNCH (error set).
+int device_cus();
+int ensure_dynamic_lds(const void *kernel, int bytes);
 
 #define DPK_REQUIRE(cond, code, ...)       \
     do {                                   \
@@ -83,6 +88,8 @@ struct RatWs {
     uint16_t *gc_tab;  //  same layout: mu^2/2 + log sqrt(2 pi)  (marginalised-evidence correction GEMM)
     float *gbias;      // [NCH][2][NT][16] per-(chunk, column) constants in the accumulator order of a lane
     float *gbias_row;  // [2][NT][16] the sums over all chunks
+    float *gbias_ks;   // [NKS][2][NT][16] the same per K-step of 16 features (small-batch kernel, ratspn_gemm_small.hip)
+    float *gbias_sl;   // [8][2][NT][16] ... per feature slice of its 8 waves (K-steps [w NKS/8, (w+1) NKS/8))
     int *gelig;        // [NT*RPT] 1: repetition is unit-scale with bounded means
     void *lg;          // tables of the leaf-only MFMA kernel (leaf_gemm_ws_bytes), null when the shape is outside it
     int g_nt, g_nksp;  // column tiles of 32, K-steps of 16 features (padded to whole chunks); 0 = not built
@@ -94,6 +101,8 @@ struct RatWs {
 constexpr int kGemmKS = 4;                // K-steps of 16 features per staged chunk
 constexpr int kGemmKC = 16 * kGemmKS;     // features per chunk
 constexpr int kGemmMaxNT = 4;             // column tiles of 32 the fused kernel is built for
+constexpr int kGemmSmallWaves = 8;        // small-batch kernel: waves per 32-sample tile = slices of the feature axis
+constexpr int kGemmSmallMaxK = 8;         // ... and the K-steps (of 16 features) one of them can hold in registers
 static inline bool gemm_shape_ok(int D, int depth, int reps, int I, int S) {
     if (depth != 2 || !(I == 2 || I == 4) || !(S == 2 || S == 4) || (D % 4) != 0 || reps < 1) return false;
     return (reps * 4 * I + 31) / 32 <= kGemmMaxNT;
@@ -185,6 +194,8 @@ inline RatWs carve_ratspn_ws(void *base, int D, int R, int d, int I, int QB, int
         w.gc_tab = (uint16_t *)take(tab);
         w.gbias = (float *)take((int64_t)((D + 31) / 32) * 2 * w.g_nt * 16 * 4);
         w.gbias_row = (float *)take((int64_t)2 * w.g_nt * 16 * 4);
+        w.gbias_ks = (float *)take((int64_t)((D + 15) / 16) * 2 * w.g_nt * 16 * 4);
+        w.gbias_sl = (float *)take((int64_t)kGemmSmallWaves * 2 * w.g_nt * 16 * 4);
         w.gelig = (int *)take((int64_t)w.g_nt * 8 * 4);
     }
     w.lg = nullptr;

@@ -562,23 +562,8 @@ static int x3_launch(const X3Args &a, hipStream_t st) {
     constexpr int STAGE = (kX3XB + W1CH) > W2CH ? (kX3XB + W1CH) : W2CH;
     const size_t lds = (size_t)kGemmStages * STAGE + (size_t)a.U * 4;
     auto kern = coupling_x3_kernel<AFFINE, NU>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
-            return DPK_ELAUNCH;
-        }
-        attr_done = true;
-    }
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-        else cus = 256;
-    }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024)) return rc;
+    const int cus = device_cus();
     const int grid = a.ntiles < cus ? a.ntiles : cus;
     hipEvent_t ev0, ev1;
     profile_take(&ev0, &ev1, DPK_KERNEL_COUPLING1D);

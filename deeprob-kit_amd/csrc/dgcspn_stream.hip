@@ -573,18 +573,6 @@ static bool stream_plan(int mode, const ProdGeom &q5, const ProdGeom *q6, Stream
     return ok;
 }
 
-static int device_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            cus = n;
-        else
-            cus = 256;
-    }
-    return cus;
-}
 
 static bool stream_shape_ok(const ProdGeom &q, int Cout, int64_t B, const float *in) {
     return q.depthwise && q.C == kStreamC && Cout == kStreamC && q.kh * q.kw <= 4 && B >= stream_min_batch() &&
@@ -614,16 +602,7 @@ static int stream_launch(StreamArgs &a, const StreamPlan &pl, int64_t B, hipStre
     a.per_wg = (int)cdiv(B, slices);
     a.slices = cdiv(B, a.per_wg);
     auto kern = spatial_stream_kernel<MODE>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kStreamLds);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
-            return DPK_ELAUNCH;
-        }
-        attr_done = true;
-    }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), kStreamLds)) return rc;
     const unsigned grid = (unsigned)(pl.T * align_up(a.slices, 8));
     static const bool debug = getenv("DPK_DGC_STREAM_DEBUG") != nullptr;
     if (debug)

@@ -37,8 +37,7 @@
 // partition's product + sum nodes in registers, swaps the S outputs with lane l ^ 32 and finishes the
 // root.  Work-groups are persistent (grid = min(tiles, CUs)); the DMA ring runs across tile boundaries.
 #include "common.h"
-#include "ratspn_nodes.h"
-#include "ratspn_gemm_common.h"
+#include "ratspn_gemm_fused.h"
 #include <math.h>
 #include <stdlib.h>
 
@@ -53,7 +52,7 @@ struct GemmPrepArgs {
     const float *loc, *scale;
     int D, d, reps, NT, NKSP, KS;
     uint16_t *mtab, *ctab;
-    float *bias, *bias_row;
+    float *bias, *bias_row, *bias_ks, *bias_sl;
     int *elig;
     const float *w[3];
     float *W[3], *LW[3];
@@ -179,6 +178,28 @@ __global__ __launch_bounds__(256) void ratspn_gemm_prep_kernel(const GemmPrepArg
         a.bias[((c * 2 + h) * a.NT + t) * 16 + u] = sum;
         csum[e] = sum;
     }
+    // the same per K-step of 16 features and per feature slice of the small-batch kernel (ratspn_gemm_small.hip)
+    const int NKS = (D + 15) / 16;
+    float *ksum = csum + NCH * 4 * I;   // [NKS][4I]
+    for (int e = threadIdx.x; e < NKS * 4 * I; e += blockDim.x) {
+        const int col = e % (4 * I), ks = e / (4 * I);
+        const int q = col / I, k = col - q * I;
+        float sum = 0.f;
+        if (real) {
+            const int f1 = min(D, (ks + 1) * 16);
+            for (int f = ks * 16; f < f1; ++f) {
+                const int p = posrow[f];
+                if (p >= 0 && p / d == q) {
+                    const float mu = locs[(q * I + k) * d + (p - q * d)];
+                    sum -= fmaf(0.5f * mu, mu, kLogSqrt2Pi);
+                }
+            }
+        }
+        const int h = q >> 1, qq = q & 1;
+        const int u = (ap * 2 + qq) * I + k;
+        a.bias_ks[((ks * 2 + h) * a.NT + t) * 16 + u] = sum;
+        ksum[e] = sum;
+    }
     __syncthreads();
     if (threadIdx.x < 4 * I) {
         const int col = threadIdx.x;
@@ -189,133 +210,16 @@ __global__ __launch_bounds__(256) void ratspn_gemm_prep_kernel(const GemmPrepArg
         const int u = (ap * 2 + qq) * I + k;
         a.bias_row[(h * a.NT + t) * 16 + u] = sum;
     }
+    for (int e = threadIdx.x; e < kGemmSmallWaves * 4 * I; e += blockDim.x) {
+        const int col = e % (4 * I), w = e / (4 * I);
+        const int q = col / I, k = col - q * I;
+        float sum = 0.f;
+        for (int ks = w * NKS / kGemmSmallWaves; ks < (w + 1) * NKS / kGemmSmallWaves; ++ks) sum += ksum[ks * 4 * I + col];
+        const int h = q >> 1, qq = q & 1;
+        const int u = (ap * 2 + qq) * I + k;
+        a.bias_sl[((w * 2 + h) * a.NT + t) * 16 + u] = sum;
+    }
     if (threadIdx.x == 0) a.elig[rho] = bad_s ? 0 : 1;
-}
-
-// ------------------------------------------------------------------------------------------------
-// main kernel
-// ------------------------------------------------------------------------------------------------
-struct GemmArgs {
-    const float *x;
-    int64_t B;
-    int D, d, reps, C, NCH, ntiles;
-    const uint16_t *mtab, *ctab;
-    const float *biasT;   // [2][NT][16] whole-row constants in the accumulator order of a lane
-    const float *biasC;   // [NCH][2][NT][16] the same per chunk (tiles with marginalised evidence)
-    const int *elig;
-    const float *W0;   // [reps*2][S][I*I] linear softmax weights (copied into LDS)
-    const float *LW0;  // log-softmax weights (exact fallback of a node, exact evaluation)
-    cfloat_p Wr, LWr;  // [C][reps*S*S]
-    float *out;
-    double *ll_sum;
-    // exact evaluation
-    const int64_t *mask;
-    const uint8_t *pad;
-    const float *loc, *scale;
-#ifdef DPK_TIMELINE
-    unsigned long long *dbg;   // [blocks][waves][64][8] s_memtime stamps (measurement builds)
-#endif
-    int ablate;       // measurement only (DPK_GEMM_ABLATE): 1 no compute, 2 no table DMA, 4 no x DMA
-    int *slow_flag;   // host-mapped hint word (may be null): launch number of the last launch that met NaN evidence
-    int launch_seq;
-};
-
-__device__ __forceinline__ void lse_merge(float &m, float &s, float m2, float s2) {
-    const float mm = fmaxf(m, m2);
-    if (mm == -INFINITY) {
-        s = 0.f;
-        return;
-    }
-    s = s * __expf(m - mm) + s2 * __expf(m2 - mm);
-    m = mm;
-}
-
-
-// ---- exp-domain helpers of the fast upper layers ---------------------------------------------------------------
-// e[i] = 2^((x[i] - max) log2 e); returns max (0 for an all -inf input, whose exponentials are then 0)
-template <int NI> __device__ __forceinline__ float exp2_children(const float (&x)[NI], float (&e)[NI]) {
-    float m = x[0];
-#pragma unroll
-    for (int i = 1; i < NI; ++i) m = fmaxf(m, x[i]);
-    const float m0 = (m == -INFINITY) ? 0.f : m;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) e[i] = __builtin_amdgcn_exp2f((x[i] - m0) * 1.4426950408889634f);
-    return m0;
-}
-
-// Exact per-element evaluation of the 32 samples of a wave (any scale, any evidence): lane (s, h) takes the
-// repetitions rho = 2m + h, the two lanes of a sample meet in one shuffle per class.  Slow by design.
-template <int I, int S, int NT>
-__device__ __noinline__ void gemm_exact_wave(const GemmArgs &a, int64_t bw0, int lane, LseScratch sc) {
-    constexpr int RPT = 8 / I;
-    constexpr int RH = (NT * RPT + 1) / 2;   // repetitions per lane half
-    const int s = lane & 31, h = lane >> 5;
-    const int64_t b = bw0 + s;
-    const bool valid = b < a.B;
-    const float *xr = a.x + (valid ? b : a.B - 1) * a.D;
-    const int d = a.d;
-    float n1[RH][2][S];
-#pragma unroll
-    for (int m = 0; m < RH; ++m) {
-        const int rho = 2 * m + h;
-        float leaf[4][I];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int k = 0; k < I; ++k) leaf[q][k] = 0.f;
-        if (rho < a.reps) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = rho * 4 + q;
-                for (int j = 0; j < d; ++j) {
-                    const int64_t o = (int64_t)r * d + j;
-                    if (a.pad != nullptr && a.pad[o]) continue;
-                    const float xv = xr[a.mask[o]];
-#pragma unroll
-                    for (int k = 0; k < I; ++k) {
-                        const int64_t po = ((int64_t)r * I + k) * d + j;
-                        const float mu = a.loc[po], sg = a.scale[po];
-                        const float dlt = xv - mu;
-                        leaf[q][k] += nan_to_num_f(fmaf(dlt * dlt, -0.5f / (sg * sg), -logf(sg) - kLogSqrt2Pi));
-                    }
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int64_t wo = ((int64_t)rho * 2 + p) * S * I * I;
-                prodsum_node<I, S>(leaf[2 * p], leaf[2 * p + 1], a.W0 + wo, a.LW0 + wo, sc, n1[m][p]);
-            }
-        }
-    }
-    const int M = a.reps * S * S;
-    double part = 0.0;
-    for (int cl = 0; cl < a.C; ++cl) {
-        float mm = -INFINITY, ss = 0.f;
-#pragma unroll
-        for (int m = 0; m < RH; ++m) {
-            const int rho = 2 * m + h;
-            if (rho < a.reps) {
-                float ea[S], ec[S], ma, mc, pm, ps;
-                exp_children<S>(n1[m][0], ea, ma);
-                exp_children<S>(n1[m][1], ec, mc);
-                const float *wr = (const float *)a.Wr + (int64_t)cl * M + rho * S * S;
-                const float *lwr = (const float *)a.LWr + (int64_t)cl * M + rho * S * S;
-                root_partial<S>(n1[m][0], n1[m][1], ea, ec, ma, mc, wr, lwr, sc, pm, ps);
-                lse_merge(mm, ss, pm, ps);
-            }
-        }
-        const float om = __shfl_xor(mm, 32, 64), os = __shfl_xor(ss, 32, 64);
-        lse_merge(mm, ss, om, os);
-        const float ll = (mm > -INFINITY) ? mm + logf(ss) : -INFINITY;
-        if (h == 0 && valid) {
-            a.out[b * a.C + cl] = ll;
-            part += (double)ll;
-        }
-    }
-    if (a.ll_sum != nullptr) {
-        part = wave_reduce_sum(part);
-        if (lane == 0) atomicAdd(a.ll_sum, part);   // (the count: once per launch, at the end of the kernel)
-    }
 }
 
 #ifdef DPK_TIMELINE
@@ -573,104 +477,8 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void ratspn_gemm_kernel(const 
                             for (int i = 0; i < 16; ++i) cst[t][i] += bc[t * 16 + i];
                     }
                 }
-                // Upper layers in the exp domain on the hardware's base-2 transcendentals; a node whose scaled sum
-                // vanishes (dominant pair under a vanishing weight) is redone exactly, out of line (gemm_node_exact).
-                constexpr float kL2E = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
-                // phase A, branch free so that the independent nodes interleave (one wave per SIMD: a dependent chain of
-                // transcendentals would otherwise run at its latency): every product + sum node of the lane's partitions
-                GEMM_STAMP(grow - 1, 0);
-                float n1[NT * RPT][S];
-                bool vanished = false;   // some node's scaled sum fell below 1e-30 (dominant pair under a vanishing weight)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-#pragma unroll
-                    for (int ap = 0; ap < RPT; ++ap) {
-                        const int rho = t * RPT + ap;
-                        float va[I], vc[I];
-#pragma unroll
-                        for (int k = 0; k < I; ++k) {
-                            va[k] = acc[t][(ap * 2) * I + k] + cst[t][(ap * 2) * I + k];
-                            vc[k] = acc[t][(ap * 2 + 1) * I + k] + cst[t][(ap * 2 + 1) * I + k];
-                        }
-                        float ea[I], ec[I];
-                        const float ma = exp2_children<I>(va, ea), mc = exp2_children<I>(vc, ec);
-                        const int wo = (min(rho, a.reps - 1) * 2 + h) * S * I * I;
-#pragma unroll
-                        for (int o = 0; o < S; ++o) {
-                            float v = 0.f;
-#pragma unroll
-                            for (int i = 0; i < I; ++i) {
-                                float tt = 0.f;
-#pragma unroll
-                                for (int j = 0; j < I; ++j) tt = fmaf(w0_l[wo + (o * I + i) * I + j], ec[j], tt);
-                                v = fmaf(ea[i], tt, v);
-                            }
-                            n1[rho][o] = fmaf(__builtin_amdgcn_logf(v), kLn2, ma + mc);
-                            vanished = vanished || (v < 1e-30f && rho < a.reps);
-                        }
-                    }
-                }
-                // both lanes of a sample finish every repetition (the root weights stay wave-uniform):
-                // v_permlane32_swap leaves partition 0's outputs in one register and partition 1's in the other
-                float ta[NT * RPT][S], tc[NT * RPT][S];
-#pragma unroll
-                for (int rho = 0; rho < NT * RPT; ++rho)
-#pragma unroll
-                    for (int o = 0; o < S; ++o) {
-                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                        const unsigned bits = __float_as_uint(n1[rho][o]);
-                        const u32x2 sw2 = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
-                        ta[rho][o] = __uint_as_float(sw2[0]);
-                        tc[rho][o] = __uint_as_float(sw2[1]);
-                    }
-                GEMM_STAMP(grow - 1, 1);
-                // root: per repetition (m, s) with logsumexp = m + ln s; the exponentials do not depend on the class
-                float ea[NT * RPT][S], ec[NT * RPT][S], mr[NT * RPT];
-                float mtop = -INFINITY;
-#pragma unroll
-                for (int rho = 0; rho < NT * RPT; ++rho) {   // (branch free: a column tile's spare repetitions get -inf)
-                    const float m2 = exp2_children<S>(ta[rho], ea[rho]) + exp2_children<S>(tc[rho], ec[rho]);
-                    mr[rho] = (rho < a.reps) ? m2 : -INFINITY;
-                    mtop = fmaxf(mtop, mr[rho]);
-                }
-                const float mtop0 = (mtop == -INFINITY) ? 0.f : mtop;
-                float scale[NT * RPT];
-#pragma unroll
-                for (int rho = 0; rho < NT * RPT; ++rho) scale[rho] = __builtin_amdgcn_exp2f((mr[rho] - mtop0) * kL2E);
-                const int M = a.reps * S * S;
-                const float qterm = -0.5f * qtot;
                 double part = 0.0;
-                GEMM_STAMP(grow - 1, 7);
-                // a vanished node anywhere in the wave: the wave's samples go through the exact evaluation instead
-                // (rare: a softmax weight below e^-69 on the dominant pair)
-                if (__any(vanished)) {
-                    const GemmArgs ac = a;
-                    gemm_exact_wave<I, S, NT>(ac, bw0, lane, sc);
-                    continue;
-                }
-                for (int cl = 0; cl < a.C; ++cl) {
-                    float tot = 0.f;
-#pragma unroll
-                    for (int rho = 0; rho < NT * RPT; ++rho) {
-                        const int wo = cl * M + min(rho, a.reps - 1) * S * S;   // (spare repetitions: scale == 0)
-                        float v = 0.f;
-#pragma unroll
-                        for (int i = 0; i < S; ++i) {
-                            float tt = 0.f;
-#pragma unroll
-                            for (int j = 0; j < S; ++j) tt = fmaf(a.Wr[wo + i * S + j], ec[rho][j], tt);
-                            v = fmaf(ea[rho][i], tt, v);
-                        }
-                        vanished = vanished || (v < 1e-30f && mr[rho] > -INFINITY);
-                        tot = fmaf(v, scale[rho], tot);
-                    }
-                    const float ll = ((mtop > -INFINITY) ? fmaf(__builtin_amdgcn_logf(tot), kLn2, mtop) : -INFINITY) + qterm;
-                    if (h == 0 && b < a.B) {
-                        a.out[b * a.C + cl] = ll;
-                        part += (double)ll;
-                    }
-                }
-                if (__any(vanished)) {   // (the exact evaluation overwrites what this wave stored and adds its own sum)
+                if (gemm_upper_fast<I, S, NT>(a, acc, cst, w0_l, qtot, h, b, part)) {
                     const GemmArgs ac = a;
                     gemm_exact_wave<I, S, NT>(ac, bw0, lane, sc);
                     continue;
@@ -722,23 +530,8 @@ static int gemm_launch(const GemmArgs &a, int reps, hipStream_t st) {
                        (size_t)(2 * NT * 16 + reps * 2 * S * I * I) * 4 + (size_t)kGemmWaves * 64 * 2 * NMAX * 4;
     DPK_REQUIRE(lds <= 160 * 1024, DPK_EUNSUPPORTED, "ratspn_gemm: %zu bytes of LDS", lds);
     auto kern = ratspn_gemm_kernel<I, S, NT>;
-    static bool attr_done = false;   // per instantiation
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
-            return DPK_ELAUNCH;
-        }
-        attr_done = true;
-    }
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-        else cus = 256;
-    }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024)) return rc;
+    const int cus = device_cus();
     const int grid = a.ntiles < cus ? a.ntiles : cus;
 #ifdef DPK_TIMELINE
     {
@@ -770,6 +563,11 @@ static int gemm_dispatch_nt(const GemmArgs &a, int reps, int NT, hipStream_t st)
     return DPK_EUNSUPPORTED;
 }
 
+// ratspn_gemm_small.hip: 32-sample tiles, features split over the waves (small batches)
+bool gemm_small_shape_ok(int D, int NT);
+int64_t gemm_small_max_batch();
+int ratspn_gemm_small_forward(const GemmArgs &a, int reps, int I, int S, int NT, hipStream_t st);
+
 // The caller (dpk_ratspn_forward) has validated the arguments and carved the workspace.
 int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const int64_t *mask, const uint8_t *pad,
                         const float *loc, const float *scale, const float *sum_weight0, const float *root_weight,
@@ -780,12 +578,13 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
         GemmPrepArgs p{};
         p.mask = mask; p.pad = pad; p.loc = loc; p.scale = scale;
         p.D = D; p.d = d; p.reps = reps; p.NT = NT; p.NKSP = w.g_nksp; p.KS = gemm_ks(NT);
-        p.mtab = w.gm_tab; p.ctab = w.gc_tab; p.bias = w.gbias; p.bias_row = w.gbias_row; p.elig = w.gelig;
+        p.mtab = w.gm_tab; p.ctab = w.gc_tab; p.bias = w.gbias; p.bias_row = w.gbias_row; p.bias_ks = w.gbias_ks;
+        p.bias_sl = w.gbias_sl; p.elig = w.gelig;
         p.w[0] = sum_weight0; p.W[0] = w.w[0]; p.LW[0] = w.lw[0]; p.rows[0] = reps * 2 * S; p.n[0] = I * I;
         p.w[1] = root_weight; p.W[1] = w.w[2]; p.LW[1] = w.lw[2]; p.rows[1] = C; p.n[1] = reps * S * S;
         const int nrb = NT * (8 / I);
         const int grid = nrb + cdiv(p.rows[0] + p.rows[1], 4);
-        const size_t lds = ((size_t)D + (size_t)4 * I * d + (size_t)cdiv(D, 32) * 4 * I) * 4;
+        const size_t lds = ((size_t)D + (size_t)4 * I * d + (size_t)cdiv(D, 32) * 4 * I + (size_t)cdiv(D, 16) * 4 * I) * 4;
         DPK_REQUIRE(lds <= 60 * 1024, DPK_EUNSUPPORTED, "ratspn_gemm: in_features=%d too large for the table kernel", D);
         if (I == 2) DPK_LAUNCH(ratspn_gemm_prep_kernel<2>, dim3(grid), dim3(256), lds, st, p);
         else DPK_LAUNCH(ratspn_gemm_prep_kernel<4>, dim3(grid), dim3(256), lds, st, p);
@@ -796,6 +595,7 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
     a.NCH = cdiv(D, 16 * gemm_ks(NT));
     a.ntiles = cdiv(B, kGemmTile);
     a.mtab = w.gm_tab; a.ctab = w.gc_tab; a.biasT = w.gbias_row; a.biasC = w.gbias; a.elig = w.gelig;
+    a.biasK = w.gbias_ks; a.biasS = w.gbias_sl;
     a.W0 = w.w[0]; a.LW0 = w.lw[0]; a.Wr = as_const(w.w[2]); a.LWr = as_const(w.lw[2]);
     a.out = out; a.ll_sum = ll_sum;
     a.mask = mask; a.pad = pad; a.loc = loc; a.scale = scale;
@@ -803,6 +603,9 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
         static const int ab = [] { const char *e = getenv("DPK_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
         a.ablate = ab;
     }
+    // below ~one 128-sample tile per compute unit the persistent ring kernel runs at the latency of its chunk walk:
+    // 32-sample tiles with the feature axis split over the waves take over (ratspn_gemm_small.hip)
+    if (B <= gemm_small_max_batch() && gemm_small_shape_ok(D, NT)) return ratspn_gemm_small_forward(a, reps, I, S, NT, st);
     if (I == 2) {
         if (S == 2) return gemm_dispatch_nt<2, 2>(a, reps, NT, st);
         return gemm_dispatch_nt<2, 4>(a, reps, NT, st);

@@ -52,24 +52,24 @@ __device__ __forceinline__ void glds16(unsigned voff, gcchar_p sbase_in, unsigne
                  : "memory");
 }
 
-// x (8 values of one sample) -> f16 halves xh + xl = x to 2^-22: xh = rn16(x), xl = rn16(x - xh)
+// x (8 values of one sample) -> f16 halves xh + xl = x to 2^-22: xh = rn16(x), xl = rn16(x - xh).
+// Plain vector conversions: on gfx950 hipcc selects v_cvt_pk_f16_f32 / v_cvt_f32_f16 (+ SDWA) / v_pk_add_f32 for them,
+// the sequence this function used to spell as inline asm -- but an asm statement's register writes are invisible to the
+// compiler's hazard recognizer: with a conversion scheduled two instructions in front of the MFMA that reads its result
+// (and an SDWA result consumed by the next VALU) the small-batch kernel computed wrong products for three of every eight
+// features, in K-steps whose schedule happened to place them so (found with a one-hot feature probe, round 3).
 __device__ __forceinline__ void split8(const float (&v)[8], half8 &xh, half8 &xl) {
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 hp, lp;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        unsigned h2, l2;
-        float b0, b1;
-        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h2) : "v"(v[2 * p]), "v"(v[2 * p + 1]));
-        asm("v_cvt_f32_f16_e32 %0, %1" : "=v"(b0) : "v"(h2));
-        asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(b1) : "v"(h2));
-        const float d0 = v[2 * p] - b0, d1 = v[2 * p + 1] - b1;
-        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l2) : "v"(d0), "v"(d1));
-        hp[p] = h2;
-        lp[p] = l2;
+        const gf32x2 a = {v[2 * p], v[2 * p + 1]};
+        const half2 h = __builtin_convertvector(a, half2);
+        const gf32x2 b = __builtin_convertvector(h, gf32x2);
+        const half2 l = __builtin_convertvector(a - b, half2);
+        xh[2 * p] = h[0];
+        xh[2 * p + 1] = h[1];
+        xl[2 * p] = l[0];
+        xl[2 * p + 1] = l[1];
     }
-    xh = __builtin_bit_cast(half8, hp);
-    xl = __builtin_bit_cast(half8, lp);
 }
 
 

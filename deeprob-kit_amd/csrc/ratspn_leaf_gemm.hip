@@ -404,23 +404,8 @@ static int leaf_gemm_launch(const LeafGemmArgs &a, int NG, hipStream_t st) {
     const size_t lds = (size_t)kGemmStages * (kGemmTile * 64 * KS + KS * (2 * NTG + 2) * 1024);
     DPK_REQUIRE(lds <= 160 * 1024, DPK_EUNSUPPORTED, "leaf_gemm: %zu bytes of LDS", lds);
     auto kern = ratspn_leaf_gemm_kernel<I, NTG>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
-            return DPK_ELAUNCH;
-        }
-        attr_done = true;
-    }
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-        else cus = 256;
-    }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024)) return rc;
+    const int cus = device_cus();
     const int per_group = cus / NG > 0 ? cus / NG : 1;
     const int gx = a.ntiles < per_group ? a.ntiles : per_group;
     hipEvent_t ev0, ev1;

@@ -2,6 +2,8 @@
 #include "common.h"
 #include <stdarg.h>
 #include <string.h>
+#include <mutex>
+#include <unordered_set>
 
 namespace dpk {
 static thread_local char g_err[512] = "";
@@ -10,6 +12,35 @@ void set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+constexpr int kMaxDevices = 64;
+int device_cus() {
+    static int cus[kMaxDevices] = {0};   // (a racing first call writes the same value twice)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
+    if (cus[dev] == 0) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus[dev];
+}
+
+int ensure_dynamic_lds(const void *kernel, int bytes) {
+    static std::mutex mu;
+    static std::unordered_set<uint64_t> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const uint64_t key = (uint64_t)(uintptr_t)kernel * 64u + (uint64_t)(dev & 63);
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count(key)) return DPK_OK;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(max dynamic LDS = %d): %s", bytes, hipGetErrorString(e));
+        return DPK_ELAUNCH;
+    }
+    done.insert(key);
+    return DPK_OK;
 }
 
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;

@@ -130,6 +130,30 @@ class RealNVP2d(NormalizingFlow):
             x = ops_flows2d.depth_to_space(x, self._perm_table(i), slices[i])
         return x, ildj
 
+    # The sampling direction of the 2-D path is evaluation only (no backward kernels): rsample() says so with the
+    # reference's own NotImplementedError instead of failing inside the first layer.
+    has_rsample = False
+
+    def rsample(self, n_samples: int, y: Optional[torch.Tensor] = None) -> torch.Tensor:
+        raise NotImplementedError("RealNVP2d on the HIP path has no reparametrised sampling (the sampling direction "
+                                  "of the 2-D flows is evaluation only); use sample()")
+
+    @torch.no_grad()
+    def sample(self, n_samples: int, y: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Reference flows/models/base.py:145-157.  Called on a model in training mode, the flow is sampled with the
+        running statistics of every batch-norm layer (the module is switched to eval for the call and back): the
+        reference would normalise the conditioners' activations with the statistics of the samples being drawn and
+        move the running averages -- a side effect of sampling that is not reproduced."""
+        was_training = self.training
+        base_training = bool(getattr(self.in_base, 'training', False))
+        if was_training:
+            self.train(False, base_training)
+        try:
+            return super().sample(n_samples, y)
+        finally:
+            if was_training:
+                self.train(True, base_training)
+
     def apply_forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """latent -> data (reference :195-220)."""
         from deeprob.hip import ops_flows2d

@@ -46,31 +46,30 @@ def coupling1d(x: torch.Tensor, layer, inverse: bool, in_affine: Optional[Tuple[
     units = lin1.weight.shape[0]
     n_masked, n_trans = layer._mask_counts()
     parity = layer._pair_parity()
-    if parity is not None and units in (32, 64, 96, 128) and D % 8 == 0:
+    if parity is not None and units in (32, 64, 96, 128) and D % 8 == 0 and x.data_ptr() % 16 == 0:
         # the reference's alternating masks: split-f16 MFMA kernel, packed tables kept while the weights (and the
-        # folded input affine) are unchanged
+        # folded input affine) are unchanged.  (Rows that are not 16-byte aligned -- a view at an odd storage offset --
+        # keep the generic kernel below; the test comes first so that nothing of this branch leaks into that route.)
         n = lib.dpk_coupling1d_pairs_workspace_bytes(D, units)
         if n < 0:
             check(int(n), 'dpk_coupling1d_pairs_workspace_bytes')
         pw = layer._ws_pairs
         ws = pw.get(n, x.device)
         out = torch.empty_like(x)
-        accumulate = ldj is not None
-        if ldj is None:
-            ldj = torch.empty(B, dtype=torch.float32, device=x.device)
-        sc, sh = in_affine if in_affine is not None else (None, None)
-        act = layer.scale_act.weight if layer.affine else None
-        w1, b1 = require_device_f32(lin1.weight, 'W1'), require_device_f32(lin1.bias, 'b1')
-        w2, b2 = require_device_f32(lin2.weight, 'W2'), require_device_f32(lin2.bias, 'b2')
-        if x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0:
+        if out.data_ptr() % 16 == 0:
+            ldj_p = ldj if ldj is not None else torch.empty(B, dtype=torch.float32, device=x.device)
+            sc, sh = in_affine if in_affine is not None else (None, None)
+            act = layer.scale_act.weight if layer.affine else None
+            w1, b1 = require_device_f32(lin1.weight, 'W1'), require_device_f32(lin1.bias, 'b1')
+            w2, b2 = require_device_f32(lin2.weight, 'W2'), require_device_f32(lin2.bias, 'b2')
             key = (_versions(w1, b1, w2, b2, sc, sh), parity, bool(layer.affine))
             flags = DPK_FLAG_PARAMS_CACHED if pw.params_key == key else 0
             pw.params_key = key
             check(lib.dpk_coupling1d_pairs_forward(
                 ptr(x), B, D, parity, ptr(w1), ptr(b1), ptr(w2), ptr(b2), units, ptr(act), ptr(sc), ptr(sh),
-                int(layer.affine), int(inverse), ptr(out), ptr(ldj), int(accumulate), ptr(ws), ws.numel(), flags,
+                int(layer.affine), int(inverse), ptr(out), ptr(ldj_p), int(ldj is not None), ptr(ws), ws.numel(), flags,
                 stream_ptr(x.device)), 'dpk_coupling1d_pairs_forward')
-            return out, ldj
+            return out, ldj_p
     n = lib.dpk_coupling1d_workspace_bytes(D, units, n_masked, n_trans)
     if n < 0:
         check(int(n), 'dpk_coupling1d_workspace_bytes')

@@ -178,11 +178,46 @@ def bn_reduce_sums(sums: torch.Tensor, n_local: int, n_total: int, group=None) -
 
 def synchronize_batchnorm(model: torch.nn.Module, group=None, enabled: bool = True):
     """Make every train-mode ``BatchNormLayer1d`` of ``model`` use the statistics of the whole (sharded) batch:
-    sets ``layer.sync_group`` (None switches it off).  ``train_model`` does this when it shards batches."""
-    from deeprob.flows.utils import BatchNormLayer1d
+    sets ``layer.sync_group`` (None switches it off).  ``train_model`` does this when it shards batches.
+
+    The 2-D layers (``BatchNormLayer2d`` and the ``nn.BatchNorm2d`` inside the convolutional conditioners of a
+    ``RealNVP2d``) are NOT synchronised: each rank normalises with the statistics of its own shard, as
+    ``DistributedDataParallel`` without ``SyncBatchNorm`` does, so sharded training of such a model differs from the
+    single-process run and the running statistics drift apart between ranks (rank 0's reach the checkpoint).  A
+    warning says so once per call."""
+    import warnings
+    from deeprob.flows.utils import BatchNormLayer1d, BatchNormLayer2d
+    unsynced = 0
     for m in model.modules():
         if isinstance(m, BatchNormLayer1d):
             m.sync_group = (group if group is not None else dist.group.WORLD) if enabled else None
+        elif isinstance(m, (BatchNormLayer2d, torch.nn.BatchNorm2d)):
+            unsynced += 1
+    if enabled and unsynced:
+        warnings.warn("synchronize_batchnorm: {} 2-D batch-norm layers keep per-rank statistics (sharded training of "
+                      "this model does not reproduce the single-process run)".format(unsynced), stacklevel=2)
+
+
+class local_batchnorm:
+    """Context manager: with ``active`` the synchronised ``BatchNormLayer1d`` layers of ``model`` use their local
+    batch only (no collective) inside the block -- for a batch that every rank evaluates in full."""
+
+    def __init__(self, model: torch.nn.Module, active: bool = True):
+        self.model, self.active, self._saved = model, active, []
+
+    def __enter__(self):
+        if self.active:
+            for m in self.model.modules():
+                if getattr(m, 'sync_group', None) is not None:
+                    self._saved.append((m, m.sync_group))
+                    m.sync_group = None
+        return self
+
+    def __exit__(self, *exc):
+        for m, g in self._saved:
+            m.sync_group = g
+        self._saved = []
+        return False
 
 
 def broadcast_model(model: torch.nn.Module, group=None, src: int = 0):

@@ -24,7 +24,7 @@ from deeprob.torch.utils import get_optimizer_class
 from deeprob.torch.callbacks import EarlyStopping
 from deeprob.torch.metrics import RunningAverageMetric
 from deeprob.parallel import (allreduce_gradients, shard_batch, broadcast_model, broadcast_seed,
-                              synchronize_batchnorm)
+                              synchronize_batchnorm, local_batchnorm)
 
 
 def _world() -> Tuple[int, int]:
@@ -147,7 +147,8 @@ def _fit(model, train_loader, valid_loader, optimizer, device, early_stopping, e
         raise ValueError("The number of epochs must be positve")
     rank, world = _world()
     if world > 1:
-        # identical replicas on every rank (parameters and buffers of rank 0), whole-batch BatchNorm statistics.
+        # identical replicas on every rank (parameters and buffers of rank 0), whole-batch statistics for every
+        # BatchNormLayer1d (2-D batch norms keep per-rank statistics: synchronize_batchnorm warns about them).
         # The caller's loaders must yield the same batches on every rank (train_model seeds its shuffle accordingly).
         broadcast_model(model)
         synchronize_batchnorm(model)
@@ -165,22 +166,33 @@ def _fit(model, train_loader, valid_loader, optimizer, device, early_stopping, e
         t0 = time.perf_counter()
         _train_mode(model, train_base)
         for item in train_loader:
-            inputs, targets = _batch(item, device, rank, world, supervised)
+            # A batch with fewer rows than ranks would leave a rank without a shard.  With synchronised BatchNorm that
+            # rank would skip the model -- and the collectives inside it -- while its peers wait in them.  Such a batch
+            # (a short last batch with drop_last=False, or batch_size < world) is therefore REPLICATED: every rank
+            # evaluates all of it with the statistics exchange switched off, the gradients and running statistics are
+            # identical everywhere, and rank 0 alone books its loss.  No rank is ever empty.
+            n_global = (item[0] if supervised else item).shape[0]
+            replicated = world > 1 and n_global < world
+            if replicated:
+                inputs, targets = _batch(item, device, 0, 1, supervised)
+            else:
+                inputs, targets = _batch(item, device, rank, world, supervised)
             n_local = inputs.shape[0]
             if graphed is not None and n_local > 0:
                 meters['train_loss'](graphed(inputs), num_samples=n_local)
                 continue
             optimizer.zero_grad()
             if n_local > 0:
-                outputs = model(inputs)
-                loss = model.loss(outputs, y=targets) if supervised else model.loss(outputs)
-                loss.backward()
+                with local_batchnorm(model, replicated):
+                    outputs = model(inputs)
+                    loss = model.loss(outputs, y=targets) if supervised else model.loss(outputs)
+                    loss.backward()
             if world > 1:
-                # every rank joins the collective, also one whose shard of a short last batch is empty
+                # every rank joins the collective (equal weights on a replicated batch: the average of identical values)
                 allreduce_gradients(model, weight=n_local)
             optimizer.step()
             model.apply_constraints()
-            if n_local > 0:
+            if n_local > 0 and (not replicated or rank == 0):
                 meters['train_loss'](loss, num_samples=n_local)           # stays on the device
                 if supervised:
                     with torch.no_grad():

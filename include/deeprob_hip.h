@@ -160,6 +160,12 @@ int dpk_root_backward(const float *in, const float *weight, const float *out, co
  * DPK_FLAG_PARAMS_CACHED honoured.  Pure function of its arguments, no device work.                     */
 int dpk_ratspn_forward_on_mfma(const float *x, int32_t D, int32_t depth, int32_t reps, int32_t I, int32_t S,
                                int32_t C, int32_t want_leaf_out, uint32_t flags);
+/* Batch size up to which the MFMA route takes its small-batch kernels (32-sample tiles, features split over the
+ * waves of a work-group: csrc/ratspn_gemm_small.hip, the small-batch path of csrc/ratspn_leaf_gemm.hip and of the
+ * folded product + sum / root layers) instead of the persistent 128-sample ring kernels.  Sets the threshold
+ * (0: ring kernels always; negative: back to the built-in default, also given by DPK_GEMM_SMALL_MAX) and returns
+ * the previous one.  Process-wide tuning knob: results of the two mappings agree to fp32 rounding.          */
+int64_t dpk_ratspn_small_batch_max(int64_t samples);
 int dpk_ratspn_forward(const float *x, int64_t B, int32_t D, const int64_t *mask,
                        const uint8_t *pad_mask, const float *loc, const float *scale,
                        const float *sum_weight0, const float *sum_weight1,

@@ -96,6 +96,24 @@ def test_sampling_runs_on_the_device():
     assert torch.isfinite(ll).all()
 
 
+def test_sampling_in_training_mode_and_rsample():
+    """sample() on a model left in training mode draws with the running statistics (and restores the mode); rsample()
+    is declared unsupported the reference's way (NotImplementedError) instead of failing inside a layer."""
+    model = flow2d_model((3, 8, 8), dict(n_flows=1, n_blocks=1, channels=8), 4).cuda()
+    torch.manual_seed(0)
+    want = model.sample(5)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    model.train()
+    torch.manual_seed(0)
+    got = model.sample(5)
+    assert model.training and all(m.training for m in model.layers.modules())
+    assert torch.equal(got, want)
+    assert all(torch.equal(v, before[k]) for k, v in model.state_dict().items())   # no running statistic moved
+    assert model.has_rsample is False
+    with pytest.raises(NotImplementedError):
+        model.rsample(2)
+
+
 def test_weight_tables_follow_the_parameters():
     """The packed convolution tables are cached per `_version`: an in-place update must be seen by the next call."""
     model = flow2d_model((3, 8, 8), dict(n_flows=1, n_blocks=1, channels=4), 9).cuda()

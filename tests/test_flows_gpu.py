@@ -101,6 +101,35 @@ def test_custom_masks_vs_oracle(D, pattern):
         assert torch.allclose(xr.cpu(), x, atol=5e-6) and torch.allclose(ldj, -ildj, atol=5e-6)
 
 
+def test_alternating_masks_on_a_view_at_an_odd_storage_offset():
+    """A contiguous x whose first element is not 16-byte aligned cannot take the column-pair MFMA kernel; the generic
+    kernel it falls through to must START its own log-det (ldj=None), not add into what the abandoned branch
+    allocated (round-2 advisor finding)."""
+    from deeprob.flows.layers.coupling import CouplingLayer1d
+    gen = torch.Generator().manual_seed(7)
+    D, B = 40, 33
+    layer = CouplingLayer1d(D, depth=1, units=32, affine=True).cuda().eval()
+    with torch.no_grad():
+        layer.scale_act.weight.fill_(0.6)
+        for p in layer.network.parameters():
+            p.copy_(torch.randn(p.shape, generator=gen) * 0.3)
+    lins = [(m.weight.detach().cpu(), m.bias.detach().cpu()) for m in layer.network if isinstance(m, torch.nn.Linear)]
+    flat = torch.randn(1 + B * D, generator=gen)
+    xc = flat[1:1 + B * D].view(B, D)
+    flat_d = torch.full((1 + B * D,), float('nan'), device='cuda')
+    flat_d[1:] = xc.reshape(-1).cuda()
+    xd = flat_d[1:1 + B * D].view(B, D)
+    assert xd.is_contiguous() and xd.data_ptr() % 16 != 0
+    wu, wildj = forc.coupling_backward(xc, layer.mask.cpu(), layer.inv_mask.cpu(), lins, torch.tensor([0.6]))
+    for _ in range(2):   # (a second call: whatever the caching allocator hands out now holds old values)
+        with torch.no_grad():
+            u, ildj = layer.apply_backward(xd)
+        assert rel_err(u.cpu().numpy(), wu.numpy()) <= TOL
+        assert rel_err(ildj.cpu().numpy(), wildj.numpy()) <= TOL
+        junk = torch.full((B,), 1e6, device='cuda')   # poison the block the next call's ldj may reuse
+        del junk
+
+
 @pytest.mark.parametrize('B', [1, 63, 65, 1000])
 def test_ragged_batches_vs_oracle(golden, B):
     g = golden('realnvp1d_15')

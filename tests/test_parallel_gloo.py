@@ -232,3 +232,65 @@ def test_sync_batchnorm_two_ranks_equal_single_process(tmp_path):
     n_run = 4 * 12
     assert np.max(np.abs(r0[-n_run:] - ref[-n_run:])) <= 1e-12
     assert np.max(np.abs(ref)) > 1e-3   # (the comparison is not of zeros)
+
+
+def _short_batch_worker(rank, world, port, out_dir):
+    """train_generative over a loader whose last batch has ONE row, model with a synchronised batch statistic."""
+    from tests import conftest  # noqa: F401  (sys.path)
+    from deeprob.flows.utils import BatchNormLayer1d
+    from deeprob.torch.routines import train_generative
+    from deeprob.torch.callbacks import EarlyStopping
+    if world > 1:
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+
+    class CpuCentering(BatchNormLayer1d):
+        """BatchNormLayer1d's role on the CPU: centres by the (detached) mean of the whole batch; with a sync_group
+        the mean comes from an all-reduce that EVERY rank must join -- the collective the routine has to keep in
+        step (the HIP layer exchanges its moments the same way, deeprob.parallel.bn_gather_moments)."""
+
+        def apply_backward(self, x):
+            if not self.training:      # (the real layer uses its running statistics here: nothing batch dependent)
+                return x + self.bias, torch.zeros(x.shape[0])
+            stat = torch.cat([x.detach().sum(0), torch.tensor([float(x.shape[0])], dtype=x.dtype)])
+            if self.sync_group is not None:
+                dist.all_reduce(stat, group=self.sync_group)
+            return x - stat[:-1] / stat[-1] + self.bias, torch.zeros(x.shape[0])
+
+    class Toy(_ToyDensity):
+        def __init__(self, d):
+            super().__init__(d)
+            self.norm = CpuCentering(d)
+
+        def forward(self, x):
+            return super().forward(self.norm.apply_backward(x)[0])
+
+    gen = torch.Generator().manual_seed(9)
+    train = torch.randn(97, 5, generator=gen) * 1.3 + 0.4      # 97 = 3 batches of 32 + ONE row
+    valid = torch.randn(20, 5, generator=gen)
+    torch.manual_seed(3)
+    model = Toy(5)
+    loader = torch.utils.data.DataLoader(train, 32, shuffle=True, drop_last=False)
+    vloader = torch.utils.data.DataLoader(valid, 20, shuffle=False)
+    opt = torch.optim.SGD(model.parameters(), lr=5e-2)
+    es = EarlyStopping(model, patience=50, filepath=os.path.join(out_dir, 'short_w{}.pt'.format(world)))
+    hist = train_generative(model, loader, vloader, opt, torch.device('cpu'), es, epochs=3, verbose=False)
+    vec = torch.cat([p.detach().reshape(-1) for p in model.parameters()] +
+                    [torch.tensor(hist['train'] + hist['valid'])]).double().numpy()
+    np.save(os.path.join(out_dir, 'short_w{}_r{}.npy'.format(world, rank)), vec)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_one_row_last_batch_with_synchronised_statistics(tmp_path):
+    """A last batch smaller than the world (round-2 advisor finding: the rank with the empty shard skipped the model
+    and its peers hung in the batch-norm all-reduce).  Such a batch is replicated on every rank instead; the run
+    finishes and equals the single-process run."""
+    _short_batch_worker(0, 1, 0, str(tmp_path))
+    mp.start_processes(_short_batch_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, start_method='spawn')
+    ref = np.load(tmp_path / 'short_w1_r0.npy')
+    r0, r1 = np.load(tmp_path / 'short_w2_r0.npy'), np.load(tmp_path / 'short_w2_r1.npy')
+    assert np.allclose(r0, r1, rtol=0, atol=1e-12)
+    assert np.allclose(r0, ref, rtol=1e-5, atol=1e-6)
