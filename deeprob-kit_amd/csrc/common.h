@@ -18,6 +18,36 @@ void profile_take(hipEvent_t *start, hipEvent_t *stop, int kernel_id = 1);
 int device_cus();
 int ensure_dynamic_lds(const void *kernel, int bytes);
 
+// ---- device-side check of cached parameter tables (DPK_FLAG_PARAMS_VERIFY) ------------------------------------------
+// The host can only tell that a parameter MAY have changed from its address / version counter; a write through
+// `param.data` bumps neither.  An entry point that keeps tables derived from parameters therefore fingerprints the live
+// parameter bytes on the device on every call (one small launch: 64-bit position-dependent hash, last block compares it
+// with the hash of the bytes the tables were built from) and its table kernels start with `if (gate_closed(gate))
+// return;` -- they run for real only when the bytes differ.  params_gate() returns the device word the kernels test
+// (1 = rebuild), or nullptr when no slot could be had (the caller then rebuilds unconditionally).  `key` names the table
+// set (a pointer into the workspace that holds it); verify = false records the hash of a build that happens anyway.
+struct FpSeg {
+    const void *p;
+    int64_t bytes;
+};
+constexpr int kFpMaxSegs = 10;
+const unsigned *params_gate(const void *key, const FpSeg *segs, int nseg, bool verify, hipStream_t st);
+__device__ __forceinline__ bool gate_closed(const unsigned *gate) { return gate != nullptr && *gate == 0u; }
+// zero `bytes` of device memory unless the gate is closed (the stream-ordered memset of a gated table build)
+int gated_zero(void *p, int64_t bytes, const unsigned *gate, hipStream_t st);
+// What an entry point does with its tables for these flags: DPK_FLAG_PARAMS_CACHED -> nothing; DPK_FLAG_PARAMS_VERIFY ->
+// fingerprint, table kernels gated on the verdict; neither -> table kernels unconditionally (the hash is recorded).
+struct TablePlan {
+    bool run;
+    const unsigned *gate;
+};
+inline TablePlan plan_tables(uint32_t flags, const void *key, const FpSeg *segs, int nseg, hipStream_t st) {
+    if (flags & DPK_FLAG_PARAMS_CACHED) return {false, nullptr};
+    const bool verify = (flags & DPK_FLAG_PARAMS_VERIFY) != 0;
+    const unsigned *g = params_gate(key, segs, nseg, verify, st);
+    return {true, verify ? g : nullptr};   // (no slot to be had: nullptr = rebuild unconditionally)
+}
+
 #define DPK_REQUIRE(cond, code, ...)       \
     do {                                   \
         if (!(cond)) {                     \

@@ -65,6 +65,7 @@ struct X3PackArgs {
     char *w2t;           // [NPT][W2CH bytes]
     float *b1f;          // [U] b1 + W1 (mask * in_shift)
     float *scales;       // [2] power-of-two scales of the W1 / W2 tables (largest entry -> [2^12, 2^13))
+    const unsigned *gate;   // table kernels return at once while *gate == 0 (common.h: params_gate)
 };
 
 // The f16 halves of a split are exact to 2^-22 relative only while the low half is a normal f16 number (|v| >= 0.25);
@@ -75,6 +76,7 @@ struct X3PackArgs {
 // parameter changed.
 __global__ __launch_bounds__(1024) void coupling_x3_scale_kernel(const X3PackArgs a) {
     __shared__ float red[2][16];
+    if (gate_closed(a.gate)) return;
     const int D = a.D, U = a.U, K1 = a.g.K1, N2 = a.g.N2;
     float m1 = 0.f, m2 = 0.f;
     for (int64_t e = threadIdx.x; e < (int64_t)U * K1; e += blockDim.x) {
@@ -108,6 +110,7 @@ __global__ __launch_bounds__(1024) void coupling_x3_scale_kernel(const X3PackArg
 }
 
 __global__ __launch_bounds__(256) void coupling_x3_pack_kernel(const X3PackArgs a) {
+    if (gate_closed(a.gate)) return;
     const int D = a.D, U = a.U, NU = a.g.NU, K1 = a.g.K1, N2 = a.g.N2;
     const int64_t n1 = (int64_t)a.g.NCH1 * 2 * NU * 64;           // W1 fragment entries (hi + lo written together)
     const int64_t n2 = (int64_t)a.g.NPT * (U / 16) * 2 * 64;      // W2 fragment entries
@@ -632,8 +635,12 @@ extern "C" int dpk_coupling1d_pairs_forward(const float *x, int64_t B, int32_t D
     DPK_REQUIRE(ws_bytes >= w.bytes, DPK_EWORKSPACE, "coupling1d_pairs: workspace %lld < %lld", (long long)ws_bytes,
                 (long long)w.bytes);
     hipStream_t st = (hipStream_t)stream;
-    if (!(flags & DPK_FLAG_PARAMS_CACHED)) {
+    const FpSeg segs[6] = {{W1, (int64_t)units * D * 4}, {b1, (int64_t)units * 4}, {W2, (int64_t)(affine ? 2 : 1) * D * units * 4},
+                           {b2, (int64_t)(affine ? 2 : 1) * D * 4}, {in_scale, (int64_t)D * 4}, {in_shift, (int64_t)D * 4}};
+    const TablePlan tp = plan_tables(flags, ws, segs, 6, st);
+    if (tp.run) {
         X3PackArgs p{};
+        p.gate = tp.gate;
         p.W1 = W1; p.b1 = b1; p.W2 = W2; p.b2 = b2; p.in_scale = in_scale; p.in_shift = in_shift;
         p.D = D; p.U = units; p.pm = masked_parity; p.affine = affine; p.g = g;
         p.w1t = w.w1t; p.w2t = w.w2t; p.b1f = w.b1f; p.scales = w.scales;

@@ -298,7 +298,8 @@ static void launch_product_bwd(const float *g, int64_t B, const ProdGeom &q, flo
 // ------------------------------------------------------------------------------------------------
 // softmax over the input channels for every (o, p): W, LW [Cout, Cin, HW]
 __global__ void spatial_softmax_kernel(const float *__restrict__ w, int Cout, int Cin, int HW,
-                                       float *__restrict__ Wl, float *__restrict__ LW) {
+                                       float *__restrict__ Wl, float *__restrict__ LW, const unsigned *gate = nullptr) {
+    if (gate_closed(gate)) return;   // (tables still match the live weights: common.h params_gate)
     const int64_t n = (int64_t)Cout * HW;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         const int p = (int)(e % HW), o = (int)(e / HW);
@@ -698,8 +699,9 @@ __global__ __launch_bounds__(256) void spatial_prodsum_fwd_kernel(const float *_
 // ------------------------------------------------------------------------------------------------
 // one 256-thread block per row (rows are thousands of entries long, there are only a few of them)
 __global__ __launch_bounds__(256) void rowwise_logsoftmax_kernel(const float *__restrict__ w, int rows, int n,
-                                                                  float *__restrict__ LW) {
+                                                                  float *__restrict__ LW, const unsigned *gate = nullptr) {
     __shared__ float red[4];
+    if (gate_closed(gate)) return;
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *src = w + (int64_t)row * n;
     float mx = -INFINITY;
@@ -1044,10 +1046,15 @@ extern "C" int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C
     DPK_REQUIRE(in && out, DPK_EINVAL, "spatial_prodsum: null pointer");
     float *Wl = (float *)ws, *LW = (float *)((char *)ws + seg);
     hipStream_t st = (hipStream_t)stream;
-    // (DPK_FLAG_PARAMS_CACHED: the workspace still holds the tables an earlier call built from this very weight)
-    if (!(flags & DPK_FLAG_PARAMS_CACHED))
-        DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW, 256)), dim3(256), 0, st, weight,
-                   Cout, C, OHW, Wl, LW);
+    // (DPK_FLAG_PARAMS_CACHED: the workspace still holds the tables an earlier call built from this very weight;
+    // DPK_FLAG_PARAMS_VERIFY: believed so, checked on the device)
+    {
+        const FpSeg segs[1] = {{weight, (int64_t)Cout * C * OHW * 4}};
+        const TablePlan tp = plan_tables(flags, ws, segs, 1, st);
+        if (tp.run)
+            DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW, 256)), dim3(256), 0, st, weight,
+                       Cout, C, OHW, Wl, LW, tp.gate);
+    }
     // large batches of the 8 -> 8 channel level: pixel-resident weights, taps staged through LDS (dgcspn_stream.hip)
     if (stream_prodsum_ok(q, Cout, B, in)) return stream_prodsum_forward(in, B, q, Wl, LW, out, st);
     const int Bi = (int)B;
@@ -1272,10 +1279,14 @@ extern "C" int dpk_spatial_sumprodroot_forward(const float *in, int64_t B, int32
     const int64_t seg = align_up((int64_t)Cout * C * OHW5 * 4, 256);
     float *Wl = (float *)ws, *LW = (float *)((char *)ws + seg), *LWr = (float *)((char *)ws + 2 * seg);
     hipStream_t st = (hipStream_t)stream;
-    if (!(flags & DPK_FLAG_PARAMS_CACHED)) {   // else: tables of an earlier call from these very weights
-        DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW5, 256)), dim3(256), 0, st, sum_weight,
-                   Cout, C, OHW5, Wl, LW);
-        DPK_LAUNCH(rowwise_logsoftmax_kernel, dim3(K), dim3(256), 0, st, root_weight, K, Cout * OHW6, LWr);
+    {   // (flags as in dpk_spatial_prodsum_forward)
+        const FpSeg segs[2] = {{sum_weight, (int64_t)Cout * C * OHW5 * 4}, {root_weight, (int64_t)K * Cout * OHW6 * 4}};
+        const TablePlan tp = plan_tables(flags, ws, segs, 2, st);
+        if (tp.run) {
+            DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW5, 256)), dim3(256), 0, st, sum_weight,
+                       Cout, C, OHW5, Wl, LW, tp.gate);
+            DPK_LAUNCH(rowwise_logsoftmax_kernel, dim3(K), dim3(256), 0, st, root_weight, K, Cout * OHW6, LWr, tp.gate);
+        }
     }
     {
         // streaming kernel when the workspace carries its per-wave partials (.._workspace_bytes_batch)

@@ -57,12 +57,14 @@ struct GemmPrepArgs {
     const float *w[3];
     float *W[3], *LW[3];
     int rows[3], n[3];
+    const unsigned *gate;   // table kernels return at once while *gate == 0 (common.h: params_gate)
 };
 
 
 template <int I>
 __global__ __launch_bounds__(256) void ratspn_gemm_prep_kernel(const GemmPrepArgs a) {
     constexpr int RPT = 8 / I;       // repetitions per 32-column tile (4 regions x I channels each)
+    if (gate_closed(a.gate)) return;
     const int nrb = a.NT * RPT;
     if ((int)blockIdx.x >= nrb) {
         // softmax rows: one wave per row (torch.log_softmax at ratspn.py:375 and :455)
@@ -574,8 +576,14 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
                         int reps, int I, int S, int C, float *out, double *ll_sum, uint32_t flags, hipStream_t st) {
     const int d = (D + (4 - D % 4) % 4) / 4;
     const int NT = w.g_nt;
-    if (!(flags & DPK_FLAG_PARAMS_CACHED)) {
+    const int R = reps * 4;
+    const FpSeg segs[6] = {{mask, (int64_t)R * d * 8}, {pad, (int64_t)R * d}, {loc, (int64_t)R * I * d * 4},
+                           {scale, (int64_t)R * I * d * 4}, {sum_weight0, (int64_t)reps * 2 * S * I * I * 4},
+                           {root_weight, (int64_t)C * reps * S * S * 4}};
+    const TablePlan tp = plan_tables(flags, w.gm_tab, segs, 6, st);
+    if (tp.run) {
         GemmPrepArgs p{};
+        p.gate = tp.gate;
         p.mask = mask; p.pad = pad; p.loc = loc; p.scale = scale;
         p.D = D; p.d = d; p.reps = reps; p.NT = NT; p.NKSP = w.g_nksp; p.KS = gemm_ks(NT);
         p.mtab = w.gm_tab; p.ctab = w.gc_tab; p.bias = w.gbias; p.bias_row = w.gbias_row; p.bias_ks = w.gbias_ks;

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kGemmSmallWaves * 64) void ratspn_gemm_small_kernel
                     }
                 }
             }
-            load_frags(kk);
+            if (kk < nk) load_frags(kk);   // (wave-uniform)
             __builtin_amdgcn_sched_barrier(0);   // (keep the request order)
         }
         SM_STAMP(1);   // loads requested

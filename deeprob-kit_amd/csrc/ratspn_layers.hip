@@ -18,7 +18,8 @@ template <typename T> __host__ __device__ __forceinline__ const DPK_CONST T *as_
 }
 
 __global__ void softmax_rows_kernel2(const float *__restrict__ w, int rows, int n, float *__restrict__ W,
-                                     float *__restrict__ LW) {
+                                     float *__restrict__ LW, const unsigned *gate = nullptr) {
+    if (gate_closed(gate)) return;   // (tables still match the live weights: common.h params_gate)
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -50,8 +51,10 @@ __device__ __forceinline__ float block_reduce(float v, bool is_max, float *red) 
     return r;
 }
 __global__ __launch_bounds__(1024) void softmax_rows_wide_kernel(const float *__restrict__ w, int rows, int n,
-                                                                 float *__restrict__ W, float *__restrict__ LW) {
+                                                                 float *__restrict__ W, float *__restrict__ LW,
+                                                                 const unsigned *gate = nullptr) {
     __shared__ float red[16];
+    if (gate_closed(gate)) return;
     const int row = blockIdx.x;
     const float *src = w + (int64_t)row * n;
     float m = -INFINITY;
@@ -78,11 +81,12 @@ __global__ __launch_bounds__(1024) void logsoftmax_jacobian_wide_kernel(const fl
     for (int i = threadIdx.x; i < n; i += blockDim.x)
         gW[(int64_t)row * n + i] = glw[(int64_t)row * n + i] - W[(int64_t)row * n + i] * s;
 }
-static void launch_softmax_rows(const float *weight, int rows, int n, float *W, float *LW, hipStream_t st) {
+static void launch_softmax_rows(const float *weight, int rows, int n, float *W, float *LW, hipStream_t st,
+                                const unsigned *gate = nullptr) {
     if (n >= 2048 && rows <= 1024)
-        DPK_LAUNCH(softmax_rows_wide_kernel, dim3(rows), dim3(1024), 0, st, weight, rows, n, W, LW);
+        DPK_LAUNCH(softmax_rows_wide_kernel, dim3(rows), dim3(1024), 0, st, weight, rows, n, W, LW, gate);
     else
-        DPK_LAUNCH(softmax_rows_kernel2, dim3(cdiv(rows, 4)), dim3(256), 0, st, weight, rows, n, W, LW);
+        DPK_LAUNCH(softmax_rows_kernel2, dim3(cdiv(rows, 4)), dim3(256), 0, st, weight, rows, n, W, LW, gate);
 }
 
 // ------------------------------------------------------------------------------------
@@ -857,7 +861,7 @@ namespace dpk {
 bool upper_mfma_shape_ok(bool root, int N, int S);
 int64_t upper_mfma_frag_bytes(int R, int N, int S);
 int upper_mfma_forward(bool root, const float *in, const float *W, const float *LW, int64_t B, int R, int N, int S,
-                       float *out, void *frag, bool frag_cached, hipStream_t st);
+                       float *out, void *frag, bool frag_cached, hipStream_t st, const unsigned *gate = nullptr);
 }
 
 static int prod_fused_common(bool root, const float *in, const float *weight, int64_t B, int R, int N, int S,
@@ -874,9 +878,12 @@ static int prod_fused_common(bool root, const float *in, const float *weight, in
     DPK_REQUIRE(in && out, DPK_EINVAL, "%s: null pointer", who);
     float *W = (float *)ws, *LW = (float *)((char *)ws + seg);
     hipStream_t st = (hipStream_t)stream;
-    // DPK_FLAG_PARAMS_CACHED: softmax rows (and MFMA fragments) of an earlier call from this very weight are in ws
-    const bool cached = flags & DPK_FLAG_PARAMS_CACHED;
-    if (!cached) launch_softmax_rows(weight, rows, n, W, LW, st);
+    // DPK_FLAG_PARAMS_CACHED: softmax rows (and MFMA fragments) of an earlier call from this very weight are in ws;
+    // DPK_FLAG_PARAMS_VERIFY: believed so, checked on the device (table kernels gated on the verdict)
+    const FpSeg segs[1] = {{weight, (int64_t)rows * n * 4}};
+    const TablePlan tp = plan_tables(flags, ws, segs, 1, st);
+    const bool cached = !tp.run;
+    if (!cached) launch_softmax_rows(weight, rows, n, W, LW, st, tp.gate);
     {
         static const bool mfma = [] {
             const char *e = getenv("DPK_RATSPN_GEMM");
@@ -885,7 +892,7 @@ static int prod_fused_common(bool root, const float *in, const float *weight, in
         const int64_t fb = upper_mfma_frag_bytes(R, N, S);
         if (mfma && upper_mfma_shape_ok(root, N, S) && ws_bytes >= 2 * seg + fb &&
             (reinterpret_cast<uintptr_t>(in) & 15) == 0)
-            return upper_mfma_forward(root, in, W, LW, B, R, N, S, out, (char *)ws + 2 * seg, cached, st);
+            return upper_mfma_forward(root, in, W, LW, B, R, N, S, out, (char *)ws + 2 * seg, cached, st, tp.gate);
     }
     const dim3 block(256);
 #define DPK_LAUNCH_PS(NMAX)                                                                                         \

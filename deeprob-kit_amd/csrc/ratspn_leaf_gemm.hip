@@ -35,6 +35,7 @@ struct LeafPrepArgs {
     float *bias;             // [NG][NCH][2][NTG][16]  per-(chunk, column) constants in accumulator order
     float *bias_row;         // [NG][2][NTG][16]
     int *elig;               // [R]
+    const unsigned *gate;    // table kernels return at once while *gate == 0 (common.h: params_gate)
 };
 
 __global__ __launch_bounds__(256) void ratspn_leaf_gemm_prep_kernel(const LeafPrepArgs a) {
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(256) void ratspn_leaf_gemm_prep_kernel(const LeafPr
     float *locs = reinterpret_cast<float *>(featpos + a.D);     // [I][d]
     float *csum = locs + a.I * a.d;                             // [NCH][I]
     __shared__ int bad_s;
+    if (gate_closed(a.gate)) return;
     const int r = blockIdx.x, D = a.D, d = a.d, I = a.I, NTG = a.NTG;
     for (int f = threadIdx.x; f < D; f += blockDim.x) featpos[f] = -1;
     if (threadIdx.x == 0) bad_s = 0;
@@ -431,9 +433,13 @@ int ratspn_leaf_gemm_forward(void *ws, const float *x, int64_t B, int D, const i
     uint16_t *mtab = (uint16_t *)p, *ctab = (uint16_t *)(p + tab);
     float *biasC = (float *)(p + 2 * tab), *biasT = (float *)(p + 2 * tab + bias);
     int *elig = (int *)(p + 2 * tab + bias + brow);
-    if (!(flags & DPK_FLAG_PARAMS_CACHED)) {
-        DPK_REQUIRE(hipMemsetAsync(p, 0, (size_t)(2 * tab + bias + brow), st) == hipSuccess, DPK_ELAUNCH, "memset");
+    const FpSeg segs[4] = {{mask, (int64_t)R * d * 8}, {pad, (int64_t)R * d}, {loc, (int64_t)R * I * d * 4},
+                           {scale, (int64_t)R * I * d * 4}};
+    const TablePlan tp = plan_tables(flags, ws, segs, 4, st);
+    if (tp.run) {
+        if (int rc = gated_zero(p, 2 * tab + bias + brow, tp.gate, st)) return rc;
         LeafPrepArgs pa{};
+        pa.gate = tp.gate;
         pa.mask = mask; pa.pad = pad; pa.loc = loc; pa.scale = scale;
         pa.D = D; pa.d = d; pa.R = R; pa.I = I; pa.NTG = NTG; pa.NG = NG; pa.NKSP = NKSP; pa.KS = KS;
         pa.mtab = mtab; pa.ctab = ctab; pa.bias = biasC; pa.bias_row = biasT; pa.elig = elig;

@@ -37,7 +37,8 @@ constexpr float kUpScale = 32768.f, kUpScaleLog2 = 15.f, kUpUnscale = 1.f / (327
 //   sum layer : Wl [P][S][N*N]      -> frag [P][S*N/32 tiles][2][64][8]
 //   root layer: Wl [C][P][N*N]      -> frag [P][ceil(C*N/32) tiles][2][64][8]
 __global__ __launch_bounds__(256) void upper_pack_kernel(const float *__restrict__ Wl, int P, int N, int S, int root,
-                                                         int tiles, uint16_t *__restrict__ frag) {
+                                                         int tiles, uint16_t *__restrict__ frag, const unsigned *gate) {
+    if (gate_closed(gate)) return;   // (tables still match the live weights: common.h params_gate)
     const int64_t total = (int64_t)P * tiles * 64;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int l = (int)(e & 63);
@@ -295,11 +296,11 @@ int64_t upper_mfma_frag_bytes(int R, int N, int S) {   // (covers the sum and th
 
 // W / LW: linear and log softmax weights (already computed by the caller), frag: upper_mfma_frag_bytes() of scratch
 int upper_mfma_forward(bool root, const float *in, const float *W, const float *LW, int64_t B, int R, int N, int S,
-                       float *out, void *frag, bool frag_cached, hipStream_t st) {
+                       float *out, void *frag, bool frag_cached, hipStream_t st, const unsigned *gate) {
     const int P = R / 2, tiles = root ? root_ct(N, S) : cdiv((int64_t)S * N, 32);
     if (!frag_cached)
         DPK_LAUNCH(upper_pack_kernel, dim3(cdiv((int64_t)P * tiles * 64, 256)), dim3(256), 0, st, W, P, N, S,
-                       root ? 1 : 0, tiles, (uint16_t *)frag);
+                       root ? 1 : 0, tiles, (uint16_t *)frag, gate);
     UpperArgs a{};
     a.in = in; a.frag = (const uint16_t *)frag; a.LW = LW; a.out = out; a.B = B; a.R = R; a.S = S; a.tiles = tiles;
     const int gx = cdiv(B, 128);

@@ -4,6 +4,7 @@
 #include <string.h>
 #include <mutex>
 #include <unordered_set>
+#include <unordered_map>
 
 namespace dpk {
 static thread_local char g_err[512] = "";
@@ -41,6 +42,132 @@ int ensure_dynamic_lds(const void *kernel, int bytes) {
     }
     done.insert(key);
     return DPK_OK;
+}
+
+// ---- parameter fingerprints (common.h: params_gate) -----------------------------------------------------------------
+struct FpArgs {
+    FpSeg seg[kFpMaxSegs];
+    int nseg;
+    int verify;
+    unsigned long long *state;   // [0] hash of the bytes the tables were built from, [1] accumulator, [2] lo: tickets, hi: gate
+};
+constexpr int64_t kFpSpan = 16384;   // bytes hashed per work-group
+
+__device__ __forceinline__ unsigned long long fp_mix(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void params_fingerprint_kernel(const FpArgs a) {
+    // block b hashes bytes [b, b + 1) * kFpSpan of the concatenated segments: sum over 4-byte words (single bytes
+    // where a segment is not word aligned) of mix(word ^ mix(position)): order independent, so the blocks meet in one
+    // 64-bit atomic sum
+    const int64_t lo = (int64_t)blockIdx.x * kFpSpan, hi = lo + kFpSpan;
+    unsigned long long h = 0ull;
+    int64_t base = 0;
+    for (int i = 0; i < a.nseg; ++i) {
+        const int64_t n = a.seg[i].bytes;
+        const int64_t s0 = lo > base ? lo - base : 0, s1 = (hi - base) < n ? (hi - base) : n;   // span within the segment
+        if (s0 < s1) {
+            const unsigned char *p = (const unsigned char *)a.seg[i].p;
+            const bool words = (((uintptr_t)p | (uintptr_t)n) & 3) == 0;   // (kFpSpan is a multiple of 4)
+            if (words) {
+                const unsigned *w = (const unsigned *)p;
+                for (int64_t e = (s0 >> 2) + threadIdx.x; e < (s1 >> 2); e += blockDim.x)
+                    h += fp_mix((unsigned long long)w[e] ^ fp_mix(((unsigned long long)(i + 1) << 48) ^ (unsigned long long)e));
+            } else {
+                for (int64_t e = s0 + threadIdx.x; e < s1; e += blockDim.x)
+                    h += fp_mix((unsigned long long)p[e] ^ fp_mix(((unsigned long long)(i + 65) << 48) ^ (unsigned long long)e));
+            }
+        }
+        base += n;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) h += (unsigned long long)__shfl_xor((long long)h, o, 64);
+    __shared__ unsigned long long part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) part[wave] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned *tick = reinterpret_cast<unsigned *>(a.state + 2);
+        atomicAdd(a.state + 1, part[0] + part[1] + part[2] + part[3]);
+        __threadfence();
+        if (atomicAdd(tick, 1u) == gridDim.x - 1) {   // last block: every partial sum has arrived
+            __threadfence();
+            const unsigned long long sum = atomicExch(a.state + 1, 0ull);
+            tick[1] = (!a.verify || sum != a.state[0]) ? 1u : 0u;
+            a.state[0] = sum;
+            tick[0] = 0u;
+        }
+    }
+}
+
+__global__ void gated_zero_kernel(uint4 *p, int64_t n16, const unsigned *gate) {
+    if (gate_closed(gate)) return;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = uint4{0u, 0u, 0u, 0u};
+}
+
+int gated_zero(void *p, int64_t bytes, const unsigned *gate, hipStream_t st) {
+    DPK_REQUIRE(((uintptr_t)p & 15) == 0 && (bytes & 15) == 0, DPK_EINVAL, "gated_zero: unaligned");
+    if (bytes == 0) return DPK_OK;
+    int grid = cdiv(bytes / 16, 256 * 4);
+    if (grid > 2048) grid = 2048;
+    DPK_LAUNCH(gated_zero_kernel, dim3(grid), dim3(256), 0, st, (uint4 *)p, bytes / 16, gate);
+    DPK_CHECK_LAUNCH("gated_zero_kernel");
+    return DPK_OK;
+}
+
+const unsigned *params_gate(const void *key, const FpSeg *segs, int nseg, bool verify, hipStream_t st) {
+    // state slots: one 32-byte record per table set, carved from a per-device pool the library owns (the first use of
+    // a device allocates it -- outside any stream capture: captured steps are preceded by eager ones)
+    constexpr int kSlots = 4096;
+    struct Pool {
+        unsigned long long *base = nullptr;
+        std::unordered_map<const void *, int> slot;
+        bool failed = false;
+    };
+    static std::mutex mu;
+    static Pool pools[kMaxDevices];
+    if (nseg < 1 || nseg > kFpMaxSegs) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    unsigned long long *state = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        Pool &pl = pools[dev];
+        if (pl.failed) return nullptr;
+        if (pl.base == nullptr) {
+            if (hipMalloc(&pl.base, (size_t)kSlots * 32) != hipSuccess || hipMemset(pl.base, 0, (size_t)kSlots * 32) != hipSuccess) {
+                (void)hipGetLastError();
+                pl.base = nullptr;
+                pl.failed = true;
+                return nullptr;
+            }
+        }
+        auto it = pl.slot.find(key);
+        if (it == pl.slot.end()) {
+            if ((int)pl.slot.size() >= kSlots) return nullptr;
+            it = pl.slot.emplace(key, (int)pl.slot.size()).first;
+            verify = false;   // a fresh slot holds no hash: this call's build is unconditional
+        }
+        state = pl.base + (int64_t)it->second * 4;
+    }
+    FpArgs a{};
+    int64_t total = 0;
+    for (int i = 0; i < nseg; ++i) {
+        a.seg[i] = segs[i];
+        if (segs[i].p == nullptr) a.seg[i].bytes = 0;
+        total += a.seg[i].bytes;
+    }
+    a.nseg = nseg;
+    a.verify = verify ? 1 : 0;
+    a.state = state;
+    const int grid = total > 0 ? cdiv(total, kFpSpan) : 1;
+    DPK_LAUNCH(params_fingerprint_kernel, dim3(grid), dim3(256), 0, st, a);
+    if (hipGetLastError() != hipSuccess) return nullptr;
+    return reinterpret_cast<const unsigned *>(state + 2) + 1;
 }
 
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;

@@ -18,6 +18,25 @@ LIB_PATH = os.environ.get(  # DEEPROB_HIP_LIB: measurement builds of the same AB
 DPK_FLAG_STRUCT_CACHED = 1
 DPK_FLAG_UNIT_SCALE = 2
 DPK_FLAG_PARAMS_CACHED = 4
+DPK_FLAG_PARAMS_VERIFY = 8
+
+# What the operators pass when a module's cached tables were built from parameters whose addresses, shapes and version
+# counters are unchanged.  A write through ``param.data`` (hand-written optimisers, clipping, ``.data.copy_`` loaders)
+# moves none of those, so by default the belief is CHECKED ON THE DEVICE (DPK_FLAG_PARAMS_VERIFY: one small fingerprint
+# launch per table set and call; tables are rebuilt when the bytes differ).  ``trust_version_counters(True)`` restores
+# the unchecked fast path (DPK_FLAG_PARAMS_CACHED) for callers that never write through ``.data``.
+_trust_versions = False
+
+
+def trust_version_counters(flag: bool = True) -> bool:
+    """Skip the device-side check of cached parameter tables (see above); returns the previous setting."""
+    global _trust_versions
+    prev, _trust_versions = _trust_versions, bool(flag)
+    return prev
+
+
+def cached_tables_flag() -> int:
+    return DPK_FLAG_PARAMS_CACHED if _trust_versions else DPK_FLAG_PARAMS_VERIFY
 
 _c_void = ctypes.c_void_p
 _i64 = ctypes.c_int64

@@ -10,7 +10,7 @@ import torch
 
 from deeprob.hip import (
     load_library, check, ptr, stream_ptr, require_device_f32, Workspace, HipError, DPK_FLAG_STRUCT_CACHED,
-    DPK_FLAG_UNIT_SCALE, DPK_FLAG_PARAMS_CACHED,
+    DPK_FLAG_UNIT_SCALE, DPK_FLAG_PARAMS_CACHED, cached_tables_flag,
 )
 
 
@@ -45,15 +45,15 @@ class LeafContext:
 
 
 def _params_flag(lib, lctx: 'LeafContext', x_ptr, flags: int, tensors) -> int:
-    """DPK_FLAG_PARAMS_CACHED when this fused call runs on the MFMA route and the tables in the workspace were built
-    by an earlier call on that route from the same, unchanged parameters (addresses and version counters; a
-    structure rebuild invalidates them too)."""
+    """The cached-tables flag (``hip.cached_tables_flag``: checked on the device by default) when this fused call runs
+    on the MFMA route and the tables in the workspace were built by an earlier call on that route from parameters at the
+    same addresses with the same version counters (a structure rebuild invalidates them too)."""
     if not lib.dpk_ratspn_forward_on_mfma(x_ptr, lctx.D, lctx.depth, lctx.reps, lctx.I, lctx.S, lctx.C, 0, flags):
         lctx.ws.params_key = None
         return 0
     key = (_buffers_key(*tensors), lctx.ws.struct_key)
     if lctx.ws.params_key == key and (flags & DPK_FLAG_STRUCT_CACHED):
-        return DPK_FLAG_PARAMS_CACHED
+        return cached_tables_flag()
     lctx.ws.params_key = key
     return 0
 
@@ -79,7 +79,7 @@ class GaussianLeafFn(torch.autograd.Function):
             # MFMA route: its parameter tables survive between calls while loc / scale are unchanged
             key = (_buffers_key(loc_c, scale_c), lctx.ws.struct_key)
             if lctx.ws.params_key == key and (flags & DPK_FLAG_STRUCT_CACHED):
-                flags |= DPK_FLAG_PARAMS_CACHED
+                flags |= cached_tables_flag()
             lctx.ws.params_key = key
         else:
             lctx.ws.params_key = None
@@ -408,7 +408,11 @@ class FusedForwardPlan:
     where they are -- ``valid()`` re-checks that cheaply.  The output tensor is reused by every ``run``.
     """
 
-    def __init__(self, x, mask, pad_mask, loc, scale, sum_weights, root_weight, lctx: LeafContext):
+    def __init__(self, x, mask, pad_mask, loc, scale, sum_weights, root_weight, lctx: LeafContext,
+                 static_params: bool = False):
+        # static_params: the caller guarantees that the parameter BYTES do not change while the plan lives (a frozen
+        # model serving / evaluating): later runs pass DPK_FLAG_PARAMS_CACHED and skip the device-side fingerprint
+        self.static_params = bool(static_params)
         self.lib = load_library()
         x = require_device_f32(x, 'x')
         self.tensors = [x, mask, _pad_u8(pad_mask), require_device_f32(loc, 'loc'), require_device_f32(scale, 'scale')]
@@ -454,7 +458,10 @@ class FusedForwardPlan:
         args = self.args
         args[17] = None if ll_acc is None else ll_acc.data_ptr()
         args[-1] = torch.cuda.current_stream(self.device).cuda_stream
-        args[-2] = self.base_flags | _params_flag(self.lib, self.lctx, args[0], self.base_flags, self.params)
+        pf = _params_flag(self.lib, self.lctx, args[0], self.base_flags, self.params)
+        if pf and self.static_params:
+            pf = DPK_FLAG_PARAMS_CACHED
+        args[-2] = self.base_flags | pf
         rc = self.lib.dpk_ratspn_forward(*args)
         if rc:
             check(rc, 'dpk_ratspn_forward')
@@ -483,7 +490,7 @@ def _upper_tables_flag(ws: Workspace, route: str, w: torch.Tensor) -> int:
     operators sharing the workspace drop the key (_sum_ws), so does a replaced buffer (Workspace.get)."""
     key = (route, w.data_ptr(), tuple(w.shape), w._version)
     if ws.params_key == key:
-        return DPK_FLAG_PARAMS_CACHED
+        return cached_tables_flag()
     ws.params_key = key
     return 0
 

@@ -10,11 +10,16 @@ from typing import Optional, Tuple
 import torch
 
 from deeprob.hip import (load_library, check, ptr, stream_ptr, require_device_f32, HipError,
-                         DPK_FLAG_PARAMS_CACHED)
+                         DPK_FLAG_PARAMS_CACHED, cached_tables_flag)
 
 
 def _versions(*tensors) -> tuple:
     return tuple(None if t is None else (t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+
+
+def _trusting() -> bool:
+    from deeprob import hip
+    return hip._trust_versions
 
 
 def _no_graph(*tensors):
@@ -63,7 +68,7 @@ def coupling1d(x: torch.Tensor, layer, inverse: bool, in_affine: Optional[Tuple[
             w1, b1 = require_device_f32(lin1.weight, 'W1'), require_device_f32(lin1.bias, 'b1')
             w2, b2 = require_device_f32(lin2.weight, 'W2'), require_device_f32(lin2.bias, 'b2')
             key = (_versions(w1, b1, w2, b2, sc, sh), parity, bool(layer.affine))
-            flags = DPK_FLAG_PARAMS_CACHED if pw.params_key == key else 0
+            flags = cached_tables_flag() if pw.params_key == key else 0
             pw.params_key = key
             check(lib.dpk_coupling1d_pairs_forward(
                 ptr(x), B, D, parity, ptr(w1), ptr(b1), ptr(w2), ptr(b2), units, ptr(act), ptr(sc), ptr(sh),
@@ -151,18 +156,24 @@ def bn1d_fold(bn, inverse: bool, in_affine=None, ldj_const: Optional[torch.Tenso
     s_in, h_in = in_affine if in_affine is not None else (None, None)
     key = (_versions(bn.weight, bn.bias, bn.running_var, bn.running_mean, s_in, h_in), bool(inverse), float(bn.eps))
     hit = getattr(bn, '_fold_cache', None)
-    if hit is None or hit[0] != key:
+    fresh = hit is None or hit[0] != key
+    if fresh:
         sc = torch.empty(D, dtype=torch.float32, device=dev)
         sh = torch.empty(D, dtype=torch.float32, device=dev)
         own = torch.empty(1, dtype=torch.float32, device=dev)     # this layer's constant log-det
+        # (s_in / h_in are kept alive with the entry: their addresses are part of the key)
+        hit = (key, (sc, sh), own, (s_in, h_in))
+        bn._fold_cache = hit
+    if fresh or not _trusting():
+        # The fold is one D-element kernel: it runs on every call (into the SAME tensors), so that a write through
+        # `.data` of a statistic or parameter -- which moves no version counter -- is folded in; the coupling behind it
+        # fingerprints these tensors on the device.  With hip.trust_version_counters(True) it runs on a key change only.
+        (sc, sh), own = hit[1], hit[2]
         check(lib.dpk_bn1d_fold(ptr(require_device_f32(bn.weight, 'weight')), ptr(require_device_f32(bn.bias, 'bias')),
                                 ptr(require_device_f32(bn.running_var, 'running_var')),
                                 ptr(require_device_f32(bn.running_mean, 'running_mean')), float(bn.eps), D,
                                 int(inverse), ptr(s_in), ptr(h_in), ptr(sc), ptr(sh), ptr(own), 0, stream_ptr(dev)),
               'dpk_bn1d_fold')
-        # (s_in / h_in are kept alive with the entry: their addresses are part of the key)
-        hit = (key, (sc, sh), own, (s_in, h_in))
-        bn._fold_cache = hit
     if isinstance(ldj_const, list):      # the caller sums the layers' constants itself (sum_constants below)
         ldj_const.append(hit[2])
         return hit[1], ldj_const
@@ -183,6 +194,9 @@ def sum_constants(owner, consts) -> Optional[torch.Tensor]:
     if hit is None or hit[0] != key:
         hit = (key, torch.stack([t.reshape(()) for t in consts]).sum().reshape(1), list(consts))   # (keeps them alive)
         owner._const_sum_cache = hit
+    elif not _trusting():
+        # (bn1d_fold rewrites the constants in place on every call: the total follows them, into the same tensor)
+        torch.sum(torch.stack([t.reshape(()) for t in consts]), dim=0, keepdim=True, out=hit[1])
     return hit[1]
 
 

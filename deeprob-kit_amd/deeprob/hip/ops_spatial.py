@@ -5,7 +5,8 @@ there is no CPU path.
 """
 import torch
 
-from deeprob.hip import load_library, check, ptr, stream_ptr, require_device_f32, Workspace, DPK_FLAG_PARAMS_CACHED
+from deeprob.hip import (load_library, check, ptr, stream_ptr, require_device_f32, Workspace, DPK_FLAG_PARAMS_CACHED,
+                         cached_tables_flag)
 
 
 class SpatialGaussianFn(torch.autograd.Function):
@@ -134,13 +135,13 @@ class SpatialSumFn(torch.autograd.Function):
 
 
 def _tables_flag(ws: Workspace, route: str, *weights) -> int:
-    """DPK_FLAG_PARAMS_CACHED when the workspace's softmaxed-weight tables were built by an earlier call of the same
-    entry point from these very tensors (address, shape, version counter; Workspace.get() drops the key when the
-    buffer is replaced).  In-place writes that bypass the version counter (``weight.data.copy_``) are not seen --
-    the same caveat as the RAT-SPN tables."""
+    """The cached-tables flag (``hip.cached_tables_flag``: checked on the device by default, so that a write through
+    ``weight.data`` is seen) when the workspace's softmaxed-weight tables were built by an earlier call of the same entry
+    point from these very tensors (address, shape, version counter; Workspace.get() drops the key when the buffer is
+    replaced)."""
     key = (route,) + tuple((w.data_ptr(), tuple(w.shape), w._version) for w in weights)
     if ws.params_key == key:
-        return DPK_FLAG_PARAMS_CACHED
+        return cached_tables_flag()
     ws.params_key = key
     return 0
 

@@ -46,7 +46,7 @@ class ShardedLogLikelihood:
     """
 
     def __init__(self, model=None, group=None, local_sum_fn: Optional[Callable] = None,
-                 static_inputs: bool = False, reduce_every: int = 32):
+                 static_inputs: bool = False, reduce_every: int = 32, static_params: bool = False):
         self.model = model
         self.group = group
         self.local_sum_fn = local_sum_fn
@@ -60,6 +60,9 @@ class ShardedLogLikelihood:
         # static_inputs: the caller steps over a fixed set of resident buffers (an evaluation ring): the fused
         # call is bound once per buffer (model.fused_plan) and each step is one C call
         self.static_inputs = static_inputs
+        # static_params: the model is frozen for the evaluator's lifetime (no write to a parameter, through .data
+        # included): the bound calls skip the device-side fingerprint of the cached parameter tables
+        self.static_params = static_params
         self._plans = {}
         self._pending: List[Tuple[torch.Tensor, Optional[object]]] = []
         self.last_ll: Optional[torch.Tensor] = None
@@ -98,7 +101,7 @@ class ShardedLogLikelihood:
                 key = (x.data_ptr(), x.shape[0])
                 plan = self._plans.get(key)
                 if plan is None or (plan is not False and not plan.valid()):
-                    plan = self.model.fused_plan(x) or False
+                    plan = self.model.fused_plan(x, static_params=self.static_params) or False
                     self._plans[key] = plan
                 if plan is not False:
                     ll = plan.run(acc)

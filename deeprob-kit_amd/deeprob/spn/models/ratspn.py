@@ -157,9 +157,10 @@ class RatSpn(ProbabilisticModel):
                     return None
             return None
 
-    def fused_plan(self, x: torch.Tensor) -> Optional['ops.FusedForwardPlan']:
+    def fused_plan(self, x: torch.Tensor, static_params: bool = False) -> Optional['ops.FusedForwardPlan']:
         """A pre-bound fused forward for a resident input buffer (see ``ops.FusedForwardPlan``); None when the
-        model is outside the fused kernel's envelope."""
+        model is outside the fused kernel's envelope.  ``static_params``: the caller guarantees a frozen model (the
+        plan then skips the device-side check of the cached parameter tables)."""
         if not isinstance(self.base_layer, GaussianLayer):
             return None
         if self.training and (self.in_dropout is not None or self.sum_dropout is not None):
@@ -167,7 +168,7 @@ class RatSpn(ProbabilisticModel):
         base = self.base_layer
         sum_weights = [layer.weight for layer in self.layers if isinstance(layer, SumLayer)]
         plan = ops.FusedForwardPlan(x, base.mask, base._pad_mask_or_none(), base.loc, base.scale, sum_weights,
-                                    self.root_layer.weight, self._fused_ctx)
+                                    self.root_layer.weight, self._fused_ctx, static_params=static_params)
         return plan if plan.supported else None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

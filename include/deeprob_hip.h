@@ -59,6 +59,13 @@ extern "C" {
                                      same, unchanged loc / scale / weights: skip rebuilding them.  Ignored
                                      on every other route (tables are rebuilt per call there)              */
 
+#define DPK_FLAG_PARAMS_VERIFY 8u  /* the same belief, checked on the device: the entry point fingerprints the live
+                                     parameter bytes (one small launch) and rebuilds its tables only if they differ
+                                     from the bytes the tables were built from.  What a caller passes when all it
+                                     knows is that addresses and version counters are unchanged -- a write through
+                                     `param.data` moves neither.  DPK_FLAG_PARAMS_CACHED remains the caller's own
+                                     guarantee that the bytes are unchanged (no check, no launch).                  */
+
 const char *dpk_last_error(void);
 int dpk_abi_version(void);
 
