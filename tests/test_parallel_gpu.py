@@ -20,6 +20,22 @@ FAMILIES = ('ratspn', 'ratspn_wide', 'dgcspn', 'realnvp1d', 'realnvp2d')
 BATCHES = (257, 64, 1000, 33)
 
 
+def _init(rank, world, port):
+    """Process group + device of a worker: two gloo ranks sharing cuda:0 by default; DPK_TEST_BACKEND=nccl (set by
+    tests/test_parallel_nccl_gpu.py on a box with >= 2 devices) gives every rank its own device over RCCL."""
+    backend = os.environ.get('DPK_TEST_BACKEND', 'gloo')
+    dev = rank if backend == 'nccl' else 0
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
@@ -69,11 +85,7 @@ def _inputs(kind, shape):
 def _eval_worker(rank, world, port, out_dir):
     from tests import conftest  # noqa: F401  (sys.path)
     from deeprob.parallel import ShardedLogLikelihood, shard_batch
-    if world > 1:
-        os.environ['MASTER_ADDR'] = '127.0.0.1'
-        os.environ['MASTER_PORT'] = str(port)
-        dist.init_process_group('gloo', rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    _init(rank, world, port)
     out = {}
     for kind in FAMILIES:
         model, shape, _ = _family(kind)
@@ -127,11 +139,7 @@ def _train_worker(rank, world, port, out_dir):
     from deeprob.flows.models import RealNVP1d
     from deeprob.parallel import shard_batch, allreduce_gradients, broadcast_model, synchronize_batchnorm
     from tests.util import randomise_flow
-    if world > 1:
-        os.environ['MASTER_ADDR'] = '127.0.0.1'
-        os.environ['MASTER_PORT'] = str(port)
-        dist.init_process_group('gloo', rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    _init(rank, world, port)
     torch.manual_seed(100 + rank)                      # replicas start DIFFERENT: broadcast_model must fix that
     model = RealNVP1d(20, n_flows=3, units=32, batch_norm=True)
     randomise_flow(model, 5 + rank)

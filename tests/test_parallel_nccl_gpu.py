@@ -1,0 +1,80 @@
+"""The batch-sharded path over RCCL: two processes, one device each, ``backend='nccl'`` -- sharded evaluation of the
+model families (16-byte {sum LL, count} all-reduce, several steps per asynchronous collective on slices of the slot pool
+that the compute stream writes) and one sharded training step (sample-weighted flat gradient all-reduce, synchronised
+BatchNorm).  Needs two devices: skipped on the single-GPU test boxes, runs wherever the driver has a multi-GPU node.
+
+Stream ordering (round-2 verdict, item 12): ProcessGroupNCCL runs a collective on its own stream after making that
+stream wait for the CURRENT stream at the time of the call, and ``work.wait()`` makes the current stream wait for the
+collective; the kernels that fill the slots run on the current stream before ``all_reduce`` is called, slots of later
+steps are disjoint memory of the same pool, and the Work objects keep the pool alive -- the gloo tests (host-staged)
+cannot exercise this, this file does."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests import test_parallel_gpu as tp
+
+pytestmark = pytest.mark.gpu
+needs_two = pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two HIP devices (RCCL between them)')
+
+
+@pytest.fixture
+def nccl_backend(monkeypatch):
+    monkeypatch.setenv('DPK_TEST_BACKEND', 'nccl')
+    monkeypatch.setenv('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    yield
+
+
+@needs_two
+def test_sharded_mean_ll_two_ranks_over_rccl(tmp_path, nccl_backend):
+    mp.start_processes(tp._eval_worker, args=(2, tp._free_port(), str(tmp_path)), nprocs=2, start_method='spawn')
+    r0, r1 = np.load(tmp_path / 'ev_w2_r0.npy'), np.load(tmp_path / 'ev_w2_r1.npy')
+    assert np.array_equal(r0, r1)
+    want = tp._want()
+    assert np.max(np.abs(r0 - want) / np.maximum(1.0, np.abs(want))) <= 1e-5
+
+
+@needs_two
+def test_sharded_training_step_over_rccl(tmp_path, nccl_backend):
+    os.environ.pop('DPK_TEST_BACKEND', None)
+    tp._train_worker(0, 1, 0, str(tmp_path))            # the single-process reference on cuda:0
+    os.environ['DPK_TEST_BACKEND'] = 'nccl'
+    mp.start_processes(tp._train_worker, args=(2, tp._free_port(), str(tmp_path)), nprocs=2, start_method='spawn')
+    ref = np.load(tmp_path / 'tr_w1_r0.npy')
+    r0, r1 = np.load(tmp_path / 'tr_w2_r0.npy'), np.load(tmp_path / 'tr_w2_r1.npy')
+    scale = np.max(np.abs(ref))
+    assert np.max(np.abs(r0 - r1)) <= 1e-6 * scale
+    assert np.max(np.abs(r0 - ref)) <= 1e-4 * scale
+
+
+def test_single_rank_nccl_group_on_this_device(tmp_path, nccl_backend):
+    """What a one-GPU box CAN check: the RCCL backend initialises and a world of one runs the sharded evaluator's
+    collective path (all_reduce with async_op on pool slices) on the device."""
+    import torch.distributed as dist
+    from tests import conftest  # noqa: F401
+    from deeprob.parallel import ShardedLogLikelihood
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(tp._free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        model, shape, ll = tp._family('ratspn')
+        model.cuda()
+        ev = ShardedLogLikelihood(model, group=dist.group.WORLD, reduce_every=2)
+        xs = tp._inputs('ratspn', shape)
+        with torch.no_grad():
+            for x in xs:
+                ev.step(x.cuda())
+            # (a world of one: step() skips the exchange, so it is driven here -- RCCL all-reduces, asynchronous, on
+            # the very pool slots the fused kernels have just written on the compute stream; the sums are unchanged)
+            works = [dist.all_reduce(a, async_op=True) for a, _ in ev._pending]
+            for w in works:
+                w.wait()
+            got = ev.drain()
+        want = [float(ll(x).double().mean()) for x in xs]
+        assert np.allclose(got, want, rtol=1e-5)
+    finally:
+        dist.destroy_process_group()
