@@ -18,6 +18,25 @@ void profile_take(hipEvent_t *start, hipEvent_t *stop, int kernel_id = 1);
 int device_cus();
 int ensure_dynamic_lds(const void *kernel, int bytes);
 
+// Marginalised-evidence hint shared by the RAT-SPN forward kernels: a work-group that meets NaN evidence stores the
+// launch number in a host-mapped word; the host reads it without synchronising (a stale value only costs speed) and
+// picks the kernel build / variant that keeps such inputs fast while one of the recent launches did so.
+struct SlowHint {
+    int *host = nullptr, *dev = nullptr;   // one host-mapped word per process (one process per GPU)
+    unsigned seq = 0;
+};
+SlowHint &slow_hint();
+// next launch number + whether a launch within the last 256 met marginalised evidence (dev == nullptr: no hint word)
+inline bool slow_hint_next(int **dev_word, int *launch_seq) {
+    SlowHint &h = slow_hint();
+    *dev_word = h.dev;
+    *launch_seq = 0;
+    if (h.dev == nullptr) return false;
+    *launch_seq = (int)++h.seq;
+    // the host runs ahead of the device by its launch queue: "recent" = within 256 launches
+    return (unsigned)(*launch_seq - *(volatile int *)h.host) <= 256u;
+}
+
 // ---- device-side check of cached parameter tables (DPK_FLAG_PARAMS_VERIFY) ------------------------------------------
 // The host can only tell that a parameter MAY have changed from its address / version counter; a write through
 // `param.data` bumps neither.  An entry point that keeps tables derived from parameters therefore fingerprints the live
@@ -121,6 +140,7 @@ struct RatWs {
     float *gbias_ks;   // [NKS][2][NT][16] the same per K-step of 16 features (small-batch kernel, ratspn_gemm_small.hip)
     float *gbias_sl;   // [8][2][NT][16] ... per feature slice of its 8 waves (K-steps [w NKS/8, (w+1) NKS/8))
     int *gelig;        // [NT*RPT] 1: repetition is unit-scale with bounded means
+    unsigned long long *ghash;   // [NT*RPT] fingerprint of the parameter bytes each repetition's tables were built from
     void *lg;          // tables of the leaf-only MFMA kernel (leaf_gemm_ws_bytes), null when the shape is outside it
     int g_nt, g_nksp;  // column tiles of 32, K-steps of 16 features (padded to whole chunks); 0 = not built
     int64_t bytes;
@@ -151,7 +171,7 @@ static inline int64_t leaf_gemm_ws_bytes(int D, int R, int I) {
     const int64_t tab = align_up((int64_t)NG * NKSP * (2 * NTG + 2) * 1024, 256);
     const int64_t bias = align_up((int64_t)NG * NCH * 2 * NTG * 16 * 4, 256);
     const int64_t brow = align_up((int64_t)NG * 2 * NTG * 16 * 4, 256);
-    return 2 * tab + bias + brow + align_up((int64_t)R * 4, 256);
+    return 2 * tab + bias + brow + align_up((int64_t)R * 4, 256) + align_up((int64_t)R * 8, 256);   // (+ per-region fingerprints)
 }
 
 // region-group size used by the per-layer leaf operators (the fused model uses 2^depth)
@@ -227,6 +247,7 @@ inline RatWs carve_ratspn_ws(void *base, int D, int R, int d, int I, int QB, int
         w.gbias_ks = (float *)take((int64_t)((D + 15) / 16) * 2 * w.g_nt * 16 * 4);
         w.gbias_sl = (float *)take((int64_t)kGemmSmallWaves * 2 * w.g_nt * 16 * 4);
         w.gelig = (int *)take((int64_t)w.g_nt * 8 * 4);
+        w.ghash = (unsigned long long *)take((int64_t)w.g_nt * 8 * 8);
     }
     w.lg = nullptr;
     if (leaf_gemm_shape_ok(D, R, I, d)) w.lg = take(leaf_gemm_ws_bytes(D, R, I));
@@ -267,6 +288,54 @@ __device__ __forceinline__ float wave_reduce_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+// ---- fingerprints of parameter bytes (DPK_FLAG_PARAMS_VERIFY) ------------------------------------------------------
+__host__ __device__ __forceinline__ unsigned long long fp_mix(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// This thread's share of the fingerprint of `bytes` bytes at p (4-byte words where the range is word aligned, single
+// bytes otherwise), position dependent through `tag`; the block's fingerprint is the sum over its threads (block_sum_u64).
+// Two independent 32-bit multiply-rotate mixes per word packed into one 64-bit sum (a 64-bit multiply costs four VALU
+// multiplies here, and the first version of this check spent 5 us hashing 20 KB): change detection, not cryptography.
+__device__ __forceinline__ unsigned long long fp_word(unsigned w, unsigned pos) {
+    unsigned a = (w ^ (pos * 0x9E3779B1u)) * 0x85EBCA6Bu;
+    a ^= a >> 15;
+    a *= 0xC2B2AE35u;
+    unsigned b = (w + pos) * 0xCC9E2D51u;
+    b = (b << 13) | (b >> 19);
+    b = b * 0x1B873593u + (pos ^ 0x27D4EB2Fu);
+    return ((unsigned long long)(b ^ (b >> 16)) << 32) | (unsigned long long)(a ^ (a >> 13));
+}
+__device__ __forceinline__ unsigned long long fp_range(const void *p, int64_t bytes, unsigned tag) {
+    unsigned long long h = 0ull;
+    if (p == nullptr) return h;
+    if ((((uintptr_t)p | (uintptr_t)bytes) & 3) == 0) {
+        const unsigned *w = (const unsigned *)p;
+        for (int64_t e = threadIdx.x; e < (bytes >> 2); e += blockDim.x) h += fp_word(w[e], (unsigned)e * 8u + tag);
+    } else {
+        const unsigned char *b = (const unsigned char *)p;
+        for (int64_t e = threadIdx.x; e < bytes; e += blockDim.x) h += fp_word(b[e], (unsigned)e * 8u + tag + 4u);
+    }
+    return h;
+}
+// sum of a 64-bit value over the block, returned to every thread (red: 17 words of LDS; blockDim a multiple of 64)
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long h, unsigned long long *red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) h += (unsigned long long)__shfl_xor((long long)h, o, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0ull;
+        for (int w = 0; w < nw; ++w) t += red[w];
+        red[16] = t;
+    }
+    __syncthreads();
+    return red[16];
 }
 
 }  // namespace dpk

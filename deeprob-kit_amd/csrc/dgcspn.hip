@@ -1048,13 +1048,10 @@ extern "C" int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C
     hipStream_t st = (hipStream_t)stream;
     // (DPK_FLAG_PARAMS_CACHED: the workspace still holds the tables an earlier call built from this very weight;
     // DPK_FLAG_PARAMS_VERIFY: believed so, checked on the device)
-    {
-        const FpSeg segs[1] = {{weight, (int64_t)Cout * C * OHW * 4}};
-        const TablePlan tp = plan_tables(flags, ws, segs, 1, st);
-        if (tp.run)
-            DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW, 256)), dim3(256), 0, st, weight,
-                       Cout, C, OHW, Wl, LW, tp.gate);
-    }
+    // (rebuilding IS the check here: the softmax pass costs what a fingerprint of the same bytes would)
+    if (!(flags & DPK_FLAG_PARAMS_CACHED))
+        DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW, 256)), dim3(256), 0, st, weight,
+                   Cout, C, OHW, Wl, LW);
     // large batches of the 8 -> 8 channel level: pixel-resident weights, taps staged through LDS (dgcspn_stream.hip)
     if (stream_prodsum_ok(q, Cout, B, in)) return stream_prodsum_forward(in, B, q, Wl, LW, out, st);
     const int Bi = (int)B;
@@ -1279,14 +1276,10 @@ extern "C" int dpk_spatial_sumprodroot_forward(const float *in, int64_t B, int32
     const int64_t seg = align_up((int64_t)Cout * C * OHW5 * 4, 256);
     float *Wl = (float *)ws, *LW = (float *)((char *)ws + seg), *LWr = (float *)((char *)ws + 2 * seg);
     hipStream_t st = (hipStream_t)stream;
-    {   // (flags as in dpk_spatial_prodsum_forward)
-        const FpSeg segs[2] = {{sum_weight, (int64_t)Cout * C * OHW5 * 4}, {root_weight, (int64_t)K * Cout * OHW6 * 4}};
-        const TablePlan tp = plan_tables(flags, ws, segs, 2, st);
-        if (tp.run) {
-            DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW5, 256)), dim3(256), 0, st, sum_weight,
-                       Cout, C, OHW5, Wl, LW, tp.gate);
-            DPK_LAUNCH(rowwise_logsoftmax_kernel, dim3(K), dim3(256), 0, st, root_weight, K, Cout * OHW6, LWr, tp.gate);
-        }
+    if (!(flags & DPK_FLAG_PARAMS_CACHED)) {   // (flags as in dpk_spatial_prodsum_forward: VERIFY = rebuild)
+        DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW5, 256)), dim3(256), 0, st, sum_weight,
+                   Cout, C, OHW5, Wl, LW);
+        DPK_LAUNCH(rowwise_logsoftmax_kernel, dim3(K), dim3(256), 0, st, root_weight, K, Cout * OHW6, LWr);
     }
     {
         // streaming kernel when the workspace carries its per-wave partials (.._workspace_bytes_batch)

@@ -1413,29 +1413,6 @@ static void fill_leaf_args(LeafArgs &a, const RatWs &w) {
     a.unit = as_const(w.unit);
 }
 
-struct SlowHint {
-    int *host = nullptr, *dev = nullptr;   // one host-mapped word per process (one process per GPU)
-    unsigned seq = 0;
-};
-static SlowHint &slow_hint() {
-    static SlowHint h = [] {
-        SlowHint s;
-        int *p = nullptr;
-        if (hipHostMalloc((void **)&p, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && p) {
-            *p = -1000;
-            int *d = nullptr;
-            if (hipHostGetDevicePointer((void **)&d, p, 0) == hipSuccess && d) {
-                s.host = p;
-                s.dev = d;
-            }
-        } else {
-            (void)hipGetLastError();
-        }
-        return s;
-    }();
-    return h;
-}
-
 template <int DIST, int QB, int CB, int SPL, int DEPTH, int S, bool GEN, bool XLDS = false>
 static int launch_leaf_gen(const LeafArgs &a, hipStream_t st) {
     using G = TileGeom<SPL>;
@@ -1488,14 +1465,7 @@ static int launch_leaf(const LeafArgs &a, hipStream_t st) {
                 // ones because of the extra code in the chunk loop).  A work-group that meets a slow chunk stores the
                 // launch number in a host-mapped word; a launch takes the second build while one of the recent
                 // launches did so.  The word is read without synchronising: a stale value only costs speed.
-                SlowHint &h = slow_hint();
-                bool marginal = false;
-                if (h.dev != nullptr) {
-                    c.slow_flag = h.dev;
-                    c.launch_seq = (int)++h.seq;
-                    // the host runs ahead of the device by its launch queue: "recent" = within 256 launches
-                    marginal = (unsigned)(c.launch_seq - *(volatile int *)h.host) <= 256u;
-                }
+                const bool marginal = slow_hint_next(&c.slow_flag, &c.launch_seq);
                 if (marginal) return launch_leaf_gen<DIST, QB, CB, SPL, DEPTH, S, false, true>(c, st);
                 return launch_leaf_gen<DIST, QB, CB, SPL, DEPTH, S, false>(c, st);
             }

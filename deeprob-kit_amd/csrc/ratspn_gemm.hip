@@ -57,14 +57,14 @@ struct GemmPrepArgs {
     const float *w[3];
     float *W[3], *LW[3];
     int rows[3], n[3];
-    const unsigned *gate;   // table kernels return at once while *gate == 0 (common.h: params_gate)
+    int verify;                 // DPK_FLAG_PARAMS_VERIFY: a block rebuilds only if the bytes it depends on changed
+    unsigned long long *hash;   // [NT*RPT] fingerprint of the bytes each repetition's tables were built from
 };
 
 
 template <int I>
 __global__ __launch_bounds__(256) void ratspn_gemm_prep_kernel(const GemmPrepArgs a) {
     constexpr int RPT = 8 / I;       // repetitions per 32-column tile (4 regions x I channels each)
-    if (gate_closed(a.gate)) return;
     const int nrb = a.NT * RPT;
     if ((int)blockIdx.x >= nrb) {
         // softmax rows: one wave per row (torch.log_softmax at ratspn.py:375 and :455)
@@ -96,9 +96,27 @@ __global__ __launch_bounds__(256) void ratspn_gemm_prep_kernel(const GemmPrepArg
     extern __shared__ int posrow[];  // [D] position q*d + j of variable f in this repetition, -1 if absent
     float *locs = reinterpret_cast<float *>(posrow + a.D);   // [4][I][d] the repetition's means
     __shared__ int bad_s;
+    __shared__ unsigned long long red_s[17];
     const int rho = blockIdx.x;
     const bool real = rho < a.reps;
     const int D = a.D, d = a.d;
+    {
+        // Everything this block writes depends on the repetition's own slice of mask / pad_mask / loc / scale only, so
+        // the cached-table check is block local: fingerprint those bytes, compare with the fingerprint of the bytes the
+        // tables were built from (a write through `param.data` moves no version counter on the host), and
+        // return when nothing changed -- one ~2 us launch per call instead of a 30 us rebuild.
+        unsigned long long h = 0x9E3779B97F4A7C15ull + (unsigned long long)rho;
+        if (real) {
+            h += fp_range(a.mask + (int64_t)rho * 4 * d, (int64_t)4 * d * 8, 1);
+            h += fp_range(a.pad ? a.pad + (int64_t)rho * 4 * d : nullptr, (int64_t)4 * d, 2);
+            h += fp_range(a.loc + (int64_t)rho * 4 * I * d, (int64_t)4 * I * d * 4, 3);
+            h += fp_range(a.scale + (int64_t)rho * 4 * I * d, (int64_t)4 * I * d * 4, 4);
+        }
+        h = block_sum_u64(h, red_s);
+        if (a.verify && a.hash[rho] == h) return;
+        __syncthreads();
+        if (threadIdx.x == 0) a.hash[rho] = h;
+    }
     for (int f = threadIdx.x; f < D; f += blockDim.x) posrow[f] = -1;
     if (threadIdx.x == 0) bad_s = 0;
     __syncthreads();
@@ -230,10 +248,14 @@ __global__ __launch_bounds__(256) void ratspn_gemm_prep_kernel(const GemmPrepArg
 #define GEMM_STAMP(row, slot) do { } while (0)
 #endif
 
-template <int I, int S, int NT>
+// CT: the marginalised-evidence variant (taken while a recent launch met NaN inputs, slow_hint): chunks of 32 features
+// whose stage carries the negated-constant table next to the mean table, so that the validity GEMM of a chunk that
+// holds NaN reads its fragments from LDS like the mean GEMM does (the default build fetches them from L2 just in time,
+// one round trip per K-step: 3.9x the clean time on 30 % NaN inputs in round 2).  Same arithmetic, same results.
+template <int I, int S, int NT, bool CT = false>
 __global__ __launch_bounds__(2 * kGemmWaves * 64) void ratspn_gemm_kernel(const GemmArgs a) {
     constexpr int RPT = 8 / I;                           // repetitions per column tile
-    constexpr int KS = gemm_ks(NT);
+    constexpr int KS = CT ? 2 : gemm_ks(NT);
     constexpr int KC = 16 * KS;                          // features per chunk
     constexpr int W = 4 * KS;                            // 16-byte pieces per staged row
     constexpr int ROWB = KC * 4;
@@ -241,11 +263,11 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void ratspn_gemm_kernel(const 
     constexpr int SWS = (W == 16) ? 0 : (W == 8 ? 1 : 2);  // swizzle: piece ^= (row >> SWS) & (W-1)
     constexpr int XB = kGemmTile * ROWB;                 // x chunk bytes
     constexpr int BB = KS * NT * 2 * 1024;               // mean-table bytes per chunk
-    constexpr int STAGE = XB + BB;
+    constexpr int STAGE = XB + (CT ? 2 : 1) * BB;
     constexpr int NS = kGemmStages;
     constexpr int PX = 32 / RPI;                         // x DMA instructions per loader wave and chunk
-    constexpr int PB = BB / (kGemmWaves * 1024);         // table DMA instructions per loader wave and chunk
-    constexpr int P = PX + PB;                           // DMA instructions per loader wave and chunk
+    constexpr int PB = BB / (kGemmWaves * 1024);         // table DMA instructions per loader wave and chunk (per table)
+    constexpr int P = PX + (CT ? 2 : 1) * PB;            // DMA instructions per loader wave and chunk
     static_assert(BB % (kGemmWaves * 1024) == 0, "table chunk must split over the waves");
     static_assert(NS == 3 && P <= 63, "the counted waits leave exactly one chunk in flight");
     constexpr int NMAX = (I > S ? I : S);
@@ -281,8 +303,8 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void ratspn_gemm_kernel(const 
     double red_ll = 0.0;
     bool saw_nan_any = false;
     if (loader) {
-        gemm_loader_run<KS, PB>(a.x, a.B, D, NCH, ntiles, (int)blockIdx.x, grid, (gcchar_p)a.mtab, BB, wave * PB,
-                                (unsigned)(uintptr_t)smem, STAGE, wave, lane);
+        gemm_loader_run<KS, PB, CT ? PB : 0>(a.x, a.B, D, NCH, ntiles, (int)blockIdx.x, grid, (gcchar_p)a.mtab, BB,
+                                             wave * PB, (unsigned)(uintptr_t)smem, STAGE, wave, lane, (gcchar_p)a.ctab);
     } else {
     // ================================================ compute waves =========================================
     // constants into LDS
@@ -422,14 +444,24 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void ratspn_gemm_kernel(const 
                         }
                         if (odd_chunk) {
                             // - (mu^2/2 + log sqrt(2 pi)) of the variables that ARE observed (table of negated constants)
-                            typedef const __attribute__((address_space(1))) half8 gh8;
-                            const gcchar_p cb = (gcchar_p)a.ctab + ((((int64_t)(c * KS + ks) * NT) * 2) * 512 + lane * 8) * 2;
+                            if constexpr (CT) {   // staged next to the mean table
 #pragma unroll
-                            for (int t = 0; t < NT; ++t) {
-                                const half8 ch = *(gh8 *)(cb + t * 2048);
-                                const half8 cl = *(gh8 *)(cb + t * 2048 + 1024);
-                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, valid[ks], acc[t], 0, 0, 0);
-                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, valid[ks], acc[t], 0, 0, 0);
+                                for (int t = 0; t < NT; ++t) {
+                                    const half8 ch = *(lh8 *)(tb + BB + (ks * NT + t) * 2048);
+                                    const half8 cl = *(lh8 *)(tb + BB + (ks * NT + t) * 2048 + 1024);
+                                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, valid[ks], acc[t], 0, 0, 0);
+                                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, valid[ks], acc[t], 0, 0, 0);
+                                }
+                            } else {
+                                typedef const __attribute__((address_space(1))) half8 gh8;
+                                const gcchar_p cb = (gcchar_p)a.ctab + ((((int64_t)(c * KS + ks) * NT) * 2) * 512 + lane * 8) * 2;
+#pragma unroll
+                                for (int t = 0; t < NT; ++t) {
+                                    const half8 ch = *(gh8 *)(cb + t * 2048);
+                                    const half8 cl = *(gh8 *)(cb + t * 2048 + 1024);
+                                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, valid[ks], acc[t], 0, 0, 0);
+                                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, valid[ks], acc[t], 0, 0, 0);
+                                }
                             }
                         }
                     }
@@ -472,11 +504,21 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void ratspn_gemm_kernel(const 
                         for (int i = 0; i < 16; ++i) cst[t][i] = 0.f;
                     for (int c = 0; c < NCH; ++c) {
                         if ((odd_mask >> c) & 1u) continue;
-                        const float *bc = a.biasC + ((c * 2 + h) * NT) * 16;
+                        if constexpr (CT) {   // (32-feature chunks: the constants per K-step, prepared for the small-batch kernel)
+                            for (int ks = c * KS; ks < min((c + 1) * KS, (D + 15) >> 4); ++ks) {
+                                const float *bk = a.biasK + ((ks * 2 + h) * NT) * 16;
 #pragma unroll
-                        for (int t = 0; t < NT; ++t)
+                                for (int t = 0; t < NT; ++t)
 #pragma unroll
-                            for (int i = 0; i < 16; ++i) cst[t][i] += bc[t * 16 + i];
+                                    for (int i = 0; i < 16; ++i) cst[t][i] += bk[t * 16 + i];
+                            }
+                        } else {
+                            const float *bc = a.biasC + ((c * 2 + h) * NT) * 16;
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                                for (int i = 0; i < 16; ++i) cst[t][i] += bc[t * 16 + i];
+                        }
                     }
                 }
                 double part = 0.0;
@@ -523,15 +565,15 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void ratspn_gemm_kernel(const 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <int I, int S, int NT>
+template <int I, int S, int NT, bool CT = false>
 static int gemm_launch(const GemmArgs &a, int reps, hipStream_t st) {
-    constexpr int KS = gemm_ks(NT);
+    constexpr int KS = CT ? 2 : gemm_ks(NT);
     constexpr int BB = KS * NT * 2 * 1024;
     constexpr int NMAX = (I > S ? I : S);
-    const size_t lds = (size_t)kGemmStages * (kGemmTile * 64 * KS + BB) +
+    const size_t lds = (size_t)kGemmStages * (kGemmTile * 64 * KS + (CT ? 2 : 1) * BB) +
                        (size_t)(2 * NT * 16 + reps * 2 * S * I * I) * 4 + (size_t)kGemmWaves * 64 * 2 * NMAX * 4;
     DPK_REQUIRE(lds <= 160 * 1024, DPK_EUNSUPPORTED, "ratspn_gemm: %zu bytes of LDS", lds);
-    auto kern = ratspn_gemm_kernel<I, S, NT>;
+    auto kern = ratspn_gemm_kernel<I, S, NT, CT>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024)) return rc;
     const int cus = device_cus();
     const int grid = a.ntiles < cus ? a.ntiles : cus;
@@ -555,6 +597,11 @@ static int gemm_launch(const GemmArgs &a, int reps, hipStream_t st) {
 
 template <int I, int S>
 static int gemm_dispatch_nt(const GemmArgs &a, int reps, int NT, hipStream_t st) {
+    if (a.marginal && NT <= 2 && cdiv(a.D, 32) <= 32) {   // recent NaN evidence: the variant that stages both tables
+        GemmArgs c = a;
+        c.NCH = cdiv(a.D, 32);
+        return NT == 1 ? gemm_launch<I, S, 1, true>(c, reps, st) : gemm_launch<I, S, 2, true>(c, reps, st);
+    }
     switch (NT) {
         case 1: return gemm_launch<I, S, 1>(a, reps, st);
         case 2: return gemm_launch<I, S, 2>(a, reps, st);
@@ -576,14 +623,10 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
                         int reps, int I, int S, int C, float *out, double *ll_sum, uint32_t flags, hipStream_t st) {
     const int d = (D + (4 - D % 4) % 4) / 4;
     const int NT = w.g_nt;
-    const int R = reps * 4;
-    const FpSeg segs[6] = {{mask, (int64_t)R * d * 8}, {pad, (int64_t)R * d}, {loc, (int64_t)R * I * d * 4},
-                           {scale, (int64_t)R * I * d * 4}, {sum_weight0, (int64_t)reps * 2 * S * I * I * 4},
-                           {root_weight, (int64_t)C * reps * S * S * 4}};
-    const TablePlan tp = plan_tables(flags, w.gm_tab, segs, 6, st);
-    if (tp.run) {
+    if (!(flags & DPK_FLAG_PARAMS_CACHED)) {
         GemmPrepArgs p{};
-        p.gate = tp.gate;
+        p.verify = (flags & DPK_FLAG_PARAMS_VERIFY) ? 1 : 0;
+        p.hash = w.ghash;
         p.mask = mask; p.pad = pad; p.loc = loc; p.scale = scale;
         p.D = D; p.d = d; p.reps = reps; p.NT = NT; p.NKSP = w.g_nksp; p.KS = gemm_ks(NT);
         p.mtab = w.gm_tab; p.ctab = w.gc_tab; p.bias = w.gbias; p.bias_row = w.gbias_row; p.bias_ks = w.gbias_ks;
@@ -607,6 +650,11 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
     a.W0 = w.w[0]; a.LW0 = w.lw[0]; a.Wr = as_const(w.w[2]); a.LWr = as_const(w.lw[2]);
     a.out = out; a.ll_sum = ll_sum;
     a.mask = mask; a.pad = pad; a.loc = loc; a.scale = scale;
+    a.marginal = slow_hint_next(&a.slow_flag, &a.launch_seq) ? 1 : 0;
+    {   // (measurement: DPK_GEMM_MARGINAL=0 / 1 pins the variant)
+        static const int force = [] { const char *e = getenv("DPK_GEMM_MARGINAL"); return e ? atoi(e) : -1; }();
+        if (force >= 0) a.marginal = force;
+    }
     {
         static const int ab = [] { const char *e = getenv("DPK_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
         a.ablate = ab;

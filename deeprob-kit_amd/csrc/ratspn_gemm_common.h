@@ -79,15 +79,18 @@ __device__ __forceinline__ void split8(const float (&v)[8], half8 &xh, half8 &xl
 // the compute waves.  Tiles: tile0, tile0 + tstride, ... < ntiles.  The caller has already passed the work-group's
 // opening __syncthreads() count into account: this function executes exactly ONE __syncthreads() (after its first two
 // chunks are issued) and then one s_barrier per chunk.
-template <int KS, int PB>
+// PB2 > 0: a second table with the same chunk geometry (the negated-constant table of the marginalised-evidence variant)
+// is staged behind the first one, PB2 pieces per wave starting at piece wave * PB2.
+template <int KS, int PB, int PB2 = 0>
 __device__ __forceinline__ void gemm_loader_run(const float *x, int64_t B, int D, int NCH, int ntiles, int tile0,
                                                 int tstride, gcchar_p table, int chunk_table_bytes, int tab_kb0,
-                                                unsigned smem_base, int stage_bytes, int wave, int lane) {
+                                                unsigned smem_base, int stage_bytes, int wave, int lane,
+                                                gcchar_p table2 = nullptr) {
     constexpr int KC = 16 * KS, W = 4 * KS, ROWB = KC * 4, RPI = 64 / W;
     constexpr int SWS = (W == 16) ? 0 : (W == 8 ? 1 : 2);
     constexpr int XB = kGemmTile * ROWB;
     constexpr int PX = 32 / RPI;
-    constexpr int P = PX + PB;
+    constexpr int P = PX + PB + PB2;
     static_assert(P <= 63, "vmcnt field");
     unsigned voff[PX];
 #pragma unroll
@@ -119,6 +122,12 @@ __device__ __forceinline__ void gemm_loader_run(const float *x, int64_t B, int D
         }
 #pragma unroll
         for (int j = 0; j < PB; ++j) glds16(toff + j * 1024, tsrc, st + XB + tab_kb0 * 1024 + j * 1024);
+        if constexpr (PB2 > 0) {
+            const gcchar_p tsrc2 = table2 + (int64_t)pc * chunk_table_bytes;
+#pragma unroll
+            for (int j = 0; j < PB2; ++j)
+                glds16((unsigned)((wave * PB2 + j) * 1024 + lane * 16), tsrc2, st + XB + chunk_table_bytes + (wave * PB2 + j) * 1024);
+        }
         pstage = (pstage + 1 == kGemmStages) ? 0 : pstage + 1;
         if (++pc == NCH) {
             pc = 0;

@@ -38,6 +38,7 @@ struct GemmArgs {
     int ablate;       // measurement only (DPK_GEMM_ABLATE): 1 no compute, 2 no table DMA, 4 no x DMA
     int *slow_flag;   // host-mapped hint word (may be null): launch number of the last launch that met NaN evidence
     int launch_seq;
+    int marginal;     // host: a launch within the last 256 met NaN evidence (selects the variant built for it)
 };
 
 __device__ __forceinline__ void lse_merge(float &m, float &s, float m2, float s2) {

@@ -880,10 +880,9 @@ static int prod_fused_common(bool root, const float *in, const float *weight, in
     hipStream_t st = (hipStream_t)stream;
     // DPK_FLAG_PARAMS_CACHED: softmax rows (and MFMA fragments) of an earlier call from this very weight are in ws;
     // DPK_FLAG_PARAMS_VERIFY: believed so, checked on the device (table kernels gated on the verdict)
-    const FpSeg segs[1] = {{weight, (int64_t)rows * n * 4}};
-    const TablePlan tp = plan_tables(flags, ws, segs, 1, st);
-    const bool cached = !tp.run;
-    if (!cached) launch_softmax_rows(weight, rows, n, W, LW, st, tp.gate);
+    // (VERIFY = rebuild: the softmax rows + fragment pack cost what fingerprinting the weights would)
+    const bool cached = (flags & DPK_FLAG_PARAMS_CACHED) != 0;
+    if (!cached) launch_softmax_rows(weight, rows, n, W, LW, st);
     {
         static const bool mfma = [] {
             const char *e = getenv("DPK_RATSPN_GEMM");
@@ -892,7 +891,7 @@ static int prod_fused_common(bool root, const float *in, const float *weight, in
         const int64_t fb = upper_mfma_frag_bytes(R, N, S);
         if (mfma && upper_mfma_shape_ok(root, N, S) && ws_bytes >= 2 * seg + fb &&
             (reinterpret_cast<uintptr_t>(in) & 15) == 0)
-            return upper_mfma_forward(root, in, W, LW, B, R, N, S, out, (char *)ws + 2 * seg, cached, st, tp.gate);
+            return upper_mfma_forward(root, in, W, LW, B, R, N, S, out, (char *)ws + 2 * seg, cached, st);
     }
     const dim3 block(256);
 #define DPK_LAUNCH_PS(NMAX)                                                                                         \

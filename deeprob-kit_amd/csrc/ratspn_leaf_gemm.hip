@@ -35,7 +35,8 @@ struct LeafPrepArgs {
     float *bias;             // [NG][NCH][2][NTG][16]  per-(chunk, column) constants in accumulator order
     float *bias_row;         // [NG][2][NTG][16]
     int *elig;               // [R]
-    const unsigned *gate;    // table kernels return at once while *gate == 0 (common.h: params_gate)
+    int verify;                 // DPK_FLAG_PARAMS_VERIFY: a block rebuilds only if the bytes it depends on changed
+    unsigned long long *hash;   // [R] fingerprint of the bytes each region's tables were built from
 };
 
 __global__ __launch_bounds__(256) void ratspn_leaf_gemm_prep_kernel(const LeafPrepArgs a) {
@@ -43,8 +44,20 @@ __global__ __launch_bounds__(256) void ratspn_leaf_gemm_prep_kernel(const LeafPr
     float *locs = reinterpret_cast<float *>(featpos + a.D);     // [I][d]
     float *csum = locs + a.I * a.d;                             // [NCH][I]
     __shared__ int bad_s;
-    if (gate_closed(a.gate)) return;
+    __shared__ unsigned long long red_s[17];
     const int r = blockIdx.x, D = a.D, d = a.d, I = a.I, NTG = a.NTG;
+    {
+        // block-local cached-table check (see ratspn_gemm_prep_kernel): the region's slice of mask / pad_mask / loc / scale
+        unsigned long long h = 0x9E3779B97F4A7C15ull + (unsigned long long)r;
+        h += fp_range(a.mask + (int64_t)r * d, (int64_t)d * 8, 1);
+        h += fp_range(a.pad ? a.pad + (int64_t)r * d : nullptr, (int64_t)d, 2);
+        h += fp_range(a.loc + (int64_t)r * I * d, (int64_t)I * d * 4, 3);
+        h += fp_range(a.scale + (int64_t)r * I * d, (int64_t)I * d * 4, 4);
+        h = block_sum_u64(h, red_s);
+        if (a.verify && a.hash[r] == h) return;
+        __syncthreads();
+        if (threadIdx.x == 0) a.hash[r] = h;
+    }
     for (int f = threadIdx.x; f < D; f += blockDim.x) featpos[f] = -1;
     if (threadIdx.x == 0) bad_s = 0;
     __syncthreads();
@@ -433,13 +446,15 @@ int ratspn_leaf_gemm_forward(void *ws, const float *x, int64_t B, int D, const i
     uint16_t *mtab = (uint16_t *)p, *ctab = (uint16_t *)(p + tab);
     float *biasC = (float *)(p + 2 * tab), *biasT = (float *)(p + 2 * tab + bias);
     int *elig = (int *)(p + 2 * tab + bias + brow);
-    const FpSeg segs[4] = {{mask, (int64_t)R * d * 8}, {pad, (int64_t)R * d}, {loc, (int64_t)R * I * d * 4},
-                           {scale, (int64_t)R * I * d * 4}};
-    const TablePlan tp = plan_tables(flags, ws, segs, 4, st);
-    if (tp.run) {
-        if (int rc = gated_zero(p, 2 * tab + bias + brow, tp.gate, st)) return rc;
+    if (!(flags & DPK_FLAG_PARAMS_CACHED)) {
+        // The slots no region block writes (padding columns of the last tile, the zero half of the indicator tile) are
+        // zeroed by the unconditional build; a verifying call keeps them (every region block rewrites all of its own)
+        const bool verify = (flags & DPK_FLAG_PARAMS_VERIFY) != 0;
+        if (!verify)
+            DPK_REQUIRE(hipMemsetAsync(p, 0, (size_t)(2 * tab + bias + brow), st) == hipSuccess, DPK_ELAUNCH, "memset");
         LeafPrepArgs pa{};
-        pa.gate = tp.gate;
+        pa.verify = verify ? 1 : 0;
+        pa.hash = (unsigned long long *)(p + 2 * tab + bias + brow + align_up((int64_t)R * 4, 256));
         pa.mask = mask; pa.pad = pad; pa.loc = loc; pa.scale = scale;
         pa.D = D; pa.d = d; pa.R = R; pa.I = I; pa.NTG = NTG; pa.NG = NG; pa.NKSP = NKSP; pa.KS = KS;
         pa.mtab = mtab; pa.ctab = ctab; pa.bias = biasC; pa.bias_row = biasT; pa.elig = elig;

@@ -64,7 +64,11 @@ extern "C" {
                                      from the bytes the tables were built from.  What a caller passes when all it
                                      knows is that addresses and version counters are unchanged -- a write through
                                      `param.data` moves neither.  DPK_FLAG_PARAMS_CACHED remains the caller's own
-                                     guarantee that the bytes are unchanged (no check, no launch).                  */
+                                     guarantee that the bytes are unchanged (no check, no launch).  How an entry
+                                     point checks is its own business: the RAT-SPN table kernels fingerprint the
+                                     slice of parameters each work-group depends on and return when it is unchanged
+                                     (one ~2 us launch), the coupling tables use a fingerprint kernel + gated table
+                                     kernels, entry points whose tables are cheap simply rebuild them.              */
 
 const char *dpk_last_error(void);
 int dpk_abi_version(void);
