@@ -145,13 +145,18 @@ def cpu_baseline(model_state, D, n_samples):
                       'restatement of the reference'.format(n_samples, chunk, dt, threads, ncpu)}, threads
 
 
-def read_traffic():
-    """HBM bytes per launch of the fused kernel from this round's rocprofv3 --pmc pass (a separate run: PMC and
-    timing do not mix; tools/collect_profiles.sh writes the file, the summary sits beside it in profiles/)."""
+def read_traffic(key='headline'):
+    """HBM bytes per launch of a kernel from this round's rocprofv3 --pmc passes (separate runs: PMC and timing do not
+    mix; tools/collect_profiles.sh / tools/pmc_secondary.sh write profiles/pmc_traffic.json, the summaries sit beside
+    it in profiles/).  Returns (bytes per launch, source) or (None, None)."""
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     try:
         with open(path) as f:
             d = json.load(f)
+        if 'kernels' in d:
+            d = d['kernels'].get(key) or {}
+        elif key != 'headline':
+            d = {}
         return d.get('bytes_per_launch'), d.get('source')
     except (OSError, ValueError):
         return None, None
@@ -191,6 +196,40 @@ def _time_eval(model, xs, timer, kernel_id, steps=30, warm=5):
             except AssertionError:
                 pass
     return ms, (sum(k_ms) / len(k_ms) if k_ms else None)
+
+
+def _time_eval_graph(model, xs, reps=4):
+    """ms per model(x) call when a pass over the resident batches `xs` (x `reps`) is replayed from ONE HIP graph: what a
+    density-evaluation loop over resident data costs once the launch-bound host loop is out of the way (the kernels,
+    their inter-kernel gaps and the per-call table check are all inside).  None when the pass cannot be captured."""
+    import torch
+    try:
+        side = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.stream(side):
+            for x in xs:
+                model(x)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(reps):
+                    for x in xs:
+                        model(x)
+        torch.cuda.synchronize()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        best = float('inf')
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / (5 * reps * len(xs)))
+        return best
+    except Exception:
+        return None
 
 
 def _time_train(model, x, steps=15, warm=3):
@@ -261,6 +300,42 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
         return {'bound': bound, 'achieved': a, 'peak': F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': a / F32_PEAK_TFLOPS,
                 'traffic': None}
 
+    # ---- BASELINE config 1: vanilla SPN log_likelihood, 16 binary variables, 1000 samples (flat-array evaluator) ----
+    try:
+        import numpy as np
+        from deeprob.spn.structure.io import load_spn_json
+        from deeprob.spn.algorithms.inference import log_likelihood
+        from oracle import flat_spn_oracle as fsorc
+        path = os.path.join(ROOT, 'tests', 'golden', 'spn_binary16.json')
+        spn = load_spn_json(path)
+        x_np = (np.random.RandomState(0).rand(1000, 16) < 0.5).astype(np.float32)
+        xd = torch.from_numpy(x_np).to(dev)
+        for _ in range(5):
+            log_likelihood(spn, xd)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            log_likelihood(spn, xd)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 100 * 1e3
+        t0 = time.perf_counter()
+        n_rep = 20
+        for _ in range(n_rep):
+            fsorc.log_likelihood(path, x_np)
+        dc = (time.perf_counter() - t0) / n_rep
+        out.append({'workload': 'vanilla node-graph SPN log_likelihood (the circuit the reference learns on 16 binary '
+                                'variables, 72 nodes), 1000 samples per call, flat-array HIP evaluator',
+                    'config': 'BASELINE config 1', 'batch': 1000, 'ms_per_step': ms, 'value': 1000 / ms * 1e3,
+                    'unit': 'log-likelihoods/sec', 'kernel': 'flat_spn_kernel',
+                    'roofline': hbm(1000 * 68, ms),
+                    'roofline_basis': 'whole call; 68 algorithmic B/sample (16 fp32 inputs + 1 result): a 68 KB problem, '
+                                      'launch-latency bound by construction',
+                    'cpu_baseline': {'value': 1000 / dc, 'unit': 'log-likelihoods/sec', 'cores': 1, 'kind': 'port',
+                                     'sample': '{} calls of 1000 samples ({:.2f} s), oracle/flat_spn_oracle.py = the '
+                                               "reference's numpy / scipy bottom-up pass".format(n_rep, dc * n_rep)}})
+    except Exception as ex:
+        out.append({'config': 'BASELINE config 1', 'error': '{}: {}'.format(type(ex).__name__, ex)})
+
     # ---- BASELINE config 2: RAT-SPN, B = 4096 (constructor defaults + the two wider settings) ----------
     B = 4096
     # bytes / flops per sample: fully fused 4*(784+1); (8,8) and (16,16) run as leaf | prod+sum | prod+root
@@ -270,23 +345,65 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
         m = GaussianRatSpn(D, rg_depth=2, rg_repetitions=8, rg_batch=I, rg_sum=S, random_state=42).eval()
         sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
         m.to(dev)
-        xs = [torch.randn(B, D, device=dev) for _ in range(4)]
+        xs = [torch.randn(B, D, device=dev) for _ in range(8)]
         kid = KERNEL_FUSED if I < 8 else KERNEL_LEAF   # rg_batch 8 and 16 run leaf | prod+sum | prod+root on the MFMA
-        ms, k_ms = _time_eval(m, xs, timer, kid, steps=50)
+        ms_eager, k_ms = _time_eval(m, xs, timer, kid, steps=50)
+        ms_graph = _time_eval_graph(m, xs)
+        ms = ms_graph if ms_graph is not None else ms_eager
+        from deeprob import hip as _hip
+        prev = _hip.trust_version_counters(True)     # the unchecked fast path (no write through .data, caller's word)
+        try:
+            with torch.no_grad():
+                m(xs[0]); m(xs[0])
+            ms_trust = _time_eval_graph(m, xs)
+        finally:
+            _hip.trust_version_counters(prev)
         n_cpu = 4096 if I <= 8 else 1024
         xc = torch.randn(n_cpu, D)
         rate, dt = _oracle_rate(lambda a, b: orc.ratspn_forward(sd, xc[a:b]), n_cpu, 1024 if I > 8 else 4096, threads)
+        traffic, tsrc = read_traffic('config2_{}_{}'.format(I, S))
+        roof = hbm(B * alg, ms) if I <= 8 else flops(B * fl, ms, 'valu')
+        roof['traffic'], roof['traffic_source'] = traffic, tsrc
         e = {'workload': 'GaussianRatSpn(784, rg_depth=2, rg_repetitions=8, rg_batch={}, rg_sum={}) forward, '
-                         'model(x) under no_grad'.format(I, S),
+                         'model(x) under no_grad over 8 resident batches'.format(I, S),
              'config': 'BASELINE config 2', 'batch': B, 'ms_per_step': ms, 'value': B / ms * 1e3,
-             'unit': 'log-likelihoods/sec', 'kernel_ms': k_ms,
-             'kernel': 'fused forward' if I < 8 else 'leaf MFMA kernel (then the prod+sum and prod+root MFMA kernels)',
-             'roofline': hbm(B * alg, ms) if I <= 8 else flops(B * fl, ms, 'valu'),
+             'unit': 'log-likelihoods/sec',
+             'step_basis': 'model(x) calls replayed from one HIP graph (32 calls per replay; kernels, gaps and the per-call '
+                           'parameter-table check included)' if ms_graph is not None else 'eager python loop',
+             'ms_per_step_eager': ms_eager, 'ms_per_step_trusting_version_counters': ms_trust, 'kernel_ms': k_ms,
+             'kernel': ('fused forward, small-batch kernel (one HIP event pair around a single launch: includes its '
+                        'dispatch latency; rocprofv3: profiles/r03_config2_kernel_stats.txt)') if I < 8
+                       else 'leaf MFMA kernel (then the prod+sum and prod+root MFMA kernels)',
+             'roofline': roof,
              'roofline_basis': 'whole step; {} algorithmic B/sample'.format(alg) if I <= 8
                                else 'whole step; {:.0f} flop/sample on the fp32 VALU (SURVEY 8d: VALU-bound)'.format(fl),
              'cpu_baseline': {'value': rate, 'unit': 'log-likelihoods/sec', 'cores': threads, 'kind': 'port',
                               'sample': '{} samples ({:.1f} s), oracle/ratspn_oracle.py'.format(n_cpu, dt)}}
         out.append(e)
+        if (I, S) == (2, 2):
+            # the marginalisation path (nan_to_num_ at ratspn.py:103): 30 % of the entries NaN, at B = 4096 and 65536
+            for Bn in (4096, 65536):
+                gen = torch.Generator(device=dev).manual_seed(7)
+                xn = [torch.randn(Bn, D, device=dev, generator=gen) for _ in range(4 if Bn > 4096 else 8)]
+                for t in xn:
+                    t[torch.rand(Bn, D, device=dev, generator=gen) < 0.3] = float('nan')
+                xcl = [torch.randn(Bn, D, device=dev, generator=gen) for _ in range(len(xn))]
+                with torch.no_grad():
+                    for t in xn[:2]:
+                        m(t)       # (raises the marginalised-evidence hint: the later launches take the variant built for it)
+                msn_e, _ = _time_eval(m, xn, timer, kid, steps=30)
+                msn_g = _time_eval_graph(m, xn)
+                msn = msn_g if msn_g is not None else msn_e
+                torch.cuda.synchronize()
+                time.sleep(0.05)
+                msc_g = _time_eval_graph(m, xcl)     # clean inputs, same size, same protocol (right after: same variant)
+                out.append({'workload': 'the same model, 30 % of the inputs NaN (marginalised evidence)',
+                            'config': 'BASELINE config 2 / headline size, marginalised', 'batch': Bn, 'ms_per_step': msn,
+                            'value': Bn / msn * 1e3, 'unit': 'log-likelihoods/sec', 'ms_per_step_eager': msn_e,
+                            'ms_per_step_clean_same_protocol': msc_g,
+                            'slowdown_vs_clean': (msn / msc_g) if msc_g else None,
+                            'roofline': hbm(Bn * alg, msn), 'roofline_basis': 'whole step; 3140 algorithmic B/sample'})
+                del xn, xcl
         del m, xs
 
     # ---- BASELINE config 4: DGC-SPN, B = 8192 ----------------------------------------------------------------------
@@ -304,7 +421,7 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
                 'config': 'BASELINE config 4', 'batch': B, 'ms_per_step': ms, 'value': B / ms * 1e3,
                 'unit': 'log-likelihoods/sec', 'kernel_ms': k_ms,
                 'kernel': 'spatial_sumprodroot_fwd_kernel (last sum level + product + root)',
-                'roofline': hbm(B * 588164, ms),
+                'roofline': dict(hbm(B * 588164, ms), **dict(zip(('traffic', 'traffic_source'), read_traffic('config4')))),
                 'roofline_basis': 'whole step; 588164 algorithmic B/sample (SURVEY 8d, products folded into sums)',
                 'cpu_baseline': {'value': rate, 'unit': 'log-likelihoods/sec', 'cores': threads, 'kind': 'port',
                                  'sample': '256 samples ({:.1f} s), oracle/dgcspn_oracle.py'.format(dt)}})
@@ -322,12 +439,18 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
     m.to(dev)
     xs = [torch.randn(B, D, device=dev) for _ in range(2)]
     ms, k_ms = _time_eval(m, xs, timer, KERNEL_COUPLING, steps=20, warm=3)
+    from deeprob import hip as _hip
+    prev = _hip.trust_version_counters(True)
+    try:
+        ms_trust, _ = _time_eval(m, xs, timer, KERNEL_COUPLING, steps=20, warm=3)
+    finally:
+        _hip.trust_version_counters(prev)
     per_layer = B * 2 * (392 * 128 + 128 * 784)
     xc = torch.randn(16384, D)
     rate, dt = _oracle_rate(lambda a, b: forc.flow_log_prob(sd, xc[a:b]), 16384, 4096, threads)
     e = {'workload': 'RealNVP1d(784, n_flows=5, depth=1, units=128, batch_norm, affine) forward log-likelihood',
          'config': 'BASELINE config 5', 'batch': B, 'ms_per_step': ms, 'value': B / ms * 1e3,
-         'unit': 'log-likelihoods/sec', 'kernel_ms': k_ms,
+         'unit': 'log-likelihoods/sec', 'ms_per_step_trusting_version_counters': ms_trust, 'kernel_ms': k_ms,
          'kernel': 'coupling_x3_kernel (one of the 5 layers; split-f16 MFMA, fp32-grade products)',
          'roofline': hbm(B * 2 * D * 4, k_ms) if k_ms else hbm(5 * B * 2 * D * 4, ms),
          'roofline_basis': 'one coupling kernel; x read + out written once: 2*784*4 algorithmic B per sample and layer '
@@ -336,6 +459,7 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
          'fp32_equivalent_tflops': (per_layer / (k_ms * 1e-3) / 1e12) if k_ms else None,
          'cpu_baseline': {'value': rate, 'unit': 'log-likelihoods/sec', 'cores': threads, 'kind': 'port',
                           'sample': '16384 samples ({:.1f} s), oracle/flows_oracle.py'.format(dt)}}
+    e['roofline']['traffic'], e['roofline']['traffic_source'] = read_traffic('config5')
     out.append(e)
     m_flow = m
     del xs
@@ -569,7 +693,7 @@ def main():
             k_ms = sum(timer.ms(handles[i]) for i, _ in sampled) / n_launches
             alg_bytes = B * 4 * (D + model.out_classes)
             achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-            traffic, source = read_traffic()
+            traffic, source = read_traffic('headline')
             out['roofline'] = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic if B == 65536 else None,
                                'traffic_source': source if B == 65536 else None,
