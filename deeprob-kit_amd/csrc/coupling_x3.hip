@@ -72,40 +72,81 @@ struct X3PackArgs {
 // conditioner weights are a few hundredths, so unscaled they carry an ABSOLUTE error of 3e-8 each -- invisible on
 // standardised data, 1e-3 relative on a log-likelihood once BatchNorm scales of 100 and |x| of 30 multiply it (measured
 // against an fp64 evaluation of the reference formulas).  Each table is therefore multiplied by the power of two that puts its largest entry into
-// [2^12, 2^13); the kernel divides the accumulators by it again.  One block; the tables are rebuilt only when a
-// parameter changed.
-__global__ __launch_bounds__(1024) void coupling_x3_scale_kernel(const X3PackArgs a) {
-    __shared__ float red[2][16];
-    if (gate_closed(a.gate)) return;
+// [2^12, 2^13); the kernel divides the accumulators by it again.
+//
+// One pass over the parameters does two things (round 3): the maxima behind those scales, and a fingerprint of every byte
+// the tables depend on -- the used columns of W1 with the folded input affine, b1, the used rows of W2 and b2.  The last
+// work-group to finish compares the fingerprint with the one the tables were built from and opens the gate of the pack
+// kernel only if it differs (DPK_FLAG_PARAMS_VERIFY; an unconditional build opens it always): a verifying call costs
+// this pass + an empty pack launch instead of the generic fingerprint + scale + pack launches.
+struct X3Check {   // 32 bytes in the workspace, zeroed by the unconditional build
+    unsigned long long stored, acc;
+    unsigned m1, m2, tickets, gate;
+};
+constexpr int kX3CheckBlocks = 48;
+__global__ __launch_bounds__(256) void coupling_x3_check_kernel(const X3PackArgs a, X3Check *st, int verify) {
+    __shared__ float red[2][4];
+    __shared__ unsigned long long hred[4];
     const int D = a.D, U = a.U, K1 = a.g.K1, N2 = a.g.N2;
+    // (32-bit indices: U K1 and 2 N2 U are a few hundred thousand; a 64-bit division per element tripled this pass)
+    const int gtid = (int)(blockIdx.x * blockDim.x + threadIdx.x), gsz = (int)(gridDim.x * blockDim.x);
     float m1 = 0.f, m2 = 0.f;
-    for (int64_t e = threadIdx.x; e < (int64_t)U * K1; e += blockDim.x) {
-        const int unit = (int)(e / K1), col = 2 * (int)(e % K1) + a.pm;
-        float v = a.W1[(int64_t)unit * D + col];
+    unsigned long long h = 0ull;
+    for (int e = gtid; e < U * K1; e += gsz) {
+        const int unit = e / K1, col = 2 * (e - unit * K1) + a.pm;
+        float v = a.W1[unit * D + col];
+        h += fp_word(__float_as_uint(v), (unsigned)e * 8u + 1u);
         if (a.in_scale) v *= a.in_scale[col];
         m1 = fmaxf(m1, fabsf(v));
     }
     const int rows2 = a.affine ? 2 : 1;
-    for (int64_t e = threadIdx.x; e < (int64_t)rows2 * N2 * U; e += blockDim.x) {
-        const int unit = (int)(e % U);
-        const int64_t r = e / U;
-        const int ts = (int)(r / N2), var = 2 * (int)(r % N2) + (1 - a.pm);
-        m2 = fmaxf(m2, fabsf(a.W2[((int64_t)ts * D + var) * U + unit]));
+    for (int e = gtid; e < rows2 * N2 * U; e += gsz) {
+        const int r = e / U, unit = e - r * U;
+        const int ts = r / N2, var = 2 * (r - ts * N2) + (1 - a.pm);
+        const float v = a.W2[(ts * D + var) * U + unit];
+        h += fp_word(__float_as_uint(v), (unsigned)e * 8u + 2u);
+        m2 = fmaxf(m2, fabsf(v));
     }
+    for (int e = gtid; e < U; e += gsz) h += fp_word(__float_as_uint(a.b1[e]), (unsigned)e * 8u + 3u);
+    for (int e = gtid; e < rows2 * D; e += gsz) h += fp_word(__float_as_uint(a.b2[e]), (unsigned)e * 8u + 4u);
+    if (a.in_scale)
+        for (int e = gtid; e < D; e += gsz)
+            h += fp_word(__float_as_uint(a.in_scale[e]), (unsigned)e * 8u + 5u) + fp_word(__float_as_uint(a.in_shift[e]), (unsigned)e * 8u + 6u);
     m1 = wave_reduce_max(m1);
     m2 = wave_reduce_max(m2);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) h += (unsigned long long)__shfl_xor((long long)h, o, 64);
     if ((threadIdx.x & 63) == 0) {
         red[0][threadIdx.x >> 6] = m1;
         red[1][threadIdx.x >> 6] = m2;
+        hred[threadIdx.x >> 6] = h;
     }
     __syncthreads();
-    if (threadIdx.x < 2) {
-        float m = 0.f;
-        for (int w = 0; w < 16; ++w) m = fmaxf(m, red[threadIdx.x][w]);
-        // m * scale in [2^12, 2^13); degenerate tables (all zero, inf, NaN) keep scale 1
-        float sc = 1.f;
-        if (m > 0.f && m < 3.0e38f) sc = exp2f(fminf(fmaxf(12.f - floorf(log2f(m)), -60.f), 60.f));
-        a.scales[threadIdx.x] = sc;
+    if (threadIdx.x == 0) {
+        // (non-negative floats order like their bit patterns: an unsigned atomic max is the float max)
+        atomicMax(&st->m1, __float_as_uint(fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]))));
+        atomicMax(&st->m2, __float_as_uint(fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]))));
+        atomicAdd(&st->acc, (hred[0] + hred[1]) + (hred[2] + hred[3]) + (unsigned long long)(a.pm + 2 * a.affine + 1));
+        __threadfence();
+        if (atomicAdd(&st->tickets, 1u) == gridDim.x - 1) {   // last block: every partial result has arrived
+            __threadfence();
+            const unsigned long long sum = atomicExch(&st->acc, 0ull);
+            const unsigned b1 = atomicExch(&st->m1, 0u), b2 = atomicExch(&st->m2, 0u);
+            const bool rebuild = !verify || sum != st->stored;
+            if (rebuild) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float m = __uint_as_float(t ? b2 : b1);
+                    // m * scale in [2^12, 2^13); degenerate tables (all zero, inf, NaN) keep scale 1
+                    float sc = 1.f;
+                    if (m > 0.f && m < 3.0e38f) sc = exp2f(fminf(fmaxf(12.f - floorf(log2f(m)), -60.f), 60.f));
+                    a.scales[t] = sc;
+                }
+            }
+            st->stored = sum;
+            st->gate = rebuild ? 1u : 0u;
+            st->tickets = 0u;
+        }
     }
 }
 
@@ -198,6 +239,12 @@ struct X3Args {
     const uint16_t *w1t;
     const char *w2t;
     const float *b1f, *act_weight, *scales;
+    // BASE mode (last coupling of a flow + the affine behind it + the Normal base, dpk_coupling1d_pairs_logprob): the
+    // per-column (a_d, c_d) pairs with -t^2 = -(u' - loc)^2 / (2 sigma^2), t = a_d u_d + c_d, their constant, the
+    // log-det accumulated so far and the log-likelihoods written instead of `out`
+    const float *base_ac;      // [2][D] then [1] constant
+    const float *ildj_in;      // [B] or null
+    float *ll_out;             // [B]
     long long *dbg;   // measurement only (-DDPK_X3_TIMELINE + DPK_X3_TIMELINE=1): s_memtime stamps of work-group 0
 };
 
@@ -221,7 +268,7 @@ __device__ __forceinline__ float x3_tanh(float v) {
 #define X3_STAMP(row, slot) do { } while (0)
 #endif
 
-template <bool AFFINE, int NU>
+template <bool AFFINE, int NU, bool BASE = false>
 __global__ __launch_bounds__(2 * kGemmWaves * 64) void coupling_x3_kernel(const X3Args a) {
     constexpr int W1CH = 2 * NU * 2 * 1024;
     constexpr int KK = NU * 2;                                   // K-steps of GEMM 2 (16 hidden units each)
@@ -237,6 +284,7 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void coupling_x3_kernel(const 
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
     lchar *smem = (lchar *)smem_generic;
     lfloat *b1_l = (lfloat *)(smem + kGemmStages * STAGE);       // [U]
+    lfloat *base_l = b1_l + ((a.U + 3) & ~3);                    // BASE: [2][D] (a_d, c_d), 16-byte aligned (D % 8 == 0)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = wave8 >= kGemmWaves;
@@ -321,6 +369,9 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void coupling_x3_kernel(const 
     }
     // ================================================ compute waves =========================================
     for (int e = tid; e < a.U; e += kGemmWaves * 64) b1_l[e] = a.b1f[e];
+    if (BASE)
+        for (int e = tid; e < 2 * a.D; e += kGemmWaves * 64) base_l[e] = a.base_ac[e];
+    const float base_cst = BASE ? a.base_ac[2 * a.D] : 0.f;
     const float act = AFFINE ? a.act_weight[0] : 0.f;
     const float w1sc = a.scales[0], w2sc = a.scales[1];
     __syncthreads();
@@ -436,7 +487,7 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void coupling_x3_kernel(const 
         const bool row_ok = b < a.B;
         const float *xrow = a.x + (row_ok ? b : a.B - 1) * D;
         float *orow = a.out + (row_ok ? b : a.B - 1) * D;
-        float ssum = 0.f;
+        float ssum = 0.f, bacc = 0.f;
         for (int pt = 0; pt < NPT; ++pt) {
             X3_STAMP(crow, 0);
             gemm_lds_barrier();
@@ -512,7 +563,22 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void coupling_x3_kernel(const 
                     o[(2 * i) >> 2][(2 * i) & 3] = lo;
                     o[(2 * i + 1) >> 2][(2 * i + 1) & 3] = hi;
                 }
-                if (row_ok && 2 * n0 < D) {
+                if (BASE) {
+                    // the Normal base on the 8 raw columns of the group: -t^2 with t = a_d u_d + c_d (no store of u)
+                    if (2 * n0 < D) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            if (2 * n0 + 4 * q < D) {
+                                const gf32x4 ba = *(lf4 *)(base_l + 2 * n0 + 4 * q), bc = *(lf4 *)(base_l + D + 2 * n0 + 4 * q);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const float t = fmaf(o[q][i], ba[i], bc[i]);
+                                    bacc = fmaf(-t, t, bacc);
+                                }
+                            }
+                        }
+                    }
+                } else if (row_ok && 2 * n0 < D) {
                     *reinterpret_cast<gf32x4 *>(orow + 2 * n0) = o[0];
                     if (2 * n0 + 4 < D) *reinterpret_cast<gf32x4 *>(orow + 2 * n0 + 4) = o[1];
                 }
@@ -522,11 +588,35 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void coupling_x3_kernel(const 
         }
         // ---- log-det: the two lanes of a sample hold disjoint halves of the transformed variables -----------------
         const float tot = ssum + __shfl_xor(ssum, 32, 64);
-        if (h == 0 && row_ok) {
+        if (BASE) {
+            const float btot = bacc + __shfl_xor(bacc, 32, 64);
+            if (h == 0 && row_ok)
+                a.ll_out[b] = btot + base_cst + (a.ildj_in ? a.ildj_in[b] : 0.f) + (AFFINE ? -tot : 0.f);
+        } else if (h == 0 && row_ok) {
             const float v = AFFINE ? (a.inverse ? tot : -tot) : 0.f;
             if (a.accumulate) a.ldj[b] += v; else a.ldj[b] = v;
         }
     }
+}
+
+// (a_d, c_d) of the fused Normal base: t_d = a_d u_d + c_d with -t_d^2 = -(sc_d u_d + sh_d - loc_d)^2 / (2 sigma_d^2), and the
+// constant sum_d (-log sigma_d - log sqrt(2 pi)) + ildj_const (reference: flows/models/base.py:139-143 behind the affine
+// of an eval-mode BatchNormLayer1d, flows/utils.py:118-139).  One block, every call (D-sized, live parameters).
+__global__ __launch_bounds__(256) void x3_base_prep_kernel(const float *__restrict__ sc, const float *__restrict__ sh,
+                                                           const float *__restrict__ loc, const float *__restrict__ scale,
+                                                           const float *__restrict__ ildj_const, int D, float *__restrict__ ac) {
+    __shared__ float part[4];
+    float csum = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const float sg = scale[d], r = 0.70710678118654752440f / sg;
+        ac[d] = (sc ? sc[d] : 1.f) * r;
+        ac[D + d] = ((sc ? sh[d] : 0.f) - loc[d]) * r;
+        csum += -logf(sg) - kLogSqrt2Pi;
+    }
+    csum = wave_reduce_sum(csum);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = csum;
+    __syncthreads();
+    if (threadIdx.x == 0) ac[2 * D] = (part[0] + part[1]) + (part[2] + part[3]) + (ildj_const ? *ildj_const : 0.f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -536,6 +626,8 @@ struct X3Ws {
     uint16_t *w1t;
     char *w2t;
     float *b1f, *scales;
+    float *base_ac;   // [2][D] + constant: the fused Normal base of dpk_coupling1d_pairs_logprob (rebuilt per call)
+    X3Check *check;   // fingerprint / gate state of the tables
     int64_t bytes;
 };
 static X3Ws x3_carve(void *base, const X3Geom &g, int U) {
@@ -551,6 +643,8 @@ static X3Ws x3_carve(void *base, const X3Geom &g, int U) {
     w.w2t = take((int64_t)g.NPT * g.W2CH);
     w.b1f = (float *)take((int64_t)U * 4);
     w.scales = (float *)take(8);
+    w.base_ac = (float *)take((int64_t)(4 * g.K1 + 4) * 4);
+    w.check = (X3Check *)take(sizeof(X3Check));
     w.bytes = o;
     return w;
 }
@@ -558,13 +652,14 @@ static X3Ws x3_carve(void *base, const X3Geom &g, int U) {
 // (D % 8: a lane's four consecutive transformed variables are one aligned run of 8 raw columns)
 static bool x3_shape_ok(int D, int U) { return D >= 8 && (D % 8) == 0 && (U == 32 || U == 64 || U == 96 || U == 128); }
 
-template <bool AFFINE, int NU>
+template <bool AFFINE, int NU, bool BASE = false>
 static int x3_launch(const X3Args &a, hipStream_t st) {
     constexpr int W1CH = 2 * NU * 2 * 1024, KK = NU * 2;
     constexpr int W2CH = ((KK * 4 * 1024 + 1024 + 4095) / 4096) * 4096;
     constexpr int STAGE = (kX3XB + W1CH) > W2CH ? (kX3XB + W1CH) : W2CH;
-    const size_t lds = (size_t)kGemmStages * STAGE + (size_t)a.U * 4;
-    auto kern = coupling_x3_kernel<AFFINE, NU>;
+    const size_t lds = (size_t)kGemmStages * STAGE + (size_t)((a.U + 3) & ~3) * 4 + (BASE ? (size_t)2 * a.D * 4 : 0);
+    DPK_REQUIRE(lds <= 160 * 1024, DPK_EUNSUPPORTED, "coupling1d_pairs: %zu bytes of LDS", lds);
+    auto kern = coupling_x3_kernel<AFFINE, NU, BASE>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024)) return rc;
     const int cus = device_cus();
     const int grid = a.ntiles < cus ? a.ntiles : cus;
@@ -614,12 +709,16 @@ extern "C" int64_t dpk_coupling1d_pairs_workspace_bytes(int32_t D, int32_t units
     return x3_carve(nullptr, x3_geom(D, units), units).bytes;
 }
 
-extern "C" int dpk_coupling1d_pairs_forward(const float *x, int64_t B, int32_t D, int32_t masked_parity,
-                                            const float *W1, const float *b1, const float *W2, const float *b2,
-                                            int32_t units, const float *act_weight, const float *in_scale,
-                                            const float *in_shift, int32_t affine, int32_t inverse, float *out,
-                                            float *ldj, int32_t accumulate_ldj, void *ws, int64_t ws_bytes,
-                                            uint32_t flags, void *stream) {
+struct X3Base {   // the fused tail of dpk_coupling1d_pairs_logprob (all null: plain coupling)
+    const float *out_scale, *out_shift, *loc, *scale, *ildj_in, *ildj_const;
+    float *ll;
+};
+static int x3_forward_common(const float *x, int64_t B, int32_t D, int32_t masked_parity,
+                             const float *W1, const float *b1, const float *W2, const float *b2,
+                             int32_t units, const float *act_weight, const float *in_scale,
+                             const float *in_shift, int32_t affine, int32_t inverse, float *out,
+                             float *ldj, int32_t accumulate_ldj, void *ws, int64_t ws_bytes,
+                             uint32_t flags, void *stream, const X3Base *base) {
     DPK_REQUIRE(B >= 0 && D > 0 && units > 0 && (masked_parity == 0 || masked_parity == 1), DPK_EINVAL,
                 "coupling1d_pairs: bad sizes");
     DPK_REQUIRE(x3_shape_ok(D, units), DPK_EUNSUPPORTED, "coupling1d_pairs: D=%d units=%d not built", D, units);
@@ -627,24 +726,31 @@ extern "C" int dpk_coupling1d_pairs_forward(const float *x, int64_t B, int32_t D
     DPK_REQUIRE(!affine || act_weight, DPK_EINVAL, "coupling1d_pairs: affine coupling needs the ScaledTanh weight");
     DPK_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), DPK_EINVAL, "coupling1d_pairs: scale/shift mismatch");
     if (B == 0) return DPK_OK;
-    DPK_REQUIRE(x && out && ldj, DPK_EINVAL, "coupling1d_pairs: null pointer");
-    DPK_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
-                DPK_EUNSUPPORTED, "coupling1d_pairs: x / out must be 16-byte aligned");
+    if (base) {
+        DPK_REQUIRE(x && base->loc && base->scale && base->ll && !inverse, DPK_EINVAL, "coupling1d_pairs_logprob: null pointer");
+        DPK_REQUIRE((base->out_scale == nullptr) == (base->out_shift == nullptr), DPK_EINVAL,
+                    "coupling1d_pairs_logprob: scale/shift mismatch");
+        DPK_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, DPK_EUNSUPPORTED, "coupling1d_pairs: x must be 16-byte aligned");
+    } else {
+        DPK_REQUIRE(x && out && ldj, DPK_EINVAL, "coupling1d_pairs: null pointer");
+        DPK_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+                    DPK_EUNSUPPORTED, "coupling1d_pairs: x / out must be 16-byte aligned");
+    }
     const X3Geom g = x3_geom(D, units);
     const X3Ws w = x3_carve(ws, g, units);
     DPK_REQUIRE(ws_bytes >= w.bytes, DPK_EWORKSPACE, "coupling1d_pairs: workspace %lld < %lld", (long long)ws_bytes,
                 (long long)w.bytes);
     hipStream_t st = (hipStream_t)stream;
-    const FpSeg segs[6] = {{W1, (int64_t)units * D * 4}, {b1, (int64_t)units * 4}, {W2, (int64_t)(affine ? 2 : 1) * D * units * 4},
-                           {b2, (int64_t)(affine ? 2 : 1) * D * 4}, {in_scale, (int64_t)D * 4}, {in_shift, (int64_t)D * 4}};
-    const TablePlan tp = plan_tables(flags, ws, segs, 6, st);
-    if (tp.run) {
+    if (!(flags & DPK_FLAG_PARAMS_CACHED)) {
+        const bool verify = (flags & DPK_FLAG_PARAMS_VERIFY) != 0;
+        if (!verify)   // (the workspace may be fresh memory: the check state starts from zero)
+            DPK_REQUIRE(hipMemsetAsync(w.check, 0, sizeof(X3Check), st) == hipSuccess, DPK_ELAUNCH, "memset");
         X3PackArgs p{};
-        p.gate = tp.gate;
         p.W1 = W1; p.b1 = b1; p.W2 = W2; p.b2 = b2; p.in_scale = in_scale; p.in_shift = in_shift;
         p.D = D; p.U = units; p.pm = masked_parity; p.affine = affine; p.g = g;
         p.w1t = w.w1t; p.w2t = w.w2t; p.b1f = w.b1f; p.scales = w.scales;
-        DPK_LAUNCH(coupling_x3_scale_kernel, dim3(1), dim3(1024), 0, st, p);
+        p.gate = &w.check->gate;
+        DPK_LAUNCH(coupling_x3_check_kernel, dim3(kX3CheckBlocks), dim3(256), 0, st, p, w.check, verify ? 1 : 0);
         const int64_t total = (int64_t)g.NCH1 * 2 * g.NU * 64 + (int64_t)g.NPT * (units / 16) * 2 * 64 + (int64_t)g.NPT * 32 +
                               units;
         DPK_LAUNCH(coupling_x3_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p);
@@ -654,10 +760,44 @@ extern "C" int dpk_coupling1d_pairs_forward(const float *x, int64_t B, int32_t D
     a.x = x; a.out = out; a.ldj = ldj; a.B = B; a.D = D; a.U = units; a.pm = masked_parity; a.inverse = inverse;
     a.accumulate = accumulate_ldj; a.ntiles = cdiv(B, kX3Tile); a.g = g;
     a.w1t = w.w1t; a.w2t = w.w2t; a.b1f = w.b1f; a.act_weight = act_weight; a.scales = w.scales;
+    if (base) {
+        DPK_LAUNCH(x3_base_prep_kernel, dim3(1), dim3(256), 0, st, base->out_scale, base->out_shift, base->loc, base->scale,
+                   base->ildj_const, D, w.base_ac);
+        DPK_CHECK_LAUNCH("x3_base_prep_kernel");
+        a.base_ac = w.base_ac; a.ildj_in = base->ildj_in; a.ll_out = base->ll;
+        switch (units / 32) {
+            case 1: return affine ? x3_launch<true, 1, true>(a, st) : x3_launch<false, 1, true>(a, st);
+            case 2: return affine ? x3_launch<true, 2, true>(a, st) : x3_launch<false, 2, true>(a, st);
+            case 3: return affine ? x3_launch<true, 3, true>(a, st) : x3_launch<false, 3, true>(a, st);
+            default: return affine ? x3_launch<true, 4, true>(a, st) : x3_launch<false, 4, true>(a, st);
+        }
+    }
     switch (units / 32) {
         case 1: return affine ? x3_launch<true, 1>(a, st) : x3_launch<false, 1>(a, st);
         case 2: return affine ? x3_launch<true, 2>(a, st) : x3_launch<false, 2>(a, st);
         case 3: return affine ? x3_launch<true, 3>(a, st) : x3_launch<false, 3>(a, st);
         default: return affine ? x3_launch<true, 4>(a, st) : x3_launch<false, 4>(a, st);
     }
+}
+
+extern "C" int dpk_coupling1d_pairs_forward(const float *x, int64_t B, int32_t D, int32_t masked_parity,
+                                            const float *W1, const float *b1, const float *W2, const float *b2,
+                                            int32_t units, const float *act_weight, const float *in_scale,
+                                            const float *in_shift, int32_t affine, int32_t inverse, float *out,
+                                            float *ldj, int32_t accumulate_ldj, void *ws, int64_t ws_bytes,
+                                            uint32_t flags, void *stream) {
+    return x3_forward_common(x, B, D, masked_parity, W1, b1, W2, b2, units, act_weight, in_scale, in_shift, affine, inverse,
+                             out, ldj, accumulate_ldj, ws, ws_bytes, flags, stream, nullptr);
+}
+
+extern "C" int dpk_coupling1d_pairs_logprob(const float *x, int64_t B, int32_t D, int32_t masked_parity,
+                                            const float *W1, const float *b1, const float *W2, const float *b2,
+                                            int32_t units, const float *act_weight, const float *in_scale,
+                                            const float *in_shift, int32_t affine, const float *out_scale,
+                                            const float *out_shift, const float *base_loc, const float *base_scale,
+                                            const float *ildj_in, const float *ildj_const, float *ll, void *ws,
+                                            int64_t ws_bytes, uint32_t flags, void *stream) {
+    const X3Base base{out_scale, out_shift, base_loc, base_scale, ildj_in, ildj_const, ll};
+    return x3_forward_common(x, B, D, masked_parity, W1, b1, W2, b2, units, act_weight, in_scale, in_shift, affine, 0,
+                             nullptr, nullptr, 0, ws, ws_bytes, flags, stream, &base);
 }

@@ -116,9 +116,24 @@ class NormalizingFlow(ProbabilisticModel):
         affine, ldj_const, ildj = None, [], None
         if torch.is_tensor(pre_ildj):
             ildj = pre_ildj.to(torch.float32).contiguous().clone()
-        for layer in self.layers:
+        # the last coupling, when nothing but batch-norm layers follows it, is evaluated together with their folded
+        # affine and the Normal base (ops_flows.coupling1d_logprob): its output is never written, the base pass over it
+        # never launched
+        layers = list(self.layers)
+        last = max((i for i, l in enumerate(layers) if not isinstance(l, BatchNormLayer1d)), default=-1)
+        for i, layer in enumerate(layers):
             if isinstance(layer, BatchNormLayer1d):
                 affine, ldj_const = ops_flows.bn1d_fold(layer, inverse=False, in_affine=affine, ldj_const=ldj_const)
+            elif i == last:
+                tail, tail_const = None, list(ldj_const)     # (a copy: the plain route below folds the tail itself)
+                for bn in layers[i + 1:]:
+                    tail, tail_const = ops_flows.bn1d_fold(bn, inverse=False, in_affine=tail, ldj_const=tail_const)
+                ll = ops_flows.coupling1d_logprob(x, layer, affine, ildj, tail, self.in_base_loc, self.in_base_scale,
+                                                  ops_flows.sum_constants(self, tail_const))
+                if ll is not None:
+                    return ll
+                x, ildj = ops_flows.coupling1d(x, layer, inverse=False, in_affine=affine, ldj=ildj)
+                affine = None
             else:
                 x, ildj = ops_flows.coupling1d(x, layer, inverse=False, in_affine=affine, ldj=ildj)
                 affine = None

@@ -81,6 +81,9 @@ SIGNATURES = {
                                               _c_void, _c_void, _i32, _c_void, _c_void, _c_void, _i32, _i32,
                                               _c_void, _c_void, _i32, _c_void, _i64, _c_void]),
     'dpk_coupling1d_pairs_workspace_bytes': (_i64, [_i32, _i32]),
+    'dpk_coupling1d_pairs_logprob': (ctypes.c_int, [_c_void, _i64, _i32, _i32, _c_void, _c_void, _c_void, _c_void, _i32,
+                                                    _c_void, _c_void, _c_void, _i32, _c_void, _c_void, _c_void, _c_void,
+                                                    _c_void, _c_void, _c_void, _c_void, _i64, _u32, _c_void]),
     'dpk_coupling1d_pairs_forward': (ctypes.c_int, [_c_void, _i64, _i32, _i32, _c_void, _c_void, _c_void, _c_void, _i32,
                                                     _c_void, _c_void, _c_void, _i32, _i32, _c_void, _c_void, _i32,
                                                     _c_void, _i64, _u32, _c_void]),

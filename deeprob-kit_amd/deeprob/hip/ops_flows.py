@@ -94,6 +94,49 @@ def coupling1d(x: torch.Tensor, layer, inverse: bool, in_affine: Optional[Tuple[
     return out, ldj
 
 
+def coupling1d_logprob(x: torch.Tensor, layer, in_affine, ildj: Optional[torch.Tensor], out_affine,
+                       base_loc: torch.Tensor, base_scale: torch.Tensor,
+                       ildj_const: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """The last CouplingLayer1d of a flow (density direction) + the folded affine behind it + the diagonal Normal base in
+    ONE kernel (reference: coupling.py:72-87 followed by flows/utils.py:118-139 and flows/models/base.py:139-143):
+    ``ll = sum_d log N(out_affine(u)_d; loc_d, scale_d) + ildj - sum s + ildj_const``.  None when the layer is outside
+    the column-pair MFMA kernel's envelope (the caller then chains coupling1d and normal_base_logprob)."""
+    lib = load_library()
+    x = require_device_f32(x, 'x')
+    lin1, lin2 = layer.network[0], layer.network[-1]
+    if len(layer.network) != 3 or x.dim() != 2:
+        return None
+    B, D = x.shape
+    units = lin1.weight.shape[0]
+    parity = layer._pair_parity()
+    if parity is None or units not in (32, 64, 96, 128) or D % 8 != 0 or x.data_ptr() % 16 != 0 or base_loc.numel() != D:
+        return None
+    n = lib.dpk_coupling1d_pairs_workspace_bytes(D, units)
+    if n < 0:
+        return None
+    pw = layer._ws_pairs
+    ws = pw.get(n, x.device)
+    sc, sh = in_affine if in_affine is not None else (None, None)
+    osc, osh = out_affine if out_affine is not None else (None, None)
+    act = layer.scale_act.weight if layer.affine else None
+    w1, b1 = require_device_f32(lin1.weight, 'W1'), require_device_f32(lin1.bias, 'b1')
+    w2, b2 = require_device_f32(lin2.weight, 'W2'), require_device_f32(lin2.bias, 'b2')
+    key = (_versions(w1, b1, w2, b2, sc, sh), parity, bool(layer.affine))
+    flags = cached_tables_flag() if pw.params_key == key else 0
+    pw.params_key = key
+    ll = torch.empty(B, dtype=torch.float32, device=x.device)
+    rc = lib.dpk_coupling1d_pairs_logprob(
+        ptr(x), B, D, parity, ptr(w1), ptr(b1), ptr(w2), ptr(b2), units, ptr(act), ptr(sc), ptr(sh), int(layer.affine),
+        ptr(osc), ptr(osh), ptr(require_device_f32(base_loc.reshape(-1), 'loc')),
+        ptr(require_device_f32(base_scale.reshape(-1), 'scale')), ptr(ildj), ptr(ildj_const), ptr(ll), ptr(ws),
+        ws.numel(), flags, stream_ptr(x.device))
+    if rc == -4:
+        pw.params_key = None
+        return None
+    check(rc, 'dpk_coupling1d_pairs_logprob')
+    return ll
+
+
 def _mlp_args(layer):
     """(n_hidden, W pointer array, b pointer array, widths array, tensors kept alive) of the conditioner."""
     import ctypes

@@ -220,6 +220,19 @@ int dpk_coupling1d_pairs_forward(const float *x, int64_t B, int32_t D, int32_t m
                                  const float *act_weight, const float *in_scale, const float *in_shift,
                                  int32_t affine, int32_t inverse, float *out, float *ldj, int32_t accumulate_ldj,
                                  void *ws, int64_t ws_bytes, uint32_t flags, void *stream);
+/* The LAST coupling of a flow fused with what follows it in NormalizingFlow.log_prob (reference: flows/models/base.py:
+ * 123-143): the density-direction coupling above, the per-variable affine behind it (out_scale / out_shift: an eval-mode
+ * BatchNormLayer1d folded by dpk_bn1d_fold, or NULL) and the diagonal Normal base --
+ *   ll[b] = sum_d log N(out_scale_d u_d + out_shift_d; base_loc_d, base_scale_d) + ildj_in[b] - sum s + *ildj_const.
+ * u is never written: the layer reads x once more than the plain coupling writes nothing, and the separate
+ * dpk_normal_base_logprob pass (one more read of u) disappears.  ildj_in / ildj_const may be NULL.  Same shapes,
+ * workspace and flags as dpk_coupling1d_pairs_forward.                                                        */
+int dpk_coupling1d_pairs_logprob(const float *x, int64_t B, int32_t D, int32_t masked_parity, const float *W1,
+                                 const float *b1, const float *W2, const float *b2, int32_t units,
+                                 const float *act_weight, const float *in_scale, const float *in_shift, int32_t affine,
+                                 const float *out_scale, const float *out_shift, const float *base_loc,
+                                 const float *base_scale, const float *ildj_in, const float *ildj_const, float *ll,
+                                 void *ws, int64_t ws_bytes, uint32_t flags, void *stream);
 
 /* Eval-mode BatchNormLayer1d.apply_backward (inverse = 0) / apply_forward (1)
  * (deeprob/flows/utils.py:118-153) as a per-variable affine y = x*scale_out + shift_out
