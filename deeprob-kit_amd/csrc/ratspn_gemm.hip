@@ -242,20 +242,150 @@ __global__ __launch_bounds__(256) void ratspn_gemm_prep_kernel(const GemmPrepArg
     if (threadIdx.x == 0) a.elig[rho] = bad_s ? 0 : 1;
 }
 
+// The ring kernel below is kept exactly as round 2 left it, in a namespace of its own with its own argument block and
+// its own copy of the upper layers: its hand-balanced schedule (one compute wave per SIMD, LDS-DMA ring, counted waits)
+// moved by 3-7 us of 46 when the upper layers were factored into a function shared with the other two mappings, when a
+// template flag for the marginalised-evidence variant was threaded through it, and by 0.7 us when three fields were
+// appended to its argument block (same-box A/B runs, round 3).  The small-batch kernel (ratspn_gemm_small.hip) and the
+// marginalised-evidence variant (ratspn_gemm_nan.hip) share ratspn_gemm_fused.h instead.
+namespace ring {
+
+// ------------------------------------------------------------------------------------------------
+// main kernel
+// ------------------------------------------------------------------------------------------------
+struct GemmArgs {
+    const float *x;
+    int64_t B;
+    int D, d, reps, C, NCH, ntiles;
+    const uint16_t *mtab, *ctab;
+    const float *biasT;   // [2][NT][16] whole-row constants in the accumulator order of a lane
+    const float *biasC;   // [NCH][2][NT][16] the same per chunk (tiles with marginalised evidence)
+    const int *elig;
+    const float *W0;   // [reps*2][S][I*I] linear softmax weights (copied into LDS)
+    const float *LW0;  // log-softmax weights (exact fallback of a node, exact evaluation)
+    cfloat_p Wr, LWr;  // [C][reps*S*S]
+    float *out;
+    double *ll_sum;
+    // exact evaluation
+    const int64_t *mask;
+    const uint8_t *pad;
+    const float *loc, *scale;
+#ifdef DPK_TIMELINE
+    unsigned long long *dbg;   // [blocks][waves][64][8] s_memtime stamps (measurement builds)
+#endif
+    int ablate;       // measurement only (DPK_GEMM_ABLATE): 1 no compute, 2 no table DMA, 4 no x DMA
+    int *slow_flag;   // host-mapped hint word (may be null): launch number of the last launch that met NaN evidence
+    int launch_seq;
+};
+
+__device__ __forceinline__ void lse_merge(float &m, float &s, float m2, float s2) {
+    const float mm = fmaxf(m, m2);
+    if (mm == -INFINITY) {
+        s = 0.f;
+        return;
+    }
+    s = s * __expf(m - mm) + s2 * __expf(m2 - mm);
+    m = mm;
+}
+
+
+// ---- exp-domain helpers of the fast upper layers ---------------------------------------------------------------
+// e[i] = 2^((x[i] - max) log2 e); returns max (0 for an all -inf input, whose exponentials are then 0)
+template <int NI> __device__ __forceinline__ float exp2_children(const float (&x)[NI], float (&e)[NI]) {
+    float m = x[0];
+#pragma unroll
+    for (int i = 1; i < NI; ++i) m = fmaxf(m, x[i]);
+    const float m0 = (m == -INFINITY) ? 0.f : m;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) e[i] = __builtin_amdgcn_exp2f((x[i] - m0) * 1.4426950408889634f);
+    return m0;
+}
+
+// Exact per-element evaluation of the 32 samples of a wave (any scale, any evidence): lane (s, h) takes the
+// repetitions rho = 2m + h, the two lanes of a sample meet in one shuffle per class.  Slow by design.
+template <int I, int S, int NT>
+__device__ __noinline__ void gemm_exact_wave(const GemmArgs &a, int64_t bw0, int lane, LseScratch sc) {
+    constexpr int RPT = 8 / I;
+    constexpr int RH = (NT * RPT + 1) / 2;   // repetitions per lane half
+    const int s = lane & 31, h = lane >> 5;
+    const int64_t b = bw0 + s;
+    const bool valid = b < a.B;
+    const float *xr = a.x + (valid ? b : a.B - 1) * a.D;
+    const int d = a.d;
+    float n1[RH][2][S];
+#pragma unroll
+    for (int m = 0; m < RH; ++m) {
+        const int rho = 2 * m + h;
+        float leaf[4][I];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < I; ++k) leaf[q][k] = 0.f;
+        if (rho < a.reps) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = rho * 4 + q;
+                for (int j = 0; j < d; ++j) {
+                    const int64_t o = (int64_t)r * d + j;
+                    if (a.pad != nullptr && a.pad[o]) continue;
+                    const float xv = xr[a.mask[o]];
+#pragma unroll
+                    for (int k = 0; k < I; ++k) {
+                        const int64_t po = ((int64_t)r * I + k) * d + j;
+                        const float mu = a.loc[po], sg = a.scale[po];
+                        const float dlt = xv - mu;
+                        leaf[q][k] += nan_to_num_f(fmaf(dlt * dlt, -0.5f / (sg * sg), -logf(sg) - kLogSqrt2Pi));
+                    }
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int64_t wo = ((int64_t)rho * 2 + p) * S * I * I;
+                prodsum_node<I, S>(leaf[2 * p], leaf[2 * p + 1], a.W0 + wo, a.LW0 + wo, sc, n1[m][p]);
+            }
+        }
+    }
+    const int M = a.reps * S * S;
+    double part = 0.0;
+    for (int cl = 0; cl < a.C; ++cl) {
+        float mm = -INFINITY, ss = 0.f;
+#pragma unroll
+        for (int m = 0; m < RH; ++m) {
+            const int rho = 2 * m + h;
+            if (rho < a.reps) {
+                float ea[S], ec[S], ma, mc, pm, ps;
+                exp_children<S>(n1[m][0], ea, ma);
+                exp_children<S>(n1[m][1], ec, mc);
+                const float *wr = (const float *)a.Wr + (int64_t)cl * M + rho * S * S;
+                const float *lwr = (const float *)a.LWr + (int64_t)cl * M + rho * S * S;
+                root_partial<S>(n1[m][0], n1[m][1], ea, ec, ma, mc, wr, lwr, sc, pm, ps);
+                lse_merge(mm, ss, pm, ps);
+            }
+        }
+        const float om = __shfl_xor(mm, 32, 64), os = __shfl_xor(ss, 32, 64);
+        lse_merge(mm, ss, om, os);
+        const float ll = (mm > -INFINITY) ? mm + logf(ss) : -INFINITY;
+        if (h == 0 && valid) {
+            a.out[b * a.C + cl] = ll;
+            part += (double)ll;
+        }
+    }
+    if (a.ll_sum != nullptr) {
+        part = wave_reduce_sum(part);
+        if (lane == 0) atomicAdd(a.ll_sum, part);   // (the count: once per launch, at the end of the kernel)
+    }
+}
+
 #ifdef DPK_TIMELINE
 #define GEMM_STAMP(row, slot) do { __builtin_amdgcn_sched_barrier(0); if (a.dbg && lane == 0 && !loader && (row) < 64) a.dbg[(((int64_t)blockIdx.x * kGemmWaves + wave) * 64 + (row)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define GEMM_STAMP(row, slot) do { } while (0)
 #endif
 
-// CT: the marginalised-evidence variant (taken while a recent launch met NaN inputs, slow_hint): chunks of 32 features
-// whose stage carries the negated-constant table next to the mean table, so that the validity GEMM of a chunk that
-// holds NaN reads its fragments from LDS like the mean GEMM does (the default build fetches them from L2 just in time,
-// one round trip per K-step: 3.9x the clean time on 30 % NaN inputs in round 2).  Same arithmetic, same results.
-template <int I, int S, int NT, bool CT = false>
+template <int I, int S, int NT>
 __global__ __launch_bounds__(2 * kGemmWaves * 64) void ratspn_gemm_kernel(const GemmArgs a) {
     constexpr int RPT = 8 / I;                           // repetitions per column tile
-    constexpr int KS = CT ? 2 : gemm_ks(NT);
+    constexpr int KS = gemm_ks(NT);
     constexpr int KC = 16 * KS;                          // features per chunk
     constexpr int W = 4 * KS;                            // 16-byte pieces per staged row
     constexpr int ROWB = KC * 4;
@@ -263,11 +393,11 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void ratspn_gemm_kernel(const 
     constexpr int SWS = (W == 16) ? 0 : (W == 8 ? 1 : 2);  // swizzle: piece ^= (row >> SWS) & (W-1)
     constexpr int XB = kGemmTile * ROWB;                 // x chunk bytes
     constexpr int BB = KS * NT * 2 * 1024;               // mean-table bytes per chunk
-    constexpr int STAGE = XB + (CT ? 2 : 1) * BB;
+    constexpr int STAGE = XB + BB;
     constexpr int NS = kGemmStages;
     constexpr int PX = 32 / RPI;                         // x DMA instructions per loader wave and chunk
-    constexpr int PB = BB / (kGemmWaves * 1024);         // table DMA instructions per loader wave and chunk (per table)
-    constexpr int P = PX + (CT ? 2 : 1) * PB;            // DMA instructions per loader wave and chunk
+    constexpr int PB = BB / (kGemmWaves * 1024);         // table DMA instructions per loader wave and chunk
+    constexpr int P = PX + PB;                           // DMA instructions per loader wave and chunk
     static_assert(BB % (kGemmWaves * 1024) == 0, "table chunk must split over the waves");
     static_assert(NS == 3 && P <= 63, "the counted waits leave exactly one chunk in flight");
     constexpr int NMAX = (I > S ? I : S);
@@ -303,8 +433,8 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void ratspn_gemm_kernel(const 
     double red_ll = 0.0;
     bool saw_nan_any = false;
     if (loader) {
-        gemm_loader_run<KS, PB, CT ? PB : 0>(a.x, a.B, D, NCH, ntiles, (int)blockIdx.x, grid, (gcchar_p)a.mtab, BB,
-                                             wave * PB, (unsigned)(uintptr_t)smem, STAGE, wave, lane, (gcchar_p)a.ctab);
+        gemm_loader_run<KS, PB>(a.x, a.B, D, NCH, ntiles, (int)blockIdx.x, grid, (gcchar_p)a.mtab, BB, wave * PB,
+                                (unsigned)(uintptr_t)smem, STAGE, wave, lane);
     } else {
     // ================================================ compute waves =========================================
     // constants into LDS
@@ -444,24 +574,14 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void ratspn_gemm_kernel(const 
                         }
                         if (odd_chunk) {
                             // - (mu^2/2 + log sqrt(2 pi)) of the variables that ARE observed (table of negated constants)
-                            if constexpr (CT) {   // staged next to the mean table
+                            typedef const __attribute__((address_space(1))) half8 gh8;
+                            const gcchar_p cb = (gcchar_p)a.ctab + ((((int64_t)(c * KS + ks) * NT) * 2) * 512 + lane * 8) * 2;
 #pragma unroll
-                                for (int t = 0; t < NT; ++t) {
-                                    const half8 ch = *(lh8 *)(tb + BB + (ks * NT + t) * 2048);
-                                    const half8 cl = *(lh8 *)(tb + BB + (ks * NT + t) * 2048 + 1024);
-                                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, valid[ks], acc[t], 0, 0, 0);
-                                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, valid[ks], acc[t], 0, 0, 0);
-                                }
-                            } else {
-                                typedef const __attribute__((address_space(1))) half8 gh8;
-                                const gcchar_p cb = (gcchar_p)a.ctab + ((((int64_t)(c * KS + ks) * NT) * 2) * 512 + lane * 8) * 2;
-#pragma unroll
-                                for (int t = 0; t < NT; ++t) {
-                                    const half8 ch = *(gh8 *)(cb + t * 2048);
-                                    const half8 cl = *(gh8 *)(cb + t * 2048 + 1024);
-                                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, valid[ks], acc[t], 0, 0, 0);
-                                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, valid[ks], acc[t], 0, 0, 0);
-                                }
+                            for (int t = 0; t < NT; ++t) {
+                                const half8 ch = *(gh8 *)(cb + t * 2048);
+                                const half8 cl = *(gh8 *)(cb + t * 2048 + 1024);
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, valid[ks], acc[t], 0, 0, 0);
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, valid[ks], acc[t], 0, 0, 0);
                             }
                         }
                     }
@@ -504,25 +624,111 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void ratspn_gemm_kernel(const 
                         for (int i = 0; i < 16; ++i) cst[t][i] = 0.f;
                     for (int c = 0; c < NCH; ++c) {
                         if ((odd_mask >> c) & 1u) continue;
-                        if constexpr (CT) {   // (32-feature chunks: the constants per K-step, prepared for the small-batch kernel)
-                            for (int ks = c * KS; ks < min((c + 1) * KS, (D + 15) >> 4); ++ks) {
-                                const float *bk = a.biasK + ((ks * 2 + h) * NT) * 16;
+                        const float *bc = a.biasC + ((c * 2 + h) * NT) * 16;
 #pragma unroll
-                                for (int t = 0; t < NT; ++t)
+                        for (int t = 0; t < NT; ++t)
 #pragma unroll
-                                    for (int i = 0; i < 16; ++i) cst[t][i] += bk[t * 16 + i];
+                            for (int i = 0; i < 16; ++i) cst[t][i] += bc[t * 16 + i];
+                    }
+                }
+                // Upper layers in the exp domain on the hardware's base-2 transcendentals; a node whose scaled sum
+                // vanishes (dominant pair under a vanishing weight) is redone exactly, out of line (gemm_node_exact).
+                constexpr float kL2E = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+                // phase A, branch free so that the independent nodes interleave (one wave per SIMD: a dependent chain of
+                // transcendentals would otherwise run at its latency): every product + sum node of the lane's partitions
+                GEMM_STAMP(grow - 1, 0);
+                float n1[NT * RPT][S];
+                bool vanished = false;   // some node's scaled sum fell below 1e-30 (dominant pair under a vanishing weight)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                    for (int ap = 0; ap < RPT; ++ap) {
+                        const int rho = t * RPT + ap;
+                        float va[I], vc[I];
+#pragma unroll
+                        for (int k = 0; k < I; ++k) {
+                            va[k] = acc[t][(ap * 2) * I + k] + cst[t][(ap * 2) * I + k];
+                            vc[k] = acc[t][(ap * 2 + 1) * I + k] + cst[t][(ap * 2 + 1) * I + k];
+                        }
+                        float ea[I], ec[I];
+                        const float ma = exp2_children<I>(va, ea), mc = exp2_children<I>(vc, ec);
+                        const int wo = (min(rho, a.reps - 1) * 2 + h) * S * I * I;
+#pragma unroll
+                        for (int o = 0; o < S; ++o) {
+                            float v = 0.f;
+#pragma unroll
+                            for (int i = 0; i < I; ++i) {
+                                float tt = 0.f;
+#pragma unroll
+                                for (int j = 0; j < I; ++j) tt = fmaf(w0_l[wo + (o * I + i) * I + j], ec[j], tt);
+                                v = fmaf(ea[i], tt, v);
                             }
-                        } else {
-                            const float *bc = a.biasC + ((c * 2 + h) * NT) * 16;
-#pragma unroll
-                            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                                for (int i = 0; i < 16; ++i) cst[t][i] += bc[t * 16 + i];
+                            n1[rho][o] = fmaf(__builtin_amdgcn_logf(v), kLn2, ma + mc);
+                            vanished = vanished || (v < 1e-30f && rho < a.reps);
                         }
                     }
                 }
+                // both lanes of a sample finish every repetition (the root weights stay wave-uniform):
+                // v_permlane32_swap leaves partition 0's outputs in one register and partition 1's in the other
+                float ta[NT * RPT][S], tc[NT * RPT][S];
+#pragma unroll
+                for (int rho = 0; rho < NT * RPT; ++rho)
+#pragma unroll
+                    for (int o = 0; o < S; ++o) {
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        const unsigned bits = __float_as_uint(n1[rho][o]);
+                        const u32x2 sw2 = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
+                        ta[rho][o] = __uint_as_float(sw2[0]);
+                        tc[rho][o] = __uint_as_float(sw2[1]);
+                    }
+                GEMM_STAMP(grow - 1, 1);
+                // root: per repetition (m, s) with logsumexp = m + ln s; the exponentials do not depend on the class
+                float ea[NT * RPT][S], ec[NT * RPT][S], mr[NT * RPT];
+                float mtop = -INFINITY;
+#pragma unroll
+                for (int rho = 0; rho < NT * RPT; ++rho) {   // (branch free: a column tile's spare repetitions get -inf)
+                    const float m2 = exp2_children<S>(ta[rho], ea[rho]) + exp2_children<S>(tc[rho], ec[rho]);
+                    mr[rho] = (rho < a.reps) ? m2 : -INFINITY;
+                    mtop = fmaxf(mtop, mr[rho]);
+                }
+                const float mtop0 = (mtop == -INFINITY) ? 0.f : mtop;
+                float scale[NT * RPT];
+#pragma unroll
+                for (int rho = 0; rho < NT * RPT; ++rho) scale[rho] = __builtin_amdgcn_exp2f((mr[rho] - mtop0) * kL2E);
+                const int M = a.reps * S * S;
+                const float qterm = -0.5f * qtot;
                 double part = 0.0;
-                if (gemm_upper_fast<I, S, NT>(a, acc, cst, w0_l, qtot, h, b, part)) {
+                GEMM_STAMP(grow - 1, 7);
+                // a vanished node anywhere in the wave: the wave's samples go through the exact evaluation instead
+                // (rare: a softmax weight below e^-69 on the dominant pair)
+                if (__any(vanished)) {
+                    const GemmArgs ac = a;
+                    gemm_exact_wave<I, S, NT>(ac, bw0, lane, sc);
+                    continue;
+                }
+                for (int cl = 0; cl < a.C; ++cl) {
+                    float tot = 0.f;
+#pragma unroll
+                    for (int rho = 0; rho < NT * RPT; ++rho) {
+                        const int wo = cl * M + min(rho, a.reps - 1) * S * S;   // (spare repetitions: scale == 0)
+                        float v = 0.f;
+#pragma unroll
+                        for (int i = 0; i < S; ++i) {
+                            float tt = 0.f;
+#pragma unroll
+                            for (int j = 0; j < S; ++j) tt = fmaf(a.Wr[wo + i * S + j], ec[rho][j], tt);
+                            v = fmaf(ea[rho][i], tt, v);
+                        }
+                        vanished = vanished || (v < 1e-30f && mr[rho] > -INFINITY);
+                        tot = fmaf(v, scale[rho], tot);
+                    }
+                    const float ll = ((mtop > -INFINITY) ? fmaf(__builtin_amdgcn_logf(tot), kLn2, mtop) : -INFINITY) + qterm;
+                    if (h == 0 && b < a.B) {
+                        a.out[b * a.C + cl] = ll;
+                        part += (double)ll;
+                    }
+                }
+                if (__any(vanished)) {   // (the exact evaluation overwrites what this wave stored and adds its own sum)
                     const GemmArgs ac = a;
                     gemm_exact_wave<I, S, NT>(ac, bw0, lane, sc);
                     continue;
@@ -562,18 +768,20 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void ratspn_gemm_kernel(const 
 #endif
 }
 
+}  // namespace ring
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <int I, int S, int NT, bool CT = false>
-static int gemm_launch(const GemmArgs &a, int reps, hipStream_t st) {
-    constexpr int KS = CT ? 2 : gemm_ks(NT);
+template <int I, int S, int NT>
+static int gemm_launch(const ring::GemmArgs &a, int reps, hipStream_t st) {
+    constexpr int KS = gemm_ks(NT);
     constexpr int BB = KS * NT * 2 * 1024;
     constexpr int NMAX = (I > S ? I : S);
-    const size_t lds = (size_t)kGemmStages * (kGemmTile * 64 * KS + (CT ? 2 : 1) * BB) +
+    const size_t lds = (size_t)kGemmStages * (kGemmTile * 64 * KS + BB) +
                        (size_t)(2 * NT * 16 + reps * 2 * S * I * I) * 4 + (size_t)kGemmWaves * 64 * 2 * NMAX * 4;
     DPK_REQUIRE(lds <= 160 * 1024, DPK_EUNSUPPORTED, "ratspn_gemm: %zu bytes of LDS", lds);
-    auto kern = ratspn_gemm_kernel<I, S, NT, CT>;
+    auto kern = ring::ratspn_gemm_kernel<I, S, NT>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024)) return rc;
     const int cus = device_cus();
     const int grid = a.ntiles < cus ? a.ntiles : cus;
@@ -581,7 +789,7 @@ static int gemm_launch(const GemmArgs &a, int reps, hipStream_t st) {
     {
         static unsigned long long *dbg = nullptr;
         if (!dbg) (void)hipMalloc(&dbg, (size_t)1024 * kGemmWaves * 64 * 8 * 8);
-        const_cast<GemmArgs &>(a).dbg = dbg;
+        const_cast<ring::GemmArgs &>(a).dbg = dbg;
         FILE *f = fopen("/tmp/dpk_timeline_ptr.txt", "w");
         if (f) { fprintf(f, "%p %d %d\n", (void *)dbg, grid, a.NCH); fclose(f); }
     }
@@ -596,12 +804,7 @@ static int gemm_launch(const GemmArgs &a, int reps, hipStream_t st) {
 }
 
 template <int I, int S>
-static int gemm_dispatch_nt(const GemmArgs &a, int reps, int NT, hipStream_t st) {
-    if (a.marginal && NT <= 2 && cdiv(a.D, 32) <= 32) {   // recent NaN evidence: the variant that stages both tables
-        GemmArgs c = a;
-        c.NCH = cdiv(a.D, 32);
-        return NT == 1 ? gemm_launch<I, S, 1, true>(c, reps, st) : gemm_launch<I, S, 2, true>(c, reps, st);
-    }
+static int gemm_dispatch_nt(const ring::GemmArgs &a, int reps, int NT, hipStream_t st) {
     switch (NT) {
         case 1: return gemm_launch<I, S, 1>(a, reps, st);
         case 2: return gemm_launch<I, S, 2>(a, reps, st);
@@ -612,10 +815,13 @@ static int gemm_dispatch_nt(const GemmArgs &a, int reps, int NT, hipStream_t st)
     return DPK_EUNSUPPORTED;
 }
 
-// ratspn_gemm_small.hip: 32-sample tiles, features split over the waves (small batches)
+// ratspn_gemm_small.hip: 32-sample tiles, features split over the waves (small batches);
+// ratspn_gemm_nan.hip: the ring kernel's variant for marginalised evidence
 bool gemm_small_shape_ok(int D, int NT);
 int64_t gemm_small_max_batch();
 int ratspn_gemm_small_forward(const GemmArgs &a, int reps, int I, int S, int NT, hipStream_t st);
+bool gemm_marginal_shape_ok(int D, int NT);
+int ratspn_gemm_marginal_forward(const GemmArgs &a, int reps, int I, int S, int NT, hipStream_t st);
 
 // The caller (dpk_ratspn_forward) has validated the arguments and carved the workspace.
 int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const int64_t *mask, const uint8_t *pad,
@@ -641,27 +847,44 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
         else DPK_LAUNCH(ratspn_gemm_prep_kernel<4>, dim3(grid), dim3(256), lds, st, p);
         DPK_CHECK_LAUNCH("ratspn_gemm_prep_kernel");
     }
-    GemmArgs a{};
+    int *slow_word = nullptr;
+    int launch_seq = 0;
+    bool marginal = slow_hint_next(&slow_word, &launch_seq);
+    static const int ablate = [] { const char *e = getenv("DPK_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
+    {   // (measurement: DPK_GEMM_MARGINAL=0 / 1 pins the variant)
+        static const int force = [] { const char *e = getenv("DPK_GEMM_MARGINAL"); return e ? atoi(e) : -1; }();
+        if (force >= 0) marginal = force != 0;
+    }
+    // Three mappings of the same arithmetic: below ~one 128-sample tile per compute unit the persistent ring kernel
+    // runs at the latency of its chunk walk and 32-sample tiles with the feature axis split over the waves take over
+    // (ratspn_gemm_small.hip); while recent launches met NaN evidence the ring variant that stages both tables runs
+    // (ratspn_gemm_nan.hip); otherwise the ring kernel below.
+    const bool small = B <= gemm_small_max_batch() && gemm_small_shape_ok(D, NT);
+    if (small || (marginal && gemm_marginal_shape_ok(D, NT))) {
+        GemmArgs a{};
+        a.x = x; a.B = B; a.D = D; a.d = d; a.reps = reps; a.C = C;
+        a.NCH = cdiv(D, 16 * gemm_ks(NT));
+        a.ntiles = cdiv(B, kGemmTile);
+        a.mtab = w.gm_tab; a.ctab = w.gc_tab; a.biasT = w.gbias_row; a.biasC = w.gbias; a.elig = w.gelig;
+        a.biasK = w.gbias_ks; a.biasS = w.gbias_sl;
+        a.W0 = w.w[0]; a.LW0 = w.lw[0]; a.Wr = as_const(w.w[2]); a.LWr = as_const(w.lw[2]);
+        a.out = out; a.ll_sum = ll_sum;
+        a.mask = mask; a.pad = pad; a.loc = loc; a.scale = scale;
+        a.slow_flag = slow_word; a.launch_seq = launch_seq; a.marginal = marginal ? 1 : 0;
+        a.ablate = ablate;
+        if (small) return ratspn_gemm_small_forward(a, reps, I, S, NT, st);
+        return ratspn_gemm_marginal_forward(a, reps, I, S, NT, st);
+    }
+    ring::GemmArgs a{};
     a.x = x; a.B = B; a.D = D; a.d = d; a.reps = reps; a.C = C;
     a.NCH = cdiv(D, 16 * gemm_ks(NT));
     a.ntiles = cdiv(B, kGemmTile);
     a.mtab = w.gm_tab; a.ctab = w.gc_tab; a.biasT = w.gbias_row; a.biasC = w.gbias; a.elig = w.gelig;
-    a.biasK = w.gbias_ks; a.biasS = w.gbias_sl;
     a.W0 = w.w[0]; a.LW0 = w.lw[0]; a.Wr = as_const(w.w[2]); a.LWr = as_const(w.lw[2]);
     a.out = out; a.ll_sum = ll_sum;
     a.mask = mask; a.pad = pad; a.loc = loc; a.scale = scale;
-    a.marginal = slow_hint_next(&a.slow_flag, &a.launch_seq) ? 1 : 0;
-    {   // (measurement: DPK_GEMM_MARGINAL=0 / 1 pins the variant)
-        static const int force = [] { const char *e = getenv("DPK_GEMM_MARGINAL"); return e ? atoi(e) : -1; }();
-        if (force >= 0) a.marginal = force;
-    }
-    {
-        static const int ab = [] { const char *e = getenv("DPK_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
-        a.ablate = ab;
-    }
-    // below ~one 128-sample tile per compute unit the persistent ring kernel runs at the latency of its chunk walk:
-    // 32-sample tiles with the feature axis split over the waves take over (ratspn_gemm_small.hip)
-    if (B <= gemm_small_max_batch() && gemm_small_shape_ok(D, NT)) return ratspn_gemm_small_forward(a, reps, I, S, NT, st);
+    a.slow_flag = slow_word; a.launch_seq = launch_seq;
+    a.ablate = ablate;
     if (I == 2) {
         if (S == 2) return gemm_dispatch_nt<2, 2>(a, reps, NT, st);
         return gemm_dispatch_nt<2, 4>(a, reps, NT, st);

@@ -16,6 +16,10 @@ typedef float gf32x16 __attribute__((ext_vector_type(16)));
 constexpr int kGemmWaves = 4;
 constexpr int kGemmTile = 32 * kGemmWaves;           // samples per work-group tile
 constexpr int kGemmStages = 3;
+#ifndef DPK_X_NT
+#define DPK_X_NT 0
+#endif
+constexpr bool kGemmXNonTemporal = DPK_X_NT != 0;   // x pieces of the ring: non-temporal LDS-DMA
 typedef __attribute__((address_space(3))) float lfloat;
 typedef __attribute__((address_space(3))) char lchar;
 typedef const __attribute__((address_space(1))) char *gcchar_p;
@@ -39,6 +43,8 @@ __device__ __forceinline__ void gemm_lds_barrier() {
 // hipcc neither counts it (the ring below is ordered by hand-counted vmcnt + s_barrier) nor drains it with a
 // vmcnt(0) in front of an unrelated load; M0 (the DMA's LDS base) is compiler-reserved, hence saved and restored.
 // The leading s_nop covers the SALU-write -> VMEM-read hazard of a freshly computed base (cdna_hip_programming 5.7).
+// NT: the non-temporal form for data that ONE compute unit reads once (the x stream): measured on this ring, see DESIGN.
+template <bool NT = false>
 __device__ __forceinline__ void glds16(unsigned voff, gcchar_p sbase_in, unsigned lds_dst_in) {
     // (readfirstlane: a no-op for values hipcc already holds in SGPRs, a guarantee where it has moved them to VGPRs)
     const uint64_t sb = (uint64_t)(uintptr_t)sbase_in;
@@ -46,10 +52,16 @@ __device__ __forceinline__ void glds16(unsigned voff, gcchar_p sbase_in, unsigne
                            (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sb);
     const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst_in);
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_dst)
-                 : "memory");
+    if constexpr (NT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(sbase), "s"(lds_dst)
+                     : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(sbase), "s"(lds_dst)
+                     : "memory");
 }
 
 // x (8 values of one sample) -> f16 halves xh + xl = x to 2^-22: xh = rn16(x), xl = rn16(x - xh).
@@ -59,6 +71,25 @@ __device__ __forceinline__ void glds16(unsigned voff, gcchar_p sbase_in, unsigne
 // (and an SDWA result consumed by the next VALU) the small-batch kernel computed wrong products for three of every eight
 // features, in K-steps whose schedule happened to place them so (found with a one-hot feature probe, round 3).
 __device__ __forceinline__ void split8(const float (&v)[8], half8 &xh, half8 &xl) {
+#ifdef DPK_SPLIT8_ASM   // (measurement: the round-2 inline-asm form, for A/B runs of the ring kernel)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 hp, lp;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        unsigned h2, l2;
+        float b0, b1;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h2) : "v"(v[2 * p]), "v"(v[2 * p + 1]));
+        asm("v_cvt_f32_f16_e32 %0, %1" : "=v"(b0) : "v"(h2));
+        asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(b1) : "v"(h2));
+        const float d0 = v[2 * p] - b0, d1 = v[2 * p + 1] - b1;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l2) : "v"(d0), "v"(d1));
+        hp[p] = h2;
+        lp[p] = l2;
+    }
+    xh = __builtin_bit_cast(half8, hp);
+    xl = __builtin_bit_cast(half8, lp);
+    return;
+#endif
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const gf32x2 a = {v[2 * p], v[2 * p + 1]};
@@ -109,7 +140,7 @@ __device__ __forceinline__ void gemm_loader_run(const float *x, int64_t B, int D
         const bool full = (b0 + kGemmTile <= B) && ((pc + 1) * KC <= D);
         if (full) {
 #pragma unroll
-            for (int j = 0; j < PX; ++j) glds16(voff[j], xt, st + (wave * 32 + j * RPI) * ROWB);
+            for (int j = 0; j < PX; ++j) glds16<kGemmXNonTemporal>(voff[j], xt, st + (wave * 32 + j * RPI) * ROWB);
         } else {   // ragged tile / last chunk: clamp to rows and pieces that exist (clamped slots are never consumed)
             const int nvalid = (int)min((int64_t)kGemmTile, B - b0);
             const int vp = min(W, (D - pc * KC) >> 2);
@@ -117,7 +148,7 @@ __device__ __forceinline__ void gemm_loader_run(const float *x, int64_t B, int D
             for (int j = 0; j < PX; ++j) {
                 const int rl = wave * 32 + j * RPI + lane / W;
                 const int gp = min((lane & (W - 1)) ^ ((rl >> SWS) & (W - 1)), vp - 1);
-                glds16((unsigned)(min(rl, nvalid - 1) * D + gp * 4) * 4u, xt, st + (wave * 32 + j * RPI) * ROWB);
+                glds16<kGemmXNonTemporal>((unsigned)(min(rl, nvalid - 1) * D + gp * 4) * 4u, xt, st + (wave * 32 + j * RPI) * ROWB);
             }
         }
 #pragma unroll

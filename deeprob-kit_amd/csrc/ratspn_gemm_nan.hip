@@ -1,0 +1,389 @@
+// RAT-SPN fused forward, ring kernel, MARGINALISED-EVIDENCE variant (depth 2, unit-scale Gaussian leaves).
+//
+// reference: RatSpn.forward (deeprob/spn/models/ratspn.py:105-122) on inputs with NaN entries: nan_to_num_ at
+// deeprob/spn/layers/ratspn.py:103 is the marginalisation path.
+//
+// The same kernel as ratspn_gemm.hip (read its header first) with 32-feature chunks whose LDS stage carries the
+// negated-constant table next to the mean table, so that the validity GEMM of a chunk that holds NaN reads its fragments
+// from LDS like the mean GEMM does.  The default kernel fetches them from L2 just in time, one round trip per K-step:
+// 3.9x the clean time on 30 % NaN inputs in round 2; this variant runs them at ~1.4x.  It is taken while a launch
+// within the last 256 met NaN evidence (slow_hint, common.h).  Same arithmetic, same results.
+//
+// Kept in a file of its own, sharing the upper layers through ratspn_gemm_fused.h: the default kernel's schedule is
+// sensitive to every edit around it (folding this variant into its template cost the clean path 3 us of 46, round 3).
+#include "ratspn_gemm_fused.h"
+#include <stdlib.h>
+
+namespace dpk {
+
+#ifdef DPK_TIMELINE
+#define GEMM_STAMP(row, slot) do { __builtin_amdgcn_sched_barrier(0); if (a.dbg && lane == 0 && !loader && (row) < 64) a.dbg[(((int64_t)blockIdx.x * kGemmWaves + wave) * 64 + (row)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define GEMM_STAMP(row, slot) do { } while (0)
+#endif
+
+// CT: the marginalised-evidence variant (taken while a recent launch met NaN inputs, slow_hint): chunks of 32 features
+// whose stage carries the negated-constant table next to the mean table, so that the validity GEMM of a chunk that
+// holds NaN reads its fragments from LDS like the mean GEMM does (the default build fetches them from L2 just in time,
+// one round trip per K-step: 3.9x the clean time on 30 % NaN inputs in round 2).  Same arithmetic, same results.
+template <int I, int S, int NT, bool CT>
+__global__ __launch_bounds__(2 * kGemmWaves * 64) void ratspn_gemm_marginal_kernel(const GemmArgs a) {
+    constexpr int RPT = 8 / I;                           // repetitions per column tile
+    constexpr int KS = CT ? 2 : gemm_ks(NT);
+    constexpr int KC = 16 * KS;                          // features per chunk
+    constexpr int W = 4 * KS;                            // 16-byte pieces per staged row
+    constexpr int ROWB = KC * 4;
+    constexpr int RPI = 64 / W;                          // rows per x DMA instruction
+    constexpr int SWS = (W == 16) ? 0 : (W == 8 ? 1 : 2);  // swizzle: piece ^= (row >> SWS) & (W-1)
+    constexpr int XB = kGemmTile * ROWB;                 // x chunk bytes
+    constexpr int BB = KS * NT * 2 * 1024;               // mean-table bytes per chunk
+    constexpr int STAGE = XB + (CT ? 2 : 1) * BB;
+    constexpr int NS = kGemmStages;
+    constexpr int PX = 32 / RPI;                         // x DMA instructions per loader wave and chunk
+    constexpr int PB = BB / (kGemmWaves * 1024);         // table DMA instructions per loader wave and chunk (per table)
+    constexpr int P = PX + (CT ? 2 : 1) * PB;            // DMA instructions per loader wave and chunk
+    static_assert(BB % (kGemmWaves * 1024) == 0, "table chunk must split over the waves");
+    static_assert(NS == 3 && P <= 63, "the counted waits leave exactly one chunk in flight");
+    constexpr int NMAX = (I > S ? I : S);
+    typedef __attribute__((address_space(3))) const gf32x4 lf4;
+    typedef __attribute__((address_space(3))) const half8 lh8;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_generic[];
+    lchar *smem = (lchar *)smem_generic;
+    lfloat *bias_l = (lfloat *)(smem + NS * STAGE);                  // [2][NT][16] constants of a whole row
+    lfloat *w0_l = bias_l + 2 * NT * 16;                             // [reps*2][S*I*I]
+    float *scr_l = reinterpret_cast<float *>(smem_generic + NS * STAGE) + 2 * NT * 16 +
+                   a.reps * 2 * S * I * I;                           // [256][2*NMAX] exact_lse scratch
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Waves 0-3 compute (one per SIMD), waves 4-7 only feed the LDS ring: wave 4+w copies the 32 rows of wave w and a
+    // quarter of the mean-table chunk.  A compute wave never issues a DMA (an LDS-DMA instruction costs its wave
+    // 60-150 issue cycles), a loader never touches a VALU; the two meet at one s_barrier per chunk.
+    const bool loader = wave8 >= kGemmWaves;
+    const int wave = wave8 & (kGemmWaves - 1);
+    const int s = lane & 31, h = lane >> 5;
+    const int D = a.D, NCH = a.NCH;
+    GEMM_STAMP(63, 0);
+#ifdef DPK_TIMELINE
+    if (a.dbg && lane == 0 && !loader) a.dbg[(((int64_t)blockIdx.x * kGemmWaves + wave) * 64 + 63) * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    // this work-group's tiles: blockIdx.x, + gridDim.x, ... (persistent); every counter below is wave-uniform
+    const int grid = (int)gridDim.x;
+    const int ntiles = a.ntiles;
+
+    double red_ll = 0.0;
+    bool saw_nan_any = false;
+    if (loader) {
+        gemm_loader_run<KS, PB, CT ? PB : 0>(a.x, a.B, D, NCH, ntiles, (int)blockIdx.x, grid, (gcchar_p)a.mtab, BB,
+                                             wave * PB, (unsigned)(uintptr_t)smem, STAGE, wave, lane, (gcchar_p)a.ctab);
+    } else {
+    // ================================================ compute waves =========================================
+    // constants into LDS
+    for (int e = tid; e < 2 * NT * 16; e += kGemmWaves * 64) bias_l[e] = a.biasT[e];
+    for (int e = tid; e < a.reps * 2 * S * I * I; e += kGemmWaves * 64) w0_l[e] = a.W0[e];
+    bool model_ok = true;
+    for (int e = lane; e < NT * RPT; e += 64) model_ok = model_ok && (a.elig[e] != 0);
+    model_ok = __all(model_ok);
+    LseScratch sc{scr_l + tid * (2 * NMAX)};
+    __syncthreads();
+
+    // LDS byte offsets (within a stage) of the lane's x pieces and of its table fragments
+    const int rl_own = wave * 32 + s;
+    const int sw = (rl_own >> SWS) & (W - 1);
+    unsigned xoff[2 * KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int pcs = ks * 4 + h * 2;
+        xoff[2 * ks] = (unsigned)(rl_own * ROWB + ((pcs ^ sw) << 4));
+        xoff[2 * ks + 1] = (unsigned)(rl_own * ROWB + (((pcs | 1) ^ sw) << 4));
+    }
+    const unsigned foff = (unsigned)(XB + lane * 16);
+
+    GEMM_STAMP(63, 1);
+    [[maybe_unused]] int grow = 0;   // timeline row = chunk count of this work-group
+    bool saw_nan = false;
+    double ll_part = 0.0;   // this lane's share of the sum of the LLs written by the fast path (all tiles)
+    int cstage = 0;
+    for (int tile = (int)blockIdx.x; tile < ntiles; tile += grid) {
+        gf32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        float qsum = 0.f;
+        bool need_exact = false;
+        unsigned odd_mask = 0u;   // chunks that met NaN evidence: their constants were accumulated by the validity GEMM
+        for (int c = 0; c < NCH; ++c) {
+            GEMM_STAMP(grow, 0);
+            GEMM_STAMP(grow, 1);
+            gemm_lds_barrier();   // the loaders have seen this chunk land; everyone is done reading the previous one
+            GEMM_STAMP(grow, 2);
+            const lchar *st = smem + cstage * STAGE;
+            cstage = (cstage + 1 == NS) ? 0 : cstage + 1;
+            if (a.ablate & 1) continue;
+            const lchar *tb = st + foff;
+            // the chunk's table fragments and the lane's 8*KS values: every LDS read of the chunk is issued up front
+            half8 mh[KS][NT], ml[KS][NT];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    mh[ks][t] = *(lh8 *)(tb + (ks * NT + t) * 2048);
+                    ml[ks][t] = *(lh8 *)(tb + (ks * NT + t) * 2048 + 1024);
+                }
+            // the lane's 8*KS values of this chunk
+            float v[KS][8];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const gf32x4 x0 = *(lf4 *)(st + xoff[2 * ks]);
+                const gf32x4 x1 = *(lf4 *)(st + xoff[2 * ks + 1]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[ks][i] = x0[i];
+                    v[ks][4 + i] = x1[i];
+                }
+            }
+            const bool partial = (c + 1) * KC > D;
+            if (partial) {   // last chunk: slots beyond D hold clamped copies (or nothing this chunk wrote)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int f0 = c * KC + ks * 16 + h * 8;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[ks][i] = (f0 + i < D) ? v[ks][i] : 0.f;
+                }
+            }
+            gf32x2 tq2 = {0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    const gf32x2 pv = {v[ks][i], v[ks][i + 1]};
+                    tq2 = __builtin_elementwise_fma(pv, pv, tq2);
+                }
+            float tq = tq2[0] + tq2[1];
+            // NaN / +-inf / huge evidence anywhere in the wave's share of the chunk?
+            const bool odd_chunk = __any(!(tq < kGemmStepBound));
+            if (!odd_chunk && !partial) {
+                // ---- hot path: clean, complete chunk -------------------------------------------------------
+                qsum += tq;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    half8 xh, xl;
+                    split8(v[ks], xh, xl);
+                    // independent accumulators alternate (a dependent 32x32x16 chain would stall on its own latency)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[ks][t], xh, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[ks][t], xl, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[ks][t], xh, acc[t], 0, 0, 0);
+                }
+            } else {
+                // ---- generic path: last (partial) chunk, or NaN / inf / huge evidence ----------------------------
+                const int nks = min(KS, (D - c * KC + 15) >> 4);
+                half8 valid[KS];
+                if (odd_chunk) {
+                    // NaN (marginalised) entries count as 0 and drop out of the constants (validity indicator below);
+                    // +-inf / huge entries send the wave through the exact evaluation at the end of the tile
+                    odd_mask |= 1u << c;
+                    tq = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const float vi = v[ks][i];
+                            const bool isn = vi != vi;
+                            const bool big = !isn && !(fabsf(vi) < kGemmAbsBound);
+                            need_exact = need_exact || big;
+                            saw_nan = saw_nan || isn;
+                            v[ks][i] = (isn || big) ? 0.f : vi;
+                            valid[ks][i] = isn ? (_Float16)0.0f : (_Float16)1.0f;
+                            tq = fmaf(v[ks][i], v[ks][i], tq);
+                        }
+                }
+                qsum += tq;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    if (ks < nks) {
+                        half8 xh, xl;
+                        split8(v[ks], xh, xl);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[ks][t], xh, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[ks][t], xl, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[ks][t], xh, acc[t], 0, 0, 0);
+                        }
+                        if (odd_chunk) {
+                            // - (mu^2/2 + log sqrt(2 pi)) of the variables that ARE observed (table of negated constants)
+                            if constexpr (CT) {   // staged next to the mean table
+#pragma unroll
+                                for (int t = 0; t < NT; ++t) {
+                                    const half8 ch = *(lh8 *)(tb + BB + (ks * NT + t) * 2048);
+                                    const half8 cl = *(lh8 *)(tb + BB + (ks * NT + t) * 2048 + 1024);
+                                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, valid[ks], acc[t], 0, 0, 0);
+                                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, valid[ks], acc[t], 0, 0, 0);
+                                }
+                            } else {
+                                typedef const __attribute__((address_space(1))) half8 gh8;
+                                const gcchar_p cb = (gcchar_p)a.ctab + ((((int64_t)(c * KS + ks) * NT) * 2) * 512 + lane * 8) * 2;
+#pragma unroll
+                                for (int t = 0; t < NT; ++t) {
+                                    const half8 ch = *(gh8 *)(cb + t * 2048);
+                                    const half8 cl = *(gh8 *)(cb + t * 2048 + 1024);
+                                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, valid[ks], acc[t], 0, 0, 0);
+                                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, valid[ks], acc[t], 0, 0, 0);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            GEMM_STAMP(grow, 4);
+            ++grow;
+        }
+        GEMM_STAMP(grow - 1, 5);
+        if (!(a.ablate & 8)) {
+            // ---- upper layers of the tile ------------------------------------------------------------
+            const int64_t b0 = (int64_t)tile * kGemmTile;
+            const int64_t bw0 = b0 + wave * 32;
+            const int64_t b = bw0 + s;
+            const float qtot = qsum + __shfl_xor(qsum, 32, 64);
+            // the expanded square is within the 1e-5 bar while sum x^2 <= 36 D (|mu| <= 6: DESIGN 3.3)
+            const bool lane_exact = need_exact || !(qtot <= kExpandBound * kExpandBound * (float)D);
+            if (!model_ok || __any(lane_exact)) {
+                // (a private copy: handing the kernel argument block itself to a call would move it, and with it
+                // every loop counter derived from it, out of the scalar registers)
+                const GemmArgs ac = a;
+                gemm_exact_wave<I, S, NT>(ac, bw0, lane, sc);
+            } else {
+                // per-column constants: the whole-row sums, or -- after chunks with marginalised evidence, whose
+                // constants the validity GEMM accumulated -- the sums of the clean chunks only
+                float cst[NT][16];
+                if (odd_mask == 0u) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const gf32x4 q4 = *(lf4 *)(bias_l + (h * NT + t) * 16 + 4 * i);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) cst[t][4 * i + j] = q4[j];
+                        }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) cst[t][i] = 0.f;
+                    for (int c = 0; c < NCH; ++c) {
+                        if ((odd_mask >> c) & 1u) continue;
+                        if constexpr (CT) {   // (32-feature chunks: the constants per K-step, prepared for the small-batch kernel)
+                            for (int ks = c * KS; ks < min((c + 1) * KS, (D + 15) >> 4); ++ks) {
+                                const float *bk = a.biasK + ((ks * 2 + h) * NT) * 16;
+#pragma unroll
+                                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                                    for (int i = 0; i < 16; ++i) cst[t][i] += bk[t * 16 + i];
+                            }
+                        } else {
+                            const float *bc = a.biasC + ((c * 2 + h) * NT) * 16;
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                                for (int i = 0; i < 16; ++i) cst[t][i] += bc[t * 16 + i];
+                        }
+                    }
+                }
+                double part = 0.0;
+                if (gemm_upper_fast<I, S, NT>(a, acc, cst, w0_l, qtot, h, b, part)) {
+                    const GemmArgs ac = a;
+                    gemm_exact_wave<I, S, NT>(ac, bw0, lane, sc);
+                    continue;
+                }
+                GEMM_STAMP(grow - 1, 6);
+                ll_part += part;
+            }
+            // (measured: sending the sums of all tiles but the last as one atomic per wave here, while the work-group
+            // is still streaming, costs 8 us per launch -- the compute waves' next LDS-DMA-fed chunk waits behind it)
+        }
+    }
+    GEMM_STAMP(63, 2);
+    red_ll = wave_reduce_sum(ll_part);
+    saw_nan_any = saw_nan;
+    }   // compute waves
+    // {sum LL, count}: one atomic per work-group, issued when no counted wait is left to trip over it (an atomic is a
+    // VMEM operation: inside the ring it would sit in every wave's vmcnt until the L2 has serialised thousands of them)
+    if (a.ll_sum != nullptr && !(a.ablate & 16)) {
+        double *red = reinterpret_cast<double *>(smem_generic);   // the stages are idle now
+        __syncthreads();
+        if (lane == 0 && !loader) red[wave] = red_ll;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < kGemmWaves; ++w) tot += red[w];
+            atomicAdd(a.ll_sum, tot);
+            // every sample of the launch is evaluated by exactly one path: the count needs no per-work-group atomic
+            // (256 same-address fp64 atomics at the very end of the kernel cost it 1.5 us)
+            if (blockIdx.x == 0) atomicAdd(a.ll_sum + 1, (double)a.B * (double)a.C);
+        }
+    }
+    if (saw_nan_any && lane == 0 && a.slow_flag != nullptr) *a.slow_flag = a.launch_seq;
+    GEMM_STAMP(63, 3);
+#ifdef DPK_TIMELINE
+    if (a.dbg && lane == 0 && !loader) a.dbg[(((int64_t)blockIdx.x * kGemmWaves + wave) * 64 + 63) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+template <int I, int S, int NT, bool CT>
+static int gemm_launch(const GemmArgs &a, int reps, hipStream_t st) {
+    constexpr int KS = CT ? 2 : gemm_ks(NT);
+    constexpr int BB = KS * NT * 2 * 1024;
+    constexpr int NMAX = (I > S ? I : S);
+    const size_t lds = (size_t)kGemmStages * (kGemmTile * 64 * KS + (CT ? 2 : 1) * BB) +
+                       (size_t)(2 * NT * 16 + reps * 2 * S * I * I) * 4 + (size_t)kGemmWaves * 64 * 2 * NMAX * 4;
+    DPK_REQUIRE(lds <= 160 * 1024, DPK_EUNSUPPORTED, "ratspn_gemm: %zu bytes of LDS", lds);
+    auto kern = ratspn_gemm_marginal_kernel<I, S, NT, CT>;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024)) return rc;
+    const int cus = device_cus();
+    const int grid = a.ntiles < cus ? a.ntiles : cus;
+#ifdef DPK_TIMELINE
+    {
+        static unsigned long long *dbg = nullptr;
+        if (!dbg) (void)hipMalloc(&dbg, (size_t)1024 * kGemmWaves * 64 * 8 * 8);
+        const_cast<GemmArgs &>(a).dbg = dbg;
+        FILE *f = fopen("/tmp/dpk_timeline_ptr.txt", "w");
+        if (f) { fprintf(f, "%p %d %d\n", (void *)dbg, grid, a.NCH); fclose(f); }
+    }
+#endif
+    hipEvent_t ev0, ev1;
+    profile_take(&ev0, &ev1, DPK_KERNEL_RATSPN_FUSED);
+    if (ev0) (void)hipEventRecord(ev0, st);
+    DPK_LAUNCH(kern, dim3(grid), dim3(2 * kGemmWaves * 64), lds, st, a);
+    if (ev1) (void)hipEventRecord(ev1, st);
+    DPK_CHECK_LAUNCH("ratspn_gemm_marginal_kernel");
+    return DPK_OK;
+}
+
+// `a` as filled by ratspn_gemm_forward for the default kernel; NCH is re-derived for 32-feature chunks
+int ratspn_gemm_marginal_forward(const GemmArgs &a, int reps, int I, int S, int NT, hipStream_t st) {
+    GemmArgs c = a;
+    c.NCH = cdiv(a.D, 32);
+#define DPK_MARG(II, SS)                                                                                   \
+    if (I == II && S == SS)                                                                                \
+        return NT == 1 ? gemm_launch<II, SS, 1, true>(c, reps, st) : gemm_launch<II, SS, 2, true>(c, reps, st)
+    DPK_MARG(2, 2);
+    DPK_MARG(2, 4);
+    DPK_MARG(4, 2);
+    DPK_MARG(4, 4);
+#undef DPK_MARG
+    set_error("ratspn_gemm_marginal: (channels=%d, sums=%d) not built", I, S);
+    return DPK_EUNSUPPORTED;
+}
+bool gemm_marginal_shape_ok(int D, int NT) { return NT <= 2 && cdiv(D, 32) <= 32; }
+
+}  // namespace dpk
