@@ -313,8 +313,16 @@ __device__ __forceinline__ unsigned long long fp_range(const void *p, int64_t by
     unsigned long long h = 0ull;
     if (p == nullptr) return h;
     if ((((uintptr_t)p | (uintptr_t)bytes) & 3) == 0) {
+        // (four loads in flight per thread: one load per trip made this pass latency bound -- 11 us for 26 KB)
         const unsigned *w = (const unsigned *)p;
-        for (int64_t e = threadIdx.x; e < (bytes >> 2); e += blockDim.x) h += fp_word(w[e], (unsigned)e * 8u + tag);
+        const int n = (int)(bytes >> 2), step = (int)blockDim.x;
+        int e = (int)threadIdx.x;
+        for (; e + 3 * step < n; e += 4 * step) {
+            const unsigned w0 = w[e], w1 = w[e + step], w2 = w[e + 2 * step], w3 = w[e + 3 * step];
+            h += fp_word(w0, (unsigned)e * 8u + tag) + fp_word(w1, (unsigned)(e + step) * 8u + tag) +
+                 fp_word(w2, (unsigned)(e + 2 * step) * 8u + tag) + fp_word(w3, (unsigned)(e + 3 * step) * 8u + tag);
+        }
+        for (; e < n; e += step) h += fp_word(w[e], (unsigned)e * 8u + tag);
     } else {
         const unsigned char *b = (const unsigned char *)p;
         for (int64_t e = threadIdx.x; e < bytes; e += blockDim.x) h += fp_word(b[e], (unsigned)e * 8u + tag + 4u);

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void ratspn_gemm_prep_kernel(const GemmPrepArg
         // the cached-table check is block local: fingerprint those bytes, compare with the fingerprint of the bytes the
         // tables were built from (a write through `param.data` moves no version counter on the host), and
         // return when nothing changed -- one ~2 us launch per call instead of a 30 us rebuild.
+        const unsigned long long stored = a.verify ? a.hash[rho] : 0ull;   // (requested first: back when the hash is)
         unsigned long long h = 0x9E3779B97F4A7C15ull + (unsigned long long)rho;
         if (real) {
             h += fp_range(a.mask + (int64_t)rho * 4 * d, (int64_t)4 * d * 8, 1);
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void ratspn_gemm_prep_kernel(const GemmPrepArg
             h += fp_range(a.scale + (int64_t)rho * 4 * I * d, (int64_t)4 * I * d * 4, 4);
         }
         h = block_sum_u64(h, red_s);
-        if (a.verify && a.hash[rho] == h) return;
+        if (a.verify && stored == h) return;
         __syncthreads();
         if (threadIdx.x == 0) a.hash[rho] = h;
     }
