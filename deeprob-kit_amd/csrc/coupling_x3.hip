@@ -92,20 +92,45 @@ __global__ __launch_bounds__(256) void coupling_x3_check_kernel(const X3PackArgs
     const int gtid = (int)(blockIdx.x * blockDim.x + threadIdx.x), gsz = (int)(gridDim.x * blockDim.x);
     float m1 = 0.f, m2 = 0.f;
     unsigned long long h = 0ull;
-    for (int e = gtid; e < U * K1; e += gsz) {
-        const int unit = e / K1, col = 2 * (e - unit * K1) + a.pm;
-        float v = a.W1[unit * D + col];
-        h += fp_word(__float_as_uint(v), (unsigned)e * 8u + 1u);
-        if (a.in_scale) v *= a.in_scale[col];
-        m1 = fmaxf(m1, fabsf(v));
+    // (four elements per trip, their loads requested together: one load per trip left this pass latency bound)
+    const int n1 = U * K1;
+    for (int e0 = gtid; e0 < n1; e0 += 4 * gsz) {
+        float v[4], sc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = min(e0 + q * gsz, n1 - 1);
+            const int unit = e / K1, col = 2 * (e - unit * K1) + a.pm;
+            v[q] = a.W1[unit * D + col];
+            sc[q] = a.in_scale ? a.in_scale[col] : 1.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = e0 + q * gsz;
+            if (e < n1) {
+                h += fp_word(__float_as_uint(v[q]), (unsigned)e * 8u + 1u);
+                m1 = fmaxf(m1, fabsf(v[q] * sc[q]));
+            }
+        }
     }
     const int rows2 = a.affine ? 2 : 1;
-    for (int e = gtid; e < rows2 * N2 * U; e += gsz) {
-        const int r = e / U, unit = e - r * U;
-        const int ts = r / N2, var = 2 * (r - ts * N2) + (1 - a.pm);
-        const float v = a.W2[(ts * D + var) * U + unit];
-        h += fp_word(__float_as_uint(v), (unsigned)e * 8u + 2u);
-        m2 = fmaxf(m2, fabsf(v));
+    const int n2 = rows2 * N2 * U;
+    for (int e0 = gtid; e0 < n2; e0 += 4 * gsz) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = min(e0 + q * gsz, n2 - 1);
+            const int r = e / U, unit = e - r * U;
+            const int ts = r / N2, var = 2 * (r - ts * N2) + (1 - a.pm);
+            v[q] = a.W2[(ts * D + var) * U + unit];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = e0 + q * gsz;
+            if (e < n2) {
+                h += fp_word(__float_as_uint(v[q]), (unsigned)e * 8u + 2u);
+                m2 = fmaxf(m2, fabsf(v[q]));
+            }
+        }
     }
     for (int e = gtid; e < U; e += gsz) h += fp_word(__float_as_uint(a.b1[e]), (unsigned)e * 8u + 3u);
     for (int e = gtid; e < rows2 * D; e += gsz) h += fp_word(__float_as_uint(a.b2[e]), (unsigned)e * 8u + 4u);

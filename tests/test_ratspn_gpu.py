@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import ratspn_oracle as orc
-from tests.util import rel_err, grad_err, state_to_model
+from tests.util import rel_err, grad_err, state_to_model, report_measured
 
 pytestmark = pytest.mark.gpu
 
@@ -113,11 +113,16 @@ def test_backward_golden(golden, name):
     def tol(key):
         return max(GRAD_TOL, 4.0 * grad_err(g['grad.' + key], ref64[key]))
 
+    report_measured('test_backward_golden[%s] grad.x' % name, grad_err(x.grad.cpu().numpy(), g['grad.x']), tol('x'),
+                    '(GRAD_TOL 1e-4, or 4x the golden fp32 gradient\'s own distance from fp64)')
     assert grad_err(x.grad.cpu().numpy(), g['grad.x']) <= tol('x')
     for k, p in model.named_parameters():
         if 'grad.' + k in g.files:
             assert p.grad is not None, k
-            assert grad_err(p.grad.cpu().numpy(), g['grad.' + k]) <= tol(k), k
+            err = grad_err(p.grad.cpu().numpy(), g['grad.' + k])
+            if tol(k) > GRAD_TOL:
+                report_measured('test_backward_golden[%s] grad.%s' % (name, k), err, tol(k), '(widened: golden fp32 vs fp64 = %.2e)' % (tol(k) / 4))
+            assert err <= tol(k), k
 
 
 @pytest.mark.parametrize('B', [1, 63, 64, 129, 1000])
@@ -641,6 +646,9 @@ def test_backward_wide_model_vs_oracle(golden):
     got['x'] = xg.grad.cpu().numpy()
     for k in got:
         tol = max(GRAD_TOL, 4.0 * grad_err(ref32[k], ref64[k]))
+        if tol > GRAD_TOL:
+            report_measured('test_backward_wide_model_vs_oracle grad.%s' % k, grad_err(got[k], ref64[k]), tol,
+                            '(reference fp32 vs fp64 = %.2e)' % (tol / 4))
         assert grad_err(got[k], ref64[k]) <= tol, k
 
 
