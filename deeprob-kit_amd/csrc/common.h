@@ -154,7 +154,10 @@ constexpr int kGemmMaxNT = 4;             // column tiles of 32 the fused kernel
 constexpr int kGemmSmallWaves = 8;        // small-batch kernel: waves per 32-sample tile = slices of the feature axis
 constexpr int kGemmSmallMaxK = 8;         // ... and the K-steps (of 16 features) one of them can hold in registers
 static inline bool gemm_shape_ok(int D, int depth, int reps, int I, int S) {
-    if (depth != 2 || !(I == 2 || I == 4) || !(S == 2 || S == 4) || (D % 4) != 0 || reps < 1) return false;
+    if (depth != 2 || (D % 4) != 0 || reps < 1) return false;
+    // 8 channels: one column tile per repetition, a wave per tile (ratspn_gemm_wide.hip); x tile + weights in LDS
+    if (I == 8) return (S == 2 || S == 4 || S == 8) && reps <= 8 && (D + 15) / 16 <= 64;
+    if (!(I == 2 || I == 4) || !(S == 2 || S == 4)) return false;
     return (reps * 4 * I + 31) / 32 <= kGemmMaxNT;
 }
 

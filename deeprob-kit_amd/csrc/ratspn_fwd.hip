@@ -1582,12 +1582,14 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
                         const float *loc, const float *scale, const float *sum_weight0, const float *root_weight,
                         int reps, int I, int S, int C, float *out, double *ll_sum, uint32_t flags, hipStream_t st);
 
+bool gemm_wide_shape_ok(int D, int reps, int I, int S, int C);   // ratspn_gemm_wide.hip
+
 // The MFMA route takes a fused evaluation when the model is in its envelope (depth 2, 2 or 4 channels / sums),
 // the caller hints unit scales (checked on the device), the rows of x are 16-byte aligned (LDS-DMA) and the leaf
 // outputs are not wanted.  DPK_RATSPN_GEMM=0 in the environment keeps the VALU kernels (A/B measurements).
 static bool gemm_route(const float *x, int D, int depth, int reps, int I, int S, int C, bool want_leaf, uint32_t flags) {
     return mfma_enabled() && !want_leaf && (flags & DPK_FLAG_UNIT_SCALE) != 0 && gemm_shape_ok(D, depth, reps, I, S) &&
-           C <= 64 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+           C <= 64 && (I != 8 || gemm_wide_shape_ok(D, reps, I, S, C)) && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
 }
 
 }  // namespace dpk

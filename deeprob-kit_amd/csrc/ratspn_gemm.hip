@@ -822,6 +822,9 @@ bool gemm_small_shape_ok(int D, int NT);
 int64_t gemm_small_max_batch();
 int ratspn_gemm_small_forward(const GemmArgs &a, int reps, int I, int S, int NT, hipStream_t st);
 bool gemm_marginal_shape_ok(int D, int NT);
+// ratspn_gemm_wide.hip: 8-channel models, a wave per repetition
+bool gemm_wide_shape_ok(int D, int reps, int I, int S, int C);
+int ratspn_gemm_wide_forward(const GemmArgs &a, int S, hipStream_t st);
 int ratspn_gemm_marginal_forward(const GemmArgs &a, int reps, int I, int S, int NT, hipStream_t st);
 
 // The caller (dpk_ratspn_forward) has validated the arguments and carved the workspace.
@@ -845,7 +848,8 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
         const size_t lds = ((size_t)D + (size_t)4 * I * d + (size_t)cdiv(D, 32) * 4 * I + (size_t)cdiv(D, 16) * 4 * I) * 4;
         DPK_REQUIRE(lds <= 60 * 1024, DPK_EUNSUPPORTED, "ratspn_gemm: in_features=%d too large for the table kernel", D);
         if (I == 2) DPK_LAUNCH(ratspn_gemm_prep_kernel<2>, dim3(grid), dim3(256), lds, st, p);
-        else DPK_LAUNCH(ratspn_gemm_prep_kernel<4>, dim3(grid), dim3(256), lds, st, p);
+        else if (I == 4) DPK_LAUNCH(ratspn_gemm_prep_kernel<4>, dim3(grid), dim3(256), lds, st, p);
+        else DPK_LAUNCH(ratspn_gemm_prep_kernel<8>, dim3(grid), dim3(256), lds, st, p);
         DPK_CHECK_LAUNCH("ratspn_gemm_prep_kernel");
     }
     int *slow_word = nullptr;
@@ -860,8 +864,9 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
     // runs at the latency of its chunk walk and 32-sample tiles with the feature axis split over the waves take over
     // (ratspn_gemm_small.hip); while recent launches met NaN evidence the ring variant that stages both tables runs
     // (ratspn_gemm_nan.hip); otherwise the ring kernel below.
-    const bool small = B <= gemm_small_max_batch() && gemm_small_shape_ok(D, NT);
-    if (small || (marginal && gemm_marginal_shape_ok(D, NT))) {
+    const bool wide = I == 8;
+    const bool small = !wide && B <= gemm_small_max_batch() && gemm_small_shape_ok(D, NT);
+    if (wide || small || (marginal && gemm_marginal_shape_ok(D, NT))) {
         GemmArgs a{};
         a.x = x; a.B = B; a.D = D; a.d = d; a.reps = reps; a.C = C;
         a.NCH = cdiv(D, 16 * gemm_ks(NT));
@@ -873,6 +878,7 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
         a.mask = mask; a.pad = pad; a.loc = loc; a.scale = scale;
         a.slow_flag = slow_word; a.launch_seq = launch_seq; a.marginal = marginal ? 1 : 0;
         a.ablate = ablate;
+        if (wide) return ratspn_gemm_wide_forward(a, S, st);
         if (small) return ratspn_gemm_small_forward(a, reps, I, S, NT, st);
         return ratspn_gemm_marginal_forward(a, reps, I, S, NT, st);
     }

@@ -126,8 +126,14 @@ class RatSpn(ProbabilisticModel):
         single-launch VALU kernel (measured 0.065 vs 0.194 ms at 4096 samples, 0.209 vs 0.243 ms at 65536;
         tools/bench_wide.py)."""
         base = self.base_layer
-        return (isinstance(base, GaussianLayer) and self.rg_batch == 8 and self.rg_sum in (8, 16)
-                and not base.scale.requires_grad and self.in_features % 4 == 0)
+        if not (isinstance(base, GaussianLayer) and self.rg_batch == 8 and self.rg_sum in (8, 16)
+                and not base.scale.requires_grad and self.in_features % 4 == 0):
+            return False
+        # round 3: depth-2 models with up to 8 repetitions and 32 classes run as ONE launch (a wave per repetition,
+        # csrc/ratspn_gemm_wide.hip) -- the single-launch route then comes first
+        one_launch = (self.rg_depth == 2 and self.rg_repetitions <= 8 and self.out_classes <= 32 and self.rg_sum == 8
+                      and self.in_features <= 1024)
+        return not one_launch
 
     def _forward_folded(self, x: torch.Tensor) -> Optional[torch.Tensor]:
         """Evaluation outside the single-launch kernel's envelope (e.g. rg_batch = rg_sum = 16): leaf kernel, then
