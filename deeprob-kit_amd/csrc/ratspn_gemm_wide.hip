@@ -23,6 +23,7 @@
 // (every wave sees the same x tile, so all eight take that decision together).  Vanished sum nodes fall back to the
 // log domain inside prodsum_node / root_partial (ratspn_nodes.h).
 #include "ratspn_gemm_fused.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace dpk {
@@ -30,6 +31,159 @@ namespace dpk {
 constexpr int kWideWaves = 8;      // waves per work-group = repetitions (column tiles) it can hold
 constexpr int kWideI = 8;
 constexpr int kWideMaxC = 32;      // classes: the repetitions' root partials are exchanged through LDS
+
+// The upper part of ONE 32-sample block on the eight compute waves of a work-group (wave = repetition): leaf sums of the
+// lane's partition from its accumulators (or exactly, per element), the partition's product + sum node, the
+// repetition's share of the root, the log-sum-exp over the repetitions through LDS and the store.  `lds` = scratch the
+// block may overwrite (>= wide_upper_lds_bytes: per-lane log-domain scratch + the root exchange buffer).  Executes
+// kWideUpperBarriers work-group barriers (waves without this work call wide_upper_barriers() instead).  Returns the
+// thread's fp64 share of the sum of the log-likelihoods it stored.
+constexpr int kWideUpperBarriers = 2;
+__device__ __forceinline__ void wide_upper_barriers() {
+#pragma unroll
+    for (int i = 0; i < kWideUpperBarriers; ++i) __syncthreads();
+}
+__host__ __device__ constexpr size_t wide_upper_lds_bytes(int reps, int C) {
+    return (size_t)kWideWaves * 64 * 2 * kWideI * 4 + ((size_t)reps * 32 * C * 2 + 32) * 4;
+}
+
+// Leaf sums of the lane's partition -- regions 2h (va) and 2h + 1 (vc) of repetition rho, for sample b0 + s -- from the
+// block's accumulators, or exactly, per element (any scale, any evidence).
+__device__ __forceinline__ void wide_leaf_sums(const GemmArgs &a, const gf32x16 &acc, unsigned long long odd_mask, bool exact,
+                                               int rho, int64_t b0, float (&va)[kWideI], float (&vc)[kWideI]) {
+    constexpr int I = kWideI;
+    const int lane = threadIdx.x & 63;
+    const int s = lane & 31, h = lane >> 5;
+    const int D = a.D, NT = a.reps, NKS = (D + 15) >> 4;
+    const int64_t b = b0 + s;
+    if (!exact) {
+        float cst[16];
+        if (odd_mask == 0ull) {
+            const float *bt = a.biasT + (h * NT + rho) * 16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cst[i] = bt[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cst[i] = 0.f;
+            for (int ks = 0; ks < NKS; ++ks) {
+                if ((odd_mask >> ks) & 1ull) continue;
+                const float *bk = a.biasK + ((ks * 2 + h) * NT + rho) * 16;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) cst[i] += bk[i];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < I; ++k) {
+            va[k] = acc[k] + cst[k];                       // (the common -1/2 sum x^2 reaches the root as qtot)
+            vc[k] = acc[I + k] + cst[I + k];
+        }
+    } else {
+        // exact per-element evaluation of the partition's two regions (nan_to_num_ at ratspn.py:103)
+        const float *xr = a.x + (b < a.B ? b : a.B - 1) * D;
+        const int d = a.d;
+#pragma unroll
+        for (int k = 0; k < I; ++k) {
+            va[k] = 0.f;
+            vc[k] = 0.f;
+        }
+        for (int qq = 0; qq < 2; ++qq) {
+            const int r = rho * 4 + 2 * h + qq;
+            float t[I];
+#pragma unroll
+            for (int k = 0; k < I; ++k) t[k] = 0.f;
+            for (int j = 0; j < d; ++j) {
+                const int64_t o = (int64_t)r * d + j;
+                if (a.pad != nullptr && a.pad[o]) continue;
+                const float xv = xr[a.mask[o]];
+#pragma unroll
+                for (int k = 0; k < I; ++k) {
+                    const int64_t po = ((int64_t)r * I + k) * d + j;
+                    const float mu = a.loc[po], sg = a.scale[po];
+                    const float dlt = xv - mu;
+                    t[k] += nan_to_num_f(fmaf(dlt * dlt, -0.5f / (sg * sg), -logf(sg) - kLogSqrt2Pi));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < I; ++k) {
+                if (qq == 0) va[k] = t[k]; else vc[k] = t[k];
+            }
+        }
+    }
+}
+
+template <int S>
+__device__ __forceinline__ double wide_block_upper(const GemmArgs &a, const gf32x16 &acc, unsigned long long odd_mask,
+                                                   float qtot, bool exact, int rho, bool mine, int64_t b0,
+                                                   const lfloat *w0_l, char *lds) {
+    constexpr int I = kWideI;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = lane & 31, h = lane >> 5;
+    const int NT = a.reps;
+    // ---- leaf sums of the lane's partition: regions 2h (a) and 2h + 1 (c) of repetition rho -------------------------
+    float va[I], vc[I];
+    wide_leaf_sums(a, acc, odd_mask, exact, rho, b0, va, vc);
+    if (a.ablate & 2) {
+        wide_upper_barriers();
+        return 0.0;
+    }
+
+    // ---- the partition's product + sum node, then the repetition's share of the root ---------------------------------
+    LseScratch sc{reinterpret_cast<float *>(lds) + tid * (2 * I)};                  // [512][16] floats = 32 KB
+    float *xch = reinterpret_cast<float *>(lds) + kWideWaves * 64 * 2 * I;           // [reps][32][2 C]
+    float n1[S];
+    {
+        const lfloat *wl = w0_l + h * S * I * I;
+        const float *lw = a.LW0 + ((int64_t)rho * 2 + h) * S * I * I;
+        prodsum_node<I, S>(va, vc, wl, lw, sc, n1);
+    }
+    float ta[S], tc[S];
+#pragma unroll
+    for (int o = 0; o < S; ++o) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const unsigned bits = __float_as_uint(n1[o]);
+        const u32x2 sw2 = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
+        ta[o] = __uint_as_float(sw2[0]);
+        tc[o] = __uint_as_float(sw2[1]);
+    }
+    float ea[S], ec[S], ma, mc;
+    exp_children<S>(ta, ea, ma);
+    exp_children<S>(tc, ec, mc);
+    const int M = NT * S * S, C = a.C;
+    if (mine) {
+        // the two lanes of a sample hold the same (ta, tc): they split the classes
+        for (int cl = h; cl < C; cl += 2) {
+            float pm, ps;
+            const cfloat_p wr = a.Wr + (int64_t)cl * M + rho * S * S;
+            const cfloat_p lwr = a.LWr + (int64_t)cl * M + rho * S * S;
+            root_partial<S>(ta, tc, ea, ec, ma, mc, wr, lwr, sc, pm, ps);
+            if (!(ps > 0.f)) pm = -INFINITY;
+            xch[((rho * 32 + s) * C + cl) * 2] = pm;
+            xch[((rho * 32 + s) * C + cl) * 2 + 1] = ps;
+        }
+    }
+    // sum x^2 of the sample: computed by the lanes (s, h = 0 / 1) of every wave; the root takes wave 0's through LDS
+    float *qx = xch + NT * 32 * C * 2;
+    if (wave == 0 && h == 0) qx[s] = exact ? 0.f : -0.5f * qtot;       // (the exact leaf sums already carry it)
+    __syncthreads();                                   // (barrier 1 of kWideUpperBarriers)
+    // ---- root: log-sum-exp over the repetitions; thread = (sample, class slot) ---------------------------------------
+    double part = 0.0;
+    {
+        const int smp = tid >> 4, slot = tid & 15;
+        const int64_t bs = b0 + smp;
+        const float qterm = qx[smp];
+        for (int cl = slot; cl < C; cl += 16) {
+            float mm = -INFINITY, ss = 0.f;
+            for (int r = 0; r < NT; ++r) lse_merge(mm, ss, xch[((r * 32 + smp) * C + cl) * 2], xch[((r * 32 + smp) * C + cl) * 2 + 1]);
+            const float ll = ((mm > -INFINITY) ? mm + logf(ss) : -INFINITY) + qterm;
+            if (bs < a.B) {
+                a.out[bs * C + cl] = ll;
+                part += (double)ll;
+            }
+        }
+    }
+    __syncthreads();                                   // (barrier 2: the scratch may be overwritten by the next block)
+    return part;
+}
 
 template <int S, bool MARG>
 __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const GemmArgs a) {
@@ -47,7 +201,6 @@ __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const
     const int D = a.D, NT = a.reps;
     const int NKS = (D + 15) >> 4;
     const int64_t b0 = (int64_t)blockIdx.x * 32;
-    const int64_t b = b0 + s;
     const int nvalid = (int)min((int64_t)32, a.B - b0);
     const bool mine = wave < NT;                       // (a model with fewer repetitions leaves waves without a tile)
     const int rho = mine ? wave : NT - 1;
@@ -98,7 +251,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const
         const float *wp = a.W0 + (int64_t)rho * 2 * S * I * I;
         for (int e = lane; e < 2 * S * I * I; e += 64) w0_l[e] = wp[e];
     }
-    bool model_ok = a.elig[rho] != 0;
+    bool model_ok = a.elig[min(lane, NT - 1)] != 0;   // (every repetition's verdict: the root adds one common term)
     __syncthreads();   // (drains every request above: the x tile is in LDS for everyone)
 
     // ---- phase 1: P^T = M^T x^T over the whole K range of the wave's tile --------------------------------------------
@@ -181,121 +334,10 @@ __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const
     model_ok = __all(model_ok);
     const bool exact = !model_ok || __any(lane_exact);   // (the same x tile in every wave: the same verdict in every wave)
 
-    // ---- leaf sums of the lane's partition: regions 2h (a) and 2h + 1 (c) of repetition rho -------------------------
-    float va[I], vc[I];
-    if (!exact) {
-        float cst[16];
-        if (odd_mask == 0ull) {
-            const float *bt = a.biasT + (h * NT + rho) * 16;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) cst[i] = bt[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) cst[i] = 0.f;
-            for (int ks = 0; ks < NKS; ++ks) {
-                if ((odd_mask >> ks) & 1ull) continue;
-                const float *bk = a.biasK + ((ks * 2 + h) * NT + rho) * 16;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) cst[i] += bk[i];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < I; ++k) {
-            va[k] = acc[k] + cst[k];                       // (the common -1/2 sum x^2 reaches the root as qtot)
-            vc[k] = acc[I + k] + cst[I + k];
-        }
-    } else {
-        // exact per-element evaluation of the partition's two regions (any scale, any evidence: nan_to_num_ at ratspn.py:103)
-        const float *xr = a.x + (b < a.B ? b : a.B - 1) * D;
-        const int d = a.d;
-#pragma unroll
-        for (int k = 0; k < I; ++k) {
-            va[k] = 0.f;
-            vc[k] = 0.f;
-        }
-        for (int qq = 0; qq < 2; ++qq) {
-            const int r = rho * 4 + 2 * h + qq;
-            float t[I];
-#pragma unroll
-            for (int k = 0; k < I; ++k) t[k] = 0.f;
-            for (int j = 0; j < d; ++j) {
-                const int64_t o = (int64_t)r * d + j;
-                if (a.pad != nullptr && a.pad[o]) continue;
-                const float xv = xr[a.mask[o]];
-#pragma unroll
-                for (int k = 0; k < I; ++k) {
-                    const int64_t po = ((int64_t)r * I + k) * d + j;
-                    const float mu = a.loc[po], sg = a.scale[po];
-                    const float dlt = xv - mu;
-                    t[k] += nan_to_num_f(fmaf(dlt * dlt, -0.5f / (sg * sg), -logf(sg) - kLogSqrt2Pi));
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < I; ++k) {
-                if (qq == 0) va[k] = t[k]; else vc[k] = t[k];
-            }
-        }
-    }
     __syncthreads();   // every wave is done with the x tile: its LDS becomes scratch and the root exchange buffer
-    if (a.ablate & 2) return;
-
-    // ---- the partition's product + sum node, then the repetition's share of the root ---------------------------------
-    LseScratch sc{reinterpret_cast<float *>(smem_generic) + tid * (2 * I)};                  // [512][16] floats = 32 KB
-    float *xch = reinterpret_cast<float *>(smem_generic) + kWideWaves * 64 * 2 * I;           // [reps][32][2 C]
-    float n1[S];
-    {
-        const lfloat *wl = w0_l + h * S * I * I;
-        const float *lw = a.LW0 + ((int64_t)rho * 2 + h) * S * I * I;
-        prodsum_node<I, S>(va, vc, wl, lw, sc, n1);
-    }
-    float ta[S], tc[S];
-#pragma unroll
-    for (int o = 0; o < S; ++o) {
-        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        const unsigned bits = __float_as_uint(n1[o]);
-        const u32x2 sw2 = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
-        ta[o] = __uint_as_float(sw2[0]);
-        tc[o] = __uint_as_float(sw2[1]);
-    }
-    float ea[S], ec[S], ma, mc;
-    exp_children<S>(ta, ea, ma);
-    exp_children<S>(tc, ec, mc);
-    const int M = NT * S * S, C = a.C;
-    if (mine) {
-        // the two lanes of a sample hold the same (ta, tc): they split the classes
-        for (int cl = h; cl < C; cl += 2) {
-            float pm, ps;
-            const cfloat_p wr = a.Wr + (int64_t)cl * M + rho * S * S;
-            const cfloat_p lwr = a.LWr + (int64_t)cl * M + rho * S * S;
-            root_partial<S>(ta, tc, ea, ec, ma, mc, wr, lwr, sc, pm, ps);
-            if (!(ps > 0.f)) pm = -INFINITY;
-            xch[((rho * 32 + s) * C + cl) * 2] = pm;
-            xch[((rho * 32 + s) * C + cl) * 2 + 1] = ps;
-        }
-    }
-    __syncthreads();
-    // ---- root: log-sum-exp over the repetitions; thread = (sample, class slot) ---------------------------------------
-    double part = 0.0;
-    {
-        const int smp = tid >> 4, slot = tid & 15;
-        const int64_t bs = b0 + smp;
-        // sum x^2 of the sample: computed by the lanes (smp, h = 0 / 1) of every wave; take wave 0's through LDS
-        float *qx = xch + NT * 32 * C * 2;
-        if (wave == 0 && h == 0) qx[s] = exact ? 0.f : -0.5f * qtot;   // (the exact leaf sums already carry it)
-        __syncthreads();
-        const float qterm = qx[smp];
-        for (int cl = slot; cl < C; cl += 16) {
-            float mm = -INFINITY, ss = 0.f;
-            for (int r = 0; r < NT; ++r) lse_merge(mm, ss, xch[((r * 32 + smp) * C + cl) * 2], xch[((r * 32 + smp) * C + cl) * 2 + 1]);
-            const float ll = ((mm > -INFINITY) ? mm + logf(ss) : -INFINITY) + qterm;
-            if (bs < a.B) {
-                a.out[bs * C + cl] = ll;
-                part += (double)ll;
-            }
-        }
-    }
+    double part = wide_block_upper<S>(a, acc, odd_mask, qtot, exact, rho, mine, b0, w0_l, smem_generic);
+    double *red = reinterpret_cast<double *>(smem_generic + wide_upper_lds_bytes(NT, a.C));
     if (a.ll_sum != nullptr) {
-        double *red = reinterpret_cast<double *>(xch + NT * 32 * C * 2 + 32);
         part = wave_reduce_sum(part);
         __syncthreads();
         if (lane == 0) red[wave] = part;
@@ -309,6 +351,332 @@ __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const
         }
     }
     if (saw_nan && tid == 0 && a.slow_flag != nullptr) *a.slow_flag = a.launch_seq;
+}
+
+// ------------------------------------------------------------------------------------------------
+// large batches: 128-sample tiles, x through a three-stage LDS-DMA ring, converted once per tile
+// ------------------------------------------------------------------------------------------------
+// The 32-sample kernel above re-reads the repetition's table fragments (98 KB per wave, 784 KB per work-group) for every
+// 32 samples -- 27.6 KB of L2 -> CU traffic per sample, which bounds it -- and every one of its 8 waves converts the SAME
+// x values to f16 pairs (45 VALU instructions against 3 MFMAs per K-step).  Here
+//   * a compute wave (= repetition) keeps FOUR 32-sample blocks in flight against each fragment (64 accumulator
+//     registers): 6.9 KB of table traffic per sample;
+//   * 128 rows of x do not fit LDS next to the scratch, so x arrives in 64-feature chunks through a ring of three 32 KB
+//     stages (the row layout of the 2-channel ring: 256-byte rows of sixteen 16-byte pieces, XOR-swizzled by row & 15 on
+//     the source side).  Waves 8-11 are the loader waves, one per sample block: a loader wave DMAs its block's 32 rows
+//     of the chunk, waits for them (counted vmcnt), and converts them IN PLACE -- the 32 bytes a lane read as 8 floats
+//     become [8 x f16 high | 8 x f16 low], exactly the two B operands the MFMAs take -- before the chunk's barrier.  It
+//     also does the per-chunk bookkeeping once instead of eight times: sum x^2 per row, the K-steps that hold NaN / out of
+//     range values (flags per block and K-step; such a value counts as 0 in the product),
+//     the block's exact-evaluation verdict;
+//   * the compute waves' K loop is then two 16-byte LDS reads and three MFMAs per block and K-step.
+// One tile per work-group: the upper part needs work-group barriers, which a ring running on across tile boundaries could
+// not share with the loaders.
+constexpr int kWideRingBlocks = 4;
+struct WideRingTail {                                 // LDS behind the ring's stages
+    unsigned flags[kGemmStages][kWideRingBlocks];     // per stage and block: bit k = K-step k of the chunk needs the validity GEMM
+    float qrow[kGemmTile];                            // sum x^2 per row of the tile (finite, in-range values)
+    int exact[kWideRingBlocks];                       // the block leaves the expanded form
+    int saw_nan;
+    int pad[3];
+};
+static_assert(sizeof(WideRingTail) % 16 == 0, "the waves' weight slices follow");
+
+template <int S>
+__global__ __launch_bounds__((kWideWaves + kGemmWaves) * 64) void ratspn_gemm_wide_ring_kernel(const GemmArgs a) {
+    constexpr int NB = kWideRingBlocks;
+    constexpr int KS = 4, KC = 16 * KS, ROWB = KC * 4, STAGE = kGemmTile * ROWB, NS = kGemmStages;
+    constexpr int PX = 8;                              // DMA instructions per loader wave and chunk (4 rows each)
+    constexpr int PF = KS;                             // K-steps of table fragments in flight (one chunk: 168 VGPRs at 12 waves)
+    typedef const __attribute__((address_space(1))) half8 gh8;
+    typedef __attribute__((address_space(3))) gf32x4 lf4;
+    typedef __attribute__((address_space(3))) half8 lh8;
+    typedef __attribute__((address_space(3))) WideRingTail ltail;
+    static_assert(kGemmTile == 32 * NB && kGemmWaves == NB && NS == 3, "one loader wave per block; counted waits");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_generic[];
+    lchar *smem = (lchar *)smem_generic;
+    ltail *tail = (ltail *)(smem + NS * STAGE);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = a.D, NT = a.reps, NCH = (D + KC - 1) / KC;
+    const int NKS = (D + 15) >> 4;
+    const int64_t t0 = (int64_t)blockIdx.x * kGemmTile;
+    if (tid == 0) tail->saw_nan = 0;
+
+    if (wave12 >= kWideWaves) {
+        // ================= loader wave w: rows [32 w, 32 w + 32) of the tile = sample block w ==========================
+        const int w = wave12 - kWideWaves;
+        __builtin_amdgcn_s_setprio(3);                 // (the chunk's barrier waits for this wave's conversion: first in line at issue)
+        const int nvalid = (int)min((int64_t)kGemmTile, a.B - t0);
+        const gcchar_p xt = (gcchar_p)(a.x + t0 * D);
+        const unsigned smem_base = (unsigned)(uintptr_t)smem;
+        unsigned voff[PX];
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const int rl = w * 32 + j * 4 + (lane >> 4);
+            voff[j] = (unsigned)(min(rl, nvalid - 1) * D + (((lane & 15) ^ (rl & 15)) << 2)) * 4u;
+        }
+        auto issue = [&](int pc) {
+            const unsigned st = smem_base + (pc % NS) * STAGE + w * 32 * ROWB;
+            if ((pc + 1) * KC <= D) {
+#pragma unroll
+                for (int j = 0; j < PX; ++j) glds16(voff[j] + pc * (KC * 4), xt, st + j * 4 * ROWB);
+            } else {   // last chunk of a ragged row: pieces beyond it re-fetch the last one (zeroed by the conversion)
+                const int vp = (D - pc * KC) >> 2;
+#pragma unroll
+                for (int j = 0; j < PX; ++j) {
+                    const int rl = w * 32 + j * 4 + (lane >> 4);
+                    const int gp = min((lane & 15) ^ (rl & 15), vp - 1);
+                    glds16((unsigned)(min(rl, nvalid - 1) * D + pc * KC + gp * 4) * 4u, xt, st + j * 4 * ROWB);
+                }
+            }
+        };
+        // the lane's share of a chunk: K-step (lane & 7) >> 1, feature half lane & 1 of the rows j * 8 + (lane >> 3)
+        const int ks4 = (lane & 7) >> 1, h = lane & 1, pcs = ks4 * 4 + h * 2;
+        float qacc[4] = {0.f, 0.f, 0.f, 0.f};
+        bool need_exact = false, saw_nan = false;
+        auto convert = [&](int pc) {
+            lchar *st = smem + (pc % NS) * STAGE;
+            const int f0 = (pc * KS + ks4) * 16 + h * 8;
+            const bool in0 = f0 + 4 <= D, in1 = f0 + 8 <= D;
+            unsigned long long bad_lanes = 0ull;
+            gf32x4 xa[4], xb[4];                       // (all eight reads first: one LDS round trip per chunk, not four)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rl = w * 32 + j * 8 + (lane >> 3), sw = rl & 15;
+                xa[j] = *(lf4 *)(st + rl * ROWB + ((pcs ^ sw) << 4));
+                xb[j] = *(lf4 *)(st + rl * ROWB + (((pcs | 1) ^ sw) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rl = w * 32 + j * 8 + (lane >> 3), sw = rl & 15;
+                lchar *p0 = st + rl * ROWB + ((pcs ^ sw) << 4), *p1 = st + rl * ROWB + (((pcs | 1) ^ sw) << 4);
+                const gf32x4 x0 = xa[j], x1 = xb[j];
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = in0 ? x0[i] : 0.f;
+                    v[4 + i] = in1 ? x1[i] : 0.f;
+                }
+                gf32x2 tq2 = {0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    const gf32x2 pv = {v[i], v[i + 1]};
+                    tq2 = __builtin_elementwise_fma(pv, pv, tq2);
+                }
+                float tq = tq2[0] + tq2[1];
+                const bool bad = !(tq < kGemmStepBound);
+                bad_lanes |= __ballot(bad);
+                if (bad) {   // (a NaN or an out-of-range value counts as 0 here; the compute waves add the K-step's validity GEMM)
+                    tq = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float vi = v[i];
+                        const bool isn = vi != vi;
+                        const bool big = !isn && !(fabsf(vi) < kGemmAbsBound);
+                        need_exact = need_exact || big;
+                        saw_nan = saw_nan || isn;
+                        v[i] = (isn || big) ? 0.f : vi;
+                        tq = fmaf(v[i], v[i], tq);
+                    }
+                }
+                qacc[j] += tq;
+                half8 xh, xl;
+                split8(v, xh, xl);
+                *(lh8 *)p0 = xh;
+                *(lh8 *)p1 = xl;
+            }
+            if (lane == 0) {
+                unsigned fl = 0u;
+#pragma unroll
+                for (int k = 0; k < KS; ++k) fl |= (bad_lanes & (0x0303030303030303ull << (2 * k))) ? (1u << k) : 0u;
+                tail->flags[pc % NS][w] = fl;
+            }
+        };
+        issue(0);
+        if (NCH > 1) issue(1);
+        __syncthreads();   // (the compute waves fill their constants meanwhile)
+        for (int c = 0; c < NCH; ++c) {
+            // this wave's rows of chunk c have landed once at most one later chunk is still in flight
+            if (c + 1 < NCH) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PX) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (!(a.ablate & 4)) convert(c);
+            gemm_lds_barrier();   // chunk c is converted for everyone; everyone is done reading chunk c - 1
+            if (c + 2 < NCH) issue(c + 2);
+        }
+        // the tile's sums: 8 lanes hold a row's K-step / half shares
+        bool blk_exact = need_exact;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float q = qacc[j];
+            q += __shfl_xor(q, 1, 64);
+            q += __shfl_xor(q, 2, 64);
+            q += __shfl_xor(q, 4, 64);
+            if ((lane & 7) == 0) tail->qrow[w * 32 + j * 8 + (lane >> 3)] = q;
+            // the expanded square is within the 1e-5 bar while sum x^2 <= 36 D (|mu| <= 6: DESIGN 3.3)
+            blk_exact = blk_exact || !(q <= kExpandBound * kExpandBound * (float)D);
+        }
+        blk_exact = __any(blk_exact);
+        if (lane == 0) tail->exact[w] = blk_exact ? 1 : 0;
+        if (__any(saw_nan) && lane == 0) tail->saw_nan = 1;
+        __syncthreads();                               // (the compute waves' "ring is idle" barrier)
+        for (int blk = 0; blk < NB; ++blk) wide_upper_barriers();
+        if (a.ll_sum != nullptr) {
+            __syncthreads();
+            __syncthreads();
+        }
+        return;
+    }
+    // ===================== compute wave = repetition ======================================================================
+    const int wave = wave12;
+    const int s = lane & 31, h = lane >> 5;
+    const bool mine = wave < NT;
+    const int rho = mine ? wave : NT - 1;
+    half8 mh[PF], ml[PF];
+    const gcchar_p tbase = (gcchar_p)a.mtab + ((int64_t)rho * 2048 + lane * 16);
+    const gcchar_p cbase = (gcchar_p)a.ctab + ((int64_t)rho * 2048 + lane * 16);
+    auto load_frags = [&](int slot, int ks) {
+        const int64_t o = (int64_t)min(ks, NKS - 1) * NT * 2048;
+        mh[slot] = *(gh8 *)(tbase + o);
+        ml[slot] = *(gh8 *)(tbase + o + 1024);
+    };
+#pragma unroll
+    for (int k = 0; k < PF; ++k) load_frags(k, k);
+    lfloat *w0_l = (lfloat *)(smem + NS * STAGE + sizeof(WideRingTail)) + wave * (2 * S * kWideI * kWideI);
+    {
+        const float *wp = a.W0 + (int64_t)rho * 2 * S * kWideI * kWideI;
+        for (int e = lane; e < 2 * S * kWideI * kWideI; e += 64) w0_l[e] = wp[e];
+    }
+    bool model_ok = a.elig[min(lane, NT - 1)] != 0;   // (every repetition's verdict: the root adds one common term)
+    __syncthreads();   // (pairs with the loaders' opening one)
+
+    gf32x16 acc[NB];
+    unsigned long long odd_mask[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+        odd_mask[q] = 0ull;
+    }
+    // The hot loop is straight-line code -- two LDS reads and three MFMAs per block and K-step, the fragments one chunk
+    // ahead -- with nothing conditional that touches a memory counter: a branch with a load behind it makes hipcc's
+    // counter bookkeeping give up at the join (vmcnt(1) in front of every K-step: the L2 latency of the fragment just
+    // requested, 20 us per tile).  Hence K-steps with flagged values only leave a bit here and are finished below.
+    auto chunk = [&](auto nk_c, int c, int cstage) {
+        constexpr int NK = decltype(nk_c)::value;
+        gemm_lds_barrier();   // the loaders have converted this chunk; everyone is done with the previous one
+        const lchar *st = smem + cstage * STAGE;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const unsigned fl = (unsigned)__builtin_amdgcn_readfirstlane((int)tail->flags[cstage][q]);
+            odd_mask[q] |= (unsigned long long)fl << (c * KS);
+        }
+        // (block, K-step) pairs in sequence, the operands of the pair two ahead requested before each MFMA group; the
+        // scheduling barriers keep hipcc from hoisting all 32 reads of the chunk (128 registers) to the top
+        if (a.ablate & 1) return;
+        constexpr int NP = NK * NB, AHEAD = 2;
+        half8 xh[AHEAD + 1], xl[AHEAD + 1];
+        auto request = [&](int n, half8 &dh, half8 &dl) {
+            const int kk = n / NB, q = n % NB;
+            const int rl = q * 32 + s, sw = rl & 15, pcs = kk * 4 + h * 2;
+            dh = *(const lh8 *)(st + rl * ROWB + ((pcs ^ sw) << 4));
+            dl = *(const lh8 *)(st + rl * ROWB + (((pcs | 1) ^ sw) << 4));
+        };
+#pragma unroll
+        for (int n = 0; n < AHEAD && n < NP; ++n) request(n, xh[n], xl[n]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NP; ++n) {
+            const int kk = n / NB, q = n % NB, cur = n % (AHEAD + 1);
+            if (n + AHEAD < NP) request(n + AHEAD, xh[(n + AHEAD) % (AHEAD + 1)], xl[(n + AHEAD) % (AHEAD + 1)]);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[kk], xh[cur], acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[kk], xl[cur], acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[kk], xh[cur], acc[q], 0, 0, 0);
+            if (q == NB - 1) load_frags(kk, c * KS + kk + PF);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const int NCHF = NKS / KS, NKT = NKS - NCHF * KS;   // full chunks, K-steps of the last one
+    int cstage = 0;
+    for (int c = 0; c < NCHF; ++c) {
+        chunk(std::integral_constant<int, KS>(), c, cstage);
+        cstage = (cstage + 1 == NS) ? 0 : cstage + 1;
+    }
+    if (NKT > 0) {   // the row's last, partial chunk (once per tile: plain code)
+        gemm_lds_barrier();
+        const lchar *st = smem + cstage * STAGE;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const unsigned fl = (unsigned)__builtin_amdgcn_readfirstlane((int)tail->flags[cstage][q]);
+            odd_mask[q] |= (unsigned long long)fl << (NCHF * KS);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KS - 1; ++kk) {
+            if (kk < NKT) {
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+                    const int rl = q * 32 + s, sw = rl & 15, pcs = kk * 4 + h * 2;
+                    const half8 xh = *(const lh8 *)(st + rl * ROWB + ((pcs ^ sw) << 4));
+                    const half8 xl = *(const lh8 *)(st + rl * ROWB + (((pcs | 1) ^ sw) << 4));
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[kk], xh, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[kk], xl, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[kk], xh, acc[q], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // flagged K-steps (NaN or out-of-range values, counted as 0 above): the constants of the features that ARE present,
+    // as a validity GEMM from x as it lies in global memory.  (On demand: a launch that keeps meeting NaN takes the
+    // 32-sample kernel's build with both tables in flight.)
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        if (odd_mask[q] == 0ull) continue;   // (wave-uniform)
+        const float *xr = a.x + min(t0 + q * 32 + s, a.B - 1) * D;
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (!((odd_mask[q] >> ks) & 1ull)) continue;
+            const int f0 = ks * 16 + h * 8;
+            half8 valid;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float vi = (f0 + i < D) ? xr[f0 + i] : 0.f;
+                valid[i] = (vi != vi) ? (_Float16)0.0f : (_Float16)1.0f;
+            }
+            const int64_t o = (int64_t)ks * NT * 2048;
+            const half8 c0 = *(gh8 *)(cbase + o), c1 = *(gh8 *)(cbase + o + 1024);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c0, valid, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1, valid, acc[q], 0, 0, 0);
+        }
+    }
+    model_ok = __all(model_ok);
+    __syncthreads();   // the ring is idle: its stages become scratch and the root exchange buffer; the tail is complete
+    // (Measured and dropped, round 3: the two halves of a wave trading partitions across two blocks so that the sum weights
+    // are wave-uniform and come through the scalar cache instead of LDS -- 63 us per tile against 54: 32 KB of weights per
+    // work-group do not stay in the 16 KB scalar cache, and every s_load_dwordx16 then waits for the L2.)
+    double part = 0.0;
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+        part += wide_block_upper<S>(a, acc[q], odd_mask[q], tail->qrow[q * 32 + s], !model_ok || tail->exact[q] != 0, rho, mine,
+                                    t0 + q * 32, w0_l, smem_generic);
+    if (a.ll_sum != nullptr) {
+        double *red = reinterpret_cast<double *>(smem_generic + wide_upper_lds_bytes(NT, a.C));
+        part = wave_reduce_sum(part);
+        __syncthreads();
+        if (lane == 0) red[wave] = part;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < kWideWaves; ++w) tot += red[w];
+            atomicAdd(a.ll_sum, tot);
+            if (blockIdx.x == 0) atomicAdd(a.ll_sum + 1, (double)a.B * (double)a.C);
+        }
+    }
+    if (tid == 0 && tail->saw_nan != 0 && a.slow_flag != nullptr) *a.slow_flag = a.launch_seq;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -339,9 +707,44 @@ static int gemm_wide_launch(const GemmArgs &a, hipStream_t st) {
     return DPK_OK;
 }
 
+template <int S>
+static int gemm_wide_ring_launch(const GemmArgs &a, hipStream_t st) {
+    const size_t lds = (size_t)kGemmStages * kGemmTile * 256 + sizeof(WideRingTail) + (size_t)kWideWaves * 2 * S * kWideI * kWideI * 4;
+    auto kern = ratspn_gemm_wide_ring_kernel<S>;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024)) return rc;
+    hipEvent_t ev0, ev1;
+    profile_take(&ev0, &ev1, DPK_KERNEL_RATSPN_FUSED);
+    if (ev0) (void)hipEventRecord(ev0, st);
+    DPK_LAUNCH(kern, dim3(cdiv(a.B, kGemmTile)), dim3((kWideWaves + kGemmWaves) * 64), lds, st, a);
+    if (ev1) (void)hipEventRecord(ev1, st);
+    DPK_CHECK_LAUNCH("ratspn_gemm_wide_ring_kernel");
+    return DPK_OK;
+}
+
+// The 128-sample ring kernel is taken above a multiple of the small-batch threshold (dpk_ratspn_small_batch_max: 0 = ring
+// kernels always, which is how the tests reach it at every batch size); DPK_WIDE_RING_MIN overrides for measurements.
+constexpr int kWideRingFactor = 1;
+int64_t gemm_small_max_batch();   // ratspn_gemm_small.hip
+static bool wide_takes_ring(int64_t B) {
+    static const int64_t forced = [] {
+        const char *e = getenv("DPK_WIDE_RING_MIN");
+        return e ? (int64_t)atoll(e) : (int64_t)-1;
+    }();
+    return forced >= 0 ? B >= forced : B > gemm_small_max_batch() * kWideRingFactor;
+}
+
 // The caller (ratspn_gemm_forward) has built the tables and filled the argument block.
 int ratspn_gemm_wide_forward(const GemmArgs &a, int S, hipStream_t st) {
     const bool marg = a.marginal != 0;
+    // large clean batches: 128-sample tiles behind the LDS-DMA ring (its scratch must fit the ring's stages)
+    if (!marg && wide_takes_ring(a.B) && (a.D % 4) == 0 &&
+        wide_upper_lds_bytes(a.reps, a.C) + kWideWaves * 8 + 64 <= (size_t)kGemmStages * kGemmTile * 256) {
+        switch (S) {
+            case 2: return gemm_wide_ring_launch<2>(a, st);
+            case 4: return gemm_wide_ring_launch<4>(a, st);
+            case 8: return gemm_wide_ring_launch<8>(a, st);
+        }
+    }
     switch (S) {
         case 2: return marg ? gemm_wide_launch<2, true>(a, st) : gemm_wide_launch<2, false>(a, st);
         case 4: return marg ? gemm_wide_launch<4, true>(a, st) : gemm_wide_launch<4, false>(a, st);
