@@ -235,7 +235,7 @@ def _time_eval_graph(model, xs, reps=4):
 def _time_train(model, x, steps=15, warm=3):
     import torch
     model.train()
-    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, fused=True)  # (as train_model builds it)
 
     def step():
         opt.zero_grad()
@@ -263,7 +263,7 @@ def _time_train_graph(model, x, steps=30):
     from deeprob.hip.graphs import GraphedTrainStep
     try:
         model.train()
-        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, capturable=True)
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, capturable=True, fused=True)
         gstep = GraphedTrainStep(model, opt)
         for _ in range(6):
             gstep(x)
@@ -338,7 +338,8 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
 
     # ---- BASELINE config 2: RAT-SPN, B = 4096 (constructor defaults + the two wider settings) ----------
     B = 4096
-    # bytes / flops per sample: fully fused 4*(784+1); (8,8) and (16,16) run as leaf | prod+sum | prod+root
+    # bytes / flops per sample: fully fused (one launch) 4*(784+1) for (2,2) and (8,8); (16,16) runs as
+    # leaf | prod+sum | prod+root
     rat = {(2, 2): (3140, 50.6e3), (8, 8): (3140, 219.6e3), (16, 16): (9284, 542.7e3)}
     for (I, S), (alg, fl) in rat.items():
         torch.manual_seed(0)
@@ -346,7 +347,7 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
         sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
         m.to(dev)
         xs = [torch.randn(B, D, device=dev) for _ in range(8)]
-        kid = KERNEL_FUSED if I < 8 else KERNEL_LEAF   # rg_batch 8 and 16 run leaf | prod+sum | prod+root on the MFMA
+        kid = KERNEL_FUSED if I <= 8 else KERNEL_LEAF   # rg_batch 16 runs leaf | prod+sum | prod+root on the MFMA
         ms_eager, k_ms = _time_eval(m, xs, timer, kid, steps=50)
         ms_graph = _time_eval_graph(m, xs)
         ms = ms_graph if ms_graph is not None else ms_eager
@@ -373,6 +374,8 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
              'ms_per_step_eager': ms_eager, 'ms_per_step_trusting_version_counters': ms_trust, 'kernel_ms': k_ms,
              'kernel': ('fused forward, small-batch kernel (one HIP event pair around a single launch: includes its '
                         'dispatch latency; rocprofv3: profiles/r03_config2_kernel_stats.txt)') if I < 8
+                       else ('fused forward, one-launch 8-channel kernel (a wave per repetition; event pair around a '
+                             'single launch: includes its dispatch latency)') if I == 8
                        else 'leaf MFMA kernel (then the prod+sum and prod+root MFMA kernels)',
              'roofline': roof,
              'roofline_basis': 'whole step; {} algorithmic B/sample'.format(alg) if I <= 8
@@ -380,6 +383,28 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
              'cpu_baseline': {'value': rate, 'unit': 'log-likelihoods/sec', 'cores': threads, 'kind': 'port',
                               'sample': '{} samples ({:.1f} s), oracle/ratspn_oracle.py'.format(n_cpu, dt)}}
         out.append(e)
+        if (I, S) == (8, 8):
+            # the same model at the headline batch size: the 128-sample ring mapping of the 8-channel kernel
+            Bl = 65536
+            xl = [torch.randn(Bl, D, device=dev) for _ in range(4)]
+            msl_e, kl_ms = _time_eval(m, xl, timer, kid, steps=20)
+            msl_g = _time_eval_graph(m, xl)
+            msl = msl_g if msl_g is not None else msl_e
+            roofl = hbm(Bl * alg, msl)
+            roofl['traffic'], roofl['traffic_source'] = read_traffic('wide_65536')
+            out.append({'workload': 'the same (8,8) model at the headline batch size (128-sample tiles: x through an LDS-DMA '
+                                    'ring, converted to f16 pairs once per tile by the loader waves)',
+                        'config': 'headline size, rg_batch = rg_sum = 8', 'batch': Bl, 'ms_per_step': msl,
+                        'value': Bl / msl * 1e3, 'unit': 'log-likelihoods/sec', 'ms_per_step_eager': msl_e,
+                        'kernel_ms': kl_ms, 'kernel': 'ratspn_gemm_wide_ring_kernel', 'roofline': roofl,
+                        'roofline_basis': 'whole step; 3140 algorithmic B/sample (the kernel is bound by its MFMA + node '
+                                          'evaluation phases, not by HBM: DESIGN 3.10)',
+                        'mfma': (lambda a: {'bound': 'mfma', 'achieved': a, 'peak': 2500.0, 'unit': 'TFLOP/s',
+                                            'frac': a / 2500.0,
+                                            'basis': 'executed f16 MFMA flops: 3 products x 2 x 784 x 256 outputs per '
+                                                     'sample, over the kernel time'})(
+                            Bl * 2.0 * 3 * 784 * 256 / ((kl_ms if kl_ms else msl) * 1e-3) / 1e12)})
+            del xl
         if (I, S) == (2, 2):
             # the marginalisation path (nan_to_num_ at ratspn.py:103): 30 % of the entries NaN, at B = 4096 and 65536
             for Bn in (4096, 65536):

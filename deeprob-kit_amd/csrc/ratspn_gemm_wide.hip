@@ -185,12 +185,23 @@ __device__ __forceinline__ double wide_block_upper(const GemmArgs &a, const gf32
     return part;
 }
 
+constexpr unsigned short kWideNanMark = 0x7E00;       // f16 quiet NaN: the low half of a value that is missing
+struct WideTail {                                     // LDS behind the x tile and the weight slices: the waves' shares
+    unsigned long long odd[kWideWaves];               // K-steps (of those the wave converted) that hold flagged values
+    float qpart[kWideWaves][64];                      // sum x^2 of the lane's 8 features over those K-steps
+    int flags[kWideWaves];                            // 1: out-of-range value (exact evaluation), 2: NaN seen
+};
+static_assert(sizeof(WideTail) % 16 == 0, "LDS layout");
+
 template <int S, bool MARG>
 __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const GemmArgs a) {
     constexpr int I = kWideI;
     constexpr int PF = MARG ? 6 : 12;                 // K-steps of table fragments in flight per wave
     typedef const __attribute__((address_space(1))) half8 gh8;
     typedef __attribute__((address_space(3))) const gf32x4 lf4;
+    typedef __attribute__((address_space(3))) half8 lh8;
+    typedef __attribute__((address_space(3))) WideTail ltail;
+    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
     lchar *smem = (lchar *)smem_generic;
@@ -246,89 +257,168 @@ __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const
     };
 #pragma unroll
     for (int k = 0; k < PF; ++k) load_frags(k, k);
+    static_assert((MARG ? 4 : 2) * PF == 24, "the counted wait below");
+    // The wave's own K-steps of the tile have landed once only the 24 fragment loads behind them are outstanding (hipcc
+    // does not count the asm DMAs, and they are older than every load it does count).
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+
+    // ---- phase 0: f32 -> f16 pairs, in place, ONCE per tile -----------------------------------------------------------
+    // Every wave multiplies the same x tile: converting in the K loop was 45 VALU instructions per K-step in each of the
+    // 8 waves.  Here a wave converts the K-steps it fetched itself: the 32 bytes lane (s, h) would read as 8 floats become
+    // [8 x f16 high | 8 x f16 low], the two B operands of its MFMAs.  With the conversion go the bookkeeping of the
+    // K-step (sum x^2, NaN / out-of-range values -> 0 with the K-step flagged; a NaN leaves a NaN low half as its mark,
+    // which a finite residual never is) -- per wave, combined through the LDS tail after the barrier.
+    const int sw = (s >> 2) & 3;
+    const unsigned xo0 = (unsigned)(s * 64 + (((h * 2) ^ sw) << 4)), xo1 = (unsigned)(s * 64 + (((h * 2 + 1) ^ sw) << 4));
+    ltail *tail = (ltail *)(smem + NKS * 2048 + kWideWaves * 2 * S * I * I * 4);
+    {
+        float qsum = 0.f;
+        bool need_exact = false, saw_nan = false;
+        unsigned long long odd_part = 0ull;
+        for (int ks = wave; ks < NKS; ks += kWideWaves) {
+            lchar *xb = smem + ks * 2048;
+            const gf32x4 x0 = *(lf4 *)(xb + xo0), x1 = *(lf4 *)(xb + xo1);
+            float v[8];
+            {
+                const int f0 = ks * 16 + h * 8;
+                const bool in0 = f0 + 4 <= D, in1 = f0 + 8 <= D;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = in0 ? x0[i] : 0.f;
+                    v[4 + i] = in1 ? x1[i] : 0.f;
+                }
+            }
+            gf32x2 tq2 = {0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+                const gf32x2 pv = {v[i], v[i + 1]};
+                tq2 = __builtin_elementwise_fma(pv, pv, tq2);
+            }
+            float tq = tq2[0] + tq2[1];
+            const bool bad = !(tq < kGemmStepBound);
+            unsigned nanm = 0u;
+            if (__any(bad)) odd_part |= 1ull << ks;
+            if (bad) {
+                tq = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float vi = v[i];
+                    const bool isn = vi != vi;
+                    const bool big = !isn && !(fabsf(vi) < kGemmAbsBound);
+                    need_exact = need_exact || big;
+                    saw_nan = saw_nan || isn;
+                    nanm |= isn ? (1u << i) : 0u;
+                    v[i] = (isn || big) ? 0.f : vi;
+                    tq = fmaf(v[i], v[i], tq);
+                }
+            }
+            qsum += tq;
+            half8 xh, xl;
+            split8(v, xh, xl);
+            if (bad) {
+                u16x8 lb = __builtin_bit_cast(u16x8, xl);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) lb[i] = ((nanm >> i) & 1u) ? kWideNanMark : lb[i];
+                xl = __builtin_bit_cast(half8, lb);
+            }
+            *(lh8 *)(xb + xo0) = xh;
+            *(lh8 *)(xb + xo1) = xl;
+        }
+        tail->qpart[wave][lane] = qsum;
+        need_exact = __any(need_exact);
+        saw_nan = __any(saw_nan);
+        if (lane == 0) {
+            tail->odd[wave] = odd_part;
+            tail->flags[wave] = (need_exact ? 1 : 0) | (saw_nan ? 2 : 0);
+        }
+    }
     // the wave's sum weights (linear softmax rows of its two partitions) into its LDS slice
     {
         const float *wp = a.W0 + (int64_t)rho * 2 * S * I * I;
         for (int e = lane; e < 2 * S * I * I; e += 64) w0_l[e] = wp[e];
     }
     bool model_ok = a.elig[min(lane, NT - 1)] != 0;   // (every repetition's verdict: the root adds one common term)
-    __syncthreads();   // (drains every request above: the x tile is in LDS for everyone)
+    __syncthreads();   // the converted tile and the waves' shares of its bookkeeping are in LDS for everyone
+
+    unsigned long long odd_mask = 0ull;   // K-steps whose constants the validity GEMM accumulates
+    float qtot = 0.f;
+    int tflags = 0;
+#pragma unroll
+    for (int w = 0; w < kWideWaves; ++w) {
+        odd_mask |= tail->odd[w];
+        qtot += tail->qpart[w][lane];
+        tflags |= tail->flags[w];
+    }
+    odd_mask = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(odd_mask >> 32)) << 32) |
+               (unsigned)__builtin_amdgcn_readfirstlane((int)odd_mask);
+    tflags = __builtin_amdgcn_readfirstlane(tflags);
+    qtot += __shfl_xor(qtot, 32, 64);
+    const bool need_exact = (tflags & 1) != 0, saw_nan = (tflags & 2) != 0;
 
     // ---- phase 1: P^T = M^T x^T over the whole K range of the wave's tile --------------------------------------------
     gf32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    float qsum = 0.f;
-    bool need_exact = false, saw_nan = false;
-    unsigned long long odd_mask = 0ull;   // K-steps whose constants the validity GEMM accumulated
-    const int sw = (s >> 2) & 3;
-    const unsigned xo0 = (unsigned)(s * 64 + (((h * 2) ^ sw) << 4)), xo1 = (unsigned)(s * 64 + (((h * 2 + 1) ^ sw) << 4));
-    // (a.ablate: measurement only, DPK_GEMM_ABLATE -- 1 no K loop, 2 no upper layers)
-    for (int k0 = 0; k0 < ((a.ablate & 1) ? 0 : NKS); k0 += PF) {
+    // One K-step of the wave's tile against the fragments in slot k (a constant in every unrolled copy): two LDS reads,
+    // three MFMAs; a flagged K-step (wave-uniform, no memory operation behind the branch) takes its validity operand from
+    // the NaN marks and, in the build for marginalised evidence, multiplies it with the constants in flight.
+    auto kstep = [&](int k, int ks) __attribute__((always_inline)) {
+        const lchar *xb = smem + ks * 2048;
+        const half8 xh = *(const lh8 *)(xb + xo0);
+        half8 xl = *(const lh8 *)(xb + xo1);
+        const bool odd = (odd_mask >> ks) & 1ull;
+        half8 valid;
+        if (odd) {
+            u16x8 lb = __builtin_bit_cast(u16x8, xl);
 #pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const int ks = k0 + k;
-            if (ks < NKS) {   // (wave-uniform)
-                const lchar *xb = smem + ks * 2048;
-                const gf32x4 x0 = *(lf4 *)(xb + xo0), x1 = *(lf4 *)(xb + xo1);
-                float v[8];
-                {
-                    const int f0 = ks * 16 + h * 8;
-                    const bool in0 = f0 + 4 <= D, in1 = f0 + 8 <= D;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        v[i] = in0 ? x0[i] : 0.f;
-                        v[4 + i] = in1 ? x1[i] : 0.f;
-                    }
-                }
-                gf32x2 tq2 = {0.f, 0.f};
-#pragma unroll
-                for (int i = 0; i < 8; i += 2) {
-                    const gf32x2 pv = {v[i], v[i + 1]};
-                    tq2 = __builtin_elementwise_fma(pv, pv, tq2);
-                }
-                float tq = tq2[0] + tq2[1];
-                const bool odd = __any(!(tq < kGemmStepBound));
-                half8 valid;
-                if (odd) {
-                    odd_mask |= 1ull << ks;
-                    tq = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float vi = v[i];
-                        const bool isn = vi != vi;
-                        const bool big = !isn && !(fabsf(vi) < kGemmAbsBound);
-                        need_exact = need_exact || big;
-                        saw_nan = saw_nan || isn;
-                        v[i] = (isn || big) ? 0.f : vi;
-                        valid[i] = isn ? (_Float16)0.0f : (_Float16)1.0f;
-                        tq = fmaf(v[i], v[i], tq);
-                    }
-                }
-                qsum += tq;
-                half8 xh, xl;
-                split8(v, xh, xl);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[k], xh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[k], xl, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[k], xh, acc, 0, 0, 0);
-                if (odd) {
-                    half8 c0, c1;
-                    if constexpr (MARG) {
-                        c0 = ch[k];
-                        c1 = cl[k];
-                    } else {
-                        const int64_t o = (int64_t)ks * NT * 2048;
-                        c0 = *(gh8 *)(cbase + o);
-                        c1 = *(gh8 *)(cbase + o + 1024);
-                    }
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(c0, valid, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1, valid, acc, 0, 0, 0);
-                }
-                load_frags(k, ks + PF);   // (the slot is free again: the fragments PF K-steps ahead)
+            for (int i = 0; i < 8; ++i) {
+                const bool isn = lb[i] == kWideNanMark;
+                valid[i] = isn ? (_Float16)0.0f : (_Float16)1.0f;
+                lb[i] = isn ? (unsigned short)0 : lb[i];
+            }
+            xl = __builtin_bit_cast(half8, lb);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[k], xh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[k], xl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[k], xh, acc, 0, 0, 0);
+        if constexpr (MARG) {
+            if (odd) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch[k], valid, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl[k], valid, acc, 0, 0, 0);
             }
         }
+    };
+    // (a.ablate: measurement only, DPK_GEMM_ABLATE -- 1 no K loop, 2 no upper layers)
+    // Whole groups of PF K-steps first: straight-line code, the fragment loads unconditional (a load behind a branch makes
+    // hipcc wait for ALL outstanding loads at the join).  The row's last K-steps after them, without prefetch.
+    int k0 = 0;
+    if (!(a.ablate & 1)) {
+        for (; k0 + PF <= NKS; k0 += PF) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                kstep(k, k0 + k);
+                load_frags(k, k0 + k + PF);   // (the slot is free again: the fragments PF K-steps ahead)
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PF - 1; ++k)
+            if (k0 + k < NKS) kstep(k, k0 + k);   // (wave-uniform)
     }
-    const float qtot = qsum + __shfl_xor(qsum, 32, 64);
+    if constexpr (!MARG) {
+        // Flagged K-steps of the clean build: their validity GEMM, from the tile still in LDS (out of the loop above: its
+        // constants are loaded on demand).
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (!((odd_mask >> ks) & 1ull)) continue;   // (wave-uniform)
+            const u16x8 lb = __builtin_bit_cast(u16x8, *(const lh8 *)(smem + ks * 2048 + xo1));
+            half8 valid;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) valid[i] = (lb[i] == kWideNanMark) ? (_Float16)0.0f : (_Float16)1.0f;
+            const int64_t o = (int64_t)ks * NT * 2048;
+            const half8 c0 = *(gh8 *)(cbase + o), c1 = *(gh8 *)(cbase + o + 1024);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(c0, valid, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1, valid, acc, 0, 0, 0);
+        }
+    }
     // the expanded square is within the 1e-5 bar while sum x^2 <= 36 D (|mu| <= 6: DESIGN 3.3)
     const bool lane_exact = need_exact || !(qtot <= kExpandBound * kExpandBound * (float)D);
     model_ok = __all(model_ok);
@@ -687,7 +777,7 @@ bool gemm_wide_shape_ok(int D, int reps, int I, int S, int C) {
     const int NKS = cdiv(D, 16);
     if (NKS > 64) return false;   // K-step bit mask
     // LDS: the x tile + the waves' sum weights; afterwards scratch (32 KB) + the root exchange buffer in its place
-    const size_t p1 = (size_t)NKS * 2048 + (size_t)kWideWaves * 2 * S * kWideI * kWideI * 4;
+    const size_t p1 = (size_t)NKS * 2048 + (size_t)kWideWaves * 2 * S * kWideI * kWideI * 4 + sizeof(WideTail);
     const size_t p2 = (size_t)kWideWaves * 64 * 2 * kWideI * 4 + ((size_t)reps * 32 * C * 2 + 32) * 4 + kWideWaves * 8 + 64;
     return p1 <= 160 * 1024 && p2 <= (size_t)NKS * 2048;
 }
@@ -695,7 +785,7 @@ bool gemm_wide_shape_ok(int D, int reps, int I, int S, int C) {
 template <int S, bool MARG>
 static int gemm_wide_launch(const GemmArgs &a, hipStream_t st) {
     const int NKS = cdiv(a.D, 16);
-    const size_t lds = (size_t)NKS * 2048 + (size_t)kWideWaves * 2 * S * kWideI * kWideI * 4;
+    const size_t lds = (size_t)NKS * 2048 + (size_t)kWideWaves * 2 * S * kWideI * kWideI * 4 + sizeof(WideTail);
     auto kern = ratspn_gemm_wide_kernel<S, MARG>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024)) return rc;
     hipEvent_t ev0, ev1;

@@ -268,20 +268,28 @@ __global__ __launch_bounds__(256) void root_wide_kernel(const float *__restrict_
 // o inside the thread and glw a sum over the samples of the tile, flushed with one atomic per
 // (tile, column, o).
 // ------------------------------------------------------------------------------------
-constexpr int kBwdTile = 32;   // samples per block in the sum backward
+constexpr int kBwdTile = 32;   // samples per block in the sum backward (16 / 8 while the grid would not cover the chip)
 constexpr int kBwdOB = 16;     // outputs held in registers at a time
+constexpr int kBwdWaves = 4;
 
-__global__ __launch_bounds__(256) void sum_bwd_kernel(const float *__restrict__ x,
-                                                     const float *__restrict__ LW,
-                                                     const float *__restrict__ out,
-                                                     const float *__restrict__ g, int64_t B, int P, int N,
-                                                     int S, float *__restrict__ gx,
-                                                     float *__restrict__ glw) {
-    const int col = blockIdx.y * blockDim.x + threadIdx.x;  // (p, n) flattened
-    if (col >= P * N) return;
-    const int p = col / N, n = col - p * N;
-    const int64_t b0 = (int64_t)blockIdx.x * kBwdTile;
-    const int64_t b1 = min(b0 + kBwdTile, B);
+// block = (sample tile, 64 columns): its four waves take a quarter of the tile's samples each (a training batch of 512
+// is 16 tiles: one wave per CU walking 32 samples in a chain of dependent loads was 55 us for the (8,8) sum layer) and
+// meet in LDS before the one atomic per (tile, column, output).
+__global__ __launch_bounds__(64 * kBwdWaves) void sum_bwd_kernel(const float *__restrict__ x,
+                                                                const float *__restrict__ LW,
+                                                                const float *__restrict__ out,
+                                                                const float *__restrict__ g, int64_t B, int P, int N,
+                                                                int S, float *__restrict__ gx,
+                                                                float *__restrict__ glw, int tile) {
+    __shared__ float red[kBwdWaves][kBwdOB][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.y * 64 + lane;  // (p, n) flattened
+    const bool live = col < P * N;
+    const int cc = live ? col : P * N - 1;
+    const int p = cc / N, n = cc - p * N;
+    const int per = tile / kBwdWaves;
+    const int64_t b0 = (int64_t)blockIdx.x * tile + wave * per;
+    const int64_t b1 = min(b0 + per, B);
     // samples outer, outputs inner: x and gx are touched once per sample, the per-output weights and the
     // batch sums of glw stay in registers (kBwdOB outputs at a time)
     for (int ob = 0; ob < S; ob += kBwdOB) {
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(256) void sum_bwd_kernel(const float *__restrict__ 
             acc[q] = 0.f;
         }
         for (int64_t b = b0; b < b1; ++b) {
-            const float xv = x[b * P * N + col];
+            const float xv = x[b * P * N + cc];
             const float *op = out + (b * P + p) * S + ob, *gp = g + (b * P + p) * S + ob;
             float tot = 0.f;
 #pragma unroll
@@ -306,15 +314,21 @@ __global__ __launch_bounds__(256) void sum_bwd_kernel(const float *__restrict__ 
                     tot += t;
                 }
             }
-            if (gx != nullptr) {
+            if (gx != nullptr && live) {
                 float *dst = gx + b * P * N + col;
                 *dst = (ob == 0) ? tot : (*dst + tot);
             }
         }
         if (glw != nullptr) {
 #pragma unroll
-            for (int q = 0; q < kBwdOB; ++q)
-                if (ob + q < S) atomicAdd(glw + ((int64_t)p * S + ob + q) * N + n, acc[q]);
+            for (int q = 0; q < kBwdOB; ++q) red[wave][q][lane] = acc[q];
+            __syncthreads();
+            // wave w flushes the outputs q = w, w + 4, ...
+            for (int q = wave; q < kBwdOB && ob + q < S; q += kBwdWaves) {
+                const float t = (red[0][q][lane] + red[1][q][lane]) + (red[2][q][lane] + red[3][q][lane]);
+                if (live) atomicAdd(glw + ((int64_t)p * S + ob + q) * N + n, t);
+            }
+            __syncthreads();
         }
     }
 }
@@ -385,6 +399,86 @@ __global__ __launch_bounds__(256) void leaf_bwd_param_kernel(
             for (int k = 0; k < CBK; ++k) {
                 // training-mode input dropout: the same (seed, element) decision as the forward kernel
                 if (drop_p > 0.f && dropout_hit(seed, (((uint64_t)b * R + r) * I + kb + k) * d + j, drop_p)) continue;
+                const float gv = live ? gp[k] : 0.f;
+                if (DIST == 0) {
+                    const float dl = xv - c0[k];
+                    a0[k] = fmaf(gv, dl * c1[k], a0[k]);
+                    a1[k] = fmaf(gv, dl * dl * c1[k] * c2[k] - c2[k], a1[k]);
+                } else {
+                    a0[k] = fmaf(gv, xv - c0[k], a0[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CBK; ++k) {
+            const int64_t po = ((int64_t)r * I + kb + k) * d + j;
+            if (gp0) atomicAdd(gp0 + po, a0[k]);
+            if (DIST == 0 && gp1) atomicAdd(gp1 + po, a1[k]);
+        }
+    }
+}
+
+// The same for small batches (16-sample tiles so that the grid covers the chip), with the tile's rows of x and of the
+// upstream gradient staged in LDS first: a thread's x[b, f] is a gather along the row (f follows the region graph's
+// permutation) and g[b, r, k] depends on the entry's region -- from global memory those were 5 uncoalesced loads per entry
+// and sample, 53 us of the (8,8) training step at B = 512; staged, the rows arrive coalesced once per block and the
+// gathers are LDS reads.
+template <int DIST, int CBK>
+__global__ __launch_bounds__(256) void leaf_bwd_param_lds_kernel(
+    const float *__restrict__ x, const float *__restrict__ g, int64_t B, int D, int R, int I, int d, int SP,
+    const int *__restrict__ feat, const int *__restrict__ srcr, const float *__restrict__ p0,
+    const float *__restrict__ p1, float *__restrict__ gp0, float *__restrict__ gp1, int tile) {
+    extern __shared__ float leaf_bwd_sm[];
+    float *xs = leaf_bwd_sm, *gs = leaf_bwd_sm + (size_t)tile * D;   // xs[tile][D], gs[tile][R][CBK]
+    const int grp = blockIdx.y;
+    const int kb = blockIdx.z * CBK;
+    const int64_t b0 = (int64_t)blockIdx.x * tile;
+    const int nb = (int)(min(b0 + tile, B) - b0);
+    {
+        const float *xsrc = x + b0 * D;
+        const int tot = nb * D;
+        if ((D & 3) == 0) {
+            for (int i = threadIdx.x * 4; i < tot; i += blockDim.x * 4)
+                *reinterpret_cast<float4 *>(xs + i) = *reinterpret_cast<const float4 *>(xsrc + i);
+        } else {
+            for (int i = threadIdx.x; i < tot; i += blockDim.x) xs[i] = xsrc[i];
+        }
+        const int gt = nb * R * CBK;
+        for (int i = threadIdx.x; i < gt; i += blockDim.x) {
+            const int bl = i / (R * CBK), rem = i - bl * (R * CBK);
+            const int r = rem / CBK, k = rem - r * CBK;
+            gs[i] = g[((b0 + bl) * R + r) * I + kb + k];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < SP; e += blockDim.x) {
+        const int rj = srcr[(int64_t)grp * SP + e];
+        if (rj < 0) continue;
+        const int r = rj / d, j = rj - r * d;
+        const int f = feat[(int64_t)grp * SP + e];
+        float c0[CBK], c1[CBK], c2[CBK], a0[CBK], a1[CBK];
+#pragma unroll
+        for (int k = 0; k < CBK; ++k) {
+            const int64_t po = ((int64_t)r * I + kb + k) * d + j;
+            a0[k] = a1[k] = 0.f;
+            if (DIST == 0) {
+                const float sg = p1[po];
+                c0[k] = p0[po];           // mu
+                c1[k] = 1.f / (sg * sg);  // 1/s^2
+                c2[k] = 1.f / sg;
+            } else {
+                c0[k] = 1.f / (1.f + expf(-p0[po]));  // sigmoid(logit)
+                c1[k] = c2[k] = 0.f;
+            }
+        }
+#pragma unroll 4
+        for (int bl = 0; bl < nb; ++bl) {
+            const float xr = xs[bl * D + f];
+            const bool live = (xr == xr);   // marginalised: no contribution
+            const float xv = live ? xr : 0.f;
+            const float *gp = gs + (bl * R + r) * CBK;
+#pragma unroll
+            for (int k = 0; k < CBK; ++k) {
                 const float gv = live ? gp[k] : 0.f;
                 if (DIST == 0) {
                     const float dl = xv - c0[k];
@@ -528,8 +622,10 @@ static int sum_backward_impl(const float *in, const float *weight, const float *
     }
     if (B > 0) {
         const int cols = P * N;
-        DPK_LAUNCH(sum_bwd_kernel, dim3(cdiv(B, kBwdTile), cdiv(cols, 256)), dim3(256), 0, st, in, LW,
-                           out, g, B, P, N, S, grad_in, grad_weight ? glw : nullptr);
+        int tile = kBwdTile;   // (shorter sample slices while the grid would leave compute units idle)
+        while (tile > 8 && cdiv(B, tile) * cdiv(cols, 64) < 2 * device_cus()) tile /= 2;
+        DPK_LAUNCH(sum_bwd_kernel, dim3(cdiv(B, tile), cdiv(cols, 64)), dim3(64 * kBwdWaves), 0, st, in, LW,
+                           out, g, B, P, N, S, grad_in, grad_weight ? glw : nullptr, tile);
     } else if (grad_in) {
         // nothing to write
     }
@@ -591,9 +687,19 @@ static int leaf_backward_common(int dist, const float *x, const float *g, int64_
         // small batches: shorter sample slices so that the grid still covers the chip (more atomics per parameter)
         const int tile = (B > 1024) ? kLeafBwdTile : 16;
         const dim3 grid(cdiv(B, tile), w.G, I / cbk), block(256);
+        // (no dropout, rows 16-byte aligned, the tile's rows within 64 KB of LDS: the staged kernel)
+        const size_t stage_bytes = (size_t)tile * ((size_t)D + (size_t)R * cbk) * 4;
+        const bool staged = tile == 16 && drop_p == 0.f && stage_bytes <= 64 * 1024 &&
+                            ((D & 3) != 0 || (reinterpret_cast<uintptr_t>(x) & 15) == 0);
 #define DPK_LEAF_BWD(DIST, CBK)                                                                                  \
-    DPK_LAUNCH((leaf_bwd_param_kernel<DIST, CBK>), grid, block, 0, st, x, g, B, D, R, I, d, w.SP, w.feat, \
-                       w.srcr, p0, p1, gp0, gp1, drop_p, seed, tile)
+    do {                                                                                                         \
+        if (staged)                                                                                              \
+            DPK_LAUNCH((leaf_bwd_param_lds_kernel<DIST, CBK>), grid, block, stage_bytes, st, x, g, B, D, R, I, d, \
+                       w.SP, w.feat, w.srcr, p0, p1, gp0, gp1, tile);                                            \
+        else                                                                                                     \
+            DPK_LAUNCH((leaf_bwd_param_kernel<DIST, CBK>), grid, block, 0, st, x, g, B, D, R, I, d, w.SP, w.feat, \
+                       w.srcr, p0, p1, gp0, gp1, drop_p, seed, tile);                                            \
+    } while (0)
         if (dist == 0) {
             if (cbk == 4) DPK_LEAF_BWD(0, 4);
             else if (cbk == 2) DPK_LEAF_BWD(0, 2);

@@ -351,7 +351,8 @@ def test_fused_plan_is_the_same_call(golden):
 
 @pytest.mark.parametrize('name', ['ratspn_g784_d2_r8_i2_s2', 'ratspn_g784_d2_r8_i4_s2', 'ratspn_g784_d2_r8_i8_s8',
                                   'ratspn_g784_d2_r8_i16_s16'])
-@pytest.mark.parametrize('case', ['means_beyond_bound', 'outlier_evidence', 'offset_data', 'at_the_bound'])
+@pytest.mark.parametrize('case', ['means_beyond_bound', 'one_repetition_beyond_bound', 'outlier_evidence', 'offset_data',
+                                  'at_the_bound'])
 def test_expanded_square_guard(golden, case, name, mapping):
     """The unit-scale fused kernel evaluates sum (x-mu)^2 as sum x^2 - 2 sum x mu + sum mu^2 only while |x| and
     |mu| stay <= 6; outside it must take the direct / exact forms.  Every regime is held to the same
@@ -361,6 +362,9 @@ def test_expanded_square_guard(golden, case, name, mapping):
     with torch.no_grad():
         if case == 'means_beyond_bound':
             model.base_layer.loc.mul_(4.0)           # N(0,1) * 4: many |mu| > 6 -> direct form for the model
+        elif case == 'one_repetition_beyond_bound':
+            model.base_layer.loc[4:8].mul_(4.0)      # the regions of repetition 1 only: the verdict is the MODEL's (the
+                                                     # root adds one common -1/2 sum x^2 term for every repetition)
         elif case == 'outlier_evidence':
             x[3, 100] = 50.0                         # one value beyond the bound: its tile leaves the fast path
             x[20] = 7.5

@@ -24,7 +24,7 @@ else:
     x = torch.randn(B, 784)
 model = model.cuda().train()
 x = x.cuda()
-opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
 
 
 def step():

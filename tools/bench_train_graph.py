@@ -20,7 +20,7 @@ else:
     model, x = RealNVP1d(784), torch.randn(B, 784)
 model = model.cuda().train()
 static_x = x.cuda()
-opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True, fused=True)
 
 
 def step():
