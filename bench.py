@@ -359,6 +359,30 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
             ms_trust = _time_eval_graph(m, xs)
         finally:
             _hip.trust_version_counters(prev)
+        wide_entry = None
+        if (I, S) == (8, 8):
+            # the same model at the headline batch size: the 128-sample ring mapping of the 8-channel kernel (timed before
+            # the CPU baseline below: its 32 worker threads keep spinning for a while and slow an eager launch loop)
+            Bl = 65536
+            xl = [torch.randn(Bl, D, device=dev) for _ in range(4)]
+            msl_e, kl_ms = _time_eval(m, xl, timer, kid, steps=20)
+            msl_g = _time_eval_graph(m, xl)
+            msl = msl_g if msl_g is not None else msl_e
+            roofl = hbm(Bl * alg, msl)
+            roofl['traffic'], roofl['traffic_source'] = read_traffic('wide_65536')
+            wide_entry = ({'workload': 'the same (8,8) model at the headline batch size (128-sample tiles: x through an LDS-DMA '
+                                    'ring, converted to f16 pairs once per tile by the loader waves)',
+                        'config': 'headline size, rg_batch = rg_sum = 8', 'batch': Bl, 'ms_per_step': msl,
+                        'value': Bl / msl * 1e3, 'unit': 'log-likelihoods/sec', 'ms_per_step_eager': msl_e,
+                        'kernel_ms': kl_ms, 'kernel': 'ratspn_gemm_wide_ring_kernel', 'roofline': roofl,
+                        'roofline_basis': 'whole step; 3140 algorithmic B/sample (the kernel is bound by its MFMA + node '
+                                          'evaluation phases, not by HBM: DESIGN 3.10)',
+                        'mfma': (lambda a: {'bound': 'mfma', 'achieved': a, 'peak': 2500.0, 'unit': 'TFLOP/s',
+                                            'frac': a / 2500.0,
+                                            'basis': 'executed f16 MFMA flops: 3 products x 2 x 784 x 256 outputs per '
+                                                     'sample, over the kernel time'})(
+                            Bl * 2.0 * 3 * 784 * 256 / ((kl_ms if kl_ms else msl) * 1e-3) / 1e12)})
+            del xl
         n_cpu = 4096 if I <= 8 else 1024
         xc = torch.randn(n_cpu, D)
         rate, dt = _oracle_rate(lambda a, b: orc.ratspn_forward(sd, xc[a:b]), n_cpu, 1024 if I > 8 else 4096, threads)
@@ -383,28 +407,8 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
              'cpu_baseline': {'value': rate, 'unit': 'log-likelihoods/sec', 'cores': threads, 'kind': 'port',
                               'sample': '{} samples ({:.1f} s), oracle/ratspn_oracle.py'.format(n_cpu, dt)}}
         out.append(e)
-        if (I, S) == (8, 8):
-            # the same model at the headline batch size: the 128-sample ring mapping of the 8-channel kernel
-            Bl = 65536
-            xl = [torch.randn(Bl, D, device=dev) for _ in range(4)]
-            msl_e, kl_ms = _time_eval(m, xl, timer, kid, steps=20)
-            msl_g = _time_eval_graph(m, xl)
-            msl = msl_g if msl_g is not None else msl_e
-            roofl = hbm(Bl * alg, msl)
-            roofl['traffic'], roofl['traffic_source'] = read_traffic('wide_65536')
-            out.append({'workload': 'the same (8,8) model at the headline batch size (128-sample tiles: x through an LDS-DMA '
-                                    'ring, converted to f16 pairs once per tile by the loader waves)',
-                        'config': 'headline size, rg_batch = rg_sum = 8', 'batch': Bl, 'ms_per_step': msl,
-                        'value': Bl / msl * 1e3, 'unit': 'log-likelihoods/sec', 'ms_per_step_eager': msl_e,
-                        'kernel_ms': kl_ms, 'kernel': 'ratspn_gemm_wide_ring_kernel', 'roofline': roofl,
-                        'roofline_basis': 'whole step; 3140 algorithmic B/sample (the kernel is bound by its MFMA + node '
-                                          'evaluation phases, not by HBM: DESIGN 3.10)',
-                        'mfma': (lambda a: {'bound': 'mfma', 'achieved': a, 'peak': 2500.0, 'unit': 'TFLOP/s',
-                                            'frac': a / 2500.0,
-                                            'basis': 'executed f16 MFMA flops: 3 products x 2 x 784 x 256 outputs per '
-                                                     'sample, over the kernel time'})(
-                            Bl * 2.0 * 3 * 784 * 256 / ((kl_ms if kl_ms else msl) * 1e-3) / 1e12)})
-            del xl
+        if wide_entry is not None:
+            out.append(wide_entry)
         if (I, S) == (2, 2):
             # the marginalisation path (nan_to_num_ at ratspn.py:103): 30 % of the entries NaN, at B = 4096 and 65536
             for Bn in (4096, 65536):

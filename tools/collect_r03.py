@@ -18,6 +18,8 @@ WORKLOADS = {   # name -> command (relative to the repo root)
     'headline': ['python', 'bench.py', '--cpu-samples', '0', '--no-secondary'],
     'config2': ['python', 'tools/bench_small.py', '--wide', '4096'],
     'marginal': ['python', 'tools/bench_small.py', '65536'],
+    'wide': ['python', 'tools/bench_wide_small.py', '4096', '65536'],
+    'train': ['python', 'tools/bench_train.py', 'ratspn', '512'],
     'config4': ['python', 'tools/bench_dgc.py'],
     'config5': ['python', 'tools/bench_flows.py'],
 }
@@ -79,12 +81,15 @@ if what in ('all', 'pmc'):
     # (kernel-name filter, grid filter or None, key in pmc_traffic.json, launches per step or None = per launch)
     want = {
         'headline': [('ratspn_gemm_kernel', None, 'headline')],
-        'config2': [('ratspn_gemm_small_kernel', None, 'config2_2_2'), ('ratspn_leaf_gemm_kernel', None, 'config2_8_8_leaf')],
+        'config2': [('ratspn_gemm_small_kernel', None, 'config2_2_2')],
+        'wide': [('ratspn_gemm_wide_ring_kernel', None, 'wide_65536'), ('ratspn_gemm_wide_kernel<8, false>', None, 'config2_8_8')],
         'marginal': [('ratspn_gemm_marginal_kernel', None, 'marginal_65536')],
         'config5': [('coupling_x3_kernel<true, 4, false>', None, 'config5')],
         'config4': [('', None, 'config4')],
     }
     for name, cmd in WORKLOADS.items():
+        if name == 'train':
+            continue
         fetch, write = pmc(name, cmd, 'FETCH_SIZE'), pmc(name, cmd, 'WRITE_SIZE')
         report.append('== %s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs) -- %s' % (name, ' '.join(cmd)))
         report.append('%-64s %7s %7s %14s %14s' % ('kernel', 'blocks', 'calls', 'FETCH_SIZE KB', 'WRITE_SIZE KB'))
