@@ -290,6 +290,39 @@ def test_wide_channel_blocks_above_the_tile_switch(kw):
     assert rel_err(small.cpu().numpy(), want) <= LL_TOL
 
 
+@pytest.mark.parametrize('kw,D', [(dict(rg_repetitions=3, rg_sum=4, out_classes=5), 52),
+                                  (dict(rg_repetitions=8, rg_sum=2), 784),
+                                  (dict(rg_repetitions=5, rg_sum=8, out_classes=3, rg_depth=1), 200)])
+def test_eight_channel_ring_kernel_shapes(kw, D):
+    """The 128-sample mapping of the 8-channel kernel (batches above 16384; csrc/ratspn_gemm_wide.hip): fewer repetitions
+    than waves, several classes, 2 / 4 / 8 sum nodes, feature counts that end inside a 64-feature chunk, a ragged last
+    tile, clean rows next to rows with NaN / inf / far-tail evidence -- against the oracle on a scattered subset, and
+    against the 32-sample mapping on the same rows."""
+    from deeprob.spn.models import GaussianRatSpn
+    torch.manual_seed(11)
+    base = dict(in_features=D, rg_depth=2, rg_batch=8, random_state=5)
+    base.update(kw)
+    model = GaussianRatSpn(**base).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    B = 16384 + 128 + 77
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randn(B, D, generator=gen)
+    x[7, ::3] = float('nan')
+    x[130] = float('nan')
+    x[4097, 5] = float('-inf')
+    x[B - 1, 11] = 35.0
+    x[B - 40, :] *= 9.0                                   # sum x^2 beyond the expanded-square bound for the row
+    rows = torch.cat([torch.tensor([7, 130, 4097, B - 1, B - 40, B - 77, B - 78, 128, 127]),
+                      torch.randint(0, B, (200,), generator=gen)])
+    want = orc.ratspn_forward(sd, x[rows]).numpy()
+    model = model.cuda()
+    with torch.no_grad():
+        big = model(x.cuda())
+        small = model(x[rows].cuda())
+    assert rel_err(big[rows.cuda()].cpu().numpy(), want) <= LL_TOL
+    assert rel_err(small.cpu().numpy(), want) <= LL_TOL
+
+
 def test_marginalised_inputs_on_both_kernel_builds(mapping):
     """The two-channel unit-scale kernel exists in two builds (tiles with NaN / inf / out-of-bound evidence leave the
     LDS record pipeline, or stay on it in the exact per-entry form); a launch takes the second one while a recent
