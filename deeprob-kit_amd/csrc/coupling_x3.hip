@@ -264,6 +264,7 @@ struct X3Args {
     const uint16_t *w1t;
     const char *w2t;
     const float *b1f, *act_weight, *scales;
+    const float *in_scale, *in_shift;   // the folded input affine per raw column (x-once kernel; null: identity)
     // BASE mode (last coupling of a flow + the affine behind it + the Normal base, dpk_coupling1d_pairs_logprob): the
     // per-column (a_d, c_d) pairs with -t^2 = -(u' - loc)^2 / (2 sigma^2), t = a_d u_d + c_d, their constant, the
     // log-det accumulated so far and the log-likelihoods written instead of `out`
@@ -624,6 +625,594 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void coupling_x3_kernel(const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// round 3: the same layer with x read ONCE (coupling_x1_kernel)
+// ------------------------------------------------------------------------------------------------
+// coupling_x3_kernel reads every row twice (phase 1 through the ring, phase 2 as column pairs from global memory) and runs
+// its MFMAs and its epilogue in series on the same four waves while the four loader waves idle.  This kernel keeps the
+// tables and the fragment mapping and changes the roles:
+//  * a work-group owns 64 samples.  Four HOLDER waves copy every landed x chunk from the ring into registers, input
+//    affine applied (a lane keeps 16 raw columns of one sample per chunk: 13 chunks x 16 = 208 VGPRs hold the 64 x 832
+//    tile between them -- the one place on the CU with room for it: 200 KB against 160 KB of LDS), and run the whole
+//    epilogue in phase 2 from those registers: no second read of x.
+//  * four MFMA waves = (sample block of 32) x (role 0 / 1).  In phase 1 a role computes every other 32-unit block of the
+//    hidden layer; the two roles of a sample block swap their B fragments through LDS once per tile.  In phase 2 role 0
+//    runs the t rows and role 1 the s rows of GEMM 2 and hands z = acc / scale + bias to the holders through a
+//    double-buffered 18 KB LDS slab; the holders work on variable tile p - 1 while the MFMA waves run tile p.
+//    One s_barrier per chunk, as before, plus one per tile behind the fragment swap.
+//  * the ring's LDS-DMA is issued by whoever has the time: by the holders during phase-1 steps (they only copy 256 bytes
+//    per lane there), by the MFMA waves during phase-2 steps (they have no other vector-memory traffic, and the holders'
+//    stores would spoil a counted wait).  A chunk's issuer waits for it (counted vmcnt) before the chunk's barrier.
+constexpr int kX1Tile = 64;
+constexpr int kX1XB = kX1Tile * 256;    // x chunk: 64 raw columns of 64 rows
+constexpr int kX1ZRow = 36 * 4;         // bytes per sample row of a z slab (32 variables + 16 bytes: conflict-free b128 writes)
+constexpr int kX1ZSlab = kX1Tile * kX1ZRow;
+constexpr int kX1SwapWave = 8192;       // fragment-swap bytes per MFMA wave (<= 2 blocks x 2 K-steps x (hi, lo) KiB)
+
+template <int NU>
+struct X1Cfg {
+    static constexpr int W1CH = 2 * NU * 2 * 1024;
+    static constexpr int KK = NU * 2;
+    static constexpr int W2CH = ((KK * 4 * 1024 + 1024 + 4095) / 4096) * 4096;
+    static constexpr int STAGE = (kX1XB + W1CH) > W2CH ? (kX1XB + W1CH) : W2CH;
+    static constexpr int P1 = 4 + W1CH / (4 * 1024);   // DMA instructions per issuing wave: phase-1 chunk
+    static constexpr int P2 = W2CH / (4 * 1024);       //                                    phase-2 chunk
+    static_assert(W1CH % 4096 == 0 && P1 <= 63 && P2 <= 63, "chunk split");
+};
+
+// N (<= 4) consecutive 1-KiB pieces of a table with ONE M0 setting: the instruction offset advances the global and the
+// LDS address alike (glds16 per piece costs five scalar instructions around every load; a wave issues one instruction per
+// four cycles, and the issuing waves have none to spare).
+template <int N>
+__device__ __forceinline__ void x1_glds_run(unsigned voff, gcchar_p sbase_in, unsigned lds_dst_in) {
+    static_assert(N >= 1 && N <= 4, "instruction offset field");
+    const uint64_t sb = (uint64_t)(uintptr_t)sbase_in;
+    const uint64_t sbase = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sb >> 32)) << 32) |
+                           (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sb);
+    const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst_in);
+    unsigned keep;
+    if constexpr (N == 1)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    else if constexpr (N == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    else if constexpr (N == 3)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:3072\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void x1_glds_table(unsigned voff, gcchar_p sbase, unsigned lds_dst) {
+    if constexpr (N >= 4) {
+        x1_glds_run<4>(voff, sbase, lds_dst);
+        if constexpr (N > 4) x1_glds_table<N - 4>(voff, sbase + 4096, lds_dst + 4096);
+    } else if constexpr (N >= 1) {
+        x1_glds_run<N>(voff, sbase, lds_dst);
+    }
+}
+
+// Issue this wave's quarter of chunk (tile, c) into ring stage `stage` (wave = 0..3 within its group of four).
+template <int NU>
+__device__ __forceinline__ void x1_issue(const X3Args &a, int tile, int c, int stage, int wave, int lane, unsigned smem_base,
+                                         const unsigned (&voff)[4]) {
+    typedef X1Cfg<NU> C;
+    const int D = a.D, NCH1 = a.g.NCH1;
+    const unsigned st = smem_base + stage * C::STAGE;
+    if (c < NCH1) {
+        const int64_t b0 = (int64_t)tile * kX1Tile;
+        const gcchar_p xt = (gcchar_p)a.x + (b0 * D + c * 64) * 4;
+        const bool full = (b0 + kX1Tile <= a.B) && ((c + 1) * 64 <= D);
+        if (full) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) glds16(voff[j], xt, st + (wave * 16 + j * 4) * 256);
+        } else {   // ragged tile / last chunk: clamp to rows and pieces that exist (clamped slots are never consumed)
+            const int nvalid = (int)min((int64_t)kX1Tile, a.B - b0);
+            const int vp = min(16, (D - c * 64) >> 2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = wave * 16 + j * 4 + (lane >> 4);
+                const int gp = min((lane & 15) ^ (r & 15), vp - 1);
+                glds16((unsigned)(min(r, nvalid - 1) * D + gp * 4) * 4u, xt, st + (wave * 16 + j * 4) * 256);
+            }
+        }
+        const gcchar_p tsrc = (gcchar_p)a.w1t + (int64_t)c * C::W1CH;
+        const unsigned t0 = (unsigned)(wave * (C::W1CH / 4));
+        x1_glds_table<C::W1CH / 4096>(t0 + lane * 16, tsrc, st + kX1XB + t0);
+    } else {
+        const gcchar_p tsrc = (gcchar_p)a.w2t + (int64_t)(c - NCH1) * C::W2CH;
+        const unsigned t0 = (unsigned)(wave * (C::W2CH / 4));
+        x1_glds_table<C::P2>(t0 + lane * 16, tsrc, st + t0);
+    }
+}
+
+// s_waitcnt vmcnt(n) for the three counts a ring wait can need (0 = nothing younger in flight)
+template <int NU>
+__device__ __forceinline__ void x1_wait(int kind) {   // kind: 0 -> 0, 1 -> P1, 2 -> P2
+    typedef X1Cfg<NU> C;
+    if (kind == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (kind == 1) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::P1) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::P2) : "memory");
+    }
+}
+
+// max over the two lanes (l, l + 32) that share a sample, as a vector-ALU operation (v_permlane32_swap, gfx950):
+// __shfl_xor(v, 32) is an LDS round trip in the middle of the K loop's dependency chain
+__device__ __forceinline__ float x1_pair_max(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+// ---- holder / epilogue waves ------------------------------------------------------------------------------------------
+// One epilogue step: NP pieces of four raw columns (two variables each) of one row.  xk: the kept pieces (input affine
+// applied), zb: the lane's z values (t; s one slab further), col0: the first raw column.  Pairs of variables go through
+// the packed fp32 instructions; PM (the parity of the masked columns) is a template parameter: as a run-time value every
+// element select became a chain of v_cndmask (310 instructions per step).
+template <bool AFFINE, bool BASE, int PM, bool INV, int NP>
+__device__ __forceinline__ void x1_epilogue(const gf32x4 *xk, const lchar *zb, float act, const lfloat *base_l, int D, int col0,
+                                            bool row_ok, float *orow, float &ssum, float &bacc) {
+    typedef __attribute__((address_space(3))) const gf32x4 lf4;
+    typedef __attribute__((address_space(3))) const gf32x2 lf2;
+    const float c2 = (INV ? act : -act) * 1.4426950408889634f;
+    gf32x2 ssum2 = {0.f, 0.f};
+    // (every z value requested before the first is used: one LDS round trip per step, not one per piece)
+    gf32x2 tz[NP], sz[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        tz[k] = *(lf2 *)(zb + k * 8);
+        sz[k] = tz[k];
+        if (AFFINE) sz[k] = *(lf2 *)(zb + kX1ZSlab + k * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        gf32x4 y = xk[k];
+        // elements 2 i + (1 - PM) are transformed
+        const gf32x2 xv = {y[1 - PM], y[3 - PM]};
+        const gf32x2 tv = tz[k];
+        gf32x2 ov;
+        if (AFFINE) {
+            const gf32x2 zz = sz[k];
+            // tanh(v) = (e^{2v} - 1) / (e^{2v} + 1) on the hardware exp2 / rcp (absolute error ~1e-7, as x3_tanh)
+            gf32x2 e;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float c = fminf(fmaxf(zz[i], -15.f), 15.f);
+                e[i] = __builtin_amdgcn_exp2f(c * 2.8853900817779268f);
+            }
+            const gf32x2 ep = e + 1.f;
+            gf32x2 r;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) r[i] = __builtin_amdgcn_rcpf(ep[i]);
+            const gf32x2 th = (e - 1.f) * r;
+            ssum2 += th;                              // (x act at the end; D % 16 == 0: the variables exist)
+            const gf32x2 ea = th * c2;
+            gf32x2 es;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) es[i] = __builtin_amdgcn_exp2f(ea[i]);
+            ov = INV ? xv * es + tv : (xv - tv) * es;
+        } else {
+            ov = INV ? xv + tv : xv - tv;
+        }
+        y[1 - PM] = ov[0];
+        y[3 - PM] = ov[1];
+        if (BASE) {
+            const gf32x4 ba = *(lf4 *)(base_l + col0 + 4 * k), bc = *(lf4 *)(base_l + D + col0 + 4 * k);
+            const gf32x4 t = y * ba + bc;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bacc = fmaf(-t[i], t[i], bacc);
+        } else if (row_ok) {
+            *reinterpret_cast<gf32x4 *>(orow + col0 + 4 * k) = y;
+        }
+        if (BASE && NP > 1 && (k & 1)) __builtin_amdgcn_sched_barrier(0);   // (register pressure: eight columns at a time)
+    }
+    if (AFFINE) ssum += act * (ssum2[0] + ssum2[1]);
+}
+
+// The register file of the four holder waves is the tile's home: kX1FullCh full chunks (16 columns per lane) and, when D
+// ends with a 16-column chunk (784 = 12 x 64 + 16), that chunk spread over the four lanes of a row (one piece each).
+constexpr int kX1FullCh = 12;
+
+template <bool AFFINE, int NU, bool BASE, int PM>
+__device__ __forceinline__ void x1_holder(const X3Args &a, lchar *smem, lchar *zbuf, const lfloat *aff_l, const lfloat *base_l,
+                                          int wave, int lane_in, int wave8) {
+    typedef X1Cfg<NU> C;
+    typedef __attribute__((address_space(3))) const gf32x4 lf4;
+    const int D = a.D, NCH1 = a.g.NCH1, NPT = a.g.NPT;
+    const int NFULL = D >> 6;                       // full chunks; NCH1 == NFULL + 1: a 16-column tail chunk follows
+    const int grid = (int)gridDim.x, ntiles = a.ntiles;
+    const float base_cst = BASE ? a.base_ac[2 * D] : 0.f;
+    const float act = AFFINE ? a.act_weight[0] : 0.f;
+    const bool inv = a.inverse != 0;
+    const unsigned smem_base = (unsigned)(uintptr_t)smem;
+    gf32x4 xr[kX1FullCh][4];
+    gf32x4 xtail = {0.f, 0.f, 0.f, 0.f};
+    int hstage = 0;
+    [[maybe_unused]] int hrow = 0;
+    [[maybe_unused]] const int lane = lane_in;     // (X3_STAMP)
+    __syncthreads();
+    for (int tile = (int)blockIdx.x; tile < ntiles; tile += grid) {
+        float ssum = 0.f, bacc = 0.f;
+        // ---- phase-1 steps: issue chunk c + 2 (chunks 2 .. NCH1 + 1 are the holders'), keep chunk c ----
+        // (unrolled: the register file is indexed statically; the lane number made opaque per step so that the offsets
+        // derived from it are recomputed instead of living in registers -- every register here is wanted for x)
+#pragma unroll
+        for (int c = 0; c <= kX1FullCh; ++c) {
+            if (c < NCH1) {
+                if (c > 0) {   // (the barrier of chunk 0 is the last step of the previous tile / the opening one below)
+                    X3_STAMP(hrow, 0);
+                    // chunks 2.. were issued by this wave; chunk c + 1 (issued one step ago) may stay in flight
+                    if (c >= 2) x1_wait<NU>(c + 1 < NCH1 ? 1 : 2);
+                    gemm_lds_barrier();
+                    X3_STAMP(hrow, 1);
+                } else if (tile == (int)blockIdx.x) {
+                    gemm_lds_barrier();
+                }
+                int lo = lane_in;
+                asm volatile("" : "+v"(lo));
+                {
+                    int is = hstage + 2;
+                    is = is >= kGemmStages ? is - kGemmStages : is;
+                    // (the chunk number made opaque: thirteen unrolled copies of the issue code with constant chunk numbers
+                    // had their ragged-edge offsets hoisted out of the tile loop -- 120 spilled registers)
+                    int cn = c + 2;
+                    asm volatile("" : "+s"(cn));
+                    unsigned voff[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = wave * 16 + j * 4 + (lo >> 4);
+                        voff[j] = (unsigned)(r * D + ((lo & 15) ^ (r & 15)) * 4) * 4u;
+                    }
+                    x1_issue<NU>(a, tile, cn, is, wave, lo, smem_base, voff);
+                }
+                const lchar *st = smem + hstage * C::STAGE;
+                hstage = (hstage + 1 == kGemmStages) ? 0 : hstage + 1;
+                const int rl = wave * 16 + (lo >> 2), q = lo & 3;
+                if (c < kX1FullCh && c < NFULL) {
+                    const int col0 = 64 * c + 16 * q;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const gf32x4 v = *(lf4 *)(st + (unsigned)(rl * 256 + (((4 * q + i) ^ (rl & 15)) << 4)));
+                        const gf32x4 sc = *(lf4 *)(aff_l + col0 + 4 * i), sh = *(lf4 *)(aff_l + D + col0 + 4 * i);
+                        xr[c < kX1FullCh ? c : 0][i] = v * sc + sh;
+                        __builtin_amdgcn_sched_barrier(0);   // (register pressure: one 16-byte piece at a time)
+                    }
+                } else {   // the 16-column tail chunk: piece q of row rl
+                    const int col0 = 64 * c + 4 * q;
+                    const gf32x4 v = *(lf4 *)(st + (unsigned)(rl * 256 + ((q ^ (rl & 15)) << 4)));
+                    const gf32x4 sc = *(lf4 *)(aff_l + col0), sh = *(lf4 *)(aff_l + D + col0);
+                    xtail = v * sc + sh;
+                }
+                X3_STAMP(hrow, 2);
+                ++hrow;
+            }
+        }
+        // ---- phase-2 steps ----
+#pragma unroll
+        for (int pt = 0; pt <= kX1FullCh + 1; ++pt) {
+            if (pt <= NPT) {
+                // pt < NPT: this tile's chunk NCH1 + pt; pt == NPT: chunk 0 of the next tile, or the closing barrier
+                X3_STAMP(hrow, 0);
+                if (pt == 0) x1_wait<NU>(2);        // chunk NCH1 (ours); chunk NCH1 + 1 may stay in flight
+                else if (pt == 1) x1_wait<NU>(0);   // chunk NCH1 + 1, the last one the holders issue (no store is in flight yet)
+                gemm_lds_barrier();
+                X3_STAMP(hrow, 1);
+                if (pt == 0) gemm_lds_barrier();    // behind the MFMA waves' fragment swap
+                if (pt < NPT) hstage = (hstage + 1 == kGemmStages) ? 0 : hstage + 1;
+                if (pt > 0) {
+                    // ---- epilogue of variable tile p = pt - 1 ----
+                    const int pc_ = pt > 0 ? pt - 1 : 0;   // (a constant after unrolling: xr stays in registers)
+                    int lo = lane_in;
+                    asm volatile("" : "+v"(lo));
+                    const int rl = wave * 16 + (lo >> 2), q = lo & 3;
+                    const int64_t b = (int64_t)tile * kX1Tile + rl;
+                    const bool row_ok = b < a.B;
+                    float *orow = a.out + (row_ok ? b : 0) * D;
+                    const lchar *zb = zbuf + (pc_ & 1) * 2 * kX1ZSlab + rl * kX1ZRow;
+                    if (pc_ < kX1FullCh && pc_ < NFULL) {   // raw columns 64 p + 16 q .. + 15 of row rl
+                        const gf32x4 *xk = xr[pc_ < kX1FullCh ? pc_ : 0];
+                        if (inv) x1_epilogue<AFFINE, BASE, PM, true, 4>(xk, zb + q * 32, act, base_l, D, 64 * pc_ + 16 * q, row_ok, orow, ssum, bacc);
+                        else x1_epilogue<AFFINE, BASE, PM, false, 4>(xk, zb + q * 32, act, base_l, D, 64 * pc_ + 16 * q, row_ok, orow, ssum, bacc);
+                    } else {                                // the tail: raw columns 64 p + 4 q .. + 3
+                        if (inv) x1_epilogue<AFFINE, BASE, PM, true, 1>(&xtail, zb + q * 8, act, base_l, D, 64 * pc_ + 4 * q, row_ok, orow, ssum, bacc);
+                        else x1_epilogue<AFFINE, BASE, PM, false, 1>(&xtail, zb + q * 8, act, base_l, D, 64 * pc_ + 4 * q, row_ok, orow, ssum, bacc);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                X3_STAMP(hrow, 2);
+                ++hrow;
+            }
+        }
+        // ---- the four lanes of a sample hold disjoint quarters of its variables ----
+        const int rl = wave * 16 + (lane_in >> 2), q = lane_in & 3;
+        const int64_t b = (int64_t)tile * kX1Tile + rl;
+        const bool row_ok = b < a.B;
+        float tot = ssum + __shfl_xor(ssum, 1, 64);
+        tot += __shfl_xor(tot, 2, 64);
+        if (BASE) {
+            float btot = bacc + __shfl_xor(bacc, 1, 64);
+            btot += __shfl_xor(btot, 2, 64);
+            if (q == 0 && row_ok)
+                a.ll_out[b] = btot + base_cst + (a.ildj_in ? a.ildj_in[b] : 0.f) + (AFFINE ? -tot : 0.f);
+        } else if (q == 0 && row_ok) {
+            const float v = AFFINE ? (inv ? tot : -tot) : 0.f;
+            if (a.accumulate) a.ldj[b] += v; else a.ldj[b] = v;
+        }
+    }
+}
+
+// ---- MFMA waves ---------------------------------------------------------------------------------------------------------
+template <bool AFFINE, int NU, int ROLE, int PM>
+__device__ __forceinline__ void x1_mfma(const X3Args &a, lchar *smem, lchar *zbuf, const lfloat *b1_l, int wave, int lane,
+                                        int wave8) {
+    typedef X1Cfg<NU> C;
+    constexpr int KK = C::KK;
+    constexpr int NT = (NU + 1 - ROLE) / 2;          // hidden blocks of this role: T = ROLE, ROLE + 2, ...
+    constexpr int NTP = (NU + ROLE) / 2;             // ... and of the partner: T = 1 - ROLE, 3 - ROLE, ...
+    constexpr int NTA = NT > 0 ? NT : 1;
+    typedef __attribute__((address_space(3))) const gf32x4 lf4;
+    typedef __attribute__((address_space(3))) gf32x4 lf4w;
+    typedef __attribute__((address_space(3))) const half8 lh8;
+    typedef __attribute__((address_space(3))) half8 lh8w;
+    const int D = a.D, NCH1 = a.g.NCH1, NPT = a.g.NPT;
+    const int grid = (int)gridDim.x, ntiles = a.ntiles;
+    const int nchunks = NCH1 + NPT;
+    const int s = lane & 31, h = lane >> 5;
+    const int sb = wave >> 1;
+    const float w1sc = a.scales[0], w2sc = a.scales[1];
+    const unsigned smem_base = (unsigned)(uintptr_t)smem;
+    unsigned voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = wave * 16 + j * 4 + (lane >> 4);
+        voff[j] = (unsigned)(r * D + ((lane & 15) ^ (r & 15)) * 4) * 4u;
+    }
+    // (the prologue's table loads are compiler-counted and complete at this barrier; the DMAs start after it)
+    __syncthreads();
+    x1_issue<NU>(a, (int)blockIdx.x, 0, 0, wave, lane, smem_base, voff);
+    x1_issue<NU>(a, (int)blockIdx.x, 1, 1, wave, lane, smem_base, voff);
+
+    const int rl_own = sb * 32 + s;
+    const int sw = rl_own & 15;
+    unsigned xoff[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) xoff[j][qq] = (unsigned)(rl_own * 256 + (((8 * j + 4 * h + qq) ^ sw) << 4));
+    const unsigned foff = (unsigned)(lane * 16);
+    constexpr bool z_active = AFFINE || ROLE == 0;
+    lchar *zrow = zbuf + ROLE * kX1ZSlab + rl_own * kX1ZRow + h * 16;
+    lchar *swap_own = zbuf + wave * kX1SwapWave + foff;           // [2 NT K-steps][hi, lo][64 lanes x 16 B]
+    const lchar *swap_par = zbuf + (wave ^ 1) * kX1SwapWave + foff;
+    lfloat *hsc_own = (lfloat *)(zbuf + 4 * kX1SwapWave) + wave * 64 + lane;
+    const lfloat *hsc_par = (lfloat *)(zbuf + 4 * kX1SwapWave) + (wave ^ 1) * 64 + lane;
+
+    int cstage = 0;
+    [[maybe_unused]] int crow = 0;
+    for (int tile = (int)blockIdx.x; tile < ntiles; tile += grid) {
+        const bool more = tile + grid < ntiles;
+        gf32x16 acc[NTA];
+#pragma unroll
+        for (int t = 0; t < NTA; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        constexpr float kBig = 16384.f;
+        float xsc = 1.f;
+        // ---- phase 1: this role's blocks of H^T = W1m X^T ------------------------------------------------------
+        for (int c = 0; c < NCH1; ++c) {
+            X3_STAMP(crow, 0);
+            // chunks 0 and 1 of a tile are the MFMA waves' (issued two steps back); chunk 1 may stay in flight behind 0
+            if (c == 0) x1_wait<NU>(1);
+            else if (c == 1) x1_wait<NU>(0);
+            X3_STAMP(crow, 1);
+            gemm_lds_barrier();
+            X3_STAMP(crow, 2);
+            const lchar *st = smem + cstage * C::STAGE;
+            cstage = (cstage + 1 == kGemmStages) ? 0 : cstage + 1;
+            const lchar *tb = st + kX1XB + foff;
+            if (NT > 0) {
+                // both K-steps of the chunk at once: one wait for the x pieces, one range check (max over the 16 values,
+                // the partner lane's through v_permlane32_swap), then conversions and MFMAs -- as two K-steps in series the
+                // chain ds_read -> max -> LDS shuffle -> branch -> split -> MFMA ran twice per chunk
+                float v[2][8];
+                float m8 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float raw[16];
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const gf32x4 p4 = *(lf4 *)(st + xoff[j][qq]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) raw[4 * qq + i] = p4[i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float m = PM ? raw[2 * i + 1] : raw[2 * i];
+                        // (columns beyond D hold clamped copies; their W1 entries are zero, the values must be finite)
+                        v[j][i] = (c * 64 + j * 32 + 16 * h + 2 * i < D) ? m : 0.f;
+                        m8 = fmaxf(m8, fabsf(v[j][i]));
+                    }
+                }
+                m8 = x1_pair_max(m8);
+                if (__builtin_expect(m8 * xsc > kBig && m8 < 3.0e38f, 0)) {
+                    const float f = exp2f(-ceilf(log2f(m8 * xsc * (1.f / kBig))));
+#pragma unroll
+                    for (int t = 0; t < NTA; ++t)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[t][i] *= f;
+                    xsc *= f;
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (c * 64 + j * 32 < D) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[j][i] *= xsc;
+                        half8 xh, xl;
+                        split8(v[j], xh, xl);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const int T = ROLE + 2 * t;
+                            const half8 wh = *(lh8 *)(tb + (j * NU + T) * 2048);
+                            const half8 wl = *(lh8 *)(tb + (j * NU + T) * 2048 + 1024);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc[t], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            X3_STAMP(crow, 4);
+            ++crow;
+        }
+        // ---- bias + ReLU + split of this role's blocks; swap with the partner role ----------------------------
+        half8 hh[KK], hl[KK];
+        const float xinv = 1.f / (xsc * w1sc);
+        float hmax = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int unit = 32 * (ROLE + 2 * t) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                acc[t][reg] = fmaxf(fmaf(acc[t][reg], xinv, b1_l[unit]), 0.f);
+                hmax = fmaxf(hmax, acc[t][reg]);
+            }
+        hmax = x1_pair_max(hmax);
+        float hsc = 1.f;
+        if (__builtin_expect(hmax > kBig && hmax < 3.0e38f, 0)) hsc = exp2f(-ceilf(log2f(hmax * (1.f / kBig))));
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = acc[t][8 * j + i] * hsc;
+                const int kk = 2 * (ROLE + 2 * t) + j;
+                split8(v, hh[kk], hl[kk]);
+                *(lh8w *)(swap_own + (2 * t + j) * 2048) = hh[kk];
+                *(lh8w *)(swap_own + (2 * t + j) * 2048 + 1024) = hl[kk];
+            }
+        *hsc_own = hsc;
+        float hinv = 1.f;
+        // ---- phase 2: this role's rows of Z^T = W2 H^T per tile of 32 transformed variables -> z slab ----------
+        for (int pt = 0; pt < NPT; ++pt) {
+            X3_STAMP(crow, 0);
+            // chunks NCH1 + 2 .. are the MFMA waves'; the chunk issued one step later (the next tile's first one after
+            // this tile's last) may stay in flight
+            if (pt >= 2) {
+                if (pt + 1 < NPT) x1_wait<NU>(2);
+                else x1_wait<NU>(more ? 1 : 0);
+            }
+            X3_STAMP(crow, 1);
+            gemm_lds_barrier();
+            X3_STAMP(crow, 2);
+            {   // issue the chunk two steps ahead: this tile's, then chunks 0 and 1 of the next tile
+                int is = cstage + 2;
+                is = is >= kGemmStages ? is - kGemmStages : is;
+                const int cn = NCH1 + pt + 2;
+                if (cn < nchunks) x1_issue<NU>(a, tile, cn, is, wave, lane, smem_base, voff);
+                else if (more) x1_issue<NU>(a, tile + grid, cn - nchunks, is, wave, lane, smem_base, voff);
+            }
+            X3_STAMP(crow, 3);
+            const lchar *st = smem + cstage * C::STAGE;
+            cstage = (cstage + 1 == kGemmStages) ? 0 : cstage + 1;
+            if (pt == 0) {
+                // the partner's fragments (scaled by ITS power of two) and the common scale of the sample
+                const float hp = *hsc_par;
+#pragma unroll
+                for (int t = 0; t < NTP; ++t)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int kk = 2 * (1 - ROLE + 2 * t) + j;
+                        hh[kk] = *(lh8 *)(swap_par + (2 * t + j) * 2048);
+                        hl[kk] = *(lh8 *)(swap_par + (2 * t + j) * 2048 + 1024);
+                    }
+                const float hc = fminf(hsc, hp);
+                if (__builtin_expect(hsc != hp, 0)) {   // (rare: activations beyond the f16 range in one role only)
+                    const _Float16 fo = (_Float16)(hc / hsc), fp = (_Float16)(hc / hp);
+#pragma unroll
+                    for (int kk = 0; kk < KK; ++kk) {
+                        const bool own = ((kk >> 1) & 1) == ROLE;
+                        const _Float16 f = own ? fo : fp;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            hh[kk][i] *= f;
+                            hl[kk][i] *= f;
+                        }
+                    }
+                }
+                hinv = 1.f / (hc * w2sc);
+                gemm_lds_barrier();   // every fragment is read: the z slabs (same LDS) may be written
+            }
+            if (z_active) {
+                const lchar *tb = st + foff + ROLE * 2048;
+                gf32x16 z, z1;   // (two accumulator chains: a dependent MFMA waits for its predecessor's last pass)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    z[i] = 0.f;
+                    z1[i] = 0.f;
+                }
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) {
+                    const half8 th = *(lh8 *)(tb + kk * 4096);
+                    const half8 tl = *(lh8 *)(tb + kk * 4096 + 1024);
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, hh[kk], z, 0, 0, 0);
+                    z1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, hl[kk], z1, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl, hh[kk], z, 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) z[i] += z1[i];
+                const lchar *ex = st + KK * 4096 + ROLE * 128;   // extras: bt (role 0) / bs (role 1), 32 floats each
+                lchar *zw = zrow + (pt & 1) * 2 * kX1ZSlab;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const gf32x4 bb = *(lf4 *)(ex + (8 * g4 + 4 * h) * 4);
+                    gf32x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = fmaf(z[4 * g4 + i], hinv, bb[i]);
+                    *(lf4w *)(zw + g4 * 32) = o;
+                }
+            }
+            X3_STAMP(crow, 4);
+            ++crow;
+        }
+    }
+    gemm_lds_barrier();   // closing barrier: the holders' epilogue of the last variable tile follows it
+}
+
+template <bool AFFINE, int NU, bool BASE, int PM>
+__global__ __launch_bounds__(512) void coupling_x1_kernel(const X3Args a) {
+    typedef X1Cfg<NU> C;
+    extern __shared__ __attribute__((aligned(16))) char smem_generic[];
+    lchar *smem = (lchar *)smem_generic;
+    lchar *zbuf = smem + kGemmStages * C::STAGE;                 // z slabs [2 buffers][2 roles][64 rows][36 floats] / swap area
+    lfloat *b1_l = (lfloat *)(zbuf + 4 * kX1ZSlab);              // [U]
+    lfloat *aff_l = b1_l + ((a.U + 3) & ~3);                     // [2][D] input affine (scale, shift) per raw column
+    lfloat *base_l = aff_l + 2 * a.D;                            // BASE: [2][D] (a_d, c_d)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3;
+    const int D = a.D;
+    for (int e = tid; e < a.U; e += 512) b1_l[e] = a.b1f[e];
+    for (int e = tid; e < D; e += 512) {
+        aff_l[e] = a.in_scale ? a.in_scale[e] : 1.f;
+        aff_l[D + e] = a.in_shift ? a.in_shift[e] : 0.f;
+    }
+    if (BASE)
+        for (int e = tid; e < 2 * D; e += 512) base_l[e] = a.base_ac[e];
+    if (wave8 >= 4) x1_holder<AFFINE, NU, BASE, PM>(a, smem, zbuf, aff_l, base_l, wave, lane, wave8);
+    else if (wave & 1) x1_mfma<AFFINE, NU, 1, PM>(a, smem, zbuf, b1_l, wave, lane, wave8);
+    else x1_mfma<AFFINE, NU, 0, PM>(a, smem, zbuf, b1_l, wave, lane, wave8);
+}
+
 // (a_d, c_d) of the fused Normal base: t_d = a_d u_d + c_d with -t_d^2 = -(sc_d u_d + sh_d - loc_d)^2 / (2 sigma_d^2), and the
 // constant sum_d (-log sigma_d - log sqrt(2 pi)) + ildj_const (reference: flows/models/base.py:139-143 behind the affine
 // of an eval-mode BatchNormLayer1d, flows/utils.py:118-139).  One block, every call (D-sized, live parameters).
@@ -724,6 +1313,60 @@ static int x3_launch(const X3Args &a, hipStream_t st) {
     return DPK_OK;
 }
 
+// x-once kernel (coupling_x1_kernel) where its holders can keep the tile.
+// DPK_X3_TWO_PASS=1 keeps the two-pass kernel (A/B measurements).
+static bool x1_shape_ok(int D) {   // D = 64 n or 64 n + 16, 2 chunks .. 12 full chunks + tail (784 = 12 x 64 + 16)
+    static const bool two_pass = getenv("DPK_X3_TWO_PASS") != nullptr;
+    // (two chunks at least: ring protocol; the holders keep twelve full chunks and a 16-column tail)
+    return !two_pass && D > 64 && ((D % 64) == 0 || (D % 64) == 16) && (D >> 6) <= kX1FullCh;
+}
+
+template <bool AFFINE, int NU, bool BASE = false>
+static int x1_launch(const X3Args &a_in, hipStream_t st) {
+    constexpr int STAGE = X1Cfg<NU>::STAGE;
+    X3Args a = a_in;
+    a.ntiles = (int)cdiv(a.B, (int64_t)kX1Tile);
+    const size_t lds = (size_t)kGemmStages * STAGE + (size_t)4 * kX1ZSlab + (size_t)((a.U + 3) & ~3) * 4 +
+                       (size_t)2 * a.D * 4 + (BASE ? (size_t)2 * a.D * 4 : 0);
+    DPK_REQUIRE(lds <= 160 * 1024, DPK_EUNSUPPORTED, "coupling1d_pairs: %zu bytes of LDS", lds);
+    auto kern = a.pm ? coupling_x1_kernel<AFFINE, NU, BASE, 1> : coupling_x1_kernel<AFFINE, NU, BASE, 0>;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024)) return rc;
+    const int cus = device_cus();
+    const int grid = a.ntiles < cus ? a.ntiles : cus;
+    hipEvent_t ev0, ev1;
+    profile_take(&ev0, &ev1, DPK_KERNEL_COUPLING1D);
+    if (ev0) (void)hipEventRecord(ev0, st);
+#ifdef DPK_X3_TIMELINE
+    if (getenv("DPK_X3_TIMELINE")) {
+        (void)hipMalloc(&a.dbg, 8 * 64 * 8 * 8);
+        (void)hipMemset(a.dbg, 0, 8 * 64 * 8 * 8);
+    }
+#endif
+    DPK_LAUNCH(kern, dim3(grid), dim3(512), lds, st, a);
+#ifdef DPK_X3_TIMELINE
+    if (a.dbg) {   // synchronous read-back: measurement builds only
+        std::vector<long long> hb(8 * 64 * 8);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(hb.data(), a.dbg, hb.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(a.dbg);
+        const long long t0 = hb[0];
+        for (int w : {0, 1, 4}) {
+            fprintf(stderr, "x1 timeline wave %d:", w);
+            for (int r = 0; r < 60; ++r) {
+                fprintf(stderr, " [");
+                for (int sl = 0; sl < 5; ++sl)
+                    fprintf(stderr, " %lld", hb[(w * 64 + r) * 8 + sl] ? hb[(w * 64 + r) * 8 + sl] - t0 : -1);
+                fprintf(stderr, " ]");
+            }
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
+    if (ev1) (void)hipEventRecord(ev1, st);
+    DPK_CHECK_LAUNCH("coupling_x1_kernel");
+    return DPK_OK;
+}
+
 }  // namespace dpk
 
 using namespace dpk;
@@ -785,17 +1428,31 @@ static int x3_forward_common(const float *x, int64_t B, int32_t D, int32_t maske
     a.x = x; a.out = out; a.ldj = ldj; a.B = B; a.D = D; a.U = units; a.pm = masked_parity; a.inverse = inverse;
     a.accumulate = accumulate_ldj; a.ntiles = cdiv(B, kX3Tile); a.g = g;
     a.w1t = w.w1t; a.w2t = w.w2t; a.b1f = w.b1f; a.act_weight = act_weight; a.scales = w.scales;
+    a.in_scale = in_scale; a.in_shift = in_shift;
+    const bool once = x1_shape_ok(D);
     if (base) {
         DPK_LAUNCH(x3_base_prep_kernel, dim3(1), dim3(256), 0, st, base->out_scale, base->out_shift, base->loc, base->scale,
                    base->ildj_const, D, w.base_ac);
         DPK_CHECK_LAUNCH("x3_base_prep_kernel");
         a.base_ac = w.base_ac; a.ildj_in = base->ildj_in; a.ll_out = base->ll;
+        if (once) switch (units / 32) {
+            case 1: return affine ? x1_launch<true, 1, true>(a, st) : x1_launch<false, 1, true>(a, st);
+            case 2: return affine ? x1_launch<true, 2, true>(a, st) : x1_launch<false, 2, true>(a, st);
+            case 3: return affine ? x1_launch<true, 3, true>(a, st) : x1_launch<false, 3, true>(a, st);
+            default: return affine ? x1_launch<true, 4, true>(a, st) : x1_launch<false, 4, true>(a, st);
+        }
         switch (units / 32) {
             case 1: return affine ? x3_launch<true, 1, true>(a, st) : x3_launch<false, 1, true>(a, st);
             case 2: return affine ? x3_launch<true, 2, true>(a, st) : x3_launch<false, 2, true>(a, st);
             case 3: return affine ? x3_launch<true, 3, true>(a, st) : x3_launch<false, 3, true>(a, st);
             default: return affine ? x3_launch<true, 4, true>(a, st) : x3_launch<false, 4, true>(a, st);
         }
+    }
+    if (once) switch (units / 32) {
+        case 1: return affine ? x1_launch<true, 1>(a, st) : x1_launch<false, 1>(a, st);
+        case 2: return affine ? x1_launch<true, 2>(a, st) : x1_launch<false, 2>(a, st);
+        case 3: return affine ? x1_launch<true, 3>(a, st) : x1_launch<false, 3>(a, st);
+        default: return affine ? x1_launch<true, 4>(a, st) : x1_launch<false, 4>(a, st);
     }
     switch (units / 32) {
         case 1: return affine ? x3_launch<true, 1>(a, st) : x3_launch<false, 1>(a, st);

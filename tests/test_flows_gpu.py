@@ -101,6 +101,43 @@ def test_custom_masks_vs_oracle(D, pattern):
         assert torch.allclose(xr.cpu(), x, atol=5e-6) and torch.allclose(ldj, -ildj, atol=5e-6)
 
 
+@pytest.mark.parametrize('D,units,affine', [(80, 32, True), (128, 64, True), (144, 96, True), (784, 128, True),
+                                            (768, 128, False), (784, 32, False), (96, 32, True), (832, 64, True)])
+def test_column_pair_kernels_shapes_vs_oracle(D, units, affine):
+    """The alternating-mask layer on the f16 matrix cores at the edges of the x-once kernel's envelope (round 3:
+    coupling_x1_kernel keeps a 64-sample tile of x in the registers of four waves; D = 64 n or 64 n + 16 with 2 chunks
+    to 12 full chunks + tail): one full chunk + tail (80), full chunks only (128, 768), two full chunks + tail (144), the
+    benchmark width (784), and the two-pass kernel's shapes next to it (96: a 32-column tail; 832: thirteen full
+    chunks); every hidden width, both mask parities, both directions, ragged and single-row batches."""
+    from deeprob.flows.layers.coupling import CouplingLayer1d
+    from oracle import flows_oracle as forc
+    gen = torch.Generator().manual_seed(D + units)
+    layer = CouplingLayer1d(D, depth=1, units=units, affine=affine).cuda().eval()
+    idx = torch.arange(D)
+    for reverse in (False, True):
+        mask = (idx % 2).float()
+        inv = 1 - mask
+        if reverse:
+            mask, inv = inv, mask
+        with torch.no_grad():
+            layer.mask.copy_(mask)
+            layer.inv_mask.copy_(inv)
+            if affine:
+                layer.scale_act.weight.fill_(0.8)
+            for p in layer.network.parameters():
+                p.copy_(torch.randn(p.shape, generator=gen) * (1.0 / D ** 0.5))
+        lins = [(m.weight.detach().cpu(), m.bias.detach().cpu()) for m in layer.network if isinstance(m, torch.nn.Linear)]
+        for B in (1, 63, 64, 65, 200):
+            x = torch.randn(B, D, generator=gen)
+            with torch.no_grad():
+                u, ildj = layer.apply_backward(x.cuda())
+                xr, ldj = layer.apply_forward(u)
+            wu, wildj = forc.coupling_backward(x, mask, inv, lins, torch.tensor([0.8]) if affine else None)
+            assert rel_err(u.cpu().numpy(), wu.numpy()) <= 1e-5, (B, reverse)
+            assert rel_err(ildj.cpu().numpy(), wildj.numpy()) <= 1e-5, (B, reverse)
+            assert torch.allclose(xr.cpu(), x, atol=2e-5) and torch.allclose(ldj, -ildj, atol=2e-5), (B, reverse)
+
+
 def test_alternating_masks_on_a_view_at_an_odd_storage_offset():
     """A contiguous x whose first element is not 16-byte aligned cannot take the column-pair MFMA kernel; the generic
     kernel it falls through to must START its own log-det (ldj=None), not add into what the abandoned branch
