@@ -754,7 +754,9 @@ __device__ __forceinline__ float x1_pair_max(float v) {
 }
 
 // ---- holder / epilogue waves ------------------------------------------------------------------------------------------
-// One epilogue step: NP pieces of four raw columns (two variables each) of one row.  xk: the kept pieces (input affine
+// One epilogue step: NP pieces of four raw columns (two variables each) of one row, 16 columns apart: the four lanes of
+// a row own interleaved pieces, so one store instruction writes 64 contiguous bytes per row (a lane owning 16 contiguous
+// columns wrote four 16-byte fragments 64 bytes apart per row and instruction).  xk: the kept pieces (input affine
 // applied), zb: the lane's z values (t; s one slab further), col0: the first raw column.  Pairs of variables go through
 // the packed fp32 instructions; PM (the parity of the masked columns) is a template parameter: as a run-time value every
 // element select became a chain of v_cndmask (310 instructions per step).
@@ -769,9 +771,9 @@ __device__ __forceinline__ void x1_epilogue(const gf32x4 *xk, const lchar *zb, f
     gf32x2 tz[NP], sz[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-        tz[k] = *(lf2 *)(zb + k * 8);
+        tz[k] = *(lf2 *)(zb + k * 32);
         sz[k] = tz[k];
-        if (AFFINE) sz[k] = *(lf2 *)(zb + kX1ZSlab + k * 8);
+        if (AFFINE) sz[k] = *(lf2 *)(zb + kX1ZSlab + k * 32);
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
@@ -806,12 +808,12 @@ __device__ __forceinline__ void x1_epilogue(const gf32x4 *xk, const lchar *zb, f
         y[1 - PM] = ov[0];
         y[3 - PM] = ov[1];
         if (BASE) {
-            const gf32x4 ba = *(lf4 *)(base_l + col0 + 4 * k), bc = *(lf4 *)(base_l + D + col0 + 4 * k);
+            const gf32x4 ba = *(lf4 *)(base_l + col0 + 16 * k), bc = *(lf4 *)(base_l + D + col0 + 16 * k);
             const gf32x4 t = y * ba + bc;
 #pragma unroll
             for (int i = 0; i < 4; ++i) bacc = fmaf(-t[i], t[i], bacc);
         } else if (row_ok) {
-            *reinterpret_cast<gf32x4 *>(orow + col0 + 4 * k) = y;
+            *reinterpret_cast<gf32x4 *>(orow + col0 + 16 * k) = y;
         }
         if (BASE && NP > 1 && (k & 1)) __builtin_amdgcn_sched_barrier(0);   // (register pressure: eight columns at a time)
     }
@@ -878,11 +880,11 @@ __device__ __forceinline__ void x1_holder(const X3Args &a, lchar *smem, lchar *z
                 hstage = (hstage + 1 == kGemmStages) ? 0 : hstage + 1;
                 const int rl = wave * 16 + (lo >> 2), q = lo & 3;
                 if (c < kX1FullCh && c < NFULL) {
-                    const int col0 = 64 * c + 16 * q;
+                    const int col0 = 64 * c + 4 * q;   // piece i of the lane: raw columns col0 + 16 i .. + 3
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const gf32x4 v = *(lf4 *)(st + (unsigned)(rl * 256 + (((4 * q + i) ^ (rl & 15)) << 4)));
-                        const gf32x4 sc = *(lf4 *)(aff_l + col0 + 4 * i), sh = *(lf4 *)(aff_l + D + col0 + 4 * i);
+                        const gf32x4 v = *(lf4 *)(st + (unsigned)(rl * 256 + (((4 * i + q) ^ (rl & 15)) << 4)));
+                        const gf32x4 sc = *(lf4 *)(aff_l + col0 + 16 * i), sh = *(lf4 *)(aff_l + D + col0 + 16 * i);
                         xr[c < kX1FullCh ? c : 0][i] = v * sc + sh;
                         __builtin_amdgcn_sched_barrier(0);   // (register pressure: one 16-byte piece at a time)
                     }
@@ -918,10 +920,10 @@ __device__ __forceinline__ void x1_holder(const X3Args &a, lchar *smem, lchar *z
                     const bool row_ok = b < a.B;
                     float *orow = a.out + (row_ok ? b : 0) * D;
                     const lchar *zb = zbuf + (pc_ & 1) * 2 * kX1ZSlab + rl * kX1ZRow;
-                    if (pc_ < kX1FullCh && pc_ < NFULL) {   // raw columns 64 p + 16 q .. + 15 of row rl
+                    if (pc_ < kX1FullCh && pc_ < NFULL) {   // raw columns 64 p + 16 k + 4 q .. + 3 (k = 0..3) of row rl
                         const gf32x4 *xk = xr[pc_ < kX1FullCh ? pc_ : 0];
-                        if (inv) x1_epilogue<AFFINE, BASE, PM, true, 4>(xk, zb + q * 32, act, base_l, D, 64 * pc_ + 16 * q, row_ok, orow, ssum, bacc);
-                        else x1_epilogue<AFFINE, BASE, PM, false, 4>(xk, zb + q * 32, act, base_l, D, 64 * pc_ + 16 * q, row_ok, orow, ssum, bacc);
+                        if (inv) x1_epilogue<AFFINE, BASE, PM, true, 4>(xk, zb + q * 8, act, base_l, D, 64 * pc_ + 4 * q, row_ok, orow, ssum, bacc);
+                        else x1_epilogue<AFFINE, BASE, PM, false, 4>(xk, zb + q * 8, act, base_l, D, 64 * pc_ + 4 * q, row_ok, orow, ssum, bacc);
                     } else {                                // the tail: raw columns 64 p + 4 q .. + 3
                         if (inv) x1_epilogue<AFFINE, BASE, PM, true, 1>(&xtail, zb + q * 8, act, base_l, D, 64 * pc_ + 4 * q, row_ok, orow, ssum, bacc);
                         else x1_epilogue<AFFINE, BASE, PM, false, 1>(&xtail, zb + q * 8, act, base_l, D, 64 * pc_ + 4 * q, row_ok, orow, ssum, bacc);
