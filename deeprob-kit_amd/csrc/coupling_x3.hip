@@ -647,6 +647,10 @@ constexpr int kX1Tile = 64;
 constexpr int kX1XB = kX1Tile * 256;    // x chunk: 64 raw columns of 64 rows
 constexpr int kX1ZRow = 36 * 4;         // bytes per sample row of a z slab (32 variables + 16 bytes: conflict-free b128 writes)
 constexpr int kX1ZSlab = kX1Tile * kX1ZRow;
+#ifndef DPK_X1_NT
+#define DPK_X1_NT 1
+#endif
+constexpr bool kX1XNonTemporal = DPK_X1_NT != 0;   // x is read once: non-temporal LDS-DMA (the L2 keeps the tables)
 constexpr int kX1SwapWave = 8192;       // fragment-swap bytes per MFMA wave (<= 2 blocks x 2 K-steps x (hi, lo) KiB)
 
 template <int NU>
@@ -711,7 +715,7 @@ __device__ __forceinline__ void x1_issue(const X3Args &a, int tile, int c, int s
         const bool full = (b0 + kX1Tile <= a.B) && ((c + 1) * 64 <= D);
         if (full) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) glds16(voff[j], xt, st + (wave * 16 + j * 4) * 256);
+            for (int j = 0; j < 4; ++j) glds16<kX1XNonTemporal>(voff[j], xt, st + (wave * 16 + j * 4) * 256);
         } else {   // ragged tile / last chunk: clamp to rows and pieces that exist (clamped slots are never consumed)
             const int nvalid = (int)min((int64_t)kX1Tile, a.B - b0);
             const int vp = min(16, (D - c * 64) >> 2);
@@ -719,7 +723,7 @@ __device__ __forceinline__ void x1_issue(const X3Args &a, int tile, int c, int s
             for (int j = 0; j < 4; ++j) {
                 const int r = wave * 16 + j * 4 + (lane >> 4);
                 const int gp = min((lane & 15) ^ (r & 15), vp - 1);
-                glds16((unsigned)(min(r, nvalid - 1) * D + gp * 4) * 4u, xt, st + (wave * 16 + j * 4) * 256);
+                glds16<kX1XNonTemporal>((unsigned)(min(r, nvalid - 1) * D + gp * 4) * 4u, xt, st + (wave * 16 + j * 4) * 256);
             }
         }
         const gcchar_p tsrc = (gcchar_p)a.w1t + (int64_t)c * C::W1CH;
