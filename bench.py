@@ -480,7 +480,7 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
     e = {'workload': 'RealNVP1d(784, n_flows=5, depth=1, units=128, batch_norm, affine) forward log-likelihood',
          'config': 'BASELINE config 5', 'batch': B, 'ms_per_step': ms, 'value': B / ms * 1e3,
          'unit': 'log-likelihoods/sec', 'ms_per_step_trusting_version_counters': ms_trust, 'kernel_ms': k_ms,
-         'kernel': 'coupling_x3_kernel (one of the 5 layers; split-f16 MFMA, fp32-grade products)',
+         'kernel': 'coupling_x1_kernel (one of the 5 layers; x read once: 64-sample tiles held in registers; split-f16 MFMA, fp32-grade products)',
          'roofline': hbm(B * 2 * D * 4, k_ms) if k_ms else hbm(5 * B * 2 * D * 4, ms),
          'roofline_basis': 'one coupling kernel; x read + out written once: 2*784*4 algorithmic B per sample and layer '
                            '(the conditioner runs on the f16 matrix cores at 3 MFMAs per fp32-grade product, far '

@@ -174,6 +174,7 @@ struct LeafGemmArgs {
     const int64_t *mask;
     const uint8_t *pad;
     const float *loc, *scale;
+    int ablate;   // measurement only (DPK_LEAF_ABLATE): 1 = no output stores
 };
 
 // exact per-element evaluation of the wave's 32 samples for the columns of this group (any scale, any evidence)
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void ratspn_leaf_gemm_kernel(c
                         const int u = 4 * q4 + i;
                         w4[i] = acc[t][u] + cst[u] - 0.5f * acc[NTG][t * RPL + u / I];
                     }
-                    if (n0 + 4 * q4 < ncol) *reinterpret_cast<gf32x4 *>(o + 4 * q4) = w4;
+                    if (n0 + 4 * q4 < ncol && !(a.ablate & 1)) *reinterpret_cast<gf32x4 *>(o + 4 * q4) = w4;
                 }
             }
         }
@@ -465,6 +466,10 @@ int ratspn_leaf_gemm_forward(void *ws, const float *x, int64_t B, int D, const i
         DPK_CHECK_LAUNCH("ratspn_leaf_gemm_prep_kernel");
     }
     LeafGemmArgs a{};
+    {
+        static const int ab = getenv("DPK_LEAF_ABLATE") ? atoi(getenv("DPK_LEAF_ABLATE")) : 0;
+        a.ablate = ab;
+    }
     a.x = x; a.B = B; a.D = D; a.d = d; a.R = R; a.I = I; a.NCH = NCH; a.NKSP = NKSP;
     a.ntiles = cdiv(B, kGemmTile);
     a.mtab = mtab; a.ctab = ctab; a.biasC = biasC; a.biasT = biasT; a.elig = elig;

@@ -84,7 +84,7 @@ if what in ('all', 'pmc'):
         'config2': [('ratspn_gemm_small_kernel', None, 'config2_2_2')],
         'wide': [('ratspn_gemm_wide_ring_kernel', None, 'wide_65536'), ('ratspn_gemm_wide_kernel<8, false>', None, 'config2_8_8')],
         'marginal': [('ratspn_gemm_marginal_kernel', None, 'marginal_65536')],
-        'config5': [('coupling_x3_kernel<true, 4, false>', None, 'config5')],
+        'config5': [('coupling_x1_kernel<true, 4, false', None, 'config5')],
         'config4': [('', None, 'config4')],
     }
     for name, cmd in WORKLOADS.items():
