@@ -779,6 +779,7 @@ __device__ __forceinline__ void x1_epilogue(const gf32x4 *xk, const lchar *zb, f
         sz[k] = tz[k];
         if (AFFINE) sz[k] = *(lf2 *)(zb + kX1ZSlab + k * 32);
     }
+    gf32x4 yo[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         gf32x4 y = xk[k];
@@ -816,10 +817,15 @@ __device__ __forceinline__ void x1_epilogue(const gf32x4 *xk, const lchar *zb, f
             const gf32x4 t = y * ba + bc;
 #pragma unroll
             for (int i = 0; i < 4; ++i) bacc = fmaf(-t[i], t[i], bacc);
-        } else if (row_ok) {
-            *reinterpret_cast<gf32x4 *>(orow + col0 + 16 * k) = y;
         }
+        yo[k] = y;
         if (BASE && NP > 1 && (k & 1)) __builtin_amdgcn_sched_barrier(0);   // (register pressure: eight columns at a time)
+    }
+    // (the stores behind ONE branch after the arithmetic of all pieces: a guarded store per piece split the step into
+    // basic blocks and every piece's exp -> rcp -> exp chain ran alone, 1850 cycles for ~100 instructions)
+    if (!BASE && row_ok) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) *reinterpret_cast<gf32x4 *>(orow + col0 + 16 * k) = yo[k];
     }
     if (AFFINE) ssum += act * (ssum2[0] + ssum2[1]);
 }
@@ -921,7 +927,12 @@ __device__ __forceinline__ void x1_holder(const X3Args &a, lchar *smem, lchar *z
                     asm volatile("" : "+v"(lo));
                     const int rl = wave * 16 + (lo >> 2), q = lo & 3;
                     const int64_t b = (int64_t)tile * kX1Tile + rl;
+#ifdef DPK_X3_TIMELINE
+                    // measurement: DPK_X3_TIMELINE=2 drops the stores of the stamped work-group (results are wrong)
+                    const bool row_ok = b < a.B && !(a.dbg && blockIdx.x == 0 && a.accumulate == 7);
+#else
                     const bool row_ok = b < a.B;
+#endif
                     float *orow = a.out + (row_ok ? b : 0) * D;
                     const lchar *zb = zbuf + (pc_ & 1) * 2 * kX1ZSlab + rl * kX1ZRow;
                     if (pc_ < kX1FullCh && pc_ < NFULL) {   // raw columns 64 p + 16 k + 4 q .. + 3 (k = 0..3) of row rl
@@ -1029,6 +1040,17 @@ __device__ __forceinline__ void x1_mfma(const X3Args &a, lchar *smem, lchar *zbu
                 // both K-steps of the chunk at once: one wait for the x pieces, one range check (max over the 16 values,
                 // the partner lane's through v_permlane32_swap), then conversions and MFMAs -- as two K-steps in series the
                 // chain ds_read -> max -> LDS shuffle -> branch -> split -> MFMA ran twice per chunk
+                // (the chunk's W1 fragments are requested with the x pieces: behind the range-check branch they were a second
+                // LDS round trip in the step's dependency chain)
+                half8 wh[2][NTA], wl[2][NTA];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int T = ROLE + 2 * t;
+                        wh[j][t] = *(lh8 *)(tb + (j * NU + T) * 2048);
+                        wl[j][t] = *(lh8 *)(tb + (j * NU + T) * 2048 + 1024);
+                    }
                 float v[2][8];
                 float m8 = 0.f;
 #pragma unroll
@@ -1064,15 +1086,14 @@ __device__ __forceinline__ void x1_mfma(const X3Args &a, lchar *smem, lchar *zbu
                         for (int i = 0; i < 8; ++i) v[j][i] *= xsc;
                         half8 xh, xl;
                         split8(v[j], xh, xl);
+                        // independent accumulators alternate (a dependent 32x32x16 MFMA waits out its predecessor's
+                        // 64-cycle latency; back-to-back independent ones issue every 32)
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) {
-                            const int T = ROLE + 2 * t;
-                            const half8 wh = *(lh8 *)(tb + (j * NU + T) * 2048);
-                            const half8 wl = *(lh8 *)(tb + (j * NU + T) * 2048 + 1024);
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc[t], 0, 0, 0);
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc[t], 0, 0, 0);
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc[t], 0, 0, 0);
-                        }
+                        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j][t], xh, acc[t], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j][t], xl, acc[t], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j][t], xh, acc[t], 0, 0, 0);
                     }
                 }
             }
@@ -1120,6 +1141,17 @@ __device__ __forceinline__ void x1_mfma(const X3Args &a, lchar *smem, lchar *zbu
             X3_STAMP(crow, 1);
             gemm_lds_barrier();
             X3_STAMP(crow, 2);
+            const lchar *st = smem + cstage * C::STAGE;
+            // this step's W2 fragments are requested BEFORE the DMA issue (650 cycles: their LDS latency hides under it)
+            half8 th[KK], tl[KK];
+            if (z_active) {
+                const lchar *tb = st + foff + ROLE * 2048;
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) {
+                    th[kk] = *(lh8 *)(tb + kk * 4096);
+                    tl[kk] = *(lh8 *)(tb + kk * 4096 + 1024);
+                }
+            }
             {   // issue the chunk two steps ahead: this tile's, then chunks 0 and 1 of the next tile
                 int is = cstage + 2;
                 is = is >= kGemmStages ? is - kGemmStages : is;
@@ -1128,7 +1160,6 @@ __device__ __forceinline__ void x1_mfma(const X3Args &a, lchar *smem, lchar *zbu
                 else if (more) x1_issue<NU>(a, tile + grid, cn - nchunks, is, wave, lane, smem_base, voff);
             }
             X3_STAMP(crow, 3);
-            const lchar *st = smem + cstage * C::STAGE;
             cstage = (cstage + 1 == kGemmStages) ? 0 : cstage + 1;
             if (pt == 0) {
                 // the partner's fragments (scaled by ITS power of two) and the common scale of the sample
@@ -1159,23 +1190,24 @@ __device__ __forceinline__ void x1_mfma(const X3Args &a, lchar *smem, lchar *zbu
                 gemm_lds_barrier();   // every fragment is read: the z slabs (same LDS) may be written
             }
             if (z_active) {
-                const lchar *tb = st + foff + ROLE * 2048;
-                gf32x16 z, z1;   // (two accumulator chains: a dependent MFMA waits for its predecessor's last pass)
+                // three accumulator chains, one per product term: a dependent 32x32x16 MFMA waits out its predecessor's
+                // 64-cycle latency, independent ones issue every 32 (two chains left z -> z pairs back to back: 1550
+                // cycles for 24 MFMAs)
+                gf32x16 z, z1, z2;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     z[i] = 0.f;
                     z1[i] = 0.f;
+                    z2[i] = 0.f;
                 }
 #pragma unroll
                 for (int kk = 0; kk < KK; ++kk) {
-                    const half8 th = *(lh8 *)(tb + kk * 4096);
-                    const half8 tl = *(lh8 *)(tb + kk * 4096 + 1024);
-                    z = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, hh[kk], z, 0, 0, 0);
-                    z1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, hl[kk], z1, 0, 0, 0);
-                    z = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl, hh[kk], z, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[kk], hh[kk], z, 0, 0, 0);
+                    z1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[kk], hl[kk], z1, 0, 0, 0);
+                    z2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl[kk], hh[kk], z2, 0, 0, 0);
                 }
 #pragma unroll
-                for (int i = 0; i < 16; ++i) z[i] += z1[i];
+                for (int i = 0; i < 16; ++i) z[i] += z1[i] + z2[i];
                 const lchar *ex = st + KK * 4096 + ROLE * 128;   // extras: bt (role 0) / bs (role 1), 32 floats each
                 lchar *zw = zrow + (pt & 1) * 2 * kX1ZSlab;
 #pragma unroll
@@ -1346,6 +1378,7 @@ static int x1_launch(const X3Args &a_in, hipStream_t st) {
     if (getenv("DPK_X3_TIMELINE")) {
         (void)hipMalloc(&a.dbg, 8 * 64 * 8 * 8);
         (void)hipMemset(a.dbg, 0, 8 * 64 * 8 * 8);
+        if (atoi(getenv("DPK_X3_TIMELINE")) == 2) a.accumulate = 7;
     }
 #endif
     DPK_LAUNCH(kern, dim3(grid), dim3(512), lds, st, a);

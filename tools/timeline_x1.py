@@ -16,6 +16,6 @@ with torch.no_grad():
     for i in range(3):
         flow(x)
     torch.cuda.synchronize()
-    os.environ['DPK_X3_TIMELINE'] = '1'
+    os.environ['DPK_X3_TIMELINE'] = sys.argv[1] if len(sys.argv) > 1 else '1'
     flow(x)
     torch.cuda.synchronize()
