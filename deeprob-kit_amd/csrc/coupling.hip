@@ -617,6 +617,82 @@ extern "C" int dpk_bn1d_fold(const float *weight, const float *bias, const float
     return DPK_OK;
 }
 
+// every eval-mode BatchNormLayer1d of a flow in one launch (n x D elements: the work is nothing, the launches were the
+// cost), plus the sum of their constants
+struct Bn1dFoldMany {
+    dpk_bn1d_fold_args L[16];
+    int n;
+    float *total;
+};
+__global__ __launch_bounds__(1024) void bn1d_fold_many_kernel(const Bn1dFoldMany a) {
+    // four groups of 256 threads, a layer per group and round, each with the arithmetic AND the summation order of
+    // bn1d_fold_kernel: the constants are bit-identical to the per-layer entry's
+    __shared__ float red[4][4];
+    __shared__ float cst[16];
+    const int grp = threadIdx.x >> 8, t = threadIdx.x & 255;
+    for (int l0 = 0; l0 < a.n; l0 += 4) {
+        const int l = l0 + grp;
+        const bool active = l < a.n;
+        float part = 0.f;
+        if (active) {
+            const dpk_bn1d_fold_args &q = a.L[l];
+            for (int d = t; d < q.D; d += 256) {
+                const float v = q.running_var[d] + q.eps;
+                float g, h;
+                if (!q.inverse) {
+                    g = expf(q.weight[d]) / sqrtf(v);
+                    h = q.bias[d] - q.running_mean[d] * g;
+                    part += q.weight[d] - 0.5f * logf(v);
+                } else {
+                    g = expf(-q.weight[d]) * sqrtf(v);
+                    h = q.running_mean[d] - q.bias[d] * g;
+                    part += -q.weight[d] + 0.5f * logf(v);
+                }
+                const float s0 = q.scale_in ? q.scale_in[d] : 1.f, h0 = q.shift_in ? q.shift_in[d] : 0.f;
+                q.scale_out[d] = s0 * g;
+                q.shift_out[d] = fmaf(h0, g, h);
+            }
+        }
+        part = wave_reduce_sum(part);
+        if ((t & 63) == 0) red[grp][t >> 6] = part;
+        __syncthreads();
+        if (active && t == 0) {
+            const float tot = red[grp][0] + red[grp][1] + red[grp][2] + red[grp][3];
+            const dpk_bn1d_fold_args &q = a.L[l];
+            if (q.accumulate) *q.ldj_const += tot; else *q.ldj_const = tot;
+            cst[l] = q.accumulate ? 0.f : tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && a.total) {
+        float total = 0.f;
+        for (int l = 0; l < a.n; ++l) total += cst[l];
+        *a.total = total;
+    }
+}
+
+extern "C" int dpk_bn1d_fold_many(int32_t n, const dpk_bn1d_fold_args *layers, float *ldj_total, void *stream) {
+    DPK_REQUIRE(n >= 0 && n <= 16, DPK_EINVAL, "bn1d_fold_many: n = %d (0..16)", n);
+    if (n == 0) return DPK_OK;
+    DPK_REQUIRE(layers, DPK_EINVAL, "bn1d_fold_many: null pointer");
+    Bn1dFoldMany a{};
+    a.n = n;
+    a.total = ldj_total;
+    for (int l = 0; l < n; ++l) {
+        const dpk_bn1d_fold_args &q = layers[l];
+        DPK_REQUIRE(q.weight && q.bias && q.running_var && q.running_mean && q.scale_out && q.shift_out && q.ldj_const,
+                    DPK_EINVAL, "bn1d_fold_many: null pointer in layer %d", l);
+        DPK_REQUIRE(q.D > 0 && (q.scale_in == nullptr) == (q.shift_in == nullptr), DPK_EINVAL,
+                    "bn1d_fold_many: bad arguments in layer %d", l);
+        // (the total is the sum of the constants written by this call: accumulating entries would need the old values)
+        DPK_REQUIRE(!(ldj_total && q.accumulate), DPK_EINVAL, "bn1d_fold_many: ldj_total with an accumulating layer");
+        a.L[l] = q;
+    }
+    DPK_LAUNCH(bn1d_fold_many_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+    DPK_CHECK_LAUNCH("bn1d_fold_many_kernel");
+    return DPK_OK;
+}
+
 extern "C" int dpk_affine1d_forward(const float *x, const float *scale, const float *shift, int64_t B, int32_t D,
                                     float *out, void *stream) {
     DPK_REQUIRE(B >= 0 && D > 0, DPK_EINVAL, "affine1d: bad sizes");

@@ -84,12 +84,14 @@ struct X3Check {   // 32 bytes in the workspace, zeroed by the unconditional bui
     unsigned m1, m2, tickets, gate;
 };
 constexpr int kX3CheckBlocks = 48;
-__global__ __launch_bounds__(256) void coupling_x3_check_kernel(const X3PackArgs a, X3Check *st, int verify) {
+// (bid / nblocks: the block's place among the blocks that share this layer -- the whole grid for the per-layer launch,
+// a slice of it for dpk_coupling1d_pairs_tables)
+__device__ __forceinline__ void x3_check_body(const X3PackArgs &a, X3Check *st, int verify, int bid, int nblocks) {
     __shared__ float red[2][4];
     __shared__ unsigned long long hred[4];
     const int D = a.D, U = a.U, K1 = a.g.K1, N2 = a.g.N2;
     // (32-bit indices: U K1 and 2 N2 U are a few hundred thousand; a 64-bit division per element tripled this pass)
-    const int gtid = (int)(blockIdx.x * blockDim.x + threadIdx.x), gsz = (int)(gridDim.x * blockDim.x);
+    const int gtid = (int)(bid * blockDim.x + threadIdx.x), gsz = (int)(nblocks * blockDim.x);
     float m1 = 0.f, m2 = 0.f;
     unsigned long long h = 0ull;
     // (four elements per trip, their loads requested together: one load per trip left this pass latency bound)
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void coupling_x3_check_kernel(const X3PackArgs
         atomicMax(&st->m2, __float_as_uint(fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]))));
         atomicAdd(&st->acc, (hred[0] + hred[1]) + (hred[2] + hred[3]) + (unsigned long long)(a.pm + 2 * a.affine + 1));
         __threadfence();
-        if (atomicAdd(&st->tickets, 1u) == gridDim.x - 1) {   // last block: every partial result has arrived
+        if (atomicAdd(&st->tickets, 1u) == (unsigned)nblocks - 1u) {   // last block: every partial result has arrived
             __threadfence();
             const unsigned long long sum = atomicExch(&st->acc, 0ull);
             const unsigned b1 = atomicExch(&st->m1, 0u), b2 = atomicExch(&st->m2, 0u);
@@ -175,14 +177,18 @@ __global__ __launch_bounds__(256) void coupling_x3_check_kernel(const X3PackArgs
     }
 }
 
-__global__ __launch_bounds__(256) void coupling_x3_pack_kernel(const X3PackArgs a) {
+__global__ __launch_bounds__(256) void coupling_x3_check_kernel(const X3PackArgs a, X3Check *st, int verify) {
+    x3_check_body(a, st, verify, (int)blockIdx.x, (int)gridDim.x);
+}
+
+__device__ __forceinline__ void x3_pack_body(const X3PackArgs &a, int bid, int nblocks) {
     if (gate_closed(a.gate)) return;
     const int D = a.D, U = a.U, NU = a.g.NU, K1 = a.g.K1, N2 = a.g.N2;
     const int64_t n1 = (int64_t)a.g.NCH1 * 2 * NU * 64;           // W1 fragment entries (hi + lo written together)
     const int64_t n2 = (int64_t)a.g.NPT * (U / 16) * 2 * 64;      // W2 fragment entries
     const int64_t n3 = (int64_t)a.g.NPT * 32;                     // per-variable extras
     const int64_t total = n1 + n2 + n3 + U;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t e = (int64_t)bid * blockDim.x + threadIdx.x; e < total; e += (int64_t)nblocks * blockDim.x) {
         if (e < n1) {
             const int l = (int)(e & 63);
             const int64_t r = e >> 6;
@@ -250,6 +256,28 @@ __global__ __launch_bounds__(256) void coupling_x3_pack_kernel(const X3PackArgs 
             a.b1f[unit] = v;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void coupling_x3_pack_kernel(const X3PackArgs a) {
+    x3_pack_body(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Several layers per launch (dpk_coupling1d_pairs_tables): kX3CheckBlocks / kX3PackBlocks blocks per layer.  The
+// layers' argument blocks travel as kernel arguments (16 x ~140 bytes).
+constexpr int kX3ManyMax = 16;
+constexpr int kX3PackBlocks = 96;
+struct X3ManyArgs {
+    X3PackArgs L[kX3ManyMax];
+    X3Check *st[kX3ManyMax];
+    int verify[kX3ManyMax];
+};
+__global__ __launch_bounds__(256) void coupling_x3_check_many_kernel(const X3ManyArgs m) {
+    const int l = (int)blockIdx.x / kX3CheckBlocks;
+    x3_check_body(m.L[l], m.st[l], m.verify[l], (int)blockIdx.x - l * kX3CheckBlocks, kX3CheckBlocks);
+}
+__global__ __launch_bounds__(256) void coupling_x3_pack_many_kernel(const X3ManyArgs m) {
+    const int l = (int)blockIdx.x / kX3PackBlocks;
+    x3_pack_body(m.L[l], (int)blockIdx.x - l * kX3PackBlocks, kX3PackBlocks);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1499,6 +1527,40 @@ static int x3_forward_common(const float *x, int64_t B, int32_t D, int32_t maske
         case 3: return affine ? x3_launch<true, 3>(a, st) : x3_launch<false, 3>(a, st);
         default: return affine ? x3_launch<true, 4>(a, st) : x3_launch<false, 4>(a, st);
     }
+}
+
+extern "C" int dpk_coupling1d_pairs_tables(int32_t n, const dpk_pairs_tables_args *layers, void *stream) {
+    DPK_REQUIRE(n >= 0 && n <= kX3ManyMax, DPK_EINVAL, "coupling1d_pairs_tables: n = %d (0..%d)", n, kX3ManyMax);
+    if (n == 0) return DPK_OK;
+    DPK_REQUIRE(layers, DPK_EINVAL, "coupling1d_pairs_tables: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    X3ManyArgs m{};
+    for (int l = 0; l < n; ++l) {
+        const dpk_pairs_tables_args &q = layers[l];
+        DPK_REQUIRE(q.D > 0 && q.units > 0 && (q.masked_parity == 0 || q.masked_parity == 1), DPK_EINVAL,
+                    "coupling1d_pairs_tables: bad sizes in layer %d", l);
+        DPK_REQUIRE(x3_shape_ok(q.D, q.units), DPK_EUNSUPPORTED, "coupling1d_pairs_tables: D=%d units=%d not built", q.D, q.units);
+        DPK_REQUIRE(q.W1 && q.b1 && q.W2 && q.b2 && q.ws, DPK_EINVAL, "coupling1d_pairs_tables: null pointer in layer %d", l);
+        DPK_REQUIRE((q.in_scale == nullptr) == (q.in_shift == nullptr), DPK_EINVAL, "coupling1d_pairs_tables: scale/shift mismatch");
+        const X3Geom g = x3_geom(q.D, q.units);
+        const X3Ws w = x3_carve(q.ws, g, q.units);
+        DPK_REQUIRE(q.ws_bytes >= w.bytes, DPK_EWORKSPACE, "coupling1d_pairs_tables: workspace %lld < %lld",
+                    (long long)q.ws_bytes, (long long)w.bytes);
+        const bool verify = (q.flags & DPK_FLAG_PARAMS_VERIFY) != 0;
+        if (!verify)   // (the workspace may be fresh memory: the check state starts from zero)
+            DPK_REQUIRE(hipMemsetAsync(w.check, 0, sizeof(X3Check), st) == hipSuccess, DPK_ELAUNCH, "memset");
+        X3PackArgs &p = m.L[l];
+        p.W1 = q.W1; p.b1 = q.b1; p.W2 = q.W2; p.b2 = q.b2; p.in_scale = q.in_scale; p.in_shift = q.in_shift;
+        p.D = q.D; p.U = q.units; p.pm = q.masked_parity; p.affine = q.affine; p.g = g;
+        p.w1t = w.w1t; p.w2t = w.w2t; p.b1f = w.b1f; p.scales = w.scales;
+        p.gate = &w.check->gate;
+        m.st[l] = w.check;
+        m.verify[l] = verify ? 1 : 0;
+    }
+    DPK_LAUNCH(coupling_x3_check_many_kernel, dim3(n * kX3CheckBlocks), dim3(256), 0, st, m);
+    DPK_LAUNCH(coupling_x3_pack_many_kernel, dim3(n * kX3PackBlocks), dim3(256), 0, st, m);
+    DPK_CHECK_LAUNCH("coupling_x3_pack_many_kernel");
+    return DPK_OK;
 }
 
 extern "C" int dpk_coupling1d_pairs_forward(const float *x, int64_t B, int32_t D, int32_t masked_parity,

@@ -113,6 +113,16 @@ class NormalizingFlow(ProbabilisticModel):
 
     def _forward_fused(self, x: torch.Tensor, pre_ildj) -> torch.Tensor:
         from deeprob.hip import ops_flows
+        # (one batched fold of the batch norms and one verification pass over the couplings' tables for the whole forward:
+        # three launches instead of three per layer; the operators below then run their main kernels only)
+        ops_flows.flow1d_prepare(self, list(self.layers), x)
+        try:
+            return self._forward_fused_layers(x, pre_ildj)
+        finally:
+            ops_flows.flow1d_release()
+
+    def _forward_fused_layers(self, x: torch.Tensor, pre_ildj) -> torch.Tensor:
+        from deeprob.hip import ops_flows
         affine, ldj_const, ildj = None, [], None
         if torch.is_tensor(pre_ildj):
             ildj = pre_ildj.to(torch.float32).contiguous().clone()

@@ -5,6 +5,7 @@ Density direction (`apply_backward`, what `log_prob` / training uses): forward a
 (`apply_forward`): forward only -- asking autograd for a graph through it raises instead of silently returning a
 detached result.
 """
+import ctypes
 from typing import Optional, Tuple
 
 import torch
@@ -20,6 +21,136 @@ def _versions(*tensors) -> tuple:
 def _trusting() -> bool:
     from deeprob import hip
     return hip._trust_versions
+
+
+# ---- one verification pass per flow forward (round 3) -----------------------------------------------------------------
+# NormalizingFlow._forward_fused calls flow1d_prepare once: every eval-mode BatchNormLayer1d is folded by ONE launch
+# (dpk_bn1d_fold_many, which also leaves the sum of the constant log-determinants) and the packed tables of every
+# alternating-mask coupling are fingerprinted / rebuilt by TWO launches (dpk_coupling1d_pairs_tables) -- instead of three
+# small launches per layer.  The per-layer operators below recognise the forward's token and skip their own launches.
+_prep_token = None
+
+
+class _BnFoldArgs(ctypes.Structure):          # dpk_bn1d_fold_args
+    _fields_ = [(n, ctypes.c_void_p) for n in ('weight', 'bias', 'running_var', 'running_mean', 'scale_in', 'shift_in',
+                                               'scale_out', 'shift_out', 'ldj_const')] + \
+               [('eps', ctypes.c_float), ('D', ctypes.c_int32), ('inverse', ctypes.c_int32), ('accumulate', ctypes.c_int32)]
+
+
+class _PairsTablesArgs(ctypes.Structure):     # dpk_pairs_tables_args
+    _fields_ = [(n, ctypes.c_void_p) for n in ('W1', 'b1', 'W2', 'b2', 'in_scale', 'in_shift', 'ws')] + \
+               [('ws_bytes', ctypes.c_int64), ('D', ctypes.c_int32), ('units', ctypes.c_int32),
+                ('masked_parity', ctypes.c_int32), ('affine', ctypes.c_int32), ('flags', ctypes.c_uint32)]
+
+
+def _prepared(obj) -> bool:
+    return _prep_token is not None and getattr(obj, '_prep_token', None) is _prep_token
+
+
+def flow1d_release():
+    global _prep_token
+    _prep_token = None
+
+
+def flow1d_prepare(flow, layers, x: torch.Tensor):
+    """Fold the batch norms and verify the coupling tables of one density evaluation in three launches (see above).
+    Layers outside the batched entries' envelope are left to their own operators.  No-op when the version counters are
+    trusted (nothing is launched per call then) or for host tensors (the operators raise)."""
+    global _prep_token
+    _prep_token = None
+    if _trusting() or not x.is_cuda or x.dim() != 2 or x.dtype != torch.float32 or len(layers) > 32:
+        return
+    from deeprob.flows.utils import BatchNormLayer1d
+    lib = load_library()
+    dev = x.device
+    token = object()
+    # ---- batch norms whose input is not another batch norm's output (the fold chain restarts behind every coupling)
+    bn_idx = [i for i, l in enumerate(layers) if isinstance(l, BatchNormLayer1d)]
+    simple = [i for i in bn_idx if i == 0 or not isinstance(layers[i - 1], BatchNormLayer1d)]
+    entries, folded = [], {}
+    for i in simple[:16]:
+        bn = layers[i]
+        if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+                   for t in (bn.weight, bn.bias, bn.running_var, bn.running_mean)):
+            continue
+        D = bn.in_features
+        key = (_versions(bn.weight, bn.bias, bn.running_var, bn.running_mean, None, None), False, float(bn.eps))
+        hit = getattr(bn, '_fold_cache', None)
+        if hit is None or hit[0] != key:
+            hit = (key, (torch.empty(D, dtype=torch.float32, device=dev), torch.empty(D, dtype=torch.float32, device=dev)),
+                   torch.empty(1, dtype=torch.float32, device=dev), (None, None))
+            bn._fold_cache = hit
+        (sc, sh), own = hit[1], hit[2]
+        entries.append(_BnFoldArgs(ptr(bn.weight), ptr(bn.bias), ptr(bn.running_var), ptr(bn.running_mean), None, None, ptr(sc), ptr(sh), ptr(own), float(bn.eps),
+                                   D, 0, 0))
+        folded[i] = (bn, hit)
+    if entries:
+        total = None
+        if len(folded) == len(bn_idx):      # every constant comes from this launch: their sum too (sum_constants' tensor)
+            consts = [folded[i][1][2] for i in bn_idx]
+            ckey = tuple(id(t) for t in consts)
+            chit = getattr(flow, '_const_sum_cache', None)
+            if chit is None or chit[0] != ckey:
+                chit = (ckey, torch.empty(1, dtype=torch.float32, device=dev), list(consts))
+                flow._const_sum_cache = chit
+            total = chit[1]
+        arr = (_BnFoldArgs * len(entries))(*entries)
+        check(lib.dpk_bn1d_fold_many(len(entries), ctypes.cast(arr, ctypes.c_void_p), ptr(total), stream_ptr(dev)),
+              'dpk_bn1d_fold_many')
+        for bn, _ in folded.values():
+            bn._prep_token = token
+        if total is not None:
+            flow._const_sum_token = token
+    # ---- couplings inside the column-pair kernel's envelope (the tests of coupling1d / coupling1d_logprob)
+    centries, marked = [], []
+    for i, layer in enumerate(layers):
+        if isinstance(layer, BatchNormLayer1d) or len(centries) == 16:
+            continue
+        net = getattr(layer, 'network', None)
+        if net is None or len(net) != 3:
+            continue
+        lin1, lin2 = net[0], net[-1]
+        units, D = lin1.weight.shape[0], x.shape[1]
+        parity = layer._pair_parity()
+        if parity is None or units not in (32, 64, 96, 128) or D % 8 != 0 or not lin1.weight.is_cuda:
+            continue
+        if lin1.weight.dtype != torch.float32 or not all(t.is_contiguous() for t in (lin1.weight, lin1.bias, lin2.weight, lin2.bias)):
+            continue
+        if i > 0 and isinstance(layers[i - 1], BatchNormLayer1d):
+            if (i - 1) not in folded:
+                continue            # a chain of batch norms in front: the per-layer route folds and verifies it
+            sc, sh = folded[i - 1][1][1]
+        else:
+            sc, sh = None, None
+        n = lib.dpk_coupling1d_pairs_workspace_bytes(D, units)
+        if n < 0:
+            continue
+        pw = layer._ws_pairs
+        ws = pw.get(n, dev)
+        w1, b1, w2, b2 = lin1.weight, lin1.bias, lin2.weight, lin2.bias
+        key = (_versions(w1, b1, w2, b2, sc, sh), parity, bool(layer.affine))
+        flags = cached_tables_flag() if pw.params_key == key else 0
+        pw.params_key = key
+        centries.append(_PairsTablesArgs(ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(sc), ptr(sh), ptr(ws), ws.numel(), D, units,
+                                         parity, int(layer.affine), flags))
+        marked.append((pw, key))
+    if centries:
+        arr = (_PairsTablesArgs * len(centries))(*centries)
+        check(lib.dpk_coupling1d_pairs_tables(len(centries), ctypes.cast(arr, ctypes.c_void_p), stream_ptr(dev)),
+              'dpk_coupling1d_pairs_tables')
+        for pw, key in marked:
+            pw._prep_token = token
+            pw._prep_key = key
+    _prep_token = token
+
+
+def _tables_flags(pw, key) -> int:
+    """Flags of a column-pair call: tables verified by this forward's flow1d_prepare are taken as they are."""
+    if _prepared(pw) and getattr(pw, '_prep_key', None) == key:
+        return DPK_FLAG_PARAMS_CACHED
+    flags = cached_tables_flag() if pw.params_key == key else 0
+    pw.params_key = key
+    return flags
 
 
 def _no_graph(*tensors):
@@ -68,8 +199,7 @@ def coupling1d(x: torch.Tensor, layer, inverse: bool, in_affine: Optional[Tuple[
             w1, b1 = require_device_f32(lin1.weight, 'W1'), require_device_f32(lin1.bias, 'b1')
             w2, b2 = require_device_f32(lin2.weight, 'W2'), require_device_f32(lin2.bias, 'b2')
             key = (_versions(w1, b1, w2, b2, sc, sh), parity, bool(layer.affine))
-            flags = cached_tables_flag() if pw.params_key == key else 0
-            pw.params_key = key
+            flags = _tables_flags(pw, key)
             check(lib.dpk_coupling1d_pairs_forward(
                 ptr(x), B, D, parity, ptr(w1), ptr(b1), ptr(w2), ptr(b2), units, ptr(act), ptr(sc), ptr(sh),
                 int(layer.affine), int(inverse), ptr(out), ptr(ldj_p), int(ldj is not None), ptr(ws), ws.numel(), flags,
@@ -122,8 +252,7 @@ def coupling1d_logprob(x: torch.Tensor, layer, in_affine, ildj: Optional[torch.T
     w1, b1 = require_device_f32(lin1.weight, 'W1'), require_device_f32(lin1.bias, 'b1')
     w2, b2 = require_device_f32(lin2.weight, 'W2'), require_device_f32(lin2.bias, 'b2')
     key = (_versions(w1, b1, w2, b2, sc, sh), parity, bool(layer.affine))
-    flags = cached_tables_flag() if pw.params_key == key else 0
-    pw.params_key = key
+    flags = _tables_flags(pw, key)
     ll = torch.empty(B, dtype=torch.float32, device=x.device)
     rc = lib.dpk_coupling1d_pairs_logprob(
         ptr(x), B, D, parity, ptr(w1), ptr(b1), ptr(w2), ptr(b2), units, ptr(act), ptr(sc), ptr(sh), int(layer.affine),
@@ -207,7 +336,7 @@ def bn1d_fold(bn, inverse: bool, in_affine=None, ldj_const: Optional[torch.Tenso
         # (s_in / h_in are kept alive with the entry: their addresses are part of the key)
         hit = (key, (sc, sh), own, (s_in, h_in))
         bn._fold_cache = hit
-    if fresh or not _trusting():
+    if (fresh or not _trusting()) and not (not fresh and not inverse and in_affine is None and _prepared(bn)):
         # The fold is one D-element kernel: it runs on every call (into the SAME tensors), so that a write through
         # `.data` of a statistic or parameter -- which moves no version counter -- is folded in; the coupling behind it
         # fingerprints these tensors on the device.  With hip.trust_version_counters(True) it runs on a key change only.
@@ -237,7 +366,7 @@ def sum_constants(owner, consts) -> Optional[torch.Tensor]:
     if hit is None or hit[0] != key:
         hit = (key, torch.stack([t.reshape(()) for t in consts]).sum().reshape(1), list(consts))   # (keeps them alive)
         owner._const_sum_cache = hit
-    elif not _trusting():
+    elif not _trusting() and not (_prep_token is not None and getattr(owner, '_const_sum_token', None) is _prep_token):
         # (bn1d_fold rewrites the constants in place on every call: the total follows them, into the same tensor)
         torch.sum(torch.stack([t.reshape(()) for t in consts]), dim=0, keepdim=True, out=hit[1])
     return hit[1]

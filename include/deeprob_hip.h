@@ -234,6 +234,20 @@ int dpk_coupling1d_pairs_logprob(const float *x, int64_t B, int32_t D, int32_t m
                                  const float *base_scale, const float *ildj_in, const float *ildj_const, float *ll,
                                  void *ws, int64_t ws_bytes, uint32_t flags, void *stream);
 
+/* The parameter tables of n alternating-mask couplings verified / rebuilt in TWO launches (one fingerprint pass, one
+ * gated pack pass over all layers) instead of two per layer: afterwards each layer's dpk_coupling1d_pairs_forward /
+ * _logprob may be called with DPK_FLAG_PARAMS_CACHED.  Entry i carries the table-related arguments of those calls;
+ * flags = DPK_FLAG_PARAMS_VERIFY: rebuild only if the parameters' fingerprint differs from the one the tables in ws
+ * were built from; 0: rebuild.  n <= 16.                                                                          */
+typedef struct dpk_pairs_tables_args {
+    const float *W1, *b1, *W2, *b2, *in_scale, *in_shift;
+    void *ws;
+    int64_t ws_bytes;
+    int32_t D, units, masked_parity, affine;
+    uint32_t flags;
+} dpk_pairs_tables_args;
+int dpk_coupling1d_pairs_tables(int32_t n, const dpk_pairs_tables_args *layers, void *stream);
+
 /* Eval-mode BatchNormLayer1d.apply_backward (inverse = 0) / apply_forward (1)
  * (deeprob/flows/utils.py:118-153) as a per-variable affine y = x*scale_out + shift_out
  * composed with an optional incoming affine; ldj_const [1] = its (constant) log-det,
@@ -242,6 +256,17 @@ int dpk_bn1d_fold(const float *weight, const float *bias, const float *running_v
                   const float *running_mean, float eps, int32_t D, int32_t inverse, const float *scale_in,
                   const float *shift_in, float *scale_out, float *shift_out, float *ldj_const,
                   int32_t accumulate, void *stream);
+/* Every eval-mode BatchNormLayer1d of a flow in ONE launch (round 3): NormalizingFlow.log_prob walks its layers in a
+ * Python loop (flows/models/base.py:182-193); per layer the fold above is a 5 us launch of a D-element kernel.  Entry i
+ * is the argument list of dpk_bn1d_fold (scale_in / shift_in must not be outputs of another entry of the same call);
+ * ldj_total (may be NULL) receives the sum of the n constants.                                                    */
+typedef struct dpk_bn1d_fold_args {
+    const float *weight, *bias, *running_var, *running_mean, *scale_in, *shift_in;
+    float *scale_out, *shift_out, *ldj_const;
+    float eps;
+    int32_t D, inverse, accumulate;
+} dpk_bn1d_fold_args;
+int dpk_bn1d_fold_many(int32_t n, const dpk_bn1d_fold_args *layers, float *ldj_total, void *stream);
 /* out[b,d] = x[b,d]*scale[d] + shift[d]  (materialises a folded BatchNormLayer1d). */
 int dpk_affine1d_forward(const float *x, const float *scale, const float *shift, int64_t B, int32_t D,
                          float *out, void *stream);

@@ -116,6 +116,42 @@ def test_round2_entry_error_codes():
     assert pairs(parity=2) == DPK_EINVAL
     assert pairs(w1=None) == DPK_EINVAL
     assert pairs(nbytes=64) == DPK_EWORKSPACE
+    # --- the same tables through the batched entry (round 3): built by it, then used with DPK_FLAG_PARAMS_CACHED ----------
+    import ctypes
+    from deeprob.hip import DPK_FLAG_PARAMS_CACHED, DPK_FLAG_PARAMS_VERIFY
+    from deeprob.hip.ops_flows import _PairsTablesArgs, _BnFoldArgs
+    want = out.clone()
+    ws2 = torch.zeros(n, dtype=torch.uint8, device='cuda')
+
+    def tables(k=1, flags=0, d=D, nbytes=n, w1=W1):
+        arr = (_PairsTablesArgs * max(k, 1))(*[_PairsTablesArgs(ptr(w1), ptr(b1), ptr(W2), ptr(b2), None, None, ptr(ws2), nbytes,
+                                                                d, U, 0, 1, flags) for _ in range(max(k, 1))])
+        return lib.dpk_coupling1d_pairs_tables(k, ctypes.cast(arr, ctypes.c_void_p), st)
+    assert tables() == 0
+    out2 = torch.empty_like(x)
+    assert lib.dpk_coupling1d_pairs_forward(ptr(x), B, D, 0, ptr(W1), ptr(b1), ptr(W2), ptr(b2), U, ptr(act), None, None, 1, 0,
+                                            ptr(out2), ptr(ldj), 0, ptr(ws2), n, DPK_FLAG_PARAMS_CACHED, st) == 0
+    assert torch.equal(out2, want)
+    assert tables(flags=DPK_FLAG_PARAMS_VERIFY) == 0              # unchanged parameters: the gate stays closed
+    assert tables(k=0) == 0 and tables(k=17) == DPK_EINVAL
+    assert tables(d=12) == DPK_EUNSUPPORTED and tables(w1=None) == DPK_EINVAL and tables(nbytes=64) == DPK_EWORKSPACE
+    # --- batched BatchNormLayer1d fold: bit-identical to the per-layer entry, plus the sum of the constants ---------------
+    Dn, nl = 50, 6
+    prm = [[torch.randn(Dn, device='cuda') * 0.3, torch.randn(Dn, device='cuda'), torch.rand(Dn, device='cuda') + 0.1,
+            torch.randn(Dn, device='cuda')] for _ in range(nl)]
+    one = [[torch.empty(Dn, device='cuda'), torch.empty(Dn, device='cuda'), torch.empty(1, device='cuda')] for _ in range(nl)]
+    many = [[torch.empty(Dn, device='cuda'), torch.empty(Dn, device='cuda'), torch.empty(1, device='cuda')] for _ in range(nl)]
+    for (w, b, v, m), (sc, sh, c) in zip(prm, one):
+        assert lib.dpk_bn1d_fold(ptr(w), ptr(b), ptr(v), ptr(m), 1e-5, Dn, 0, None, None, ptr(sc), ptr(sh), ptr(c), 0, st) == 0
+    total = torch.empty(1, device='cuda')
+    arr = (_BnFoldArgs * nl)(*[_BnFoldArgs(ptr(w), ptr(b), ptr(v), ptr(m), None, None, ptr(sc), ptr(sh), ptr(c), 1e-5, Dn, 0, 0)
+                               for (w, b, v, m), (sc, sh, c) in zip(prm, many)])
+    assert lib.dpk_bn1d_fold_many(nl, ctypes.cast(arr, ctypes.c_void_p), ptr(total), st) == 0
+    for a3, b3 in zip(one, many):
+        assert all(torch.equal(p, q) for p, q in zip(a3, b3))
+    assert abs(total.item() - sum(c.item() for _, _, c in one)) <= 1e-4 * max(1.0, abs(total.item()))
+    assert lib.dpk_bn1d_fold_many(17, ctypes.cast(arr, ctypes.c_void_p), None, st) == DPK_EINVAL
+    assert lib.dpk_bn1d_fold_many(nl, None, None, st) == DPK_EINVAL
     # --- fused product + sum level of a DGC-SPN, forward and backward --------------------------------------------
     C, H, W, OH, OW = 8, 6, 6, 7, 7                               # 2x2 taps, 'full' padding 1, dilation 1
     xin = torch.randn(4, C, H, W, device='cuda')
