@@ -127,7 +127,9 @@ def test_column_pair_kernels_shapes_vs_oracle(D, units, affine):
             for p in layer.network.parameters():
                 p.copy_(torch.randn(p.shape, generator=gen) * (1.0 / D ** 0.5))
         lins = [(m.weight.detach().cpu(), m.bias.detach().cpu()) for m in layer.network if isinstance(m, torch.nn.Linear)]
-        for B in (1, 63, 64, 65, 200):
+        # (20001 rows at D = 784: 313 tiles on 256 work-groups -- two tiles per work-group, the ring and the holders'
+        # last epilogue crossing a tile boundary, and a one-row last tile)
+        for B in (1, 63, 64, 65, 200) + ((20001,) if D == 784 and units == 128 else ()):
             x = torch.randn(B, D, generator=gen)
             with torch.no_grad():
                 u, ildj = layer.apply_backward(x.cuda())
