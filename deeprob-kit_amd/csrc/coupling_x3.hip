@@ -821,7 +821,7 @@ __device__ __forceinline__ void x1_epilogue(const gf32x4 *xk, const lchar *zb, f
             gf32x2 e;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const float c = fminf(fmaxf(zz[i], -15.f), 15.f);
+                const float c = __builtin_amdgcn_fmed3f(zz[i], -15.f, 15.f);   // (one instruction; NaN -> -15 like fmaxf first)
                 e[i] = __builtin_amdgcn_exp2f(c * 2.8853900817779268f);
             }
             const gf32x2 ep = e + 1.f;
@@ -924,7 +924,9 @@ __device__ __forceinline__ void x1_holder(const X3Args &a, lchar *smem, lchar *z
                         const gf32x4 v = *(lf4 *)(st + (unsigned)(rl * 256 + (((4 * i + q) ^ (rl & 15)) << 4)));
                         const gf32x4 sc = *(lf4 *)(aff_l + col0 + 16 * i), sh = *(lf4 *)(aff_l + D + col0 + 16 * i);
                         xr[c < kX1FullCh ? c : 0][i] = v * sc + sh;
-                        __builtin_amdgcn_sched_barrier(0);   // (register pressure: one 16-byte piece at a time)
+                        // (register pressure: one 16-byte piece at a time once most of the tile is held; the early chunks'
+                        // twelve LDS reads go out together)
+                        if (c >= 7) __builtin_amdgcn_sched_barrier(0);
                     }
                 } else {   // the 16-column tail chunk: piece q of row rl
                     const int col0 = 64 * c + 4 * q;
