@@ -297,11 +297,12 @@ static void launch_product_bwd(const float *g, int64_t B, const ProdGeom &q, flo
 // Sum layer: out[b,o,p] = logsumexp_c(x[b,c,p] + log_softmax(weight, 1)[o,c,p])
 // ------------------------------------------------------------------------------------------------
 // softmax over the input channels for every (o, p): W, LW [Cout, Cin, HW]
-__global__ void spatial_softmax_kernel(const float *__restrict__ w, int Cout, int Cin, int HW,
-                                       float *__restrict__ Wl, float *__restrict__ LW, const unsigned *gate = nullptr) {
-    if (gate_closed(gate)) return;   // (tables still match the live weights: common.h params_gate)
+// (bid / nblocks: the block's place among the blocks that share this table -- the whole grid for the per-level launch,
+// a slice of it for dpk_spatial_tables)
+__device__ __forceinline__ void spatial_softmax_body(const float *__restrict__ w, int Cout, int Cin, int HW,
+                                                     float *__restrict__ Wl, float *__restrict__ LW, int bid, int nblocks) {
     const int64_t n = (int64_t)Cout * HW;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t e = (int64_t)bid * blockDim.x + threadIdx.x; e < n; e += (int64_t)nblocks * blockDim.x) {
         const int p = (int)(e % HW), o = (int)(e / HW);
         const float *src = w + (int64_t)o * Cin * HW + p;
         float m = -INFINITY;
@@ -317,6 +318,11 @@ __global__ void spatial_softmax_kernel(const float *__restrict__ w, int Cout, in
             Wl[((int64_t)o * Cin + c) * HW + p] = expf(d) / s;
         }
     }
+}
+__global__ void spatial_softmax_kernel(const float *__restrict__ w, int Cout, int Cin, int HW,
+                                       float *__restrict__ Wl, float *__restrict__ LW, const unsigned *gate = nullptr) {
+    if (gate_closed(gate)) return;   // (tables still match the live weights: common.h params_gate)
+    spatial_softmax_body(w, Cout, Cin, HW, Wl, LW, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // thread per (b, p); exp-domain with the row maximum, exact two-pass fallback when the scaled sum
@@ -698,11 +704,9 @@ __global__ __launch_bounds__(256) void spatial_prodsum_fwd_kernel(const float *_
 //   per-lane online log-sum-exp in the log domain for up to kRootK classes at a time, then a wave combine.
 // ------------------------------------------------------------------------------------------------
 // one 256-thread block per row (rows are thousands of entries long, there are only a few of them)
-__global__ __launch_bounds__(256) void rowwise_logsoftmax_kernel(const float *__restrict__ w, int rows, int n,
-                                                                  float *__restrict__ LW, const unsigned *gate = nullptr) {
+__device__ __forceinline__ void rowwise_logsoftmax_body(const float *__restrict__ w, int row, int n, float *__restrict__ LW) {
     __shared__ float red[4];
-    if (gate_closed(gate)) return;
-    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *src = w + (int64_t)row * n;
     float mx = -INFINITY;
     for (int i = tid; i < n; i += 256) mx = fmaxf(mx, src[i]);
@@ -718,6 +722,35 @@ __global__ __launch_bounds__(256) void rowwise_logsoftmax_kernel(const float *__
     __syncthreads();
     const float ls = logf((red[0] + red[1]) + (red[2] + red[3]));
     for (int i = tid; i < n; i += 256) LW[(int64_t)row * n + i] = src[i] - mx - ls;
+}
+__global__ __launch_bounds__(256) void rowwise_logsoftmax_kernel(const float *__restrict__ w, int rows, int n,
+                                                                  float *__restrict__ LW, const unsigned *gate = nullptr) {
+    if (gate_closed(gate)) return;
+    rowwise_logsoftmax_body(w, (int)blockIdx.x, n, LW);
+}
+
+// The softmaxed-weight tables of several levels of a model (and the root's log-softmax rows) in ONE launch
+// (dpk_spatial_tables): DgcSpn.forward walks its levels in a Python loop (reference dgcspn.py:134-151) and every level's
+// entry point rebuilt its table with a 9 us launch of its own before its main kernel.
+constexpr int kSpTablesMax = 8;
+struct SpTablesArgs {
+    const float *w[kSpTablesMax];
+    float *Wl[kSpTablesMax], *LW[kSpTablesMax];
+    int Cout[kSpTablesMax], Cin[kSpTablesMax], HW[kSpTablesMax], blk0[kSpTablesMax + 1];
+    int n;
+    const float *rw;     // root weight [K, M] or null
+    float *rLW;
+    int K, M;
+};
+__global__ __launch_bounds__(256) void spatial_tables_many_kernel(const SpTablesArgs a) {
+    const int bid = (int)blockIdx.x;
+    if (bid >= a.blk0[a.n]) {   // (uniform per block) the root's rows
+        rowwise_logsoftmax_body(a.rw, bid - a.blk0[a.n], a.M, a.rLW);
+        return;
+    }
+    int l = 0;
+    while (l + 1 < a.n && bid >= a.blk0[l + 1]) ++l;
+    spatial_softmax_body(a.w[l], a.Cout[l], a.Cin[l], a.HW[l], a.Wl[l], a.LW[l], bid - a.blk0[l], a.blk0[l + 1] - a.blk0[l]);
 }
 
 constexpr int kRootK = 4;
@@ -1327,5 +1360,37 @@ extern "C" int dpk_spatial_prodroot_forward(const float *in, int64_t B, int32_t 
     DPK_LAUNCH(rowwise_logsoftmax_kernel, dim3(K), dim3(256), 0, st, weight, K, M, LW);
     DPK_LAUNCH(spatial_prodroot_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, in, LW, B, q, K, out);
     DPK_CHECK_LAUNCH("spatial_prodroot_fwd_kernel");
+    return DPK_OK;
+}
+
+extern "C" int dpk_spatial_tables(int32_t n, const dpk_spatial_tables_args *levels, void *stream) {
+    DPK_REQUIRE(n >= 0 && n <= kSpTablesMax, DPK_EINVAL, "spatial_tables: n = %d (0..%d)", n, kSpTablesMax);
+    if (n == 0) return DPK_OK;
+    DPK_REQUIRE(levels, DPK_EINVAL, "spatial_tables: null pointer");
+    SpTablesArgs a{};
+    a.n = n;
+    int blocks = 0;
+    for (int l = 0; l < n; ++l) {
+        const dpk_spatial_tables_args &q = levels[l];
+        DPK_REQUIRE(q.sum_weight && q.ws && q.C > 0 && q.Cout > 0 && q.OHW > 0, DPK_EINVAL, "spatial_tables: bad level %d", l);
+        const int64_t seg = align_up((int64_t)q.Cout * q.C * q.OHW * 4, 256);
+        DPK_REQUIRE(q.ws_bytes >= 2 * seg, DPK_EWORKSPACE, "spatial_tables: workspace of level %d too small", l);
+        a.w[l] = q.sum_weight;
+        a.Wl[l] = (float *)q.ws;
+        a.LW[l] = (float *)((char *)q.ws + seg);
+        a.Cout[l] = q.Cout; a.Cin[l] = q.C; a.HW[l] = q.OHW;
+        a.blk0[l] = blocks;
+        blocks += grid_cap((int64_t)q.Cout * q.OHW, 256, 64);
+        if (q.root_weight) {
+            DPK_REQUIRE(a.rw == nullptr && q.K > 0 && q.M > 0, DPK_EINVAL, "spatial_tables: one root per call");
+            DPK_REQUIRE(q.ws_bytes >= 2 * seg + (int64_t)q.K * q.M * 4, DPK_EWORKSPACE, "spatial_tables: root workspace too small");
+            a.rw = q.root_weight;
+            a.rLW = (float *)((char *)q.ws + 2 * seg);
+            a.K = q.K; a.M = q.M;
+        }
+    }
+    a.blk0[n] = blocks;
+    DPK_LAUNCH(spatial_tables_many_kernel, dim3(blocks + (a.rw ? a.K : 0)), dim3(256), 0, (hipStream_t)stream, a);
+    DPK_CHECK_LAUNCH("spatial_tables_many_kernel");
     return DPK_OK;
 }

@@ -188,6 +188,7 @@ SIGNATURES = {
     'dpk_spatial_sumprodroot_workspace_bytes_batch': (_i64, [_i64, _i32, _i32, _i32, _c_void, _i32, _c_void, _i32]),
     'dpk_spatial_sumprodroot_forward': (ctypes.c_int, [_c_void, _i64, _i32, _i32, _i32, _c_void, _c_void, _i32, _c_void,
                                                        _c_void, _i32, _c_void, _c_void, _i64, _u32, _c_void]),
+    'dpk_spatial_tables': (ctypes.c_int, [_i32, _c_void, _c_void]),
     'dpk_bn1d_fold_many': (ctypes.c_int, [_i32, _c_void, _c_void, _c_void]),
     'dpk_coupling1d_pairs_tables': (ctypes.c_int, [_i32, _c_void, _c_void]),
     'dpk_flat_spn_workspace_bytes': (_i64, [_i64, _i32, _i32]),

@@ -3,6 +3,8 @@
 Every operator calls the C ABI directly and raises when the library or a device tensor is missing;
 there is no CPU path.
 """
+import ctypes
+
 import torch
 
 from deeprob.hip import (load_library, check, ptr, stream_ptr, require_device_f32, Workspace, DPK_FLAG_PARAMS_CACHED,
@@ -134,12 +136,94 @@ class SpatialSumFn(torch.autograd.Function):
         return gx, gw, None
 
 
+# ---- one table launch per DgcSpn.forward (round 3) ----------------------------------------------------------------------
+# DgcSpn.forward (evaluation) calls tables_prepare once with the levels its loop is about to take: their softmaxed-weight
+# tables (and the root's log-softmax rows) are rebuilt by ONE launch (dpk_spatial_tables) -- rebuilding is the check of
+# these tables, see _tables_flag -- and the level operators below recognise the forward's token and pass
+# DPK_FLAG_PARAMS_CACHED instead of launching a softmax kernel each.
+_prep_token = None
+
+
+class _SpatialTablesArgs(ctypes.Structure):     # dpk_spatial_tables_args
+    _fields_ = [('sum_weight', ctypes.c_void_p), ('ws', ctypes.c_void_p), ('ws_bytes', ctypes.c_int64),
+                ('root_weight', ctypes.c_void_p), ('C', ctypes.c_int32), ('Cout', ctypes.c_int32), ('OHW', ctypes.c_int32),
+                ('K', ctypes.c_int32), ('M', ctypes.c_int32)]
+
+
+def _weights_key(route, *weights):
+    return (route,) + tuple((w.data_ptr(), tuple(w.shape), w._version) for w in weights)
+
+
+def tables_release():
+    global _prep_token
+    _prep_token = None
+
+
+def tables_prepare(levels, x: torch.Tensor):
+    """levels: [('prodsum', product layer, sum layer)] ... optionally ending with ('sumprodroot', product layer, sum
+    layer, last product layer, root layer) -- what DgcSpn.forward is about to evaluate through spatial_prodsum /
+    spatial_sumprodroot.  No-op when the version counters are trusted (unchanged tables are not rebuilt then)."""
+    global _prep_token
+    _prep_token = None
+    from deeprob import hip
+    if hip._trust_versions or not x.is_cuda or not levels or len(levels) > 8:
+        return
+    lib = load_library()
+    dev, B = x.device, x.shape[0]
+    entries, marked = [], []
+    for lv in levels:
+        prod, sm = lv[1], lv[2]
+        w = sm.weight
+        if not (prod.depthwise and w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
+            continue
+        C, H, W, _, OH, OW, kh, kw, sh, sw, dh, dw, pt, pl, _ = _geom(prod)
+        Cout = w.shape[0]
+        if tuple(w.shape[1:]) != (C, OH, OW):
+            continue
+        if lv[0] == 'prodsum':
+            ws = sm._ws
+            buf = _spatial_sum_ws(ws, C, Cout, OH, OW, dev)
+            key = _weights_key('prodsum', w)
+            entries.append(_SpatialTablesArgs(ptr(w), ptr(buf), buf.numel(), None, C, Cout, OH * OW, 0, 0))
+        else:
+            prod6, root = lv[3], lv[4]
+            wr = root.weight
+            if not (prod6.depthwise and wr.is_cuda and wr.dtype == torch.float32 and wr.is_contiguous()):
+                continue
+            C6, H6, W6, _, OH6, OW6, kh6, kw6, sh6, sw6, dh6, dw6, pt6, pl6, _ = _geom(prod6)
+            K = wr.shape[0]
+            if (C6, H6, W6) != (Cout, OH, OW) or wr.shape[1] != Cout * OH6 * OW6:
+                continue
+            g5 = (ctypes.c_int32 * 10)(OH, OW, kh, kw, sh, sw, dh, dw, pt, pl)
+            g6 = (ctypes.c_int32 * 10)(OH6, OW6, kh6, kw6, sh6, sw6, dh6, dw6, pt6, pl6)
+            n = lib.dpk_spatial_sumprodroot_workspace_bytes_batch(B, C, H, W, g5, Cout, g6, K)
+            if n < 0:
+                continue
+            ws = root._ws3
+            buf = ws.get(n, dev)
+            key = _weights_key('sumprodroot', w, wr)
+            entries.append(_SpatialTablesArgs(ptr(w), ptr(buf), buf.numel(), ptr(wr), C, Cout, OH * OW, K, wr.shape[1]))
+        marked.append((ws, key))
+    if not entries:
+        return
+    arr = (_SpatialTablesArgs * len(entries))(*entries)
+    check(lib.dpk_spatial_tables(len(entries), ctypes.cast(arr, ctypes.c_void_p), stream_ptr(dev)), 'dpk_spatial_tables')
+    token = object()
+    for ws, key in marked:
+        ws.params_key = key
+        ws._prep_token = token
+        ws._prep_key = key
+    _prep_token = token
+
+
 def _tables_flag(ws: Workspace, route: str, *weights) -> int:
     """The cached-tables flag (``hip.cached_tables_flag``: checked on the device by default, so that a write through
     ``weight.data`` is seen) when the workspace's softmaxed-weight tables were built by an earlier call of the same entry
     point from these very tensors (address, shape, version counter; Workspace.get() drops the key when the buffer is
     replaced)."""
     key = (route,) + tuple((w.data_ptr(), tuple(w.shape), w._version) for w in weights)
+    if _prep_token is not None and getattr(ws, '_prep_token', None) is _prep_token and getattr(ws, '_prep_key', None) == key:
+        return DPK_FLAG_PARAMS_CACHED      # rebuilt by this forward's tables_prepare
     if ws.params_key == key:
         return cached_tables_flag()
     ws.params_key = key

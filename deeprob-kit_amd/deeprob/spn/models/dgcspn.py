@@ -120,6 +120,32 @@ class DgcSpn(ProbabilisticModel):
             return self.root_layer(x)
         # evaluation: every depthwise product is folded into the sum layer above it
         from deeprob.hip import ops_spatial
+        # (the tables of every fused level rebuilt by one launch for the whole forward instead of one per level)
+        ops_spatial.tables_prepare(self._fused_levels(), x)
+        try:
+            return self._forward_eval(x)
+        finally:
+            ops_spatial.tables_release()
+
+    def _fused_levels(self):
+        """The (product, sum) levels the evaluation loop below hands to spatial_prodsum / spatial_sumprodroot, in order."""
+        levels, i, n = [], 0, len(self.layers)
+        while i < n:
+            layer = self.layers[i]
+            nxt = self.layers[i + 1] if i + 1 < n else None
+            if not (isinstance(layer, SpatialProductLayer) and isinstance(nxt, SpatialSumLayer)) or \
+                    (self.training and nxt.dropout is not None):
+                i += 1
+                continue
+            if i == n - 3 and isinstance(self.layers[i + 2], SpatialProductLayer):
+                levels.append(('sumprodroot', layer, nxt, self.layers[i + 2], self.root_layer))
+                break
+            levels.append(('prodsum', layer, nxt))
+            i += 2
+        return levels
+
+    def _forward_eval(self, x: torch.Tensor) -> torch.Tensor:
+        from deeprob.hip import ops_spatial
         x = self.base_layer(x)
         i, n = 0, len(self.layers)
         while i < n:

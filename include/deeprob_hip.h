@@ -500,7 +500,20 @@ int64_t dpk_spatial_sumprodroot_workspace_bytes_batch(int64_t B, int32_t C, int3
 int dpk_spatial_sumprodroot_forward(const float *in, int64_t B, int32_t C, int32_t H, int32_t W, const int32_t *geom5,
                                     const float *sum_weight, int32_t Cout, const int32_t *geom6,
                                     const float *root_weight, int32_t K, float *out, void *ws, int64_t ws_bytes,
-                                    uint32_t flags, void *stream);   /* flags: DPK_FLAG_PARAMS_CACHED as above */
+                                    uint32_t flags, void *stream);
+/* The softmaxed-weight tables of up to 8 fused levels (dpk_spatial_prodsum_forward / dpk_spatial_sumprodroot_forward
+ * workspaces; for the last one also the root's log-softmax rows, root_weight [K, M] or NULL) in ONE launch, after
+ * which those entry points may be called with DPK_FLAG_PARAMS_CACHED (round 3: one table launch per DgcSpn.forward
+ * instead of one per level).  sum_weight [Cout, C, OHW]; ws / ws_bytes: the workspace the level's entry point gets. */
+typedef struct dpk_spatial_tables_args {
+    const float *sum_weight;
+    void *ws;
+    int64_t ws_bytes;
+    const float *root_weight;
+    int32_t C, Cout, OHW, K, M;
+} dpk_spatial_tables_args;
+int dpk_spatial_tables(int32_t n, const dpk_spatial_tables_args *levels, void *stream);
+   /* flags: DPK_FLAG_PARAMS_CACHED as above */
 
 /* ---- vanilla (node-graph) SPN, flattened (BASELINE config 1) ---------------------------------------------
  * Bottom-up log-likelihood of deeprob/spn/algorithms/inference.py:37-58 (eval_bottom_up, evaluation.py:37-96;

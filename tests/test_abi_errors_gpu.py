@@ -152,6 +152,30 @@ def test_round2_entry_error_codes():
     assert abs(total.item() - sum(c.item() for _, _, c in one)) <= 1e-4 * max(1.0, abs(total.item()))
     assert lib.dpk_bn1d_fold_many(17, ctypes.cast(arr, ctypes.c_void_p), None, st) == DPK_EINVAL
     assert lib.dpk_bn1d_fold_many(nl, None, None, st) == DPK_EINVAL
+    # --- softmaxed-weight tables of several DGC-SPN levels in one launch: the same bytes as the per-level builds --------------
+    from deeprob.hip.ops_spatial import _SpatialTablesArgs
+    Ct, HWs = 8, (49, 81)
+    wts = [torch.randn(8, Ct, hw, device='cuda') for hw in HWs]
+    rootw = torch.randn(3, 8 * 25, device='cuda')
+    segs = [((8 * Ct * hw * 4 + 255) // 256) * 256 for hw in HWs]
+    wsl = [torch.zeros(2 * sg + (3 * 200 * 4 if i == 1 else 0), dtype=torch.uint8, device='cuda') for i, sg in enumerate(segs)]
+
+    def sp_tables(k=2, nbytes=None, w0=wts[0]):
+        ents = [_SpatialTablesArgs(ptr(w0 if i == 0 else wts[i]), ptr(wsl[i]), wsl[i].numel() if nbytes is None else nbytes,
+                                   ptr(rootw) if i == 1 else None, Ct, 8, HWs[i], 3 if i == 1 else 0, 200 if i == 1 else 0)
+                for i in range(2)]
+        arr = (_SpatialTablesArgs * 2)(*ents)
+        return lib.dpk_spatial_tables(k, ctypes.cast(arr, ctypes.c_void_p), st)
+    assert sp_tables() == 0
+    for i, hw in enumerate(HWs):
+        tab = wsl[i][:8 * Ct * hw * 4].view(torch.float32).view(8, Ct, hw)
+        ltab = wsl[i][segs[i]:segs[i] + 8 * Ct * hw * 4].view(torch.float32).view(8, Ct, hw)
+        assert torch.allclose(tab, torch.softmax(wts[i], dim=1), atol=1e-6)
+        assert torch.allclose(ltab, torch.log_softmax(wts[i], dim=1), atol=2e-6)
+    lr = wsl[1][2 * segs[1]:2 * segs[1] + 3 * 200 * 4].view(torch.float32).view(3, 200)
+    assert torch.allclose(lr, torch.log_softmax(rootw, dim=1), atol=2e-6)
+    assert sp_tables(k=0) == 0 and sp_tables(k=9) == DPK_EINVAL and sp_tables(w0=None) == DPK_EINVAL
+    assert sp_tables(nbytes=64) == DPK_EWORKSPACE
     # --- fused product + sum level of a DGC-SPN, forward and backward --------------------------------------------
     C, H, W, OH, OW = 8, 6, 6, 7, 7                               # 2x2 taps, 'full' padding 1, dilation 1
     xin = torch.randn(4, C, H, W, device='cuda')
