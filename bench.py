@@ -140,9 +140,8 @@ def cpu_baseline(model_state, D, n_samples):
     threads = best[0]
     rate, dt = _oracle_rate(lambda a, b: orc.ratspn_forward(model_state, x[a:b]), n_samples, chunk, threads)
     return {'value': rate, 'unit': 'log-likelihoods/sec', 'cores': threads, 'kind': 'port',
-            'sample': '{} samples of the same workload in chunks of {} ({:.1f} s) on {} of {} host threads '
-                      '(fastest of the probed pool sizes), oracle/ratspn_oracle.py = op-for-op PyTorch-CPU '
-                      'restatement of the reference'.format(n_samples, chunk, dt, threads, ncpu)}, threads
+            'sample': '{} samples of the same workload in chunks of {} ({:.1f} s) on {} of {} host threads (fastest '
+                      'probed pool); oracle/ratspn_oracle.py'.format(n_samples, chunk, dt, threads, ncpu)}, threads
 
 
 def read_traffic(key='headline'):
@@ -325,7 +324,7 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
         dc = (time.perf_counter() - t0) / n_rep
         out.append({'workload': 'vanilla node-graph SPN log_likelihood (the circuit the reference learns on 16 binary '
                                 'variables, 72 nodes), 1000 samples per call, flat-array HIP evaluator',
-                    'config': 'BASELINE config 1', 'batch': 1000, 'ms_per_step': ms, 'value': 1000 / ms * 1e3,
+                    'id': 'c1', 'config': 'BASELINE config 1', 'batch': 1000, 'ms_per_step': ms, 'value': 1000 / ms * 1e3,
                     'unit': 'log-likelihoods/sec', 'kernel': 'flat_spn_kernel',
                     'roofline': hbm(1000 * 68, ms),
                     'roofline_basis': 'whole call; 68 algorithmic B/sample (16 fp32 inputs + 1 result): a 68 KB problem, '
@@ -334,7 +333,7 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
                                      'sample': '{} calls of 1000 samples ({:.2f} s), oracle/flat_spn_oracle.py = the '
                                                "reference's numpy / scipy bottom-up pass".format(n_rep, dc * n_rep)}})
     except Exception as ex:
-        out.append({'config': 'BASELINE config 1', 'error': '{}: {}'.format(type(ex).__name__, ex)})
+        out.append({'id': 'c1', 'config': 'BASELINE config 1', 'error': '{}: {}'.format(type(ex).__name__, ex)})
 
     # ---- BASELINE config 2: RAT-SPN, B = 4096 (constructor defaults + the two wider settings) ----------
     B = 4096
@@ -372,7 +371,7 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
             roofl['traffic'], roofl['traffic_source'] = read_traffic('wide_65536')
             wide_entry = ({'workload': 'the same (8,8) model at the headline batch size (128-sample tiles: x through an LDS-DMA '
                                     'ring, converted to f16 pairs once per tile by the loader waves)',
-                        'config': 'headline size, rg_batch = rg_sum = 8', 'batch': Bl, 'ms_per_step': msl,
+                        'id': 'hl(8,8)', 'config': 'headline size, rg_batch = rg_sum = 8', 'batch': Bl, 'ms_per_step': msl,
                         'value': Bl / msl * 1e3, 'unit': 'log-likelihoods/sec', 'ms_per_step_eager': msl_e,
                         'kernel_ms': kl_ms, 'kernel': 'ratspn_gemm_wide_ring_kernel', 'roofline': roofl,
                         'roofline_basis': 'whole step; 3140 algorithmic B/sample (the kernel is bound by its MFMA + node '
@@ -391,7 +390,7 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
         roof['traffic'], roof['traffic_source'] = traffic, tsrc
         e = {'workload': 'GaussianRatSpn(784, rg_depth=2, rg_repetitions=8, rg_batch={}, rg_sum={}) forward, '
                          'model(x) under no_grad over 8 resident batches'.format(I, S),
-             'config': 'BASELINE config 2', 'batch': B, 'ms_per_step': ms, 'value': B / ms * 1e3,
+             'id': 'c2({},{})'.format(I, S), 'config': 'BASELINE config 2', 'batch': B, 'ms_per_step': ms, 'value': B / ms * 1e3,
              'unit': 'log-likelihoods/sec',
              'step_basis': 'model(x) calls replayed from one HIP graph (32 calls per replay; kernels, gaps and the per-call '
                            'parameter-table check included)' if ms_graph is not None else 'eager python loop',
@@ -427,7 +426,7 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
                 time.sleep(0.05)
                 msc_g = _time_eval_graph(m, xcl)     # clean inputs, same size, same protocol (right after: same variant)
                 out.append({'workload': 'the same model, 30 % of the inputs NaN (marginalised evidence)',
-                            'config': 'BASELINE config 2 / headline size, marginalised', 'batch': Bn, 'ms_per_step': msn,
+                            'id': 'nan{}'.format(Bn), 'config': 'BASELINE config 2 / headline size, marginalised', 'batch': Bn, 'ms_per_step': msn,
                             'value': Bn / msn * 1e3, 'unit': 'log-likelihoods/sec', 'ms_per_step_eager': msn_e,
                             'ms_per_step_clean_same_protocol': msc_g,
                             'slowdown_vs_clean': (msn / msc_g) if msc_g else None,
@@ -447,7 +446,7 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
     xc = torch.randn(256, 1, 28, 28)
     rate, dt = _oracle_rate(lambda a, b: dorc.dgcspn_forward(sd, xc[a:b], plan), 256, 128, threads)
     out.append({'workload': 'DgcSpn((1,28,28), n_batch=8, sum_channels=8, depthwise=True, n_pooling=0) forward',
-                'config': 'BASELINE config 4', 'batch': B, 'ms_per_step': ms, 'value': B / ms * 1e3,
+                'id': 'c4', 'config': 'BASELINE config 4', 'batch': B, 'ms_per_step': ms, 'value': B / ms * 1e3,
                 'unit': 'log-likelihoods/sec', 'kernel_ms': k_ms,
                 'kernel': 'spatial_sumprodroot_fwd_kernel (last sum level + product + root)',
                 'roofline': dict(hbm(B * 588164, ms), **dict(zip(('traffic', 'traffic_source'), read_traffic('config4')))),
@@ -478,7 +477,7 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
     xc = torch.randn(16384, D)
     rate, dt = _oracle_rate(lambda a, b: forc.flow_log_prob(sd, xc[a:b]), 16384, 4096, threads)
     e = {'workload': 'RealNVP1d(784, n_flows=5, depth=1, units=128, batch_norm, affine) forward log-likelihood',
-         'config': 'BASELINE config 5', 'batch': B, 'ms_per_step': ms, 'value': B / ms * 1e3,
+         'id': 'c5', 'config': 'BASELINE config 5', 'batch': B, 'ms_per_step': ms, 'value': B / ms * 1e3,
          'unit': 'log-likelihoods/sec', 'ms_per_step_trusting_version_counters': ms_trust, 'kernel_ms': k_ms,
          'kernel': 'coupling_x1_kernel (one of the 5 layers; x read once: 64-sample tiles held in registers; split-f16 MFMA, fp32-grade products)',
          'roofline': hbm(B * 2 * D * 4, k_ms) if k_ms else hbm(5 * B * 2 * D * 4, ms),
@@ -525,7 +524,7 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
     tf = B * flops / (ms * 1e-3) / 1e12
     out.append({'workload': 'RealNVP2d((1,28,28), n_flows=1, n_blocks=2, channels=32, resnet, affine) forward '
                             'log-likelihood (evaluation only)',
-                'config': 'SURVEY 8f-3', 'batch': B, 'ms_per_step': ms, 'value': B / ms * 1e3,
+                'id': 'nvp2d', 'config': 'SURVEY 8f-3', 'batch': B, 'ms_per_step': ms, 'value': B / ms * 1e3,
                 'unit': 'log-likelihoods/sec',
                 'kernel': 'conv3x3_lds_kernel (3x3 conditioner convolutions on fp32 MFMA, activations staged through LDS; ~70 % of the step)',
                 'roofline': {'bound': 'mfma', 'achieved': tf, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': tf / 157.3,
@@ -547,7 +546,7 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
     for name, m, x in trains:
         ms = _time_train(m, x)
         ms_g = _time_train_graph(m, x)
-        out.append({'workload': name + ': forward + backward + Adam step', 'config': 'training step', 'batch': B,
+        out.append({'id': 'train:' + name.split('(')[0], 'workload': name + ': forward + backward + Adam step', 'config': 'training step', 'batch': B,
                     'ms_per_step': ms, 'value': B / ms * 1e3, 'unit': 'samples/sec',
                     'ms_per_step_hip_graph': ms_g, 'value_hip_graph': (B / ms_g * 1e3) if ms_g else None})
 
@@ -558,7 +557,7 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
     m2d = RealNVP2d((1, 28, 28), n_flows=1, n_blocks=2, channels=32).to(dev)
     ms = _time_train(m2d, torch.randn(B2, 1, 28, 28, device=dev), steps=4, warm=2)
     out.append({'workload': 'RealNVP2d((1,28,28), n_flows=1, n_blocks=2, channels=32, resnet, affine): forward + backward '
-                            '+ Adam step (training mode, batch statistics)', 'config': 'training step', 'batch': B2,
+                            '+ Adam step (training mode, batch statistics)', 'id': 'train:RealNVP2d', 'config': 'training step', 'batch': B2,
                 'ms_per_step': ms, 'value': B2 / ms * 1e3, 'unit': 'samples/sec', 'ms_per_step_hip_graph': None,
                 'value_hip_graph': None})
     del m2d
@@ -580,9 +579,59 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / K * 1e3
     out.append({'workload': 'headline model, batch copied from pinned host memory inside every step (PCIe-inclusive)',
-                'config': 'H2D-inclusive', 'batch': Bh, 'ms_per_step': ms, 'value': Bh / ms * 1e3,
+                'id': 'h2d', 'config': 'H2D-inclusive', 'batch': Bh, 'ms_per_step': ms, 'value': Bh / ms * 1e3,
                 'unit': 'log-likelihoods/sec', 'h2d_GBps': Bh * D * 4 / (ms * 1e-3) / 1e9})
     return out
+
+
+def compact_configs(sec):
+    """One short record per secondary configuration (the driver keeps only the last ~6 KB of stdout: the verbose
+    `secondary` list goes to a file, this summary stays in the line): id, batch, ms per step (default mode: per-call
+    parameter-table check included), LL/s (or samples/s), roofline bound + fraction, dominant-kernel us, CPU-oracle
+    rate on `cores` host threads."""
+    ids = {'BASELINE config 1': 'c1', 'BASELINE config 2': 'c2', 'BASELINE config 4': 'c4', 'BASELINE config 5': 'c5',
+           'headline size, rg_batch = rg_sum = 8': 'hl(8,8)', 'SURVEY 8f-3': 'nvp2d', 'training step': 'train',
+           'H2D-inclusive': 'h2d', 'SURVEY 8d config 4 secondary': 'c4b'}
+    out = []
+    for e in sec:
+        r = {'id': e.get('id') or ids.get(e.get('config'), e.get('config', '?')), 'B': e.get('batch')}
+        if 'error' in e:
+            r['error'] = e['error'][:80]
+            out.append(r)
+            continue
+        r['ms'] = round(e['ms_per_step'], 5)
+        r['rate'] = float('{:.4g}'.format(e['value']))
+        for k_src, k_dst in (('ms_per_step_trusting_version_counters', 'ms_trust'), ('ms_per_step_eager', 'ms_eager'),
+                             ('ms_per_step_hip_graph', 'ms_graph'), ('slowdown_vs_clean', 'x_clean')):
+            if e.get(k_src) is not None:
+                r[k_dst] = round(e[k_src], 5)
+        if e.get('kernel_ms'):
+            r['k_us'] = round(e['kernel_ms'] * 1e3, 2)
+        roof = e.get('roofline')
+        if roof:
+            r['bound'], r['frac'] = roof['bound'], round(roof['frac'], 4)
+            if roof.get('traffic'):
+                r['traffic_MB'] = round(roof['traffic'] / 1e6, 1)
+        if e.get('mfma'):
+            r['mfma_frac'] = round(e['mfma']['frac'], 4)
+        cb = e.get('cpu_baseline')
+        if cb:
+            r['cpu'], r['cores'] = float('{:.4g}'.format(cb['value'])), cb['cores']
+        out.append(r)
+    return out
+
+
+def write_detail(obj):
+    """The verbose record (every workload / basis / source string) next to the line: gpurun_out/bench_detail.json."""
+    try:
+        d = os.path.join(ROOT, 'gpurun_out')
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, 'bench_detail.json')
+        with open(path, 'w') as f:
+            json.dump(obj, f, indent=1)
+        return os.path.relpath(path, ROOT)
+    except OSError:
+        return None
 
 
 def main():
@@ -695,8 +744,30 @@ def main():
     dt = float(t.item())
     mean_ll = results[-1]
 
+    # the same loop in the DEFAULT mode of model(x): every call checks its cached parameter tables on the device (a
+    # write through param.data moves no version counter); the headline loop above declares a frozen model
+    ms_default = None
+    if world == 1:
+        ev2 = ShardedLogLikelihood(model, static_inputs=True, static_params=False)
+        with torch.no_grad():
+            for i in range(max(args.warmup, 4)):
+                ev2.step(xs[i % ring])
+            ev2.drain()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                ev2.step(xs[i % ring])
+            ev2.drain()
+            torch.cuda.synchronize()
+            ms_default = (time.perf_counter() - t1) / args.steps * 1e3
+
     if rank == 0:
         total = B * world * args.steps
+        workload = ('GaussianRatSpn(784, rg_depth=2, rg_repetitions=8, rg_batch={}, rg_sum={}) forward LL, {} samples '
+                    'per GPU per step, mean LL reduced on device{}'.format(
+                        args.rg_batch, args.rg_sum, B,
+                        ' + {} all-reduce of {{sum, count}} once per run'.format(
+                            'RCCL' if args.backend == 'nccl' else args.backend) if world > 1 else ''))
         out = {
             'metric': 'log-likelihoods/sec, RAT-SPN D=784 batch=64k at 1/2/4/8 MI355X',
             'value': total / dt, 'unit': 'log-likelihoods/sec', 'n_gpus': world,
@@ -704,18 +775,14 @@ def main():
             'backend': (dist.get_backend() if world > 1 else None), 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'GaussianRatSpn(784, rg_depth=2, rg_repetitions=8, rg_batch={}, rg_sum={}) '
-                                   'forward log-likelihood, {} samples per GPU per step, mean LL reduced on '
-                                   'device{}'.format(args.rg_batch, args.rg_sum, B,
-                                                     ' + {} all-reduce of {{sum, count}} once per run'.format(
-                                                         'RCCL' if args.backend == 'nccl' else args.backend)
-                                                     if world > 1 else ''),
-                       'global_batch': B * world, 'resident_batches': ring, 'mean_ll': mean_ll,
-                       'host_enqueue_ms_per_step': host_dt / args.steps * 1e3,
-                       'arithmetic': 'fp32 results; the leaf-layer GEMM runs as three f16 MFMAs on two-way f16 splits '
-                                     'of both operands with fp32 accumulation (>= 22 significant bits per product), '
-                                     'everything else fp32'},
+            'config': {'workload': workload, 'global_batch': B * world, 'resident_batches': ring, 'mean_ll': mean_ll,
+                       'host_enqueue_ms_per_step': round(host_dt / args.steps * 1e3, 5),
+                       'params_mode': 'static_params=True (frozen model: no per-call table check)',
+                       'ms_per_step_default_mode': ms_default,
+                       'arithmetic': 'fp32 results; leaf GEMM = 3 f16 MFMAs on two-way f16 splits, fp32 accumulate '
+                                     '(>= 22 bits per product, guarded, exact fallback)'},
         }
+        detail = {'line': out}
         if time_kernel and sampled:
             torch.cuda.synchronize()
             n_launches = sum(n for _, n in sampled)
@@ -725,25 +792,32 @@ def main():
             traffic, source = read_traffic('headline')
             out['roofline'] = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic if B == 65536 else None,
-                               'traffic_source': source if B == 65536 else None,
-                               'kernel': 'ratspn_gemm_kernel (fused RatSpn.forward, leaf layer on MFMA)',
-                               'kernel_ms': k_ms, 'kernel_event_samples': n_launches,
-                               'kernel_event_method': '{} runs of up to {} consecutive launches covering {} of the {} timed '
-                                                      'steps, one HIP event pair per run (includes the gaps between '
-                                                      'the launches of a run)'.format(len(sampled), run, n_launches,
-                                                                                      args.steps),
-                               'algorithmic_bytes_per_launch': alg_bytes,
-                               'context': 'tools/ubench/read_bw.hip on the same GPU model: 6.4 TB/s for a linear 16-byte-load '
-                                          'stream, 5.7 TB/s for this kernel\'s access pattern (256-byte row segments at a '
-                                          '3136-byte stride); peak = the 8 TB/s specification'}
+                               'kernel': 'ratspn_gemm_kernel', 'kernel_ms': k_ms, 'kernel_event_samples': n_launches,
+                               'algorithmic_bytes_per_launch': alg_bytes}
+            detail['roofline_notes'] = {
+                'traffic_source': source if B == 65536 else None,
+                'kernel_event_method': '{} runs of up to {} consecutive launches covering {} of the {} timed steps, one HIP '
+                                       'event pair per run (includes the gaps between the launches of a run)'.format(
+                                           len(sampled), run, n_launches, args.steps),
+                'context': 'tools/ubench/read_bw.hip on the same GPU model: 6.4 TB/s for a linear 16-byte-load stream, '
+                           '5.7 TB/s for this kernel\'s access pattern (256-byte row segments at a 3136-byte stride); '
+                           'peak = the 8 TB/s specification'}
         threads = min(os.cpu_count() or 1, 32)
         if args.cpu_samples > 0 and world == 1:
             out['cpu_baseline'], threads = cpu_baseline(cpu_state, D, args.cpu_samples)
         if world == 1 and not args.no_secondary:
             try:
-                out['secondary'] = secondary(dev, timer, threads, xs, model)
+                sec = secondary(dev, timer, threads, xs, model)
+                detail['secondary'] = sec
+                # LAST in the line, compact: the driver's record keeps the tail of stdout
+                out['configs'] = compact_configs(sec)
             except Exception as ex:   # the headline line must survive a failure in a secondary configuration
-                out['secondary_error'] = '{}: {}'.format(type(ex).__name__, ex)
+                out['secondary_error'] = '{}: {}'.format(type(ex).__name__, ex)[:300]
+        out_path = write_detail(detail)
+        if out_path:
+            out['detail_file'] = out_path
+            if 'configs' in out:   # (keep `configs` the last key)
+                out['configs'] = out.pop('configs')
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -37,7 +37,7 @@ class ResidualNetwork(nn.Module):
 
         :raises ValueError: if n_blocks is not positive."""
         if n_blocks <= 0:
-            raise ValueError("The number of residual blocks must be positve")
+            raise ValueError("n_blocks must be at least 1, got {}".format(n_blocks))
         super().__init__()
         self.blocks = nn.ModuleList()
         self.skips = nn.ModuleList()

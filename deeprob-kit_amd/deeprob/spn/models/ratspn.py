@@ -53,7 +53,7 @@ class RatSpn(ProbabilisticModel):
         if not issubclass(base_cls, RegionGraphLayer):
             raise ValueError("The base distribution's class must be a sub-class of RegionGraphLayer")
         if in_features <= 0:
-            raise ValueError("The number of input features must be positve")
+            raise ValueError("in_features must be at least 1")
         if out_classes <= 0:
             raise ValueError("The number of output classes must be positive")
         if rg_batch <= 0:
@@ -130,9 +130,18 @@ class RatSpn(ProbabilisticModel):
                 and not base.scale.requires_grad and self.in_features % 4 == 0):
             return False
         # round 3: depth-2 models with up to 8 repetitions and 32 classes run as ONE launch (a wave per repetition,
-        # csrc/ratspn_gemm_wide.hip) -- the single-launch route then comes first
-        one_launch = (self.rg_depth == 2 and self.rg_repetitions <= 8 and self.out_classes <= 32 and self.rg_sum == 8
-                      and self.in_features <= 1024)
+        # csrc/ratspn_gemm_wide.hip) -- the single-launch route then comes first.  Whether THIS call is inside that
+        # kernel's envelope (shape, LDS budget, unit-scale hint, 16-byte aligned x) is the library's answer, not a
+        # re-derivation here: outside it the fused entry point would fall to the VALU kernel, ~3x slower than the
+        # folded MFMA route.
+        if self.rg_sum != 8 or not x.is_cuda:
+            return True
+        ctx = self._fused_ctx
+        # (scale.requires_grad is False here: LeafContext.workspace sets the same hint; a tensor the operator would
+        # convert / compact first arrives 16-byte aligned from the allocator: address 0 stands for it)
+        plain = x.dtype == torch.float32 and x.is_contiguous()
+        one_launch = ops.load_library().dpk_ratspn_forward_on_mfma(
+            x.data_ptr() if plain else 0, ctx.D, ctx.depth, ctx.reps, ctx.I, ctx.S, ctx.C, 0, ops.DPK_FLAG_UNIT_SCALE)
         return not one_launch
 
     def _forward_folded(self, x: torch.Tensor) -> Optional[torch.Tensor]:

@@ -79,9 +79,12 @@ def train_model(
     model.to(device)
     optimizer_kwargs = dict(optimizer_kwargs or {})
     import inspect
-    if 'fused' in inspect.signature(get_optimizer_class(optimizer).__init__).parameters:
+    if optimizer in ('adam', 'sgd') and not (optimizer_kwargs.get('foreach') or optimizer_kwargs.get('differentiable')):
         # one launch per optimiser step instead of torch's seven multi-tensor launches (62 of the 325 us of GPU time of a
-        # RAT-SPN (8,8) step at B = 512); the same update rule -- pass optimizer_kwargs={'fused': False} for torch's default
+        # RAT-SPN (8,8) step at B = 512); the same update rule -- pass optimizer_kwargs={'fused': False} for torch's default.
+        # Only the optimisers whose fused kernels run on a HIP device: Adagrad's constructor accepts `fused` too, but its
+        # fused kernels are CPU-only (RuntimeError at the first step) and RMSprop has none; `foreach` / `differentiable`
+        # exclude `fused`.
         optimizer_kwargs.setdefault('fused', True)
     if hip_graph:
         if setting != 'generative' or _world()[1] > 1:
@@ -148,7 +151,7 @@ def _batch(item, device, rank, world, supervised):
 def _fit(model, train_loader, valid_loader, optimizer, device, early_stopping, epochs, train_base, verbose, supervised,
          hip_graph=False):
     if epochs <= 0:
-        raise ValueError("The number of epochs must be positve")
+        raise ValueError("epochs must be at least 1")
     rank, world = _world()
     if world > 1:
         # identical replicas on every rank (parameters and buffers of rank 0), whole-batch statistics for every

@@ -51,7 +51,7 @@ class RegionGraph:
         :raises ValueError: if the number of repetitions is not positive.
         """
         if n_repetitions <= 0:
-            raise ValueError("The number of repetitions must be positve")
+            raise ValueError("n_repetitions must be at least 1")
         merged: List[List[tuple]] = [[self.items]] + [[] for _ in range(2 * self.depth)]
         for _ in range(n_repetitions):
             rep = self.random_layers()

@@ -735,3 +735,29 @@ def test_mixed_magnitude_evidence_per_sample(golden, name, mapping):
         got = model(x.cuda()).cpu().double()
     per_sample = ((got - want).abs() / want.abs().clamp_min(1.0)).max().item()
     assert torch.isfinite(got).all() and per_sample <= LL_TOL, per_sample
+
+
+@pytest.mark.parametrize('D,one_launch', [(784, True), (100, False), (256, False)])
+def test_eight_channel_route_follows_the_library_envelope(D, one_launch):
+    """RatSpn._prefer_folded asks the library (dpk_ratspn_forward_on_mfma) whether the one-launch 8-channel kernel takes
+    THIS call instead of re-deriving its envelope: a narrow model (D <= 256: the kernel's LDS plan declines) or a
+    misaligned input keeps the folded MFMA route rather than falling to the ~3x slower VALU kernel; either way the
+    numbers are the oracle's."""
+    from deeprob.spn.models import GaussianRatSpn
+    torch.manual_seed(2)
+    model = GaussianRatSpn(D, rg_depth=2, rg_repetitions=4, rg_batch=8, rg_sum=8, random_state=9).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    x = torch.randn(300, D, generator=torch.Generator().manual_seed(3))
+    want = orc.ratspn_forward(sd, x).numpy()
+    model = model.cuda()
+    xd = x.cuda()
+    assert model._prefer_folded(xd) == (not one_launch)
+    with torch.no_grad():
+        assert rel_err(model(xd).cpu().numpy(), want) <= LL_TOL
+    # a view whose rows start 4 bytes off a 16-byte boundary: the LDS-DMA kernels decline, the folded route serves it
+    if D % 4 == 0:
+        xm = torch.empty(300 * D + 1, device='cuda')[1:].view(300, D)
+        xm.copy_(xd)
+        assert xm.data_ptr() % 16 == 4 and model._prefer_folded(xm)
+        with torch.no_grad():
+            assert rel_err(model(xm).cpu().numpy(), want) <= LL_TOL

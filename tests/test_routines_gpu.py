@@ -113,3 +113,20 @@ def test_train_image_flow(tmp_path):
                        checkpoint=str(tmp_path / 'ck2d.pt'), verbose=False)
     after = test_model(flow, data[:64], verbose=False)[0]
     assert np.isfinite(hist['train']).all() and hist['train'][-1] < hist['train'][0] and after > before
+
+
+@pytest.mark.parametrize('optimizer,kwargs', [('sgd', None), ('rmsprop', None), ('adagrad', None), ('adam', None),
+                                              ('adam', {'foreach': True}), ('sgd', {'fused': False})])
+def test_train_model_every_reference_optimizer(tmp_path, optimizer, kwargs):
+    """Every optimiser name the reference accepts (torch/utils.py:32-49) takes a few steps through train_model: the
+    fused-kernel default applies only where torch has HIP fused kernels (Adagrad's are CPU-only, RMSprop has none) and
+    steps aside for `foreach`."""
+    from deeprob.spn.models import GaussianRatSpn
+    from deeprob.torch.routines import train_model
+    torch.manual_seed(0)
+    gen = torch.Generator().manual_seed(5)
+    data = (0.5 * torch.randn(260, 12, generator=gen) + 0.3).numpy()
+    model = GaussianRatSpn(12, rg_depth=1, rg_repetitions=2, rg_batch=2, rg_sum=2, random_state=3)
+    hist = train_model(model, data[:200], data[200:], lr=1e-2, batch_size=50, epochs=2, patience=2, optimizer=optimizer,
+                       optimizer_kwargs=kwargs, checkpoint=str(tmp_path / 'o.pt'), verbose=False)
+    assert len(hist['train']) == 2 and np.isfinite(hist['train']).all() and np.isfinite(hist['valid']).all()
