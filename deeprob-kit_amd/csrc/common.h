@@ -112,6 +112,7 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // entries (LDS row kChunk = all zeros, parameters 0).  SP = stream capacity per group.
 constexpr int kBlock = 4;
 constexpr int kTableSlack = 16;  // neutral entries the software-pipelined readers may run into
+struct VerifyCtl;
 struct RatWs {
     // structure tables (depend on mask / pad_mask only)
     int *fl1;     // [G*SP] LDS byte offset of the entry's row for 1 sample per lane
@@ -140,7 +141,9 @@ struct RatWs {
     float *gbias_ks;   // [NKS][2][NT][16] the same per K-step of 16 features (small-batch kernel, ratspn_gemm_small.hip)
     float *gbias_sl;   // [8][2][NT][16] ... per feature slice of its 8 waves (K-steps [w NKS/8, (w+1) NKS/8))
     int *gelig;        // [NT*RPT] 1: repetition is unit-scale with bounded means
-    unsigned long long *ghash;   // [NT*RPT] fingerprint of the parameter bytes each repetition's tables were built from
+    unsigned long long *ghash;   // [NT*RPT] fingerprint of the parameter bytes each repetition's tables were built from,
+                                 // then one per softmax-row work-group of the table build (ratspn_gemm_prep.h)
+    struct VerifyCtl *gctl;      // the verdict word of a launch that checks its tables itself (ratspn_gemm_prep.h)
     void *lg;          // tables of the leaf-only MFMA kernel (leaf_gemm_ws_bytes), null when the shape is outside it
     int g_nt, g_nksp;  // column tiles of 32, K-steps of 16 features (padded to whole chunks); 0 = not built
     int64_t bytes;
@@ -152,6 +155,8 @@ constexpr int kGemmKS = 4;                // K-steps of 16 features per staged c
 constexpr int kGemmKC = 16 * kGemmKS;     // features per chunk
 constexpr int kGemmMaxNT = 4;             // column tiles of 32 the fused kernel is built for
 constexpr int kGemmSmallWaves = 8;        // small-batch kernel: waves per 32-sample tile = slices of the feature axis
+constexpr int kGemmPrepThreads = 512;     // threads of a table work-group (stand-alone launch and in-launch alike: the
+                                          // softmax-row fingerprints are per work-group of kGemmPrepThreads / 64 rows)
 constexpr int kGemmSmallMaxK = 8;         // ... and the K-steps (of 16 features) one of them can hold in registers
 static inline bool gemm_shape_ok(int D, int depth, int reps, int I, int S) {
     if (depth != 2 || (D % 4) != 0 || reps < 1) return false;
@@ -250,7 +255,8 @@ inline RatWs carve_ratspn_ws(void *base, int D, int R, int d, int I, int QB, int
         w.gbias_ks = (float *)take((int64_t)((D + 15) / 16) * 2 * w.g_nt * 16 * 4);
         w.gbias_sl = (float *)take((int64_t)kGemmSmallWaves * 2 * w.g_nt * 16 * 4);
         w.gelig = (int *)take((int64_t)w.g_nt * 8 * 4);
-        w.ghash = (unsigned long long *)take((int64_t)w.g_nt * 8 * 8);
+        w.ghash = (unsigned long long *)take(((int64_t)w.g_nt * 8 + cdiv(reps * 2 * S + C, 4) + 4) * 8);
+        w.gctl = (struct VerifyCtl *)take(64);
     }
     w.lg = nullptr;
     if (leaf_gemm_shape_ok(D, R, I, d)) w.lg = take(leaf_gemm_ws_bytes(D, R, I));

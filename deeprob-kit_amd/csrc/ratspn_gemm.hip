@@ -38,209 +38,25 @@
 // root.  Work-groups are persistent (grid = min(tiles, CUs)); the DMA ring runs across tile boundaries.
 #include "common.h"
 #include "ratspn_gemm_fused.h"
+#include "ratspn_gemm_prep.h"
 #include <math.h>
 #include <stdlib.h>
 
 namespace dpk {
 
 // ------------------------------------------------------------------------------------------------
-// tables, rebuilt from the live parameters: one block per repetition (+ the softmax rows behind them)
+// tables, rebuilt from the live parameters (ratspn_gemm_prep.h): one work-group per repetition slot + the softmax rows
+// behind them.  This is the stand-alone launch (kPrepBuild / kPrepVerify); the small-batch and 8-channel kernels run the
+// same work-groups inside their own launch (kPrepInline).
 // ------------------------------------------------------------------------------------------------
-struct GemmPrepArgs {
-    const int64_t *mask;
-    const uint8_t *pad;
-    const float *loc, *scale;
-    int D, d, reps, NT, NKSP, KS;
-    uint16_t *mtab, *ctab;
-    float *bias, *bias_row, *bias_ks, *bias_sl;
-    int *elig;
-    const float *w[3];
-    float *W[3], *LW[3];
-    int rows[3], n[3];
-    int verify;                 // DPK_FLAG_PARAMS_VERIFY: a block rebuilds only if the bytes it depends on changed
-    unsigned long long *hash;   // [NT*RPT] fingerprint of the bytes each repetition's tables were built from
-};
-
-
 template <int I>
-__global__ __launch_bounds__(256) void ratspn_gemm_prep_kernel(const GemmPrepArgs a) {
-    constexpr int RPT = 8 / I;       // repetitions per 32-column tile (4 regions x I channels each)
-    const int nrb = a.NT * RPT;
-    if ((int)blockIdx.x >= nrb) {
-        // softmax rows: one wave per row (torch.log_softmax at ratspn.py:375 and :455)
-        int row = (blockIdx.x - nrb) * 4 + (threadIdx.x >> 6);
-        const int lane = threadIdx.x & 63;
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            if (row < a.rows[m]) {
-                const int n = a.n[m];
-                const float *src = a.w[m] + (int64_t)row * n;
-                float mx = -INFINITY;
-                for (int i = lane; i < n; i += 64) mx = fmaxf(mx, src[i]);
-                mx = wave_reduce_max(mx);
-                float sum = 0.f;
-                for (int i = lane; i < n; i += 64) sum += expf(src[i] - mx);
-                sum = wave_reduce_sum(sum);
-                const float ls = logf(sum);
-                for (int i = lane; i < n; i += 64) {
-                    const float l = src[i] - mx - ls;
-                    a.LW[m][(int64_t)row * n + i] = l;
-                    a.W[m][(int64_t)row * n + i] = expf(l);
-                }
-                return;
-            }
-            row -= a.rows[m];
-        }
-        return;
+__global__ __launch_bounds__(kGemmPrepThreads) void ratspn_gemm_prep_kernel(const GemmPrepArgs a) {
+    extern __shared__ int prep_dyn[];
+    if (a.mode == kPrepBuild && blockIdx.x == 0 && threadIdx.x == 0) {   // (no launch of this module is in flight: stream order)
+        a.ctl->word = 0ull;
+        a.ctl->readers = 0u;
     }
-    extern __shared__ int posrow[];  // [D] position q*d + j of variable f in this repetition, -1 if absent
-    float *locs = reinterpret_cast<float *>(posrow + a.D);   // [4][I][d] the repetition's means
-    __shared__ int bad_s;
-    __shared__ unsigned long long red_s[17];
-    const int rho = blockIdx.x;
-    const bool real = rho < a.reps;
-    const int D = a.D, d = a.d;
-    {
-        // Everything this block writes depends on the repetition's own slice of mask / pad_mask / loc / scale only, so
-        // the cached-table check is block local: fingerprint those bytes, compare with the fingerprint of the bytes the
-        // tables were built from (a write through `param.data` moves no version counter on the host), and
-        // return when nothing changed -- one ~2 us launch per call instead of a 30 us rebuild.
-        const unsigned long long stored = a.verify ? a.hash[rho] : 0ull;   // (requested first: back when the hash is)
-        unsigned long long h = 0x9E3779B97F4A7C15ull + (unsigned long long)rho;
-        if (real) {
-            h += fp_range(a.mask + (int64_t)rho * 4 * d, (int64_t)4 * d * 8, 1);
-            h += fp_range(a.pad ? a.pad + (int64_t)rho * 4 * d : nullptr, (int64_t)4 * d, 2);
-            h += fp_range(a.loc + (int64_t)rho * 4 * I * d, (int64_t)4 * I * d * 4, 3);
-            h += fp_range(a.scale + (int64_t)rho * 4 * I * d, (int64_t)4 * I * d * 4, 4);
-        }
-        h = block_sum_u64(h, red_s);
-        if (a.verify && stored == h) return;
-        __syncthreads();
-        if (threadIdx.x == 0) a.hash[rho] = h;
-    }
-    for (int f = threadIdx.x; f < D; f += blockDim.x) posrow[f] = -1;
-    if (threadIdx.x == 0) bad_s = 0;
-    __syncthreads();
-    bool bad = false;
-    if (real) {
-        for (int e = threadIdx.x; e < 4 * d; e += blockDim.x) {
-            const int64_t o = (int64_t)rho * 4 * d + e;
-            if (a.pad != nullptr && a.pad[o]) continue;
-            const int f = (int)a.mask[o];
-            if (f >= 0 && f < D) posrow[f] = e;
-        }
-        // eligibility of the repetition for the expanded form: scale == 1 everywhere, |mu| <= kExpandBound
-        for (int e = threadIdx.x; e < 4 * I * d; e += blockDim.x) {
-            const int64_t o = (int64_t)rho * 4 * I * d + e;
-            const float mu = a.loc[o];
-            locs[e] = mu;
-            const int rr = e / (I * d), j = e % d;
-            if (a.pad != nullptr && a.pad[((int64_t)rho * 4 + rr) * d + j]) continue;
-            bad = bad || !(fabsf(mu) <= kExpandBound) || (a.scale[o] != 1.0f);
-        }
-    }
-    if (bad) bad_s = 1;
-    __syncthreads();
-    const int t = rho / RPT, ap = rho - t * RPT;
-    // fragment entries: (K-step, lane half, column of this repetition) -> 8 consecutive variables
-    for (int e = threadIdx.x; e < a.NKSP * 2 * 4 * I; e += blockDim.x) {
-        const int col = e % (4 * I);
-        const int hg = (e / (4 * I)) & 1;
-        const int ks = e / (8 * I);
-        const int q = col / I, k = col - q * I;
-        const int h = q >> 1, qq = q & 1;
-        const int u = (ap * 2 + qq) * I + k;               // accumulator register of the lane half
-        const int row = (u & 3) + 8 * (u >> 2) + 4 * h;    // MFMA output row = A-fragment row
-        half8 mh, ml, ch, cl;
-#pragma unroll
-        for (int el = 0; el < 8; ++el) {
-            const int f = ks * 16 + hg * 8 + el;
-            float mu = 0.f, cc = 0.f;
-            if (real && f < D) {
-                const int p = posrow[f];
-                if (p >= 0 && p / d == q) {
-                    mu = locs[(q * I + k) * d + (p - q * d)];
-                    cc = -fmaf(0.5f * mu, mu, kLogSqrt2Pi);
-                }
-            }
-            _Float16 hi, lo;
-            split_f16(mu, hi, lo);
-            mh[el] = hi; ml[el] = lo;
-            split_f16(cc, hi, lo);
-            ch[el] = hi; cl[el] = lo;
-        }
-        const int64_t o = (((int64_t)ks * a.NT + t) * 2) * 512 + (hg * 32 + row) * 8;
-        *reinterpret_cast<half8 *>(a.mtab + o) = mh;
-        *reinterpret_cast<half8 *>(a.mtab + o + 512) = ml;
-        *reinterpret_cast<half8 *>(a.ctab + o) = ch;
-        *reinterpret_cast<half8 *>(a.ctab + o + 512) = cl;
-    }
-    // per-(chunk, column) constants - sum_f (mu^2/2 + log sqrt(2 pi)) over the variables of the chunk that belong to
-    // the column's region, and their sum over the chunks; fixed summation order (launches must agree bit for bit)
-    const int KC = 16 * a.KS;
-    const int NCH = (D + KC - 1) / KC;
-    float *csum = locs + 4 * I * d;   // [NCH][4I]
-    for (int e = threadIdx.x; e < NCH * 4 * I; e += blockDim.x) {
-        const int col = e % (4 * I), c = e / (4 * I);
-        const int q = col / I, k = col - q * I;
-        float sum = 0.f;
-        if (real) {
-            const int f1 = min(D, (c + 1) * KC);
-            for (int f = c * KC; f < f1; ++f) {
-                const int p = posrow[f];
-                if (p >= 0 && p / d == q) {
-                    const float mu = locs[(q * I + k) * d + (p - q * d)];
-                    sum -= fmaf(0.5f * mu, mu, kLogSqrt2Pi);
-                }
-            }
-        }
-        const int h = q >> 1, qq = q & 1;
-        const int u = (ap * 2 + qq) * I + k;
-        a.bias[((c * 2 + h) * a.NT + t) * 16 + u] = sum;
-        csum[e] = sum;
-    }
-    // the same per K-step of 16 features and per feature slice of the small-batch kernel (ratspn_gemm_small.hip)
-    const int NKS = (D + 15) / 16;
-    float *ksum = csum + NCH * 4 * I;   // [NKS][4I]
-    for (int e = threadIdx.x; e < NKS * 4 * I; e += blockDim.x) {
-        const int col = e % (4 * I), ks = e / (4 * I);
-        const int q = col / I, k = col - q * I;
-        float sum = 0.f;
-        if (real) {
-            const int f1 = min(D, (ks + 1) * 16);
-            for (int f = ks * 16; f < f1; ++f) {
-                const int p = posrow[f];
-                if (p >= 0 && p / d == q) {
-                    const float mu = locs[(q * I + k) * d + (p - q * d)];
-                    sum -= fmaf(0.5f * mu, mu, kLogSqrt2Pi);
-                }
-            }
-        }
-        const int h = q >> 1, qq = q & 1;
-        const int u = (ap * 2 + qq) * I + k;
-        a.bias_ks[((ks * 2 + h) * a.NT + t) * 16 + u] = sum;
-        ksum[e] = sum;
-    }
-    __syncthreads();
-    if (threadIdx.x < 4 * I) {
-        const int col = threadIdx.x;
-        const int q = col / I, k = col - q * I;
-        float sum = 0.f;
-        for (int c = 0; c < NCH; ++c) sum += csum[c * 4 * I + col];
-        const int h = q >> 1, qq = q & 1;
-        const int u = (ap * 2 + qq) * I + k;
-        a.bias_row[(h * a.NT + t) * 16 + u] = sum;
-    }
-    for (int e = threadIdx.x; e < kGemmSmallWaves * 4 * I; e += blockDim.x) {
-        const int col = e % (4 * I), w = e / (4 * I);
-        const int q = col / I, k = col - q * I;
-        float sum = 0.f;
-        for (int ks = w * NKS / kGemmSmallWaves; ks < (w + 1) * NKS / kGemmSmallWaves; ++ks) sum += ksum[ks * 4 * I + col];
-        const int h = q >> 1, qq = q & 1;
-        const int u = (ap * 2 + qq) * I + k;
-        a.bias_sl[((w * 2 + h) * a.NT + t) * 16 + u] = sum;
-    }
-    if (threadIdx.x == 0) a.elig[rho] = bad_s ? 0 : 1;
+    gemm_prep_block<I>(a, (int)blockIdx.x, prep_dyn);
 }
 
 // The ring kernel below is kept exactly as round 2 left it, in a namespace of its own with its own argument block and
@@ -820,11 +636,12 @@ static int gemm_dispatch_nt(const ring::GemmArgs &a, int reps, int NT, hipStream
 // ratspn_gemm_nan.hip: the ring kernel's variant for marginalised evidence
 bool gemm_small_shape_ok(int D, int NT);
 int64_t gemm_small_max_batch();
-int ratspn_gemm_small_forward(const GemmArgs &a, int reps, int I, int S, int NT, hipStream_t st);
+int ratspn_gemm_small_forward(const GemmArgs &a, const GemmPrepArgs &p, int reps, int I, int S, int NT, hipStream_t st);
 bool gemm_marginal_shape_ok(int D, int NT);
 // ratspn_gemm_wide.hip: 8-channel models, a wave per repetition
 bool gemm_wide_shape_ok(int D, int reps, int I, int S, int C);
-int ratspn_gemm_wide_forward(const GemmArgs &a, int S, hipStream_t st);
+int ratspn_gemm_wide_forward(const GemmArgs &a, const GemmPrepArgs &p, int S, hipStream_t st);
+bool gemm_wide_takes_tile32(int64_t B, int D, int reps, int C, bool marginal);
 int ratspn_gemm_marginal_forward(const GemmArgs &a, int reps, int I, int S, int NT, hipStream_t st);
 
 // The caller (dpk_ratspn_forward) has validated the arguments and carved the workspace.
@@ -833,25 +650,6 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
                         int reps, int I, int S, int C, float *out, double *ll_sum, uint32_t flags, hipStream_t st) {
     const int d = (D + (4 - D % 4) % 4) / 4;
     const int NT = w.g_nt;
-    if (!(flags & DPK_FLAG_PARAMS_CACHED)) {
-        GemmPrepArgs p{};
-        p.verify = (flags & DPK_FLAG_PARAMS_VERIFY) ? 1 : 0;
-        p.hash = w.ghash;
-        p.mask = mask; p.pad = pad; p.loc = loc; p.scale = scale;
-        p.D = D; p.d = d; p.reps = reps; p.NT = NT; p.NKSP = w.g_nksp; p.KS = gemm_ks(NT);
-        p.mtab = w.gm_tab; p.ctab = w.gc_tab; p.bias = w.gbias; p.bias_row = w.gbias_row; p.bias_ks = w.gbias_ks;
-        p.bias_sl = w.gbias_sl; p.elig = w.gelig;
-        p.w[0] = sum_weight0; p.W[0] = w.w[0]; p.LW[0] = w.lw[0]; p.rows[0] = reps * 2 * S; p.n[0] = I * I;
-        p.w[1] = root_weight; p.W[1] = w.w[2]; p.LW[1] = w.lw[2]; p.rows[1] = C; p.n[1] = reps * S * S;
-        const int nrb = NT * (8 / I);
-        const int grid = nrb + cdiv(p.rows[0] + p.rows[1], 4);
-        const size_t lds = ((size_t)D + (size_t)4 * I * d + (size_t)cdiv(D, 32) * 4 * I + (size_t)cdiv(D, 16) * 4 * I) * 4;
-        DPK_REQUIRE(lds <= 60 * 1024, DPK_EUNSUPPORTED, "ratspn_gemm: in_features=%d too large for the table kernel", D);
-        if (I == 2) DPK_LAUNCH(ratspn_gemm_prep_kernel<2>, dim3(grid), dim3(256), lds, st, p);
-        else if (I == 4) DPK_LAUNCH(ratspn_gemm_prep_kernel<4>, dim3(grid), dim3(256), lds, st, p);
-        else DPK_LAUNCH(ratspn_gemm_prep_kernel<8>, dim3(grid), dim3(256), lds, st, p);
-        DPK_CHECK_LAUNCH("ratspn_gemm_prep_kernel");
-    }
     int *slow_word = nullptr;
     int launch_seq = 0;
     bool marginal = slow_hint_next(&slow_word, &launch_seq);
@@ -866,6 +664,34 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
     // (ratspn_gemm_nan.hip); otherwise the ring kernel below.
     const bool wide = I == 8;
     const bool small = !wide && B <= gemm_small_max_batch() && gemm_small_shape_ok(D, NT);
+    // The tables.  "Believed current -- check" (DPK_FLAG_PARAMS_VERIFY) costs the 32-sample mappings nothing extra: their
+    // launch carries the table work-groups itself (kPrepInline, ratspn_gemm_prep.h).  The ring kernels keep the
+    // stand-alone check launch in front of them (DPK_VERIFY_INLINE=0 forces it everywhere: A/B measurements).
+    static const bool inline_allowed = [] { const char *e = getenv("DPK_VERIFY_INLINE"); return !(e && atoi(e) == 0); }();
+    GemmPrepArgs p{};
+    p.mask = mask; p.pad = pad; p.loc = loc; p.scale = scale;
+    p.D = D; p.d = d; p.reps = reps; p.NT = NT; p.NKSP = w.g_nksp; p.KS = gemm_ks(NT);
+    p.mtab = w.gm_tab; p.ctab = w.gc_tab; p.bias = w.gbias; p.bias_row = w.gbias_row; p.bias_ks = w.gbias_ks;
+    p.bias_sl = w.gbias_sl; p.elig = w.gelig;
+    p.w[0] = sum_weight0; p.W[0] = w.w[0]; p.LW[0] = w.lw[0]; p.rows[0] = reps * 2 * S; p.n[0] = I * I;
+    p.w[1] = root_weight; p.W[1] = w.w[2]; p.LW[1] = w.lw[2]; p.rows[1] = C; p.n[1] = reps * S * S;
+    p.hash = w.ghash; p.ctl = w.gctl;
+    const int np = gemm_prep_blocks(NT, I, p.rows[0] + p.rows[1], kGemmPrepThreads);
+    const size_t prep_lds = gemm_prep_lds_bytes(D, I, d);
+    DPK_REQUIRE(prep_lds <= 60 * 1024, DPK_EUNSUPPORTED, "ratspn_gemm: in_features=%d too large for the table kernel", D);
+    const bool verify_inline = inline_allowed && (flags & DPK_FLAG_PARAMS_VERIFY) && !(flags & DPK_FLAG_PARAMS_CACHED) &&
+                               ((wide && gemm_wide_takes_tile32(B, D, reps, C, marginal)) || small);
+    if (verify_inline) {
+        p.mode = kPrepInline;
+        p.np = np;
+    } else if (!(flags & DPK_FLAG_PARAMS_CACHED)) {
+        p.mode = (flags & DPK_FLAG_PARAMS_VERIFY) ? kPrepVerify : kPrepBuild;
+        if (I == 2) DPK_LAUNCH(ratspn_gemm_prep_kernel<2>, dim3(np), dim3(kGemmPrepThreads), prep_lds, st, p);
+        else if (I == 4) DPK_LAUNCH(ratspn_gemm_prep_kernel<4>, dim3(np), dim3(kGemmPrepThreads), prep_lds, st, p);
+        else DPK_LAUNCH(ratspn_gemm_prep_kernel<8>, dim3(np), dim3(kGemmPrepThreads), prep_lds, st, p);
+        DPK_CHECK_LAUNCH("ratspn_gemm_prep_kernel");
+        p.np = 0;
+    }
     if (wide || small || (marginal && gemm_marginal_shape_ok(D, NT))) {
         GemmArgs a{};
         a.x = x; a.B = B; a.D = D; a.d = d; a.reps = reps; a.C = C;
@@ -878,8 +704,8 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
         a.mask = mask; a.pad = pad; a.loc = loc; a.scale = scale;
         a.slow_flag = slow_word; a.launch_seq = launch_seq; a.marginal = marginal ? 1 : 0;
         a.ablate = ablate;
-        if (wide) return ratspn_gemm_wide_forward(a, S, st);
-        if (small) return ratspn_gemm_small_forward(a, reps, I, S, NT, st);
+        if (wide) return ratspn_gemm_wide_forward(a, p, S, st);
+        if (small) return ratspn_gemm_small_forward(a, p, reps, I, S, NT, st);
         return ratspn_gemm_marginal_forward(a, reps, I, S, NT, st);
     }
     ring::GemmArgs a{};

@@ -21,6 +21,7 @@ constexpr int kGemmStages = 3;
 #endif
 constexpr bool kGemmXNonTemporal = DPK_X_NT != 0;   // x pieces of the ring: non-temporal LDS-DMA
 typedef __attribute__((address_space(3))) float lfloat;
+typedef __attribute__((address_space(3))) unsigned lunsigned;
 typedef __attribute__((address_space(3))) char lchar;
 typedef const __attribute__((address_space(1))) char *gcchar_p;
 typedef const __attribute__((address_space(1))) void *gvoid_p;

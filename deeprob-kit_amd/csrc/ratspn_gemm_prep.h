@@ -1,0 +1,388 @@
+// Parameter tables of the fused RAT-SPN kernels with the leaf layer on the matrix cores (ratspn_gemm*.hip), and the
+// check that keeps them honest.
+//
+// reference: what the tables cache is RegionGraphLayer's gather + GaussianLayer's parameters
+// (deeprob/spn/layers/ratspn.py:42-66, :87-108, :160-213) and the log_softmax of the sum / root weights (:375, :455).
+//
+// The tables (f16 MFMA fragments of the means, per-chunk / per-K-step constants, softmax rows) are a pure function of
+// mask / pad_mask / loc / scale / sum weights / root weights.  The host keys them on (address, version counter), but a
+// write through `param.data` moves neither, so by default every call CHECKS them on the device
+// (DPK_FLAG_PARAMS_VERIFY).  Three ways to run the work of one table work-group (`gemm_prep_block`):
+//   kPrepBuild   unconditional rebuild (the host knows the parameters changed): its own launch, before the model kernel;
+//   kPrepVerify  its own launch: fingerprint the bytes the block's outputs depend on, rebuild if they differ from the
+//                fingerprint stored at the last build (block local; round 3) -- the large-batch ring kernels;
+//   kPrepInline  round 4: the table work-groups are the LEADING work-groups of the model kernel's own launch.  They
+//                fingerprint and publish ONE verdict for the launch (VerifyCtl); the model work-groups run
+//                speculatively on the cached tables and read the verdict before they produce anything.  Clean (every
+//                call but the first after a `.data` write): the tables were right, nothing else happens -- the check
+//                costs no launch and hides under the x stream.  Dirty: every model work-group evaluates its samples on
+//                the table-free exact route (per-element leaves, log-sum-exp straight from the raw weights), while the
+//                table work-groups rebuild IN PLACE (nobody consumes a table value in a dirty launch) and store the new
+//                fingerprints: the next launch is clean again.  No host round trip, replays from a HIP graph heal
+//                themselves.
+// Protocol of a launch (np table work-groups, nm model work-groups; all counters zero between launches):
+//   table wg:  h = fingerprint; arrive: word += 1 + (h != stored) << 32;  wait until low32(word) == np;  dirty = hi32 != 0;
+//              ticket = readers++;  [dirty: rebuild, store h];  last ticket (np + nm - 1) zeroes word and readers
+//   model wg:  ... main loop ...; wait until low32(word) == np; dirty = hi32 != 0; ticket = readers++; ...; the same reset
+// A work-group only ever waits for table work-groups, which have lower block indices (dispatched first) and never wait
+// for a model work-group: no circular wait, whatever the residency.  One module evaluates on one stream at a time (as
+// its workspace already requires); a wait that does not end within ~1 s is taken as "dirty" (exact route), never a hang.
+#pragma once
+#include "common.h"
+#include "ratspn_gemm_common.h"
+#include <math.h>
+
+namespace dpk {
+
+struct VerifyCtl {
+    unsigned long long word;   // low 32: table work-groups that have published; high 32: those that found changed bytes
+    unsigned readers;          // work-groups that have read the verdict
+    unsigned pad;
+};
+
+enum { kPrepBuild = 0, kPrepVerify = 1, kPrepInline = 2 };
+
+struct GemmPrepArgs {
+    const int64_t *mask;
+    const uint8_t *pad;
+    const float *loc, *scale;
+    int D, d, reps, NT, NKSP, KS;
+    uint16_t *mtab, *ctab;
+    float *bias, *bias_row, *bias_ks, *bias_sl;
+    int *elig;
+    const float *w[3];
+    float *W[3], *LW[3];
+    int rows[3], n[3];
+    int mode;                   // kPrepBuild / kPrepVerify / kPrepInline
+    unsigned long long *hash;   // [NT*RPT] per repetition, then one per softmax-row work-group (kPrepInline)
+    VerifyCtl *ctl;
+    int np;                     // table work-groups of the launch
+    int readers;                // work-groups that read the verdict (np + model work-groups)
+};
+
+// table work-groups a launch needs: one per repetition slot + one per (threads / 64) softmax rows
+__host__ __device__ inline int gemm_prep_blocks(int NT, int I, int rows_total, int threads) {
+    return NT * (8 / I) + cdiv(rows_total, threads / 64);
+}
+
+// ---- the verdict word ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ void vi_arrive(VerifyCtl *c, bool mismatch) {
+    __hip_atomic_fetch_add(&c->word, 1ull + (mismatch ? (1ull << 32) : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one thread: wait for the np arrivals; returns the verdict (true = some table is stale) and takes a reader ticket
+__device__ __forceinline__ bool vi_wait(VerifyCtl *c, int np, unsigned &ticket) {
+    unsigned long long v = __hip_atomic_load(&c->word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool timed_out = false;
+    if ((unsigned)v < (unsigned)np) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+        do {
+            __builtin_amdgcn_s_sleep(8);
+            v = __hip_atomic_load(&c->word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            timed_out = __builtin_amdgcn_s_memrealtime() - t0 > 100000000ull;
+        } while ((unsigned)v < (unsigned)np && !timed_out);
+    }
+    ticket = __hip_atomic_fetch_add(&c->readers, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (v >> 32) != 0ull || timed_out;
+}
+// the last reader of the launch leaves the counters as it found them
+__device__ __forceinline__ void vi_done(VerifyCtl *c, unsigned ticket, int readers) {
+    if (ticket == (unsigned)(readers - 1)) {
+        __hip_atomic_store(&c->word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&c->readers, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---- one table work-group -------------------------------------------------------------------------------------------
+// blk < NT * RPT: the fragments / constants / eligibility flag of repetition slot blk; otherwise (blockDim.x / 64)
+// softmax rows, one wave per row (torch.log_softmax at ratspn.py:375 and :455).  dyn = the launch's dynamic LDS
+// (>= gemm_prep_lds_bytes).  Every thread of the work-group calls this.
+constexpr int kGemmPrepScratchInts = 64;   // reduction / verdict scratch in front of the tables' staging area
+__host__ __device__ inline size_t gemm_prep_lds_bytes(int D, int I, int d) {
+    return ((size_t)kGemmPrepScratchInts + (size_t)D + (size_t)4 * I * d + (size_t)cdiv(D, 32) * 4 * I +
+            (size_t)cdiv(D, 16) * 4 * I) * 4;
+}
+
+template <int I>
+__device__ __forceinline__ void gemm_prep_block(const GemmPrepArgs &a, int blk, int *dyn) {
+    constexpr int RPT = 8 / I;       // repetitions per 32-column tile (4 regions x I channels each)
+    const int nrb = a.NT * RPT;
+    const int rpb = (int)blockDim.x >> 6;   // softmax rows per work-group
+    // (no static LDS: the model kernels that carry these work-groups ask for the whole 160 KB as dynamic LDS)
+    unsigned long long *red_s = reinterpret_cast<unsigned long long *>(dyn);   // [17]
+    unsigned *vi_s = reinterpret_cast<unsigned *>(dyn) + 34;                    // [2]
+    int &bad_s = dyn[36];
+    dyn += kGemmPrepScratchInts;
+    const bool rows_blk = blk >= nrb;
+    const int rho = blk;
+    const bool real = !rows_blk && rho < a.reps;
+    const int D = a.D, d = a.d;
+
+    // ---- fingerprint of the bytes this work-group's outputs depend on ------------------------------------------------
+    // (block local: a repetition's tables depend on its own slice of mask / pad_mask / loc / scale only; a write through
+    // `param.data` moves no version counter on the host)
+    unsigned long long h = 0x9E3779B97F4A7C15ull + (unsigned long long)blk;
+    {
+        const unsigned long long stored_early = a.mode != kPrepBuild ? a.hash[blk] : 0ull;   // (requested first)
+        if (real) {
+            h += fp_range(a.mask + (int64_t)rho * 4 * d, (int64_t)4 * d * 8, 1);
+            h += fp_range(a.pad ? a.pad + (int64_t)rho * 4 * d : nullptr, (int64_t)4 * d, 2);
+            h += fp_range(a.loc + (int64_t)rho * 4 * I * d, (int64_t)4 * I * d * 4, 3);
+            h += fp_range(a.scale + (int64_t)rho * 4 * I * d, (int64_t)4 * I * d * 4, 4);
+        } else if (rows_blk) {
+            // the raw weight rows this work-group normalises (fingerprints are per work-group: the standalone table
+            // kernel and the model kernels all run 512 threads = 8 rows per work-group)
+            int row = (blk - nrb) * rpb;
+            for (int r = 0; r < rpb; ++r, ++row) {
+                int rr = row;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    if (rr < a.rows[m]) {
+                        // (position-dependent through the row number: rows that trade places change the sum)
+                        h += fp_range(a.w[m] + (int64_t)rr * a.n[m], (int64_t)a.n[m] * 4, 5u + 8192u * (unsigned)row);
+                        break;
+                    }
+                    rr -= a.rows[m];
+                }
+            }
+        }
+        h = block_sum_u64(h, red_s);
+        if (a.mode == kPrepVerify) {
+            if (stored_early == h) return;                    // nothing this work-group's outputs depend on has changed
+        } else if (a.mode == kPrepInline) {
+            if (threadIdx.x == 0) {
+                vi_arrive(a.ctl, stored_early != h);
+                unsigned ticket;
+                const bool dirty = vi_wait(a.ctl, a.np, ticket);
+                vi_done(a.ctl, ticket, a.readers);
+                vi_s[0] = dirty ? 1u : 0u;
+            }
+            __syncthreads();
+            if (vi_s[0] == 0u) return;                        // clean launch: nothing to do
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) a.hash[blk] = h;
+    }
+
+    if (rows_blk) {
+        int row = (blk - nrb) * rpb + (threadIdx.x >> 6);
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            if (row < a.rows[m]) {
+                const int n = a.n[m];
+                const float *src = a.w[m] + (int64_t)row * n;
+                float mx = -INFINITY;
+                for (int i = lane; i < n; i += 64) mx = fmaxf(mx, src[i]);
+                mx = wave_reduce_max(mx);
+                float sum = 0.f;
+                for (int i = lane; i < n; i += 64) sum += expf(src[i] - mx);
+                sum = wave_reduce_sum(sum);
+                const float ls = logf(sum);
+                for (int i = lane; i < n; i += 64) {
+                    const float l = src[i] - mx - ls;
+                    a.LW[m][(int64_t)row * n + i] = l;
+                    a.W[m][(int64_t)row * n + i] = expf(l);
+                }
+                return;
+            }
+            row -= a.rows[m];
+        }
+        return;
+    }
+
+    int *posrow = dyn;               // [D] position q*d + j of variable f in this repetition, -1 if absent
+    float *locs = reinterpret_cast<float *>(posrow + a.D);   // [4][I][d] the repetition's means
+    for (int f = threadIdx.x; f < D; f += blockDim.x) posrow[f] = -1;
+    if (threadIdx.x == 0) bad_s = 0;
+    __syncthreads();
+    bool bad = false;
+    if (real) {
+        for (int e = threadIdx.x; e < 4 * d; e += blockDim.x) {
+            const int64_t o = (int64_t)rho * 4 * d + e;
+            if (a.pad != nullptr && a.pad[o]) continue;
+            const int f = (int)a.mask[o];
+            if (f >= 0 && f < D) posrow[f] = e;
+        }
+        // eligibility of the repetition for the expanded form: scale == 1 everywhere, |mu| <= kExpandBound
+        for (int e = threadIdx.x; e < 4 * I * d; e += blockDim.x) {
+            const int64_t o = (int64_t)rho * 4 * I * d + e;
+            const float mu = a.loc[o];
+            locs[e] = mu;
+            const int rr = e / (I * d), j = e % d;
+            if (a.pad != nullptr && a.pad[((int64_t)rho * 4 + rr) * d + j]) continue;
+            bad = bad || !(fabsf(mu) <= kExpandBound) || (a.scale[o] != 1.0f);
+        }
+    }
+    if (bad) bad_s = 1;
+    __syncthreads();
+    const int t = rho / RPT, ap = rho - t * RPT;
+    // fragment entries: (K-step, lane half, column of this repetition) -> 8 consecutive variables
+    for (int e = threadIdx.x; e < a.NKSP * 2 * 4 * I; e += blockDim.x) {
+        const int col = e % (4 * I);
+        const int hg = (e / (4 * I)) & 1;
+        const int ks = e / (8 * I);
+        const int q = col / I, k = col - q * I;
+        const int hh = q >> 1, qq = q & 1;
+        const int u = (ap * 2 + qq) * I + k;               // accumulator register of the lane half
+        const int row = (u & 3) + 8 * (u >> 2) + 4 * hh;   // MFMA output row = A-fragment row
+        half8 mh, ml, ch, cl;
+#pragma unroll
+        for (int el = 0; el < 8; ++el) {
+            const int f = ks * 16 + hg * 8 + el;
+            float mu = 0.f, cc = 0.f;
+            if (real && f < D) {
+                const int p = posrow[f];
+                if (p >= 0 && p / d == q) {
+                    mu = locs[(q * I + k) * d + (p - q * d)];
+                    cc = -fmaf(0.5f * mu, mu, kLogSqrt2Pi);
+                }
+            }
+            _Float16 hi, lo;
+            split_f16(mu, hi, lo);
+            mh[el] = hi; ml[el] = lo;
+            split_f16(cc, hi, lo);
+            ch[el] = hi; cl[el] = lo;
+        }
+        const int64_t o = (((int64_t)ks * a.NT + t) * 2) * 512 + (hg * 32 + row) * 8;
+        *reinterpret_cast<half8 *>(a.mtab + o) = mh;
+        *reinterpret_cast<half8 *>(a.mtab + o + 512) = ml;
+        *reinterpret_cast<half8 *>(a.ctab + o) = ch;
+        *reinterpret_cast<half8 *>(a.ctab + o + 512) = cl;
+    }
+    // per-(chunk, column) constants - sum_f (mu^2/2 + log sqrt(2 pi)) over the variables of the chunk that belong to
+    // the column's region, and their sum over the chunks; fixed summation order (launches must agree bit for bit)
+    const int KC = 16 * a.KS;
+    const int NCH = (D + KC - 1) / KC;
+    float *csum = locs + 4 * I * d;   // [NCH][4I]
+    for (int e = threadIdx.x; e < NCH * 4 * I; e += blockDim.x) {
+        const int col = e % (4 * I), c = e / (4 * I);
+        const int q = col / I, k = col - q * I;
+        float sum = 0.f;
+        if (real) {
+            const int f1 = min(D, (c + 1) * KC);
+            for (int f = c * KC; f < f1; ++f) {
+                const int p = posrow[f];
+                if (p >= 0 && p / d == q) {
+                    const float mu = locs[(q * I + k) * d + (p - q * d)];
+                    sum -= fmaf(0.5f * mu, mu, kLogSqrt2Pi);
+                }
+            }
+        }
+        const int hh = q >> 1, qq = q & 1;
+        const int u = (ap * 2 + qq) * I + k;
+        a.bias[((c * 2 + hh) * a.NT + t) * 16 + u] = sum;
+        csum[e] = sum;
+    }
+    // the same per K-step of 16 features and per feature slice of the small-batch kernel (ratspn_gemm_small.hip)
+    const int NKS = (D + 15) / 16;
+    float *ksum = csum + NCH * 4 * I;   // [NKS][4I]
+    for (int e = threadIdx.x; e < NKS * 4 * I; e += blockDim.x) {
+        const int col = e % (4 * I), ks = e / (4 * I);
+        const int q = col / I, k = col - q * I;
+        float sum = 0.f;
+        if (real) {
+            const int f1 = min(D, (ks + 1) * 16);
+            for (int f = ks * 16; f < f1; ++f) {
+                const int p = posrow[f];
+                if (p >= 0 && p / d == q) {
+                    const float mu = locs[(q * I + k) * d + (p - q * d)];
+                    sum -= fmaf(0.5f * mu, mu, kLogSqrt2Pi);
+                }
+            }
+        }
+        const int hh = q >> 1, qq = q & 1;
+        const int u = (ap * 2 + qq) * I + k;
+        a.bias_ks[((ks * 2 + hh) * a.NT + t) * 16 + u] = sum;
+        ksum[e] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 * I) {
+        const int col = threadIdx.x;
+        const int q = col / I, k = col - q * I;
+        float sum = 0.f;
+        for (int c = 0; c < NCH; ++c) sum += csum[c * 4 * I + col];
+        const int hh = q >> 1, qq = q & 1;
+        const int u = (ap * 2 + qq) * I + k;
+        a.bias_row[(hh * a.NT + t) * 16 + u] = sum;
+    }
+    for (int e = threadIdx.x; e < kGemmSmallWaves * 4 * I; e += blockDim.x) {
+        const int col = e % (4 * I), w = e / (4 * I);
+        const int q = col / I, k = col - q * I;
+        float sum = 0.f;
+        for (int ks = w * NKS / kGemmSmallWaves; ks < (w + 1) * NKS / kGemmSmallWaves; ++ks) sum += ksum[ks * 4 * I + col];
+        const int hh = q >> 1, qq = q & 1;
+        const int u = (ap * 2 + qq) * I + k;
+        a.bias_sl[((w * 2 + hh) * a.NT + t) * 16 + u] = sum;
+    }
+    if (threadIdx.x == 0) a.elig[rho] = bad_s ? 0 : 1;
+}
+
+// ---- the table-free nodes of a dirty launch --------------------------------------------------------------------------
+// out[o] = logsumexp_{i,j}(a[i] + c[j] + log_softmax(w[o, :])[i, j]) straight from the RAW weights w [NO][NI*NI]
+// (ProductLayer.forward ratspn.py:280-285 followed by SumLayer.forward :375-377): two log-sum-exps per node, rolled
+// loops -- slow by design, this is the route of the one launch that finds its tables stale.
+template <int NI, int NO>
+__device__ __forceinline__ void prodsum_node_raw(const float (&a)[NI], const float (&c)[NI], const float *w, float *slot,
+                                                 float (&out)[NO]) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        slot[i] = a[i];
+        slot[NI + i] = c[i];
+    }
+#pragma unroll 1
+    for (int o = 0; o < NO; ++o) {
+        const float *wo = w + o * NI * NI;
+        float mw = -INFINITY, m = -INFINITY;
+#pragma unroll 1
+        for (int e = 0; e < NI * NI; ++e) {
+            const float we = wo[e];
+            mw = fmaxf(mw, we);
+            m = fmaxf(m, slot[e / NI] + slot[NI + e % NI] + we);
+        }
+        float sw = 0.f, sv = 0.f;
+#pragma unroll 1
+        for (int e = 0; e < NI * NI; ++e) {
+            const float we = wo[e];
+            sw += expf(we - mw);
+            if (m > -INFINITY) sv += expf(slot[e / NI] + slot[NI + e % NI] + we - m);
+        }
+        const float res = (m > -INFINITY) ? (m + logf(sv)) - (mw + logf(sw)) : -INFINITY;
+#pragma unroll
+        for (int q = 0; q < NO; ++q)
+            if (q == o) out[q] = res;
+    }
+}
+
+// log-sum-exp of one raw weight row (the normaliser of torch.log_softmax), by one thread
+__device__ __forceinline__ float raw_row_lse(const float *w, int n) {
+    float m = -INFINITY;
+#pragma unroll 1
+    for (int e = 0; e < n; ++e) m = fmaxf(m, w[e]);
+    float s = 0.f;
+#pragma unroll 1
+    for (int e = 0; e < n; ++e) s += expf(w[e] - m);
+    return m + logf(s);
+}
+
+// (m, s) of one repetition's share of the root: logsumexp_{i,j}(a[i] + c[j] + w[i, j] - lse_row) = m + log s
+template <int NI>
+__device__ __forceinline__ void root_partial_raw(const float (&a)[NI], const float (&c)[NI], const float *w, float lse_row,
+                                                 float *slot, float &m_out, float &s_out) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        slot[i] = a[i];
+        slot[NI + i] = c[i];
+    }
+    float m = -INFINITY;
+#pragma unroll 1
+    for (int e = 0; e < NI * NI; ++e) m = fmaxf(m, slot[e / NI] + slot[NI + e % NI] + (w[e] - lse_row));
+    float s = 0.f;
+    if (m > -INFINITY) {
+#pragma unroll 1
+        for (int e = 0; e < NI * NI; ++e) s += expf(slot[e / NI] + slot[NI + e % NI] + (w[e] - lse_row) - m);
+    }
+    m_out = m;
+    s_out = s;
+}
+
+}  // namespace dpk

@@ -23,6 +23,7 @@
 // Results agree with the ring kernel to fp32 rounding, not bit for bit: the K-steps are summed in eight partial
 // accumulators here and in one there.  A given batch size always takes the same kernel.
 #include "ratspn_gemm_fused.h"
+#include "ratspn_gemm_prep.h"
 #include <stdlib.h>
 
 namespace dpk {
@@ -87,9 +88,11 @@ __device__ __forceinline__ void row16_lse_merge(float &m, float &sum) {
 // (repetition, partition)): any scale, any evidence -- the reference's formula term by term (nan_to_num_ at
 // ratspn.py:103), log-domain fallbacks inside the nodes.  Slow by design; returns the sample's log-likelihoods through
 // `store` (called by every lane with identical values, class by class).
+// `raw0` / `rawr` non-null (a launch that found its tables stale, ratspn_gemm_prep.h): the nodes take their log-softmax
+// weights straight from the raw sum / root weights instead of the (being rebuilt) tables.
 template <int I, int S, class Store>
 __device__ __forceinline__ void small_exact_wave(const GemmArgs &a, const float *xr, int rc, int p, bool active,
-                                                 LseScratch sc, Store store) {
+                                                 LseScratch sc, const float *raw0, const float *rawr, Store store) {
     const int d = a.d;
     float leaf[2][I];
 #pragma unroll
@@ -112,7 +115,8 @@ __device__ __forceinline__ void small_exact_wave(const GemmArgs &a, const float 
     }
     float n1[S];
     const int64_t wo = ((int64_t)rc * 2 + p) * S * I * I;
-    prodsum_node<I, S>(leaf[0], leaf[1], a.W0 + wo, a.LW0 + wo, sc, n1);
+    if (raw0 != nullptr) prodsum_node_raw<I, S>(leaf[0], leaf[1], raw0 + wo, sc.slot, n1);
+    else prodsum_node<I, S>(leaf[0], leaf[1], a.W0 + wo, a.LW0 + wo, sc, n1);
     float ta[S], tc[S];
 #pragma unroll
     for (int o = 0; o < S; ++o) {
@@ -127,9 +131,14 @@ __device__ __forceinline__ void small_exact_wave(const GemmArgs &a, const float 
     for (int cl = 0; cl < a.C; ++cl) {
         float pm = -INFINITY, ps = 0.f;
         if (active && p == 0) {
-            const float *wr = (const float *)a.Wr + (int64_t)cl * M + rc * S * S;
-            const float *lwr = (const float *)a.LWr + (int64_t)cl * M + rc * S * S;
-            root_partial<S>(ta, tc, ea, ec, ma, mc, wr, lwr, sc, pm, ps);
+            if (rawr != nullptr) {
+                root_partial_raw<S>(ta, tc, rawr + (int64_t)cl * M + rc * S * S, raw_row_lse(rawr + (int64_t)cl * M, M),
+                                    sc.slot, pm, ps);
+            } else {
+                const float *wr = (const float *)a.Wr + (int64_t)cl * M + rc * S * S;
+                const float *lwr = (const float *)a.LWr + (int64_t)cl * M + rc * S * S;
+                root_partial<S>(ta, tc, ea, ec, ma, mc, wr, lwr, sc, pm, ps);
+            }
             if (!(ps > 0.f)) pm = -INFINITY;
         }
         row16_lse_merge(pm, ps);
@@ -138,7 +147,7 @@ __device__ __forceinline__ void small_exact_wave(const GemmArgs &a, const float 
 }
 
 template <int I, int S, int NT, int MAXK>
-__global__ __launch_bounds__(kGemmSmallWaves * 64) void ratspn_gemm_small_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(kGemmSmallWaves * 64) void ratspn_gemm_small_kernel(const GemmArgs a, const GemmPrepArgs pa) {
     constexpr int RPT = 8 / I;
     constexpr int NMAX = (I > S ? I : S);
     constexpr int NR = NT * 16;                      // accumulator registers of a lane
@@ -159,9 +168,16 @@ __global__ __launch_bounds__(kGemmSmallWaves * 64) void ratspn_gemm_small_kernel
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // A launch that checks its parameter tables itself (kPrepInline, ratspn_gemm_prep.h): the first pa.np work-groups are
+    // the table work-groups -- fingerprint, verdict, rebuild if stale -- the others evaluate tile blockIdx.x - pa.np.
+    const int np = pa.np;
+    if ((int)blockIdx.x < np) {
+        gemm_prep_block<I>(pa, (int)blockIdx.x, reinterpret_cast<int *>(smem_generic));
+        return;
+    }
     const int D = a.D;
     const int NKS = (D + 15) >> 4;
-    const int64_t b0 = (int64_t)blockIdx.x * 32;
+    const int64_t b0 = (int64_t)((int)blockIdx.x - np) * 32;
     SM_STAMP(0);
     SM_STAMP(15);
 
@@ -360,7 +376,16 @@ __global__ __launch_bounds__(kGemmSmallWaves * 64) void ratspn_gemm_small_kernel
         mine[(NR + 1) * RSTR] = __uint_as_float((need_exact ? 1u : 0u) | (odd_mask != 0u ? 2u : 0u) | (saw_nan ? 4u : 0u));
     }
     SM_STAMP(4);   // partials written
+    // the launch's verdict on its tables (np > 0): by now the table work-groups published it long ago -- one L2 round
+    // trip for thread 0, under the other waves' MFMA tails; the barrier hands it to everyone
+    lunsigned *verdict_l = (lunsigned *)(smem + kGemmSmallWaves * REG + kGemmSmallWaves * 8);
+    unsigned vi_ticket = 0u;
+    if (np > 0 && tid == 0) {
+        const bool dirty = vi_wait(pa.ctl, np, vi_ticket);
+        verdict_l[0] = dirty ? 1u : 0u;
+    }
     __syncthreads();
+    const bool tables_stale = np > 0 && verdict_l[0] != 0u;
     SM_STAMP(5);   // barrier passed
     if (a.ablate & 2) return;
 
@@ -402,7 +427,7 @@ __global__ __launch_bounds__(kGemmSmallWaves * 64) void ratspn_gemm_small_kernel
         }
     }
     // the expanded square is within the 1e-5 bar while sum x^2 <= 36 D (|mu| <= 6: DESIGN 3.3)
-    bool bad = (flags & 1u) != 0u || !(qtot <= kExpandBound * kExpandBound * (float)D) || (active && elig == 0);
+    bool bad = (flags & 1u) != 0u || !(qtot <= kExpandBound * kExpandBound * (float)D) || (active && elig == 0) || tables_stale;
     SM_STAMP(7);   // flags, constants
 
     // ---- product + sum node of the partition (exp domain, base-2 transcendentals) -------------------------------
@@ -481,7 +506,8 @@ __global__ __launch_bounds__(kGemmSmallWaves * 64) void ratspn_gemm_small_kernel
         LseScratch sc{reinterpret_cast<float *>(smem_generic + wave * REG + SLOT * 4) + lane * (2 * NMAX)};
         const float *xr = a.x + (b2 < a.B ? b2 : a.B - 1) * D;
         part = 0.0;
-        small_exact_wave<I, S>(a, xr, rc, p, active, sc, [&](int cl, float ll) {
+        small_exact_wave<I, S>(a, xr, rc, p, active, sc, tables_stale ? pa.w[0] : nullptr, tables_stale ? pa.w[1] : nullptr,
+                               [&](int cl, float ll) {
             if (writer) a.out[b2 * a.C + cl] = ll;
             part += (double)ll;
         });
@@ -502,10 +528,11 @@ __global__ __launch_bounds__(kGemmSmallWaves * 64) void ratspn_gemm_small_kernel
 #pragma unroll
             for (int w = 0; w < kGemmSmallWaves; ++w) tot += red_l[w];
             atomicAdd(a.ll_sum, tot);
-            if (blockIdx.x == 0) atomicAdd(a.ll_sum + 1, (double)a.B * (double)a.C);
+            if ((int)blockIdx.x == np) atomicAdd(a.ll_sum + 1, (double)a.B * (double)a.C);
         }
     }
     if ((flags & 4u) != 0u && lane == 0 && a.slow_flag != nullptr) *a.slow_flag = a.launch_seq;
+    if (np > 0 && tid == 0) vi_done(pa.ctl, vi_ticket, pa.readers);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -529,8 +556,9 @@ static int64_t &small_batch_max_ref() {
 int64_t gemm_small_max_batch() { return small_batch_max_ref(); }
 
 template <int I, int S, int NT, int MAXK>
-static int gemm_small_launch(const GemmArgs &a, hipStream_t st) {
-    const size_t lds = (size_t)kGemmSmallWaves * gemm_small_region_bytes(NT, MAXK) + kGemmSmallWaves * 8;
+static int gemm_small_launch(const GemmArgs &a, const GemmPrepArgs &p, hipStream_t st) {
+    size_t lds = (size_t)kGemmSmallWaves * gemm_small_region_bytes(NT, MAXK) + kGemmSmallWaves * 8 + 16;
+    if (p.np > 0 && gemm_prep_lds_bytes(a.D, I, a.d) > lds) lds = gemm_prep_lds_bytes(a.D, I, a.d);
     DPK_REQUIRE(lds <= 160 * 1024, DPK_EUNSUPPORTED, "ratspn_gemm_small: %zu bytes of LDS", lds);
     auto kern = ratspn_gemm_small_kernel<I, S, NT, MAXK>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024)) return rc;
@@ -546,26 +574,28 @@ static int gemm_small_launch(const GemmArgs &a, hipStream_t st) {
     hipEvent_t ev0, ev1;
     profile_take(&ev0, &ev1, DPK_KERNEL_RATSPN_FUSED);
     if (ev0) (void)hipEventRecord(ev0, st);
-    DPK_LAUNCH(kern, dim3(cdiv(a.B, 32)), dim3(kGemmSmallWaves * 64), lds, st, a);
+    GemmPrepArgs pp = p;
+    pp.readers = p.np + (int)cdiv(a.B, 32);
+    DPK_LAUNCH(kern, dim3(p.np + cdiv(a.B, 32)), dim3(kGemmSmallWaves * 64), lds, st, a, pp);
     if (ev1) (void)hipEventRecord(ev1, st);
     DPK_CHECK_LAUNCH("ratspn_gemm_small_kernel");
     return DPK_OK;
 }
 
 template <int I, int S, int NT>
-static int gemm_small_launch_k(const GemmArgs &a, hipStream_t st) {
+static int gemm_small_launch_k(const GemmArgs &a, const GemmPrepArgs &p, hipStream_t st) {
     // K-steps of 16 features per wave: the smallest instantiation that holds the slice
     const int per_wave = cdiv(cdiv(a.D, 16), kGemmSmallWaves);
-    if (per_wave <= 4) return gemm_small_launch<I, S, NT, 4>(a, st);
-    if (per_wave <= 7) return gemm_small_launch<I, S, NT, 7>(a, st);
-    return gemm_small_launch<I, S, NT, 8>(a, st);
+    if (per_wave <= 4) return gemm_small_launch<I, S, NT, 4>(a, p, st);
+    if (per_wave <= 7) return gemm_small_launch<I, S, NT, 7>(a, p, st);
+    return gemm_small_launch<I, S, NT, 8>(a, p, st);
 }
 
 // The caller (ratspn_gemm_forward) has built the tables and filled the argument block.
-int ratspn_gemm_small_forward(const GemmArgs &a, int reps, int I, int S, int NT, hipStream_t st) {
+int ratspn_gemm_small_forward(const GemmArgs &a, const GemmPrepArgs &p, int reps, int I, int S, int NT, hipStream_t st) {
 #define DPK_SMALL(II, SS)                                                 \
     if (I == II && S == SS)                                               \
-        return NT == 1 ? gemm_small_launch_k<II, SS, 1>(a, st) : gemm_small_launch_k<II, SS, 2>(a, st)
+        return NT == 1 ? gemm_small_launch_k<II, SS, 1>(a, p, st) : gemm_small_launch_k<II, SS, 2>(a, p, st)
     DPK_SMALL(2, 2);
     DPK_SMALL(2, 4);
     DPK_SMALL(4, 2);

@@ -23,6 +23,7 @@
 // (every wave sees the same x tile, so all eight take that decision together).  Vanished sum nodes fall back to the
 // log domain inside prodsum_node / root_partial (ratspn_nodes.h).
 #include "ratspn_gemm_fused.h"
+#include "ratspn_gemm_prep.h"
 #include <type_traits>
 #include <stdlib.h>
 
@@ -111,10 +112,13 @@ __device__ __forceinline__ void wide_leaf_sums(const GemmArgs &a, const gf32x16 
     }
 }
 
+// raw0 / rawr non-null: a launch that found its tables stale (ratspn_gemm_prep.h; `exact` is then set as well) -- the
+// nodes take their log-softmax weights straight from the raw sum / root weights.
 template <int S>
 __device__ __forceinline__ double wide_block_upper(const GemmArgs &a, const gf32x16 &acc, unsigned long long odd_mask,
                                                    float qtot, bool exact, int rho, bool mine, int64_t b0,
-                                                   const lfloat *w0_l, char *lds) {
+                                                   const lfloat *w0_l, char *lds, const float *raw0 = nullptr,
+                                                   const float *rawr = nullptr) {
     constexpr int I = kWideI;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = lane & 31, h = lane >> 5;
@@ -134,7 +138,8 @@ __device__ __forceinline__ double wide_block_upper(const GemmArgs &a, const gf32
     {
         const lfloat *wl = w0_l + h * S * I * I;
         const float *lw = a.LW0 + ((int64_t)rho * 2 + h) * S * I * I;
-        prodsum_node<I, S>(va, vc, wl, lw, sc, n1);
+        if (raw0 != nullptr) prodsum_node_raw<I, S>(va, vc, raw0 + ((int64_t)rho * 2 + h) * S * I * I, sc.slot, n1);
+        else prodsum_node<I, S>(va, vc, wl, lw, sc, n1);
     }
     float ta[S], tc[S];
 #pragma unroll
@@ -153,9 +158,14 @@ __device__ __forceinline__ double wide_block_upper(const GemmArgs &a, const gf32
         // the two lanes of a sample hold the same (ta, tc): they split the classes
         for (int cl = h; cl < C; cl += 2) {
             float pm, ps;
-            const cfloat_p wr = a.Wr + (int64_t)cl * M + rho * S * S;
-            const cfloat_p lwr = a.LWr + (int64_t)cl * M + rho * S * S;
-            root_partial<S>(ta, tc, ea, ec, ma, mc, wr, lwr, sc, pm, ps);
+            if (rawr != nullptr) {
+                root_partial_raw<S>(ta, tc, rawr + (int64_t)cl * M + rho * S * S, raw_row_lse(rawr + (int64_t)cl * M, M),
+                                    sc.slot, pm, ps);
+            } else {
+                const cfloat_p wr = a.Wr + (int64_t)cl * M + rho * S * S;
+                const cfloat_p lwr = a.LWr + (int64_t)cl * M + rho * S * S;
+                root_partial<S>(ta, tc, ea, ec, ma, mc, wr, lwr, sc, pm, ps);
+            }
             if (!(ps > 0.f)) pm = -INFINITY;
             xch[((rho * 32 + s) * C + cl) * 2] = pm;
             xch[((rho * 32 + s) * C + cl) * 2 + 1] = ps;
@@ -190,11 +200,13 @@ struct WideTail {                                     // LDS behind the x tile a
     unsigned long long odd[kWideWaves];               // K-steps (of those the wave converted) that hold flagged values
     float qpart[kWideWaves][64];                      // sum x^2 of the lane's 8 features over those K-steps
     int flags[kWideWaves];                            // 1: out-of-range value (exact evaluation), 2: NaN seen
+    int verdict;                                      // the launch found its parameter tables stale (ratspn_gemm_prep.h)
+    int pad[3];
 };
 static_assert(sizeof(WideTail) % 16 == 0, "LDS layout");
 
 template <int S, bool MARG>
-__global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const GemmArgs a, const GemmPrepArgs pa) {
     constexpr int I = kWideI;
     constexpr int PF = MARG ? 6 : 12;                 // K-steps of table fragments in flight per wave
     typedef const __attribute__((address_space(1))) half8 gh8;
@@ -209,9 +221,16 @@ __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s = lane & 31, h = lane >> 5;
+    // A launch that checks its parameter tables itself (kPrepInline, ratspn_gemm_prep.h): the first pa.np work-groups are
+    // the table work-groups -- fingerprint, verdict, rebuild if stale -- the others evaluate block blockIdx.x - pa.np.
+    const int np = pa.np;
+    if ((int)blockIdx.x < np) {
+        gemm_prep_block<kWideI>(pa, (int)blockIdx.x, reinterpret_cast<int *>(smem_generic));
+        return;
+    }
     const int D = a.D, NT = a.reps;
     const int NKS = (D + 15) >> 4;
-    const int64_t b0 = (int64_t)blockIdx.x * 32;
+    const int64_t b0 = (int64_t)((int)blockIdx.x - np) * 32;
     const int nvalid = (int)min((int64_t)32, a.B - b0);
     const bool mine = wave < NT;                       // (a model with fewer repetitions leaves waves without a tile)
     const int rho = mine ? wave : NT - 1;
@@ -422,10 +441,16 @@ __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const
     // the expanded square is within the 1e-5 bar while sum x^2 <= 36 D (|mu| <= 6: DESIGN 3.3)
     const bool lane_exact = need_exact || !(qtot <= kExpandBound * kExpandBound * (float)D);
     model_ok = __all(model_ok);
-    const bool exact = !model_ok || __any(lane_exact);   // (the same x tile in every wave: the same verdict in every wave)
+    // the launch's verdict on its tables (np > 0): published long ago by the table work-groups -- one L2 round trip for
+    // thread 0 under the other waves' K loops; the barrier below hands it to everyone
+    unsigned vi_ticket = 0u;
+    if (np > 0 && tid == 0) tail->verdict = vi_wait(pa.ctl, np, vi_ticket) ? 1 : 0;
 
     __syncthreads();   // every wave is done with the x tile: its LDS becomes scratch and the root exchange buffer
-    double part = wide_block_upper<S>(a, acc, odd_mask, qtot, exact, rho, mine, b0, w0_l, smem_generic);
+    const bool tables_stale = np > 0 && tail->verdict != 0;
+    const bool exact = !model_ok || __any(lane_exact) || tables_stale;   // (the same x tile in every wave: the same verdict in every wave)
+    double part = wide_block_upper<S>(a, acc, odd_mask, qtot, exact, rho, mine, b0, w0_l, smem_generic,
+                                      tables_stale ? pa.w[0] : nullptr, tables_stale ? pa.w[1] : nullptr);
     double *red = reinterpret_cast<double *>(smem_generic + wide_upper_lds_bytes(NT, a.C));
     if (a.ll_sum != nullptr) {
         part = wave_reduce_sum(part);
@@ -437,10 +462,11 @@ __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const
 #pragma unroll
             for (int w = 0; w < kWideWaves; ++w) tot += red[w];
             atomicAdd(a.ll_sum, tot);
-            if (blockIdx.x == 0) atomicAdd(a.ll_sum + 1, (double)a.B * (double)a.C);
+            if ((int)blockIdx.x == np) atomicAdd(a.ll_sum + 1, (double)a.B * (double)a.C);
         }
     }
     if (saw_nan && tid == 0 && a.slow_flag != nullptr) *a.slow_flag = a.launch_seq;
+    if (np > 0 && tid == 0) vi_done(pa.ctl, vi_ticket, pa.readers);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -783,15 +809,18 @@ bool gemm_wide_shape_ok(int D, int reps, int I, int S, int C) {
 }
 
 template <int S, bool MARG>
-static int gemm_wide_launch(const GemmArgs &a, hipStream_t st) {
+static int gemm_wide_launch(const GemmArgs &a, const GemmPrepArgs &p, hipStream_t st) {
     const int NKS = cdiv(a.D, 16);
-    const size_t lds = (size_t)NKS * 2048 + (size_t)kWideWaves * 2 * S * kWideI * kWideI * 4 + sizeof(WideTail);
+    size_t lds = (size_t)NKS * 2048 + (size_t)kWideWaves * 2 * S * kWideI * kWideI * 4 + sizeof(WideTail);
+    if (p.np > 0 && gemm_prep_lds_bytes(a.D, kWideI, a.d) > lds) lds = gemm_prep_lds_bytes(a.D, kWideI, a.d);
     auto kern = ratspn_gemm_wide_kernel<S, MARG>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024)) return rc;
     hipEvent_t ev0, ev1;
     profile_take(&ev0, &ev1, DPK_KERNEL_RATSPN_FUSED);
     if (ev0) (void)hipEventRecord(ev0, st);
-    DPK_LAUNCH(kern, dim3(cdiv(a.B, 32)), dim3(kWideWaves * 64), lds, st, a);
+    GemmPrepArgs pp = p;
+    pp.readers = p.np + (int)cdiv(a.B, 32);
+    DPK_LAUNCH(kern, dim3(p.np + cdiv(a.B, 32)), dim3(kWideWaves * 64), lds, st, a, pp);
     if (ev1) (void)hipEventRecord(ev1, st);
     DPK_CHECK_LAUNCH("ratspn_gemm_wide_kernel");
     return DPK_OK;
@@ -823,12 +852,19 @@ static bool wide_takes_ring(int64_t B) {
     return forced >= 0 ? B >= forced : B > gemm_small_max_batch() * kWideRingFactor;
 }
 
-// The caller (ratspn_gemm_forward) has built the tables and filled the argument block.
-int ratspn_gemm_wide_forward(const GemmArgs &a, int S, hipStream_t st) {
+// large clean batches: 128-sample tiles behind the LDS-DMA ring (its scratch must fit the ring's stages); everything else
+// takes the 32-sample kernel -- the mapping that carries its own table work-groups (ratspn_gemm_forward asks)
+bool gemm_wide_takes_tile32(int64_t B, int D, int reps, int C, bool marginal) {
+    return !(!marginal && wide_takes_ring(B) && (D % 4) == 0 &&
+             wide_upper_lds_bytes(reps, C) + kWideWaves * 8 + 64 <= (size_t)kGemmStages * kGemmTile * 256);
+}
+
+// The caller (ratspn_gemm_forward) has built the tables (or handed their check to this launch: p.np > 0, 32-sample kernel
+// only) and filled the argument block.
+int ratspn_gemm_wide_forward(const GemmArgs &a, const GemmPrepArgs &p, int S, hipStream_t st) {
     const bool marg = a.marginal != 0;
-    // large clean batches: 128-sample tiles behind the LDS-DMA ring (its scratch must fit the ring's stages)
-    if (!marg && wide_takes_ring(a.B) && (a.D % 4) == 0 &&
-        wide_upper_lds_bytes(a.reps, a.C) + kWideWaves * 8 + 64 <= (size_t)kGemmStages * kGemmTile * 256) {
+    if (!gemm_wide_takes_tile32(a.B, a.D, a.reps, a.C, marg)) {
+        DPK_REQUIRE(p.np == 0, DPK_EINVAL, "ratspn_gemm_wide: the ring kernel does not check its tables itself");
         switch (S) {
             case 2: return gemm_wide_ring_launch<2>(a, st);
             case 4: return gemm_wide_ring_launch<4>(a, st);
@@ -836,9 +872,9 @@ int ratspn_gemm_wide_forward(const GemmArgs &a, int S, hipStream_t st) {
         }
     }
     switch (S) {
-        case 2: return marg ? gemm_wide_launch<2, true>(a, st) : gemm_wide_launch<2, false>(a, st);
-        case 4: return marg ? gemm_wide_launch<4, true>(a, st) : gemm_wide_launch<4, false>(a, st);
-        case 8: return marg ? gemm_wide_launch<8, true>(a, st) : gemm_wide_launch<8, false>(a, st);
+        case 2: return marg ? gemm_wide_launch<2, true>(a, p, st) : gemm_wide_launch<2, false>(a, p, st);
+        case 4: return marg ? gemm_wide_launch<4, true>(a, p, st) : gemm_wide_launch<4, false>(a, p, st);
+        case 8: return marg ? gemm_wide_launch<8, true>(a, p, st) : gemm_wide_launch<8, false>(a, p, st);
     }
     set_error("ratspn_gemm_wide: sums=%d not built", S);
     return DPK_EUNSUPPORTED;
