@@ -402,15 +402,77 @@ def test_pairs_kernel_stress_vs_fp64_oracle(D, units):
     x = torch.randn(257, D, generator=g) * torch.where(torch.rand(257, 1, generator=g) < 0.2, 10.0, 1.0)
     want = forc.flow_log_prob(sd64, x.double()).numpy()
     sd32 = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    want32 = forc.flow_log_prob(sd32, x).numpy()                   # the reference's own fp32 arithmetic on this input
-    noise = np.max(np.abs(want32 - want) / np.maximum(np.abs(want), 1.0))
+    # The reference's own fp32 arithmetic on this input -- as written, and with the terms of its two GEMMs summed in four
+    # other orders (the columns of each Linear permuted together with its input: the same mathematics).  On an input this
+    # badly conditioned the fp32 result moves by up to 6x with the summation order (8.1e-5 .. 5.8e-4 across hosts, thread
+    # counts and orders, tools/diag_coupling_noise.py: the error IS fp32 accumulation under cancellation; with the GEMMs
+    # in fp64 it is 6e-6).  The yardstick is the largest of these draws, not a single one.
+    noises = []
+    plain_network = forc._network
+    try:
+        for trial in range(5):
+            if trial > 0:
+                gp = torch.Generator().manual_seed(100 + trial)
+
+                def permuted(h, lins, gp=gp):
+                    for w, b in lins[:-1]:
+                        perm = torch.randperm(w.shape[1], generator=gp)
+                        h = torch.relu(torch.nn.functional.linear(h[:, perm].contiguous(), w[:, perm].contiguous(), b))
+                    w, b = lins[-1]
+                    perm = torch.randperm(w.shape[1], generator=gp)
+                    return torch.nn.functional.linear(h[:, perm].contiguous(), w[:, perm].contiguous(), b)
+                forc._network = permuted
+            want32 = forc.flow_log_prob(sd32, x).numpy()
+            noises.append(float(np.max(np.abs(want32 - want) / np.maximum(np.abs(want), 1.0))))
+    finally:
+        forc._network = plain_network
+    noise = max(noises)
     with torch.no_grad():
         got = model.cuda()(x.cuda()).cpu().numpy()
     assert np.isfinite(want).all() and np.isfinite(got).all()
     # per sample: the batch mixes log-likelihoods of very different magnitudes
     per_sample = np.max(np.abs(got - want) / np.maximum(np.abs(want), 1.0))
-    # (two-way f16 splits carry 22 bits per product against fp32's 24: up to 4x the reference's own rounding error, which
-    # this ill-conditioned input amplifies for both alike)
-    report_measured('test_pairs_kernel_stress_vs_fp64_oracle[%d-%d]' % (D, units), per_sample, max(TOL, 8 * noise),
-                    '(TOL 1e-5, or 8x the reference fp32 arithmetic\'s own distance from fp64 = %.2e)' % noise)
-    assert per_sample <= max(TOL, 8 * noise), (per_sample, noise)
+    # Round 4: two-way f16 splits carry 22 bits per product against fp32's 24, and a layer whose conditioner gain
+    # (ops_flows.PAIRS_GAIN_LIMIT) amplifies that rounding is kept on the fp32-MFMA kernel -- the flow as a whole then
+    # stays within 2x of what the reference's own fp32 arithmetic loses on this input (round 3: 6.4x measured, 8x allowed).
+    from deeprob.hip import ops_flows
+    from deeprob.flows.layers.coupling import CouplingLayer1d
+    verdicts = [getattr(l._ws_pairs, '_cond', (None, None, None)) for l in model.layers if isinstance(l, CouplingLayer1d)]
+    report_measured('test_pairs_kernel_stress_vs_fp64_oracle[%d-%d]' % (D, units), per_sample, max(TOL, 2 * noise),
+                    '(TOL 1e-5, or 2x the reference fp32 arithmetic\'s own distance from fp64: %s = as written + 4 summation orders); conditioner gains %s'
+                    % (['%.1e' % v for v in noises], ['%.0f%s' % (v[2], '' if v[1] else ' -> fp32 kernel') for v in verdicts if v[2] is not None]))
+    assert per_sample <= max(TOL, 2 * noise), (per_sample, noise)
+    if D % 8 == 0 and units in (32, 64, 96, 128):
+        assert any(v[1] is False for v in verdicts), verdicts        # the stress flow does trip the guard
+
+
+def test_accuracy_guard_leaves_ordinary_flows_on_the_split_f16_kernels():
+    """The conditioner-gain guard (ops_flows.PAIRS_GAIN_LIMIT) is a property of the parameters, judged once per parameter
+    version: default-initialised and fixture-style randomised flows stay on the column-pair kernels (BASELINE config 5's
+    timing is theirs), a second call judges nothing, and a weight update through an optimizer-style in-place op re-judges."""
+    from deeprob.flows.models import RealNVP1d
+    from deeprob.flows.layers.coupling import CouplingLayer1d
+    from deeprob.hip import ops_flows
+    from tests.util import randomise_flow
+    for randomised in (False, True):
+        torch.manual_seed(10)
+        flow = RealNVP1d(784)
+        if randomised:
+            randomise_flow(flow, 11)
+        flow = flow.cuda().eval()
+        x = torch.randn(256, 784, device='cuda')
+        with torch.no_grad():
+            flow(x)
+        cps = [l for l in flow.layers if isinstance(l, CouplingLayer1d)]
+        gains = [l._ws_pairs._cond for l in cps]
+        assert all(g[1] and g[2] < 0.2 * ops_flows.PAIRS_GAIN_LIMIT for g in gains), gains
+        with torch.no_grad():
+            flow(x)
+        assert all(l._ws_pairs._cond is g for l, g in zip(cps, gains))          # same verdict objects: nothing re-judged
+        with torch.no_grad():
+            cps[1].network[0].weight.mul_(40.0)                                     # a (visible) in-place update
+            got = flow(x).cpu().numpy()
+        assert cps[1]._ws_pairs._cond[1] is False and cps[0]._ws_pairs._cond is gains[0]
+        sd = {k: v.detach().cpu().clone() for k, v in flow.state_dict().items()}
+        want = forc.flow_log_prob(sd, x.cpu()).numpy()
+        assert rel_err(got, want) <= 1e-4          # (an ill-conditioned flow: the reference's own fp32 noise is ~1e-5 here)
