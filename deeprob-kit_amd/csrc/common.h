@@ -144,6 +144,7 @@ struct RatWs {
     unsigned long long *ghash;   // [NT*RPT] fingerprint of the parameter bytes each repetition's tables were built from,
                                  // then one per softmax-row work-group of the table build (ratspn_gemm_prep.h)
     struct VerifyCtl *gctl;      // the verdict word of a launch that checks its tables itself (ratspn_gemm_prep.h)
+    uint16_t *gup;               // 8-channel models: MFMA fragments of the first sum layer (ratspn_gemm_prep.h: wide_upfrag_*)
     void *lg;          // tables of the leaf-only MFMA kernel (leaf_gemm_ws_bytes), null when the shape is outside it
     int g_nt, g_nksp;  // column tiles of 32, K-steps of 16 features (padded to whole chunks); 0 = not built
     int64_t bytes;
@@ -257,6 +258,8 @@ inline RatWs carve_ratspn_ws(void *base, int D, int R, int d, int I, int QB, int
         w.gelig = (int *)take((int64_t)w.g_nt * 8 * 4);
         w.ghash = (unsigned long long *)take(((int64_t)w.g_nt * 8 + cdiv(reps * 2 * S + C, 4) + 4) * 8);
         w.gctl = (struct VerifyCtl *)take(64);
+        w.gup = nullptr;
+        if (I == 8) w.gup = (uint16_t *)take((int64_t)reps * (S / 2 > 0 ? S / 2 : 1) * 1024 * 2);
     }
     w.lg = nullptr;
     if (leaf_gemm_shape_ok(D, R, I, d)) w.lg = take(leaf_gemm_ws_bytes(D, R, I));

@@ -676,6 +676,7 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
     p.w[0] = sum_weight0; p.W[0] = w.w[0]; p.LW[0] = w.lw[0]; p.rows[0] = reps * 2 * S; p.n[0] = I * I;
     p.w[1] = root_weight; p.W[1] = w.w[2]; p.LW[1] = w.lw[2]; p.rows[1] = C; p.n[1] = reps * S * S;
     p.hash = w.ghash; p.ctl = w.gctl;
+    p.upfrag = (I == 8 && S >= 2) ? w.gup : nullptr; p.up_S = S;
     const int np = gemm_prep_blocks(NT, I, p.rows[0] + p.rows[1], kGemmPrepThreads);
     const size_t prep_lds = gemm_prep_lds_bytes(D, I, d);
     DPK_REQUIRE(prep_lds <= 60 * 1024, DPK_EUNSUPPORTED, "ratspn_gemm: in_features=%d too large for the table kernel", D);
@@ -704,6 +705,7 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
         a.mask = mask; a.pad = pad; a.loc = loc; a.scale = scale;
         a.slow_flag = slow_word; a.launch_seq = launch_seq; a.marginal = marginal ? 1 : 0;
         a.ablate = ablate;
+        a.upfrag = p.upfrag;
         if (wide) return ratspn_gemm_wide_forward(a, p, S, st);
         if (small) return ratspn_gemm_small_forward(a, p, reps, I, S, NT, st);
         return ratspn_gemm_marginal_forward(a, reps, I, S, NT, st);

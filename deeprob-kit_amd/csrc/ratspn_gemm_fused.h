@@ -39,6 +39,7 @@ struct GemmArgs {
     int *slow_flag;   // host-mapped hint word (may be null): launch number of the last launch that met NaN evidence
     int launch_seq;
     int marginal;     // host: a launch within the last 256 met NaN evidence (selects the variant built for it)
+    const uint16_t *upfrag;   // 8-channel kernels: MFMA fragments of the first sum layer (ratspn_gemm_prep.h)
 };
 
 __device__ __forceinline__ void lse_merge(float &m, float &s, float m2, float s2) {

@@ -53,6 +53,8 @@ struct GemmPrepArgs {
     const float *w[3];
     float *W[3], *LW[3];
     int rows[3], n[3];
+    uint16_t *upfrag;           // 8-channel models: MFMA A-fragments of the first sum layer (wide_upfrag_*), else null
+    int up_S;                   // ... its sum nodes per region
     int mode;                   // kPrepBuild / kPrepVerify / kPrepInline
     unsigned long long *hash;   // [NT*RPT] per repetition, then one per softmax-row work-group (kPrepInline)
     VerifyCtl *ctl;
@@ -90,6 +92,32 @@ __device__ __forceinline__ void vi_done(VerifyCtl *c, unsigned ticket, int reade
         __hip_atomic_store(&c->word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&c->readers, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// ---- 8-channel models: the first sum layer on the matrix cores (ratspn_gemm_wide.hip: wide_block_upper) -------------
+// Per repetition the two partitions' product + sum nodes are ONE small GEMM  T[(h, o, i), s] = sum_j W[h][o][i][j] ec_h[j, s]
+// with the partition h in the K index: K-slots 8h .. 8h+7 carry partition h's exponentials (lane half h of the B operand
+// holds exactly its own partition's values after the leaf GEMM -- no exchange), and the rows that land in lane half h of
+// the accumulator belong to partition h and have zeros in the other partition's K-slots.  Tile t holds outputs
+// o = 2t, 2t+1: accumulator register u = (o & 1) * 8 + i.  Fragments [rep][S/2 tiles][hi, lo][64 lanes][8 halves] of
+// the softmaxed weights scaled by 2^15 (ratspn_upper_gemm.hip: both operands are in [0, 1]; the scale keeps the low
+// halves of the f16 split normal).
+constexpr float kWideUpScale = 32768.f;
+__host__ __device__ inline int64_t wide_upfrag_halves(int reps, int S) { return (int64_t)reps * (S / 2 > 0 ? S / 2 : 1) * 1024; }
+// softmax row `row` = (rep * 2 + h) * S + o of the first sum layer, entry e = i * 8 + j, value wl
+__device__ __forceinline__ void wide_upfrag_store(uint16_t *frag, int S, int row, int e, float wl) {
+    const int o = row % S, ph = row / S, h = ph & 1, rep = ph >> 1;
+    const int i = e >> 3, j = e & 7;
+    const int tiles = S / 2 > 0 ? S / 2 : 1, t = o >> 1, u = (o & 1) * 8 + i;
+    const int r = (u & 3) + 8 * (u >> 2) + 4 * h;          // A-fragment row = accumulator row of lane half h
+    _Float16 hi, lo;
+    split_f16(wl * kWideUpScale, hi, lo);
+    uint16_t *base = frag + ((int64_t)rep * tiles + t) * 1024;
+    const int own = (h * 32 + r) * 8 + j, other = ((1 - h) * 32 + r) * 8 + j;
+    base[own] = __builtin_bit_cast(uint16_t, hi);
+    base[512 + own] = __builtin_bit_cast(uint16_t, lo);
+    base[other] = 0;                                       // the other partition's K-slots of this row
+    base[512 + other] = 0;
 }
 
 // ---- one table work-group -------------------------------------------------------------------------------------------
@@ -180,8 +208,10 @@ __device__ __forceinline__ void gemm_prep_block(const GemmPrepArgs &a, int blk, 
                 const float ls = logf(sum);
                 for (int i = lane; i < n; i += 64) {
                     const float l = src[i] - mx - ls;
+                    const float wl = expf(l);
                     a.LW[m][(int64_t)row * n + i] = l;
-                    a.W[m][(int64_t)row * n + i] = expf(l);
+                    a.W[m][(int64_t)row * n + i] = wl;
+                    if (m == 0 && a.upfrag != nullptr) wide_upfrag_store(a.upfrag, a.up_S, row, i, wl);
                 }
                 return;
             }

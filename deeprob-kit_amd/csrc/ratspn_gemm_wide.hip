@@ -112,13 +112,30 @@ __device__ __forceinline__ void wide_leaf_sums(const GemmArgs &a, const gf32x16 
     }
 }
 
+// The wave's MFMA fragments of its repetition's first sum layer (ratspn_gemm_prep.h wide_upfrag_*), requested by the
+// caller ahead of the upper part (an L2 round trip inside it would sit on the critical path of every block).
+template <int S> struct WideUpFrags {
+    static constexpr int TILES = S / 2 > 0 ? S / 2 : 1;
+    half8 hi[TILES], lo[TILES];
+    __device__ __forceinline__ void load(const GemmArgs &a, int rho, int lane) {
+        typedef const __attribute__((address_space(1))) half8 gh8u;
+        if (a.upfrag == nullptr) return;
+        const gh8u *fp = (const gh8u *)(a.upfrag + (int64_t)rho * TILES * 1024) + lane;
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            hi[t] = fp[t * 128];
+            lo[t] = fp[t * 128 + 64];
+        }
+    }
+};
+
 // raw0 / rawr non-null: a launch that found its tables stale (ratspn_gemm_prep.h; `exact` is then set as well) -- the
 // nodes take their log-softmax weights straight from the raw sum / root weights.
-template <int S>
+template <int S, bool PRE = true>
 __device__ __forceinline__ double wide_block_upper(const GemmArgs &a, const gf32x16 &acc, unsigned long long odd_mask,
                                                    float qtot, bool exact, int rho, bool mine, int64_t b0,
-                                                   const lfloat *w0_l, char *lds, const float *raw0 = nullptr,
-                                                   const float *rawr = nullptr) {
+                                                   const lfloat *w0_l, char *lds, const WideUpFrags<S> &uf,
+                                                   const float *raw0 = nullptr, const float *rawr = nullptr) {
     constexpr int I = kWideI;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = lane & 31, h = lane >> 5;
@@ -138,8 +155,62 @@ __device__ __forceinline__ double wide_block_upper(const GemmArgs &a, const gf32
     {
         const lfloat *wl = w0_l + h * S * I * I;
         const float *lw = a.LW0 + ((int64_t)rho * 2 + h) * S * I * I;
-        if (raw0 != nullptr) prodsum_node_raw<I, S>(va, vc, raw0 + ((int64_t)rho * 2 + h) * S * I * I, sc.slot, n1);
-        else prodsum_node<I, S>(va, vc, wl, lw, sc, n1);
+        if (raw0 != nullptr) {
+            prodsum_node_raw<I, S>(va, vc, raw0 + ((int64_t)rho * 2 + h) * S * I * I, sc.slot, n1);
+        } else if (PRE && a.upfrag != nullptr && !(a.ablate & 32)) {
+            // Round 4: the repetition's two product + sum nodes as ONE small GEMM on the matrix cores (fragment layout:
+            // ratspn_gemm_prep.h wide_upfrag_*): T[(h, o, i), s] = sum_j W[h][o][i][j] e^{c_j - max c}, the partition h in
+            // the K index -- lane half h of the B operand holds its own partition's exponentials as they fall out of the
+            // leaf GEMM -- then the lane's dot product with e^{a_i - max a}: 3 S/2 MFMAs + 8 S FMAs per lane instead of
+            // 72 S FMAs and 16 S broadcast LDS reads.  Operands in [0, 1] scaled by 2^15 before the f16 split, 2^-30
+            // after (ratspn_upper_gemm.hip); a node below 1e-8 sends the wave through the log-domain-safe form.
+            constexpr int TILES = WideUpFrags<S>::TILES;
+            constexpr float kL2E = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+            // (PRE: the 32-sample kernel, whose caller requested the fragments ahead of the upper part.  The ring kernel
+            // keeps the vector-ALU form below: with four blocks' accumulators live, the GEMM form's operands spilled 80-130
+            // registers to scratch at its 168-register budget and measured 7 us per tile SLOWER -- round 4, not kept.)
+            float ma = va[0], mc = vc[0];
+#pragma unroll
+            for (int k = 1; k < I; ++k) {
+                ma = fmaxf(ma, va[k]);
+                mc = fmaxf(mc, vc[k]);
+            }
+            ma = (ma == -INFINITY) ? 0.f : ma;
+            mc = (mc == -INFINITY) ? 0.f : mc;
+            float ea[I], eb[I];
+#pragma unroll
+            for (int k = 0; k < I; ++k) {
+                ea[k] = __builtin_amdgcn_exp2f((va[k] - ma) * kL2E);
+                eb[k] = __builtin_amdgcn_exp2f(fmaf(vc[k] - mc, kL2E, 15.f));      // e^{c - max c} * 2^15
+            }
+            half8 eh, el8;
+            split8(eb, eh, el8);
+            bool vanished = false;
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+                gf32x16 tt;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tt[i] = 0.f;
+                const half8 fh = uf.hi[t], fl = uf.lo[t];
+                tt = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, eh, tt, 0, 0, 0);
+                tt = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, el8, tt, 0, 0, 0);
+                tt = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl, eh, tt, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (2 * t + q < S) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int i = 0; i < I; ++i) v = fmaf(ea[i], tt[q * 8 + i], v);
+                        v *= 1.f / (kWideUpScale * kWideUpScale);
+                        vanished = vanished || (v < 1e-8f);
+                        n1[2 * t + q] = fmaf(__builtin_amdgcn_logf(v), kLn2, ma + mc);
+                    }
+                }
+            }
+            if (__any(vanished)) prodsum_node<I, S>(va, vc, wl, lw, sc, n1);   // (rare: vanishing weight on the dominant pair)
+        } else {
+            prodsum_node<I, S>(va, vc, wl, lw, sc, n1);
+        }
     }
     float ta[S], tc[S];
 #pragma unroll
@@ -441,6 +512,8 @@ __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const
     // the expanded square is within the 1e-5 bar while sum x^2 <= 36 D (|mu| <= 6: DESIGN 3.3)
     const bool lane_exact = need_exact || !(qtot <= kExpandBound * kExpandBound * (float)D);
     model_ok = __all(model_ok);
+    WideUpFrags<S> uf;
+    uf.load(a, rho, lane);      // (in flight under the MFMA tail, the verdict and the barrier)
     // the launch's verdict on its tables (np > 0): published long ago by the table work-groups -- one L2 round trip for
     // thread 0 under the other waves' K loops; the barrier below hands it to everyone
     unsigned vi_ticket = 0u;
@@ -449,7 +522,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const
     __syncthreads();   // every wave is done with the x tile: its LDS becomes scratch and the root exchange buffer
     const bool tables_stale = np > 0 && tail->verdict != 0;
     const bool exact = !model_ok || __any(lane_exact) || tables_stale;   // (the same x tile in every wave: the same verdict in every wave)
-    double part = wide_block_upper<S>(a, acc, odd_mask, qtot, exact, rho, mine, b0, w0_l, smem_generic,
+    double part = wide_block_upper<S>(a, acc, odd_mask, qtot, exact, rho, mine, b0, w0_l, smem_generic, uf,
                                       tables_stale ? pa.w[0] : nullptr, tables_stale ? pa.w[1] : nullptr);
     double *red = reinterpret_cast<double *>(smem_generic + wide_upper_lds_bytes(NT, a.C));
     if (a.ll_sum != nullptr) {
@@ -769,6 +842,7 @@ __global__ __launch_bounds__((kWideWaves + kGemmWaves) * 64) void ratspn_gemm_wi
         }
     }
     model_ok = __all(model_ok);
+    WideUpFrags<S> uf{};        // (unused: the ring kernel fetches the fragments tile by tile inside the upper part)
     __syncthreads();   // the ring is idle: its stages become scratch and the root exchange buffer; the tail is complete
     // (Measured and dropped, round 3: the two halves of a wave trading partitions across two blocks so that the sum weights
     // are wave-uniform and come through the scalar cache instead of LDS -- 63 us per tile against 54: 32 KB of weights per
@@ -776,8 +850,8 @@ __global__ __launch_bounds__((kWideWaves + kGemmWaves) * 64) void ratspn_gemm_wi
     double part = 0.0;
 #pragma unroll
     for (int q = 0; q < NB; ++q)
-        part += wide_block_upper<S>(a, acc[q], odd_mask[q], tail->qrow[q * 32 + s], !model_ok || tail->exact[q] != 0, rho, mine,
-                                    t0 + q * 32, w0_l, smem_generic);
+        part += wide_block_upper<S, false>(a, acc[q], odd_mask[q], tail->qrow[q * 32 + s], !model_ok || tail->exact[q] != 0, rho, mine,
+                                    t0 + q * 32, w0_l, smem_generic, uf);
     if (a.ll_sum != nullptr) {
         double *red = reinterpret_cast<double *>(smem_generic + wide_upper_lds_bytes(NT, a.C));
         part = wave_reduce_sum(part);
