@@ -968,6 +968,7 @@ bool upper_mfma_shape_ok(bool root, int N, int S);
 int64_t upper_mfma_frag_bytes(int R, int N, int S);
 int upper_mfma_forward(bool root, const float *in, const float *W, const float *LW, int64_t B, int R, int N, int S,
                        float *out, void *frag, bool frag_cached, hipStream_t st, const unsigned *gate = nullptr);
+int upper_mfma_tables(bool root, const float *weight, float *W, float *LW, int R, int N, int S, void *frag, hipStream_t st);
 }
 
 static int prod_fused_common(bool root, const float *in, const float *weight, int64_t B, int R, int N, int S,
@@ -988,7 +989,6 @@ static int prod_fused_common(bool root, const float *in, const float *weight, in
     // DPK_FLAG_PARAMS_VERIFY: believed so, checked on the device (table kernels gated on the verdict)
     // (VERIFY = rebuild: the softmax rows + fragment pack cost what fingerprinting the weights would)
     const bool cached = (flags & DPK_FLAG_PARAMS_CACHED) != 0;
-    if (!cached) launch_softmax_rows(weight, rows, n, W, LW, st);
     {
         static const bool mfma = [] {
             const char *e = getenv("DPK_RATSPN_GEMM");
@@ -996,9 +996,15 @@ static int prod_fused_common(bool root, const float *in, const float *weight, in
         }();
         const int64_t fb = upper_mfma_frag_bytes(R, N, S);
         if (mfma && upper_mfma_shape_ok(root, N, S) && ws_bytes >= 2 * seg + fb &&
-            (reinterpret_cast<uintptr_t>(in) & 15) == 0)
-            return upper_mfma_forward(root, in, W, LW, B, R, N, S, out, (char *)ws + 2 * seg, cached, st);
+            (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+            // softmax rows and MFMA fragments in ONE launch (round 4; two before)
+            if (!cached) {
+                if (int rc = upper_mfma_tables(root, weight, W, LW, R, N, S, (char *)ws + 2 * seg, st)) return rc;
+            }
+            return upper_mfma_forward(root, in, W, LW, B, R, N, S, out, (char *)ws + 2 * seg, true, st);
+        }
     }
+    if (!cached) launch_softmax_rows(weight, rows, n, W, LW, st);
     const dim3 block(256);
 #define DPK_LAUNCH_PS(NMAX)                                                                                         \
     do {                                                                                                            \

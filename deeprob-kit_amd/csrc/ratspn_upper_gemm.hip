@@ -19,6 +19,7 @@
 #include "common.h"
 #include "ratspn_gemm_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace dpk {
 
@@ -79,6 +80,75 @@ __global__ __launch_bounds__(256) void upper_pack_kernel(const float *__restrict
     }
 }
 
+// Softmax rows AND their fragments in one launch (round 4: the folded route's per-call table rebuild was two launches per
+// layer -- softmax rows, then upper_pack_kernel over them; at B = 4096 the four small launches of a (16,16) model cost a
+// third of its kernels' time).  One block per softmax row: W = softmax(w[row]), LW = log_softmax(w[row]) and every
+// fragment entry the row owns (the inverse of upper_pack_kernel's mapping); the root layout's padding rows (class tiles
+// beyond C N rows) are zeroed by one extra block.
+__global__ __launch_bounds__(256) void upper_tables_kernel(const float *__restrict__ w, int rows, int n, float *__restrict__ W,
+                                                           float *__restrict__ LW, uint16_t *__restrict__ frag, int P, int N,
+                                                           int S, int root, int tiles) {
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x >= rows) {   // root layout: rows S N .. tiles * 32 of every partition are zero
+        const int g0 = S * N, g1 = tiles * 32;
+        const int per_p = (g1 - g0) * 16;
+        for (int e = tid; e < P * per_p; e += blockDim.x) {
+            const int p = e / per_p, q = e - p * per_p;
+            const int g = g0 + q / 16, k = q % 16;
+            uint16_t *dst = frag + ((int64_t)p * tiles + g / 32) * 1024 + ((k >> 3) * 32 + (g & 31)) * 8 + (k & 7);
+            dst[0] = 0;
+            dst[512] = 0;
+        }
+        return;
+    }
+    const int row = blockIdx.x;
+    const float *src = w + (int64_t)row * n;
+    float m = -INFINITY;
+    for (int i = tid; i < n; i += blockDim.x) m = fmaxf(m, src[i]);
+    m = wave_reduce_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int i = tid; i < n; i += blockDim.x) sum += expf(src[i] - m);
+    sum = wave_reduce_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float ls = logf((red[4] + red[5]) + (red[6] + red[7]));
+    const int NN = N * N;
+    for (int e = tid; e < n; e += blockDim.x) {
+        const float l = src[e] - m - ls, wl = expf(l);
+        LW[(int64_t)row * n + e] = l;
+        W[(int64_t)row * n + e] = wl;
+        int p, o, t, r;
+        const int ij = root ? e % NN : e, i = ij / N, j = ij - i * N;
+        if (root) {   // global row = class * N + i
+            o = row;
+            p = e / NN;
+            const int g = o * N + i;
+            t = g >> 5;
+            r = g & 31;
+        } else {
+            p = row / S;
+            o = row - p * S;
+            int hrow, u;
+            if (N == 16) { t = o >> 1; hrow = o & 1; u = i; }
+            else { t = o >> 2; hrow = (o >> 1) & 1; u = (o & 1) * 8 + i; }
+            r = (u & 3) + 8 * (u >> 2) + 4 * hrow;
+        }
+        _Float16 hi, lo;
+        split_f16(wl * kUpScale, hi, lo);
+        uint16_t *dst = frag + ((int64_t)p * tiles + t) * 1024 + ((j >> 3) * 32 + r) * 8 + (j & 7);
+        dst[0] = __builtin_bit_cast(uint16_t, hi);
+        dst[512] = __builtin_bit_cast(uint16_t, lo);
+        if (N == 8) {   // the upper half of the K-step is unused
+            dst[256] = 0;
+            dst[256 + 512] = 0;
+        }
+    }
+}
+
 template <int N>
 __device__ __forceinline__ void upper_load(const float *xa, float (&a)[N], float (&c)[N]) {
 #pragma unroll
@@ -99,16 +169,29 @@ template <int N> __device__ __forceinline__ float upper_max(const float (&x)[N])
     return (m == -INFINITY) ? 0.f : m;
 }
 
-// exact log-domain (m, s) of logsumexp_ij(a_i + c_j + lw[i*N + j])
+// exact log-domain (m, s) of logsumexp_ij(a_i + c_j + lw[i*N + j]) for ONE node, by the whole wave (every lane calls it with the same arguments): the N^2 pairs are dealt over the
+// 64 lanes, two wave reductions.  The vanished-node fallbacks of the kernels below call it for the flagged (sample, node)
+// pairs only: a launch of a few thousand samples meets a handful of them (a softmax weight of 1e-8 on the dominant pair),
+// and redoing every node of the wave's 32 samples in the serial form above made those few waves 20 us long -- the
+// duration of the whole launch at small batches (round 4).
 template <int N>
-__device__ __noinline__ void upper_exact_ms(const float *xa, const float *lw, float &m, float &sum) {
-    m = -INFINITY;
-    for (int i = 0; i < N; ++i)
-        for (int j = 0; j < N; ++j) m = fmaxf(m, xa[i] + xa[N + j] + lw[i * N + j]);
-    sum = 0.f;
-    if (m > -INFINITY)
-        for (int i = 0; i < N; ++i)
-            for (int j = 0; j < N; ++j) sum += expf(xa[i] + xa[N + j] + lw[i * N + j] - m);
+__device__ __forceinline__ void upper_exact_ms_wave(const float *xa, const float *lw, int lane, float &m, float &sum) {
+    float t[(N * N + 63) / 64];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < (N * N + 63) / 64; ++k) {
+        const int e = k * 64 + lane;
+        t[k] = (e < N * N) ? xa[e / N] + xa[N + e % N] + lw[e] : -INFINITY;
+        mx = fmaxf(mx, t[k]);
+    }
+    mx = wave_reduce_max(mx);
+    float sm = 0.f;
+    if (mx > -INFINITY) {
+#pragma unroll
+        for (int k = 0; k < (N * N + 63) / 64; ++k) sm += expf(t[k] - mx);
+    }
+    m = mx;
+    sum = wave_reduce_sum(sm);
 }
 
 struct UpperArgs {
@@ -133,6 +216,10 @@ __global__ __launch_bounds__(256) void prodsum_mfma_kernel(const UpperArgs a) {
     const bool row_ok = b_raw < a.B;
     const int64_t b = row_ok ? b_raw : a.B - 1;
     const int p0 = blockIdx.y * a.ppb, p1 = min(P, p0 + a.ppb);
+    extern __shared__ float upper_res[];                 // [4 waves][32][S + 1]: a wave's outputs on their way to whole rows
+    const int SP = S + 1;                                // (row stride: the 32 samples of a half-wave hit 32 banks)
+    float *res_l = upper_res + wave * 32 * SP;
+    const int64_t b0w = ((int64_t)blockIdx.x * 4 + wave) * 32;
     for (int p = p0; p < p1; ++p) {
         const float *xa = a.in + (b * a.R + 2 * p) * N;
         float av[N], cv[N];
@@ -153,9 +240,17 @@ __global__ __launch_bounds__(256) void prodsum_mfma_kernel(const UpperArgs a) {
         half8 eh, el8;
         split8(eb, eh, el8);
         const ug_h8 *fp = (ug_h8 *)(a.frag + (int64_t)p * a.tiles * 1024) + lane;
-        bool vanished = false;
-        for (int t = 0; t < a.tiles; ++t) {
-            const half8 wh = fp[t * 128], wl = fp[t * 128 + 64];
+        bool vanished = false, vmask_over = false;
+        unsigned long long vmask = 0ull;   // outputs of this lane's sample whose scaled sum vanished
+        // Tile loop, two tiles per trip: the fragments of tile t + 1 are requested before the MFMAs of tile t, into a
+        // second register set (a copy between the sets would make hipcc wait in the trip that issued the request).  The
+        // outputs go to a wave-private LDS tile and leave as whole rows after the loop.  What this replaces (round 4): a
+        // request AND a store per tile inside the loop -- on this hardware a store counts in vmcnt like a load, so every
+        // tile waited for the previous tile's store to complete and for its own L2 round trip -- and, when unrolled, a
+        // straight-line body of 4000 instructions that each wave executes once (the instruction fetch of a cold kernel
+        // was most of its 15-22 us at B = 4096).
+        const int T = a.tiles;
+        auto tile_body = [&](int t, const half8 &wh, const half8 &wl) {
             gf32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -169,18 +264,57 @@ __global__ __launch_bounds__(256) void prodsum_mfma_kernel(const UpperArgs a) {
                 for (int i = 0; i < N; ++i) v = fmaf(ea[i], acc[q * N + i], v);
                 v *= kUpUnscale;
                 const int o = (N == 16) ? 2 * t + h : 4 * t + 2 * h + q;
-                vanished = vanished || (v < kUpExactBelow);
-                const float r = fmaf(__builtin_amdgcn_logf(v), kUpLn2, ma + mc);
-                if (row_ok && o < S) a.out[(b * P + p) * S + o] = r;
+                if (v < kUpExactBelow) {
+                    vanished = true;
+                    if (o < 64) vmask |= 1ull << o;
+                    else vmask_over = true;
+                }
+                if (o < S) res_l[s * SP + o] = fmaf(__builtin_amdgcn_logf(v), kUpLn2, ma + mc);
+            }
+        };
+        half8 ah = fp[0], al = fp[64], bh, bl;
+#pragma clang loop unroll(disable)
+        for (int t = 0; t < T; t += 2) {
+            {
+                const int tn = min(t + 1, T - 1);
+                bh = fp[tn * 128];
+                bl = fp[tn * 128 + 64];
+            }
+            tile_body(t, ah, al);
+            if (t + 1 < T) {
+                const int tn = min(t + 2, T - 1);
+                ah = fp[tn * 128];
+                al = fp[tn * 128 + 64];
+                tile_body(t + 1, bh, bl);
             }
         }
-        if (__any(vanished)) {   // rare: the wave redoes this partition exactly (every output of its samples)
-            if (row_ok)
-                for (int o = h; o < S; o += 2) {
-                    float m, sum;
-                    upper_exact_ms<N>(xa, a.LW + ((int64_t)p * S + o) * N * N, m, sum);
-                    a.out[(b * P + p) * S + o] = (m > -INFINITY) ? m + logf(sum) : -INFINITY;
+        // the wave's [32 samples][S] outputs of this partition: whole rows (S floats = 64 bytes at S = 16) per sample
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (wave-private tile: no barrier, only the wave's own writes)
+        for (int e = lane; e < 32 * S; e += 64) {
+            const int rs = e / S, o = e - rs * S;
+            if (b0w + rs < a.B) a.out[((b0w + rs) * P + p) * S + o] = res_l[rs * SP + o];
+        }
+        if (__any(vanished)) {   // rare: the flagged (sample, output) nodes are redone exactly, by the whole wave each
+            {
+                // (outputs beyond the 64-bit mask: such a sample redoes all of its outputs)
+                unsigned long long lanes = __ballot((vmask != 0ull || vmask_over) && row_ok);
+                while (lanes) {
+                    const int src = __builtin_ctzll(lanes);
+                    lanes &= lanes - 1;
+                    const int64_t bs = __shfl(b, src, 64);
+                    unsigned long long om = __shfl(vmask, src, 64);
+                    const bool all = __shfl((int)vmask_over, src, 64) != 0;
+                    const float *xs = a.in + (bs * a.R + 2 * p) * N;
+                    const int hs = src >> 5;
+                    for (int o = 0; o < S; ++o) {
+                        const int owner = (N == 16) ? (o & 1) : ((o >> 1) & 1);   // lane half that computed output o
+                        if (!(all ? owner == hs : (o < 64 && ((om >> o) & 1ull)))) continue;
+                        float m, sum;
+                        upper_exact_ms_wave<N>(xs, a.LW + ((int64_t)p * S + o) * N * N, lane, m, sum);
+                        if (lane == src) a.out[(bs * P + p) * S + o] = (m > -INFINITY) ? m + logf(sum) : -INFINITY;
+                    }
                 }
+            }
         }
     }
 }
@@ -203,34 +337,49 @@ __global__ __launch_bounds__(256) void prodroot_mfma_kernel(const UpperArgs a) {
         rs[k] = 0.f;
     }
     bool vanished = false;
-    for (int p = 0; p < P; ++p) {
-        const float *xa = a.in + (b * a.R + 2 * p) * N;
+    unsigned cmask = 0u;   // classes of this lane's sample with a vanished partition share (CT * CPT <= 32)
+    // Partition p + 1's inputs and fragments are requested before the arithmetic of partition p, into a SECOND register
+    // set (two partitions per trip: a copy between the sets makes hipcc wait for the request in the trip that issued it).
+    // A wave used to pay two dependent L2 round trips per partition: 18 us for the 8 partitions of the (16,16) root at
+    // B = 4096 (round 4).
+    struct Operands {
         float av[N], cv[N];
-        upper_load<N>(xa, av, cv);
-        const float ma = upper_max<N>(av), mc = upper_max<N>(cv);
+        half8 fh[CT], fl[CT];
+    };
+    auto request = [&](int p, Operands &o) {
+        const int pc = min(p, P - 1);
+        upper_load<N>(a.in + (b * a.R + 2 * pc) * N, o.av, o.cv);
+        const ug_h8 *fp = (ug_h8 *)(a.frag + (int64_t)pc * CT * 1024) + lane;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            o.fh[t] = fp[t * 128];
+            o.fl[t] = fp[t * 128 + 64];
+        }
+    };
+    auto partition = [&](const Operands &o) {
+        const float ma = upper_max<N>(o.av), mc = upper_max<N>(o.cv);
         // this lane's rows of a tile are i = (u & 3) + 8 ((u >> 2) & 1) + 4 h (N = 16) / (u & 3) + 4 h (N = 8)
         float es[HALF];
 #pragma unroll
         for (int k = 0; k < HALF; ++k) {
             const int i0 = (N == 16) ? (k & 3) + 8 * (k >> 2) : k;
-            const float ai = h ? av[i0 + 4] : av[i0];
+            const float ai = h ? o.av[i0 + 4] : o.av[i0];
             es[k] = __builtin_amdgcn_exp2f((ai - ma) * kUpL2E);
         }
         float eb[8];
 #pragma unroll
         for (int el = 0; el < 8; ++el) {
             float cj;
-            if (N == 16) cj = h ? cv[8 + el] : cv[el]; else cj = cv[el];
+            if (N == 16) cj = h ? o.cv[8 + el] : o.cv[el]; else cj = o.cv[el];
             const float e = __builtin_amdgcn_exp2f(fmaf(cj - mc, kUpL2E, kUpScaleLog2));   // e^{c - max c} * 2^15
             eb[el] = (N == 8 && h) ? 0.f : e;
         }
         half8 eh, el8;
         split8(eb, eh, el8);
-        const ug_h8 *fp = (ug_h8 *)(a.frag + (int64_t)p * CT * 1024) + lane;
         const float m = ma + mc;
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
-            const half8 wh = fp[t * 128], wl = fp[t * 128 + 64];
+            const half8 wh = o.fh[t], wl = o.fl[t];
             gf32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -245,7 +394,10 @@ __global__ __launch_bounds__(256) void prodroot_mfma_kernel(const UpperArgs a) {
                 v += __shfl_xor(v, 32, 64);              // the other half of the i's
                 v *= kUpUnscale;
                 const int k = t * CPT + q;
-                vanished = vanished || (v < kUpExactBelow && k < C && m > -INFINITY);
+                if (v < kUpExactBelow && k < C && m > -INFINITY) {
+                    vanished = true;
+                    cmask |= 1u << k;
+                }
                 // running (max, scaled sum) over the partitions
                 const float mm = fmaxf(rm[k], m);
                 const float mm0 = (mm == -INFINITY) ? 0.f : mm;
@@ -253,17 +405,41 @@ __global__ __launch_bounds__(256) void prodroot_mfma_kernel(const UpperArgs a) {
                 rm[k] = mm;
             }
         }
+    };
+    Operands opa, opb;
+    request(0, opa);
+    for (int p = 0; p < P; p += 2) {
+        request(p + 1, opb);
+        partition(opa);
+        if (p + 1 < P) {
+            request(p + 2, opa);
+            partition(opb);
+        }
     }
-    const bool redo = __any(vanished);
+    // results of the fast path; then, rare, the flagged (sample, class) roots are redone exactly over all partitions, by
+    // the whole wave each (upper_exact_ms_wave)
 #pragma unroll
     for (int k = 0; k < CT * CPT; ++k) {
         if (k < C) {
-            float r = (rm[k] > -INFINITY) ? fmaf(__builtin_amdgcn_logf(rs[k]), kUpLn2, rm[k]) : -INFINITY;
-            if (redo) {   // rare: exact log-domain root over all partitions
+            const float r = (rm[k] > -INFINITY) ? fmaf(__builtin_amdgcn_logf(rs[k]), kUpLn2, rm[k]) : -INFINITY;
+            if (row_ok && h == 0) a.out[b * C + k] = r;
+        }
+    }
+    if (__any(vanished)) {
+        cmask |= (unsigned)__shfl_xor((int)cmask, 32, 64);          // (both lane halves of a sample saw the same sums)
+        unsigned long long lanes = __ballot(cmask != 0u && row_ok && h == 0);
+        while (lanes) {
+            const int src = __builtin_ctzll(lanes);
+            lanes &= lanes - 1;
+            const int64_t bs = __shfl(b, src, 64);
+            unsigned cm = (unsigned)__shfl((int)cmask, src, 64);
+            while (cm) {
+                const int k = __builtin_ctz(cm);
+                cm &= cm - 1;
                 float mm = -INFINITY, ss = 0.f;
                 for (int p = 0; p < P; ++p) {
                     float pm, ps;
-                    upper_exact_ms<N>(a.in + (b * a.R + 2 * p) * N, a.LW + ((int64_t)k * P + p) * N * N, pm, ps);
+                    upper_exact_ms_wave<N>(a.in + (bs * a.R + 2 * p) * N, a.LW + ((int64_t)k * P + p) * N * N, lane, pm, ps);
                     if (ps > 0.f && pm > -INFINITY) {
                         if (pm > mm) {
                             ss = ss * expf(mm - pm) + ps;
@@ -273,9 +449,8 @@ __global__ __launch_bounds__(256) void prodroot_mfma_kernel(const UpperArgs a) {
                         }
                     }
                 }
-                r = (mm > -INFINITY) ? mm + logf(ss) : -INFINITY;
+                if (lane == src) a.out[bs * C + k] = (mm > -INFINITY) ? mm + logf(ss) : -INFINITY;
             }
-            if (row_ok && h == 0) a.out[b * C + k] = r;
         }
     }
 }
@@ -295,6 +470,17 @@ int64_t upper_mfma_frag_bytes(int R, int N, int S) {   // (covers the sum and th
 }
 
 // W / LW: linear and log softmax weights (already computed by the caller), frag: upper_mfma_frag_bytes() of scratch
+// softmax rows + fragments of a layer from its raw weights (the per-call rebuild of the folded route)
+int upper_mfma_tables(bool root, const float *weight, float *W, float *LW, int R, int N, int S, void *frag, hipStream_t st) {
+    const int P = R / 2, tiles = root ? root_ct(N, S) : cdiv((int64_t)S * N, 32);
+    const int rows = root ? S : P * S, n = root ? P * N * N : N * N;
+    const int extra = (root && S * N < tiles * 32) ? 1 : 0;
+    DPK_LAUNCH(upper_tables_kernel, dim3(rows + extra), dim3(256), 0, st, weight, rows, n, W, LW, (uint16_t *)frag, P, N, S,
+               root ? 1 : 0, tiles);
+    DPK_CHECK_LAUNCH("upper_tables_kernel");
+    return DPK_OK;
+}
+
 int upper_mfma_forward(bool root, const float *in, const float *W, const float *LW, int64_t B, int R, int N, int S,
                        float *out, void *frag, bool frag_cached, hipStream_t st, const unsigned *gate) {
     const int P = R / 2, tiles = root ? root_ct(N, S) : cdiv((int64_t)S * N, 32);
@@ -305,13 +491,16 @@ int upper_mfma_forward(bool root, const float *in, const float *W, const float *
     a.in = in; a.frag = (const uint16_t *)frag; a.LW = LW; a.out = out; a.B = B; a.R = R; a.S = S; a.tiles = tiles;
     const int gx = cdiv(B, 128);
     if (!root) {
-        // partitions per block: enough blocks to fill the chip at small batches, all of them in one block at large ones
+        // partitions per block: a wave's partitions run one after the other, each behind its own L2 round trip, so they
+        // are spread over the grid until it is a few waves deep per SIMD (DPK_UPPER_BLOCKS overrides: measurements)
+        static const int64_t want = [] { const char *e = getenv("DPK_UPPER_BLOCKS"); return e ? (int64_t)atoll(e) : (int64_t)8192; }();
         int ppb = P;
-        while (ppb > 1 && (int64_t)gx * cdiv(P, ppb) < 1024) ppb = (ppb + 1) / 2;
+        while (ppb > 1 && (int64_t)gx * cdiv(P, ppb) < want) ppb = (ppb + 1) / 2;
         a.ppb = ppb;
         const dim3 grid(gx, cdiv(P, ppb));
-        if (N == 16) DPK_LAUNCH(prodsum_mfma_kernel<16>, grid, dim3(256), 0, st, a);
-        else DPK_LAUNCH(prodsum_mfma_kernel<8>, grid, dim3(256), 0, st, a);
+        const size_t lds = (size_t)4 * 32 * (S + 1) * 4;
+        if (N == 16) DPK_LAUNCH(prodsum_mfma_kernel<16>, grid, dim3(256), lds, st, a);
+        else DPK_LAUNCH(prodsum_mfma_kernel<8>, grid, dim3(256), lds, st, a);
     } else {
 #define DPK_ROOT(NN, CTT) DPK_LAUNCH((prodroot_mfma_kernel<NN, CTT>), dim3(gx), dim3(256), 0, st, a)
         if (N == 16) {
