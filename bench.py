@@ -456,6 +456,35 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
     m_dgc = m
     del xs
 
+    # ---- SURVEY 8d config 4, secondary: the example's model (examples/dgcspn_mnist.py:27-37): two pooling levels, 16 leaf
+    # and 32 sum channels -- outside the 8 -> 8 channel streaming kernels: the generic fused product+sum level kernels
+    try:
+        torch.manual_seed(6)
+        m2 = DgcSpn((1, 28, 28), n_batch=16, sum_channels=32, depthwise=True, n_pooling=2).eval()
+        sd2 = {k: v.detach().clone() for k, v in m2.state_dict().items()}
+        # algorithmic floats per sample, products folded into the sums above them (the SURVEY 8d recipe): every map written
+        # once and read once, + the input and the result
+        outs = [sd2['base_layer.loc'].numel()] + [int(v.shape[0] * v.shape[2] * v.shape[3]) for k, v in sd2.items()
+                                                   if k.startswith('layers.') and v.dim() == 4 and int(k.split('.')[1]) % 2 == 1]
+        alg2 = 4 * (784 + 2 * sum(outs) + 1)
+        m2.to(dev)
+        xs = [torch.randn(B, 1, 28, 28, device=dev) for _ in range(2)]
+        ms2, _ = _time_eval(m2, xs, timer, KERNEL_SUMPRODROOT, steps=6, warm=2)
+        plan2 = dorc.schedule((1, 28, 28), 16, 32, True, 2)
+        xc = torch.randn(128, 1, 28, 28)
+        rate2, dt2 = _oracle_rate(lambda a, b: dorc.dgcspn_forward(sd2, xc[a:b], plan2), 128, 64, threads)
+        out.append({'id': 'c4b', 'workload': 'DgcSpn((1,28,28), n_batch=16, sum_channels=32, depthwise=True, n_pooling=2) forward '
+                                             '(examples/dgcspn_mnist.py)', 'config': 'SURVEY 8d config 4 secondary', 'batch': B,
+                    'ms_per_step': ms2, 'value': B / ms2 * 1e3, 'unit': 'log-likelihoods/sec',
+                    'kernel': 'spatial_prodsum_fwd_kernel<32, 1> (generic fused product+sum level, 32 channels)',
+                    'roofline': hbm(B * alg2, ms2),
+                    'roofline_basis': 'whole step; {} algorithmic B/sample (every map written and read once)'.format(alg2),
+                    'cpu_baseline': {'value': rate2, 'unit': 'log-likelihoods/sec', 'cores': threads, 'kind': 'port',
+                                     'sample': '128 samples ({:.1f} s), oracle/dgcspn_oracle.py'.format(dt2)}})
+        del m2, xs
+    except Exception as ex:
+        out.append({'id': 'c4b', 'config': 'SURVEY 8d config 4 secondary', 'error': '{}: {}'.format(type(ex).__name__, ex)})
+
     # ---- BASELINE config 5: RealNVP-1D, B = 65536 ------------------------------------------------------------------
     from tests.util import randomise_flow
     B = 65536
@@ -485,6 +514,12 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
                            '(the conditioner runs on the f16 matrix cores at 3 MFMAs per fp32-grade product, far '
                            'from their peak)' if k_ms else 'whole step, 5 layers',
          'fp32_equivalent_tflops': (per_layer / (k_ms * 1e-3) / 1e12) if k_ms else None,
+         # executed f16 matrix-core work of one coupling kernel: 3 MFMA products per fp32-grade product of the mask-aware
+         # GEMMs (392 x 128 and 128 x 784 per sample), against the dense f16 MFMA peak
+         'mfma': (lambda a: {'bound': 'mfma', 'achieved': a, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': a / 2500.0,
+                             'basis': 'executed f16 MFMA flops of one coupling kernel: 3 products x 2 x (392 x 128 + 128 x 784) '
+                                      'per sample over its HIP-event time; SQ_VALU_MFMA_BUSY_CYCLES pass in profiles/'})(
+             3.0 * per_layer / (k_ms * 1e-3) / 1e12) if k_ms else None,
          'cpu_baseline': {'value': rate, 'unit': 'log-likelihoods/sec', 'cores': threads, 'kind': 'port',
                           'sample': '16384 samples ({:.1f} s), oracle/flows_oracle.py'.format(dt)}}
     e['roofline']['traffic'], e['roofline']['traffic_source'] = read_traffic('config5')

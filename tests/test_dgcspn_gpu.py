@@ -232,6 +232,33 @@ def test_full_size_properties():
     assert torch.isfinite(ll2).all() and not torch.equal(ll2[0], ll[0])
 
 
+def test_full_size_properties_example_model():
+    """SURVEY 8d config 4's secondary model (examples/dgcspn_mnist.py:27-37: two pooling levels, 16 leaf / 32 sum channels;
+    the generic fused product+sum level kernels) at the full batch: a scattered subset against the oracle, slices of the
+    batch bit for bit, a fully marginalised image gives LL = 0 and marginalised pixels leave the other samples alone."""
+    from deeprob.spn.models import DgcSpn
+    torch.manual_seed(6)
+    model = DgcSpn((1, 28, 28), n_batch=16, sum_channels=32, depthwise=True, n_pooling=2).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    plan = dorc.schedule((1, 28, 28), 16, 32, True, 2)
+    model.cuda()
+    x = torch.randn(8192, 1, 28, 28, device='cuda', generator=torch.Generator('cuda').manual_seed(1))
+    x[555] = float('nan')
+    rows = torch.randint(0, 8192, (48,), generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        ll = model(x)
+        part = model(x[3000:3000 + 1024])
+        x2 = x.clone()
+        x2[::2, :, 10:, :] = float('nan')
+        ll2 = model(x2)
+    want = dorc.dgcspn_forward(sd, x[rows.cuda()].cpu(), plan).numpy()
+    assert tuple(ll.shape) == (8192, 1) and torch.isfinite(ll).all()
+    assert rel_err(ll[rows.cuda()].cpu().numpy(), want) <= LL_TOL
+    assert torch.equal(ll[3000:3000 + 1024], part)
+    assert abs(ll[555].item()) < 1e-5
+    assert torch.equal(ll2[1::2], ll[1::2]) and not torch.equal(ll2[0], ll[0])
+
+
 def test_streaming_levels_golden(golden, monkeypatch):
     """The streaming kernels of the 8 -> 8 channel levels (dgcspn_stream.hip; default route from B = 256) forced onto
     the golden batch of BASELINE config 4's model: same tolerance as the batch-independent route."""
