@@ -321,14 +321,15 @@ __device__ __forceinline__ unsigned long long fp_word(unsigned w, unsigned pos) 
     b = b * 0x1B873593u + (pos ^ 0x27D4EB2Fu);
     return ((unsigned long long)(b ^ (b >> 16)) << 32) | (unsigned long long)(a ^ (a >> 13));
 }
-__device__ __forceinline__ unsigned long long fp_range(const void *p, int64_t bytes, unsigned tag) {
+// (tid of nthreads: the threads that share the range -- the whole block by default; the sum over them is what counts)
+__device__ __forceinline__ unsigned long long fp_range_n(const void *p, int64_t bytes, unsigned tag, int tid, int nthreads) {
     unsigned long long h = 0ull;
     if (p == nullptr) return h;
     if ((((uintptr_t)p | (uintptr_t)bytes) & 3) == 0) {
         // (four loads in flight per thread: one load per trip made this pass latency bound -- 11 us for 26 KB)
         const unsigned *w = (const unsigned *)p;
-        const int n = (int)(bytes >> 2), step = (int)blockDim.x;
-        int e = (int)threadIdx.x;
+        const int n = (int)(bytes >> 2), step = nthreads;
+        int e = tid;
         for (; e + 3 * step < n; e += 4 * step) {
             const unsigned w0 = w[e], w1 = w[e + step], w2 = w[e + 2 * step], w3 = w[e + 3 * step];
             h += fp_word(w0, (unsigned)e * 8u + tag) + fp_word(w1, (unsigned)(e + step) * 8u + tag) +
@@ -337,9 +338,12 @@ __device__ __forceinline__ unsigned long long fp_range(const void *p, int64_t by
         for (; e < n; e += step) h += fp_word(w[e], (unsigned)e * 8u + tag);
     } else {
         const unsigned char *b = (const unsigned char *)p;
-        for (int64_t e = threadIdx.x; e < bytes; e += blockDim.x) h += fp_word(b[e], (unsigned)e * 8u + tag + 4u);
+        for (int64_t e = tid; e < bytes; e += nthreads) h += fp_word(b[e], (unsigned)e * 8u + tag + 4u);
     }
     return h;
+}
+__device__ __forceinline__ unsigned long long fp_range(const void *p, int64_t bytes, unsigned tag) {
+    return fp_range_n(p, bytes, tag, (int)threadIdx.x, (int)blockDim.x);
 }
 // sum of a 64-bit value over the block, returned to every thread (red: 17 words of LDS; blockDim a multiple of 64)
 __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long h, unsigned long long *red) {

@@ -130,6 +130,42 @@ __host__ __device__ inline size_t gemm_prep_lds_bytes(int D, int I, int d) {
             (size_t)cdiv(D, 16) * 4 * I) * 4;
 }
 
+// This thread's share (tid of nthreads) of the fingerprint of table work-group blk's inputs; the work-group's fingerprint is
+// kPrepHashBase + blk + the sum of the shares (position-tagged words: any split of the threads gives the same sum).
+constexpr unsigned long long kPrepHashBase = 0x9E3779B97F4A7C15ull;
+template <int I>
+__device__ __forceinline__ unsigned long long gemm_prep_hash_share(const GemmPrepArgs &a, int blk, int tid, int nthreads) {
+    constexpr int RPT = 8 / I;
+    const int nrb = a.NT * RPT, d = a.d;
+    unsigned long long h = 0ull;
+    if (blk < nrb) {
+        if (blk < a.reps) {
+            const int rho = blk;
+            h += fp_range_n(a.mask + (int64_t)rho * 4 * d, (int64_t)4 * d * 8, 1, tid, nthreads);
+            h += fp_range_n(a.pad ? a.pad + (int64_t)rho * 4 * d : nullptr, (int64_t)4 * d, 2, tid, nthreads);
+            h += fp_range_n(a.loc + (int64_t)rho * 4 * I * d, (int64_t)4 * I * d * 4, 3, tid, nthreads);
+            h += fp_range_n(a.scale + (int64_t)rho * 4 * I * d, (int64_t)4 * I * d * 4, 4, tid, nthreads);
+        }
+    } else {
+        // the raw weight rows this work-group normalises (fingerprints are per work-group of kGemmPrepThreads / 64 rows)
+        constexpr int rpb = kGemmPrepThreads / 64;
+        int row = (blk - nrb) * rpb;
+        for (int r = 0; r < rpb; ++r, ++row) {
+            int rr = row;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                if (rr < a.rows[m]) {
+                    // (position-dependent through the row number: rows that trade places change the sum)
+                    h += fp_range_n(a.w[m] + (int64_t)rr * a.n[m], (int64_t)a.n[m] * 4, 5u + 8192u * (unsigned)row, tid, nthreads);
+                    break;
+                }
+                rr -= a.rows[m];
+            }
+        }
+    }
+    return h;
+}
+
 template <int I>
 __device__ __forceinline__ void gemm_prep_block(const GemmPrepArgs &a, int blk, int *dyn) {
     constexpr int RPT = 8 / I;       // repetitions per 32-column tile (4 regions x I channels each)
@@ -148,31 +184,10 @@ __device__ __forceinline__ void gemm_prep_block(const GemmPrepArgs &a, int blk, 
     // ---- fingerprint of the bytes this work-group's outputs depend on ------------------------------------------------
     // (block local: a repetition's tables depend on its own slice of mask / pad_mask / loc / scale only; a write through
     // `param.data` moves no version counter on the host)
-    unsigned long long h = 0x9E3779B97F4A7C15ull + (unsigned long long)blk;
+    unsigned long long h = threadIdx.x == 0 ? kPrepHashBase + (unsigned long long)blk : 0ull;   // (once per work-group)
     {
         const unsigned long long stored_early = a.mode != kPrepBuild ? a.hash[blk] : 0ull;   // (requested first)
-        if (real) {
-            h += fp_range(a.mask + (int64_t)rho * 4 * d, (int64_t)4 * d * 8, 1);
-            h += fp_range(a.pad ? a.pad + (int64_t)rho * 4 * d : nullptr, (int64_t)4 * d, 2);
-            h += fp_range(a.loc + (int64_t)rho * 4 * I * d, (int64_t)4 * I * d * 4, 3);
-            h += fp_range(a.scale + (int64_t)rho * 4 * I * d, (int64_t)4 * I * d * 4, 4);
-        } else if (rows_blk) {
-            // the raw weight rows this work-group normalises (fingerprints are per work-group: the standalone table
-            // kernel and the model kernels all run 512 threads = 8 rows per work-group)
-            int row = (blk - nrb) * rpb;
-            for (int r = 0; r < rpb; ++r, ++row) {
-                int rr = row;
-#pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    if (rr < a.rows[m]) {
-                        // (position-dependent through the row number: rows that trade places change the sum)
-                        h += fp_range(a.w[m] + (int64_t)rr * a.n[m], (int64_t)a.n[m] * 4, 5u + 8192u * (unsigned)row);
-                        break;
-                    }
-                    rr -= a.rows[m];
-                }
-            }
-        }
+        h += gemm_prep_hash_share<I>(a, blk, (int)threadIdx.x, (int)blockDim.x);
         h = block_sum_u64(h, red_s);
         if (a.mode == kPrepVerify) {
             if (stored_early == h) return;                    // nothing this work-group's outputs depend on has changed

@@ -251,3 +251,47 @@ def test_in_launch_table_check_more_work_groups_than_the_chip_holds():
             want = orc.ratspn_forward(_state(model), x[rows]).numpy()
             for _ in range(3):
                 assert rel_err(model(xd)[rows.cuda()].cpu().numpy(), want) <= TOL
+
+
+@pytest.mark.parametrize('kw,D', [(dict(rg_batch=2, rg_sum=2, rg_repetitions=8), 784),
+                                  (dict(rg_batch=4, rg_sum=4, rg_repetitions=5, out_classes=3), 200)], ids=['i2s2', 'i4s4c3'])
+@pytest.mark.parametrize('self_checking', [False, True], ids=['checklaunch', 'selfcheck'])
+def test_in_launch_table_check_ring_kernel(kw, D, self_checking):
+    """The persistent ring kernel (batches above 16384): by default the stand-alone check launch in front of it; with
+    DPK_RING_VI=1 (read once per process: the second case runs in a child process) the variant that carries the check --
+    the compute waves of its first work-groups fingerprint in the prologue, a stale launch evaluates on the table-free
+    route and rebuilds at its end (measured slower than kernel + check launch, hence opt-in: csrc/ratspn_gemm.hip).
+    Writes to each parameter kind in turn, two batch sizes, a scattered subset against the oracle every time."""
+    if self_checking:
+        import os, subprocess, sys
+        env = dict(os.environ, DPK_RING_VI='1')
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', __file__, '-k',
+                            'test_in_launch_table_check_ring_kernel and checklaunch and ' + ('i2s2' if D == 784 else 'i4s4c3')],
+                           cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert r.returncode == 0, r.stdout.decode()[-2000:]
+        return
+    from deeprob.spn.models import GaussianRatSpn
+    from oracle import ratspn_oracle as orc
+    torch.manual_seed(21)
+    model = GaussianRatSpn(D, rg_depth=2, random_state=42, **kw).cuda().eval()
+    gen = torch.Generator().manual_seed(22)
+    xs = {B: torch.randn(B, D, generator=gen) for B in (20000, 33001)}
+    xd = {B: v.cuda() for B, v in xs.items()}
+    rows = {B: torch.randint(0, B, (160,), generator=gen) for B in xs}
+    with torch.no_grad():
+        for B in xd:
+            model(xd[B])
+        for step, what in enumerate(('loc', 'sum', 'root', 'loc')):
+            if what == 'loc':
+                model.base_layer.loc.data.add_(0.02 * (step + 1))
+            elif what == 'sum':
+                for layer in model.layers:
+                    if hasattr(layer, 'weight'):
+                        layer.weight.data.add_(torch.randn_like(layer.weight))
+            else:
+                model.root_layer.weight.data.add_(torch.randn_like(model.root_layer.weight))
+            sd = _state(model)
+            for B in ((20000, 33001, 20000) if step % 2 == 0 else (33001, 20000)):
+                got = model(xd[B])[rows[B].cuda()].cpu().numpy()
+                assert rel_err(got, orc.ratspn_forward(sd, xs[B][rows[B]]).numpy()) <= TOL, (step, what, B)
