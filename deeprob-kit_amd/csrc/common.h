@@ -18,24 +18,17 @@ void profile_take(hipEvent_t *start, hipEvent_t *stop, int kernel_id = 1);
 int device_cus();
 int ensure_dynamic_lds(const void *kernel, int bytes);
 
-// Marginalised-evidence hint shared by the RAT-SPN forward kernels: a work-group that meets NaN evidence stores the
-// launch number in a host-mapped word; the host reads it without synchronising (a stale value only costs speed) and
-// picks the kernel build / variant that keeps such inputs fast while one of the recent launches did so.
-struct SlowHint {
-    int *host = nullptr, *dev = nullptr;   // one host-mapped word per process (one process per GPU)
-    unsigned seq = 0;
-};
-SlowHint &slow_hint();
-// next launch number + whether a launch within the last 256 met marginalised evidence (dev == nullptr: no hint word)
-inline bool slow_hint_next(int **dev_word, int *launch_seq) {
-    SlowHint &h = slow_hint();
-    *dev_word = h.dev;
-    *launch_seq = 0;
-    if (h.dev == nullptr) return false;
-    *launch_seq = (int)++h.seq;
-    // the host runs ahead of the device by its launch queue: "recent" = within 256 launches
-    return (unsigned)(*launch_seq - *(volatile int *)h.host) <= 256u;
-}
+// Marginalised-evidence hint of the RAT-SPN forward kernels: a work-group that meets NaN evidence stores the launch
+// number in a host-mapped word; the host reads it without synchronising (a stale value only costs speed) and picks the
+// kernel build / variant that keeps such inputs fast while one of the recent launches did so.  One word PER WORKSPACE
+// (round 4; a process-wide word before: two models -- or a clean and a marginalised stream -- in one process steered each
+// other's variant): slots of one host-mapped page per process, keyed by the workspace's address, released by
+// dpk_workspace_forget.  A captured HIP graph freezes the variant that was current at capture time (results identical).
+// Returns whether a launch of this workspace within its last 256 met marginalised evidence; *dev_word = nullptr (and
+// false) when no slot could be had.
+bool slow_hint_next(const void *ws_key, int **dev_word, int *launch_seq);
+// releases what the library keeps per workspace address (hint slot, params_gate slots) for keys in [base, base + bytes)
+void workspace_forget(const void *base, int64_t bytes);
 
 // ---- device-side check of cached parameter tables (DPK_FLAG_PARAMS_VERIFY) ------------------------------------------
 // The host can only tell that a parameter MAY have changed from its address / version counter; a write through

@@ -1465,7 +1465,7 @@ static int launch_leaf(const LeafArgs &a, hipStream_t st) {
                 // ones because of the extra code in the chunk loop).  A work-group that meets a slow chunk stores the
                 // launch number in a host-mapped word; a launch takes the second build while one of the recent
                 // launches did so.  The word is read without synchronising: a stale value only costs speed.
-                const bool marginal = slow_hint_next(&c.slow_flag, &c.launch_seq);
+                const bool marginal = slow_hint_next(a.rec, &c.slow_flag, &c.launch_seq);
                 if (marginal) return launch_leaf_gen<DIST, QB, CB, SPL, DEPTH, S, false, true>(c, st);
                 return launch_leaf_gen<DIST, QB, CB, SPL, DEPTH, S, false>(c, st);
             }

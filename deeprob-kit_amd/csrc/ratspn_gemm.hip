@@ -372,7 +372,7 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
     const int NT = w.g_nt;
     int *slow_word = nullptr;
     int launch_seq = 0;
-    bool marginal = slow_hint_next(&slow_word, &launch_seq);
+    bool marginal = slow_hint_next(w.gm_tab, &slow_word, &launch_seq);   // (keyed by this workspace's tables)
     static const int ablate = [] { const char *e = getenv("DPK_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
     {   // (measurement: DPK_GEMM_MARGINAL=0 / 1 pins the variant)
         static const int force = [] { const char *e = getenv("DPK_GEMM_MARGINAL"); return e ? atoi(e) : -1; }();

@@ -5,6 +5,7 @@
 #include <mutex>
 #include <unordered_set>
 #include <unordered_map>
+#include <vector>
 
 namespace dpk {
 static thread_local char g_err[512] = "";
@@ -27,23 +28,61 @@ int device_cus() {
     return cus[dev];
 }
 
-SlowHint &slow_hint() {
-    static SlowHint h = [] {
-        SlowHint s;
-        int *p = nullptr;
-        if (hipHostMalloc((void **)&p, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && p) {
-            *p = -1000;
-            int *d = nullptr;
-            if (hipHostGetDevicePointer((void **)&d, p, 0) == hipSuccess && d) {
-                s.host = p;
-                s.dev = d;
-            }
-        } else {
+namespace {
+constexpr int kHintSlots = 1024;
+struct HintPool {
+    std::mutex mu;
+    int *host = nullptr, *dev = nullptr;
+    bool failed = false;
+    std::unordered_map<const void *, int> slot;
+    std::vector<int> free_list;
+    unsigned seq[kHintSlots] = {};
+    int next = 0;
+};
+HintPool &hint_pool() {
+    static HintPool p;
+    return p;
+}
+}  // namespace
+
+bool slow_hint_next(const void *ws_key, int **dev_word, int *launch_seq) {
+    HintPool &hp = hint_pool();
+    *dev_word = nullptr;
+    *launch_seq = 0;
+    std::lock_guard<std::mutex> lock(hp.mu);
+    if (hp.failed) return false;
+    if (hp.host == nullptr) {
+        int *p = nullptr, *d = nullptr;
+        if (hipHostMalloc((void **)&p, kHintSlots * sizeof(int), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess || !p ||
+            hipHostGetDevicePointer((void **)&d, p, 0) != hipSuccess || !d) {
             (void)hipGetLastError();
+            hp.failed = true;
+            return false;
         }
-        return s;
-    }();
-    return h;
+        for (int i = 0; i < kHintSlots; ++i) p[i] = -1000;
+        hp.host = p;
+        hp.dev = d;
+    }
+    auto it = hp.slot.find(ws_key);
+    if (it == hp.slot.end()) {
+        int idx;
+        if (!hp.free_list.empty()) {
+            idx = hp.free_list.back();
+            hp.free_list.pop_back();
+        } else if (hp.next < kHintSlots) {
+            idx = hp.next++;
+        } else {
+            return false;   // (no slot: this workspace runs without the hint -- the default variants, same results)
+        }
+        hp.host[idx] = -1000;
+        hp.seq[idx] = 0;
+        it = hp.slot.emplace(ws_key, idx).first;
+    }
+    const int idx = it->second;
+    *dev_word = hp.dev + idx;
+    *launch_seq = (int)++hp.seq[idx];
+    // the host runs ahead of the device by its launch queue: "recent" = within 256 launches
+    return (unsigned)(*launch_seq - *(volatile int *)(hp.host + idx)) <= 256u;
 }
 
 int ensure_dynamic_lds(const void *kernel, int bytes) {
@@ -133,24 +172,76 @@ int gated_zero(void *p, int64_t bytes, const unsigned *gate, hipStream_t st) {
     return DPK_OK;
 }
 
+namespace {
+struct GatePool {
+    unsigned long long *base = nullptr;
+    std::unordered_map<const void *, int> slot;
+    std::vector<int> free_list;
+    int next = 0;
+    bool failed = false;
+};
+struct GatePools {
+    std::mutex mu;
+    GatePool pools[kMaxDevices];
+};
+GatePools &gate_pools() {
+    static GatePools g;
+    return g;
+}
+}  // namespace
+
+// Slots are keyed by an address inside the workspace that holds the table set; a workspace that goes away hands them
+// back (deeprob.hip.Workspace.__del__ -> dpk_workspace_forget), so a long-lived process that builds many models does not
+// run the 4096-slot pool dry (round-3 advice: exhausted, every verifying call silently became a rebuild).  A recycled
+// slot's first use is an unconditional build, whatever its old contents.  One module evaluates on one stream at a time:
+// the slot's accumulator and ticket are per table set, not per stream.
+void workspace_forget(const void *base, int64_t bytes) {
+    const char *lo = (const char *)base, *hi = lo + bytes;
+    {
+        GatePools &gp = gate_pools();
+        std::lock_guard<std::mutex> lock(gp.mu);
+        for (int d = 0; d < kMaxDevices; ++d) {
+            GatePool &pl = gp.pools[d];
+            for (auto it = pl.slot.begin(); it != pl.slot.end();) {
+                const char *k = (const char *)it->first;
+                if (k >= lo && k < hi) {
+                    pl.free_list.push_back(it->second);
+                    it = pl.slot.erase(it);
+                } else {
+                    ++it;
+                }
+            }
+        }
+    }
+    {
+        HintPool &hp = hint_pool();
+        std::lock_guard<std::mutex> lock(hp.mu);
+        for (auto it = hp.slot.begin(); it != hp.slot.end();) {
+            const char *k = (const char *)it->first;
+            if (k >= lo && k < hi) {
+                hp.free_list.push_back(it->second);
+                it = hp.slot.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
+}
+
 const unsigned *params_gate(const void *key, const FpSeg *segs, int nseg, bool verify, hipStream_t st) {
     // state slots: one 32-byte record per table set, carved from a per-device pool the library owns (the first use of
     // a device allocates it -- outside any stream capture: captured steps are preceded by eager ones)
     constexpr int kSlots = 4096;
-    struct Pool {
-        unsigned long long *base = nullptr;
-        std::unordered_map<const void *, int> slot;
-        bool failed = false;
-    };
-    static std::mutex mu;
-    static Pool pools[kMaxDevices];
+    GatePools &gp = gate_pools();
+    std::mutex &mu = gp.mu;
+    GatePool *pools = gp.pools;
     if (nseg < 1 || nseg > kFpMaxSegs) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
     unsigned long long *state = nullptr;
     {
         std::lock_guard<std::mutex> lock(mu);
-        Pool &pl = pools[dev];
+        GatePool &pl = pools[dev];
         if (pl.failed) return nullptr;
         if (pl.base == nullptr) {
             if (hipMalloc(&pl.base, (size_t)kSlots * 32) != hipSuccess || hipMemset(pl.base, 0, (size_t)kSlots * 32) != hipSuccess) {
@@ -162,9 +253,17 @@ const unsigned *params_gate(const void *key, const FpSeg *segs, int nseg, bool v
         }
         auto it = pl.slot.find(key);
         if (it == pl.slot.end()) {
-            if ((int)pl.slot.size() >= kSlots) return nullptr;
-            it = pl.slot.emplace(key, (int)pl.slot.size()).first;
-            verify = false;   // a fresh slot holds no hash: this call's build is unconditional
+            int idx;
+            if (!pl.free_list.empty()) {
+                idx = pl.free_list.back();
+                pl.free_list.pop_back();
+            } else if (pl.next < kSlots) {
+                idx = pl.next++;
+            } else {
+                return nullptr;
+            }
+            it = pl.slot.emplace(key, idx).first;
+            verify = false;   // a fresh (or recycled) slot holds no valid hash: this call's build is unconditional
         }
         state = pl.base + (int64_t)it->second * 4;
     }
@@ -216,6 +315,11 @@ __global__ void ll_accumulate_kernel(const float *__restrict__ ll, int64_t n, do
 }  // namespace dpk
 
 extern "C" const char *dpk_last_error(void) { return dpk::g_err; }
+extern "C" int dpk_workspace_forget(const void *base, int64_t bytes) {
+    if (base == nullptr || bytes <= 0) return DPK_OK;
+    dpk::workspace_forget(base, bytes);
+    return DPK_OK;
+}
 extern "C" int dpk_abi_version(void) { return 1; }
 extern "C" int dpk_profile_next_kernel(void *ev_start, void *ev_stop) {
     dpk::g_ev_start = (hipEvent_t)ev_start;

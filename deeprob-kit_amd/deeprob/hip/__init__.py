@@ -47,6 +47,7 @@ _u32 = ctypes.c_uint32
 SIGNATURES = {
     'dpk_last_error': (ctypes.c_char_p, []),
     'dpk_abi_version': (ctypes.c_int, []),
+    'dpk_workspace_forget': (ctypes.c_int, [_c_void, _i64]),
     'dpk_ratspn_workspace_bytes': (_i64, [_i32] * 8),
     'dpk_gaussian_leaf_forward_on_mfma': (ctypes.c_int, [_c_void, _c_void, _i32, _i32, _i32, _i32, _u32]),
     'dpk_gaussian_leaf_forward': (ctypes.c_int, [_c_void, _i64, _i32, _c_void, _c_void, _c_void, _c_void,
@@ -268,6 +269,17 @@ class Workspace:
         self.struct_key = None  # what the cached structure tables were built from
         self.params_key = None  # parameters (addresses, versions) the MFMA route's tables were built from
         self._retired = []      # outgrown buffers: a captured HIP graph may still address them
+
+    def __del__(self):
+        # the library keeps a few words per workspace ADDRESS (fingerprint slots, the marginalised-evidence hint): hand
+        # them back before the allocator reuses the memory
+        try:
+            if _lib is not None:
+                for t in [self.buf] + list(self._retired):
+                    if t is not None and t.is_cuda:
+                        _lib.dpk_workspace_forget(t.data_ptr(), t.numel())
+        except Exception:   # (interpreter shutdown: modules may be gone)
+            pass
 
     def get(self, n_bytes: int, device: torch.device) -> torch.Tensor:
         if self.buf is None or self.buf.numel() < n_bytes or self.buf.device != device:

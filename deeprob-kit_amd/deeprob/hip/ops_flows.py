@@ -132,15 +132,21 @@ def flow1d_prepare(flow, layers, x: torch.Tensor):
         if not _pairs_well_conditioned(pw, key, w1, w2, sc, parity):
             continue                # (the fp32-MFMA kernel takes this layer: no packed tables)
         flags = cached_tables_flag() if pw.params_key == key else 0
-        pw.params_key = key
         centries.append(_PairsTablesArgs(ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(sc), ptr(sh), ptr(ws), ws.numel(), D, units,
                                          parity, int(layer.affine), flags))
         marked.append((pw, key))
     if centries:
         arr = (_PairsTablesArgs * len(centries))(*centries)
-        check(lib.dpk_coupling1d_pairs_tables(len(centries), ctypes.cast(arr, ctypes.c_void_p), stream_ptr(dev)),
-              'dpk_coupling1d_pairs_tables')
+        rc = lib.dpk_coupling1d_pairs_tables(len(centries), ctypes.cast(arr, ctypes.c_void_p), stream_ptr(dev))
+        if rc:
+            # nothing is known about any of these table sets now: the per-layer operators rebuild (round-3 advice: the keys
+            # used to be recorded BEFORE the launch, and a failure left them claiming tables that were never built)
+            for pw, _ in marked:
+                pw.params_key = None
+                pw._prep_token = None
+            check(rc, 'dpk_coupling1d_pairs_tables')
         for pw, key in marked:
+            pw.params_key = key
             pw._prep_token = token
             pw._prep_key = key
     _prep_token = token
@@ -153,7 +159,7 @@ def flow1d_prepare(flow, layers, x: torch.Tensor):
 # 50-80, and 2^-22 A |x| stays below 1e-6 of |log p|.  A badly conditioned layer (conditioner weights 10x, BatchNorm
 # variances of 1e-4: A = 2e3 .. 4e4) amplifies every product's rounding by A, the reference's fp32 arithmetic included --
 # there 22 bits measured 6x the reference's own distance from fp64 (tests/test_flows_gpu.py::
-# test_pairs_kernel_stress_vs_fp64_oracle).  Such layers keep the fp32-MFMA kernel (dpk_coupling1d_forward: exact fp32
+# the stress test of the column-pair kernels).  Such layers keep the fp32-MFMA kernel (dpk_coupling1d_forward: exact fp32
 # products, csrc/coupling.hip).  The verdict is taken where the packed tables are keyed -- once per (parameter versions,
 # folded affine), one small reduction and one host read -- so a frozen model pays nothing per call.
 PAIRS_GAIN_LIMIT = 1024.0
@@ -233,10 +239,13 @@ def coupling1d(x: torch.Tensor, layer, inverse: bool, in_affine: Optional[Tuple[
             # (accuracy guard: a badly conditioned layer keeps the fp32-MFMA kernel below)
             if _pairs_well_conditioned(pw, key, w1, w2, sc, parity):
                 flags = _tables_flags(pw, key)
-                check(lib.dpk_coupling1d_pairs_forward(
+                rc = lib.dpk_coupling1d_pairs_forward(
                     ptr(x), B, D, parity, ptr(w1), ptr(b1), ptr(w2), ptr(b2), units, ptr(act), ptr(sc), ptr(sh),
                     int(layer.affine), int(inverse), ptr(out), ptr(ldj_p), int(ldj is not None), ptr(ws), ws.numel(),
-                    flags, stream_ptr(x.device)), 'dpk_coupling1d_pairs_forward')
+                    flags, stream_ptr(x.device))
+                if rc:
+                    pw.params_key = None        # (a failed call built nothing: the next one does not trust the tables)
+                check(rc, 'dpk_coupling1d_pairs_forward')
                 return out, ldj_p
     n = lib.dpk_coupling1d_workspace_bytes(D, units, n_masked, n_trans)
     if n < 0:
@@ -294,8 +303,9 @@ def coupling1d_logprob(x: torch.Tensor, layer, in_affine, ildj: Optional[torch.T
         ptr(osc), ptr(osh), ptr(require_device_f32(base_loc.reshape(-1), 'loc')),
         ptr(require_device_f32(base_scale.reshape(-1), 'scale')), ptr(ildj), ptr(ildj_const), ptr(ll), ptr(ws),
         ws.numel(), flags, stream_ptr(x.device))
-    if rc == -4:
+    if rc:
         pw.params_key = None
+    if rc == -4:
         return None
     check(rc, 'dpk_coupling1d_pairs_logprob')
     return ll

@@ -65,13 +65,21 @@ extern "C" {
                                      knows is that addresses and version counters are unchanged -- a write through
                                      `param.data` moves neither.  DPK_FLAG_PARAMS_CACHED remains the caller's own
                                      guarantee that the bytes are unchanged (no check, no launch).  How an entry
-                                     point checks is its own business: the RAT-SPN table kernels fingerprint the
-                                     slice of parameters each work-group depends on and return when it is unchanged
-                                     (one ~2 us launch), the coupling tables use a fingerprint kernel + gated table
+                                     point checks is its own business: the RAT-SPN table work-groups fingerprint the
+                                     slice of parameters each depends on -- inside the model kernel's own launch for
+                                     the 32-sample kernels (round 4), as a ~5 us launch in front of the ring kernels --, the coupling tables use a fingerprint kernel + gated table
                                      kernels, entry points whose tables are cheap simply rebuild them.              */
 
 const char *dpk_last_error(void);
 int dpk_abi_version(void);
+
+/* A workspace handed to the entry points below is about to be released (or its memory reused for something else): the
+ * library forgets what it keeps per workspace ADDRESS -- the fingerprint slots of the cached-table checks and the
+ * marginalised-evidence hint word (one host-mapped word per workspace; a performance hint only).  Optional: a process that
+ * builds a few models never needs it; one that builds thousands would otherwise run the 4096-slot pool dry (every check
+ * then degrades to a rebuild).  No reference counterpart (the reference keeps no derived tables).  Host side only, no
+ * stream work. */
+int dpk_workspace_forget(const void *workspace, int64_t bytes);
 
 /* ------------------------------------------------------------------------ *
  * RAT-SPN                                                                   *

@@ -210,3 +210,39 @@ def test_round2_entry_error_codes():
     assert lib.dpk_spatial_sumprodroot_workspace_bytes_batch(4096, C, H, W, None, 8, g6, 1) == DPK_EINVAL
     assert lib.dpk_spatial_sumprodroot_workspace_bytes_batch(-1, C, H, W, g5, 8, g6, 1) == DPK_EINVAL
     torch.cuda.synchronize()
+
+
+def test_workspace_forget_and_per_workspace_hint():
+    """dpk_workspace_forget hands back what the library keeps per workspace address (fingerprint slots, the
+    marginalised-evidence hint word); the hint is per workspace since round 4: a model fed NaN evidence and a model fed
+    clean evidence in the same process both stay right, and models can come and go by the hundred."""
+    import gc
+    from deeprob.hip import load_library
+    from deeprob.spn.models import GaussianRatSpn
+    from oracle import ratspn_oracle as orc
+    lib = load_library()
+    assert lib.dpk_workspace_forget(None, 0) == 0
+    buf = torch.empty(4096, dtype=torch.uint8, device='cuda')
+    assert lib.dpk_workspace_forget(buf.data_ptr(), buf.numel()) == 0          # nothing registered: a no-op
+    torch.manual_seed(0)
+    a = GaussianRatSpn(64, rg_depth=2, rg_repetitions=4, random_state=1).cuda().eval()
+    b = GaussianRatSpn(64, rg_depth=2, rg_repetitions=4, random_state=2).cuda().eval()
+    x = torch.randn(500, 64, generator=torch.Generator().manual_seed(3))
+    xn = x.clone()
+    xn[torch.rand(500, 64, generator=torch.Generator().manual_seed(4)) < 0.3] = float('nan')
+    sa = {k: v.detach().cpu().clone() for k, v in a.state_dict().items()}
+    sb = {k: v.detach().cpu().clone() for k, v in b.state_dict().items()}
+    with torch.no_grad():
+        for _ in range(4):          # a meets NaN evidence on every call, b never does
+            ga, gb = a(xn.cuda()), b(x.cuda())
+    err = lambda got, want: float(((got.cpu() - want).abs() / want.abs().clamp_min(1.0)).max())
+    assert err(ga, orc.ratspn_forward(sa, xn)) <= 1e-5 and err(gb, orc.ratspn_forward(sb, x)) <= 1e-5
+    for i in range(150):            # workspaces come and go (each model's __del__ returns its slots)
+        m = GaussianRatSpn(32, rg_depth=2, rg_repetitions=2, random_state=i).cuda().eval()
+        with torch.no_grad():
+            m(x[:40, :32].cuda())
+            m(x[:40, :32].cuda())
+        del m
+    gc.collect()
+    with torch.no_grad():
+        assert err(a(xn.cuda()), orc.ratspn_forward(sa, xn)) <= 1e-5
