@@ -37,11 +37,37 @@ def _grad_image(g: torch.Tensor) -> torch.Tensor:
     return g.contiguous() if g.dtype == torch.float32 else g.float().contiguous()
 
 
+def _sync_counts(group, B: int, HW: int, sums: torch.Tensor):
+    """Synchronised batch statistics (deeprob.parallel.synchronize_batchnorm): all-reduce the per-channel fp64 sums and
+    return (elements of the whole batch, this rank's weight n_r / N).  The counts come from the training loop's shard
+    sizes (host integers, no read-back); without them the count travels with the sums and is read back once."""
+    import torch.distributed as dist
+    from deeprob import parallel
+    sizes = parallel.shard_sizes()
+    if sizes is not None and sizes[0] == B:
+        dist.all_reduce(sums, group=group)
+        return sizes[1] * HW, float(sizes[0]) / float(sizes[1])
+    buf = torch.cat([sums, torch.tensor([float(B * HW)], dtype=torch.float64, device=sums.device)])
+    dist.all_reduce(buf, group=group)
+    sums.copy_(buf[:-1])
+    n_total = int(round(float(buf[-1].item())))
+    return n_total, float(B * HW) / float(n_total)
+
+
+def _sync_stat_grads(group, weight: float, dstat: torch.Tensor) -> torch.Tensor:
+    """d(whole-batch loss) / d(mean, var) from the ranks' d(local loss) / d(mean, var): their n_r / N weighted sum."""
+    import torch.distributed as dist
+    g = dstat * weight
+    dist.all_reduce(g, group=group)
+    return g
+
+
 class ChannelStatsFn(torch.autograd.Function):
-    """Per-channel mean and biased variance of a [B, C, H, W] tensor over (B, H, W)."""
+    """Per-channel mean and biased variance of a [B, C, H, W] tensor over (B, H, W) -- over the whole sharded batch when a
+    process group is given (synchronised batch normalisation)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, group=None):
         lib = load_library()
         x = ev._image(x, 'x')
         B, C, H, W = x.shape
@@ -51,6 +77,11 @@ class ChannelStatsFn(torch.autograd.Function):
         check(lib.dpk_channel_stats(ptr(x), x.stride(0), B, C, H, W, 1, ptr(sums), stream_ptr(x.device)),
               'dpk_channel_stats')
         n = float(B * H * W)
+        ctx.group, ctx.weight = group, 1.0
+        if group is not None:
+            n_total, ctx.weight = _sync_counts(group, B, H * W, sums)
+            n = float(n_total)
+        ctx.n_total = n
         mean64 = sums[:C] / n
         var64 = (sums[C:] / n - mean64 * mean64).clamp_min_(0.0)
         mean, var = mean64.float(), var64.float()
@@ -65,10 +96,15 @@ class ChannelStatsFn(torch.autograd.Function):
         B, C, H, W = x.shape
         dmean = torch.zeros_like(mean) if dmean is None else _grad_image(dmean)
         dvar = torch.zeros_like(mean) if dvar is None else _grad_image(dvar)
+        if ctx.group is not None:
+            # (the kernel divides by the LOCAL element count: with the weighted sum over the ranks that is exactly
+            # d(whole-batch loss)/dx as this rank's autograd must see it before the n_r / N weighted gradient exchange)
+            g = _sync_stat_grads(ctx.group, ctx.weight, torch.cat([dmean, dvar]))
+            dmean, dvar = g[:C].contiguous(), g[C:].contiguous()
         dx = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
         check(lib.dpk_channel_stats_backward(ptr(x), x.stride(0), B, C, H, W, ptr(mean), ptr(dmean), ptr(dvar), 0,
                                              ptr(dx), stream_ptr(x.device)), 'dpk_channel_stats_backward')
-        return dx
+        return dx, None
 
 
 class ChannelAffineFn(torch.autograd.Function):
@@ -199,7 +235,11 @@ class BnConv2dFn(torch.autograd.Function):
         stat = torch.empty(2 * cin, dtype=torch.float32, device=dev)
         bn.num_batches_tracked.add_(1)
         momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked.item())
-        check(lib.dpk_bn2d_fold_train(ptr(sums), B * H * W, cin, ptr(gamma), ptr(beta), float(bn.eps), float(momentum),
+        n_elems = B * H * W
+        ctx.group, ctx.weight = getattr(bn, 'sync_group', None), 1.0
+        if ctx.group is not None:       # statistics of the whole sharded batch (deeprob.parallel.synchronize_batchnorm)
+            n_elems, ctx.weight = _sync_counts(ctx.group, B, H * W, sums)
+        check(lib.dpk_bn2d_fold_train(ptr(sums), n_elems, cin, ptr(gamma), ptr(beta), float(bn.eps), float(momentum),
                                       ptr(bn.running_mean), ptr(bn.running_var), ptr(pre), ptr(stat), st),
               'dpk_bn2d_fold_train')
         bias = None if bias is None else require_device_f32(bias, 'bias')
@@ -229,6 +269,8 @@ class BnConv2dFn(torch.autograd.Function):
         dgamma, dbeta, dstat = small[:cin], small[cin:2 * cin], small[2 * cin:]
         check(lib.dpk_bn2d_fold_backward(ptr(dab), cin, ptr(gamma), ptr(stat), ptr(dgamma), ptr(dbeta), ptr(dstat), st),
               'dpk_bn2d_fold_backward')
+        if ctx.group is not None:
+            dstat = _sync_stat_grads(ctx.group, ctx.weight, dstat)
         check(lib.dpk_channel_stats_backward(ptr(x), x.stride(0), B, cin, H, W, ptr(stat), ptr(dstat), ptr(dstat[cin:]),
                                              1, ptr(dx), st), 'dpk_channel_stats_backward')
         dw = dbias = None
@@ -277,9 +319,15 @@ def batchnorm_operand_map(bn, x: torch.Tensor) -> torch.Tensor:
     if bn.weight is None or bn.running_mean is None:
         raise HipError("conv2d: BatchNorm2d without affine parameters / running statistics is not built")
     if bn.training:
-        mean, var = ChannelStatsFn.apply(x)
+        group = getattr(bn, 'sync_group', None)
+        mean, var = ChannelStatsFn.apply(x, group)
         with torch.no_grad():
             n = x.shape[0] * x.shape[2] * x.shape[3]
+            if group is not None:
+                from deeprob import parallel
+                sizes = parallel.shard_sizes()
+                if sizes is not None and sizes[0] == x.shape[0]:
+                    n = sizes[1] * x.shape[2] * x.shape[3]
             bn.num_batches_tracked.add_(1)
             m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked.item())
             bn.running_mean.mul_(1.0 - m).add_(mean.detach(), alpha=m)
@@ -350,7 +398,7 @@ def bn2d(x: torch.Tensor, layer) -> Tuple[torch.Tensor, torch.Tensor]:
     """BatchNormLayer2d.apply_backward (flows/utils.py:186-208) with the statistics in the graph."""
     B, C, H, W = x.shape
     if layer.training:
-        mean, var = ChannelStatsFn.apply(x)
+        mean, var = ChannelStatsFn.apply(x, getattr(layer, 'sync_group', None))
         with torch.no_grad():
             layer.running_var.mul_(layer.momentum).add_(var.view_as(layer.running_var), alpha=1.0 - layer.momentum)
             layer.running_mean.mul_(layer.momentum).add_(mean.view_as(layer.running_mean), alpha=1.0 - layer.momentum)

@@ -20,6 +20,21 @@ def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+# The shard of the current training batch: (samples on this rank, samples of the whole batch).  Set by the training loop
+# (routines._batch) so that layers that need the size of the WHOLE batch on the host -- the synchronised 2-D batch norms:
+# their kernels take the element count as an argument -- do not have to read a collective's result back.
+_shard_sizes: Optional[Tuple[int, int]] = None
+
+
+def set_shard_sizes(local: Optional[int], total: Optional[int] = None):
+    global _shard_sizes
+    _shard_sizes = None if local is None else (int(local), int(total))
+
+
+def shard_sizes() -> Optional[Tuple[int, int]]:
+    return _shard_sizes
+
+
 def shard_batch(x: torch.Tensor, rank: Optional[int] = None, world: Optional[int] = None) -> torch.Tensor:
     """The slice of ``x`` this rank evaluates."""
     if world is None:
@@ -180,25 +195,21 @@ def bn_reduce_sums(sums: torch.Tensor, n_local: int, n_total: int, group=None) -
 
 
 def synchronize_batchnorm(model: torch.nn.Module, group=None, enabled: bool = True):
-    """Make every train-mode ``BatchNormLayer1d`` of ``model`` use the statistics of the whole (sharded) batch:
-    sets ``layer.sync_group`` (None switches it off).  ``train_model`` does this when it shards batches.
+    """Make every train-mode batch normalisation of ``model`` use the statistics of the whole (sharded) batch: sets
+    ``layer.sync_group`` (None switches it off) on ``BatchNormLayer1d`` and, since round 4, on ``BatchNormLayer2d`` and the
+    ``nn.BatchNorm2d`` inside the convolutional conditioners of a ``RealNVP2d``.  ``train_model`` does this when it shards
+    batches.
 
-    The 2-D layers (``BatchNormLayer2d`` and the ``nn.BatchNorm2d`` inside the convolutional conditioners of a
-    ``RealNVP2d``) are NOT synchronised: each rank normalises with the statistics of its own shard, as
-    ``DistributedDataParallel`` without ``SyncBatchNorm`` does, so sharded training of such a model differs from the
-    single-process run and the running statistics drift apart between ranks (rank 0's reach the checkpoint).  A
-    warning says so once per call."""
-    import warnings
+    2-D layers (deeprob/hip/ops_flows2d_train.py): the per-channel fp64 sums {sum x, sum x^2} of every rank meet in one
+    all-reduce per layer before the fold kernel (which then normalises with -- and updates the running statistics from --
+    the statistics of the whole batch, identically on every rank), and in the backward the gradients of the local loss
+    with respect to (mean, var) are all-reduced weighted by n_r / N before they flow into ``dx``.  With the
+    sample-weighted gradient all-reduce of ``allreduce_gradients`` the step then equals the single-process step on the
+    unsharded batch (tests/test_parallel_gpu.py)."""
     from deeprob.flows.utils import BatchNormLayer1d, BatchNormLayer2d
-    unsynced = 0
     for m in model.modules():
-        if isinstance(m, BatchNormLayer1d):
+        if isinstance(m, (BatchNormLayer1d, BatchNormLayer2d, torch.nn.BatchNorm2d)):
             m.sync_group = (group if group is not None else dist.group.WORLD) if enabled else None
-        elif isinstance(m, (BatchNormLayer2d, torch.nn.BatchNorm2d)):
-            unsynced += 1
-    if enabled and unsynced:
-        warnings.warn("synchronize_batchnorm: {} 2-D batch-norm layers keep per-rank statistics (sharded training of "
-                      "this model does not reproduce the single-process run)".format(unsynced), stacklevel=2)
 
 
 class local_batchnorm:

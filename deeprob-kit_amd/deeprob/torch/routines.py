@@ -141,6 +141,11 @@ def train_discriminative(
 
 def _batch(item, device, rank, world, supervised):
     """This rank's shard of a loader item, moved to the device."""
+    if world > 1:
+        from deeprob.parallel import set_shard_sizes, shard_bounds
+        n = (item[0] if supervised else item).shape[0]
+        lo, hi = shard_bounds(n, rank, world)
+        set_shard_sizes(hi - lo, n)
     if supervised:
         inputs, targets = item
         return (shard_batch(inputs.to(device, non_blocking=True), rank, world),

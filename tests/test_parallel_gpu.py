@@ -179,3 +179,47 @@ def test_sharded_training_step_with_batchnorm_equals_single_process(tmp_path):
     assert scale > 1e-3
     assert np.max(np.abs(r0 - r1)) <= 1e-6 * scale
     assert np.max(np.abs(r0 - ref)) <= 1e-4 * scale
+
+
+def _train2d_worker(rank, world, port, out_dir):
+    from tests import conftest  # noqa: F401  (sys.path)
+    from deeprob.flows.models import RealNVP2d
+    from deeprob.parallel import (shard_batch, shard_bounds, allreduce_gradients, broadcast_model, synchronize_batchnorm,
+                                  set_shard_sizes)
+    _init(rank, world, port)
+    torch.manual_seed(200)
+    model = RealNVP2d((2, 8, 8), n_flows=1, n_blocks=1, channels=8).cuda()
+    if world > 1:
+        broadcast_model(model)
+        synchronize_batchnorm(model)
+    model.train()
+    x = torch.randn(37, 2, 8, 8, generator=torch.Generator().manual_seed(10)) * 0.8 + 0.2
+    lo, hi = shard_bounds(37, rank, world)
+    if world > 1:
+        set_shard_sizes(hi - lo, 37)                  # (what routines._batch does for every training batch)
+    xs = shard_batch(x, rank, world).cuda()           # 19 + 18 images
+    model.zero_grad()
+    loss = model.loss(model(xs))
+    loss.backward()
+    if world > 1:
+        allreduce_gradients(model, weight=xs.shape[0])
+        set_shard_sizes(None)
+    vec = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.requires_grad and p.grad is not None] +
+                    [b.reshape(-1).float() for n, b in model.named_buffers() if 'running' in n]).double().cpu().numpy()
+    np.save(os.path.join(out_dir, 'tr2d_w{}_r{}.npy'.format(world, rank)), vec)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_sharded_training_step_of_an_image_flow_equals_single_process(tmp_path):
+    """Round 4: the 2-D batch norms (BatchNormLayer2d and the nn.BatchNorm2d of the convolutional conditioners) take the
+    statistics of the whole sharded batch too (deeprob.parallel.synchronize_batchnorm): gradients after the sample-weighted
+    all-reduce and the running statistics of a 2-rank step on 19 + 18 images equal the single-process step on the 37."""
+    _train2d_worker(0, 1, 0, str(tmp_path))
+    mp.start_processes(_train2d_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, start_method='spawn')
+    ref = np.load(tmp_path / 'tr2d_w1_r0.npy')
+    r0, r1 = np.load(tmp_path / 'tr2d_w2_r0.npy'), np.load(tmp_path / 'tr2d_w2_r1.npy')
+    scale = np.max(np.abs(ref))
+    assert scale > 1e-3 and ref.shape == r0.shape
+    assert np.max(np.abs(r0 - r1)) <= 1e-6 * scale
+    assert np.max(np.abs(r0 - ref)) <= 2e-4 * scale
