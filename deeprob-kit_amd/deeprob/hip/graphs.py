@@ -20,13 +20,20 @@ def _has_dropout(model: torch.nn.Module) -> bool:
 
 
 class GraphedTrainStep:
-    def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, warmup: int = 3):
+    """``grad_exchange(n_local)``: called between backward and the optimiser update, inside the captured region -- the
+    sharded step's gradient all-reduce (``deeprob.parallel.allreduce_gradients``: device operations and one RCCL
+    collective, which ProcessGroupNCCL records on the capturing stream).  Every rank captures its own shard shape; ranks
+    replay / run eagerly in lockstep because both forms issue the same collectives."""
+
+    def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, warmup: int = 3,
+                 grad_exchange: Optional[Callable[[int], None]] = None):
         if _has_dropout(model):
             raise NotImplementedError("hip_graph: training-mode dropout draws its seeds on the host every step")
         for group in optimizer.param_groups:
             if 'capturable' in group and not group['capturable']:
                 raise ValueError("hip_graph: build the optimizer with capturable=True")
         self.model, self.optimizer, self.warmup = model, optimizer, warmup
+        self.grad_exchange = grad_exchange
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.static_in: Optional[torch.Tensor] = None
         self.static_loss: Optional[torch.Tensor] = None
@@ -36,6 +43,8 @@ class GraphedTrainStep:
         self.optimizer.zero_grad(set_to_none=False)
         loss = self.model.loss(self.model(inputs))
         loss.backward()
+        if self.grad_exchange is not None:
+            self.grad_exchange(int(inputs.shape[0]))
         self.optimizer.step()
         self.model.apply_constraints()
         return loss

@@ -97,10 +97,11 @@ class ShardedLogLikelihood:
         from deeprob.spn.models.ratspn import RatSpn
         return isinstance(self.model, RatSpn)
 
-    def _local(self, x: torch.Tensor, kernel_events=None) -> torch.Tensor:
+    def _local(self, x: torch.Tensor, kernel_events=None, acc: Optional[torch.Tensor] = None) -> torch.Tensor:
         if self.local_sum_fn is not None:
             return self.local_sum_fn(x)
-        acc = self._acc_slot(x.device)
+        if acc is None:
+            acc = self._acc_slot(x.device)
         if kernel_events is not None:
             from deeprob.hip import load_library, check
             # (start, stop): raw hipEvent_t handles or torch.cuda.Event objects; either may be None (a run of
@@ -168,6 +169,44 @@ class ShardedLogLikelihood:
         self._pending = []
         means = (accs[:, 0] / accs[:, 1]).cpu().tolist()  # one device->host copy for the whole window
         return means
+
+
+class GraphedEvaluationWindow:
+    """A window of sharded evaluation steps -- the local evaluations of ``xs`` (resident inputs) AND the one all-reduce of
+    their ``{sum LL, count}`` pairs -- captured once as a HIP graph and replayed: ``replay()`` returns the mean
+    log-likelihood of every step of the window (identical on all ranks).  The RCCL collective is part of the graph
+    (ProcessGroupNCCL records it on the capturing stream), so a replay costs one graph launch whatever the number of steps.
+    Built from a ``ShardedLogLikelihood`` (its model, group and parameter mode); the evaluator itself stays usable.
+
+    ``always_reduce``: run the collective for a world of one too (exercises the captured RCCL path on a one-GPU box)."""
+
+    def __init__(self, evaluator: 'ShardedLogLikelihood', xs: List[torch.Tensor], always_reduce: bool = False):
+        if evaluator.local_sum_fn is not None:
+            raise ValueError("GraphedEvaluationWindow captures the HIP evaluation path, not a custom local_sum_fn")
+        self.evaluator, self.xs = evaluator, list(xs)
+        dev = self.xs[0].device
+        world = dist.get_world_size(evaluator.group) if evaluator.group is not None else 1
+        reduce = evaluator.group is not None and (world > 1 or always_reduce)
+        side = torch.cuda.Stream(device=dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.stream(side):
+            warm = torch.zeros(len(self.xs), 2, dtype=torch.float64, device=dev)
+            for i, x in enumerate(self.xs):          # eager pass: plans bound, tables built, RCCL communicator up
+                evaluator._local(x, acc=warm[i])
+            if reduce:
+                dist.all_reduce(warm, op=dist.ReduceOp.SUM, group=evaluator.group)
+            torch.cuda.synchronize(dev)
+            with torch.cuda.graph(self.graph, stream=side):
+                self.pool = torch.zeros(len(self.xs), 2, dtype=torch.float64, device=dev)
+                for i, x in enumerate(self.xs):
+                    evaluator._local(x, acc=self.pool[i])
+                if reduce:
+                    dist.all_reduce(self.pool, op=dist.ReduceOp.SUM, group=evaluator.group)
+        torch.cuda.synchronize(dev)
+
+    def replay(self) -> List[float]:
+        self.graph.replay()
+        return (self.pool[:, 0] / self.pool[:, 1]).cpu().tolist()
 
 
 def bn_gather_moments(moments: torch.Tensor, group=None) -> torch.Tensor:
@@ -266,7 +305,7 @@ def broadcast_seed(device, group=None, src: int = 0) -> int:
     return int(seed.item())
 
 
-def allreduce_gradients(model: torch.nn.Module, group=None, weight: Optional[float] = None):
+def allreduce_gradients(model: torch.nn.Module, group=None, weight: Optional[float] = None, force: bool = False):
     """Data-parallel gradient exchange in ONE collective: every ``.grad`` is packed into a flat fp32 bucket,
     all-reduced (sum) over RCCL/xGMI and unpacked.  The models of the path hold 50 KB .. 6 MB of parameters
     (SURVEY 8e), so a single bucket is both the latency- and the bandwidth-optimal choice on the 7-link xGMI mesh.
@@ -274,11 +313,12 @@ def allreduce_gradients(model: torch.nn.Module, group=None, weight: Optional[flo
     ``weight`` = number of samples behind this rank's (mean-reduced) loss: the result is then the gradient of the
     mean over the GLOBAL batch, sum_r n_r g_r / sum_r n_r, exactly what a single process would compute on the
     unsharded batch (a rank with an empty shard passes 0).  ``weight=None``: plain average over the ranks.
-    Parameters without a gradient on this rank contribute zeros."""
+    Parameters without a gradient on this rank contribute zeros.  No host read anywhere: the exchange can be captured in
+    a HIP graph with the step around it (``deeprob.hip.graphs.GraphedTrainStep(grad_exchange=...)``)."""
     if not (dist.is_available() and dist.is_initialized()):
         return
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:        # (force: run the collective for a world of one -- one-GPU rehearsals of the path)
         return
     params = [p for p in model.parameters() if p.requires_grad]
     if not params:

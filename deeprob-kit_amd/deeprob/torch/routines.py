@@ -61,7 +61,8 @@ def train_model(
     hip_graph: bool = False
 ) -> Dict[str, list]:
     """Reference signature (:21-37) + ``hip_graph``.  ``batch_size`` is the GLOBAL batch: with N ranks each one sees
-    batch_size/N samples per step.  ``hip_graph`` (generative setting, single process, no dropout): the optimisation
+    batch_size/N samples per step.  ``hip_graph`` (generative setting, no dropout; sharded runs capture their gradient
+    all-reduce and synchronised batch-norm exchanges with the step): the optimisation
     step of full batches is captured once as a HIP graph and replayed (``deeprob.hip.graphs.GraphedTrainStep``);
     Adam-family optimisers are built with ``capturable=True``.
     :raises ValueError: for an unknown setting or non-positive epochs."""
@@ -87,8 +88,8 @@ def train_model(
         # exclude `fused`.
         optimizer_kwargs.setdefault('fused', True)
     if hip_graph:
-        if setting != 'generative' or _world()[1] > 1:
-            raise ValueError("hip_graph covers the generative setting in a single process")
+        if setting != 'generative':
+            raise ValueError("hip_graph covers the generative setting")
         if 'capturable' in inspect.signature(get_optimizer_class(optimizer).__init__).parameters:
             optimizer_kwargs.setdefault('capturable', True)
         elif optimizer != 'sgd':   # (plain SGD keeps no step counter on the host: it captures as it is)
@@ -166,10 +167,13 @@ def _fit(model, train_loader, valid_loader, optimizer, device, early_stopping, e
         synchronize_batchnorm(model)
     graphed = None
     if hip_graph:
-        if supervised or world > 1:
-            raise ValueError("hip_graph covers the generative setting in a single process")
+        if supervised:
+            raise ValueError("hip_graph covers the generative setting")
         from deeprob.hip.graphs import GraphedTrainStep
-        graphed = GraphedTrainStep(model, optimizer)
+        # sharded: the gradient all-reduce (and the synchronised batch norms' exchanges inside the model) are captured
+        # with the step -- every rank captures its own shard shape, graph replays and eager steps issue the same collectives
+        graphed = GraphedTrainStep(model, optimizer,
+                                   grad_exchange=(lambda n: allreduce_gradients(model, weight=n)) if world > 1 else None)
     history = {'train': {'loss': [], 'accuracy': []}, 'valid': {'loss': [], 'accuracy': []}}
     meters = {k: RunningAverageMetric() for k in ('train_loss', 'train_hits', 'valid_loss', 'valid_hits')}
     for epoch in range(1, epochs + 1):
@@ -190,7 +194,7 @@ def _fit(model, train_loader, valid_loader, optimizer, device, early_stopping, e
             else:
                 inputs, targets = _batch(item, device, rank, world, supervised)
             n_local = inputs.shape[0]
-            if graphed is not None and n_local > 0:
+            if graphed is not None and n_local > 0 and not replicated:
                 meters['train_loss'](graphed(inputs), num_samples=n_local)
                 continue
             optimizer.zero_grad()
