@@ -233,8 +233,9 @@ def _time_eval_graph(model, xs, reps=4):
 
 def _time_train(model, x, steps=15, warm=3):
     import torch
+    from deeprob.torch.routines import build_optimizer
     model.train()
-    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, fused=True)  # (as train_model builds it)
+    opt = build_optimizer('adam', [p for p in model.parameters() if p.requires_grad], 1e-3, {'fused': True})  # (as train_model builds it)
 
     def step():
         opt.zero_grad()
@@ -260,9 +261,10 @@ def _time_train_graph(model, x, steps=30):
     """The same step replayed from a HIP graph (train_model(..., hip_graph=True)): None when it cannot be captured."""
     import torch
     from deeprob.hip.graphs import GraphedTrainStep
+    from deeprob.torch.routines import build_optimizer
     try:
         model.train()
-        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, capturable=True, fused=True)
+        opt = build_optimizer('adam', [p for p in model.parameters() if p.requires_grad], 1e-3, {'fused': True, 'capturable': True})
         gstep = GraphedTrainStep(model, opt)
         for _ in range(6):
             gstep(x)

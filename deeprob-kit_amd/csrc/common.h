@@ -162,6 +162,7 @@ static inline bool gemm_shape_ok(int D, int depth, int reps, int I, int S) {
 
 // geometry of the leaf-only MFMA kernel (ratspn_leaf_gemm.hip): column groups of NTG tiles, chunks of 32 features
 constexpr int kLeafGemmKS = 2;
+constexpr int kLeafPrepParts = 4;   // work-groups per region of the table kernel (the last one owns the constants)
 static inline int leaf_ntg(int I) { return I >= 4 ? 4 : I; }
 static inline bool leaf_gemm_shape_ok(int D, int R, int I, int d) {
     if (!(I == 2 || I == 4 || I == 8 || I == 16) || (D % 4) != 0 || R < 1 || d < 1) return false;
@@ -173,7 +174,7 @@ static inline int64_t leaf_gemm_ws_bytes(int D, int R, int I) {
     const int64_t tab = align_up((int64_t)NG * NKSP * (2 * NTG + 2) * 1024, 256);
     const int64_t bias = align_up((int64_t)NG * NCH * 2 * NTG * 16 * 4, 256);
     const int64_t brow = align_up((int64_t)NG * 2 * NTG * 16 * 4, 256);
-    return 2 * tab + bias + brow + align_up((int64_t)R * 4, 256) + align_up((int64_t)R * 8, 256);   // (+ per-region fingerprints)
+    return 2 * tab + bias + brow + align_up((int64_t)R * 4, 256) + align_up((int64_t)R * 8 * kLeafPrepParts, 256);   // (+ fingerprints)
 }
 
 // region-group size used by the per-layer leaf operators (the fused model uses 2^depth)

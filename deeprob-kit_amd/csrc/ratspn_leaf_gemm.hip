@@ -36,19 +36,24 @@ struct LeafPrepArgs {
     float *bias_row;         // [NG][2][NTG][16]
     int *elig;               // [R]
     int verify;                 // DPK_FLAG_PARAMS_VERIFY: a block rebuilds only if the bytes it depends on changed
-    unsigned long long *hash;   // [R] fingerprint of the bytes each region's tables were built from
+    unsigned long long *hash;   // [R][kLeafPrepParts] fingerprint of the bytes each region's tables were built from
 };
 
+// Grid (R, kLeafPrepParts): a region's tables are a latency chain (fingerprint -> variable positions -> fragments /
+// constants), 17 us on R = 32 work-groups when one work-group did all of it (round-4 trace of the training step, where every
+// launch rebuilds).  Parts 0 .. P-2 share the fragment stores, part P-1 owns the per-chunk constants; every part keeps its
+// own fingerprint word (a part that finished must not make its neighbours skip their share).
 __global__ __launch_bounds__(256) void ratspn_leaf_gemm_prep_kernel(const LeafPrepArgs a) {
     extern __shared__ int featpos[];                            // [D] position j of variable f in this region, -1 if absent
     float *locs = reinterpret_cast<float *>(featpos + a.D);     // [I][d]
     float *csum = locs + a.I * a.d;                             // [NCH][I]
     __shared__ int bad_s;
     __shared__ unsigned long long red_s[17];
-    const int r = blockIdx.x, D = a.D, d = a.d, I = a.I, NTG = a.NTG;
+    constexpr int P = kLeafPrepParts;
+    const int r = blockIdx.x, part = blockIdx.y, D = a.D, d = a.d, I = a.I, NTG = a.NTG;
     {
         // block-local cached-table check (see ratspn_gemm_prep_kernel): the region's slice of mask / pad_mask / loc / scale
-        const unsigned long long stored = a.verify ? a.hash[r] : 0ull;   // (requested first: back when the hash is)
+        const unsigned long long stored = a.verify ? a.hash[r * P + part] : 0ull;   // (requested first: back when the hash is)
         unsigned long long h = 0x9E3779B97F4A7C15ull + (unsigned long long)r;
         h += fp_range(a.mask + (int64_t)r * d, (int64_t)d * 8, 1);
         h += fp_range(a.pad ? a.pad + (int64_t)r * d : nullptr, (int64_t)d, 2);
@@ -57,7 +62,7 @@ __global__ __launch_bounds__(256) void ratspn_leaf_gemm_prep_kernel(const LeafPr
         h = block_sum_u64(h, red_s);
         if (a.verify && stored == h) return;
         __syncthreads();
-        if (threadIdx.x == 0) a.hash[r] = h;
+        if (threadIdx.x == 0) a.hash[r * P + part] = h;
     }
     for (int f = threadIdx.x; f < D; f += blockDim.x) featpos[f] = -1;
     if (threadIdx.x == 0) bad_s = 0;
@@ -75,50 +80,51 @@ __global__ __launch_bounds__(256) void ratspn_leaf_gemm_prep_kernel(const LeafPr
         locs[e] = mu;
         const int j = e % d;
         if (a.pad != nullptr && a.pad[(int64_t)r * d + j]) continue;
-        bad = bad || !(fabsf(mu) <= kExpandBound) || (a.scale[o] != 1.0f);
+        if (part == P - 1) bad = bad || !(fabsf(mu) <= kExpandBound) || (a.scale[o] != 1.0f);
     }
     if (bad) bad_s = 1;
     __syncthreads();
     const int tile_cols = 32 * NTG;
     const int64_t tile_halves = 2 * 512, ks_halves = (int64_t)(NTG + 1) * tile_halves;
-    // mean / constant fragments: (K-step, lane half, channel) -> 8 consecutive variables
-    for (int e = threadIdx.x; e < a.NKSP * 2 * I; e += blockDim.x) {
-        const int k = e % I, hg = (e / I) & 1, ks = e / (2 * I);
-        const int n = r * I + k, g = n / tile_cols, nl = n - g * tile_cols;
-        const int t = nl >> 5, idx = nl & 31, h = idx >> 4, u = idx & 15;
-        const int row = (u & 3) + 8 * (u >> 2) + 4 * h;
-        half8 mh, ml, ch, cl;
+    if (part < P - 1) {
+        const int tid = part * (int)blockDim.x + (int)threadIdx.x, nth = (P - 1) * (int)blockDim.x;
+        // mean / constant fragments: (K-step, lane half, channel) -> 8 consecutive variables
+        for (int e = tid; e < a.NKSP * 2 * I; e += nth) {
+            const int k = e % I, hg = (e / I) & 1, ks = e / (2 * I);
+            const int n = r * I + k, g = n / tile_cols, nl = n - g * tile_cols;
+            const int t = nl >> 5, idx = nl & 31, h = idx >> 4, u = idx & 15;
+            const int row = (u & 3) + 8 * (u >> 2) + 4 * h;
+            half8 mh, ml, ch, cl;
 #pragma unroll
-        for (int el = 0; el < 8; ++el) {
-            const int f = ks * 16 + hg * 8 + el;
-            float mu = 0.f, cc = 0.f;
-            if (f < D) {
-                const int j = featpos[f];
-                if (j >= 0) {
-                    mu = locs[k * d + j];
-                    cc = -fmaf(0.5f * mu, mu, kLogSqrt2Pi);
+            for (int el = 0; el < 8; ++el) {
+                const int f = ks * 16 + hg * 8 + el;
+                float mu = 0.f, cc = 0.f;
+                if (f < D) {
+                    const int j = featpos[f];
+                    if (j >= 0) {
+                        mu = locs[k * d + j];
+                        cc = -fmaf(0.5f * mu, mu, kLogSqrt2Pi);
+                    }
                 }
+                _Float16 hi, lo;
+                split_f16(mu, hi, lo);
+                mh[el] = hi; ml[el] = lo;
+                split_f16(cc, hi, lo);
+                ch[el] = hi; cl[el] = lo;
             }
-            _Float16 hi, lo;
-            split_f16(mu, hi, lo);
-            mh[el] = hi; ml[el] = lo;
-            split_f16(cc, hi, lo);
-            ch[el] = hi; cl[el] = lo;
+            const int64_t o = ((int64_t)g * a.NKSP + ks) * ks_halves + t * tile_halves + (hg * 32 + row) * 8;
+            *reinterpret_cast<half8 *>(a.mtab + o) = mh;
+            *reinterpret_cast<half8 *>(a.mtab + o + 512) = ml;
+            *reinterpret_cast<half8 *>(a.ctab + o) = ch;
+            *reinterpret_cast<half8 *>(a.ctab + o + 512) = cl;
         }
-        const int64_t o = ((int64_t)g * a.NKSP + ks) * ks_halves + t * tile_halves + (hg * 32 + row) * 8;
-        *reinterpret_cast<half8 *>(a.mtab + o) = mh;
-        *reinterpret_cast<half8 *>(a.mtab + o + 512) = ml;
-        *reinterpret_cast<half8 *>(a.ctab + o) = ch;
-        *reinterpret_cast<half8 *>(a.ctab + o + 512) = cl;
-    }
-    // the region's row of the indicator tile (tile NTG of its group): lane half h owns the regions whose columns it
-    // holds, in the order it meets them
-    {
+        // the region's row of the indicator tile (tile NTG of its group): lane half h owns the regions whose columns it
+        // holds, in the order it meets them
         const int g = (r * I) / tile_cols, nl = r * I - g * tile_cols;
         const int t = nl >> 5, h = (nl & 31) >> 4, j = (nl & 15) / I;
         const int up = t * (16 / I) + j;
         const int row = (up & 3) + 8 * (up >> 2) + 4 * h;
-        for (int e = threadIdx.x; e < a.NKSP * 2; e += blockDim.x) {
+        for (int e = tid; e < a.NKSP * 2; e += nth) {
             const int hg = e & 1, ks = e >> 1;
             half8 ind;
 #pragma unroll
@@ -129,24 +135,34 @@ __global__ __launch_bounds__(256) void ratspn_leaf_gemm_prep_kernel(const LeafPr
             const int64_t o = ((int64_t)g * a.NKSP + ks) * ks_halves + NTG * tile_halves + (hg * 32 + row) * 8;
             *reinterpret_cast<half8 *>(a.mtab + o) = ind;   // (the lo half of this tile stays zero: memset by the host)
         }
+        return;
     }
-    // per-(chunk, channel) constants and their sum, fixed summation order (launches must agree bit for bit)
+    // per-(chunk, channel) constants and their sum, fixed summation order (launches must agree bit for bit): 16 lanes
+    // per constant, lane l takes variables l, l + 16, .. of the chunk, then a butterfly over the 16 lanes
     const int KC = 16 * a.KS, NCH = (D + KC - 1) / KC;
-    for (int e = threadIdx.x; e < NCH * I; e += blockDim.x) {
-        const int k = e % I, c = e / I;
+    const int sub = threadIdx.x & 15;
+    for (int e0 = 0; e0 < NCH * I; e0 += (int)blockDim.x / 16) {
+        const int e = e0 + ((int)threadIdx.x >> 4);
+        const bool live = e < NCH * I;
+        const int k = live ? e % I : 0, c = live ? e / I : 0;
         float sum = 0.f;
         const int f1 = min(D, (c + 1) * KC);
-        for (int f = c * KC; f < f1; ++f) {
-            const int j = featpos[f];
-            if (j >= 0) {
-                const float mu = locs[k * d + j];
-                sum -= fmaf(0.5f * mu, mu, kLogSqrt2Pi);
+        if (live)
+            for (int f = c * KC + sub; f < f1; f += 16) {
+                const int j = featpos[f];
+                if (j >= 0) {
+                    const float mu = locs[k * d + j];
+                    sum -= fmaf(0.5f * mu, mu, kLogSqrt2Pi);
+                }
             }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (live && sub == 0) {
+            const int n = r * I + k, g = n / tile_cols, nl = n - g * tile_cols;
+            const int t = nl >> 5, idx = nl & 31, h = idx >> 4, u = idx & 15;
+            a.bias[((((int64_t)g * NCH + c) * 2 + h) * NTG + t) * 16 + u] = sum;
+            csum[e] = sum;
         }
-        const int n = r * I + k, g = n / tile_cols, nl = n - g * tile_cols;
-        const int t = nl >> 5, idx = nl & 31, h = idx >> 4, u = idx & 15;
-        a.bias[((((int64_t)g * NCH + c) * 2 + h) * NTG + t) * 16 + u] = sum;
-        csum[e] = sum;
     }
     __syncthreads();
     if ((int)threadIdx.x < I) {
@@ -462,7 +478,7 @@ int ratspn_leaf_gemm_forward(void *ws, const float *x, int64_t B, int D, const i
         pa.mtab = mtab; pa.ctab = ctab; pa.bias = biasC; pa.bias_row = biasT; pa.elig = elig;
         const size_t lds = ((size_t)D + (size_t)I * d + (size_t)NCH * I) * 4;
         DPK_REQUIRE(lds <= 60 * 1024, DPK_EUNSUPPORTED, "leaf_gemm: in_features=%d too large for the table kernel", D);
-        DPK_LAUNCH(ratspn_leaf_gemm_prep_kernel, dim3(R), dim3(256), lds, st, pa);
+        DPK_LAUNCH(ratspn_leaf_gemm_prep_kernel, dim3(R, kLeafPrepParts), dim3(256), lds, st, pa);
         DPK_CHECK_LAUNCH("ratspn_leaf_gemm_prep_kernel");
     }
     LeafGemmArgs a{};

@@ -476,6 +476,21 @@ int dpk_profile_next_kernel(void *ev_start, void *ev_stop);
 #define DPK_KERNEL_SPATIAL_SUMPRODROOT 5 /* dpk_spatial_sumprodroot_forward                      */
 int dpk_profile_next_kernel_of(void *ev_start, void *ev_stop, int32_t kernel_id);
 
+/* torch.optim.Adam's update (the optimiser the reference's training loops build by name: torch/utils.py:32-49, stepped at
+ * torch/routines.py:164 / :280) for up to 96 parameter tensors in ONE launch: m = m + (g - m)(1 - b1),
+ * v = b2 v + (1 - b2) g^2, p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps), fp32, non-amsgrad; weight_decay
+ * is the L2 form (added to the gradient), maximize negates the gradient.  `step` [1] fp32 holds the number of updates
+ * done (read by every work-group, incremented by the last to finish: the launch is HIP-graph capturable), `ticket` [1]
+ * a zeroed word the library uses for that hand-over.  The tensor table is host memory, copied into the kernel arguments. */
+typedef struct {
+    float *param;
+    const float *grad;
+    float *exp_avg, *exp_avg_sq;
+    int64_t numel;
+} dpk_adam_tensor;
+int dpk_adam_step(int32_t n, const dpk_adam_tensor *tensors, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int32_t maximize, float *step, uint32_t *ticket, void *stream);
+
 /* sum and count of a vector of log-likelihoods in fp64 (the per-rank partial of
  * the mean-LL all-reduce): acc[0] += sum(ll), acc[1] += n.                   */
 int dpk_ll_accumulate(const float *ll, int64_t n, double *acc, void *stream);

@@ -130,3 +130,43 @@ def test_train_model_every_reference_optimizer(tmp_path, optimizer, kwargs):
     hist = train_model(model, data[:200], data[200:], lr=1e-2, batch_size=50, epochs=2, patience=2, optimizer=optimizer,
                        optimizer_kwargs=kwargs, checkpoint=str(tmp_path / 'o.pt'), verbose=False)
     assert len(hist['train']) == 2 and np.isfinite(hist['train']).all() and np.isfinite(hist['valid']).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kwargs', [{}, {'weight_decay': 0.01, 'betas': (0.8, 0.99)}, {'maximize': True, 'eps': 1e-6}])
+def test_fused_adam_follows_torch_adam(kwargs):
+    """deeprob.hip.optim.FusedAdam (one launch for all tensors, device-side step count) against torch.optim.Adam on the
+    same gradients over 25 steps, ragged tensor sizes included (1 element, 2047, 2048, 2049, 70 001); fp32 round-off
+    only.  reference: the optimiser of torch/routines.py:164."""
+    from deeprob.hip.optim import FusedAdam
+    torch.manual_seed(3)
+    sizes = [(1,), (2047,), (2048,), (2049,), (7, 10001), (3, 5, 11)]
+    ours = [torch.nn.Parameter(torch.randn(s, device='cuda')) for s in sizes]
+    theirs = [torch.nn.Parameter(p.detach().clone()) for p in ours]
+    a, b = FusedAdam(ours, lr=3e-3, **kwargs), torch.optim.Adam(theirs, lr=3e-3, **kwargs)
+    for it in range(25):
+        for p, q in zip(ours, theirs):
+            g = torch.randn_like(p) * (1.0 + it % 3)
+            p.grad, q.grad = g.clone(), g.clone()
+        a.step(), b.step()
+    for p, q in zip(ours, theirs):
+        assert torch.allclose(p, q, rtol=2e-6, atol=2e-6), float((p - q).abs().max())
+    assert float(a.state[ours[0]]['step']) == 25.0
+    # a tensor without a gradient is skipped, like torch does
+    ours[1].grad = None
+    before = ours[1].detach().clone()
+    a.step()
+    assert torch.equal(ours[1], before)
+
+
+@pytest.mark.gpu
+def test_build_optimizer_choices():
+    from deeprob.torch.routines import build_optimizer
+    from deeprob.hip.optim import FusedAdam
+    ps = [torch.nn.Parameter(torch.randn(5, device='cuda'))]
+    assert isinstance(build_optimizer('adam', ps, 1e-3, {'fused': True}), FusedAdam)
+    assert type(build_optimizer('adam', ps, 1e-3, {'fused': False})) is torch.optim.Adam
+    assert type(build_optimizer('adam', ps, 1e-3, {'fused': True, 'amsgrad': True})) is torch.optim.Adam
+    assert type(build_optimizer('adam', ps * 1 + [torch.nn.Parameter(torch.randn(2, device='cuda')) for _ in range(100)],
+                                1e-3, {'fused': True})) is torch.optim.Adam
+    assert type(build_optimizer('sgd', ps, 1e-3, {'fused': True})) is torch.optim.SGD

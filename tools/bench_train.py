@@ -5,6 +5,7 @@ sys.path[:0] = [os.path.join(ROOT, 'deeprob-kit_amd'), ROOT]
 import torch
 from deeprob.spn.models import GaussianRatSpn, DgcSpn
 from deeprob.flows.models import RealNVP1d
+from deeprob.torch.routines import build_optimizer
 
 which = sys.argv[1] if len(sys.argv) > 1 else 'ratspn'
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
@@ -24,7 +25,8 @@ else:
     x = torch.randn(B, 784)
 model = model.cuda().train()
 x = x.cuda()
-opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+opt = (torch.optim.Adam(model.parameters(), lr=1e-3, fused=True) if os.environ.get('DPK_TORCH_ADAM') else
+       build_optimizer('adam', list(model.parameters()), 1e-3, {'fused': True}))
 
 
 def step():

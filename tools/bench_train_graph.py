@@ -6,6 +6,7 @@ sys.path[:0] = [os.path.join(ROOT, 'deeprob-kit_amd'), ROOT]
 import torch
 from deeprob.spn.models import GaussianRatSpn, DgcSpn
 from deeprob.flows.models import RealNVP1d
+from deeprob.torch.routines import build_optimizer
 
 which = sys.argv[1] if len(sys.argv) > 1 else 'realnvp'
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
@@ -20,7 +21,8 @@ else:
     model, x = RealNVP1d(784), torch.randn(B, 784)
 model = model.cuda().train()
 static_x = x.cuda()
-opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True, fused=True)
+opt = (torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True, fused=True) if os.environ.get('DPK_TORCH_ADAM') else
+       build_optimizer('adam', list(model.parameters()), 1e-3, {'fused': True, 'capturable': True}))
 
 
 def step():
