@@ -161,6 +161,9 @@ static inline bool gemm_shape_ok(int D, int depth, int reps, int I, int S) {
 }
 
 // geometry of the leaf-only MFMA kernel (ratspn_leaf_gemm.hip): column groups of NTG tiles, chunks of 32 features
+// training forward of the fused MFMA route (dpk_ratspn_forward_train): see GemmArgs::emit_* in ratspn_gemm_fused.h
+struct GemmEmit { float *leaf, *sum, *out; };
+
 constexpr int kLeafGemmKS = 2;
 constexpr int kLeafPrepParts = 4;   // work-groups per region of the table kernel (the last one owns the constants)
 static inline int leaf_ntg(int I) { return I >= 4 ? 4 : I; }

@@ -37,21 +37,29 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamArgs a) {
     while (t + 1 < a.n && blk >= a.first_block[t + 1]) ++t;
     const int e0 = (blk - a.first_block[t]) * kAdamChunk;
     const int n = a.numel[t];
+    float *p = a.p[t], *m = a.m[t], *v = a.v[t];
+    const float *g = a.g[t];
+    constexpr int K = kAdamChunk / 256;
+    // all of the chunk's reads in flight before anything waits on the step count
+    float gr[K], pr[K], mr[K], vr[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int e = e0 + k * 256 + (int)threadIdx.x;
+        const bool in = e < n;
+        gr[k] = in ? g[e] : 0.f; pr[k] = in ? p[e] : 0.f; mr[k] = in ? m[e] : 0.f; vr[k] = in ? v[e] : 0.f;
+    }
     const float tstep = *a.step + 1.0f;
     const float bc1 = 1.0f - powf(a.b1, tstep), bc2 = 1.0f - powf(a.b2, tstep);
     const float step_size = a.lr / bc1, bc2_sqrt = sqrtf(bc2);
-    float *p = a.p[t], *m = a.m[t], *v = a.v[t];
-    const float *g = a.g[t];
 #pragma unroll
-    for (int k = 0; k < kAdamChunk / 256; ++k) {
+    for (int k = 0; k < K; ++k) {
         const int e = e0 + k * 256 + (int)threadIdx.x;
         if (e < n) {
-            float grad = a.maximize ? -g[e] : g[e];
-            const float param = p[e];
+            float grad = a.maximize ? -gr[k] : gr[k];
+            const float param = pr[k];
             if (a.weight_decay != 0.f) grad = fmaf(param, a.weight_decay, grad);
-            const float mo = m[e], vo = v[e];
-            const float mn = mo + (grad - mo) * (1.0f - a.b1);
-            const float vn = a.b2 * vo + (1.0f - a.b2) * grad * grad;
+            const float mn = mr[k] + (grad - mr[k]) * (1.0f - a.b1);
+            const float vn = a.b2 * vr[k] + (1.0f - a.b2) * grad * grad;
             m[e] = mn;
             v[e] = vn;
             const float denom = sqrtf(vn) / bc2_sqrt + a.eps;

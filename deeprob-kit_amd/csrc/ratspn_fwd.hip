@@ -1580,7 +1580,8 @@ static int fused_dispatch_i(const LeafArgs &a, int S, hipStream_t st) {
 // ratspn_gemm.hip: fused forward with the leaf layer on the matrix cores
 int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const int64_t *mask, const uint8_t *pad,
                         const float *loc, const float *scale, const float *sum_weight0, const float *root_weight,
-                        int reps, int I, int S, int C, float *out, double *ll_sum, uint32_t flags, hipStream_t st);
+                        int reps, int I, int S, int C, float *out, double *ll_sum, uint32_t flags, hipStream_t st,
+                        const GemmEmit *emit = nullptr);
 
 bool gemm_wide_shape_ok(int D, int reps, int I, int S, int C);   // ratspn_gemm_wide.hip
 
@@ -1635,6 +1636,37 @@ extern "C" int dpk_bernoulli_leaf_forward(const float *x, int64_t B, int32_t D, 
                                           uint32_t flags, void *stream) {
     return leaf_forward_common(1, x, B, D, mask, pad_mask, logits, nullptr, R, I, d, out, ws, ws_bytes,
                                flags, stream);
+}
+
+extern "C" int dpk_ratspn_forward_train(const float *x, int64_t B, int32_t D, const int64_t *mask, const uint8_t *pad_mask,
+                                        const float *loc, const float *scale, const float *sum_weight0,
+                                        const float *root_weight, int32_t depth, int32_t reps, int32_t I, int32_t S,
+                                        int32_t C, float *out, float *leaf_rel, float *sum_rel, float *out_rel, void *ws,
+                                        int64_t ws_bytes, uint32_t flags, void *stream) {
+    DPK_REQUIRE(B >= 0 && D > 0 && reps > 0 && I > 0 && S > 0 && C > 0, DPK_EINVAL, "ratspn_forward_train: bad sizes");
+    DPK_REQUIRE(mask && loc && scale && sum_weight0 && root_weight && ws, DPK_EINVAL, "ratspn_forward_train: null pointer");
+    DPK_REQUIRE(B == 0 || (x && out && leaf_rel && sum_rel && out_rel), DPK_EINVAL, "ratspn_forward_train: null pointer");
+    if (depth != 2 || !gemm_route(x, D, depth, reps, I, S, C, false, flags)) {
+        set_error("ratspn_forward_train: outside the fused MFMA route (depth 2, unit scales, 16-byte aligned rows)");
+        return DPK_EUNSUPPORTED;
+    }
+    const int Q = 4, R = reps * Q;
+    const int pad = (Q - D % Q) % Q, d = (D + pad) / Q;
+    DPK_REQUIRE(pad == 0 || pad_mask, DPK_EINVAL, "ratspn_forward_train: padded model needs pad_mask");
+    RatWs w = carve_ratspn_ws(ws, D, R, d, I, Q, depth, reps, S, C);
+    DPK_REQUIRE(ws_bytes >= w.bytes, DPK_EWORKSPACE, "ratspn_forward_train: workspace %lld < %lld", (long long)ws_bytes,
+                (long long)w.bytes);
+    if (w.g_nt <= 0) {
+        set_error("ratspn_forward_train: shape outside the MFMA tables");
+        return DPK_EUNSUPPORTED;
+    }
+    if (B == 0) return DPK_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = prepare_leaf_structure(w, mask, pad_mask, R, d, flags, st);
+    if (rc) return rc;
+    const GemmEmit emit{leaf_rel, sum_rel, out_rel};
+    return ratspn_gemm_forward(w, x, B, D, mask, pad_mask, loc, scale, sum_weight0, root_weight, reps, I, S, C, out, nullptr,
+                               flags, st, &emit);
 }
 
 extern "C" int dpk_ratspn_forward(const float *x, int64_t B, int32_t D, const int64_t *mask,

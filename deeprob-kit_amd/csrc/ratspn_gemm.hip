@@ -361,13 +361,14 @@ bool gemm_marginal_shape_ok(int D, int NT);
 // ratspn_gemm_wide.hip: 8-channel models, a wave per repetition
 bool gemm_wide_shape_ok(int D, int reps, int I, int S, int C);
 int ratspn_gemm_wide_forward(const GemmArgs &a, const GemmPrepArgs &p, int S, hipStream_t st);
-bool gemm_wide_takes_tile32(int64_t B, int D, int reps, int C, bool marginal);
+bool gemm_wide_takes_tile32(int64_t B, int D, int reps, int C, bool marginal, bool emit);
 int ratspn_gemm_marginal_forward(const GemmArgs &a, int reps, int I, int S, int NT, hipStream_t st);
 
 // The caller (dpk_ratspn_forward) has validated the arguments and carved the workspace.
 int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const int64_t *mask, const uint8_t *pad,
                         const float *loc, const float *scale, const float *sum_weight0, const float *root_weight,
-                        int reps, int I, int S, int C, float *out, double *ll_sum, uint32_t flags, hipStream_t st) {
+                        int reps, int I, int S, int C, float *out, double *ll_sum, uint32_t flags, hipStream_t st,
+                        const GemmEmit *emit) {
     const int d = (D + (4 - D % 4) % 4) / 4;
     const int NT = w.g_nt;
     int *slow_word = nullptr;
@@ -384,6 +385,11 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
     // (ratspn_gemm_nan.hip); otherwise the ring kernel below.
     const bool wide = I == 8;
     const bool small = !wide && B <= gemm_small_max_batch() && gemm_small_shape_ok(D, NT);
+    const bool emitting = emit != nullptr;
+    if (emitting && !wide) {   // (training forward: the 8-channel 32-sample kernel so far)
+        set_error("ratspn_forward_train: channels=%d at %lld samples not built", I, (long long)B);
+        return DPK_EUNSUPPORTED;
+    }
     // The tables.  "Believed current -- check" (DPK_FLAG_PARAMS_VERIFY) costs the 32-sample mappings nothing extra: their
     // launch carries the table work-groups itself (kPrepInline, ratspn_gemm_prep.h).  The ring kernels keep the
     // stand-alone check launch in front of them (DPK_VERIFY_INLINE=0 forces it everywhere: A/B measurements).
@@ -409,7 +415,7 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
     static const bool ring_vi = [] { const char *e = getenv("DPK_RING_VI"); return e && atoi(e) != 0; }();
     const bool ring_inline = ring_vi && ring_plain && (int64_t)np <= std::min<int64_t>(cdiv(B, kGemmTile), device_cus());
     const bool verify_inline = inline_allowed && (flags & DPK_FLAG_PARAMS_VERIFY) && !(flags & DPK_FLAG_PARAMS_CACHED) &&
-                               ((wide && gemm_wide_takes_tile32(B, D, reps, C, marginal)) || small || ring_inline);
+                               ((wide && gemm_wide_takes_tile32(B, D, reps, C, marginal, emitting)) || small || ring_inline);
     if (verify_inline) {
         p.mode = kPrepInline;
         p.np = np;
@@ -434,6 +440,7 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
         a.slow_flag = slow_word; a.launch_seq = launch_seq; a.marginal = marginal ? 1 : 0;
         a.ablate = ablate;
         a.upfrag = p.upfrag;
+        if (emitting) { a.emit_leaf = emit->leaf; a.emit_sum = emit->sum; a.emit_out = emit->out; }
         if (wide) return ratspn_gemm_wide_forward(a, p, S, st);
         if (small) return ratspn_gemm_small_forward(a, p, reps, I, S, NT, st);
         return ratspn_gemm_marginal_forward(a, reps, I, S, NT, st);

@@ -40,6 +40,13 @@ struct GemmArgs {
     int launch_seq;
     int marginal;     // host: a launch within the last 256 met NaN evidence (selects the variant built for it)
     const uint16_t *upfrag;   // 8-channel kernels: MFMA fragments of the first sum layer (ratspn_gemm_prep.h)
+    // Training forward (dpk_ratspn_forward_train, EMIT instantiations of the 32-sample kernels): what the layers' backward
+    // kernels read, written on the way up.  All three are RELATIVE to the sample's common quadratic term: the GEMM form
+    // carries -1/2 sum x^2 to the root instead of through the regions, and the backward of a sum / root layer only ever
+    // sees in - out (ratspn_layers.hip sum_bwd_kernel), so the shift cancels level by level.
+    float *emit_leaf;   // [B, R, I]        leaf layer outputs (+ 1/2 sum x^2 over the region's variables)
+    float *emit_sum;    // [B, 2 reps, S]   first sum layer outputs (+ 1/2 sum x^2 over the partition's variables)
+    float *emit_out;    // [B, C]           root outputs (+ 1/2 sum x^2 over all variables)
 };
 
 __device__ __forceinline__ void lse_merge(float &m, float &s, float m2, float s2) {

@@ -127,7 +127,7 @@ __device__ __forceinline__ void wide_upfrag_store(uint16_t *frag, int S, int row
 constexpr int kGemmPrepScratchInts = 64;   // reduction / verdict scratch in front of the tables' staging area
 __host__ __device__ inline size_t gemm_prep_lds_bytes(int D, int I, int d) {
     return ((size_t)kGemmPrepScratchInts + (size_t)D + (size_t)4 * I * d + (size_t)cdiv(D, 32) * 4 * I +
-            (size_t)cdiv(D, 16) * 4 * I) * 4;
+            (size_t)cdiv(D, 16) * 4 * I + (size_t)d) * 4;   // (+ 4 d padding flags, one byte each)
 }
 
 // This thread's share (tid of nthreads) of the fingerprint of table work-group blk's inputs; the work-group's fingerprint is
@@ -166,11 +166,17 @@ __device__ __forceinline__ unsigned long long gemm_prep_hash_share(const GemmPre
     return h;
 }
 
+// Round 4 (training forward: every launch rebuilds): every global read of the work-group's inputs is requested up front and
+// used twice -- for the fingerprint and for the tables -- and the per-K-step / per-chunk constant sums read LDS sixteen
+// variables at a time.  The first form (fingerprint passes, then `if (pad[o]) continue; .. scale[o]` per element, then
+// serial 16- and 32-term LDS chains per constant) was ~60 dependent round trips: 46 us for the (8,8) model's 8 repetitions.
+// Same fingerprint values (gemm_prep_hash_share) and the same summation orders as before: tables bit for bit.
 template <int I>
 __device__ __forceinline__ void gemm_prep_block(const GemmPrepArgs &a, int blk, int *dyn) {
     constexpr int RPT = 8 / I;       // repetitions per 32-column tile (4 regions x I channels each)
     const int nrb = a.NT * RPT;
-    const int rpb = (int)blockDim.x >> 6;   // softmax rows per work-group
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int rpb = nth >> 6;        // softmax rows per work-group
     // (no static LDS: the model kernels that carry these work-groups ask for the whole 160 KB as dynamic LDS)
     unsigned long long *red_s = reinterpret_cast<unsigned long long *>(dyn);   // [17]
     unsigned *vi_s = reinterpret_cast<unsigned *>(dyn) + 34;                    // [2]
@@ -181,88 +187,180 @@ __device__ __forceinline__ void gemm_prep_block(const GemmPrepArgs &a, int blk, 
     const bool real = !rows_blk && rho < a.reps;
     const int D = a.D, d = a.d;
 
-    // ---- fingerprint of the bytes this work-group's outputs depend on ------------------------------------------------
-    // (block local: a repetition's tables depend on its own slice of mask / pad_mask / loc / scale only; a write through
-    // `param.data` moves no version counter on the host)
-    unsigned long long h = threadIdx.x == 0 ? kPrepHashBase + (unsigned long long)blk : 0ull;   // (once per work-group)
-    {
-        const unsigned long long stored_early = a.mode != kPrepBuild ? a.hash[blk] : 0ull;   // (requested first)
-        h += gemm_prep_hash_share<I>(a, blk, (int)threadIdx.x, (int)blockDim.x);
-        h = block_sum_u64(h, red_s);
+    // fingerprint of the bytes this work-group's outputs depend on (block local: a repetition's tables depend on its own
+    // slice of mask / pad_mask / loc / scale only; a write through `param.data` moves no version counter on the host,
+    // DESIGN 3.9) -> does this work-group rebuild?
+    const unsigned long long stored_early = a.mode != kPrepBuild ? a.hash[blk] : 0ull;   // (requested first)
+    unsigned long long h = tid == 0 ? kPrepHashBase + (unsigned long long)blk : 0ull;    // (once per work-group)
+    auto decide = [&](unsigned long long share) -> bool {
+        const unsigned long long hb = block_sum_u64(share, red_s);
         if (a.mode == kPrepVerify) {
-            if (stored_early == h) return;                    // nothing this work-group's outputs depend on has changed
+            if (stored_early == hb) return false;             // nothing this work-group's outputs depend on has changed
         } else if (a.mode == kPrepInline) {
-            if (threadIdx.x == 0) {
-                vi_arrive(a.ctl, stored_early != h);
+            if (tid == 0) {
+                vi_arrive(a.ctl, stored_early != hb);
                 unsigned ticket;
                 const bool dirty = vi_wait(a.ctl, a.np, ticket);
                 vi_done(a.ctl, ticket, a.readers);
                 vi_s[0] = dirty ? 1u : 0u;
             }
             __syncthreads();
-            if (vi_s[0] == 0u) return;                        // clean launch: nothing to do
+            if (vi_s[0] == 0u) return false;                  // clean launch: nothing to do
         }
         __syncthreads();
-        if (threadIdx.x == 0) a.hash[blk] = h;
-    }
+        if (tid == 0) a.hash[blk] = hb;
+        return true;
+    };
 
     if (rows_blk) {
-        int row = (blk - nrb) * rpb + (threadIdx.x >> 6);
-        const int lane = threadIdx.x & 63;
+        // a wave per softmax row (torch.log_softmax at ratspn.py:375 and :455); rows of up to 512 weights live in registers
+        const int lane = tid & 63;
+        const int grow = (blk - nrb) * rpb + (tid >> 6);      // row number over the (up to three) weight matrices
+        int row = grow, m = 0;
+        bool has = false;
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            if (row < a.rows[m]) {
-                const int n = a.n[m];
-                const float *src = a.w[m] + (int64_t)row * n;
-                float mx = -INFINITY;
-                for (int i = lane; i < n; i += 64) mx = fmaxf(mx, src[i]);
-                mx = wave_reduce_max(mx);
-                float sum = 0.f;
-                for (int i = lane; i < n; i += 64) sum += expf(src[i] - mx);
-                sum = wave_reduce_sum(sum);
-                const float ls = logf(sum);
-                for (int i = lane; i < n; i += 64) {
-                    const float l = src[i] - mx - ls;
-                    const float wl = expf(l);
-                    a.LW[m][(int64_t)row * n + i] = l;
-                    a.W[m][(int64_t)row * n + i] = wl;
-                    if (m == 0 && a.upfrag != nullptr) wide_upfrag_store(a.upfrag, a.up_S, row, i, wl);
-                }
-                return;
+        for (int mm = 0; mm < 3; ++mm) {
+            if (!has) {
+                if (row < a.rows[mm]) { has = true; m = mm; }
+                else row -= a.rows[mm];
             }
-            row -= a.rows[m];
+        }
+        constexpr int RV = 8;
+        const int n = has ? a.n[m] : 0;
+        const float *src = has ? a.w[m] + (int64_t)row * n : nullptr;
+        const bool fits = n <= 64 * RV;
+        const unsigned tag = 5u + 8192u * (unsigned)grow;     // (position-dependent through the row number)
+        float v[RV];
+        if (has && fits) {
+#pragma unroll
+            for (int k = 0; k < RV; ++k) v[k] = (lane + 64 * k < n) ? src[lane + 64 * k] : -INFINITY;
+#pragma unroll
+            for (int k = 0; k < RV; ++k)
+                if (lane + 64 * k < n) h += fp_word(__float_as_uint(v[k]), (unsigned)(lane + 64 * k) * 8u + tag);
+        } else if (has) {
+            h += fp_range_n(src, (int64_t)n * 4, tag, lane, 64);
+        }
+        if (!decide(h)) return;
+        if (!has) return;
+        float mx = -INFINITY, sum = 0.f;
+        if (fits) {
+#pragma unroll
+            for (int k = 0; k < RV; ++k) mx = fmaxf(mx, v[k]);
+            mx = wave_reduce_max(mx);
+#pragma unroll
+            for (int k = 0; k < RV; ++k)
+                if (lane + 64 * k < n) sum += expf(v[k] - mx);
+        } else {
+            for (int i = lane; i < n; i += 64) mx = fmaxf(mx, src[i]);
+            mx = wave_reduce_max(mx);
+            for (int i = lane; i < n; i += 64) sum += expf(src[i] - mx);
+        }
+        sum = wave_reduce_sum(sum);
+        const float ls = logf(sum);
+        auto put = [&](int i, float sv) {
+            const float l = sv - mx - ls;
+            const float wl = expf(l);
+            a.LW[m][(int64_t)row * n + i] = l;
+            a.W[m][(int64_t)row * n + i] = wl;
+            if (m == 0 && a.upfrag != nullptr) wide_upfrag_store(a.upfrag, a.up_S, row, i, wl);
+        };
+        if (fits) {
+#pragma unroll
+            for (int k = 0; k < RV; ++k)
+                if (lane + 64 * k < n) put(lane + 64 * k, v[k]);
+        } else {
+            for (int i = lane; i < n; i += 64) put(i, src[i]);
         }
         return;
     }
 
-    int *posrow = dyn;               // [D] position q*d + j of variable f in this repetition, -1 if absent
+    // ---- a repetition's fragments, constants and eligibility flag -----------------------------------------------------
+    constexpr int PSH = 20;           // posrow: (region of the repetition << 20) | position in the region
+    const int KC = 16 * a.KS;
+    const int NCH = (D + KC - 1) / KC, NKS = (D + 15) / 16;
+    int *posrow = dyn;               // [D] packed position of variable f in this repetition, -1 if absent
     float *locs = reinterpret_cast<float *>(posrow + a.D);   // [4][I][d] the repetition's means
-    for (int f = threadIdx.x; f < D; f += blockDim.x) posrow[f] = -1;
-    if (threadIdx.x == 0) bad_s = 0;
-    __syncthreads();
-    bool bad = false;
+    float *csum = locs + 4 * I * d;   // [NCH][4I]
+    float *ksum = csum + NCH * 4 * I;   // [NKS][4I]
+    unsigned char *padl = reinterpret_cast<unsigned char *>(ksum + NKS * 4 * I);   // [4 d] padding flags
+    const int n4 = 4 * I * d;
+    constexpr int KB = 16;
+    unsigned vl[KB], vs[KB];
+    const unsigned *wl = reinterpret_cast<const unsigned *>(a.loc) + (int64_t)rho * n4;
+    const unsigned *wsc = reinterpret_cast<const unsigned *>(a.scale) + (int64_t)rho * n4;
     if (real) {
-        for (int e = threadIdx.x; e < 4 * d; e += blockDim.x) {
-            const int64_t o = (int64_t)rho * 4 * d + e;
-            if (a.pad != nullptr && a.pad[o]) continue;
-            const int f = (int)a.mask[o];
-            if (f >= 0 && f < D) posrow[f] = e;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            const int e = k * nth + tid;
+            vl[k] = e < n4 ? wl[e] : 0u;
+            vs[k] = e < n4 ? wsc[e] : 0u;
         }
-        // eligibility of the repetition for the expanded form: scale == 1 everywhere, |mu| <= kExpandBound
-        for (int e = threadIdx.x; e < 4 * I * d; e += blockDim.x) {
-            const int64_t o = (int64_t)rho * 4 * I * d + e;
-            const float mu = a.loc[o];
-            locs[e] = mu;
-            const int rr = e / (I * d), j = e % d;
-            if (a.pad != nullptr && a.pad[((int64_t)rho * 4 + rr) * d + j]) continue;
-            bad = bad || !(fabsf(mu) <= kExpandBound) || (a.scale[o] != 1.0f);
+        h += fp_range_n(a.pad ? a.pad + (int64_t)rho * 4 * d : nullptr, (int64_t)4 * d, 2, tid, nth);
+    }
+    for (int f = tid; f < D; f += nth) posrow[f] = -1;
+    if (tid == 0) bad_s = 0;
+    __syncthreads();
+    if (real) {
+        for (int e0 = 0; e0 < 4 * d; e0 += 2 * nth) {
+            long long mk[2];
+            unsigned pd[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int e = e0 + k * nth + tid;
+                mk[k] = e < 4 * d ? a.mask[(int64_t)rho * 4 * d + e] : -1;
+                pd[k] = (e < 4 * d && a.pad != nullptr) ? a.pad[(int64_t)rho * 4 * d + e] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int e = e0 + k * nth + tid;
+                if (e < 4 * d) {
+                    h += fp_word((unsigned)mk[k], (unsigned)(2 * e) * 8u + 1u) +
+                         fp_word((unsigned)(mk[k] >> 32), (unsigned)(2 * e + 1) * 8u + 1u);
+                    padl[e] = (unsigned char)(pd[k] != 0u);
+                    const int q = e / d;
+                    if (!pd[k] && mk[k] >= 0 && mk[k] < D) posrow[(int)mk[k]] = (q << PSH) | (e - q * d);
+                }
+            }
         }
     }
+    __syncthreads();
+    // eligibility of the repetition for the expanded form: scale == 1 everywhere, |mu| <= kExpandBound
+    bool bad = false;
+    if (real) {
+        for (int e0 = 0; e0 < n4; e0 += KB * nth) {
+            if (e0 > 0) {
+#pragma unroll
+                for (int k = 0; k < KB; ++k) {
+                    const int e = e0 + k * nth + tid;
+                    vl[k] = e < n4 ? wl[e] : 0u;
+                    vs[k] = e < n4 ? wsc[e] : 0u;
+                }
+            }
+            // (e / d and e % d stepped from one division per batch: sixteen unrolled runtime divisions were 800 instructions,
+            // and this code runs once per wave -- instruction fetch is what it costs)
+            int quo = (e0 + tid) / d, rem = (e0 + tid) - quo * d;
+            const int sq = nth / d, sr = nth - sq * d;
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                const int e = e0 + k * nth + tid;
+                if (e < n4) {
+                    h += fp_word(vl[k], (unsigned)e * 8u + 3u) + fp_word(vs[k], (unsigned)e * 8u + 4u);
+                    const float mu = __uint_as_float(vl[k]);
+                    locs[e] = mu;
+                    const int rr = quo / I;                   // region of the repetition: e / (I d)
+                    if (!padl[rr * d + rem]) bad = bad || !(fabsf(mu) <= kExpandBound) || (__uint_as_float(vs[k]) != 1.0f);
+                }
+                quo += sq; rem += sr;
+                if (rem >= d) { rem -= d; ++quo; }
+            }
+        }
+    }
+    if (!decide(h)) return;
     if (bad) bad_s = 1;
     __syncthreads();
     const int t = rho / RPT, ap = rho - t * RPT;
     // fragment entries: (K-step, lane half, column of this repetition) -> 8 consecutive variables
-    for (int e = threadIdx.x; e < a.NKSP * 2 * 4 * I; e += blockDim.x) {
+    for (int e = tid; e < a.NKSP * 2 * 4 * I; e += nth) {
         const int col = e % (4 * I);
         const int hg = (e / (4 * I)) & 1;
         const int ks = e / (8 * I);
@@ -270,17 +368,19 @@ __device__ __forceinline__ void gemm_prep_block(const GemmPrepArgs &a, int blk, 
         const int hh = q >> 1, qq = q & 1;
         const int u = (ap * 2 + qq) * I + k;               // accumulator register of the lane half
         const int row = (u & 3) + 8 * (u >> 2) + 4 * hh;   // MFMA output row = A-fragment row
-        half8 mh, ml, ch, cl;
+        int pp[8];
 #pragma unroll
         for (int el = 0; el < 8; ++el) {
             const int f = ks * 16 + hg * 8 + el;
+            pp[el] = (real && f < D) ? posrow[f] : -1;
+        }
+        half8 mh, ml, ch, cl;
+#pragma unroll
+        for (int el = 0; el < 8; ++el) {
             float mu = 0.f, cc = 0.f;
-            if (real && f < D) {
-                const int p = posrow[f];
-                if (p >= 0 && p / d == q) {
-                    mu = locs[(q * I + k) * d + (p - q * d)];
-                    cc = -fmaf(0.5f * mu, mu, kLogSqrt2Pi);
-                }
+            if ((pp[el] >> PSH) == q) {                    // (-1 >> 20 = -1: absent)
+                mu = locs[(q * I + k) * d + (pp[el] & ((1 << PSH) - 1))];
+                cc = -fmaf(0.5f * mu, mu, kLogSqrt2Pi);
             }
             _Float16 hi, lo;
             split_f16(mu, hi, lo);
@@ -294,55 +394,48 @@ __device__ __forceinline__ void gemm_prep_block(const GemmPrepArgs &a, int blk, 
         *reinterpret_cast<half8 *>(a.ctab + o) = ch;
         *reinterpret_cast<half8 *>(a.ctab + o + 512) = cl;
     }
-    // per-(chunk, column) constants - sum_f (mu^2/2 + log sqrt(2 pi)) over the variables of the chunk that belong to
-    // the column's region, and their sum over the chunks; fixed summation order (launches must agree bit for bit)
-    const int KC = 16 * a.KS;
-    const int NCH = (D + KC - 1) / KC;
-    float *csum = locs + 4 * I * d;   // [NCH][4I]
-    for (int e = threadIdx.x; e < NCH * 4 * I; e += blockDim.x) {
-        const int col = e % (4 * I), c = e / (4 * I);
+    // - sum_f (mu^2/2 + log sqrt(2 pi)) over the variables [f0, f1) that belong to column (q, k)'s region, ascending f (fixed
+    // summation order: launches must agree bit for bit); the positions of 16 variables are read together
+    // One loop over both families of constants: per (chunk, column) [bias, csum] and per (K-step of 16 features, column)
+    // [bias_ks, ksum; also the per-slice sums of the small-batch kernel below].
+    const int n_c = NCH * 4 * I, n_k = NKS * 4 * I;
+    for (int e = tid; e < n_c + n_k; e += nth) {
+        const bool chunk = e < n_c;
+        const int ee = chunk ? e : e - n_c;
+        const int col = ee % (4 * I), c = ee / (4 * I);
         const int q = col / I, k = col - q * I;
+        const int span = chunk ? KC : 16;
+        const int f0 = c * span, f1 = min(D, f0 + span);
         float sum = 0.f;
         if (real) {
-            const int f1 = min(D, (c + 1) * KC);
-            for (int f = c * KC; f < f1; ++f) {
-                const int p = posrow[f];
-                if (p >= 0 && p / d == q) {
-                    const float mu = locs[(q * I + k) * d + (p - q * d)];
-                    sum -= fmaf(0.5f * mu, mu, kLogSqrt2Pi);
+            for (int fb = f0; fb < f1; fb += 16) {
+                int pp[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pp[i] = (fb + i < f1) ? posrow[fb + i] : -1;
+                float mu[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const bool ok = (pp[i] >> PSH) == q;
+                    mu[i] = locs[(q * I + k) * d + (ok ? (pp[i] & ((1 << PSH) - 1)) : 0)];
+                    mu[i] = ok ? -fmaf(0.5f * mu[i], mu[i], kLogSqrt2Pi) : 0.f;
                 }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sum += mu[i];     // (absent variables add an exact 0)
             }
         }
         const int hh = q >> 1, qq = q & 1;
         const int u = (ap * 2 + qq) * I + k;
-        a.bias[((c * 2 + hh) * a.NT + t) * 16 + u] = sum;
-        csum[e] = sum;
-    }
-    // the same per K-step of 16 features and per feature slice of the small-batch kernel (ratspn_gemm_small.hip)
-    const int NKS = (D + 15) / 16;
-    float *ksum = csum + NCH * 4 * I;   // [NKS][4I]
-    for (int e = threadIdx.x; e < NKS * 4 * I; e += blockDim.x) {
-        const int col = e % (4 * I), ks = e / (4 * I);
-        const int q = col / I, k = col - q * I;
-        float sum = 0.f;
-        if (real) {
-            const int f1 = min(D, (ks + 1) * 16);
-            for (int f = ks * 16; f < f1; ++f) {
-                const int p = posrow[f];
-                if (p >= 0 && p / d == q) {
-                    const float mu = locs[(q * I + k) * d + (p - q * d)];
-                    sum -= fmaf(0.5f * mu, mu, kLogSqrt2Pi);
-                }
-            }
+        if (chunk) {
+            a.bias[((c * 2 + hh) * a.NT + t) * 16 + u] = sum;
+            csum[ee] = sum;
+        } else {
+            a.bias_ks[((c * 2 + hh) * a.NT + t) * 16 + u] = sum;
+            ksum[ee] = sum;
         }
-        const int hh = q >> 1, qq = q & 1;
-        const int u = (ap * 2 + qq) * I + k;
-        a.bias_ks[((ks * 2 + hh) * a.NT + t) * 16 + u] = sum;
-        ksum[e] = sum;
     }
     __syncthreads();
-    if (threadIdx.x < 4 * I) {
-        const int col = threadIdx.x;
+    if (tid < 4 * I) {
+        const int col = tid;
         const int q = col / I, k = col - q * I;
         float sum = 0.f;
         for (int c = 0; c < NCH; ++c) sum += csum[c * 4 * I + col];
@@ -350,7 +443,7 @@ __device__ __forceinline__ void gemm_prep_block(const GemmPrepArgs &a, int blk, 
         const int u = (ap * 2 + qq) * I + k;
         a.bias_row[(hh * a.NT + t) * 16 + u] = sum;
     }
-    for (int e = threadIdx.x; e < kGemmSmallWaves * 4 * I; e += blockDim.x) {
+    for (int e = tid; e < kGemmSmallWaves * 4 * I; e += nth) {
         const int col = e % (4 * I), w = e / (4 * I);
         const int q = col / I, k = col - q * I;
         float sum = 0.f;
@@ -359,7 +452,7 @@ __device__ __forceinline__ void gemm_prep_block(const GemmPrepArgs &a, int blk, 
         const int u = (ap * 2 + qq) * I + k;
         a.bias_sl[((w * 2 + hh) * a.NT + t) * 16 + u] = sum;
     }
-    if (threadIdx.x == 0) a.elig[rho] = bad_s ? 0 : 1;
+    if (tid == 0) a.elig[rho] = bad_s ? 0 : 1;
 }
 
 // ---- the table-free nodes of a dirty launch --------------------------------------------------------------------------

@@ -131,7 +131,7 @@ template <int S> struct WideUpFrags {
 
 // raw0 / rawr non-null: a launch that found its tables stale (ratspn_gemm_prep.h; `exact` is then set as well) -- the
 // nodes take their log-softmax weights straight from the raw sum / root weights.
-template <int S, bool PRE = true>
+template <int S, bool PRE = true, bool EMIT = false>
 __device__ __forceinline__ double wide_block_upper(const GemmArgs &a, const gf32x16 &acc, unsigned long long odd_mask,
                                                    float qtot, bool exact, int rho, bool mine, int64_t b0,
                                                    const lfloat *w0_l, char *lds, const WideUpFrags<S> &uf,
@@ -143,6 +143,19 @@ __device__ __forceinline__ double wide_block_upper(const GemmArgs &a, const gf32
     // ---- leaf sums of the lane's partition: regions 2h (a) and 2h + 1 (c) of repetition rho -------------------------
     float va[I], vc[I];
     wide_leaf_sums(a, acc, odd_mask, exact, rho, b0, va, vc);
+    if constexpr (EMIT) {
+        // (training forward: the lane's two regions are 16 consecutive floats of the [B, R, I] leaf tensor)
+        if (mine && b0 + s < a.B) {
+            gf32x4 *dst = reinterpret_cast<gf32x4 *>(a.emit_leaf + ((b0 + s) * (4 * NT) + rho * 4 + 2 * h) * I);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const gf32x4 v0 = {va[4 * q], va[4 * q + 1], va[4 * q + 2], va[4 * q + 3]};
+                const gf32x4 v1 = {vc[4 * q], vc[4 * q + 1], vc[4 * q + 2], vc[4 * q + 3]};
+                dst[q] = v0;
+                dst[2 + q] = v1;
+            }
+        }
+    }
     if (a.ablate & 2) {
         wide_upper_barriers();
         return 0.0;
@@ -212,6 +225,13 @@ __device__ __forceinline__ double wide_block_upper(const GemmArgs &a, const gf32
             prodsum_node<I, S>(va, vc, wl, lw, sc, n1);
         }
     }
+    if constexpr (EMIT) {
+        if (mine && b0 + s < a.B) {
+            float *dst = a.emit_sum + ((b0 + s) * (2 * NT) + rho * 2 + h) * S;
+#pragma unroll
+            for (int o = 0; o < S; ++o) dst[o] = n1[o];
+        }
+    }
     float ta[S], tc[S];
 #pragma unroll
     for (int o = 0; o < S; ++o) {
@@ -255,9 +275,11 @@ __device__ __forceinline__ double wide_block_upper(const GemmArgs &a, const gf32
         for (int cl = slot; cl < C; cl += 16) {
             float mm = -INFINITY, ss = 0.f;
             for (int r = 0; r < NT; ++r) lse_merge(mm, ss, xch[((r * 32 + smp) * C + cl) * 2], xch[((r * 32 + smp) * C + cl) * 2 + 1]);
-            const float ll = ((mm > -INFINITY) ? mm + logf(ss) : -INFINITY) + qterm;
+            const float rel = (mm > -INFINITY) ? mm + logf(ss) : -INFINITY;
+            const float ll = rel + qterm;
             if (bs < a.B) {
                 a.out[bs * C + cl] = ll;
+                if constexpr (EMIT) a.emit_out[bs * C + cl] = rel;
                 part += (double)ll;
             }
         }
@@ -276,7 +298,7 @@ struct WideTail {                                     // LDS behind the x tile a
 };
 static_assert(sizeof(WideTail) % 16 == 0, "LDS layout");
 
-template <int S, bool MARG>
+template <int S, bool MARG, bool EMIT>
 __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const GemmArgs a, const GemmPrepArgs pa) {
     constexpr int I = kWideI;
     constexpr int PF = MARG ? 6 : 12;                 // K-steps of table fragments in flight per wave
@@ -522,7 +544,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const
     __syncthreads();   // every wave is done with the x tile: its LDS becomes scratch and the root exchange buffer
     const bool tables_stale = np > 0 && tail->verdict != 0;
     const bool exact = !model_ok || __any(lane_exact) || tables_stale;   // (the same x tile in every wave: the same verdict in every wave)
-    double part = wide_block_upper<S>(a, acc, odd_mask, qtot, exact, rho, mine, b0, w0_l, smem_generic, uf,
+    double part = wide_block_upper<S, true, EMIT>(a, acc, odd_mask, qtot, exact, rho, mine, b0, w0_l, smem_generic, uf,
                                       tables_stale ? pa.w[0] : nullptr, tables_stale ? pa.w[1] : nullptr);
     double *red = reinterpret_cast<double *>(smem_generic + wide_upper_lds_bytes(NT, a.C));
     if (a.ll_sum != nullptr) {
@@ -882,12 +904,12 @@ bool gemm_wide_shape_ok(int D, int reps, int I, int S, int C) {
     return p1 <= 160 * 1024 && p2 <= (size_t)NKS * 2048;
 }
 
-template <int S, bool MARG>
+template <int S, bool MARG, bool EMIT = false>
 static int gemm_wide_launch(const GemmArgs &a, const GemmPrepArgs &p, hipStream_t st) {
     const int NKS = cdiv(a.D, 16);
     size_t lds = (size_t)NKS * 2048 + (size_t)kWideWaves * 2 * S * kWideI * kWideI * 4 + sizeof(WideTail);
     if (p.np > 0 && gemm_prep_lds_bytes(a.D, kWideI, a.d) > lds) lds = gemm_prep_lds_bytes(a.D, kWideI, a.d);
-    auto kern = ratspn_gemm_wide_kernel<S, MARG>;
+    auto kern = ratspn_gemm_wide_kernel<S, MARG, EMIT>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024)) return rc;
     hipEvent_t ev0, ev1;
     profile_take(&ev0, &ev1, DPK_KERNEL_RATSPN_FUSED);
@@ -928,7 +950,8 @@ static bool wide_takes_ring(int64_t B) {
 
 // large clean batches: 128-sample tiles behind the LDS-DMA ring (its scratch must fit the ring's stages); everything else
 // takes the 32-sample kernel -- the mapping that carries its own table work-groups (ratspn_gemm_forward asks)
-bool gemm_wide_takes_tile32(int64_t B, int D, int reps, int C, bool marginal) {
+bool gemm_wide_takes_tile32(int64_t B, int D, int reps, int C, bool marginal, bool emit) {
+    if (emit) return true;   // (the training forward lives in the 32-sample kernel only)
     return !(!marginal && wide_takes_ring(B) && (D % 4) == 0 &&
              wide_upper_lds_bytes(reps, C) + kWideWaves * 8 + 64 <= (size_t)kGemmStages * kGemmTile * 256);
 }
@@ -937,7 +960,16 @@ bool gemm_wide_takes_tile32(int64_t B, int D, int reps, int C, bool marginal) {
 // only) and filled the argument block.
 int ratspn_gemm_wide_forward(const GemmArgs &a, const GemmPrepArgs &p, int S, hipStream_t st) {
     const bool marg = a.marginal != 0;
-    if (!gemm_wide_takes_tile32(a.B, a.D, a.reps, a.C, marg)) {
+    if (a.emit_leaf != nullptr) {
+        switch (S) {
+            case 2: return marg ? gemm_wide_launch<2, true, true>(a, p, st) : gemm_wide_launch<2, false, true>(a, p, st);
+            case 4: return marg ? gemm_wide_launch<4, true, true>(a, p, st) : gemm_wide_launch<4, false, true>(a, p, st);
+            case 8: return marg ? gemm_wide_launch<8, true, true>(a, p, st) : gemm_wide_launch<8, false, true>(a, p, st);
+        }
+        set_error("ratspn_gemm_wide: sums=%d not built", S);
+        return DPK_EUNSUPPORTED;
+    }
+    if (!gemm_wide_takes_tile32(a.B, a.D, a.reps, a.C, marg, false)) {
         DPK_REQUIRE(p.np == 0, DPK_EINVAL, "ratspn_gemm_wide: the ring kernel does not check its tables itself");
         switch (S) {
             case 2: return gemm_wide_ring_launch<2>(a, st);

@@ -51,37 +51,72 @@ __global__ __launch_bounds__(256) void ratspn_leaf_gemm_prep_kernel(const LeafPr
     __shared__ unsigned long long red_s[17];
     constexpr int P = kLeafPrepParts;
     const int r = blockIdx.x, part = blockIdx.y, D = a.D, d = a.d, I = a.I, NTG = a.NTG;
-    {
-        // block-local cached-table check (see ratspn_gemm_prep_kernel): the region's slice of mask / pad_mask / loc / scale
-        const unsigned long long stored = a.verify ? a.hash[r * P + part] : 0ull;   // (requested first: back when the hash is)
-        unsigned long long h = 0x9E3779B97F4A7C15ull + (unsigned long long)r;
-        h += fp_range(a.mask + (int64_t)r * d, (int64_t)d * 8, 1);
-        h += fp_range(a.pad ? a.pad + (int64_t)r * d : nullptr, (int64_t)d, 2);
-        h += fp_range(a.loc + (int64_t)r * I * d, (int64_t)I * d * 4, 3);
-        h += fp_range(a.scale + (int64_t)r * I * d, (int64_t)I * d * 4, 4);
-        h = block_sum_u64(h, red_s);
-        if (a.verify && stored == h) return;
-        __syncthreads();
-        if (threadIdx.x == 0) a.hash[r * P + part] = h;
+    // Every global read of the region's parameters is issued up front and used twice (fingerprint + tables): the earlier
+    // form (fingerprint loops, then `if (pad[j]) continue; .. scale[o]` per element) was ~25 dependent round trips to
+    // memory, 17 us for 12 KB.  Fingerprint = sum of fp_word(word, position * 8 + tag) as in fp_range, over mask (tag 1),
+    // pad_mask (2, one byte per word), loc (3), scale (4).
+    unsigned char *padl = reinterpret_cast<unsigned char *>(csum + ((D + 16 * a.KS - 1) / (16 * a.KS)) * I);   // [d]
+    const unsigned long long stored = a.verify ? a.hash[r * P + part] : 0ull;   // (requested first: back when the hash is)
+    unsigned long long hsum = 0ull;
+    const int tid = threadIdx.x, n = I * d;
+    const unsigned *wl = reinterpret_cast<const unsigned *>(a.loc + (int64_t)r * n);
+    const unsigned *wsc = reinterpret_cast<const unsigned *>(a.scale + (int64_t)r * n);
+    constexpr int KB = 8;
+    unsigned vl[KB], vs[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+        const int e = k * 256 + tid;
+        vl[k] = e < n ? wl[e] : 0u;
+        vs[k] = e < n ? wsc[e] : 0u;
     }
-    for (int f = threadIdx.x; f < D; f += blockDim.x) featpos[f] = -1;
-    if (threadIdx.x == 0) bad_s = 0;
+    for (int f = tid; f < D; f += 256) featpos[f] = -1;
+    if (tid == 0) bad_s = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < d; j0 += 512) {
+        long long mk[2];
+        unsigned pd[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int j = j0 + k * 256 + tid;
+            mk[k] = j < d ? a.mask[(int64_t)r * d + j] : -1;
+            pd[k] = (j < d && a.pad != nullptr) ? a.pad[(int64_t)r * d + j] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int j = j0 + k * 256 + tid;
+            if (j < d) {
+                hsum += fp_word((unsigned)mk[k], (unsigned)j * 16u + 1u) + fp_word((unsigned)(mk[k] >> 32), (unsigned)j * 16u + 9u) +
+                        fp_word(pd[k], (unsigned)j * 8u + 2u);
+                padl[j] = (unsigned char)(pd[k] != 0u);
+                if (!pd[k] && mk[k] >= 0 && mk[k] < D) featpos[(int)mk[k]] = j;
+            }
+        }
+    }
     __syncthreads();
     bool bad = false;
-    for (int j = threadIdx.x; j < d; j += blockDim.x) {
-        const int64_t o = (int64_t)r * d + j;
-        if (a.pad != nullptr && a.pad[o]) continue;
-        const int f = (int)a.mask[o];
-        if (f >= 0 && f < D) featpos[f] = j;
+    for (int e0 = 0; e0 < n; e0 += KB * 256) {
+        if (e0 > 0) {
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                const int e = e0 + k * 256 + tid;
+                vl[k] = e < n ? wl[e] : 0u;
+                vs[k] = e < n ? wsc[e] : 0u;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            const int e = e0 + k * 256 + tid;
+            if (e < n) {
+                hsum += fp_word(vl[k], (unsigned)e * 8u + 3u) + fp_word(vs[k], (unsigned)e * 8u + 4u);
+                const float mu = __uint_as_float(vl[k]);
+                locs[e] = mu;
+                if (!padl[e % d]) bad = bad || !(fabsf(mu) <= kExpandBound) || (__uint_as_float(vs[k]) != 1.0f);
+            }
+        }
     }
-    for (int e = threadIdx.x; e < I * d; e += blockDim.x) {
-        const int64_t o = (int64_t)r * I * d + e;
-        const float mu = a.loc[o];
-        locs[e] = mu;
-        const int j = e % d;
-        if (a.pad != nullptr && a.pad[(int64_t)r * d + j]) continue;
-        if (part == P - 1) bad = bad || !(fabsf(mu) <= kExpandBound) || (a.scale[o] != 1.0f);
-    }
+    hsum = block_sum_u64(hsum + 0x9E3779B97F4A7C15ull * (tid == 0 ? (unsigned long long)(r + 1) : 0ull), red_s);
+    if (a.verify && stored == hsum) return;
+    if (tid == 0) a.hash[r * P + part] = hsum;
     if (bad) bad_s = 1;
     __syncthreads();
     const int tile_cols = 32 * NTG;
@@ -476,7 +511,7 @@ int ratspn_leaf_gemm_forward(void *ws, const float *x, int64_t B, int D, const i
         pa.mask = mask; pa.pad = pad; pa.loc = loc; pa.scale = scale;
         pa.D = D; pa.d = d; pa.R = R; pa.I = I; pa.NTG = NTG; pa.NG = NG; pa.NKSP = NKSP; pa.KS = KS;
         pa.mtab = mtab; pa.ctab = ctab; pa.bias = biasC; pa.bias_row = biasT; pa.elig = elig;
-        const size_t lds = ((size_t)D + (size_t)I * d + (size_t)NCH * I) * 4;
+        const size_t lds = ((size_t)D + (size_t)I * d + (size_t)NCH * I) * 4 + (size_t)align_up(d, 4);
         DPK_REQUIRE(lds <= 60 * 1024, DPK_EUNSUPPORTED, "leaf_gemm: in_features=%d too large for the table kernel", D);
         DPK_LAUNCH(ratspn_leaf_gemm_prep_kernel, dim3(R, kLeafPrepParts), dim3(256), lds, st, pa);
         DPK_CHECK_LAUNCH("ratspn_leaf_gemm_prep_kernel");

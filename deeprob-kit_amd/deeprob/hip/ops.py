@@ -334,30 +334,106 @@ class ProdSumFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        lib = load_library()
         x, w, out = ctx.saved_tensors
-        g = require_device_f32(g, 'grad')
-        B, R, N = x.shape
-        P, st = R // 2, stream_ptr(x.device)
-        prod = torch.empty((B, P, N * N), dtype=torch.float32, device=x.device)
-        check(lib.dpk_product_forward(ptr(x), B, R, N, ptr(prod), st), 'dpk_product_forward')
-        gprod = torch.empty_like(prod) if ctx.needs_input_grad[0] else None
-        gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
-        if ctx.root:
-            M, C = P * N * N, w.shape[0]
-            buf = _sum_ws(ctx.ws, B, 1, M, C, x.device)
-            check(lib.dpk_root_backward(ptr(prod), ptr(w), ptr(out), ptr(g), B, M, C, ptr(gprod), ptr(gw), ptr(buf),
-                                        buf.numel(), st), 'dpk_root_backward')
-        else:
-            S = w.shape[1]
-            buf = _sum_ws(ctx.ws, B, P, N * N, S, x.device)
-            check(lib.dpk_sum_backward(ptr(prod), ptr(w), ptr(out), ptr(g), B, P, N * N, S, ptr(gprod), ptr(gw), ptr(buf),
-                                       buf.numel(), st), 'dpk_sum_backward')
-        gx = None
-        if gprod is not None:
-            gx = torch.empty_like(x)
-            check(lib.dpk_product_backward(ptr(gprod), B, R, N, ptr(gx), st), 'dpk_product_backward')
+        gx, gw = _prodsum_backward(x, w, out, g, ctx.ws, ctx.root, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return gx, gw, None, None
+
+
+def _prodsum_backward(x, w, out, g, ws: Workspace, root: bool, need_gx: bool, need_gw: bool):
+    """Backward of a folded level from its saved (input, weight, output): the product tensor recomputed, then the Sum /
+    Root layer's and the ProductLayer's own backward kernels.  ``(x, out)`` may carry a common per-sample shift (the
+    training forward's relative tensors): the kernels only use ``in - out``."""
+    lib = load_library()
+    g = require_device_f32(g, 'grad')
+    B, R, N = x.shape
+    P, st = R // 2, stream_ptr(x.device)
+    prod = torch.empty((B, P, N * N), dtype=torch.float32, device=x.device)
+    check(lib.dpk_product_forward(ptr(x), B, R, N, ptr(prod), st), 'dpk_product_forward')
+    gprod = torch.empty_like(prod) if need_gx else None
+    gw = torch.empty_like(w) if need_gw else None
+    if root:
+        M, C = P * N * N, w.shape[0]
+        buf = _sum_ws(ws, B, 1, M, C, x.device)
+        check(lib.dpk_root_backward(ptr(prod), ptr(w), ptr(out), ptr(g), B, M, C, ptr(gprod), ptr(gw), ptr(buf),
+                                    buf.numel(), st), 'dpk_root_backward')
+    else:
+        S = w.shape[1]
+        buf = _sum_ws(ws, B, P, N * N, S, x.device)
+        check(lib.dpk_sum_backward(ptr(prod), ptr(w), ptr(out), ptr(g), B, P, N * N, S, ptr(gprod), ptr(gw), ptr(buf),
+                                   buf.numel(), st), 'dpk_sum_backward')
+    gx = None
+    if gprod is not None:
+        gx = torch.empty_like(x)
+        check(lib.dpk_product_backward(ptr(gprod), B, R, N, ptr(gx), st), 'dpk_product_backward')
+    return gx, gw
+
+
+class RatSpnTrainFn(torch.autograd.Function):
+    """RatSpn.forward of a training step as ONE autograd node (reference: models/ratspn.py:105-122 under autograd): the
+    forward is the single-launch kernel of the evaluation path, which also writes the leaf and sum layer outputs the
+    backward needs (``dpk_ratspn_forward_train``); the backward chains the layers' own backward kernels.  Depth 2,
+    Gaussian leaves with a frozen (unit) scale, no dropout, no gradient with respect to the evidence."""
+
+    @staticmethod
+    def forward(ctx, x, loc, scale, w0, wr, mask, pad_mask, lctx: LeafContext, leaf_lctx: LeafContext, ws0: Workspace,
+                wsr: Workspace):
+        lib = load_library()
+        x = require_device_f32(x, 'x')
+        loc_c, scale_c = require_device_f32(loc, 'loc'), require_device_f32(scale, 'scale')
+        w0_c, wr_c = require_device_f32(w0, 'sum weight'), require_device_f32(wr, 'root weight')
+        B, dev = x.shape[0], x.device
+        out = torch.empty((B, lctx.C), dtype=torch.float32, device=dev)
+        out_rel = torch.empty_like(out)
+        leaf_rel = torch.empty((B, lctx.R, lctx.I), dtype=torch.float32, device=dev)
+        sum_rel = torch.empty((B, 2 * lctx.reps, lctx.S), dtype=torch.float32, device=dev)
+        ws, flags = lctx.workspace(dev, mask, pad_mask, scale)
+        flags |= _params_flag(lib, lctx, ptr(x), flags, [loc_c, scale_c, w0_c, wr_c])
+        rc = lib.dpk_ratspn_forward_train(ptr(x), B, lctx.D, ptr(mask), ptr(_pad_u8(pad_mask)), ptr(loc_c), ptr(scale_c),
+                                          ptr(w0_c), ptr(wr_c), lctx.depth, lctx.reps, lctx.I, lctx.S, lctx.C, ptr(out),
+                                          ptr(leaf_rel), ptr(sum_rel), ptr(out_rel), ptr(ws), ws.numel(), flags,
+                                          stream_ptr(dev))
+        if rc:
+            lctx.ws.params_key = None
+            if rc == -4:  # DPK_EUNSUPPORTED
+                lctx.ws.struct_key = None
+                raise _TrainForwardUnsupported()
+        check(rc, 'dpk_ratspn_forward_train')
+        ctx.save_for_backward(x, loc_c, scale_c, w0_c, wr_c, mask, pad_mask, leaf_rel, sum_rel, out_rel)
+        ctx.leaf_lctx, ctx.ws0, ctx.wsr = leaf_lctx, ws0, wsr
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load_library()
+        x, loc, scale, w0, wr, mask, pad_mask, leaf_rel, sum_rel, out_rel = ctx.saved_tensors
+        need_loc, need_w0, need_wr = ctx.needs_input_grad[1], ctx.needs_input_grad[3], ctx.needs_input_grad[4]
+        need_below = need_loc or need_w0
+        gsum, gwr = _prodsum_backward(sum_rel, wr, out_rel, g, ctx.wsr, True, need_below, need_wr)
+        gleaf, gw0, gloc = None, None, None
+        if need_below:
+            gleaf, gw0 = _prodsum_backward(leaf_rel, w0, sum_rel, gsum, ctx.ws0, False, need_loc, need_w0)
+        if need_loc:
+            lctx = ctx.leaf_lctx
+            gloc = torch.empty_like(loc)
+            ws, flags = lctx.workspace(x.device, mask, pad_mask)
+            check(lib.dpk_gaussian_leaf_backward(ptr(x), ptr(gleaf), x.shape[0], lctx.D, ptr(mask), ptr(_pad_u8(pad_mask)),
+                                                 ptr(loc), ptr(scale), lctx.R, lctx.I, lctx.d, ptr(gloc), None, None,
+                                                 ptr(ws), ws.numel(), flags, stream_ptr(x.device)),
+                  'dpk_gaussian_leaf_backward')
+        return (None, gloc, None, gw0, gwr) + (None,) * 6
+
+
+class _TrainForwardUnsupported(Exception):
+    pass
+
+
+def ratspn_forward_train(x, mask, pad_mask, loc, scale, sum_weight, root_weight, lctx: LeafContext,
+                         leaf_lctx: LeafContext, ws0: Workspace, wsr: Workspace) -> Optional[torch.Tensor]:
+    """``RatSpnTrainFn`` or None when the model / batch is outside the single-launch training forward."""
+    try:
+        return RatSpnTrainFn.apply(x, loc, scale, sum_weight, root_weight, mask, pad_mask, lctx, leaf_lctx, ws0, wsr)
+    except _TrainForwardUnsupported:
+        return None
 
 
 def prodsum_autograd(x: torch.Tensor, weight: torch.Tensor, ws: Workspace, root: bool = False) -> Optional[torch.Tensor]:

@@ -50,7 +50,7 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         lib = load_library()
         for group in self.param_groups:
-            entries, keep = [], []
+            entries, keep, touched = [], [], []
             for p in group['params']:
                 if p.grad is None:
                     continue
@@ -64,6 +64,7 @@ class FusedAdam(torch.optim.Optimizer):
                 entries.append(_AdamTensor(p.data_ptr(), g.data_ptr(), state['exp_avg'].data_ptr(),
                                            state['exp_avg_sq'].data_ptr(), p.numel()))
                 keep.append(g)
+                touched += [p, state['exp_avg'], state['exp_avg_sq']]
             if not entries:
                 continue
             if len(entries) > MAX_TENSORS:
@@ -79,5 +80,7 @@ class FusedAdam(torch.optim.Optimizer):
                                     float(group['eps']), float(group['weight_decay']), int(bool(group['maximize'])),
                                     step_t.data_ptr(), ticket.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
                   'dpk_adam_step')
+            # (the kernel wrote through raw pointers: tell autograd -- and the table caches keyed on version counters)
+            torch.autograd.graph.increment_version(touched + [step_t])
             del keep
         return loss

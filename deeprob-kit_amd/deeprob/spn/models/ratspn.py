@@ -99,6 +99,7 @@ class RatSpn(ProbabilisticModel):
         self.root_layer = RootLayer(groups, nodes, self.out_classes)
 
         self._fused_declined = False
+        self._train_fused_declined = False
         self._fused_ctx = ops.LeafContext(
             self.in_features, self.base_layer.in_regions, self.rg_batch, self.base_layer.dimension,
             depth=self.rg_depth, reps=rg_repetitions, sums=self.rg_sum, classes=self.out_classes
@@ -120,6 +121,27 @@ class RatSpn(ProbabilisticModel):
             x, base.mask, base._pad_mask_or_none(), base.loc, base.scale, sum_weights,
             self.root_layer.weight, self._fused_ctx, ll_acc
         )
+
+    def _forward_train_fused(self, x: torch.Tensor) -> Optional[torch.Tensor]:
+        base = self.base_layer
+        if self._train_fused_declined or not isinstance(base, GaussianLayer) or self.rg_depth != 2:
+            return None
+        if base.scale.requires_grad or x.requires_grad or not x.is_cuda:
+            return None
+        if self.training and (self.in_dropout is not None or self.sum_dropout is not None):
+            return None
+        layers = list(self.layers)
+        if not (len(layers) == 3 and isinstance(layers[0], ProductLayer) and isinstance(layers[1], SumLayer)
+                and isinstance(layers[2], ProductLayer)):
+            return None
+        out = ops.ratspn_forward_train(x, base.mask, base._pad_mask_or_none(), base.loc, base.scale, layers[1].weight,
+                                       self.root_layer.weight, self._fused_ctx, base._leaf_ctx, layers[1]._ws,
+                                       self.root_layer._ws)
+        if out is None:
+            # (declined on the model's constants -- channels, sums, classes: do not ask again; a batch-size dependent
+            # refusal of the 2 / 4 channel kernels is asked again, it costs one failed call)
+            self._train_fused_declined = self.rg_batch == 8
+        return out
 
     def _prefer_folded(self, x: torch.Tensor) -> bool:
         """8-channel unit-scale models: the leaf layer and the folded product / sum layers on the matrix cores beat the
@@ -206,7 +228,12 @@ class RatSpn(ProbabilisticModel):
             out = self._forward_folded(x)
             if out is not None:
                 return out
-        # training / gradients: the layer chain, every ProductLayer folded with the Sum / Root layer above it into one
+        # training / gradients.  Depth-2 models inside the single-launch kernel's envelope: that kernel, writing what the
+        # backward needs on its way up (ops.RatSpnTrainFn: one launch instead of leaf + 2 folded levels + 3 table builds)
+        out = self._forward_train_fused(x)
+        if out is not None:
+            return out
+        # otherwise the layer chain, every ProductLayer folded with the Sum / Root layer above it into one
         # autograd node (ops.ProdSumFn: no [B, P, N^2] product tensor in the forward)
         x = self.base_layer(x)
         layers, i = list(self.layers), 0

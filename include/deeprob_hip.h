@@ -193,6 +193,21 @@ int dpk_ratspn_forward(const float *x, int64_t B, int32_t D, const int64_t *mask
                        float *out, float *leaf_out, double *ll_sum, void *ws, int64_t ws_bytes,
                        uint32_t flags, void *stream);
 
+/* RatSpn.forward of a TRAINING step (models/ratspn.py:105-122 under autograd; the loop of torch/routines.py:150-170):
+ * the same single launch as dpk_ratspn_forward on the MFMA route, which on its way up also writes what the layers'
+ * backward entry points read -- the three launches + three table builds of the per-layer chain become one launch.
+ *   leaf_rel [B, R, I]       leaf layer outputs      \  each RELATIVE to the sample: plus 1/2 sum x^2 over the variables
+ *   sum_rel  [B, 2 reps, S]  first sum layer outputs  } below the node (the GEMM form carries that common term to the root);
+ *   out_rel  [B, C]          root outputs            /  dpk_sum_backward / dpk_root_backward only use in - out, so
+ *                                                       (leaf_rel, sum_rel) and (sum_rel, out_rel) are valid (in, out) pairs.
+ *   out      [B, C]          the log-likelihoods themselves.
+ * Built for depth 2, Gaussian leaves with the unit-scale hint, 8 channels (<= 8 repetitions, <= 32 classes) or 2 / 4
+ * channels up to dpk_ratspn_small_batch_max samples; DPK_EUNSUPPORTED otherwise (the caller chains the layers).        */
+int dpk_ratspn_forward_train(const float *x, int64_t B, int32_t D, const int64_t *mask, const uint8_t *pad_mask,
+                             const float *loc, const float *scale, const float *sum_weight0, const float *root_weight,
+                             int32_t depth, int32_t reps, int32_t I, int32_t S, int32_t C, float *out, float *leaf_rel,
+                             float *sum_rel, float *out_rel, void *ws, int64_t ws_bytes, uint32_t flags, void *stream);
+
 /* ------------------------------------------------------------------------ *
  * RealNVP-1D                                                                *
  * ------------------------------------------------------------------------ */

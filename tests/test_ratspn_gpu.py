@@ -761,3 +761,105 @@ def test_eight_channel_route_follows_the_library_envelope(D, one_launch):
         assert xm.data_ptr() % 16 == 4 and model._prefer_folded(xm)
         with torch.no_grad():
             assert rel_err(model(xm).cpu().numpy(), want) <= LL_TOL
+
+
+@pytest.mark.parametrize('B', [1, 37, 512])
+@pytest.mark.parametrize('evidence', ['plain', 'marginalised', 'huge'])
+def test_training_forward_single_launch_matches_layer_chain(golden, B, evidence):
+    """ops.RatSpnTrainFn (dpk_ratspn_forward_train: the evaluation kernel writing the leaf / sum layer outputs relative to
+    the sample's quadratic term, the layers' backward kernels on those) against the per-layer autograd chain of the same
+    model: log-likelihoods and every parameter gradient; NaN evidence (validity GEMM) and evidence beyond the expansion
+    bound (exact per-element leaf sums) included.  reference: models/ratspn.py:105-122 under autograd."""
+    model, g = build('ratspn_g784_d2_r8_i8_s8', golden)
+    model.train()
+    gen = torch.Generator().manual_seed(5 + B)
+    x = torch.randn(B, 784, generator=gen)
+    if evidence == 'marginalised':
+        x[torch.rand(B, 784, generator=gen) < 0.2] = float('nan')
+    elif evidence == 'huge':
+        x[0] *= 2000.0
+        x[B // 2, 5] = 1e6
+    x = x.cuda()
+    params = [p for p in model.parameters() if p.requires_grad]
+    calls = {'n': 0}
+    from deeprob.hip import ops
+    real = ops.RatSpnTrainFn.apply
+
+    def counted(*a):
+        calls['n'] += 1
+        return real(*a)
+
+    ops.RatSpnTrainFn.apply = counted
+    try:
+        out_f = model(x)
+        gf = torch.autograd.grad(model.loss(out_f), params)
+    finally:
+        ops.RatSpnTrainFn.apply = real
+    assert calls['n'] == 1, "the training forward did not take the single-launch route"
+    model._train_fused_declined = True
+    out_c = model(x)
+    gc = torch.autograd.grad(model.loss(out_c), params)
+    model._train_fused_declined = False
+    assert rel_err(out_f.detach().cpu().numpy(), out_c.detach().cpu().numpy()) <= 2e-6
+    # yardstick: the oracle's fp64 autograd on the same evidence (the two fp32 routes sit ~1e-4 of the largest gradient
+    # apart at B = 1 -- responsibilities exp(in - out) of leaf sums near -1000 -- each within GRAD_TOL of fp64)
+    names = [k for k, p in model.named_parameters() if p.requires_grad]
+    sd = orc.state_from_npz(g, dtype=torch.float64)
+    for k in names:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    with torch.enable_grad():
+        orc.ratspn_loss(orc.ratspn_forward(sd, x.double().cpu()), None).backward()
+    for k, p, a, b in zip(names, params, gf, gc):
+        assert torch.isfinite(a).all()
+        exact = sd[k].grad.numpy()
+        assert grad_err(a.cpu().numpy(), exact) <= max(GRAD_TOL, 2.0 * grad_err(b.cpu().numpy(), exact)), k
+        assert grad_err(a.cpu().numpy(), b.cpu().numpy()) <= 4 * GRAD_TOL, k
+    with torch.no_grad():                       # and the evaluation path agrees with the training forward's values
+        assert rel_err(model.eval()(x).cpu().numpy(), out_f.detach().cpu().numpy()) <= 2e-6
+
+
+def test_training_forward_classes_and_stale_tables(golden):
+    """10 classes; then a parameter written through .data between two training forwards (no version bump): the second
+    forward's in-launch table check finds it and both values and gradients follow the new parameters."""
+    from deeprob.spn.models import GaussianRatSpn
+    torch.manual_seed(0)
+    model = GaussianRatSpn(784, out_classes=10, rg_depth=2, rg_repetitions=8, rg_batch=8, rg_sum=8, random_state=3).cuda().train()
+    x = torch.randn(70, 784, device='cuda')
+    y = torch.randint(0, 10, (70,), device='cuda')
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def both():
+        res = []
+        for declined in (False, True):
+            model._train_fused_declined = declined
+            out = model(x)
+            res.append((out.detach(), torch.autograd.grad(model.loss(out, y), params)))
+        model._train_fused_declined = False
+        return res
+
+    for trial in range(2):
+        (of, gf), (oc, gc) = both()
+        assert rel_err(of.cpu().numpy(), oc.cpu().numpy()) <= 2e-6
+        for a, b in zip(gf, gc):
+            assert grad_err(a.cpu().numpy(), b.cpu().numpy()) <= 2 * GRAD_TOL
+        model.base_layer.loc.data.add_(0.3)
+        model.root_layer.weight.data.mul_(0.5)
+
+
+def test_training_forward_golden_gradients(golden):
+    """The reference's own parameter gradients (fixture generated by importing the reference) through the single-launch
+    training forward: test_backward_golden asks for the input gradient too, which keeps it on the layer chain."""
+    name = 'ratspn_g784_d2_r8_i8_s8'
+    model, g = build(name, golden)
+    x = torch.from_numpy(g['x']).cuda()
+    y = torch.from_numpy(g['y']).cuda() if 'y' in g.files else None
+    assert model._forward_train_fused(x) is not None
+    with torch.enable_grad():
+        loss = model.loss(model(x), y)
+        loss.backward()
+    assert abs(loss.item() - float(g['loss'])) <= LL_TOL * max(1.0, abs(float(g['loss'])))
+    ref64 = _oracle_grads_fp64(g)
+    for k, p in model.named_parameters():
+        if 'grad.' + k in g.files:
+            tol = max(GRAD_TOL, 4.0 * grad_err(g['grad.' + k], ref64[k]))
+            assert grad_err(p.grad.cpu().numpy(), g['grad.' + k]) <= tol, k

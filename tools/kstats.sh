@@ -12,7 +12,7 @@ python - "$f" <<'PY' | tee $OUT/summary.txt
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 print('%-90s %8s %12s %8s' % ('kernel', 'calls', 'avg_us', 'pct'))
-for r in rows[:10]:
+for r in rows[:26]:
     print('%-90s %8s %12.2f %8s' % (r['Name'][:90], r['Calls'], float(r['AverageNs']) / 1e3, r['Percentage']))
 PY
 rm -rf $OUT/trace
