@@ -154,9 +154,11 @@ __device__ __forceinline__ void x3_check_body(const X3PackArgs &a, X3Check *st, 
         atomicMax(&st->m1, __float_as_uint(fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]))));
         atomicMax(&st->m2, __float_as_uint(fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]))));
         atomicAdd(&st->acc, (hred[0] + hred[1]) + (hred[2] + hred[3]) + (unsigned long long)(a.pm + 2 * a.affine + 1));
-        __threadfence();
-        if (atomicAdd(&st->tickets, 1u) == (unsigned)nblocks - 1u) {   // last block: every partial result has arrived
-            __threadfence();
+        // (the partial results above are device-scope atomics: their acknowledgement is all the release there is to wait for;
+        // a __threadfence() writes back this XCD's L2 -- 17 .. 40 us behind a kernel that left it dirty, round-4 measurement)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        if (atomicAdd(&st->tickets, 1u) == (unsigned)nblocks - 1u) {   // last block: every partial result has arrived (read back with atomics)
             const unsigned long long sum = atomicExch(&st->acc, 0ull);
             const unsigned b1 = atomicExch(&st->m1, 0u), b2 = atomicExch(&st->m2, 0u);
             const bool rebuild = !verify || sum != st->stored;

@@ -60,6 +60,7 @@ struct GemmPrepArgs {
     VerifyCtl *ctl;
     int np;                     // table work-groups of the launch
     int readers;                // work-groups that read the verdict (np + model work-groups)
+    int ablate;                 // measurement only (DPK_PREP_ABLATE): 1 stop after the verdict, 2 no fragments, 4 no constants
 };
 
 // table work-groups a launch needs: one per repetition slot + one per (threads / 64) softmax rows
@@ -356,11 +357,12 @@ __device__ __forceinline__ void gemm_prep_block(const GemmPrepArgs &a, int blk, 
         }
     }
     if (!decide(h)) return;
+    if (a.ablate & 1) return;
     if (bad) bad_s = 1;
     __syncthreads();
     const int t = rho / RPT, ap = rho - t * RPT;
     // fragment entries: (K-step, lane half, column of this repetition) -> 8 consecutive variables
-    for (int e = tid; e < a.NKSP * 2 * 4 * I; e += nth) {
+    for (int e = tid; e < ((a.ablate & 2) ? 0 : a.NKSP * 2 * 4 * I); e += nth) {
         const int col = e % (4 * I);
         const int hg = (e / (4 * I)) & 1;
         const int ks = e / (8 * I);
@@ -399,7 +401,7 @@ __device__ __forceinline__ void gemm_prep_block(const GemmPrepArgs &a, int blk, 
     // One loop over both families of constants: per (chunk, column) [bias, csum] and per (K-step of 16 features, column)
     // [bias_ks, ksum; also the per-slice sums of the small-batch kernel below].
     const int n_c = NCH * 4 * I, n_k = NKS * 4 * I;
-    for (int e = tid; e < n_c + n_k; e += nth) {
+    for (int e = tid; e < ((a.ablate & 4) ? 0 : n_c + n_k); e += nth) {
         const bool chunk = e < n_c;
         const int ee = chunk ? e : e - n_c;
         const int col = ee % (4 * I), c = ee / (4 * I);

@@ -145,9 +145,11 @@ __global__ __launch_bounds__(256) void params_fingerprint_kernel(const FpArgs a)
     if (threadIdx.x == 0) {
         unsigned *tick = reinterpret_cast<unsigned *>(a.state + 2);
         atomicAdd(a.state + 1, part[0] + part[1] + part[2] + part[3]);
-        __threadfence();
-        if (atomicAdd(tick, 1u) == gridDim.x - 1) {   // last block: every partial sum has arrived
-            __threadfence();
+        // (the partial results above are device-scope atomics: their acknowledgement is all the release there is to wait for;
+        // a __threadfence() writes back this XCD's L2 -- 17 .. 40 us behind a kernel that left it dirty, round-4 measurement)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        if (atomicAdd(tick, 1u) == gridDim.x - 1) {   // last block: every partial sum has arrived (read back with atomics)
             const unsigned long long sum = atomicExch(a.state + 1, 0ull);
             tick[1] = (!a.verify || sum != a.state[0]) ? 1u : 0u;
             a.state[0] = sum;

@@ -339,6 +339,9 @@ class ProdSumFn(torch.autograd.Function):
         return gx, gw, None, None
 
 
+_LEVEL_BACKWARD = [True]     # (tests and A/B measurements switch the single-launch level backward off here)
+
+
 def _prodsum_backward(x, w, out, g, ws: Workspace, root: bool, need_gx: bool, need_gw: bool):
     """Backward of a folded level from its saved (input, weight, output): the product tensor recomputed, then the Sum /
     Root layer's and the ProductLayer's own backward kernels.  ``(x, out)`` may carry a common per-sample shift (the
@@ -347,6 +350,17 @@ def _prodsum_backward(x, w, out, g, ws: Workspace, root: bool, need_gx: bool, ne
     g = require_device_f32(g, 'grad')
     B, R, N = x.shape
     P, st = R // 2, stream_ptr(x.device)
+    if _LEVEL_BACKWARD[0] and x.is_contiguous() and out.is_contiguous():
+        # the level's backward in one launch (+ the Jacobian of the weight gradient); DPK_EUNSUPPORTED: the chain below
+        S = w.shape[0] if root else w.shape[1]
+        gx = torch.empty_like(x) if need_gx else None
+        gw = torch.empty_like(w) if need_gw else None
+        buf = _sum_ws(ws, B, P, N * N, S, x.device)
+        rc = lib.dpk_prodsum_backward(ptr(x), ptr(w), ptr(out), ptr(g), B, R, N, S, int(root), ptr(gx), ptr(gw), ptr(buf),
+                                      buf.numel(), st)
+        if rc != -4:
+            check(rc, 'dpk_prodsum_backward')
+            return gx, gw
     prod = torch.empty((B, P, N * N), dtype=torch.float32, device=x.device)
     check(lib.dpk_product_forward(ptr(x), B, R, N, ptr(prod), st), 'dpk_product_forward')
     gprod = torch.empty_like(prod) if need_gx else None

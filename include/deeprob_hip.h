@@ -193,6 +193,17 @@ int dpk_ratspn_forward(const float *x, int64_t B, int32_t D, const int64_t *mask
                        float *out, float *leaf_out, double *ll_sum, void *ws, int64_t ws_bytes,
                        uint32_t flags, void *stream);
 
+/* Backward of a whole level -- ProductLayer (ratspn.py:272-286) under a SumLayer (:363-378; root = 0: weight
+ * [R/2, S, N*N], out / g [B, R/2, S]) or under the RootLayer (:446-458; root = 1: weight [S, (R/2)*N*N], out / g [B, S]) --
+ * from the level's INPUT in [B, R, N]: the [B, R/2, N*N] product tensor is never formed.  grad_in [B, R, N] and
+ * grad_weight (like weight) may each be NULL.  Equivalent to dpk_product_forward + dpk_sum_backward (dpk_root_backward)
+ * + dpk_product_backward; like them it only uses in - out, so a common per-sample shift of (in, out) is allowed.
+ * ws as dpk_sum_workspace_bytes(B, R/2, N*N, S).  Built for N in {2,4,8}, S in {2,4,8} (sum) / (R/2)*N*N <= 1024 (root);
+ * DPK_EUNSUPPORTED otherwise.                                                                                       */
+int dpk_prodsum_backward(const float *in, const float *weight, const float *out, const float *g, int64_t B, int32_t R,
+                         int32_t N, int32_t S, int32_t root, float *grad_in, float *grad_weight, void *ws,
+                         int64_t ws_bytes, void *stream);
+
 /* RatSpn.forward of a TRAINING step (models/ratspn.py:105-122 under autograd; the loop of torch/routines.py:150-170):
  * the same single launch as dpk_ratspn_forward on the MFMA route, which on its way up also writes what the layers'
  * backward entry points read -- the three launches + three table builds of the per-layer chain become one launch.

@@ -690,7 +690,11 @@ def test_backward_wide_model_vs_oracle(golden):
 
 
 @pytest.mark.parametrize('R,N,S,B,root', [(8, 8, 8, 33, False), (4, 16, 16, 70, False), (6, 5, 3, 17, False),
-                                           (8, 8, 10, 33, True), (2, 16, 1, 5, True)])
+                                           (8, 8, 10, 33, True), (2, 16, 1, 5, True),
+                                           # the single-launch level backward (dpk_prodsum_backward) at its other shapes:
+                                           # several samples per wave, classes in chunks of 8, idle lanes, long tiles
+                                           (8, 2, 2, 70, False), (4, 4, 8, 33, False), (32, 8, 4, 700, False),
+                                           (16, 2, 3, 40, True), (8, 4, 20, 19, True), (16, 8, 1, 5000, True)])
 def test_folded_level_autograd_matches_layer_chain(R, N, S, B, root):
     """ops.ProdSumFn (product + sum / root as one autograd node: folded forward, product recomputed in the backward)
     against the per-layer operators chained: values, input gradient and weight gradient."""
@@ -807,8 +811,17 @@ def test_training_forward_single_launch_matches_layer_chain(golden, B, evidence)
     sd = orc.state_from_npz(g, dtype=torch.float64)
     for k in names:
         sd[k] = sd[k].clone().requires_grad_(True)
+    xo = x.double().cpu()
+    drops = None
+    if evidence == 'marginalised':
+        # (the reference's own backward returns NaN where NaN evidence was touched -- test_gradients_with_marginalised_inputs;
+        # the yardstick is the masked gradient: marginalised terms cut out of the graph)
+        nan_mask = torch.isnan(xo)
+        mask = sd['base_layer.mask']
+        drops = {'leaf': nan_mask[:, mask].unsqueeze(2).expand(-1, -1, sd['base_layer.loc'].shape[1], -1)}
+        xo = torch.where(nan_mask, torch.zeros_like(xo), xo)
     with torch.enable_grad():
-        orc.ratspn_loss(orc.ratspn_forward(sd, x.double().cpu()), None).backward()
+        orc.ratspn_loss(orc.ratspn_forward(sd, xo, drops=drops), None).backward()
     for k, p, a, b in zip(names, params, gf, gc):
         assert torch.isfinite(a).all()
         exact = sd[k].grad.numpy()
@@ -820,28 +833,36 @@ def test_training_forward_single_launch_matches_layer_chain(golden, B, evidence)
 
 def test_training_forward_classes_and_stale_tables(golden):
     """10 classes; then a parameter written through .data between two training forwards (no version bump): the second
-    forward's in-launch table check finds it and both values and gradients follow the new parameters."""
+    forward's in-launch table check finds it and both values and gradients follow the new parameters.  Yardstick: the
+    oracle's fp64 autograd (the cross-entropy gradient cancels: the fp32 restatement itself sits up to ~1e-3 from fp64)."""
     from deeprob.spn.models import GaussianRatSpn
     torch.manual_seed(0)
     model = GaussianRatSpn(784, out_classes=10, rg_depth=2, rg_repetitions=8, rg_batch=8, rg_sum=8, random_state=3).cuda().train()
     x = torch.randn(70, 784, device='cuda')
     y = torch.randint(0, 10, (70,), device='cuda')
-    params = [p for p in model.parameters() if p.requires_grad]
+    names = [k for k, p in model.named_parameters() if p.requires_grad]
+    params = [p for k, p in model.named_parameters() if p.requires_grad]
 
-    def both():
-        res = []
+    def oracle(dtype):
+        sd = {k: (v.detach().cpu().to(dtype) if v.is_floating_point() else v.detach().cpu()) for k, v in model.state_dict().items()}
+        for k in names:
+            sd[k] = sd[k].clone().requires_grad_(True)
+        with torch.enable_grad():
+            out = orc.ratspn_forward(sd, x.cpu().to(dtype))
+            orc.ratspn_loss(out, y.cpu()).backward()
+        return out.detach().double().numpy(), [sd[k].grad.double().numpy() for k in names]
+
+    for trial in range(2):
+        out64, g64 = oracle(torch.float64)
+        _, g32 = oracle(torch.float32)
         for declined in (False, True):
             model._train_fused_declined = declined
             out = model(x)
-            res.append((out.detach(), torch.autograd.grad(model.loss(out, y), params)))
+            grads = torch.autograd.grad(model.loss(out, y), params)
+            assert rel_err(out.detach().cpu().numpy(), out64) <= LL_TOL
+            for k, a, e64, e32 in zip(names, grads, g64, g32):
+                assert grad_err(a.cpu().numpy(), e64) <= max(GRAD_TOL, 4.0 * grad_err(e32, e64)), (k, declined, trial)
         model._train_fused_declined = False
-        return res
-
-    for trial in range(2):
-        (of, gf), (oc, gc) = both()
-        assert rel_err(of.cpu().numpy(), oc.cpu().numpy()) <= 2e-6
-        for a, b in zip(gf, gc):
-            assert grad_err(a.cpu().numpy(), b.cpu().numpy()) <= 2 * GRAD_TOL
         model.base_layer.loc.data.add_(0.3)
         model.root_layer.weight.data.mul_(0.5)
 
