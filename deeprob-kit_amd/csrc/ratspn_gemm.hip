@@ -386,8 +386,8 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
     const bool wide = I == 8;
     const bool small = !wide && B <= gemm_small_max_batch() && gemm_small_shape_ok(D, NT);
     const bool emitting = emit != nullptr;
-    if (emitting && !wide) {   // (training forward: the 8-channel 32-sample kernel so far)
-        set_error("ratspn_forward_train: channels=%d at %lld samples not built", I, (long long)B);
+    if (emitting && !wide && !small) {   // (training forward: the 32-sample kernels)
+        set_error("ratspn_forward_train: channels=%d at %lld samples not built (dpk_ratspn_small_batch_max)", I, (long long)B);
         return DPK_EUNSUPPORTED;
     }
     // The tables.  "Believed current -- check" (DPK_FLAG_PARAMS_VERIFY) costs the 32-sample mappings nothing extra: their

@@ -285,10 +285,15 @@ __device__ __forceinline__ void gemm_prep_block(const GemmPrepArgs &a, int blk, 
     float *ksum = csum + NCH * 4 * I;   // [NKS][4I]
     unsigned char *padl = reinterpret_cast<unsigned char *>(ksum + NKS * 4 * I);   // [4 d] padding flags
     const int n4 = 4 * I * d;
-    constexpr int KB = 16;
+    constexpr int KB = 2 * I;       // first batch = the whole repetition at D <= 1024 with 512 threads (predicated-off loads still cost issue slots and code)
     unsigned vl[KB], vs[KB];
+    long long mk[2];
+    unsigned pd[2];
     const unsigned *wl = reinterpret_cast<const unsigned *>(a.loc) + (int64_t)rho * n4;
     const unsigned *wsc = reinterpret_cast<const unsigned *>(a.scale) + (int64_t)rho * n4;
+    const int64_t m0 = (int64_t)rho * 4 * d;
+    // ---- the fingerprint first (a checking launch's verdict waits for it): every first-batch load in flight at once, the
+    // values stay in registers for the tables
     if (real) {
 #pragma unroll
         for (int k = 0; k < KB; ++k) {
@@ -296,27 +301,50 @@ __device__ __forceinline__ void gemm_prep_block(const GemmPrepArgs &a, int blk, 
             vl[k] = e < n4 ? wl[e] : 0u;
             vs[k] = e < n4 ? wsc[e] : 0u;
         }
-        h += fp_range_n(a.pad ? a.pad + (int64_t)rho * 4 * d : nullptr, (int64_t)4 * d, 2, tid, nth);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = k * nth + tid;
+            mk[k] = e < 4 * d ? a.mask[m0 + e] : -1;
+            pd[k] = (e < 4 * d && a.pad != nullptr) ? a.pad[m0 + e] : 0u;
+        }
+        h += fp_range_n(a.pad ? a.pad + m0 : nullptr, (int64_t)4 * d, 2, tid, nth);
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            const int e = k * nth + tid;
+            if (e < n4) h += fp_word(vl[k], (unsigned)e * 8u + 3u) + fp_word(vs[k], (unsigned)e * 8u + 4u);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = k * nth + tid;
+            if (e < 4 * d)
+                h += fp_word((unsigned)mk[k], (unsigned)(2 * e) * 8u + 1u) + fp_word((unsigned)(mk[k] >> 32), (unsigned)(2 * e + 1) * 8u + 1u);
+        }
+        // (larger models: the batches behind the first)
+        for (int e = KB * nth + tid; e < n4; e += nth) h += fp_word(wl[e], (unsigned)e * 8u + 3u) + fp_word(wsc[e], (unsigned)e * 8u + 4u);
+        for (int e = 2 * nth + tid; e < 4 * d; e += nth) {
+            const long long mv = a.mask[m0 + e];
+            h += fp_word((unsigned)mv, (unsigned)(2 * e) * 8u + 1u) + fp_word((unsigned)(mv >> 32), (unsigned)(2 * e + 1) * 8u + 1u);
+        }
     }
+    if (!decide(h)) return;
+    // ---- rebuilding: positions, padding flags and means into LDS -------------------------------------------------------
     for (int f = tid; f < D; f += nth) posrow[f] = -1;
     if (tid == 0) bad_s = 0;
     __syncthreads();
     if (real) {
         for (int e0 = 0; e0 < 4 * d; e0 += 2 * nth) {
-            long long mk[2];
-            unsigned pd[2];
+            if (e0 > 0) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int e = e0 + k * nth + tid;
-                mk[k] = e < 4 * d ? a.mask[(int64_t)rho * 4 * d + e] : -1;
-                pd[k] = (e < 4 * d && a.pad != nullptr) ? a.pad[(int64_t)rho * 4 * d + e] : 0u;
+                for (int k = 0; k < 2; ++k) {
+                    const int e = e0 + k * nth + tid;
+                    mk[k] = e < 4 * d ? a.mask[m0 + e] : -1;
+                    pd[k] = (e < 4 * d && a.pad != nullptr) ? a.pad[m0 + e] : 0u;
+                }
             }
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int e = e0 + k * nth + tid;
                 if (e < 4 * d) {
-                    h += fp_word((unsigned)mk[k], (unsigned)(2 * e) * 8u + 1u) +
-                         fp_word((unsigned)(mk[k] >> 32), (unsigned)(2 * e + 1) * 8u + 1u);
                     padl[e] = (unsigned char)(pd[k] != 0u);
                     const int q = e / d;
                     if (!pd[k] && mk[k] >= 0 && mk[k] < D) posrow[(int)mk[k]] = (q << PSH) | (e - q * d);
@@ -345,7 +373,6 @@ __device__ __forceinline__ void gemm_prep_block(const GemmPrepArgs &a, int blk, 
             for (int k = 0; k < KB; ++k) {
                 const int e = e0 + k * nth + tid;
                 if (e < n4) {
-                    h += fp_word(vl[k], (unsigned)e * 8u + 3u) + fp_word(vs[k], (unsigned)e * 8u + 4u);
                     const float mu = __uint_as_float(vl[k]);
                     locs[e] = mu;
                     const int rr = quo / I;                   // region of the repetition: e / (I d)
@@ -356,7 +383,6 @@ __device__ __forceinline__ void gemm_prep_block(const GemmPrepArgs &a, int blk, 
             }
         }
     }
-    if (!decide(h)) return;
     if (a.ablate & 1) return;
     if (bad) bad_s = 1;
     __syncthreads();

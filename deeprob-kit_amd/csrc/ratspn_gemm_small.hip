@@ -91,7 +91,7 @@ __device__ __forceinline__ void row16_lse_merge(float &m, float &sum) {
 // `raw0` / `rawr` non-null (a launch that found its tables stale, ratspn_gemm_prep.h): the nodes take their log-softmax
 // weights straight from the raw sum / root weights instead of the (being rebuilt) tables.
 template <int I, int S, class Store>
-__device__ __forceinline__ void small_exact_wave(const GemmArgs &a, const float *xr, int rc, int p, bool active,
+__device__ __forceinline__ void small_exact_wave(const GemmArgs &a, const float *xr, int64_t emit_b, int rc, int p, bool active,
                                                  LseScratch sc, const float *raw0, const float *rawr, Store store) {
     const int d = a.d;
     float leaf[2][I];
@@ -117,6 +117,14 @@ __device__ __forceinline__ void small_exact_wave(const GemmArgs &a, const float 
     const int64_t wo = ((int64_t)rc * 2 + p) * S * I * I;
     if (raw0 != nullptr) prodsum_node_raw<I, S>(leaf[0], leaf[1], raw0 + wo, sc.slot, n1);
     else prodsum_node<I, S>(leaf[0], leaf[1], a.W0 + wo, a.LW0 + wo, sc, n1);
+    if (a.emit_leaf != nullptr && active && emit_b >= 0) {   // (training forward: the exact values, no shift)
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+            for (int k = 0; k < I; ++k) a.emit_leaf[(emit_b * (4 * a.reps) + rc * 4 + 2 * p + qq) * I + k] = leaf[qq][k];
+#pragma unroll
+        for (int o = 0; o < S; ++o) a.emit_sum[(emit_b * (2 * a.reps) + rc * 2 + p) * S + o] = n1[o];
+    }
     float ta[S], tc[S];
 #pragma unroll
     for (int o = 0; o < S; ++o) {
@@ -437,6 +445,17 @@ __global__ __launch_bounds__(kGemmSmallWaves * 64) void ratspn_gemm_small_kernel
         va[k] = leaf[0][k] + cst[0][k];
         vc[k] = leaf[1][k] + cst[1][k];
     }
+    // training forward (dpk_ratspn_forward_train): the leaf / sum layer outputs relative to the sample's quadratic term; a
+    // wave that turns out to need the exact evaluation overwrites its four samples' values below (same lanes, program order)
+    const bool emitting = a.emit_leaf != nullptr;
+    if (emitting && active && b2 < a.B) {
+        float *dst = a.emit_leaf + (b2 * (4 * a.reps) + rc * 4 + 2 * p) * I;
+#pragma unroll
+        for (int k = 0; k < I; ++k) {
+            dst[k] = va[k];
+            dst[I + k] = vc[k];
+        }
+    }
     float ea[I], ec[I];
     const float ma = exp2_children<I>(va, ea), mc = exp2_children<I>(vc, ec);
     float n1[S];
@@ -452,6 +471,10 @@ __global__ __launch_bounds__(kGemmSmallWaves * 64) void ratspn_gemm_small_kernel
         }
         n1[o] = fmaf(__builtin_amdgcn_logf(v), kLn2, ma + mc);
         bad = bad || (v < 1e-30f && active);   // vanished: dominant pair under a vanishing weight
+    }
+    if (emitting && active && b2 < a.B) {
+#pragma unroll
+        for (int o = 0; o < S; ++o) a.emit_sum[(b2 * (2 * a.reps) + rc * 2 + p) * S + o] = n1[o];
     }
     SM_STAMP(8);   // node
     // ---- root: the two partitions of a repetition meet (lane ^ 1), then the repetitions of the sample ------------
@@ -490,7 +513,9 @@ __global__ __launch_bounds__(kGemmSmallWaves * 64) void ratspn_gemm_small_kernel
         }
         bad = bad || (v < 1e-30f && mr > -INFINITY);
         const float tot = row16_sum(v * scale);
-        const float ll = ((mtop > -INFINITY) ? fmaf(__builtin_amdgcn_logf(tot), kLn2, mtop) : -INFINITY) + qterm;
+        const float rel = (mtop > -INFINITY) ? fmaf(__builtin_amdgcn_logf(tot), kLn2, mtop) : -INFINITY;
+        const float ll = rel + qterm;
+        if (emitting && writer) a.emit_out[b2 * a.C + cl] = rel;
         if (cl < 4) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -506,9 +531,12 @@ __global__ __launch_bounds__(kGemmSmallWaves * 64) void ratspn_gemm_small_kernel
         LseScratch sc{reinterpret_cast<float *>(smem_generic + wave * REG + SLOT * 4) + lane * (2 * NMAX)};
         const float *xr = a.x + (b2 < a.B ? b2 : a.B - 1) * D;
         part = 0.0;
-        small_exact_wave<I, S>(a, xr, rc, p, active, sc, tables_stale ? pa.w[0] : nullptr, tables_stale ? pa.w[1] : nullptr,
-                               [&](int cl, float ll) {
-            if (writer) a.out[b2 * a.C + cl] = ll;
+        small_exact_wave<I, S>(a, xr, b2 < a.B ? b2 : (int64_t)-1, rc, p, active, sc, tables_stale ? pa.w[0] : nullptr,
+                               tables_stale ? pa.w[1] : nullptr, [&](int cl, float ll) {
+            if (writer) {
+                a.out[b2 * a.C + cl] = ll;
+                if (emitting) a.emit_out[b2 * a.C + cl] = ll;
+            }
             part += (double)ll;
         });
     } else if (writer) {

@@ -104,21 +104,49 @@ __global__ __launch_bounds__(256) void upper_tables_kernel(const float *__restri
     }
     const int row = blockIdx.x;
     const float *src = w + (int64_t)row * n;
+    // rows of up to 2048 weights are read ONCE, every load in flight together (three passes over global memory were three
+    // dependent round trips of this 7 us launch)
+    constexpr int RV = 8;
+    const bool fits = n <= 256 * RV;
+    float v[RV];
+    if (fits) {
+#pragma unroll
+        for (int k = 0; k < RV; ++k) v[k] = (tid + 256 * k < n) ? src[tid + 256 * k] : -INFINITY;
+    }
     float m = -INFINITY;
-    for (int i = tid; i < n; i += blockDim.x) m = fmaxf(m, src[i]);
+    if (fits) {
+#pragma unroll
+        for (int k = 0; k < RV; ++k) m = fmaxf(m, v[k]);
+    } else {
+        for (int i = tid; i < n; i += blockDim.x) m = fmaxf(m, src[i]);
+    }
     m = wave_reduce_max(m);
     if (lane == 0) red[wave] = m;
     __syncthreads();
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float sum = 0.f;
-    for (int i = tid; i < n; i += blockDim.x) sum += expf(src[i] - m);
+    if (fits) {
+#pragma unroll
+        for (int k = 0; k < RV; ++k)
+            if (tid + 256 * k < n) sum += expf(v[k] - m);
+    } else {
+        for (int i = tid; i < n; i += blockDim.x) sum += expf(src[i] - m);
+    }
     sum = wave_reduce_sum(sum);
     if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
     const float ls = logf((red[4] + red[5]) + (red[6] + red[7]));
     const int NN = N * N;
-    for (int e = tid; e < n; e += blockDim.x) {
-        const float l = src[e] - m - ls, wl = expf(l);
+    for (int e = tid, kk = 0; e < n; e += blockDim.x, ++kk) {
+        float sv;
+        if (fits) {
+            sv = v[0];
+#pragma unroll
+            for (int k = 1; k < RV; ++k) sv = (kk == k) ? v[k] : sv;
+        } else {
+            sv = src[e];
+        }
+        const float l = sv - m - ls, wl = expf(l);
         LW[(int64_t)row * n + e] = l;
         W[(int64_t)row * n + e] = wl;
         int p, o, t, r;

@@ -100,6 +100,7 @@ class RatSpn(ProbabilisticModel):
 
         self._fused_declined = False
         self._train_fused_declined = False
+        self._train_fused_max_batch = 1 << 62
         self._fused_ctx = ops.LeafContext(
             self.in_features, self.base_layer.in_regions, self.rg_batch, self.base_layer.dimension,
             depth=self.rg_depth, reps=rg_repetitions, sums=self.rg_sum, classes=self.out_classes
@@ -126,7 +127,7 @@ class RatSpn(ProbabilisticModel):
         base = self.base_layer
         if self._train_fused_declined or not isinstance(base, GaussianLayer) or self.rg_depth != 2:
             return None
-        if base.scale.requires_grad or x.requires_grad or not x.is_cuda:
+        if base.scale.requires_grad or x.requires_grad or not x.is_cuda or x.shape[0] > self._train_fused_max_batch:
             return None
         if self.training and (self.in_dropout is not None or self.sum_dropout is not None):
             return None
@@ -138,9 +139,12 @@ class RatSpn(ProbabilisticModel):
                                        self.root_layer.weight, self._fused_ctx, base._leaf_ctx, layers[1]._ws,
                                        self.root_layer._ws)
         if out is None:
-            # (declined on the model's constants -- channels, sums, classes: do not ask again; a batch-size dependent
-            # refusal of the 2 / 4 channel kernels is asked again, it costs one failed call)
-            self._train_fused_declined = self.rg_batch == 8
+            # (8 channels: declined on the model's constants -- sums, classes, repetitions: do not ask again; the 2 / 4
+            # channel kernels stop at dpk_ratspn_small_batch_max samples: do not ask again for batches this large)
+            if self.rg_batch == 8:
+                self._train_fused_declined = True
+            else:
+                self._train_fused_max_batch = min(self._train_fused_max_batch, x.shape[0] - 1)
         return out
 
     def _prefer_folded(self, x: torch.Tensor) -> bool:

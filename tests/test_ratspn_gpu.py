@@ -769,12 +769,13 @@ def test_eight_channel_route_follows_the_library_envelope(D, one_launch):
 
 @pytest.mark.parametrize('B', [1, 37, 512])
 @pytest.mark.parametrize('evidence', ['plain', 'marginalised', 'huge'])
-def test_training_forward_single_launch_matches_layer_chain(golden, B, evidence):
+@pytest.mark.parametrize('name', ['ratspn_g784_d2_r8_i8_s8', 'ratspn_g784_d2_r8_i2_s2'])
+def test_training_forward_single_launch_matches_layer_chain(golden, name, B, evidence):
     """ops.RatSpnTrainFn (dpk_ratspn_forward_train: the evaluation kernel writing the leaf / sum layer outputs relative to
     the sample's quadratic term, the layers' backward kernels on those) against the per-layer autograd chain of the same
     model: log-likelihoods and every parameter gradient; NaN evidence (validity GEMM) and evidence beyond the expansion
     bound (exact per-element leaf sums) included.  reference: models/ratspn.py:105-122 under autograd."""
-    model, g = build('ratspn_g784_d2_r8_i8_s8', golden)
+    model, g = build(name, golden)
     model.train()
     gen = torch.Generator().manual_seed(5 + B)
     x = torch.randn(B, 784, generator=gen)
@@ -867,10 +868,10 @@ def test_training_forward_classes_and_stale_tables(golden):
         model.root_layer.weight.data.mul_(0.5)
 
 
-def test_training_forward_golden_gradients(golden):
+@pytest.mark.parametrize('name', ['ratspn_g784_d2_r8_i8_s8', 'ratspn_g784_d2_r8_i2_s2'])
+def test_training_forward_golden_gradients(golden, name):
     """The reference's own parameter gradients (fixture generated by importing the reference) through the single-launch
     training forward: test_backward_golden asks for the input gradient too, which keeps it on the layer chain."""
-    name = 'ratspn_g784_d2_r8_i8_s8'
     model, g = build(name, golden)
     x = torch.from_numpy(g['x']).cuda()
     y = torch.from_numpy(g['y']).cuda() if 'y' in g.files else None
