@@ -483,6 +483,40 @@ __device__ __forceinline__ void gemm_prep_block(const GemmPrepArgs &a, int blk, 
     if (tid == 0) a.elig[rho] = bad_s ? 0 : 1;
 }
 
+// ---- table work-groups inside a model kernel's launch (kPrepInline) ------------------------------------------------------
+// A clean launch -- every launch but the one after a parameter changed -- only needs the fingerprint and the verdict: the
+// compact loops of gemm_prep_hash_share, nothing staged, nothing kept in registers for a rebuild that does not happen.
+// Measured, same box, (2,2) at B = 4096 per graph-replayed model(x): this form 9.87 us; gemm_prep_block's own
+// loads-first fingerprint (built for the rebuilding launches of a training step) 10.40 us; the rebuild behind a noinline
+// call 15.6 us default AND 12.9 us trusted -- the call makes the kernel use 536 bytes of scratch per lane, which costs
+// 3.5 us per launch whether or not the call is ever made (the 0.2 us of tools/ubench/scratch_cost.hip was for 64 bytes).
+template <int I>
+__device__ __forceinline__ void gemm_prep_rebuild_cold(const GemmPrepArgs *a, int blk, int *dyn) {
+    GemmPrepArgs b = *a;
+    b.mode = kPrepBuild;
+    gemm_prep_block<I>(b, blk, dyn);
+}
+template <int I>
+__device__ __forceinline__ void gemm_prep_block_inline(const GemmPrepArgs &a, int blk, int *dyn) {
+    unsigned long long *red_s = reinterpret_cast<unsigned long long *>(dyn);   // [17]
+    unsigned *vi_s = reinterpret_cast<unsigned *>(dyn) + 34;                    // [2]
+    const unsigned long long stored = a.hash[blk];                             // (requested first)
+    unsigned long long h = threadIdx.x == 0 ? kPrepHashBase + (unsigned long long)blk : 0ull;
+    h += gemm_prep_hash_share<I>(a, blk, (int)threadIdx.x, (int)blockDim.x);
+    h = block_sum_u64(h, red_s);
+    if (threadIdx.x == 0) {
+        vi_arrive(a.ctl, stored != h);
+        unsigned ticket;
+        const bool dirty = vi_wait(a.ctl, a.np, ticket);
+        vi_done(a.ctl, ticket, a.readers);
+        vi_s[0] = dirty ? 1u : 0u;
+    }
+    __syncthreads();
+    if (vi_s[0] == 0u) return;                                                 // clean launch: nothing to do
+    __syncthreads();
+    gemm_prep_rebuild_cold<I>(&a, blk, dyn);
+}
+
 // ---- the table-free nodes of a dirty launch --------------------------------------------------------------------------
 // out[o] = logsumexp_{i,j}(a[i] + c[j] + log_softmax(w[o, :])[i, j]) straight from the RAW weights w [NO][NI*NI]
 // (ProductLayer.forward ratspn.py:280-285 followed by SumLayer.forward :375-377): two log-sum-exps per node, rolled

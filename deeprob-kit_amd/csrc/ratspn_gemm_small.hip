@@ -180,7 +180,7 @@ __global__ __launch_bounds__(kGemmSmallWaves * 64) void ratspn_gemm_small_kernel
     // the table work-groups -- fingerprint, verdict, rebuild if stale -- the others evaluate tile blockIdx.x - pa.np.
     const int np = pa.np;
     if ((int)blockIdx.x < np) {
-        gemm_prep_block<I>(pa, (int)blockIdx.x, reinterpret_cast<int *>(smem_generic));
+        gemm_prep_block_inline<I>(pa, (int)blockIdx.x, reinterpret_cast<int *>(smem_generic));
         return;
     }
     const int D = a.D;

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const
     // the table work-groups -- fingerprint, verdict, rebuild if stale -- the others evaluate block blockIdx.x - pa.np.
     const int np = pa.np;
     if ((int)blockIdx.x < np) {
-        gemm_prep_block<kWideI>(pa, (int)blockIdx.x, reinterpret_cast<int *>(smem_generic));
+        gemm_prep_block_inline<kWideI>(pa, (int)blockIdx.x, reinterpret_cast<int *>(smem_generic));
         return;
     }
     const int D = a.D, NT = a.reps;
