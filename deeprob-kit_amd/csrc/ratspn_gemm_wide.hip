@@ -504,8 +504,10 @@ __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const
     // Whole groups of PF K-steps first: straight-line code, the fragment loads unconditional (a load behind a branch makes
     // hipcc wait for ALL outstanding loads at the join).  The row's last K-steps after them, without prefetch.
     int k0 = 0;
+    unsigned long long peeked = 0ull;     // the launch's verdict word as of the last full group of K-steps (np > 0)
     if (!(a.ablate & 1)) {
         for (; k0 + PF <= NKS; k0 += PF) {
+            peeked = vi_peek(pa.ctl);      // (unconditional, every thread, one request per wave: the last group's is the one used)
 #pragma unroll
             for (int k = 0; k < PF; ++k) {
                 kstep(k, k0 + k);
@@ -539,7 +541,11 @@ __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const
     // the launch's verdict on its tables (np > 0): published long ago by the table work-groups -- one L2 round trip for
     // thread 0 under the other waves' K loops; the barrier below hands it to everyone
     unsigned vi_ticket = 0u;
-    if (np > 0 && tid == 0) tail->verdict = vi_wait(pa.ctl, np, vi_ticket) ? 1 : 0;
+    if (np > 0 && tid == 0) {
+        tail->verdict = vi_verdict(pa.ctl, np, peeked) ? 1 : 0;
+        // (the reader ticket: requested now, looked at when the work-group leaves -- nothing in between waits for it)
+        vi_ticket = __hip_atomic_fetch_add(&pa.ctl->readers, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     __syncthreads();   // every wave is done with the x tile: its LDS becomes scratch and the root exchange buffer
     const bool tables_stale = np > 0 && tail->verdict != 0;
