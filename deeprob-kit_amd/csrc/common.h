@@ -319,6 +319,7 @@ __device__ __forceinline__ unsigned long long fp_word(unsigned w, unsigned pos) 
     return ((unsigned long long)(b ^ (b >> 16)) << 32) | (unsigned long long)(a ^ (a >> 13));
 }
 // (tid of nthreads: the threads that share the range -- the whole block by default; the sum over them is what counts)
+template <bool PRED_TAIL = false>
 __device__ __forceinline__ unsigned long long fp_range_n(const void *p, int64_t bytes, unsigned tag, int tid, int nthreads) {
     unsigned long long h = 0ull;
     if (p == nullptr) return h;
@@ -326,6 +327,21 @@ __device__ __forceinline__ unsigned long long fp_range_n(const void *p, int64_t 
         // (four loads in flight per thread: one load per trip made this pass latency bound -- 11 us for 26 KB)
         const unsigned *w = (const unsigned *)p;
         const int n = (int)(bytes >> 2), step = nthreads;
+        // PRED_TAIL: the ragged end predicated instead of a one-load-per-trip tail loop (1568 words over 512 threads are three
+        // dependent round trips in the tail for all but 32 threads).  Same sum.  Measured on the in-launch table check at
+        // B = 4096, same box: 8-channel kernel 20.7 -> 20.25 us per call with it, the (2,2) small-batch kernel 9.9 -> 10.45 us
+        // (its work-groups have every load of their own in flight in the first microseconds; a fingerprint that spreads its
+        // requests out disturbs them less) -- so the caller chooses.
+        if constexpr (PRED_TAIL) {
+        for (int e = tid; e < n; e += 4 * step) {
+            const bool p1 = e + step < n, p2 = e + 2 * step < n, p3 = e + 3 * step < n;
+            const unsigned w0 = w[e], w1 = p1 ? w[e + step] : 0u, w2 = p2 ? w[e + 2 * step] : 0u, w3 = p3 ? w[e + 3 * step] : 0u;
+            h += fp_word(w0, (unsigned)e * 8u + tag);
+            if (p1) h += fp_word(w1, (unsigned)(e + step) * 8u + tag);
+            if (p2) h += fp_word(w2, (unsigned)(e + 2 * step) * 8u + tag);
+            if (p3) h += fp_word(w3, (unsigned)(e + 3 * step) * 8u + tag);
+        }
+        } else {
         int e = tid;
         for (; e + 3 * step < n; e += 4 * step) {
             const unsigned w0 = w[e], w1 = w[e + step], w2 = w[e + 2 * step], w3 = w[e + 3 * step];
@@ -333,6 +349,7 @@ __device__ __forceinline__ unsigned long long fp_range_n(const void *p, int64_t 
                  fp_word(w2, (unsigned)(e + 2 * step) * 8u + tag) + fp_word(w3, (unsigned)(e + 3 * step) * 8u + tag);
         }
         for (; e < n; e += step) h += fp_word(w[e], (unsigned)e * 8u + tag);
+        }
     } else {
         const unsigned char *b = (const unsigned char *)p;
         for (int64_t e = tid; e < bytes; e += nthreads) h += fp_word(b[e], (unsigned)e * 8u + tag + 4u);
@@ -340,7 +357,7 @@ __device__ __forceinline__ unsigned long long fp_range_n(const void *p, int64_t 
     return h;
 }
 __device__ __forceinline__ unsigned long long fp_range(const void *p, int64_t bytes, unsigned tag) {
-    return fp_range_n(p, bytes, tag, (int)threadIdx.x, (int)blockDim.x);
+    return fp_range_n<false>(p, bytes, tag, (int)threadIdx.x, (int)blockDim.x);
 }
 // sum of a 64-bit value over the block, returned to every thread (red: 17 words of LDS; blockDim a multiple of 64)
 __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long h, unsigned long long *red) {

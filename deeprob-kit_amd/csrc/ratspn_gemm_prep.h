@@ -169,10 +169,10 @@ __device__ __forceinline__ unsigned long long gemm_prep_hash_share(const GemmPre
     if (blk < nrb) {
         if (blk < a.reps) {
             const int rho = blk;
-            h += fp_range_n(a.mask + (int64_t)rho * 4 * d, (int64_t)4 * d * 8, 1, tid, nthreads);
-            h += fp_range_n(a.pad ? a.pad + (int64_t)rho * 4 * d : nullptr, (int64_t)4 * d, 2, tid, nthreads);
-            h += fp_range_n(a.loc + (int64_t)rho * 4 * I * d, (int64_t)4 * I * d * 4, 3, tid, nthreads);
-            h += fp_range_n(a.scale + (int64_t)rho * 4 * I * d, (int64_t)4 * I * d * 4, 4, tid, nthreads);
+            h += fp_range_n<I == 8>(a.mask + (int64_t)rho * 4 * d, (int64_t)4 * d * 8, 1, tid, nthreads);
+            h += fp_range_n<I == 8>(a.pad ? a.pad + (int64_t)rho * 4 * d : nullptr, (int64_t)4 * d, 2, tid, nthreads);
+            h += fp_range_n<I == 8>(a.loc + (int64_t)rho * 4 * I * d, (int64_t)4 * I * d * 4, 3, tid, nthreads);
+            h += fp_range_n<I == 8>(a.scale + (int64_t)rho * 4 * I * d, (int64_t)4 * I * d * 4, 4, tid, nthreads);
         }
     } else {
         // the raw weight rows this work-group normalises (fingerprints are per work-group of kGemmPrepThreads / 64 rows)
@@ -184,7 +184,7 @@ __device__ __forceinline__ unsigned long long gemm_prep_hash_share(const GemmPre
             for (int m = 0; m < 3; ++m) {
                 if (rr < a.rows[m]) {
                     // (position-dependent through the row number: rows that trade places change the sum)
-                    h += fp_range_n(a.w[m] + (int64_t)rr * a.n[m], (int64_t)a.n[m] * 4, 5u + 8192u * (unsigned)row, tid, nthreads);
+                    h += fp_range_n<I == 8>(a.w[m] + (int64_t)rr * a.n[m], (int64_t)a.n[m] * 4, 5u + 8192u * (unsigned)row, tid, nthreads);
                     break;
                 }
                 rr -= a.rows[m];
