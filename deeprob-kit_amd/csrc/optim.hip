@@ -11,6 +11,7 @@
 // graph: every work-group reads it, the LAST work-group to finish increments it for the next launch.
 #include "common.h"
 #include <math.h>
+#include <algorithm>
 
 namespace dpk {
 
@@ -76,9 +77,43 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamArgs a) {
     }
 }
 
+// loss = -mean(x) (RatSpn.loss / DgcSpn.loss / NormalizingFlow.loss with one class: models/ratspn.py:184-191) and its
+// gradient -g / n: torch runs mean, neg and their two backward nodes as four launches -- 12 us of a 140 us training step.
+__global__ __launch_bounds__(1024) void neg_mean_kernel(const float *__restrict__ x, int64_t n, float *__restrict__ out) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += (double)x[i];
+    s = wave_reduce_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        out[0] = (float)(-t / (double)n);
+    }
+}
+__global__ void neg_mean_bwd_kernel(const float *__restrict__ gout, int64_t n, float *__restrict__ gx) {
+    const float v = -gout[0] / (float)n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) gx[i] = v;
+}
+
 }  // namespace dpk
 
 using namespace dpk;
+
+extern "C" int dpk_neg_mean_forward(const float *x, int64_t n, float *out, void *stream) {
+    DPK_REQUIRE(x && out && n > 0, DPK_EINVAL, "neg_mean_forward: bad arguments");
+    DPK_LAUNCH(neg_mean_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, out);
+    DPK_CHECK_LAUNCH("neg_mean_kernel");
+    return DPK_OK;
+}
+extern "C" int dpk_neg_mean_backward(const float *grad_out, int64_t n, float *grad_x, void *stream) {
+    DPK_REQUIRE(grad_out && grad_x && n > 0, DPK_EINVAL, "neg_mean_backward: bad arguments");
+    const int blocks = (int)std::min<int64_t>(1024, cdiv(n, 256));
+    DPK_LAUNCH(neg_mean_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grad_out, n, grad_x);
+    DPK_CHECK_LAUNCH("neg_mean_bwd_kernel");
+    return DPK_OK;
+}
 
 extern "C" int dpk_adam_step(int32_t n, const dpk_adam_tensor *tensors, float lr, float beta1, float beta2, float eps,
                              float weight_decay, int32_t maximize, float *step, uint32_t *ticket, void *stream) {

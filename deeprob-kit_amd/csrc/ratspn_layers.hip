@@ -423,77 +423,101 @@ __global__ __launch_bounds__(256) void leaf_bwd_param_kernel(
 // permutation) and g[b, r, k] depends on the entry's region -- from global memory those were 5 uncoalesced loads per entry
 // and sample, 53 us of the (8,8) training step at B = 512; staged, the rows arrive coalesced once per block and the
 // gathers are LDS reads.
-template <int DIST, int CBK>
+// A work-group walks `passes` consecutive 16-sample tiles with its entries' sums in registers (up to 4 entries per thread)
+// and adds them to memory once: the atomics -- 32 per parameter at B = 512 with one tile per work-group, 1.6 M in all --
+// were a third of the kernel.
+template <int DIST, int CBK, bool WANT1>
 __global__ __launch_bounds__(256) void leaf_bwd_param_lds_kernel(
     const float *__restrict__ x, const float *__restrict__ g, int64_t B, int D, int R, int I, int d, int SP,
     const int *__restrict__ feat, const int *__restrict__ srcr, const float *__restrict__ p0,
-    const float *__restrict__ p1, float *__restrict__ gp0, float *__restrict__ gp1, int tile) {
+    const float *__restrict__ p1, float *__restrict__ gp0, float *__restrict__ gp1, int tile, int passes) {
     extern __shared__ float leaf_bwd_sm[];
     float *xs = leaf_bwd_sm, *gs = leaf_bwd_sm + (size_t)tile * D;   // xs[tile][D], gs[tile][R][CBK]
+    constexpr int EMAX = 4;             // entries per thread (the host checks SP <= 4 * 256 before asking for passes > 1)
     const int grp = blockIdx.y;
     const int kb = blockIdx.z * CBK;
-    const int64_t b0 = (int64_t)blockIdx.x * tile;
-    const int nb = (int)(min(b0 + tile, B) - b0);
-    {
-        const float *xsrc = x + b0 * D;
-        const int tot = nb * D;
-        if ((D & 3) == 0) {
-            for (int i = threadIdx.x * 4; i < tot; i += blockDim.x * 4)
-                *reinterpret_cast<float4 *>(xs + i) = *reinterpret_cast<const float4 *>(xsrc + i);
-        } else {
-            for (int i = threadIdx.x; i < tot; i += blockDim.x) xs[i] = xsrc[i];
-        }
-        const int gt = nb * R * CBK;
-        for (int i = threadIdx.x; i < gt; i += blockDim.x) {
-            const int bl = i / (R * CBK), rem = i - bl * (R * CBK);
-            const int r = rem / CBK, k = rem - r * CBK;
-            gs[i] = g[((b0 + bl) * R + r) * I + kb + k];
-        }
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < SP; e += blockDim.x) {
-        const int rj = srcr[(int64_t)grp * SP + e];
-        if (rj < 0) continue;
-        const int r = rj / d, j = rj - r * d;
-        const int f = feat[(int64_t)grp * SP + e];
-        float c0[CBK], c1[CBK], c2[CBK], a0[CBK], a1[CBK];
+    // the thread's entries: (region, position), variable, parameters
+    int rr[EMAX], ff[EMAX];
+    int64_t po0[EMAX];
+    float c0[EMAX][CBK], c1[EMAX][CBK], c2[EMAX][CBK], a0[EMAX][CBK], a1[EMAX][CBK];
+#pragma unroll
+    for (int q = 0; q < EMAX; ++q) {
+        const int e = threadIdx.x + q * 256;
+        const int rj = e < SP ? srcr[(int64_t)grp * SP + e] : -1;
+        rr[q] = rj < 0 ? -1 : rj / d;
+        const int j = rj < 0 ? 0 : rj - rr[q] * d;
+        ff[q] = rj < 0 ? 0 : feat[(int64_t)grp * SP + e];
+        po0[q] = ((int64_t)(rj < 0 ? 0 : rr[q]) * I + kb) * d + j;
 #pragma unroll
         for (int k = 0; k < CBK; ++k) {
-            const int64_t po = ((int64_t)r * I + kb + k) * d + j;
-            a0[k] = a1[k] = 0.f;
-            if (DIST == 0) {
-                const float sg = p1[po];
-                c0[k] = p0[po];           // mu
-                c1[k] = 1.f / (sg * sg);  // 1/s^2
-                c2[k] = 1.f / sg;
-            } else {
-                c0[k] = 1.f / (1.f + expf(-p0[po]));  // sigmoid(logit)
-                c1[k] = c2[k] = 0.f;
-            }
-        }
-#pragma unroll 4
-        for (int bl = 0; bl < nb; ++bl) {
-            const float xr = xs[bl * D + f];
-            const bool live = (xr == xr);   // marginalised: no contribution
-            const float xv = live ? xr : 0.f;
-            const float *gp = gs + (bl * R + r) * CBK;
-#pragma unroll
-            for (int k = 0; k < CBK; ++k) {
-                const float gv = live ? gp[k] : 0.f;
+            a0[q][k] = a1[q][k] = 0.f;
+            c0[q][k] = c1[q][k] = c2[q][k] = 0.f;
+            if (rj >= 0) {
+                const int64_t po = po0[q] + (int64_t)k * d;
                 if (DIST == 0) {
-                    const float dl = xv - c0[k];
-                    a0[k] = fmaf(gv, dl * c1[k], a0[k]);
-                    a1[k] = fmaf(gv, dl * dl * c1[k] * c2[k] - c2[k], a1[k]);
+                    const float sg = p1[po];
+                    c0[q][k] = p0[po];           // mu
+                    c1[q][k] = 1.f / (sg * sg);  // 1/s^2
+                    c2[q][k] = 1.f / sg;
                 } else {
-                    a0[k] = fmaf(gv, xv - c0[k], a0[k]);
+                    c0[q][k] = 1.f / (1.f + expf(-p0[po]));  // sigmoid(logit)
                 }
             }
         }
+    }
+    for (int pass = 0; pass < passes; ++pass) {
+        const int64_t b0 = ((int64_t)blockIdx.x * passes + pass) * tile;
+        if (b0 >= B) break;
+        const int nb = (int)(min(b0 + tile, B) - b0);
+        if (pass > 0) __syncthreads();
+        {
+            const float *xsrc = x + b0 * D;
+            const int tot = nb * D;
+            if ((D & 3) == 0) {
+                for (int i = threadIdx.x * 4; i < tot; i += blockDim.x * 4)
+                    *reinterpret_cast<float4 *>(xs + i) = *reinterpret_cast<const float4 *>(xsrc + i);
+            } else {
+                for (int i = threadIdx.x; i < tot; i += blockDim.x) xs[i] = xsrc[i];
+            }
+            const int gt = nb * R * CBK;
+            for (int i = threadIdx.x; i < gt; i += blockDim.x) {
+                const int bl = i / (R * CBK), rem = i - bl * (R * CBK);
+                const int r = rem / CBK, k = rem - r * CBK;
+                gs[i] = g[((b0 + bl) * R + r) * I + kb + k];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < EMAX; ++q) {
+            if (rr[q] < 0) continue;
+#pragma unroll 4
+            for (int bl = 0; bl < nb; ++bl) {
+                const float xr = xs[bl * D + ff[q]];
+                const bool live = (xr == xr);   // marginalised: no contribution
+                const float xv = live ? xr : 0.f;
+                const float *gp = gs + (bl * R + rr[q]) * CBK;
+#pragma unroll
+                for (int k = 0; k < CBK; ++k) {
+                    const float gv = live ? gp[k] : 0.f;
+                    if (DIST == 0) {
+                        const float dl = xv - c0[q][k];
+                        a0[q][k] = fmaf(gv, dl * c1[q][k], a0[q][k]);
+                        if (WANT1) a1[q][k] = fmaf(gv, dl * dl * c1[q][k] * c2[q][k] - c2[q][k], a1[q][k]);
+                    } else {
+                        a0[q][k] = fmaf(gv, xv - c0[q][k], a0[q][k]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < EMAX; ++q) {
+        if (rr[q] < 0) continue;
 #pragma unroll
         for (int k = 0; k < CBK; ++k) {
-            const int64_t po = ((int64_t)r * I + kb + k) * d + j;
-            if (gp0) atomicAdd(gp0 + po, a0[k]);
-            if (DIST == 0 && gp1) atomicAdd(gp1 + po, a1[k]);
+            const int64_t po = po0[q] + (int64_t)k * d;
+            if (gp0) atomicAdd(gp0 + po, a0[q][k]);
+            if (DIST == 0 && WANT1 && gp1) atomicAdd(gp1 + po, a1[q][k]);
         }
     }
 }
@@ -689,13 +713,21 @@ static int leaf_backward_common(int dist, const float *x, const float *g, int64_
         const dim3 grid(cdiv(B, tile), w.G, I / cbk), block(256);
         // (no dropout, rows 16-byte aligned, the tile's rows within 64 KB of LDS: the staged kernel)
         const size_t stage_bytes = (size_t)tile * ((size_t)D + (size_t)R * cbk) * 4;
-        const bool staged = tile == 16 && drop_p == 0.f && stage_bytes <= 64 * 1024 &&
+        const bool staged = tile == 16 && drop_p == 0.f && stage_bytes <= 64 * 1024 && w.SP <= 4 * 256 &&
                             ((D & 3) != 0 || (reinterpret_cast<uintptr_t>(x) & 15) == 0);
+        // tiles per work-group of the staged kernel: as many as keep two work-groups per compute unit busy
+        int passes = 1;
+        if (staged)
+            while (passes < 8 && cdiv(B, tile * passes * 2) * w.G * (I / cbk) >= 2 * device_cus()) passes *= 2;
+        const dim3 sgrid(cdiv(B, tile * passes), w.G, I / cbk);
 #define DPK_LEAF_BWD(DIST, CBK)                                                                                  \
     do {                                                                                                         \
-        if (staged)                                                                                              \
-            DPK_LAUNCH((leaf_bwd_param_lds_kernel<DIST, CBK>), grid, block, stage_bytes, st, x, g, B, D, R, I, d, \
-                       w.SP, w.feat, w.srcr, p0, p1, gp0, gp1, tile);                                            \
+        if (staged && gp1)                                                                                       \
+            DPK_LAUNCH((leaf_bwd_param_lds_kernel<DIST, CBK, true>), sgrid, block, stage_bytes, st, x, g, B, D, R, I, d, \
+                       w.SP, w.feat, w.srcr, p0, p1, gp0, gp1, tile, passes);                                    \
+        else if (staged)                                                                                         \
+            DPK_LAUNCH((leaf_bwd_param_lds_kernel<DIST, CBK, false>), sgrid, block, stage_bytes, st, x, g, B, D, R, I, d, \
+                       w.SP, w.feat, w.srcr, p0, p1, gp0, gp1, tile, passes);                                    \
         else                                                                                                     \
             DPK_LAUNCH((leaf_bwd_param_kernel<DIST, CBK>), grid, block, 0, st, x, g, B, D, R, I, d, w.SP, w.feat, \
                        w.srcr, p0, p1, gp0, gp1, drop_p, seed, tile);                                            \

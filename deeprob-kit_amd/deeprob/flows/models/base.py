@@ -186,4 +186,5 @@ class NormalizingFlow(ProbabilisticModel):
         return x, ldj
 
     def loss(self, x: torch.Tensor, y: Optional[torch.Tensor] = None) -> torch.Tensor:
-        return -torch.mean(x)
+        from deeprob.hip import ops
+        return ops.neg_mean(x)

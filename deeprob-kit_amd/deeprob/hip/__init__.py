@@ -187,6 +187,8 @@ SIGNATURES = {
     'dpk_profile_next_kernel': (ctypes.c_int, [_c_void, _c_void]),
     'dpk_profile_next_kernel_of': (ctypes.c_int, [_c_void, _c_void, _i32]),
     'dpk_ll_accumulate': (ctypes.c_int, [_c_void, _i64, _c_void, _c_void]),
+    'dpk_neg_mean_forward': (ctypes.c_int, [_c_void, _i64, _c_void, _c_void]),
+    'dpk_neg_mean_backward': (ctypes.c_int, [_c_void, _i64, _c_void, _c_void]),
     'dpk_adam_step': (ctypes.c_int, [_i32, _c_void, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                      ctypes.c_float, _i32, _c_void, _c_void, _c_void]),
     'dpk_spatial_prodsum_backward': (ctypes.c_int, [_c_void, _i64] + [_i32] * 13 + [_c_void, _i32, _c_void, _c_void,

@@ -625,3 +625,32 @@ def prodroot_forward(x: torch.Tensor, weight: torch.Tensor, ws: Workspace) -> Op
         return None
     check(rc, 'dpk_prodroot_forward')
     return out
+
+
+class NegMeanFn(torch.autograd.Function):
+    """``-torch.mean(x)``, the generative loss (reference: models/ratspn.py:184-191), one launch forward (fp64
+    accumulation) and one backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = load_library()
+        x = require_device_f32(x, 'x')
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        check(lib.dpk_neg_mean_forward(ptr(x), x.numel(), ptr(out), stream_ptr(x.device)), 'dpk_neg_mean_forward')
+        ctx.shape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load_library()
+        g = require_device_f32(g, 'grad')
+        gx = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        check(lib.dpk_neg_mean_backward(ptr(g), gx.numel(), ptr(gx), stream_ptr(g.device)), 'dpk_neg_mean_backward')
+        return gx
+
+
+def neg_mean(x: torch.Tensor) -> torch.Tensor:
+    """``-torch.mean(x)``; torch's own ops outside the kernel's range (CPU tensors, other dtypes, more than 2^20 entries)."""
+    if x.is_cuda and x.dtype == torch.float32 and 0 < x.numel() <= (1 << 20):
+        return NegMeanFn.apply(x)
+    return -torch.mean(x)

@@ -198,7 +198,8 @@ class DgcSpn(ProbabilisticModel):
 
     def loss(self, x: torch.Tensor, y: Optional[torch.Tensor] = None) -> torch.Tensor:
         if self.out_classes == 1:
-            return -torch.mean(x)
+            from deeprob.hip import ops
+            return ops.neg_mean(x)
         return torch.nn.functional.nll_loss(torch.log_softmax(x, dim=1), y)
 
     def apply_constraints(self):

@@ -292,7 +292,7 @@ class RatSpn(ProbabilisticModel):
     def loss(self, x: torch.Tensor, y: Optional[torch.Tensor] = None) -> torch.Tensor:
         """-mean LL (generative) or cross entropy over classes (reference: ratspn.py:184-191)."""
         if self.out_classes == 1:
-            return -torch.mean(x)
+            return ops.neg_mean(x)
         return torch.nn.functional.nll_loss(torch.log_softmax(x, dim=1), y)
 
 

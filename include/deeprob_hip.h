@@ -517,6 +517,12 @@ typedef struct {
 int dpk_adam_step(int32_t n, const dpk_adam_tensor *tensors, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int32_t maximize, float *step, uint32_t *ticket, void *stream);
 
+/* The generative loss of the three model families, loss = -mean(x) over all n entries (models/ratspn.py:184-191,
+ * models/dgcspn.py loss, flows/models/base.py loss), accumulated in fp64, and its gradient grad_x[i] = -grad_out[0] / n:
+ * one launch each instead of torch's mean + neg and their two backward nodes.  out / grad_out: one float on the device. */
+int dpk_neg_mean_forward(const float *x, int64_t n, float *out, void *stream);
+int dpk_neg_mean_backward(const float *grad_out, int64_t n, float *grad_x, void *stream);
+
 /* sum and count of a vector of log-likelihoods in fp64 (the per-rank partial of
  * the mean-LL all-reduce): acc[0] += sum(ll), acc[1] += n.                   */
 int dpk_ll_accumulate(const float *ll, int64_t n, double *acc, void *stream);

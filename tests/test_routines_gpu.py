@@ -170,3 +170,19 @@ def test_build_optimizer_choices():
     assert type(build_optimizer('adam', ps * 1 + [torch.nn.Parameter(torch.randn(2, device='cuda')) for _ in range(100)],
                                 1e-3, {'fused': True})) is torch.optim.Adam
     assert type(build_optimizer('sgd', ps, 1e-3, {'fused': True})) is torch.optim.SGD
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(1, 1), (512, 1), (4097, 1), (100000,)])
+def test_neg_mean_loss_op(shape):
+    """ops.neg_mean = -torch.mean (models/ratspn.py:184-191): value (fp64 accumulation) and gradient, incl. -inf entries."""
+    from deeprob.hip import ops
+    x = (torch.randn(shape, device='cuda') * 50 - 700).requires_grad_(True)
+    got = ops.neg_mean(x)
+    want = -torch.mean(x.detach().double())
+    assert abs(float(got) - float(want)) <= 1e-6 * abs(float(want))
+    (g,) = torch.autograd.grad(got * 3.0, x)
+    assert torch.allclose(g, torch.full_like(g, -3.0 / x.numel()), rtol=1e-6, atol=0)
+    y = x.detach().clone()
+    y.view(-1)[0] = float('-inf')
+    assert float(ops.neg_mean(y)) == float('inf')
