@@ -718,7 +718,7 @@ static int leaf_backward_common(int dist, const float *x, const float *g, int64_
         // tiles per work-group of the staged kernel: as many as keep two work-groups per compute unit busy
         int passes = 1;
         if (staged)
-            while (passes < 8 && cdiv(B, tile * passes * 2) * w.G * (I / cbk) >= 2 * device_cus()) passes *= 2;
+            while (passes < 8 && cdiv(B, tile * passes * 2) * w.G * (I / cbk) >= 2 * device_cus()) passes *= 2;   // (B = 512: one pass; two measured 32 vs 27 us)
         const dim3 sgrid(cdiv(B, tile * passes), w.G, I / cbk);
 #define DPK_LEAF_BWD(DIST, CBK)                                                                                  \
     do {                                                                                                         \
