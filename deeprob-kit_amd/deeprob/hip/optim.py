@@ -34,13 +34,25 @@ class FusedAdam(torch.optim.Optimizer):
         return (0 < len(params) <= MAX_TENSORS and
                 all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params))
 
-    def _group_state(self, group):
-        key = id(group)
-        st = self.state.setdefault('_dpk_groups', {})
-        if key not in st:
-            dev = group['params'][0].device
-            st[key] = (torch.zeros(1, dtype=torch.float32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev))
-        return st[key]
+    def _group_state(self, group, params):
+        """The group's device-side step count (kept under torch.optim.Adam's state name ``step`` in every parameter's state,
+        one shared tensor: it travels with ``state_dict()`` / ``load_state_dict()``) and its ticket word (scratch, not state)."""
+        dev = params[0].device
+        step_t = None
+        for p in params:
+            st = self.state[p].get('step')
+            if torch.is_tensor(st):
+                step_t = st.to(device=dev, dtype=torch.float32).reshape(1)
+                break
+        if step_t is None:
+            step_t = torch.zeros(1, dtype=torch.float32, device=dev)
+        for p in params:
+            self.state[p]['step'] = step_t
+        tickets = self.__dict__.setdefault('_dpk_tickets', {})
+        key = (id(group), dev)
+        if key not in tickets:
+            tickets[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+        return step_t, tickets[key]
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -50,7 +62,7 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         lib = load_library()
         for group in self.param_groups:
-            entries, keep, touched = [], [], []
+            entries, keep, touched, updated = [], [], [], []
             for p in group['params']:
                 if p.grad is None:
                     continue
@@ -64,15 +76,13 @@ class FusedAdam(torch.optim.Optimizer):
                 entries.append(_AdamTensor(p.data_ptr(), g.data_ptr(), state['exp_avg'].data_ptr(),
                                            state['exp_avg_sq'].data_ptr(), p.numel()))
                 keep.append(g)
+                updated.append(p)
                 touched += [p, state['exp_avg'], state['exp_avg_sq']]
             if not entries:
                 continue
             if len(entries) > MAX_TENSORS:
                 raise HipError("FusedAdam: {} parameter tensors in a group (at most {})".format(len(entries), MAX_TENSORS))
-            step_t, ticket = self._group_state(group)
-            for p in group['params']:
-                if p in self.state:
-                    self.state[p]['step'] = step_t          # (torch.optim.Adam's state name; shared by the group)
+            step_t, ticket = self._group_state(group, updated)
             arr = (_AdamTensor * len(entries))(*entries)
             b1, b2 = group['betas']
             dev = group['params'][0].device

@@ -186,3 +186,30 @@ def test_neg_mean_loss_op(shape):
     y = x.detach().clone()
     y.view(-1)[0] = float('-inf')
     assert float(ops.neg_mean(y)) == float('inf')
+
+
+@pytest.mark.gpu
+def test_fused_adam_state_dict_round_trip():
+    """The device-side step count lives under torch.optim.Adam's state name and survives state_dict() / load_state_dict():
+    a resumed optimiser continues with the right bias correction (compared with torch.optim.Adam run straight through)."""
+    from deeprob.hip.optim import FusedAdam
+    torch.manual_seed(4)
+    ours = [torch.nn.Parameter(torch.randn(s, device='cuda')) for s in [(33,), (5, 7)]]
+    theirs = [torch.nn.Parameter(p.detach().clone()) for p in ours]
+    a, b = FusedAdam(ours, lr=1e-2), torch.optim.Adam(theirs, lr=1e-2)
+    grads = [[torch.randn_like(p) for p in ours] for _ in range(9)]
+    for it in range(5):
+        for p, q, g in zip(ours, theirs, grads[it]):
+            p.grad, q.grad = g.clone(), g.clone()
+        a.step(), b.step()
+    sd = a.state_dict()
+    resumed = [torch.nn.Parameter(p.detach().clone()) for p in ours]
+    a2 = FusedAdam(resumed, lr=1e-2)
+    a2.load_state_dict(sd)
+    for it in range(5, 9):
+        for p, q, g in zip(resumed, theirs, grads[it]):
+            p.grad, q.grad = g.clone(), g.clone()
+        a2.step(), b.step()
+    for p, q in zip(resumed, theirs):
+        assert torch.allclose(p, q, rtol=2e-6, atol=2e-6)
+    assert float(a2.state[resumed[0]]['step']) == 9.0
