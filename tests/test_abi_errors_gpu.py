@@ -246,3 +246,46 @@ def test_workspace_forget_and_per_workspace_hint():
     gc.collect()
     with torch.no_grad():
         assert err(a(xn.cuda()), orc.ratspn_forward(sa, xn)) <= 1e-5
+
+
+def test_round4_training_entries_error_codes():
+    """dpk_adam_step / dpk_prodsum_backward / dpk_ratspn_forward_train / dpk_neg_mean_*: refusals are codes + messages."""
+    import ctypes
+    from deeprob.hip import load_library, ptr
+    from deeprob.hip.optim import _AdamTensor
+    lib = load_library()
+    st = torch.cuda.current_stream().cuda_stream
+    # Adam: more tensors than one launch carries; null state
+    p = torch.zeros(4, device='cuda')
+    ent = (_AdamTensor * 97)(*[_AdamTensor(ptr(p), ptr(p), ptr(p), ptr(p), 4) for _ in range(97)])
+    step, tick = torch.zeros(1, device='cuda'), torch.zeros(1, dtype=torch.int32, device='cuda')
+    assert lib.dpk_adam_step(97, ctypes.cast(ent, ctypes.c_void_p), 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, ptr(step), ptr(tick), st) == DPK_EUNSUPPORTED
+    assert lib.dpk_adam_step(1, ctypes.cast(ent, ctypes.c_void_p), 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None, ptr(tick), st) == DPK_EINVAL
+    assert lib.dpk_adam_step(0, None, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, ptr(step), ptr(tick), st) == 0
+    # level backward: shapes outside the single-launch kernels are refused (the caller chains the layers), small workspace
+    B, R, N, S = 5, 4, 16, 16
+    x = torch.randn(B, R, N, device='cuda')
+    w = torch.randn(R // 2, S, N * N, device='cuda')
+    out = torch.randn(B, R // 2, S, device='cuda')
+    ws = torch.empty(lib.dpk_sum_workspace_bytes(B, R // 2, N * N, S), dtype=torch.uint8, device='cuda')
+    assert lib.dpk_prodsum_backward(ptr(x), ptr(w), ptr(out), ptr(out), B, R, N, S, 0, ptr(x), ptr(w), ptr(ws), ws.numel(), st) == DPK_EUNSUPPORTED
+    assert b'not built' in lib.dpk_last_error()
+    x8, w8, o8 = torch.randn(B, R, 8, device='cuda'), torch.randn(R // 2, 8, 64, device='cuda'), torch.randn(B, R // 2, 8, device='cuda')
+    assert lib.dpk_prodsum_backward(ptr(x8), ptr(w8), ptr(o8), ptr(o8), B, R, 8, 8, 0, None, None, ptr(ws), 16, st) == DPK_EWORKSPACE
+    assert lib.dpk_prodsum_backward(ptr(x8), ptr(w8), ptr(o8), ptr(o8), B, 3, 8, 8, 0, None, None, ptr(ws), ws.numel(), st) == DPK_EINVAL
+    # training forward: a depth-3 model is outside the single-launch route
+    m = _model(rg_depth=3)
+    base = m.base_layer
+    Rm, I, d = base.mask.shape[0], base.out_channels, base.mask.shape[1]
+    xin = torch.randn(6, 64, device='cuda')
+    n = lib.dpk_ratspn_workspace_bytes(64, Rm, d, I, 3, 4, 2, 1)
+    wsm = torch.empty(n, dtype=torch.uint8, device='cuda')
+    t = [torch.empty(6, Rm, I, device='cuda'), torch.empty(6, Rm // 2, 2, device='cuda'), torch.empty(6, 1, device='cuda'), torch.empty(6, 1, device='cuda')]
+    sums = [l.weight for l in m.layers if hasattr(l, 'weight')]
+    rc = lib.dpk_ratspn_forward_train(ptr(xin), 6, 64, ptr(base.mask), None, ptr(base.loc), ptr(base.scale), ptr(sums[0]),
+                                      ptr(m.root_layer.weight), 3, 4, I, 2, 1, ptr(t[3]), ptr(t[0]), ptr(t[1]), ptr(t[2]), ptr(wsm),
+                                      wsm.numel(), 2, st)   # (DPK_FLAG_UNIT_SCALE)
+    assert rc == DPK_EUNSUPPORTED and lib.dpk_last_error()
+    # loss
+    assert lib.dpk_neg_mean_forward(ptr(xin), 0, ptr(step), st) == DPK_EINVAL
+    assert lib.dpk_neg_mean_backward(None, 4, ptr(p), st) == DPK_EINVAL
