@@ -8,6 +8,8 @@
 // batches are hundreds of samples, so this route is correctness-first; the 64k-sample density path is the
 // fused forward kernel in coupling.hip.
 #include "common.h"
+#include <mutex>
+#include <type_traits>
 #include <math.h>
 
 namespace dpk {
@@ -25,8 +27,10 @@ struct GemmArgs {
     const float *gate;     // result zeroed where gate[m*ldg + n] <= 0
     int64_t ldg;
     int relu, accumulate;
-    int ksplit, kchunk;    // > 1: blockIdx.z owns K range [z*kchunk, (z+1)*kchunk), partial sums meet by atomicAdd
-};
+    int ksplit, kchunk;    // > 1: blockIdx.z owns K range [z*kchunk, (z+1)*kchunk)
+    float *partials;       // split-K: [tile][slice][16][256] partial tiles; the last slice to finish a tile sums them in slice
+    unsigned *tickets;     // order and runs the epilogue ([tile] arrival counts, zero between launches).  Null: the partial
+};                         // sums meet by atomicAdd into a zeroed C and gemm_epilogue_kernel follows (fallback)
 
 constexpr int kGT = 64, kGK = 64;
 
@@ -53,32 +57,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     const int kbeg = (g.ksplit > 1) ? (int)blockIdx.z * g.kchunk : 0;
     const int kend = (g.ksplit > 1) ? min(g.K, kbeg + g.kchunk) : g.K;
     constexpr int kPer = kGT * kGK / 256;       // 16 elements of each operand per thread and slab
-    // element i of this thread: fast index f (the operand's contiguous axis), slow index s0 + 4 i
+    // element i of this thread: fast index f (the operand's contiguous axis), slow index s0 + 4 i.
+    // Every load is unconditional at a clamped (in-range) address and zeroed afterwards: the first version predicated
+    // each load with a branch, and hipcc waits for ALL outstanding loads where such a branch joins -- the 32 loads of a
+    // slab were 32 dependent round trips, 9 us per slab (round-4 trace: 18 us for a two-slab product).
     const int f = lane, s0 = wave;
-    const float *pa = g.A + (int64_t)(m0 + (A_KFAST ? s0 : f)) * g.sam + (int64_t)(kbeg + (A_KFAST ? f : s0)) * g.sak;
-    const float *pb = g.Bm + (int64_t)(kbeg + (B_NFAST ? s0 : f)) * g.sbk + (int64_t)(n0 + (B_NFAST ? f : s0)) * g.sbn;
-    const int64_t a_step = 4 * (A_KFAST ? g.sam : g.sak), b_step = 4 * (B_NFAST ? g.sbk : g.sbn);
-    const int64_t a_slab = (int64_t)kGK * g.sak, b_slab = (int64_t)kGK * g.sbk;
+    // (a second slab of operands in flight in registers was measured: no gain -- the slab is not waiting for its loads)
     float ar[kPer], br[kPer];
-    auto fetch = [&](int k0) {
-        const bool a_fast_ok = A_KFAST ? (k0 + f < kend) : (m0 + f < g.M);
-        const bool b_fast_ok = B_NFAST ? (n0 + f < g.N) : (k0 + f < kend);
-        const int a_slow0 = A_KFAST ? m0 + s0 : k0 + s0, a_lim = A_KFAST ? g.M : kend;
-        const int b_slow0 = B_NFAST ? k0 + s0 : n0 + s0, b_lim = B_NFAST ? kend : g.N;
-        const float ks_fast = (A_KFAST && g.kscale && a_fast_ok) ? g.kscale[k0 + f] : 1.f;
+    auto fetch_with = [&](int k0, auto has_kscale) {
 #pragma unroll
         for (int i = 0; i < kPer; ++i) {
-            float av = 0.f;
-            if (a_fast_ok && a_slow0 + 4 * i < a_lim) {
-                av = pa[i * a_step];
-                if (A_KFAST) av *= ks_fast;
-                else if (g.kscale) av *= g.kscale[a_slow0 + 4 * i];
-            }
-            ar[i] = av;
-            br[i] = (b_fast_ok && b_slow0 + 4 * i < b_lim) ? pb[i * b_step] : 0.f;
+            const int am = A_KFAST ? m0 + s0 + 4 * i : m0 + f, ak = A_KFAST ? k0 + f : k0 + s0 + 4 * i;
+            const int bk = B_NFAST ? k0 + s0 + 4 * i : k0 + f, bn = B_NFAST ? n0 + f : n0 + s0 + 4 * i;
+            const bool aok = am < g.M && ak < kend, bok = bk < kend && bn < g.N;
+            const int amc = min(am, g.M - 1), akc = min(ak, g.K - 1), bkc = min(bk, g.K - 1), bnc = min(bn, g.N - 1);
+            float av = g.A[(int64_t)amc * g.sam + (int64_t)akc * g.sak];
+            if constexpr (decltype(has_kscale)::value) av *= g.kscale[akc];
+            const float bv = g.Bm[(int64_t)bkc * g.sbk + (int64_t)bnc * g.sbn];
+            ar[i] = aok ? av : 0.f;
+            br[i] = bok ? bv : 0.f;
         }
-        pa += a_slab;
-        pb += b_slab;
+    };
+    auto fetch = [&](int k0) {
+        if (g.kscale != nullptr) fetch_with(k0, std::true_type{});
+        else fetch_with(k0, std::false_type{});
     };
     fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += kGK) {
@@ -98,10 +100,46 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
         }
     }
     const int n = n0 + wn + (lane & 31);
-    if (n >= g.N) return;
-    const float ns = g.nscale ? g.nscale[n] : 1.f, bs = g.bias ? g.bias[n] : 0.f;
-    if (g.ksplit > 1) {
-        // split-K: raw partial sums (times the per-column scale, which is linear) are added into C; bias / ReLU /
+    if (g.ksplit > 1 && g.partials != nullptr) {
+        // Split-K without atomics on C (round 4: 0.8 - 1.6 M same-address float atomics per product were most of these
+        // launches, plus a memset in front and an epilogue launch behind): every slice stores its 64 x 64 partial tile
+        // device-coherently, the LAST slice of a tile to arrive adds them up in slice order (deterministic) and runs the
+        // ordinary epilogue.  Release = acknowledged stores (no L2 write-back fence: ratspn_level_bwd.hip).
+        __shared__ unsigned last_s;
+        float *P = g.partials + ((int64_t)tile * g.ksplit) * 4096 + tid;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            __hip_atomic_store(P + (int64_t)blockIdx.z * 4096 + r * 256, acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) last_s = (atomicAdd(g.tickets + tile, 1u) == (unsigned)g.ksplit - 1u) ? 1u : 0u;
+        __syncthreads();
+        if (last_s == 0u) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // (four slices' loads in flight at a time: one slice per trip was one round trip per slice; summed in slice order)
+        for (int z0 = 0; z0 < g.ksplit; z0 += 4) {
+            float v[4][16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int z = min(z0 + q, g.ksplit - 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    v[q][r] = __hip_atomic_load(P + (int64_t)z * 4096 + r * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool in = z0 + q < g.ksplit;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += in ? v[q][r] : 0.f;
+            }
+        }
+        if (tid == 0) __hip_atomic_store(g.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (g.ksplit > 1) {
+        if (n >= g.N) return;
+        const float ns = g.nscale ? g.nscale[n] : 1.f;
+        // fallback: raw partial sums (times the per-column scale, which is linear) are added into C; bias / ReLU /
         // gate are applied by gemm_epilogue_kernel once every slice has landed
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -110,6 +148,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
         }
         return;
     }
+    if (n >= g.N) return;
+    const float ns = g.nscale ? g.nscale[n] : 1.f, bs = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -146,32 +186,86 @@ __global__ void gemm_epilogue_kernel(const GemmArgs g) {
 }
 
 // Few output tiles and a long K (the training-batch products dH = dZ W2, H = x W1^T, dW = dOut^T In): split K over
-// blockIdx.z so that the grid fills the chip; partial sums meet by atomicAdd.
+// blockIdx.z so that the grid fills the chip.  Scratch for the partial tiles and the arrival counts comes from a
+// process-wide pool (64 MB ring + 64 K counters, allocated at the first product that needs it; a first use inside a stream
+// capture cannot allocate and takes the atomicAdd fallback).  A product takes a fresh region of the ring, so products of
+// one stream never meet; more than ~8 split products in flight at once on different streams would.
+struct GemmPool {
+    std::mutex mu;
+    float *partials = nullptr;
+    unsigned *tickets = nullptr;
+    int64_t cursor = 0, tcursor = 0;
+    bool failed = false;
+};
+constexpr int64_t kGemmPoolFloats = 16ll << 20;   // 64 MB
+constexpr int kGemmPoolTickets = 1 << 16;
+static bool gemm_pool_take(int64_t floats, int tiles, float **p, unsigned **t, hipStream_t st) {
+    static GemmPool pool;
+    std::lock_guard<std::mutex> lock(pool.mu);
+    if (pool.failed || floats > kGemmPoolFloats / 2 || tiles > kGemmPoolTickets / 2) return false;
+    if (pool.partials == nullptr) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return false;          // (an allocation would invalidate the capture: the fallback this once)
+        }
+        void *a = nullptr, *b = nullptr;
+        if (hipMalloc(&a, (size_t)kGemmPoolFloats * 4) != hipSuccess || hipMalloc(&b, (size_t)kGemmPoolTickets * 4) != hipSuccess ||
+            hipMemset(b, 0, (size_t)kGemmPoolTickets * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            if (a) (void)hipFree(a);
+            if (b) (void)hipFree(b);
+            (void)hipGetLastError();
+            return false;          // (e.g. inside a stream capture: ask again next time)
+        }
+        pool.partials = (float *)a;
+        pool.tickets = (unsigned *)b;
+    }
+    if (pool.cursor + floats > kGemmPoolFloats) pool.cursor = 0;
+    if (pool.tcursor + tiles > kGemmPoolTickets) pool.tcursor = 0;
+    *p = pool.partials + pool.cursor;
+    *t = pool.tickets + pool.tcursor;
+    pool.cursor += (floats + 63) / 64 * 64;
+    pool.tcursor += tiles;
+    return true;
+}
+
 static void launch_gemm(const GemmArgs &g_in, hipStream_t st) {
     if (g_in.M <= 0 || g_in.N <= 0) return;
     GemmArgs g = g_in;
     const int tiles = cdiv(g.N, kGT) * cdiv(g.M, kGT);
     int ksplit = 1;
-    constexpr int target = 1024;                              // about four work-groups per compute unit
-    if (tiles < target / 2 && g.K >= 2 * kGK && !(g.bias && g.nscale)) {
+    const int target = device_cus();                          // one work-group per compute unit: a slab is ~1.5 us
+    if (tiles < target / 2 + target / 4 && g.K >= 2 * kGK) {
         ksplit = cdiv(target, tiles);
         const int max_split = cdiv(g.K, kGK);
         if (ksplit > max_split) ksplit = max_split;
+        if (ksplit > 8) ksplit = 8;   // (the last slice reads them all back: 13 slices of one slab measured 21 us, 7 of two 14)
     }
     if (ksplit > 1) {
         g.kchunk = (int)align_up(cdiv(g.K, ksplit), kGK);
         g.ksplit = cdiv(g.K, g.kchunk);
-        if (!g.accumulate) {
-            if (g.ldc == g.N) (void)hipMemsetAsync(g.C, 0, (size_t)g.M * g.N * 4, st);
-            else (void)hipMemset2DAsync(g.C, (size_t)g.ldc * 4, 0, (size_t)g.N * 4, (size_t)g.M, st);
+    }
+    if (g.ksplit > 1) {
+        if (gemm_pool_take((int64_t)tiles * g.ksplit * 4096, tiles, &g.partials, &g.tickets, st)) {
+            launch_gemm_kernel(g, dim3(cdiv(g.N, kGT), cdiv(g.M, kGT), g.ksplit), st);
+            return;
         }
-        launch_gemm_kernel(g, dim3(cdiv(g.N, kGT), cdiv(g.M, kGT), g.ksplit), st);
-        if (g.bias || g.relu || g.gate) {
-            const int64_t total = (int64_t)g.M * g.N;
-            const int64_t nb = (total + 255) / 256;
-            DPK_LAUNCH(gemm_epilogue_kernel, dim3((int)(nb > 4096 ? 4096 : nb)), dim3(256), 0, st, g);
+        g.partials = nullptr;
+        g.tickets = nullptr;
+        if (!(g.bias && g.nscale)) {   // (the fallback's epilogue order: bias -> relu, the scale already applied)
+            if (!g.accumulate) {
+                if (g.ldc == g.N) (void)hipMemsetAsync(g.C, 0, (size_t)g.M * g.N * 4, st);
+                else (void)hipMemset2DAsync(g.C, (size_t)g.ldc * 4, 0, (size_t)g.N * 4, (size_t)g.M, st);
+            }
+            launch_gemm_kernel(g, dim3(cdiv(g.N, kGT), cdiv(g.M, kGT), g.ksplit), st);
+            if (g.bias || g.relu || g.gate) {
+                const int64_t total = (int64_t)g.M * g.N;
+                const int64_t nb = (total + 255) / 256;
+                DPK_LAUNCH(gemm_epilogue_kernel, dim3((int)(nb > 4096 ? 4096 : nb)), dim3(256), 0, st, g);
+            }
+            return;
         }
-        return;
     }
     g.ksplit = 1;
     launch_gemm_kernel(g, dim3(cdiv(g.N, kGT), cdiv(g.M, kGT)), st);
@@ -212,6 +306,9 @@ __global__ __launch_bounds__(kRThreads) void colsum_kernel(const float *__restri
 //   ds = -g_u u - g_ildj ; dt = -g_u e^{-s} ; ds_hat = inv_mask ds a (1 - tanh^2) ; da = sum inv_mask ds tanh
 // inverse != 0: the sampling direction (coupling.py:89-104), x_out = x e^{s} + t, ldj = +sum s:
 //   ds = g x e^{s} + g_ldj ; dt = g ; direct term g e^{s}
+// A wave per sample row (rows strided over the grid), lanes over the columns four at a time with every load of the four
+// requested before anything is used: the first version (a thread per element, `e % D`, loads behind `if (live)`) was a
+// chain of dependent round trips and 1024 same-address atomics per launch -- 17 us for 400 k elements (round-4 trace).
 __global__ __launch_bounds__(256) void coupling_bwd_elem_kernel(const float *__restrict__ x, float *__restrict__ Z,
                                                                 const float *__restrict__ inv_mask,
                                                                 const float *__restrict__ act_weight,
@@ -219,48 +316,48 @@ __global__ __launch_bounds__(256) void coupling_bwd_elem_kernel(const float *__r
                                                                 const float *__restrict__ gildj, int64_t B, int D,
                                                                 int affine, int inverse, float *__restrict__ gx,
                                                                 float *__restrict__ gact) {
-    const int64_t total = B * D;
+    constexpr int U = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float a = affine ? act_weight[0] : 0.f;
     float da = 0.f;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-         e += (int64_t)gridDim.x * blockDim.x) {
-        const int d = (int)(e % D);
-        const int64_t b = e / D;
-        const float g = gu ? gu[e] : 0.f;
-        const bool live = inv_mask[d] != 0.f;
-        if (affine) {
-            float *zt = Z + b * 2 * D + d, *zs = zt + D;
-            if (live) {
-                const float th = tanhf(*zs);
-                const float s = a * th, t = *zt;
-                float ds, es;
-                if (inverse) {
-                    es = expf(s);
-                    ds = g * x[e] * es + (gildj ? gildj[b] : 0.f);
-                    *zt = g;
-                } else {
-                    es = expf(-s);
-                    const float u = (x[e] - t) * es;
-                    ds = -g * u - (gildj ? gildj[b] : 0.f);
-                    *zt = -g * es;
-                }
-                *zs = ds * a * (1.f - th * th);
-                da += ds * th;
-                gx[e] = g * es;
-            } else {
-                *zt = 0.f;
-                *zs = 0.f;
-                gx[e] = g;
+    for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < B; b += (int64_t)gridDim.x * 4) {
+        const float gl = gildj ? gildj[b] : 0.f;
+        for (int d0 = lane; d0 < D; d0 += 64 * U) {
+            float g[U], mk[U], xv[U], zt[U], zs[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int dc = min(d0 + 64 * u, D - 1);
+                g[u] = gu ? gu[b * D + dc] : 0.f;
+                mk[u] = inv_mask[dc];
+                xv[u] = x[b * D + dc];
+                zt[u] = affine ? Z[b * 2 * D + dc] : 0.f;
+                zs[u] = affine ? Z[b * 2 * D + D + dc] : 0.f;
             }
-        } else {
-            Z[b * D + d] = live ? (inverse ? g : -g) : 0.f;
-            gx[e] = g;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int d = d0 + 64 * u;
+                if (d >= D) continue;
+                const bool live = mk[u] != 0.f;
+                if (affine) {
+                    const float th = tanhf(zs[u]);
+                    const float s = a * th;
+                    const float es = expf(inverse ? s : -s);
+                    const float ds = inverse ? g[u] * xv[u] * es + gl : -g[u] * ((xv[u] - zt[u]) * es) - gl;
+                    Z[b * 2 * D + d] = live ? (inverse ? g[u] : -g[u] * es) : 0.f;
+                    Z[b * 2 * D + D + d] = live ? ds * a * (1.f - th * th) : 0.f;
+                    if (live) da += ds * th;
+                    gx[b * D + d] = live ? g[u] * es : g[u];
+                } else {
+                    Z[b * D + d] = live ? (inverse ? g[u] : -g[u]) : 0.f;
+                    gx[b * D + d] = g[u];
+                }
+            }
         }
     }
     if (affine && gact) {   // one atomic per work-group (every wave adding on its own serialised on the one address)
         __shared__ float wsum[4];
         da = wave_reduce_sum(da);
-        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = da;
+        if (lane == 0) wsum[wave] = da;
         __syncthreads();
         if (threadIdx.x == 0) {
             const float t = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
@@ -508,26 +605,37 @@ __global__ __launch_bounds__(256) void coupling_fwd_elem_kernel(const float *__r
                                                                 const float *__restrict__ act_weight, int64_t B, int D,
                                                                 int affine, int inverse, float *__restrict__ out,
                                                                 float *__restrict__ ldj) {
+    constexpr int U = 4;      // columns per lane in flight: all their loads are requested before the first is used
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
     const float a = affine ? act_weight[0] : 0.f;
     float acc = 0.f;
-    for (int d = lane; d < D; d += 64) {
-        const float xv = x[b * D + d];
-        const bool live = inv_mask[d] != 0.f;
-        float r = xv;
-        if (affine) {
-            if (live) {
-                const float t = Z[b * 2 * D + d], s = a * tanhf(Z[b * 2 * D + D + d]);
-                r = inverse ? fmaf(xv, expf(s), t) : (xv - t) * expf(-s);
-                acc += s;
-            }
-        } else if (live) {
-            const float z = Z[b * D + d];
-            r = inverse ? xv + z : xv - z;
+    for (int d0 = lane; d0 < D; d0 += 64 * U) {
+        float xv[U], mk[U], zt[U], zs[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int dc = min(d0 + 64 * u, D - 1);
+            xv[u] = x[b * D + dc];
+            mk[u] = inv_mask[dc];
+            zt[u] = affine ? Z[b * 2 * D + dc] : Z[b * D + dc];
+            zs[u] = affine ? Z[b * 2 * D + D + dc] : 0.f;
         }
-        out[b * D + d] = r;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int d = d0 + 64 * u;
+            if (d >= D) continue;
+            const bool live = mk[u] != 0.f;
+            float r;
+            if (affine) {
+                const float s = a * tanhf(zs[u]);
+                r = inverse ? fmaf(xv[u], expf(s), zt[u]) : (xv[u] - zt[u]) * expf(-s);
+                if (live) acc += s;
+            } else {
+                r = inverse ? xv[u] + zt[u] : xv[u] - zt[u];
+            }
+            out[b * D + d] = live ? r : xv[u];
+        }
     }
     acc = wave_reduce_sum(acc);
     if (lane == 0) ldj[b] = inverse ? acc : -acc;
@@ -593,7 +701,7 @@ extern "C" int dpk_coupling1d_backward(const float *x, int64_t B, int32_t D, con
     g.C = Z; g.ldc = zc; g.M = (int)B; g.N = zc; g.K = units; g.bias = b2;
     launch_gemm(g, st);
     // element-wise core: Z <- dZ, grad_x <- direct term
-    DPK_LAUNCH(coupling_bwd_elem_kernel, dim3(grid1d(B * D, 256, 1024)), dim3(256), 0, st, x, Z, inv_mask, act_weight,
+    DPK_LAUNCH(coupling_bwd_elem_kernel, dim3(grid1d(B * 64, 256, 1024)), dim3(256), 0, st, x, Z, inv_mask, act_weight,
                        grad_u, grad_ildj, B, D, affine, 0, grad_x, grad_act);
     // dW2 = dZ^T H, db2 = colsum(dZ)
     if (grad_W2) {
@@ -895,7 +1003,7 @@ static int mlp_backward_dir(const float *x, int64_t B, int32_t D, const float *m
     }
     DPK_REQUIRE(x && grad_x && (grad_u || grad_ildj), DPK_EINVAL, "coupling1d_mlp_backward: null pointer");
     if (!ws_holds_forward) mlp_forward(w, x, B, D, mask, n_hidden, W, b, widths, st);
-    DPK_LAUNCH(coupling_bwd_elem_kernel, dim3(grid1d(B * D, 256, 1024)), dim3(256), 0, st, x, w.Z, inv_mask, act_weight,
+    DPK_LAUNCH(coupling_bwd_elem_kernel, dim3(grid1d(B * 64, 256, 1024)), dim3(256), 0, st, x, w.Z, inv_mask, act_weight,
                        grad_u, grad_ildj, B, D, affine, inverse, grad_x, grad_act);
     // back through the layers: dOut starts as dZ (in w.Z)
     float *dout = w.Z;

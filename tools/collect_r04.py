@@ -13,6 +13,7 @@ OUT = os.path.join(ROOT, 'gpurun_out', 'profiles_r04')
 os.makedirs(OUT, exist_ok=True)
 ENV = dict(os.environ, TMPDIR='/tmp')
 what = sys.argv[1] if len(sys.argv) > 1 else 'all'
+only = sys.argv[2:]      # optional: workload names
 
 WORKLOADS = {   # name -> command (relative to the repo root)
     'headline': ['python', 'bench.py', '--cpu-samples', '0', '--no-secondary'],
@@ -21,6 +22,8 @@ WORKLOADS = {   # name -> command (relative to the repo root)
     'wide': ['python', 'tools/bench_wide_small.py', '4096', '65536'],
     'folded': ['python', 'tools/bench_folded_layers.py', '4096', '65536'],
     'train': ['python', 'tools/bench_train.py', 'ratspn', '512'],
+    'train_nvp': ['python', 'tools/bench_train.py', 'realnvp', '512'],
+    'train_dgc': ['python', 'tools/bench_train.py', 'dgcspn', '512'],
     'config4': ['python', 'tools/bench_dgc.py'],
     'config5': ['python', 'tools/bench_flows.py'],
 }
@@ -73,7 +76,11 @@ def pmc(name, cmd, counter):
 
 if what in ('all', 'trace'):
     for name, cmd in WORKLOADS.items():
+        if only and name not in only:
+            continue
         kernel_trace(name, cmd)
+    if only:
+        sys.exit(0)
     r = subprocess.run(['python', os.path.join(ROOT, 'bench.py')], cwd=ROOT, env=ENV, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     open(os.path.join(OUT, 'r04_bench_line.json'), 'wb').write(r.stdout.strip().splitlines()[-1] + b'\n' if r.stdout.strip() else b'')
 
@@ -89,7 +96,7 @@ if what in ('all', 'pmc'):
         'config4': [('', None, 'config4')],
     }
     for name, cmd in WORKLOADS.items():
-        if name in ('train', 'folded'):
+        if name in ('train', 'folded', 'train_nvp', 'train_dgc'):
             continue
         fetch, write = pmc(name, cmd, 'FETCH_SIZE'), pmc(name, cmd, 'WRITE_SIZE')
         report.append('== %s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs) -- %s' % (name, ' '.join(cmd)))
