@@ -606,11 +606,17 @@ template <int CMAX, int NB>
 __global__ __launch_bounds__(256) void spatial_prodsum_fwd_kernel(const float *__restrict__ in,
                                                                    const float *__restrict__ Wl,
                                                                    const float *__restrict__ LW, int B, ProdGeom q,
-                                                                   int Cout, float *__restrict__ out) {
+                                                                   int Cout, float *__restrict__ out, int slots) {
     const int OHW = q.OH * q.OW, HW = q.H * q.W;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= OHW) return;
-    const int b0 = blockIdx.y * NB;
+    // small maps (the pooled levels: 14 x 14, 7 x 7): `slots` groups of samples share a work-group, so that the pixel's
+    // weights -- Cout x C floats per thread and sample group, re-read from L2 by every work-group -- serve slots x NB samples
+    // (pt = pixels per work-group: 256 / slots, or the whole map when it is smaller)
+    const int pt = slots > 1 ? min(256 / slots, OHW) : 256;
+    const int slot = threadIdx.x / pt;
+    const int p = blockIdx.x * pt + (threadIdx.x - slot * pt);
+    if (slot >= slots || p >= OHW) return;
+    const int b0 = (blockIdx.y * slots + slot) * NB;
+    if (b0 >= B) return;
     const int oh = p / q.OW, ow = p - oh * q.OW;
     // tap offsets inside one channel plane, -1 = padding (contributes log 1 = 0)
     int toff[4];
@@ -1091,9 +1097,20 @@ extern "C" int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C
     hipEvent_t pev0, pev1;
     profile_take(&pev0, &pev1, DPK_KERNEL_SPATIAL_PRODSUM);
     if (pev0) (void)hipEventRecord(pev0, st);
+    // Wide levels (C >= 16): a thread reads Cout x C weights of its pixel per NB samples -- 800 KB per work-group at
+    // 32 -> 32 channels on a 14 x 14 map, 3.3 GB of L2 traffic per launch with one sample group per work-group (round-4
+    // trace: 865 us).  There a work-group is 16 pixels x 16 groups of samples: the 16 groups read the same weights.
+    int slots = 1, ptile = 256;
+    if (C >= 16) {
+        ptile = OHW < 16 ? OHW : 16;
+        slots = 256 / ptile;
+    } else if (OHW <= 128) {
+        ptile = OHW;
+        slots = 256 / OHW;
+    }
 #define DPK_PRODSUM(CMAX, NB)                                                                                      \
-    DPK_LAUNCH((spatial_prodsum_fwd_kernel<CMAX, NB>), dim3(cdiv(OHW, 256), cdiv(Bi, NB)), dim3(256), 0, st, \
-                       in, Wl, LW, Bi, q, Cout, out)
+    DPK_LAUNCH((spatial_prodsum_fwd_kernel<CMAX, NB>), dim3(cdiv(OHW, ptile), cdiv(Bi, NB * slots)), dim3(256), 0, st, \
+                       in, Wl, LW, Bi, q, Cout, out, slots)
     if (C <= 4)
         DPK_PRODSUM(4, 4);
     else if (C <= 8)
@@ -1101,7 +1118,7 @@ extern "C" int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C
     else if (C <= 16)
         DPK_PRODSUM(16, 2);
     else
-        DPK_PRODSUM(32, 1);
+        DPK_PRODSUM(32, 1);   // (NB = 2 / 4: 256 registers or scratch, one wave per SIMD in a latency chain over the outputs -- measured slower)
 #undef DPK_PRODSUM
     if (pev1) (void)hipEventRecord(pev1, st);
     DPK_CHECK_LAUNCH("spatial_prodsum_fwd_kernel");

@@ -24,6 +24,8 @@ WORKLOADS = {   # name -> command (relative to the repo root)
     'train': ['python', 'tools/bench_train.py', 'ratspn', '512'],
     'train_nvp': ['python', 'tools/bench_train.py', 'realnvp', '512'],
     'train_dgc': ['python', 'tools/bench_train.py', 'dgcspn', '512'],
+    'train_nvp2d': ['python', 'tools/bench_flows2d_train.py'],
+    'config4b': ['python', 'tools/diag_dgc_secondary.py'],
     'config4': ['python', 'tools/bench_dgc.py'],
     'config5': ['python', 'tools/bench_flows.py'],
 }
@@ -96,7 +98,7 @@ if what in ('all', 'pmc'):
         'config4': [('', None, 'config4')],
     }
     for name, cmd in WORKLOADS.items():
-        if name in ('train', 'folded', 'train_nvp', 'train_dgc'):
+        if name in ('train', 'folded', 'train_nvp', 'train_dgc', 'train_nvp2d', 'config4b'):
             continue
         fetch, write = pmc(name, cmd, 'FETCH_SIZE'), pmc(name, cmd, 'WRITE_SIZE')
         report.append('== %s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs) -- %s' % (name, ' '.join(cmd)))
