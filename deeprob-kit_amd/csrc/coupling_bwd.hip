@@ -150,16 +150,37 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     }
     if (n >= g.N) return;
     const float ns = g.nscale ? g.nscale[n] : 1.f, bs = g.bias ? g.bias[n] : 0.f;
+    // gate values and the old C (accumulate) of all 16 rows are requested together, each under ONE uniform branch: a load
+    // behind a per-row condition was one dependent round trip per row (16 of them: the gated product was the slowest)
+    float gv[16], cv[16];
+    if (g.gate != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = min(m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), g.M - 1);
+            gv[r] = g.gate[(int64_t)m * g.ldg + n];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gv[r] = 1.f;
+    }
+    if (g.accumulate) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = min(m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), g.M - 1);
+            cv[r] = g.C[(int64_t)m * g.ldc + n];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cv[r] = 0.f;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m >= g.M) continue;
         float v = acc[r] + bs;
         if (g.relu) v = fmaxf(v, 0.f);
         v *= ns;
-        if (g.gate && !(g.gate[(int64_t)m * g.ldg + n] > 0.f)) v = 0.f;
-        float *dst = g.C + (int64_t)m * g.ldc + n;
-        *dst = g.accumulate ? *dst + v : v;
+        v = (gv[r] > 0.f) ? v : 0.f;
+        if (m < g.M) g.C[(int64_t)m * g.ldc + n] = cv[r] + v;
     }
 }
 
