@@ -146,8 +146,10 @@ if what in ('all', 'mfma'):
         else:
             lines.append('%-32s no matching kernel row' % counter)
     if 'SQ_VALU_MFMA_BUSY_CYCLES' in vals and 'GRBM_GUI_ACTIVE' in vals and vals['GRBM_GUI_ACTIVE'] > 0:
-        # busy cycles summed over the chip's 1024 SIMDs against the kernel's active cycles on each of them
-        lines.append('matrix-pipe busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE) = %.4f'
-                     % (vals['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * vals['GRBM_GUI_ACTIVE'])))
+        # Both counters arrive summed over the 8 XCDs: GRBM_GUI_ACTIVE per launch is 8 x the kernel's cycles (2.29e6 for a
+        # 128 us launch at ~2.2 GHz), the busy cycles are summed over every SIMD.  Per XCD: 128 SIMDs (32 CUs x 4).
+        lines.append('matrix-pipe busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (128 SIMDs per XCD x GRBM_GUI_ACTIVE summed over the XCDs) = %.4f'
+                     % (vals['SQ_VALU_MFMA_BUSY_CYCLES'] / (128.0 * vals['GRBM_GUI_ACTIVE'])))
+        lines.append('(cross-check: the bench line\'s mfma_frac for config 5 -- executed f16 MFMA flops / 2.5 PF over the kernel time -- is 0.19)')
     open(os.path.join(OUT, 'r04_config5_mfma_pmc.txt'), 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines))
