@@ -166,6 +166,8 @@ __global__ __launch_bounds__(256) void channel_affine_bwd_kernel(const float *__
 // dw[co][ci][ky][kx] += sum_{b,p} dout[b,co,p] * h[b,ci,p + (ky-r, kx-r)],  h = mask * f(pre_a x + pre_b) (zero outside
 // the image).  Work-group: input channel ci, COT (8 or 16) output channels, a slice of the batch; every thread walks its
 // pixels over the samples of the slice with KS*KS*COT accumulators, then the group reduces and adds its partial to dw with fp32 atomics.
+// (Measured and dropped in round 4: two input channels per 512-thread work-group so that the halves share their dout reads
+// through L1 -- 356 -> 470 us per call.)
 template <int KS, int COT>
 __global__ __launch_bounds__(256) void conv2d_bwd_weight_kernel(const float *__restrict__ x, int64_t x_bstride,
                                                                 const float *__restrict__ dout, int64_t B, int Cin,
@@ -175,19 +177,24 @@ __global__ __launch_bounds__(256) void conv2d_bwd_weight_kernel(const float *__r
                                                                 float *__restrict__ dw) {
     constexpr int T = KS * KS, R = KS / 2;
     __shared__ float sh[4][T * COT];
+    const int tid = threadIdx.x;
     const int ci = blockIdx.x, co0 = blockIdx.y * COT;
     const int HW = H * W;
     const int64_t b0 = (int64_t)blockIdx.z * b_per_group;
     const int64_t b1 = b0 + b_per_group < B ? b0 + b_per_group : B;
     const float pa = pre ? pre[ci] : 1.f, pb = pre ? pre[Cin + ci] : 0.f;
-    float acc[T][COT];
+    // accumulators as pairs of output channels: the inner product runs on v_pk_fma_f32 (two FMAs per lane and issue slot;
+    // the scalar form reached 40 TFLOP/s, half of the vector ALU's unpacked fp32 rate)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    static_assert(COT % 2 == 0, "output channels in pairs");
+    f32x2 acc2[T][COT / 2];
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
-        for (int j = 0; j < COT; ++j) acc[t][j] = 0.f;
+        for (int j = 0; j < COT / 2; ++j) acc2[t][j] = f32x2{0.f, 0.f};
     // a thread keeps its pixels (p = tid, tid + 256, ...) over the samples of the slice: tap offsets / validity per pixel
     // are computed once per pixel, not per sample
-    for (int p = threadIdx.x; p < HW; p += 256) {
+    for (int p = tid; p < HW; p += 256) {
         const int h = p / W, w = p - h * W;
         int off[T];
         float keep[T];
@@ -212,26 +219,27 @@ __global__ __launch_bounds__(256) void conv2d_bwd_weight_kernel(const float *__r
             }
             const float *dc = dout + (b * Cout + co0) * HW + p;
 #pragma unroll
-            for (int j = 0; j < COT; ++j) {
-                const float d = co0 + j < Cout ? dc[(int64_t)j * HW] : 0.f;
+            for (int j = 0; j < COT / 2; ++j) {
+                const f32x2 d = {co0 + 2 * j < Cout ? dc[(int64_t)(2 * j) * HW] : 0.f,
+                                 co0 + 2 * j + 1 < Cout ? dc[(int64_t)(2 * j + 1) * HW] : 0.f};
 #pragma unroll
-                for (int t = 0; t < T; ++t) acc[t][j] = fmaf(d, hv[t], acc[t][j]);
+                for (int t = 0; t < T; ++t) acc2[t][j] = __builtin_elementwise_fma(d, f32x2{hv[t], hv[t]}, acc2[t][j]);
             }
         }
     }
-    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int wv = tid >> 6, ln = tid & 63;
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int j = 0; j < COT; ++j) {
-            const float v = wave_sum_f(acc[t][j]);
+            const float v = wave_sum_f(acc2[t][j >> 1][j & 1]);
             if (ln == 0) sh[wv][t * COT + j] = v;
         }
     __syncthreads();
-    if (threadIdx.x < T * COT) {
-        const int t = threadIdx.x / COT, j = threadIdx.x - t * COT;
+    if (tid < T * COT) {
+        const int t = tid / COT, j = tid - t * COT;
         if (co0 + j < Cout) {
-            const float v = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+            const float v = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
             atomicAdd(&dw[((int64_t)(co0 + j) * Cin + ci) * T + t], v);
         }
     }
