@@ -290,8 +290,12 @@ class SpatialProdSumFn(torch.autograd.Function):
         gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
         gprod = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device) if gx is not None else None
         buf = _spatial_sum_ws(ctx.ws, C, Cout, OH, OW, x.device)
-        # the forward's tables (softmax(W), log softmax(W)) are still there unless the weight or the workspace changed
+        # the forward's tables (softmax(W), log softmax(W)) are still there unless the weight or the workspace changed.
+        # "Believed current -- check on the device" becomes "current" here: the gradient wanted is that of the function the
+        # forward evaluated, with the tables IT used (a rebuild was five softmax launches per DGC-SPN step, 42 us of 840)
         flags = _tables_flag(ctx.ws, 'prodsum', w)
+        if flags:
+            flags = DPK_FLAG_PARAMS_CACHED
         check(lib.dpk_spatial_prodsum_backward(ptr(x), B, C, H, W, OH, OW, kh, kw, sh, sw, dh, dw, pt, pl, ptr(w), Cout,
                                                ptr(out), ptr(g), ptr(gprod), ptr(gx), ptr(gw), ptr(buf), buf.numel(),
                                                flags, stream_ptr(x.device)), 'dpk_spatial_prodsum_backward')
