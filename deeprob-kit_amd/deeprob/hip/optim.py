@@ -61,8 +61,9 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = load_library()
-        for group in self.param_groups:
-            entries, keep, touched, updated = [], [], [], []
+        cache = self.__dict__.setdefault('_dpk_tables', {})
+        for gi, group in enumerate(self.param_groups):
+            keep, updated = [], []
             for p in group['params']:
                 if p.grad is None:
                     continue
@@ -73,17 +74,29 @@ class FusedAdam(torch.optim.Optimizer):
                 if 'exp_avg' not in state:
                     state['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                entries.append(_AdamTensor(p.data_ptr(), g.data_ptr(), state['exp_avg'].data_ptr(),
-                                           state['exp_avg_sq'].data_ptr(), p.numel()))
                 keep.append(g)
                 updated.append(p)
-                touched += [p, state['exp_avg'], state['exp_avg_sq']]
-            if not entries:
+            if not updated:
                 continue
-            if len(entries) > MAX_TENSORS:
-                raise HipError("FusedAdam: {} parameter tensors in a group (at most {})".format(len(entries), MAX_TENSORS))
+            if len(updated) > MAX_TENSORS:
+                raise HipError("FusedAdam: {} parameter tensors in a group (at most {})".format(len(updated), MAX_TENSORS))
             step_t, ticket = self._group_state(group, updated)
-            arr = (_AdamTensor * len(entries))(*entries)
+            # the tensor table handed to the kernel: rebuilt only when the set of updated tensors (or their storage) changes;
+            # per step only the gradient addresses move (zero_grad(set_to_none=True) gives every step fresh gradients)
+            key = tuple((p.data_ptr(), id(self.state[p]['exp_avg']), id(self.state[p]['exp_avg_sq'])) for p in updated)
+            hit = cache.get(gi)
+            if hit is None or hit[0] != key:
+                arr = (_AdamTensor * len(updated))(*[
+                    _AdamTensor(p.data_ptr(), 0, self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr(),
+                                p.numel()) for p in updated])
+                touched = []
+                for p in updated:
+                    touched += [p, self.state[p]['exp_avg'], self.state[p]['exp_avg_sq']]
+                hit = cache[gi] = (key, arr, touched)
+            _, arr, touched = hit
+            for i, g in enumerate(keep):
+                arr[i].grad = g.data_ptr()
+            entries = updated
             b1, b2 = group['betas']
             dev = group['params'][0].device
             check(lib.dpk_adam_step(len(entries), ctypes.cast(arr, ctypes.c_void_p), float(group['lr']), float(b1), float(b2),
