@@ -487,30 +487,29 @@ constexpr int kBaseRows = 8;
 __global__ __launch_bounds__(256) void normal_base_logprob_kernel(
     const float *__restrict__ u, const float *__restrict__ sc, const float *__restrict__ sh,
     const float *__restrict__ loc, const float *__restrict__ scale, const float *__restrict__ ildj,
-    const float *__restrict__ ildj_const, int64_t B, int D, float *__restrict__ out) {
+    const float *__restrict__ ildj_const, int64_t B, int D, float *__restrict__ out, int rows) {
     extern __shared__ __attribute__((aligned(16))) float base_lds[];   // [2][D4*4] sc', sh' (zero padded), [4] sums
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Dp = (D + 3) & ~3;
     float *scp = base_lds, *shp = base_lds + Dp, *part = base_lds + 2 * Dp;
     float csum = 0.f;
     for (int d = tid; d < Dp; d += 256) {
-        float a = 0.f, c = 0.f;
-        if (d < D) {
-            const float s = scale[d], r = 0.70710678118654752440f / s;
-            a = (sc ? sc[d] : 1.f) * r;
-            c = ((sc ? sh[d] : 0.f) - loc[d]) * r;
-            csum += -logf(s) - kLogSqrt2Pi;
-        }
-        scp[d] = a;
-        shp[d] = c;
+        // (clamped, unconditional loads + selects: a load behind `if (d < D)` is a dependent round trip per trip of this loop)
+        const int dc = min(d, D - 1);
+        const float s = scale[dc], r = 0.70710678118654752440f / s;
+        const float scv = sc ? sc[dc] : 1.f, shv = sc ? sh[dc] : 0.f, lc = loc[dc];
+        const bool in = d < D;
+        scp[d] = in ? scv * r : 0.f;
+        shp[d] = in ? (shv - lc) * r : 0.f;
+        csum += in ? -logf(s) - kLogSqrt2Pi : 0.f;
     }
     csum = wave_reduce_sum(csum);
     if (lane == 0) part[wave] = csum;
     __syncthreads();
     const float cst = (part[0] + part[1]) + (part[2] + part[3]) + (ildj_const ? *ildj_const : 0.f);
-    const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * kBaseRows;
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * rows;
     const bool vec = (D & 3) == 0;
-    for (int64_t b = r0; b < min(r0 + kBaseRows, B); ++b) {
+    for (int64_t b = r0; b < min(r0 + rows, B); ++b) {
         const float *row = u + b * D;
         float acc = 0.f;
         if (vec) {
@@ -758,8 +757,11 @@ extern "C" int dpk_normal_base_logprob(const float *u, const float *scale_in, co
     DPK_REQUIRE((scale_in == nullptr) == (shift_in == nullptr), DPK_EINVAL, "normal_base_logprob: scale/shift");
     const size_t lds = (size_t)(2 * ((D + 3) & ~3) + 4) * sizeof(float);
     DPK_REQUIRE(lds <= 64 * 1024, DPK_EUNSUPPORTED, "normal_base_logprob: D=%d above the on-chip parameter table", D);
-    DPK_LAUNCH(normal_base_logprob_kernel, dim3(cdiv(B, 4 * kBaseRows)), dim3(256), lds, (hipStream_t)stream,
-                       u, scale_in, shift_in, loc, scale, ildj, ildj_const, B, D, out);
+    // rows per wave: 8 once the grid covers the chip a few times over (the per-work-group parameter table amortised), 1 for
+    // training batches (B = 512 was 16 work-groups walking 8 rows each: 15 us)
+    const int rows = B >= 4 * kBaseRows * 4 * (int64_t)device_cus() ? kBaseRows : 1;
+    DPK_LAUNCH(normal_base_logprob_kernel, dim3(cdiv(B, 4 * rows)), dim3(256), lds, (hipStream_t)stream,
+                       u, scale_in, shift_in, loc, scale, ildj, ildj_const, B, D, out, rows);
     DPK_CHECK_LAUNCH("normal_base_logprob_kernel");
     return DPK_OK;
 }
