@@ -200,8 +200,9 @@ __device__ __forceinline__ unsigned long long gemm_prep_hash_share(const GemmPre
 // serial 16- and 32-term LDS chains per constant) was ~60 dependent round trips: 46 us for the (8,8) model's 8 repetitions.
 // Same fingerprint values (gemm_prep_hash_share) and the same summation orders as before: tables bit for bit.
 template <int I>
-__device__ __forceinline__ void gemm_prep_block(const GemmPrepArgs &a, int blk, int *dyn) {
+__device__ __forceinline__ void gemm_prep_block(const GemmPrepArgs &a, int blk, int *dyn, int mode_override = -1) {
     constexpr int RPT = 8 / I;       // repetitions per 32-column tile (4 regions x I channels each)
+    const int mode = mode_override >= 0 ? mode_override : a.mode;   // (a copy of the argument block with another mode lives in scratch)
     const int nrb = a.NT * RPT;
     const int tid = threadIdx.x, nth = blockDim.x;
     const int rpb = nth >> 6;        // softmax rows per work-group
@@ -218,13 +219,13 @@ __device__ __forceinline__ void gemm_prep_block(const GemmPrepArgs &a, int blk, 
     // fingerprint of the bytes this work-group's outputs depend on (block local: a repetition's tables depend on its own
     // slice of mask / pad_mask / loc / scale only; a write through `param.data` moves no version counter on the host,
     // DESIGN 3.9) -> does this work-group rebuild?
-    const unsigned long long stored_early = a.mode != kPrepBuild ? a.hash[blk] : 0ull;   // (requested first)
+    const unsigned long long stored_early = mode != kPrepBuild ? a.hash[blk] : 0ull;   // (requested first)
     unsigned long long h = tid == 0 ? kPrepHashBase + (unsigned long long)blk : 0ull;    // (once per work-group)
     auto decide = [&](unsigned long long share) -> bool {
         const unsigned long long hb = block_sum_u64(share, red_s);
-        if (a.mode == kPrepVerify) {
+        if (mode == kPrepVerify) {
             if (stored_early == hb) return false;             // nothing this work-group's outputs depend on has changed
-        } else if (a.mode == kPrepInline) {
+        } else if (mode == kPrepInline) {
             if (tid == 0) {
                 vi_arrive(a.ctl, stored_early != hb);
                 unsigned ticket;
@@ -519,9 +520,7 @@ __device__ __forceinline__ void gemm_prep_block(const GemmPrepArgs &a, int blk, 
 // 3.5 us per launch whether or not the call is ever made (the 0.2 us of tools/ubench/scratch_cost.hip was for 64 bytes).
 template <int I>
 __device__ __forceinline__ void gemm_prep_rebuild_cold(const GemmPrepArgs *a, int blk, int *dyn) {
-    GemmPrepArgs b = *a;
-    b.mode = kPrepBuild;
-    gemm_prep_block<I>(b, blk, dyn);
+    gemm_prep_block<I>(*a, blk, dyn, kPrepBuild);
 }
 template <int I>
 __device__ __forceinline__ void gemm_prep_block_inline(const GemmPrepArgs &a, int blk, int *dyn) {

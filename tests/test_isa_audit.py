@@ -43,3 +43,29 @@ def test_x_once_coupling_reloads_are_waited_for_in_full(tmp_path):
                 j += 1
             assert j < len(ins) and 'vmcnt(0)' in ins[j] and dmas == 0, (name, i, ins[j] if j < len(ins) else None, dmas)
     print('x-once coupling kernels: {} instantiations, {} scratch reloads, all behind vmcnt(0)'.format(len(names), reloads))
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='needs hipcc')
+@pytest.mark.parametrize('source,pattern,expect', [
+    ('ratspn_gemm_small.hip', r'ratspn_gemm_small_kernelILi\d+ELi\d+ELi\d+ELi\d+E', 24),
+    ('ratspn_gemm_wide.hip', r'ratspn_gemm_wide_kernelILi\d+ELb[01]ELb[01]E', 12),
+])
+def test_small_batch_kernels_use_no_scratch(tmp_path, source, pattern, expect):
+    """The 32-sample RAT-SPN kernels run for 9 .. 20 us; a kernel that uses scratch pays for its set-up on every launch
+    whether or not the spilling path is taken (round 4: 536 B per lane behind a noinline call cost 3.5 us, a by-value copy
+    of the table arguments 264 B).  Every instantiation must report ScratchSize 0."""
+    src = os.path.join(ROOT, 'deeprob-kit_amd', 'csrc', source)
+    r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include'),
+                        '-c', '--cuda-device-only', '-Rpass-analysis=kernel-resource-usage', src, '-o', str(tmp_path / 'o.o')],
+                       cwd=os.path.dirname(src), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1800, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    blocks = re.split(r'remark: [^\n]*Function Name: ', r.stdout)[1:]
+    seen = 0
+    for blk in blocks:
+        name = blk.split()[0]
+        if not re.search(pattern, name):
+            continue
+        seen += 1
+        m = re.search(r'ScratchSize \[bytes/lane\]: (\d+)', blk)
+        assert m and int(m.group(1)) == 0, (name, m.group(0) if m else None)
+    assert seen == expect, seen
