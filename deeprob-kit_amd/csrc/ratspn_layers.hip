@@ -303,16 +303,23 @@ __global__ __launch_bounds__(64 * kBwdWaves) void sum_bwd_kernel(const float *__
             const float xv = x[b * P * N + cc];
             const float *op = out + (b * P + p) * S + ob, *gp = g + (b * P + p) * S + ob;
             float tot = 0.f;
+            // (outputs beyond S read the last valid one and are dropped by a select: `if (ob + q < S) { loads }` was a
+            // dependent round trip per output and sample)
+            float xo8[kBwdOB], g8[kBwdOB];
 #pragma unroll
             for (int q = 0; q < kBwdOB; ++q) {
-                if (ob + q < S) {
-                    const float xo = op[q];
-                    // an all -inf row has out = -inf: its gradient is defined as zero (reference: the
-                    // masked_fill guard inside torch.logsumexp's backward gives the same)
-                    const float t = (xo > -INFINITY) ? gp[q] * expf(xv + lw[q] - xo) : 0.f;
-                    acc[q] += t;
-                    tot += t;
-                }
+                const int qc = min(q, S - 1 - ob);
+                xo8[q] = op[qc];
+                g8[q] = gp[qc];
+            }
+#pragma unroll
+            for (int q = 0; q < kBwdOB; ++q) {
+                const float xo = xo8[q];
+                // an all -inf row has out = -inf: its gradient is defined as zero (reference: the
+                // masked_fill guard inside torch.logsumexp's backward gives the same)
+                const float t = (ob + q < S && xo > -INFINITY) ? g8[q] * expf(xv + lw[q] - xo) : 0.f;
+                acc[q] += t;
+                tot += t;
             }
             if (gx != nullptr && live) {
                 float *dst = gx + b * P * N + col;
@@ -713,7 +720,7 @@ static int leaf_backward_common(int dist, const float *x, const float *g, int64_
         const dim3 grid(cdiv(B, tile), w.G, I / cbk), block(256);
         // (no dropout, rows 16-byte aligned, the tile's rows within 64 KB of LDS: the staged kernel)
         const size_t stage_bytes = (size_t)tile * ((size_t)D + (size_t)R * cbk) * 4;
-        const bool staged = tile == 16 && drop_p == 0.f && stage_bytes <= 64 * 1024 && w.SP <= 4 * 256 &&
+        const bool staged = tile == 16 && drop_p == 0.f && stage_bytes <= 80 * 1024 && w.SP <= 4 * 256 &&
                             ((D & 3) != 0 || (reinterpret_cast<uintptr_t>(x) & 15) == 0);
         // tiles per work-group of the staged kernel: as many as keep two work-groups per compute unit busy
         int passes = 1;
@@ -722,13 +729,15 @@ static int leaf_backward_common(int dist, const float *x, const float *g, int64_
         const dim3 sgrid(cdiv(B, tile * passes), w.G, I / cbk);
 #define DPK_LEAF_BWD(DIST, CBK)                                                                                  \
     do {                                                                                                         \
-        if (staged && gp1)                                                                                       \
+        if (staged && gp1) {                                                                                     \
+            if (int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&leaf_bwd_param_lds_kernel<DIST, CBK, true>), 96 * 1024)) return lrc; \
             DPK_LAUNCH((leaf_bwd_param_lds_kernel<DIST, CBK, true>), sgrid, block, stage_bytes, st, x, g, B, D, R, I, d, \
                        w.SP, w.feat, w.srcr, p0, p1, gp0, gp1, tile, passes);                                    \
-        else if (staged)                                                                                         \
+        } else if (staged) {                                                                                     \
+            if (int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&leaf_bwd_param_lds_kernel<DIST, CBK, false>), 96 * 1024)) return lrc; \
             DPK_LAUNCH((leaf_bwd_param_lds_kernel<DIST, CBK, false>), sgrid, block, stage_bytes, st, x, g, B, D, R, I, d, \
                        w.SP, w.feat, w.srcr, p0, p1, gp0, gp1, tile, passes);                                    \
-        else                                                                                                     \
+        } else                                                                                                     \
             DPK_LAUNCH((leaf_bwd_param_kernel<DIST, CBK>), grid, block, 0, st, x, g, B, D, R, I, d, w.SP, w.feat, \
                        w.srcr, p0, p1, gp0, gp1, drop_p, seed, tile);                                            \
     } while (0)
