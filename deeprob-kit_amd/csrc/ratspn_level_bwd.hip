@@ -181,6 +181,110 @@ __global__ __launch_bounds__(256) void prodsum_bwd_kernel(const LevelBwdArgs a) 
     }
 }
 
+// ---- a SumLayer level with 16 nodes per region: the (i, j) pairs of a partition are the 256 threads of a work-group -----
+// (the example model of examples/ratspn_mnist.py: rg_batch = rg_sum = 16, depth 3 -- its levels were the per-layer chain:
+// product recomputed 13 us + softmax rows 5 + sum backward 33 + product backward 11 + Jacobian 5 per level.)
+// Same term as prodsum_bwd_kernel; what differs is that a row's log-softmax and the column sums over i cross the four
+// waves (LDS), and the samples of the tile are walked one at a time by the whole work-group.
+template <int S>
+__global__ __launch_bounds__(256) void prodsum16_bwd_kernel(const LevelBwdArgs a) {
+    constexpr int N = 16, NN = 256;
+    __shared__ float red[4][S];
+    __shared__ float bc[2][S];
+    __shared__ float colp[2][4][N];
+    __shared__ unsigned last_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = tid >> 4, j = tid & 15;
+    const int p = blockIdx.y, P = a.P;
+    float lw[S], acc[S];
+    {
+        float wv[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) wv[s] = a.w[((int64_t)p * S + s) * NN + tid];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float mx = wave_reduce_max(wv[s]);
+            if (lane == 0) red[wave][s] = mx;
+        }
+        __syncthreads();
+        if (tid < S) bc[0][tid] = fmaxf(fmaxf(red[0][tid], red[1][tid]), fmaxf(red[2][tid], red[3][tid]));
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float sum = wave_reduce_sum(expf(wv[s] - bc[0][s]));
+            if (lane == 0) red[wave][s] = sum;      // (the maxima were read behind the barrier above)
+        }
+        __syncthreads();
+        if (tid < S) bc[1][tid] = logf((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            lw[s] = wv[s] - bc[0][s] - bc[1][s];
+            acc[s] = 0.f;
+            if (blockIdx.x == 0)
+                __hip_atomic_store(a.W + ((int64_t)p * S + s) * NN + tid, expf(lw[s]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    const int64_t b0 = (int64_t)blockIdx.x * a.tile, b1 = min(b0 + a.tile, a.B);
+    // two samples per trip, their loads requested together.  (Measured and dropped: the factored form W e^{xa-ma} e^{xc-mc}
+    // g e^{ma+mc-out} with 3 instead of 16 exponentials per thread and sample -- same 63-65 us: the launch is bound by its
+    // 2.1 M weight-gradient atomics and the serial walk over the tile, not by the vector ALU.)
+    constexpr int UN = 2;
+    for (int64_t bb = b0; bb < b1; bb += UN) {
+        float xa[UN], xc[UN], o[UN][S], gg[UN][S];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int64_t b = min(bb + u, b1 - 1);
+            xa[u] = a.x[(b * 2 * P + 2 * p) * N + i];
+            xc[u] = a.x[(b * 2 * P + 2 * p + 1) * N + j];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                o[u][s] = a.out[(b * P + p) * S + s];
+                gg[u][s] = a.g[(b * P + p) * S + s];
+            }
+        }
+        float ga[UN], gc[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const bool in = bb + u < b1;
+            float tot = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const float t = (in && o[u][s] > -INFINITY) ? gg[u][s] * expf(xa[u] + xc[u] + lw[s] - o[u][s]) : 0.f;
+                acc[s] += t;
+                tot += t;
+            }
+            // child a (region 2p), node i: sum over j = 16 consecutive lanes; child c, node j: sum over i = the wave's four
+            // rows by shuffle, then the four waves through LDS
+            ga[u] = tot;
+            gc[u] = tot;
+#pragma unroll
+            for (int of = 8; of > 0; of >>= 1) ga[u] += __shfl_xor(ga[u], of, 64);
+            gc[u] += __shfl_xor(gc[u], 16, 64);
+            gc[u] += __shfl_xor(gc[u], 32, 64);
+        }
+        if (a.gx != nullptr) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                if (bb + u < b1 && j == 0) a.gx[((bb + u) * 2 * P + 2 * p) * N + i] = ga[u];
+                if (lane < N) colp[u][wave][lane] = gc[u];
+            }
+            __syncthreads();
+            if (tid < UN * N) {
+                const int u = tid >> 4, jj = tid & 15;
+                if (bb + u < b1)
+                    a.gx[((bb + u) * 2 * P + 2 * p + 1) * N + jj] = (colp[u][0][jj] + colp[u][1][jj]) + (colp[u][2][jj] + colp[u][3][jj]);
+            }
+            __syncthreads();
+        }
+    }
+    if (a.glw != nullptr) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) atomicAdd(a.glw + ((int64_t)p * S + s) * NN + tid, acc[s]);
+        level_jacobian_tail(a, a.ticket + p, gridDim.x, p * S, S, &last_s);
+    }
+}
+
 // ---- the RootLayer level: one work-group per sample tile, a lane per (partition, i, j) input of the root ----------------
 // CB classes at a time (their log-softmax rows over all M = P N^2 inputs are work-group reductions).
 template <int N, int CB>
@@ -317,7 +421,9 @@ extern "C" int dpk_prodsum_backward(const float *in, const float *weight, const 
     DPK_REQUIRE(B >= 0 && R > 0 && (R % 2) == 0 && N > 0 && S > 0, DPK_EINVAL, "prodsum_backward: bad sizes");
     DPK_REQUIRE(weight && ws && (B == 0 || (in && out && g)), DPK_EINVAL, "prodsum_backward: null pointer");
     const int P = R / 2, NN = N * N;
-    const bool shape_ok = (N == 2 || N == 4 || N == 8) && (root ? (P * NN <= 1024) : (S == 2 || S == 4 || S == 8)) && P <= 65535;
+    const bool wide16 = !root && N == 16 && (S == 8 || S == 16);
+    const bool shape_ok = ((N == 2 || N == 4 || N == 8) && (root ? (P * NN <= 1024) : (S == 2 || S == 4 || S == 8)) && P <= 65535) ||
+                          (wide16 && P <= 65535);
     if (!shape_ok) {
         set_error("prodsum_backward: (nodes=%d, sums=%d, partitions=%d) not built; chain the layers' backward entry points", N, S, P);
         return DPK_EUNSUPPORTED;
@@ -356,7 +462,18 @@ extern "C" int dpk_prodsum_backward(const float *in, const float *weight, const 
             int tile = 256;
             while (tile > 8 && cdiv(B, tile) * P < 2 * device_cus()) tile /= 2;
             a.tile = tile;
-            int rc = N == 2 ? launch_sum_level<2>(a, S, st) : (N == 4 ? launch_sum_level<4>(a, S, st) : launch_sum_level<8>(a, S, st));
+            int rc = DPK_OK;
+            if (wide16) {
+                // (a work-group per partition walks its samples one at a time: tiles short enough to cover the chip)
+                int t16 = 64;
+                while (t16 > 4 && cdiv(B, t16) * P < 2 * device_cus()) t16 /= 2;   // (longer tiles, fewer atomics: 91 against 63 us -- the walk over the tile is serial)
+                a.tile = t16;
+                const dim3 grid16((unsigned)cdiv(B, t16), (unsigned)P);
+                if (S == 8) DPK_LAUNCH((prodsum16_bwd_kernel<8>), grid16, dim3(256), 0, st, a);
+                else DPK_LAUNCH((prodsum16_bwd_kernel<16>), grid16, dim3(256), 0, st, a);
+            } else {
+                rc = N == 2 ? launch_sum_level<2>(a, S, st) : (N == 4 ? launch_sum_level<4>(a, S, st) : launch_sum_level<8>(a, S, st));
+            }
             if (rc) return rc;
         }
         DPK_CHECK_LAUNCH("prodsum_bwd_kernel");

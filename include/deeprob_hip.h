@@ -198,8 +198,8 @@ int dpk_ratspn_forward(const float *x, int64_t B, int32_t D, const int64_t *mask
  * from the level's INPUT in [B, R, N]: the [B, R/2, N*N] product tensor is never formed.  grad_in [B, R, N] and
  * grad_weight (like weight) may each be NULL.  Equivalent to dpk_product_forward + dpk_sum_backward (dpk_root_backward)
  * + dpk_product_backward; like them it only uses in - out, so a common per-sample shift of (in, out) is allowed.
- * ws as dpk_sum_workspace_bytes(B, R/2, N*N, S).  Built for N in {2,4,8}, S in {2,4,8} (sum) / (R/2)*N*N <= 1024 (root);
- * DPK_EUNSUPPORTED otherwise.                                                                                       */
+ * ws as dpk_sum_workspace_bytes(B, R/2, N*N, S).  Built for N in {2,4,8}, S in {2,4,8} (sum) / (R/2)*N*N <= 1024 (root)
+ * and for N = 16, S in {8,16} (sum); DPK_EUNSUPPORTED otherwise.                                                                                       */
 int dpk_prodsum_backward(const float *in, const float *weight, const float *out, const float *g, int64_t B, int32_t R,
                          int32_t N, int32_t S, int32_t root, float *grad_in, float *grad_weight, void *ws,
                          int64_t ws_bytes, void *stream);

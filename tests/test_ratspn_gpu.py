@@ -694,7 +694,9 @@ def test_backward_wide_model_vs_oracle(golden):
                                            # the single-launch level backward (dpk_prodsum_backward) at its other shapes:
                                            # several samples per wave, classes in chunks of 8, idle lanes, long tiles
                                            (8, 2, 2, 70, False), (4, 4, 8, 33, False), (32, 8, 4, 700, False),
-                                           (16, 2, 3, 40, True), (8, 4, 20, 19, True), (16, 8, 1, 5000, True)])
+                                           (16, 2, 3, 40, True), (8, 4, 20, 19, True), (16, 8, 1, 5000, True),
+                                           # 16 nodes per region (the example model's levels): the work-group-wide instantiation
+                                           (8, 16, 8, 33, False), (6, 16, 16, 300, False)])
 def test_folded_level_autograd_matches_layer_chain(R, N, S, B, root):
     """ops.ProdSumFn (product + sum / root as one autograd node: folded forward, product recomputed in the backward)
     against the per-layer operators chained: values, input gradient and weight gradient."""
