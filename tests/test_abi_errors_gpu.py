@@ -263,7 +263,7 @@ def test_round4_training_entries_error_codes():
     assert lib.dpk_adam_step(1, ctypes.cast(ent, ctypes.c_void_p), 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None, ptr(tick), st) == DPK_EINVAL
     assert lib.dpk_adam_step(0, None, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, ptr(step), ptr(tick), st) == 0
     # level backward: shapes outside the single-launch kernels are refused (the caller chains the layers), small workspace
-    B, R, N, S = 5, 4, 16, 16
+    B, R, N, S = 5, 4, 32, 16      # (32 nodes per region: beyond the 2 / 4 / 8 / 16-node instantiations)
     x = torch.randn(B, R, N, device='cuda')
     w = torch.randn(R // 2, S, N * N, device='cuda')
     out = torch.randn(B, R // 2, S, device='cuda')
