@@ -1065,6 +1065,36 @@ static int prod_fused_common(bool root, const float *in, const float *weight, in
     return DPK_OK;
 }
 
+// The softmax rows + MFMA fragments of a depth-2 model's sum layer and root layer in ONE launch, into the two layers' own
+// workspaces (same layout as prod_fused_common carves): the following dpk_prodsum_forward / dpk_prodroot_forward calls take
+// DPK_FLAG_PARAMS_CACHED.  DPK_EUNSUPPORTED when either layer is outside the MFMA route (the caller lets the layers build
+// their own tables).
+namespace dpk {
+int upper_mfma_tables_pair(const float *w0, float *W0, float *LW0, int R0, int N0, int S0, void *frag0, const float *w1,
+                           float *W1, float *LW1, int R1, int N1, int C, void *frag1, hipStream_t st);
+}
+extern "C" int dpk_upper_tables_pair(const float *sum_weight, int32_t R0, int32_t N0, int32_t S0, void *ws0, int64_t ws0_bytes,
+                                     const float *root_weight, int32_t R1, int32_t N1, int32_t C, void *ws1,
+                                     int64_t ws1_bytes, void *stream) {
+    DPK_REQUIRE(sum_weight && root_weight && ws0 && ws1, DPK_EINVAL, "upper_tables_pair: null pointer");
+    DPK_REQUIRE(R0 > 0 && (R0 % 2) == 0 && R1 > 0 && (R1 % 2) == 0 && N0 > 0 && N1 > 0 && S0 > 0 && C > 0, DPK_EINVAL,
+                "upper_tables_pair: bad sizes");
+    static const bool mfma = [] {
+        const char *e = getenv("DPK_RATSPN_GEMM");
+        return !(e && e[0] == '0');
+    }();
+    const int64_t seg0 = align_up((int64_t)(R0 / 2) * S0 * N0 * N0 * 4, 256), seg1 = align_up((int64_t)C * (R1 / 2) * N1 * N1 * 4, 256);
+    const int64_t fb0 = upper_mfma_frag_bytes(R0, N0, S0), fb1 = upper_mfma_frag_bytes(R1, N1, C);
+    if (!mfma || !upper_mfma_shape_ok(false, N0, S0) || !upper_mfma_shape_ok(true, N1, C) || ws0_bytes < 2 * seg0 + fb0 ||
+        ws1_bytes < 2 * seg1 + fb1) {
+        set_error("upper_tables_pair: a layer is outside the MFMA route");
+        return DPK_EUNSUPPORTED;
+    }
+    return upper_mfma_tables_pair(sum_weight, (float *)ws0, (float *)((char *)ws0 + seg0), R0, N0, S0, (char *)ws0 + 2 * seg0,
+                                  root_weight, (float *)ws1, (float *)((char *)ws1 + seg1), R1, N1, C, (char *)ws1 + 2 * seg1,
+                                  (hipStream_t)stream);
+}
+
 extern "C" int64_t dpk_prodsum_workspace_bytes(int32_t R, int32_t N, int32_t S) {
     if (R <= 0 || N <= 0 || S <= 0) return DPK_EINVAL;
     return 2 * align_up((int64_t)(R / 2) * S * N * N * 4, 256) + upper_mfma_frag_bytes(R, N, S) + 256;

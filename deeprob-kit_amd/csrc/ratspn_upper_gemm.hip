@@ -85,12 +85,17 @@ __global__ __launch_bounds__(256) void upper_pack_kernel(const float *__restrict
 // third of its kernels' time).  One block per softmax row: W = softmax(w[row]), LW = log_softmax(w[row]) and every
 // fragment entry the row owns (the inverse of upper_pack_kernel's mapping); the root layout's padding rows (class tiles
 // beyond C N rows) are zeroed by one extra block.
-__global__ __launch_bounds__(256) void upper_tables_kernel(const float *__restrict__ w, int rows, int n, float *__restrict__ W,
-                                                           float *__restrict__ LW, uint16_t *__restrict__ frag, int P, int N,
-                                                           int S, int root, int tiles) {
-    __shared__ float red[8];
+struct UpperTabJob {
+    const float *w;
+    float *W, *LW;
+    uint16_t *frag;
+    int rows, n, P, N, S, root, tiles, blocks;
+};
+__device__ __forceinline__ void upper_tables_body(const float *__restrict__ w, int rows, int n, float *__restrict__ W,
+                                                  float *__restrict__ LW, uint16_t *__restrict__ frag, int P, int N, int S,
+                                                  int root, int tiles, int blk, float *red) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if ((int)blockIdx.x >= rows) {   // root layout: rows S N .. tiles * 32 of every partition are zero
+    if (blk >= rows) {   // root layout: rows S N .. tiles * 32 of every partition are zero
         const int g0 = S * N, g1 = tiles * 32;
         const int per_p = (g1 - g0) * 16;
         for (int e = tid; e < P * per_p; e += blockDim.x) {
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(256) void upper_tables_kernel(const float *__restri
         }
         return;
     }
-    const int row = blockIdx.x;
+    const int row = blk;
     const float *src = w + (int64_t)row * n;
     // rows of up to 2048 weights are read ONCE, every load in flight together (three passes over global memory were three
     // dependent round trips of this 7 us launch)
@@ -175,6 +180,21 @@ __global__ __launch_bounds__(256) void upper_tables_kernel(const float *__restri
             dst[256 + 512] = 0;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void upper_tables_kernel(const float *__restrict__ w, int rows, int n, float *__restrict__ W,
+                                                           float *__restrict__ LW, uint16_t *__restrict__ frag, int P, int N,
+                                                           int S, int root, int tiles) {
+    __shared__ float red[8];
+    upper_tables_body(w, rows, n, W, LW, frag, P, N, S, root, tiles, (int)blockIdx.x, red);
+}
+// the tables of a model's sum layer AND root layer in one launch (the folded route's default mode rebuilds both per call:
+// two 6 us launches in front of two 10 us kernels at B = 4096)
+__global__ __launch_bounds__(256) void upper_tables_pair_kernel(const UpperTabJob j0, const UpperTabJob j1) {
+    __shared__ float red[8];
+    const int blk = (int)blockIdx.x;
+    if (blk < j0.blocks) upper_tables_body(j0.w, j0.rows, j0.n, j0.W, j0.LW, j0.frag, j0.P, j0.N, j0.S, j0.root, j0.tiles, blk, red);
+    else upper_tables_body(j1.w, j1.rows, j1.n, j1.W, j1.LW, j1.frag, j1.P, j1.N, j1.S, j1.root, j1.tiles, blk - j0.blocks, red);
 }
 
 template <int N>
@@ -506,6 +526,24 @@ int upper_mfma_tables(bool root, const float *weight, float *W, float *LW, int R
     DPK_LAUNCH(upper_tables_kernel, dim3(rows + extra), dim3(256), 0, st, weight, rows, n, W, LW, (uint16_t *)frag, P, N, S,
                root ? 1 : 0, tiles);
     DPK_CHECK_LAUNCH("upper_tables_kernel");
+    return DPK_OK;
+}
+
+static UpperTabJob upper_tab_job(bool root, const float *weight, float *W, float *LW, int R, int N, int S, void *frag) {
+    UpperTabJob j{};
+    const int P = R / 2;
+    j.w = weight; j.W = W; j.LW = LW; j.frag = (uint16_t *)frag; j.P = P; j.N = N; j.S = S; j.root = root ? 1 : 0;
+    j.tiles = root ? root_ct(N, S) : cdiv((int64_t)S * N, 32);
+    j.rows = root ? S : P * S;
+    j.n = root ? P * N * N : N * N;
+    j.blocks = j.rows + ((root && S * N < j.tiles * 32) ? 1 : 0);
+    return j;
+}
+int upper_mfma_tables_pair(const float *w0, float *W0, float *LW0, int R0, int N0, int S0, void *frag0, const float *w1,
+                           float *W1, float *LW1, int R1, int N1, int C, void *frag1, hipStream_t st) {
+    const UpperTabJob j0 = upper_tab_job(false, w0, W0, LW0, R0, N0, S0, frag0), j1 = upper_tab_job(true, w1, W1, LW1, R1, N1, C, frag1);
+    DPK_LAUNCH(upper_tables_pair_kernel, dim3(j0.blocks + j1.blocks), dim3(256), 0, st, j0, j1);
+    DPK_CHECK_LAUNCH("upper_tables_pair_kernel");
     return DPK_OK;
 }
 

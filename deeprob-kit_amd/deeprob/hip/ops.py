@@ -585,7 +585,30 @@ def _upper_tables_flag(ws: Workspace, route: str, w: torch.Tensor) -> int:
     return 0
 
 
-def prodsum_forward(x: torch.Tensor, weight: torch.Tensor, ws: Workspace) -> Optional[torch.Tensor]:
+def upper_tables_pair(sum_weight: torch.Tensor, ws0: Workspace, R0: int, N0: int, root_weight: torch.Tensor, ws1: Workspace,
+                      R1: int, N1: int, device) -> bool:
+    """The tables (softmax rows + MFMA fragments) of a depth-2 model's sum layer and root layer in ONE launch, written into
+    the two layers' workspaces; True when done -- the caller then passes ``tables_current=True`` to ``prodsum_forward`` /
+    ``prodroot_forward``.  The default mode rebuilds these tables on every call (a write through ``weight.data`` must be
+    seen): two launches before, one now."""
+    lib = load_library()
+    w0, w1 = require_device_f32(sum_weight, 'sum weight'), require_device_f32(root_weight, 'root weight')
+    S0, C = w0.shape[1], w1.shape[0]
+    b0, b1 = _prodsum_ws(ws0, R0, N0, S0, device), _prodsum_ws(ws1, R1, N1, C, device)
+    key0 = ('prodsum', w0.data_ptr(), tuple(w0.shape), w0._version)
+    key1 = ('prodroot', w1.data_ptr(), tuple(w1.shape), w1._version)
+    if cached_tables_flag() == DPK_FLAG_PARAMS_CACHED and ws0.params_key == key0 and ws1.params_key == key1:
+        return False     # (trusting the version counters and nothing moved: the layers skip their tables themselves)
+    rc = lib.dpk_upper_tables_pair(ptr(w0), R0, N0, S0, ptr(b0), b0.numel(), ptr(w1), R1, N1, C, ptr(b1), b1.numel(),
+                                   stream_ptr(device))
+    if rc == -4:
+        return False
+    check(rc, 'dpk_upper_tables_pair')
+    ws0.params_key, ws1.params_key = key0, key1
+    return True
+
+
+def prodsum_forward(x: torch.Tensor, weight: torch.Tensor, ws: Workspace, tables_current: bool = False) -> Optional[torch.Tensor]:
     """ProductLayer + SumLayer in one launch, eval mode, no autograd graph (reference: ratspn.py:272-286, :363-378).
     x [B,R,N], weight [R/2,S,N*N] -> [B,R/2,S]; None when N is beyond what the kernel is built for."""
     lib = load_library()
@@ -595,7 +618,7 @@ def prodsum_forward(x: torch.Tensor, weight: torch.Tensor, ws: Workspace) -> Opt
     S = w.shape[1]
     out = torch.empty((B, R // 2, S), dtype=torch.float32, device=x.device)
     buf = _prodsum_ws(ws, R, N, S, x.device)
-    flags = _upper_tables_flag(ws, 'prodsum', w)
+    flags = DPK_FLAG_PARAMS_CACHED if tables_current else _upper_tables_flag(ws, 'prodsum', w)
     rc = lib.dpk_prodsum_forward(ptr(x), ptr(w), B, R, N, S, ptr(out), ptr(buf), buf.numel(), flags,
                                  stream_ptr(x.device))
     if rc:
@@ -606,7 +629,7 @@ def prodsum_forward(x: torch.Tensor, weight: torch.Tensor, ws: Workspace) -> Opt
     return out
 
 
-def prodroot_forward(x: torch.Tensor, weight: torch.Tensor, ws: Workspace) -> Optional[torch.Tensor]:
+def prodroot_forward(x: torch.Tensor, weight: torch.Tensor, ws: Workspace, tables_current: bool = False) -> Optional[torch.Tensor]:
     """Last ProductLayer + RootLayer in one launch (reference: ratspn.py:272-286, :446-458). x [B,R,N],
     weight [C,(R/2)*N*N] -> [B,C]."""
     lib = load_library()
@@ -616,7 +639,7 @@ def prodroot_forward(x: torch.Tensor, weight: torch.Tensor, ws: Workspace) -> Op
     C = w.shape[0]
     out = torch.empty((B, C), dtype=torch.float32, device=x.device)
     buf = _prodsum_ws(ws, R, N, C, x.device)
-    flags = _upper_tables_flag(ws, 'prodroot', w)
+    flags = DPK_FLAG_PARAMS_CACHED if tables_current else _upper_tables_flag(ws, 'prodroot', w)
     rc = lib.dpk_prodroot_forward(ptr(x), ptr(w), B, R, N, C, ptr(out), ptr(buf), buf.numel(), flags,
                                   stream_ptr(x.device))
     if rc:

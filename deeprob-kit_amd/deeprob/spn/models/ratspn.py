@@ -178,6 +178,13 @@ class RatSpn(ProbabilisticModel):
         with torch.no_grad():
             h = self.base_layer(x)
             layers = list(self.layers)
+            # depth 2: the sum layer's and the root layer's tables in one launch (each layer rebuilt its own per call)
+            current = False
+            if (len(layers) == 3 and isinstance(layers[0], ProductLayer) and isinstance(layers[1], SumLayer)
+                    and isinstance(layers[2], ProductLayer) and h.dim() == 3 and h.is_cuda):
+                R0, N0 = h.shape[1], h.shape[2]
+                current = ops.upper_tables_pair(layers[1].weight, layers[1]._ws, R0, N0, self.root_layer.weight,
+                                                self.root_layer._ws, R0 // 2, layers[1].weight.shape[1], h.device)
             i = 0
             while i < len(layers):
                 if not isinstance(layers[i], ProductLayer):
@@ -186,10 +193,10 @@ class RatSpn(ProbabilisticModel):
                     nxt = layers[i + 1]
                     if not isinstance(nxt, SumLayer):
                         return None
-                    h = ops.prodsum_forward(h, nxt.weight, nxt._ws)
+                    h = ops.prodsum_forward(h, nxt.weight, nxt._ws, tables_current=current)
                     i += 2
                 else:
-                    h = ops.prodroot_forward(h, self.root_layer.weight, self.root_layer._ws)
+                    h = ops.prodroot_forward(h, self.root_layer.weight, self.root_layer._ws, tables_current=current)
                     i += 1
                     if h is None:
                         return None

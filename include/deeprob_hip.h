@@ -193,6 +193,14 @@ int dpk_ratspn_forward(const float *x, int64_t B, int32_t D, const int64_t *mask
                        float *out, float *leaf_out, double *ll_sum, void *ws, int64_t ws_bytes,
                        uint32_t flags, void *stream);
 
+/* The log-softmax tables (torch.log_softmax(weight) at ratspn.py:375 and :455) and matrix-core fragments of a depth-2
+ * model's SumLayer (weight [R0/2, S0, N0*N0]) and RootLayer (weight [C, (R1/2)*N1*N1]) in ONE launch, into the two layers'
+ * own workspaces (dpk_prodsum_workspace_bytes each): the dpk_prodsum_forward / dpk_prodroot_forward calls that follow take
+ * DPK_FLAG_PARAMS_CACHED.  DPK_EUNSUPPORTED when a layer is outside the matrix-core route (the layers then build their own). */
+int dpk_upper_tables_pair(const float *sum_weight, int32_t R0, int32_t N0, int32_t S0, void *ws0, int64_t ws0_bytes,
+                          const float *root_weight, int32_t R1, int32_t N1, int32_t C, void *ws1, int64_t ws1_bytes,
+                          void *stream);
+
 /* Backward of a whole level -- ProductLayer (ratspn.py:272-286) under a SumLayer (:363-378; root = 0: weight
  * [R/2, S, N*N], out / g [B, R/2, S]) or under the RootLayer (:446-458; root = 1: weight [S, (R/2)*N*N], out / g [B, S]) --
  * from the level's INPUT in [B, R, N]: the [B, R/2, N*N] product tensor is never formed.  grad_in [B, R, N] and

@@ -289,3 +289,9 @@ def test_round4_training_entries_error_codes():
     # loss
     assert lib.dpk_neg_mean_forward(ptr(xin), 0, ptr(step), st) == DPK_EINVAL
     assert lib.dpk_neg_mean_backward(None, 4, ptr(p), st) == DPK_EINVAL
+    # one launch for the tables of a sum layer and a root layer: shapes outside the matrix-core route are refused
+    w5 = torch.randn(2, 3, 25, device='cuda')
+    wr = torch.randn(1, 2 * 9, device='cuda')
+    wsb = torch.empty(1 << 20, dtype=torch.uint8, device='cuda')
+    assert lib.dpk_upper_tables_pair(ptr(w5), 4, 5, 3, ptr(wsb), wsb.numel(), ptr(wr), 4, 3, 1, ptr(wsb), wsb.numel(), st) == DPK_EUNSUPPORTED
+    assert lib.dpk_upper_tables_pair(None, 4, 8, 8, ptr(wsb), wsb.numel(), ptr(wr), 4, 8, 1, ptr(wsb), wsb.numel(), st) == DPK_EINVAL
