@@ -602,6 +602,10 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
     trains = [('GaussianRatSpn(784, depth 2, reps 8, rg_batch=8, rg_sum=8)',
                GaussianRatSpn(D, rg_depth=2, rg_repetitions=8, rg_batch=8, rg_sum=8, random_state=42).to(dev),
                torch.randn(B, D, device=dev)),
+              # the model of examples/ratspn_mnist.py: depth 3, 16 channels / sums, trainable scales (outside the fused routes)
+              ('GaussianRatSpn16(784, depth 3, reps 8, rg_batch=16, rg_sum=16, optimize_scale)',
+               GaussianRatSpn(D, rg_depth=3, rg_repetitions=8, rg_batch=16, rg_sum=16, optimize_scale=True, random_state=42).to(dev),
+               torch.randn(B, D, device=dev)),
               ('DgcSpn((1,28,28), 8, 8, depthwise)', m_dgc, torch.randn(B, 1, 28, 28, device=dev)),
               ('RealNVP1d(784)', m_flow, torch.randn(B, D, device=dev))]
     for name, m, x in trains:
