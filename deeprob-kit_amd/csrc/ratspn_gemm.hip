@@ -358,6 +358,10 @@ bool gemm_small_shape_ok(int D, int NT);
 int64_t gemm_small_max_batch();
 int ratspn_gemm_small_forward(const GemmArgs &a, const GemmPrepArgs &p, int reps, int I, int S, int NT, hipStream_t st);
 bool gemm_marginal_shape_ok(int D, int NT);
+// ratspn_gemm_slice.hip: persistent 32-sample blocks, the feature axis split over seven waves with the mean table in registers
+bool gemm_slice_shape_ok(int D, int reps, int I, int S, int NT);
+int64_t gemm_slice_min_batch();
+int ratspn_gemm_slice_forward(const GemmArgs &a, int I, int S, int NT, hipStream_t st);
 // ratspn_gemm_wide.hip: 8-channel models, a wave per repetition
 bool gemm_wide_shape_ok(int D, int reps, int I, int S, int C);
 int ratspn_gemm_wide_forward(const GemmArgs &a, const GemmPrepArgs &p, int S, hipStream_t st);
@@ -384,8 +388,12 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
     // (ratspn_gemm_small.hip); while recent launches met NaN evidence the ring variant that stages both tables runs
     // (ratspn_gemm_nan.hip); otherwise the ring kernel below.
     const bool wide = I == 8;
-    const bool small = !wide && B <= gemm_small_max_batch() && gemm_small_shape_ok(D, NT);
     const bool emitting = emit != nullptr;
+    const bool marginal_ring = marginal && gemm_marginal_shape_ok(D, NT);
+    // (the slice mapping: clean evidence only -- a block that meets NaN is evaluated exactly and sets the hint)
+    const bool slice = !wide && !emitting && !marginal_ring && gemm_slice_min_batch() >= 0 && B >= gemm_slice_min_batch() &&
+                       gemm_slice_shape_ok(D, reps, I, S, NT);
+    const bool small = !wide && !slice && B <= gemm_small_max_batch() && gemm_small_shape_ok(D, NT);
     if (emitting && !wide && !small) {   // (training forward: the 32-sample kernels)
         set_error("ratspn_forward_train: channels=%d at %lld samples not built (dpk_ratspn_small_batch_max)", I, (long long)B);
         return DPK_EUNSUPPORTED;
@@ -408,7 +416,7 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
     const size_t prep_lds = gemm_prep_lds_bytes(D, I, d);
     DPK_REQUIRE(prep_lds <= 60 * 1024, DPK_EUNSUPPORTED, "ratspn_gemm: in_features=%d too large for the table kernel", D);
     // (the ring kernel: its table work rides on the compute waves of its first np work-groups -- it needs that many)
-    const bool ring_plain = !wide && !small && !(marginal && gemm_marginal_shape_ok(D, NT));
+    const bool ring_plain = !wide && !small && !slice && !marginal_ring;
     // Measured (round 4, B = 65536, default-mode step): frozen kernel 47.4 us; kernel + stand-alone check launch 52.8 us;
     // self-checking ring kernel 58.8 us, 55.6 us even WITHOUT its table work (DPK_RING_VI_NP0=1) -- the verdict logic at
     // the first tile's upper layers is enough to cost the hot loop its register allocation (237 VGPRs, 71 spilled SGPRs
@@ -428,7 +436,7 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
         DPK_CHECK_LAUNCH("ratspn_gemm_prep_kernel");
         p.np = 0;
     }
-    if (wide || small || (marginal && gemm_marginal_shape_ok(D, NT))) {
+    if (wide || small || slice || marginal_ring) {
         GemmArgs a{};
         a.x = x; a.B = B; a.D = D; a.d = d; a.reps = reps; a.C = C;
         a.NCH = cdiv(D, 16 * gemm_ks(NT));
@@ -444,6 +452,7 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
         if (emitting) { a.emit_leaf = emit->leaf; a.emit_sum = emit->sum; a.emit_out = emit->out; }
         if (wide) return ratspn_gemm_wide_forward(a, p, S, st);
         if (small) return ratspn_gemm_small_forward(a, p, reps, I, S, NT, st);
+        if (slice) return ratspn_gemm_slice_forward(a, I, S, NT, st);
         return ratspn_gemm_marginal_forward(a, reps, I, S, NT, st);
     }
     ring::GemmArgs a{};

@@ -185,6 +185,13 @@ int dpk_ratspn_forward_on_mfma(const float *x, int32_t D, int32_t depth, int32_t
  * (0: ring kernels always; negative: back to the built-in default, also given by DPK_GEMM_SMALL_MAX) and returns
  * the previous one.  Process-wide tuning knob: results of the two mappings agree to fp32 rounding.          */
 int64_t dpk_ratspn_small_batch_max(int64_t samples);
+/* Batch size FROM which the MFMA route of the two-channel depth-2 models over 784 variables takes its third mapping
+ * (csrc/ratspn_gemm_slice.hip: persistent 32-sample blocks, the feature axis split over seven waves that keep their
+ * slice of the mean table in registers; replaces RatSpn.forward, deeprob/spn/models/ratspn.py:105-122, like the other
+ * two).  It has precedence over the small-batch kernels where both thresholds admit a batch.  Sets the threshold
+ * (-1: never; below -1: back to the built-in default, also given by DPK_GEMM_SLICE_MIN) and returns the previous one.
+ * Process-wide tuning knob: results of the mappings agree to fp32 rounding.                                          */
+int64_t dpk_ratspn_slice_batch_min(int64_t samples);
 int dpk_ratspn_forward(const float *x, int64_t B, int32_t D, const int64_t *mask,
                        const uint8_t *pad_mask, const float *loc, const float *scale,
                        const float *sum_weight0, const float *sum_weight1,

@@ -30,16 +30,20 @@ MODELS = {
 SEEDS = {'ratspn_g784_d3_r5_i4_s4_c10': 7, 'ratspn_g100_d2_r11_i2_s4_c3': 3, 'ratspn_g15_d3_r2_i2_s2_pad': 1}
 
 
-@pytest.fixture(params=['small', 'ring'])
+@pytest.fixture(params=['small', 'ring', 'slice'])
 def mapping(request):
-    """Both tile mappings of the matrix-core route: the small-batch kernels (32-sample tiles, feature axis split over
-    the waves; what a batch of up to 16384 samples takes by default) and the persistent 128-sample ring kernels
-    (forced here by a zero threshold).  Tests that take this fixture run on each."""
+    """The tile mappings of the matrix-core route: the small-batch kernels (32-sample tiles, feature axis split over
+    the waves; what a batch of up to 16384 samples takes by default), the persistent 128-sample ring kernels (forced
+    here by a zero threshold) and the persistent 32-sample blocks with the mean table in registers
+    (csrc/ratspn_gemm_slice.hip; what larger batches of the two-channel 784-variable models take by default, forced
+    here for every batch size -- shapes outside it keep the small-batch kernels).  Tests that take this fixture run on each."""
     from deeprob.hip import load_library
     lib = load_library()
-    prev = lib.dpk_ratspn_small_batch_max(-1 if request.param == 'small' else 0)
+    prev = lib.dpk_ratspn_small_batch_max(0 if request.param == 'ring' else -1)
+    prev_slice = lib.dpk_ratspn_slice_batch_min(0 if request.param == 'slice' else -1)
     yield request.param
     lib.dpk_ratspn_small_batch_max(prev)
+    lib.dpk_ratspn_slice_batch_min(prev_slice)
 
 
 def build(name, golden, device='cuda'):
