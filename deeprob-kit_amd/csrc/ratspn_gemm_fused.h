@@ -60,6 +60,49 @@ __device__ __forceinline__ void lse_merge(float &m, float &s, float m2, float s2
 }
 
 
+// 16-lane (one sample's partitions) exchanges on the DPP path (VALU operand modifiers, a few cycles; ds_bpermute-based
+// shuffles cost an LDS round trip each, and four dependent ones per reduction were a third of phase 2).
+// quad_perm [1,0,3,2] = lane ^ 1, [2,3,0,1] = lane ^ 2; row_half_mirror: i <-> 7 - i; row_mirror: i <-> 15 - i -- after
+// the four steps every lane of the row holds the reduction over all 16.
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ __forceinline__ unsigned dpp_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<kDppXor1>(v);
+    v += dpp_f<kDppXor2>(v);
+    v += dpp_f<kDppHalfMirror>(v);
+    v += dpp_f<kDppMirror>(v);
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f<kDppXor1>(v));
+    v = fmaxf(v, dpp_f<kDppXor2>(v));
+    v = fmaxf(v, dpp_f<kDppHalfMirror>(v));
+    v = fmaxf(v, dpp_f<kDppMirror>(v));
+    return v;
+}
+__device__ __forceinline__ unsigned row16_or(unsigned v) {
+    v |= dpp_u<kDppXor1>(v);
+    v |= dpp_u<kDppXor2>(v);
+    v |= dpp_u<kDppHalfMirror>(v);
+    v |= dpp_u<kDppMirror>(v);
+    return v;
+}
+
+__device__ __forceinline__ void row16_lse_merge(float &m, float &sum) {
+    // (m, sum) pairs of the 16 lanes of a row -> their log-sum-exp combination in every lane
+    float om, os;
+    om = dpp_f<kDppXor1>(m); os = dpp_f<kDppXor1>(sum); lse_merge(m, sum, om, os);
+    om = dpp_f<kDppXor2>(m); os = dpp_f<kDppXor2>(sum); lse_merge(m, sum, om, os);
+    om = dpp_f<kDppHalfMirror>(m); os = dpp_f<kDppHalfMirror>(sum); lse_merge(m, sum, om, os);
+    om = dpp_f<kDppMirror>(m); os = dpp_f<kDppMirror>(sum); lse_merge(m, sum, om, os);
+}
+
+
 // ---- exp-domain helpers of the fast upper layers ---------------------------------------------------------------
 // e[i] = 2^((x[i] - max) log2 e); returns max (0 for an all -inf input, whose exponentials are then 0)
 template <int NI> __device__ __forceinline__ float exp2_children(const float (&x)[NI], float (&e)[NI]) {

@@ -40,7 +40,7 @@ constexpr int kSliceSlot = kSliceKW * 2048;      // bytes of a wave's x slot: [K
 
 __host__ __device__ constexpr int slice_part_bytes(int NT) { return NT * 4 * 1024; }   // a wave's partial accumulators
 __host__ __device__ constexpr int slice_lds_bytes(int NT, int w0_floats) {
-    return kSliceCompute * kSliceSlot + kSliceCompute * slice_part_bytes(NT) + kSliceCompute * 256 + w0_floats * 4 + 64;
+    return kSliceCompute * kSliceSlot + kSliceCompute * slice_part_bytes(NT) + kSliceCompute * 256 + 64 + 1024 + 0 * w0_floats;
 }
 
 #ifdef DPK_TIMELINE
@@ -55,18 +55,18 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
     constexpr int NMAX = (I > S ? I : S);
     constexpr int KW = kSliceKW;
     constexpr int PW = slice_part_bytes(NT);
+    constexpr float kL2E = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+    static_assert(I == 2 && NT == 2 && NT * RPT == 8, "phase-2 roles: 8 repetitions x 2 partitions = the 16 lanes of a sample; one b128 per partition");
     typedef const __attribute__((address_space(1))) half8 gh8;
     typedef __attribute__((address_space(3))) const gf32x4 lf4;
     typedef __attribute__((address_space(3))) gf32x4 lf4w;
 
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
     lchar *smem = (lchar *)smem_generic;
-    lchar *part_l = smem + kSliceCompute * kSliceSlot;                        // [7][NT*4][64 lanes][16 bytes]
+    lchar *part_l = smem + kSliceCompute * kSliceSlot;                        // [7 slices][32 samples][16 units of 16 bytes]
     lfloat *q_l = (lfloat *)(part_l + kSliceCompute * PW);                    // [7][64] sums of squares
-    lfloat *w0_l = q_l + kSliceCompute * 64;                                  // [reps*2][S*I*I]
-    unsigned long long *exact_l = reinterpret_cast<unsigned long long *>(
-        reinterpret_cast<float *>(smem_generic + kSliceCompute * kSliceSlot + kSliceCompute * PW + kSliceCompute * 256) +
-        a.reps * 2 * S * I * I);                                              // blocks left to the exact evaluation
+    lunsigned *flag_l = (lunsigned *)(q_l + kSliceCompute * 64);              // [2][8] a wave's verdict on its 4 samples of a block
+    lfloat *c2_l = (lfloat *)(flag_l + 16);                                   // [16 slots][16]: sum weights, leaf constants, root weights
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -77,74 +77,149 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
     // body per length and spill 184 registers)
     const int nblk = a.ntiles;                                                // blocks of 32 samples
     const int first = (int)blockIdx.x, stride = (int)gridDim.x;
+    const bool slicer = wave < kSliceCompute;                                 // (the eighth wave only joins phase 2)
     SL_STAMP(15, 0);
 
-    if (wave < kSliceCompute) {
-        // ============================================ slice waves ==================================================
-        const int k0 = wave * KW;
-        lchar *my = smem + wave * kSliceSlot;
-        const unsigned my_u = (unsigned)(uintptr_t)my;
-        // DMA roles: piece P = i*64 + lane of a K-step's [32 rows][4 pieces]: row P >> 2, LDS piece P & 3 holds source
-        // piece (P & 3) ^ ((row >> 2) & 3)
-        int drow[2], dcol[2];
-        unsigned voff[2];
+    // ---- phase-1 roles (slice waves): MFMA lane (sample s, half h) ----------------------------------------------------
+    const int k0 = wave * KW;
+    lchar *my = smem + (slicer ? wave : 0) * kSliceSlot;
+    const unsigned my_u = (unsigned)(uintptr_t)my;
+#ifndef DPK_SLICE_ROWRUN
+#define DPK_SLICE_ROWRUN 1
+#endif
+#if DPK_SLICE_ROWRUN
+    // Slot layout [32 rows][28 pieces of 16 bytes] = the slice's 448 contiguous bytes of every row: DMA instruction j
+    // (of 14) copies pieces q = 64 j + lane (row q / 28, piece q % 28), i.e. ~2.3 whole row runs -- 7 to 8 runs of
+    // contiguous bytes per instruction instead of the 16 separate 64-byte segments of a [K-step][row] layout.  The four
+    // pieces of a K-step are XOR-swizzled by (row >> 2) & 3 on the source side: the MFMA-shaped ds_read_b128 (16 rows x
+    // one piece) then covers 16 different 16-byte bank groups.
+    // (dp0 is made opaque once per block: with the loop-invariant lane roles in view hipcc hoists all 14 source offsets
+    // out of the block loop -- 14 registers this kernel does not have)
+    const int dr0 = lane / 28;
+    int dp0 = lane - dr0 * 28;
+    auto dma_src = [&](int jdma, int nvalid) -> unsigned {   // byte offset of this lane's source piece within the block
+        const int pp = dp0 + 8 * jdma;                       // (64 j = 28 * 2j + 8j)
+        const int c = (pp * 2341) >> 16;                     // pp / 28 for pp < 896
+        const int r = 2 * jdma + dr0 + c, pos = pp - 28 * c;
+        const int sp = pos ^ ((r >> 2) & 3);
+        return (unsigned)(min(r, nvalid - 1) * D + k0 * 16 + sp * 4) * 4u;
+    };
+    auto issue = [&](int blk) {
+        const int64_t b0 = (int64_t)blk * 32;
+        const gcchar_p xt = (gcchar_p)(a.x + b0 * D);
+        const int nvalid = (int)min((int64_t)32, a.B - b0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int P = i * 64 + lane;
-            drow[i] = P >> 2;
-            dcol[i] = (P & 3) ^ ((drow[i] >> 2) & 3);
-            voff[i] = (unsigned)(drow[i] * D + k0 * 16 + dcol[i] * 4) * 4u;
-        }
-        auto issue = [&](int blk) {
-            const int64_t b0 = (int64_t)blk * 32;
-            const gcchar_p xt = (gcchar_p)(a.x + b0 * D);
-            if (b0 + 32 <= a.B) {
+        for (int jd = 0; jd < 2 * KW; ++jd) glds16<kGemmXNonTemporal>(dma_src(jd, nvalid), xt, my_u + jd * 1024);
+    };
+#else
+    // DMA roles: piece P = i*64 + lane of a K-step's [32 rows][4 pieces]: row P >> 2, LDS piece P & 3 holds source
+    // piece (P & 3) ^ ((row >> 2) & 3)
+    unsigned voff[2];
 #pragma unroll
-                for (int kk = 0; kk < KW; ++kk) {
-                    glds16<kGemmXNonTemporal>(voff[0] + kk * 64u, xt, my_u + kk * 2048);
-                    glds16<kGemmXNonTemporal>(voff[1] + kk * 64u, xt, my_u + kk * 2048 + 1024);
+    for (int i = 0; i < 2; ++i) {
+        const int P = i * 64 + lane, drow = P >> 2, dcol = (P & 3) ^ ((drow >> 2) & 3);
+        voff[i] = (unsigned)(drow * D + k0 * 16 + dcol * 4) * 4u;
+    }
+    auto issue = [&](int blk) {
+        const int64_t b0 = (int64_t)blk * 32;
+        const gcchar_p xt = (gcchar_p)(a.x + b0 * D);
+        if (b0 + 32 <= a.B) {
+#pragma unroll
+            for (int kk = 0; kk < KW; ++kk) {
+                glds16<kGemmXNonTemporal>(voff[0] + kk * 64u, xt, my_u + kk * 2048);
+                glds16<kGemmXNonTemporal>(voff[1] + kk * 64u, xt, my_u + kk * 2048 + 1024);
+            }
+        } else {   // ragged last block: rows beyond the batch re-fetch its last row (never stored)
+            const int nvalid = (int)(a.B - b0);
+#pragma unroll
+            for (int kk = 0; kk < KW; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int P = i * 64 + lane, drow = P >> 2, dcol = (P & 3) ^ ((drow >> 2) & 3);
+                    glds16<kGemmXNonTemporal>((unsigned)(min(drow, nvalid - 1) * D + (k0 + kk) * 16 + dcol * 4) * 4u, xt,
+                                              my_u + kk * 2048 + i * 1024);
                 }
-            } else {   // ragged last block: rows beyond the batch re-fetch its last row (never stored)
-                const int nvalid = (int)(a.B - b0);
-#pragma unroll
-                for (int kk = 0; kk < KW; ++kk)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        glds16<kGemmXNonTemporal>((unsigned)(min(drow[i], nvalid - 1) * D + (k0 + kk) * 16 + dcol[i] * 4) * 4u, xt,
-                                                  my_u + kk * 2048 + i * 1024);
-            }
-        };
-        if (first < nblk && !(a.ablate & 4)) issue(first);
-        // the slice of the mean table: registers for the whole launch (plain loads, L2; hipcc's waits for them also cover
-        // the older DMA requests above -- loads retire in order)
-        half8 mh[KW][NT], ml[KW][NT];
-#pragma unroll
-        for (int kk = 0; kk < KW; ++kk) {
-            const int ks = k0 + kk;
-            const gcchar_p tb = (gcchar_p)a.mtab + ((int64_t)ks * NT * 2048 + lane * 16);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                mh[kk][t] = *(gh8 *)(tb + t * 2048);
-                ml[kk][t] = *(gh8 *)(tb + t * 2048 + 1024);
-            }
         }
-        // The fragments must have ARRIVED before the loop: a wait that hipcc placed at their first use inside it would be a
-        // vmcnt(0) behind the next block's DMA requests, every iteration.  An empty asm that reads each fragment pins the
-        // wait here (and keeps hipcc from re-materialising the loads inside the loop).
+    };
+#endif
+    if (slicer && first < nblk) issue(first);
+    // the slice of the mean table: registers for the whole launch (plain loads, L2; hipcc's waits for them also cover
+    // the older DMA requests above -- loads retire in order)
+    half8 mh[KW][NT], ml[KW][NT];
 #pragma unroll
-        for (int kk = 0; kk < KW; ++kk)
+    for (int kk = 0; kk < KW; ++kk) {
+        const int ks = (slicer ? k0 : 0) + kk;
+        const gcchar_p tb = (gcchar_p)a.mtab + ((int64_t)ks * NT * 2048 + lane * 16);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                asm volatile("" : "+v"(mh[kk][t]));
-                asm volatile("" : "+v"(ml[kk][t]));
-            }
-        const int sw = (s >> 2) & 3;
-        const lchar *xr0 = my + s * 64 + (((h * 2) ^ sw) << 4);
-        const lchar *xr1 = my + s * 64 + (((h * 2 + 1) ^ sw) << 4);
-        lf4w *pw = (lf4w *)(part_l + wave * PW + lane * 16);
-        SL_STAMP(15, 1);
-        [[maybe_unused]] int row = 0;
-        for (int blk = first; blk < nblk; blk += stride) {
+        for (int t = 0; t < NT; ++t) {
+            mh[kk][t] = *(gh8 *)(tb + t * 2048);
+            ml[kk][t] = *(gh8 *)(tb + t * 2048 + 1024);
+        }
+    }
+    // ---- phase-2 roles (all eight waves): 16 consecutive lanes own a sample, slot j = 2 rho + p ------------------------
+    const int sl = lane >> 4, j = lane & 15;
+    const int rho = j >> 1, p = j & 1;
+    const int s2 = wave * 4 + sl;                    // sample of the block
+    const bool active = rho < a.reps;
+    const int rc = active ? rho : a.reps - 1;        // (spare slots compute on a copy and are masked out)
+    const int t2 = rc / RPT, ap = rc - t2 * RPT;
+    // phase-2 constants of slot j (sum weights of its partition, leaf constants of its two regions, root weights of
+    // class 0) live in LDS, 64 bytes per slot: four b128 reads per block instead of 16 registers held through phase 1
+    static_assert(S * I * I == 8 && 2 * I == 4 && S * S == 4, "slot record layout");
+    if (wave == 7 && sl == 0) {
+        const float *wp = a.W0 + ((int64_t)(rc * 2 + p) * S) * I * I;
+#pragma unroll
+        for (int e = 0; e < S * I * I; ++e) c2_l[j * 16 + e] = wp[e];
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+            for (int k = 0; k < I; ++k) c2_l[j * 16 + 8 + qq * I + k] = a.biasT[(p * NT + t2) * 16 + (ap * 2 + qq) * I + k];
+#pragma unroll
+        for (int e = 0; e < S * S; ++e) c2_l[j * 16 + 12 + e] = ((const float *)a.Wr)[rc * S * S + e];
+    }
+    const bool model_ok = a.elig[rc] != 0;
+    const int M = a.reps * S * S;
+    const float *wr0 = (const float *)a.Wr + rc * S * S;
+    // The fragments must have ARRIVED before the loop: a wait that hipcc placed at their first use inside it would be a
+    // vmcnt(0) behind the next block's DMA requests, every iteration.  An empty asm that reads each value pins the wait
+    // here (and keeps hipcc from re-materialising the loads inside the loop).
+#pragma unroll
+    for (int kk = 0; kk < KW; ++kk)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            asm volatile("" : "+v"(mh[kk][t]));
+            asm volatile("" : "+v"(ml[kk][t]));
+        }
+    {
+        int mo = model_ok ? 1 : 0;
+        asm volatile("" : "+v"(mo));
+    }
+    if (tid < 16) flag_l[tid] = 0u;
+
+    // partial accumulators in LDS: slice w, unit (16 bytes) U(s, h, g) = s*16 + ((2 g + h) ^ (s & 7)) for the four values
+    // of partition (repetition g, half h) of sample s.  Writers (fixed g; 8 consecutive lanes = 8 samples per
+    // ds_write_b128 group) cover 8 different units mod 8, readers (16-lane ds_read_b128 groups = two samples x 8 of the 16
+    // (g, h) slots) 16 different units mod 16: both sides conflict free.
+    const int sw = (s >> 2) & 3;
+#if DPK_SLICE_ROWRUN
+    constexpr int XROW = KW * 64, XKK = 64;          // bytes between rows / between K-steps of a row
+#else
+    constexpr int XROW = 64, XKK = 2048;
+#endif
+    const lchar *xr0 = my + s * XROW + (((h * 2) ^ sw) << 4);
+    const lchar *xr1 = my + s * XROW + (((h * 2 + 1) ^ sw) << 4);
+    lchar *pw = part_l + (slicer ? wave : 0) * PW + s * 256;
+
+    double ll_part = 0.0, pend_part = 0.0;
+    bool saw_nan = false;
+    unsigned long long exact_mask = 0ull;   // bit i: the i-th block of this work-group (host: at most 64 per launch)
+    SL_STAMP(15, 1);
+    [[maybe_unused]] int row = 0;
+    int it = 0;
+    for (int blk = first; blk < nblk; blk += stride, ++it) {
+        gf32x16 acc[NT];
+        float qlane = 0.f;
+        if (slicer) {
             SL_STAMP(row, 0);
             // the block's slice has landed (only this wave's own DMA requests are outstanding)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -152,7 +227,7 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
             float v[KW][8];
 #pragma unroll
             for (int kk = 0; kk < KW; ++kk) {
-                const gf32x4 x0 = *(lf4 *)(xr0 + kk * 2048), x1 = *(lf4 *)(xr1 + kk * 2048);
+                const gf32x4 x0 = *(lf4 *)(xr0 + kk * XKK), x1 = *(lf4 *)(xr1 + kk * XKK);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     v[kk][i] = x0[i];
@@ -162,130 +237,204 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
             // ... and is in registers: the slot is free, the next block's slice travels under this block's arithmetic
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             SL_STAMP(row, 2);
-            if (blk + stride < nblk && !(a.ablate & 4)) issue(blk + stride);
+#if DPK_SLICE_ROWRUN
+            asm volatile("" : "+v"(dp0));
+#endif
+            const bool more = blk + stride < nblk;
+            const int64_t nb0 = (int64_t)(blk + stride) * 32;
+            const bool nfull = nb0 + 32 <= a.B;
+            if (more && !nfull) issue(blk + stride);     // (ragged last block: the clamped form, all at once)
+            const gcchar_p nxt = (gcchar_p)(a.x + nb0 * D);
             SL_STAMP(row, 3);
-            gf32x16 acc[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
             gf32x2 tq2 = {0.f, 0.f};
-            if (!(a.ablate & 1)) {
 #pragma unroll
-                for (int kk = 0; kk < KW; ++kk) {
-#pragma unroll
-                    for (int i = 0; i < 8; i += 2) {
-                        const gf32x2 pv = {v[kk][i], v[kk][i + 1]};
-                        tq2 = __builtin_elementwise_fma(pv, pv, tq2);
-                    }
-                    half8 xh, xl;
-                    split8(v[kk], xh, xl);
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[kk][t], xh, acc[t], 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[kk][t], xl, acc[t], 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[kk][t], xh, acc[t], 0, 0, 0);
+            for (int kk = 0; kk < KW; ++kk) {
+                // the next block's K-step kk is requested between this K-step's products: a wave that waits at the
+                // request path (every DMA instruction of the compute unit queues there, ~35 cycles per KiB) leaves the
+                // matrix pipe to its SIMD partner instead of stalling in front of its own products
+                if (more && nfull) {
+#if DPK_SLICE_ROWRUN
+                    glds16<kGemmXNonTemporal>(dma_src(2 * kk, 32), nxt, my_u + kk * 2048);
+                    glds16<kGemmXNonTemporal>(dma_src(2 * kk + 1, 32), nxt, my_u + kk * 2048 + 1024);
+#else
+                    glds16<kGemmXNonTemporal>(voff[0] + kk * 64u, nxt, my_u + kk * 2048);
+                    glds16<kGemmXNonTemporal>(voff[1] + kk * 64u, nxt, my_u + kk * 2048 + 1024);
+#endif
                 }
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    const gf32x2 pv = {v[kk][i], v[kk][i + 1]};
+                    tq2 = __builtin_elementwise_fma(pv, pv, tq2);
+                }
+                half8 xh, xl;
+                split8(v[kk], xh, xl);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[kk][t], xh, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[kk][t], xl, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[kk][t], xh, acc[t], 0, 0, 0);
             }
+            qlane = tq2[0] + tq2[1];
             SL_STAMP(row, 4);
-            // the eighth wave has read the previous block's partials
-            gemm_lds_barrier();
-            SL_STAMP(row, 5);
+        }
+        // everyone has read the previous block's partials (and published its verdict on it)
+        gemm_lds_barrier();
+        SL_STAMP(row, 5);
+        if (slicer) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int i4 = 0; i4 < 4; ++i4) {
+                    const int g = t * 4 + i4;
                     const gf32x4 o = {acc[t][4 * i4], acc[t][4 * i4 + 1], acc[t][4 * i4 + 2], acc[t][4 * i4 + 3]};
-                    pw[(t * 4 + i4) * 64] = o;
+                    *(lf4w *)(pw + (((g * 2 + h) ^ (s & 7)) << 4)) = o;
                 }
-            q_l[wave * 64 + lane] = tq2[0] + tq2[1];
-            gemm_lds_barrier();   // this block's partials are complete
-            SL_STAMP(row, 6);
-            ++row;
+            q_l[wave * 64 + lane] = qlane;
         }
-    } else {
-        // ============================================ the eighth wave ==============================================
-        for (int e = lane; e < a.reps * 2 * S * I * I; e += 64) w0_l[e] = a.W0[e];
-        bool model_ok = true;
-        for (int e = lane; e < NT * RPT; e += 64) model_ok = model_ok && (a.elig[e] != 0);
-        model_ok = __all(model_ok);
-        float cst[NT][16];
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) cst[t][i] = a.biasT[(h * NT + t) * 16 + i];
-        const lf4 *pr = (const lf4 *)(part_l + lane * 16);
-        double ll_part = 0.0;
-        bool saw_nan = false;
-        unsigned long long exact_mask = 0ull;   // bit i: the i-th block of this work-group (host: at most 64 per launch)
-        [[maybe_unused]] int row = 0;
-        int it = 0;
-        for (int blk = first; blk < nblk; blk += stride, ++it) {
-            gemm_lds_barrier();   // (hands the partial buffer to the slice waves)
-            gemm_lds_barrier();   // the block's seven partials are in LDS
-            SL_STAMP(row, 0);
-            gf32x16 acc[NT];
-            float qsum;
-            {
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int i4 = 0; i4 < 4; ++i4) {
-                        gf32x4 sum4 = pr[(t * 4 + i4) * 64];
-#pragma unroll
-                        for (int w = 1; w < kSliceCompute; ++w) sum4 += pr[(w * (PW / 16)) + (t * 4 + i4) * 64];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[t][4 * i4 + j] = sum4[j];
-                    }
-                qsum = q_l[lane];
-#pragma unroll
-                for (int w = 1; w < kSliceCompute; ++w) qsum += q_l[w * 64 + lane];
-            }
-            // (every read above has returned before this wave arrives at the next barrier: gemm_lds_barrier waits)
-            SL_STAMP(row, 1);
-            if (a.ablate & 2) { ++row; continue; }
-            const int64_t bw0 = (int64_t)blk * 32;
-            const int64_t b = bw0 + s;
-            const float qtot = qsum + __shfl_xor(qsum, 32, 64);
-            saw_nan = saw_nan || (qtot != qtot);
-            // the f16 split and the expanded square hold while sum x^2 <= 36 D (|mu| <= 6: DESIGN 3.3): NaN, +-inf and
-            // huge evidence fail the same test
-            const bool lane_exact = !(qtot <= kExpandBound * kExpandBound * (float)D);
-            bool exact = !model_ok || __any(lane_exact);
-            if (!exact) {
-                double part = 0.0;
-                exact = gemm_upper_fast<I, S, NT>(a, acc, cst, w0_l, qtot, h, b, part);
-                if (!exact) ll_part += part;
-            }
-            // a block outside the fast path's envelope is evaluated exactly AFTER the stream, by all eight waves (what the
-            // fast path stored for it is overwritten there).  Inside this loop the exact evaluation cost 150 spilled
-            // registers -- and a kernel with scratch pays for it at every dispatch, used or not.
-            if (exact) exact_mask |= 1ull << it;
-            SL_STAMP(row, 2);
-            ++row;
+        // the previous block's verdict: its sum joins the total only if no wave left the fast path on it (the exact
+        // evaluation at the end then covers -- and sums -- all 32 samples of the block)
+        if (it > 0) {
+            const lunsigned *fl = flag_l + ((it - 1) & 1) * 8;
+            const unsigned any_bad = (unsigned)__builtin_amdgcn_readfirstlane(
+                (int)((fl[0] | fl[1]) | (fl[2] | fl[3]) | (fl[4] | fl[5]) | (fl[6] | fl[7])));
+            if (any_bad) exact_mask |= 1ull << (it - 1);
+            else ll_part += pend_part;
         }
-        if (a.ll_sum != nullptr) {
-            const double red = wave_reduce_sum(ll_part);
-            if (lane == 0) {
-                atomicAdd(a.ll_sum, red);
-                if (blockIdx.x == 0) atomicAdd(a.ll_sum + 1, (double)a.B * (double)a.C);
+        gemm_lds_barrier();   // this block's partials are complete
+        SL_STAMP(row, 6);
+
+        // =========================== phase 2: one (sample, repetition, partition) per lane ==============================
+        // leaf sums of the lane's two regions: seven partials each, fixed order (launches agree bit for bit)
+        // (the phase-2 addresses are recomputed per block from an opaque copy of the lane id: held through phase 1 they
+        // cost the registers that decide between 256 and a spill)
+        int jo = j;
+        asm volatile("" : "+v"(jo));
+        const lchar *pr = part_l + s2 * 256 + ((jo ^ (s2 & 7)) << 4);
+        const lfloat *qr = q_l + (jo < 2 * kSliceCompute ? (jo >> 1) * 64 + (jo & 1) * 32 + s2 : 0);
+        gf32x4 lf = *(lf4 *)pr;
+#pragma unroll
+        for (int w = 1; w < kSliceCompute; ++w) lf += *(lf4 *)(pr + w * PW);
+        float qv = *qr;
+        qv = j < 2 * kSliceCompute ? qv : 0.f;
+        const float qtot = row16_sum(qv);
+        const int64_t b2 = (int64_t)blk * 32 + s2;
+        saw_nan = saw_nan || (qtot != qtot);
+        // the f16 split and the expanded square hold while sum x^2 <= 36 D (|mu| <= 6: DESIGN 3.3): NaN, +-inf and huge
+        // evidence fail the same test
+        bool bad = !(qtot <= kExpandBound * kExpandBound * (float)D) || (active && !model_ok);
+        const lf4 *c2 = (const lf4 *)(c2_l + jo * 16);
+        const gf32x4 w0a = c2[0], w0b = c2[1], cs4 = c2[2], wr4 = c2[3];
+        const float w0[S][I * I] = {{w0a[0], w0a[1], w0a[2], w0a[3]}, {w0b[0], w0b[1], w0b[2], w0b[3]}};
+        float va[I], vc[I];
+#pragma unroll
+        for (int k = 0; k < I; ++k) {
+            va[k] = lf[k] + cs4[k];
+            vc[k] = lf[I + k] + cs4[I + k];
+        }
+        float ea[I], ec[I];
+        const float ma = exp2_children<I>(va, ea), mc = exp2_children<I>(vc, ec);
+        float n1[S];
+#pragma unroll
+        for (int o = 0; o < S; ++o) {
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < I; ++i) {
+                float tt = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < I; ++jj) tt = fmaf(w0[o][i * I + jj], ec[jj], tt);
+                v = fmaf(ea[i], tt, v);
+            }
+            n1[o] = fmaf(__builtin_amdgcn_logf(v), kLn2, ma + mc);
+            bad = bad || (v < 1e-30f && active);   // vanished: dominant pair under a vanishing weight
+        }
+        // root: the two partitions of a repetition meet (lane ^ 1), then the repetitions of the sample
+        float ta[S], tc[S];
+#pragma unroll
+        for (int o = 0; o < S; ++o) {
+            const float other = dpp_f<kDppXor1>(n1[o]);
+            ta[o] = p == 0 ? n1[o] : other;
+            tc[o] = p == 0 ? other : n1[o];
+        }
+        float ra[S], rcx[S];
+        const float m2 = exp2_children<S>(ta, ra) + exp2_children<S>(tc, rcx);
+        const float mr = active ? m2 : -INFINITY;
+        const float mtop = row16_max(mr);
+        const float mtop0 = (mtop == -INFINITY) ? 0.f : mtop;
+        const float scale = (active && p == 0) ? __builtin_amdgcn_exp2f((mr - mtop0) * kL2E) : 0.f;
+        const float qterm = -0.5f * qtot;
+        const bool writer = j == 0 && b2 < a.B;
+        double part = 0.0;
+        for (int cl = 0; cl < a.C; ++cl) {
+            float wr[S * S];
+            if (cl == 0) {
+#pragma unroll
+                for (int e = 0; e < S * S; ++e) wr[e] = wr4[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < S * S; ++e) wr[e] = wr0[(int64_t)cl * M + e];
+            }
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                float tt = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < S; ++jj) tt = fmaf(wr[i * S + jj], rcx[jj], tt);
+                v = fmaf(ra[i], tt, v);
+            }
+            bad = bad || (v < 1e-30f && mr > -INFINITY);
+            const float tot = row16_sum(v * scale);
+            const float ll = ((mtop > -INFINITY) ? fmaf(__builtin_amdgcn_logf(tot), kLn2, mtop) : -INFINITY) + qterm;
+            if (writer) {
+                a.out[b2 * a.C + cl] = ll;      // (an exact verdict rewrites these at the end of the kernel)
+                part += (double)ll;
             }
         }
-        if (__any(saw_nan) && lane == 0 && a.slow_flag != nullptr) *a.slow_flag = a.launch_seq;
-        if (lane == 0) *exact_l = exact_mask;
+        pend_part = part;
+        // the wave's verdict on its 4 samples of this block, read by everyone behind the next barrier
+        const bool wave_bad = __any(bad);
+        if (lane == 0) flag_l[(it & 1) * 8 + wave] = wave_bad ? 1u : 0u;
+        SL_STAMP(row, 7);
+        ++row;
     }
     SL_STAMP(15, 2);
-    // ---- blocks that left the fast path: exact evaluation, a wave per block, the x slots as the nodes' scratch ----------
+    // ---- the last block's verdict, then the blocks that left the fast path: exact evaluation, a wave per block ---------
     __syncthreads();
-    const unsigned long long todo = *exact_l;
-    if (todo != 0ull) {
-        LseScratch sc{reinterpret_cast<float *>(smem_generic) + tid * (2 * NMAX)};
+    if (it > 0) {
+        const lunsigned *fl = flag_l + ((it - 1) & 1) * 8;
+        const unsigned any_bad = (fl[0] | fl[1]) | (fl[2] | fl[3]) | (fl[4] | fl[5]) | (fl[6] | fl[7]);
+        if (any_bad) exact_mask |= 1ull << (it - 1);
+        else ll_part += pend_part;
+    }
+    if (a.ll_sum != nullptr) {
+        // {sum of LLs, count}: one atomic per work-group (and one for the count per launch)
+        double *red_l = reinterpret_cast<double *>(smem_generic + kSliceCompute * kSliceSlot);   // (the partials are idle now)
+        const double red = wave_reduce_sum(ll_part);
+        if (lane == 0) red_l[wave] = red;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) tot += red_l[w];
+            atomicAdd(a.ll_sum, tot);
+            if (blockIdx.x == 0) atomicAdd(a.ll_sum + 1, (double)a.B * (double)a.C);
+        }
+    }
+    if (__any(saw_nan) && lane == 0 && a.slow_flag != nullptr) *a.slow_flag = a.launch_seq;
+    if (exact_mask != 0ull) {   // (every wave holds the same mask)
+        int tid_x = (int)threadIdx.x;   // (an opaque copy: nothing of this tail is worth a register held through the loop)
+        asm volatile("" : "+v"(tid_x));
+        const int lane_x = tid_x & 63;
+        LseScratch sc{reinterpret_cast<float *>(smem_generic) + tid_x * (2 * NMAX)};   // (the x slots are idle now)
         int n = 0;
-        for (int it = 0; it < 64; ++it) {
-            if (!((todo >> it) & 1ull)) continue;
+        for (int e = 0; e < 64; ++e) {
+            if (!((exact_mask >> e) & 1ull)) continue;
             if ((n++ & 7) != wave) continue;
-            gemm_exact_body<I, S, NT>(a, (int64_t)(first + it * stride) * 32, lane, sc);
+            gemm_exact_body<I, S, NT>(a, (int64_t)(first + e * stride) * 32, lane_x, sc);
         }
     }
 }
@@ -294,7 +443,7 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
 // host side
 // ------------------------------------------------------------------------------------------------
 bool gemm_slice_shape_ok(int D, int reps, int I, int S, int NT) {
-    if (!(I == 2 && S == 2) || NT > 2) return false;   // (instantiations built; the mapping itself is general in I, S)
+    if (!(I == 2 && S == 2) || NT != 2) return false;   // (the instantiation built: two channels, 5..8 repetitions)
     if (D != 16 * kSliceCompute * kSliceKW) return false;   // 784 = 7 slices x 7 K-steps of 16 features
     return slice_lds_bytes(NT, reps * 2 * S * I * I) <= 160 * 1024;
 }
@@ -350,7 +499,7 @@ static int gemm_slice_launch(const GemmArgs &a0, hipStream_t st) {
 
 // The caller (ratspn_gemm_forward) has built / checked the tables and filled the argument block.
 int ratspn_gemm_slice_forward(const GemmArgs &a, int I, int S, int NT, hipStream_t st) {
-    if (I == 2 && S == 2) return NT == 1 ? gemm_slice_launch<2, 2, 1>(a, st) : gemm_slice_launch<2, 2, 2>(a, st);
+    if (I == 2 && S == 2 && NT == 2) return gemm_slice_launch<2, 2, 2>(a, st);
     set_error("ratspn_gemm_slice: (channels=%d, sums=%d) not built", I, S);
     return DPK_EUNSUPPORTED;
 }
