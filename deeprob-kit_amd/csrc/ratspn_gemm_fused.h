@@ -118,13 +118,15 @@ template <int NI> __device__ __forceinline__ float exp2_children(const float (&x
 // Exact per-element evaluation of the 32 samples of a wave (any scale, any evidence): lane (s, h) takes the
 // repetitions rho = 2m + h, the two lanes of a sample meet in one shuffle per class.  Slow by design.
 template <int I, int S, int NT>
-__device__ __forceinline__ void gemm_exact_body(const GemmArgs &a, int64_t bw0, int lane, LseScratch sc) {
+__device__ __forceinline__ void gemm_exact_body(const GemmArgs &a, int64_t bw0, int lane, LseScratch sc, unsigned gmask = 0xFu) {
+    // gmask: bit g set = the samples 8 g .. 8 g + 7 of the wave are stored (and summed); the slice mapping leaves the
+    // fast path in groups of 8 samples
     constexpr int RPT = 8 / I;
     constexpr int RH = (NT * RPT + 1) / 2;   // repetitions per lane half
     const int s = lane & 31, h = lane >> 5;
     const int64_t b = bw0 + s;
-    const bool valid = b < a.B;
-    const float *xr = a.x + (valid ? b : a.B - 1) * a.D;
+    const bool valid = b < a.B && ((gmask >> (s >> 3)) & 1u) != 0u;
+    const float *xr = a.x + (b < a.B ? b : a.B - 1) * a.D;
     const int d = a.d;
     float n1[RH][2][S];
 #pragma unroll

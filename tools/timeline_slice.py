@@ -29,19 +29,21 @@ t = buf.reshape(grid, 8, 16, 8).astype(np.int64)
 nb = -(-(-(-B // 32)) // grid)
 t0 = t[:, :, 15, 0].min()          # (s_memtime is per-XCD comparable only approximately; good enough for phases)
 print('B = %d, %d work-groups, %d blocks each; s_memtime ticks (100 MHz -> 10 ns each? no: shader clock)' % (B, grid, nb))
-names = ['loop top', 'DMA landed', 'slot in regs', '(ragged issue)', 'K loop + next DMA', 'barrier A', 'partials + barrier B', 'phase 2']
+names = ['loop top', 'slot landed', 'slot in regs', 'K loop', 'readers done (wait)', 'partials written', 'all written (wait)', 'upper layers']
 c = t[:, :7]
 print('slice waves, ticks between stamps, mean over work-groups / waves, per block row:')
 print('  row  ' + ' '.join('%20s' % s for s in names[1:]) + '   block total')
-for r in range(min(nb, 15)):
-    d = [(c[:, :, r, i + 1] - c[:, :, r, i]).mean() for i in range(7)]
-    tot = (c[:, :, r, 7] - c[:, :, r, 0]).mean()
-    print('  %3d  ' % r + ' '.join('%20.0f' % v for v in d) + '   %10.0f' % tot)
+for grp, sel, last in (('reader waves 0-3', slice(0, 4), 7), ('waves 4-6', slice(4, 7), 5)):
+    print(' ', grp)
+    for r in range(min(nb, 15)):
+        d = [(c[:, sel, r, i + 1] - c[:, sel, r, i]).mean() for i in range(last)]
+        tot = (c[:, sel, r, last] - c[:, sel, r, 0]).mean()
+        print('  %3d  ' % r + ' '.join('%20.0f' % v for v in d) + ' ' * (21 * (7 - last)) + '   %10.0f' % tot)
 start = t[:, :, 15, 0]
 end = t[:, :, 15, 2]
 print('kernel span per wave (entry -> loop exit), mean / max ticks: %.0f / %d' % ((end - start).mean(), (end - start).max()))
 print('entry -> loop (table in registers), mean ticks: %.0f' % (t[:, :7, 15, 1] - t[:, :7, 15, 0]).mean())
-for w in (0, 3, 7):
+for w in (0, 3, 4, 6):
     print('work-group 0, wave %d rows (ticks since entry):' % w)
     for r in range(min(nb, 15)):
         print('   ', ' '.join('%7d' % (v - t[0, w, 15, 0]) for v in t[0, w, r, :8]))
