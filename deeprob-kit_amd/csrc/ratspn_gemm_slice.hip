@@ -55,6 +55,7 @@ __host__ __device__ constexpr int slice_lds_bytes(int NT, int w0_floats) {
 #endif
 
 constexpr int kSliceReaders = 4;                 // waves 0..3 also evaluate the upper layers (8 samples of a block each)
+constexpr int kSliceServed = 4;                  // ... and have their slots filled by the loader wave; waves 4..6 fill their own
 constexpr int kSliceSpinCap = 1 << 22;           // polls before a wait gives up (~0.5 s: a protocol error, never a hang)
 // flag words (u32 counters of blocks) in LDS
 constexpr int kFlagLanded = 0, kFlagFreed = 8, kFlagWritten = 16, kFlagRead = 24, kFlagC2 = 28, kFlagErr = 29, kFlagWords = 32;
@@ -113,17 +114,35 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
     if (tid < kFlagWords) flag_l[tid] = 0u;
     gemm_lds_barrier();   // (the only barrier in front of the stream: the counters start at zero for everyone)
 
+    // One slot's worth of DMA: slice w of the 32 rows at xt (rows beyond nvalid re-fetch the last one: never stored).
+    const int dr0 = lane / 28;
+    int dp0 = lane - dr0 * 28;
+    auto fill_slot = [&](gcchar_p xt, int nvalid, int w) {
+        const unsigned dst = (unsigned)(uintptr_t)smem + w * kSliceSlot;
+#pragma unroll
+        for (int jd = 0; jd < 2 * KW; ++jd) {
+            const int pp = dp0 + 8 * jd;                              // (64 j = 28 * 2j + 8j)
+            const int c = (pp * 2341) >> 16;                          // pp / 28 for pp < 896
+            const int r = 2 * jd + dr0 + c, pos = pp - 28 * c;
+            const int sp = pos ^ ((r >> 2) & 3);
+            glds16<kGemmXNonTemporal>((unsigned)(min(r, nvalid - 1) * D + w * (KW * 16) + sp * 4) * 4u, xt, dst + jd * 1024);
+        }
+    };
+    auto fill_block = [&](int it, int w) {
+        const int64_t b0 = (int64_t)(first + it * stride) * 32;
+        fill_slot((gcchar_p)(a.x + b0 * D), (int)min((int64_t)32, a.B - b0), w);
+    };
+
     if (wave == kSliceCompute) {
         // ================================================ loader ====================================================
         // Slot layout [32 rows][28 pieces of 16 bytes] = the slice's 448 contiguous bytes of every row: DMA instruction j
         // (of 14) copies pieces q = 64 j + lane (row q / 28, piece q % 28).  The four pieces of a K-step are XOR-swizzled
         // by (row >> 2) & 3 on the source side.  At most four slots' requests are outstanding (vmcnt is a 6-bit counter);
         // before slot-issue k goes out, slot-issue k - 4 has landed and is published.
-        const int dr0 = lane / 28, dp0 = lane - dr0 * 28;
         int pit = 0, pw_ = 0;                                                 // next slot-issue to publish
         auto publish = [&]() {
             if (lane == 0) slice_post(flag_l + kFlagLanded + pw_, (unsigned)(pit + 1));
-            if (++pw_ == kSliceCompute) { pw_ = 0; ++pit; }
+            if (++pw_ == kSliceServed) { pw_ = 0; ++pit; }
         };
         int k = 0;
         bool ok = true;
@@ -131,21 +150,14 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
             const int64_t b0 = (int64_t)(first + it * stride) * 32;
             const gcchar_p xt = (gcchar_p)(a.x + b0 * D);
             const int nvalid = (int)min((int64_t)32, a.B - b0);
-            for (int w = 0; w < kSliceCompute; ++w, ++k) {
+            for (int w = 0; w < kSliceServed; ++w, ++k) {
                 if (k >= 4) {
                     asm volatile("s_waitcnt vmcnt(42)" ::: "memory");
                     publish();
                 }
                 if (it > 0 && !slice_wait<1>(flag_l + kFlagFreed + w, (unsigned)it)) { ok = false; break; }
-                const unsigned dst = (unsigned)(uintptr_t)smem + w * kSliceSlot;
-#pragma unroll
-                for (int jd = 0; jd < 2 * KW; ++jd) {
-                    const int pp = dp0 + 8 * jd;                              // (64 j = 28 * 2j + 8j)
-                    const int c = (pp * 2341) >> 16;                          // pp / 28 for pp < 896
-                    const int r = 2 * jd + dr0 + c, pos = pp - 28 * c;
-                    const int sp = pos ^ ((r >> 2) & 3);
-                    glds16<kGemmXNonTemporal>((unsigned)(min(r, nvalid - 1) * D + w * (KW * 16) + sp * 4) * 4u, xt, dst + jd * 1024);
-                }
+                asm volatile("" : "+v"(dp0));
+                fill_slot(xt, nvalid, w);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -156,6 +168,11 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
         const int s = lane & 31, h = lane >> 5;      // MFMA roles: sample of the block, half of the K-step / of the columns
         const int k0 = wave * KW;
         lchar *my = smem + wave * kSliceSlot;
+        // waves 4..6 (no reader duty: ~7k idle cycles per block) fill their own slot -- producer and consumer of the slot
+        // are the same wave, a counted vmcnt is the whole protocol -- so 42 + 56 DMA instructions can be outstanding per
+        // compute unit (one loader wave alone: 56, and it became latency bound)
+        const bool self = wave >= kSliceServed;
+        if (self && nit > 0) fill_block(0, wave);
         // the slice of the mean table: registers for the whole launch
         half8 mh[KW][NT], ml[KW][NT];
 #pragma unroll
@@ -228,7 +245,9 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
             const int blk = first + it * stride;
             SL_STAMP(row, 0);
             // ---- the block's slice: landed -> registers -> slot free ----------------------------------------------
-            if (!slice_wait<1>(flag_l + kFlagLanded + wave, (unsigned)(it + 1))) { ok = false; break; }
+            if (self) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (only this wave's own DMA requests are outstanding)
+            } else if (!slice_wait<1>(flag_l + kFlagLanded + wave, (unsigned)(it + 1))) { ok = false; break; }
             SL_STAMP(row, 1);
             float v[KW][8];
 #pragma unroll
@@ -241,7 +260,10 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) slice_post(flag_l + kFlagFreed + wave, (unsigned)(it + 1));
+            if (self) {
+                asm volatile("" : "+v"(dp0));   // (opaque per block: hipcc otherwise hoists the 14 source offsets out of the loop)
+                if (it + 1 < nit) fill_block(it + 1, wave);
+            } else if (lane == 0) slice_post(flag_l + kFlagFreed + wave, (unsigned)(it + 1));
             SL_STAMP(row, 2);
             // ---- the slice's share of the leaf GEMM ----------------------------------------------------------------
             gf32x16 acc[NT];
