@@ -49,16 +49,18 @@ __host__ __device__ constexpr int slice_lds_bytes(int NT, int w0_floats) {
 }
 
 #ifdef DPK_TIMELINE
+#define SL_RT(slot) do { __builtin_amdgcn_sched_barrier(0); if (a.dbg && lane == 0 && blockIdx.x < 256) a.dbg[(((int64_t)blockIdx.x * 8 + wave) * 16 + 15) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define SL_STAMP(row, slot) do { __builtin_amdgcn_sched_barrier(0); if (a.dbg && lane == 0 && (row) < 16 && blockIdx.x < 256) a.dbg[(((int64_t)blockIdx.x * 8 + wave) * 16 + (row)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define SL_STAMP(row, slot) do { } while (0)
+#define SL_RT(slot) do { } while (0)
 #endif
 
 constexpr int kSliceReaders = 4;                 // waves 0..3 also evaluate the upper layers (8 samples of a block each)
 constexpr int kSliceServed = 4;                  // ... and have their slots filled by the loader wave; waves 4..6 fill their own
 constexpr int kSliceSpinCap = 1 << 22;           // polls before a wait gives up (~0.5 s: a protocol error, never a hang)
 // flag words (u32 counters of blocks) in LDS
-constexpr int kFlagLanded = 0, kFlagFreed = 8, kFlagWritten = 16, kFlagRead = 24, kFlagC2 = 28, kFlagErr = 29, kFlagWords = 32;
+constexpr int kFlagLanded = 0, kFlagFreed = 8, kFlagC2 = 28, kFlagErr = 29, kFlagWords = 32;
 
 // spin until every one of n consecutive counters has reached `target` (wave-uniform; s_sleep between polls)
 template <int N> __device__ __forceinline__ bool slice_wait(const lunsigned *p, unsigned target) {
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
     const int first = (int)blockIdx.x, stride = (int)gridDim.x;
     const int nit = first < nblk ? (nblk - first + stride - 1) / stride : 0;  // blocks of this work-group
     SL_STAMP(15, 0);
+    SL_RT(4);
     if (tid < kFlagWords) flag_l[tid] = 0u;
     gemm_lds_barrier();   // (the only barrier in front of the stream: the counters start at zero for everyone)
 
@@ -135,33 +138,28 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
 
     if (wave == kSliceCompute) {
         // ================================================ loader ====================================================
-        // Slot layout [32 rows][28 pieces of 16 bytes] = the slice's 448 contiguous bytes of every row: DMA instruction j
-        // (of 14) copies pieces q = 64 j + lane (row q / 28, piece q % 28).  The four pieces of a K-step are XOR-swizzled
-        // by (row >> 2) & 3 on the source side.  At most four slots' requests are outstanding (vmcnt is a 6-bit counter);
-        // before slot-issue k goes out, slot-issue k - 4 has landed and is published.
-        int pit = 0, pw_ = 0;                                                 // next slot-issue to publish
-        auto publish = [&]() {
-            if (lane == 0) slice_post(flag_l + kFlagLanded + pw_, (unsigned)(pit + 1));
-            if (++pw_ == kSliceServed) { pw_ = 0; ++pit; }
-        };
-        int k = 0;
+        // fills the slots of waves 0..3: 56 DMA instructions per block (vmcnt is a 6-bit counter: one wave holds at most 63).
+        // Per block: its requests of the previous round have landed -> publish; the four slots have been copied into
+        // registers (counters) -> refill them with the next block; then the block's two barriers with everyone.
         bool ok = true;
-        for (int it = 0; it < nit && ok; ++it) {
-            const int64_t b0 = (int64_t)(first + it * stride) * 32;
-            const gcchar_p xt = (gcchar_p)(a.x + b0 * D);
-            const int nvalid = (int)min((int64_t)32, a.B - b0);
-            for (int w = 0; w < kSliceServed; ++w, ++k) {
-                if (k >= 4) {
-                    asm volatile("s_waitcnt vmcnt(42)" ::: "memory");
-                    publish();
-                }
-                if (it > 0 && !slice_wait<1>(flag_l + kFlagFreed + w, (unsigned)it)) { ok = false; break; }
-                asm volatile("" : "+v"(dp0));
-                fill_slot(xt, nvalid, w);
-            }
+        if (nit > 0) {
+#pragma unroll 1
+            for (int w = 0; w < kSliceServed; ++w) fill_block(0, w);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        while (pit < nit && ok) publish();
+        for (int it = 0; it < nit; ++it) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) slice_post(flag_l + kFlagLanded, (unsigned)(it + 1));
+            if (it + 1 < nit) {
+#pragma unroll 1
+                for (int w = 0; w < kSliceServed; ++w) {
+                    ok = slice_wait<1>(flag_l + kFlagFreed + w, (unsigned)(it + 1)) && ok;
+                    asm volatile("" : "+v"(dp0));
+                    fill_block(it + 1, w);
+                }
+            }
+            gemm_lds_barrier();   // A
+            gemm_lds_barrier();   // B
+        }
         if (!ok && lane == 0) flag_l[kFlagErr] = 1u;
     } else {
         // ================================================ slice waves ===============================================
@@ -241,175 +239,183 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
         unsigned long long exact_mask = 0ull;        // bit i: this reader's 8 samples of the work-group's i-th block left the fast path
         SL_STAMP(15, 1);
         [[maybe_unused]] int row = 0;
-        for (int it = 0; it < nit && ok; ++it) {
-            const int blk = first + it * stride;
-            SL_STAMP(row, 0);
-            // ---- the block's slice: landed -> registers -> slot free ----------------------------------------------
-            if (self) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (only this wave's own DMA requests are outstanding)
-            } else if (!slice_wait<1>(flag_l + kFlagLanded + wave, (unsigned)(it + 1))) { ok = false; break; }
-            SL_STAMP(row, 1);
-            float v[KW][8];
-#pragma unroll
-            for (int kk = 0; kk < KW; ++kk) {
-                const gf32x4 x0 = *(lf4 *)(xr0 + kk * 64), x1 = *(lf4 *)(xr1 + kk * 64);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[kk][i] = x0[i];
-                    v[kk][4 + i] = x1[i];
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (self) {
-                asm volatile("" : "+v"(dp0));   // (opaque per block: hipcc otherwise hoists the 14 source offsets out of the loop)
-                if (it + 1 < nit) fill_block(it + 1, wave);
-            } else if (lane == 0) slice_post(flag_l + kFlagFreed + wave, (unsigned)(it + 1));
-            SL_STAMP(row, 2);
-            // ---- the slice's share of the leaf GEMM ----------------------------------------------------------------
+        // Iteration `it`: the slice's products of block it, then (waves 0..3, whose slots the loader fills: they have no
+        // DMA to issue) the upper layers of block it - 1 from the partials written at the end of the previous iteration,
+        // then barrier A (those partials are read), the partials of block it, barrier B.  One extra iteration finishes
+        // the last block's upper layers.
+        for (int it = 0; it <= nit; ++it) {
+            const bool body = it < nit;
             gf32x16 acc[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-            gf32x2 tq2 = {0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < KW; ++kk) {
-#pragma unroll
-                for (int i = 0; i < 8; i += 2) {
-                    const gf32x2 pv = {v[kk][i], v[kk][i + 1]};
-                    tq2 = __builtin_elementwise_fma(pv, pv, tq2);
+            float qlane = 0.f;
+            SL_STAMP(row, 0);
+            if (body) {
+                // ---- the block's slice: landed -> registers -> slot free ------------------------------------------
+                if (self) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (only this wave's own DMA requests are outstanding)
+                } else {
+                    ok = slice_wait<1>(flag_l + kFlagLanded, (unsigned)(it + 1)) && ok;
                 }
-                half8 xh, xl;
-                split8(v[kk], xh, xl);
+                SL_STAMP(row, 1);
+                float v[KW][8];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[kk][t], xh, acc[t], 0, 0, 0);
+                for (int kk = 0; kk < KW; ++kk) {
+                    const gf32x4 x0 = *(lf4 *)(xr0 + kk * 64), x1 = *(lf4 *)(xr1 + kk * 64);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[kk][t], xl, acc[t], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) {
+                        v[kk][i] = x0[i];
+                        v[kk][4 + i] = x1[i];
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (self) {
+                    asm volatile("" : "+v"(dp0));   // (opaque per block: hipcc otherwise hoists the 14 source offsets out of the loop)
+                    if (it + 1 < nit) fill_block(it + 1, wave);
+                } else if (lane == 0) slice_post(flag_l + kFlagFreed + wave, (unsigned)(it + 1));
+                SL_STAMP(row, 2);
+                // ---- the slice's share of the leaf GEMM ------------------------------------------------------------
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[kk][t], xh, acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+                gf32x2 tq2 = {0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < KW; ++kk) {
+#pragma unroll
+                    for (int i = 0; i < 8; i += 2) {
+                        const gf32x2 pv = {v[kk][i], v[kk][i + 1]};
+                        tq2 = __builtin_elementwise_fma(pv, pv, tq2);
+                    }
+                    half8 xh, xl;
+                    split8(v[kk], xh, xl);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[kk][t], xh, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[kk][t], xl, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[kk][t], xh, acc[t], 0, 0, 0);
+                }
+                qlane = tq2[0] + tq2[1];
+                SL_STAMP(row, 3);
             }
-            SL_STAMP(row, 3);
-            // ---- partial accumulator -> LDS once the readers are done with the previous block's ---------------------
-            if (!slice_wait<kSliceReaders>(flag_l + kFlagRead, (unsigned)it)) { ok = false; break; }
-            SL_STAMP(row, 4);
+            if (reader && it > 0) {
+                // =========================== upper layers of block it - 1: lane = (sample, repetition) ====================
+                const int blk = first + (it - 1) * stride;
+                if (it == 1) ok = slice_wait<1>(flag_l + kFlagC2, 1u) && ok;
+                // (addresses from an opaque copy of the lane id: held through phase 1 they would cost registers the K loop needs)
+                int lo = lane;
+                asm volatile("" : "+v"(lo));
+                const int rho_o = lo & 7;
+                // leaf sums of the repetition's two partitions: seven partials each, fixed order (launches agree bit for bit)
+                const lchar *pr0 = part_l + s2 * 256 + (((rho_o * 2) ^ (s2 & 7)) << 4);
+                const lchar *pr1 = part_l + s2 * 256 + (((rho_o * 2 + 1) ^ (s2 & 7)) << 4);
+                gf32x4 lf[2] = {*(lf4 *)pr0, *(lf4 *)pr1};
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int i4 = 0; i4 < 4; ++i4) {
-                    const int g = t * 4 + i4;
-                    const gf32x4 o = {acc[t][4 * i4], acc[t][4 * i4 + 1], acc[t][4 * i4 + 2], acc[t][4 * i4 + 3]};
-                    *(lf4w *)(pw + (((g * 2 + h) ^ (s & 7)) << 4)) = o;
+                for (int w = 1; w < kSliceCompute; ++w) {
+                    lf[0] += *(lf4 *)(pr0 + w * PW);
+                    lf[1] += *(lf4 *)(pr1 + w * PW);
                 }
-            q_l[wave * 64 + lane] = tq2[0] + tq2[1];
-            if (lane == 0) slice_post(flag_l + kFlagWritten + wave, (unsigned)(it + 1));   // (LDS executes a wave's operations in order)
-            SL_STAMP(row, 5);
-            if (!reader) { ++row; continue; }
-
-            // =========================== upper layers: lane = (sample, repetition) ======================================
-            if (it == 0 && !slice_wait<1>(flag_l + kFlagC2, 1u)) { ok = false; break; }
-            if (!slice_wait<kSliceCompute>(flag_l + kFlagWritten, (unsigned)(it + 1))) { ok = false; break; }
-            SL_STAMP(row, 6);
-            // (addresses from an opaque copy of the lane id: held through phase 1 they would cost registers the K loop needs)
-            int lo = lane;
-            asm volatile("" : "+v"(lo));
-            const int rho_o = lo & 7;
-            // leaf sums of the repetition's two partitions: seven partials each, fixed order (launches agree bit for bit)
-            const lchar *pr0 = part_l + s2 * 256 + (((rho_o * 2) ^ (s2 & 7)) << 4);
-            const lchar *pr1 = part_l + s2 * 256 + (((rho_o * 2 + 1) ^ (s2 & 7)) << 4);
-            gf32x4 lf[2] = {*(lf4 *)pr0, *(lf4 *)pr1};
+                // sum of squares of the sample: 14 partials (7 slices x 2 K halves), two per lane
+                const int qi = rho_o < kSliceCompute ? rho_o : 0;
+                float qv = q_l[qi * 64 + s2] + q_l[qi * 64 + 32 + s2];
+                const lf4 *c2 = (const lf4 *)(c2_l + rho_o * 32);
+                const gf32x4 w00 = c2[0], w01 = c2[1], w10 = c2[2], w11 = c2[3], cs0 = c2[4], cs1 = c2[5], wr4 = c2[6];
+                qv = rho_o < kSliceCompute ? qv : 0.f;
+                qv += dpp_f<kDppXor1>(qv);
+                qv += dpp_f<kDppXor2>(qv);
+                const float qtot = qv + dpp_f<kDppHalfMirror>(qv);
+                const int64_t b2 = (int64_t)blk * 32 + s2;
+                saw_nan = saw_nan || (qtot != qtot);
+                // the f16 split and the expanded square hold while sum x^2 <= 36 D (|mu| <= 6: DESIGN 3.3): NaN, +-inf and
+                // huge evidence fail the same test
+                bool bad = !(qtot <= kExpandBound * kExpandBound * (float)D) || (active && !model_ok);
+                float n1[2][S];
 #pragma unroll
-            for (int w = 1; w < kSliceCompute; ++w) {
-                lf[0] += *(lf4 *)(pr0 + w * PW);
-                lf[1] += *(lf4 *)(pr1 + w * PW);
-            }
-            // sum of squares of the sample: 14 partials (7 slices x 2 K halves), two per lane
-            const int qi = rho_o < kSliceCompute ? rho_o : 0;
-            float qv = q_l[qi * 64 + s2] + q_l[qi * 64 + 32 + s2];
-            const lf4 *c2 = (const lf4 *)(c2_l + rho_o * 32);
-            const gf32x4 w00 = c2[0], w01 = c2[1], w10 = c2[2], w11 = c2[3], cs0 = c2[4], cs1 = c2[5], wr4 = c2[6];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) slice_post(flag_l + kFlagRead + wave, (unsigned)(it + 1));
-            qv = rho_o < kSliceCompute ? qv : 0.f;
-            qv += dpp_f<kDppXor1>(qv);
-            qv += dpp_f<kDppXor2>(qv);
-            const float qtot = qv + dpp_f<kDppHalfMirror>(qv);
-            const int64_t b2 = (int64_t)blk * 32 + s2;
-            saw_nan = saw_nan || (qtot != qtot);
-            // the f16 split and the expanded square hold while sum x^2 <= 36 D (|mu| <= 6: DESIGN 3.3): NaN, +-inf and
-            // huge evidence fail the same test
-            bool bad = !(qtot <= kExpandBound * kExpandBound * (float)D) || (active && !model_ok);
-            float n1[2][S];
+                for (int p = 0; p < 2; ++p) {
+                    const gf32x4 wa = p == 0 ? w00 : w10, wb = p == 0 ? w01 : w11, cs = p == 0 ? cs0 : cs1;
+                    const float w0[S][I * I] = {{wa[0], wa[1], wa[2], wa[3]}, {wb[0], wb[1], wb[2], wb[3]}};
+                    float va[I], vc[I];
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const gf32x4 wa = p == 0 ? w00 : w10, wb = p == 0 ? w01 : w11, cs = p == 0 ? cs0 : cs1;
-                const float w0[S][I * I] = {{wa[0], wa[1], wa[2], wa[3]}, {wb[0], wb[1], wb[2], wb[3]}};
-                float va[I], vc[I];
+                    for (int kq = 0; kq < I; ++kq) {
+                        va[kq] = lf[p][kq] + cs[kq];
+                        vc[kq] = lf[p][I + kq] + cs[I + kq];
+                    }
+                    float ea[I], ec[I];
+                    const float ma = exp2_children<I>(va, ea), mc = exp2_children<I>(vc, ec);
 #pragma unroll
-                for (int kq = 0; kq < I; ++kq) {
-                    va[kq] = lf[p][kq] + cs[kq];
-                    vc[kq] = lf[p][I + kq] + cs[I + kq];
+                    for (int o = 0; o < S; ++o) {
+                        float vv = 0.f;
+#pragma unroll
+                        for (int i = 0; i < I; ++i) {
+                            float tt = 0.f;
+#pragma unroll
+                            for (int jj = 0; jj < I; ++jj) tt = fmaf(w0[o][i * I + jj], ec[jj], tt);
+                            vv = fmaf(ea[i], tt, vv);
+                        }
+                        n1[p][o] = fmaf(__builtin_amdgcn_logf(vv), kLn2, ma + mc);
+                        bad = bad || (vv < 1e-30f && active);   // vanished: dominant pair under a vanishing weight
+                    }
                 }
-                float ea[I], ec[I];
-                const float ma = exp2_children<I>(va, ea), mc = exp2_children<I>(vc, ec);
+                // root: the repetition's partial, then the 8 repetitions of the sample (three DPP steps over 8 lanes)
+                float ra[S], rcx[S];
+                const float m2 = exp2_children<S>(n1[0], ra) + exp2_children<S>(n1[1], rcx);
+                const float mr = active ? m2 : -INFINITY;
+                float mtop = fmaxf(mr, dpp_f<kDppXor1>(mr));
+                mtop = fmaxf(mtop, dpp_f<kDppXor2>(mtop));
+                mtop = fmaxf(mtop, dpp_f<kDppHalfMirror>(mtop));
+                const float mtop0 = (mtop == -INFINITY) ? 0.f : mtop;
+                const float scale = active ? __builtin_amdgcn_exp2f((mr - mtop0) * kL2E) : 0.f;
+                const float qterm = -0.5f * qtot;
+                const bool writer = rho == 0 && b2 < a.B;
+                double part = 0.0;
+                for (int cl = 0; cl < a.C; ++cl) {
+                    float wr[S * S];
+                    if (cl == 0) {
 #pragma unroll
-                for (int o = 0; o < S; ++o) {
+                        for (int e = 0; e < S * S; ++e) wr[e] = wr4[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < S * S; ++e) wr[e] = wr0[(int64_t)cl * M + e];
+                    }
                     float vv = 0.f;
 #pragma unroll
-                    for (int i = 0; i < I; ++i) {
+                    for (int i = 0; i < S; ++i) {
                         float tt = 0.f;
 #pragma unroll
-                        for (int jj = 0; jj < I; ++jj) tt = fmaf(w0[o][i * I + jj], ec[jj], tt);
-                        vv = fmaf(ea[i], tt, vv);
+                        for (int jj = 0; jj < S; ++jj) tt = fmaf(wr[i * S + jj], rcx[jj], tt);
+                        vv = fmaf(ra[i], tt, vv);
                     }
-                    n1[p][o] = fmaf(__builtin_amdgcn_logf(vv), kLn2, ma + mc);
-                    bad = bad || (vv < 1e-30f && active);   // vanished: dominant pair under a vanishing weight
+                    bad = bad || (vv < 1e-30f && mr > -INFINITY);
+                    float tot = vv * scale;
+                    tot += dpp_f<kDppXor1>(tot);
+                    tot += dpp_f<kDppXor2>(tot);
+                    tot += dpp_f<kDppHalfMirror>(tot);
+                    const float ll = ((mtop > -INFINITY) ? fmaf(__builtin_amdgcn_logf(tot), kLn2, mtop) : -INFINITY) + qterm;
+                    if (writer) {
+                        a.out[b2 * a.C + cl] = ll;      // (an exact verdict rewrites these at the end of the kernel)
+                        part += (double)ll;
+                    }
                 }
+                // the wave's verdict on its 8 samples: inside the envelope -> their sum counts; else the exact evaluation at
+                // the end of the kernel covers -- and sums -- exactly these 8
+                if (__any(bad)) exact_mask |= 1ull << (it - 1);
+                else ll_part += part;
+                SL_STAMP(row, 4);
             }
-            // root: the repetition's partial, then the 8 repetitions of the sample (three DPP steps over 8 lanes)
-            float ra[S], rcx[S];
-            const float m2 = exp2_children<S>(n1[0], ra) + exp2_children<S>(n1[1], rcx);
-            const float mr = active ? m2 : -INFINITY;
-            float mtop = fmaxf(mr, dpp_f<kDppXor1>(mr));
-            mtop = fmaxf(mtop, dpp_f<kDppXor2>(mtop));
-            mtop = fmaxf(mtop, dpp_f<kDppHalfMirror>(mtop));
-            const float mtop0 = (mtop == -INFINITY) ? 0.f : mtop;
-            const float scale = active ? __builtin_amdgcn_exp2f((mr - mtop0) * kL2E) : 0.f;
-            const float qterm = -0.5f * qtot;
-            const bool writer = rho == 0 && b2 < a.B;
-            double part = 0.0;
-            for (int cl = 0; cl < a.C; ++cl) {
-                float wr[S * S];
-                if (cl == 0) {
+            if (body) {
+                gemm_lds_barrier();   // A: the previous block's partials are read
+                SL_STAMP(row, 5);
 #pragma unroll
-                    for (int e = 0; e < S * S; ++e) wr[e] = wr4[e];
-                } else {
+                for (int t = 0; t < NT; ++t)
 #pragma unroll
-                    for (int e = 0; e < S * S; ++e) wr[e] = wr0[(int64_t)cl * M + e];
-                }
-                float vv = 0.f;
-#pragma unroll
-                for (int i = 0; i < S; ++i) {
-                    float tt = 0.f;
-#pragma unroll
-                    for (int jj = 0; jj < S; ++jj) tt = fmaf(wr[i * S + jj], rcx[jj], tt);
-                    vv = fmaf(ra[i], tt, vv);
-                }
-                bad = bad || (vv < 1e-30f && mr > -INFINITY);
-                float tot = vv * scale;
-                tot += dpp_f<kDppXor1>(tot);
-                tot += dpp_f<kDppXor2>(tot);
-                tot += dpp_f<kDppHalfMirror>(tot);
-                const float ll = ((mtop > -INFINITY) ? fmaf(__builtin_amdgcn_logf(tot), kLn2, mtop) : -INFINITY) + qterm;
-                if (writer) {
-                    a.out[b2 * a.C + cl] = ll;      // (an exact verdict rewrites these at the end of the kernel)
-                    part += (double)ll;
-                }
+                    for (int i4 = 0; i4 < 4; ++i4) {
+                        const int g = t * 4 + i4;
+                        const gf32x4 o = {acc[t][4 * i4], acc[t][4 * i4 + 1], acc[t][4 * i4 + 2], acc[t][4 * i4 + 3]};
+                        *(lf4w *)(pw + (((g * 2 + h) ^ (s & 7)) << 4)) = o;
+                    }
+                q_l[wave * 64 + lane] = qlane;
+                gemm_lds_barrier();   // B: this block's partials are complete
+                SL_STAMP(row, 6);
             }
-            // the wave's verdict on its 8 samples: inside the envelope -> their sum counts; else the exact evaluation at the
-            // end of the kernel covers -- and sums -- exactly these 8
-            if (__any(bad)) exact_mask |= 1ull << it;
-            else ll_part += part;
-            SL_STAMP(row, 7);
             ++row;
         }
         if (!ok && lane == 0) flag_l[kFlagErr] = 1u;
@@ -470,6 +476,8 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
             gemm_exact_body<I, S, NT>(a, (int64_t)(first + e * stride) * 32, lane_x, sc, gm);
         }
     }
+    SL_STAMP(15, 3);
+    SL_RT(5);
 }
 
 // ------------------------------------------------------------------------------------------------
