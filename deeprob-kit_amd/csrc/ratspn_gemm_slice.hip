@@ -1,6 +1,5 @@
 // RAT-SPN fused forward, third mapping of the matrix-core route: persistent 32-sample blocks, the FEATURE axis split
-// over seven waves that keep their slice of the mean table in REGISTERS for the whole launch, an eighth wave that only
-// feeds them, and no work-group barrier anywhere in the stream.
+// over seven waves that keep their slice of the mean table in REGISTERS for the whole launch.
 //
 // reference: RatSpn.forward (deeprob/spn/models/ratspn.py:105-122) = RegionGraphLayer.forward + GaussianLayer
 // (deeprob/spn/layers/ratspn.py:87-108, :160-213), ProductLayer :272-286, SumLayer :363-378, RootLayer :446-458.
@@ -9,32 +8,29 @@
 // kernel there streams 48 KB stages of which a third is the mean-table chunk, re-fetched from L2 for every 128-sample
 // tile by the same four loader waves that fetch x (its ring floor, 38.8 us at 65 536 samples, is those waves' DMA issue
 // rate), and a tile's upper layers run with the ring stalled (+4.6 us).  Here
-//   * the table never moves: 49 K-steps of 16 features = 7 slice waves x 7 K-steps; a wave holds its 7 x NT x {hi, lo}
+//   * the table never moves: 49 K-steps of 16 features = 7 waves x 7 K-steps; a wave holds its 7 x NT x {hi, lo}
 //     A-fragments (112 VGPRs at NT = 2) from the prologue to the end of the launch;
-//   * x is the only stream.  A block is 32 CONSECUTIVE rows = one contiguous 100 KB range of x; slice wave w consumes
-//     rows x features [112 w, 112 w + 112) from its private 14 KB slot of LDS.  The LOADER wave fills the slots by LDS-DMA
-//     (14 instructions per slot, each ~2.3 contiguous 448-byte row runs, 16-byte pieces XOR-swizzled on the source side so
-//     that the MFMA-shaped ds_read_b128 is conflict free).  A compute unit's request path takes ~37 cycles per DMA
-//     instruction whoever issues it; with the requests inside the slice waves' own loops (second version of this file)
-//     the unluckiest wave of a block queued behind all 98 of them before its own matrix products, and the block waited for
-//     it.  The loader stalls there instead of them;
-//   * hand-offs are monotonic counters in LDS (landed / freed per slot, written per partial buffer, read per reader
-//     wave), polled with s_sleep: a slice wave copies its slot into registers, frees it, multiplies, writes its partial
-//     accumulator (8 KB) and goes on to the next block.  Waves 0-3 also evaluate the upper layers of a block -- lane =
-//     (sample, repetition), 8 samples per wave, seven partials added in a fixed order -- while waves 4-6, their SIMD
-//     partners, already run the next block's products: the upper layers leave the critical path without a barrier;
-//   * a group of 8 samples outside the fast path's envelope (NaN / +-inf / huge evidence, large sum of squares, model
-//     outside the expanded square's bound, vanished sum node) is evaluated exactly after the stream, by all eight waves
-//     (gemm_exact_body) -- correctness never depends on a hint; launches that meet NaN evidence set the hint that routes
-//     the following ones to the variant built for marginalised evidence (ratspn_gemm_nan.hip).
-// Every spin is bounded (kSliceSpinCap polls): a protocol error ends the launch with an error word set instead of hanging
-// the device.
+//   * x is the only stream.  A block is 32 CONSECUTIVE rows = one contiguous 100 KB range of x.  Wave w copies ITS OWN
+//     slice (rows x features [112 w, 112 w + 112)) into its private 14 KB of LDS by LDS-DMA (14 instructions, four
+//     consecutive lanes fetching 64 contiguous bytes of a row, 16-byte pieces XOR-swizzled on the source side so that the
+//     MFMA-shaped ds_read_b128 is conflict free -- the small-batch kernel's layout), reads it into registers, and
+//     re-issues the DMA of its next block BEFORE it converts and multiplies: producer and consumer of a slot are the same
+//     wave, so the x stream needs no barrier at all -- a counted vmcnt is the whole protocol -- and 98 KB per compute
+//     unit are in flight while the matrix cores work;
+//   * the seven partial accumulators of a block meet in LDS (56 KB) and the EIGHTH wave adds them in a fixed order and
+//     evaluates the upper layers (gemm_upper_fast, the ring kernel's code) while the seven are already on the next
+//     block: the upper layers leave the critical path.  Two s_barriers per block hand the partial buffer back and forth.
+// A block outside the fast path's envelope (NaN / +-inf / huge evidence, large sum of squares, model outside the expanded
+// square's bound, vanished sum node) is evaluated exactly by the eighth wave (gemm_exact_body) -- correctness never
+// depends on a hint; launches that meet NaN evidence set the hint that routes the following ones to the variant built
+// for marginalised evidence (ratspn_gemm_nan.hip).
 //
 // Results agree with the other two mappings to fp32 rounding, not bit for bit (seven partial sums in a fixed order).
 #include "ratspn_gemm_fused.h"
 #include "ratspn_gemm_prep.h"
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 
 namespace dpk {
 
@@ -45,45 +41,14 @@ constexpr int kSliceSlot = kSliceKW * 2048;      // bytes of a wave's x slot: [K
 
 __host__ __device__ constexpr int slice_part_bytes(int NT) { return NT * 4 * 1024; }   // a wave's partial accumulators
 __host__ __device__ constexpr int slice_lds_bytes(int NT, int w0_floats) {
-    return kSliceCompute * kSliceSlot + kSliceCompute * slice_part_bytes(NT) + kSliceCompute * 256 + 128 + 1024 + 0 * w0_floats;
+    return kSliceCompute * kSliceSlot + kSliceCompute * slice_part_bytes(NT) + kSliceCompute * 256 + 64 + 1024 + 0 * w0_floats;
 }
 
 #ifdef DPK_TIMELINE
-#define SL_RT(slot) do { __builtin_amdgcn_sched_barrier(0); if (a.dbg && lane == 0 && blockIdx.x < 256) a.dbg[(((int64_t)blockIdx.x * 8 + wave) * 16 + 15) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define SL_STAMP(row, slot) do { __builtin_amdgcn_sched_barrier(0); if (a.dbg && lane == 0 && (row) < 16 && blockIdx.x < 256) a.dbg[(((int64_t)blockIdx.x * 8 + wave) * 16 + (row)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define SL_STAMP(row, slot) do { } while (0)
-#define SL_RT(slot) do { } while (0)
 #endif
-
-constexpr int kSliceReaders = 4;                 // waves 0..3 also evaluate the upper layers (8 samples of a block each)
-constexpr int kSliceServed = 4;                  // ... and have their slots filled by the loader wave; waves 4..6 fill their own
-constexpr int kSliceSpinCap = 1 << 22;           // polls before a wait gives up (~0.5 s: a protocol error, never a hang)
-// flag words (u32 counters of blocks) in LDS
-constexpr int kFlagLanded = 0, kFlagFreed = 8, kFlagC2 = 28, kFlagErr = 29, kFlagWords = 32;
-
-// spin until every one of n consecutive counters has reached `target` (wave-uniform; s_sleep between polls)
-template <int N> __device__ __forceinline__ bool slice_wait(const lunsigned *p, unsigned target) {
-    for (int spin = 0; spin < kSliceSpinCap; ++spin) {
-        unsigned lo = *(const volatile lunsigned *)p;
-#pragma unroll
-        for (int i = 1; i < N; ++i) {
-            const unsigned v = *(const volatile lunsigned *)(p + i);
-            lo = (int)(v - lo) < 0 ? v : lo;
-        }
-        lo = (unsigned)__builtin_amdgcn_readfirstlane((int)lo);
-        if ((int)(lo - target) >= 0) {
-            asm volatile("" ::: "memory");
-            return true;
-        }
-        __builtin_amdgcn_s_sleep(1);
-    }
-    return false;
-}
-__device__ __forceinline__ void slice_post(lunsigned *p, unsigned v) {
-    asm volatile("" ::: "memory");
-    *(volatile lunsigned *)p = v;
-}
 
 template <int I, int S, int NT>
 __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const GemmArgs a) {
@@ -92,7 +57,7 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
     constexpr int KW = kSliceKW;
     constexpr int PW = slice_part_bytes(NT);
     constexpr float kL2E = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
-    static_assert(I == 2 && S == 2 && NT == 2 && NT * RPT == 8, "reader roles: lane = (8 samples) x (8 repetitions); one b128 per partition");
+    static_assert(I == 2 && NT == 2 && NT * RPT == 8, "phase-2 roles: 8 repetitions x 2 partitions = the 16 lanes of a sample; one b128 per partition");
     typedef const __attribute__((address_space(1))) half8 gh8;
     typedef __attribute__((address_space(3))) const gf32x4 lf4;
     typedef __attribute__((address_space(3))) gf32x4 lf4w;
@@ -101,383 +66,352 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
     lchar *smem = (lchar *)smem_generic;
     lchar *part_l = smem + kSliceCompute * kSliceSlot;                        // [7 slices][32 samples][16 units of 16 bytes]
     lfloat *q_l = (lfloat *)(part_l + kSliceCompute * PW);                    // [7][64] sums of squares
-    lunsigned *flag_l = (lunsigned *)(q_l + kSliceCompute * 64);              // [kFlagWords] hand-off counters
-    lfloat *c2_l = (lfloat *)(flag_l + kFlagWords);                           // [8 repetitions][32]: sum weights, leaf constants, root weights
+    lunsigned *flag_l = (lunsigned *)(q_l + kSliceCompute * 64);              // [2][8] a wave's verdict on its 4 samples of a block
+    lfloat *c2_l = (lfloat *)(flag_l + 16);                                   // [16 slots][16]: sum weights, leaf constants, root weights
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = lane & 31, h = lane >> 5;
     const int D = a.D;
-    // (host: D == 16 * 7 * 7 -- every slice holds exactly KW K-steps)
+    // (host: D == 16 * 7 * 7 -- every slice holds exactly KW K-steps; a run-time slice length made hipcc clone the loop
+    // body per length and spill 184 registers)
     const int nblk = a.ntiles;                                                // blocks of 32 samples
     const int first = (int)blockIdx.x, stride = (int)gridDim.x;
-    const int nit = first < nblk ? (nblk - first + stride - 1) / stride : 0;  // blocks of this work-group
+    const bool slicer = wave < kSliceCompute;                                 // (the eighth wave only joins phase 2)
     SL_STAMP(15, 0);
-    SL_RT(4);
-    if (tid < kFlagWords) flag_l[tid] = 0u;
-    gemm_lds_barrier();   // (the only barrier in front of the stream: the counters start at zero for everyone)
 
-    // One slot's worth of DMA: slice w of the 32 rows at xt (rows beyond nvalid re-fetch the last one: never stored).
-    const int dr0 = lane / 28;
-    int dp0 = lane - dr0 * 28;
-    auto fill_slot = [&](gcchar_p xt, int nvalid, int w) {
-        const unsigned dst = (unsigned)(uintptr_t)smem + w * kSliceSlot;
+    // ---- phase-1 roles (slice waves): MFMA lane (sample s, half h) ----------------------------------------------------
+    const int k0 = wave * KW;
+    lchar *my = smem + (slicer ? wave : 0) * kSliceSlot;
+    const unsigned my_u = (unsigned)(uintptr_t)my;
+    // Slot layout [K-step][32 rows][4 pieces of 16 bytes]: a K-step is two DMA instructions (piece P = i*64 + lane: row
+    // P >> 2, LDS piece P & 3 holds source piece (P & 3) ^ ((row >> 2) & 3), so that the MFMA-shaped ds_read_b128 -- 16 rows
+    // x one piece -- covers 16 different 16-byte bank groups).  The K-step is the unit of the stream: the wave copies K-step
+    // kk of block b into registers and at once requests K-step kk of block b + 1 into the same 2 KB, so every piece has a
+    // whole block period to land.  (With the slot as the unit -- all 14 requests after the whole copy -- the period could
+    // not fall below request latency + 98 instructions of issue + copy: measured 11k cycles; the row-run layout, 3 % cheaper
+    // to request, does not split by K-step.)
+    unsigned voff[2];
 #pragma unroll
-        for (int jd = 0; jd < 2 * KW; ++jd) {
-            const int pp = dp0 + 8 * jd;                              // (64 j = 28 * 2j + 8j)
-            const int c = (pp * 2341) >> 16;                          // pp / 28 for pp < 896
-            const int r = 2 * jd + dr0 + c, pos = pp - 28 * c;
-            const int sp = pos ^ ((r >> 2) & 3);
-            glds16<kGemmXNonTemporal>((unsigned)(min(r, nvalid - 1) * D + w * (KW * 16) + sp * 4) * 4u, xt, dst + jd * 1024);
+    for (int i = 0; i < 2; ++i) {
+        const int P = i * 64 + lane, drow = P >> 2, dcol = (P & 3) ^ ((drow >> 2) & 3);
+        voff[i] = (unsigned)(drow * D + k0 * 16 + dcol * 4) * 4u;
+    }
+    // the two requests of K-step kk of the 32 rows at xt (rows beyond nvalid re-fetch the last one: never stored)
+    auto issue_kk = [&](gcchar_p xt, int nvalid, int kk) {
+        if (nvalid >= 32) {
+            glds16<kGemmXNonTemporal>(voff[0] + kk * 64u, xt, my_u + kk * 2048);
+            glds16<kGemmXNonTemporal>(voff[1] + kk * 64u, xt, my_u + kk * 2048 + 1024);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int P = i * 64 + lane, drow = P >> 2, dcol = (P & 3) ^ ((drow >> 2) & 3);
+                glds16<kGemmXNonTemporal>((unsigned)(min(drow, nvalid - 1) * D + (k0 + kk) * 16 + dcol * 4) * 4u, xt,
+                                          my_u + kk * 2048 + i * 1024);
+            }
         }
     };
-    auto fill_block = [&](int it, int w) {
-        const int64_t b0 = (int64_t)(first + it * stride) * 32;
-        fill_slot((gcchar_p)(a.x + b0 * D), (int)min((int64_t)32, a.B - b0), w);
+    auto issue = [&](int blk) {
+        const int64_t b0 = (int64_t)blk * 32;
+        const gcchar_p xt = (gcchar_p)(a.x + b0 * D);
+        const int nvalid = (int)min((int64_t)32, a.B - b0);
+#pragma unroll
+        for (int kk = 0; kk < KW; ++kk) issue_kk(xt, nvalid, kk);
     };
+    if (slicer && first < nblk) issue(first);
+    // the slice of the mean table: registers for the whole launch (plain loads, L2; hipcc's waits for them also cover
+    // the older DMA requests above -- loads retire in order)
+    half8 mh[KW][NT], ml[KW][NT];
+#pragma unroll
+    for (int kk = 0; kk < KW; ++kk) {
+        const int ks = (slicer ? k0 : 0) + kk;
+        const gcchar_p tb = (gcchar_p)a.mtab + ((int64_t)ks * NT * 2048 + lane * 16);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            mh[kk][t] = *(gh8 *)(tb + t * 2048);
+            ml[kk][t] = *(gh8 *)(tb + t * 2048 + 1024);
+        }
+    }
+    // ---- phase-2 roles (all eight waves): 16 consecutive lanes own a sample, slot j = 2 rho + p ------------------------
+    const int sl = lane >> 4, j = lane & 15;
+    const int rho = j >> 1, p = j & 1;
+    const int s2 = wave * 4 + sl;                    // sample of the block
+    const bool active = rho < a.reps;
+    const int rc = active ? rho : a.reps - 1;        // (spare slots compute on a copy and are masked out)
+    const int t2 = rc / RPT, ap = rc - t2 * RPT;
+    // phase-2 constants of slot j (sum weights of its partition, leaf constants of its two regions, root weights of
+    // class 0) live in LDS, 64 bytes per slot: four b128 reads per block instead of 16 registers held through phase 1
+    static_assert(S * I * I == 8 && 2 * I == 4 && S * S == 4, "slot record layout");
+    if (wave == 7 && sl == 0) {
+        const float *wp = a.W0 + ((int64_t)(rc * 2 + p) * S) * I * I;
+#pragma unroll
+        for (int e = 0; e < S * I * I; ++e) c2_l[j * 16 + e] = wp[e];
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+            for (int k = 0; k < I; ++k) c2_l[j * 16 + 8 + qq * I + k] = a.biasT[(p * NT + t2) * 16 + (ap * 2 + qq) * I + k];
+#pragma unroll
+        for (int e = 0; e < S * S; ++e) c2_l[j * 16 + 12 + e] = ((const float *)a.Wr)[rc * S * S + e];
+    }
+    const bool model_ok = a.elig[rc] != 0;
+    const int M = a.reps * S * S;
+    const float *wr0 = (const float *)a.Wr + rc * S * S;
+    // The fragments must have ARRIVED before the loop: a wait that hipcc placed at their first use inside it would be a
+    // vmcnt(0) behind the next block's DMA requests, every iteration.  An empty asm that reads each value pins the wait
+    // here (and keeps hipcc from re-materialising the loads inside the loop).
+#pragma unroll
+    for (int kk = 0; kk < KW; ++kk)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            asm volatile("" : "+v"(mh[kk][t]));
+            asm volatile("" : "+v"(ml[kk][t]));
+        }
+    {
+        int mo = model_ok ? 1 : 0;
+        asm volatile("" : "+v"(mo));
+    }
+    if (tid < 16) flag_l[tid] = 0u;
 
-    if (wave == kSliceCompute) {
-        // ================================================ loader ====================================================
-        // fills the slots of waves 0..3: 56 DMA instructions per block (vmcnt is a 6-bit counter: one wave holds at most 63).
-        // Per block: its requests of the previous round have landed -> publish; the four slots have been copied into
-        // registers (counters) -> refill them with the next block; then the block's two barriers with everyone.
-        bool ok = true;
-        if (nit > 0) {
-#pragma unroll 1
-            for (int w = 0; w < kSliceServed; ++w) fill_block(0, w);
-        }
-        for (int it = 0; it < nit; ++it) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) slice_post(flag_l + kFlagLanded, (unsigned)(it + 1));
-            if (it + 1 < nit) {
-#pragma unroll 1
-                for (int w = 0; w < kSliceServed; ++w) {
-                    ok = slice_wait<1>(flag_l + kFlagFreed + w, (unsigned)(it + 1)) && ok;
-                    asm volatile("" : "+v"(dp0));
-                    fill_block(it + 1, w);
-                }
-            }
-            gemm_lds_barrier();   // A
-            gemm_lds_barrier();   // B
-        }
-        if (!ok && lane == 0) flag_l[kFlagErr] = 1u;
-    } else {
-        // ================================================ slice waves ===============================================
-        const int s = lane & 31, h = lane >> 5;      // MFMA roles: sample of the block, half of the K-step / of the columns
-        const int k0 = wave * KW;
-        lchar *my = smem + wave * kSliceSlot;
-        // waves 4..6 (no reader duty: ~7k idle cycles per block) fill their own slot -- producer and consumer of the slot
-        // are the same wave, a counted vmcnt is the whole protocol -- so 42 + 56 DMA instructions can be outstanding per
-        // compute unit (one loader wave alone: 56, and it became latency bound)
-        const bool self = wave >= kSliceServed;
-        if (self && nit > 0) fill_block(0, wave);
-        // the slice of the mean table: registers for the whole launch
-        half8 mh[KW][NT], ml[KW][NT];
-#pragma unroll
-        for (int kk = 0; kk < KW; ++kk) {
-            const gcchar_p tb = (gcchar_p)a.mtab + ((int64_t)(k0 + kk) * NT * 2048 + lane * 16);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                mh[kk][t] = *(gh8 *)(tb + t * 2048);
-                ml[kk][t] = *(gh8 *)(tb + t * 2048 + 1024);
-            }
-        }
-        // reader roles (waves 0..3): lane = (sample sl of the wave's 8, repetition rho); both partitions of the repetition
-        const int sl = lane >> 3, rho = lane & 7;
-        const int s2 = (wave & 3) * 8 + sl;          // sample of the block
-        const bool active = rho < a.reps;
-        const int rc = active ? rho : a.reps - 1;    // (spare slots compute on a copy and are masked out)
-        const bool reader = wave < kSliceReaders;
-        // constants of repetition rc in LDS, 128 bytes each: [p][S*I*I] sum weights, [p][2 I] leaf constants, [S*S] root
-        // weights of class 0 (written by wave 4, which has no reader duty; readers wait for its flag)
-        if (wave == kSliceReaders && lane < 8) {
-            const int t2 = rc / RPT, ap = rc - t2 * RPT;
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const float *wp = a.W0 + ((int64_t)(rc * 2 + p) * S) * I * I;
-#pragma unroll
-                for (int e = 0; e < S * I * I; ++e) c2_l[lane * 32 + p * 8 + e] = wp[e];
-#pragma unroll
-                for (int qq = 0; qq < 2; ++qq)
-#pragma unroll
-                    for (int kq = 0; kq < I; ++kq)
-                        c2_l[lane * 32 + 16 + p * 4 + qq * I + kq] = a.biasT[(p * NT + t2) * 16 + (ap * 2 + qq) * I + kq];
-            }
-#pragma unroll
-            for (int e = 0; e < S * S; ++e) c2_l[lane * 32 + 24 + e] = ((const float *)a.Wr)[rc * S * S + e];
-        }
-        if (wave == kSliceReaders) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) slice_post(flag_l + kFlagC2, 1u);
-        }
-        const bool model_ok = a.elig[rc] != 0;
-        const int M = a.reps * S * S;
-        const float *wr0 = (const float *)a.Wr + rc * S * S;
-        // (pin the table in registers here: a wait that hipcc placed at its first use inside the loop would be repeated there)
-#pragma unroll
-        for (int kk = 0; kk < KW; ++kk)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                asm volatile("" : "+v"(mh[kk][t]));
-                asm volatile("" : "+v"(ml[kk][t]));
-            }
-        {
-            int mo = model_ok ? 1 : 0;
-            asm volatile("" : "+v"(mo));
-        }
-        // partial accumulators in LDS: slice w, unit (16 bytes) U(s, h, g) = s*16 + ((2 g + h) ^ (s & 7)) for the four
-        // values of partition (repetition g, half h) of sample s.  Writers (fixed g; 8 consecutive lanes = 8 samples per
-        // ds_write_b128 group) cover 8 different units mod 8; readers (fixed h; 16-lane ds_read_b128 groups = four samples
-        // x four repetitions) 16 different units mod 16: both sides conflict free.
-        const int sw = (s >> 2) & 3;
-        const lchar *xr0 = my + s * (KW * 64) + (((h * 2) ^ sw) << 4);
-        const lchar *xr1 = my + s * (KW * 64) + (((h * 2 + 1) ^ sw) << 4);
-        lchar *pw = part_l + wave * PW + s * 256;
+    // partial accumulators in LDS: slice w, unit (16 bytes) U(s, h, g) = s*16 + ((2 g + h) ^ (s & 7)) for the four values
+    // of partition (repetition g, half h) of sample s.  Writers (fixed g; 8 consecutive lanes = 8 samples per
+    // ds_write_b128 group) cover 8 different units mod 8, readers (16-lane ds_read_b128 groups = two samples x 8 of the 16
+    // (g, h) slots) 16 different units mod 16: both sides conflict free.
+    const int sw = (s >> 2) & 3;
+    constexpr int XROW = 64, XKK = 2048;             // bytes between rows / between K-steps of a row
+    const lchar *xr0 = my + s * XROW + (((h * 2) ^ sw) << 4);
+    const lchar *xr1 = my + s * XROW + (((h * 2 + 1) ^ sw) << 4);
+    lchar *pw = part_l + (slicer ? wave : 0) * PW + s * 256;
 
-        double ll_part = 0.0;
-        bool saw_nan = false, ok = true;
-        unsigned long long exact_mask = 0ull;        // bit i: this reader's 8 samples of the work-group's i-th block left the fast path
-        SL_STAMP(15, 1);
-        [[maybe_unused]] int row = 0;
-        // Iteration `it`: the slice's products of block it, then (waves 0..3, whose slots the loader fills: they have no
-        // DMA to issue) the upper layers of block it - 1 from the partials written at the end of the previous iteration,
-        // then barrier A (those partials are read), the partials of block it, barrier B.  One extra iteration finishes
-        // the last block's upper layers.
-        for (int it = 0; it <= nit; ++it) {
-            const bool body = it < nit;
-            gf32x16 acc[NT];
-            float qlane = 0.f;
+    double ll_part = 0.0, pend_part = 0.0;
+    bool saw_nan = false;
+    unsigned long long exact_mask = 0ull;   // bit i: the i-th block of this work-group (host: at most 64 per launch)
+    SL_STAMP(15, 1);
+    [[maybe_unused]] int row = 0;
+    int it = 0;
+    for (int blk = first; blk < nblk; blk += stride, ++it) {
+        gf32x16 acc[NT];
+        float qlane = 0.f;
+        if (slicer) {
             SL_STAMP(row, 0);
-            if (body) {
-                // ---- the block's slice: landed -> registers -> slot free ------------------------------------------
-                if (self) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (only this wave's own DMA requests are outstanding)
-                } else {
-                    ok = slice_wait<1>(flag_l + kFlagLanded, (unsigned)(it + 1)) && ok;
-                }
-                SL_STAMP(row, 1);
-                float v[KW][8];
+            const bool more = blk + stride < nblk;
+            const int64_t nb0 = (int64_t)(blk + stride) * 32;
+            const gcchar_p nxt = (gcchar_p)(a.x + nb0 * D);
+            const int nnv = (int)min((int64_t)32, a.B - nb0);
 #pragma unroll
-                for (int kk = 0; kk < KW; ++kk) {
-                    const gf32x4 x0 = *(lf4 *)(xr0 + kk * 64), x1 = *(lf4 *)(xr1 + kk * 64);
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        v[kk][i] = x0[i];
-                        v[kk][4 + i] = x1[i];
-                    }
-                }
+                for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+            gf32x2 tq2 = {0.f, 0.f};
+            // K-step p: landed -> registers -> its 2 KB requested again for the next block.  Requests complete in order,
+            // so "all but the youngest 12 have completed" (14 outstanding: K-steps p .. 6 of this block, 0 .. p - 1 of the
+            // next) is K-step p; the last block of the work-group requests nothing and counts down instead.  (Stores of the
+            // upper layers still in flight only make the wait longer: k completed operations include k - #stores loads.)
+            gf32x4 xa0, xa1, xb0, xb1;
+            auto land = [&](auto pc) {
+                constexpr int p = decltype(pc)::value;
+                if (more) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 - 2 * p) : "memory");
+            };
+            land(std::integral_constant<int, 0>{});
+            xa0 = *(lf4 *)(xr0);
+            xa1 = *(lf4 *)(xr1);
+            SL_STAMP(row, 1);
+#pragma unroll
+            for (int kk = 0; kk < KW; ++kk) {
+                // (K-step kk is on its way to the registers; once there, its slot is requested again)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (self) {
-                    asm volatile("" : "+v"(dp0));   // (opaque per block: hipcc otherwise hoists the 14 source offsets out of the loop)
-                    if (it + 1 < nit) fill_block(it + 1, wave);
-                } else if (lane == 0) slice_post(flag_l + kFlagFreed + wave, (unsigned)(it + 1));
-                SL_STAMP(row, 2);
-                // ---- the slice's share of the leaf GEMM ------------------------------------------------------------
+                if (more) issue_kk(nxt, nnv, kk);
+                float v[8];
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-                gf32x2 tq2 = {0.f, 0.f};
-#pragma unroll
-                for (int kk = 0; kk < KW; ++kk) {
-#pragma unroll
-                    for (int i = 0; i < 8; i += 2) {
-                        const gf32x2 pv = {v[kk][i], v[kk][i + 1]};
-                        tq2 = __builtin_elementwise_fma(pv, pv, tq2);
-                    }
-                    half8 xh, xl;
-                    split8(v[kk], xh, xl);
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[kk][t], xh, acc[t], 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[kk][t], xl, acc[t], 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[kk][t], xh, acc[t], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = xa0[i];
+                    v[4 + i] = xa1[i];
                 }
-                qlane = tq2[0] + tq2[1];
-                SL_STAMP(row, 3);
+                if (kk + 1 < KW) {
+                    if (kk == 0) land(std::integral_constant<int, 1>{});
+                    if (kk == 1) land(std::integral_constant<int, 2>{});
+                    if (kk == 2) land(std::integral_constant<int, 3>{});
+                    if (kk == 3) land(std::integral_constant<int, 4>{});
+                    if (kk == 4) land(std::integral_constant<int, 5>{});
+                    if (kk == 5) land(std::integral_constant<int, 6>{});
+                    xb0 = *(lf4 *)(xr0 + (kk + 1) * XKK);
+                    xb1 = *(lf4 *)(xr1 + (kk + 1) * XKK);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    const gf32x2 pv = {v[i], v[i + 1]};
+                    tq2 = __builtin_elementwise_fma(pv, pv, tq2);
+                }
+                half8 xh, xl;
+                split8(v, xh, xl);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[kk][t], xh, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[kk][t], xl, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[kk][t], xh, acc[t], 0, 0, 0);
+                xa0 = xb0;
+                xa1 = xb1;
             }
-            if (reader && it > 0) {
-                // =========================== upper layers of block it - 1: lane = (sample, repetition) ====================
-                const int blk = first + (it - 1) * stride;
-                if (it == 1) ok = slice_wait<1>(flag_l + kFlagC2, 1u) && ok;
-                // (addresses from an opaque copy of the lane id: held through phase 1 they would cost registers the K loop needs)
-                int lo = lane;
-                asm volatile("" : "+v"(lo));
-                const int rho_o = lo & 7;
-                // leaf sums of the repetition's two partitions: seven partials each, fixed order (launches agree bit for bit)
-                const lchar *pr0 = part_l + s2 * 256 + (((rho_o * 2) ^ (s2 & 7)) << 4);
-                const lchar *pr1 = part_l + s2 * 256 + (((rho_o * 2 + 1) ^ (s2 & 7)) << 4);
-                gf32x4 lf[2] = {*(lf4 *)pr0, *(lf4 *)pr1};
-#pragma unroll
-                for (int w = 1; w < kSliceCompute; ++w) {
-                    lf[0] += *(lf4 *)(pr0 + w * PW);
-                    lf[1] += *(lf4 *)(pr1 + w * PW);
-                }
-                // sum of squares of the sample: 14 partials (7 slices x 2 K halves), two per lane
-                const int qi = rho_o < kSliceCompute ? rho_o : 0;
-                float qv = q_l[qi * 64 + s2] + q_l[qi * 64 + 32 + s2];
-                const lf4 *c2 = (const lf4 *)(c2_l + rho_o * 32);
-                const gf32x4 w00 = c2[0], w01 = c2[1], w10 = c2[2], w11 = c2[3], cs0 = c2[4], cs1 = c2[5], wr4 = c2[6];
-                qv = rho_o < kSliceCompute ? qv : 0.f;
-                qv += dpp_f<kDppXor1>(qv);
-                qv += dpp_f<kDppXor2>(qv);
-                const float qtot = qv + dpp_f<kDppHalfMirror>(qv);
-                const int64_t b2 = (int64_t)blk * 32 + s2;
-                saw_nan = saw_nan || (qtot != qtot);
-                // the f16 split and the expanded square hold while sum x^2 <= 36 D (|mu| <= 6: DESIGN 3.3): NaN, +-inf and
-                // huge evidence fail the same test
-                bool bad = !(qtot <= kExpandBound * kExpandBound * (float)D) || (active && !model_ok);
-                float n1[2][S];
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const gf32x4 wa = p == 0 ? w00 : w10, wb = p == 0 ? w01 : w11, cs = p == 0 ? cs0 : cs1;
-                    const float w0[S][I * I] = {{wa[0], wa[1], wa[2], wa[3]}, {wb[0], wb[1], wb[2], wb[3]}};
-                    float va[I], vc[I];
-#pragma unroll
-                    for (int kq = 0; kq < I; ++kq) {
-                        va[kq] = lf[p][kq] + cs[kq];
-                        vc[kq] = lf[p][I + kq] + cs[I + kq];
-                    }
-                    float ea[I], ec[I];
-                    const float ma = exp2_children<I>(va, ea), mc = exp2_children<I>(vc, ec);
-#pragma unroll
-                    for (int o = 0; o < S; ++o) {
-                        float vv = 0.f;
-#pragma unroll
-                        for (int i = 0; i < I; ++i) {
-                            float tt = 0.f;
-#pragma unroll
-                            for (int jj = 0; jj < I; ++jj) tt = fmaf(w0[o][i * I + jj], ec[jj], tt);
-                            vv = fmaf(ea[i], tt, vv);
-                        }
-                        n1[p][o] = fmaf(__builtin_amdgcn_logf(vv), kLn2, ma + mc);
-                        bad = bad || (vv < 1e-30f && active);   // vanished: dominant pair under a vanishing weight
-                    }
-                }
-                // root: the repetition's partial, then the 8 repetitions of the sample (three DPP steps over 8 lanes)
-                float ra[S], rcx[S];
-                const float m2 = exp2_children<S>(n1[0], ra) + exp2_children<S>(n1[1], rcx);
-                const float mr = active ? m2 : -INFINITY;
-                float mtop = fmaxf(mr, dpp_f<kDppXor1>(mr));
-                mtop = fmaxf(mtop, dpp_f<kDppXor2>(mtop));
-                mtop = fmaxf(mtop, dpp_f<kDppHalfMirror>(mtop));
-                const float mtop0 = (mtop == -INFINITY) ? 0.f : mtop;
-                const float scale = active ? __builtin_amdgcn_exp2f((mr - mtop0) * kL2E) : 0.f;
-                const float qterm = -0.5f * qtot;
-                const bool writer = rho == 0 && b2 < a.B;
-                double part = 0.0;
-                for (int cl = 0; cl < a.C; ++cl) {
-                    float wr[S * S];
-                    if (cl == 0) {
-#pragma unroll
-                        for (int e = 0; e < S * S; ++e) wr[e] = wr4[e];
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < S * S; ++e) wr[e] = wr0[(int64_t)cl * M + e];
-                    }
-                    float vv = 0.f;
-#pragma unroll
-                    for (int i = 0; i < S; ++i) {
-                        float tt = 0.f;
-#pragma unroll
-                        for (int jj = 0; jj < S; ++jj) tt = fmaf(wr[i * S + jj], rcx[jj], tt);
-                        vv = fmaf(ra[i], tt, vv);
-                    }
-                    bad = bad || (vv < 1e-30f && mr > -INFINITY);
-                    float tot = vv * scale;
-                    tot += dpp_f<kDppXor1>(tot);
-                    tot += dpp_f<kDppXor2>(tot);
-                    tot += dpp_f<kDppHalfMirror>(tot);
-                    const float ll = ((mtop > -INFINITY) ? fmaf(__builtin_amdgcn_logf(tot), kLn2, mtop) : -INFINITY) + qterm;
-                    if (writer) {
-                        a.out[b2 * a.C + cl] = ll;      // (an exact verdict rewrites these at the end of the kernel)
-                        part += (double)ll;
-                    }
-                }
-                // the wave's verdict on its 8 samples: inside the envelope -> their sum counts; else the exact evaluation at
-                // the end of the kernel covers -- and sums -- exactly these 8
-                if (__any(bad)) exact_mask |= 1ull << (it - 1);
-                else ll_part += part;
-                SL_STAMP(row, 4);
-            }
-            if (body) {
-                gemm_lds_barrier();   // A: the previous block's partials are read
-                SL_STAMP(row, 5);
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int i4 = 0; i4 < 4; ++i4) {
-                        const int g = t * 4 + i4;
-                        const gf32x4 o = {acc[t][4 * i4], acc[t][4 * i4 + 1], acc[t][4 * i4 + 2], acc[t][4 * i4 + 3]};
-                        *(lf4w *)(pw + (((g * 2 + h) ^ (s & 7)) << 4)) = o;
-                    }
-                q_l[wave * 64 + lane] = qlane;
-                gemm_lds_barrier();   // B: this block's partials are complete
-                SL_STAMP(row, 6);
-            }
-            ++row;
+            qlane = tq2[0] + tq2[1];
+            SL_STAMP(row, 4);
         }
-        if (!ok && lane == 0) flag_l[kFlagErr] = 1u;
-        // what the tail needs from the stream, through LDS (idle x slot of this wave): the wave's sum, its mask, the NaN hint
-        {
-            const double red = wave_reduce_sum(reader ? ll_part : 0.0);
-            const bool nan_w = __any(saw_nan);
-            if (lane == 0) {
-                unsigned long long *tail = reinterpret_cast<unsigned long long *>(smem_generic) + wave * (kSliceSlot / 8);
-                tail[0] = (unsigned long long)__double_as_longlong(red);
-                tail[1] = reader ? exact_mask : 0ull;
-                tail[2] = nan_w ? 1ull : 0ull;
+        // everyone has read the previous block's partials (and published its verdict on it)
+        gemm_lds_barrier();
+        SL_STAMP(row, 5);
+        if (slicer) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    const int g = t * 4 + i4;
+                    const gf32x4 o = {acc[t][4 * i4], acc[t][4 * i4 + 1], acc[t][4 * i4 + 2], acc[t][4 * i4 + 3]};
+                    *(lf4w *)(pw + (((g * 2 + h) ^ (s & 7)) << 4)) = o;
+                }
+            q_l[wave * 64 + lane] = qlane;
+        }
+        // the previous block's verdict: its sum joins the total only if no wave left the fast path on it (the exact
+        // evaluation at the end then covers -- and sums -- all 32 samples of the block)
+        if (it > 0) {
+            const lunsigned *fl = flag_l + ((it - 1) & 1) * 8;
+            const unsigned any_bad = (unsigned)__builtin_amdgcn_readfirstlane(
+                (int)((fl[0] | fl[1]) | (fl[2] | fl[3]) | (fl[4] | fl[5]) | (fl[6] | fl[7])));
+            if (any_bad) exact_mask |= 1ull << (it - 1);
+            else ll_part += pend_part;
+        }
+        gemm_lds_barrier();   // this block's partials are complete
+        SL_STAMP(row, 6);
+
+        // =========================== phase 2: one (sample, repetition, partition) per lane ==============================
+        // leaf sums of the lane's two regions: seven partials each, fixed order (launches agree bit for bit)
+        // (the phase-2 addresses are recomputed per block from an opaque copy of the lane id: held through phase 1 they
+        // cost the registers that decide between 256 and a spill)
+        int jo = j;
+        asm volatile("" : "+v"(jo));
+        const lchar *pr = part_l + s2 * 256 + ((jo ^ (s2 & 7)) << 4);
+        const lfloat *qr = q_l + (jo < 2 * kSliceCompute ? (jo >> 1) * 64 + (jo & 1) * 32 + s2 : 0);
+        gf32x4 lf = *(lf4 *)pr;
+#pragma unroll
+        for (int w = 1; w < kSliceCompute; ++w) lf += *(lf4 *)(pr + w * PW);
+        float qv = *qr;
+        qv = j < 2 * kSliceCompute ? qv : 0.f;
+        const float qtot = row16_sum(qv);
+        const int64_t b2 = (int64_t)blk * 32 + s2;
+        saw_nan = saw_nan || (qtot != qtot);
+        // the f16 split and the expanded square hold while sum x^2 <= 36 D (|mu| <= 6: DESIGN 3.3): NaN, +-inf and huge
+        // evidence fail the same test
+        bool bad = !(qtot <= kExpandBound * kExpandBound * (float)D) || (active && !model_ok);
+        const lf4 *c2 = (const lf4 *)(c2_l + jo * 16);
+        const gf32x4 w0a = c2[0], w0b = c2[1], cs4 = c2[2], wr4 = c2[3];
+        const float w0[S][I * I] = {{w0a[0], w0a[1], w0a[2], w0a[3]}, {w0b[0], w0b[1], w0b[2], w0b[3]}};
+        float va[I], vc[I];
+#pragma unroll
+        for (int k = 0; k < I; ++k) {
+            va[k] = lf[k] + cs4[k];
+            vc[k] = lf[I + k] + cs4[I + k];
+        }
+        float ea[I], ec[I];
+        const float ma = exp2_children<I>(va, ea), mc = exp2_children<I>(vc, ec);
+        float n1[S];
+#pragma unroll
+        for (int o = 0; o < S; ++o) {
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < I; ++i) {
+                float tt = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < I; ++jj) tt = fmaf(w0[o][i * I + jj], ec[jj], tt);
+                v = fmaf(ea[i], tt, v);
+            }
+            n1[o] = fmaf(__builtin_amdgcn_logf(v), kLn2, ma + mc);
+            bad = bad || (v < 1e-30f && active);   // vanished: dominant pair under a vanishing weight
+        }
+        // root: the two partitions of a repetition meet (lane ^ 1), then the repetitions of the sample
+        float ta[S], tc[S];
+#pragma unroll
+        for (int o = 0; o < S; ++o) {
+            const float other = dpp_f<kDppXor1>(n1[o]);
+            ta[o] = p == 0 ? n1[o] : other;
+            tc[o] = p == 0 ? other : n1[o];
+        }
+        float ra[S], rcx[S];
+        const float m2 = exp2_children<S>(ta, ra) + exp2_children<S>(tc, rcx);
+        const float mr = active ? m2 : -INFINITY;
+        const float mtop = row16_max(mr);
+        const float mtop0 = (mtop == -INFINITY) ? 0.f : mtop;
+        const float scale = (active && p == 0) ? __builtin_amdgcn_exp2f((mr - mtop0) * kL2E) : 0.f;
+        const float qterm = -0.5f * qtot;
+        const bool writer = j == 0 && b2 < a.B;
+        double part = 0.0;
+        for (int cl = 0; cl < a.C; ++cl) {
+            float wr[S * S];
+            if (cl == 0) {
+#pragma unroll
+                for (int e = 0; e < S * S; ++e) wr[e] = wr4[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < S * S; ++e) wr[e] = wr0[(int64_t)cl * M + e];
+            }
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                float tt = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < S; ++jj) tt = fmaf(wr[i * S + jj], rcx[jj], tt);
+                v = fmaf(ra[i], tt, v);
+            }
+            bad = bad || (v < 1e-30f && mr > -INFINITY);
+            const float tot = row16_sum(v * scale);
+            const float ll = ((mtop > -INFINITY) ? fmaf(__builtin_amdgcn_logf(tot), kLn2, mtop) : -INFINITY) + qterm;
+            if (writer) {
+                a.out[b2 * a.C + cl] = ll;      // (an exact verdict rewrites these at the end of the kernel)
+                part += (double)ll;
             }
         }
+        pend_part = part;
+        // the wave's verdict on its 4 samples of this block, read by everyone behind the next barrier
+        const bool wave_bad = __any(bad);
+        if (lane == 0) flag_l[(it & 1) * 8 + wave] = wave_bad ? 1u : 0u;
+        SL_STAMP(row, 7);
+        ++row;
     }
     SL_STAMP(15, 2);
-    // ---- the tail: {sum, count}, then the groups that left the fast path: exact evaluation, a wave per block ------------
+    // ---- the last block's verdict, then the blocks that left the fast path: exact evaluation, a wave per block ---------
     __syncthreads();
-    const unsigned long long *tails = reinterpret_cast<const unsigned long long *>(smem_generic);
-    unsigned long long masks[kSliceReaders];
-    unsigned long long any_mask = 0ull, nan_any = 0ull;
-#pragma unroll
-    for (int r = 0; r < kSliceReaders; ++r) {
-        masks[r] = tails[r * (kSliceSlot / 8) + 1];
-        any_mask |= masks[r];
-        nan_any |= tails[r * (kSliceSlot / 8) + 2];
+    if (it > 0) {
+        const lunsigned *fl = flag_l + ((it - 1) & 1) * 8;
+        const unsigned any_bad = (fl[0] | fl[1]) | (fl[2] | fl[3]) | (fl[4] | fl[5]) | (fl[6] | fl[7]);
+        if (any_bad) exact_mask |= 1ull << (it - 1);
+        else ll_part += pend_part;
     }
-    const bool proto_err = flag_l[kFlagErr] != 0u;
-    if (tid == 0) {
-        if (a.ll_sum != nullptr) {
+    if (a.ll_sum != nullptr) {
+        // {sum of LLs, count}: one atomic per work-group (and one for the count per launch)
+        double *red_l = reinterpret_cast<double *>(smem_generic + kSliceCompute * kSliceSlot);   // (the partials are idle now)
+        const double red = wave_reduce_sum(ll_part);
+        if (lane == 0) red_l[wave] = red;
+        __syncthreads();
+        if (tid == 0) {
             double tot = 0.0;
 #pragma unroll
-            for (int r = 0; r < kSliceReaders; ++r) tot += __longlong_as_double((long long)tails[r * (kSliceSlot / 8)]);
-            if (!proto_err) atomicAdd(a.ll_sum, tot);   // (after a protocol error the exact evaluation sums every block)
+            for (int w = 0; w < 8; ++w) tot += red_l[w];
+            atomicAdd(a.ll_sum, tot);
             if (blockIdx.x == 0) atomicAdd(a.ll_sum + 1, (double)a.B * (double)a.C);
         }
-        if (nan_any != 0ull && a.slow_flag != nullptr) *a.slow_flag = a.launch_seq;
     }
-    __syncthreads();   // (the tails are read: the x slots become the exact evaluation's scratch)
-    if (proto_err) {
-        // a hand-off timed out (never observed; a safeguard against hanging the device): every block of this work-group is
-        // evaluated exactly -- slow and correct
-        any_mask = ~0ull;
-    }
-    if (any_mask != 0ull) {
-        int tid_x = (int)threadIdx.x;
+    if (__any(saw_nan) && lane == 0 && a.slow_flag != nullptr) *a.slow_flag = a.launch_seq;
+    if (exact_mask != 0ull) {   // (every wave holds the same mask)
+        int tid_x = (int)threadIdx.x;   // (an opaque copy: nothing of this tail is worth a register held through the loop)
         asm volatile("" : "+v"(tid_x));
         const int lane_x = tid_x & 63;
-        LseScratch sc{reinterpret_cast<float *>(smem_generic) + tid_x * (2 * NMAX)};
+        LseScratch sc{reinterpret_cast<float *>(smem_generic) + tid_x * (2 * NMAX)};   // (the x slots are idle now)
         int n = 0;
-        for (int e = 0; e < nit && e < 64; ++e) {
-            unsigned gm = 0u;
-#pragma unroll
-            for (int r = 0; r < kSliceReaders; ++r) gm |= (unsigned)((masks[r] >> e) & 1ull) << r;
-            if (proto_err) gm = 0xFu;
-            if (gm == 0u) continue;
+        for (int e = 0; e < 64; ++e) {
+            if (!((exact_mask >> e) & 1ull)) continue;
             if ((n++ & 7) != wave) continue;
-            gemm_exact_body<I, S, NT>(a, (int64_t)(first + e * stride) * 32, lane_x, sc, gm);
+            gemm_exact_body<I, S, NT>(a, (int64_t)(first + e * stride) * 32, lane_x, sc);
         }
     }
-    SL_STAMP(15, 3);
-    SL_RT(5);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -29,26 +29,19 @@ t = buf.reshape(grid, 8, 16, 8).astype(np.int64)
 nb = -(-(-(-B // 32)) // grid)
 t0 = t[:, :, 15, 0].min()          # (s_memtime is per-XCD comparable only approximately; good enough for phases)
 print('B = %d, %d work-groups, %d blocks each; s_memtime ticks (100 MHz -> 10 ns each? no: shader clock)' % (B, grid, nb))
+names = ['loop top', 'DMA landed', 'slot in regs', '(ragged issue)', 'K loop + next DMA', 'barrier A', 'partials + barrier B', 'phase 2']
 c = t[:, :7]
-print('slice waves, ticks between stamps, mean over work-groups / waves, per iteration:')
-for grp, sel, idx, names in (('waves 0-3 (loader-fed, upper layers of the previous block)', slice(0, 4), [0, 1, 2, 3, 4, 5, 6],
-                              ['slot landed', 'copied', 'K loop', 'upper layers', 'barrier A', 'partials + B']),
-                             ('waves 4-6 (own DMA)', slice(4, 7), [0, 1, 2, 3, 5, 6],
-                              ['slot landed', 'copied + DMA', 'K loop', 'barrier A', 'partials + B'])):
-    print(' ', grp)
-    print('  row  ' + ' '.join('%16s' % n for n in names) + '      total')
-    for r in range(min(nb, 15)):
-        d = [(c[:, sel, r, idx[i + 1]] - c[:, sel, r, idx[i]]).mean() for i in range(len(idx) - 1)]
-        tot = (c[:, sel, r, idx[-1]] - c[:, sel, r, 0]).mean()
-        print('  %3d  ' % r + ' '.join('%16.0f' % v for v in d) + ' %10.0f' % tot)
-rt0, rt1 = t[:, :, 15, 4], t[:, :, 15, 5]
-print('s_memrealtime (100 MHz): kernel first entry -> last exit %.2f us; per wave entry->exit mean %.2f us; entry spread %.2f us' % ((rt1.max() - rt0.min()) / 100.0, (rt1 - rt0).mean() / 100.0, (rt0.max() - rt0.min()) / 100.0))
-print('ticks: loop exit -> kernel end mean %.0f; entry->end mean %.0f' % ((t[:, :, 15, 3] - t[:, :, 15, 2]).mean(), (t[:, :, 15, 3] - t[:, :, 15, 0]).mean()))
+print('slice waves, ticks between stamps, mean over work-groups / waves, per block row:')
+print('  row  ' + ' '.join('%20s' % s for s in names[1:]) + '   block total')
+for r in range(min(nb, 15)):
+    d = [(c[:, :, r, i + 1] - c[:, :, r, i]).mean() for i in range(7)]
+    tot = (c[:, :, r, 7] - c[:, :, r, 0]).mean()
+    print('  %3d  ' % r + ' '.join('%20.0f' % v for v in d) + '   %10.0f' % tot)
 start = t[:, :, 15, 0]
 end = t[:, :, 15, 2]
 print('kernel span per wave (entry -> loop exit), mean / max ticks: %.0f / %d' % ((end - start).mean(), (end - start).max()))
 print('entry -> loop (table in registers), mean ticks: %.0f' % (t[:, :7, 15, 1] - t[:, :7, 15, 0]).mean())
-for w in (0, 3, 4, 6):
+for w in (0, 3, 7):
     print('work-group 0, wave %d rows (ticks since entry):' % w)
     for r in range(min(nb, 15)):
         print('   ', ' '.join('%7d' % (v - t[0, w, 15, 0]) for v in t[0, w, r, :8]))
