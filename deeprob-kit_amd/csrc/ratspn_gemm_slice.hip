@@ -192,12 +192,12 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
     for (int blk = first; blk < nblk; blk += stride, ++it) {
         gf32x16 acc[NT];
         float qlane = 0.f;
+        const bool more = blk + stride < nblk;
+        const int64_t nb0 = (int64_t)(blk + stride) * 32;
+        const gcchar_p nxt = (gcchar_p)(a.x + nb0 * D);
+        const int nnv = (int)min((int64_t)32, a.B - nb0);
         if (slicer) {
             SL_STAMP(row, 0);
-            const bool more = blk + stride < nblk;
-            const int64_t nb0 = (int64_t)(blk + stride) * 32;
-            const gcchar_p nxt = (gcchar_p)(a.x + nb0 * D);
-            const int nnv = (int)min((int64_t)32, a.B - nb0);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -208,9 +208,14 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
             // next) is K-step p; the last block of the work-group requests nothing and counts down instead.  (Stores of the
             // upper layers still in flight only make the wait longer: k completed operations include k - #stores loads.)
             gf32x4 xa0, xa1, xb0, xb1;
+            // The requests of the next block are spread over the whole block period -- K-steps 0..2 right after their copy,
+            // 3 and 4 behind the K loop (in front of barrier A, where the wave would wait anyway), 5 and 6 behind barrier B
+            // -- because a compute unit's request path takes ~37 cycles per DMA instruction: all 98 in the K loop made it
+            // 6k cycles long.  Hence "younger requests outstanding" at the wait for K-step p: 2 (6 - p) of this block +
+            // 2 min(p, 3) of the next.
             auto land = [&](auto pc) {
                 constexpr int p = decltype(pc)::value;
-                if (more) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (6 - p) + 2 * (p < 3 ? p : 3)) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 - 2 * p) : "memory");
             };
             land(std::integral_constant<int, 0>{});
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
             for (int kk = 0; kk < KW; ++kk) {
                 // (K-step kk is on its way to the registers; once there, its slot is requested again)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (more) issue_kk(nxt, nnv, kk);
+                if (more && kk <= 2) issue_kk(nxt, nnv, kk);
                 float v[8];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -255,6 +260,10 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
                 xa1 = xb1;
             }
             qlane = tq2[0] + tq2[1];
+            if (more) {
+                issue_kk(nxt, nnv, 3);
+                issue_kk(nxt, nnv, 4);
+            }
             SL_STAMP(row, 4);
         }
         // everyone has read the previous block's partials (and published its verdict on it)
@@ -281,6 +290,10 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
             else ll_part += pend_part;
         }
         gemm_lds_barrier();   // this block's partials are complete
+        if (slicer && more) {
+            issue_kk(nxt, nnv, 5);
+            issue_kk(nxt, nnv, 6);
+        }
         SL_STAMP(row, 6);
 
         // =========================== phase 2: one (sample, repetition, partition) per lane ==============================
