@@ -58,7 +58,6 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
     constexpr int PW = slice_part_bytes(NT);
     constexpr float kL2E = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
     static_assert(I == 2 && NT == 2 && NT * RPT == 8, "phase-2 roles: 8 repetitions x 2 partitions = the 16 lanes of a sample; one b128 per partition");
-    typedef const __attribute__((address_space(1))) half8 gh8;
     typedef __attribute__((address_space(3))) const gf32x4 lf4;
     typedef __attribute__((address_space(3))) gf32x4 lf4w;
 
@@ -120,18 +119,25 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
         for (int kk = 0; kk < KW; ++kk) issue_kk(xt, nvalid, kk);
     };
     if (slicer && first < nblk) issue(first);
-    // the slice of the mean table: registers for the whole launch (plain loads, L2; hipcc's waits for them also cover
-    // the older DMA requests above -- loads retire in order)
+    // The slice of the mean table: registers for the whole launch.  The loads are asm statements that hipcc does not count:
+    // the first block's K loop starts as soon as ITS K-step of the table is here (the table takes ~6k cycles of the compute
+    // unit's request path) and requests the second block meanwhile; a compiler wait for "its" loads would be a vmcnt(0)
+    // behind those requests.  Queue order: x of block 0 (14 requests), table (4 loads per K-step, K-step major), then what
+    // the K loop requests.
     half8 mh[KW][NT], ml[KW][NT];
+    if (slicer) {
+        const unsigned lane16 = (unsigned)lane * 16u;
 #pragma unroll
-    for (int kk = 0; kk < KW; ++kk) {
-        const int ks = (slicer ? k0 : 0) + kk;
-        const gcchar_p tb = (gcchar_p)a.mtab + ((int64_t)ks * NT * 2048 + lane * 16);
+        for (int kk = 0; kk < KW; ++kk)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            mh[kk][t] = *(gh8 *)(tb + t * 2048);
-            ml[kk][t] = *(gh8 *)(tb + t * 2048 + 1024);
-        }
+            for (int t = 0; t < NT; ++t) {
+                // (scalar base + one shared lane offset: 28 per-load address pairs would be 56 registers)
+                const uint64_t tb = (uint64_t)(uintptr_t)a.mtab + (uint64_t)((k0 + kk) * NT + t) * 2048u;
+                const uint64_t tbs = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(tb >> 32)) << 32) |
+                                     (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tb);
+                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(mh[kk][t]) : "v"(lane16), "s"(tbs) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(ml[kk][t]) : "v"(lane16), "s"(tbs) : "memory");
+            }
     }
     // ---- phase-2 roles (all eight waves): 16 consecutive lanes own a sample, slot j = 2 rho + p ------------------------
     const int sl = lane >> 4, j = lane & 15;
@@ -154,23 +160,16 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
 #pragma unroll
         for (int e = 0; e < S * S; ++e) c2_l[j * 16 + 12 + e] = ((const float *)a.Wr)[rc * S * S + e];
     }
-    const bool model_ok = a.elig[rc] != 0;
+    bool model_ok;
+    {   // (through the scalar cache: a vector load here would put a compiler-counted wait into the request queue above)
+        cint_p ce = as_const(a.elig);
+        unsigned bits = 0u;
+#pragma unroll
+        for (int e = 0; e < NT * RPT; ++e) bits |= (ce[e] != 0 ? 1u : 0u) << e;
+        model_ok = ((bits >> rc) & 1u) != 0u;
+    }
     const int M = a.reps * S * S;
     const float *wr0 = (const float *)a.Wr + rc * S * S;
-    // The fragments must have ARRIVED before the loop: a wait that hipcc placed at their first use inside it would be a
-    // vmcnt(0) behind the next block's DMA requests, every iteration.  An empty asm that reads each value pins the wait
-    // here (and keeps hipcc from re-materialising the loads inside the loop).
-#pragma unroll
-    for (int kk = 0; kk < KW; ++kk)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            asm volatile("" : "+v"(mh[kk][t]));
-            asm volatile("" : "+v"(ml[kk][t]));
-        }
-    {
-        int mo = model_ok ? 1 : 0;
-        asm volatile("" : "+v"(mo));
-    }
     if (tid < 16) flag_l[tid] = 0u;
 
     // partial accumulators in LDS: slice w, unit (16 bytes) U(s, h, g) = s*16 + ((2 g + h) ^ (s & 7)) for the four values
@@ -213,11 +212,29 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
             // -- because a compute unit's request path takes ~37 cycles per DMA instruction: all 98 in the K loop made it
             // 6k cycles long.  Hence "younger requests outstanding" at the wait for K-step p: 2 (6 - p) of this block +
             // 2 min(p, 3) of the next.
+            // In the work-group's first block the 28 table loads sit between this block's requests and the next one's.
             auto land = [&](auto pc) {
                 constexpr int p = decltype(pc)::value;
-                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (6 - p) + 2 * (p < 3 ? p : 3)) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 - 2 * p) : "memory");
+                constexpr int next = 2 * (p < 3 ? p : 3);
+                if (it == 0) {
+                    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (6 - p) + 28 + next) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (6 - p) + 28) : "memory");
+                } else {
+                    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (6 - p) + next) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 - 2 * p) : "memory");
+                }
             };
+            // ... and K-step kk of the table has arrived when all but the later K-steps' loads (4 each) and the next block's
+            // requests so far have completed.  The wait names the K-step's x operand (already in registers): the products
+            // depend on it, so hipcc cannot schedule them above the wait.  (Naming the fragments themselves made them loop-
+            // carried copies: 184 spilled registers.)  ScratchSize must stay 0: a spill of a fragment in flight stores garbage.
+#define DPK_SL_TABLE_HERE(kk)                                                                                                   \
+    do {                                                                                                                      \
+        if (it == 0) {                                                                                                        \
+            if (more) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(xa0), "+v"(xa1) : "n"(4 * (6 - kk) + 2 * (kk < 3 ? kk : 3)) : "memory");   \
+            else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(xa0), "+v"(xa1) : "n"(4 * (6 - kk)) : "memory");                \
+        }                                                                                                                     \
+    } while (0)
             land(std::integral_constant<int, 0>{});
             xa0 = *(lf4 *)(xr0);
             xa1 = *(lf4 *)(xr1);
@@ -226,6 +243,13 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
             for (int kk = 0; kk < KW; ++kk) {
                 // (K-step kk is on its way to the registers; once there, its slot is requested again)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (kk == 0) DPK_SL_TABLE_HERE(0);
+                if (kk == 1) DPK_SL_TABLE_HERE(1);
+                if (kk == 2) DPK_SL_TABLE_HERE(2);
+                if (kk == 3) DPK_SL_TABLE_HERE(3);
+                if (kk == 4) DPK_SL_TABLE_HERE(4);
+                if (kk == 5) DPK_SL_TABLE_HERE(5);
+                if (kk == 6) DPK_SL_TABLE_HERE(6);
                 if (more && kk <= 2) issue_kk(nxt, nnv, kk);
                 float v[8];
 #pragma unroll
