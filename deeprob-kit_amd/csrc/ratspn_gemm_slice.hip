@@ -118,26 +118,29 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
 #pragma unroll
         for (int kk = 0; kk < KW; ++kk) issue_kk(xt, nvalid, kk);
     };
-    if (slicer && first < nblk) issue(first);
-    // The slice of the mean table: registers for the whole launch.  The loads are asm statements that hipcc does not count:
-    // the first block's K loop starts as soon as ITS K-step of the table is here (the table takes ~6k cycles of the compute
-    // unit's request path) and requests the second block meanwhile; a compiler wait for "its" loads would be a vmcnt(0)
-    // behind those requests.  Queue order: x of block 0 (14 requests), table (4 loads per K-step, K-step major), then what
-    // the K loop requests.
+    const int nit = first < nblk ? (nblk - first + stride - 1) / stride : 0;   // blocks of this work-group (>= 1)
+    if (slicer && nit > 0) issue(first);
+    // The slice of the mean table: registers for the whole launch, loaded by asm statements that hipcc does not count, K-step
+    // by K-step INSIDE the first block's K loop (below).  A wave cannot compute before it has issued its requests, and a
+    // compute unit's request path takes ~37 cycles per 1 KB instruction: 14 x requests + 28 table loads per wave up front
+    // were 11k cycles before the first product; now K-step kk multiplies while K-step kk + 1 of the table and the second
+    // block's first K-steps are being requested.
     half8 mh[KW][NT], ml[KW][NT];
+    const unsigned lane16 = (unsigned)lane * 16u;
+#define DPK_SL_TABLE_LOAD(kk)                                                                                                  \
+    do {                                                                                                                      \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                                      \
+            const uint64_t tb = (uint64_t)(uintptr_t)a.mtab + (uint64_t)((k0 + (kk)) * NT + t) * 2048u;                       \
+            const uint64_t tbs = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(tb >> 32)) << 32) |      \
+                                 (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tb);                      \
+            asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(mh[kk][t]) : "v"(lane16), "s"(tbs) : "memory");   \
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(ml[kk][t]) : "v"(lane16), "s"(tbs) : "memory"); \
+        }                                                                                                                     \
+    } while (0)
     if (slicer) {
-        const unsigned lane16 = (unsigned)lane * 16u;
-#pragma unroll
-        for (int kk = 0; kk < KW; ++kk)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                // (scalar base + one shared lane offset: 28 per-load address pairs would be 56 registers)
-                const uint64_t tb = (uint64_t)(uintptr_t)a.mtab + (uint64_t)((k0 + kk) * NT + t) * 2048u;
-                const uint64_t tbs = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(tb >> 32)) << 32) |
-                                     (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tb);
-                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(mh[kk][t]) : "v"(lane16), "s"(tbs) : "memory");
-                asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(ml[kk][t]) : "v"(lane16), "s"(tbs) : "memory");
-            }
+        DPK_SL_TABLE_LOAD(0);
+        DPK_SL_TABLE_LOAD(1);
+        DPK_SL_TABLE_LOAD(2);
     }
     // ---- phase-2 roles (all eight waves): 16 consecutive lanes own a sample, slot j = 2 rho + p ------------------------
     const int sl = lane >> 4, j = lane & 15;
@@ -185,114 +188,86 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
     double ll_part = 0.0, pend_part = 0.0;
     bool saw_nan = false;
     unsigned long long exact_mask = 0ull;   // bit i: the i-th block of this work-group (host: at most 64 per launch)
+    gf32x16 acc[NT];
+    float qlane = 0.f;
+#define DPK_SL_KSTEP(kk, v, tq2)                                                                                              \
+    do {                                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 8; i += 2) {                                                                    \
+            const gf32x2 pv = {v[i], v[i + 1]};                                                                               \
+            tq2 = __builtin_elementwise_fma(pv, pv, tq2);                                                                     \
+        }                                                                                                                     \
+        half8 xh, xl;                                                                                                         \
+        split8(v, xh, xl);                                                                                                    \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[kk][t], xh, acc[t], 0, 0, 0); \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[kk][t], xl, acc[t], 0, 0, 0); \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[kk][t], xh, acc[t], 0, 0, 0); \
+    } while (0)
+    // ---- the work-group's first block: its K loop also brings the table in ---------------------------------------------------
+    // Request queue (in order): x of block 0 (14), table K-steps 0..2 (12) | per step kk: x of block 1, K-step kk (2, kk <= 2),
+    // table K-step kk + 3 (4, kk < 4) -- three steps ahead: one step ahead made the loop a chain of L2 round trips (19.6k
+    // cycles).  "All but the youngest N have completed" with N = what was issued after the awaited request: the table's
+    // K-step kk at step kk: 14, 16, 18, 16, 10, 4, 0 (12, 12, 12, 12, 8, 4, 0 when there is no second block) -- it also
+    // covers this block's x, requested before it.  The wait names the K-step's x operand: the products depend on it, so hipcc
+    // cannot schedule them above the wait.  ScratchSize must stay 0: a spill of a fragment in flight would store garbage.
+    if (slicer && nit > 0) {
+        const bool more = nit > 1;
+        const int64_t nb0 = (int64_t)(first + stride) * 32;
+        const gcchar_p nxt = (gcchar_p)(a.x + nb0 * D);
+        const int nnv = (int)min((int64_t)32, a.B - nb0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        gf32x2 tq2 = {0.f, 0.f};
+        gf32x4 xa0, xa1, xb0, xb1;
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // K-step 0 of x (12 younger x requests + 12 table loads)
+        xa0 = *(lf4 *)(xr0);
+        xa1 = *(lf4 *)(xr1);
+#define DPK_SL_FIRST_STEP(kk, NW_MORE, NW_LAST)                                                                               \
+    do {                                                                                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                    \
+        if (more && (kk) <= 2) issue_kk(nxt, nnv, kk);                                                                        \
+        if ((kk) + 3 < KW) DPK_SL_TABLE_LOAD(((kk) + 3 < KW ? (kk) + 3 : 0));                                                 \
+        if (more) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(xa0), "+v"(xa1) : "n"(NW_MORE) : "memory");                       \
+        else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(xa0), "+v"(xa1) : "n"(NW_LAST) : "memory");                            \
+        float v[8];                                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                       \
+            v[i] = xa0[i];                                                                                                    \
+            v[4 + i] = xa1[i];                                                                                                \
+        }                                                                                                                     \
+        if ((kk) + 1 < KW) {   /* (this block's x landed before the table did) */                                              \
+            xb0 = *(lf4 *)(xr0 + ((kk) + 1) * XKK);                                                                           \
+            xb1 = *(lf4 *)(xr1 + ((kk) + 1) * XKK);                                                                           \
+        }                                                                                                                     \
+        DPK_SL_KSTEP(kk, v, tq2);                                                                                             \
+        xa0 = xb0;                                                                                                            \
+        xa1 = xb1;                                                                                                            \
+    } while (0)
+        DPK_SL_FIRST_STEP(0, 14, 12);
+        DPK_SL_FIRST_STEP(1, 16, 12);
+        DPK_SL_FIRST_STEP(2, 18, 12);
+        DPK_SL_FIRST_STEP(3, 16, 12);
+        DPK_SL_FIRST_STEP(4, 10, 8);
+        DPK_SL_FIRST_STEP(5, 4, 4);
+        DPK_SL_FIRST_STEP(6, 0, 0);
+#undef DPK_SL_FIRST_STEP
+        qlane = tq2[0] + tq2[1];
+        if (more) {
+            issue_kk(nxt, nnv, 3);
+            issue_kk(nxt, nnv, 4);
+        }
+    }
     SL_STAMP(15, 1);
     [[maybe_unused]] int row = 0;
     int it = 0;
-    for (int blk = first; blk < nblk; blk += stride, ++it) {
-        gf32x16 acc[NT];
-        float qlane = 0.f;
-        const bool more = blk + stride < nblk;
-        const int64_t nb0 = (int64_t)(blk + stride) * 32;
-        const gcchar_p nxt = (gcchar_p)(a.x + nb0 * D);
-        const int nnv = (int)min((int64_t)32, a.B - nb0);
-        if (slicer) {
-            SL_STAMP(row, 0);
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-            gf32x2 tq2 = {0.f, 0.f};
-            // K-step p: landed -> registers -> its 2 KB requested again for the next block.  Requests complete in order,
-            // so "all but the youngest 12 have completed" (14 outstanding: K-steps p .. 6 of this block, 0 .. p - 1 of the
-            // next) is K-step p; the last block of the work-group requests nothing and counts down instead.  (Stores of the
-            // upper layers still in flight only make the wait longer: k completed operations include k - #stores loads.)
-            gf32x4 xa0, xa1, xb0, xb1;
-            // The requests of the next block are spread over the whole block period -- K-steps 0..2 right after their copy,
-            // 3 and 4 behind the K loop (in front of barrier A, where the wave would wait anyway), 5 and 6 behind barrier B
-            // -- because a compute unit's request path takes ~37 cycles per DMA instruction: all 98 in the K loop made it
-            // 6k cycles long.  Hence "younger requests outstanding" at the wait for K-step p: 2 (6 - p) of this block +
-            // 2 min(p, 3) of the next.
-            // In the work-group's first block the 28 table loads sit between this block's requests and the next one's.
-            auto land = [&](auto pc) {
-                constexpr int p = decltype(pc)::value;
-                constexpr int next = 2 * (p < 3 ? p : 3);
-                if (it == 0) {
-                    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (6 - p) + 28 + next) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (6 - p) + 28) : "memory");
-                } else {
-                    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (6 - p) + next) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 - 2 * p) : "memory");
-                }
-            };
-            // ... and K-step kk of the table has arrived when all but the later K-steps' loads (4 each) and the next block's
-            // requests so far have completed.  The wait names the K-step's x operand (already in registers): the products
-            // depend on it, so hipcc cannot schedule them above the wait.  (Naming the fragments themselves made them loop-
-            // carried copies: 184 spilled registers.)  ScratchSize must stay 0: a spill of a fragment in flight stores garbage.
-#define DPK_SL_TABLE_HERE(kk)                                                                                                   \
-    do {                                                                                                                      \
-        if (it == 0) {                                                                                                        \
-            if (more) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(xa0), "+v"(xa1) : "n"(4 * (6 - kk) + 2 * (kk < 3 ? kk : 3)) : "memory");   \
-            else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(xa0), "+v"(xa1) : "n"(4 * (6 - kk)) : "memory");                \
-        }                                                                                                                     \
-    } while (0)
-            land(std::integral_constant<int, 0>{});
-            xa0 = *(lf4 *)(xr0);
-            xa1 = *(lf4 *)(xr1);
-            SL_STAMP(row, 1);
-#pragma unroll
-            for (int kk = 0; kk < KW; ++kk) {
-                // (K-step kk is on its way to the registers; once there, its slot is requested again)
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (kk == 0) DPK_SL_TABLE_HERE(0);
-                if (kk == 1) DPK_SL_TABLE_HERE(1);
-                if (kk == 2) DPK_SL_TABLE_HERE(2);
-                if (kk == 3) DPK_SL_TABLE_HERE(3);
-                if (kk == 4) DPK_SL_TABLE_HERE(4);
-                if (kk == 5) DPK_SL_TABLE_HERE(5);
-                if (kk == 6) DPK_SL_TABLE_HERE(6);
-                if (more && kk <= 2) issue_kk(nxt, nnv, kk);
-                float v[8];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[i] = xa0[i];
-                    v[4 + i] = xa1[i];
-                }
-                if (kk + 1 < KW) {
-                    if (kk == 0) land(std::integral_constant<int, 1>{});
-                    if (kk == 1) land(std::integral_constant<int, 2>{});
-                    if (kk == 2) land(std::integral_constant<int, 3>{});
-                    if (kk == 3) land(std::integral_constant<int, 4>{});
-                    if (kk == 4) land(std::integral_constant<int, 5>{});
-                    if (kk == 5) land(std::integral_constant<int, 6>{});
-                    xb0 = *(lf4 *)(xr0 + (kk + 1) * XKK);
-                    xb1 = *(lf4 *)(xr1 + (kk + 1) * XKK);
-                }
-#pragma unroll
-                for (int i = 0; i < 8; i += 2) {
-                    const gf32x2 pv = {v[i], v[i + 1]};
-                    tq2 = __builtin_elementwise_fma(pv, pv, tq2);
-                }
-                half8 xh, xl;
-                split8(v, xh, xl);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[kk][t], xh, acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[kk][t], xl, acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[kk][t], xh, acc[t], 0, 0, 0);
-                xa0 = xb0;
-                xa1 = xb1;
-            }
-            qlane = tq2[0] + tq2[1];
-            if (more) {
-                issue_kk(nxt, nnv, 3);
-                issue_kk(nxt, nnv, 4);
-            }
-            SL_STAMP(row, 4);
-        }
+    for (; it < nit; ++it) {
+        const int blk = first + it * stride;
+        const bool more = it + 1 < nit;                 // a next block exists: its K loop runs at the end of this iteration
+        const bool more2 = it + 2 < nit;                // ... and requests the block after it
+        SL_STAMP(row, 0);
         // everyone has read the previous block's partials (and published its verdict on it)
         gemm_lds_barrier();
-        SL_STAMP(row, 5);
+        SL_STAMP(row, 1);
         if (slicer) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -314,11 +289,14 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
             else ll_part += pend_part;
         }
         gemm_lds_barrier();   // this block's partials are complete
-        if (slicer && more) {
+        if (slicer && more) {                           // K-steps 5, 6 of the next block
+            const int64_t nb0 = (int64_t)(first + (it + 1) * stride) * 32;
+            const gcchar_p nxt = (gcchar_p)(a.x + nb0 * D);
+            const int nnv = (int)min((int64_t)32, a.B - nb0);
             issue_kk(nxt, nnv, 5);
             issue_kk(nxt, nnv, 6);
         }
-        SL_STAMP(row, 6);
+        SL_STAMP(row, 2);
 
         // =========================== phase 2: one (sample, repetition, partition) per lane ==============================
         // leaf sums of the lane's two regions: seven partials each, fixed order (launches agree bit for bit)
@@ -410,7 +388,68 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
         // the wave's verdict on its 4 samples of this block, read by everyone behind the next barrier
         const bool wave_bad = __any(bad);
         if (lane == 0) flag_l[(it & 1) * 8 + wave] = wave_bad ? 1u : 0u;
-        SL_STAMP(row, 7);
+        SL_STAMP(row, 3);
+        // =========================== the next block's K loop ================================================================
+        if (slicer && more) {
+            const int64_t nb2 = (int64_t)(first + (it + 2) * stride) * 32;
+            const gcchar_p nxt = (gcchar_p)(a.x + nb2 * D);
+            const int nnv = (int)min((int64_t)32, a.B - nb2);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+            gf32x2 tq2 = {0.f, 0.f};
+            // K-step p: landed -> registers -> its 2 KB requested again for the block after.  Requests complete in order, so
+            // "all but the youngest N" is K-step p with N = the requests younger than it.  Those are spread over the whole
+            // block period -- K-steps 0..2 right after their copy, 3 and 4 behind the K loop (in front of barrier A, where
+            // the wave would wait anyway), 5 and 6 behind barrier B -- because a compute unit's request path takes ~37
+            // cycles per DMA instruction: all 98 in the K loop made it 6k cycles long.  Hence N = 2 (6 - p) of this block +
+            // 2 min(p, 3) of the next; the last block requests nothing and counts down.  (Stores of the upper layers still in
+            // flight only make the wait longer: k completed operations include k - #stores loads.)
+            gf32x4 xa0, xa1, xb0, xb1;
+#define DPK_SL_LAND(p)                                                                                                        \
+    do {                                                                                                                      \
+        if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (6 - (p)) + 2 * ((p) < 3 ? (p) : 3)) : "memory");              \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 - 2 * (p)) : "memory");                                              \
+    } while (0)
+            DPK_SL_LAND(0);
+            xa0 = *(lf4 *)(xr0);
+            xa1 = *(lf4 *)(xr1);
+#define DPK_SL_STEP(kk)                                                                                                       \
+    do {                                                                                                                      \
+        /* (K-step kk is on its way to the registers; once there, its slot is requested again) */                             \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                    \
+        if (more2 && (kk) <= 2) issue_kk(nxt, nnv, kk);                                                                       \
+        float v[8];                                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                       \
+            v[i] = xa0[i];                                                                                                    \
+            v[4 + i] = xa1[i];                                                                                                \
+        }                                                                                                                     \
+        if ((kk) + 1 < KW) {                                                                                                  \
+            DPK_SL_LAND(((kk) + 1 < KW ? (kk) + 1 : 6));                                                                      \
+            xb0 = *(lf4 *)(xr0 + ((kk) + 1) * XKK);                                                                           \
+            xb1 = *(lf4 *)(xr1 + ((kk) + 1) * XKK);                                                                           \
+        }                                                                                                                     \
+        DPK_SL_KSTEP(kk, v, tq2);                                                                                             \
+        xa0 = xb0;                                                                                                            \
+        xa1 = xb1;                                                                                                            \
+    } while (0)
+            DPK_SL_STEP(0);
+            DPK_SL_STEP(1);
+            DPK_SL_STEP(2);
+            DPK_SL_STEP(3);
+            DPK_SL_STEP(4);
+            DPK_SL_STEP(5);
+            DPK_SL_STEP(6);
+#undef DPK_SL_STEP
+#undef DPK_SL_LAND
+            qlane = tq2[0] + tq2[1];
+            if (more2) {
+                issue_kk(nxt, nnv, 3);
+                issue_kk(nxt, nnv, 4);
+            }
+        }
+        SL_STAMP(row, 4);
         ++row;
     }
     SL_STAMP(15, 2);

@@ -29,19 +29,19 @@ t = buf.reshape(grid, 8, 16, 8).astype(np.int64)
 nb = -(-(-(-B // 32)) // grid)
 t0 = t[:, :, 15, 0].min()          # (s_memtime is per-XCD comparable only approximately; good enough for phases)
 print('B = %d, %d work-groups, %d blocks each; s_memtime ticks (100 MHz -> 10 ns each? no: shader clock)' % (B, grid, nb))
-names = ['loop top', 'DMA landed', 'slot in regs', '(ragged issue)', 'K loop + next DMA', 'barrier A', 'partials + barrier B', 'phase 2']
 c = t[:, :7]
-print('slice waves, ticks between stamps, mean over work-groups / waves, per block row:')
-print('  row  ' + ' '.join('%20s' % s for s in names[1:]) + '   block total')
+names = ['barrier A', 'partials + B + req', 'upper layers', 'next K loop']
+print('slice waves, ticks between stamps, mean over work-groups / waves, per iteration (first block K loop = entry -> loop):')
+print('  row  ' + ' '.join('%20s' % n for n in names) + '      total')
 for r in range(min(nb, 15)):
-    d = [(c[:, :, r, i + 1] - c[:, :, r, i]).mean() for i in range(7)]
-    tot = (c[:, :, r, 7] - c[:, :, r, 0]).mean()
-    print('  %3d  ' % r + ' '.join('%20.0f' % v for v in d) + '   %10.0f' % tot)
+    d = [(c[:, :, r, i + 1] - c[:, :, r, i]).mean() for i in range(4)]
+    tot = (c[:, :, r, 4] - c[:, :, r, 0]).mean()
+    print('  %3d  ' % r + ' '.join('%20.0f' % v for v in d) + ' %10.0f' % tot)
 start = t[:, :, 15, 0]
 end = t[:, :, 15, 2]
 print('kernel span per wave (entry -> loop exit), mean / max ticks: %.0f / %d' % ((end - start).mean(), (end - start).max()))
 print('entry -> loop (table in registers), mean ticks: %.0f' % (t[:, :7, 15, 1] - t[:, :7, 15, 0]).mean())
-for w in (0, 3, 7):
+for w in (0, 3):
     print('work-group 0, wave %d rows (ticks since entry):' % w)
     for r in range(min(nb, 15)):
-        print('   ', ' '.join('%7d' % (v - t[0, w, 15, 0]) for v in t[0, w, r, :8]))
+        print('   ', ' '.join('%7d' % (v - t[0, w, 15, 0]) for v in t[0, w, r, :5]))
