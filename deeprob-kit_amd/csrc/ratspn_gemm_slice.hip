@@ -6,24 +6,32 @@
 //
 // Same formulation, tables and arithmetic as ratspn_gemm.hip (read its header first).  Why a third mapping: the ring
 // kernel there streams 48 KB stages of which a third is the mean-table chunk, re-fetched from L2 for every 128-sample
-// tile by the same four loader waves that fetch x (its ring floor, 38.8 us at 65 536 samples, is those waves' DMA issue
-// rate), and a tile's upper layers run with the ring stalled (+4.6 us).  Here
+// tile by the same four loader waves that fetch x, and a tile's upper layers run with the ring stalled (+4.6 us of 47 at
+// 65 536 samples); the small-batch kernel re-reads the whole table for every 32 samples.  Here
 //   * the table never moves: 49 K-steps of 16 features = 7 waves x 7 K-steps; a wave holds its 7 x NT x {hi, lo}
-//     A-fragments (112 VGPRs at NT = 2) from the prologue to the end of the launch;
+//     A-fragments (112 VGPRs at NT = 2) from the first block to the end of the launch;
 //   * x is the only stream.  A block is 32 CONSECUTIVE rows = one contiguous 100 KB range of x.  Wave w copies ITS OWN
-//     slice (rows x features [112 w, 112 w + 112)) into its private 14 KB of LDS by LDS-DMA (14 instructions, four
-//     consecutive lanes fetching 64 contiguous bytes of a row, 16-byte pieces XOR-swizzled on the source side so that the
-//     MFMA-shaped ds_read_b128 is conflict free -- the small-batch kernel's layout), reads it into registers, and
-//     re-issues the DMA of its next block BEFORE it converts and multiplies: producer and consumer of a slot are the same
-//     wave, so the x stream needs no barrier at all -- a counted vmcnt is the whole protocol -- and 98 KB per compute
-//     unit are in flight while the matrix cores work;
-//   * the seven partial accumulators of a block meet in LDS (56 KB) and the EIGHTH wave adds them in a fixed order and
-//     evaluates the upper layers (gemm_upper_fast, the ring kernel's code) while the seven are already on the next
-//     block: the upper layers leave the critical path.  Two s_barriers per block hand the partial buffer back and forth.
-// A block outside the fast path's envelope (NaN / +-inf / huge evidence, large sum of squares, model outside the expanded
-// square's bound, vanished sum node) is evaluated exactly by the eighth wave (gemm_exact_body) -- correctness never
-// depends on a hint; launches that meet NaN evidence set the hint that routes the following ones to the variant built
-// for marginalised evidence (ratspn_gemm_nan.hip).
+//     slice (rows x features [112 w, 112 w + 112)) into its private 14 KB of LDS by LDS-DMA: producer and consumer of a
+//     slot are the same wave, so the x stream needs no barrier -- a counted vmcnt is the whole protocol.  The unit of the
+//     stream is the K-step (2 KB per wave): K-step kk of block b goes to registers and K-step kk of block b + 1 is
+//     requested into the same bytes, so every piece has a whole block period to land;
+//   * a compute unit's request path takes ~37 cycles per 1 KB request whoever issues it (measured: 98 requests of a block
+//     in the K loop made the loop 6k cycles), so the requests of the next block are SPREAD over the block period: three
+//     K-steps inside the K loop, two in front of barrier A (where the wave would wait anyway), two behind barrier B;
+//   * the seven partial accumulators of a block meet in LDS (56 KB, a layout that is conflict free for the MFMA-shaped
+//     writers and for the readers) and all EIGHT waves evaluate the upper layers, 16 lanes per sample, one (repetition,
+//     partition) per lane, seven partials added in a fixed order; two s_barriers per block;
+//   * the prologue is the request path again (196 KB of table + 98 KB of x per compute unit): the table is loaded by asm
+//     statements inside the FIRST block's K loop, three K-steps ahead, while that loop already requests the second block.
+// What was measured on the way and not kept (git history of this file): an eighth wave evaluating the upper
+// layers alone (15k cycles per block: the bottleneck); a loader wave + LDS counters instead of barriers (a wave holds at
+// most 63 requests -- vmcnt is 6 bits -- and becomes latency bound); mixed forms of the two; the slot as the unit of the
+// stream (period >= request latency + issue of 98 requests + copy); a row-run slot layout (3 % cheaper requests, does not
+// split by K-step); staggered work-group starts (no effect); non-temporal requests (slower).
+// A block in which a sample leaves the fast path's envelope (NaN / +-inf / huge evidence, large sum of squares, model outside
+// the expanded square's bound, vanished sum node) is evaluated exactly after the stream, a wave per block (gemm_exact_body)
+// -- correctness never depends on a hint; launches that meet NaN evidence set the hint that routes the following ones to
+// the variant built for marginalised evidence (ratspn_gemm_nan.hip).
 //
 // Results agree with the other two mappings to fp32 rounding, not bit for bit (seven partial sums in a fixed order).
 #include "ratspn_gemm_fused.h"
@@ -501,7 +509,7 @@ bool gemm_slice_shape_ok(int D, int reps, int I, int S, int NT) {
 
 // samples per launch from which the slice mapping is taken (dpk_ratspn_slice_batch_min; DPK_GEMM_SLICE_MIN in the
 // environment sets the initial value; a negative value switches the mapping off)
-constexpr int64_t kSliceBatchDefault = 16385;
+constexpr int64_t kSliceBatchDefault = 8193;
 static int64_t slice_batch_initial() {
     const char *e = getenv("DPK_GEMM_SLICE_MIN");
     return e ? (int64_t)atoll(e) : kSliceBatchDefault;

@@ -234,31 +234,46 @@ def test_fused_exact_path_with_vanishing_weights(golden, mapping):
 
 def test_full_size_properties():
     """BASELINE config at full batch (65536): size-independent properties instead of an oracle run --
-    tile independence (any slice of the batch gives the same LLs), all-NaN rows give LL = 0, and the
-    fused fp64 sum equals the sum of the returned LLs."""
+    tile independence (any slice of the batch gives the same LLs, bit for bit within one mapping), all-NaN rows give
+    LL = 0, and the fused fp64 sum equals the sum of the returned LLs."""
     from deeprob.spn.models import GaussianRatSpn
     from deeprob.hip import ops
     torch.manual_seed(0)
     model = GaussianRatSpn(784, rg_depth=2, rg_repetitions=8, random_state=42).cuda().eval()
     x = torch.randn(65536, 784, device='cuda', generator=torch.Generator('cuda').manual_seed(0))
-    x[12345] = float('nan')
+    # ---- clean evidence: every launch of a given size takes the same kernel ----
     with torch.no_grad():
         ll = model(x)
         part = model(x[1000:1000 + 4097])
         acc = torch.zeros(2, dtype=torch.float64, device='cuda')
         ll2 = model._forward_fused(x, acc)
-    # a slice of 4097 rows takes the small-batch kernels, the full batch the ring kernel: same values to fp32
-    # rounding (the K-steps meet in eight partial sums there, one here), bit-identical within one mapping
-    assert rel_err(part.cpu().numpy(), ll[1000:1000 + 4097].cpu().numpy()) <= 1e-6
-    with torch.no_grad():
-        big = model(x[20000:60000])     # (clear of the all-NaN row: the rows sharing ITS wave take the marginalised form)
+        big = model(x[20000:60000])
+        odd = model(x[20007:60000])     # (not aligned to any tile of any mapping)
         sub = model(x[1000 + 33:1000 + 33 + 2000])
+    # a slice of 4097 rows takes the small-batch kernels, the full batch the persistent ones: same values to fp32
+    # rounding (the K-steps meet in eight / seven partial sums or one), bit-identical within one mapping
+    assert rel_err(part.cpu().numpy(), ll[1000:1000 + 4097].cpu().numpy()) <= 1e-6
     assert torch.equal(ll[20000:60000], big)
+    assert torch.equal(ll[20007:60000], odd)
     assert torch.equal(part[33:33 + 2000], sub)
-    assert abs(ll[12345].item()) < 1e-5
     assert torch.equal(ll, ll2)
     assert acc[1].item() == 65536
     assert abs(acc[0].item() - ll.double().sum().item()) <= 1e-9 * abs(acc[0].item())
+    # ---- one marginalised row: exactly 0 for it, the other rows unchanged to fp32 rounding (a launch that meets NaN
+    # evidence raises the hint that sends the following launches of this model to the variant built for it: same values to
+    # rounding, not bit for bit, while the hint lasts) ----
+    xn = x.clone()
+    xn[12345] = float('nan')
+    with torch.no_grad():
+        for _ in range(3):
+            acc = torch.zeros(2, dtype=torch.float64, device='cuda')
+            lln = model._forward_fused(xn, acc)
+            assert abs(lln[12345].item()) < 1e-5
+            keep = torch.ones(65536, dtype=torch.bool, device='cuda')
+            keep[12345] = False
+            assert rel_err(lln[keep].cpu().numpy(), ll[keep].cpu().numpy()) <= 1e-6
+            assert acc[1].item() == 65536
+            assert abs(acc[0].item() - lln.double().sum().item()) <= 1e-9 * abs(acc[0].item())
 
 
 @pytest.mark.parametrize('kw', [dict(rg_batch=8, rg_sum=8), dict(rg_batch=8, rg_sum=4, optimize_scale=True),
