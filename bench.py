@@ -11,11 +11,14 @@ A step = one pass of the hot path over one resident batch: the fused forward ker
 fp64 sum fused in; its parameter tables are rebuilt only when a parameter changed) + for N > 1 the RCCL all-reduce of
 {sum LL, count} that yields the mean LL on every rank (asynchronous, batched, overlapped with the next steps).
 Inputs live in HBM before the timed region; a ring of >= 4 distinct batches (>= 3x the 256 MiB Infinity Cache) is
-cycled so that the x stream really comes from HBM.  --scaling weak (default): 65536 samples per GPU; strong: 65536
-samples in total.
+cycled so that the x stream really comes from HBM.  For N > 1 the default is the metric's own reading, --scaling strong:
+65536 samples IN TOTAL, 65536 / N per rank, stepped through a sharded evaluation window captured
+as a HIP graph (deeprob.parallel.GraphedEvaluationWindow: the local evaluations and their one all-reduce in one graph
+launch -- a rank's shard kernel is shorter than the host's enqueue of it); the weak figure (65536 per rank) is measured
+in the same run and printed beside it (config.weak_scaling).  --scaling weak makes the weak figure the headline.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (ratspn_gemm_kernel, the fused whole-model
-forward): algorithmic bytes per launch = B * 4*(784 + C) (SURVEY 8d fully-fused bound) over its mean duration
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fused whole-model forward: since round 5
+ratspn_gemm_slice_kernel, csrc/ratspn_gemm_slice.hip, from 8193 samples per launch): algorithmic bytes per launch = B * 4*(784 + C) (SURVEY 8d fully-fused bound) over its mean duration
 measured with HIP events on the launch stream inside the timed loop.  `cpu_baseline` times the oracle (op-for-op
 PyTorch-CPU restatement of the reference) on the host cores over a bounded sample of the same workload.  `secondary`
 (N = 1 only) carries the other BASELINE configurations, each measured the same way in this run: RAT-SPN at B = 4096
@@ -46,7 +49,8 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default=None,
+                    help="default: the metric's reading -- 'strong' (65536 samples in total) for N > 1; identical at N = 1")
     ap.add_argument('--batch', type=int, default=65536, help='samples per GPU per step (weak) / in total (strong)')
     ap.add_argument('--rg-batch', type=int, default=2)
     ap.add_argument('--rg-sum', type=int, default=2)
@@ -58,6 +62,8 @@ def parse():
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only to "
                     "rehearse the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument('--share-device', action='store_true', help='rehearsal: every rank uses cuda:0')
+    ap.add_argument('--graph-window', action='store_true',
+                    help='time the K steps through the graphed evaluation window at N = 1 too (the N > 1 default)')
     ap.add_argument('--kernel-event-every', type=int, default=0,
                     help='a run of --kernel-event-run consecutive timed steps is bracketed by one HIP event pair every '
                          'N timed steps (0 = back to back: every timed step lies in a bracketed run, the last run may be shorter; '
@@ -458,6 +464,41 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
         del m, xs
 
     _peek_hip_error('config2')
+    # ---- the metric's strong-scaling reading on one GPU: the headline model at 65536 / N samples (N = 2, 4, 8 ranks) --------
+    # = the per-rank step of `bench.py --gpus N` (strong scaling is the default there); default mode (per-call table check) and
+    # frozen-model mode, replayed from a HIP graph like the sharded evaluation window replays them
+    try:
+        from deeprob import hip as _hip
+        base = {}
+        for Bs in (65536, 32768, 16384, 8192):
+            nb = max(2, -(-(320 << 20) // (Bs * D * 4)))
+            xs_s = xs_headline[:nb] if Bs == 65536 and len(xs_headline) >= nb else \
+                [torch.randn(Bs, D, device=dev) for _ in range(nb)]
+            reps = max(1, -(-32 // nb))
+            ms_def = _time_eval_graph(headline_model, xs_s, reps=reps)
+            prev = _hip.trust_version_counters(True)
+            try:
+                with torch.no_grad():
+                    headline_model(xs_s[0])
+                ms_tr = _time_eval_graph(headline_model, xs_s, reps=reps)
+            finally:
+                _hip.trust_version_counters(prev)
+            base[Bs] = (ms_def, ms_tr)
+            if Bs == 65536 or ms_def is None:
+                continue
+            n = 65536 // Bs
+            out.append({'workload': 'headline model, one rank\'s shard of the 65536-sample batch at N = {} (strong scaling), '
+                                    'model(x) replayed from a HIP graph over {} resident shards'.format(n, nb),
+                        'id': 'shard/{}'.format(n), 'config': 'strong-scaling shard', 'batch': Bs, 'ms_per_step': ms_def,
+                        'value': Bs / ms_def * 1e3, 'unit': 'log-likelihoods/sec',
+                        'ms_per_step_trusting_version_counters': ms_tr,
+                        'predicted_speedup': (base[65536][0] / ms_def) if base[65536][0] else None,
+                        'predicted_speedup_trusted': (base[65536][1] / ms_tr) if base[65536][1] and ms_tr else None,
+                        'roofline': hbm(Bs * 3140, ms_def), 'roofline_basis': 'whole step; 3140 algorithmic B/sample'})
+            del xs_s
+    except Exception as ex:
+        out.append({'id': 'shard', 'config': 'strong-scaling shard', 'error': '{}: {}'.format(type(ex).__name__, ex)})
+    _peek_hip_error('shards')
     # ---- BASELINE config 4: DGC-SPN, B = 8192 ----------------------------------------------------------------------
     B = 8192
     torch.manual_seed(5)
@@ -670,8 +711,14 @@ def compact_configs(sec):
                              ('ms_per_step_hip_graph', 'ms_graph'), ('slowdown_vs_clean', 'x_clean')):
             if e.get(k_src) is not None:
                 r[k_dst] = round(e[k_src], 5)
-        if e.get('kernel_ms'):
+        # (a single-launch HIP event pair brackets its own dispatch: only a figure below the step it belongs to is evidence;
+        # the rocprofv3 kernel times are in profiles/)
+        if e.get('kernel_ms') and e['kernel_ms'] <= e['ms_per_step']:
             r['k_us'] = round(e['kernel_ms'] * 1e3, 2)
+        if e.get('predicted_speedup') is not None:
+            r['x_vs_64k'] = round(e['predicted_speedup'], 2)
+            if e.get('predicted_speedup_trusted') is not None:
+                r['x_vs_64k_trust'] = round(e['predicted_speedup_trusted'], 2)
         roof = e.get('roofline')
         if roof:
             r['bound'], r['frac'] = roof['bound'], round(roof['frac'], 4)
@@ -725,12 +772,44 @@ def main():
     from deeprob.parallel import ShardedLogLikelihood
 
     D = 784
+    if args.scaling is None:
+        args.scaling = 'strong' if world > 1 else 'weak'
     B = args.batch if args.scaling == 'weak' else max(1, args.batch // world)
     torch.manual_seed(0)  # identical replica on every rank
     model = GaussianRatSpn(D, rg_depth=2, rg_repetitions=8, rg_batch=args.rg_batch, rg_sum=args.rg_sum,
                            random_state=42).eval()
     cpu_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model.to(dev)
+
+    def graphed_run(Bg, steps, warmup):
+        """K steps on shards of Bg samples per rank through the graphed evaluation window: (seconds for the K steps,
+        max over ranks; mean LL of the last step; steps per graph replay)."""
+        from deeprob.parallel import GraphedEvaluationWindow
+        L = max(d for d in range(1, min(steps, 40) + 1) if steps % d == 0)
+        ring_g = max(4, -(-(768 << 20) // (Bg * D * 4)))
+        gen_g = torch.Generator(device=dev).manual_seed(4321 + rank)
+        xs_g = [torch.randn(Bg, D, device=dev, generator=gen_g) for _ in range(min(ring_g, max(L, 4)))]
+        ev = ShardedLogLikelihood(model, group=dist.group.WORLD if world > 1 else None, static_inputs=True,
+                                  static_params=True)
+        win = GraphedEvaluationWindow(ev, [xs_g[i % len(xs_g)] for i in range(L)])
+        for _ in range(max(1, -(-warmup // L))):
+            win.replay()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        means = None
+        for _ in range(steps // L):
+            means = win.replay()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dtg = time.perf_counter() - t0
+        tt = torch.tensor([dtg], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        del win, xs_g
+        return float(tt.item()), means[-1], L
 
     ring = args.ring or max(4, -(-(768 << 20) // (B * D * 4)))
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)  # every rank its own shard of the batch
@@ -808,6 +887,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     mean_ll = results[-1]
+    eager_ms = dt / args.steps * 1e3
+    step_mode = 'eager: one C call per step (host enqueue below the kernel time at this shard size)'
+    weak_entry = None
+    if world > 1 or args.graph_window:
+        # N > 1: the contract's K steps are timed through the graphed window (the eager loop above only warms the path up
+        # and carries the kernel events); the other scaling mode is measured the same way and printed beside it.  A window
+        # that cannot be captured (a backend whose collective is not capturable) leaves the eager figure in place.
+        try:
+            with torch.no_grad():
+                dtg, mean_g, L = graphed_run(B, args.steps, args.warmup)
+                dt, mean_ll = dtg, mean_g
+                step_mode = ('HIP graph: {} steps + their one all-reduce per replay (eager loop of the same steps: {:.5f} '
+                             'ms/step)'.format(L, eager_ms))
+                if world > 1:
+                    Bo = max(1, args.batch // world) if args.scaling == 'weak' else args.batch
+                    dto, _, _ = graphed_run(Bo, args.steps, args.warmup)
+                    weak_entry = {'scaling': 'strong' if args.scaling == 'weak' else 'weak', 'samples_per_gpu_per_step': Bo,
+                                  'value': Bo * world * args.steps / dto, 'ms_per_step': dto / args.steps * 1e3}
+        except Exception as ex:
+            step_mode = 'eager (graphed window failed: {}: {})'.format(type(ex).__name__, str(ex)[:120])
 
     # the same loop in the DEFAULT mode of model(x): every call checks its cached parameter tables on the device (a
     # write through param.data moves no version counter); the headline loop above declares a frozen model
@@ -841,7 +940,8 @@ def main():
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': workload, 'global_batch': B * world, 'resident_batches': ring, 'mean_ll': mean_ll,
-                       'host_enqueue_ms_per_step': round(host_dt / args.steps * 1e3, 5),
+                       'host_enqueue_ms_per_step': round(host_dt / args.steps * 1e3, 5), 'step_mode': step_mode,
+                       'other_scaling': weak_entry,
                        'params_mode': 'static_params=True (frozen model: no per-call table check)',
                        'ms_per_step_default_mode': ms_default,
                        'arithmetic': 'fp32 results; leaf GEMM = 3 f16 MFMAs on two-way f16 splits, fp32 accumulate '
@@ -855,18 +955,21 @@ def main():
             alg_bytes = B * 4 * (D + model.out_classes)
             achieved = alg_bytes / (k_ms * 1e-3) / 1e9
             traffic, source = read_traffic('headline')
+            two = (args.rg_batch, args.rg_sum) == (2, 2)
+            kernel_name = ('ratspn_gemm_slice_kernel' if two and B >= 8193 else 'ratspn_gemm_small_kernel' if B <= 16384
+                           else 'ring::ratspn_gemm_kernel')
             out['roofline'] = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic if B == 65536 else None,
-                               'kernel': 'ratspn_gemm_kernel', 'kernel_ms': k_ms, 'kernel_event_samples': n_launches,
+                               'kernel': kernel_name, 'kernel_ms': k_ms, 'kernel_event_samples': n_launches,
                                'algorithmic_bytes_per_launch': alg_bytes}
             detail['roofline_notes'] = {
                 'traffic_source': source if B == 65536 else None,
                 'kernel_event_method': '{} runs of up to {} consecutive launches covering {} of the {} timed steps, one HIP '
                                        'event pair per run (includes the gaps between the launches of a run)'.format(
                                            len(sampled), run, n_launches, args.steps),
-                'context': 'tools/ubench/read_bw.hip on the same GPU model: 6.4 TB/s for a linear 16-byte-load stream, '
-                           '5.7 TB/s for this kernel\'s access pattern (256-byte row segments at a 3136-byte stride); '
-                           'peak = the 8 TB/s specification'}
+                'context': 'tools/ubench/read_bw.hip on the same GPU model: 6.4 TB/s for a linear 16-byte-load stream; the '
+                           'slice kernel reads whole 100 KB blocks of 32 consecutive rows (64-byte pieces per request '
+                           'lane quad); peak = the 8 TB/s specification'}
         threads = min(os.cpu_count() or 1, 32)
         if args.cpu_samples > 0 and world == 1:
             out['cpu_baseline'], threads = cpu_baseline(cpu_state, D, args.cpu_samples)

@@ -188,6 +188,9 @@ class GraphedEvaluationWindow:
         world = dist.get_world_size(evaluator.group) if evaluator.group is not None else 1
         reduce = evaluator.group is not None and (world > 1 or always_reduce)
         side = torch.cuda.Stream(device=dev)
+        # (inputs / parameters still being written on the caller's stream must be complete before the warm pass reads them:
+        # the tables it builds and the verdicts it caches would otherwise come from incomplete data)
+        side.wait_stream(torch.cuda.current_stream(dev))
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.stream(side):
             warm = torch.zeros(len(self.xs), 2, dtype=torch.float64, device=dev)
@@ -202,6 +205,7 @@ class GraphedEvaluationWindow:
                     evaluator._local(x, acc=self.pool[i])
                 if reduce:
                     dist.all_reduce(self.pool, op=dist.ReduceOp.SUM, group=evaluator.group)
+        torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
 
     def replay(self) -> List[float]:
