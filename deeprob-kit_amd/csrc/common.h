@@ -6,6 +6,16 @@
 #include <float.h>
 #include "../../include/deeprob_hip.h"
 
+// gfx950 only, and not as a formality: the "last work-group finishes" protocols of this library (params_fingerprint_kernel,
+// level_jacobian_tail, the split-K tickets of coupling_bwd.hip, the in-launch table verdict of ratspn_gemm_prep.h) order
+// their data with device-scope relaxed atomics + a work-group-scope release + s_waitcnt 0 in front of the ticket instead of
+// __threadfence() (which writes back the XCD's L2: 17-40 us here).  That relies on gfx950's acknowledgement semantics: an
+// agent-scope atomic (sc1) is performed at the memory side, and s_waitcnt vmcnt(0) returns only when it has been.  Another
+// architecture needs the release / acquire fences back.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libdeeprob_hip is written for gfx950 (MI355X): see the note on fence-free ticket protocols in common.h"
+#endif
+
 namespace dpk {
 
 void set_error(const char *fmt, ...);

@@ -207,10 +207,13 @@ __global__ void gemm_epilogue_kernel(const GemmArgs g) {
 }
 
 // Few output tiles and a long K (the training-batch products dH = dZ W2, H = x W1^T, dW = dOut^T In): split K over
-// blockIdx.z so that the grid fills the chip.  Scratch for the partial tiles and the arrival counts comes from a
-// process-wide pool (64 MB ring + 64 K counters, allocated at the first product that needs it; a first use inside a stream
-// capture cannot allocate and takes the atomicAdd fallback).  A product takes a fresh region of the ring, so products of
-// one stream never meet; more than ~8 split products in flight at once on different streams would.
+// blockIdx.z so that the grid fills the chip.  Scratch for the partial tiles and the arrival counts comes from a pool PER
+// DEVICE (64 MB ring + 64 K counters on the device that is current at the launch, allocated at the first product that
+// needs it there; a first use inside a stream capture cannot allocate and takes the atomicAdd fallback).  A process that
+// trains on a second GPU must not store its partials and tickets into device 0's memory: that faults without peer access,
+// and with it the agent-scope ticket protocol does not order memory across devices.  A product takes a fresh region of the
+// ring, so products of one stream never meet.  Restriction: one stream per device at a time -- more than ~8 split products
+// in flight at once on DIFFERENT streams of one device would wrap the ring into regions still in use.
 struct GemmPool {
     std::mutex mu;
     float *partials = nullptr;
@@ -220,8 +223,15 @@ struct GemmPool {
 };
 constexpr int64_t kGemmPoolFloats = 16ll << 20;   // 64 MB
 constexpr int kGemmPoolTickets = 1 << 16;
+constexpr int kGemmPoolDevices = 16;
 static bool gemm_pool_take(int64_t floats, int tiles, float **p, unsigned **t, hipStream_t st) {
-    static GemmPool pool;
+    static GemmPool pools[kGemmPoolDevices];
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kGemmPoolDevices) {
+        (void)hipGetLastError();
+        return false;              // (no pool for this device: the atomicAdd fallback)
+    }
+    GemmPool &pool = pools[dev];
     std::lock_guard<std::mutex> lock(pool.mu);
     if (pool.failed || floats > kGemmPoolFloats / 2 || tiles > kGemmPoolTickets / 2) return false;
     if (pool.partials == nullptr) {

@@ -37,6 +37,7 @@ class GraphedTrainStep:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.static_in: Optional[torch.Tensor] = None
         self.static_loss: Optional[torch.Tensor] = None
+        self.static_key = None
         self.seen = 0
 
     def _eager(self, inputs: torch.Tensor) -> torch.Tensor:
@@ -51,9 +52,17 @@ class GraphedTrainStep:
 
     def __call__(self, inputs: torch.Tensor) -> torch.Tensor:
         """Train on one batch; returns the loss tensor (valid until the next call)."""
+        # What a capture bakes in besides the shard's shape: the host integers of a sharded step -- the whole-batch element
+        # count and the n_r / N weight of the synchronised 2-D batch norms (deeprob.parallel.shard_sizes) are kernel
+        # scalars.  On a ragged last batch (511 rows on 2 ranks: 256 + 255) one rank's shard still has the captured shape:
+        # replaying there while its peer runs eagerly with N = 511 would leave the replicas silently diverged.  The step is
+        # therefore keyed on (local shape, shard sizes): anything else runs eagerly, on every rank alike.
+        from deeprob import parallel
+        key = parallel.shard_sizes()
         if self.static_in is None:
             self.static_in = torch.empty_like(inputs)
-        if inputs.shape != self.static_in.shape:
+            self.static_key = key
+        if inputs.shape != self.static_in.shape or key != self.static_key:
             return self._eager(inputs)                       # e.g. the last, shorter batch of an epoch
         self.static_in.copy_(inputs)
         if self.graph is not None:

@@ -4,7 +4,13 @@
 parameter tensors on a HIP device: torch's fused kernel deals a tensor out in chunks of 65 536 elements, which leaves the
 models of this path (3 .. 30 tensors, 50 k .. 1.5 M parameters) on a handful of work-groups -- 30 us of a 200 us RAT-SPN
 step.  Same update rule and state names (``exp_avg``, ``exp_avg_sq``, ``step``) as ``torch.optim.Adam`` (non-amsgrad);
-the step count lives on the device, so the optimiser is always capturable in a HIP graph."""
+the step count lives on the device, so the optimiser is always capturable in a HIP graph.
+
+Restriction (checked, not silent): ONE step count per parameter group, where ``torch.optim.Adam`` keeps one per parameter.
+The two agree as long as every parameter of a group is updated from the group's first step on.  A parameter that first
+receives a gradient later (frozen then unfrozen, a conditionally used branch) would get the bias corrections of step
+k + 1 instead of step 1: ``step`` raises for it, and ``load_state_dict`` raises for a state whose per-parameter steps
+differ -- use ``torch.optim.Adam`` for such schedules."""
 import ctypes
 from typing import Iterable
 
@@ -54,6 +60,20 @@ class FusedAdam(torch.optim.Optimizer):
             tickets[key] = torch.zeros(1, dtype=torch.int32, device=dev)
         return step_t, tickets[key]
 
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for gi, group in enumerate(self.param_groups):
+            steps = set()
+            for p in group['params']:
+                st = self.state.get(p, {}).get('step')
+                if st is not None:
+                    steps.add(float(st.item()) if torch.is_tensor(st) else float(st))
+            if len(steps) > 1:
+                raise ValueError("FusedAdam.load_state_dict: the parameters of group {} carry different step counts {}; "
+                                 "FusedAdam keeps one per group -- load this state into torch.optim.Adam".format(gi, sorted(steps)))
+            # (parameters that already have moments count as members of the group's schedule)
+            self.__dict__.setdefault('_dpk_seen', {})[gi] = {id(p) for p in group['params'] if 'exp_avg' in self.state.get(p, {})}
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -80,6 +100,13 @@ class FusedAdam(torch.optim.Optimizer):
                 continue
             if len(updated) > MAX_TENSORS:
                 raise HipError("FusedAdam: {} parameter tensors in a group (at most {})".format(len(updated), MAX_TENSORS))
+            seen = self.__dict__.setdefault('_dpk_seen', {}).setdefault(gi, set())
+            late = [p for p in updated if id(p) not in seen]
+            if late and seen and len(late) != len(updated):
+                raise HipError("FusedAdam: {} parameter tensor(s) of group {} receive their first gradient after the group's "
+                               "first step; FusedAdam keeps one step count per group (torch.optim.Adam: one per parameter) -- "
+                               "use torch.optim.Adam for this schedule".format(len(late), gi))
+            seen.update(id(p) for p in updated)
             step_t, ticket = self._group_state(group, updated)
             # the tensor table handed to the kernel: rebuilt only when the set of updated tensors (or their storage) changes;
             # per step only the gradient addresses move (zero_grad(set_to_none=True) gives every step fresh gradients)

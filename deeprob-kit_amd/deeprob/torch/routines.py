@@ -158,11 +158,13 @@ def train_discriminative(
 
 def _batch(item, device, rank, world, supervised):
     """This rank's shard of a loader item, moved to the device."""
+    from deeprob.parallel import set_shard_sizes, shard_bounds
     if world > 1:
-        from deeprob.parallel import set_shard_sizes, shard_bounds
         n = (item[0] if supervised else item).shape[0]
         lo, hi = shard_bounds(n, rank, world)
         set_shard_sizes(hi - lo, n)
+    else:
+        set_shard_sizes(None)      # (a replicated batch: stale sizes of the previous sharded one must not describe it)
     if supervised:
         inputs, targets = item
         return (shard_batch(inputs.to(device, non_blocking=True), rank, world),
@@ -192,6 +194,21 @@ def _fit(model, train_loader, valid_loader, optimizer, device, early_stopping, e
                                    grad_exchange=(lambda n: allreduce_gradients(model, weight=n)) if world > 1 else None)
     history = {'train': {'loss': [], 'accuracy': []}, 'valid': {'loss': [], 'accuracy': []}}
     meters = {k: RunningAverageMetric() for k in ('train_loss', 'train_hits', 'valid_loss', 'valid_hits')}
+    try:
+        return _fit_epochs(model, train_loader, valid_loader, optimizer, device, early_stopping, epochs, train_base, verbose,
+                           supervised, graphed, history, meters, rank, world)
+    finally:
+        # nothing of the sharded run may describe a later call: a stale (local, total) pair would be taken for the sizes of
+        # a train-mode batch that happens to have the same local size, and a sync_group left on the model would make a
+        # later single-process call wait in a collective
+        from deeprob.parallel import set_shard_sizes
+        set_shard_sizes(None)
+        if world > 1:
+            synchronize_batchnorm(model, enabled=False)
+
+
+def _fit_epochs(model, train_loader, valid_loader, optimizer, device, early_stopping, epochs, train_base, verbose, supervised,
+                graphed, history, meters, rank, world):
     for epoch in range(1, epochs + 1):
         for m in meters.values():
             m.reset()

@@ -213,3 +213,61 @@ def test_fused_adam_state_dict_round_trip():
     for p, q in zip(resumed, theirs):
         assert torch.allclose(p, q, rtol=2e-6, atol=2e-6)
     assert float(a2.state[resumed[0]]['step']) == 9.0
+
+
+def test_fused_adam_one_step_count_per_group_is_enforced():
+    """FusedAdam keeps ONE step count per parameter group (torch.optim.Adam: one per parameter).  A parameter that joins after
+    the group's first step, or a loaded state with differing per-parameter steps, would silently get other bias
+    corrections than the optimiser train_model('adam') used to build: both raise instead."""
+    from deeprob.hip.optim import FusedAdam
+    from deeprob.hip import HipError
+    a = torch.nn.Parameter(torch.randn(300, device='cuda'))
+    b = torch.nn.Parameter(torch.randn(200, device='cuda'))
+    opt = FusedAdam([a, b], lr=1e-2)
+    a.grad = torch.randn_like(a)
+    opt.step()                                   # only `a` has a gradient: the group's schedule starts with `a` alone
+    a.grad = torch.randn_like(a)
+    b.grad = torch.randn_like(b)
+    with pytest.raises(HipError):
+        opt.step()                               # `b` joins late
+    ref = torch.optim.Adam([a, b], lr=1e-2, capturable=True)
+    a.grad = torch.randn_like(a)
+    b.grad = None
+    ref.step()
+    b.grad = torch.randn_like(b)
+    ref.step()                                   # torch: a at step 2, b at step 1
+    with pytest.raises(ValueError):
+        FusedAdam([a, b], lr=1e-2).load_state_dict(ref.state_dict())
+
+
+def test_graphed_train_step_is_keyed_on_the_shard_sizes():
+    """A captured sharded step bakes the whole-batch element count of the synchronised batch norms into kernel scalars: a
+    batch with the same LOCAL shape but another global size (511 rows on two ranks: 256 + 255) must run eagerly, or the
+    replicas diverge."""
+    from deeprob import parallel
+    from deeprob.flows.models import RealNVP1d
+    from deeprob.hip.graphs import GraphedTrainStep
+    from deeprob.torch.routines import build_optimizer
+    torch.manual_seed(0)
+    flow = RealNVP1d(16, n_flows=2, units=32).cuda().train()
+    opt = build_optimizer('adam', list(flow.parameters()), 1e-3, dict(fused=True, capturable=True))
+    step = GraphedTrainStep(flow, opt, warmup=1)
+    x = torch.randn(64, 16, device='cuda')
+    try:
+        parallel.set_shard_sizes(64, 128)
+        for _ in range(3):
+            step(x)
+        assert step.graph is not None
+        replays = []
+        orig = step.graph.replay
+        step.graph.replay = lambda: (replays.append(1), orig())[1]
+        step(x)
+        assert len(replays) == 1                  # same shape, same sizes: replayed
+        parallel.set_shard_sizes(64, 127)
+        step(x)
+        assert len(replays) == 1                  # same local shape, other global size: eager
+        parallel.set_shard_sizes(64, 128)
+        step(x)
+        assert len(replays) == 2
+    finally:
+        parallel.set_shard_sizes(None)
