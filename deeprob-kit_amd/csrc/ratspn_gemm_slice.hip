@@ -509,7 +509,9 @@ bool gemm_slice_shape_ok(int D, int reps, int I, int S, int NT) {
 
 // samples per launch from which the slice mapping is taken (dpk_ratspn_slice_batch_min; DPK_GEMM_SLICE_MIN in the
 // environment sets the initial value; a negative value switches the mapping off)
-constexpr int64_t kSliceBatchDefault = 8193;
+// (7681 = 240 blocks: up to there the small-batch kernel's 13 in-launch table work-groups still fit beside its tiles in one
+// round of 256 compute units; at 8192 it needs a second round -- 25.7 us against 15.0, profiles/r05_shard8192_kernel_stats.txt)
+constexpr int64_t kSliceBatchDefault = 7681;
 static int64_t slice_batch_initial() {
     const char *e = getenv("DPK_GEMM_SLICE_MIN");
     return e ? (int64_t)atoll(e) : kSliceBatchDefault;
