@@ -56,6 +56,9 @@ __global__ __launch_bounds__(kGemmPrepThreads) void ratspn_gemm_prep_kernel(cons
     if (a.mode == kPrepBuild && blockIdx.x == 0 && threadIdx.x == 0) {   // (no launch of this module is in flight: stream order)
         a.ctl->word = 0ull;
         a.ctl->readers = 0u;
+        // (the slice mapping's distributed check, ratspn_gemm_slice.hip SliceVerify: 16 accumulators + the arrival count)
+        unsigned long long *sv = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.ctl) + 64);
+        for (int i = 0; i < 18; ++i) sv[i] = 0ull;
     }
     gemm_prep_block<I>(a, (int)blockIdx.x, prep_dyn);
 }
@@ -361,7 +364,8 @@ bool gemm_marginal_shape_ok(int D, int NT);
 // ratspn_gemm_slice.hip: persistent 32-sample blocks, the feature axis split over seven waves with the mean table in registers
 bool gemm_slice_shape_ok(int D, int reps, int I, int S, int NT);
 int64_t gemm_slice_min_batch();
-int ratspn_gemm_slice_forward(const GemmArgs &a, int I, int S, int NT, hipStream_t st);
+int ratspn_gemm_slice_forward(const GemmArgs &a, const GemmPrepArgs &p, int I, int S, int NT, hipStream_t st);
+bool gemm_slice_checks_inline(int64_t B, int np);
 // ratspn_gemm_wide.hip: 8-channel models, a wave per repetition
 bool gemm_wide_shape_ok(int D, int reps, int I, int S, int C);
 int ratspn_gemm_wide_forward(const GemmArgs &a, const GemmPrepArgs &p, int S, hipStream_t st);
@@ -424,7 +428,8 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
     static const bool ring_vi = [] { const char *e = getenv("DPK_RING_VI"); return e && atoi(e) != 0; }();
     const bool ring_inline = ring_vi && ring_plain && (int64_t)np <= std::min<int64_t>(cdiv(B, kGemmTile), device_cus());
     const bool verify_inline = inline_allowed && (flags & DPK_FLAG_PARAMS_VERIFY) && !(flags & DPK_FLAG_PARAMS_CACHED) &&
-                               ((wide && gemm_wide_takes_tile32(B, D, reps, C, marginal, emitting)) || small || ring_inline);
+                               ((wide && gemm_wide_takes_tile32(B, D, reps, C, marginal, emitting)) || small || ring_inline ||
+                                (slice && gemm_slice_checks_inline(B, np)));
     if (verify_inline) {
         p.mode = kPrepInline;
         p.np = np;
@@ -452,7 +457,7 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
         if (emitting) { a.emit_leaf = emit->leaf; a.emit_sum = emit->sum; a.emit_out = emit->out; }
         if (wide) return ratspn_gemm_wide_forward(a, p, S, st);
         if (small) return ratspn_gemm_small_forward(a, p, reps, I, S, NT, st);
-        if (slice) return ratspn_gemm_slice_forward(a, I, S, NT, st);
+        if (slice) return ratspn_gemm_slice_forward(a, p, I, S, NT, st);
         return ratspn_gemm_marginal_forward(a, reps, I, S, NT, st);
     }
     ring::GemmArgs a{};

@@ -58,8 +58,123 @@ __host__ __device__ constexpr int slice_lds_bytes(int NT, int w0_floats) {
 #define SL_STAMP(row, slot) do { } while (0)
 #endif
 
+// The table-free exact evaluation of 32 samples (a launch that found its parameter tables stale, ratspn_gemm_prep.h):
+// gemm_exact_body with the log-softmax weights taken straight from the raw sum / root weights.
 template <int I, int S, int NT>
-__global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const GemmArgs a) {
+__device__ __forceinline__ void slice_exact_raw(const GemmArgs &a, const float *raw0, const float *rawr, int64_t bw0, int lane,
+                                                LseScratch sc) {
+    constexpr int RPT = 8 / I;
+    constexpr int RH = (NT * RPT + 1) / 2;
+    const int s = lane & 31, h = lane >> 5;
+    const int64_t b = bw0 + s;
+    const bool valid = b < a.B;
+    const float *xr = a.x + (valid ? b : a.B - 1) * a.D;
+    const int d = a.d;
+    float n1[RH][2][S];
+#pragma unroll
+    for (int m = 0; m < RH; ++m) {
+        const int rho = 2 * m + h;
+        float leaf[4][I];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < I; ++k) leaf[q][k] = 0.f;
+        if (rho < a.reps) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = rho * 4 + q;
+                for (int j = 0; j < d; ++j) {
+                    const int64_t o = (int64_t)r * d + j;
+                    if (a.pad != nullptr && a.pad[o]) continue;
+                    const float xv = xr[a.mask[o]];
+#pragma unroll
+                    for (int k = 0; k < I; ++k) {
+                        const int64_t po = ((int64_t)r * I + k) * d + j;
+                        const float mu = a.loc[po], sg = a.scale[po];
+                        const float dlt = xv - mu;
+                        leaf[q][k] += nan_to_num_f(fmaf(dlt * dlt, -0.5f / (sg * sg), -logf(sg) - kLogSqrt2Pi));
+                    }
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                prodsum_node_raw<I, S>(leaf[2 * p], leaf[2 * p + 1], raw0 + ((int64_t)rho * 2 + p) * S * I * I, sc.slot, n1[m][p]);
+        }
+    }
+    const int M = a.reps * S * S;
+    double part = 0.0;
+    for (int cl = 0; cl < a.C; ++cl) {
+        const float lse_row = raw_row_lse(rawr + (int64_t)cl * M, M);
+        float mm = -INFINITY, ss = 0.f;
+#pragma unroll
+        for (int m = 0; m < RH; ++m) {
+            const int rho = 2 * m + h;
+            if (rho < a.reps) {
+                float pm, ps;
+                root_partial_raw<S>(n1[m][0], n1[m][1], rawr + (int64_t)cl * M + rho * S * S, lse_row, sc.slot, pm, ps);
+                lse_merge(mm, ss, pm, ps);
+            }
+        }
+        const float om = __shfl_xor(mm, 32, 64), os = __shfl_xor(ss, 32, 64);
+        lse_merge(mm, ss, om, os);
+        const float ll = (mm > -INFINITY) ? mm + logf(ss) : -INFINITY;
+        if (h == 0 && valid) {
+            a.out[b * a.C + cl] = ll;
+            part += (double)ll;
+        }
+    }
+    if (a.ll_sum != nullptr) {
+        part = wave_reduce_sum(part);
+        if (lane == 0) atomicAdd(a.ll_sum, part);
+    }
+}
+
+// The in-launch check of the parameter tables (DPK_FLAG_PARAMS_VERIFY, ratspn_gemm_prep.h) for THIS mapping.  The small
+// kernels put np table work-groups in front of their tiles; here every work-group is a persistent model work-group that
+// owns its compute unit (13 more would start 13 of the 256 late by the check's 4-5 us).  Instead the eighth wave of EVERY
+// work-group, idle during the first K loop, fingerprints a 1 / nparts share of one table work-group's inputs (the
+// fingerprint is a sum of position-tagged words: any split gives the same sum), adds it to that table work-group's
+// accumulator in the workspace and takes an arrival ticket; the last arriver compares the np sums with the stored
+// fingerprints, zeroes the accumulators and publishes the launch's verdict in the VerifyCtl word the readers of the other
+// kernels use.  Every work-group reads it after its stream; a dirty launch discards what it computed, evaluates on the
+// table-free exact route, and its first np work-groups rebuild the tables in place.
+struct SliceVerify {               // behind the VerifyCtl in the workspace (zero between launches)
+    unsigned long long acc[16];
+    unsigned arrived, pad[3];
+};
+__device__ __forceinline__ SliceVerify *slice_verify_of(VerifyCtl *c) {
+    return reinterpret_cast<SliceVerify *>(reinterpret_cast<char *>(c) + 64);
+}
+template <int I>
+__device__ __forceinline__ void slice_verify_share(const GemmPrepArgs &pa, int lane) {
+    const int np = pa.np, G = (int)gridDim.x, g = (int)blockIdx.x;
+    const int twg = g % np, part = g / np, nparts = (G - 1 - twg) / np + 1;
+    unsigned long long h = gemm_prep_hash_share<I>(pa, twg, part * 64 + lane, nparts * 64);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) h += (unsigned long long)__shfl_xor((long long)h, o, 64);
+    if (lane == 0) {
+        SliceVerify *sv = slice_verify_of(pa.ctl);
+        // (the share is PERFORMED before the arrival is: the returned value is waited for)
+        const unsigned long long before = __hip_atomic_fetch_add(&sv->acc[twg], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(before) : "memory");
+        const unsigned n = __hip_atomic_fetch_add(&sv->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n == (unsigned)(G - 1)) {
+            bool dirty = false;
+            for (int t = 0; t < np; ++t) {
+                const unsigned long long sum = __hip_atomic_load(&sv->acc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dirty = dirty || (kPrepHashBase + (unsigned long long)t + sum != pa.hash[t]);
+                __hip_atomic_store(&sv->acc[t], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __hip_atomic_store(&sv->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&pa.ctl->word, (unsigned long long)np + (dirty ? (1ull << 32) : 0ull), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+template <int I, int S, int NT>
+__global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const GemmArgs a, const GemmPrepArgs pa) {
     constexpr int RPT = 8 / I;
     constexpr int NMAX = (I > S ? I : S);
     constexpr int KW = kSliceKW;
@@ -265,6 +380,8 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
             issue_kk(nxt, nnv, 4);
         }
     }
+    // (the eighth wave, idle during the first K loop: its share of the launch's table check)
+    if (!slicer && pa.np > 0) slice_verify_share<I>(pa, lane);
     SL_STAMP(15, 1);
     [[maybe_unused]] int row = 0;
     int it = 0;
@@ -461,13 +578,25 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
         ++row;
     }
     SL_STAMP(15, 2);
-    // ---- the last block's verdict, then the blocks that left the fast path: exact evaluation, a wave per block ---------
+    // ---- the launch's verdict on its tables, the last block's verdict, then what left the fast path ------------------------
+    lunsigned *dirty_l = flag_l + 16 - 1;            // (the last word of the flag block: free)
+    if (pa.np > 0 && tid == 0) {
+        unsigned ticket;
+        const bool dirty = vi_wait(pa.ctl, pa.np, ticket);
+        vi_done(pa.ctl, ticket, pa.readers);
+        *dirty_l = dirty ? 1u : 0u;
+    }
     __syncthreads();
+    const bool tables_stale = pa.np > 0 && *dirty_l != 0u;
     if (it > 0) {
         const lunsigned *fl = flag_l + ((it - 1) & 1) * 8;
         const unsigned any_bad = (fl[0] | fl[1]) | (fl[2] | fl[3]) | (fl[4] | fl[5]) | (fl[6] | fl[7]);
         if (any_bad) exact_mask |= 1ull << (it - 1);
         else ll_part += pend_part;
+    }
+    if (tables_stale) {   // (nothing computed from the stale tables counts: every block goes through the table-free route)
+        ll_part = 0.0;
+        exact_mask = nit >= 64 ? ~0ull : ((1ull << nit) - 1ull);
     }
     if (a.ll_sum != nullptr) {
         // {sum of LLs, count}: one atomic per work-group (and one for the count per launch)
@@ -493,8 +622,16 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
         for (int e = 0; e < 64; ++e) {
             if (!((exact_mask >> e) & 1ull)) continue;
             if ((n++ & 7) != wave) continue;
-            gemm_exact_body<I, S, NT>(a, (int64_t)(first + e * stride) * 32, lane_x, sc);
+            if (tables_stale) slice_exact_raw<I, S, NT>(a, pa.w[0], pa.w[1], (int64_t)(first + e * stride) * 32, lane_x, sc);
+            else gemm_exact_body<I, S, NT>(a, (int64_t)(first + e * stride) * 32, lane_x, sc);
         }
+    }
+    // a stale launch: the first np work-groups rebuild their table work-group's outputs in place (nobody consumes a table
+    // value any more) and store the new fingerprints -- the next launch is clean again
+    if (tables_stale && (int)blockIdx.x < pa.np) {
+        __syncthreads();   // (the exact evaluation's scratch is the rebuild's staging area)
+        // (mode through the override: a by-value copy of the argument block costs 264 bytes of scratch per lane, every launch)
+        gemm_prep_block<I>(pa, (int)blockIdx.x, reinterpret_cast<int *>(smem_generic), kPrepBuild);
     }
 }
 
@@ -523,8 +660,9 @@ static int64_t &slice_batch_min_ref() {
 int64_t gemm_slice_min_batch() { return slice_batch_min_ref(); }
 
 template <int I, int S, int NT>
-static int gemm_slice_launch(const GemmArgs &a0, hipStream_t st) {
-    const size_t lds = (size_t)slice_lds_bytes(NT, a0.reps * 2 * S * I * I);
+static int gemm_slice_launch(const GemmArgs &a0, const GemmPrepArgs &p, hipStream_t st) {
+    size_t lds = (size_t)slice_lds_bytes(NT, a0.reps * 2 * S * I * I);
+    if (p.np > 0 && gemm_prep_lds_bytes(a0.D, I, a0.d) > lds) lds = gemm_prep_lds_bytes(a0.D, I, a0.d);
     DPK_REQUIRE(lds <= 160 * 1024, DPK_EUNSUPPORTED, "ratspn_gemm_slice: %zu bytes of LDS", lds);
     auto kern = ratspn_gemm_slice_kernel<I, S, NT>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024)) return rc;
@@ -534,6 +672,7 @@ static int gemm_slice_launch(const GemmArgs &a0, hipStream_t st) {
     if (ev0) (void)hipEventRecord(ev0, st);
     // a work-group remembers the blocks it leaves to the exact evaluation in a 64-bit mask: at most 64 blocks per
     // work-group and launch, i.e. 524 288 samples per launch on 256 compute units -- larger batches take several launches
+    // (the caller keeps the in-launch table check to single-launch batches: gemm_slice_checks_inline)
     const int64_t per_launch = (int64_t)64 * 32 * cus;
     for (int64_t off = 0; off < a0.B; off += per_launch) {
         GemmArgs a = a0;
@@ -542,6 +681,8 @@ static int gemm_slice_launch(const GemmArgs &a0, hipStream_t st) {
         a.B = std::min(per_launch, a0.B - off);
         a.ntiles = cdiv(a.B, 32);
         const int grid = a.ntiles < cus ? a.ntiles : cus;
+        GemmPrepArgs pp = p;
+        pp.readers = grid;
 #ifdef DPK_TIMELINE
         {
             static unsigned long long *dbg = nullptr;
@@ -551,16 +692,23 @@ static int gemm_slice_launch(const GemmArgs &a0, hipStream_t st) {
             if (f) { fprintf(f, "%p %d\n", (void *)dbg, grid); fclose(f); }
         }
 #endif
-        DPK_LAUNCH(kern, dim3(grid), dim3(kSliceThreads), lds, st, a);
+        DPK_LAUNCH(kern, dim3(grid), dim3(kSliceThreads), lds, st, a, pp);
         DPK_CHECK_LAUNCH("ratspn_gemm_slice_kernel");
     }
     if (ev1) (void)hipEventRecord(ev1, st);
     return DPK_OK;
 }
 
+// whether a launch of B samples can carry its own table check: one launch, at least np work-groups (each of the np table
+// work-groups' fingerprints is shared out over the work-groups g = twg mod np), np accumulators in the workspace
+bool gemm_slice_checks_inline(int64_t B, int np) {
+    const int cus = device_cus();
+    return np <= 16 && B <= (int64_t)64 * 32 * cus && cdiv(B, 32) >= np;
+}
+
 // The caller (ratspn_gemm_forward) has built / checked the tables and filled the argument block.
-int ratspn_gemm_slice_forward(const GemmArgs &a, int I, int S, int NT, hipStream_t st) {
-    if (I == 2 && S == 2 && NT == 2) return gemm_slice_launch<2, 2, 2>(a, st);
+int ratspn_gemm_slice_forward(const GemmArgs &a, const GemmPrepArgs &p, int I, int S, int NT, hipStream_t st) {
+    if (I == 2 && S == 2 && NT == 2) return gemm_slice_launch<2, 2, 2>(a, p, st);
     set_error("ratspn_gemm_slice: (channels=%d, sums=%d) not built", I, S);
     return DPK_EUNSUPPORTED;
 }

@@ -204,10 +204,11 @@ def test_in_launch_table_check_under_graph_replay():
     next replay (exact route), the one after it runs on the rebuilt tables -- no host involvement."""
     from deeprob.spn.models import GaussianRatSpn
     from oracle import ratspn_oracle as orc
-    for I, S in ((2, 2), (8, 8)):
+    # (9001 samples: the slice mapping, whose check is shared out over the eighth waves of its persistent work-groups)
+    for I, S, B in ((2, 2, 4096), (8, 8, 4096), (2, 2, 9001)):
         torch.manual_seed(13)
         model = GaussianRatSpn(784, rg_depth=2, rg_repetitions=8, rg_batch=I, rg_sum=S, random_state=42).cuda().eval()
-        x = torch.randn(4096, 784, generator=torch.Generator().manual_seed(14))
+        x = torch.randn(B, 784, generator=torch.Generator().manual_seed(14))
         xd = x.cuda()
         side = torch.cuda.Stream()
         g = torch.cuda.CUDAGraph()
