@@ -116,6 +116,7 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 constexpr int kBlock = 4;
 constexpr int kTableSlack = 16;  // neutral entries the software-pipelined readers may run into
 struct VerifyCtl;
+constexpr int kSliceVerifyBytes = 2304;   // ratspn_gemm_slice.hip SliceVerify, in the workspace behind the VerifyCtl
 struct RatWs {
     // structure tables (depend on mask / pad_mask only)
     int *fl1;     // [G*SP] LDS byte offset of the entry's row for 1 sample per lane
@@ -264,7 +265,7 @@ inline RatWs carve_ratspn_ws(void *base, int D, int R, int d, int I, int QB, int
         w.gbias_sl = (float *)take((int64_t)kGemmSmallWaves * 2 * w.g_nt * 16 * 4);
         w.gelig = (int *)take((int64_t)w.g_nt * 8 * 4);
         w.ghash = (unsigned long long *)take(((int64_t)w.g_nt * 8 + cdiv(reps * 2 * S + C, 4) + 4) * 8);
-        w.gctl = (struct VerifyCtl *)take(256);   // (+ the slice mapping's accumulators behind it)
+        w.gctl = (struct VerifyCtl *)take(64 + kSliceVerifyBytes);   // (+ the slice mapping's counters behind it)
         w.gup = nullptr;
         if (I == 8) w.gup = (uint16_t *)take((int64_t)reps * (S / 2 > 0 ? S / 2 : 1) * 1024 * 2);
     }

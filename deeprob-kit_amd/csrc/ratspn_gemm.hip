@@ -53,12 +53,14 @@ namespace dpk {
 template <int I>
 __global__ __launch_bounds__(kGemmPrepThreads) void ratspn_gemm_prep_kernel(const GemmPrepArgs a) {
     extern __shared__ int prep_dyn[];
-    if (a.mode == kPrepBuild && blockIdx.x == 0 && threadIdx.x == 0) {   // (no launch of this module is in flight: stream order)
-        a.ctl->word = 0ull;
-        a.ctl->readers = 0u;
-        // (the slice mapping's distributed check, ratspn_gemm_slice.hip SliceVerify: 16 accumulators + the arrival count)
+    if (a.mode == kPrepBuild && blockIdx.x == 0) {   // (no launch of this module is in flight: stream order)
+        if (threadIdx.x == 0) {
+            a.ctl->word = 0ull;
+            a.ctl->readers = 0u;
+        }
+        // (the slice mapping's check, ratspn_gemm_slice.hip SliceVerify: counters that only grow from here)
         unsigned long long *sv = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.ctl) + 64);
-        for (int i = 0; i < 18; ++i) sv[i] = 0ull;
+        for (int i = (int)threadIdx.x; i < kSliceVerifyBytes / 8; i += (int)blockDim.x) sv[i] = 0ull;
     }
     gemm_prep_block<I>(a, (int)blockIdx.x, prep_dyn);
 }
@@ -365,7 +367,7 @@ bool gemm_marginal_shape_ok(int D, int NT);
 bool gemm_slice_shape_ok(int D, int reps, int I, int S, int NT);
 int64_t gemm_slice_min_batch();
 int ratspn_gemm_slice_forward(const GemmArgs &a, const GemmPrepArgs &p, int I, int S, int NT, hipStream_t st);
-bool gemm_slice_checks_inline(int64_t B, int np);
+bool gemm_slice_checks_inline(int64_t B, int np, int d);
 // ratspn_gemm_wide.hip: 8-channel models, a wave per repetition
 bool gemm_wide_shape_ok(int D, int reps, int I, int S, int C);
 int ratspn_gemm_wide_forward(const GemmArgs &a, const GemmPrepArgs &p, int S, hipStream_t st);
@@ -429,7 +431,7 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
     const bool ring_inline = ring_vi && ring_plain && (int64_t)np <= std::min<int64_t>(cdiv(B, kGemmTile), device_cus());
     const bool verify_inline = inline_allowed && (flags & DPK_FLAG_PARAMS_VERIFY) && !(flags & DPK_FLAG_PARAMS_CACHED) &&
                                ((wide && gemm_wide_takes_tile32(B, D, reps, C, marginal, emitting)) || small || ring_inline ||
-                                (slice && gemm_slice_checks_inline(B, np)));
+                                (slice && gemm_slice_checks_inline(B, np, p.d)));
     if (verify_inline) {
         p.mode = kPrepInline;
         p.np = np;

@@ -49,7 +49,7 @@ constexpr int kSliceSlot = kSliceKW * 2048;      // bytes of a wave's x slot: [K
 
 __host__ __device__ constexpr int slice_part_bytes(int NT) { return NT * 4 * 1024; }   // a wave's partial accumulators
 __host__ __device__ constexpr int slice_lds_bytes(int NT, int w0_floats) {
-    return kSliceCompute * kSliceSlot + kSliceCompute * slice_part_bytes(NT) + kSliceCompute * 256 + 64 + 1024 + 0 * w0_floats;
+    return kSliceCompute * kSliceSlot + kSliceCompute * slice_part_bytes(NT) + kSliceCompute * 256 + 128 + 1024 + 0 * w0_floats;
 }
 
 #ifdef DPK_TIMELINE
@@ -131,46 +131,211 @@ __device__ __forceinline__ void slice_exact_raw(const GemmArgs &a, const float *
 
 // The in-launch check of the parameter tables (DPK_FLAG_PARAMS_VERIFY, ratspn_gemm_prep.h) for THIS mapping.  The small
 // kernels put np table work-groups in front of their tiles; here every work-group is a persistent model work-group that
-// owns its compute unit (13 more would start 13 of the 256 late by the check's 4-5 us).  Instead the eighth wave of EVERY
-// work-group, idle during the first K loop, fingerprints a 1 / nparts share of one table work-group's inputs (the
-// fingerprint is a sum of position-tagged words: any split gives the same sum), adds it to that table work-group's
-// accumulator in the workspace and takes an arrival ticket; the last arriver compares the np sums with the stored
-// fingerprints, zeroes the accumulators and publishes the launch's verdict in the VerifyCtl word the readers of the other
-// kernels use.  Every work-group reads it after its stream; a dirty launch discards what it computed, evaluates on the
-// table-free exact route, and its first np work-groups rebuild the tables in place.
-struct SliceVerify {               // behind the VerifyCtl in the workspace (zero between launches)
-    unsigned long long acc[16];
-    unsigned arrived, pad[3];
+// owns its compute unit (13 more would start 13 of the 256 late by the check's 4-5 us), and ANY work-group that reaches
+// its first barrier late ends the launch late.  So the check is the eighth wave's -- idle until the first barrier, ~8 us
+// away -- in the first np work-groups: wave 7 of work-group g fingerprints ALL of table work-group g's inputs (20 KB for a
+// repetition of the headline model: every load requested before the first is consumed, one round trip), compares with the
+// stored fingerprint and counts itself in; the last of the np publishes the verdict.  Every work-group reads the verdict
+// under a later K loop, or at its tail if it has no later block; a stale launch discards what it computed, evaluates on
+// the table-free exact route, and its first np work-groups rebuild the tables in place.
+//
+// Nothing is reset and nobody leaves last (the VerifyCtl protocol's 256 reader tickets on one address were 3-4 us at
+// the tail of every work-group here; 256 arrivals on one address, and a last arriver with two more round trips in front
+// of ITS first barrier, +6.5 us at every batch size -- measured, both).  All counters only grow.  Launches on a stream
+// follow one another, so the tickets launch k draws from shard s are exactly [T_s(k-1), T_s(k)), and T_s(k-1) is what
+// verdict[s] holds until launch k's last hasher replaces it with T_s(k) = T_s(k-1) + (this launch's work-groups in
+// shard s): a work-group with ticket n knows its launch's verdict is out as soon as verdict[s]'s total exceeds n.  The
+// same for the hashers' own count (`hashed`, its pre-launch value in `hashed_base`; mismatches are counted in its upper
+// half, and a carry out of the lower half after 2^32 arrivals reads as one spurious stale launch: a rebuild, same results).
+constexpr int kSliceShards = 16;
+struct SliceVerify {               // behind the VerifyCtl in the workspace (zeroed with the tables' first build)
+    unsigned long long verdict[kSliceShards];   // T_s << 1 | the launch found a stale table
+    unsigned long long hashed, hashed_base;     // arrivals of the hashing waves | mismatches << 32
+    unsigned long long pad[14];
+    struct { unsigned long long n, pad[15]; } tickets[kSliceShards];   // (an address per shard, 128 bytes apart)
 };
+static_assert(sizeof(SliceVerify) == kSliceVerifyBytes, "the workspace block behind the VerifyCtl (common.h)");
 __device__ __forceinline__ SliceVerify *slice_verify_of(VerifyCtl *c) {
     return reinterpret_cast<SliceVerify *>(reinterpret_cast<char *>(c) + 64);
 }
+// A thread's share (tid of nthreads) of the fingerprint of `nwords` 4-byte words at p -- the value fp_range_n gives -- in
+// two halves, so that the loads of SEVERAL ranges are all requested before any is consumed (fp_range_n's loops are one
+// dependent round trip per trip).  Ranges of more than kFpK * nthreads words: fp_range_n (the host does not route those here).
+constexpr int kFpK = 32;
+template <int K>
+__device__ __forceinline__ void fpw_issue(const unsigned *p, int nwords, int tid, int nthreads, unsigned (&w)[K]) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int e = tid + nthreads * k;
+        w[k] = p[e < nwords ? e : 0];
+    }
+}
+template <int K>
+__device__ __forceinline__ unsigned long long fpw_sum(const unsigned (&w)[K], int nwords, unsigned tag, int tid, int nthreads) {
+    unsigned long long h = 0ull;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int e = tid + nthreads * k;
+        if (e < nwords) h += fp_word(w[k], (unsigned)e * 8u + tag);
+    }
+    return h;
+}
+// the same with 16-byte loads (nwords a multiple of 4, p 16-byte aligned): a quarter of the requests -- the eighth wave's
+// requests take turns with the seven slice waves' 1 KB table and evidence requests on the compute unit's one request path
+typedef unsigned fp_u4 __attribute__((ext_vector_type(4)));
+template <int K>
+__device__ __forceinline__ void fpw_issue4(const unsigned *p, int nwords, int tid, int nthreads, fp_u4 (&w)[K]) {
+    const fp_u4 *p4 = (const fp_u4 *)p;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int e = tid + nthreads * k;
+        w[k] = p4[4 * e < nwords ? e : 0];
+    }
+}
+template <int K>
+__device__ __forceinline__ unsigned long long fpw_sum4(const fp_u4 (&w)[K], int nwords, unsigned tag, int tid, int nthreads) {
+    unsigned long long h = 0ull;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int e = 4 * (tid + nthreads * k);
+        if (e < nwords)
+            h += (fp_word(w[k].x, (unsigned)e * 8u + tag) + fp_word(w[k].y, (unsigned)(e + 1) * 8u + tag)) +
+                 (fp_word(w[k].z, (unsigned)(e + 2) * 8u + tag) + fp_word(w[k].w, (unsigned)(e + 3) * 8u + tag));
+    }
+    return h;
+}
+// gemm_prep_hash_share's value for table work-group blk, all loads up front (word-aligned ranges: what the tables' inputs are)
 template <int I>
-__device__ __forceinline__ void slice_verify_share(const GemmPrepArgs &pa, int lane) {
+__device__ __forceinline__ unsigned long long slice_hash_share(const GemmPrepArgs &a, int blk, int tid, int nthreads) {
+    constexpr int RPT = 8 / I;
+    const int nrb = a.NT * RPT, d = a.d;
+    if (blk < nrb) {
+        if (blk >= a.reps) return 0ull;
+        const int rho = blk;
+        const int nm = 8 * d, npd = a.pad != nullptr ? d : 0, nl = 4 * I * d;
+        const unsigned *pm = (const unsigned *)(a.mask + (int64_t)rho * 4 * d);
+        const unsigned *pl = (const unsigned *)(a.loc + (int64_t)rho * 4 * I * d);
+        const unsigned *ps = (const unsigned *)(a.scale + (int64_t)rho * 4 * I * d);
+        const unsigned *pp = a.pad != nullptr ? (const unsigned *)(a.pad + (int64_t)rho * 4 * d) : pm;
+        if (nl > kFpK * nthreads || nm > kFpK * nthreads || npd > 8 * nthreads || ((uintptr_t)pp & 3) != 0 ||
+            (((uintptr_t)pm | (uintptr_t)pl | (uintptr_t)ps) & 15) != 0)
+            return gemm_prep_hash_share<I>(a, blk, tid, nthreads);   // (long, byte-wise or unaligned ranges: the general form)
+        fp_u4 wm[kFpK / 4], wl[kFpK / 4], ws[kFpK / 4];
+        unsigned wp[8];
+        fpw_issue4(pm, nm, tid, nthreads, wm);
+        fpw_issue4(pl, nl, tid, nthreads, wl);
+        fpw_issue4(ps, nl, tid, nthreads, ws);
+        fpw_issue(pp, npd > 0 ? npd : 1, tid, nthreads, wp);
+        return (fpw_sum4(wm, nm, 1, tid, nthreads) + fpw_sum(wp, npd, 2, tid, nthreads)) +
+               (fpw_sum4(wl, nl, 3, tid, nthreads) + fpw_sum4(ws, nl, 4, tid, nthreads));
+    }
+    constexpr int rpb = kGemmPrepThreads / 64;
+    unsigned long long h = 0ull;
+    unsigned wv[rpb];
+    bool in[rpb];
+    unsigned tg[rpb];
+#pragma unroll
+    for (int r = 0; r < rpb; ++r) {   // (rows of up to nthreads weights: one load per thread and row, all in flight together)
+        const int row = (blk - nrb) * rpb + r;
+        int rr = row, m = -1;
+#pragma unroll
+        for (int mm = 0; mm < 3; ++mm) {
+            if (m < 0) {
+                if (rr < a.rows[mm]) m = mm;
+                else rr -= a.rows[mm];
+            }
+        }
+        const int n = m >= 0 ? a.n[m] : 0;
+        if (n > nthreads) return gemm_prep_hash_share<I>(a, blk, tid, nthreads);   // (wave-uniform: the general form)
+        in[r] = tid < n;
+        const float *base = m >= 0 ? a.w[m] + (int64_t)rr * n : a.w[0];
+        wv[r] = __float_as_uint(base[in[r] ? tid : 0]);
+        tg[r] = (unsigned)tid * 8u + (5u + 8192u * (unsigned)row);
+    }
+#pragma unroll
+    for (int r = 0; r < rpb; ++r)
+        if (in[r]) h += fp_word(wv[r], tg[r]);
+    return h;
+}
+// ctl_l (LDS, this work-group, written and read by the eighth wave's lane 0 only until the tail's barrier):
+// [0] = 2 | stale once the verdict is known, [2..3] the work-group's ticket
+template <int I>
+__device__ __forceinline__ void slice_verify_share(const GemmPrepArgs &pa, int lane, lunsigned *ctl_l) {
     const int np = pa.np, G = (int)gridDim.x, g = (int)blockIdx.x;
-    const int twg = g % np, part = g / np, nparts = (G - 1 - twg) / np + 1;
-    unsigned long long h = gemm_prep_hash_share<I>(pa, twg, part * 64 + lane, nparts * 64);
+    SliceVerify *sv = slice_verify_of(pa.ctl);
+    const int shard = g & (kSliceShards - 1);
+    if (g >= np) {   // (wave-uniform) not a hashing work-group: the ticket, nothing else
+        if (lane == 0) {
+            const unsigned long long t = __hip_atomic_fetch_add(&sv->tickets[shard].n, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ctl_l[0] = 0u;
+            ctl_l[2] = (unsigned)t;
+            ctl_l[3] = (unsigned)(t >> 32);
+        }
+        return;
+    }
+    // (what the last hasher needs, requested with the inputs: the shards' totals before this launch, lane s = shard s)
+    const unsigned long long vold = __hip_atomic_load(&sv->verdict[lane & (kSliceShards - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hb = __hip_atomic_load(&sv->hashed_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long stored = pa.hash[g];
+    unsigned long long h = slice_hash_share<I>(pa, g, lane, 64);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) h += (unsigned long long)__shfl_xor((long long)h, o, 64);
+    const bool mismatch = kPrepHashBase + (unsigned long long)g + h != stored;
+    unsigned long long t = 0ull, r = 0ull;
     if (lane == 0) {
-        SliceVerify *sv = slice_verify_of(pa.ctl);
-        // (the share is PERFORMED before the arrival is: the returned value is waited for)
-        const unsigned long long before = __hip_atomic_fetch_add(&sv->acc[twg], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("" ::"v"(before) : "memory");
-        const unsigned n = __hip_atomic_fetch_add(&sv->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (n == (unsigned)(G - 1)) {
-            bool dirty = false;
-            for (int t = 0; t < np; ++t) {
-                const unsigned long long sum = __hip_atomic_load(&sv->acc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                dirty = dirty || (kPrepHashBase + (unsigned long long)t + sum != pa.hash[t]);
-                __hip_atomic_store(&sv->acc[t], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __hip_atomic_store(&sv->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&pa.ctl->word, (unsigned long long)np + (dirty ? (1ull << 32) : 0ull), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        }
+        // (requests return in order: the ticket is drawn here, behind the inputs, not in front of them)
+        t = __hip_atomic_fetch_add(&sv->tickets[shard].n, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r = __hip_atomic_fetch_add(&sv->hashed, 1ull + (mismatch ? (1ull << 32) : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ctl_l[0] = 0u;
+        ctl_l[2] = (unsigned)t;
+        ctl_l[3] = (unsigned)(t >> 32);
     }
+    const unsigned rlo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)r);
+    const unsigned rhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(r >> 32));
+    const unsigned hblo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)hb);
+    const unsigned hbhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(hb >> 32));
+    // (a hasher that read the NEW hashed_base is not the last one: its count is below that total)
+    if (rlo - hblo != (unsigned)(np - 1)) return;
+    const unsigned mism_now = rhi + (mismatch ? 1u : 0u);
+    const bool stale = mism_now != hbhi;
+    if (lane == 0)
+        __hip_atomic_store(&sv->hashed_base, ((unsigned long long)mism_now << 32) | (unsigned long long)(rlo + 1u), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    // (hashed_base is read by the NEXT launch's hashers only: no wait between it and the verdicts)
+    if (lane < kSliceShards) {
+        const int cnt = lane < G ? (G - 1 - lane) / kSliceShards + 1 : 0;
+        __hip_atomic_store(&sv->verdict[lane], (((vold >> 1) + (unsigned long long)cnt) << 1) | (stale ? 1ull : 0ull), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) ctl_l[0] = 2u | (stale ? 1u : 0u);
+}
+// one look at the verdict (the eighth wave's lane 0): requested in front of a block's upper layers, looked at behind them
+__device__ __forceinline__ unsigned long long slice_verdict_request(const GemmPrepArgs &pa) {
+    const int shard = (int)blockIdx.x & (kSliceShards - 1);
+    return __hip_atomic_load(&slice_verify_of(pa.ctl)->verdict[shard], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void slice_verdict_peek(unsigned long long v, lunsigned *ctl_l) {
+    if ((ctl_l[0] & 2u) != 0u) return;
+    const unsigned long long n = ((unsigned long long)ctl_l[3] << 32) | ctl_l[2];
+    if ((v >> 1) > n) ctl_l[0] = 2u | (unsigned)(v & 1ull);
+}
+// ... and the wait for it where the work-group cannot go on without (stale also if nothing came for 1 s)
+__device__ __forceinline__ void slice_verdict_wait(const GemmPrepArgs &pa, lunsigned *ctl_l) {
+    if ((ctl_l[0] & 2u) != 0u) return;
+    const int shard = (int)blockIdx.x & (kSliceShards - 1);
+    const unsigned long long *vp = &slice_verify_of(pa.ctl)->verdict[shard];
+    const unsigned long long n = ((unsigned long long)ctl_l[3] << 32) | ctl_l[2];
+    unsigned long long v = __hip_atomic_load(vp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool timed_out = false;
+    if ((v >> 1) <= n) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+        do {
+            __builtin_amdgcn_s_sleep(8);
+            v = __hip_atomic_load(vp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            timed_out = __builtin_amdgcn_s_memrealtime() - t0 > 100000000ull;
+        } while ((v >> 1) <= n && !timed_out);
+    }
+    ctl_l[0] = 2u | ((v & 1ull) != 0ull || timed_out ? 1u : 0u);
 }
 
 template <int I, int S, int NT>
@@ -189,7 +354,8 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
     lchar *part_l = smem + kSliceCompute * kSliceSlot;                        // [7 slices][32 samples][16 units of 16 bytes]
     lfloat *q_l = (lfloat *)(part_l + kSliceCompute * PW);                    // [7][64] sums of squares
     lunsigned *flag_l = (lunsigned *)(q_l + kSliceCompute * 64);              // [2][8] a wave's verdict on its 4 samples of a block
-    lfloat *c2_l = (lfloat *)(flag_l + 16);                                   // [16 slots][16]: sum weights, leaf constants, root weights
+    lunsigned *ctl_l = flag_l + 16;                                           // the table check: slice_verify_share
+    lfloat *c2_l = (lfloat *)(flag_l + 32);                                   // [16 slots][16]: sum weights, leaf constants, root weights
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -202,6 +368,12 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
     const int first = (int)blockIdx.x, stride = (int)gridDim.x;
     const bool slicer = wave < kSliceCompute;                                 // (the eighth wave only joins phase 2)
     SL_STAMP(15, 0);
+    // (the eighth wave, idle until the first barrier: the launch's table check, before anything of the stream is live)
+    if (!slicer && pa.np > 0) {
+        __builtin_amdgcn_s_setprio(3);   // (its requests in front of the same SIMD's slice wave's: the chain below is three round trips)
+        slice_verify_share<I>(pa, lane, ctl_l);
+        __builtin_amdgcn_s_setprio(0);
+    }
 
     // ---- phase-1 roles (slice waves): MFMA lane (sample s, half h) ----------------------------------------------------
     const int k0 = wave * KW;
@@ -380,8 +552,6 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
             issue_kk(nxt, nnv, 4);
         }
     }
-    // (the eighth wave, idle during the first K loop: its share of the launch's table check)
-    if (!slicer && pa.np > 0) slice_verify_share<I>(pa, lane);
     SL_STAMP(15, 1);
     [[maybe_unused]] int row = 0;
     int it = 0;
@@ -393,6 +563,9 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
         // everyone has read the previous block's partials (and published its verdict on it)
         gemm_lds_barrier();
         SL_STAMP(row, 1);
+        // (the eighth wave asks for the launch's verdict here and looks at the answer behind the upper layers)
+        unsigned long long vpeek = 0ull;
+        if (!slicer && pa.np > 0 && lane == 0) vpeek = slice_verdict_request(pa);
         if (slicer) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -574,20 +747,15 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
                 issue_kk(nxt, nnv, 4);
             }
         }
+        if (!slicer && pa.np > 0 && lane == 0) slice_verdict_peek(vpeek, ctl_l);
         SL_STAMP(row, 4);
         ++row;
     }
     SL_STAMP(15, 2);
     // ---- the launch's verdict on its tables, the last block's verdict, then what left the fast path ------------------------
-    lunsigned *dirty_l = flag_l + 16 - 1;            // (the last word of the flag block: free)
-    if (pa.np > 0 && tid == 0) {
-        unsigned ticket;
-        const bool dirty = vi_wait(pa.ctl, pa.np, ticket);
-        vi_done(pa.ctl, ticket, pa.readers);
-        *dirty_l = dirty ? 1u : 0u;
-    }
+    if (pa.np > 0 && !slicer && lane == 0) slice_verdict_wait(pa, ctl_l);
     __syncthreads();
-    const bool tables_stale = pa.np > 0 && *dirty_l != 0u;
+    const bool tables_stale = pa.np > 0 && (ctl_l[0] & 1u) != 0u;
     if (it > 0) {
         const lunsigned *fl = flag_l + ((it - 1) & 1) * 8;
         const unsigned any_bad = (fl[0] | fl[1]) | (fl[2] | fl[3]) | (fl[4] | fl[5]) | (fl[6] | fl[7]);
@@ -699,11 +867,11 @@ static int gemm_slice_launch(const GemmArgs &a0, const GemmPrepArgs &p, hipStrea
     return DPK_OK;
 }
 
-// whether a launch of B samples can carry its own table check: one launch, at least np work-groups (each of the np table
-// work-groups' fingerprints is shared out over the work-groups g = twg mod np), np accumulators in the workspace
-bool gemm_slice_checks_inline(int64_t B, int np) {
+// whether a launch of B samples can carry its own table check: one launch, at least np work-groups (the eighth wave of
+// work-group g fingerprints table work-group g's inputs: ranges of at most kFpK x 64 words -- d <= 256 features per region)
+bool gemm_slice_checks_inline(int64_t B, int np, int d) {
     const int cus = device_cus();
-    return np <= 16 && B <= (int64_t)64 * 32 * cus && cdiv(B, 32) >= np;
+    return B <= (int64_t)64 * 32 * cus && cdiv(B, 32) >= np && 8 * d <= kFpK * 64;
 }
 
 // The caller (ratspn_gemm_forward) has built / checked the tables and filled the argument block.

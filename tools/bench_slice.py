@@ -6,7 +6,7 @@ Every batch size cycles through enough resident inputs to exceed the 256 MiB Inf
 streams at 6.7-6.9 TB/s through these kernels: never benchmark this path on one buffer).  Prints host-clock step times of
 the frozen-model call (ops.FusedForwardPlan, static_params) and the max LL difference against the ring mapping; run it
 under `rocprofv3 --kernel-trace` and feed the trace to tools/trace_summary.py for kernel durations by grid size.
-usage: python tools/bench_slice.py [batch ...] [--steps K]"""
+usage: python tools/bench_slice.py [batch ...] [--steps K] [--default-mode]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, 'deeprob-kit_amd'), ROOT]
@@ -17,6 +17,7 @@ from deeprob.spn.models import GaussianRatSpn
 lib = load_library()
 args = sys.argv[1:]
 K = int(args[args.index('--steps') + 1]) if '--steps' in args else 200
+STATIC = '--default-mode' not in args   # (--default-mode: the launches check their parameter tables, as model(x) does)
 batches = [int(a) for a in args if a.isdigit() and (args.index(a) == 0 or args[args.index(a) - 1] != '--steps')] or \
     [4096, 8192, 16384, 32768, 65536]
 torch.manual_seed(0)
@@ -27,12 +28,12 @@ for B in batches:
     gen = torch.Generator('cuda').manual_seed(B)
     xs = [torch.randn(B, 784, device='cuda', generator=gen) for _ in range(min(nbuf, 64))]
     ref = None
-    for mapping in ('ring', 'small', 'slice'):
+    for mapping in (('ring', 'small', 'slice') if '--only-slice' not in args else ('slice',)):
         lib.dpk_ratspn_small_batch_max(0 if mapping == 'ring' else (1 << 40 if mapping == 'small' else -1))
         lib.dpk_ratspn_slice_batch_min(0 if mapping == 'slice' else -1)
         with torch.no_grad():
             out0 = m(xs[0]).clone()
-            plans = [m.fused_plan(x, static_params=True) for x in xs]
+            plans = [m.fused_plan(x, static_params=STATIC) for x in xs]
             for p in plans:
                 p.run()
             torch.cuda.synchronize()
