@@ -235,6 +235,41 @@ def test_in_launch_table_check_under_graph_replay():
             assert torch.equal(second, out)
 
 
+@pytest.mark.parametrize('what', ['loc', 'sum', 'root', 'scale'])
+def test_in_launch_table_check_slice_mapping_across_grids(what):
+    """Round 5: the persistent 32-sample-block kernel (csrc/ratspn_gemm_slice.hip, 7681 samples and up) checks its tables in
+    its own launch on counters that only grow: launches with different grids (241 .. 256 work-groups), a small-batch launch
+    (the other protocol, same workspace) and a 65536-sample launch in between, one parameter kind written at a time."""
+    from deeprob.spn.models import GaussianRatSpn
+    from oracle import ratspn_oracle as orc
+    torch.manual_seed(21)
+    model = GaussianRatSpn(784, rg_depth=2, rg_repetitions=8, random_state=42).cuda().eval()
+    gen = torch.Generator().manual_seed(22)
+    sizes = (7700, 9001, 300, 65536, 8000)
+    xs = {B: torch.randn(B, 784, generator=gen) for B in sizes}
+    xd = {B: v.cuda() for B, v in xs.items()}
+    rows = {B: torch.randint(0, B, (96,), generator=gen) for B in sizes}
+    with torch.no_grad():
+        for B in sizes:
+            model(xd[B])
+        for step in range(3):
+            if what == 'loc':
+                model.base_layer.loc.data.add_(0.03 * (step + 1))
+            elif what == 'sum':
+                for layer in model.layers:
+                    if hasattr(layer, 'weight'):
+                        layer.weight.data.add_(torch.randn_like(layer.weight))
+            elif what == 'root':
+                model.root_layer.weight.data.add_(torch.randn_like(model.root_layer.weight))
+            else:
+                model.base_layer.scale.data.mul_(1.0 + 0.1 * torch.rand_like(model.base_layer.scale))
+            sd = _state(model)
+            order = sizes if step % 2 == 0 else sizes[::-1]
+            for B in order + order[:2]:
+                got = model(xd[B])[rows[B].cuda()].cpu().numpy()
+                assert rel_err(got, orc.ratspn_forward(sd, xs[B][rows[B]]).numpy()) <= TOL, (step, B)
+
+
 def test_in_launch_table_check_more_work_groups_than_the_chip_holds():
     """16384 samples = 512 model work-groups behind the table work-groups, two rounds of the chip: a work-group only ever
     waits for table work-groups, which are dispatched first."""
