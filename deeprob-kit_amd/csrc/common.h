@@ -116,6 +116,7 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 constexpr int kBlock = 4;
 constexpr int kTableSlack = 16;  // neutral entries the software-pipelined readers may run into
 struct VerifyCtl;
+constexpr int kSliceTabBytes = 512;       // compact mean table: bytes per (K-step, column tile) -- [hi, lo][lane half][repetition, channel][8 variables]
 constexpr int kSliceVerifyBytes = 2304;   // ratspn_gemm_slice.hip SliceVerify, in the workspace behind the VerifyCtl
 struct RatWs {
     // structure tables (depend on mask / pad_mask only)
@@ -148,6 +149,8 @@ struct RatWs {
     unsigned long long *ghash;   // [NT*RPT] fingerprint of the parameter bytes each repetition's tables were built from,
                                  // then one per softmax-row work-group of the table build (ratspn_gemm_prep.h)
     struct VerifyCtl *gctl;      // the verdict word of a launch that checks its tables itself (ratspn_gemm_prep.h)
+    uint16_t *gs_tab;            // two-channel models: the mean table without its structural zeros (ratspn_gemm_slice.hip)
+    unsigned char *gs_mask;      // ... and which of a lane's entries its column keeps, per slice wave
     uint16_t *gup;               // 8-channel models: MFMA fragments of the first sum layer (ratspn_gemm_prep.h: wide_upfrag_*)
     void *lg;          // tables of the leaf-only MFMA kernel (leaf_gemm_ws_bytes), null when the shape is outside it
     int g_nt, g_nksp;  // column tiles of 32, K-steps of 16 features (padded to whole chunks); 0 = not built
@@ -267,6 +270,12 @@ inline RatWs carve_ratspn_ws(void *base, int D, int R, int d, int I, int QB, int
         w.ghash = (unsigned long long *)take(((int64_t)w.g_nt * 8 + cdiv(reps * 2 * S + C, 4) + 4) * 8);
         w.gctl = (struct VerifyCtl *)take(64 + kSliceVerifyBytes);   // (+ the slice mapping's counters behind it)
         w.gup = nullptr;
+        w.gs_tab = nullptr;
+        w.gs_mask = nullptr;
+        if (I == 2) {
+            w.gs_tab = (uint16_t *)take((int64_t)w.g_nksp * w.g_nt * kSliceTabBytes);
+            w.gs_mask = (unsigned char *)take((int64_t)cdiv(w.g_nksp, 7) * 64 * 16);
+        }
         if (I == 8) w.gup = (uint16_t *)take((int64_t)reps * (S / 2 > 0 ? S / 2 : 1) * 1024 * 2);
     }
     w.lg = nullptr;

@@ -416,6 +416,7 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
     p.w[0] = sum_weight0; p.W[0] = w.w[0]; p.LW[0] = w.lw[0]; p.rows[0] = reps * 2 * S; p.n[0] = I * I;
     p.w[1] = root_weight; p.W[1] = w.w[2]; p.LW[1] = w.lw[2]; p.rows[1] = C; p.n[1] = reps * S * S;
     p.hash = w.ghash; p.ctl = w.gctl;
+    p.stab = w.gs_tab; p.smask = w.gs_mask;
     { static const int pab = [] { const char *e = getenv("DPK_PREP_ABLATE"); return e ? atoi(e) : 0; }(); p.ablate = pab; }
     p.upfrag = (I == 8 && S >= 2) ? w.gup : nullptr; p.up_S = S;
     const int np = gemm_prep_blocks(NT, I, p.rows[0] + p.rows[1], kGemmPrepThreads);

@@ -61,6 +61,8 @@ struct GemmPrepArgs {
     int np;                     // table work-groups of the launch
     int readers;                // work-groups that read the verdict (np + model work-groups)
     int ablate;                 // measurement only (DPK_PREP_ABLATE): 1 stop after the verdict, 2 no fragments, 4 no constants
+    uint16_t *stab;             // two-channel models: the compact mean table of the slice mapping (slice_tab_*), else null
+    unsigned char *smask;       // ... and the keep-masks of its lanes
 };
 
 // table work-groups a launch needs: one per repetition slot + one per (threads / 64) softmax rows
@@ -449,6 +451,44 @@ __device__ __forceinline__ void gemm_prep_block(const GemmPrepArgs &a, int blk, 
         *reinterpret_cast<half8 *>(a.mtab + o + 512) = ml;
         *reinterpret_cast<half8 *>(a.ctab + o) = ch;
         *reinterpret_cast<half8 *>(a.ctab + o + 512) = cl;
+    }
+    // The slice mapping's compact table (ratspn_gemm_slice.hip): three quarters of a repetition's fragment entries are
+    // structural zeros -- variable f belongs to ONE of the repetition's four regions -- so entry (K-step, lane half,
+    // channel) holds f's mean in whichever region that is, and a lane's keep-mask says which of its 8 variables belong to
+    // its own column's region.  A quarter of the bytes and of the requests on the compute unit's request path.
+    if (a.stab != nullptr && !(a.ablate & 2)) {
+        for (int e = tid; e < a.NKSP * 2 * I; e += nth) {
+            const int k = e % I, hg = (e / I) & 1, ks = e / (2 * I);
+            half8 mh, ml;
+#pragma unroll
+            for (int el = 0; el < 8; ++el) {
+                const int f = ks * 16 + hg * 8 + el;
+                const int pp = (real && f < D) ? posrow[f] : -1;
+                const float mu = pp >= 0 ? locs[((pp >> PSH) * I + k) * d + (pp & ((1 << PSH) - 1))] : 0.f;
+                _Float16 hi, lo;
+                split_f16(mu, hi, lo);
+                mh[el] = hi; ml[el] = lo;
+            }
+            const int64_t o = ((int64_t)ks * a.NT + t) * (kSliceTabBytes / 2) + (hg * 4 * I + ap * I + k) * 8;
+            *reinterpret_cast<half8 *>(a.stab + o) = mh;
+            *reinterpret_cast<half8 *>(a.stab + o + kSliceTabBytes / 4) = ml;
+        }
+        // keep-masks [slice wave][lane][K-step of the wave (8 slots)][tile (2)]: bit el = variable el of the lane's 8
+        const int nwv = a.NKSP / 7;
+        for (int e = tid; e < nwv * 7 * 2 * 4 * I; e += nth) {
+            const int k = e % I, q = (e / I) & 3, hg = (e / (4 * I)) & 1, kk = (e / (8 * I)) % 7, wv = e / (56 * I);
+            const int hh = q >> 1, qq = q & 1;
+            const int u = (ap * 2 + qq) * I + k;
+            const int row = (u & 3) + 8 * (u >> 2) + 4 * hh;
+            unsigned bits = 0u;
+#pragma unroll
+            for (int el = 0; el < 8; ++el) {
+                const int f = (wv * 7 + kk) * 16 + hg * 8 + el;
+                const int pp = (real && f < D) ? posrow[f] : -1;
+                if ((pp >> PSH) == q) bits |= 1u << el;
+            }
+            a.smask[((wv * 64 + hg * 32 + row) * 8 + kk) * 2 + (t & 1)] = (unsigned char)bits;
+        }
     }
     // - sum_f (mu^2/2 + log sqrt(2 pi)) over the variables [f0, f1) that belong to column (q, k)'s region, ascending f (fixed
     // summation order: launches must agree bit for bit); the positions of 16 variables are read together

@@ -414,29 +414,50 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
         for (int kk = 0; kk < KW; ++kk) issue_kk(xt, nvalid, kk);
     };
     const int nit = first < nblk ? (nblk - first + stride - 1) / stride : 0;   // blocks of this work-group (>= 1)
-    if (slicer && nit > 0) issue(first);
-    // The slice of the mean table: registers for the whole launch, loaded by asm statements that hipcc does not count, K-step
-    // by K-step INSIDE the first block's K loop (below).  A wave cannot compute before it has issued its requests, and a
-    // compute unit's request path takes ~37 cycles per 1 KB instruction: 14 x requests + 28 table loads per wave up front
-    // were 11k cycles before the first product; now K-step kk multiplies while K-step kk + 1 of the table and the second
-    // block's first K-steps are being requested.
+    // The slice of the mean table: registers for the whole launch.  Its 28 KB per wave were 28 requests of 1 KB on the compute
+    // unit's request path (196 per compute unit, 37 cycles each, in front of the first product -- and 50 MB out of the
+    // L2s per launch); three quarters of the entries are structural zeros (a variable belongs to ONE region of a
+    // repetition), so the table travels without them (ratspn_gemm_prep.h: stab, 7 KB per wave + 1 KB of keep-masks) by
+    // LDS-DMA into the wave's own partial-accumulator block, idle until the first barrier, and is expanded from there:
+    // ds_read_b128 (four lanes -- the four regions of a (repetition, channel) -- share an address: broadcast), then an AND
+    // with the lane's keep-mask.  All of it while the first block's x is on its way from HBM.
+    // (measured with a quarter of the table requests and garbage values: -1.5 / -2.5 / -4.5 / -4.3 us at 8192 / 16384 /
+    // 32768 / 65536 samples)
+    lchar *tl = part_l + (slicer ? wave : 0) * PW;
+    static_assert(PW >= KW * NT * kSliceTabBytes + 1024, "compact table + keep-masks in the wave's partial block");
+    if (slicer && nit > 0) {
+        // (the table in front of x: interleaved K-step by K-step -- the first product then needs the first four requests
+        // only -- measured the same; x first puts the table behind x's HBM latency: requests complete in order)
+        const unsigned tl_u = (unsigned)(uintptr_t)tl;
+        glds16<false>((unsigned)lane * 16u, (gcchar_p)pa.smask + wave * 1024, tl_u + KW * NT * kSliceTabBytes);
+#pragma unroll
+        for (int kk = 0; kk < KW; ++kk)
+            glds16<false>((unsigned)lane * 16u, (gcchar_p)pa.stab + (int64_t)(k0 + kk) * NT * kSliceTabBytes,
+                          tl_u + kk * NT * kSliceTabBytes);
+        issue(first);
+    }
     half8 mh[KW][NT], ml[KW][NT];
-    const unsigned lane16 = (unsigned)lane * 16u;
-#define DPK_SL_TABLE_LOAD(kk)                                                                                                  \
+    typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const gu32x4 lu4;
+    typedef __attribute__((address_space(3))) const unsigned short lushort;
+#define DPK_SL_TABLE_EXPAND(kk)                                                                                                \
     do {                                                                                                                      \
+        const unsigned bits = *(lushort *)(tl + KW * NT * kSliceTabBytes + lane * 16 + (kk) * 2);                             \
+        const lchar *te = tl + (kk) * NT * kSliceTabBytes + ((lane >> 5) * 8 + ((lane >> 3) & 3) * 2 + (lane & 1)) * 16;      \
         _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                                      \
-            const uint64_t tb = (uint64_t)(uintptr_t)a.mtab + (uint64_t)((k0 + (kk)) * NT + t) * 2048u;                       \
-            const uint64_t tbs = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(tb >> 32)) << 32) |      \
-                                 (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tb);                      \
-            asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(mh[kk][t]) : "v"(lane16), "s"(tbs) : "memory");   \
-            asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(ml[kk][t]) : "v"(lane16), "s"(tbs) : "memory"); \
+            gu32x4 hi = *(lu4 *)(te + t * kSliceTabBytes);                                                                    \
+            gu32x4 lo = *(lu4 *)(te + t * kSliceTabBytes + kSliceTabBytes / 2);                                               \
+            _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                                \
+                const int e0 = __builtin_amdgcn_sbfe((int)bits, t * 8 + 2 * jj, 1);                                           \
+                const int e1 = __builtin_amdgcn_sbfe((int)bits, t * 8 + 2 * jj + 1, 1);                                       \
+                const unsigned keep = ((unsigned)e0 & 0xFFFFu) | ((unsigned)e1 & 0xFFFF0000u);                                \
+                hi[jj] &= keep;                                                                                               \
+                lo[jj] &= keep;                                                                                               \
+            }                                                                                                                 \
+            mh[kk][t] = __builtin_bit_cast(half8, hi);                                                                        \
+            ml[kk][t] = __builtin_bit_cast(half8, lo);                                                                        \
         }                                                                                                                     \
     } while (0)
-    if (slicer) {
-        DPK_SL_TABLE_LOAD(0);
-        DPK_SL_TABLE_LOAD(1);
-        DPK_SL_TABLE_LOAD(2);
-    }
     // ---- phase-2 roles (all eight waves): 16 consecutive lanes own a sample, slot j = 2 rho + p ------------------------
     const int sl = lane >> 4, j = lane & 15;
     const int rho = j >> 1, p = j & 1;
@@ -497,13 +518,11 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
         _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(mh[kk][t], xl, acc[t], 0, 0, 0); \
         _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ml[kk][t], xh, acc[t], 0, 0, 0); \
     } while (0)
-    // ---- the work-group's first block: its K loop also brings the table in ---------------------------------------------------
-    // Request queue (in order): x of block 0 (14), table K-steps 0..2 (12) | per step kk: x of block 1, K-step kk (2, kk <= 2),
-    // table K-step kk + 3 (4, kk < 4) -- three steps ahead: one step ahead made the loop a chain of L2 round trips (19.6k
-    // cycles).  "All but the youngest N have completed" with N = what was issued after the awaited request: the table's
-    // K-step kk at step kk: 14, 16, 18, 16, 10, 4, 0 (12, 12, 12, 12, 8, 4, 0 when there is no second block) -- it also
-    // covers this block's x, requested before it.  The wait names the K-step's x operand: the products depend on it, so hipcc
-    // cannot schedule them above the wait.  ScratchSize must stay 0: a spill of a fragment in flight would store garbage.
+    // ---- the work-group's first block ------------------------------------------------------------------------------------------
+    // Request queue (in order): keep-masks (1), table K-steps (7), x of block 0 (14) | per step kk <= 2: x of block 1, K-step kk
+    // (2).  "All but the youngest N have completed" with N = what was issued after the awaited request: the table: 14; x
+    // K-step 0: 12; x K-step kk + 1 at step kk (it is copied a step ahead): 12, 12, 12, 10, 8, 6 (10, 8, 6, 4, 2, 0 when there
+    // is no second block).  K-step kk + 1 of the table is expanded under K-step kk's products.
     if (slicer && nit > 0) {
         const bool more = nit > 1;
         const int64_t nb0 = (int64_t)(first + stride) * 32;
@@ -515,37 +534,40 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
         gf32x2 tq2 = {0.f, 0.f};
         gf32x4 xa0, xa1, xb0, xb1;
-        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // K-step 0 of x (12 younger x requests + 12 table loads)
+        asm volatile("s_waitcnt vmcnt(14)" ::: "memory");   // the table and the masks (x of block 0 is younger)
+        DPK_SL_TABLE_EXPAND(0);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // K-step 0 of x
         xa0 = *(lf4 *)(xr0);
         xa1 = *(lf4 *)(xr1);
 #define DPK_SL_FIRST_STEP(kk, NW_MORE, NW_LAST)                                                                               \
     do {                                                                                                                      \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                    \
         if (more && (kk) <= 2) issue_kk(nxt, nnv, kk);                                                                        \
-        if ((kk) + 3 < KW) DPK_SL_TABLE_LOAD(((kk) + 3 < KW ? (kk) + 3 : 0));                                                 \
-        if (more) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(xa0), "+v"(xa1) : "n"(NW_MORE) : "memory");                       \
-        else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(xa0), "+v"(xa1) : "n"(NW_LAST) : "memory");                            \
         float v[8];                                                                                                           \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                       \
             v[i] = xa0[i];                                                                                                    \
             v[4 + i] = xa1[i];                                                                                                \
         }                                                                                                                     \
-        if ((kk) + 1 < KW) {   /* (this block's x landed before the table did) */                                              \
+        if ((kk) + 1 < KW) {                                                                                                  \
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW_MORE) : "memory");                                          \
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW_LAST) : "memory");                                               \
             xb0 = *(lf4 *)(xr0 + ((kk) + 1) * XKK);                                                                           \
             xb1 = *(lf4 *)(xr1 + ((kk) + 1) * XKK);                                                                           \
         }                                                                                                                     \
+        if ((kk) + 1 < KW) DPK_SL_TABLE_EXPAND(((kk) + 1 < KW ? (kk) + 1 : 0));                                               \
         DPK_SL_KSTEP(kk, v, tq2);                                                                                             \
         xa0 = xb0;                                                                                                            \
         xa1 = xb1;                                                                                                            \
     } while (0)
-        DPK_SL_FIRST_STEP(0, 14, 12);
-        DPK_SL_FIRST_STEP(1, 16, 12);
-        DPK_SL_FIRST_STEP(2, 18, 12);
-        DPK_SL_FIRST_STEP(3, 16, 12);
-        DPK_SL_FIRST_STEP(4, 10, 8);
-        DPK_SL_FIRST_STEP(5, 4, 4);
+        DPK_SL_FIRST_STEP(0, 12, 10);
+        DPK_SL_FIRST_STEP(1, 12, 8);
+        DPK_SL_FIRST_STEP(2, 12, 6);
+        DPK_SL_FIRST_STEP(3, 10, 4);
+        DPK_SL_FIRST_STEP(4, 8, 2);
+        DPK_SL_FIRST_STEP(5, 6, 0);
         DPK_SL_FIRST_STEP(6, 0, 0);
 #undef DPK_SL_FIRST_STEP
+#undef DPK_SL_TABLE_EXPAND
         qlane = tq2[0] + tq2[1];
         if (more) {
             issue_kk(nxt, nnv, 3);
