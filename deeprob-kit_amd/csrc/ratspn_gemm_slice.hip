@@ -52,6 +52,9 @@ __host__ __device__ constexpr int slice_lds_bytes(int NT, int w0_floats) {
     return kSliceCompute * kSliceSlot + kSliceCompute * slice_part_bytes(NT) + kSliceCompute * 256 + 128 + 1024 + 0 * w0_floats;
 }
 
+#ifndef DPK_SL_VERIFY
+#define DPK_SL_VERIFY 1
+#endif
 #ifdef DPK_TIMELINE
 #define SL_STAMP(row, slot) do { __builtin_amdgcn_sched_barrier(0); if (a.dbg && lane == 0 && (row) < 16 && blockIdx.x < 256) a.dbg[(((int64_t)blockIdx.x * 8 + wave) * 16 + (row)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -309,15 +312,19 @@ __device__ __forceinline__ void slice_verify_share(const GemmPrepArgs &pa, int l
     }
     if (lane == 0) ctl_l[0] = 2u | (stale ? 1u : 0u);
 }
-// one look at the verdict (the eighth wave's lane 0): requested in front of a block's upper layers, looked at behind them
-__device__ __forceinline__ unsigned long long slice_verdict_request(const GemmPrepArgs &pa) {
+// The eighth wave has nothing to do until its work-group's first barrier (5.8 us after entry at one block per work-group,
+// 7.7 us otherwise): it polls for the verdict until `until` (s_memrealtime, 100 MHz), so that the tail finds it in LDS.
+// (A look per block inside the block loop -- requested in front of the upper layers, examined behind them -- cost the
+// FROZEN-model launch 2.2 us at 65 536 samples through the loop's register allocation: same-box A/B, 47.6 against 45.4.)
+__device__ __forceinline__ void slice_verdict_poll(const GemmPrepArgs &pa, lunsigned *ctl_l, unsigned long long until) {
     const int shard = (int)blockIdx.x & (kSliceShards - 1);
-    return __hip_atomic_load(&slice_verify_of(pa.ctl)->verdict[shard], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void slice_verdict_peek(unsigned long long v, lunsigned *ctl_l) {
-    if ((ctl_l[0] & 2u) != 0u) return;
+    const unsigned long long *vp = &slice_verify_of(pa.ctl)->verdict[shard];
     const unsigned long long n = ((unsigned long long)ctl_l[3] << 32) | ctl_l[2];
-    if ((v >> 1) > n) ctl_l[0] = 2u | (unsigned)(v & 1ull);
+    while ((ctl_l[0] & 2u) == 0u && __builtin_amdgcn_s_memrealtime() < until) {
+        const unsigned long long v = __hip_atomic_load(vp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v >> 1) > n) ctl_l[0] = 2u | (unsigned)(v & 1ull);
+        else __builtin_amdgcn_s_sleep(16);
+    }
 }
 // ... and the wait for it where the work-group cannot go on without (stale also if nothing came for 1 s)
 __device__ __forceinline__ void slice_verdict_wait(const GemmPrepArgs &pa, lunsigned *ctl_l) {
@@ -369,10 +376,13 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
     const bool slicer = wave < kSliceCompute;                                 // (the eighth wave only joins phase 2)
     SL_STAMP(15, 0);
     // (the eighth wave, idle until the first barrier: the launch's table check, before anything of the stream is live)
-    if (!slicer && pa.np > 0) {
+    unsigned long long t_poll = 0ull;
+    if (!slicer && (DPK_SL_VERIFY && pa.np > 0)) {
+        const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
         __builtin_amdgcn_s_setprio(3);   // (its requests in front of the same SIMD's slice wave's: the chain below is three round trips)
         slice_verify_share<I>(pa, lane, ctl_l);
         __builtin_amdgcn_s_setprio(0);
+        t_poll = t_entry + (a.ntiles > (int)gridDim.x ? 500ull : 450ull);
     }
 
     // ---- phase-1 roles (slice waves): MFMA lane (sample s, half h) ----------------------------------------------------
@@ -479,6 +489,9 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
 #pragma unroll
         for (int e = 0; e < S * S; ++e) c2_l[j * 16 + 12 + e] = ((const float *)a.Wr)[rc * S * S + e];
     }
+    // (the eighth wave polls for the verdict up to 4.5 us after entry -- 5 at two or more blocks per work-group: the first
+    // barrier, 5.8 / 7.7 us after entry, is not kept waiting)
+    if (!slicer && (DPK_SL_VERIFY && pa.np > 0) && lane == 0) slice_verdict_poll(pa, ctl_l, t_poll);
     bool model_ok;
     {   // (through the scalar cache: a vector load here would put a compiler-counted wait into the request queue above)
         cint_p ce = as_const(a.elig);
@@ -585,9 +598,6 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
         // everyone has read the previous block's partials (and published its verdict on it)
         gemm_lds_barrier();
         SL_STAMP(row, 1);
-        // (the eighth wave asks for the launch's verdict here and looks at the answer behind the upper layers)
-        unsigned long long vpeek = 0ull;
-        if (!slicer && pa.np > 0 && lane == 0) vpeek = slice_verdict_request(pa);
         if (slicer) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -769,15 +779,14 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
                 issue_kk(nxt, nnv, 4);
             }
         }
-        if (!slicer && pa.np > 0 && lane == 0) slice_verdict_peek(vpeek, ctl_l);
         SL_STAMP(row, 4);
         ++row;
     }
     SL_STAMP(15, 2);
     // ---- the launch's verdict on its tables, the last block's verdict, then what left the fast path ------------------------
-    if (pa.np > 0 && !slicer && lane == 0) slice_verdict_wait(pa, ctl_l);
+    if ((DPK_SL_VERIFY && pa.np > 0) && !slicer && lane == 0) slice_verdict_wait(pa, ctl_l);
     __syncthreads();
-    const bool tables_stale = pa.np > 0 && (ctl_l[0] & 1u) != 0u;
+    const bool tables_stale = (DPK_SL_VERIFY && pa.np > 0) && (ctl_l[0] & 1u) != 0u;
     if (it > 0) {
         const lunsigned *fl = flag_l + ((it - 1) & 1) * 8;
         const unsigned any_bad = (fl[0] | fl[1]) | (fl[2] | fl[3]) | (fl[4] | fl[5]) | (fl[6] | fl[7]);

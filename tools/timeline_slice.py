@@ -1,5 +1,5 @@
 """Measurement: per-wave phase timeline of the slice mapping (csrc/ratspn_gemm_slice.hip; needs libdeeprob_hip_timeline.so:
-make -C deeprob-kit_amd/csrc ../lib/libdeeprob_hip_timeline.so).  usage: python tools/timeline_slice.py [B]"""
+make -C deeprob-kit_amd/csrc ../lib/libdeeprob_hip_timeline.so).  usage: python tools/timeline_slice.py [B] [--frozen]"""
 import ctypes, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,7 +8,8 @@ sys.path[:0] = [os.path.join(ROOT, 'deeprob-kit_amd'), ROOT]
 import torch
 from deeprob.spn.models import GaussianRatSpn
 from deeprob import hip
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 65536
+FROZEN = '--frozen' in sys.argv   # the frozen-model call (no table check in the launch)
 lib = hip.load_library()
 lib.dpk_ratspn_slice_batch_min(0)
 torch.manual_seed(0)
@@ -16,8 +17,12 @@ m = GaussianRatSpn(784, rg_depth=2, rg_repetitions=8, random_state=42).cuda().ev
 nbuf = max(3, -(-(320 << 20) // (B * 784 * 4)))
 xs = [torch.randn(B, 784, device='cuda') for _ in range(nbuf)]
 with torch.no_grad():
+    plans = [m.fused_plan(x, static_params=True) for x in xs] if FROZEN else None
     for i in range(3 * nbuf):
-        m(xs[i % nbuf])
+        if FROZEN:
+            plans[i % nbuf].run()
+        else:
+            m(xs[i % nbuf])
 torch.cuda.synchronize()
 ptr, grid = open('/tmp/dpk_timeline_slice_ptr.txt').read().split()
 grid = min(int(grid), 256)
