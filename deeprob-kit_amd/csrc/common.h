@@ -116,6 +116,7 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 constexpr int kBlock = 4;
 constexpr int kTableSlack = 16;  // neutral entries the software-pipelined readers may run into
 struct VerifyCtl;
+constexpr int kWideSplitBlocks = 128;     // 8-channel models, blocks of 32 samples shared by two work-groups: up to this many per launch
 constexpr int kSliceTabBytes = 512;       // compact mean table: bytes per (K-step, column tile) -- [hi, lo][lane half][repetition, channel][8 variables]
 constexpr int kSliceVerifyBytes = 2304;   // ratspn_gemm_slice.hip SliceVerify, in the workspace behind the VerifyCtl
 struct RatWs {
@@ -152,6 +153,8 @@ struct RatWs {
     uint16_t *gs_tab;            // two-channel models: the mean table without its structural zeros (ratspn_gemm_slice.hip)
     unsigned char *gs_mask;      // ... and which of a lane's entries its column keeps, per slice wave
     uint16_t *gup;               // 8-channel models: MFMA fragments of the first sum layer (ratspn_gemm_prep.h: wide_upfrag_*)
+    float *gwx_part;             // ... root partials of the two work-groups that share a block (ratspn_gemm_wide.hip, kWideSplit*)
+    unsigned *gwx_tick;          // ... and the blocks' tickets (only ever counted up)
     void *lg;          // tables of the leaf-only MFMA kernel (leaf_gemm_ws_bytes), null when the shape is outside it
     int g_nt, g_nksp;  // column tiles of 32, K-steps of 16 features (padded to whole chunks); 0 = not built
     int64_t bytes;
@@ -277,6 +280,12 @@ inline RatWs carve_ratspn_ws(void *base, int D, int R, int d, int I, int QB, int
             w.gs_mask = (unsigned char *)take((int64_t)cdiv(w.g_nksp, 7) * 64 * 16);
         }
         if (I == 8) w.gup = (uint16_t *)take((int64_t)reps * (S / 2 > 0 ? S / 2 : 1) * 1024 * 2);
+        w.gwx_part = nullptr;
+        w.gwx_tick = nullptr;
+        if (I == 8 && reps > 4) {
+            w.gwx_part = (float *)take((int64_t)kWideSplitBlocks * 2 * 32 * C * 2 * 4);
+            w.gwx_tick = (unsigned *)take((int64_t)kWideSplitBlocks * 4);
+        }
     }
     w.lg = nullptr;
     if (leaf_gemm_shape_ok(D, R, I, d)) w.lg = take(leaf_gemm_ws_bytes(D, R, I));

@@ -61,6 +61,9 @@ __global__ __launch_bounds__(kGemmPrepThreads) void ratspn_gemm_prep_kernel(cons
         // (the slice mapping's check, ratspn_gemm_slice.hip SliceVerify: counters that only grow from here)
         unsigned long long *sv = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.ctl) + 64);
         for (int i = (int)threadIdx.x; i < kSliceVerifyBytes / 8; i += (int)blockDim.x) sv[i] = 0ull;
+        // (8-channel models: the tickets of blocks shared by two work-groups, ratspn_gemm_wide.hip)
+        if (a.wx_tick != nullptr)
+            for (int i = (int)threadIdx.x; i < kWideSplitBlocks; i += (int)blockDim.x) a.wx_tick[i] = 0u;
     }
     gemm_prep_block<I>(a, (int)blockIdx.x, prep_dyn);
 }
@@ -417,6 +420,7 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
     p.w[1] = root_weight; p.W[1] = w.w[2]; p.LW[1] = w.lw[2]; p.rows[1] = C; p.n[1] = reps * S * S;
     p.hash = w.ghash; p.ctl = w.gctl;
     p.stab = w.gs_tab; p.smask = w.gs_mask;
+    p.wx_part = w.gwx_part; p.wx_tick = w.gwx_tick;
     { static const int pab = [] { const char *e = getenv("DPK_PREP_ABLATE"); return e ? atoi(e) : 0; }(); p.ablate = pab; }
     p.upfrag = (I == 8 && S >= 2) ? w.gup : nullptr; p.up_S = S;
     const int np = gemm_prep_blocks(NT, I, p.rows[0] + p.rows[1], kGemmPrepThreads);

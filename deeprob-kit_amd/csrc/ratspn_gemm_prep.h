@@ -63,6 +63,8 @@ struct GemmPrepArgs {
     int ablate;                 // measurement only (DPK_PREP_ABLATE): 1 stop after the verdict, 2 no fragments, 4 no constants
     uint16_t *stab;             // two-channel models: the compact mean table of the slice mapping (slice_tab_*), else null
     unsigned char *smask;       // ... and the keep-masks of its lanes
+    float *wx_part;             // 8-channel models: exchange of two work-groups that share a block (ratspn_gemm_wide.hip), else null
+    unsigned *wx_tick;          // ... the blocks' tickets
 };
 
 // table work-groups a launch needs: one per repetition slot + one per (threads / 64) softmax rows

@@ -131,15 +131,27 @@ template <int S> struct WideUpFrags {
 
 // raw0 / rawr non-null: a launch that found its tables stale (ratspn_gemm_prep.h; `exact` is then set as well) -- the
 // nodes take their log-softmax weights straight from the raw sum / root weights.
-template <int S, bool PRE = true, bool EMIT = false>
+// NW = 4: the block is shared by TWO work-groups of four waves, repetitions [4 g, 4 g + 4) each (the 32-sample kernel at
+// batches that would otherwise leave half the chip idle).  Each leaves its (max, sum) root partials in its slot of the
+// workspace (xpart), performed before it draws the block's ticket (xtick, only ever counted up: two per launch and
+// block); the work-group that draws the odd ticket merges the other's partials with its own and stores.
+template <int S, bool PRE = true, bool EMIT = false, int NW = kWideWaves>
 __device__ __forceinline__ double wide_block_upper(const GemmArgs &a, const gf32x16 &acc, unsigned long long odd_mask,
                                                    float qtot, bool exact, int rho, bool mine, int64_t b0,
                                                    const lfloat *w0_l, char *lds, const WideUpFrags<S> &uf,
-                                                   const float *raw0 = nullptr, const float *rawr = nullptr) {
+                                                   const float *raw0 = nullptr, const float *rawr = nullptr,
+                                                   float *xpart = nullptr, unsigned *xtick = nullptr, int grp = 0) {
     constexpr int I = kWideI;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = lane & 31, h = lane >> 5;
     const int NT = a.reps;
+    if constexpr (NW < kWideWaves) {
+        if (wave >= NW) {   // (the x-tile helpers of a shared block: the four barriers of the path below)
+#pragma unroll
+            for (int i = 0; i < ((a.ablate & 2) ? kWideUpperBarriers : 4); ++i) __syncthreads();
+            return 0.0;
+        }
+    }
     // ---- leaf sums of the lane's partition: regions 2h (a) and 2h + 1 (c) of repetition rho -------------------------
     float va[I], vc[I];
     wide_leaf_sums(a, acc, odd_mask, exact, rho, b0, va, vc);
@@ -268,7 +280,7 @@ __device__ __forceinline__ double wide_block_upper(const GemmArgs &a, const gf32
     __syncthreads();                                   // (barrier 1 of kWideUpperBarriers)
     // ---- root: log-sum-exp over the repetitions; thread = (sample, class slot) ---------------------------------------
     double part = 0.0;
-    {
+    if constexpr (NW == kWideWaves) {
         const int smp = tid >> 4, slot = tid & 15;
         const int64_t bs = b0 + smp;
         const float qterm = qx[smp];
@@ -281,6 +293,53 @@ __device__ __forceinline__ double wide_block_upper(const GemmArgs &a, const gf32
                 a.out[bs * C + cl] = ll;
                 if constexpr (EMIT) a.emit_out[bs * C + cl] = rel;
                 part += (double)ll;
+            }
+        }
+    } else {
+        static_assert(NW == 4, "two work-groups per block");
+        typedef unsigned long long u64;
+        const int r0 = grp * NW, r1 = min(NT, r0 + NW);
+        u64 *mine_x = reinterpret_cast<u64 *>(xpart) + (int64_t)grp * 32 * C;
+        const u64 *other_x = reinterpret_cast<const u64 *>(xpart) + (int64_t)(1 - grp) * 32 * C;
+        int *tick_l = reinterpret_cast<int *>(qx + 32);
+        // this work-group's partials: kept in registers for the merge, and left where the other one finds them
+        constexpr int kMaxPer = (32 * kWideMaxC + NW * 64 - 1) / (NW * 64);
+        float pm[kMaxPer], ps[kMaxPer];
+#pragma unroll
+        for (int i = 0; i < kMaxPer; ++i) {
+            const int e = i * NW * 64 + tid;
+            pm[i] = -INFINITY;
+            ps[i] = 0.f;
+            if (e < 32 * C) {
+                const int smp = e / C, cl = e - smp * C;
+                for (int r = r0; r < r1; ++r)
+                    lse_merge(pm[i], ps[i], xch[((r * 32 + smp) * C + cl) * 2], xch[((r * 32 + smp) * C + cl) * 2 + 1]);
+                __hip_atomic_store(mine_x + e, ((u64)__float_as_uint(ps[i]) << 32) | __float_as_uint(pm[i]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the partials are PERFORMED before the ticket is drawn)
+        __syncthreads();
+        if (tid == 0) *tick_l = (int)__hip_atomic_fetch_add(xtick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if ((*tick_l & 1) != 0) {   // the second of the two: the other's partials are there
+#pragma unroll
+            for (int i = 0; i < kMaxPer; ++i) {
+                const int e = i * NW * 64 + tid;
+                if (e < 32 * C) {
+                    const int smp = e / C, cl = e - smp * C;
+                    const u64 o = __hip_atomic_load(other_x + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    float mm = pm[i], ss = ps[i];
+                    lse_merge(mm, ss, __uint_as_float((unsigned)o), __uint_as_float((unsigned)(o >> 32)));
+                    const float rel = (mm > -INFINITY) ? mm + logf(ss) : -INFINITY;
+                    const float ll = rel + qx[smp];
+                    const int64_t bs = b0 + smp;
+                    if (bs < a.B) {
+                        a.out[bs * C + cl] = ll;
+                        if constexpr (EMIT) a.emit_out[bs * C + cl] = rel;
+                        part += (double)ll;
+                    }
+                }
             }
         }
     }
@@ -298,7 +357,12 @@ struct WideTail {                                     // LDS behind the x tile a
 };
 static_assert(sizeof(WideTail) % 16 == 0, "LDS layout");
 
-template <int S, bool MARG, bool EMIT>
+// NW = 8: a work-group per block, wave = repetition.  NW = 4: two work-groups per block, repetitions [4 g, 4 g + 4) each on
+// waves 0..3 -- at up to cus / 2 blocks (B <= 4096) the other form leaves half the chip idle with two repetitions' MFMA
+// streams and upper layers per SIMD.  Still eight waves per work-group (the in-launch table work-groups are built for that;
+// waves 4..7 help to stage and convert the x tile, then only keep the barriers); both work-groups stage the block's x
+// tile (the second read is an Infinity-Cache hit) and meet at the root (wide_block_upper).
+template <int S, bool MARG, bool EMIT, int NW>
 __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const GemmArgs a, const GemmPrepArgs pa) {
     constexpr int I = kWideI;
     constexpr int PF = MARG ? 6 : 12;                 // K-steps of table fragments in flight per wave
@@ -323,10 +387,14 @@ __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const
     }
     const int D = a.D, NT = a.reps;
     const int NKS = (D + 15) >> 4;
-    const int64_t b0 = (int64_t)((int)blockIdx.x - np) * 32;
+    const int mb = (int)blockIdx.x - np;               // model work-group
+    const int grp = NW == kWideWaves ? 0 : (mb & 1);   // which half of the repetitions
+    const int blk = NW == kWideWaves ? mb : (mb >> 1);
+    const int64_t b0 = (int64_t)blk * 32;
     const int nvalid = (int)min((int64_t)32, a.B - b0);
-    const bool mine = wave < NT;                       // (a model with fewer repetitions leaves waves without a tile)
-    const int rho = mine ? wave : NT - 1;
+    const bool compute = wave < NW;                    // (NW = 4: waves 4..7 only help with the x tile)
+    const bool mine = compute && grp * NW + wave < NT; // (a model with fewer repetitions leaves waves without a tile)
+    const int rho = mine ? grp * NW + wave : NT - 1;
     // LDS: [0, NKS * 2048) the x tile; behind it the wave's copy of its two partitions' sum weights (2 x S x 64 floats)
     lfloat *w0_l = (lfloat *)(smem + NKS * 2048) + wave * (2 * S * I * I);
 
@@ -505,7 +573,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const
     // hipcc wait for ALL outstanding loads at the join).  The row's last K-steps after them, without prefetch.
     int k0 = 0;
     unsigned long long peeked = 0ull;     // the launch's verdict word as of the last full group of K-steps (np > 0)
-    if (!(a.ablate & 1)) {
+    if (compute && !(a.ablate & 1)) {
         for (; k0 + PF <= NKS; k0 += PF) {
             peeked = vi_peek(pa.ctl);      // (unconditional, every thread, one request per wave: the last group's is the one used)
 #pragma unroll
@@ -521,7 +589,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const
     if constexpr (!MARG) {
         // Flagged K-steps of the clean build: their validity GEMM, from the tile still in LDS (out of the loop above: its
         // constants are loaded on demand).
-        for (int ks = 0; ks < NKS; ++ks) {
+        for (int ks = 0; ks < (compute ? NKS : 0); ++ks) {
             if (!((odd_mask >> ks) & 1ull)) continue;   // (wave-uniform)
             const u16x8 lb = __builtin_bit_cast(u16x8, *(const lh8 *)(smem + ks * 2048 + xo1));
             half8 valid;
@@ -550,8 +618,10 @@ __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const
     __syncthreads();   // every wave is done with the x tile: its LDS becomes scratch and the root exchange buffer
     const bool tables_stale = np > 0 && tail->verdict != 0;
     const bool exact = !model_ok || __any(lane_exact) || tables_stale;   // (the same x tile in every wave: the same verdict in every wave)
-    double part = wide_block_upper<S, true, EMIT>(a, acc, odd_mask, qtot, exact, rho, mine, b0, w0_l, smem_generic, uf,
-                                      tables_stale ? pa.w[0] : nullptr, tables_stale ? pa.w[1] : nullptr);
+    double part = wide_block_upper<S, true, EMIT, NW>(a, acc, odd_mask, qtot, exact, rho, mine, b0, w0_l, smem_generic, uf,
+                                      tables_stale ? pa.w[0] : nullptr, tables_stale ? pa.w[1] : nullptr,
+                                      NW == kWideWaves ? nullptr : pa.wx_part + (int64_t)blk * 2 * 32 * a.C * 2,
+                                      NW == kWideWaves ? nullptr : pa.wx_tick + blk, grp);
     double *red = reinterpret_cast<double *>(smem_generic + wide_upper_lds_bytes(NT, a.C));
     if (a.ll_sum != nullptr) {
         part = wave_reduce_sum(part);
@@ -910,22 +980,37 @@ bool gemm_wide_shape_ok(int D, int reps, int I, int S, int C) {
     return p1 <= 160 * 1024 && p2 <= (size_t)NKS * 2048;
 }
 
-template <int S, bool MARG, bool EMIT = false>
-static int gemm_wide_launch(const GemmArgs &a, const GemmPrepArgs &p, hipStream_t st) {
+// two work-groups per block (NW = 4) while that still fits one round of the chip and the model has repetitions for both
+static bool wide_splits_blocks(const GemmArgs &a, const GemmPrepArgs &p) {
+    static const int mode = [] { const char *e = getenv("DPK_WIDE_SPLIT"); return e ? atoi(e) : -1; }();   // (0 / 1: A/B runs)
+    const int64_t blocks = cdiv(a.B, 32);
+    if (p.wx_part == nullptr || a.reps <= 4 || blocks > kWideSplitBlocks) return false;
+    if (mode >= 0) return mode != 0;
+    return 2 * blocks + p.np <= device_cus();
+}
+
+template <int S, bool MARG, bool EMIT, int NW>
+static int gemm_wide_launch_nw(const GemmArgs &a, const GemmPrepArgs &p, hipStream_t st) {
     const int NKS = cdiv(a.D, 16);
     size_t lds = (size_t)NKS * 2048 + (size_t)kWideWaves * 2 * S * kWideI * kWideI * 4 + sizeof(WideTail);
     if (p.np > 0 && gemm_prep_lds_bytes(a.D, kWideI, a.d) > lds) lds = gemm_prep_lds_bytes(a.D, kWideI, a.d);
-    auto kern = ratspn_gemm_wide_kernel<S, MARG, EMIT>;
+    auto kern = ratspn_gemm_wide_kernel<S, MARG, EMIT, NW>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), 160 * 1024)) return rc;
     hipEvent_t ev0, ev1;
     profile_take(&ev0, &ev1, DPK_KERNEL_RATSPN_FUSED);
     if (ev0) (void)hipEventRecord(ev0, st);
     GemmPrepArgs pp = p;
-    pp.readers = p.np + (int)cdiv(a.B, 32);
-    DPK_LAUNCH(kern, dim3(p.np + cdiv(a.B, 32)), dim3(kWideWaves * 64), lds, st, a, pp);
+    const int model_wgs = (int)cdiv(a.B, 32) * (NW == kWideWaves ? 1 : 2);
+    pp.readers = p.np + model_wgs;
+    DPK_LAUNCH(kern, dim3(p.np + model_wgs), dim3(kWideWaves * 64), lds, st, a, pp);
     if (ev1) (void)hipEventRecord(ev1, st);
     DPK_CHECK_LAUNCH("ratspn_gemm_wide_kernel");
     return DPK_OK;
+}
+template <int S, bool MARG, bool EMIT = false>
+static int gemm_wide_launch(const GemmArgs &a, const GemmPrepArgs &p, hipStream_t st) {
+    if (wide_splits_blocks(a, p)) return gemm_wide_launch_nw<S, MARG, EMIT, 4>(a, p, st);
+    return gemm_wide_launch_nw<S, MARG, EMIT, kWideWaves>(a, p, st);
 }
 
 template <int S>
