@@ -446,6 +446,46 @@ def test_pairs_kernel_stress_vs_fp64_oracle(D, units):
         assert any(v[1] is False for v in verdicts), verdicts        # the stress flow does trip the guard
 
 
+@pytest.mark.parametrize('target', [250.0, 800.0])
+def test_pairs_kernel_between_ordinary_and_the_gain_limit(target):
+    """Round 5: the split-f16 column-pair kernel itself at BASELINE config 5's width (D = 784), with
+    every layer's conditioner gain set between the ordinary 50-80 and ops_flows.PAIRS_GAIN_LIMIT (1024) -- all layers stay on
+    ``coupling_x1_kernel`` -- held per sample to 2x the distance of the reference's as-written fp32 arithmetic from fp64."""
+    from deeprob.flows.models import RealNVP1d
+    from deeprob.flows.layers.coupling import CouplingLayer1d
+    from deeprob.hip import ops_flows
+    from tests.util import randomise_flow
+    torch.manual_seed(41)
+    model = RealNVP1d(784, n_flows=3, units=128)
+    randomise_flow(model, 42)
+    model = model.cuda().eval()
+    g = torch.Generator().manual_seed(43)
+    x = torch.randn(257, 784, generator=g) * torch.where(torch.rand(257, 1, generator=g) < 0.2, 3.0, 1.0)
+    xd = x.cuda()
+    cps = [l for l in model.layers if isinstance(l, CouplingLayer1d)]
+    with torch.no_grad():
+        for _ in range(2):      # the gain is bilinear in (W1, W2): one correction lands on the target
+            model(xd)
+            for l in cps:
+                f = (target / l._ws_pairs._cond[2]) ** 0.5
+                l.network[0].weight.mul_(f)
+                l.network[-1].weight.mul_(f)
+        got = model(xd).cpu().numpy()
+    gains = [l._ws_pairs._cond for l in cps]
+    assert all(c[1] and 0.8 * target <= c[2] <= 1.2 * target and c[2] < ops_flows.PAIRS_GAIN_LIMIT for c in gains), gains
+    sd32 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd32.items()}
+    want = forc.flow_log_prob(sd64, x.double()).numpy()
+    want32 = forc.flow_log_prob(sd32, x).numpy()
+    noise = float(np.max(np.abs(want32 - want) / np.maximum(np.abs(want), 1.0)))
+    assert np.isfinite(want).all() and np.isfinite(got).all()
+    per_sample = float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1.0)))
+    report_measured('test_pairs_kernel_between_ordinary_and_the_gain_limit[%d]' % int(target), per_sample, max(TOL, 2 * noise),
+                    '(TOL 1e-5, or 2x the as-written reference fp32 distance from fp64 = %.1e); conditioner gains %s, all on the split-f16 kernel'
+                    % (noise, ['%.0f' % c[2] for c in gains]))
+    assert per_sample <= max(TOL, 2 * noise), (per_sample, noise, gains)
+
+
 def test_accuracy_guard_leaves_ordinary_flows_on_the_split_f16_kernels():
     """The conditioner-gain guard (ops_flows.PAIRS_GAIN_LIMIT) is a property of the parameters, judged once per parameter
     version: default-initialised and fixture-style randomised flows stay on the column-pair kernels (BASELINE config 5's
