@@ -529,6 +529,129 @@ __global__ __launch_bounds__(256) void leaf_bwd_param_lds_kernel(
     }
 }
 
+// Round 5: the same sums as three small GEMMs on the matrix cores.  With the upstream gradient of the live samples
+// gl[b, (r,k)] = g[b,r,k] [x[b,f] observed],
+//     S0[(r,k), f] = sum_b gl,   S1 = sum_b gl x[b,f],   S2 = sum_b gl x[b,f]^2      (G^T [R I x B] times [B x D] operands)
+// and  d/dmu = (S1 - mu S0) / s^2,   d/ds = ((S2 - 2 mu S1 + mu^2 S0) / s^2 - S0) / s  (Bernoulli: d/dlogit = S1 - p S0):
+// no gather along the row of x, no per-parameter atomics, no zeroing of the gradients.  A work-group owns 32 rows
+// (32 / I regions) x 32 variables; four waves a quarter of the batch each on v_mfma_f32_32x32x2_f32 (exact fp32 products),
+// summed through LDS; the epilogue keeps the (row, variable) pairs whose variable belongs to the row's region -- one in
+// 2^depth -- through a map built from the region masks.  Measured at B = 512, (8,8): 26.9 us (staged VALU kernel) ->
+// see DESIGN.md.  Batches up to kLeafMomentMaxB (the K loop is not split over work-groups).
+constexpr int kLeafMomentMaxB = 2048;
+constexpr int kLeafMomentChunk = 64;               // samples a wave stages at a time
+constexpr int kLeafMomentStride = 36;              // floats between staged rows (32 + 4: the b128 writes of 8 rows spread over the banks)
+constexpr int kLeafMomentLds = 4 * 2 * kLeafMomentChunk * kLeafMomentStride * 4 + 32 * 32 * 2;   // staging (reused for the partial sums) + map
+template <int DIST, bool WANT1>
+__global__ __launch_bounds__(256) void leaf_bwd_moment_kernel(
+    const float *__restrict__ x, const float *__restrict__ g, int64_t B, int D, int R, int I, int d,
+    const int64_t *__restrict__ mask, const uint8_t *__restrict__ pad, const float *__restrict__ p0,
+    const float *__restrict__ p1, float *__restrict__ gp0, float *__restrict__ gp1) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int CH = kLeafMomentChunk, ST = kLeafMomentStride;
+    extern __shared__ __attribute__((aligned(16))) float leaf_mom_sm[];
+    static_assert(4 * 2 * CH * ST >= 4 * 3 * 32 * 33, "the partial sums reuse the staging area");
+    float *stage = leaf_mom_sm;                                                  // [wave][g, x][CH][ST]
+    float (*part)[3][32 * 33] = reinterpret_cast<float (*)[3][32 * 33]>(leaf_mom_sm);   // [wave][S0, S1, S2][32 x 33]
+    short (*jmap)[32] = reinterpret_cast<short (*)[32]>(leaf_mom_sm + 4 * 2 * CH * ST);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * 32, f0 = blockIdx.y * 32;
+    const int RI = R * I;
+    const int nreg = 32 / I, r0 = row0 / I;            // regions of this row tile (32 % I == 0, R I % 32 == 0: the host checks)
+    // ---- which variable of the column tile sits where in the tile's regions -------------------------------------------
+    for (int e = tid; e < 32 * 32; e += 256) jmap[e >> 5][e & 31] = -1;
+    __syncthreads();
+    for (int e = tid; e < nreg * d; e += 256) {
+        const int rl = e / d, j = e - rl * d;
+        const int64_t o = (int64_t)(r0 + rl) * d + j;
+        if (pad != nullptr && pad[o]) continue;
+        const int f = (int)mask[o];
+        if (f >= f0 && f < f0 + 32) jmap[rl][f - f0] = (short)j;
+    }
+    // ---- the wave's quarter of the batch, staged CH samples at a time: 16-byte loads (a compute unit's request path
+    // takes ~37 cycles per load INSTRUCTION: one 4-byte load per operand and K-step was 512 of them, 23 us) ----------------
+    const int m = lane & 31, kh = lane >> 5;
+    const int64_t per = (B + 3) / 4;
+    const int64_t bq0 = wave * per, bq1 = min(B, bq0 + per);
+    float *gst = stage + (size_t)wave * 2 * CH * ST, *xst = gst + CH * ST;
+    const int lr = lane >> 3, lc = (lane & 7) * 4;      // the lane's row (of 8 per instruction) and columns of a staged piece
+    const bool xvec = (D % 4) == 0 && f0 + 32 <= D && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    f32x16 a0, a1, a2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a0[i] = a1[i] = a2[i] = 0.f;
+    for (int64_t b = bq0; b < bq1; b += CH) {
+        f32x4 gq[CH / 8], xq[CH / 8];
+#pragma unroll
+        for (int it = 0; it < CH / 8; ++it) {
+            const int64_t bb = b + it * 8 + lr;
+            const int64_t bc = min(bb, B - 1);
+            gq[it] = *reinterpret_cast<const f32x4 *>(g + bc * RI + row0 + lc);          // (R I % 32 == 0: 16-byte aligned)
+            if (xvec) {
+                xq[it] = *reinterpret_cast<const f32x4 *>(x + bc * D + f0 + lc);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xq[it][q] = x[bc * D + min(f0 + lc + q, D - 1)];
+            }
+            if (bb >= bq1) gq[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int it = 0; it < CH / 8; ++it) {
+            *reinterpret_cast<f32x4 *>(gst + (it * 8 + lr) * ST + lc) = gq[it];
+            *reinterpret_cast<f32x4 *>(xst + (it * 8 + lr) * ST + lc) = xq[it];
+        }
+        // (the wave reads what it wrote itself: no barrier)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 8
+        for (int u = 0; u < CH / 2; ++u) {
+            const float gv = gst[(2 * u + kh) * ST + m];
+            const float xr = xst[(2 * u + kh) * ST + m];
+            const bool live = xr == xr;                 // marginalised: no contribution
+            const float xl = live ? xr : 0.f;
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, live ? 1.f : 0.f, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, xl, a1, 0, 0, 0);
+            if (DIST == 0 && WANT1) a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, xl * xl, a2, 0, 0, 0);
+        }
+    }
+    __syncthreads();   // (every wave is done with its staging area: the partial sums take its place)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int i = (v >> 2) * 8 + kh * 4 + (v & 3);
+        part[wave][0][i * 33 + m] = a0[v];
+        part[wave][1][i * 33 + m] = a1[v];
+        if (DIST == 0 && WANT1) part[wave][2][i * 33 + m] = a2[v];
+    }
+    __syncthreads();
+    // ---- epilogue: thread = (row i, 4 variables) ---------------------------------------------------------------------------
+    {
+        const int i = tid >> 3, c0 = (tid & 7) * 4;
+        const int rl = i / I, k = i - rl * I;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int c = c0 + cc;
+            const int j = jmap[rl][c];
+            if (j < 0) continue;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                s0 += part[w][0][i * 33 + c];
+                s1 += part[w][1][i * 33 + c];
+                if (DIST == 0 && WANT1) s2 += part[w][2][i * 33 + c];
+            }
+            const int64_t po = ((int64_t)(r0 + rl) * I + k) * d + j;
+            if (DIST == 0) {
+                const float mu = p0[po], sg = p1[po];
+                const float is2 = 1.f / (sg * sg);
+                if (gp0) gp0[po] = (s1 - mu * s0) * is2;
+                if (WANT1 && gp1) gp1[po] = (fmaf(mu, fmaf(mu, s0, -2.f * s1), s2) * is2 - s0) / sg;
+            } else {
+                if (gp0) gp0[po] = s1 - s0 / (1.f + expf(-p0[po]));
+            }
+        }
+    }
+}
+
 // inverse structure: for repetition rho and variable f, the (region, position) r*d+j holding it
 __global__ void leaf_inverse_kernel(const int *__restrict__ feat, const int *__restrict__ srcr, int d, int SP,
                                     int D, int regions_per_rep, int *__restrict__ inv) {
@@ -711,9 +834,30 @@ static int leaf_backward_common(int dist, const float *x, const float *g, int64_
     int rc = prepare_leaf_structure(w, mask, pad_mask, R, d, flags, st);
     if (rc) return rc;
     const size_t pbytes = (size_t)R * I * d * 4;
-    if (gp0) DPK_REQUIRE(hipMemsetAsync(gp0, 0, pbytes, st) == hipSuccess, DPK_ELAUNCH, "leaf_backward: memset");
-    if (gp1) DPK_REQUIRE(hipMemsetAsync(gp1, 0, pbytes, st) == hipSuccess, DPK_ELAUNCH, "leaf_backward: memset");
-    if (B > 0 && (gp0 || gp1)) {
+    // small batches: the parameter gradients as moment GEMMs (leaf_bwd_moment_kernel) -- every entry that has a variable
+    // is written exactly once, so only a padded model's gradients are zeroed first
+    static const bool moment_off = [] { const char *e = getenv("DPK_LEAF_MOMENT"); return e && atoi(e) == 0; }();
+    const bool moment = !moment_off && B > 0 && B <= kLeafMomentMaxB && drop_p == 0.f && I <= 32 && (32 % I) == 0 &&
+                        ((R * I) % 32) == 0 && d <= 32767 && (gp0 || gp1) &&
+                        (reinterpret_cast<uintptr_t>(g) & 15) == 0;
+    if (!moment || pad_mask != nullptr) {
+        if (gp0) DPK_REQUIRE(hipMemsetAsync(gp0, 0, pbytes, st) == hipSuccess, DPK_ELAUNCH, "leaf_backward: memset");
+        if (gp1) DPK_REQUIRE(hipMemsetAsync(gp1, 0, pbytes, st) == hipSuccess, DPK_ELAUNCH, "leaf_backward: memset");
+    }
+    if (moment) {
+        const dim3 mgrid(R * I / 32, cdiv(D, 32)), mblock(256);
+#define DPK_LEAF_MOMENT(DIST, W1)                                                                                          \
+    do {                                                                                                                   \
+        if (int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&leaf_bwd_moment_kernel<DIST, W1>), 96 * 1024)) return lrc; \
+        DPK_LAUNCH((leaf_bwd_moment_kernel<DIST, W1>), mgrid, mblock, kLeafMomentLds, st, x, g, B, D, R, I, d, mask, pad_mask, p0, \
+                   p1, gp0, gp1);                                                                                          \
+    } while (0)
+        if (dist == 0 && gp1) DPK_LEAF_MOMENT(0, true);
+        else if (dist == 0) DPK_LEAF_MOMENT(0, false);
+        else DPK_LEAF_MOMENT(1, false);
+#undef DPK_LEAF_MOMENT
+        DPK_CHECK_LAUNCH("leaf_bwd_moment_kernel");
+    } else if (B > 0 && (gp0 || gp1)) {
         const int cbk = (I % 4 == 0) ? 4 : ((I % 2 == 0) ? 2 : 1);
         // small batches: shorter sample slices so that the grid still covers the chip (more atomics per parameter)
         const int tile = (B > 1024) ? kLeafBwdTile : 16;
