@@ -704,6 +704,144 @@ __global__ __launch_bounds__(256) void spatial_prodsum_fwd_kernel(const float *_
 
 
 // ------------------------------------------------------------------------------------------------
+// The same level for WIDE layers (16 / 32 input channels, up to 32 sum channels), round 5.  In the kernel above a thread
+// reads the Cout x C weights of its pixel from global memory for every group of NB samples: one load per multiply-add,
+// 3.3 GB of L2 traffic per launch at 32 -> 32 channels (c4b, the example model: 504 + 284 + 2 x 191 us for four levels
+// whose multiply-adds are 70 us of vector-ALU time).  Here a work-group owns 16 pixels and keeps their softmaxed
+// weights in LDS for a slice of the batch: [output][4 inputs][pixel][4] floats, so that the 16 pixels of a wave read 16
+// consecutive 16-byte pieces (four lanes -- four sample slots -- share a piece: broadcast); a thread = (pixel, sample slot)
+// walks the slice two samples at a time: 2 C exponentials in registers, 8 ds_read_b128 per output against 64
+// multiply-adds.  The rare vanished node takes the exact log-domain form from the taps, as above.
+// ------------------------------------------------------------------------------------------------
+constexpr int kWidePix = 16;          // pixels per work-group (256 threads = 16 pixels x 16 sample slots)
+template <int CIN, bool PAIRS>
+__global__ __launch_bounds__(256) void spatial_prodsum_wide_kernel(const float *__restrict__ in, const float *__restrict__ Wl,
+                                                                    const float *__restrict__ LW, int B, ProdGeom q, int Cout,
+                                                                    float *__restrict__ out, int per_wg) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float wide_w[];   // [Cout][CIN / 4][kWidePix][4]
+    constexpr int PT = kWidePix, C4 = CIN / 4;
+    const int OHW = q.OH * q.OW, HW = q.H * q.W;
+    const int px = threadIdx.x & (PT - 1), slot = threadIdx.x / PT;
+    const int p0 = blockIdx.x * PT;
+    const int p = p0 + px;
+    const bool has_p = p < OHW;
+    // ---- the tile's weights: thread -> (output, input) rows of 16 consecutive pixels ---------------------------------------
+    for (int e = threadIdx.x; e < Cout * CIN * PT; e += 256) {
+        const int pp = e % PT, oc = e / PT;                  // oc = o * CIN + c
+        const int o = oc / CIN, c = oc - o * CIN;
+        const float w = (p0 + pp < OHW && c < q.C) ? Wl[((size_t)o * q.C + c) * OHW + p0 + pp] : 0.f;
+        wide_w[((o * C4 + (c >> 2)) * PT + pp) * 4 + (c & 3)] = w;
+    }
+    __syncthreads();
+    if (!has_p) return;
+    const int oh = p / q.OW, ow = p - oh * q.OW;
+    int tclamp[4];
+    bool tval[4];
+    {
+        const int T = q.kh * q.kw;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int th = t / q.kw, tw = t - th * q.kw;
+            const int ih = oh * q.sh - q.pt + th * q.dh, iw = ow * q.sw - q.pl + tw * q.dw;
+            tval[t] = t < T && ih >= 0 && ih < q.H && iw >= 0 && iw < q.W;
+            tclamp[t] = tval[t] ? ih * q.W + iw : 0;
+        }
+    }
+    const int b_begin = blockIdx.y * per_wg, b_end = min(B, b_begin + per_wg);
+    // Horizontally adjacent taps (2 x 2 window, dilation 1 along the row, no padding: the pooling levels) travel as ONE
+    // 8-byte load per tap row: the level is bound by the number of load instructions (a compute unit's request path takes
+    // ~37 cycles each), not by bytes.  (With padding the pair has to be clamped into the row and its elements selected
+    // per lane: measured slower than four loads.)
+    constexpr bool paired = PAIRS;
+    int pbase[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) pbase[r] = (oh * q.sh + r * q.dh) * q.W + ow * q.sw;
+    constexpr int NB = 2;
+    for (int b0 = b_begin + slot * NB; b0 < b_end; b0 += (256 / PT) * NB) {
+        float ev[NB][CIN], m0[NB];
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+            const float *src = in + (size_t)min(b0 + s, B - 1) * q.C * HW;
+            float m = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                float a = 0.f;
+                if (paired) {
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+                        const f32x2u v = *reinterpret_cast<const f32x2u *>(src + (size_t)c * HW + pbase[r]);
+                        a += v[0] + v[1];
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float v = src[(size_t)c * HW + tclamp[t]];
+                        a += tval[t] ? v : 0.f;
+                    }
+                }
+                ev[s][c] = a;
+                m = fmaxf(m, a);
+            }
+            m0[s] = (m == -INFINITY) ? 0.f : m;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) ev[s][c] = __expf(ev[s][c] - m0[s]);
+        }
+#pragma unroll 4
+        for (int o = 0; o < Cout; ++o) {
+            float v[NB];
+#pragma unroll
+            for (int s = 0; s < NB; ++s) v[s] = 0.f;
+            const f32x4 *wp = reinterpret_cast<const f32x4 *>(wide_w) + (size_t)o * C4 * PT + px;
+#pragma unroll
+            for (int c4 = 0; c4 < C4; ++c4) {
+                const f32x4 w = wp[c4 * PT];
+#pragma unroll
+                for (int s = 0; s < NB; ++s) {
+                    v[s] = fmaf(w[0], ev[s][4 * c4], v[s]);
+                    v[s] = fmaf(w[1], ev[s][4 * c4 + 1], v[s]);
+                    v[s] = fmaf(w[2], ev[s][4 * c4 + 2], v[s]);
+                    v[s] = fmaf(w[3], ev[s][4 * c4 + 3], v[s]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < NB; ++s) {
+                if (b0 + s >= b_end) break;
+                float r;
+                if (v[s] < 1e-30f) {
+                    // exact log-domain pass (rare): rebuild the products from the taps
+                    const float *src = in + (size_t)(b0 + s) * q.C * HW;
+                    const float *lp = LW + (size_t)o * q.C * OHW + p;
+                    float mm = -INFINITY;
+                    for (int c = 0; c < q.C; ++c) {
+                        float a = 0.f;
+                        for (int t = 0; t < 4; ++t)
+                            if (tval[t]) a += src[(size_t)c * HW + tclamp[t]];
+                        mm = fmaxf(mm, a + lp[(size_t)c * OHW]);
+                    }
+                    if (mm > -INFINITY) {
+                        float acc = 0.f;
+                        for (int c = 0; c < q.C; ++c) {
+                            float a = 0.f;
+                            for (int t = 0; t < 4; ++t)
+                                if (tval[t]) a += src[(size_t)c * HW + tclamp[t]];
+                            acc += expf(a + lp[(size_t)c * OHW] - mm);
+                        }
+                        r = mm + logf(acc);
+                    } else {
+                        r = -INFINITY;
+                    }
+                } else {
+                    r = m0[s] + logf(v[s]);
+                }
+                out[((size_t)(b0 + s) * Cout + o) * OHW + p] = r;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Last level of the eval route: depthwise product ('final' padding) folded into the root sum nodes.
 //   out[b,k] = logsumexp_m( prod[b,m] + log_softmax(weight,1)[k,m] ),  m = (c, oh, ow) flattened,
 //   prod[b,m] = sum of the window taps of in[b,c] -- never written.  One wave per sample, lanes stride m,
@@ -1100,6 +1238,33 @@ extern "C" int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C
     // Wide levels (C >= 16): a thread reads Cout x C weights of its pixel per NB samples -- 800 KB per work-group at
     // 32 -> 32 channels on a 14 x 14 map, 3.3 GB of L2 traffic per launch with one sample group per work-group (round-4
     // trace: 865 us).  There a work-group is 16 pixels x 16 groups of samples: the 16 groups read the same weights.
+    // wide levels with exactly 16 / 32 input channels: the tile's weights in LDS (spatial_prodsum_wide_kernel)
+    static const bool wide_off = [] { const char *e = getenv("DPK_DGC_WIDE"); return e && atoi(e) == 0; }();
+    if (!wide_off && (C == 16 || C == 32) && Cout <= 32) {
+        const int ptiles = cdiv(OHW, kWidePix);
+        // samples per work-group: enough work-groups for four rounds of the chip, at least 32 samples each
+        int per_wg = (int)std::max<int64_t>(32, cdiv((int64_t)Bi * ptiles, 4 * (int64_t)device_cus()));
+        per_wg = (int)align_up(per_wg, 32);
+        const size_t lds = (size_t)Cout * C * kWidePix * 4;
+        const dim3 wgrid(ptiles, cdiv(Bi, per_wg));
+        // (every tap inside the map, the two of a row adjacent)
+        const bool pairs = kh == 2 && kw == 2 && dw == 1 && pad_top == 0 && pad_left == 0 && (OW - 1) * sw + 1 < W &&
+                           (OH - 1) * sh + dh < H;
+#define DPK_WIDE(CIN, PR)                                                                                                  \
+    do {                                                                                                                   \
+        if (int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&spatial_prodsum_wide_kernel<CIN, PR>), 64 * 1024)) return lrc; \
+        DPK_LAUNCH((spatial_prodsum_wide_kernel<CIN, PR>), wgrid, dim3(256), lds, st, in, Wl, LW, Bi, q, Cout, out, per_wg);   \
+    } while (0)
+        if (C == 16) {
+            if (pairs) DPK_WIDE(16, true); else DPK_WIDE(16, false);
+        } else {
+            if (pairs) DPK_WIDE(32, true); else DPK_WIDE(32, false);
+        }
+#undef DPK_WIDE
+        if (pev1) (void)hipEventRecord(pev1, st);
+        DPK_CHECK_LAUNCH("spatial_prodsum_wide_kernel");
+        return DPK_OK;
+    }
     int slots = 1, ptile = 256;
     if (C >= 16) {
         ptile = OHW < 16 ? OHW : 16;

@@ -193,6 +193,37 @@ def test_sum_backward_extreme_weights_against_oracle(cin, cout):
         assert grad_err(s.weight.grad.cpu().numpy(), w64.grad.numpy()) <= GRAD_TOL
 
 
+@pytest.mark.parametrize('shape,padding,stride,dil,cout,B', [((16, 14, 14), 'full', 1, 1, 32, 300), ((32, 7, 7), 'full', 1, 2, 32, 131),
+                                                           ((32, 9, 9), 'valid', 2, 1, 20, 67), ((16, 6, 6), 'final', 1, 4, 32, 45)])
+def test_wide_fused_level_against_oracle(shape, padding, stride, dil, cout, B):
+    """Round 5: the eval-mode fused level for 16 / 32 input channels (csrc/dgcspn.hip: spatial_prodsum_wide_kernel, the
+    tile's weights in LDS) against the oracle's product + sum: maps that are not a multiple of the 16-pixel tile, fewer
+    than 32 sum channels, a batch that is not a multiple of the sample slots, a sample of log 0, marginalised (log 1)
+    inputs, and a weight row whose dominant entry sits on a vanishing input (the exact log-domain form)."""
+    from deeprob.spn.layers.dgcspn import SpatialProductLayer, SpatialSumLayer
+    from deeprob.hip import ops_spatial
+    gen = torch.Generator().manual_seed(19)
+    prod = SpatialProductLayer(shape, 2, padding, stride, dil, depthwise=True).cuda()
+    ssum = SpatialSumLayer(prod.out_features, cout).cuda()
+    with torch.no_grad():
+        ssum.weight.copy_(torch.randn(ssum.weight.shape, generator=gen) * 2)
+        ssum.weight[0, 1] = -300.0                          # softmax weight ~ e^-300 everywhere but ...
+        ssum.weight[0, 1, 1, 1] = 80.0                      # ... one pixel, where channel 1 dominates
+    x = torch.randn(B, *shape, generator=gen) * 3
+    x[0] = float('-inf')
+    x[1] = 0.0
+    x[2, 1] = -400.0                                        # the dominant channel's input vanishes in the exp domain
+    want = dorc.spatial_sum(dorc.spatial_product(x, prod.pad, stride, dil, True), ssum.weight.detach().cpu())
+    with torch.no_grad():
+        got = ops_spatial.spatial_prodsum(x.cuda(), prod, ssum.weight, ssum._ws)
+        again = ops_spatial.spatial_prodsum(x.cuda()[5:40], prod, ssum.weight, ssum._ws)
+    assert got is not None
+    fin = torch.isfinite(want)
+    assert torch.equal(fin, torch.isfinite(got.cpu()))
+    assert rel_err(got.cpu()[fin].numpy(), want[fin].numpy()) <= LL_TOL
+    assert torch.equal(again, got[5:40])                    # a sample's result does not depend on its place in the batch
+
+
 def test_empty_batch_and_errors():
     from deeprob.hip import HipError
     from deeprob.spn.models import DgcSpn
