@@ -714,6 +714,18 @@ __global__ __launch_bounds__(256) void spatial_prodsum_fwd_kernel(const float *_
 // multiply-adds.  The rare vanished node takes the exact log-domain form from the taps, as above.
 // ------------------------------------------------------------------------------------------------
 constexpr int kWidePix = 16;          // pixels per work-group (256 threads = 16 pixels x 16 sample slots)
+// Work-group -> (pixel tile, slice of the batch).  The pixel tiles of ONE slice read the same input planes (a tile touches
+// a tenth of each), and consecutive work-groups go to different XCDs, each with its own L2: dispatched tile-fastest, the 13
+// tiles of a slice pulled every plane into up to eight L2s (c4b: 4.6 GB of traffic per step for 1.2 GB of maps).  The grid
+// is one-dimensional: work-group L lands on XCD L mod 8 and takes slice (L / 8 / tiles) * 8 + L mod 8 -- all tiles of a
+// slice on one XCD, one after the other.
+__device__ __forceinline__ bool wide_block_of(const ProdGeom &q, int &tile, int &chunk, int B, int per_wg) {
+    const int tiles = (q.OH * q.OW + kWidePix - 1) / kWidePix;
+    const int L = (int)blockIdx.x, x = L & 7, i = L >> 3;
+    tile = i % tiles;
+    chunk = (i / tiles) * 8 + x;
+    return chunk * per_wg < B;
+}
 template <int CIN, bool PAIRS>
 __global__ __launch_bounds__(256) void spatial_prodsum_wide_kernel(const float *__restrict__ in, const float *__restrict__ Wl,
                                                                     const float *__restrict__ LW, int B, ProdGeom q, int Cout,
@@ -723,7 +735,9 @@ __global__ __launch_bounds__(256) void spatial_prodsum_wide_kernel(const float *
     constexpr int PT = kWidePix, C4 = CIN / 4;
     const int OHW = q.OH * q.OW, HW = q.H * q.W;
     const int px = threadIdx.x & (PT - 1), slot = threadIdx.x / PT;
-    const int p0 = blockIdx.x * PT;
+    int tile_x, chunk_y;
+    if (!wide_block_of(q, tile_x, chunk_y, B, per_wg)) return;
+    const int p0 = tile_x * PT;
     const int p = p0 + px;
     const bool has_p = p < OHW;
     // ---- the tile's weights: thread -> (output, input) rows of 16 consecutive pixels ---------------------------------------
@@ -748,7 +762,7 @@ __global__ __launch_bounds__(256) void spatial_prodsum_wide_kernel(const float *
             tclamp[t] = tval[t] ? ih * q.W + iw : 0;
         }
     }
-    const int b_begin = blockIdx.y * per_wg, b_end = min(B, b_begin + per_wg);
+    const int b_begin = chunk_y * per_wg, b_end = min(B, b_begin + per_wg);
     // Horizontally adjacent taps (2 x 2 window, dilation 1 along the row, no padding: the pooling levels) travel as ONE
     // 8-byte load per tap row: the level is bound by the number of load instructions (a compute unit's request path takes
     // ~37 cycles each), not by bytes.  (With padding the pair has to be clamped into the row and its elements selected
@@ -837,6 +851,101 @@ __global__ __launch_bounds__(256) void spatial_prodsum_wide_kernel(const float *
                 }
                 out[((size_t)(b0 + s) * Cout + o) * OHW + p] = r;
             }
+        }
+    }
+}
+
+// The pooling level with an even output width (2 x 2 window, stride 2, no padding: the model's first level): a thread owns
+// TWO horizontally adjacent output pixels of one sample -- their eight taps are two aligned 16-byte loads per channel, their
+// results one 8-byte store per output: half the memory instructions of the kernel above per pixel and sample (the level is
+// bound by their number).  256 threads = 8 pixel pairs x 32 sample slots; weights in LDS as above.
+template <int CIN>
+__global__ __launch_bounds__(256) void spatial_prodsum_wide_pool_kernel(const float *__restrict__ in, const float *__restrict__ Wl,
+                                                                         const float *__restrict__ LW, int B, ProdGeom q, int Cout,
+                                                                         float *__restrict__ out, int per_wg) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) float wide_w[];   // [Cout][CIN / 4][kWidePix][4]
+    constexpr int PT = kWidePix, C4 = CIN / 4, NP = PT / 2;
+    const int OHW = q.OH * q.OW, HW = q.H * q.W;
+    const int pr = threadIdx.x & (NP - 1), slot = threadIdx.x / NP;
+    int tile_x, chunk_y;
+    if (!wide_block_of(q, tile_x, chunk_y, B, per_wg)) return;
+    const int p0 = tile_x * PT;
+    const int p = p0 + 2 * pr;                               // (OW even, p0 even: p and p + 1 share a row)
+    for (int e = threadIdx.x; e < Cout * CIN * PT; e += 256) {
+        const int pp = e % PT, oc = e / PT;
+        const int o = oc / CIN, c = oc - o * CIN;
+        const float w = (p0 + pp < OHW && c < q.C) ? Wl[((size_t)o * q.C + c) * OHW + p0 + pp] : 0.f;
+        wide_w[((o * C4 + (c >> 2)) * PT + pp) * 4 + (c & 3)] = w;
+    }
+    __syncthreads();
+    if (p >= OHW) return;
+    const int oh = p / q.OW, ow = p - oh * q.OW;
+    const int base0 = (oh * 2) * q.W + ow * 2, base1 = base0 + q.W;      // four consecutive inputs per tap row
+    const int b_begin = chunk_y * per_wg, b_end = min(B, b_begin + per_wg);
+    for (int b = b_begin + slot; b < b_end; b += 256 / NP) {
+        const float *src = in + (size_t)b * q.C * HW;
+        float ev[2][CIN], m0[2];
+        float ma = -INFINITY, mb = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+            const f32x4 r0 = *reinterpret_cast<const f32x4 *>(src + (size_t)c * HW + base0);
+            const f32x4 r1 = *reinterpret_cast<const f32x4 *>(src + (size_t)c * HW + base1);
+            ev[0][c] = (r0[0] + r0[1]) + (r1[0] + r1[1]);
+            ev[1][c] = (r0[2] + r0[3]) + (r1[2] + r1[3]);
+            ma = fmaxf(ma, ev[0][c]);
+            mb = fmaxf(mb, ev[1][c]);
+        }
+        m0[0] = (ma == -INFINITY) ? 0.f : ma;
+        m0[1] = (mb == -INFINITY) ? 0.f : mb;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+            ev[0][c] = __expf(ev[0][c] - m0[0]);
+            ev[1][c] = __expf(ev[1][c] - m0[1]);
+        }
+        for (int o = 0; o < Cout; ++o) {
+            float v[2] = {0.f, 0.f};
+            const f32x4 *wp = reinterpret_cast<const f32x4 *>(wide_w) + (size_t)o * C4 * PT + 2 * pr;
+#pragma unroll
+            for (int c4 = 0; c4 < C4; ++c4) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const f32x4 w = wp[c4 * PT + s];
+                    v[s] = fmaf(w[0], ev[s][4 * c4], v[s]);
+                    v[s] = fmaf(w[1], ev[s][4 * c4 + 1], v[s]);
+                    v[s] = fmaf(w[2], ev[s][4 * c4 + 2], v[s]);
+                    v[s] = fmaf(w[3], ev[s][4 * c4 + 3], v[s]);
+                }
+            }
+            f32x2 r;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (v[s] < 1e-30f) {
+                    // exact log-domain pass (rare): rebuild the products from the taps
+                    const float *lp = LW + (size_t)o * q.C * OHW + p + s;
+                    float mm = -INFINITY;
+                    for (int c = 0; c < q.C; ++c) {
+                        const float *t0 = src + (size_t)c * HW + base0 + 2 * s;
+                        const float a = (t0[0] + t0[1]) + (t0[q.W] + t0[q.W + 1]);
+                        mm = fmaxf(mm, a + lp[(size_t)c * OHW]);
+                    }
+                    if (mm > -INFINITY) {
+                        float acc = 0.f;
+                        for (int c = 0; c < q.C; ++c) {
+                            const float *t0 = src + (size_t)c * HW + base0 + 2 * s;
+                            const float a = (t0[0] + t0[1]) + (t0[q.W] + t0[q.W + 1]);
+                            acc += expf(a + lp[(size_t)c * OHW] - mm);
+                        }
+                        r[s] = mm + logf(acc);
+                    } else {
+                        r[s] = -INFINITY;
+                    }
+                } else {
+                    r[s] = m0[s] + logf(v[s]);
+                }
+            }
+            *reinterpret_cast<f32x2 *>(out + ((size_t)b * Cout + o) * OHW + p) = r;
         }
     }
 }
@@ -1246,7 +1355,7 @@ extern "C" int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C
         int per_wg = (int)std::max<int64_t>(32, cdiv((int64_t)Bi * ptiles, 4 * (int64_t)device_cus()));
         per_wg = (int)align_up(per_wg, 32);
         const size_t lds = (size_t)Cout * C * kWidePix * 4;
-        const dim3 wgrid(ptiles, cdiv(Bi, per_wg));
+        const dim3 wgrid(ptiles * (int)align_up(cdiv(Bi, per_wg), 8));   // (one-dimensional: wide_block_of)
         // (every tap inside the map, the two of a row adjacent)
         const bool pairs = kh == 2 && kw == 2 && dw == 1 && pad_top == 0 && pad_left == 0 && (OW - 1) * sw + 1 < W &&
                            (OH - 1) * sh + dh < H;
@@ -1255,7 +1364,18 @@ extern "C" int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C
         if (int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&spatial_prodsum_wide_kernel<CIN, PR>), 64 * 1024)) return lrc; \
         DPK_LAUNCH((spatial_prodsum_wide_kernel<CIN, PR>), wgrid, dim3(256), lds, st, in, Wl, LW, Bi, q, Cout, out, per_wg);   \
     } while (0)
-        if (C == 16) {
+        // (the pooling level with an even output width: two pixels per thread, 16-byte tap loads -- rows 16-byte aligned)
+        const bool pool2 = pairs && sh == 2 && sw == 2 && dh == 1 && (OW % 2) == 0 && (W % 4) == 0 && (OHW % 2) == 0 &&
+                           (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0;
+        if (pool2 && (C == 16 || C == 32)) {
+            if (C == 16) {
+                if (int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&spatial_prodsum_wide_pool_kernel<16>), 64 * 1024)) return lrc;
+                DPK_LAUNCH((spatial_prodsum_wide_pool_kernel<16>), wgrid, dim3(256), lds, st, in, Wl, LW, Bi, q, Cout, out, per_wg);
+            } else {
+                if (int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&spatial_prodsum_wide_pool_kernel<32>), 64 * 1024)) return lrc;
+                DPK_LAUNCH((spatial_prodsum_wide_pool_kernel<32>), wgrid, dim3(256), lds, st, in, Wl, LW, Bi, q, Cout, out, per_wg);
+            }
+        } else if (C == 16) {
             if (pairs) DPK_WIDE(16, true); else DPK_WIDE(16, false);
         } else {
             if (pairs) DPK_WIDE(32, true); else DPK_WIDE(32, false);

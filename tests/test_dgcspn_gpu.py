@@ -194,7 +194,8 @@ def test_sum_backward_extreme_weights_against_oracle(cin, cout):
 
 
 @pytest.mark.parametrize('shape,padding,stride,dil,cout,B', [((16, 14, 14), 'full', 1, 1, 32, 300), ((32, 7, 7), 'full', 1, 2, 32, 131),
-                                                           ((32, 9, 9), 'valid', 2, 1, 20, 67), ((16, 6, 6), 'final', 1, 4, 32, 45)])
+                                                           ((32, 9, 9), 'valid', 2, 1, 20, 67), ((16, 6, 6), 'final', 1, 4, 32, 45),
+                                                           ((16, 12, 12), 'valid', 2, 1, 32, 77), ((32, 8, 8), 'valid', 2, 1, 32, 33)])
 def test_wide_fused_level_against_oracle(shape, padding, stride, dil, cout, B):
     """Round 5: the eval-mode fused level for 16 / 32 input channels (csrc/dgcspn.hip: spatial_prodsum_wide_kernel, the
     tile's weights in LDS) against the oracle's product + sum: maps that are not a multiple of the 16-pixel tile, fewer
