@@ -719,6 +719,38 @@ constexpr int kWidePix = 16;          // pixels per work-group (256 threads = 16
 // tiles of a slice pulled every plane into up to eight L2s (c4b: 4.6 GB of traffic per step for 1.2 GB of maps).  The grid
 // is one-dimensional: work-group L lands on XCD L mod 8 and takes slice (L / 8 / tiles) * 8 + L mod 8 -- all tiles of a
 // slice on one XCD, one after the other.
+// The tile's weights into LDS, [output][4 inputs][pixel][4]: a thread takes (output, 4 inputs) x 4 pixels -- four 16-byte
+// loads along the pixels (when the map's rows of the weight tensor are 16-byte aligned: OHW % 4 == 0), transposed in
+// registers, four 16-byte LDS writes.  (One 4-byte load and one 4-byte LDS write per element was 50 us of a 243 us level:
+// every work-group loads 64 KB.)
+template <int CIN>
+__device__ __forceinline__ void wide_tile_weights(const float *__restrict__ Wl, float *wide_w, int C, int Cout, int OHW, int p0) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int PT = kWidePix, C4 = CIN / 4;
+    const bool vec = (OHW & 3) == 0 && p0 + PT <= OHW && C == CIN && (reinterpret_cast<uintptr_t>(Wl) & 15) == 0;
+    if (vec) {
+        for (int e = threadIdx.x; e < Cout * C4 * (PT / 4); e += 256) {
+            const int pq = e % (PT / 4), oc4 = e / (PT / 4);   // oc4 = o * C4 + c4
+            const int o = oc4 / C4, c4 = oc4 - o * C4;
+            f32x4 r[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                r[i] = *reinterpret_cast<const f32x4 *>(Wl + ((size_t)o * C + 4 * c4 + i) * OHW + p0 + 4 * pq);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 t = {r[0][j], r[1][j], r[2][j], r[3][j]};
+                *reinterpret_cast<f32x4 *>(wide_w + ((size_t)oc4 * PT + 4 * pq + j) * 4) = t;
+            }
+        }
+    } else {
+        for (int e = threadIdx.x; e < Cout * CIN * PT; e += 256) {
+            const int pp = e % PT, oc = e / PT;                  // oc = o * CIN + c
+            const int o = oc / CIN, c = oc - o * CIN;
+            const float w = (p0 + pp < OHW && c < C) ? Wl[((size_t)o * C + c) * OHW + p0 + pp] : 0.f;
+            wide_w[((o * C4 + (c >> 2)) * PT + pp) * 4 + (c & 3)] = w;
+        }
+    }
+}
 __device__ __forceinline__ bool wide_block_of(const ProdGeom &q, int &tile, int &chunk, int B, int per_wg) {
     const int tiles = (q.OH * q.OW + kWidePix - 1) / kWidePix;
     const int L = (int)blockIdx.x, x = L & 7, i = L >> 3;
@@ -741,12 +773,7 @@ __global__ __launch_bounds__(256) void spatial_prodsum_wide_kernel(const float *
     const int p = p0 + px;
     const bool has_p = p < OHW;
     // ---- the tile's weights: thread -> (output, input) rows of 16 consecutive pixels ---------------------------------------
-    for (int e = threadIdx.x; e < Cout * CIN * PT; e += 256) {
-        const int pp = e % PT, oc = e / PT;                  // oc = o * CIN + c
-        const int o = oc / CIN, c = oc - o * CIN;
-        const float w = (p0 + pp < OHW && c < q.C) ? Wl[((size_t)o * q.C + c) * OHW + p0 + pp] : 0.f;
-        wide_w[((o * C4 + (c >> 2)) * PT + pp) * 4 + (c & 3)] = w;
-    }
+    wide_tile_weights<CIN>(Wl, wide_w, q.C, Cout, OHW, p0);
     __syncthreads();
     if (!has_p) return;
     const int oh = p / q.OW, ow = p - oh * q.OW;
@@ -873,12 +900,7 @@ __global__ __launch_bounds__(256) void spatial_prodsum_wide_pool_kernel(const fl
     if (!wide_block_of(q, tile_x, chunk_y, B, per_wg)) return;
     const int p0 = tile_x * PT;
     const int p = p0 + 2 * pr;                               // (OW even, p0 even: p and p + 1 share a row)
-    for (int e = threadIdx.x; e < Cout * CIN * PT; e += 256) {
-        const int pp = e % PT, oc = e / PT;
-        const int o = oc / CIN, c = oc - o * CIN;
-        const float w = (p0 + pp < OHW && c < q.C) ? Wl[((size_t)o * q.C + c) * OHW + p0 + pp] : 0.f;
-        wide_w[((o * C4 + (c >> 2)) * PT + pp) * 4 + (c & 3)] = w;
-    }
+    wide_tile_weights<CIN>(Wl, wide_w, q.C, Cout, OHW, p0);
     __syncthreads();
     if (p >= OHW) return;
     const int oh = p / q.OW, ow = p - oh * q.OW;
@@ -937,6 +959,129 @@ __global__ __launch_bounds__(256) void spatial_prodsum_wide_pool_kernel(const fl
                             const float a = (t0[0] + t0[1]) + (t0[q.W] + t0[q.W + 1]);
                             acc += expf(a + lp[(size_t)c * OHW] - mm);
                         }
+                        r[s] = mm + logf(acc);
+                    } else {
+                        r[s] = -INFINITY;
+                    }
+                } else {
+                    r[s] = m0[s] + logf(v[s]);
+                }
+            }
+            *reinterpret_cast<f32x2 *>(out + ((size_t)b * Cout + o) * OHW + p) = r;
+        }
+    }
+}
+
+// The model's FIRST level with the Gaussian leaf layer folded in (dpk_spatial_leaf_prodsum_forward): the leaf map --
+// [B, K, H, W], the largest tensor of the example model, 411 MB written by the leaf kernel and read back by this level at
+// B = 8192 -- is never formed.  Same mapping as the pooling kernel above (a thread = two adjacent output pixels of one
+// sample); the eight input pixels of the pair come from the IMAGE (two 16-byte loads per image channel), and the leaf
+// parameters of those eight pixels (mean, 1 / 2 s^2, -log s - log sqrt(2 pi): 16 bytes per leaf channel, image channel and
+// pixel) live in LDS beside the tile's sum weights.  leaf = sum over the image channels of nan_to_num(log N(x; mu, s))
+// (layers/dgcspn.py:101-120), then the window's four taps are added as the product layer does.
+template <int CIN>
+__global__ __launch_bounds__(256) void spatial_leaf_pool_prodsum_kernel(const float *__restrict__ x, const float *__restrict__ loc,
+                                                                         const float *__restrict__ scale, int Cx,
+                                                                         const float *__restrict__ Wl, const float *__restrict__ LW,
+                                                                         int B, ProdGeom q, int Cout, float *__restrict__ out,
+                                                                         int per_wg) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) float wide_w[];   // [Cout][CIN / 4][kWidePix][4], then the leaf parameters
+    constexpr int PT = kWidePix, C4 = CIN / 4, NP = PT / 2;
+    const int OHW = q.OH * q.OW, HW = q.H * q.W;
+    f32x4 *lp = reinterpret_cast<f32x4 *>(wide_w + (size_t)Cout * CIN * PT);   // [CIN * Cx][pair][row][4 pixels]: (mu, iv, cs, -)
+    const int pr = threadIdx.x & (NP - 1), slot = threadIdx.x / NP;
+    int tile_x, chunk_y;
+    if (!wide_block_of(q, tile_x, chunk_y, B, per_wg)) return;
+    const int p0 = tile_x * PT;
+    const int p = p0 + 2 * pr;                               // (OW even, p0 even: p and p + 1 share a row)
+    wide_tile_weights<CIN>(Wl, wide_w, q.C, Cout, OHW, p0);
+    for (int e = threadIdx.x; e < CIN * Cx * NP * 8; e += 256) {
+        const int j = e & 3, row = (e >> 2) & 1, pp = (e >> 3) % NP, kc = e / (8 * NP);
+        const int pe = p0 + 2 * pp;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (pe < OHW) {
+            const int oh = pe / q.OW, ow = pe - oh * q.OW;
+            const int64_t o = (int64_t)kc * HW + (oh * 2 + row) * q.W + ow * 2 + j;
+            const float sg = scale[o];
+            v[0] = loc[o];
+            v[1] = 0.5f / (sg * sg);
+            v[2] = -logf(sg) - kLogSqrt2Pi;
+        }
+        lp[e] = v;
+    }
+    __syncthreads();
+    if (p >= OHW) return;
+    const int oh = p / q.OW, ow = p - oh * q.OW;
+    const int base0 = (oh * 2) * q.W + ow * 2, base1 = base0 + q.W;      // four consecutive inputs per tap row
+    const int b_begin = chunk_y * per_wg, b_end = min(B, b_begin + per_wg);
+    for (int b = b_begin + slot; b < b_end; b += 256 / NP) {
+        const float *src = x + (size_t)b * Cx * HW;
+        float ev[2][CIN], m0[2];
+#pragma unroll
+        for (int k = 0; k < CIN; ++k) ev[0][k] = ev[1][k] = 0.f;
+        for (int cx = 0; cx < Cx; ++cx) {
+            const f32x4 r0 = *reinterpret_cast<const f32x4 *>(src + (size_t)cx * HW + base0);
+            const f32x4 r1 = *reinterpret_cast<const f32x4 *>(src + (size_t)cx * HW + base1);
+#pragma unroll
+            for (int k = 0; k < CIN; ++k) {
+                const f32x4 *pk = lp + ((size_t)(k * Cx + cx) * NP + pr) * 8;
+                float t[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 a = pk[j], c = pk[4 + j];
+                    const float d0 = r0[j] - a[0], d1 = r1[j] - c[0];
+                    t[j] = nan_to_num_f(fmaf(-(d0 * d0), a[1], a[2]));
+                    t[4 + j] = nan_to_num_f(fmaf(-(d1 * d1), c[1], c[2]));
+                }
+                ev[0][k] += (t[0] + t[1]) + (t[4] + t[5]);
+                ev[1][k] += (t[2] + t[3]) + (t[6] + t[7]);
+            }
+        }
+        float ma = -INFINITY, mb = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < CIN; ++k) {
+            ma = fmaxf(ma, ev[0][k]);
+            mb = fmaxf(mb, ev[1][k]);
+        }
+        m0[0] = (ma == -INFINITY) ? 0.f : ma;
+        m0[1] = (mb == -INFINITY) ? 0.f : mb;
+        float la[2][CIN];                                    // (the log-domain products, kept for the rare exact form)
+#pragma unroll
+        for (int k = 0; k < CIN; ++k) {
+            la[0][k] = ev[0][k];
+            la[1][k] = ev[1][k];
+            ev[0][k] = __expf(ev[0][k] - m0[0]);
+            ev[1][k] = __expf(ev[1][k] - m0[1]);
+        }
+        for (int o = 0; o < Cout; ++o) {
+            float v[2] = {0.f, 0.f};
+            const f32x4 *wp = reinterpret_cast<const f32x4 *>(wide_w) + (size_t)o * C4 * PT + 2 * pr;
+#pragma unroll
+            for (int c4 = 0; c4 < C4; ++c4) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const f32x4 w = wp[c4 * PT + s];
+                    v[s] = fmaf(w[0], ev[s][4 * c4], v[s]);
+                    v[s] = fmaf(w[1], ev[s][4 * c4 + 1], v[s]);
+                    v[s] = fmaf(w[2], ev[s][4 * c4 + 2], v[s]);
+                    v[s] = fmaf(w[3], ev[s][4 * c4 + 3], v[s]);
+                }
+            }
+            f32x2 r;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (v[s] < 1e-30f) {
+                    // exact log-domain pass (rare)
+                    const float *lw = LW + (size_t)o * q.C * OHW + p + s;
+                    float mm = -INFINITY;
+#pragma unroll
+                    for (int k = 0; k < CIN; ++k) mm = fmaxf(mm, la[s][k] + lw[(size_t)k * OHW]);
+                    if (mm > -INFINITY) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int k = 0; k < CIN; ++k) acc += expf(la[s][k] + lw[(size_t)k * OHW] - mm);
                         r[s] = mm + logf(acc);
                     } else {
                         r[s] = -INFINITY;
@@ -1407,6 +1552,57 @@ extern "C" int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C
 #undef DPK_PRODSUM
     if (pev1) (void)hipEventRecord(pev1, st);
     DPK_CHECK_LAUNCH("spatial_prodsum_fwd_kernel");
+    return DPK_OK;
+}
+
+// SpatialGaussianLayer + the first depthwise product + sum level in one launch (eval route; models/dgcspn.py:134-147 for
+// i = 0, 1): the pooling level only -- 2 x 2 window, stride 2, no padding, even output width, rows 16-byte aligned, 16 or
+// 32 leaf channels -- DPK_EUNSUPPORTED otherwise (the caller runs dpk_spatial_gaussian_forward + dpk_spatial_prodsum_forward).
+extern "C" int dpk_spatial_leaf_prodsum_forward(const float *x, const float *loc, const float *scale, int64_t B, int32_t Cx,
+                                                int32_t K, int32_t H, int32_t W, int32_t OH, int32_t OW, int32_t kh, int32_t kw,
+                                                int32_t sh, int32_t sw, int32_t dh, int32_t dw, int32_t pad_top,
+                                                int32_t pad_left, const float *weight, int32_t Cout, float *out, void *ws,
+                                                int64_t ws_bytes, uint32_t flags, void *stream) {
+    ProdGeom q;
+    int rc = make_geom(q, K, H, W, K, OH, OW, kh, kw, sh, sw, dh, dw, pad_top, pad_left, 1);
+    if (rc) return rc;
+    DPK_REQUIRE(B >= 0 && Cout > 0 && Cx > 0, DPK_EINVAL, "spatial_leaf_prodsum: bad sizes");
+    DPK_REQUIRE(weight && ws && loc && scale, DPK_EINVAL, "spatial_leaf_prodsum: null pointer");
+    const int OHW = OH * OW;
+    const size_t lds = (size_t)Cout * K * kWidePix * 4 + (size_t)K * Cx * (kWidePix / 2) * 8 * 16;
+    const bool ok = (K == 16 || K == 32) && Cout <= 32 && kh == 2 && kw == 2 && sh == 2 && sw == 2 && dh == 1 && dw == 1 &&
+                    pad_top == 0 && pad_left == 0 && (OW - 1) * 2 + 1 < W && (OH - 1) * 2 + 1 < H && (OW % 2) == 0 &&
+                    (W % 4) == 0 && (OHW % 2) == 0 && lds <= 150 * 1024 && B <= INT32_MAX / 2 &&
+                    (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0;
+    if (!ok) {
+        set_error("spatial_leaf_prodsum: outside the fused first level's envelope");
+        return DPK_EUNSUPPORTED;
+    }
+    const int64_t seg = align_up((int64_t)Cout * K * OHW * 4, 256);
+    DPK_REQUIRE(ws_bytes >= 3 * seg, DPK_EWORKSPACE, "spatial_leaf_prodsum: workspace too small");
+    if (B == 0) return DPK_OK;
+    DPK_REQUIRE(x && out, DPK_EINVAL, "spatial_leaf_prodsum: null pointer");
+    float *Wl = (float *)ws, *LW = (float *)((char *)ws + seg);
+    hipStream_t st = (hipStream_t)stream;
+    if (!(flags & DPK_FLAG_PARAMS_CACHED))
+        DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW, 256)), dim3(256), 0, st, weight, Cout, K, OHW, Wl, LW);
+    const int Bi = (int)B;
+    const int ptiles = cdiv(OHW, kWidePix);
+    int per_wg = (int)std::max<int64_t>(32, cdiv((int64_t)Bi * ptiles, 4 * (int64_t)device_cus()));
+    per_wg = (int)align_up(per_wg, 32);
+    const dim3 wgrid(ptiles * (int)align_up(cdiv(Bi, per_wg), 8));   // (one-dimensional: wide_block_of)
+    hipEvent_t pev0, pev1;
+    profile_take(&pev0, &pev1, DPK_KERNEL_SPATIAL_PRODSUM);
+    if (pev0) (void)hipEventRecord(pev0, st);
+    if (K == 16) {
+        if (int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&spatial_leaf_pool_prodsum_kernel<16>), 160 * 1024)) return lrc;
+        DPK_LAUNCH((spatial_leaf_pool_prodsum_kernel<16>), wgrid, dim3(256), lds, st, x, loc, scale, Cx, Wl, LW, Bi, q, Cout, out, per_wg);
+    } else {
+        if (int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&spatial_leaf_pool_prodsum_kernel<32>), 160 * 1024)) return lrc;
+        DPK_LAUNCH((spatial_leaf_pool_prodsum_kernel<32>), wgrid, dim3(256), lds, st, x, loc, scale, Cx, Wl, LW, Bi, q, Cout, out, per_wg);
+    }
+    if (pev1) (void)hipEventRecord(pev1, st);
+    DPK_CHECK_LAUNCH("spatial_leaf_pool_prodsum_kernel");
     return DPK_OK;
 }
 

@@ -141,6 +141,8 @@ SIGNATURES = {
                                                 _c_void, _c_void, _c_void, _i64, _c_void]),
     'dpk_spatial_prodsum_forward': (ctypes.c_int, [_c_void, _i64] + [_i32] * 13 + [_c_void, _i32, _c_void, _c_void,
                                                                                   _i64, _u32, _c_void]),
+    'dpk_spatial_leaf_prodsum_forward': (ctypes.c_int, [_c_void, _c_void, _c_void, _i64] + [_i32] * 14 + [_c_void, _i32, _c_void,
+                                                        _c_void, _i64, _u32, _c_void]),
     'dpk_coupling1d_backward_workspace_bytes': (_i64, [_i64, _i32, _i32, _i32]),
     'dpk_coupling1d_backward': (ctypes.c_int, [_c_void, _i64, _i32] + [_c_void] * 6 + [_i32, _c_void, _i32] +
                                 [_c_void] * 9 + [_i64, _c_void]),

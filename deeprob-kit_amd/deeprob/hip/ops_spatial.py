@@ -256,6 +256,36 @@ def spatial_prodsum(x, prod_layer, weight, ws: Workspace):
     return out
 
 
+def spatial_leaf_prodsum(x, leaf_layer, prod_layer, weight, ws: Workspace):
+    """SpatialGaussianLayer + the first depthwise product + sum level of the eval route in ONE launch (reference:
+    deeprob/spn/models/dgcspn.py:134-147): the [B, K, H, W] leaf map is never written.  None when the level is outside
+    the fused kernel's envelope (the caller evaluates the leaf layer and then ``spatial_prodsum``)."""
+    lib = load_library()
+    if not prod_layer.depthwise or not x.is_cuda or x.dim() != 4:
+        return None
+    x = require_device_f32(x, 'x')
+    w = require_device_f32(weight, 'weight')
+    loc, scale = require_device_f32(leaf_layer.loc, 'loc'), require_device_f32(leaf_layer.scale, 'scale')
+    if loc.dim() != 4 or tuple(loc.shape) != tuple(scale.shape) or tuple(x.shape[1:]) != tuple(loc.shape[1:]):
+        return None
+    K, Cx = loc.shape[0], loc.shape[1]
+    C, H, W, _, OH, OW, kh, kw, sh, sw, dh, dw, pt, pl, _ = _geom(prod_layer)
+    if C != K or (H, W) != tuple(x.shape[2:]):
+        return None
+    B, Cout = x.shape[0], w.shape[0]
+    out = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
+    buf = _spatial_sum_ws(ws, C, Cout, OH, OW, x.device)
+    flags = _tables_flag(ws, 'prodsum', w)
+    rc = lib.dpk_spatial_leaf_prodsum_forward(ptr(x), ptr(loc), ptr(scale), B, Cx, K, H, W, OH, OW, kh, kw, sh, sw, dh, dw, pt,
+                                              pl, ptr(w), Cout, ptr(out), ptr(buf), buf.numel(), flags, stream_ptr(x.device))
+    if rc:
+        ws.params_key = None
+    if rc == -4:  # DPK_EUNSUPPORTED
+        return None
+    check(rc, 'dpk_spatial_leaf_prodsum_forward')
+    return out
+
+
 class SpatialProdSumFn(torch.autograd.Function):
     """Depthwise SpatialProductLayer + SpatialSumLayer as ONE autograd node (training route of a DGC-SPN level,
     reference: deeprob/spn/models/dgcspn.py:146-147 chaining layers/dgcspn.py:224-236 and :289-304): the forward is the

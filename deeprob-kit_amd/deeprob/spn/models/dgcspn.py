@@ -146,8 +146,16 @@ class DgcSpn(ProbabilisticModel):
 
     def _forward_eval(self, x: torch.Tensor) -> torch.Tensor:
         from deeprob.hip import ops_spatial
-        x = self.base_layer(x)
         i, n = 0, len(self.layers)
+        y = None
+        if (n >= 4 and isinstance(self.base_layer, SpatialGaussianLayer) and isinstance(self.layers[0], SpatialProductLayer)
+                and isinstance(self.layers[1], SpatialSumLayer) and not self.training):
+            # the Gaussian leaf layer folded into the first (pooling) level: the leaf map is never written
+            y = ops_spatial.spatial_leaf_prodsum(x, self.base_layer, self.layers[0], self.layers[1].weight, self.layers[1]._ws)
+        if y is not None:
+            x, i = y, 2
+        else:
+            x = self.base_layer(x)
         while i < n:
             layer = self.layers[i]
             if (i == n - 3 and isinstance(layer, SpatialProductLayer) and isinstance(self.layers[i + 1], SpatialSumLayer)
