@@ -874,7 +874,7 @@ __global__ __launch_bounds__(256) void spatial_prodsum_wide_kernel(const float *
                         r = -INFINITY;
                     }
                 } else {
-                    r = m0[s] + logf(v[s]);
+                    r = fmaf(__builtin_amdgcn_logf(v[s]), 0.6931471805599453f, m0[s]);   // (v >= 1e-30: a normal number; v_log_f32 is good to 1 ulp)
                 }
                 out[((size_t)(b0 + s) * Cout + o) * OHW + p] = r;
             }
@@ -964,7 +964,7 @@ __global__ __launch_bounds__(256) void spatial_prodsum_wide_pool_kernel(const fl
                         r[s] = -INFINITY;
                     }
                 } else {
-                    r[s] = m0[s] + logf(v[s]);
+                    r[s] = fmaf(__builtin_amdgcn_logf(v[s]), 0.6931471805599453f, m0[s]);   // (v >= 1e-30: a normal number; v_log_f32 is good to 1 ulp)
                 }
             }
             *reinterpret_cast<f32x2 *>(out + ((size_t)b * Cout + o) * OHW + p) = r;
@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(256) void spatial_leaf_pool_prodsum_kernel(const fl
                         r[s] = -INFINITY;
                     }
                 } else {
-                    r[s] = m0[s] + logf(v[s]);
+                    r[s] = fmaf(__builtin_amdgcn_logf(v[s]), 0.6931471805599453f, m0[s]);   // (v >= 1e-30: a normal number; v_log_f32 is good to 1 ulp)
                 }
             }
             *reinterpret_cast<f32x2 *>(out + ((size_t)b * Cout + o) * OHW + p) = r;
