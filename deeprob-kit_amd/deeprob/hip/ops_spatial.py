@@ -198,6 +198,13 @@ def tables_prepare(levels, x: torch.Tensor):
             g6 = (ctypes.c_int32 * 10)(OH6, OW6, kh6, kw6, sh6, sw6, dh6, dw6, pt6, pl6)
             n = lib.dpk_spatial_sumprodroot_workspace_bytes_batch(B, C, H, W, g5, Cout, g6, K)
             if n < 0:
+                # outside the last-level kernel (wide models): the forward will run this level through spatial_prodsum --
+                # its tables join this launch instead of costing one of their own
+                ws = sm._ws
+                buf = _spatial_sum_ws(ws, C, Cout, OH, OW, dev)
+                key = _weights_key('prodsum', w)
+                entries.append(_SpatialTablesArgs(ptr(w), ptr(buf), buf.numel(), None, C, Cout, OH * OW, 0, 0))
+                marked.append((ws, key))
                 continue
             ws = root._ws3
             buf = ws.get(n, dev)
