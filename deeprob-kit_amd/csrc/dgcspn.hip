@@ -1555,9 +1555,138 @@ extern "C" int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C
     return DPK_OK;
 }
 
+// The same fusion for any 2 x 2 window (stride, dilation, padding as the product layer has them; 8, 16 or 32 leaf channels):
+// thread = (pixel, sample slot) as in spatial_prodsum_wide_kernel, two samples at a time; the four taps of the pixel are
+// four 4-byte loads of the IMAGE per image channel, their leaf parameters 16 bytes per (leaf channel, image channel, tap)
+// in LDS ([..][pixel][tap]: a lane's four taps are one 64-byte run); a tap in the padding has zero parameters and adds
+// nan_to_num(-(d^2) 0 + 0) = 0, the log 1 of the product layer's padding.
+template <int CIN>
+__global__ __launch_bounds__(256) void spatial_leaf_prodsum_kernel(const float *__restrict__ x, const float *__restrict__ loc,
+                                                                    const float *__restrict__ scale, int Cx,
+                                                                    const float *__restrict__ Wl, const float *__restrict__ LW, int B,
+                                                                    ProdGeom q, int Cout, float *__restrict__ out, int per_wg) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float wide_w[];   // [Cout][CIN / 4][kWidePix][4], then the leaf parameters
+    constexpr int PT = kWidePix, C4 = CIN / 4;
+    const int OHW = q.OH * q.OW, HW = q.H * q.W;
+    f32x4 *lp = reinterpret_cast<f32x4 *>(wide_w + (size_t)Cout * CIN * PT);   // [CIN * Cx][pixel][tap]: (mu, iv, cs, -)
+    const int px = threadIdx.x & (PT - 1), slot = threadIdx.x / PT;
+    int tile_x, chunk_y;
+    if (!wide_block_of(q, tile_x, chunk_y, B, per_wg)) return;
+    const int p0 = tile_x * PT;
+    const int p = p0 + px;
+    wide_tile_weights<CIN>(Wl, wide_w, q.C, Cout, OHW, p0);
+    for (int e = threadIdx.x; e < CIN * Cx * PT * 4; e += 256) {
+        const int t = e & 3, pp = (e >> 2) & (PT - 1), kc = e / (4 * PT);
+        const int pe = p0 + pp;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (pe < OHW) {
+            const int oh = pe / q.OW, ow = pe - oh * q.OW;
+            const int th = t / q.kw, tw = t - th * q.kw;
+            const int ih = oh * q.sh - q.pt + th * q.dh, iw = ow * q.sw - q.pl + tw * q.dw;
+            if (t < q.kh * q.kw && ih >= 0 && ih < q.H && iw >= 0 && iw < q.W) {
+                const int64_t o = (int64_t)kc * HW + ih * q.W + iw;
+                const float sg = scale[o];
+                v[0] = loc[o];
+                v[1] = 0.5f / (sg * sg);
+                v[2] = -logf(sg) - kLogSqrt2Pi;
+            }
+        }
+        lp[e] = v;
+    }
+    __syncthreads();
+    if (p >= OHW) return;
+    const int oh = p / q.OW, ow = p - oh * q.OW;
+    int tclamp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int th = t / q.kw, tw = t - th * q.kw;
+        const int ih = oh * q.sh - q.pt + th * q.dh, iw = ow * q.sw - q.pl + tw * q.dw;
+        tclamp[t] = (t < q.kh * q.kw && ih >= 0 && ih < q.H && iw >= 0 && iw < q.W) ? ih * q.W + iw : 0;
+    }
+    const int b_begin = chunk_y * per_wg, b_end = min(B, b_begin + per_wg);
+    constexpr int NB = 2;
+    for (int b0 = b_begin + slot * NB; b0 < b_end; b0 += (256 / PT) * NB) {
+        float ev[NB][CIN], la[NB][CIN], m0[NB];
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+            const float *src = x + (size_t)min(b0 + s, B - 1) * Cx * HW;
+#pragma unroll
+            for (int k = 0; k < CIN; ++k) ev[s][k] = 0.f;
+            for (int cx = 0; cx < Cx; ++cx) {
+                float xv[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) xv[t] = src[(size_t)cx * HW + tclamp[t]];
+#pragma unroll
+                for (int k = 0; k < CIN; ++k) {
+                    const f32x4 *pk = lp + ((size_t)(k * Cx + cx) * PT + px) * 4;
+                    float a = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const f32x4 pr = pk[t];
+                        const float d = xv[t] - pr[0];
+                        a += nan_to_num_f(fmaf(-(d * d), pr[1], pr[2]));
+                    }
+                    ev[s][k] += a;
+                }
+            }
+            float m = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < CIN; ++k) m = fmaxf(m, ev[s][k]);
+            m0[s] = (m == -INFINITY) ? 0.f : m;
+#pragma unroll
+            for (int k = 0; k < CIN; ++k) {
+                la[s][k] = ev[s][k];
+                ev[s][k] = __expf(ev[s][k] - m0[s]);
+            }
+        }
+        for (int o = 0; o < Cout; ++o) {
+            float v[NB];
+#pragma unroll
+            for (int s = 0; s < NB; ++s) v[s] = 0.f;
+            const f32x4 *wp = reinterpret_cast<const f32x4 *>(wide_w) + (size_t)o * C4 * PT + px;
+#pragma unroll
+            for (int c4 = 0; c4 < C4; ++c4) {
+                const f32x4 w = wp[c4 * PT];
+#pragma unroll
+                for (int s = 0; s < NB; ++s) {
+                    v[s] = fmaf(w[0], ev[s][4 * c4], v[s]);
+                    v[s] = fmaf(w[1], ev[s][4 * c4 + 1], v[s]);
+                    v[s] = fmaf(w[2], ev[s][4 * c4 + 2], v[s]);
+                    v[s] = fmaf(w[3], ev[s][4 * c4 + 3], v[s]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < NB; ++s) {
+                if (b0 + s >= b_end) break;
+                float r;
+                if (v[s] < 1e-30f) {
+                    // exact log-domain pass (rare)
+                    const float *lw = LW + (size_t)o * q.C * OHW + p;
+                    float mm = -INFINITY;
+#pragma unroll
+                    for (int k = 0; k < CIN; ++k) mm = fmaxf(mm, la[s][k] + lw[(size_t)k * OHW]);
+                    if (mm > -INFINITY) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int k = 0; k < CIN; ++k) acc += expf(la[s][k] + lw[(size_t)k * OHW] - mm);
+                        r = mm + logf(acc);
+                    } else {
+                        r = -INFINITY;
+                    }
+                } else {
+                    r = fmaf(__builtin_amdgcn_logf(v[s]), 0.6931471805599453f, m0[s]);
+                }
+                out[((size_t)(b0 + s) * Cout + o) * OHW + p] = r;
+            }
+        }
+    }
+}
+
 // SpatialGaussianLayer + the first depthwise product + sum level in one launch (eval route; models/dgcspn.py:134-147 for
-// i = 0, 1): the pooling level only -- 2 x 2 window, stride 2, no padding, even output width, rows 16-byte aligned, 16 or
-// 32 leaf channels -- DPK_EUNSUPPORTED otherwise (the caller runs dpk_spatial_gaussian_forward + dpk_spatial_prodsum_forward).
+// i = 0, 1): 2 x 2 windows, 8 / 16 / 32 leaf channels, up to 32 sum channels -- DPK_EUNSUPPORTED otherwise (the caller runs
+// dpk_spatial_gaussian_forward + dpk_spatial_prodsum_forward).  DPK_DGC_LEAF_FUSE_MIN_K (measurement only) raises the
+// smallest channel count that takes this route.
 extern "C" int dpk_spatial_leaf_prodsum_forward(const float *x, const float *loc, const float *scale, int64_t B, int32_t Cx,
                                                 int32_t K, int32_t H, int32_t W, int32_t OH, int32_t OW, int32_t kh, int32_t kw,
                                                 int32_t sh, int32_t sw, int32_t dh, int32_t dw, int32_t pad_top,
@@ -1569,11 +1698,18 @@ extern "C" int dpk_spatial_leaf_prodsum_forward(const float *x, const float *loc
     DPK_REQUIRE(B >= 0 && Cout > 0 && Cx > 0, DPK_EINVAL, "spatial_leaf_prodsum: bad sizes");
     DPK_REQUIRE(weight && ws && loc && scale, DPK_EINVAL, "spatial_leaf_prodsum: null pointer");
     const int OHW = OH * OW;
-    const size_t lds = (size_t)Cout * K * kWidePix * 4 + (size_t)K * Cx * (kWidePix / 2) * 8 * 16;
-    const bool ok = (K == 16 || K == 32) && Cout <= 32 && kh == 2 && kw == 2 && sh == 2 && sw == 2 && dh == 1 && dw == 1 &&
-                    pad_top == 0 && pad_left == 0 && (OW - 1) * 2 + 1 < W && (OH - 1) * 2 + 1 < H && (OW % 2) == 0 &&
-                    (W % 4) == 0 && (OHW % 2) == 0 && lds <= 150 * 1024 && B <= INT32_MAX / 2 &&
-                    (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0;
+    const size_t lds = (size_t)Cout * K * kWidePix * 4 + (size_t)K * Cx * kWidePix * 4 * 16;   // (both kernels: 64 parameter slots per (k, cx))
+    const bool pool = (K == 16 || K == 32) && kh == 2 && kw == 2 && sh == 2 && sw == 2 && dh == 1 && dw == 1 &&
+                      pad_top == 0 && pad_left == 0 && (OW - 1) * 2 + 1 < W && (OH - 1) * 2 + 1 < H && (OW % 2) == 0 &&
+                      (W % 4) == 0 && (OHW % 2) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(out) & 7) == 0;
+    // (the general form evaluates an input pixel's leaf once per window that taps it -- four times at stride 1: for 8 leaf
+    // channels that costs what the leaf map's round trip saves, 186 us against 76 + 110 on config 4's first level, so the
+    // 8-channel models keep the leaf kernel + the streaming level; DPK_DGC_LEAF_FUSE_MIN_K: measurement only)
+    const char *leaf_env = getenv("DPK_DGC_LEAF_FUSE_MIN_K");   // (per call: the tests switch it)
+    const int leaf_min_k = leaf_env ? atoi(leaf_env) : 16;
+    const bool ok = (K == 8 || K == 16 || K == 32) && (pool || K >= leaf_min_k) && Cout <= 32 && kh == 2 && kw == 2 &&
+                    lds <= 150 * 1024 && B <= INT32_MAX / 2;
     if (!ok) {
         set_error("spatial_leaf_prodsum: outside the fused first level's envelope");
         return DPK_EUNSUPPORTED;
@@ -1594,13 +1730,17 @@ extern "C" int dpk_spatial_leaf_prodsum_forward(const float *x, const float *loc
     hipEvent_t pev0, pev1;
     profile_take(&pev0, &pev1, DPK_KERNEL_SPATIAL_PRODSUM);
     if (pev0) (void)hipEventRecord(pev0, st);
-    if (K == 16) {
-        if (int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&spatial_leaf_pool_prodsum_kernel<16>), 160 * 1024)) return lrc;
-        DPK_LAUNCH((spatial_leaf_pool_prodsum_kernel<16>), wgrid, dim3(256), lds, st, x, loc, scale, Cx, Wl, LW, Bi, q, Cout, out, per_wg);
-    } else {
-        if (int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&spatial_leaf_pool_prodsum_kernel<32>), 160 * 1024)) return lrc;
-        DPK_LAUNCH((spatial_leaf_pool_prodsum_kernel<32>), wgrid, dim3(256), lds, st, x, loc, scale, Cx, Wl, LW, Bi, q, Cout, out, per_wg);
-    }
+#define DPK_LEAF_FUSED(KERN)                                                                                               \
+    do {                                                                                                                   \
+        if (int lrc = ensure_dynamic_lds(reinterpret_cast<const void *>(&KERN), 160 * 1024)) return lrc;                  \
+        DPK_LAUNCH((KERN), wgrid, dim3(256), lds, st, x, loc, scale, Cx, Wl, LW, Bi, q, Cout, out, per_wg);              \
+    } while (0)
+    if (pool && K == 16) DPK_LEAF_FUSED(spatial_leaf_pool_prodsum_kernel<16>);
+    else if (pool) DPK_LEAF_FUSED(spatial_leaf_pool_prodsum_kernel<32>);
+    else if (K == 8) DPK_LEAF_FUSED(spatial_leaf_prodsum_kernel<8>);
+    else if (K == 16) DPK_LEAF_FUSED(spatial_leaf_prodsum_kernel<16>);
+    else DPK_LEAF_FUSED(spatial_leaf_prodsum_kernel<32>);
+#undef DPK_LEAF_FUSED
     if (pev1) (void)hipEventRecord(pev1, st);
     DPK_CHECK_LAUNCH("spatial_leaf_pool_prodsum_kernel");
     return DPK_OK;

@@ -389,8 +389,9 @@ int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C, int32_t H
 /* SpatialGaussianLayer followed by the FIRST depthwise product + sum level, eval route, in one launch
  * (models/dgcspn.py:134-147 at i = 0, 1; layers/dgcspn.py:101-120 for the leaf): x [B,Cx,H,W] (NaN = marginalised),
  * loc / scale [K,Cx,H,W], weight [Cout,K,OH,OW], workspace and flags as dpk_spatial_prodsum_forward.  The [B,K,H,W] leaf
- * map is never written.  Built for the pooling level (2 x 2 window, stride 2, no padding, even output width, W % 4 == 0,
- * K = 16 or 32, Cout <= 32); DPK_EUNSUPPORTED otherwise: the caller runs the two entry points it replaces.            */
+ * map is never written.  2 x 2 windows (any stride, dilation, padding), K = 8, 16 or 32, Cout <= 32; the pooling level
+ * (stride 2, no padding, even output width, W % 4 == 0) takes a form with 16-byte image loads.  DPK_EUNSUPPORTED
+ * otherwise: the caller runs the two entry points it replaces.                                                       */
 int dpk_spatial_leaf_prodsum_forward(const float *x, const float *loc, const float *scale, int64_t B, int32_t Cx, int32_t K,
                                      int32_t H, int32_t W, int32_t OH, int32_t OW, int32_t kh, int32_t kw, int32_t sh,
                                      int32_t sw, int32_t dh, int32_t dw, int32_t pad_top, int32_t pad_left,

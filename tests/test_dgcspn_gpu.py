@@ -225,17 +225,21 @@ def test_wide_fused_level_against_oracle(shape, padding, stride, dil, cout, B):
     assert torch.equal(again, got[5:40])                    # a sample's result does not depend on its place in the batch
 
 
-@pytest.mark.parametrize('shape,k,cout,B', [((1, 28, 28), 16, 32, 150), ((3, 12, 12), 16, 20, 67), ((2, 8, 8), 32, 32, 33)])
-def test_fused_leaf_and_first_level_against_oracle(shape, k, cout, B):
-    """Round 5: the Gaussian leaf layer folded into the first (pooling) level of the eval route
+@pytest.mark.parametrize('shape,k,cout,B,padding,stride,dil', [
+    ((1, 28, 28), 16, 32, 150, 'valid', 2, 1), ((3, 12, 12), 16, 20, 67, 'valid', 2, 1), ((2, 8, 8), 32, 32, 33, 'valid', 2, 1),
+    ((1, 28, 28), 8, 8, 150, 'full', 1, 1), ((3, 9, 9), 16, 12, 41, 'full', 1, 2), ((1, 11, 11), 32, 32, 37, 'valid', 2, 1),
+    ((2, 7, 7), 8, 5, 300, 'final', 1, 4)])
+def test_fused_leaf_and_first_level_against_oracle(shape, k, cout, B, padding, stride, dil, monkeypatch):
+    """Round 5: the Gaussian leaf layer folded into the first level of the eval route (the pooling form and the general one)
     (dpk_spatial_leaf_prodsum_forward: the [B, K, H, W] leaf map is never written) against the oracle's leaf + product +
     sum: several image channels, marginalised (NaN) pixels and a whole marginalised image, scales away from 1, a batch
     that is not a multiple of the sample slots; the result of a sample does not depend on its place in the batch."""
     from deeprob.spn.layers.dgcspn import SpatialGaussianLayer, SpatialProductLayer, SpatialSumLayer
     from deeprob.hip import ops_spatial
+    monkeypatch.setenv('DPK_DGC_LEAF_FUSE_MIN_K', '8')     # (by default 8-channel models keep leaf kernel + streaming level: faster)
     gen = torch.Generator().manual_seed(29)
     leaf = SpatialGaussianLayer(shape, k, optimize_scale=True).cuda()
-    prod = SpatialProductLayer((k,) + tuple(shape[1:]), 2, 'valid', 2, 1, depthwise=True).cuda()
+    prod = SpatialProductLayer((k,) + tuple(shape[1:]), 2, padding, stride, dil, depthwise=True).cuda()
     ssum = SpatialSumLayer(prod.out_features, cout).cuda()
     with torch.no_grad():
         leaf.scale.copy_(0.3 + 2.0 * torch.rand(leaf.scale.shape, generator=gen))
@@ -246,10 +250,10 @@ def test_fused_leaf_and_first_level_against_oracle(shape, k, cout, B):
     x[1, :, ::2, 1::3] = float('nan')
     x[2] = 40.0                                             # log-densities of -800 and below
     lv = dorc.spatial_gaussian(x, leaf.loc.detach().cpu(), leaf.scale.detach().cpu())
-    want = dorc.spatial_sum(dorc.spatial_product(lv, prod.pad, 2, 1, True), ssum.weight.detach().cpu())
+    want = dorc.spatial_sum(dorc.spatial_product(lv, prod.pad, stride, dil, True), ssum.weight.detach().cpu())
     with torch.no_grad():
         got = ops_spatial.spatial_leaf_prodsum(x.cuda(), leaf, prod, ssum.weight, ssum._ws)
-        assert got is not None                              # (the pooling level with an even output width: inside the envelope)
+        assert got is not None                              # (2 x 2 windows, 8 / 16 / 32 leaf channels: inside the envelope)
         again = ops_spatial.spatial_leaf_prodsum(x.cuda()[3:29], leaf, prod, ssum.weight, ssum._ws)
         chained = ops_spatial.spatial_prodsum(leaf(x.cuda()), prod, ssum.weight, ssum._ws)
     fin = torch.isfinite(want)
