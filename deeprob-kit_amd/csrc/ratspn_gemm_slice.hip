@@ -21,9 +21,13 @@
 //   * the seven partial accumulators of a block meet in LDS (56 KB, a layout that is conflict free for the MFMA-shaped
 //     writers and for the readers) and all EIGHT waves evaluate the upper layers, 16 lanes per sample, one (repetition,
 //     partition) per lane, seven partials added in a fixed order; two s_barriers per block;
-//   * the prologue is the request path again (196 KB of table + 98 KB of x per compute unit): the table is loaded by asm
-//     statements inside the FIRST block's K loop, three K-steps ahead, while that loop already requests the second block.
-// What was measured on the way and not kept (git history of this file, DESIGN 3.14): an eighth wave evaluating the upper
+//   * the prologue is the request path again: the table travels WITHOUT its structural zeros (a variable belongs to one of a
+//     repetition's four regions: 7 KB + 1 KB of keep-masks per wave instead of 28 KB, ratspn_gemm_prep.h: stab / smask) by
+//     LDS-DMA into the wave's idle partial-accumulator block and is expanded from there, K-step kk + 1 under K-step kk's
+//     products of the first block (broadcast ds_read_b128 + AND);
+//   * a launch that checks its parameter tables (the default of model(x)) does so on the EIGHTH wave of its first np
+//     work-groups while the other seven run the first block; counters that only grow, nothing reset (slice_verify_share).
+// What was measured on the way and not kept (git history of this file, DESIGN 3.3): an eighth wave evaluating the upper
 // layers alone (15k cycles per block: the bottleneck); a loader wave + LDS counters instead of barriers (a wave holds at
 // most 63 requests -- vmcnt is 6 bits -- and becomes latency bound); mixed forms of the two; the slot as the unit of the
 // stream (period >= request latency + issue of 98 requests + copy); a row-run slot layout (3 % cheaper requests, does not
@@ -52,9 +56,6 @@ __host__ __device__ constexpr int slice_lds_bytes(int NT, int w0_floats) {
     return kSliceCompute * kSliceSlot + kSliceCompute * slice_part_bytes(NT) + kSliceCompute * 256 + 128 + 1024 + 0 * w0_floats;
 }
 
-#ifndef DPK_SL_VERIFY
-#define DPK_SL_VERIFY 1
-#endif
 #ifdef DPK_TIMELINE
 #define SL_STAMP(row, slot) do { __builtin_amdgcn_sched_barrier(0); if (a.dbg && lane == 0 && (row) < 16 && blockIdx.x < 256) a.dbg[(((int64_t)blockIdx.x * 8 + wave) * 16 + (row)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
     SL_STAMP(15, 0);
     // (the eighth wave, idle until the first barrier: the launch's table check, before anything of the stream is live)
     unsigned long long t_poll = 0ull;
-    if (!slicer && (DPK_SL_VERIFY && pa.np > 0)) {
+    if (!slicer && pa.np > 0) {
         const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
         __builtin_amdgcn_s_setprio(3);   // (its requests in front of the same SIMD's slice wave's: the chain below is three round trips)
         slice_verify_share<I>(pa, lane, ctl_l);
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
     }
     // (the eighth wave polls for the verdict up to 4.5 us after entry -- 5 at two or more blocks per work-group: the first
     // barrier, 5.8 / 7.7 us after entry, is not kept waiting)
-    if (!slicer && (DPK_SL_VERIFY && pa.np > 0) && lane == 0) slice_verdict_poll(pa, ctl_l, t_poll);
+    if (!slicer && pa.np > 0 && lane == 0) slice_verdict_poll(pa, ctl_l, t_poll);
     bool model_ok;
     {   // (through the scalar cache: a vector load here would put a compiler-counted wait into the request queue above)
         cint_p ce = as_const(a.elig);
@@ -784,9 +785,9 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
     }
     SL_STAMP(15, 2);
     // ---- the launch's verdict on its tables, the last block's verdict, then what left the fast path ------------------------
-    if ((DPK_SL_VERIFY && pa.np > 0) && !slicer && lane == 0) slice_verdict_wait(pa, ctl_l);
+    if (pa.np > 0 && !slicer && lane == 0) slice_verdict_wait(pa, ctl_l);
     __syncthreads();
-    const bool tables_stale = (DPK_SL_VERIFY && pa.np > 0) && (ctl_l[0] & 1u) != 0u;
+    const bool tables_stale = pa.np > 0 && (ctl_l[0] & 1u) != 0u;
     if (it > 0) {
         const lunsigned *fl = flag_l + ((it - 1) & 1) * 8;
         const unsigned any_bad = (fl[0] | fl[1]) | (fl[2] | fl[3]) | (fl[4] | fl[5]) | (fl[6] | fl[7]);
