@@ -388,8 +388,12 @@ __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const
     const int D = a.D, NT = a.reps;
     const int NKS = (D + 15) >> 4;
     const int mb = (int)blockIdx.x - np;               // model work-group
-    const int grp = NW == kWideWaves ? 0 : (mb & 1);   // which half of the repetitions
-    const int blk = NW == kWideWaves ? mb : (mb >> 1);
+    // (NW = 4: the two work-groups of a block stage the same x tile -- consecutive work-groups go to different XCDs, each
+    // with its own L2, so the pair is work-groups L and L + 8: the second read of the tile is an L2 hit.  The host pads the
+    // grid to whole groups of 16; work-groups beyond the last block leave at once.)
+    const int grp = NW == kWideWaves ? 0 : ((mb >> 3) & 1);   // which half of the repetitions
+    const int blk = NW == kWideWaves ? mb : ((mb >> 4) * 8 + (mb & 7));
+    if (NW < kWideWaves && (int64_t)blk * 32 >= a.B) return;
     const int64_t b0 = (int64_t)blk * 32;
     const int nvalid = (int)min((int64_t)32, a.B - b0);
     const bool compute = wave < NW;                    // (NW = 4: waves 4..7 only help with the x tile)
@@ -1000,8 +1004,9 @@ static int gemm_wide_launch_nw(const GemmArgs &a, const GemmPrepArgs &p, hipStre
     profile_take(&ev0, &ev1, DPK_KERNEL_RATSPN_FUSED);
     if (ev0) (void)hipEventRecord(ev0, st);
     GemmPrepArgs pp = p;
-    const int model_wgs = (int)cdiv(a.B, 32) * (NW == kWideWaves ? 1 : 2);
-    pp.readers = p.np + model_wgs;
+    const int blocks = (int)cdiv(a.B, 32);
+    const int model_wgs = NW == kWideWaves ? blocks : 2 * (int)align_up(blocks, 8);   // (NW = 4: whole groups of 16, see the kernel)
+    pp.readers = p.np + (NW == kWideWaves ? blocks : 2 * blocks);
     DPK_LAUNCH(kern, dim3(p.np + model_wgs), dim3(kWideWaves * 64), lds, st, a, pp);
     if (ev1) (void)hipEventRecord(ev1, st);
     DPK_CHECK_LAUNCH("ratspn_gemm_wide_kernel");
