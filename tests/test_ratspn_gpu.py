@@ -906,3 +906,30 @@ def test_training_forward_golden_gradients(golden, name):
         if 'grad.' + k in g.files:
             tol = max(GRAD_TOL, 4.0 * grad_err(g['grad.' + k], ref64[k]))
             assert grad_err(p.grad.cpu().numpy(), g['grad.' + k]) <= tol, k
+
+def test_eight_channel_blocks_shared_by_two_work_groups_agree_with_whole_blocks():
+    """Round 5: up to 128 blocks of 32 samples the 8-channel kernel gives a block to two work-groups (four repetitions each,
+    root partials merged through the workspace on a ticket that is only counted up); larger launches keep one work-group
+    per block.  The same samples through both forms, launches of different sizes interleaved (the tickets of a block are
+    drawn twice per launch whatever ran before), a ragged last block, against each other and the oracle."""
+    from deeprob.spn.models import GaussianRatSpn
+    from oracle import ratspn_oracle as orc
+    torch.manual_seed(31)
+    model = GaussianRatSpn(784, rg_depth=2, rg_repetitions=8, rg_batch=8, rg_sum=8, random_state=42).cuda().eval()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    x = torch.randn(6001, 784, generator=torch.Generator().manual_seed(32))
+    xd = x.cuda()
+    with torch.no_grad():
+        whole = model(xd)                                   # 188 blocks: one work-group per block
+        parts = []
+        for lo, hi in ((0, 2000), (2000, 2977), (2977, 6001)):   # 63, 31 (ragged) and 95 blocks: shared
+            parts.append(model(xd[lo:hi]))
+            model(xd[:50])                                  # (a two-block launch in between)
+        chunks = torch.cat(parts)
+        again = model(xd[2000:2977])
+    rows = torch.randint(0, 6001, (64,), generator=torch.Generator().manual_seed(33))
+    want = orc.ratspn_forward(sd, x[rows]).numpy()
+    assert rel_err(chunks[rows.cuda()].cpu().numpy(), want) <= 1e-5
+    assert rel_err(whole[rows.cuda()].cpu().numpy(), want) <= 1e-5
+    assert rel_err(chunks.cpu().numpy(), whole.cpu().numpy()) <= 2e-6
+    assert torch.equal(again, parts[1])                      # the same launch twice: bit for bit

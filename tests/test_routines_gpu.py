@@ -271,3 +271,33 @@ def test_graphed_train_step_is_keyed_on_the_shard_sizes():
         assert len(replays) == 2
     finally:
         parallel.set_shard_sizes(None)
+
+def test_leaf_parameter_gradients_of_a_batch_are_the_sum_over_its_halves():
+    """Round 5: up to 2048 samples the leaf layer's parameter gradients are moment GEMMs on the matrix cores
+    (csrc/ratspn_layers.hip: leaf_bwd_moment_kernel), larger batches keep the vector-ALU kernel with atomics.  The gradient
+    of a sum over samples is additive: 3000 samples in one call (the second) against two calls of 1500 (the first), with
+    marginalised entries, trainable scales, means and scales away from their initial values."""
+    from deeprob.spn.models import GaussianRatSpn
+    leaf = GaussianRatSpn(784, rg_depth=2, rg_repetitions=4, rg_batch=8, rg_sum=8, optimize_scale=True,
+                          random_state=42).cuda().train().base_layer
+    gen = torch.Generator().manual_seed(41)
+    with torch.no_grad():
+        leaf.loc.copy_(torch.randn(leaf.loc.shape, generator=gen))
+        leaf.scale.copy_(0.5 + torch.rand(leaf.scale.shape, generator=gen))
+    x = torch.randn(3000, 784, generator=gen)
+    x[torch.rand(x.shape, generator=gen) < 0.05] = float('nan')
+    xd = x.cuda()
+    g = torch.randn(3000, leaf.loc.shape[0], 8, generator=gen).cuda()
+
+    def grads(lo, hi):
+        leaf.zero_grad(set_to_none=True)
+        out = leaf(xd[lo:hi])
+        out.backward(g[lo:hi])
+        return leaf.loc.grad.clone(), leaf.scale.grad.clone()
+
+    l_all, s_all = grads(0, 3000)
+    l_a, s_a = grads(0, 1500)
+    l_b, s_b = grads(1500, 3000)
+    for whole, parts in ((l_all, l_a + l_b), (s_all, s_a + s_b)):
+        scale = whole.abs().max().item()
+        assert scale > 0 and (whole - parts).abs().max().item() <= 2e-5 * scale
