@@ -10,6 +10,23 @@ from deeprob.flows.utils import DequantizeLayer, LogitLayer, BatchNormLayer1d
 from deeprob.flows.layers.coupling import CouplingLayer1d
 
 
+def _sum_log_dets(ds, x: torch.Tensor):
+    """The layers' log-det-Jacobian terms added up.  The reference adds them one by one (flows/models/base.py:182-193);
+    on the device that is one tiny element-wise launch per layer -- ten of a RealNVP-1D training step's hundred.  Per-sample
+    vectors [B] and one-element constants are therefore stacked and summed in ONE reduction (same terms; the additions
+    associate differently, 1 ulp); anything else keeps the loop."""
+    if x.is_cuda and x.dim() >= 1 and len(ds) >= 3:
+        B = x.shape[0]
+        tens = [d for d in ds if torch.is_tensor(d)]
+        if len(tens) == len(ds) and all(d.is_cuda and d.dtype == tens[0].dtype and (d.numel() == 1 or tuple(d.shape) == (B,))
+                                        for d in tens) and any(tuple(d.shape) == (B,) for d in tens):
+            return torch.stack([d.reshape(-1).expand(B) if d.numel() == 1 and tuple(d.shape) != (B,) else d for d in tens]).sum(0)
+    total = 0.0
+    for d in ds:
+        total = total + d
+    return total
+
+
 class NormalizingFlow(ProbabilisticModel):
     has_rsample = True
 
@@ -171,11 +188,11 @@ class NormalizingFlow(ProbabilisticModel):
 
     def apply_backward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """data -> latent through every layer (reference :182-193)."""
-        ildj = 0.0
+        ds = []
         for layer in self.layers:
             x, d = layer.apply_backward(x)
-            ildj = ildj + d
-        return x, ildj
+            ds.append(d)
+        return x, _sum_log_dets(ds, x)
 
     def apply_forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """latent -> data through the layers in reverse (reference :195-206)."""
