@@ -5,7 +5,7 @@ import torch
 
 from oracle import dgcspn_oracle as dorc
 from tests.dgc_cases import CASES, SMALL, build_dgc, plan_of
-from tests.util import rel_err, grad_err
+from tests.util import rel_err, grad_err, report_measured
 
 pytestmark = pytest.mark.gpu
 
@@ -281,11 +281,23 @@ def test_full_size_properties():
     for the other samples."""
     from deeprob.spn.models import DgcSpn
     torch.manual_seed(5)
-    model = DgcSpn((1, 28, 28), n_batch=8, sum_channels=8, depthwise=True, n_pooling=0).cuda().eval()
+    model = DgcSpn((1, 28, 28), n_batch=8, sum_channels=8, depthwise=True, n_pooling=0).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    plan = dorc.schedule((1, 28, 28), 8, 8, True, 0)
+    model.cuda()
     x = torch.randn(8192, 1, 28, 28, device='cuda', generator=torch.Generator('cuda').manual_seed(0))
     x[777] = float('nan')
+    # 2048 rows drawn from the WHOLE batch (every slice of the streaming kernels' batch split) against the oracle
+    rows = torch.randint(0, 8192, (2048,), generator=torch.Generator().manual_seed(9))
+    rows[0], rows[1], rows[2] = 0, 8191, 777
     with torch.no_grad():
         ll = model(x)
+        xr = x[rows.cuda()].cpu()
+        want = np.concatenate([dorc.dgcspn_forward(sd, xr[i:i + 256], plan).numpy() for i in range(0, 2048, 256)])
+    err = rel_err(ll[rows.cuda()].cpu().numpy(), want)
+    report_measured('test_full_size_properties[DgcSpn config 4, B=8192] 2048 rows of the whole batch vs oracle', err, LL_TOL)
+    assert err <= LL_TOL
+    with torch.no_grad():
         part = model(x[1001:1001 + 2048])
         small = model(x[1001:1001 + 200])    # below the streaming kernels' batch threshold: the other route
         x2 = x.clone()

@@ -189,10 +189,20 @@ def test_full_size_round_trip():
     torch.manual_seed(10)
     flow = RealNVP1d(784)
     randomise_flow(flow, 11)
-    flow = flow.cuda().eval()
+    flow.eval()
+    sd = {k: v.detach().clone() for k, v in flow.state_dict().items()}
+    flow = flow.cuda()
     x = torch.randn(65536, 784, device='cuda', generator=torch.Generator('cuda').manual_seed(0))
+    # 2048 rows drawn from the WHOLE batch against the oracle: every tile position of the persistent coupling kernels
+    rows = torch.randint(0, 65536, (2048,), generator=torch.Generator().manual_seed(12))
+    rows[0], rows[1] = 0, 65535
     with torch.no_grad():
         ll = flow(x)
+        want = forc.flow_log_prob(sd, x[rows.cuda()].cpu()).numpy()
+    err = rel_err(ll[rows.cuda()].cpu().numpy(), want)
+    report_measured('test_full_size_round_trip[RealNVP1d config 5, B=65536] 2048 rows of the whole batch vs oracle', err, TOL)
+    assert err <= TOL
+    with torch.no_grad():
         u, ildj = flow.apply_backward(x)
         xr, ldj = flow.apply_forward(u)
         part = flow(x[777:777 + 4097])

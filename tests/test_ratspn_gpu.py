@@ -276,6 +276,38 @@ def test_full_size_properties():
             assert abs(acc[0].item() - lln.double().sum().item()) <= 1e-9 * abs(acc[0].item())
 
 
+def _oracle_rows(sd, x_rows, chunk=512):
+    """The oracle on a set of rows, in chunks (the (16,16) model's leaf temporaries are 1 GB per 1000 rows)."""
+    return np.concatenate([orc.ratspn_forward(sd, x_rows[i:i + chunk]).numpy() for i in range(0, x_rows.shape[0], chunk)])
+
+
+@pytest.mark.parametrize('B', [65536, 32768, 16384, 8192])
+@pytest.mark.parametrize('chan', [(2, 2), (8, 8), (16, 16)])
+def test_full_size_vs_oracle(chan, B):
+    """BASELINE configs 2 / 3 at their full launch sizes through the DEFAULT routing (65536 = the headline launch, 32768 /
+    16384 / 8192 = one rank's shard of config 3 and of the strong-scaling reading): 2048 rows drawn uniformly from the WHOLE
+    batch -- so that the later-iteration blocks of the persistent kernels (rotated K loop, re-requested K-step slots,
+    one-block-delayed commit) are hit, not only the first block of every work-group -- against the oracle, 1e-5."""
+    from deeprob.spn.models import GaussianRatSpn
+    torch.manual_seed(0)
+    model = GaussianRatSpn(784, rg_depth=2, rg_repetitions=8, rg_batch=chan[0], rg_sum=chan[1], random_state=42).eval()
+    with torch.no_grad():
+        model.base_layer.loc.mul_(1.5)      # away from the initialiser's scale, inside the fast path's envelope
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.cuda()
+    x = torch.randn(B, 784, device='cuda', generator=torch.Generator('cuda').manual_seed(B + chan[0]))
+    rows = torch.randint(0, B, (2048,), generator=torch.Generator().manual_seed(17))
+    rows[0], rows[1] = 0, B - 1
+    with torch.no_grad():
+        acc = torch.zeros(2, dtype=torch.float64, device='cuda')
+        ll = model._forward_fused(x, acc)
+    want = _oracle_rows(sd, x[rows.cuda()].cpu())
+    err = rel_err(ll[rows.cuda()].cpu().numpy(), want)
+    report_measured('test_full_size_vs_oracle[%dx%d, B=%d] 2048 rows of the whole batch' % (chan[0], chan[1], B), err, LL_TOL)
+    assert err <= LL_TOL
+    assert acc[1].item() == B and abs(acc[0].item() - ll.double().sum().item()) <= 1e-9 * abs(acc[0].item())
+
+
 @pytest.mark.parametrize('kw', [dict(rg_batch=8, rg_sum=8), dict(rg_batch=8, rg_sum=4, optimize_scale=True),
                                 dict(rg_batch=16, rg_sum=16), dict(rg_depth=1, rg_batch=8, rg_sum=8),
                                 dict(rg_depth=3, rg_batch=8, rg_sum=8, rg_repetitions=3)])
