@@ -312,6 +312,19 @@ __device__ __forceinline__ float nan_to_num_f(float t) {
     return fminf(fmaxf(t, -FLT_MAX), FLT_MAX);
 }
 
+// The argument of a responsibility, in_a + in_c + lw - out, for log-likelihoods of magnitude 10^2..10^3: added left to
+// right each of the three roundings is half an ulp of the LARGE operands (3e-5 at 560, 6e-5 at 1120) and lands in the
+// responsibility as a relative error of that size -- which the reference does not show, because its logsumexp normalises
+// the very same rounded terms (forward and backward errors cancel for the dominant input).  Here the large magnitudes
+// cancel exactly first: (hi, lo) = in_a + in_c without error (Knuth's two-sum), hi - out is exact when the two are within
+// a factor of two (Sterbenz; otherwise the term is e^{-|large|} = 0 either way), and what is rounded is small.
+struct TwoSum { float hi, lo; };
+__device__ __forceinline__ TwoSum two_sum(float a, float b) {
+    const float s = a + b, bb = s - a;
+    return {s, (a - (s - bb)) + (b - bb)};
+}
+__device__ __forceinline__ float resp_arg(const TwoSum ac, float lw, float out) { return (ac.hi - out) + (lw + ac.lo); }
+
 __device__ __forceinline__ float wave_reduce_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64 * kBwdWaves) void sum_bwd_kernel(const float *__
                 const float xo = xo8[q];
                 // an all -inf row has out = -inf: its gradient is defined as zero (reference: the
                 // masked_fill guard inside torch.logsumexp's backward gives the same)
-                const float t = (ob + q < S && xo > -INFINITY) ? g8[q] * expf(xv + lw[q] - xo) : 0.f;
+                const float t = (ob + q < S && xo > -INFINITY) ? g8[q] * expf((xv - xo) + lw[q]) : 0.f;   // (large magnitudes cancel first, exactly)
                 acc[q] += t;
                 tot += t;
             }
@@ -541,7 +541,19 @@ __global__ __launch_bounds__(256) void leaf_bwd_param_lds_kernel(
 constexpr int kLeafMomentMaxB = 2048;
 constexpr int kLeafMomentChunk = 64;               // samples a wave stages at a time
 constexpr int kLeafMomentStride = 36;              // floats between staged rows (32 + 4: the b128 writes of 8 rows spread over the banks)
-constexpr int kLeafMomentLds = 4 * 2 * kLeafMomentChunk * kLeafMomentStride * 4 + 32 * 32 * 2;   // staging (reused for the partial sums) + map
+constexpr int kLeafMomentExtra = (32 + 4 * 32 + 4 * 32 + 4) * 4;   // pivots, per-wave max |x - c| and sum |g|, the tile's verdict
+constexpr int kLeafMomentLds = 4 * 2 * kLeafMomentChunk * kLeafMomentStride * 4 + 32 * 32 * 2 + kLeafMomentExtra;   // staging (reused for the partial sums) + map + extras
+// Conditioning: raw moments lose d/ds = ((S2 - 2 mu S1 + mu^2 S0)/s^2 - S0)/s to cancellation once |mu| / s is
+// large (1e-3 .. 1e-2 relative for mu = 3, s = 0.1 or uint8-range data).  Two measures:
+//  (1) the moments are taken about a per-variable pivot c_f = midpoint of the means of the tile's rows that hold f
+//      (x - c_f as the B operand, mu - c_f in the epilogue): unstandardised data / small learned scales are back at the
+//      direct form's error (fp32 emulation: 8e-2 -> 1e-5);
+//  (2) what a pivot shared by the rows cannot fix -- channels of a region sitting on clusters many scales apart -- is
+//      DETECTED per entry from the moments themselves (the terms that cancel, N = |S2| + 2 |d| |S1| + d^2 |S0|, against the
+//      result and the entry's natural scale s^2 sum|g|; for mixed-sign g the bound sum|g| (max|x - c| + |d|)^2 instead), and
+//      a tile with such an entry evaluates its entries again in the direct form sum_b g ((x - mu)^2 / s^2 - 1) / s:
+//      correctness never depends on the data being well scaled, the fast path is only as fast as it is.
+constexpr float kLeafMomentTol = 2.5e-5f;          // accepted relative error of an entry from the cancellation (GRAD_TOL / 4)
 template <int DIST, bool WANT1>
 __global__ __launch_bounds__(256) void leaf_bwd_moment_kernel(
     const float *__restrict__ x, const float *__restrict__ g, int64_t B, int D, int R, int I, int d,
@@ -569,6 +581,29 @@ __global__ __launch_bounds__(256) void leaf_bwd_moment_kernel(
         const int f = (int)mask[o];
         if (f >= f0 && f < f0 + 32) jmap[rl][f - f0] = (short)j;
     }
+    float *piv = reinterpret_cast<float *>(reinterpret_cast<char *>(jmap) + 32 * 32 * 2);   // [32]
+    float (*devw)[32] = reinterpret_cast<float (*)[32]>(piv + 32);                            // [wave][column]
+    float (*gabw)[32] = reinterpret_cast<float (*)[32]>(piv + 32 + 4 * 32);                   // [wave][row]
+    int *redo = reinterpret_cast<int *>(piv + 32 + 8 * 32);
+    __syncthreads();
+    if (tid < 32) {
+        // the pivot of column tid: midpoint of the means of the rows that hold it (loads unconditional at a clamped
+        // position, selected afterwards: a load behind a branch is a round trip of its own)
+        float lo = INFINITY, hi = -INFINITY;
+        if (DIST == 0) {
+            for (int rl = 0; rl < nreg; ++rl) {
+                const int j = jmap[rl][tid];
+                for (int k = 0; k < I; ++k) {
+                    const float mu = p0[((int64_t)(r0 + rl) * I + k) * d + max(j, 0)];
+                    lo = j >= 0 ? fminf(lo, mu) : lo;
+                    hi = j >= 0 ? fmaxf(hi, mu) : hi;
+                }
+            }
+        }
+        piv[tid] = hi >= lo ? 0.5f * (lo + hi) : 0.f;
+    }
+    if (tid == 0) *redo = 0;
+    __syncthreads();
     // ---- the wave's quarter of the batch, staged CH samples at a time: 16-byte loads (a compute unit's request path
     // takes ~37 cycles per load INSTRUCTION: one 4-byte load per operand and K-step was 512 of them, 23 us) ----------------
     const int m = lane & 31, kh = lane >> 5;
@@ -580,6 +615,8 @@ __global__ __launch_bounds__(256) void leaf_bwd_moment_kernel(
     f32x16 a0, a1, a2;
 #pragma unroll
     for (int i = 0; i < 16; ++i) a0[i] = a1[i] = a2[i] = 0.f;
+    const float cm = piv[m];        // pivot of the lane's column
+    float dev = 0.f, gab = 0.f;     // max |x - c| of the lane's column, sum |g| of the lane's row (this K half)
     for (int64_t b = bq0; b < bq1; b += CH) {
         f32x4 gq[CH / 8], xq[CH / 8];
 #pragma unroll
@@ -608,13 +645,21 @@ __global__ __launch_bounds__(256) void leaf_bwd_moment_kernel(
             const float gv = gst[(2 * u + kh) * ST + m];
             const float xr = xst[(2 * u + kh) * ST + m];
             const bool live = xr == xr;                 // marginalised: no contribution
-            const float xl = live ? xr : 0.f;
+            const float xl = live ? xr - cm : 0.f;
+            dev = fmaxf(dev, fabsf(xl));
+            gab += fabsf(gv);
             a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, live ? 1.f : 0.f, a0, 0, 0, 0);
             a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, xl, a1, 0, 0, 0);
             if (DIST == 0 && WANT1) a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, xl * xl, a2, 0, 0, 0);
         }
     }
     __syncthreads();   // (every wave is done with its staging area: the partial sums take its place)
+    dev = fmaxf(dev, __shfl_xor(dev, 32, 64));
+    gab += __shfl_xor(gab, 32, 64);
+    if (lane < 32) {
+        devw[wave][m] = dev;
+        gabw[wave][m] = gab;
+    }
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
         const int i = (v >> 2) * 8 + kh * 4 + (v & 3);
@@ -643,11 +688,74 @@ __global__ __launch_bounds__(256) void leaf_bwd_moment_kernel(
             if (DIST == 0) {
                 const float mu = p0[po], sg = p1[po];
                 const float is2 = 1.f / (sg * sg);
-                if (gp0) gp0[po] = (s1 - mu * s0) * is2;
-                if (WANT1 && gp1) gp1[po] = (fmaf(mu, fmaf(mu, s0, -2.f * s1), s2) * is2 - s0) / sg;
+                const float dl = mu - piv[c], adl = fabsf(dl);
+                const float core1 = s1 - dl * s0;
+                const float core2 = fmaf(dl, fmaf(dl, s0, -2.f * s1), s2);
+                if (gp0) gp0[po] = core1 * is2;
+                if (WANT1 && gp1) gp1[po] = (core2 * is2 - s0) / sg;
+                // ---- did the pivot form cancel?  (header: measure (2)) ----
+                const float gabs = (gabw[0][i] + gabw[1][i]) + (gabw[2][i] + gabw[3][i]);
+                const float span = fmaxf(fmaxf(devw[0][c], devw[1][c]), fmaxf(devw[2][c], devw[3][c])) + adl;
+                const bool mixed = gabs > fabsf(s0) * 1.001f;          // g of both signs (or marginalised samples): the signed moments under-count
+                const float n1 = mixed ? gabs * span : fabsf(s1) + adl * fabsf(s0);
+                const float n2 = mixed ? gabs * span * span : fabsf(s2) + 2.f * adl * fabsf(s1) + dl * dl * fabsf(s0);
+                const float kap = fmaxf(4.f, (float)B * (1.f / 128.f)) * 5.96e-8f;   // accumulated rounding of a quarter-batch chain
+                bool bad = gp0 && kap * n1 > kLeafMomentTol * fmaxf(fabsf(core1), sg * gabs);
+                if (WANT1 && gp1) bad = bad || kap * n2 > kLeafMomentTol * fmaxf(fabsf(core2), sg * sg * gabs);
+                if (bad) *redo = 1;
             } else {
                 if (gp0) gp0[po] = s1 - s0 / (1.f + expf(-p0[po]));
             }
+        }
+    }
+    if (DIST != 0) return;
+    __syncthreads();
+    if (*redo == 0) return;
+    // ---- a tile with an ill-conditioned entry: its entries once more in the direct form (rare; x and g are L2 hits) ------
+    {
+        const int i = tid >> 3, c0 = (tid & 7) * 4;
+        const int rl = i / I, k = i - rl * I;
+        float mu[4], is2[4], sg[4], acc0[4], acc1[4];
+        int64_t po[4];
+        bool any = false;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int j = jmap[rl][c0 + cc];
+            po[cc] = j >= 0 ? ((int64_t)(r0 + rl) * I + k) * d + j : -1;
+            any = any || j >= 0;
+            const int64_t pc = j >= 0 ? po[cc] : 0;
+            mu[cc] = p0[pc];
+            sg[cc] = p1[pc];
+            is2[cc] = 1.f / (sg[cc] * sg[cc]);
+            acc0[cc] = acc1[cc] = 0.f;
+        }
+        if (!any) return;
+        const float *gcol = g + row0 + i;
+        for (int64_t b = 0; b < B; ++b) {
+            const float gv = gcol[b * RI];
+            float xv[4];
+            if (xvec) {
+                const f32x4 q = *reinterpret_cast<const f32x4 *>(x + b * D + f0 + c0);
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) xv[cc] = q[cc];
+            } else {
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) xv[cc] = x[b * D + min(f0 + c0 + cc, D - 1)];
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const bool live = xv[cc] == xv[cc];
+                const float dlt = live ? xv[cc] - mu[cc] : 0.f;
+                const float gl = live ? gv : 0.f;
+                acc0[cc] = fmaf(gl, dlt, acc0[cc]);
+                acc1[cc] = fmaf(gl, fmaf(dlt * dlt, is2[cc], -1.f), acc1[cc]);
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            if (po[cc] < 0) continue;
+            if (gp0) gp0[po[cc]] = acc0[cc] * is2[cc];
+            if (WANT1 && gp1) gp1[po[cc]] = acc1[cc] / sg[cc];
         }
     }
 }

@@ -142,11 +142,16 @@ __global__ __launch_bounds__(256) void prodsum_bwd_kernel(const LevelBwdArgs a) 
         for (int u = 0; u < UN; ++u) {
             const int64_t b = bb + (int64_t)u * WAVES * GPW;
             float tot = 0.f;
+            const TwoSum ac = two_sum(xa[u], xc[u]);
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 // an all -inf row has out = -inf: its gradient is defined as zero (sum_bwd_kernel, and the masked_fill
-                // guard inside torch.logsumexp's backward)
-                const float t = (in[u] && o[u][s] > -INFINITY) ? gg[u][s] * expf(xa[u] + xc[u] + lw[s] - o[u][s]) : 0.f;
+                // guard inside torch.logsumexp's backward).  The responsibilities of a sum node are normalised over its
+                // N*N inputs (the lanes of the group) instead of trusting the stored `out`, whose own rounding (half an ulp
+                // of ~560) would otherwise scale all of them alike.
+                const float e = (in[u] && o[u][s] > -INFINITY) ? expf(resp_arg(ac, lw[s], o[u][s])) : 0.f;
+                const float z = group_sum<NN>(e);
+                const float t = z > 0.f ? gg[u][s] * (e / z) : 0.f;
                 acc[s] += t;
                 tot += t;
             }
@@ -247,10 +252,11 @@ __global__ __launch_bounds__(256) void prodsum16_bwd_kernel(const LevelBwdArgs a
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const bool in = bb + u < b1;
+            const TwoSum ac = two_sum(xa[u], xc[u]);
             float tot = 0.f;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                const float t = (in && o[u][s] > -INFINITY) ? gg[u][s] * expf(xa[u] + xc[u] + lw[s] - o[u][s]) : 0.f;
+                const float t = (in && o[u][s] > -INFINITY) ? gg[u][s] * expf(resp_arg(ac, lw[s], o[u][s])) : 0.f;
                 acc[s] += t;
                 tot += t;
             }
@@ -292,6 +298,8 @@ __global__ __launch_bounds__(1024) void prodroot_bwd_kernel(const LevelBwdArgs a
     constexpr int NN = N * N;
     __shared__ float red[16][CB];
     __shared__ float bc[2][CB];
+    __shared__ float zred[16][4 * CB];
+    __shared__ float zsum[4 * CB];
     __shared__ unsigned last_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int P = a.P, M = P * NN, C = a.S;
@@ -362,11 +370,33 @@ __global__ __launch_bounds__(1024) void prodroot_bwd_kernel(const LevelBwdArgs a
             float acc[CB];
 #pragma unroll
             for (int q = 0; q < CB; ++q) acc[q] = 0.f;
+            // responsibilities of the root's M inputs, normalised over the work-group (= all inputs of a class) instead of
+            // trusting the stored `out`: its rounding -- half an ulp of ~1100, 6e-5 -- would scale every gradient of the
+            // sample alike (see two_sum in common.h)
+            float e[TB][CB];
+#pragma unroll
+            for (int u = 0; u < TB; ++u) {
+                const TwoSum ac = two_sum(xa[u], xc[u]);
+#pragma unroll
+                for (int q = 0; q < CB; ++q) {
+                    e[u][q] = (o[u][q] > -INFINITY) ? expf(resp_arg(ac, lw[q], o[u][q])) : 0.f;
+                    const float zw = wave_reduce_sum(e[u][q]);
+                    if (lane == 0) zred[wave][u * CB + q] = zw;
+                }
+            }
+            __syncthreads();
+            if (tid < TB * CB) {
+                float z = 0.f;
+                for (int w = 0; w < nw; ++w) z += zred[w][tid];
+                zsum[tid] = z;
+            }
+            __syncthreads();
 #pragma unroll
             for (int u = 0; u < TB; ++u)
 #pragma unroll
                 for (int q = 0; q < CB; ++q) {
-                    const float t = (o[u][q] > -INFINITY) ? gg[u][q] * expf(xa[u] + xc[u] + lw[q] - o[u][q]) : 0.f;
+                    const float z = zsum[u * CB + q];
+                    const float t = z > 0.f ? gg[u][q] * (e[u][q] / z) : 0.f;
                     acc[q] += t;
                     tot[u] += t;
                 }

@@ -109,24 +109,26 @@ def test_backward_golden(golden, name):
         loss = model.loss(model(x), y)
         loss.backward()
     assert abs(loss.item() - float(g['loss'])) <= LL_TOL * max(1.0, abs(float(g['loss'])))
-    # Tolerance: GRAD_TOL, widened to the reference's OWN fp32 noise where that is larger.  The
-    # discriminative loss differentiates softmax(out) - onehot, which cancels catastrophically for
-    # confident samples, so the golden (fp32) gradient itself sits up to ~1e-3 away from the fp64 one.
+    # Bar (in the form the coupling tests use): distance to the FP64 oracle <= GRAD_TOL, or -- where the
+    # reference's own fp32 gradient (the golden) is further than half of that from fp64 -- twice the golden's own distance.
+    # (The discriminative loss differentiates softmax(out) - onehot, which cancels for confident samples; the generative
+    # models' responsibilities carry the fp32 rounding of log-likelihoods of magnitude 10^3.)  Never "distance to the golden
+    # within a multiple of its noise": that admits a result 5x further from the truth than the reference.
     ref64 = _oracle_grads_fp64(g)
 
-    def tol(key):
-        return max(GRAD_TOL, 4.0 * grad_err(g['grad.' + key], ref64[key]))
+    def check(key, got):
+        own = grad_err(g['grad.' + key], ref64[key])
+        tol = max(GRAD_TOL, 2.0 * own)
+        err = grad_err(got, ref64[key])
+        report_measured('test_backward_golden[%s] grad.%s vs fp64' % (name, key), err, tol,
+                        '(golden = reference fp32 vs fp64: %.2e)' % own)
+        assert err <= tol, key
 
-    report_measured('test_backward_golden[%s] grad.x' % name, grad_err(x.grad.cpu().numpy(), g['grad.x']), tol('x'),
-                    '(GRAD_TOL 1e-4, or 4x the golden fp32 gradient\'s own distance from fp64)')
-    assert grad_err(x.grad.cpu().numpy(), g['grad.x']) <= tol('x')
+    check('x', x.grad.cpu().numpy())
     for k, p in model.named_parameters():
         if 'grad.' + k in g.files:
             assert p.grad is not None, k
-            err = grad_err(p.grad.cpu().numpy(), g['grad.' + k])
-            if tol(k) > GRAD_TOL:
-                report_measured('test_backward_golden[%s] grad.%s' % (name, k), err, tol(k), '(widened: golden fp32 vs fp64 = %.2e)' % (tol(k) / 4))
-            assert err <= tol(k), k
+            check(k, p.grad.cpu().numpy())
 
 
 @pytest.mark.parametrize('B', [1, 63, 64, 129, 1000])
@@ -733,10 +735,10 @@ def test_backward_wide_model_vs_oracle(golden):
     got = {k: p.grad.cpu().numpy() for k, p in model.named_parameters() if p.requires_grad}
     got['x'] = xg.grad.cpu().numpy()
     for k in got:
-        tol = max(GRAD_TOL, 4.0 * grad_err(ref32[k], ref64[k]))
-        if tol > GRAD_TOL:
-            report_measured('test_backward_wide_model_vs_oracle grad.%s' % k, grad_err(got[k], ref64[k]), tol,
-                            '(reference fp32 vs fp64 = %.2e)' % (tol / 4))
+        own = grad_err(ref32[k], ref64[k])
+        tol = max(GRAD_TOL, 2.0 * own)
+        report_measured('test_backward_wide_model_vs_oracle grad.%s vs fp64' % k, grad_err(got[k], ref64[k]), tol,
+                        '(reference fp32 vs fp64 = %.2e)' % own)
         assert grad_err(got[k], ref64[k]) <= tol, k
 
 
@@ -936,8 +938,66 @@ def test_training_forward_golden_gradients(golden, name):
     ref64 = _oracle_grads_fp64(g)
     for k, p in model.named_parameters():
         if 'grad.' + k in g.files:
-            tol = max(GRAD_TOL, 4.0 * grad_err(g['grad.' + k], ref64[k]))
-            assert grad_err(p.grad.cpu().numpy(), g['grad.' + k]) <= tol, k
+            own = grad_err(g['grad.' + k], ref64[k])
+            tol = max(GRAD_TOL, 2.0 * own)
+            err = grad_err(p.grad.cpu().numpy(), ref64[k])
+            report_measured('test_training_forward_golden_gradients[%s] grad.%s vs fp64' % (name, k), err, tol,
+                            '(golden = reference fp32 vs fp64: %.2e)' % own)
+            assert err <= tol, k
+
+
+@pytest.mark.parametrize('B', [512, 2048, 3000])
+@pytest.mark.parametrize('regime', ['mu_over_s_50', 'uint8_range', 'clusters'])
+def test_leaf_parameter_gradients_ill_conditioned(regime, B):
+    """the moment-GEMM leaf backward (B <= 2048) on data / parameters with |mu| / s large -- small learned
+    scales around means far from 0, uint8-range evidence, and channels sitting on clusters many scales apart (what no
+    per-variable pivot can centre: the kernel has to notice and evaluate the direct form).  d/dloc and d/dscale against
+    the fp64 oracle at GRAD_TOL, B = 3000 (the vector-ALU kernel) as the control."""
+    from deeprob.spn.models import GaussianRatSpn
+    gen = torch.Generator().manual_seed(B + len(regime))
+    model = GaussianRatSpn(64, rg_depth=2, rg_repetitions=4, rg_batch=8, rg_sum=4, optimize_scale=True, random_state=3).eval()
+    I = model.base_layer.loc.shape[1]
+    with torch.no_grad():
+        if regime == 'mu_over_s_50':
+            centre = 5.0 + torch.randn(64, generator=gen)
+            x = centre + 0.1 * torch.randn(B, 64, generator=gen)
+            spread, scale = 0.05, 0.1
+        elif regime == 'uint8_range':
+            centre = 40.0 + 170.0 * torch.rand(64, generator=gen)
+            x = (centre + 3.0 * torch.randn(B, 64, generator=gen)).round().clamp(0, 255)
+            spread, scale = 2.0, 3.0
+        else:
+            centre = torch.zeros(64)
+            offs = torch.tensor([0.0, 60.0, 128.0, 200.0])
+            x = offs[torch.randint(0, 4, (B, 1), generator=gen)] + torch.randn(B, 64, generator=gen)    # (a sample = one cluster)
+            spread, scale = 0.5, 1.0
+        loc = torch.empty_like(model.base_layer.loc)
+        mask = model.base_layer.mask                      # [regions, positions] -> variable
+        for k in range(I):
+            base = centre[mask.clamp_min(0)]
+            if regime == 'clusters':
+                base = base + offs[k % 4]
+            loc[:, k] = base + spread * torch.randn(base.shape, generator=gen)
+        model.base_layer.loc.copy_(loc)
+        model.base_layer.scale.fill_(scale).mul_(1.0 + 0.2 * torch.rand(model.base_layer.scale.shape, generator=gen))
+    ref = {}
+    for dt in (torch.float64, torch.float32):
+        sd = {k: (v.detach().to(dt).clone() if v.is_floating_point() else v.detach().clone()) for k, v in model.state_dict().items()}
+        for k in ('base_layer.loc', 'base_layer.scale'):
+            sd[k].requires_grad_(True)
+        with torch.enable_grad():
+            orc.ratspn_loss(orc.ratspn_forward(sd, x.to(dt))).backward()
+        ref[dt] = {k: sd[k].grad.double().numpy() for k in ('base_layer.loc', 'base_layer.scale')}
+    model.cuda()
+    with torch.enable_grad():
+        model.loss(model(x.cuda())).backward()
+    for k, p in (('base_layer.loc', model.base_layer.loc), ('base_layer.scale', model.base_layer.scale)):
+        own = grad_err(ref[torch.float32][k], ref[torch.float64][k])
+        tol = max(GRAD_TOL, 2.0 * own)
+        err = grad_err(p.grad.cpu().numpy(), ref[torch.float64][k])
+        report_measured('test_leaf_parameter_gradients_ill_conditioned[%s, B=%d] grad.%s vs fp64' % (regime, B, k), err, tol,
+                        '(reference fp32 arithmetic vs fp64: %.2e)' % own)
+        assert err <= tol, (k, err)
 
 def test_eight_channel_blocks_shared_by_two_work_groups_agree_with_whole_blocks():
     """Round 5: up to 128 blocks of 32 samples the 8-channel kernel gives a block to two work-groups (four repetitions each,
