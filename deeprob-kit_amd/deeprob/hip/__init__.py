@@ -189,6 +189,8 @@ SIGNATURES = {
     'dpk_prodsum_workspace_bytes': (_i64, [_i32, _i32, _i32]),
     'dpk_prodsum_forward': (ctypes.c_int, [_c_void, _c_void, _i64, _i32, _i32, _i32, _c_void, _c_void, _i64, _u32, _c_void]),
     'dpk_prodroot_forward': (ctypes.c_int, [_c_void, _c_void, _i64, _i32, _i32, _i32, _c_void, _c_void, _i64, _u32, _c_void]),
+    'dpk_ratspn_topdown': (ctypes.c_int, [_i32, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _c_void, _c_void,
+                                          _c_void, _c_void, _c_void, _c_void, _c_void, ctypes.c_uint64, _c_void, _c_void, _c_void]),
     'dpk_profile_next_kernel': (ctypes.c_int, [_c_void, _c_void]),
     'dpk_profile_next_kernel_of': (ctypes.c_int, [_c_void, _c_void, _i32]),
     'dpk_ll_accumulate': (ctypes.c_int, [_c_void, _i64, _c_void, _c_void]),

@@ -650,6 +650,52 @@ def prodroot_forward(x: torch.Tensor, weight: torch.Tensor, ws: Workspace, table
     return out
 
 
+def ratspn_topdown(mode: int, dist: int, n_samples: int, lctx: LeafContext, x: Optional[torch.Tensor], y: Optional[torch.Tensor],
+                   acts, logws, src: torch.Tensor, p0: torch.Tensor, p1: Optional[torch.Tensor], seed: int = 0,
+                   want_choice: bool = False):
+    """RatSpn.mpe (mode 0) / RatSpn.sample (mode 1) top-down in one launch (reference: deeprob/spn/models/ratspn.py:124-182
+    and the layers' mpe / sample methods).  ``acts``: [leaf output, sum level 1 output, ...] (mode 0); ``logws``: log-softmax
+    weights of the sum levels 1 .. depth-1, then of the root.  Returns the completed / generated ``[B, D]`` tensor (and the
+    ``[B, 1 + 2^depth]`` choices when asked)."""
+    import ctypes
+    lib = load_library()
+    depth = lctx.depth
+    device = p0.device
+    B = int(n_samples)
+    keep = []
+
+    def dev(t, name):
+        t = require_device_f32(t, name)
+        keep.append(t)
+        return t
+
+    act_arr = (ctypes.c_void_p * depth)()
+    if mode == 0:
+        if len(acts) != depth:
+            raise ValueError('ratspn_topdown: %d activation tensors for depth %d' % (len(acts), depth))
+        for t, a in enumerate(acts):
+            act_arr[t] = ptr(dev(a, 'act'))
+    if len(logws) != depth:
+        raise ValueError('ratspn_topdown: %d weight tensors for depth %d' % (len(logws), depth))
+    logw_arr = (ctypes.c_void_p * (depth + 1))()
+    for t, w in enumerate(logws):
+        logw_arr[t + 1] = ptr(dev(w, 'logw'))
+    xd = dev(x, 'x') if x is not None else None
+    yd = None
+    if y is not None:
+        yd = y.to(device=device, dtype=torch.int64).contiguous()
+        if not yd.is_cuda:
+            raise HipError('ratspn_topdown: y is not on a HIP device')
+    p0d, p1d = dev(p0, 'p0'), (dev(p1, 'p1') if p1 is not None else None)
+    out = torch.empty((B, lctx.D), dtype=torch.float32, device=device)
+    choice = torch.empty((B, 1 + (1 << depth)), dtype=torch.int32, device=device) if want_choice else None
+    check(lib.dpk_ratspn_topdown(mode, dist, B, lctx.D, depth, lctx.reps, lctx.I, lctx.S, lctx.C, lctx.d, ptr(xd), ptr(yd),
+                                 ctypes.cast(act_arr, ctypes.c_void_p), ctypes.cast(logw_arr, ctypes.c_void_p), ptr(src),
+                                 ptr(p0d), ptr(p1d), seed & 0xFFFFFFFFFFFFFFFF, ptr(out), ptr(choice), stream_ptr(device)),
+          'dpk_ratspn_topdown')
+    return (out, choice) if want_choice else out
+
+
 class NegMeanFn(torch.autograd.Function):
     """``-torch.mean(x)``, the generative loss (reference: models/ratspn.py:184-191), one launch forward (fp64
     accumulation) and one backward."""

@@ -264,9 +264,90 @@ class RatSpn(ProbabilisticModel):
             i += 1
         return self.root_layer(x)
 
+    # ---- top-down passes: one launch (csrc/ratspn_topdown.hip) ------------------------------------------------------------
+    def _topdown_src(self) -> torch.Tensor:
+        """``[reps, D]`` int32: where variable f sits in a repetition's region-major row (the reference's ``inv_mask`` with the
+        dummy variables dropped -- what ``unpad_samples``, ratspn.py:68-85, is meant to select; its own ``samples[inv_pad_mask]``
+        keeps the DUMMY entries instead and raises on every padded region graph, a defect this mirror does not reproduce)."""
+        base = self.base_layer
+        key = (base.inv_mask.device, base.inv_mask.data_ptr())
+        if getattr(self, '_td_src_key', None) != key:
+            inv = base.inv_mask
+            if base.pad > 0:
+                inv = inv[~base.inv_pad_mask].view(inv.shape[0], self.in_features)
+            self._td_src = inv.to(torch.int32).contiguous()
+            self._td_src_key = key
+        return self._td_src
+
+    def _topdown_logw(self):
+        """log_softmax of every sum level's weight (bottom to top) and of the root's: the tables of ratspn.py:397 / :415 /
+        :470 / :488, formed by the same torch call as the reference forms them."""
+        out = [torch.log_softmax(layer.weight, dim=2) for layer in self.layers if isinstance(layer, SumLayer)]
+        out.append(torch.log_softmax(self.root_layer.weight, dim=1))
+        return out
+
+    def _leaf_params(self):
+        base = self.base_layer
+        if isinstance(base, GaussianLayer):
+            return 0, base.loc, base.scale
+        if isinstance(base, BernoulliLayer):
+            return 1, base.logits, None
+        return None
+
+    def _upward_for_mpe(self, x: torch.Tensor):
+        """Leaf and sum-level outputs (no product tensors) + the input of the root as (regions, nodes)."""
+        h = self.base_layer(x)
+        acts = [h]
+        layers = list(self.layers)
+        i = 0
+        while i + 1 < len(layers):
+            # (Product, Sum) pairs; the last ProductLayer belongs to the root
+            y = ops.prodsum_forward(h, layers[i + 1].weight, layers[i + 1]._ws)
+            if y is None:
+                y = layers[i + 1](layers[i](h))
+            h = y
+            acts.append(h)
+            i += 2
+        return acts
+
     @torch.no_grad()
     def mpe(self, x: torch.Tensor, y: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Most probable completion of the NaN entries of ``x`` (reference: ratspn.py:124-162)."""
+        """Most probable completion of the NaN entries of ``x`` (reference: ratspn.py:124-162): the bottom-up pass through
+        the leaf and folded product+sum kernels, the whole top-down pass in one launch."""
+        leaf = self._leaf_params()
+        if leaf is None or (self.training and (self.in_dropout is not None or self.sum_dropout is not None)):
+            return self._mpe_layerwise(x, y)
+        acts = self._upward_for_mpe(x)
+        if self.out_classes == 1:
+            y = None
+        elif y is None:
+            top = ops.prodroot_forward(acts[-1], self.root_layer.weight, self.root_layer._ws)
+            if top is None:
+                top = self.root_layer(self.layers[-1](acts[-1]))
+            y = torch.argmax(top, dim=1)
+        dist, p0, p1 = leaf
+        return ops.ratspn_topdown(0, dist, x.shape[0], self._fused_ctx, x, y, acts, self._topdown_logw(),
+                                  self._topdown_src(), p0, p1)
+
+    @torch.no_grad()
+    def sample(self, n_samples: int, y: Optional[torch.Tensor] = None, seed: Optional[int] = None) -> torch.Tensor:
+        """Ancestral sampling, top-down (reference: ratspn.py:164-182), one launch.  The draws come from the library's
+        counter-based hash seeded from torch's generator (``seed``: fix them, e.g. to replay a batch)."""
+        leaf = self._leaf_params()
+        if leaf is None:
+            return self._sample_layerwise(n_samples, y)
+        device = self.root_layer.weight.device
+        if self.out_classes == 1:
+            y = None
+        elif y is None:
+            y = torch.randint(self.out_classes, [n_samples], device=device)
+        dist, p0, p1 = leaf
+        return ops.ratspn_topdown(1, dist, n_samples, self._fused_ctx, None, y, None, self._topdown_logw(),
+                                  self._topdown_src(), p0, p1, seed=ops.draw_seed() if seed is None else int(seed))
+
+    @torch.no_grad()
+    def _mpe_layerwise(self, x: torch.Tensor, y: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The layer-by-layer form (user-defined leaf layers, training-mode dropout): the layers' own ``mpe`` methods."""
         evidence = x
         n_samples = x.shape[0]
         x = self.base_layer(x)
@@ -284,8 +365,7 @@ class RatSpn(ProbabilisticModel):
         return self.base_layer.mpe(evidence, idx_group, idx_offset)
 
     @torch.no_grad()
-    def sample(self, n_samples: int, y: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Ancestral sampling, top-down (reference: ratspn.py:164-182)."""
+    def _sample_layerwise(self, n_samples: int, y: Optional[torch.Tensor] = None) -> torch.Tensor:
         device = self.root_layer.weight.device
         if self.out_classes == 1:
             y = torch.zeros(n_samples, dtype=torch.long, device=device)

@@ -343,6 +343,24 @@ int dpk_prodsum_forward(const float *in, const float *weight, int64_t B, int32_t
 int dpk_prodroot_forward(const float *in, const float *weight, int64_t B, int32_t R, int32_t N, int32_t C, float *out,
                          void *ws, int64_t ws_bytes, uint32_t flags, void *stream);
 
+/* RatSpn.mpe (mode 0; deeprob/spn/models/ratspn.py:124-162) and RatSpn.sample (mode 1; :164-182): the whole top-down pass
+ * -- RootLayer.mpe / .sample (deeprob/spn/layers/ratspn.py:460-474 / :476-490), SumLayer (:380-399 / :401-417), ProductLayer
+ * (:288-304 / :306-330), RegionGraphLayer.mpe / .sample with unpad_samples (:118-136 / :138-157, :68-85) -- in one launch,
+ * a wave per sample.  dist: 0 = Gaussian, 1 = Bernoulli leaves.  x [B, D]: evidence, NaN entries are completed (NULL:
+ * everything is generated); y [B] int64: class of the root to descend from (NULL: class 0).  act / logw are HOST arrays of
+ * device pointers: act[0] = leaf layer output [B, reps 2^depth, I], act[t] (1 <= t < depth) = output of sum level t
+ * [B, reps 2^(depth-t), S] (mode 0 only; the product tensors are not needed); logw[t] (1 <= t < depth) = log_softmax of sum
+ * level t's weight [reps 2^(depth-t), S, N^2] (N = I for t = 1, else S), logw[depth] = log_softmax of the root weight
+ * [C, reps N^2]; logw[0] is ignored.  src [reps, D] int32: (region within the repetition) * d + position that holds
+ * variable f (inv_mask without the dummy variables).  p0 / p1: loc / scale or logits / NULL, [reps 2^depth, I, d].
+ * Sampling draws are counter based on `seed` (csrc/ratspn_topdown.hip states the counter layout: a test can replay them).
+ * out [B, D]; choice (optional, [B, 1 + 2^depth] int32): the repetition and the leaf channel chosen per region.           */
+int dpk_ratspn_topdown(int32_t mode, int32_t dist, int64_t B, int32_t D, int32_t depth, int32_t reps, int32_t I,
+                       int32_t S, int32_t C, int32_t d, const float *x, const int64_t *y,
+                       const float *const *act, const float *const *logw, const int32_t *src,
+                       const float *p0, const float *p1, uint64_t seed, float *out, int32_t *choice,
+                       void *stream);
+
 /* ---- DGC-SPN spatial layers (NCHW fp32; deeprob/spn/layers/dgcspn.py) ------------------ */
 /* SpatialGaussianLayer.forward (dgcspn.py:101-120):
  * out[b,k,h,w] = sum_c nan_to_num(log N(x[b,c,h,w]; loc[k,c,h,w], scale[k,c,h,w])); NaN x = marginalised. */

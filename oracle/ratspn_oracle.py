@@ -176,3 +176,158 @@ def state_from_npz(npz, dtype=None) -> Dict[str, torch.Tensor]:
                 t = t.to(dtype)
             sd[k[3:]] = t
     return sd
+
+
+# --------------------------------------------------------------------------------------------
+# top-down passes
+# --------------------------------------------------------------------------------------------
+def _inverse_masks(sd, depth: int):
+    """inv_mask / inv_pad_mask as RegionGraphLayer.__init__ builds them (ratspn.py:58-66)."""
+    mask = sd['base_layer.mask']
+    padded = mask.shape[1] * (2 ** depth)
+    inv_mask = sd['base_layer.inv_mask'] if 'base_layer.inv_mask' in sd else torch.argsort(mask.reshape(-1, padded), dim=1)
+    inv_pad = None
+    if sd.get('base_layer.pad_mask') is not None:
+        inv_pad = torch.gather(sd['base_layer.pad_mask'].reshape(-1, padded), dim=1, index=inv_mask)
+    return inv_mask, inv_pad
+
+
+def _unpad_samples(sd, x, idx_group, depth: int, in_features: int):
+    """RegionGraphLayer.unpad_samples (ratspn.py:68-85).  NOTE: the reference's last statement, ``samples[inv_pad_mask[..]]``,
+    selects the DUMMY positions and its ``.view`` raises for every padded region graph (no reference test reaches it); the
+    restatement keeps the real variables, ``~inv_pad_mask`` -- the evident intent, and what the HIP path does."""
+    n = idx_group.shape[0]
+    inv_mask, inv_pad = _inverse_masks(sd, depth)
+    idx_rep = torch.div(idx_group[:, 0], 2 ** depth, rounding_mode='floor')
+    samples = torch.gather(x, dim=1, index=inv_mask[idx_rep])
+    if inv_pad is not None:
+        samples = samples[~inv_pad[idx_rep]].view(n, in_features)
+    return samples
+
+
+def _layer_kinds(sd):
+    kinds, i = [], 0
+    while 'layers.{}.mask'.format(i) in sd or 'layers.{}.weight'.format(i) in sd:
+        kinds.append('sum' if 'layers.{}.weight'.format(i) in sd else 'prod')
+        i += 1
+    return kinds
+
+
+def _product_down(idx_group, idx_offset, in_nodes: int):
+    """ProductLayer.sample (= .mpe; ratspn.py:306-330)."""
+    first = torch.div(idx_offset, in_nodes, rounding_mode='floor')
+    second = torch.remainder(idx_offset, in_nodes)
+    groups = torch.flatten(torch.stack([idx_group * 2, idx_group * 2 + 1], dim=2), start_dim=1)
+    offsets = torch.flatten(torch.stack([first, second], dim=2), start_dim=1)
+    return groups, offsets
+
+
+def leaf_mode(sd):
+    if 'base_layer.logits' in sd:
+        return (torch.sigmoid(sd['base_layer.logits']) >= 0.5).float()       # Bernoulli mean >= 0.5
+    return sd['base_layer.loc']                                               # Normal mean (ratspn.py:130)
+
+
+def ratspn_mpe(sd: Dict[str, torch.Tensor], x: torch.Tensor, depth: int, y: Optional[torch.Tensor] = None,
+               return_choice: bool = False):
+    """RatSpn.mpe (deeprob/spn/models/ratspn.py:124-162) with the layers' mpe methods (layers/ratspn.py:118-136, :288-304,
+    :380-399, :460-474), statement for statement."""
+    n = x.shape[0]
+    out, acts = ratspn_forward(sd, x, return_activations=True)
+    kinds = _layer_kinds(sd)
+    lls = [acts['leaf']] + [acts['layer{}'.format(i)] for i in range(len(kinds) - 1)]   # input of every layer
+    top = acts['layer{}'.format(len(kinds) - 1)]                                          # input of the root
+    if out.shape[1] == 1:
+        y = torch.zeros(n, dtype=torch.long)
+    elif y is None:
+        y = torch.argmax(out, dim=1)
+    in_nodes = top.shape[2]
+    flat = torch.flatten(top, start_dim=1)
+    w = torch.log_softmax(sd['root_layer.weight'], dim=1)
+    idx = torch.argmax(flat + w[y], dim=1, keepdim=True)                                  # :470
+    idx_group, idx_offset = torch.div(idx, in_nodes, rounding_mode='floor'), torch.remainder(idx, in_nodes)
+    for i in reversed(range(len(kinds))):
+        if kinds[i] == 'prod':
+            idx_group, idx_offset = _product_down(idx_group, idx_offset, lls[i].shape[2])
+        else:
+            rows = torch.arange(n).unsqueeze(1)
+            xs = lls[i][rows, idx_group]                                                  # :395
+            ws = torch.log_softmax(sd['layers.{}.weight'.format(i)][idx_group, idx_offset], dim=2)
+            idx_offset = torch.argmax(xs + ws, dim=2)                                     # :398
+    mode = leaf_mode(sd)
+    picked = torch.flatten(mode[idx_group, idx_offset], start_dim=1)
+    picked = _unpad_samples(sd, picked, idx_group, depth, x.shape[1])
+    res = torch.where(torch.isnan(x), picked, x)
+    return (res, idx_group, idx_offset) if return_choice else res
+
+
+def hash_uniform(seed: int, ctr: np.ndarray) -> np.ndarray:
+    """The library's counter-based uniform (csrc/ratspn_topdown.hip: td_uniform; the dropout hash of csrc/common.h):
+    (splitmix64(seed + ctr * golden) >> 40) / 2^24, as float32."""
+    with np.errstate(over='ignore'):
+        z = np.uint64(seed) + ctr.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return ((z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0))
+
+
+def _categorical_from_uniform(logw: torch.Tensor, u: np.ndarray):
+    """Inverse CDF over softmax weights in index order (what Categorical(logits=w).sample(), ratspn.py:416 / :489, does with
+    torch's own uniform).  Returns (choice, margin): margin = distance of u * total from the nearest CDF step, for tests to
+    set aside the draws that fp32 rounding may legitimately flip."""
+    p = torch.exp(logw.double()).numpy()
+    cdf = np.cumsum(p, axis=-1)
+    target = u.astype(np.float64)[..., None] * cdf[..., -1:]
+    pick = np.minimum((cdf <= target).sum(axis=-1), p.shape[-1] - 1)
+    margin = np.abs(cdf - target).min(axis=-1)
+    return pick, margin
+
+
+def ratspn_sample_replay(sd: Dict[str, torch.Tensor], n: int, depth: int, in_features: int, seed: int,
+                         y: Optional[torch.Tensor] = None):
+    """RatSpn.sample (deeprob/spn/models/ratspn.py:164-182; layers :138-157, :306-330, :401-417, :476-490) with every random
+    draw replaced by the counter-based uniform the HIP kernel uses (counter layout in csrc/ratspn_topdown.hip): the same
+    ancestral pass, replayable.  Returns (samples [n, D], repetition [n], leaf channels [n, 2^depth], margin [n] = the
+    smallest categorical margin of the sample's draws)."""
+    kinds = _layer_kinds(sd)
+    G0 = 2 ** depth
+    K = G0 + 2 * in_features
+    b = np.arange(n, dtype=np.uint64) * np.uint64(K)
+    y = torch.zeros(n, dtype=torch.long) if y is None else y
+    w = torch.log_softmax(sd['root_layer.weight'], dim=1)
+    in_nodes = w.shape[1] // (sd['base_layer.mask'].shape[0] // G0)            # inputs per partition of the root
+    idx, margin = _categorical_from_uniform(w[y], hash_uniform(seed, b + np.uint64(1)))
+    idx = torch.from_numpy(idx).unsqueeze(1)
+    idx_group, idx_offset = torch.div(idx, in_nodes, rounding_mode='floor'), torch.remainder(idx, in_nodes)
+    rep = idx_group[:, 0].clone()
+    nodes = int(round(math.sqrt(in_nodes)))
+    for i in reversed(range(len(kinds))):
+        if kinds[i] == 'prod':
+            idx_group, idx_offset = _product_down(idx_group, idx_offset, nodes)
+        else:
+            G = idx_group.shape[1]
+            ws = torch.log_softmax(sd['layers.{}.weight'.format(i)][idx_group, idx_offset], dim=2)
+            local = (idx_group - rep.unsqueeze(1) * G).numpy().astype(np.uint64)
+            u = hash_uniform(seed, b[:, None] + np.uint64(G) + local)
+            pick, m = _categorical_from_uniform(ws, u)
+            margin = np.minimum(margin, m.min(axis=1))
+            idx_offset = torch.from_numpy(pick)
+            nodes = int(round(math.sqrt(ws.shape[2])))
+    # leaves: every selected distribution draws from its own two uniforms, addressed by the VARIABLE it holds
+    mask = sd['base_layer.mask']                                                # [R, d]
+    d = mask.shape[1]
+    f = mask[idx_group].numpy().astype(np.uint64)                               # [n, G0, d]
+    c = b[:, None, None] + np.uint64(G0) + np.uint64(2) * f
+    u1, u2 = hash_uniform(seed, c), hash_uniform(seed, c + np.uint64(1))
+    if 'base_layer.logits' in sd:
+        prob = torch.sigmoid(sd['base_layer.logits'][idx_group, idx_offset]).numpy()
+        draws = (u1 < prob).astype(np.float32)
+    else:
+        z = np.sqrt(-2.0 * np.log(1.0 - u1.astype(np.float64))) * np.cos(2.0 * np.pi * u2.astype(np.float64))
+        loc = sd['base_layer.loc'][idx_group, idx_offset].double().numpy()
+        scale = sd['base_layer.scale'][idx_group, idx_offset].double().numpy()
+        draws = (loc + scale * z).astype(np.float32)
+    flat = torch.from_numpy(draws).reshape(n, G0 * d)
+    samples = _unpad_samples(sd, flat, idx_group, depth, in_features)
+    return samples, rep, idx_offset, margin

@@ -92,3 +92,60 @@ def test_fp64_agrees_with_fp32(golden):
     sd64 = orc.state_from_npz(g, dtype=torch.float64)
     out64 = orc.ratspn_forward(sd64, torch.from_numpy(g['x']).double())
     assert rel_err(out64.numpy(), g['ll']) <= 1e-6
+
+
+MPE_DEPTH = {'ratspn_g784_d2_r8_i4_s2': 2, 'ratspn_g100_d2_r11_i2_s4_c3': 2, 'ratspn_g784_d1_r4_i8_scale': 1,
+             'ratspn_g784_d3_r5_i4_s4_c10': 3}
+
+
+@pytest.mark.parametrize('name', sorted(MPE_DEPTH))
+def test_mpe_matches_reference(golden, name):
+    """The oracle's top-down restatement (RatSpn.mpe, models/ratspn.py:124-162) against the completions the reference
+    itself produced (tools/gen_golden_mpe.py): depths 1 / 2 / 3, one and several classes, given labels -- bit for bit."""
+    g, m = golden(name), golden(name + '_mpe')
+    sd = orc.state_from_npz(g)
+    x = torch.from_numpy(m['x'])
+    assert np.array_equal(orc.ratspn_mpe(sd, x, MPE_DEPTH[name]).numpy(), m['mpe'])
+    if 'y' in m.files:
+        assert np.array_equal(orc.ratspn_mpe(sd, x, MPE_DEPTH[name], y=torch.from_numpy(m['y'])).numpy(), m['mpe_y'])
+
+
+def test_mpe_bernoulli_matches_reference(golden):
+    m = golden('ratspn_bernoulli_32_d3_r3_i3_s2_c2_mpe')
+    sd = orc.state_from_npz(m)
+    x = torch.from_numpy(m['x'])
+    assert rel_err(orc.ratspn_forward(sd, x).numpy(), m['ll']) <= 1e-6
+    assert np.array_equal(orc.ratspn_mpe(sd, x, 3).numpy(), m['mpe'])
+    assert np.array_equal(orc.ratspn_mpe(sd, x, 3, y=torch.from_numpy(m['y'])).numpy(), m['mpe_y'])
+
+
+def test_sample_replay_is_an_ancestral_sample():
+    """The replayable form of RatSpn.sample (models/ratspn.py:164-182 with the library's counter-based uniforms): the
+    choices follow the model's weights (root: frequency of each repetition = its softmax mass) and the leaf draws the
+    selected distributions (tight leaves around known means), on a padded region graph as well."""
+    regions = orc.region_graph_layers(15, 2, 6, 3)
+    leaf_regions = regions[-1]
+    mask, pad = orc.leaf_masks(leaf_regions, 15, 2)
+    gen = torch.Generator().manual_seed(0)
+    R, I, d, S = mask.shape[0], 3, mask.shape[1], 2
+    sd = {'base_layer.mask': mask, 'base_layer.loc': 5.0 * torch.randn(R, I, d, generator=gen),
+          'base_layer.scale': torch.full((R, I, d), 0.01), 'layers.0.mask': torch.tensor([True, False] * (R // 2)),
+          'layers.1.weight': torch.randn(R // 2, S, I * I, generator=gen), 'layers.2.mask': torch.tensor([True, False] * (R // 4)),
+          'root_layer.weight': torch.randn(1, (R // 4) * S * S, generator=gen)}
+    if pad is not None:
+        sd['base_layer.pad_mask'] = pad
+    n = 20000
+    samples, rep, chan, margin = orc.ratspn_sample_replay(sd, n, 2, 15, seed=1234)
+    assert tuple(samples.shape) == (n, 15) and torch.isfinite(samples).all()
+    w = torch.softmax(sd['root_layer.weight'][0], 0).reshape(R // 4, S * S).sum(1).numpy()
+    freq = np.bincount(rep.numpy(), minlength=R // 4) / n
+    assert np.abs(freq - w).max() < 0.015
+    # every variable of a sample sits within a few scales of the mean of the leaf that was selected for it
+    for b in range(0, n, 997):
+        r0 = int(rep[b]) * 4
+        for rl in range(4):
+            for j in range(d):
+                if pad is not None and bool(pad[r0 + rl, 0, j]):
+                    continue
+                f = int(mask[r0 + rl, j])
+                assert abs(float(samples[b, f]) - float(sd['base_layer.loc'][r0 + rl, int(chan[b, rl]), j])) < 0.08

@@ -303,11 +303,15 @@ def test_full_size_vs_oracle(chan, B):
     with torch.no_grad():
         acc = torch.zeros(2, dtype=torch.float64, device='cuda')
         ll = model._forward_fused(x, acc)
+        fused = ll is not None
+        if not fused:                       # 16 channels: the folded route (leaf | product+sum | product+root launches)
+            ll = model(x)
     want = _oracle_rows(sd, x[rows.cuda()].cpu())
     err = rel_err(ll[rows.cuda()].cpu().numpy(), want)
     report_measured('test_full_size_vs_oracle[%dx%d, B=%d] 2048 rows of the whole batch' % (chan[0], chan[1], B), err, LL_TOL)
     assert err <= LL_TOL
-    assert acc[1].item() == B and abs(acc[0].item() - ll.double().sum().item()) <= 1e-9 * abs(acc[0].item())
+    if fused:
+        assert acc[1].item() == B and abs(acc[0].item() - ll.double().sum().item()) <= 1e-9 * abs(acc[0].item())
 
 
 @pytest.mark.parametrize('kw', [dict(rg_batch=8, rg_sum=8), dict(rg_batch=8, rg_sum=4, optimize_scale=True),
@@ -561,10 +565,12 @@ def test_unit_scale_fused_shapes_vs_oracle(kw):
     assert rel_err(got, want) <= LL_TOL
 
 
-@pytest.mark.parametrize('name', ['ratspn_g784_d2_r8_i4_s2', 'ratspn_g100_d2_r11_i2_s4_c3'])
+@pytest.mark.parametrize('name', ['ratspn_g784_d2_r8_i4_s2', 'ratspn_g100_d2_r11_i2_s4_c3', 'ratspn_g784_d1_r4_i8_scale',
+                                  'ratspn_g784_d3_r5_i4_s4_c10'])
 def test_mpe_golden(golden, name):
-    """RatSpn.mpe (reference: models/ratspn.py:124-162) on the HIP forward activations: same completions as the
-    reference, observed entries untouched, also with given class labels."""
+    """RatSpn.mpe (reference: models/ratspn.py:124-162) through the one-launch top-down kernel (csrc/ratspn_topdown.hip)
+    on the HIP forward activations: the reference's own completions (depths 1 / 2 / 3), observed entries untouched, also
+    with given class labels; and the layer-by-layer form (the layers' mpe methods) gives the same."""
     model, _ = build(name, golden)
     g = golden(name + '_mpe')
     x = torch.from_numpy(g['x']).cuda()
@@ -581,9 +587,66 @@ def test_mpe_golden(golden, name):
     assert np.allclose(got[rows], g['mpe'][rows], rtol=1e-5, atol=1e-6)
     obs = ~np.isnan(g['x'])
     assert np.array_equal(got[obs], g['x'][obs])
+    assert np.array_equal(model._mpe_layerwise(x).cpu().numpy()[rows], got[rows])
     if 'y' in g.files:
         got_y = model.mpe(x, y=torch.from_numpy(g['y']).cuda()).cpu().numpy()
         assert np.allclose(got_y, g['mpe_y'], rtol=1e-5, atol=1e-6)
+
+
+def test_mpe_bernoulli_golden(golden):
+    """Bernoulli leaves (mode = [p >= 0.5]), depth 3, two classes: the reference's completions."""
+    from deeprob.spn.models import BernoulliRatSpn
+    g = golden('ratspn_bernoulli_32_d3_r3_i3_s2_c2_mpe')
+    model = BernoulliRatSpn(32, out_classes=2, rg_depth=3, rg_repetitions=3, rg_batch=3, rg_sum=2, random_state=5)
+    state_to_model(model, g, 'cuda').eval()
+    x = torch.from_numpy(g['x']).cuda()
+    with torch.no_grad():
+        ll = model(x)
+    assert rel_err(ll.cpu().numpy(), g['ll']) <= LL_TOL
+    top = torch.topk(ll, 2, dim=1).values
+    rows = ((top[:, 0] - top[:, 1]) > 1e-4).cpu().numpy()
+    assert np.array_equal(model.mpe(x).cpu().numpy()[rows], g['mpe'][rows])
+    assert np.array_equal(model.mpe(x, y=torch.from_numpy(g['y']).cuda()).cpu().numpy(), g['mpe_y'])
+
+
+@pytest.mark.parametrize('kw', [dict(in_features=15, rg_depth=2, rg_repetitions=3, rg_batch=3, rg_sum=5, optimize_scale=True),
+                                dict(in_features=15, rg_depth=3, rg_repetitions=2, rg_batch=2, rg_sum=2),
+                                dict(in_features=70, out_classes=4, rg_depth=4, rg_repetitions=3, rg_batch=5, rg_sum=3),
+                                dict(in_features=784, rg_depth=2, rg_repetitions=8, rg_batch=16, rg_sum=16),
+                                dict(in_features=33, rg_depth=5, rg_repetitions=2, rg_batch=2, rg_sum=2)])
+def test_mpe_vs_oracle_padded_and_deep(kw):
+    """The top-down kernel where the reference cannot go (padded region graphs: its unpad_samples raises, see
+    oracle/ratspn_oracle.py::_unpad_samples) and at depths 4 / 5, 16 nodes per region, several classes: against the oracle's
+    restatement, with the chosen repetition / leaf channels compared on the rows whose decisions are not fp32 ties."""
+    from deeprob.spn.models import GaussianRatSpn
+    from deeprob.hip import ops
+    torch.manual_seed(5)
+    model = GaussianRatSpn(random_state=9, **kw).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    D = kw['in_features']
+    gen = torch.Generator().manual_seed(6)
+    x = torch.randn(300, D, generator=gen)
+    x[torch.rand(300, D, generator=gen) < 0.5] = float('nan')
+    x[0] = float('nan')
+    y = (torch.arange(300) % kw['out_classes']) if kw.get('out_classes', 1) > 1 else None
+    want, og, oo = orc.ratspn_mpe(sd, x, kw['rg_depth'], y=y, return_choice=True)
+    model.cuda()
+    got = model.mpe(x.cuda(), y=None if y is None else y.cuda()).cpu()
+    same = (got == want).all(dim=1)
+    # a near-tie between two children flips a whole subtree: such rows are set aside, but must be rare
+    assert same.float().mean().item() >= 0.97, same.float().mean().item()
+    obs = ~torch.isnan(x)
+    assert torch.equal(got[obs], x[obs]) and not torch.isnan(got).any()
+    # every completed value is the mean of SOME channel of the region that holds the variable in the chosen repetition
+    acts = model._upward_for_mpe(x.cuda())
+    leaf = model._leaf_params()
+    out, choice = ops.ratspn_topdown(0, leaf[0], 300, model._fused_ctx, x.cuda(), None if y is None else y.cuda(), acts,
+                                     model._topdown_logw(), model._topdown_src(), leaf[1], leaf[2], want_choice=True)
+    assert torch.equal(out.cpu(), got)
+    G0 = 2 ** kw['rg_depth']
+    choice = choice.cpu()
+    assert torch.equal(choice[same, 0].long(), torch.div(og[same, 0], G0, rounding_mode='floor'))
+    assert torch.equal(choice[same, 1:].long(), oo[same])
 
 
 def test_sample_shapes_and_statistics():
@@ -602,6 +665,47 @@ def test_sample_shapes_and_statistics():
     # sampled points are likely under the model: far above the density of points drawn elsewhere
     with torch.no_grad():
         assert model(s).mean().item() > model(s + 2.0).mean().item() + 100.0
+
+
+@pytest.mark.parametrize('case', ['gauss_d2_pad', 'gauss_d3_classes', 'gauss_784_wide', 'bernoulli_d3'])
+def test_sample_replays_against_the_oracle(case):
+    """RatSpn.sample through the one-launch kernel with a fixed seed, replayed by the oracle from the same counter-based
+    uniforms (oracle/ratspn_oracle.py::ratspn_sample_replay): the same repetition and leaf channels for every sample whose
+    categorical draws are not within fp32 rounding of a CDF step, and the same values (Box-Muller in fp32 against fp64)."""
+    from deeprob.spn.models import GaussianRatSpn, BernoulliRatSpn
+    from deeprob.hip import ops
+    torch.manual_seed(21)
+    kw = {'gauss_d2_pad': dict(in_features=15, rg_depth=2, rg_repetitions=3, rg_batch=3, rg_sum=5, optimize_scale=True),
+          'gauss_d3_classes': dict(in_features=64, out_classes=3, rg_depth=3, rg_repetitions=4, rg_batch=4, rg_sum=4),
+          'gauss_784_wide': dict(in_features=784, rg_depth=2, rg_repetitions=8, rg_batch=16, rg_sum=16),
+          'bernoulli_d3': dict(in_features=32, out_classes=2, rg_depth=3, rg_repetitions=3, rg_batch=3, rg_sum=2)}[case]
+    model = (BernoulliRatSpn if case.startswith('bern') else GaussianRatSpn)(random_state=4, **kw).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    n, D, depth = 5000, kw['in_features'], kw['rg_depth']
+    y = (torch.arange(n) % kw['out_classes']) if kw.get('out_classes', 1) > 1 else None
+    want, rep, chan, margin = orc.ratspn_sample_replay(sd, n, depth, D, seed=987654321, y=y)
+    model.cuda()
+    got = model.sample(n, y=None if y is None else y.cuda(), seed=987654321)
+    assert tuple(got.shape) == (n, D) and got.is_cuda and torch.isfinite(got).all()
+    leaf = model._leaf_params()
+    out, choice = ops.ratspn_topdown(1, leaf[0], n, model._fused_ctx, None, None if y is None else y.cuda(), None,
+                                     model._topdown_logw(), model._topdown_src(), leaf[1], leaf[2], seed=987654321,
+                                     want_choice=True)
+    assert torch.equal(out, got)                      # (same seed: the same batch)
+    choice = choice.cpu()
+    clear = torch.from_numpy(margin > 1e-5)
+    assert clear.float().mean().item() > 0.99
+    assert torch.equal(choice[clear, 0].long(), rep[clear])
+    assert torch.equal(choice[clear, 1:].long(), chan[clear])
+    if case.startswith('bern'):
+        # a Bernoulli draw is u < p: identical unless u is within rounding of p
+        assert (got.cpu()[clear] != want[clear]).float().mean().item() < 1e-4
+    else:
+        err = (got.cpu()[clear] - want[clear]).abs().max().item()
+        report_measured('test_sample_replays_against_the_oracle[%s] max |sample - replay|' % case, err, 1e-4)
+        assert err <= 1e-4
+    # another seed: another batch
+    assert not torch.equal(model.sample(n, y=None if y is None else y.cuda(), seed=1), got)
 
 
 def test_mfma_route_tables_follow_the_parameters(golden):

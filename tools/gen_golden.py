@@ -180,7 +180,7 @@ def gen_ratspn():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='region,ratspn,flows,flows_train,dgcspn,mpe,flows2d')
+    ap.add_argument('--only', default='region,ratspn,flows,flows_train,dgcspn,mpe,mpe6,flows2d')
     args = ap.parse_args()
     import deeprob
     ref = os.path.realpath(os.path.dirname(deeprob.__file__))
@@ -192,8 +192,9 @@ def main():
     try:
         from gen_golden_flows import gen_flows, gen_flows_train
         from gen_golden_dgcspn import gen_dgcspn
-        from gen_golden_mpe import gen_mpe
+        from gen_golden_mpe import gen_mpe, gen_mpe_round6
         gens['mpe'] = gen_mpe
+        gens['mpe6'] = gen_mpe_round6
         gens.update({'flows': gen_flows, 'flows_train': gen_flows_train, 'dgcspn': gen_dgcspn})
     except ImportError:
         pass
