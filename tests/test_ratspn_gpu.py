@@ -693,8 +693,8 @@ def test_sample_replays_against_the_oracle(case):
                                      want_choice=True)
     assert torch.equal(out, got)                      # (same seed: the same batch)
     choice = choice.cpu()
-    clear = torch.from_numpy(margin > 1e-5)
-    assert clear.float().mean().item() > 0.99
+    clear = torch.from_numpy(margin > 3e-6)           # (fp32 CDF of up to 2048 weights: steps ~5e-4 apart, rounding ~1e-7)
+    assert clear.float().mean().item() > 0.97
     assert torch.equal(choice[clear, 0].long(), rep[clear])
     assert torch.equal(choice[clear, 1:].long(), chan[clear])
     if case.startswith('bern'):
