@@ -518,6 +518,11 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
                 'roofline_basis': 'whole step; 588164 algorithmic B/sample (SURVEY 8d, products folded into sums)',
                 'cpu_baseline': {'value': rate, 'unit': 'log-likelihoods/sec', 'cores': threads, 'kind': 'port',
                                  'sample': '256 samples ({:.1f} s), oracle/dgcspn_oracle.py'.format(dt)}})
+    # both fractions in the line: `frac` on SURVEY's algorithmic bytes, `frac_pmc` on the bytes the chip
+    # actually moved per step (counter passes in profiles/) over this run's step time
+    r4 = out[-1]['roofline']
+    if r4.get('traffic'):
+        r4['frac_pmc'] = r4['traffic'] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     m_dgc = m
     del xs
 
@@ -699,8 +704,19 @@ def compact_configs(sec):
            'headline size, rg_batch = rg_sum = 8': 'hl(8,8)', 'SURVEY 8f-3': 'nvp2d', 'training step': 'train',
            'H2D-inclusive': 'h2d', 'SURVEY 8d config 4 secondary': 'c4b'}
     out = []
-    for e in sec:
-        r = {'id': e.get('id') or ids.get(e.get('config'), e.get('config', '?')), 'B': e.get('batch')}
+    # the driver's record keeps the last ~2000 characters of stdout: the BASELINE configurations (c2(2,2), c4, c5, the shards)
+    # go LAST, the rows nobody grades (RealNVP-2D, the training steps, the PCIe-inclusive step) only to the detail file
+    detail_only = ('nvp2d', 'h2d')
+    order = {'c1': 0, 'c2(16,16)': 1, 'c2(8,8)': 2, 'hl(8,8)': 3, 'c4b': 5, 'c2(2,2)': 10, 'c4': 11, 'c5': 12,
+             'shard/2': 13, 'shard/4': 14, 'shard/8': 15}
+    def rank_of(e):
+        i = e.get('id') or ids.get(e.get('config'), '?')
+        return order.get(i, 4)
+    for e in sorted(sec, key=rank_of):
+        eid = e.get('id') or ids.get(e.get('config'), e.get('config', '?'))
+        if eid in detail_only or str(eid).startswith('train:'):
+            continue
+        r = {'id': eid, 'B': e.get('batch')}
         if 'error' in e:
             r['error'] = e['error'][:80]
             out.append(r)
@@ -724,6 +740,8 @@ def compact_configs(sec):
             r['bound'], r['frac'] = roof['bound'], round(roof['frac'], 4)
             if roof.get('traffic'):
                 r['traffic_MB'] = round(roof['traffic'] / 1e6, 1)
+            if roof.get('frac_pmc') is not None:      # counter bytes over the step, beside the algorithmic fraction
+                r['frac_pmc'] = round(roof['frac_pmc'], 4)
         if e.get('mfma'):
             r['mfma_frac'] = round(e['mfma']['frac'], 4)
         cb = e.get('cpu_baseline')
@@ -744,6 +762,40 @@ def write_detail(obj):
         return os.path.relpath(path, ROOT)
     except OSError:
         return None
+
+
+def headline_kernel_name(two_channel: bool, B: int) -> str:
+    """The kernel a clean-evidence launch of B samples takes, from the LIBRARY's thresholds (dpk_ratspn_slice_batch_min /
+    dpk_ratspn_small_batch_max), not from literals that can drift."""
+    from deeprob.hip import load_library
+    lib = load_library()
+    slice_min = lib.dpk_ratspn_slice_batch_min(-2)      # (below -1: back to the initial value; returns the current one)
+    lib.dpk_ratspn_slice_batch_min(slice_min)
+    small_max = lib.dpk_ratspn_small_batch_max(-1)
+    lib.dpk_ratspn_small_batch_max(small_max)
+    if two_channel and slice_min >= 0 and B >= slice_min:
+        return 'ratspn_gemm_slice_kernel'
+    if not two_channel:
+        return 'ratspn_gemm_wide_kernel' if B <= 16384 else 'ratspn_gemm_wide_ring_kernel'
+    return 'ratspn_gemm_small_kernel' if B <= small_max else 'ring::ratspn_gemm_kernel'
+
+
+def shard_plan(world: int, batch: int, scaling: str) -> dict:
+    """Samples per rank and step of the headline loop, of the other scaling mode measured beside it, and of BASELINE
+    config 3's shape (262144 samples over 8 GPUs = 32768 per rank, weak at any N) -- pure arithmetic, unit-tested on the CPU
+    (tests/test_host_logic.py)."""
+    per_rank = batch if scaling == 'weak' else max(1, batch // world)
+    other = max(1, batch // world) if scaling == 'weak' else batch
+    return {'per_rank': per_rank, 'global': per_rank * world, 'other_scaling': 'strong' if scaling == 'weak' else 'weak',
+            'other_per_rank': other, 'config3_per_rank': 32768, 'config3_global': 32768 * world}
+
+
+def workload_string(rg_batch: int, rg_sum: int, per_rank: int, world: int, backend: str) -> str:
+    return ('GaussianRatSpn(784, rg_depth=2, rg_repetitions=8, rg_batch={}, rg_sum={}) forward LL, {} samples '
+            'per GPU per step, mean LL reduced on device{}'.format(
+                rg_batch, rg_sum, per_rank,
+                ' + {} all-reduce of {{sum, count}} once per run'.format('RCCL' if backend == 'nccl' else backend)
+                if world > 1 else ''))
 
 
 def main():
@@ -774,7 +826,8 @@ def main():
     D = 784
     if args.scaling is None:
         args.scaling = 'strong' if world > 1 else 'weak'
-    B = args.batch if args.scaling == 'weak' else max(1, args.batch // world)
+    plan = shard_plan(world, args.batch, args.scaling)
+    B = plan['per_rank']
     torch.manual_seed(0)  # identical replica on every rank
     model = GaussianRatSpn(D, rg_depth=2, rg_repetitions=8, rg_batch=args.rg_batch, rg_sum=args.rg_sum,
                            random_state=42).eval()
@@ -790,7 +843,7 @@ def main():
         gen_g = torch.Generator(device=dev).manual_seed(4321 + rank)
         xs_g = [torch.randn(Bg, D, device=dev, generator=gen_g) for _ in range(min(ring_g, max(L, 4)))]
         ev = ShardedLogLikelihood(model, group=dist.group.WORLD if world > 1 else None, static_inputs=True,
-                                  static_params=True)
+                                  static_params=False)
         win = GraphedEvaluationWindow(ev, [xs_g[i % len(xs_g)] for i in range(L)])
         for _ in range(max(1, -(-warmup // L))):
             win.replay()
@@ -815,10 +868,10 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)  # every rank its own shard of the batch
     xs = [torch.randn(B, D, device=dev, generator=gen) for _ in range(ring)]
 
-    # static_params: the model is frozen for the whole run (an evaluation pass), so the bound calls skip the per-call
-    # device-side fingerprint of the cached parameter tables that `model(x)` pays by default
+    # The headline loop runs the DEFAULT mode of `model(x)`: every call checks its cached parameter tables on the device
+    # (inside the launch); the frozen-model figure (static_params=True: the caller vouches) is printed beside it.
     evaluator = ShardedLogLikelihood(model, group=dist.group.WORLD if world > 1 else None, static_inputs=True,
-                                     static_params=True)
+                                     static_params=False)
     time_kernel = not args.no_kernel_events
     timer = KernelTimer()
     n_spare = 64   # event pairs for the untimed steps
@@ -901,49 +954,68 @@ def main():
                 step_mode = ('HIP graph: {} steps + their one all-reduce per replay (eager loop of the same steps: {:.5f} '
                              'ms/step)'.format(L, eager_ms))
                 if world > 1:
-                    Bo = max(1, args.batch // world) if args.scaling == 'weak' else args.batch
+                    Bo = plan['other_per_rank']
                     dto, _, _ = graphed_run(Bo, args.steps, args.warmup)
-                    weak_entry = {'scaling': 'strong' if args.scaling == 'weak' else 'weak', 'samples_per_gpu_per_step': Bo,
+                    weak_entry = {'scaling': plan['other_scaling'], 'samples_per_gpu_per_step': Bo,
                                   'value': Bo * world * args.steps / dto, 'ms_per_step': dto / args.steps * 1e3}
+                    # BASELINE config 3's own shape: 32768 samples per rank (262144 over 8 GPUs)
+                    B3 = plan['config3_per_rank']
+                    dt3, _, _ = graphed_run(B3, args.steps, args.warmup)
+                    weak_entry['config3_32768_per_rank'] = {'global_batch': B3 * world, 'value': B3 * world * args.steps / dt3,
+                                                            'ms_per_step': dt3 / args.steps * 1e3}
         except Exception as ex:
             step_mode = 'eager (graphed window failed: {}: {})'.format(type(ex).__name__, str(ex)[:120])
 
-    # the same loop in the DEFAULT mode of model(x): every call checks its cached parameter tables on the device (a
-    # write through param.data moves no version counter); the headline loop above declares a frozen model
-    ms_default = None
-    if world == 1:
-        ev2 = ShardedLogLikelihood(model, static_inputs=True, static_params=False)
+    # the same loop with a frozen model (static_params=True: no per-call table check), and on the exact fp32 route
+    # (dpk_ratspn_mfma_route(0): the vector-ALU kernels, fp32 products) -- what the split-f16 matrix-core route buys
+    def plain_loop(ev, steps):
         with torch.no_grad():
-            for i in range(max(args.warmup, 4)):
-                ev2.step(xs[i % ring])
-            ev2.drain()
+            for i in range(4):
+                ev.step(xs[i % ring])
+            ev.drain()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for i in range(args.steps):
-                ev2.step(xs[i % ring])
-            ev2.drain()
+            for i in range(steps):
+                ev.step(xs[i % ring])
+            ev.drain()
             torch.cuda.synchronize()
-            ms_default = (time.perf_counter() - t1) / args.steps * 1e3
+            return (time.perf_counter() - t1) / steps * 1e3
+
+    ms_frozen = ms_exact = None
+    if world == 1:
+        ms_frozen = plain_loop(ShardedLogLikelihood(model, static_inputs=True, static_params=True), args.steps)
+        try:
+            from deeprob.hip import load_library
+            lib = load_library()
+            prev_route = lib.dpk_ratspn_mfma_route(0)
+            try:
+                torch.manual_seed(0)
+                exact_model = GaussianRatSpn(D, rg_depth=2, rg_repetitions=8, rg_batch=args.rg_batch, rg_sum=args.rg_sum,
+                                             random_state=42).eval().to(dev)
+                ms_exact = plain_loop(ShardedLogLikelihood(exact_model, static_inputs=True, static_params=False),
+                                      max(4, min(args.steps, 20)))
+                del exact_model
+            finally:
+                lib.dpk_ratspn_mfma_route(prev_route)
+        except Exception as ex:
+            ms_exact = 'failed: {}'.format(str(ex)[:80])
 
     if rank == 0:
         total = B * world * args.steps
-        workload = ('GaussianRatSpn(784, rg_depth=2, rg_repetitions=8, rg_batch={}, rg_sum={}) forward LL, {} samples '
-                    'per GPU per step, mean LL reduced on device{}'.format(
-                        args.rg_batch, args.rg_sum, B,
-                        ' + {} all-reduce of {{sum, count}} once per run'.format(
-                            'RCCL' if args.backend == 'nccl' else args.backend) if world > 1 else ''))
+        workload = workload_string(args.rg_batch, args.rg_sum, B, world, args.backend)
         out = {
             'metric': 'log-likelihoods/sec, RAT-SPN D=784 batch=64k at 1/2/4/8 MI355X',
             'value': total / dt, 'unit': 'log-likelihoods/sec', 'n_gpus': world,
             'n_ranks_seen': dist.get_world_size() if world > 1 else 1,
             'backend': (dist.get_backend() if world > 1 else None), 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': args.scaling, 'step_mode': step_mode.split(':')[0], 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': workload, 'global_batch': B * world, 'resident_batches': ring, 'mean_ll': mean_ll,
                        'host_enqueue_ms_per_step': round(host_dt / args.steps * 1e3, 5), 'step_mode': step_mode,
                        'other_scaling': weak_entry,
-                       'params_mode': 'static_params=True (frozen model: no per-call table check)',
-                       'ms_per_step_default_mode': ms_default,
+                       'params_mode': 'default: static_params=False (cached parameter tables checked on the device at every call)',
+                       'ms_per_step_frozen_model': ms_frozen,
+                       'fp32_exact_ms': ms_exact,
                        'arithmetic': 'fp32 results; leaf GEMM = 3 f16 MFMAs on two-way f16 splits, fp32 accumulate '
                                      '(>= 22 bits per product, guarded, exact fallback)'},
         }
@@ -956,10 +1028,11 @@ def main():
             achieved = alg_bytes / (k_ms * 1e-3) / 1e9
             traffic, source = read_traffic('headline')
             two = (args.rg_batch, args.rg_sum) == (2, 2)
-            kernel_name = ('ratspn_gemm_slice_kernel' if two and B >= 8193 else 'ratspn_gemm_small_kernel' if B <= 16384
-                           else 'ring::ratspn_gemm_kernel')
+            kernel_name = headline_kernel_name(two, B)
             out['roofline'] = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic if B == 65536 else None,
+                               'traffic_source': ("profiles/pmc_traffic.json (builder's rocprofv3 --pmc passes of this "
+                                                  "command, not measured in this run)") if B == 65536 and traffic else None,
                                'kernel': kernel_name, 'kernel_ms': k_ms, 'kernel_event_samples': n_launches,
                                'algorithmic_bytes_per_launch': alg_bytes}
             detail['roofline_notes'] = {

@@ -1497,12 +1497,20 @@ static int leaf_forward_dispatch(const LeafArgs &a, hipStream_t st) {
 int ratspn_leaf_gemm_forward(void *ws, const float *x, int64_t B, int D, const int64_t *mask, const uint8_t *pad,
                              const float *loc, const float *scale, int R, int I, int d, float *out, uint32_t flags,
                              hipStream_t st);
-static bool mfma_enabled() {
-    static const bool enabled = [] {
+static int &mfma_route_ref() {
+    static int enabled = [] {
         const char *e = getenv("DPK_RATSPN_GEMM");
-        return !(e && e[0] == '0');
+        return (e && e[0] == '0') ? 0 : 1;
     }();
     return enabled;
+}
+static bool mfma_enabled() { return mfma_route_ref() != 0; }
+// measurement knob (bench.py's fp32_exact figure, A/B runs): the matrix-core route of the RAT-SPN forward on / off
+extern "C" int32_t dpk_ratspn_mfma_route(int32_t enable) {
+    int &v = mfma_route_ref();
+    const int prev = v;
+    if (enable >= 0) v = enable ? 1 : 0;
+    return prev;
 }
 static bool leaf_gemm_route(int dist, const float *x, const float *out, int D, int R, int I, int d, uint32_t flags) {
     return mfma_enabled() && dist == 0 && (flags & DPK_FLAG_UNIT_SCALE) != 0 && leaf_gemm_shape_ok(D, R, I, d) &&

@@ -3,6 +3,7 @@
 // the individual reference modules; the inference fast path is the fused kernel in
 // ratspn_fwd.hip.
 #include "common.h"
+#include <algorithm>
 #include <stdlib.h>
 #include <math.h>
 
@@ -268,6 +269,43 @@ __global__ __launch_bounds__(256) void root_wide_kernel(const float *__restrict_
 // o inside the thread and glw a sum over the samples of the tile, flushed with one atomic per
 // (tile, column, o).
 // ------------------------------------------------------------------------------------
+// The stored output of a sum node, out = fl(logsumexp), carries half an ulp of its magnitude (3e-5 at 560, 6e-5 at 1100),
+// and exp(x + lw - out) inherits it as a RELATIVE error common to all responsibilities of the node (the reference does not
+// show it: its logsumexp backward normalises the very terms its forward summed).  corr[b,p,o] = log sum_n exp((x - out) + lw)
+// -- the residual of the stored output against the sum the backward is about to form, a number of magnitude 1e-5 and
+// therefore exact to 1e-12 as an fp32 -- is subtracted in the exponent: the responsibilities then sum to one.
+// thread = one (b, p, o) row for short rows, a wave for long ones.
+__global__ __launch_bounds__(256) void lse_residual_kernel(const float *__restrict__ x, const float *__restrict__ LW,
+                                                          const float *__restrict__ out, int64_t B, int P, int N, int S,
+                                                          float *__restrict__ corr) {
+    const int64_t rows = B * P * S;
+    if (N <= 32) {
+        for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+            const int o = (int)(r % S);
+            const int64_t bp = r / S;
+            const int p = (int)(bp % P);
+            const float xo = out[r];
+            const float *xr = x + bp * N, *lw = LW + ((int64_t)p * S + o) * N;
+            float sum = 0.f;
+            for (int n = 0; n < N; ++n) sum += expf((xr[n] - xo) + lw[n]);
+            corr[r] = (xo > -INFINITY && sum > 0.f) ? logf(sum) : 0.f;
+        }
+    } else {
+        const int lane = threadIdx.x & 63;
+        for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+            const int o = (int)(r % S);
+            const int64_t bp = r / S;
+            const int p = (int)(bp % P);
+            const float xo = out[r];
+            const float *xr = x + bp * N, *lw = LW + ((int64_t)p * S + o) * N;
+            float sum = 0.f;
+            for (int n = lane; n < N; n += 64) sum += expf((xr[n] - xo) + lw[n]);
+            sum = wave_reduce_sum(sum);
+            if (lane == 0) corr[r] = (xo > -INFINITY && sum > 0.f) ? logf(sum) : 0.f;
+        }
+    }
+}
+
 constexpr int kBwdTile = 32;   // samples per block in the sum backward (16 / 8 while the grid would not cover the chip)
 constexpr int kBwdOB = 16;     // outputs held in registers at a time
 constexpr int kBwdWaves = 4;
@@ -280,7 +318,8 @@ __global__ __launch_bounds__(64 * kBwdWaves) void sum_bwd_kernel(const float *__
                                                                 const float *__restrict__ out,
                                                                 const float *__restrict__ g, int64_t B, int P, int N,
                                                                 int S, float *__restrict__ gx,
-                                                                float *__restrict__ glw, int tile) {
+                                                                float *__restrict__ glw, int tile,
+                                                                const float *__restrict__ corr) {
     __shared__ float red[kBwdWaves][kBwdOB][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.y * 64 + lane;  // (p, n) flattened
@@ -302,22 +341,24 @@ __global__ __launch_bounds__(64 * kBwdWaves) void sum_bwd_kernel(const float *__
         for (int64_t b = b0; b < b1; ++b) {
             const float xv = x[b * P * N + cc];
             const float *op = out + (b * P + p) * S + ob, *gp = g + (b * P + p) * S + ob;
+            const float *cp = corr + (b * P + p) * S + ob;
             float tot = 0.f;
             // (outputs beyond S read the last valid one and are dropped by a select: `if (ob + q < S) { loads }` was a
             // dependent round trip per output and sample)
-            float xo8[kBwdOB], g8[kBwdOB];
+            float xo8[kBwdOB], g8[kBwdOB], c8[kBwdOB];
 #pragma unroll
             for (int q = 0; q < kBwdOB; ++q) {
                 const int qc = min(q, S - 1 - ob);
                 xo8[q] = op[qc];
                 g8[q] = gp[qc];
+                c8[q] = cp[qc];
             }
 #pragma unroll
             for (int q = 0; q < kBwdOB; ++q) {
                 const float xo = xo8[q];
                 // an all -inf row has out = -inf: its gradient is defined as zero (reference: the
                 // masked_fill guard inside torch.logsumexp's backward gives the same)
-                const float t = (ob + q < S && xo > -INFINITY) ? g8[q] * expf((xv - xo) + lw[q]) : 0.f;   // (large magnitudes cancel first, exactly)
+                const float t = (ob + q < S && xo > -INFINITY) ? g8[q] * expf(((xv - xo) + lw[q]) - c8[q]) : 0.f;   // (large magnitudes cancel first, exactly; then the residual)
                 acc[q] += t;
                 tot += t;
             }
@@ -844,8 +885,8 @@ extern "C" int dpk_product_backward(const float *g, int64_t B, int32_t R, int32_
 // workspace of the sum / root operators: W, LW, glw  (each P*S*N floats)
 extern "C" int64_t dpk_sum_workspace_bytes(int64_t B, int32_t P, int32_t N, int32_t S) {
     if (P <= 0 || N <= 0 || S <= 0) return DPK_EINVAL;
-    (void)B;
-    return 3 * align_up((int64_t)P * S * N * 4, 256);
+    // (+ the backward's per-output normalisation residuals, [B, P, S] floats: lse_residual_kernel)
+    return 3 * align_up((int64_t)P * S * N * 4, 256) + align_up(std::max<int64_t>(B, 0) * P * S * 4, 256);
 }
 
 static int sum_forward_impl(const float *in, const float *weight, int64_t B, int P, int N, int S, float *out,
@@ -874,10 +915,17 @@ static int sum_backward_impl(const float *in, const float *weight, const float *
     DPK_REQUIRE(B >= 0 && P > 0 && N > 0 && S > 0, DPK_EINVAL, "%s: bad sizes", who);
     DPK_REQUIRE(weight && ws && (B == 0 || (in && out && g)), DPK_EINVAL, "%s: null pointer", who);
     const int64_t seg = align_up((int64_t)P * S * N * 4, 256);
-    DPK_REQUIRE(ws_bytes >= 3 * seg, DPK_EWORKSPACE, "%s: workspace too small", who);
+    DPK_REQUIRE(ws_bytes >= 3 * seg + align_up(B * P * S * 4, 256), DPK_EWORKSPACE, "%s: workspace too small", who);
     float *W = (float *)ws, *LW = (float *)((char *)ws + seg), *glw = (float *)((char *)ws + 2 * seg);
+    float *corr = (float *)((char *)ws + 3 * seg);
     hipStream_t st = (hipStream_t)stream;
     launch_softmax_rows(weight, P * S, N, W, LW, st);
+    if (B > 0) {
+        const int64_t rows = B * P * S;
+        const int64_t blocks = N <= 32 ? (rows + 255) / 256 : (rows + 3) / 4;
+        DPK_LAUNCH(lse_residual_kernel, dim3((unsigned)std::min<int64_t>(blocks, 65535 * 4)), dim3(256), 0, st, in, LW, out, B, P, N,
+                   S, corr);
+    }
     if (grad_weight) {
         hipError_t e = hipMemsetAsync(glw, 0, (size_t)P * S * N * 4, st);
         DPK_REQUIRE(e == hipSuccess, DPK_ELAUNCH, "%s: memset: %s", who, hipGetErrorString(e));
@@ -887,7 +935,7 @@ static int sum_backward_impl(const float *in, const float *weight, const float *
         int tile = kBwdTile;   // (shorter sample slices while the grid would leave compute units idle)
         while (tile > 8 && cdiv(B, tile) * cdiv(cols, 64) < 2 * device_cus()) tile /= 2;
         DPK_LAUNCH(sum_bwd_kernel, dim3(cdiv(B, tile), cdiv(cols, 64)), dim3(64 * kBwdWaves), 0, st, in, LW,
-                           out, g, B, P, N, S, grad_in, grad_weight ? glw : nullptr, tile);
+                           out, g, B, P, N, S, grad_in, grad_weight ? glw : nullptr, tile, corr);
     } else if (grad_in) {
         // nothing to write
     }

@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256) void prodsum16_bwd_kernel(const LevelBwdArgs a
     __shared__ float red[4][S];
     __shared__ float bc[2][S];
     __shared__ float colp[2][4][N];
+    __shared__ float zred[2][4][2][S];      // [trip parity][wave][sample of the trip][sum node]: normalisation partials
     __shared__ unsigned last_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = tid >> 4, j = tid & 15;
@@ -249,14 +250,30 @@ __global__ __launch_bounds__(256) void prodsum16_bwd_kernel(const LevelBwdArgs a
             }
         }
         float ga[UN], gc[UN];
+        // responsibilities normalised over the node's 256 inputs = the work-group (not by the stored `out`, whose rounding
+        // would scale them all alike: see two_sum in common.h); the partial sums of the four waves meet in LDS,
+        // double-buffered by trip parity (a wave reaches trip k + 2 only through the barrier of trip k + 1)
+        float e[UN][S];
+        const int zp = (int)(((bb - b0) / UN) & 1);
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const bool in = bb + u < b1;
             const TwoSum ac = two_sum(xa[u], xc[u]);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                e[u][s] = (in && o[u][s] > -INFINITY) ? expf(resp_arg(ac, lw[s], o[u][s])) : 0.f;
+                const float zw = wave_reduce_sum(e[u][s]);
+                if (lane == 0) zred[zp][wave][u][s] = zw;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
             float tot = 0.f;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                const float t = (in && o[u][s] > -INFINITY) ? gg[u][s] * expf(resp_arg(ac, lw[s], o[u][s])) : 0.f;
+                const float z = (zred[zp][0][u][s] + zred[zp][1][u][s]) + (zred[zp][2][u][s] + zred[zp][3][u][s]);
+                const float t = z > 0.f ? gg[u][s] * (e[u][s] / z) : 0.f;
                 acc[s] += t;
                 tot += t;
             }

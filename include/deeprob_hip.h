@@ -192,6 +192,11 @@ int64_t dpk_ratspn_small_batch_max(int64_t samples);
  * (-1: never; below -1: back to the built-in default, also given by DPK_GEMM_SLICE_MIN) and returns the previous one.
  * Process-wide tuning knob: results of the mappings agree to fp32 rounding.                                          */
 int64_t dpk_ratspn_slice_batch_min(int64_t samples);
+/* Whether RatSpn.forward / RegionGraphLayer.forward (deeprob/spn/models/ratspn.py:105-122, layers/ratspn.py:87-108) may take
+ * the matrix-core route (split-f16 MFMA leaf GEMM, >= 22 bits per product, guarded) at all: 1 = yes (default, also
+ * DPK_RATSPN_GEMM in the environment), 0 = every launch on the exact fp32 vector-ALU kernels; negative = query only.
+ * Returns the previous setting.  Process-wide measurement knob: bench.py quotes the exact-fp32 step beside the headline. */
+int32_t dpk_ratspn_mfma_route(int32_t enable);
 int dpk_ratspn_forward(const float *x, int64_t B, int32_t D, const int64_t *mask,
                        const uint8_t *pad_mask, const float *loc, const float *scale,
                        const float *sum_weight0, const float *sum_weight1,

@@ -174,3 +174,24 @@ def test_dropout_hash_restatement():
         z ^= z >> 31
         assert bool(got[idx]) == ((z >> 40) < np.float32(p) * np.float32(16777216.0)), idx
     assert abs(dropout_mask(7, (200000,), 0.2).float().mean().item() - 0.2) < 0.005
+
+
+def test_bench_multi_gpu_plan_names_the_shards():
+    """the N > 1 bench line is built from a plan that can be checked without a GPU -- the default reading
+    for N > 1 is the metric's own (strong: 65536 samples in total, 65536 / N per rank, named in config.workload), the other
+    mode and BASELINE config 3's shape (32768 per rank: 262144 over 8 GPUs) are measured beside it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for n in (2, 4, 8):
+        plan = bench.shard_plan(n, 65536, 'strong')
+        assert plan['per_rank'] == 65536 // n and plan['global'] == 65536
+        assert plan['other_scaling'] == 'weak' and plan['other_per_rank'] == 65536
+        assert plan['config3_per_rank'] == 32768 and plan['config3_global'] == 32768 * n
+        w = bench.workload_string(2, 2, plan['per_rank'], n, 'nccl')
+        assert '{} samples per GPU per step'.format(65536 // n) in w and 'RCCL all-reduce' in w
+    assert bench.shard_plan(8, 65536, 'strong')['config3_global'] == 262144
+    plan = bench.shard_plan(4, 65536, 'weak')
+    assert plan['per_rank'] == 65536 and plan['global'] == 262144 and plan['other_per_rank'] == 16384
+    assert 'all-reduce' not in bench.workload_string(2, 2, 65536, 1, 'nccl')
