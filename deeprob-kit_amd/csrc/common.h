@@ -321,9 +321,13 @@ __device__ __forceinline__ float nan_to_num_f(float t) {
 struct TwoSum { float hi, lo; };
 __device__ __forceinline__ TwoSum two_sum(float a, float b) {
     const float s = a + b, bb = s - a;
-    return {s, (a - (s - bb)) + (b - bb)};
+    const float lo = (a - (s - bb)) + (b - bb);
+    return {s, fabsf(s) < INFINITY ? lo : 0.f};      // (a dead input, -inf: the error term would be inf - inf)
 }
-__device__ __forceinline__ float resp_arg(const TwoSum ac, float lw, float out) { return (ac.hi - out) + (lw + ac.lo); }
+// (clamped: where the evidence is so large that the stored `out` is off by whole units -- ulp(4e8) = 32 -- the terms of a node
+// may exceed it by more than exp() can hold; the normalisation that follows only needs them finite)
+constexpr float kRespArgMax = 60.f;
+__device__ __forceinline__ float resp_arg(const TwoSum ac, float lw, float out) { return fminf((ac.hi - out) + (lw + ac.lo), kRespArgMax); }
 
 __device__ __forceinline__ float wave_reduce_sum(float v) {
 #pragma unroll

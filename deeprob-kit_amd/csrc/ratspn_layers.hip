@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void lse_residual_kernel(const float *__restri
             const float xo = out[r];
             const float *xr = x + bp * N, *lw = LW + ((int64_t)p * S + o) * N;
             float sum = 0.f;
-            for (int n = 0; n < N; ++n) sum += expf((xr[n] - xo) + lw[n]);
+            for (int n = 0; n < N; ++n) sum += expf(fminf((xr[n] - xo) + lw[n], kRespArgMax));
             corr[r] = (xo > -INFINITY && sum > 0.f) ? logf(sum) : 0.f;
         }
     } else {
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void lse_residual_kernel(const float *__restri
             const float xo = out[r];
             const float *xr = x + bp * N, *lw = LW + ((int64_t)p * S + o) * N;
             float sum = 0.f;
-            for (int n = lane; n < N; n += 64) sum += expf((xr[n] - xo) + lw[n]);
+            for (int n = lane; n < N; n += 64) sum += expf(fminf((xr[n] - xo) + lw[n], kRespArgMax));
             sum = wave_reduce_sum(sum);
             if (lane == 0) corr[r] = (xo > -INFINITY && sum > 0.f) ? logf(sum) : 0.f;
         }
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(64 * kBwdWaves) void sum_bwd_kernel(const float *__
                 const float xo = xo8[q];
                 // an all -inf row has out = -inf: its gradient is defined as zero (reference: the
                 // masked_fill guard inside torch.logsumexp's backward gives the same)
-                const float t = (ob + q < S && xo > -INFINITY) ? g8[q] * expf(((xv - xo) + lw[q]) - c8[q]) : 0.f;   // (large magnitudes cancel first, exactly; then the residual)
+                const float t = (ob + q < S && xo > -INFINITY) ? g8[q] * expf(fminf((xv - xo) + lw[q], kRespArgMax) - c8[q]) : 0.f;   // (large magnitudes cancel first, exactly; then the residual)
                 acc[q] += t;
                 tot += t;
             }
