@@ -62,6 +62,9 @@ def parse():
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only to "
                     "rehearse the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument('--share-device', action='store_true', help='rehearsal: every rank uses cuda:0')
+    ap.add_argument('--streams', type=int, default=2,
+                    help='N = 1, eager loop: evaluation streams the K timed steps alternate between (a model replica each); '
+                         '1 = the single-stream loop only')
     ap.add_argument('--graph-window', action='store_true',
                     help='time the K steps through the graphed evaluation window at N = 1 too (the N > 1 default)')
     ap.add_argument('--kernel-event-every', type=int, default=0,
@@ -966,6 +969,45 @@ def main():
         except Exception as ex:
             step_mode = 'eager (graphed window failed: {}: {})'.format(type(ex).__name__, str(ex)[:120])
 
+    # ---- N = 1: the K timed steps once more, alternating between two evaluation streams ----------------
+    # A launch of the slice kernel holds every compute unit with one work-group; on one stream launch k + 1 starts when
+    # launch k has completely finished (its tail: ~4 us of last-block upper layers with HBM idle; then a ~7.7 us prologue).
+    # With two streams the next launch's work-groups are dispatched as compute units come free.  A model replica per stream:
+    # the in-launch table check's tickets assume that the launches of a workspace follow one another.  This loop gives
+    # `value`; the single-stream loop above carries the kernel events (overlapping launches stretch each other's brackets) --
+    # the per-kernel roofline does not show this gain, by construction.
+    one_stream_ms = None
+    if world == 1 and args.streams > 1 and not args.graph_window:
+        import copy
+        ns = args.streams
+        replicas = [model] + [copy.deepcopy(model) for _ in range(ns - 1)]
+        lanes = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+        evs = [ShardedLogLikelihood(m, static_inputs=True, static_params=False) for m in replicas]
+
+        def run_lanes(n):
+            for i in range(n):
+                with torch.cuda.stream(lanes[i % ns]):
+                    evs[i % ns].step(xs[i % ring])
+
+        try:
+            with torch.no_grad():
+                torch.cuda.synchronize()
+                run_lanes(max(args.warmup, 4 * ns))
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                run_lanes(args.steps)
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t2
+                means2 = [e.drain() for e in evs]
+            if abs(means2[0][-1] - mean_ll) > 1e-3 * abs(mean_ll) and ring % ns == 0:
+                raise RuntimeError('two-stream mean LL {} != {}'.format(means2[0][-1], mean_ll))
+            one_stream_ms = dt / args.steps * 1e3
+            dt = dt2
+            step_mode = ('eager: {} evaluation streams, alternate steps, a model replica each (single-stream loop of the same '
+                         'steps: {:.5f} ms/step; roofline.kernel_ms comes from that loop)'.format(ns, one_stream_ms))
+        except Exception as ex:
+            step_mode += ' (two-stream loop failed: {}: {})'.format(type(ex).__name__, str(ex)[:100])
+
     # the same loop with a frozen model (static_params=True: no per-call table check), and on the exact fp32 route
     # (dpk_ratspn_mfma_route(0): the vector-ALU kernels, fp32 products) -- what the split-f16 matrix-core route buys
     def plain_loop(ev, steps):
@@ -1014,6 +1056,7 @@ def main():
                        'host_enqueue_ms_per_step': round(host_dt / args.steps * 1e3, 5), 'step_mode': step_mode,
                        'other_scaling': weak_entry,
                        'params_mode': 'default: static_params=False (cached parameter tables checked on the device at every call)',
+                       'ms_per_step_one_stream': one_stream_ms,
                        'ms_per_step_frozen_model': ms_frozen,
                        'fp32_exact_ms': ms_exact,
                        'arithmetic': 'fp32 results; leaf GEMM = 3 f16 MFMAs on two-way f16 splits, fp32 accumulate '

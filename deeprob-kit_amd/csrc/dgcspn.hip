@@ -1683,6 +1683,18 @@ __global__ __launch_bounds__(256) void spatial_leaf_prodsum_kernel(const float *
     }
 }
 
+// smallest leaf channel count that takes the general (non-pooling) form of the fused first level: measurement knob
+static int &leaf_fuse_min_k_ref() {
+    static int v = [] { const char *e = getenv("DPK_DGC_LEAF_FUSE_MIN_K"); return e ? atoi(e) : 16; }();
+    return v;
+}
+extern "C" int32_t dpk_spatial_leaf_fuse_min_k(int32_t k) {
+    int &v = leaf_fuse_min_k_ref();
+    const int prev = v;
+    if (k > 0) v = k;
+    return prev;
+}
+
 // SpatialGaussianLayer + the first depthwise product + sum level in one launch (eval route; models/dgcspn.py:134-147 for
 // i = 0, 1): 2 x 2 windows, 8 / 16 / 32 leaf channels, up to 32 sum channels -- DPK_EUNSUPPORTED otherwise (the caller runs
 // dpk_spatial_gaussian_forward + dpk_spatial_prodsum_forward).  DPK_DGC_LEAF_FUSE_MIN_K (measurement only) raises the
@@ -1706,8 +1718,7 @@ extern "C" int dpk_spatial_leaf_prodsum_forward(const float *x, const float *loc
     // (the general form evaluates an input pixel's leaf once per window that taps it -- four times at stride 1: for 8 leaf
     // channels that costs what the leaf map's round trip saves, 186 us against 76 + 110 on config 4's first level, so the
     // 8-channel models keep the leaf kernel + the streaming level; DPK_DGC_LEAF_FUSE_MIN_K: measurement only)
-    const char *leaf_env = getenv("DPK_DGC_LEAF_FUSE_MIN_K");   // (per call: the tests switch it)
-    const int leaf_min_k = leaf_env ? atoi(leaf_env) : 16;
+    const int leaf_min_k = leaf_fuse_min_k_ref();   // (dpk_spatial_leaf_fuse_min_k: read once from the environment, set by tests)
     const bool ok = (K == 8 || K == 16 || K == 32) && (pool || K >= leaf_min_k) && Cout <= 32 && kh == 2 && kw == 2 &&
                     lds <= 150 * 1024 && B <= INT32_MAX / 2;
     if (!ok) {
@@ -1905,6 +1916,11 @@ extern "C" int64_t dpk_spatial_sumprodroot_workspace_bytes(int32_t C, int32_t Co
 // kernel applies, one (max, sum) pair per sample, class and compute wave for the root's log-sum-exp.  geom5 / geom6 as
 // in dpk_spatial_sumprodroot_forward.  With only dpk_spatial_sumprodroot_workspace_bytes() bytes the entry point
 // runs the batch-independent kernel.
+// the one statement of dpk_spatial_sumprodroot_forward's shape envelope
+static bool sumprodroot_shape_ok(const ProdGeom &q5, const ProdGeom &q6, int C, int Cout) {
+    return q5.kh * q5.kw <= 4 && q6.kh * q6.kw <= 4 && C <= 8 && Cout <= 8 && q6.OH * q6.OW <= 1024;
+}
+
 extern "C" int64_t dpk_spatial_sumprodroot_workspace_bytes_batch(int64_t B, int32_t C, int32_t H, int32_t W,
                                                                  const int32_t *geom5, int32_t Cout,
                                                                  const int32_t *geom6, int32_t K) {
@@ -1917,6 +1933,8 @@ extern "C" int64_t dpk_spatial_sumprodroot_workspace_bytes_batch(int64_t B, int3
         make_geom(q6, Cout, geom5[0], geom5[1], Cout, geom6[0], geom6[1], geom6[2], geom6[3], geom6[4], geom6[5],
                   geom6[6], geom6[7], geom6[8], geom6[9], 1))
         return DPK_EINVAL;
+    // (the forward's envelope, answered here so that no caller keeps a copy of these constants: ADVICE r05)
+    if (!sumprodroot_shape_ok(q5, q6, C, Cout)) return DPK_EUNSUPPORTED;
     return base + stream_sumprodroot_partial_bytes(q5, Cout, q6, K, B);
 }
 
@@ -1934,7 +1952,7 @@ extern "C" int dpk_spatial_sumprodroot_forward(const float *in, int64_t B, int32
                    geom6[6], geom6[7], geom6[8], geom6[9], 1);
     if (rc) return rc;
     DPK_REQUIRE(B >= 0 && Cout > 0 && K > 0, DPK_EINVAL, "spatial_sumprodroot: bad sizes");
-    DPK_REQUIRE(q5.kh * q5.kw <= 4 && q6.kh * q6.kw <= 4 && C <= 8 && Cout <= 8 && q6.OH * q6.OW <= 1024,
+    DPK_REQUIRE(sumprodroot_shape_ok(q5, q6, C, Cout),
                 DPK_EUNSUPPORTED, "spatial_sumprodroot: shape outside the fused kernel (<= 8 channels, <= 1024 pixels)");
     DPK_REQUIRE(B <= INT32_MAX / 2 && (int64_t)B * C * H * W < ((int64_t)1 << 46), DPK_EUNSUPPORTED,
                 "spatial_sumprodroot: tensor too large");

@@ -133,8 +133,8 @@ template <int S> struct WideUpFrags {
 // nodes take their log-softmax weights straight from the raw sum / root weights.
 // NW = 4: the block is shared by TWO work-groups of four waves, repetitions [4 g, 4 g + 4) each (the 32-sample kernel at
 // batches that would otherwise leave half the chip idle).  Each leaves its (max, sum) root partials in its slot of the
-// workspace (xpart), performed before it draws the block's ticket (xtick, only ever counted up: two per launch and
-// block); the work-group that draws the odd ticket merges the other's partials with its own and stores.
+// workspace (xpart), performed before it draws the block's ticket (xtick: two draws per launch and block, then reset by the
+// second arriver); the work-group that draws the odd ticket merges the other's partials with its own and stores.
 template <int S, bool PRE = true, bool EMIT = false, int NW = kWideWaves>
 __device__ __forceinline__ double wide_block_upper(const GemmArgs &a, const gf32x16 &acc, unsigned long long odd_mask,
                                                    float qtot, bool exact, int rho, bool mine, int64_t b0,
@@ -323,6 +323,10 @@ __device__ __forceinline__ double wide_block_upper(const GemmArgs &a, const gf32
         if (tid == 0) *tick_l = (int)__hip_atomic_fetch_add(xtick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if ((*tick_l & 1) != 0) {   // the second of the two: the other's partials are there
+            // (both arrivals of this launch are in: the ticket goes back to zero, so that a launch that was aborted between
+            // its two arrivals costs the NEXT launch this block once instead of shifting the parity for good -- ADVICE r05;
+            // two streams on one workspace remain outside the contract: a workspace's launches follow one another)
+            if (tid == 0) __hip_atomic_store(xtick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int i = 0; i < kMaxPer; ++i) {
                 const int e = i * NW * 64 + tid;

@@ -76,6 +76,7 @@ SIGNATURES = {
     'dpk_ratspn_small_batch_max': (_i64, [_i64]),
     'dpk_ratspn_slice_batch_min': (_i64, [_i64]),
     'dpk_ratspn_mfma_route': (_i32, [_i32]),
+    'dpk_spatial_leaf_fuse_min_k': (_i32, [_i32]),
     'dpk_upper_tables_pair': (ctypes.c_int, [_c_void, _i32, _i32, _i32, _c_void, _i64, _c_void, _i32, _i32, _i32, _c_void, _i64,
                                              _c_void]),
     'dpk_prodsum_backward': (ctypes.c_int, [_c_void, _c_void, _c_void, _c_void, _i64, _i32, _i32, _i32, _i32, _c_void,

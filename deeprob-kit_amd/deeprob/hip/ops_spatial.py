@@ -197,7 +197,7 @@ def tables_prepare(levels, x: torch.Tensor):
             g5 = (ctypes.c_int32 * 10)(OH, OW, kh, kw, sh, sw, dh, dw, pt, pl)
             g6 = (ctypes.c_int32 * 10)(OH6, OW6, kh6, kw6, sh6, sw6, dh6, dw6, pt6, pl6)
             n = lib.dpk_spatial_sumprodroot_workspace_bytes_batch(B, C, H, W, g5, Cout, g6, K)
-            if n < 0 or C > 8 or Cout > 8 or OH6 * OW6 > 1024 or kh * kw > 4 or kh6 * kw6 > 4:   # (dpk_spatial_sumprodroot_forward's envelope)
+            if n < 0:   # (DPK_EUNSUPPORTED: outside dpk_spatial_sumprodroot_forward's envelope -- the library's answer, no copy of its constants here)
                 # outside the last-level kernel (wide models): the forward will run this level through spatial_prodsum --
                 # its tables join this launch instead of costing one of their own
                 ws = sm._ws
@@ -401,6 +401,8 @@ def spatial_sumprodroot(x, prod5, sum_weight, prod6, root_weight, ws: Workspace)
     g6 = (ctypes.c_int32 * 10)(OH6, OW6, kh6, kw6, sh6, sw6, dh6, dw6, pt6, pl6)
     B = x.shape[0]
     n = lib.dpk_spatial_sumprodroot_workspace_bytes_batch(B, C, H, W, g5, Cout, g6, K)
+    if n == -4:  # DPK_EUNSUPPORTED: outside the fused kernel's envelope
+        return None
     if n < 0:
         check(int(n), 'dpk_spatial_sumprodroot_workspace_bytes_batch')
     buf = ws.get(n, x.device)

@@ -420,6 +420,10 @@ int dpk_spatial_leaf_prodsum_forward(const float *x, const float *loc, const flo
                                      int32_t sw, int32_t dh, int32_t dw, int32_t pad_top, int32_t pad_left,
                                      const float *weight, int32_t Cout, float *out, void *ws, int64_t ws_bytes,
                                      uint32_t flags, void *stream);
+/* Smallest leaf channel count for which dpk_spatial_leaf_prodsum_forward takes the general (stride-1) form of the fused
+ * first level of DgcSpn.forward (deeprob/spn/models/dgcspn.py:134-147; default 16, DPK_DGC_LEAF_FUSE_MIN_K in the
+ * environment sets the initial value): k > 0 sets it, k <= 0 only queries.  Returns the previous value.  Measurement knob. */
+int32_t dpk_spatial_leaf_fuse_min_k(int32_t k);
 
 /* ---- RealNVP-1D training route (autograd of the flow) ------------------- */
 /* Backward of CouplingLayer1d.apply_backward (flows/layers/coupling.py:72-87), depth-1 conditioner:

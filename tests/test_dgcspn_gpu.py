@@ -229,14 +229,16 @@ def test_wide_fused_level_against_oracle(shape, padding, stride, dil, cout, B):
     ((1, 28, 28), 16, 32, 150, 'valid', 2, 1), ((3, 12, 12), 16, 20, 67, 'valid', 2, 1), ((2, 8, 8), 32, 32, 33, 'valid', 2, 1),
     ((1, 28, 28), 8, 8, 150, 'full', 1, 1), ((3, 9, 9), 16, 12, 41, 'full', 1, 2), ((1, 11, 11), 32, 32, 37, 'valid', 2, 1),
     ((2, 7, 7), 8, 5, 300, 'final', 1, 4)])
-def test_fused_leaf_and_first_level_against_oracle(shape, k, cout, B, padding, stride, dil, monkeypatch):
+def test_fused_leaf_and_first_level_against_oracle(shape, k, cout, B, padding, stride, dil, request):
     """Round 5: the Gaussian leaf layer folded into the first level of the eval route (the pooling form and the general one)
     (dpk_spatial_leaf_prodsum_forward: the [B, K, H, W] leaf map is never written) against the oracle's leaf + product +
     sum: several image channels, marginalised (NaN) pixels and a whole marginalised image, scales away from 1, a batch
     that is not a multiple of the sample slots; the result of a sample does not depend on its place in the batch."""
     from deeprob.spn.layers.dgcspn import SpatialGaussianLayer, SpatialProductLayer, SpatialSumLayer
     from deeprob.hip import ops_spatial
-    monkeypatch.setenv('DPK_DGC_LEAF_FUSE_MIN_K', '8')     # (by default 8-channel models keep leaf kernel + streaming level: faster)
+    from deeprob.hip import load_library
+    prev_k = load_library().dpk_spatial_leaf_fuse_min_k(8)   # (by default 8-channel models keep leaf kernel + streaming level: faster)
+    request.addfinalizer(lambda: load_library().dpk_spatial_leaf_fuse_min_k(prev_k))
     gen = torch.Generator().manual_seed(29)
     leaf = SpatialGaussianLayer(shape, k, optimize_scale=True).cuda()
     prod = SpatialProductLayer((k,) + tuple(shape[1:]), 2, padding, stride, dil, depthwise=True).cuda()
