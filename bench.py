@@ -992,8 +992,17 @@ def main():
         try:
             with torch.no_grad():
                 torch.cuda.synchronize()
+                # (the new streams are new hardware queues: the runtime's one-off pool growth -- see --prewarm -- happens per
+                # queue and must not land in the timed window either)
+                for _ in range(-(-args.prewarm * ns // 256)):
+                    run_lanes(256)
+                    torch.cuda.synchronize()
+                    for e in evs:
+                        e.drain()
                 run_lanes(max(args.warmup, 4 * ns))
                 torch.cuda.synchronize()
+                for e in evs:
+                    e.drain()
                 t2 = time.perf_counter()
                 run_lanes(args.steps)
                 torch.cuda.synchronize()
