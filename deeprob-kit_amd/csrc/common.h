@@ -334,6 +334,28 @@ __device__ __forceinline__ float wave_reduce_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Sum over the G = 4 / 16 / 64 consecutive lanes of a group on the vector ALU's DPP path (no LDS crossbar: __shfl_xor is a
+// ds_bpermute round trip per step), result in every lane of the group: quads, half rows, rows (16 lanes), then the row
+// results walk to lane 63, which is read back wave-uniform.
+#define DPK_DPP_ADD(x, ctrl, rmask) \
+    ((x) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), ctrl, rmask, 0xf, false)))
+template <int G> __device__ __forceinline__ float dpp_group_sum(float v) {
+    static_assert(G == 1 || G == 4 || G == 16 || G == 64, "quad, row or wave");
+    if (G >= 4) {
+        v = DPK_DPP_ADD(v, 0xB1, 0xf);     // quad_perm [1,0,3,2]
+        v = DPK_DPP_ADD(v, 0x4E, 0xf);     // quad_perm [2,3,0,1]
+    }
+    if (G >= 16) {
+        v = DPK_DPP_ADD(v, 0x141, 0xf);    // row_half_mirror
+        v = DPK_DPP_ADD(v, 0x140, 0xf);    // row_mirror
+    }
+    if (G == 64) {
+        v = DPK_DPP_ADD(v, 0x142, 0xa);    // row_bcast:15 into rows 1 and 3
+        v = DPK_DPP_ADD(v, 0x143, 0xc);    // row_bcast:31 into rows 2 and 3
+        v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    }
+    return v;
+}
 __device__ __forceinline__ double wave_reduce_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -627,21 +627,39 @@ __global__ __launch_bounds__(256) void leaf_bwd_moment_kernel(
     float (*gabw)[32] = reinterpret_cast<float (*)[32]>(piv + 32 + 4 * 32);                   // [wave][row]
     int *redo = reinterpret_cast<int *>(piv + 32 + 8 * 32);
     __syncthreads();
-    if (tid < 32) {
-        // the pivot of column tid: midpoint of the means of the rows that hold it (loads unconditional at a clamped
-        // position, selected afterwards: a load behind a branch is a round trip of its own)
+    {
+        // the pivot of a column: midpoint of the means of the rows that hold it.  thread = (column, one of 8 row groups): four
+        // rows each, their loads unconditional at a clamped position (a load behind a branch is a round trip of its own) and
+        // all in flight together; the groups meet in LDS (the staging area is not in use yet)
+        float (*pmm)[2][32] = reinterpret_cast<float (*)[2][32]>(stage);      // [row group][min, max][column]
+        const int col = tid & 31, part = tid >> 5;
         float lo = INFINITY, hi = -INFINITY;
         if (DIST == 0) {
-            for (int rl = 0; rl < nreg; ++rl) {
-                const int j = jmap[rl][tid];
-                for (int k = 0; k < I; ++k) {
-                    const float mu = p0[((int64_t)(r0 + rl) * I + k) * d + max(j, 0)];
-                    lo = j >= 0 ? fminf(lo, mu) : lo;
-                    hi = j >= 0 ? fmaxf(hi, mu) : hi;
-                }
+            float mu[4];
+            int jj[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = part + 8 * q, rl = i / I, k = i - rl * I;
+                jj[q] = jmap[rl][col];
+                mu[q] = p0[((int64_t)(r0 + rl) * I + k) * d + max(jj[q], 0)];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                lo = jj[q] >= 0 ? fminf(lo, mu[q]) : lo;
+                hi = jj[q] >= 0 ? fmaxf(hi, mu[q]) : hi;
             }
         }
-        piv[tid] = hi >= lo ? 0.5f * (lo + hi) : 0.f;
+        pmm[part][0][col] = lo;
+        pmm[part][1][col] = hi;
+        __syncthreads();
+        if (tid < 32) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                lo = fminf(lo, pmm[q][0][tid]);
+                hi = fmaxf(hi, pmm[q][1][tid]);
+            }
+            piv[tid] = hi >= lo ? 0.5f * (lo + hi) : 0.f;
+        }
     }
     if (tid == 0) *redo = 0;
     __syncthreads();

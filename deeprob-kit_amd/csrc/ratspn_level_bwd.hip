@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256) void prodsum_bwd_kernel(const LevelBwdArgs a) 
                 // N*N inputs (the lanes of the group) instead of trusting the stored `out`, whose own rounding (half an ulp
                 // of ~560) would otherwise scale all of them alike.
                 const float e = (in[u] && o[u][s] > -INFINITY) ? expf(resp_arg(ac, lw[s], o[u][s])) : 0.f;
-                const float z = group_sum<NN>(e);
-                const float t = z > 0.f ? gg[u][s] * (e / z) : 0.f;
+                const float z = dpp_group_sum<NN>(e);
+                const float t = z > 0.f ? gg[u][s] * (e * __builtin_amdgcn_rcpf(z)) : 0.f;   // (hardware reciprocal, 1 ulp: the IEEE division is ten instructions)
                 acc[s] += t;
                 tot += t;
             }
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void prodsum16_bwd_kernel(const LevelBwdArgs a
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 e[u][s] = (in && o[u][s] > -INFINITY) ? expf(resp_arg(ac, lw[s], o[u][s])) : 0.f;
-                const float zw = wave_reduce_sum(e[u][s]);
+                const float zw = dpp_group_sum<64>(e[u][s]);
                 if (lane == 0) zred[zp][wave][u][s] = zw;
             }
         }
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void prodsum16_bwd_kernel(const LevelBwdArgs a
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const float z = (zred[zp][0][u][s] + zred[zp][1][u][s]) + (zred[zp][2][u][s] + zred[zp][3][u][s]);
-                const float t = z > 0.f ? gg[u][s] * (e[u][s] / z) : 0.f;
+                const float t = z > 0.f ? gg[u][s] * (e[u][s] * __builtin_amdgcn_rcpf(z)) : 0.f;
                 acc[s] += t;
                 tot += t;
             }
@@ -397,8 +397,10 @@ __global__ __launch_bounds__(1024) void prodroot_bwd_kernel(const LevelBwdArgs a
 #pragma unroll
                 for (int q = 0; q < CB; ++q) {
                     e[u][q] = (o[u][q] > -INFINITY) ? expf(resp_arg(ac, lw[q], o[u][q])) : 0.f;
-                    const float zw = wave_reduce_sum(e[u][q]);
-                    if (lane == 0) zred[wave][u * CB + q] = zw;
+                    if (c0 + q < C) {      // (uniform: the classes that exist -- one, for the generative models)
+                        const float zw = dpp_group_sum<64>(e[u][q]);
+                        if (lane == 0) zred[wave][u * CB + q] = zw;
+                    }
                 }
             }
             __syncthreads();
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(1024) void prodroot_bwd_kernel(const LevelBwdArgs a
 #pragma unroll
                 for (int q = 0; q < CB; ++q) {
                     const float z = zsum[u * CB + q];
-                    const float t = z > 0.f ? gg[u][q] * (e[u][q] / z) : 0.f;
+                    const float t = (c0 + q < C && z > 0.f) ? gg[u][q] * (e[u][q] * __builtin_amdgcn_rcpf(z)) : 0.f;   // (classes beyond C: their LDS slots were never written)
                     acc[q] += t;
                     tot[u] += t;
                 }
