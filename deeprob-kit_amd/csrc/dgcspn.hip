@@ -1452,6 +1452,23 @@ extern "C" int dpk_spatial_prodsum_backward(const float *in, int64_t B, int32_t 
     return DPK_OK;
 }
 
+static bool sumprodroot_shape_ok(const ProdGeom &q5, const ProdGeom &q6, int C, int Cout);
+// Will a level of these shapes run on the streaming route (the one that takes / leaves pixel-major maps)?
+extern "C" int32_t dpk_spatial_level_streams(int32_t last, int64_t B, int32_t C, int32_t H, int32_t W, const int32_t *geom5,
+                                            int32_t Cout, const int32_t *geom6, int32_t K) {
+    if (!geom5 || B <= 0) return 0;
+    ProdGeom q5, q6;
+    if (make_geom(q5, C, H, W, C, geom5[0], geom5[1], geom5[2], geom5[3], geom5[4], geom5[5], geom5[6], geom5[7], geom5[8],
+                  geom5[9], 1))
+        return 0;
+    if (!last) return stream_prodsum_ok(q5, Cout, B, nullptr) ? 1 : 0;
+    if (!geom6 ||
+        make_geom(q6, Cout, geom5[0], geom5[1], Cout, geom6[0], geom6[1], geom6[2], geom6[3], geom6[4], geom6[5], geom6[6],
+                  geom6[7], geom6[8], geom6[9], 1))
+        return 0;
+    return (sumprodroot_shape_ok(q5, q6, C, Cout) && stream_sumprodroot_partial_bytes(q5, Cout, q6, K, B) > 0) ? 1 : 0;
+}
+
 // SpatialProductLayer (depthwise, <= 4 taps) followed by SpatialSumLayer, product map kept in registers.
 // DPK_EUNSUPPORTED for non-depthwise products, more than 4 taps or more than 32 channels: the caller chains
 // dpk_spatial_product_forward + dpk_spatial_sum_forward instead.
@@ -1484,7 +1501,9 @@ extern "C" int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C
         DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW, 256)), dim3(256), 0, st, weight,
                    Cout, C, OHW, Wl, LW);
     // large batches of the 8 -> 8 channel level: pixel-resident weights, taps staged through LDS (dgcspn_stream.hip)
-    if (stream_prodsum_ok(q, Cout, B, in)) return stream_prodsum_forward(in, B, q, Wl, LW, out, st);
+    const bool in_pm = (flags & DPK_FLAG_IN_PIXEL_MAJOR) != 0, out_pm = (flags & DPK_FLAG_OUT_PIXEL_MAJOR) != 0;
+    if (stream_prodsum_ok(q, Cout, B, in)) return stream_prodsum_forward(in, B, q, Wl, LW, out, st, in_pm, out_pm);
+    DPK_REQUIRE(!in_pm && !out_pm, DPK_EUNSUPPORTED, "spatial_prodsum: pixel-major maps only on the streaming route (dpk_spatial_level_streams)");
     const int Bi = (int)B;
     hipEvent_t pev0, pev1;
     profile_take(&pev0, &pev1, DPK_KERNEL_SPATIAL_PRODSUM);
@@ -1975,8 +1994,11 @@ extern "C" int dpk_spatial_sumprodroot_forward(const float *in, int64_t B, int32
         const int64_t base = dpk_spatial_sumprodroot_workspace_bytes(C, Cout, q5.OH, q5.OW, q6.OH, q6.OW, K);
         const int64_t part = ((uintptr_t)in & 15) == 0 ? stream_sumprodroot_partial_bytes(q5, Cout, q6, K, B) : 0;
         if (part > 0 && ws_bytes >= base + part)
-            return stream_sumprodroot_forward(in, B, q5, Wl, LW, q6, LWr, K, out, (char *)ws + base, st);
+            return stream_sumprodroot_forward(in, B, q5, Wl, LW, q6, LWr, K, out, (char *)ws + base, st,
+                                              (flags & DPK_FLAG_IN_PIXEL_MAJOR) != 0);
     }
+    DPK_REQUIRE(!(flags & DPK_FLAG_IN_PIXEL_MAJOR), DPK_EUNSUPPORTED,
+                "spatial_sumprodroot: a pixel-major input only on the streaming route (dpk_spatial_level_streams)");
     constexpr int kNB = 2;
     const int threads = (int)align_up(OHW6, 64);
     hipEvent_t pev0, pev1;

@@ -19,11 +19,12 @@ struct ProdGeom {
 //   stream_sumprodroot_*    : the same level followed by the last product and the root layer; `partials` holds
 //                             stream_sumprodroot_partial_bytes() bytes
 bool stream_prodsum_ok(const ProdGeom &q, int Cout, int64_t B, const float *in);
+//   in_pm / out_pm          : the input / output map is pixel-major ([B, H, W, 8], torch's channels_last) instead of [B, 8, H, W]
 int stream_prodsum_forward(const float *in, int64_t B, const ProdGeom &q, const float *Wl, const float *LW, float *out,
-                           hipStream_t st);
+                           hipStream_t st, bool in_pm = false, bool out_pm = false);
 int64_t stream_sumprodroot_partial_bytes(const ProdGeom &q5, int Cout, const ProdGeom &q6, int K, int64_t B);
 int stream_sumprodroot_forward(const float *in, int64_t B, const ProdGeom &q5, const float *Wl, const float *LW,
                                const ProdGeom &q6, const float *LWr, int K, float *out, void *partials,
-                               hipStream_t st);
+                               hipStream_t st, bool in_pm = false);
 
 }  // namespace dpk

@@ -16,6 +16,15 @@
 //   sub-piece shift of a channel is the same in every band) and ends with 4 guard floats that stay zero.
 //   Address of tap t in channel c: offb[t] (per thread, set once) + Kb[c] (per channel, wave-uniform).
 //
+// Round 6: PIXEL-MAJOR maps between the streaming levels (IN_PM / OUT_PM; torch's channels_last: [B, H, W, 8]).  The
+// channel-major stage costs a thread 32 ds_read_b32 + 32 address adds per sample for its 4 taps x 8 channels, and a
+// level 8 scattered stores: a third of the ~200 instructions of a pixel, on kernels that are bound by instruction issue
+// (the whole model: ~32 SIMD cycles per pixel and sample at every level).  With the 8 channels of a pixel adjacent, a tap
+// is two ds_read_b128 (8 LDS instructions and 4 address adds per sample), the level's result two 16-byte stores, a
+// stage one contiguous copy per row band (rows are 32 W bytes: no sub-piece shifts), and the loaders' piece map a
+// subtraction.  The first level of a model still reads the leaf layer's channel-major map, the caller of a single
+// level gets the layout it asks for.
+//
 // MODE 0 writes the level's map.  MODE 1 is the model's last sum level: its map (8 x 59 x 59 per sample for 28 x 28
 // inputs, the largest of the model) is consumed in registers by the last product layer (the four taps of a root
 // pixel sit in four neighbouring lanes, one DPP quad reduction) and the root layer's log-sum-exp, which leaves one
@@ -119,7 +128,7 @@ __device__ __forceinline__ float dpp_wave_sum(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-template <int MODE>
+template <int MODE, bool IN_PM, bool OUT_PM>
 __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
     lchar *smem = (lchar *)smem_generic;
@@ -144,10 +153,22 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
     const int cw = a.cw, nl = a.nl;
     const unsigned smem_base = (unsigned)(uintptr_t)smem;
 
+    // pixel-major stage: the bands back to back, band k at float offset lbp[k]; 8 zero floats (the guard pixel) behind them
+    int lbp[kStreamMaxBands], pm_floats = 0;
+#pragma unroll
+    for (int k = 0; k < kStreamMaxBands; ++k) {
+        lbp[k] = pm_floats;
+        if (k < nb) pm_floats += nr[k] * W * kStreamC;
+    }
     // guard words (never written again: the DMA pieces of the last band end before them)
-    for (int i = tid; i < nst * kStreamC * 4; i += blockDim.x) {
-        const int stg = i / (kStreamC * 4), c = (i >> 2) % kStreamC;
-        *(lfloat *)(smem + stg * stage_bytes + 4 * (c * CS + CS - 4 + (i & 3))) = 0.f;
+    if (IN_PM) {
+        for (int i = tid; i < nst * kStreamC; i += blockDim.x)
+            *(lfloat *)(smem + (i / kStreamC) * stage_bytes + 4 * (pm_floats + (i % kStreamC))) = 0.f;
+    } else {
+        for (int i = tid; i < nst * kStreamC * 4; i += blockDim.x) {
+            const int stg = i / (kStreamC * 4), c = (i >> 2) % kStreamC;
+            *(lfloat *)(smem + stg * stage_bytes + 4 * (c * CS + CS - 4 + (i & 3))) = 0.f;
+        }
     }
 
     if (wave >= cw) {
@@ -157,7 +178,7 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
         // fetches (or none: alignment slack, band gaps, the guard) never changes, so it is worked out here once and
         // a sample costs the loader nothing but the DMA instructions themselves.
         const int lw = wave - cw;
-        const int PPS = CS >> 2, NI = (kStreamC * PPS + 63) >> 6;
+        const int PPS = CS >> 2, NI = IN_PM ? ((pm_floats >> 2) + 63) >> 6 : (kStreamC * PPS + 63) >> 6;
         unsigned voff[kStreamMaxDma];
         unsigned live = 0;   // instructions with at least one lane to fetch
         int ninstr = 0;
@@ -166,7 +187,15 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
             const int j = lw + jj * nl;
             const int piece = j * 64 + lane, c = piece / PPS, f = 4 * (piece - c * PPS);   // float offset in the slot
             unsigned v = 0xffffffffu;
-            if (j < NI && c < kStreamC) {
+            if (IN_PM) {
+                // pixel-major: piece `piece` of the stage is floats [4 piece, 4 piece + 4) of the bands laid back to back; a
+                // band is one contiguous range of the sample's map (rows r0 .. r0 + nr - 1, 8 W floats each)
+                const int fp = 4 * piece;
+#pragma unroll
+                for (int k = 0; k < kStreamMaxBands; ++k)
+                    if (k < nb && fp >= lbp[k] && fp < lbp[k] + nr[k] * W * kStreamC)
+                        v = (unsigned)(r0[k] * W * kStreamC + (fp - lbp[k])) * 4u;
+            } else if (j < NI && c < kStreamC) {
 #pragma unroll
                 for (int k = 0; k < kStreamMaxBands; ++k) {
                     const int gfl = c * HW + r0[k] * W, sh = gfl & 3, np = (sh + nr[k] * W + 3) >> 2;
@@ -240,11 +269,12 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
         for (int t = 0; t < 4; ++t) {
             const int th = t / a.q5.kw, tw = t - th * a.q5.kw;
             const int ih = oh * a.q5.sh - a.q5.pt + th * a.q5.dh, iw = ow * a.q5.sw - a.q5.pl + tw * a.q5.dw;
-            int off = CS - 4;   // guard: zero padding (log 1) and taps beyond kh*kw
+            int off = IN_PM ? pm_floats : CS - 4;   // guard: zero padding (log 1) and taps beyond kh*kw
             if (act && t < T5 && ih >= 0 && ih < H && iw >= 0 && iw < W) {
 #pragma unroll
                 for (int k = 0; k < kStreamMaxBands; ++k)
-                    if (k < nb && ih >= r0[k] && ih < r0[k] + nr[k]) off = lb[k] + (ih - r0[k]) * W + iw;
+                    if (k < nb && ih >= r0[k] && ih < r0[k] + nr[k])
+                        off = IN_PM ? lbp[k] + ((ih - r0[k]) * W + iw) * kStreamC : lb[k] + (ih - r0[k]) * W + iw;
             }
             offb[t] = 4u * (unsigned)off;
         }
@@ -290,13 +320,33 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
         const unsigned sb = stg * stage_bytes;
         stg = (stg + 1 == nst) ? 0 : stg + 1;
         float acc[kStreamC], m = -INFINITY;
+        if (IN_PM) {
+            // a tap = the 8 channels of one input pixel: two 16-byte reads
+            typedef __attribute__((address_space(3))) const gf32x4 lf4;
+            gf32x4 lo[4], hi[4];
 #pragma unroll
-        for (int c = 0; c < kStreamC; ++c) {
-            const unsigned kc = sb + Kb[c];
-            const float t0 = *(lfloat *)(smem + (kc + offb[0])), t1 = *(lfloat *)(smem + (kc + offb[1]));
-            const float t2 = *(lfloat *)(smem + (kc + offb[2])), t3 = *(lfloat *)(smem + (kc + offb[3]));
-            acc[c] = (t0 + t1) + (t2 + t3);
-            m = fmaxf(m, acc[c]);
+            for (int t = 0; t < 4; ++t) {
+                const unsigned ta = sb + offb[t];
+                lo[t] = *(lf4 *)(smem + ta);
+                hi[t] = *(lf4 *)(smem + (ta + 16u));
+            }
+            const gf32x4 slo = (lo[0] + lo[1]) + (lo[2] + lo[3]), shi = (hi[0] + hi[1]) + (hi[2] + hi[3]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc[c] = slo[c];
+                acc[4 + c] = shi[c];
+            }
+#pragma unroll
+            for (int c = 0; c < kStreamC; ++c) m = fmaxf(m, acc[c]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < kStreamC; ++c) {
+                const unsigned kc = sb + Kb[c];
+                const float t0 = *(lfloat *)(smem + (kc + offb[0])), t1 = *(lfloat *)(smem + (kc + offb[1]));
+                const float t2 = *(lfloat *)(smem + (kc + offb[2])), t3 = *(lfloat *)(smem + (kc + offb[3]));
+                acc[c] = (t0 + t1) + (t2 + t3);
+                m = fmaxf(m, acc[c]);
+            }
         }
         STREAM_STAMP(2);
         const float m0 = (m == -INFINITY) ? 0.f : m;
@@ -331,7 +381,8 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
                     // 8 registers)
                     const float *lp = a.LW + (size_t)o * kStreamC * OHW + p;
                     auto taps = [&](int c) {
-                        const unsigned kc = sb + 4u * (unsigned)(c * CS + ((c * HW + r0[0] * W) & 3));
+                        const unsigned kc = IN_PM ? sb + 4u * (unsigned)c
+                                                  : sb + 4u * (unsigned)(c * CS + ((c * HW + r0[0] * W) & 3));
                         return (*(lfloat *)(smem + (kc + offb[0])) + *(lfloat *)(smem + (kc + offb[1]))) +
                                (*(lfloat *)(smem + (kc + offb[2])) + *(lfloat *)(smem + (kc + offb[3])));
                     };
@@ -352,8 +403,14 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
         if (MODE == 0) {
             if (act) {
                 float *ob = a.out + (size_t)(s0 + i) * kStreamC * OHW;   // wave-uniform base + one lane offset
+                if (OUT_PM) {
+                    gf32x4 *op = reinterpret_cast<gf32x4 *>(ob + (size_t)p * kStreamC);
+                    op[0] = gf32x4{r[0], r[1], r[2], r[3]};
+                    op[1] = gf32x4{r[4], r[5], r[6], r[7]};
+                } else {
 #pragma unroll
-                for (int o = 0; o < kStreamC; ++o) ob[(size_t)o * OHW + p] = r[o];
+                    for (int o = 0; o < kStreamC; ++o) ob[(size_t)o * OHW + p] = r[o];
+                }
             }
         } else {
             // last product layer: the four taps of a root pixel are the four lanes of a quad (padding taps add log 1)
@@ -586,7 +643,7 @@ bool stream_prodsum_ok(const ProdGeom &q, int Cout, int64_t B, const float *in) 
 }
 
 template <int MODE>
-static int stream_launch(StreamArgs &a, const StreamPlan &pl, int64_t B, hipStream_t st, int kernel_id) {
+static int stream_launch(StreamArgs &a, const StreamPlan &pl, int64_t B, hipStream_t st, int kernel_id, bool in_pm, bool out_pm) {
     a.B = (int)B;
     a.T = pl.T;
     a.cw = pl.cw;
@@ -601,7 +658,10 @@ static int stream_launch(StreamArgs &a, const StreamPlan &pl, int64_t B, hipStre
     if (slices > B) slices = B;
     a.per_wg = (int)cdiv(B, slices);
     a.slices = cdiv(B, a.per_wg);
-    auto kern = spatial_stream_kernel<MODE>;
+    void (*kern)(const StreamArgs) = nullptr;
+    if (MODE == 1) kern = in_pm ? spatial_stream_kernel<1, true, false> : spatial_stream_kernel<1, false, false>;
+    else if (in_pm) kern = out_pm ? spatial_stream_kernel<0, true, true> : spatial_stream_kernel<0, true, false>;
+    else kern = out_pm ? spatial_stream_kernel<0, false, true> : spatial_stream_kernel<0, false, false>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), kStreamLds)) return rc;
     const unsigned grid = (unsigned)(pl.T * align_up(a.slices, 8));
     static const bool debug = getenv("DPK_DGC_STREAM_DEBUG") != nullptr;
@@ -655,7 +715,7 @@ static int stream_launch(StreamArgs &a, const StreamPlan &pl, int64_t B, hipStre
 }
 
 int stream_prodsum_forward(const float *in, int64_t B, const ProdGeom &q, const float *Wl, const float *LW, float *out,
-                           hipStream_t st) {
+                           hipStream_t st, bool in_pm, bool out_pm) {
     StreamPlan pl;
     DPK_REQUIRE(stream_plan(0, q, nullptr, pl), DPK_EUNSUPPORTED, "spatial_prodsum: no streaming plan");
     StreamArgs a{};
@@ -667,7 +727,7 @@ int stream_prodsum_forward(const float *in, int64_t B, const ProdGeom &q, const 
     a.K = 0;
     a.q5 = q;
     a.q6 = q;
-    return stream_launch<0>(a, pl, B, st, DPK_KERNEL_SPATIAL_PRODSUM);
+    return stream_launch<0>(a, pl, B, st, DPK_KERNEL_SPATIAL_PRODSUM, in_pm, out_pm);
 }
 
 int64_t stream_sumprodroot_partial_bytes(const ProdGeom &q5, int Cout, const ProdGeom &q6, int K, int64_t B) {
@@ -681,7 +741,7 @@ int64_t stream_sumprodroot_partial_bytes(const ProdGeom &q5, int Cout, const Pro
 
 int stream_sumprodroot_forward(const float *in, int64_t B, const ProdGeom &q5, const float *Wl, const float *LW,
                                const ProdGeom &q6, const float *LWr, int K, float *out, void *partials,
-                               hipStream_t st) {
+                               hipStream_t st, bool in_pm) {
     StreamPlan pl;
     DPK_REQUIRE(stream_plan(1, q5, &q6, pl), DPK_EUNSUPPORTED, "spatial_sumprodroot: no streaming plan");
     StreamArgs a{};
@@ -693,7 +753,7 @@ int stream_sumprodroot_forward(const float *in, int64_t B, const ProdGeom &q5, c
     a.K = K;
     a.q5 = q5;
     a.q6 = q6;
-    int rc = stream_launch<1>(a, pl, B, st, DPK_KERNEL_SPATIAL_SUMPRODROOT);
+    int rc = stream_launch<1>(a, pl, B, st, DPK_KERNEL_SPATIAL_SUMPRODROOT, in_pm, false);
     if (rc) return rc;
     DPK_LAUNCH(stream_root_combine_kernel, dim3(cdiv(B * K, 4)), dim3(256), 0, st, (const float *)partials, B,
                pl.T * pl.cw, K, out);

@@ -19,6 +19,8 @@ DPK_FLAG_STRUCT_CACHED = 1
 DPK_FLAG_UNIT_SCALE = 2
 DPK_FLAG_PARAMS_CACHED = 4
 DPK_FLAG_PARAMS_VERIFY = 8
+DPK_FLAG_IN_PIXEL_MAJOR = 16
+DPK_FLAG_OUT_PIXEL_MAJOR = 32
 
 # What the operators pass when a module's cached tables were built from parameters whose addresses, shapes and version
 # counters are unchanged.  A write through ``param.data`` (hand-written optimisers, clipping, ``.data.copy_`` loaders)
@@ -77,6 +79,7 @@ SIGNATURES = {
     'dpk_ratspn_slice_batch_min': (_i64, [_i64]),
     'dpk_ratspn_mfma_route': (_i32, [_i32]),
     'dpk_spatial_leaf_fuse_min_k': (_i32, [_i32]),
+    'dpk_spatial_level_streams': (_i32, [_i32, _i64, _i32, _i32, _i32, _c_void, _i32, _c_void, _i32]),
     'dpk_upper_tables_pair': (ctypes.c_int, [_c_void, _i32, _i32, _i32, _c_void, _i64, _c_void, _i32, _i32, _i32, _c_void, _i64,
                                              _c_void]),
     'dpk_prodsum_backward': (ctypes.c_int, [_c_void, _c_void, _c_void, _c_void, _i64, _i32, _i32, _i32, _i32, _c_void,

@@ -8,6 +8,7 @@ import ctypes
 import torch
 
 from deeprob.hip import (load_library, check, ptr, stream_ptr, require_device_f32, Workspace, DPK_FLAG_PARAMS_CACHED,
+                         DPK_FLAG_IN_PIXEL_MAJOR, DPK_FLAG_OUT_PIXEL_MAJOR,
                          cached_tables_flag)
 
 
@@ -237,12 +238,44 @@ def _tables_flag(ws: Workspace, route: str, *weights) -> int:
     return 0
 
 
-def spatial_prodsum(x, prod_layer, weight, ws: Workspace):
+def _is_pixel_major(x: torch.Tensor) -> bool:
+    """A [B, C, H, W] view of a dense [B, H, W, C] buffer (torch's channels_last) that is NOT also plainly contiguous."""
+    return (x.dim() == 4 and x.is_cuda and x.dtype == torch.float32 and x.shape[1] > 1 and not x.is_contiguous()
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def _dense_f32(x: torch.Tensor, name: str) -> torch.Tensor:
+    """require_device_f32 that leaves a pixel-major map as it is."""
+    return x if _is_pixel_major(x) else require_device_f32(x, name)
+
+
+def level_streams(prod_layer, B: int, Cout: int, last_prod=None, K: int = 0) -> bool:
+    """Whether the fused level runs on the streaming route at this batch size -- the route that takes / leaves pixel-major
+    maps (the library's answer, dpk_spatial_level_streams)."""
+    if not prod_layer.depthwise:
+        return False
+    C, H, W, _, OH, OW, kh, kw, sh, sw, dh, dw, pt, pl, _ = _geom(prod_layer)
+    g5 = (ctypes.c_int32 * 10)(OH, OW, kh, kw, sh, sw, dh, dw, pt, pl)
+    g6 = None
+    if last_prod is not None:
+        if not last_prod.depthwise:
+            return False
+        _, _, _, _, OH6, OW6, kh6, kw6, sh6, sw6, dh6, dw6, pt6, pl6, _ = _geom(last_prod)
+        g6 = (ctypes.c_int32 * 10)(OH6, OW6, kh6, kw6, sh6, sw6, dh6, dw6, pt6, pl6)
+    return bool(load_library().dpk_spatial_level_streams(0 if last_prod is None else 1, B, C, H, W, g5, Cout, g6, K))
+
+
+def spatial_prodsum(x, prod_layer, weight, ws: Workspace, out_pixel_major: bool = False):
     """One eval-mode DGC-SPN level, depthwise SpatialProductLayer + SpatialSumLayer in a single launch
     (reference: deeprob/spn/models/dgcspn.py:146-147).  No autograd graph is recorded.  Returns None when
-    the level is outside what the fused kernel covers (the caller chains the two layer operators)."""
+    the level is outside what the fused kernel covers (the caller chains the two layer operators).
+
+    A pixel-major ``x`` (torch's channels_last) is consumed as it is by the streaming route; ``out_pixel_major`` asks that
+    route for a channels_last result (same shape, same values, other strides) -- the layout in which the next streaming
+    level reads a tap's 8 channels with two 16-byte LDS reads.  Outside the streaming route both fall back to the plain
+    layout (one conversion)."""
     lib = load_library()
-    x = require_device_f32(x, 'x')
+    x = _dense_f32(x, 'x')
     w = require_device_f32(weight, 'weight')
     if not prod_layer.depthwise:
         return None
@@ -250,11 +283,20 @@ def spatial_prodsum(x, prod_layer, weight, ws: Workspace):
         raise ValueError(f"expected input [B, {prod_layer.in_features}], got {tuple(x.shape)}")
     C, H, W, _, OH, OW, kh, kw, sh, sw, dh, dw, pt, pl, _ = _geom(prod_layer)
     B, Cout = x.shape[0], w.shape[0]
-    out = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
+    in_pm = _is_pixel_major(x)
+    if (in_pm or out_pixel_major) and not level_streams(prod_layer, B, Cout):
+        x, in_pm, out_pixel_major = x.contiguous(), False, False
+    if out_pixel_major:
+        out = torch.empty((B, OH, OW, Cout), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
+    else:
+        out = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
     buf = _spatial_sum_ws(ws, C, Cout, OH, OW, x.device)
-    flags = _tables_flag(ws, 'prodsum', w)
+    flags = _tables_flag(ws, 'prodsum', w) | (DPK_FLAG_IN_PIXEL_MAJOR if in_pm else 0) | \
+        (DPK_FLAG_OUT_PIXEL_MAJOR if out_pixel_major else 0)
     rc = lib.dpk_spatial_prodsum_forward(ptr(x), B, C, H, W, OH, OW, kh, kw, sh, sw, dh, dw, pt, pl, ptr(w), Cout,
                                          ptr(out), ptr(buf), buf.numel(), flags, stream_ptr(x.device))
+    if rc == -4 and (in_pm or out_pixel_major):      # (e.g. a misaligned view: the plain layout once more)
+        return spatial_prodsum(x.contiguous(), prod_layer, weight, ws)
     if rc:
         ws.params_key = None
     if rc == -4:  # DPK_EUNSUPPORTED
@@ -385,11 +427,14 @@ def spatial_sumprodroot(x, prod5, sum_weight, prod6, root_weight, ws: Workspace)
     envelope (the caller falls back to spatial_prodsum + spatial_prodroot)."""
     import ctypes
     lib = load_library()
-    x = require_device_f32(x, 'x')
+    x = _dense_f32(x, 'x')
     w5 = require_device_f32(sum_weight, 'weight')
     wr = require_device_f32(root_weight, 'weight')
     if not (prod5.depthwise and prod6.depthwise):
         return None
+    if _is_pixel_major(x) and not level_streams(prod5, x.shape[0], w5.shape[0], prod6, wr.shape[0]):
+        x = x.contiguous()
+    in_pm = _is_pixel_major(x)
     if x.dim() != 4 or tuple(x.shape[1:]) != tuple(prod5.in_features):
         raise ValueError(f"expected input [B, {prod5.in_features}], got {tuple(x.shape)}")
     C, H, W, _, OH5, OW5, kh5, kw5, sh5, sw5, dh5, dw5, pt5, pl5, _ = _geom(prod5)
@@ -407,9 +452,11 @@ def spatial_sumprodroot(x, prod5, sum_weight, prod6, root_weight, ws: Workspace)
         check(int(n), 'dpk_spatial_sumprodroot_workspace_bytes_batch')
     buf = ws.get(n, x.device)
     out = torch.empty((B, K), dtype=torch.float32, device=x.device)
-    flags = _tables_flag(ws, 'sumprodroot', w5, wr)
+    flags = _tables_flag(ws, 'sumprodroot', w5, wr) | (DPK_FLAG_IN_PIXEL_MAJOR if in_pm else 0)
     rc = lib.dpk_spatial_sumprodroot_forward(ptr(x), B, C, H, W, g5, ptr(w5), Cout, g6, ptr(wr), K, ptr(out), ptr(buf),
                                              buf.numel(), flags, stream_ptr(x.device))
+    if rc == -4 and in_pm:
+        return spatial_sumprodroot(x.contiguous(), prod5, sum_weight, prod6, root_weight, ws)
     if rc:
         ws.params_key = None
     if rc == -4:  # DPK_EUNSUPPORTED

@@ -169,7 +169,9 @@ class DgcSpn(ProbabilisticModel):
             if i + 1 < n and isinstance(layer, SpatialProductLayer) and isinstance(self.layers[i + 1], SpatialSumLayer):
                 nxt = self.layers[i + 1]
                 dropout = self.training and nxt.dropout is not None   # the sum layer raises: not on this path
-                y = None if dropout else ops_spatial.spatial_prodsum(x, layer, nxt.weight, nxt._ws)
+                # (the map between two streaming levels stays pixel-major: csrc/dgcspn_stream.hip, round 6)
+                y = None if dropout else ops_spatial.spatial_prodsum(x, layer, nxt.weight, nxt._ws,
+                                                                     out_pixel_major=self._level_streams(i + 2, x.shape[0]))
                 if y is not None:
                     x, i = y, i + 2
                     continue
@@ -181,6 +183,20 @@ class DgcSpn(ProbabilisticModel):
             x = layer(x)
             i += 1
         return self.root_layer(x)
+
+    def _level_streams(self, i: int, B: int) -> bool:
+        """Whether the fused level that starts at layer ``i`` of the evaluation loop runs on the streaming route (the
+        library's answer): its input may then arrive pixel-major."""
+        from deeprob.hip import ops_spatial
+        n = len(self.layers)
+        if i + 1 >= n or self.training:
+            return False
+        layer, nxt = self.layers[i], self.layers[i + 1]
+        if not (isinstance(layer, SpatialProductLayer) and isinstance(nxt, SpatialSumLayer)):
+            return False
+        if i == n - 3 and isinstance(self.layers[i + 2], SpatialProductLayer):
+            return ops_spatial.level_streams(layer, B, nxt.weight.shape[0], self.layers[i + 2], self.root_layer.weight.shape[0])
+        return ops_spatial.level_streams(layer, B, nxt.weight.shape[0])
 
     def _needs_graph(self, x: torch.Tensor) -> bool:
         if not torch.is_grad_enabled():

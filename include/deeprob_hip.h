@@ -59,6 +59,10 @@ extern "C" {
                                      same, unchanged loc / scale / weights: skip rebuilding them.  Ignored
                                      on every other route (tables are rebuilt per call there)              */
 
+#define DPK_FLAG_IN_PIXEL_MAJOR 16u  /* dpk_spatial_prodsum_forward / dpk_spatial_sumprodroot_forward: the input map is
+                                       [B, H, W, C] (torch's channels_last) instead of [B, C, H, W]; only on the streaming
+                                       route (dpk_spatial_level_streams), DPK_EUNSUPPORTED elsewhere                      */
+#define DPK_FLAG_OUT_PIXEL_MAJOR 32u /* dpk_spatial_prodsum_forward: write the output map as [B, OH, OW, Cout]; as above */
 #define DPK_FLAG_PARAMS_VERIFY 8u  /* the same belief, checked on the device: the entry point fingerprints the live
                                      parameter bytes (one small launch) and rebuilds its tables only if they differ
                                      from the bytes the tables were built from.  What a caller passes when all it
@@ -408,6 +412,12 @@ int dpk_spatial_prodsum_forward(const float *in, int64_t B, int32_t C, int32_t H
                                 int32_t OW, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t dh,
                                 int32_t dw, int32_t pad_top, int32_t pad_left, const float *weight, int32_t Cout,
                                 float *out, void *ws, int64_t ws_bytes, uint32_t flags, void *stream);
+/* Whether a fused level of these shapes runs on the streaming route of dpk_spatial_prodsum_forward (last = 0) /
+ * dpk_spatial_sumprodroot_forward (last = 1; geom6, K as there) at this batch size -- the route that accepts
+ * DPK_FLAG_IN_PIXEL_MAJOR / DPK_FLAG_OUT_PIXEL_MAJOR, so that DgcSpn.forward (deeprob/spn/models/dgcspn.py:134-151) can keep
+ * the maps between two such levels pixel-major.  geom = {OH, OW, kh, kw, sh, sw, dh, dw, pad_top, pad_left}.  1 / 0.     */
+int32_t dpk_spatial_level_streams(int32_t last, int64_t B, int32_t C, int32_t H, int32_t W, const int32_t *geom5,
+                                  int32_t Cout, const int32_t *geom6, int32_t K);
 
 /* SpatialGaussianLayer followed by the FIRST depthwise product + sum level, eval route, in one launch
  * (models/dgcspn.py:134-147 at i = 0, 1; layers/dgcspn.py:101-120 for the leaf): x [B,Cx,H,W] (NaN = marginalised),

@@ -142,6 +142,24 @@ def bn_forward(u, weight, bias, var, mean, eps=1e-5):
     return u * torch.sqrt(var) + mean, torch.sum(-weight + 0.5 * torch.log(var)).expand(u.shape[0])
 
 
+def logit_forward(u, alpha, ldj_const):
+    """LogitLayer.apply_forward, flows/utils.py:286-294."""
+    n = u.shape[0]
+    u = torch.sigmoid(u)
+    x = (u - alpha) / (1.0 - 2.0 * alpha)
+    lu, ru = torch.log(u), torch.log(1.0 - u)
+    return x, torch.sum((lu + ru).view(n, -1), dim=1) + ldj_const
+
+
+def flow_sample_from(sd, u, logit_alpha=None):
+    """NormalizingFlow.sample (flows/models/base.py:145-157) from a given base draw ``u``: apply_forward, then the inverse
+    preprocessing -- the deterministic part of sampling (the base draw itself is torch's generator)."""
+    x, _ = flow_apply_forward(sd, u)
+    if logit_alpha is not None:
+        x, _ = logit_forward(x, logit_alpha, sd['logit.ldj'])
+    return x
+
+
 def logit_backward(x, alpha, ldj_const):
     """flows/utils.py:276-284."""
     n = x.shape[0]

@@ -427,3 +427,47 @@ def test_fused_level_autograd_matches_layer_chain(shape, padding, stride, dil, c
     assert rel_err(yb[fin].detach().cpu().numpy(), ya[fin].detach().cpu().numpy()) <= 1e-6
     assert grad_err(gb_x[1:].cpu().numpy(), ga_x[1:].cpu().numpy()) <= 1e-5
     assert grad_err(gb_w.cpu().numpy(), ga_w.cpu().numpy()) <= 1e-5
+
+
+@pytest.mark.parametrize('shape,padding,stride,dil,B', [((8, 29, 29), 'full', 1, 2, 300), ((8, 43, 43), 'full', 1, 16, 270),
+                                                        ((8, 16, 16), 'valid', 2, 1, 257), ((8, 11, 13), 'full', 1, 4, 333)])
+def test_pixel_major_maps_between_streaming_levels(shape, padding, stride, dil, B):
+    """Round 6: the streaming level kernels take and leave pixel-major maps (torch's channels_last; DPK_FLAG_IN_PIXEL_MAJOR /
+    DPK_FLAG_OUT_PIXEL_MAJOR): all four layout combinations of one level give the SAME values bit for bit (the layout only
+    moves data), far-tail / -inf inputs (exact log-domain pass) and a ragged last batch slice included -- and equal the
+    oracle's product + sum."""
+    from deeprob.spn.layers.dgcspn import SpatialProductLayer, SpatialSumLayer
+    from deeprob.hip import ops_spatial
+    torch.manual_seed(17)
+    prod = SpatialProductLayer(shape, kernel_size=(2, 2), padding=padding, stride=(stride, stride), dilation=(dil, dil),
+                               depthwise=True)
+    sm = SpatialSumLayer(prod.out_features, 8)
+    with torch.no_grad():
+        sm.weight.copy_(torch.randn(sm.weight.shape) * 2)
+        sm.weight[2, :, 1, :] = -150.0
+        sm.weight[2, 5, 1, :] = 0.0
+    gen = torch.Generator().manual_seed(18)
+    x = torch.randn(B, *shape, generator=gen) * 3
+    x[1] = -2.0e4
+    x[2, 3] = float('-inf')
+    x[3, :, ::2] = 0.0
+    want = dorc.spatial_sum(dorc.spatial_product(x, prod.pad, stride, dil, True), sm.weight.detach())
+    prod, sm = prod.cuda(), sm.cuda()
+    xd = x.cuda()
+    assert ops_spatial.level_streams(prod, B, 8)
+    xpm = xd.contiguous(memory_format=torch.channels_last)
+    assert ops_spatial._is_pixel_major(xpm) and not ops_spatial._is_pixel_major(xd)
+    outs = {}
+    with torch.no_grad():
+        for in_pm in (False, True):
+            for out_pm in (False, True):
+                y = ops_spatial.spatial_prodsum(xpm if in_pm else xd, prod, sm.weight, sm._ws, out_pixel_major=out_pm)
+                assert y is not None and tuple(y.shape) == (B,) + tuple(prod.out_features)
+                assert ops_spatial._is_pixel_major(y) == out_pm
+                outs[(in_pm, out_pm)] = y.contiguous()
+    ref = outs[(False, False)]
+    for k, y in outs.items():
+        assert torch.equal(y, ref), k
+    fin = torch.isfinite(want)
+    assert torch.equal(fin, torch.isfinite(ref.cpu()))
+    assert ((ref.cpu()[fin] - want[fin]).abs() / want[fin].abs().clamp_min(1.0)).max().item() <= LL_TOL
