@@ -323,14 +323,16 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
         if (IN_PM) {
             // a tap = the 8 channels of one input pixel: two 16-byte reads
             typedef __attribute__((address_space(3))) const gf32x4 lf4;
+            // (channels 0-3 of the four taps first, then channels 4-7: sixteen registers of taps in flight instead of
+            // thirty-two -- the MODE 1 build spilled twelve at its 128-register budget)
             gf32x4 lo[4], hi[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const unsigned ta = sb + offb[t];
-                lo[t] = *(lf4 *)(smem + ta);
-                hi[t] = *(lf4 *)(smem + (ta + 16u));
-            }
-            const gf32x4 slo = (lo[0] + lo[1]) + (lo[2] + lo[3]), shi = (hi[0] + hi[1]) + (hi[2] + hi[3]);
+            for (int t = 0; t < 4; ++t) lo[t] = *(lf4 *)(smem + (sb + offb[t]));
+            const gf32x4 slo = (lo[0] + lo[1]) + (lo[2] + lo[3]);
+            if (MODE == 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) hi[t] = *(lf4 *)(smem + (sb + offb[t] + 16u));
+            const gf32x4 shi = (hi[0] + hi[1]) + (hi[2] + hi[3]);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 acc[c] = slo[c];
@@ -379,7 +381,11 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
                 if (v2[o].x + v2[o].y < 1e-30f) {
                     // (the tap sums are read again from the stage: keeping them live across the hot path costs it
                     // 8 registers)
-                    const float *lp = a.LW + (size_t)o * kStreamC * OHW + p;
+                    // (the pixel passed through an opaque copy: the address math of this rare path is otherwise hoisted out of
+                    // the sample loop and its eight pointers spilled to scratch, which the kernel then pays for at every launch)
+                    int pq = p;
+                    asm volatile("" : "+v"(pq));
+                    const float *lp = a.LW + (size_t)o * kStreamC * OHW + pq;
                     auto taps = [&](int c) {
                         const unsigned kc = IN_PM ? sb + 4u * (unsigned)c
                                                   : sb + 4u * (unsigned)(c * CS + ((c * HW + r0[0] * W) & 3));
