@@ -65,6 +65,9 @@ def parse():
     ap.add_argument('--streams', type=int, default=2,
                     help='N = 1, eager loop: evaluation streams the K timed steps alternate between (a model replica each); '
                          '1 = the single-stream loop only')
+    ap.add_argument('--chains', type=int, default=3,
+                    help='parallel chains inside the graphed evaluation window (N > 1 and the shard entries): step i on '
+                         'chain i mod chains, a workspace replica of the model per chain')
     ap.add_argument('--graph-window', action='store_true',
                     help='time the K steps through the graphed evaluation window at N = 1 too (the N > 1 default)')
     ap.add_argument('--kernel-event-every', type=int, default=0,
@@ -244,6 +247,32 @@ def _time_eval_graph(model, xs, reps=4):
         return None
 
 
+def _time_window(model, xs, reps=4, chains=1, static_params=False):
+    """ms per step of a GraphedEvaluationWindow over the resident batches `xs` (x `reps`) -- what `bench.py --gpus N` times
+    for N > 1, here without a collective: the fused forward + fp64 {sum, count} of every step, `chains` parallel chains
+    inside the graph.  None when the window cannot be captured."""
+    import torch
+    from deeprob.parallel import ShardedLogLikelihood, GraphedEvaluationWindow
+    try:
+        ev = ShardedLogLikelihood(model, static_inputs=True, static_params=static_params)
+        win = GraphedEvaluationWindow(ev, list(xs) * reps, chains=chains)
+        for _ in range(3):
+            win.graph.replay()
+        torch.cuda.synchronize()
+        best = float('inf')
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                win.graph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / (5 * reps * len(xs)))
+        return best
+    except Exception:
+        return None
+
+
 def _time_train(model, x, steps=15, warm=3):
     import torch
     from deeprob.torch.routines import build_optimizer
@@ -310,6 +339,9 @@ def _peek_hip_error(tag):
         sys.stderr.write('[bench debug] after {}: hipPeekAtLastError = {}\n'.format(tag, rc))
     except Exception as ex:
         sys.stderr.write('[bench debug] after {}: {}\n'.format(tag, ex))
+
+
+CHAINS = 3
 
 
 def secondary(dev, timer, threads, xs_headline, headline_model):
@@ -478,21 +510,18 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
             xs_s = xs_headline[:nb] if Bs == 65536 and len(xs_headline) >= nb else \
                 [torch.randn(Bs, D, device=dev) for _ in range(nb)]
             reps = max(1, -(-32 // nb))
-            ms_def = _time_eval_graph(headline_model, xs_s, reps=reps)
-            prev = _hip.trust_version_counters(True)
-            try:
-                with torch.no_grad():
-                    headline_model(xs_s[0])
-                ms_tr = _time_eval_graph(headline_model, xs_s, reps=reps)
-            finally:
-                _hip.trust_version_counters(prev)
+            # (the graphed window of `--gpus N`, CHAINS parallel chains inside the graph; one chain beside it)
+            ms_def = _time_window(headline_model, xs_s, reps=reps, chains=CHAINS)
+            ms_one = _time_window(headline_model, xs_s, reps=reps, chains=1)
+            ms_tr = _time_window(headline_model, xs_s, reps=reps, chains=CHAINS, static_params=True)
             base[Bs] = (ms_def, ms_tr)
             if Bs == 65536 or ms_def is None:
                 continue
             n = 65536 // Bs
             out.append({'workload': 'headline model, one rank\'s shard of the 65536-sample batch at N = {} (strong scaling), '
-                                    'model(x) replayed from a HIP graph over {} resident shards'.format(n, nb),
+                                    'GraphedEvaluationWindow over {} resident shards, {} parallel chains'.format(n, nb, CHAINS),
                         'id': 'shard/{}'.format(n), 'config': 'strong-scaling shard', 'batch': Bs, 'ms_per_step': ms_def,
+                        'ms_per_step_one_chain': ms_one,
                         'value': Bs / ms_def * 1e3, 'unit': 'log-likelihoods/sec',
                         'ms_per_step_trusting_version_counters': ms_tr,
                         'predicted_speedup': (base[65536][0] / ms_def) if base[65536][0] else None,
@@ -727,7 +756,8 @@ def compact_configs(sec):
         r['ms'] = round(e['ms_per_step'], 5)
         r['rate'] = float('{:.4g}'.format(e['value']))
         for k_src, k_dst in (('ms_per_step_trusting_version_counters', 'ms_trust'), ('ms_per_step_eager', 'ms_eager'),
-                             ('ms_per_step_hip_graph', 'ms_graph'), ('slowdown_vs_clean', 'x_clean')):
+                             ('ms_per_step_hip_graph', 'ms_graph'), ('slowdown_vs_clean', 'x_clean'),
+                             ('ms_per_step_one_chain', 'ms_1chain')):
             if e.get(k_src) is not None:
                 r[k_dst] = round(e[k_src], 5)
         # (a single-launch HIP event pair brackets its own dispatch: only a figure below the step it belongs to is evidence;
@@ -829,6 +859,8 @@ def main():
     D = 784
     if args.scaling is None:
         args.scaling = 'strong' if world > 1 else 'weak'
+    global CHAINS
+    CHAINS = max(1, args.chains)
     plan = shard_plan(world, args.batch, args.scaling)
     B = plan['per_rank']
     torch.manual_seed(0)  # identical replica on every rank
@@ -847,7 +879,7 @@ def main():
         xs_g = [torch.randn(Bg, D, device=dev, generator=gen_g) for _ in range(min(ring_g, max(L, 4)))]
         ev = ShardedLogLikelihood(model, group=dist.group.WORLD if world > 1 else None, static_inputs=True,
                                   static_params=False)
-        win = GraphedEvaluationWindow(ev, [xs_g[i % len(xs_g)] for i in range(L)])
+        win = GraphedEvaluationWindow(ev, [xs_g[i % len(xs_g)] for i in range(L)], chains=args.chains)
         for _ in range(max(1, -(-warmup // L))):
             win.replay()
         if world > 1:
@@ -954,8 +986,8 @@ def main():
             with torch.no_grad():
                 dtg, mean_g, L = graphed_run(B, args.steps, args.warmup)
                 dt, mean_ll = dtg, mean_g
-                step_mode = ('HIP graph: {} steps + their one all-reduce per replay (eager loop of the same steps: {:.5f} '
-                             'ms/step)'.format(L, eager_ms))
+                step_mode = ('HIP graph: {} steps on {} parallel chains + their one all-reduce per replay (eager loop of the '
+                             'same steps: {:.5f} ms/step)'.format(L, args.chains, eager_ms))
                 if world > 1:
                     Bo = plan['other_per_rank']
                     dto, _, _ = graphed_run(Bo, args.steps, args.warmup)
@@ -1032,8 +1064,9 @@ def main():
             torch.cuda.synchronize()
             return (time.perf_counter() - t1) / steps * 1e3
 
-    ms_frozen = ms_exact = None
+    ms_frozen = ms_exact = ms_graph_chains = None
     if world == 1:
+        ms_graph_chains = _time_window(model, xs, reps=max(1, 24 // len(xs)), chains=CHAINS)
         ms_frozen = plain_loop(ShardedLogLikelihood(model, static_inputs=True, static_params=True), args.steps)
         try:
             from deeprob.hip import load_library
@@ -1067,6 +1100,7 @@ def main():
                        'params_mode': 'default: static_params=False (cached parameter tables checked on the device at every call)',
                        'ms_per_step_one_stream': one_stream_ms,
                        'ms_per_step_frozen_model': ms_frozen,
+                       'ms_per_step_graph_window_{}_chains'.format(CHAINS): ms_graph_chains,
                        'fp32_exact_ms': ms_exact,
                        'arithmetic': 'fp32 results; leaf GEMM = 3 f16 MFMAs on two-way f16 splits, fp32 accumulate '
                                      '(>= 22 bits per product, guarded, exact fallback)'},

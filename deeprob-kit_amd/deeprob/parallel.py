@@ -171,6 +171,27 @@ class ShardedLogLikelihood:
         return means
 
 
+def workspace_replica(model: torch.nn.Module) -> torch.nn.Module:
+    """A second handle on ``model`` for a second stream: the SAME parameter and buffer tensors (a later write to a parameter
+    is seen by both), its own workspaces (cached tables, tickets of the in-launch table check, NaN hint): the launches of one
+    workspace must follow one another on one stream, so every concurrent chain of evaluations gets a replica."""
+    import copy
+    rep = copy.deepcopy(model)
+
+    def share(dst, src):
+        for name, p in src._parameters.items():
+            dst._parameters[name] = p
+        for name, b in src._buffers.items():
+            dst._buffers[name] = b
+        if hasattr(src, 'distribution'):          # (torch.distributions objects built over the parameters)
+            dst.distribution = src.distribution
+        for name, child in src._modules.items():
+            share(dst._modules[name], child)
+
+    share(rep, model)
+    return rep
+
+
 class GraphedEvaluationWindow:
     """A window of sharded evaluation steps -- the local evaluations of ``xs`` (resident inputs) AND the one all-reduce of
     their ``{sum LL, count}`` pairs -- captured once as a HIP graph and replayed: ``replay()`` returns the mean
@@ -178,16 +199,29 @@ class GraphedEvaluationWindow:
     (ProcessGroupNCCL records it on the capturing stream), so a replay costs one graph launch whatever the number of steps.
     Built from a ``ShardedLogLikelihood`` (its model, group and parameter mode); the evaluator itself stays usable.
 
-    ``always_reduce``: run the collective for a world of one too (exercises the captured RCCL path on a one-GPU box)."""
+    ``always_reduce``: run the collective for a world of one too (exercises the captured RCCL path on a one-GPU box).
 
-    def __init__(self, evaluator: 'ShardedLogLikelihood', xs: List[torch.Tensor], always_reduce: bool = False):
+    ``chains`` (round 6): the steps of the window run on this many parallel chains inside the graph -- one fork at its head,
+    one join in front of the all-reduce, step i on chain i mod chains, a ``workspace_replica`` of the model per extra chain.
+    A launch of the fused kernel holds every compute unit with one work-group; in one chain launch k + 1 starts when launch
+    k has completely finished, so its prologue and the predecessor's tail (HBM idle in both) are in series -- at the
+    strong-scaling shard sizes (one to four blocks per compute unit) that is most of a step.  Measured, default mode
+    (tools/bench_two_streams_graph.py): 12.5 -> 11.1 -> 10.2 us per step at 8 192 samples with 1 / 2 / 3 chains, 16.7 ->
+    14.3 at 16 384, 25.8 -> 22.9 at 32 768, 42.9 -> 40.8 -> 39.5 at 65 536; identical results."""
+
+    def __init__(self, evaluator: 'ShardedLogLikelihood', xs: List[torch.Tensor], always_reduce: bool = False, chains: int = 1):
         if evaluator.local_sum_fn is not None:
             raise ValueError("GraphedEvaluationWindow captures the HIP evaluation path, not a custom local_sum_fn")
         self.evaluator, self.xs = evaluator, list(xs)
         dev = self.xs[0].device
         world = dist.get_world_size(evaluator.group) if evaluator.group is not None else 1
         reduce = evaluator.group is not None and (world > 1 or always_reduce)
+        chains = max(1, min(int(chains), len(self.xs)))
+        self.lanes = [evaluator] + [
+            ShardedLogLikelihood(workspace_replica(evaluator.model), static_inputs=evaluator.static_inputs,
+                                 static_params=evaluator.static_params) for _ in range(chains - 1)]
         side = torch.cuda.Stream(device=dev)
+        branches = [side] + [torch.cuda.Stream(device=dev) for _ in range(chains - 1)]
         # (inputs / parameters still being written on the caller's stream must be complete before the warm pass reads them:
         # the tables it builds and the verdicts it caches would otherwise come from incomplete data)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -195,14 +229,19 @@ class GraphedEvaluationWindow:
         with torch.no_grad(), torch.cuda.stream(side):
             warm = torch.zeros(len(self.xs), 2, dtype=torch.float64, device=dev)
             for i, x in enumerate(self.xs):          # eager pass: plans bound, tables built, RCCL communicator up
-                evaluator._local(x, acc=warm[i])
+                self.lanes[i % chains]._local(x, acc=warm[i])
             if reduce:
                 dist.all_reduce(warm, op=dist.ReduceOp.SUM, group=evaluator.group)
             torch.cuda.synchronize(dev)
             with torch.cuda.graph(self.graph, stream=side):
                 self.pool = torch.zeros(len(self.xs), 2, dtype=torch.float64, device=dev)
+                for b in branches[1:]:
+                    b.wait_stream(side)              # fork (the zeroed slots are complete on every chain)
                 for i, x in enumerate(self.xs):
-                    evaluator._local(x, acc=self.pool[i])
+                    with torch.cuda.stream(branches[i % chains]):
+                        self.lanes[i % chains]._local(x, acc=self.pool[i])
+                for b in branches[1:]:
+                    side.wait_stream(b)              # join: the collective sees every chain's sums
                 if reduce:
                     dist.all_reduce(self.pool, op=dist.ReduceOp.SUM, group=evaluator.group)
         torch.cuda.current_stream(dev).wait_stream(side)

@@ -112,6 +112,40 @@ def test_graphed_evaluation_window_over_single_rank_rccl(tmp_path, nccl_backend)
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('chains', [2, 3])
+def test_graphed_evaluation_window_on_parallel_chains(chains):
+    """Round 6: the window's steps on parallel chains inside the graph (a workspace replica of the model per chain: the same
+    parameter tensors, its own tables and tickets): the same means as the single chain bit for bit, replay after replay, and
+    a parameter written through .data afterwards is seen by EVERY chain (the replicas share the tensors; each chain's
+    captured launches check their own tables)."""
+    from deeprob.parallel import ShardedLogLikelihood, GraphedEvaluationWindow, workspace_replica
+    from deeprob.spn.models import GaussianRatSpn
+    from oracle import ratspn_oracle as orc
+    torch.manual_seed(0)
+    model = GaussianRatSpn(784, rg_depth=2, rg_repetitions=8, rg_batch=2, rg_sum=2, random_state=42).cuda().eval()
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    xs = [torch.randn(n, 784, device='cuda', generator=gen) for n in (9000, 8192, 300, 16384, 8192, 777, 4096)]
+    one = GraphedEvaluationWindow(ShardedLogLikelihood(model, static_inputs=True), xs).replay()
+    win = GraphedEvaluationWindow(ShardedLogLikelihood(model, static_inputs=True), xs, chains=chains)
+    assert len(win.lanes) == chains
+    rep = win.lanes[1].model
+    assert rep is not model and rep.base_layer.loc is model.base_layer.loc and rep.root_layer.weight is model.root_layer.weight
+    assert rep._fused_ctx is not model._fused_ctx
+    for _ in range(3):
+        assert win.replay() == one
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    want = [float(orc.ratspn_forward(sd, x.cpu()).double().mean()) for x in xs]
+    assert np.allclose(one, want, rtol=1e-5)
+    with torch.no_grad():
+        model.base_layer.loc.data.add_(0.05)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    want2 = [float(orc.ratspn_forward(sd, x.cpu()).double().mean()) for x in xs]
+    assert not np.allclose(want2, want, rtol=1e-7)
+    assert np.allclose(win.replay(), want2, rtol=1e-5) and np.allclose(win.replay(), want2, rtol=1e-5)
+    # the replica's layer-by-layer helpers see the shared parameters too
+    assert workspace_replica(model).base_layer.distribution is model.base_layer.distribution
+
+
 def test_graphed_sharded_training_step_over_single_rank_rccl(tmp_path, nccl_backend):
     """Round 4: the sharded optimisation step -- forward, backward, the RCCL gradient all-reduce, the update -- captured
     as one HIP graph (GraphedTrainStep(grad_exchange=...)): on a world of one (collective forced) the replayed steps train
