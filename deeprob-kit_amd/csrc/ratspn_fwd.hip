@@ -306,7 +306,8 @@ struct LeafArgs {
     int reps, C;
     cfloat_p W0, LW0, W1, LW1, Wr, LWr;
     float *out;      // [B,C]
-    double *ll_sum;  // [2] or nullptr
+    double *ll_sum;  // [2] ([17] with DPK_FLAG_LL_SUM_SPREAD) or nullptr
+    int ll_cnt;      // index of the count: 1 or 16
     // last, so that the offsets of everything above stay what the kernels were tuned with
     int *slow_flag;   // host-mapped word: a work-group that meets a slow chunk stores launch_seq there
     int launch_seq;
@@ -1339,7 +1340,7 @@ __global__ __launch_bounds__(kLeafWaves * 64, DPK_MINW(SPL)) void ratspn_leaf_ke
                 atomicAdd(a.ll_sum, part);
                 int64_t nvalid = a.B - (b0 + (tid & ~63));
                 nvalid = nvalid < 0 ? 0 : (nvalid > 64 ? 64 : nvalid);
-                atomicAdd(a.ll_sum + 1, (double)(nvalid * a.C));
+                atomicAdd(a.ll_sum + a.ll_cnt, (double)(nvalid * a.C));
             }
         }
     }
@@ -1731,7 +1732,7 @@ extern "C" int dpk_ratspn_forward(const float *x, int64_t B, int32_t D, const in
     a.reps = reps; a.C = C;
     a.W0 = as_const(w.w[0]); a.LW0 = as_const(w.lw[0]); a.W1 = as_const(w.w[1]);
     a.LW1 = as_const(w.lw[1]); a.Wr = as_const(w.w[2]); a.LWr = as_const(w.lw[2]);
-    a.out = out; a.ll_sum = ll_sum;
+    a.out = out; a.ll_sum = ll_sum; a.ll_cnt = (flags & DPK_FLAG_LL_SUM_SPREAD) ? 16 : 1;
 #ifdef DPK_HEADLINE_ONLY  // measurement builds: only the headline instantiation
     if (depth == 2 && I == 2 && S == 2) return fused_launch<2, 2, 2>(a, st);
     set_error("measurement build: only depth=2, channels=2, sums=2");

@@ -92,6 +92,7 @@ struct GemmArgs {
     cfloat_p Wr, LWr;  // [C][reps*S*S]
     float *out;
     double *ll_sum;
+    int ll_cnt;        // index of the count behind ll_sum: 1, or 16 with DPK_FLAG_LL_SUM_SPREAD
     // exact evaluation
     const int64_t *mask;
     const uint8_t *pad;
@@ -456,7 +457,7 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
         a.mtab = w.gm_tab; a.ctab = w.gc_tab; a.biasT = w.gbias_row; a.biasC = w.gbias; a.elig = w.gelig;
         a.biasK = w.gbias_ks; a.biasS = w.gbias_sl;
         a.W0 = w.w[0]; a.LW0 = w.lw[0]; a.Wr = as_const(w.w[2]); a.LWr = as_const(w.lw[2]);
-        a.out = out; a.ll_sum = ll_sum;
+        a.out = out; a.ll_sum = ll_sum; a.ll_cnt = (flags & DPK_FLAG_LL_SUM_SPREAD) ? 16 : 1;
         a.mask = mask; a.pad = pad; a.loc = loc; a.scale = scale;
         a.slow_flag = slow_word; a.launch_seq = launch_seq; a.marginal = marginal ? 1 : 0;
         a.ablate = ablate;
@@ -473,7 +474,7 @@ int ratspn_gemm_forward(const RatWs &w, const float *x, int64_t B, int D, const 
     a.ntiles = cdiv(B, kGemmTile);
     a.mtab = w.gm_tab; a.ctab = w.gc_tab; a.biasT = w.gbias_row; a.biasC = w.gbias; a.elig = w.gelig;
     a.W0 = w.w[0]; a.LW0 = w.lw[0]; a.Wr = as_const(w.w[2]); a.LWr = as_const(w.lw[2]);
-    a.out = out; a.ll_sum = ll_sum;
+    a.out = out; a.ll_sum = ll_sum; a.ll_cnt = (flags & DPK_FLAG_LL_SUM_SPREAD) ? 16 : 1;
     a.mask = mask; a.pad = pad; a.loc = loc; a.scale = scale;
     a.slow_flag = slow_word; a.launch_seq = launch_seq;
     a.ablate = ablate;

@@ -28,6 +28,7 @@ struct GemmArgs {
     cfloat_p Wr, LWr;  // [C][reps*S*S]
     float *out;
     double *ll_sum;
+    int ll_cnt;        // index of the count behind ll_sum: 1 ({sum, count}) or 16 (DPK_FLAG_LL_SUM_SPREAD: sixteen partial sums, then the count)
     // exact evaluation
     const int64_t *mask;
     const uint8_t *pad;

@@ -323,10 +323,10 @@ __global__ __launch_bounds__(2 * kGemmWaves * 64) void ratspn_gemm_marginal_kern
             double tot = 0.0;
 #pragma unroll
             for (int w = 0; w < kGemmWaves; ++w) tot += red[w];
-            atomicAdd(a.ll_sum, tot);
+            atomicAdd(a.ll_sum + (a.ll_cnt > 1 ? ((int)blockIdx.x & 15) : 0), tot);
             // every sample of the launch is evaluated by exactly one path: the count needs no per-work-group atomic
             // (256 same-address fp64 atomics at the very end of the kernel cost it 1.5 us)
-            if (blockIdx.x == 0) atomicAdd(a.ll_sum + 1, (double)a.B * (double)a.C);
+            if (blockIdx.x == 0) atomicAdd(a.ll_sum + a.ll_cnt, (double)a.B * (double)a.C);
         }
     }
     if (saw_nan_any && lane == 0 && a.slow_flag != nullptr) *a.slow_flag = a.launch_seq;

@@ -808,8 +808,10 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
             double tot = 0.0;
 #pragma unroll
             for (int w = 0; w < 8; ++w) tot += red_l[w];
-            atomicAdd(a.ll_sum, tot);
-            if (blockIdx.x == 0) atomicAdd(a.ll_sum + 1, (double)a.B * (double)a.C);
+            // (DPK_FLAG_LL_SUM_SPREAD: sixteen partial sums -- 256 work-groups that finish together are 256 same-address
+            // fp64 atomics in series, 1.6 us behind a 12 us launch at one block per work-group; the caller adds the sixteen)
+            atomicAdd(a.ll_sum + (a.ll_cnt > 1 ? ((int)blockIdx.x & 15) : 0), tot);
+            if (blockIdx.x == 0) atomicAdd(a.ll_sum + a.ll_cnt, (double)a.B * (double)a.C);
         }
     }
     if (__any(saw_nan) && lane == 0 && a.slow_flag != nullptr) *a.slow_flag = a.launch_seq;

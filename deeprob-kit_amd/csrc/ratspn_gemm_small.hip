@@ -513,8 +513,8 @@ __global__ __launch_bounds__(kGemmSmallWaves * 64) void ratspn_gemm_small_kernel
             double tot = 0.0;
 #pragma unroll
             for (int w = 0; w < kGemmSmallWaves; ++w) tot += red_l[w];
-            atomicAdd(a.ll_sum, tot);
-            if ((int)blockIdx.x == np) atomicAdd(a.ll_sum + 1, (double)a.B * (double)a.C);
+            atomicAdd(a.ll_sum + (a.ll_cnt > 1 ? ((int)blockIdx.x & 15) : 0), tot);
+            if ((int)blockIdx.x == np) atomicAdd(a.ll_sum + a.ll_cnt, (double)a.B * (double)a.C);
         }
     }
     if ((flags & 4u) != 0u && lane == 0 && a.slow_flag != nullptr) *a.slow_flag = a.launch_seq;

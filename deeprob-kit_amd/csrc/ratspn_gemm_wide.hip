@@ -640,8 +640,8 @@ __global__ __launch_bounds__(kWideWaves * 64) void ratspn_gemm_wide_kernel(const
             double tot = 0.0;
 #pragma unroll
             for (int w = 0; w < kWideWaves; ++w) tot += red[w];
-            atomicAdd(a.ll_sum, tot);
-            if ((int)blockIdx.x == np) atomicAdd(a.ll_sum + 1, (double)a.B * (double)a.C);
+            atomicAdd(a.ll_sum + (a.ll_cnt > 1 ? ((int)blockIdx.x & 15) : 0), tot);
+            if ((int)blockIdx.x == np) atomicAdd(a.ll_sum + a.ll_cnt, (double)a.B * (double)a.C);
         }
     }
     if (saw_nan && tid == 0 && a.slow_flag != nullptr) *a.slow_flag = a.launch_seq;
@@ -968,8 +968,8 @@ __global__ __launch_bounds__((kWideWaves + kGemmWaves) * 64) void ratspn_gemm_wi
             double tot = 0.0;
 #pragma unroll
             for (int w = 0; w < kWideWaves; ++w) tot += red[w];
-            atomicAdd(a.ll_sum, tot);
-            if (blockIdx.x == 0) atomicAdd(a.ll_sum + 1, (double)a.B * (double)a.C);
+            atomicAdd(a.ll_sum + (a.ll_cnt > 1 ? ((int)blockIdx.x & 15) : 0), tot);
+            if (blockIdx.x == 0) atomicAdd(a.ll_sum + a.ll_cnt, (double)a.B * (double)a.C);
         }
     }
     if (tid == 0 && tail->saw_nan != 0 && a.slow_flag != nullptr) *a.slow_flag = a.launch_seq;

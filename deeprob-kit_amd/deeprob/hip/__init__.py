@@ -21,6 +21,8 @@ DPK_FLAG_PARAMS_CACHED = 4
 DPK_FLAG_PARAMS_VERIFY = 8
 DPK_FLAG_IN_PIXEL_MAJOR = 16
 DPK_FLAG_OUT_PIXEL_MAJOR = 32
+DPK_FLAG_LL_SUM_SPREAD = 64
+LL_SPREAD = 16            # partial sums in front of the count of a spread {sum LL, count} slot (17 doubles)
 
 # What the operators pass when a module's cached tables were built from parameters whose addresses, shapes and version
 # counters are unchanged.  A write through ``param.data`` (hand-written optimisers, clipping, ``.data.copy_`` loaders)

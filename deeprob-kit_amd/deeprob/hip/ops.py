@@ -10,7 +10,7 @@ import torch
 
 from deeprob.hip import (
     load_library, check, ptr, stream_ptr, require_device_f32, Workspace, HipError, DPK_FLAG_STRUCT_CACHED,
-    DPK_FLAG_UNIT_SCALE, DPK_FLAG_PARAMS_CACHED, cached_tables_flag,
+    DPK_FLAG_UNIT_SCALE, DPK_FLAG_PARAMS_CACHED, DPK_FLAG_LL_SUM_SPREAD, LL_SPREAD, cached_tables_flag,
 )
 
 
@@ -474,6 +474,8 @@ def ratspn_forward_fused(x, mask, pad_mask, loc, scale, sum_weights, root_weight
     out = torch.empty((B, lctx.C), dtype=torch.float32, device=x.device)
     ws, flags = lctx.workspace(x.device, mask, pad_mask, scale)
     flags |= _params_flag(lib, lctx, ptr(x), flags, [loc_c, scale_c] + sw + [rw])
+    if ll_acc is not None and ll_acc.numel() > LL_SPREAD:      # a spread slot: sixteen partial sums, then the count
+        flags |= DPK_FLAG_LL_SUM_SPREAD
     rc = lib.dpk_ratspn_forward(ptr(x), B, lctx.D, ptr(mask), ptr(_pad_u8(pad_mask)), ptr(loc_c), ptr(scale_c),
                                 ptr(sw[0]) if len(sw) > 0 else None, ptr(sw[1]) if len(sw) > 1 else None,
                                 ptr(rw), lctx.depth, lctx.reps, lctx.I, lctx.S, lctx.C, ptr(out), None,
@@ -551,7 +553,7 @@ class FusedForwardPlan:
         pf = _params_flag(self.lib, self.lctx, args[0], self.base_flags, self.params)
         if pf and self.static_params:
             pf = DPK_FLAG_PARAMS_CACHED
-        args[-2] = self.base_flags | pf
+        args[-2] = self.base_flags | pf | (DPK_FLAG_LL_SUM_SPREAD if ll_acc is not None and ll_acc.numel() > LL_SPREAD else 0)
         rc = self.lib.dpk_ratspn_forward(*args)
         if rc:
             check(rc, 'dpk_ratspn_forward')
@@ -559,9 +561,12 @@ class FusedForwardPlan:
 
 
 def ll_accumulate(ll: torch.Tensor, acc: torch.Tensor):
-    """acc[0] += sum(ll) (fp64), acc[1] += ll.numel()."""
+    """acc[0] += sum(ll) (fp64), acc[1] += ll.numel(); a spread slot (17 doubles, hip.LL_SPREAD) takes the sum in its last
+    partial and the count behind it -- the same two adjacent doubles."""
     lib = load_library()
     ll = require_device_f32(ll, 'll')
+    if acc.numel() > LL_SPREAD:
+        acc = acc.view(-1)[LL_SPREAD - 1:LL_SPREAD + 1]
     assert acc.dtype == torch.float64 and acc.numel() == 2 and acc.is_cuda
     check(lib.dpk_ll_accumulate(ptr(ll), ll.numel(), ptr(acc), stream_ptr(ll.device)), 'dpk_ll_accumulate')
 

@@ -45,6 +45,16 @@ def shard_batch(x: torch.Tensor, rank: Optional[int] = None, world: Optional[int
     return x[lo:hi]
 
 
+SLOT = 17      # doubles of a {sum LL, count} slot: hip.LL_SPREAD partial sums, then the count
+
+
+def slot_mean(slots: torch.Tensor) -> torch.Tensor:
+    """Mean log-likelihood of every ``[.., SLOT]`` (or plain ``[.., 2]`` = {sum, count}) slot."""
+    if slots.shape[-1] == 2:
+        return slots[..., 0] / slots[..., 1]
+    return slots[..., :SLOT - 1].sum(dim=-1) / slots[..., SLOT - 1]
+
+
 class ShardedLogLikelihood:
     """Mean log-likelihood of batches sharded over the ranks of ``group``.
 
@@ -85,8 +95,11 @@ class ShardedLogLikelihood:
         self._pool_next = 0
 
     def _acc_slot(self, device) -> torch.Tensor:
+        # a slot = SLOT doubles: sixteen partial sums of the log-likelihoods, then the count (DPK_FLAG_LL_SUM_SPREAD: the 256
+        # work-groups of a fused launch finish together, and 256 fp64 atomics on ONE address are 1.6 us in series behind a
+        # 12 us shard launch); `slot_mean` adds the partial sums
         if self._pool is None or self._pool_next >= self._pool.shape[0] or self._pool.device != device:
-            self._pool = torch.zeros(256, 2, dtype=torch.float64, device=device)
+            self._pool = torch.zeros(256, SLOT, dtype=torch.float64, device=device)
             self._pool_next = 0
         slot = self._pool[self._pool_next]
         self._slot_ref = (self._pool, self._pool_next)
@@ -165,10 +178,9 @@ class ShardedLogLikelihood:
         for work in self._works:
             work.wait()
         self._works = []
-        accs = torch.stack([a for a, _ in self._pending])
+        accs = torch.stack([a.view(-1) for a, _ in self._pending])
         self._pending = []
-        means = (accs[:, 0] / accs[:, 1]).cpu().tolist()  # one device->host copy for the whole window
-        return means
+        return slot_mean(accs).cpu().tolist()  # one device->host copy for the whole window
 
 
 def workspace_replica(model: torch.nn.Module) -> torch.nn.Module:
@@ -227,14 +239,14 @@ class GraphedEvaluationWindow:
         side.wait_stream(torch.cuda.current_stream(dev))
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.stream(side):
-            warm = torch.zeros(len(self.xs), 2, dtype=torch.float64, device=dev)
+            warm = torch.zeros(len(self.xs), SLOT, dtype=torch.float64, device=dev)
             for i, x in enumerate(self.xs):          # eager pass: plans bound, tables built, RCCL communicator up
                 self.lanes[i % chains]._local(x, acc=warm[i])
             if reduce:
                 dist.all_reduce(warm, op=dist.ReduceOp.SUM, group=evaluator.group)
             torch.cuda.synchronize(dev)
             with torch.cuda.graph(self.graph, stream=side):
-                self.pool = torch.zeros(len(self.xs), 2, dtype=torch.float64, device=dev)
+                self.pool = torch.zeros(len(self.xs), SLOT, dtype=torch.float64, device=dev)
                 for b in branches[1:]:
                     b.wait_stream(side)              # fork (the zeroed slots are complete on every chain)
                 for i, x in enumerate(self.xs):
@@ -249,7 +261,7 @@ class GraphedEvaluationWindow:
 
     def replay(self) -> List[float]:
         self.graph.replay()
-        return (self.pool[:, 0] / self.pool[:, 1]).cpu().tolist()
+        return slot_mean(self.pool).cpu().tolist()
 
 
 def bn_gather_moments(moments: torch.Tensor, group=None) -> torch.Tensor:

@@ -63,6 +63,10 @@ extern "C" {
                                        [B, H, W, C] (torch's channels_last) instead of [B, C, H, W]; only on the streaming
                                        route (dpk_spatial_level_streams), DPK_EUNSUPPORTED elsewhere                      */
 #define DPK_FLAG_OUT_PIXEL_MAJOR 32u /* dpk_spatial_prodsum_forward: write the output map as [B, OH, OW, Cout]; as above */
+#define DPK_FLAG_LL_SUM_SPREAD 64u   /* dpk_ratspn_forward: `ll_sum` points at 17 doubles -- sixteen partial sums of the
+                                       log-likelihoods (a work-group adds into one of them: 256 work-groups that finish
+                                       together are otherwise 256 same-address fp64 atomics in series) and then the count;
+                                       the caller adds the sixteen.  Without it: {sum, count}, 2 doubles.              */
 #define DPK_FLAG_PARAMS_VERIFY 8u  /* the same belief, checked on the device: the entry point fingerprints the live
                                      parameter bytes (one small launch) and rebuilds its tables only if they differ
                                      from the bytes the tables were built from.  What a caller passes when all it
