@@ -48,8 +48,8 @@ def _worker(rank, world, port, out_dir):
     # wraps from one pool to the next
     class PoolEval(ShardedLogLikelihood):
         def _local(self, x, kernel_events=None):
-            acc = self._acc_slot(x.device)
-            acc.copy_(local_sum(x))
+            acc = self._acc_slot(x.device)     # (a slot = sixteen partial sums, then the count: {sum, count} lands in the last two)
+            acc[-2:].copy_(local_sum(x))
             return acc
 
     ev2 = PoolEval(model=None, group=dist.group.WORLD, reduce_every=3)
