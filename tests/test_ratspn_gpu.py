@@ -1129,3 +1129,28 @@ def test_eight_channel_blocks_shared_by_two_work_groups_agree_with_whole_blocks(
     assert rel_err(whole[rows.cuda()].cpu().numpy(), want) <= 1e-5
     assert rel_err(chunks.cpu().numpy(), whole.cpu().numpy()) <= 2e-6
     assert torch.equal(again, parts[1])                      # the same launch twice: bit for bit
+
+
+def test_topdown_edge_cases():
+    """The one-launch top-down pass at its edges: an empty batch, nothing to complete (no NaN: evidence returned as it is),
+    everything to complete (all NaN = the unconditional MPE state: every row the same completion), labels of another
+    integer dtype, a CPU tensor (no silent fallback), more samples than one grid pass of the kernel."""
+    from deeprob.hip import HipError
+    from deeprob.spn.models import GaussianRatSpn
+    torch.manual_seed(1)
+    model = GaussianRatSpn(40, out_classes=3, rg_depth=2, rg_repetitions=4, rg_batch=4, rg_sum=3, random_state=2).cuda().eval()
+    assert tuple(model.mpe(torch.empty(0, 40, device='cuda')).shape) == (0, 40)
+    assert tuple(model.sample(0).shape) == (0, 40)
+    x = torch.randn(9, 40, device='cuda')
+    assert torch.equal(model.mpe(x), x)
+    allnan = torch.full((5, 40), float('nan'), device='cuda')
+    y = torch.tensor([0, 1, 2, 1, 1], dtype=torch.int32, device='cuda')
+    full = model.mpe(allnan, y=y)
+    assert not torch.isnan(full).any() and torch.equal(full[1], full[3]) and torch.equal(full[1], full[4])
+    assert torch.equal(full, model._mpe_layerwise(allnan, y=y.long()))
+    with pytest.raises((HipError, TypeError, ValueError, RuntimeError)):
+        model.mpe(torch.randn(3, 40))
+    yb = torch.arange(300000, device='cuda') % 3
+    big = model.sample(300000, y=yb, seed=5)    # > 256 compute units x 16 work-groups x 4 samples: the grid-stride loop
+    assert tuple(big.shape) == (300000, 40) and torch.isfinite(big).all()
+    assert torch.equal(big[:1000], model.sample(1000, y=yb[:1000], seed=5))    # (a draw depends on (seed, sample index) only)
