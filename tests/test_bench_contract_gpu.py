@@ -57,4 +57,5 @@ def test_bench_two_rank_rehearsal_on_one_device():
     assert d['n_gpus'] == 2 and d['n_ranks_seen'] == 2 and d['backend'] == 'gloo' and d['scaling'] == 'strong'
     assert '32768 samples per GPU per step' in d['config']['workload'] and d['config']['global_batch'] == 65536
     assert abs(d['value'] - 65536 / (d['ms_per_step'] * 1e-3)) <= 1e-6 * d['value']
-    assert d['step_mode'] in ('eager', 'HIP graph') and abs(d['config']['mean_ll'] + 1430.6) < 1.0
+    assert d['step_mode'].startswith(('eager', 'HIP graph')) and abs(d['config']['mean_ll'] + 1430.6) < 1.0
+    assert 'graphed window failed' in d['config']['step_mode'] or d['step_mode'] == 'HIP graph'
