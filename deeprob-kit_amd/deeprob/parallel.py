@@ -229,9 +229,19 @@ class GraphedEvaluationWindow:
         world = dist.get_world_size(evaluator.group) if evaluator.group is not None else 1
         reduce = evaluator.group is not None and (world > 1 or always_reduce)
         chains = max(1, min(int(chains), len(self.xs)))
-        self.lanes = [evaluator] + [
-            ShardedLogLikelihood(workspace_replica(evaluator.model), static_inputs=evaluator.static_inputs,
-                                 static_params=evaluator.static_params) for _ in range(chains - 1)]
+        if chains == 1:
+            self.lanes = [evaluator]
+        else:
+            # Concurrent launches must not wait on one another: the fused RAT-SPN kernels' in-launch table check has every
+            # work-group wait (up to a 1 s time-out) for the verdict of the launch's first work-groups -- sound while a launch
+            # has the chip to itself, a circular wait once the work-groups of three launches compete for the compute units
+            # (observed: one replay in a few taking the full second, results still right through the time-out's exact
+            # route).  With chains the parameters are therefore checked ONCE PER REPLAY at the head of every chain -- a
+            # one-sample forward in the default, verifying mode on that chain's workspace (14 work-groups: always
+            # co-resident; rebuilds the tables in place if a parameter was written) -- and the steps run on the verified
+            # tables (static_params).  A write to a parameter between two replays is seen; none happens during a replay.
+            models = [evaluator.model] + [workspace_replica(evaluator.model) for _ in range(chains - 1)]
+            self.lanes = [ShardedLogLikelihood(m, static_inputs=True, static_params=True) for m in models]
         side = torch.cuda.Stream(device=dev)
         branches = [side] + [torch.cuda.Stream(device=dev) for _ in range(chains - 1)]
         # (inputs / parameters still being written on the caller's stream must be complete before the warm pass reads them:
@@ -240,6 +250,10 @@ class GraphedEvaluationWindow:
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.stream(side):
             warm = torch.zeros(len(self.xs), SLOT, dtype=torch.float64, device=dev)
+            probe = self.xs[0][:1]
+            if chains > 1:
+                for lane in self.lanes:
+                    lane.model(probe)
             for i, x in enumerate(self.xs):          # eager pass: plans bound, tables built, RCCL communicator up
                 self.lanes[i % chains]._local(x, acc=warm[i])
             if reduce:
@@ -249,6 +263,10 @@ class GraphedEvaluationWindow:
                 self.pool = torch.zeros(len(self.xs), SLOT, dtype=torch.float64, device=dev)
                 for b in branches[1:]:
                     b.wait_stream(side)              # fork (the zeroed slots are complete on every chain)
+                if chains > 1:
+                    for lane, b in zip(self.lanes, branches):
+                        with torch.cuda.stream(b):
+                            lane.model(probe)        # the chain's table check for this replay
                 for i, x in enumerate(self.xs):
                     with torch.cuda.stream(branches[i % chains]):
                         self.lanes[i % chains]._local(x, acc=self.pool[i])
