@@ -1043,9 +1043,15 @@ def main():
             if abs(means2[0][-1] - mean_ll) > 1e-3 * abs(mean_ll) and ring % ns == 0:
                 raise RuntimeError('two-stream mean LL {} != {}'.format(means2[0][-1], mean_ll))
             one_stream_ms = dt / args.steps * 1e3
-            dt = dt2
-            step_mode = ('eager: {} evaluation streams, alternate steps, a model replica each (single-stream loop of the same '
-                         'steps: {:.5f} ms/step; roofline.kernel_ms comes from that loop)'.format(ns, one_stream_ms))
+            if dt2 <= 1.15 * dt:
+                dt = dt2
+                step_mode = ('eager: {} evaluation streams, alternate steps, a model replica each (single-stream loop of the '
+                             'same steps: {:.5f} ms/step; roofline.kernel_ms comes from that loop)'.format(ns, one_stream_ms))
+            else:
+                # (concurrent launches that check their tables in the launch wait on their own first work-groups: should the
+                # work-groups of two launches ever block one another, a 1 s time-out resolves it -- correct results, a useless
+                # timing.  Never observed at this size; the single-stream loop is the figure then.)
+                step_mode += ' (two-stream loop discarded: {:.5f} ms/step)'.format(dt2 / args.steps * 1e3)
         except Exception as ex:
             step_mode += ' (two-stream loop failed: {}: {})'.format(type(ex).__name__, str(ex)[:100])
 
