@@ -414,6 +414,10 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
         ms_eager, k_ms = _time_eval(m, xs, timer, kid, steps=50)
         ms_graph = _time_eval_graph(m, xs)
         ms = ms_graph if ms_graph is not None else ms_eager
+        # throughput of a stream of such steps: the graphed window on CHAINS parallel chains (tables verified once per replay at
+        # the head of every chain, steps on the verified tables; deeprob/parallel.py) -- at B = 4096 a launch covers half the
+        # chip or less, so launches of different chains run side by side
+        ms_chains = _time_window(m, xs, reps=4, chains=CHAINS)
         from deeprob import hip as _hip
         prev = _hip.trust_version_counters(True)     # the unchecked fast path (no write through .data, caller's word)
         try:
@@ -459,6 +463,7 @@ def secondary(dev, timer, threads, xs_headline, headline_model):
              'step_basis': 'model(x) calls replayed from one HIP graph (32 calls per replay; kernels, gaps and the per-call '
                            'parameter-table check included)' if ms_graph is not None else 'eager python loop',
              'ms_per_step_eager': ms_eager, 'ms_per_step_trusting_version_counters': ms_trust, 'kernel_ms': k_ms,
+             'ms_per_step_window_chains': ms_chains,
              'kernel': ('fused forward, small-batch kernel (one HIP event pair around a single launch: includes its '
                         'dispatch latency; rocprofv3: profiles/r03_config2_kernel_stats.txt)') if I < 8
                        else ('fused forward, one-launch 8-channel kernel (a wave per repetition; event pair around a '
@@ -757,7 +762,7 @@ def compact_configs(sec):
         r['rate'] = float('{:.4g}'.format(e['value']))
         for k_src, k_dst in (('ms_per_step_trusting_version_counters', 'ms_trust'), ('ms_per_step_eager', 'ms_eager'),
                              ('ms_per_step_hip_graph', 'ms_graph'), ('slowdown_vs_clean', 'x_clean'),
-                             ('ms_per_step_one_chain', 'ms_1chain')):
+                             ('ms_per_step_one_chain', 'ms_1chain'), ('ms_per_step_window_chains', 'ms_chains')):
             if e.get(k_src) is not None:
                 r[k_dst] = round(e[k_src], 5)
         # (a single-launch HIP event pair brackets its own dispatch: only a figure below the step it belongs to is evidence;
