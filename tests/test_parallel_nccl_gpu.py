@@ -108,6 +108,10 @@ def test_graphed_evaluation_window_over_single_rank_rccl(tmp_path, nccl_backend)
         want2 = [float(orc.ratspn_forward(sd, x.cpu()).double().mean()) for x in xs]
         assert not np.allclose(want2, want, rtol=1e-7)
         assert np.allclose(win.replay(), want2, rtol=1e-5) and np.allclose(win.replay(), want2, rtol=1e-5)
+        # round 6: the same window on three parallel chains -- the captured all-reduce sits behind the chains' join
+        win3 = GraphedEvaluationWindow(ev, xs, always_reduce=True, chains=3)
+        for _ in range(3):
+            assert np.allclose(win3.replay(), want2, rtol=1e-5)
     finally:
         dist.destroy_process_group()
 
