@@ -1738,6 +1738,24 @@ extern "C" int dpk_spatial_leaf_prodsum_forward(const float *x, const float *loc
     // channels that costs what the leaf map's round trip saves, 186 us against 76 + 110 on config 4's first level, so the
     // 8-channel models keep the leaf kernel + the streaming level; DPK_DGC_LEAF_FUSE_MIN_K: measurement only)
     const int leaf_min_k = leaf_fuse_min_k_ref();   // (dpk_spatial_leaf_fuse_min_k: read once from the environment, set by tests)
+    // Round 6: 8 -> 8 channels at streaming batch sizes -- the leaf layer inside the streaming level kernel (dgcspn_stream.hip,
+    // INK = 2): the image is what a stage holds (1/8 of the DMA), a tap's leaf values are evaluated from it and the position's
+    // parameters in LDS.  The leaf map's round trip (410 MB at B = 8192) and the leaf launch go; the level becomes bound by
+    // its arithmetic instead of HBM.  DPK_DGC_LEAF_STREAM=0 (measurement) keeps leaf kernel + streaming level.
+    static const bool leaf_stream_off = [] { const char *e = getenv("DPK_DGC_LEAF_STREAM"); return e && atoi(e) == 0; }();
+    const bool leaf_stream = !leaf_stream_off && K == 8 && Cout == 8 && B > 0 && stream_leaf_prodsum_ok(q, Cout, B, x, Cx);
+    DPK_REQUIRE(leaf_stream || !(flags & DPK_FLAG_OUT_PIXEL_MAJOR), DPK_EUNSUPPORTED,
+                "spatial_leaf_prodsum: a pixel-major output only on the streaming route");
+    if (leaf_stream) {
+        const int64_t seg = align_up((int64_t)Cout * K * OHW * 4, 256);
+        DPK_REQUIRE(ws_bytes >= 3 * seg, DPK_EWORKSPACE, "spatial_leaf_prodsum: workspace too small");
+        DPK_REQUIRE(x && out, DPK_EINVAL, "spatial_leaf_prodsum: null pointer");
+        float *Wl = (float *)ws, *LW = (float *)((char *)ws + seg);
+        hipStream_t st = (hipStream_t)stream;
+        if (!(flags & DPK_FLAG_PARAMS_CACHED))
+            DPK_LAUNCH(spatial_softmax_kernel, dim3(grid_cap((int64_t)Cout * OHW, 256)), dim3(256), 0, st, weight, Cout, K, OHW, Wl, LW);
+        return stream_leaf_prodsum_forward(x, loc, scale, Cx, B, q, Wl, LW, out, st, (flags & DPK_FLAG_OUT_PIXEL_MAJOR) != 0);
+    }
     const bool ok = (K == 8 || K == 16 || K == 32) && (pool || K >= leaf_min_k) && Cout <= 32 && kh == 2 && kw == 2 &&
                     lds <= 150 * 1024 && B <= INT32_MAX / 2;
     if (!ok) {

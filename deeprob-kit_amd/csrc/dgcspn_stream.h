@@ -22,6 +22,10 @@ bool stream_prodsum_ok(const ProdGeom &q, int Cout, int64_t B, const float *in);
 //   in_pm / out_pm          : the input / output map is pixel-major ([B, H, W, 8], torch's channels_last) instead of [B, 8, H, W]
 int stream_prodsum_forward(const float *in, int64_t B, const ProdGeom &q, const float *Wl, const float *LW, float *out,
                            hipStream_t st, bool in_pm = false, bool out_pm = false);
+//   stream_leaf_prodsum_*   : the first level with the Gaussian leaf layer folded in: x is the image [B, Cx, H, W]
+bool stream_leaf_prodsum_ok(const ProdGeom &q, int Cout, int64_t B, const float *x, int Cx);
+int stream_leaf_prodsum_forward(const float *x, const float *loc, const float *scale, int Cx, int64_t B, const ProdGeom &q,
+                                const float *Wl, const float *LW, float *out, hipStream_t st, bool out_pm);
 int64_t stream_sumprodroot_partial_bytes(const ProdGeom &q5, int Cout, const ProdGeom &q6, int K, int64_t B);
 int stream_sumprodroot_forward(const float *in, int64_t B, const ProdGeom &q5, const float *Wl, const float *LW,
                                const ProdGeom &q6, const float *LWr, int K, float *out, void *partials,

@@ -58,6 +58,8 @@ struct StreamTile {
 struct StreamArgs {
     const float *in, *Wl, *LW, *LWr;
     float *out;
+    const float *loc, *scale;   // INK = 2: leaf parameters [8, Cx, H, W]
+    int Cx;
     int B, per_wg, slices, T, cw, nl, nst, CS, stage_bytes, K;
     long long *dbg;   // measurement only (DPK_DGC_STREAM_TIMELINE): s_memtime stamps of work-group 0
     ProdGeom q5, q6;
@@ -128,8 +130,13 @@ __device__ __forceinline__ float dpp_wave_sum(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-template <int MODE, bool IN_PM, bool OUT_PM>
+template <int MODE, int INK, bool OUT_PM>
 __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a) {
+    // INK: what the stage holds -- 0 the input map channel-major, 1 the input map pixel-major, 2 the IMAGE (round 6: the Gaussian
+    // leaf layer folded into the model's first level: a tap's 8 leaf values are evaluated from the staged pixel and the leaf
+    // parameters of its position, which the work-group keeps in LDS; the [B, 8, H, W] leaf map -- 205 MB written and read back
+    // at B = 8192 -- never exists)
+    constexpr bool IN_PM = INK == 1, IN_LEAF = INK == 2;
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
     lchar *smem = (lchar *)smem_generic;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -151,6 +158,7 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
     }
     const int H = a.q5.H, W = a.q5.W, HW = H * W, CS = a.CS, nst = a.nst, stage_bytes = a.stage_bytes;
     const int cw = a.cw, nl = a.nl;
+    const int nin = IN_LEAF ? a.Cx : kStreamC;      // channel slots of a stage
     const unsigned smem_base = (unsigned)(uintptr_t)smem;
 
     // pixel-major stage: the bands back to back, band k at float offset lbp[k]; 8 zero floats (the guard pixel) behind them
@@ -165,9 +173,32 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
         for (int i = tid; i < nst * kStreamC; i += blockDim.x)
             *(lfloat *)(smem + (i / kStreamC) * stage_bytes + 4 * (pm_floats + (i % kStreamC))) = 0.f;
     } else {
-        for (int i = tid; i < nst * kStreamC * 4; i += blockDim.x) {
-            const int stg = i / (kStreamC * 4), c = (i >> 2) % kStreamC;
+        for (int i = tid; i < nst * nin * 4; i += blockDim.x) {
+            const int stg = i / (nin * 4), c = (i >> 2) % nin;
             *(lfloat *)(smem + stg * stage_bytes + 4 * (c * CS + CS - 4 + (i & 3))) = 0.f;
+        }
+    }
+    // INK = 2: the leaf parameters of the tile's staged positions, [slot offset][image channel][mu, 1/(2 s^2), -log s - log sqrt(2 pi)][8
+    // leaf channels] behind the stages; positions that hold no pixel (alignment slack, the guard) keep zeros: value 0 = log 1
+    lfloat *ptab = (lfloat *)(smem + nst * stage_bytes);
+    if (IN_LEAF) {
+        const int Cx = a.Cx;
+        for (int e = tid; e < CS * Cx * kStreamC; e += blockDim.x) {
+            const int k8 = e % kStreamC, cx = (e / kStreamC) % Cx, o = e / (kStreamC * Cx);
+            float mu = 0.f, iv = 0.f, cs = 0.f;
+#pragma unroll
+            for (int k = 0; k < kStreamMaxBands; ++k)
+                if (k < nb && o >= lb[k] && o < lb[k] + nr[k] * W) {
+                    const int pin = r0[k] * W + (o - lb[k]);
+                    const float sg = a.scale[((size_t)k8 * Cx + cx) * HW + pin];
+                    mu = a.loc[((size_t)k8 * Cx + cx) * HW + pin];
+                    iv = 0.5f / (sg * sg);
+                    cs = -logf(sg) - kLogSqrt2Pi;
+                }
+            lfloat *row = ptab + ((size_t)o * Cx + cx) * 24;
+            row[k8] = mu;
+            row[8 + k8] = iv;
+            row[16 + k8] = cs;
         }
     }
 
@@ -178,7 +209,7 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
         // fetches (or none: alignment slack, band gaps, the guard) never changes, so it is worked out here once and
         // a sample costs the loader nothing but the DMA instructions themselves.
         const int lw = wave - cw;
-        const int PPS = CS >> 2, NI = IN_PM ? ((pm_floats >> 2) + 63) >> 6 : (kStreamC * PPS + 63) >> 6;
+        const int PPS = CS >> 2, NI = IN_PM ? ((pm_floats >> 2) + 63) >> 6 : (nin * PPS + 63) >> 6;
         unsigned voff[kStreamMaxDma];
         unsigned live = 0;   // instructions with at least one lane to fetch
         int ninstr = 0;
@@ -195,7 +226,7 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
                 for (int k = 0; k < kStreamMaxBands; ++k)
                     if (k < nb && fp >= lbp[k] && fp < lbp[k] + nr[k] * W * kStreamC)
                         v = (unsigned)(r0[k] * W * kStreamC + (fp - lbp[k])) * 4u;
-            } else if (j < NI && c < kStreamC) {
+            } else if (j < NI && c < nin) {
 #pragma unroll
                 for (int k = 0; k < kStreamMaxBands; ++k) {
                     const int gfl = c * HW + r0[k] * W, sh = gfl & 3, np = (sh + nr[k] * W + 3) >> 2;
@@ -210,7 +241,7 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
         }
         const float *in = a.in;
         auto issue = [&](int i, int stg) {
-            const gcchar_p sb = (gcchar_p)(in + (int64_t)(s0 + i) * kStreamC * HW);
+            const gcchar_p sb = (gcchar_p)(in + (int64_t)(s0 + i) * nin * HW);
             const unsigned st = smem_base + stg * stage_bytes + lw * 1024;
 #pragma unroll
             for (int jj = 0; jj < kStreamMaxDma; ++jj)
@@ -340,6 +371,31 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
             }
 #pragma unroll
             for (int c = 0; c < kStreamC; ++c) m = fmaxf(m, acc[c]);
+        } else if (IN_LEAF) {
+            // SpatialGaussianLayer.forward (layers/dgcspn.py:101-120) at the four tap positions, then the product (their sum):
+            // leaf[k] = sum over the image channels of nan_to_num(-(x - mu)^2 / (2 s^2) - log s - log sqrt(2 pi)); a NaN pixel
+            // (marginalised) gives 0 through nan_to_num like the reference, a padding tap reads the guard row (all zeros)
+            typedef __attribute__((address_space(3))) const gf32x4 lf4;
+#pragma unroll
+            for (int c = 0; c < kStreamC; ++c) acc[c] = 0.f;
+            const int Cx = a.Cx;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                for (int cx = 0; cx < Cx; ++cx) {
+                    const float xv = *(lfloat *)(smem + (sb + 4u * (unsigned)(cx * CS + ((cx * HW + r0[0] * W) & 3)) + offb[t]));
+                    const lchar *row = (const lchar *)ptab + ((size_t)(offb[t] >> 2) * Cx + cx) * 96;
+                    gf32x4 pm[6];
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) pm[q] = *(lf4 *)(row + q * 16);
+#pragma unroll
+                    for (int k8 = 0; k8 < kStreamC; ++k8) {
+                        const float d = xv - pm[k8 >> 2][k8 & 3];
+                        acc[k8] += nan_to_num_f(fmaf(-(d * d), pm[2 + (k8 >> 2)][k8 & 3], pm[4 + (k8 >> 2)][k8 & 3]));
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < kStreamC; ++c) m = fmaxf(m, acc[c]);
         } else {
 #pragma unroll
             for (int c = 0; c < kStreamC; ++c) {
@@ -387,6 +443,17 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
                     asm volatile("" : "+v"(pq));
                     const float *lp = a.LW + (size_t)o * kStreamC * OHW + pq;
                     auto taps = [&](int c) {
+                        if (IN_LEAF) {       // the leaf values of channel c at the four taps, once more
+                            float tsum = 0.f;
+                            for (int t = 0; t < 4; ++t)
+                                for (int cx = 0; cx < a.Cx; ++cx) {
+                                    const float xv = *(lfloat *)(smem + (sb + 4u * (unsigned)(cx * CS + ((cx * HW + r0[0] * W) & 3)) + offb[t]));
+                                    const lfloat *row = ptab + ((size_t)(offb[t] >> 2) * a.Cx + cx) * 24;
+                                    const float d = xv - row[c];
+                                    tsum += nan_to_num_f(fmaf(-(d * d), row[8 + c], row[16 + c]));
+                                }
+                            return tsum;
+                        }
                         const unsigned kc = IN_PM ? sb + 4u * (unsigned)c
                                                   : sb + 4u * (unsigned)(c * CS + ((c * HW + r0[0] * W) & 3));
                         return (*(lfloat *)(smem + (kc + offb[0])) + *(lfloat *)(smem + (kc + offb[1]))) +
@@ -665,10 +732,17 @@ static int stream_launch(StreamArgs &a, const StreamPlan &pl, int64_t B, hipStre
     a.per_wg = (int)cdiv(B, slices);
     a.slices = cdiv(B, a.per_wg);
     void (*kern)(const StreamArgs) = nullptr;
-    if (MODE == 1) kern = in_pm ? spatial_stream_kernel<1, true, false> : spatial_stream_kernel<1, false, false>;
-    else if (in_pm) kern = out_pm ? spatial_stream_kernel<0, true, true> : spatial_stream_kernel<0, true, false>;
-    else kern = out_pm ? spatial_stream_kernel<0, false, true> : spatial_stream_kernel<0, false, false>;
+    const bool leaf = a.loc != nullptr;
+    if (MODE == 1) kern = in_pm ? spatial_stream_kernel<1, 1, false> : spatial_stream_kernel<1, 0, false>;
+    else if (leaf) kern = out_pm ? spatial_stream_kernel<0, 2, true> : spatial_stream_kernel<0, 2, false>;
+    else if (in_pm) kern = out_pm ? spatial_stream_kernel<0, 1, true> : spatial_stream_kernel<0, 1, false>;
+    else kern = out_pm ? spatial_stream_kernel<0, 0, true> : spatial_stream_kernel<0, 0, false>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), kStreamLds)) return rc;
+    size_t lds_bytes = (size_t)pl.nst * pl.stage_bytes;
+    if (leaf) {   // a stage holds Cx image channels instead of 8 map channels; the parameter table sits behind the stages
+        a.stage_bytes = (int)align_up((int64_t)a.Cx * pl.CS * 4, 16);
+        lds_bytes = (size_t)pl.nst * a.stage_bytes + (size_t)pl.CS * a.Cx * 24 * 4;
+    }
     const unsigned grid = (unsigned)(pl.T * align_up(a.slices, 8));
     static const bool debug = getenv("DPK_DGC_STREAM_DEBUG") != nullptr;
     if (debug)
@@ -684,7 +758,7 @@ static int stream_launch(StreamArgs &a, const StreamPlan &pl, int64_t B, hipStre
     a.dbg = nullptr;
     if (timeline) (void)hipMalloc(&a.dbg, 16 * 16 * 8 * 8 + 64 + 4096 * 32);
     if (a.dbg) (void)hipMemset(a.dbg, 0, 16 * 16 * 8 * 8 + 64 + 4096 * 32);
-    DPK_LAUNCH(kern, dim3(grid), dim3((pl.cw + pl.nl) * 64), (size_t)pl.nst * pl.stage_bytes, st, a);
+    DPK_LAUNCH(kern, dim3(grid), dim3((pl.cw + pl.nl) * 64), lds_bytes, st, a);
     if (pev1) (void)hipEventRecord(pev1, st);
     DPK_CHECK_LAUNCH("spatial_stream_kernel");
     if (a.dbg) {   // measurement only: synchronous read-back of work-group 0's stamps
@@ -734,6 +808,34 @@ int stream_prodsum_forward(const float *in, int64_t B, const ProdGeom &q, const 
     a.q5 = q;
     a.q6 = q;
     return stream_launch<0>(a, pl, B, st, DPK_KERNEL_SPATIAL_PRODSUM, in_pm, out_pm);
+}
+
+// the model's first level with the Gaussian leaf layer folded in (INK = 2): x [B, Cx, H, W], loc / scale [8, Cx, H, W]
+bool stream_leaf_prodsum_ok(const ProdGeom &q, int Cout, int64_t B, const float *x, int Cx) {
+    if (!stream_shape_ok(q, Cout, B, x) || Cx < 1 || Cx > 4) return false;
+    StreamPlan pl;
+    if (!stream_plan(0, q, nullptr, pl)) return false;
+    const size_t lds = (size_t)pl.nst * align_up((int64_t)Cx * pl.CS * 4, 16) + (size_t)pl.CS * Cx * 24 * 4;
+    return lds <= (size_t)kStreamLds;
+}
+
+int stream_leaf_prodsum_forward(const float *x, const float *loc, const float *scale, int Cx, int64_t B, const ProdGeom &q,
+                                const float *Wl, const float *LW, float *out, hipStream_t st, bool out_pm) {
+    StreamPlan pl;
+    DPK_REQUIRE(stream_plan(0, q, nullptr, pl), DPK_EUNSUPPORTED, "spatial_leaf_prodsum: no streaming plan");
+    StreamArgs a{};
+    a.in = x;
+    a.loc = loc;
+    a.scale = scale;
+    a.Cx = Cx;
+    a.Wl = Wl;
+    a.LW = LW;
+    a.LWr = nullptr;
+    a.out = out;
+    a.K = 0;
+    a.q5 = q;
+    a.q6 = q;
+    return stream_launch<0>(a, pl, B, st, DPK_KERNEL_SPATIAL_PRODSUM, false, out_pm);
 }
 
 int64_t stream_sumprodroot_partial_bytes(const ProdGeom &q5, int Cout, const ProdGeom &q6, int K, int64_t B) {

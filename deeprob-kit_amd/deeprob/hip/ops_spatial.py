@@ -305,7 +305,7 @@ def spatial_prodsum(x, prod_layer, weight, ws: Workspace, out_pixel_major: bool 
     return out
 
 
-def spatial_leaf_prodsum(x, leaf_layer, prod_layer, weight, ws: Workspace):
+def spatial_leaf_prodsum(x, leaf_layer, prod_layer, weight, ws: Workspace, out_pixel_major: bool = False):
     """SpatialGaussianLayer + the first depthwise product + sum level of the eval route in ONE launch (reference:
     deeprob/spn/models/dgcspn.py:134-147): the [B, K, H, W] leaf map is never written.  None when the level is outside
     the fused kernel's envelope (the caller evaluates the leaf layer and then ``spatial_prodsum``)."""
@@ -322,11 +322,16 @@ def spatial_leaf_prodsum(x, leaf_layer, prod_layer, weight, ws: Workspace):
     if C != K or (H, W) != tuple(x.shape[2:]):
         return None
     B, Cout = x.shape[0], w.shape[0]
-    out = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
+    if out_pixel_major:      # (honoured by the streaming route only: anything else answers DPK_EUNSUPPORTED, plain layout then)
+        out = torch.empty((B, OH, OW, Cout), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
+    else:
+        out = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
     buf = _spatial_sum_ws(ws, C, Cout, OH, OW, x.device)
-    flags = _tables_flag(ws, 'prodsum', w)
+    flags = _tables_flag(ws, 'prodsum', w) | (DPK_FLAG_OUT_PIXEL_MAJOR if out_pixel_major else 0)
     rc = lib.dpk_spatial_leaf_prodsum_forward(ptr(x), ptr(loc), ptr(scale), B, Cx, K, H, W, OH, OW, kh, kw, sh, sw, dh, dw, pt,
                                               pl, ptr(w), Cout, ptr(out), ptr(buf), buf.numel(), flags, stream_ptr(x.device))
+    if rc == -4 and out_pixel_major:     # (not on the streaming route: the plain layout once more)
+        return spatial_leaf_prodsum(x, leaf_layer, prod_layer, weight, ws)
     if rc:
         ws.params_key = None
     if rc == -4:  # DPK_EUNSUPPORTED

@@ -151,7 +151,8 @@ class DgcSpn(ProbabilisticModel):
         if (n >= 4 and isinstance(self.base_layer, SpatialGaussianLayer) and isinstance(self.layers[0], SpatialProductLayer)
                 and isinstance(self.layers[1], SpatialSumLayer) and not self.training):
             # the Gaussian leaf layer folded into the first (pooling) level: the leaf map is never written
-            y = ops_spatial.spatial_leaf_prodsum(x, self.base_layer, self.layers[0], self.layers[1].weight, self.layers[1]._ws)
+            y = ops_spatial.spatial_leaf_prodsum(x, self.base_layer, self.layers[0], self.layers[1].weight, self.layers[1]._ws,
+                                                 out_pixel_major=self._level_streams(2, x.shape[0]))
         if y is not None:
             x, i = y, 2
         else:
