@@ -130,8 +130,11 @@ __device__ __forceinline__ float dpp_wave_sum(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// (the leaf variant: at most 12 waves -- 170 registers; at 128 it spilled 8 of the 64 weight registers into the sample loop: 143 us
+// against 124 for the unpacked form that fits)
+constexpr int kStreamLeafWaves = 12;
 template <int MODE, int INK, bool OUT_PM>
-__global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a) {
+__global__ __launch_bounds__(INK == 2 ? kStreamLeafWaves * 64 : 1024) void spatial_stream_kernel(const StreamArgs a) {
     // INK: what the stage holds -- 0 the input map channel-major, 1 the input map pixel-major, 2 the IMAGE (round 6: the Gaussian
     // leaf layer folded into the model's first level: a tap's 8 leaf values are evaluated from the staged pixel and the leaf
     // parameters of its position, which the work-group keeps in LDS; the [B, 8, H, W] leaf map -- 205 MB written and read back
@@ -181,8 +184,12 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
     // INK = 2: the leaf parameters of the tile's staged positions, [slot offset][image channel][mu, 1/(2 s^2), -log s - log sqrt(2 pi)][8
     // leaf channels] behind the stages; positions that hold no pixel (alignment slack, the guard) keep zeros: value 0 = log 1
     lfloat *ptab = (lfloat *)(smem + nst * stage_bytes);
+    typedef __attribute__((address_space(3))) int lint;
+    lint *leaf_odd = (lint *)(ptab + (IN_LEAF ? (size_t)CS * a.Cx * 24 : 0));
     if (IN_LEAF) {
         const int Cx = a.Cx;
+        if (tid == 0) *leaf_odd = 0;
+        __syncthreads();
         for (int e = tid; e < CS * Cx * kStreamC; e += blockDim.x) {
             const int k8 = e % kStreamC, cx = (e / kStreamC) % Cx, o = e / (kStreamC * Cx);
             float mu = 0.f, iv = 0.f, cs = 0.f;
@@ -199,6 +206,9 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
             row[k8] = mu;
             row[8 + k8] = iv;
             row[16 + k8] = cs;
+            // (parameters with which a finite pixel could still give a non-finite term -- a zero / NaN / inf scale, a
+            // non-finite mean: the tile then keeps the term-by-term nan_to_num_ form for every sample)
+            if (!(fabsf(mu) < 1e18f) || !(iv < 1e30f) || !(fabsf(cs) < 1e30f)) *leaf_odd = 1;
         }
     }
 
@@ -343,6 +353,7 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
         a.dbg[16 * 16 * 8 + 0] = (long long)__builtin_readcyclecounter();
         a.dbg[16 * 16 * 8 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
     }
+    const bool leaf_odd_tile = IN_LEAF && *leaf_odd != 0;
     int stg = 0;
     for (int i = 0; i < n; ++i) {
         STREAM_STAMP(0);
@@ -376,23 +387,43 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
             // leaf[k] = sum over the image channels of nan_to_num(-(x - mu)^2 / (2 s^2) - log s - log sqrt(2 pi)); a NaN pixel
             // (marginalised) gives 0 through nan_to_num like the reference, a padding tap reads the guard row (all zeros)
             typedef __attribute__((address_space(3))) const gf32x4 lf4;
-#pragma unroll
-            for (int c = 0; c < kStreamC; ++c) acc[c] = 0.f;
             const int Cx = a.Cx;
+            gf32x4 alo = {0.f, 0.f, 0.f, 0.f}, ahi = {0.f, 0.f, 0.f, 0.f};
+            for (int cx = 0; cx < Cx; ++cx) {
+                const unsigned xb = sb + 4u * (unsigned)(cx * CS + ((cx * HW + r0[0] * W) & 3));
+                float xv[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                for (int cx = 0; cx < Cx; ++cx) {
-                    const float xv = *(lfloat *)(smem + (sb + 4u * (unsigned)(cx * CS + ((cx * HW + r0[0] * W) & 3)) + offb[t]));
+                for (int t = 0; t < 4; ++t) xv[t] = *(lfloat *)(smem + (xb + offb[t]));
+                // finite pixels of moderate size under sane parameters give finite terms: nan_to_num_ is the identity and
+                // the eight channels go through packed arithmetic (3 instead of 8 instructions per value); a NaN (marginalised)
+                // or huge pixel anywhere in the wave, or odd parameters in the tile, take the term-by-term form
+                const bool plain = (fabsf(xv[0]) < 1e18f) && (fabsf(xv[1]) < 1e18f) && (fabsf(xv[2]) < 1e18f) && (fabsf(xv[3]) < 1e18f);
+                const bool packed = __all(plain) && !leaf_odd_tile;       // (wave-uniform)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    // (the variant's launch bound leaves 170 registers: the taps' parameter reads may overlap)
                     const lchar *row = (const lchar *)ptab + ((size_t)(offb[t] >> 2) * Cx + cx) * 96;
-                    gf32x4 pm[6];
+                    const float xt = *(lfloat *)(smem + (xb + offb[t]));        // (read again: four registers less across the taps)
 #pragma unroll
-                    for (int q = 0; q < 6; ++q) pm[q] = *(lf4 *)(row + q * 16);
+                    for (int hf = 0; hf < 2; ++hf) {                            // leaf channels 0-3, then 4-7: twelve registers of parameters
+                        const gf32x4 mu4 = *(lf4 *)(row + hf * 16), iv4 = *(lf4 *)(row + 32 + hf * 16), cs4 = *(lf4 *)(row + 64 + hf * 16);
+                        // (the same arithmetic on both paths -- a sample's value must not depend on its wave-mates --, the
+                        // reference's nan_to_num_ on top where a term can be non-finite)
+                        const gf32x4 d4 = xt - mu4;
+                        gf32x4 v4 = cs4 - (d4 * d4) * iv4;
+                        if (!packed) {
 #pragma unroll
-                    for (int k8 = 0; k8 < kStreamC; ++k8) {
-                        const float d = xv - pm[k8 >> 2][k8 & 3];
-                        acc[k8] += nan_to_num_f(fmaf(-(d * d), pm[2 + (k8 >> 2)][k8 & 3], pm[4 + (k8 >> 2)][k8 & 3]));
+                            for (int k8 = 0; k8 < 4; ++k8) v4[k8] = nan_to_num_f(v4[k8]);
+                        }
+                        if (hf == 0) alo += v4;
+                        else ahi += v4;
                     }
                 }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc[c] = alo[c];
+                acc[4 + c] = ahi[c];
             }
 #pragma unroll
             for (int c = 0; c < kStreamC; ++c) m = fmaxf(m, acc[c]);
@@ -450,7 +481,7 @@ __global__ __launch_bounds__(1024) void spatial_stream_kernel(const StreamArgs a
                                     const float xv = *(lfloat *)(smem + (sb + 4u * (unsigned)(cx * CS + ((cx * HW + r0[0] * W) & 3)) + offb[t]));
                                     const lfloat *row = ptab + ((size_t)(offb[t] >> 2) * a.Cx + cx) * 24;
                                     const float d = xv - row[c];
-                                    tsum += nan_to_num_f(fmaf(-(d * d), row[8 + c], row[16 + c]));
+                                    tsum += nan_to_num_f(row[16 + c] - (d * d) * row[8 + c]);
                                 }
                             return tsum;
                         }
@@ -624,7 +655,7 @@ static int tile_slot_floats(const StreamTile &t, int W) {
     return lb + 4;
 }
 
-static bool stream_plan_build(int mode, const ProdGeom &q5, const ProdGeom *q6, StreamPlan &best) {
+static bool stream_plan_build(int mode, const ProdGeom &q5, const ProdGeom *q6, StreamPlan &best, int max_waves) {
     const int N = mode == 0 ? q5.OH * q5.OW : q6->OH * q6->OW;   // pixels / root pixels to distribute
     const int per = mode == 0 ? 1 : 4;                           // thread slots per unit
     double best_score = -1;
@@ -653,8 +684,8 @@ static bool stream_plan_build(int mode, const ProdGeom &q5, const ProdGeom *q6, 
         // kComputeTicks per sample -- enough loaders that the copy of a sample is not the longer of the two
         const int NI = cdiv(kStreamC * cs / 4, 64);
         pl.nl = std::min(4, std::max(cdiv(NI, kStreamMaxDma), cdiv(NI, 8)));
-        while (pl.nl > cdiv(NI, kStreamMaxDma) && pl.nl > 1 && pl.cw + pl.nl > kStreamMaxWaves) --pl.nl;
-        if (pl.cw + pl.nl > kStreamMaxWaves || cdiv(NI, pl.nl) > kStreamMaxDma) continue;
+        while (pl.nl > cdiv(NI, kStreamMaxDma) && pl.nl > 1 && pl.cw + pl.nl > max_waves) --pl.nl;
+        if (pl.cw + pl.nl > max_waves || cdiv(NI, pl.nl) > kStreamMaxDma) continue;
         // the waves of a work-group go round-robin over the 4 SIMDs starting at the same one: a SIMD (4 waves of 128
         // VGPRs) ends up with ceil(waves / 4) of every resident work-group
         const int by_waves = 4 / cdiv(pl.cw + pl.nl, 4);
@@ -676,9 +707,9 @@ static bool stream_plan_build(int mode, const ProdGeom &q5, const ProdGeom *q6, 
 
 // The plan depends on the geometry only: a model reuses a handful of them at every call (planning costs tens of
 // microseconds of host time: band search over up to 16 tilings), so the last few are kept.
-static bool stream_plan(int mode, const ProdGeom &q5, const ProdGeom *q6, StreamPlan &best) {
+static bool stream_plan(int mode, const ProdGeom &q5, const ProdGeom *q6, StreamPlan &best, int max_waves = kStreamMaxWaves) {
     struct Entry {
-        int mode, ok;
+        int mode, ok, max_waves;
         ProdGeom q5, q6;
         StreamPlan plan;
     };
@@ -689,16 +720,16 @@ static bool stream_plan(int mode, const ProdGeom &q5, const ProdGeom *q6, Stream
     if (!force) {
         std::lock_guard<std::mutex> lock(mu);
         for (const Entry &e : cache)
-            if (e.mode == mode && memcmp(&e.q5, &q5, sizeof(ProdGeom)) == 0 && memcmp(&e.q6, &q6v, sizeof(ProdGeom)) == 0) {
+            if (e.mode == mode && e.max_waves == max_waves && memcmp(&e.q5, &q5, sizeof(ProdGeom)) == 0 && memcmp(&e.q6, &q6v, sizeof(ProdGeom)) == 0) {
                 best = e.plan;
                 return e.ok != 0;
             }
     }
-    const bool ok = stream_plan_build(mode, q5, q6, best);
+    const bool ok = stream_plan_build(mode, q5, q6, best, max_waves);
     if (!force) {
         std::lock_guard<std::mutex> lock(mu);
         if (cache.size() >= 64) cache.erase(cache.begin());
-        cache.push_back(Entry{mode, ok ? 1 : 0, q5, q6v, best});
+        cache.push_back(Entry{mode, ok ? 1 : 0, max_waves, q5, q6v, best});
     }
     return ok;
 }
@@ -727,7 +758,12 @@ static int stream_launch(StreamArgs &a, const StreamPlan &pl, int64_t B, hipStre
     for (int i = 0; i < pl.T; ++i) a.tile[i] = pl.tile[i];
     // one slice of the batch per resident work-group
     // (all T tiles of a slice run on one XCD, see the kernel: 8 XCDs, each with an eighth of the work-group slots)
-    int64_t slices = 8 * std::max<int64_t>(1, (int64_t)(device_cus() / 8) * pl.wg_per_cu / pl.T);
+    int wg_per_cu = pl.wg_per_cu;
+    if (a.loc != nullptr) {   // the leaf variant: 141 registers (3 waves per SIMD), its parameter table in LDS beside the stages
+        const size_t lds_leaf = (size_t)pl.nst * align_up((int64_t)a.Cx * pl.CS * 4, 16) + (size_t)pl.CS * a.Cx * 24 * 4 + 16;
+        wg_per_cu = std::max(1, std::min({wg_per_cu, 3 / cdiv(pl.cw + pl.nl, 4), (int)((size_t)kStreamLds / lds_leaf)}));
+    }
+    int64_t slices = 8 * std::max<int64_t>(1, (int64_t)(device_cus() / 8) * wg_per_cu / pl.T);
     if (slices > B) slices = B;
     a.per_wg = (int)cdiv(B, slices);
     a.slices = cdiv(B, a.per_wg);
@@ -741,7 +777,12 @@ static int stream_launch(StreamArgs &a, const StreamPlan &pl, int64_t B, hipStre
     size_t lds_bytes = (size_t)pl.nst * pl.stage_bytes;
     if (leaf) {   // a stage holds Cx image channels instead of 8 map channels; the parameter table sits behind the stages
         a.stage_bytes = (int)align_up((int64_t)a.Cx * pl.CS * 4, 16);
-        lds_bytes = (size_t)pl.nst * a.stage_bytes + (size_t)pl.CS * a.Cx * 24 * 4;
+        // a stage is a kilobyte or three and ONE LDS-DMA instruction: with the plan's 4 stages the loader has 3 samples in
+        // flight against several microseconds of HBM latency under load -- the level was bound by that (5.7 k cycles per
+        // wave and sample for ~250 instructions); 16 stages
+        const size_t tab = (size_t)pl.CS * a.Cx * 24 * 4 + 16;
+        a.nst = (int)std::max<size_t>(pl.nst, std::min<size_t>(16, ((size_t)kStreamLds / wg_per_cu - tab) / a.stage_bytes));
+        lds_bytes = (size_t)a.nst * a.stage_bytes + tab;
     }
     const unsigned grid = (unsigned)(pl.T * align_up(a.slices, 8));
     static const bool debug = getenv("DPK_DGC_STREAM_DEBUG") != nullptr;
@@ -814,15 +855,15 @@ int stream_prodsum_forward(const float *in, int64_t B, const ProdGeom &q, const 
 bool stream_leaf_prodsum_ok(const ProdGeom &q, int Cout, int64_t B, const float *x, int Cx) {
     if (!stream_shape_ok(q, Cout, B, x) || Cx < 1 || Cx > 4) return false;
     StreamPlan pl;
-    if (!stream_plan(0, q, nullptr, pl)) return false;
-    const size_t lds = (size_t)pl.nst * align_up((int64_t)Cx * pl.CS * 4, 16) + (size_t)pl.CS * Cx * 24 * 4;
-    return lds <= (size_t)kStreamLds;
+    if (!stream_plan(0, q, nullptr, pl, kStreamLeafWaves)) return false;
+    const size_t lds = (size_t)pl.nst * align_up((int64_t)Cx * pl.CS * 4, 16) + (size_t)pl.CS * Cx * 24 * 4 + 16;
+    return lds <= (size_t)kStreamLds && pl.cw + pl.nl <= kStreamLeafWaves;
 }
 
 int stream_leaf_prodsum_forward(const float *x, const float *loc, const float *scale, int Cx, int64_t B, const ProdGeom &q,
                                 const float *Wl, const float *LW, float *out, hipStream_t st, bool out_pm) {
     StreamPlan pl;
-    DPK_REQUIRE(stream_plan(0, q, nullptr, pl), DPK_EUNSUPPORTED, "spatial_leaf_prodsum: no streaming plan");
+    DPK_REQUIRE(stream_plan(0, q, nullptr, pl, kStreamLeafWaves), DPK_EUNSUPPORTED, "spatial_leaf_prodsum: no streaming plan");
     StreamArgs a{};
     a.in = x;
     a.loc = loc;
