@@ -191,3 +191,20 @@ def test_graphed_sharded_training_step_over_single_rank_rccl(tmp_path, nccl_back
         assert np.allclose(graphed, eager, rtol=2e-3)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('family', ['dgcspn', 'realnvp'])
+def test_graphed_window_chains_for_the_other_model_families(family):
+    """Parallel chains for models without the fused fp64 accumulation (DGC-SPN, RealNVP-1D: model(x) + dpk_ll_accumulate
+    into the spread slot): the same means as one chain and as the oracle."""
+    from deeprob.parallel import ShardedLogLikelihood, GraphedEvaluationWindow
+    model, shape, ll = tp._family(family)
+    model.cuda()
+    xs = [x.cuda() for x in tp._inputs(family, shape)]
+    xs = xs + [x.clone() for x in xs]
+    one = GraphedEvaluationWindow(ShardedLogLikelihood(model, static_inputs=True), xs).replay()
+    two = GraphedEvaluationWindow(ShardedLogLikelihood(model, static_inputs=True), xs, chains=2)
+    want = [float(ll(x.cpu()).double().mean()) for x in xs]
+    assert np.allclose(one, want, rtol=1e-5)
+    for _ in range(3):
+        assert np.allclose(two.replay(), one, rtol=1e-6)
