@@ -1089,7 +1089,8 @@ def main():
 
     ms_frozen = ms_exact = ms_graph_chains = None
     if world == 1:
-        ms_graph_chains = _time_window(model, xs, reps=max(1, 24 // len(xs)), chains=CHAINS)
+        if args.streams > 1:      # (--streams 1 = nothing but launches that have the chip to themselves: the profiled command)
+            ms_graph_chains = _time_window(model, xs, reps=max(1, 24 // len(xs)), chains=CHAINS)
         ms_frozen = plain_loop(ShardedLogLikelihood(model, static_inputs=True, static_params=True), args.steps)
         try:
             from deeprob.hip import load_library
