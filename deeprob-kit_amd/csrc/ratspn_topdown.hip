@@ -119,7 +119,9 @@ __global__ __launch_bounds__(256) void ratspn_topdown_kernel(const TopDownArgs a
     const unsigned long long K = (unsigned long long)G0 + 2ull * (unsigned long long)a.D;
     for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < a.B; b += (int64_t)gridDim.x * 4) {
         const unsigned long long ctr0 = (unsigned long long)b * K;
-        const int cls = a.y ? (int)a.y[b] : 0;
+        // (a label outside [0, C) indexes past the root's weight rows in the reference and raises there; here it is clamped:
+        // a kernel cannot raise, and must not read past the table)
+        const int cls = a.y ? min(max((int)a.y[b], 0), a.C - 1) : 0;
         // ---- root: one of the reps * N^2 inputs (partition = repetition, (i, j) = nodes of its two regions) ----
         int rep;
         {
