@@ -260,7 +260,7 @@ class SumFn(torch.autograd.Function):
         B, P, N = x.shape
         S = w.shape[1]
         out = torch.empty((B, P, S), dtype=torch.float32, device=x.device)
-        buf = _sum_ws(ws, B, P, N, S, x.device)
+        buf = _sum_ws(ws, 0, P, N, S, x.device)      # (B sizes the backward's residual segment only)
         check(lib.dpk_sum_forward(ptr(x), ptr(w), B, P, N, S, ptr(out), ptr(buf), buf.numel(),
                                   stream_ptr(x.device)), 'dpk_sum_forward')
         ctx.save_for_backward(x, w, out)
@@ -294,7 +294,7 @@ class RootFn(torch.autograd.Function):
         M, C = w.shape[1], w.shape[0]
         x2 = x.reshape(B, M)
         out = torch.empty((B, C), dtype=torch.float32, device=x.device)
-        buf = _sum_ws(ws, B, 1, M, C, x.device)
+        buf = _sum_ws(ws, 0, 1, M, C, x.device)
         check(lib.dpk_root_forward(ptr(x2), ptr(w), B, M, C, ptr(out), ptr(buf), buf.numel(),
                                    stream_ptr(x.device)), 'dpk_root_forward')
         ctx.save_for_backward(x2, w, out)
@@ -355,7 +355,7 @@ def _prodsum_backward(x, w, out, g, ws: Workspace, root: bool, need_gx: bool, ne
         S = w.shape[0] if root else w.shape[1]
         gx = torch.empty_like(x) if need_gx else None
         gw = torch.empty_like(w) if need_gw else None
-        buf = _sum_ws(ws, B, P, N * N, S, x.device)
+        buf = _sum_ws(ws, 0, P, N * N, S, x.device)
         rc = lib.dpk_prodsum_backward(ptr(x), ptr(w), ptr(out), ptr(g), B, R, N, S, int(root), ptr(gx), ptr(gw), ptr(buf),
                                       buf.numel(), st)
         if rc != -4:
