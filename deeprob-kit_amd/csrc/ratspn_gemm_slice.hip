@@ -801,7 +801,11 @@ __global__ __launch_bounds__(kSliceThreads) void ratspn_gemm_slice_kernel(const 
     if (a.ll_sum != nullptr) {
         // {sum of LLs, count}: one atomic per work-group (and one for the count per launch)
         double *red_l = reinterpret_cast<double *>(smem_generic + kSliceCompute * kSliceSlot);   // (the partials are idle now)
-        const double red = wave_reduce_sum(ll_part);
+        // (only the lanes 0, 16, 32, 48 -- the writers of the wave's four samples -- hold anything: two exchange steps, not six;
+        // this chain sits at the very end of every work-group, and at one block per work-group -- a strong-scaling shard --
+        // the end of the work-group is the end of the launch)
+        double red = ll_part + __shfl_xor(ll_part, 16, 64);
+        red += __shfl_xor(red, 32, 64);
         if (lane == 0) red_l[wave] = red;
         __syncthreads();
         if (tid == 0) {
