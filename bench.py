@@ -213,6 +213,9 @@ def _time_eval(model, xs, timer, kernel_id, steps=30, warm=5):
     return ms, (sum(k_ms) / len(k_ms) if k_ms else None)
 
 
+_KEEP_ALIVE = []   # graphed windows of the N > 1 path (see graphed_run)
+
+
 def _time_eval_graph(model, xs, reps=4):
     """ms per model(x) call when a pass over the resident batches `xs` (x `reps`) is replayed from ONE HIP graph: what a
     density-evaluation loop over resident data costs once the launch-bound host loop is out of the way (the kernels,
@@ -225,7 +228,7 @@ def _time_eval_graph(model, xs, reps=4):
             for x in xs:
                 model(x)
             torch.cuda.synchronize()
-            with torch.cuda.graph(g, stream=side):
+            with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):   # (NCCL watchdog: see deeprob.parallel)
                 for _ in range(reps):
                     for x in xs:
                         model(x)
@@ -913,7 +916,10 @@ def main():
         tt = torch.tensor([dtg], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        del win, xs_g
+        # (the graph holds a captured collective; releasing such a graph -- like destroying its communicator -- aborts the
+        # process now and then on this stack, tests/test_parallel_nccl_gpu.py::_run_case: it stays alive to the end)
+        _KEEP_ALIVE.append(win)
+        del xs_g
         return float(tt.item()), means[-1], L
 
     ring = args.ring or max(4, -(-(768 << 20) // (B * D * 4)))
@@ -1171,9 +1177,18 @@ def main():
             out['detail_file'] = out_path
             if 'configs' in out:   # (keep `configs` the last key)
                 out['configs'] = out.pop('configs')
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
-        dist.destroy_process_group()
+        # Every rank is past its last collective; the line is out.  The ranks leave WITHOUT tearing down the communicator
+        # and the HIP graphs that captured its collectives: that teardown (destroy_process_group, or the graphs'
+        # destructors) ended 1-4 % of single-rank test runs on this stack with SIGABRT and no message -- across the ranks
+        # of an N = 2 / 4 / 8 series that is one failed run in four for nothing.
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == '__main__':

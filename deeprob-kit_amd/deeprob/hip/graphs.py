@@ -77,7 +77,12 @@ class GraphedTrainStep:
             torch.cuda.current_stream().wait_stream(side)
             return loss
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        if self.grad_exchange is not None:
+            from deeprob.parallel import quiesce_collectives
+            quiesce_collectives()     # (eager collectives of the warm-up steps: retired before the capture opens)
+        # (thread-local capture mode: with a process group up, ProcessGroupNCCL's watchdog thread may call hipEventQuery
+        # while this thread captures -- an error under the default 'global' mode, which the watchdog turns into abort())
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.static_loss = self._eager(self.static_in)
         # capture records the step without running it: replay once so that this batch is trained on as well
         self.graph.replay()

@@ -46,6 +46,44 @@ def shard_batch(x: torch.Tensor, rank: Optional[int] = None, world: Optional[int
 
 
 SLOT = 17      # doubles of a {sum LL, count} slot: hip.LL_SPREAD partial sums, then the count
+CAPTURE_ERROR_MODE = 'thread_local'   # torch.cuda.graph(..., capture_error_mode=): see GraphedEvaluationWindow
+_CAPTURED_WORKS = []   # Work objects of collectives issued inside a HIP-graph capture (all_reduce_captured)
+
+
+def quiesce_collectives(device=None, seconds: float = 0.3) -> None:
+    """Call before capturing a HIP graph that contains a collective, in a process whose group runs on RCCL: drain the
+    device, then give ProcessGroupNCCL's watchdog thread (poll period 100 ms) the time to retire the Work objects of the
+    EAGER collectives issued so far.  A Work still on the watchdog's list is polled with hipEventQuery while the capture
+    (which pulls the communicator's stream into the graph) is open; HIP answers that poll with "operation not permitted on an
+    event last recorded in a capturing stream", invalidates the capture, and the watchdog aborts the process -- the rest of the
+    2-4 % after all_reduce_captured's part of the fix.  No-op without a process group or on other backends."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    try:
+        if 'nccl' not in str(dist.get_backend()).lower():
+            return
+    except Exception:
+        return
+    import time
+    torch.cuda.synchronize(device)
+    time.sleep(seconds)
+
+
+def all_reduce_captured(t: torch.Tensor, group=None, keep: Optional[list] = None) -> None:
+    """``dist.all_reduce(t, SUM)`` that is safe to issue while the current stream is being captured into a HIP graph: the
+    collective's Work object -- and with it the HIP events ProcessGroupNCCL recorded inside the capture -- is kept alive
+    (in ``keep``, by default for the life of the process) instead of being destroyed on return.  With the synchronous
+    form the events are released while the capture is still open; the event cache (or, with the cache off, the HIP
+    runtime's allocator) hands them to the next eager collective's Work, the NCCL watchdog thread polls that Work, HIP
+    answers "operation not permitted on an event last recorded in a capturing stream", invalidates the capture in progress
+    and the watchdog aborts the process (seen in 2-4 % of the constructions of a SECOND window in one process, ROCm 7.0 /
+    RCCL 2.26 / PyTorch 2.10).  Outside a capture this is the plain synchronous call."""
+    if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return
+    work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    work.wait()
+    (_CAPTURED_WORKS if keep is None else keep).append(work)
 
 
 def slot_mean(slots: torch.Tensor) -> torch.Tensor:
@@ -248,6 +286,7 @@ class GraphedEvaluationWindow:
         # the tables it builds and the verdicts it caches would otherwise come from incomplete data)
         side.wait_stream(torch.cuda.current_stream(dev))
         self.graph = torch.cuda.CUDAGraph()
+        self._works = []     # the captured collective's Work: alive as long as the graph (all_reduce_captured)
         with torch.no_grad(), torch.cuda.stream(side):
             warm = torch.zeros(len(self.xs), SLOT, dtype=torch.float64, device=dev)
             probe = self.xs[0][:1]
@@ -259,7 +298,13 @@ class GraphedEvaluationWindow:
             if reduce:
                 dist.all_reduce(warm, op=dist.ReduceOp.SUM, group=evaluator.group)
             torch.cuda.synchronize(dev)
-            with torch.cuda.graph(self.graph, stream=side):
+            if reduce:
+                quiesce_collectives(dev)
+            # (thread-local capture mode: ProcessGroupNCCL's watchdog thread polls the events of earlier collectives with
+            # hipEventQuery; under the default 'global' mode such a call from ANOTHER thread while this one captures is an
+            # error that the watchdog turns into abort() -- seen as a crash of this constructor in one full test run of
+            # four.  Collectives issued inside the capture are not handed to the watchdog.)
+            with torch.cuda.graph(self.graph, stream=side, capture_error_mode=CAPTURE_ERROR_MODE):
                 self.pool = torch.zeros(len(self.xs), SLOT, dtype=torch.float64, device=dev)
                 for b in branches[1:]:
                     b.wait_stream(side)              # fork (the zeroed slots are complete on every chain)
@@ -273,13 +318,21 @@ class GraphedEvaluationWindow:
                 for b in branches[1:]:
                     side.wait_stream(b)              # join: the collective sees every chain's sums
                 if reduce:
-                    dist.all_reduce(self.pool, op=dist.ReduceOp.SUM, group=evaluator.group)
+                    all_reduce_captured(self.pool, group=evaluator.group, keep=self._works)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
 
     def replay(self) -> List[float]:
         self.graph.replay()
         return slot_mean(self.pool).cpu().tolist()
+
+    def close(self) -> None:
+        """Release the HIP graph.  A graph that captured a collective keeps references into its communicator: release every
+        such window BEFORE ``dist.destroy_process_group()`` (with live graphs the communicator's teardown aborted the
+        process about once in fifty runs on ROCm 7.0 / RCCL 2.x -- no message, inside ``destroy_process_group``)."""
+        torch.cuda.synchronize(self.pool.device)
+        self.graph = None
+        self._works = []
 
 
 def bn_gather_moments(moments: torch.Tensor, group=None) -> torch.Tensor:
@@ -289,7 +342,7 @@ def bn_gather_moments(moments: torch.Tensor, group=None) -> torch.Tensor:
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     table = torch.zeros((world, moments.numel()), dtype=moments.dtype, device=moments.device)
     table[rank].copy_(moments)
-    dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+    all_reduce_captured(table, group=group)
     return table
 
 
@@ -300,7 +353,7 @@ def bn_reduce_sums(sums: torch.Tensor, n_local: int, n_total: int, group=None) -
     rank's loss again, so that the later sample-weighted gradient average (``allreduce_gradients``) is the
     single-process gradient.  One all-reduce of 2D+1 floats."""
     t = sums * (float(n_local) / float(n_total))
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    all_reduce_captured(t, group=group)
     if n_local > 0:
         t *= float(n_total) / float(n_local)
     return t
@@ -400,7 +453,7 @@ def allreduce_gradients(model: torch.nn.Module, group=None, weight: Optional[flo
     parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in params]
     flat = torch.cat(parts + [torch.ones(1, dtype=torch.float32, device=parts[0].device)])
     flat *= w
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    all_reduce_captured(flat, group=group)      # (inside GraphedTrainStep's capture the Work must outlive the capture)
     flat /= flat[-1].clamp_min(1e-30)          # total weight (the world size when unweighted)
     off = 0
     for p in params:
