@@ -899,7 +899,20 @@ def main():
         xs_g = [torch.randn(Bg, D, device=dev, generator=gen_g) for _ in range(min(ring_g, max(L, 4)))]
         ev = ShardedLogLikelihood(model, group=dist.group.WORLD if world > 1 else None, static_inputs=True,
                                   static_params=False)
-        win = GraphedEvaluationWindow(ev, [xs_g[i % len(xs_g)] for i in range(L)], chains=args.chains)
+        win, err = None, None
+        try:
+            win = GraphedEvaluationWindow(ev, [xs_g[i % len(xs_g)] for i in range(L)], chains=args.chains)
+        except Exception as ex:   # (a capture that fails on ONE rank must not leave the others waiting in the barrier below)
+            err = ex
+        if world > 1:
+            flag = torch.tensor([0.0 if win is None else 1.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag.item()) < 1.0 and err is None:
+                err = RuntimeError('the window could not be captured on another rank')
+        if err is not None:
+            if win is not None:
+                _KEEP_ALIVE.append(win)
+            raise err
         for _ in range(max(1, -(-warmup // L))):
             win.replay()
         if world > 1:
