@@ -327,9 +327,8 @@ class GraphedEvaluationWindow:
         return slot_mean(self.pool).cpu().tolist()
 
     def close(self) -> None:
-        """Release the HIP graph.  A graph that captured a collective keeps references into its communicator: release every
-        such window BEFORE ``dist.destroy_process_group()`` (with live graphs the communicator's teardown aborted the
-        process about once in fifty runs on ROCm 7.0 / RCCL 2.x -- no message, inside ``destroy_process_group``)."""
+        """Release the HIP graph and the captured collective's Work.  A graph that captured a collective refers to its
+        communicator: release such windows before ``dist.destroy_process_group()``."""
         torch.cuda.synchronize(self.pool.device)
         self.graph = None
         self._works = []
